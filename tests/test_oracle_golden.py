@@ -1,0 +1,125 @@
+"""Pin the CPU oracle to the golden vectors generated from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mpi_oracle as MO
+from oracle import vid_oracle as VO
+from videoloop3d_amd import synth
+
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+def maxabs(a, b):
+    return float((torch.as_tensor(a).double() - torch.as_tensor(b).double()).abs().max())
+
+
+def test_g1_homography(golden):
+    g = golden("g1_homography.npz")
+    assert maxabs(MO.make_depths(8, 1.0, 100.0), g["depths"]) == 0
+    for ci in range(2):
+        h = MO.compute_homography(T(g[f"c{ci}_src_ext"]), T(g[f"c{ci}_src_K"]), T(g[f"c{ci}_tar_ext"]),
+                                  T(g[f"c{ci}_tar_K"]), T(g[f"c{ci}_normal"]), T(g[f"c{ci}_dist"]))
+        assert maxabs(h, g[f"c{ci}_homo"]) <= 1e-6
+
+
+def test_g2_warp(golden):
+    g = golden("g2_warp.npz")
+    img = T(g["images"]).requires_grad_(True)
+    out = MO.warp_homography(int(g["h"]), int(g["w"]), T(g["homos"]), img)
+    assert maxabs(out, g["out"]) <= 1e-6
+    (gi,) = torch.autograd.grad(out, img, T(g["grad_out"]))
+    assert maxabs(gi, g["grad_images"]) <= 1e-5
+
+
+def test_g3_overcompose(golden):
+    g = golden("g3_overcompose.npz")
+    a = T(g["alpha"]).requires_grad_(True)
+    c = T(g["content"]).requires_grad_(True)
+    rgb, bw = MO.overcompose(a, c)
+    assert maxabs(rgb, g["rgb"]) <= 1e-6 and maxabs(bw, g["blendweight"]) <= 1e-6
+    ga, gc = torch.autograd.grad([rgb, bw], [a, c], [T(g["g_rgb"]), T(g["g_bw"])])
+    assert maxabs(ga, g["grad_alpha"]) <= 1e-5 and maxabs(gc, g["grad_content"]) <= 1e-6
+    m = T(g["mpi"]).requires_grad_(True)
+    rgbN, bwN = MO.overcomposeNto0(m, ret_mask=True)
+    assert maxabs(rgbN, g["rgbN"]) <= 1e-6 and maxabs(bwN, g["bwN"]) <= 1e-6
+    (gm,) = torch.autograd.grad(rgbN, m, T(g["g_rgbN"]))
+    assert maxabs(gm, g["grad_mpi"]) <= 1e-5
+    # the two composites agree on the flipped stack
+    layers = m.detach().permute(0, 3, 4, 1, 2).flip(3)
+    rgbF, _ = MO.overcompose(layers[..., 3], layers[..., :3])
+    assert maxabs(rgbF.permute(0, 3, 1, 2), rgbN) <= 1e-6
+
+
+def test_g4_cfg1_fused_spec(golden):
+    """cfg1 (256x256, D=8): the fused spec render_planes == sigmoid -> warp_homography -> overcomposeNto0."""
+    g = golden("g4_cfg1_render.npz")
+    stack = synth.make_plane_stack(8, 1, 256, 256, seed=2).requires_grad_(True)
+    rgb, alpha, _ = MO.render_planes(stack, T(g["homos"]), 256, 256, MO.RenderSpec())
+    assert maxabs(rgb[0].permute(2, 0, 1), g["rgb"]) <= 1e-6
+    gout = synth.hash_uniform((1, 3, 256, 256), seed=7) - 0.5
+    (gs,) = torch.autograd.grad(rgb, stack, gout[0].permute(1, 2, 0)[None])
+    gs = gs[:, 0]
+    assert maxabs(gs[:, 96:160, 96:160], g["grad_stack_crop"]) <= 1e-6
+    s = g["grad_stack_sum"]
+    assert abs(float(gs.double().sum()) - s[0]) <= 1e-3 * max(1.0, abs(s[0]))
+    assert abs(float(gs.double().abs().sum()) - s[1]) <= 1e-5 * s[1]
+
+
+def test_g5_patches(golden):
+    g = golden("g5_patches.npz")
+    ramp = torch.arange(3 * 5 * 9 * 9, dtype=torch.float32).reshape(1, 3, 5, 9, 9)
+    assert maxabs(VO.extract_3Dpatches(ramp, 3, 3, 2, 1), g["p_3_3_2_1"]) == 0
+    assert maxabs(VO.extract_3Dpatches(ramp, 5, 2, 4, 2), g["p_5_2_4_2"]) == 0
+
+
+def test_g6_nn(golden):
+    g = golden("g6_nn.npz")
+    X, Y = T(g["X"]), T(g["Y"])
+    assert maxabs(VO.patch_distances(X, Y), g["dist"]) <= 1e-6
+    assert (VO.nn_indices(X, Y, None).numpy() == g["nn_none"]).all()
+    assert (VO.nn_indices(X, Y, 0.5).numpy() == g["nn_alpha05"]).all()
+    assert (VO.nn_indices(X, Y, 0.005).numpy() == g["nn_alpha0005"]).all()
+    # the fp64 cancellation-free distance agrees with the reference's Gram form
+    assert maxabs(VO.patch_distances_exact(X, Y), g["dist"]) <= 1e-5
+
+
+@pytest.mark.parametrize("ps,pt,s,st,al", [(5, 3, 2, 1, 1e10), (3, 3, 2, 1, 1e10), (5, 3, 2, 1, 0.5), (3, 2, 1, 2, 0.05)])
+def test_g7_merge(golden, ps, pt, s, st, al):
+    g = golden("g7_merge.npz")
+    key = f"ps{ps}_pt{pt}_s{s}_st{st}_a{al:g}"
+    sm, w = VO.find_nn_and_merge(T(g["x"]), T(g["y"]), patch_size=ps, patcht_size=pt, stride=s, stridet=st, alpha=al)
+    assert maxabs(w, g[key + "_weight"]) == 0
+    assert maxabs(sm, g[key + "_sum"]) <= 1e-5
+
+
+@pytest.mark.parametrize("name,cfg", [
+    ("ref", dict(macro_block=19, patch_size=11, stride=4, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=0.5)),
+    ("other", dict(macro_block=17, patch_size=3, stride=2, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=10000)),
+    ("trim", dict(macro_block=16, patch_size=5, stride=3, patcht_size=3, stridet=2, rou=0, scaling=0.2, alpha=10000)),
+])
+def test_g8_loss(golden, name, cfg):
+    g = golden("g8_loss.npz")
+    x = T(g["x"]).requires_grad_(True)
+    loss, y2x, w = VO.gpnn_loss(x, T(g["y"]), **cfg)
+    assert maxabs(w, g[name + "_weight"]) == 0
+    assert maxabs(y2x, g[name + "_y2x"]) <= 1e-6
+    assert abs(loss.item() - float(g[name + "_loss"])) <= 1e-6 * max(1.0, abs(float(g[name + "_loss"])))
+    (gx,) = torch.autograd.grad(loss, x)
+    assert gx.shape == tuple(g[name + "_grad"].shape)
+    assert maxabs(gx, g[name + "_grad"]) <= 1e-8 + 1e-5 * float(np.abs(g[name + "_grad"]).max())
+    if name != "trim":  # LowMem == Direct
+        assert abs(float(g[name + "_direct_loss"]) - float(g[name + "_loss"])) <= 1e-6
+
+
+def test_g9_robust(golden):
+    g = golden("g9_robust.npz")
+    for rou in ['mse', 'abs', '0', '2', '-2', '1']:
+        for sc in [0.1, 0.2]:
+            x = T(g["x"]).requires_grad_(True)
+            v = VO.robust_lossfun(x, rou, sc)
+            ref = g[f"rou{rou}_s{sc}"]
+            assert maxabs(v, ref) <= 1e-6 * max(1.0, float(np.abs(ref).max()))
+            (gr,) = torch.autograd.grad(v.sum(), x)
+            refg = g[f"rou{rou}_s{sc}_grad"]
+            assert maxabs(gr, refg) <= 1e-5 * max(1.0, float(np.abs(refg).max()))
