@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X (contract: see the task prompt / DESIGN.md §Measurement).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+step       = fused render forward + backward of the cfg3 workload (D=32 planes, T=50 frames, 720p; BASELINE.json
+             configs[2], the configuration the metric is quoted on; 47 GB of stack+grad, fits one GPU).
+metric     = rendered Mpix/s (fwd+bwd): T*H*W output pixels per step / step time, whole job over all N GPUs.
+N > 1      = the SAME frame is split into N row bands (strong scaling, north star "tiles shard across the 8 GPUs");
+             each rank owns the stack rows its band touches, ONE RCCL all-gather of the composited band per step
+             (overlapped with the backward on a side stream), no collective on the gradient path.
+Also reported on the same JSON line: roofline (HIP-event kernel times vs algorithmic bytes), cpu_baseline (the CPU oracle
+timed on this box's host cores on a bounded sample), and the stage-2 looping-loss iters/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--D", type=int, default=32)
+    ap.add_argument("--T", type=int, default=50)
+    ap.add_argument("--H", type=int, default=720)
+    ap.add_argument("--W", type=int, default=1280)
+    ap.add_argument("--spec", default="mpv", choices=["mpv", "utils_mpi"])
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-loss", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=1)
+    ap.add_argument("--loss-steps", type=int, default=5)
+    return ap.parse_args()
+
+
+def cpu_baseline(D, H, W, frames, spec_name):
+    """The CPU oracle (port of the reference's PyTorch CPU path, pinned to the reference goldens) on a bounded sample:
+    `frames` frames of the same D/720p workload, fwd+bwd, all host cores."""
+    from oracle import mpi_oracle as MO
+    from videoloop3d_amd import synth
+    from videoloop3d_amd.utils_mpi import compute_homography, make_depths
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    stack = synth.make_plane_stack(D, frames, H, W, seed=2).requires_grad_(True)
+    ref_e, Kr, tar_e, Kt = synth.make_cameras(H, W)
+    homos = compute_homography(ref_e[None], Kr[None], tar_e[None], Kt[None],
+                               torch.tensor([0., 0., 1.]).expand(1, D, 3), make_depths(D, 1.0, 100.0).flip(0)[None])[0]
+    ospec = MO.RenderSpec() if spec_name == "utils_mpi" else MO.RenderSpec(pixel_center=0.5, coord_mode="affine",
+                                                                            border="hardcut", act_order="post")
+    g = synth.hash_uniform((frames, H, W, 3), seed=5) - 0.5
+    t0 = time.perf_counter()
+    rgb, _, _ = MO.render_planes(stack, homos, H, W, ospec)
+    (gs,) = torch.autograd.grad(rgb, stack, g)
+    dt = time.perf_counter() - t0
+    return {"value": frames * H * W / dt / 1e6, "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "sample": f"{frames} frame(s) of the D={D} {H}x{W} workload, fwd+bwd, torch CPU fp32 oracle ({dt:.1f} s)"}
+
+
+def loss_bench(dev, H, W, T, Ty, steps):
+    """stage-2 looping-loss iters/s: one iter = NN search + vote-fold + robust mean + backward to x, both shipped cfgs."""
+    from videoloop3d_amd import synth
+    from videoloop3d_amd.utils_vid import Patch3DGPNNLowMemLoss
+    import warnings
+    x = synth.make_video(T + 2, H, W, seed=3, device=dev).requires_grad_(True)
+    y = synth.make_video(Ty, H, W, seed=4, device=dev)
+    cfgs = {"ref": dict(macro_block=65, patch_size=11, stride=4, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=0.5),
+            "other": dict(macro_block=65, patch_size=3, stride=2, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=10000)}
+    out = {}
+    for name, cfg in cfgs.items():
+        lm = Patch3DGPNNLowMemLoss()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for it in range(steps + 1):
+                if it == 1:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                loss = lm(x, y, **cfg)
+                (gx,) = torch.autograd.grad(loss, x)
+            torch.cuda.synchronize()
+        out[name] = {"iters_per_s": steps / (time.perf_counter() - t0), "loss": float(loss)}
+    out["shape"] = f"x[1,3,{T + 2},{H},{W}] y[1,3,{Ty},{H},{W}]"
+    return out
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from videoloop3d_amd import synth
+    from videoloop3d_amd.dist import all_gather_frame, plan_bands, render_band
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    from videoloop3d_amd.utils_mpi import compute_homography, make_depths
+
+    D, T, H, W = a.D, a.T, a.H, a.W
+    Hs, Ws = H, W
+    spec = RenderSpec.mpv(variant=a.variant) if a.spec == "mpv" else RenderSpec(variant=a.variant)
+    ref_e, Kr, tar_e, Kt = synth.make_cameras(H, W)
+    homos = compute_homography(ref_e[None], Kr[None], tar_e[None], Kt[None],
+                               torch.tensor([0., 0., 1.]).expand(1, D, 3), make_depths(D, 1.0, 100.0).flip(0)[None])[0]
+    homos_d = homos.to(dev)
+
+    # ---- inputs resident in HBM before the timed region ------------------------------------------------------------------
+    if world == 1:
+        stack = synth.make_plane_stack(D, T, Hs, Ws, seed=2, device=dev).requires_grad_(True)
+        g_rgb = (synth.hash_uniform((T, H, W, 3), seed=5, device=dev) - 0.5)
+        band = None
+    else:
+        bands = plan_bands(homos, H, W, Hs, world, spec)
+        band = bands[rank]
+        full_rows = band.src1 - band.src0
+        stack = torch.empty((D, T, full_rows, Ws, 4), dtype=torch.float32, device=dev)
+        per_plane = T * Hs * Ws * 4
+        for d in range(D):      # same bytes as the single-GPU stack, rows [src0,src1) only
+            for t in range(T):
+                off = d * per_plane + (t * Hs + band.src0) * Ws * 4
+                stack[d, t] = (synth.hash_uniform((full_rows, Ws, 4), 2, device=dev, offset=off) * 4.0 - 2.0)
+        stack[..., 3] -= 2.0
+        stack.requires_grad_(True)
+        g_full_off = lambda t: (t * H + band.row0) * W * 3
+        g_rgb = torch.stack([synth.hash_uniform((band.rows, W, 3), 5, device=dev, offset=g_full_off(t)) for t in range(T)]) - 0.5
+        comm_stream = torch.cuda.Stream(device=dev)
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    fwd_ms, bwd_ms = [], []
+
+    def step(timed):
+        e0, e1, e2 = ev(), ev(), ev()
+        e0.record()
+        if band is None:
+            rgb, alpha = render_planes(stack, homos_d, H, W, spec)
+        else:
+            rgb, alpha = render_band(stack, homos_d, band, W, Hs, spec)
+        e1.record()
+        if band is not None:
+            comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(comm_stream):
+                frame = all_gather_frame(rgb.detach(), bands)
+        (gs,) = torch.autograd.grad(rgb, stack, g_rgb)
+        e2.record()
+        if band is not None:
+            torch.cuda.current_stream().wait_stream(comm_stream)
+        if timed:
+            fwd_ms.append((e0, e1))
+            bwd_ms.append((e1, e2))
+        return gs
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    ms_per_step = dt / a.steps * 1e3
+    pix_per_step = T * H * W
+    value = pix_per_step / (dt / a.steps) / 1e6
+
+    f_ms = sum(s.elapsed_time(e) for s, e in fwd_ms) / len(fwd_ms)
+    b_ms = sum(s.elapsed_time(e) for s, e in bwd_ms) / len(bwd_ms)
+    my_pix = T * (H if band is None else band.rows) * W
+    # ALGORITHMIC bytes: fwd 16*D+12 B/pixel-frame, bwd 12 + 16*D (re-read) + 16*D (grad write) B/pixel-frame
+    fwd_bytes = my_pix * (16 * D + 12)
+    bwd_bytes = my_pix * (32 * D + 12)
+
+    def roof(name, nbytes, ms):
+        ach = nbytes / (ms * 1e-3) / 1e9
+        return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "avg_ms": ms, "algorithmic_bytes": nbytes}
+    r_f = roof("render_fwd_k", fwd_bytes, f_ms)
+    r_b = roof("render_bwd_k(+grad memset)", bwd_bytes, b_ms)
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            tr = json.load(open(pmc))
+            key = f"D{D}_T{T}_{H}x{W}_{a.spec}_v{a.variant}"
+            if key in tr and world == 1:
+                r_f["traffic"], r_b["traffic"] = tr[key].get("fwd"), tr[key].get("bwd")
+        except Exception:
+            pass
+    dominant = r_b if b_ms >= f_ms else r_f
+
+    res = {
+        "metric": "rendered Mpix/s (fwd+bwd) D=32 planes 720p", "value": value, "unit": "Mpix/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"cfg3 stage-2 MPV render fwd+bwd: D={D} planes, T={T} frames, {H}x{W} (720p), "
+                               f"{a.spec} convention, plane stack (D,T,H,W,4) fp32 resident in HBM",
+                   "parallelism": "single GPU" if world == 1 else f"{world} row bands + 1 all-gather of the composited frame",
+                   "variant": a.variant},
+        "roofline": dominant, "roofline_fwd": r_f, "roofline_bwd": r_b,
+        "fwd_bwd_algorithmic_frac": (fwd_bytes + bwd_bytes) / ((f_ms + b_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+    }
+    if rank == 0:
+        if not a.no_loss:
+            try:
+                res["loss"] = loss_bench(dev, H, W, T, 75, a.loss_steps)
+                res["loss_native_crop"] = loss_bench(dev, 180, 320, T, 75, a.loss_steps)
+            except Exception as e:   # the headline render number must still be reported
+                res["loss"] = {"error": repr(e)}
+        if not a.no_cpu_baseline:
+            del stack
+            torch.cuda.empty_cache()
+            res["cpu_baseline"] = cpu_baseline(D, H, W, a.cpu_frames, a.spec)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,155 @@
+/* vl3d.h -- C ABI of the MI355X-native MPI/MPV render-and-composite + looping-loss hot path.
+ *
+ * One shared library (videoloop3d_amd/lib/libvl3d_hip.so, built by hipcc for gfx950) exports
+ * exactly these symbols.  Plain pointers and sizes only: no torch types.  The reference
+ * (limacv/VideoLoop3D) is pure Python and has no FFI; each entry point cites the reference
+ * operator (file:line in /root/reference) it replaces, and INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Contract:
+ *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates or frees
+ *     and never synchronises; all work is enqueued on `stream` (a hipStream_t passed as void*).
+ *   - all tensors are dense row-major fp32 unless stated; outputs are overwritten (the library
+ *     zero-fills accumulation targets itself on the same stream).
+ *   - return value: VL3D_OK or an error code; never aborts.  vl3d_last_error() gives a message.
+ */
+#ifndef VL3D_H
+#define VL3D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *vl3d_stream_t; /* hipStream_t */
+
+enum { VL3D_OK = 0, VL3D_EINVAL = 1, VL3D_ELAUNCH = 2, VL3D_EUNSUPPORTED = 3 };
+
+/* activation table: MPI.py:21-31 (ACTIVATES); shipped configs use sigmoid for rgb and alpha
+ * (configs/mpv_base.txt:29-30). */
+enum { VL3D_ACT_NONE = 0, VL3D_ACT_SIGMOID = 1, VL3D_ACT_RELU = 2, VL3D_ACT_CLAMP = 3, VL3D_ACT_ABS = 4 };
+/* texel-coordinate convention.  UTILS_MPI: g = p/[Ws/2,Hs/2]-1 then grid_sample(align_corners=True),
+ * i.e. texel = p*(size-1)/size (utils_mpi.py:173-175).  AFFINE: texel = p*s + o (MPV.py atlas-cell UV). */
+enum { VL3D_COORD_UTILS_MPI = 0, VL3D_COORD_AFFINE = 1 };
+/* ZEROS: grid_sample padding_mode='zeros' (utils_mpi.py:174).  HARDCUT: quad extent, uncovered -> 0 after
+ * activation (MPV.py:389,441-447). */
+enum { VL3D_BORDER_ZEROS = 0, VL3D_BORDER_HARDCUT = 1 };
+/* PRE: activate texels, then sample (sigmoid -> warp_homography chain).  POST: sample, then activate (MPV.py:425-435). */
+enum { VL3D_ACT_PRE = 0, VL3D_ACT_POST = 1 };
+enum { VL3D_F32 = 0, VL3D_F16 = 1 };
+
+const char *vl3d_last_error(void);
+int vl3d_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused render: per-plane homography warp + bilinear sample + activation + front-to-back over
+ * composite across D planes.  Replaces the chain MPV.py:351-454 (planar geometry) ==
+ * utils_mpi.py:159-176 (warp_homography) + utils_mpi.py:92-107 (overcompose).
+ *
+ *   stack  : (D, T, Hs, Ws, 4) pre-activation rgba, plane 0 = nearest (MPV.py:51)
+ *   homos  : (D, 3, 3) fp32, target pixel -> plane pixel (utils_mpi.py:240-273), shared by all T frames
+ *   rgb    : (T, H, W, 3)        alpha : (T, H, W)  = sum of blend weights (MPV.py:454)
+ *   row0/col0 : offset of this output window inside the full frame (row-band sharding);
+ *               pixel (y,x) of the window is frame pixel (row0+y, col0+x).
+ */
+typedef struct vl3d_render_desc {
+    int32_t D, T, Hs, Ws;
+    int32_t H, W;
+    int32_t row0, col0;
+    int32_t coord_mode, border_mode, act_order, rgb_act, alpha_act;
+    int32_t stack_dtype;   /* VL3D_F32 | VL3D_F16 (grad_stack is always fp32) */
+    float pixel_center;    /* 0 (utils_mpi) or 0.5 (pytorch3d pixel centres) */
+    float sx, sy, ox, oy;  /* VL3D_COORD_AFFINE only */
+    int32_t variant;       /* kernel variant selector for A/B measurements; 0 = default */
+} vl3d_render_desc;
+
+int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos,
+                    float *rgb, float *alpha, vl3d_stream_t stream);
+
+/* Backward of the above w.r.t. the stack (geometry is not differentiated: MPV.py:354).
+ * rgb/alpha are the saved forward outputs; grad_alpha may be NULL (treated as 0).
+ * grad_stack (D,T,Hs,Ws,4) fp32 is overwritten. */
+int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, const float *homos,
+                    const float *rgb, const float *alpha, const float *grad_rgb, const float *grad_alpha,
+                    float *grad_stack, vl3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Unfused operators (drop-ins for the reference's L3 functions).
+ *
+ * vl3d_warp_*: utils_mpi.py:159-176 warp_homography(h, w, homos[N,3,3], images[N,C,Hs,Ws]) -> [N,C,h,w]
+ * with N = B*D (bilinear, zeros padding, align_corners=True under the utils_mpi normalisation). */
+int vl3d_warp_fwd(int32_t N, int32_t C, int32_t Hs, int32_t Ws, int32_t h, int32_t w,
+                  const float *homos, const float *images, float *out, vl3d_stream_t stream);
+int vl3d_warp_bwd(int32_t N, int32_t C, int32_t Hs, int32_t Ws, int32_t h, int32_t w,
+                  const float *homos, const float *grad_out, float *grad_images, vl3d_stream_t stream);
+
+/* vl3d_overcompose_*: utils_mpi.py:92-107 overcompose(alpha[P,D], content[P,D,C]) -> rgb[P,C], blendweight[P,D];
+ * front = index 0; P = B*H*W pixels. */
+int vl3d_overcompose_fwd(int64_t P, int32_t D, int32_t C, const float *alpha, const float *content,
+                         float *rgb, float *blendweight, vl3d_stream_t stream);
+/* grad_bw may be NULL. */
+int vl3d_overcompose_bwd(int64_t P, int32_t D, int32_t C, const float *alpha, const float *content,
+                         const float *grad_rgb, const float *grad_bw,
+                         float *grad_alpha, float *grad_content, vl3d_stream_t stream);
+
+/* vl3d_overcompose_nto0_*: utils_mpi.py:110-132 overcomposeNto0; front = LAST plane index.
+ * alpha[b,d,hw] at alpha + b*a_sb + d*a_sd + hw ; content[b,d,c,hw] at content + b*c_sb + d*c_sd + c*c_sc + hw
+ * (element strides, so slices of mpi[B,D,4,H,W] need no copy).  rgb [B,C,HW]; trans [B,D,HW] (the
+ * transmittance the reference returns as `blendweight` when ret_mask=True; may be NULL). */
+int vl3d_overcompose_nto0_fwd(int32_t B, int32_t D, int32_t C, int64_t HW,
+                              const float *alpha, int64_t a_sb, int64_t a_sd,
+                              const float *content, int64_t c_sb, int64_t c_sd, int64_t c_sc,
+                              float *rgb, float *trans, vl3d_stream_t stream);
+/* grad_alpha [B,D,HW], grad_content [B,D,C,HW] dense. */
+int vl3d_overcompose_nto0_bwd(int32_t B, int32_t D, int32_t C, int64_t HW,
+                              const float *alpha, int64_t a_sb, int64_t a_sd,
+                              const float *content, int64_t c_sb, int64_t c_sd, int64_t c_sc,
+                              const float *grad_rgb, float *grad_alpha, float *grad_content,
+                              vl3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Looping loss (utils_vid.py).  x is [3,Tx,H,W], y is [3,Ty,H,W] (batch 1, already trimmed to the
+ * patch grid: utils_vid.py:307-320); element strides are given per (channel, frame, row), columns
+ * are unit-stride.  Patch grid: h_o=(H-ps)/stride+1, w_o=(W-ps)/stride+1, n1=(Tx-pt)/stridet+1,
+ * n2=(Ty-pt)/stridet+1. */
+typedef struct vl3d_loss_desc {
+    int32_t Tx, Ty, H, W;
+    int32_t ps, pt, stride, stridet;
+    int32_t use_alpha;     /* 0: plain NN (alpha > 100 in the reference, utils_vid.py:208) */
+    float alpha;           /* utils_vid.py:133-134 normaliser offset */
+    int64_t x_sc, x_st, x_sr;
+    int64_t y_sc, y_st, y_sr;
+    int32_t variant;       /* kernel variant selector; 0 = default */
+} vl3d_loss_desc;
+
+/* bytes of device scratch vl3d_patchnn needs for this problem (0 if none). */
+int64_t vl3d_patchnn_scratch_bytes(const vl3d_loss_desc *desc);
+
+/* Per spatial location b=(by,bx): dist[i,j] = |Px_i - Py_j|^2 / (3*pt*ps*ps) (utils_vid.py:72-86),
+ * optional column-min normalisation (utils_vid.py:109-119,133-134), row argmin, first minimum wins
+ * (utils_vid.py:139-141).  nn is int32 [h_o, w_o, n1].  Replaces extract_3Dpatches x2 +
+ * get_NN_indices_low_memory (utils_vid.py:209-216). */
+int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const float *y, int32_t *nn,
+                 void *scratch, vl3d_stream_t stream);
+
+/* Gather the NN patches of y and vote-fold them onto x's grid (utils_vid.py:217-229):
+ * sum [3,Tx,H,W] dense, weight [Tx,H,W] dense = vote count clamped at 1e-10.
+ * normalize != 0 writes sum/weight (utils_vid.py:344) instead of the raw sum. */
+int vl3d_vote_fold(const vl3d_loss_desc *desc, const float *y, const int32_t *nn,
+                   float *sum, float *weight, int32_t normalize, vl3d_stream_t stream);
+
+/* robust_lossfun (utils_vid.py:10-26) fused with the mean (utils_vid.py:348).
+ * kind: 0 'mse', 1 'abs', 2 general Barron with float rou (rou==0 and rou==2 special-cased as the reference).
+ * loss_sum: device double, overwritten with sum over n elements of rho(x - y2x). */
+enum { VL3D_RHO_MSE = 0, VL3D_RHO_ABS = 1, VL3D_RHO_BARRON = 2 };
+int vl3d_robust_fwd(int64_t n, const float *x, const float *y2x, int32_t kind, float rou, float scale,
+                    double *loss_sum, vl3d_stream_t stream);
+/* grad_x[i] = rho'(x[i]-y2x[i]) * (*grad_out) * inv_n ; grad_out is a DEVICE scalar (no host sync). */
+int vl3d_robust_bwd(int64_t n, const float *x, const float *y2x, int32_t kind, float rou, float scale,
+                    const float *grad_out, float inv_n, float *grad_x, vl3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VL3D_H */

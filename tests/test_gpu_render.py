@@ -1,0 +1,237 @@
+"""Parity of the HIP render path (through the C ABI) against the golden vectors and the CPU oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mpi_oracle as MO
+from videoloop3d_amd import synth
+
+pytestmark = pytest.mark.gpu
+T_ = lambda a: torch.from_numpy(np.asarray(a))
+TOL = 1e-4   # north star: <= 1e-4 max-abs in fp32
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    import __graft_entry__ as g
+    g.build()
+    return torch.device("cuda:0")
+
+
+def maxabs(a, b):
+    return float((a.detach().double().cpu() - torch.as_tensor(b).double().cpu()).abs().max())
+
+
+def bench_homos(D, H, W, near=1.0, far=100.0, scale=1.0):
+    from videoloop3d_amd.utils_mpi import compute_homography, make_depths
+    ref_e, Kr, tar_e, Kt = synth.make_cameras(H, W)
+    tar_e = tar_e.clone()
+    tar_e[:3, 3] *= scale
+    depths = make_depths(D, near, far).flip(0)
+    return compute_homography(ref_e[None], Kr[None], tar_e[None], Kt[None],
+                              torch.tensor([0., 0., 1.]).expand(1, D, 3), depths[None])[0]
+
+
+# ---- unfused drop-ins vs the reference goldens ---------------------------------------------------------
+def test_g2_warp_homography(dev, golden):
+    from videoloop3d_amd.utils_mpi import warp_homography
+    g = golden("g2_warp.npz")
+    img = T_(g["images"]).to(dev).requires_grad_(True)
+    out = warp_homography(int(g["h"]), int(g["w"]), T_(g["homos"]).to(dev), img)
+    assert out.shape == tuple(g["out"].shape)
+    assert maxabs(out, g["out"]) <= 1e-5
+    (gi,) = torch.autograd.grad(out, img, T_(g["grad_out"]).to(dev))
+    assert maxabs(gi, g["grad_images"]) <= 1e-4
+
+
+def test_g3_overcompose(dev, golden):
+    from videoloop3d_amd.utils_mpi import overcompose, overcomposeNto0
+    g = golden("g3_overcompose.npz")
+    a = T_(g["alpha"]).to(dev).requires_grad_(True)
+    c = T_(g["content"]).to(dev).requires_grad_(True)
+    rgb, bw = overcompose(a, c)
+    assert maxabs(rgb, g["rgb"]) <= 1e-5 and maxabs(bw, g["blendweight"]) <= 1e-6
+    ga, gc = torch.autograd.grad([rgb, bw], [a, c], [T_(g["g_rgb"]).to(dev), T_(g["g_bw"]).to(dev)])
+    assert maxabs(gc, g["grad_content"]) <= 1e-5
+    assert maxabs(ga, g["grad_alpha"]) <= 1e-4 * max(1.0, float(np.abs(g["grad_alpha"]).max()))
+    m = T_(g["mpi"]).to(dev).requires_grad_(True)
+    rgbN, bwN = overcomposeNto0(m, ret_mask=True)
+    assert maxabs(rgbN, g["rgbN"]) <= 1e-5 and maxabs(bwN, g["bwN"]) <= 1e-6
+    (gm,) = torch.autograd.grad(rgbN, m, T_(g["g_rgbN"]).to(dev))
+    assert maxabs(gm, g["grad_mpi"]) <= 1e-4 * max(1.0, float(np.abs(g["grad_mpi"]).max()))
+    # caller-supplied blendweight short-circuit (utils_mpi.py:121-125)
+    rgb2 = overcomposeNto0(m.detach(), blendweight=T_(g["bwN"]).to(dev))
+    assert maxabs(rgb2, g["rgbN"]) <= 1e-5
+
+
+def test_overcompose_opaque_plane_exact_gradient(dev):
+    """alpha == 1 somewhere: cumprod's backward in the reference is exact there; ours must be too."""
+    from videoloop3d_amd.utils_mpi import overcompose
+    torch.manual_seed(0)
+    a = torch.rand(1, 4, 5, 6) * 0.9
+    a[0, 1, 2, 3] = 1.0
+    a[0, 0, 0, 0] = 1.0
+    c = torch.randn(1, 4, 5, 6, 3)
+    ao, co = a.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    r, b = MO.overcompose(ao, co)
+    gr, gb = torch.randn_like(r), torch.randn_like(b)
+    gao, gco = torch.autograd.grad([r, b], [ao, co], [gr, gb])
+    ag, cg = a.to(dev).requires_grad_(True), c.to(dev).requires_grad_(True)
+    r2, b2 = overcompose(ag, cg)
+    ga, gc = torch.autograd.grad([r2, b2], [ag, cg], [gr.to(dev), gb.to(dev)])
+    assert maxabs(ga, gao) <= 1e-4 and maxabs(gc, gco) <= 1e-5
+
+
+# ---- fused render -----------------------------------------------------------------------------------
+def test_g4_cfg1_fused_vs_reference_golden(dev, golden):
+    """cfg1: 256x256, D=8, 1 view -- fused kernel vs sigmoid->warp_homography->overcomposeNto0 of the reference."""
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    g = golden("g4_cfg1_render.npz")
+    stack = synth.make_plane_stack(8, 1, 256, 256, seed=2, device=dev).requires_grad_(True)
+    rgb, alpha = render_planes(stack, T_(g["homos"]).to(dev), 256, 256, RenderSpec())
+    assert maxabs(rgb[0].permute(2, 0, 1), g["rgb"]) <= TOL
+    gout = (synth.hash_uniform((1, 3, 256, 256), seed=7) - 0.5)[0].permute(1, 2, 0)[None].to(dev)
+    (gs,) = torch.autograd.grad(rgb, stack, gout)
+    gs = gs[:, 0]
+    assert maxabs(gs[:, 96:160, 96:160], g["grad_stack_crop"]) <= TOL
+    s = g["grad_stack_sum"]
+    assert abs(float(gs.double().sum()) - s[0]) <= 1e-3 * max(1.0, abs(s[0]))
+    assert abs(float(gs.double().abs().sum()) - s[1]) <= 1e-4 * s[1]
+
+
+SPECS = {
+    "utils_mpi": (dict(), dict()),
+    "mpv": (dict(pixel_center=0.5, coord_mode="affine", border="hardcut", act_order="post"),) * 2,
+    "mpv_atlas_pitch": (dict(pixel_center=0.5, coord_mode="affine", scale=(1.00124, 0.998), offset=(0.3, -0.2),
+                             border="hardcut", act_order="post"),) * 2,
+    "zeros_post": (dict(border="zeros", act_order="post"),) * 2,
+    "hardcut_pre": (dict(border="hardcut", act_order="pre"),) * 2,
+    "none_act": (dict(rgb_act="none", alpha_act="sigmoid"),) * 2,
+    "clamp": (dict(rgb_act="clamp", alpha_act="clamp", act_order="post", border="hardcut"),) * 2,
+}
+
+
+@pytest.mark.parametrize("name", list(SPECS))
+@pytest.mark.parametrize("shape", [(8, 2, 48, 64, 40, 56), (5, 1, 33, 47, 61, 70), (3, 3, 20, 24, 9, 130)])
+def test_fused_vs_oracle(dev, name, shape):
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    D, T, Hs, Ws, H, W = shape
+    kw_p, kw_o = SPECS[name]
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=11)
+    if "clamp" in name:
+        stack = stack * 0.4 + 0.5
+    homos = bench_homos(D, H, W, scale=4.0)     # strong parallax: planes partly leave the frame
+    # add an in-plane rotation/zoom so taps are not axis aligned
+    th = math.radians(3.0)
+    Rz = torch.tensor([[math.cos(th) * 1.07, -math.sin(th), 2.0], [math.sin(th), math.cos(th) * 0.93, -1.5], [1e-4, -2e-4, 1.0]])
+    homos = homos @ Rz
+    # map the (H,W) frame onto the (Hs,Ws) plane extent
+    S = torch.tensor([[Ws / W, 0, 0], [0, Hs / H, 0], [0, 0, 1.0]])
+    homos = S @ homos
+    g_rgb = synth.hash_uniform((T, H, W, 3), seed=5) - 0.5
+    g_a = synth.hash_uniform((T, H, W), seed=6) - 0.5
+    s_cpu = stack.clone().requires_grad_(True)
+    rgb_o, alpha_o, _ = MO.render_planes(s_cpu, homos, H, W, MO.RenderSpec(**kw_o))
+    (gs_o,) = torch.autograd.grad([rgb_o, alpha_o], s_cpu, [g_rgb, g_a])
+    s_gpu = stack.to(dev).requires_grad_(True)
+    rgb, alpha = render_planes(s_gpu, homos.to(dev), H, W, RenderSpec(**kw_p))
+    (gs,) = torch.autograd.grad([rgb, alpha], s_gpu, [g_rgb.to(dev), g_a.to(dev)])
+    assert maxabs(rgb, rgb_o) <= TOL
+    assert maxabs(alpha, alpha_o) <= TOL
+    assert maxabs(gs, gs_o) <= TOL * max(1.0, float(gs_o.abs().max()))
+    assert float(gs_o.abs().sum()) > 0
+
+
+def test_uncovered_frame_and_degenerate_homography(dev):
+    """all planes outside the frame / Z<=0 -> rgb = alpha = 0 and zero gradient (no NaNs)."""
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    D, T, Hs, Ws, H, W = 3, 1, 16, 16, 8, 8
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=1, device=dev).requires_grad_(True)
+    far_away = torch.eye(3).repeat(D, 1, 1)
+    far_away[:, 0, 2] = 1e6
+    far_away[1, 2, 2] = -1.0      # behind the camera
+    far_away[2, 2, 2] = 0.0       # division by zero
+    far_away[2, 2, 0] = 0.0
+    for spec in (RenderSpec(), RenderSpec.mpv()):
+        rgb, alpha = render_planes(stack, far_away.to(dev), H, W, spec)
+        (gs,) = torch.autograd.grad(rgb.sum() + alpha.sum(), stack)
+        assert torch.isfinite(rgb).all() and torch.isfinite(gs).all()
+    # plane 0 only is far away: still finite
+    assert float(alpha.abs().max()) <= 1.0
+
+
+def test_row_band_windows_tile_the_frame_exactly(dev):
+    """rendering row bands with window offsets and concatenating == the full render, bit for bit;
+    band gradients sum to the full gradient."""
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    D, T, Hs, Ws, H, W = 6, 2, 70, 90, 64, 80
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=3, device=dev).requires_grad_(True)
+    homos = (torch.tensor([[Ws / W, 0, 0], [0, Hs / H, 0], [0, 0, 1.0]]) @ bench_homos(D, H, W, scale=2.0)).to(dev)
+    spec = RenderSpec.mpv()
+    g = (synth.hash_uniform((T, H, W, 3), seed=9) - 0.5).to(dev)
+    full, full_a = render_planes(stack, homos, H, W, spec)
+    (g_full,) = torch.autograd.grad(full, stack, g)
+    bands, g_sum = [], torch.zeros_like(g_full)
+    for r in range(4):
+        r0 = r * H // 4
+        b, _ = render_planes(stack, homos, H // 4, W, spec, window=(r0, 0))
+        bands.append(b)
+        (gb,) = torch.autograd.grad(b, stack, g[:, r0:r0 + H // 4])
+        g_sum += gb
+    assert torch.equal(torch.cat(bands, 1), full)
+    assert maxabs(g_sum, g_full) <= 1e-5
+
+
+def test_constant_stack_closed_form_720p(dev):
+    """size-independent property at cfg2 scale (720p, D=32): a constant stack under any in-range warp renders
+    c*(1-(1-a)^D); the gradient of sum(rgb) sums to the analytic value."""
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    D, T, Hs, Ws, H, W = 32, 1, 792, 1408, 720, 1280      # mpi_h/w_scale = 1.1 (configs/mpv_base.txt:10-11)
+    v = torch.tensor([0.3, -0.7, 1.1, -1.5])
+    stack = v.to(dev).expand(D, T, Hs, Ws, 4).contiguous().requires_grad_(True)
+    homos = bench_homos(D, H, W)
+    homos = (torch.tensor([[1.0, 0, 64.0], [0, 1.0, 36.0], [0, 0, 1.0]]) @ homos).to(dev)  # centre the frame in the plane
+    rgb, alpha = render_planes(stack, homos, H, W, RenderSpec.mpv())
+    c, a = torch.sigmoid(v[:3]), torch.sigmoid(v[3])
+    A = 1 - (1 - a) ** D
+    assert maxabs(alpha, A.expand_as(alpha)) <= 1e-5
+    assert maxabs(rgb, (c * A).expand_as(rgb)) <= 1e-5
+    (gs,) = torch.autograd.grad(rgb.sum(), stack)
+    # d(sum rgb)/d(v_rgb) summed over all texels & planes = Npix * A * c(1-c) per channel
+    npix = H * W
+    got = gs.double().sum(dim=(0, 1, 2, 3)).cpu()
+    want_rgb = npix * A.double() * (c * (1 - c)).double()
+    assert (got[:3] - want_rgb).abs().max() <= 1e-3 * want_rgb.abs().max()
+    # alpha channel: d/dv_a of sum_c c*(1-(1-a)^D) over planes = Npix * sum(c) * D (1-a)^(D-1) * a(1-a) / ... summed over k
+    want_a = npix * c.double().sum() * D * (1 - a.double()) ** (D - 1) * (a * (1 - a)).double()
+    assert abs(got[3] - want_a) <= 1e-3 * abs(want_a)
+
+
+def test_720p_window_vs_oracle(dev):
+    """cfg2-sized frame (720p, D=32): a 24x40 window of the full render and of its gradient vs the CPU oracle."""
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    D, T, Hs, Ws, H, W = 32, 1, 720, 1280, 720, 1280
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=2, device=dev).requires_grad_(True)
+    homos = bench_homos(D, H, W)
+    r0, c0, h, w = 333, 611, 24, 40
+    for spec, ospec in ((RenderSpec(), MO.RenderSpec()),
+                        (RenderSpec.mpv(), MO.RenderSpec(pixel_center=0.5, coord_mode="affine", border="hardcut", act_order="post"))):
+        rgb, alpha = render_planes(stack, homos.to(dev), H, W, spec)
+        gfull = torch.zeros_like(rgb)
+        gwin = (synth.hash_uniform((T, h, w, 3), seed=5) - 0.5)
+        gfull[:, r0:r0 + h, c0:c0 + w] = gwin.to(dev)
+        (gs,) = torch.autograd.grad(rgb, stack, gfull)
+        # oracle on the window: fold the integer window offset into the homography
+        shift = torch.tensor([[1.0, 0, c0], [0, 1.0, r0], [0, 0, 1.0]])
+        lo_r, hi_r, lo_c, hi_c = r0 - 40, r0 + h + 40, c0 - 60, c0 + w + 60
+        s_cpu = stack.detach().cpu().requires_grad_(True)
+        rgb_o, alpha_o, _ = MO.render_planes(s_cpu, homos @ shift, h, w, ospec)
+        (gs_o,) = torch.autograd.grad(rgb_o, s_cpu, gwin)
+        # (pixel_center is added after the shift in both, so the fold is exact for integer offsets)
+        assert maxabs(rgb[:, r0:r0 + h, c0:c0 + w], rgb_o) <= TOL
+        assert maxabs(alpha[:, r0:r0 + h, c0:c0 + w], alpha_o) <= TOL
+        assert maxabs(gs[:, :, lo_r:hi_r, lo_c:hi_c], gs_o[:, :, lo_r:hi_r, lo_c:hi_c]) <= TOL
+        assert float(gs_o[:, :, lo_r:hi_r, lo_c:hi_c].abs().sum()) == pytest.approx(float(gs_o.abs().sum()))

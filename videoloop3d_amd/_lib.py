@@ -1,0 +1,99 @@
+"""ctypes binding of the C-ABI library (include/vl3d.h).
+
+The HIP library is the product: there is NO CPU fallback.  Any call without the built library (or with
+non-GPU tensors) raises -- see `lib()` / `check_cuda()`.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvl3d_hip.so")
+
+ACT = {"none": 0, "sigmoid": 1, "relu": 2, "clamp": 3, "abs": 4}
+COORD = {"utils_mpi": 0, "affine": 1}
+BORDER = {"zeros": 0, "hardcut": 1}
+ACT_ORDER = {"pre": 0, "post": 1}
+RHO = {"mse": 0, "abs": 1, "barron": 2}
+
+
+class RenderDesc(C.Structure):
+    _fields_ = [("D", C.c_int32), ("T", C.c_int32), ("Hs", C.c_int32), ("Ws", C.c_int32),
+                ("H", C.c_int32), ("W", C.c_int32), ("row0", C.c_int32), ("col0", C.c_int32),
+                ("coord_mode", C.c_int32), ("border_mode", C.c_int32), ("act_order", C.c_int32),
+                ("rgb_act", C.c_int32), ("alpha_act", C.c_int32), ("stack_dtype", C.c_int32),
+                ("pixel_center", C.c_float), ("sx", C.c_float), ("sy", C.c_float), ("ox", C.c_float),
+                ("oy", C.c_float), ("variant", C.c_int32)]
+
+
+class LossDesc(C.Structure):
+    _fields_ = [("Tx", C.c_int32), ("Ty", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("ps", C.c_int32), ("pt", C.c_int32), ("stride", C.c_int32), ("stridet", C.c_int32),
+                ("use_alpha", C.c_int32), ("alpha", C.c_float),
+                ("x_sc", C.c_int64), ("x_st", C.c_int64), ("x_sr", C.c_int64),
+                ("y_sc", C.c_int64), ("y_st", C.c_int64), ("y_sr", C.c_int64),
+                ("variant", C.c_int32)]
+
+
+_P = C.c_void_p
+_I32, _I64, _F = C.c_int32, C.c_int64, C.c_float
+
+# symbol -> argtypes; every symbol include/vl3d.h declares must be listed here (tests/test_abi.py checks).
+SIGNATURES = {
+    "vl3d_last_error": ([], C.c_char_p),
+    "vl3d_version": ([], C.c_int),
+    "vl3d_render_fwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P], C.c_int),
+    "vl3d_render_bwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    "vl3d_warp_fwd": ([_I32] * 6 + [_P, _P, _P, _P], C.c_int),
+    "vl3d_warp_bwd": ([_I32] * 6 + [_P, _P, _P, _P], C.c_int),
+    "vl3d_overcompose_fwd": ([_I64, _I32, _I32, _P, _P, _P, _P, _P], C.c_int),
+    "vl3d_overcompose_bwd": ([_I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    "vl3d_overcompose_nto0_fwd": ([_I32, _I32, _I32, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _P], C.c_int),
+    "vl3d_overcompose_nto0_bwd": ([_I32, _I32, _I32, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _P, _P], C.c_int),
+    "vl3d_patchnn_scratch_bytes": ([C.POINTER(LossDesc)], C.c_int64),
+    "vl3d_patchnn": ([C.POINTER(LossDesc), _P, _P, _P, _P, _P], C.c_int),
+    "vl3d_vote_fold": ([C.POINTER(LossDesc), _P, _P, _P, _P, _I32, _P], C.c_int),
+    "vl3d_robust_fwd": ([_I64, _P, _P, _I32, _F, _F, _P, _P], C.c_int),
+    "vl3d_robust_bwd": ([_I64, _P, _P, _I32, _F, _F, _P, _F, _P, _P], C.c_int),
+}
+
+_lib = None
+
+
+def lib():
+    """Load videoloop3d_amd/lib/libvl3d_hip.so (built by __graft_entry__.build()); fail loudly if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"HIP library {LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
+                "videoloop3d_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().vl3d_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def check_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("videoloop3d_amd operators run on the MI355X only (got a CPU tensor); "
+                               "there is no CPU fallback -- the CPU oracle lives in oracle/ for tests")
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,71 @@
+// Shared device/host helpers for the vl3d HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "vl3d.h"
+
+extern "C" void vl3d_set_error(const char *msg);
+
+#define VL3D_REQUIRE(cond, msg)          \
+    do {                                 \
+        if (!(cond)) {                   \
+            vl3d_set_error(msg);         \
+            return VL3D_EINVAL;          \
+        }                                \
+    } while (0)
+
+#define VL3D_CHECK_LAUNCH()                                  \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) {                             \
+            vl3d_set_error(hipGetErrorString(e__));          \
+            return VL3D_ELAUNCH;                             \
+        }                                                    \
+    } while (0)
+
+#define VL3D_HIP(call)                                       \
+    do {                                                     \
+        hipError_t e__ = (call);                             \
+        if (e__ != hipSuccess) {                             \
+            vl3d_set_error(hipGetErrorString(e__));          \
+            return VL3D_ELAUNCH;                             \
+        }                                                    \
+    } while (0)
+
+// ---- activations (MPI.py:21-31) -----------------------------------------------------------------
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float v) {
+    if constexpr (ACT == VL3D_ACT_SIGMOID) return 1.0f / (1.0f + __expf(-v));
+    else if constexpr (ACT == VL3D_ACT_RELU) return fmaxf(v, 0.0f);
+    else if constexpr (ACT == VL3D_ACT_CLAMP) return fminf(fmaxf(v, 0.0f), 1.0f);
+    else if constexpr (ACT == VL3D_ACT_ABS) return fabsf(v);
+    else return v;
+}
+
+// derivative given pre-activation input `v` and activated output `o`
+template <int ACT>
+__device__ __forceinline__ float act_bwd(float v, float o) {
+    if constexpr (ACT == VL3D_ACT_SIGMOID) return o * (1.0f - o);
+    else if constexpr (ACT == VL3D_ACT_RELU) return v > 0.0f ? 1.0f : 0.0f;
+    else if constexpr (ACT == VL3D_ACT_CLAMP) return (v > 0.0f && v < 1.0f) ? 1.0f : 0.0f;
+    else if constexpr (ACT == VL3D_ACT_ABS) return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f);
+    else return 1.0f;
+}
+
+// ---- texel coordinates ----------------------------------------------------------------------------
+// UTILS_MPI: exactly the reference's fp32 op sequence (utils_mpi.py:173 then ATen's align_corners=True
+// un-normalisation ((g+1)/2)*(size-1)) so that tap weights match the reference bit-for-bit where the
+// homography product does.  AFFINE: tex = p*s + o.
+template <int COORD>
+__device__ __forceinline__ float texel_coord(float p, float half_size, float size_m1, float s, float o) {
+    if constexpr (COORD == VL3D_COORD_UTILS_MPI) {
+        float g = p / half_size - 1.0f;
+        return ((g + 1.0f) / 2.0f) * size_m1;
+    } else {
+        return p * s + o;
+    }
+}
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

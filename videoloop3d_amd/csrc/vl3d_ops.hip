@@ -1,0 +1,293 @@
+// Unfused drop-in operators of the reference's utils_mpi.py for gfx950:
+//   warp_homography (utils_mpi.py:159-176), overcompose (:92-107), overcomposeNto0 (:110-132)
+// plus library-wide error state.  These exist for API parity with the reference's L3 functions; the
+// training/render hot path uses the fused kernel in vl3d_render.hip.
+#include <string.h>
+
+#include "vl3d_common.h"
+
+static thread_local char g_err[256] = "";
+
+extern "C" void vl3d_set_error(const char *msg) {
+    strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
+    g_err[sizeof(g_err) - 1] = 0;
+}
+extern "C" const char *vl3d_last_error(void) { return g_err; }
+extern "C" int vl3d_version(void) { return 100; }
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// warp_homography: images [N,C,Hs,Ws] channel-planar (the reference's layout), out [N,C,h,w].
+struct WarpTap {
+    int idx[4];
+    float w[4];
+};
+
+__device__ __forceinline__ WarpTap warp_taps(const float *__restrict__ hm, int x, int y, int Hs, int Ws) {
+    WarpTap t;
+    const float px = (float)x, py = (float)y;
+    float X = hm[0] * px + hm[1] * py + hm[2];
+    float Y = hm[3] * px + hm[4] * py + hm[5];
+    float Z = hm[6] * px + hm[7] * py + hm[8];
+    float tx = texel_coord<VL3D_COORD_UTILS_MPI>(X / Z, (float)Ws / 2.0f, (float)(Ws - 1), 0.f, 0.f);
+    float ty = texel_coord<VL3D_COORD_UTILS_MPI>(Y / Z, (float)Hs / 2.0f, (float)(Hs - 1), 0.f, 0.f);
+    bool in = (tx > -1.0f) && (tx < (float)Ws) && (ty > -1.0f) && (ty < (float)Hs);
+    if (!in) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { t.idx[i] = -1; t.w[i] = 0.f; }
+        return t;
+    }
+    float fx0 = floorf(tx), fy0 = floorf(ty);
+    float fx = tx - fx0, fy = ty - fy0;
+    int x0 = (int)fx0, y0 = (int)fy0;
+    bool xl = x0 >= 0, xr = x0 + 1 < Ws, yt = y0 >= 0, yb = y0 + 1 < Hs;
+    int base = y0 * Ws + x0;
+    t.idx[0] = (xl && yt) ? base : -1;
+    t.idx[1] = (xr && yt) ? base + 1 : -1;
+    t.idx[2] = (xl && yb) ? base + Ws : -1;
+    t.idx[3] = (xr && yb) ? base + Ws + 1 : -1;
+    t.w[0] = (1.f - fx) * (1.f - fy); t.w[1] = fx * (1.f - fy);
+    t.w[2] = (1.f - fx) * fy;         t.w[3] = fx * fy;
+    return t;
+}
+
+__global__ __launch_bounds__(256) void warp_fwd_k(int C, int Hs, int Ws, int h, int w, const float *__restrict__ homos,
+                                                  const float *__restrict__ images, float *__restrict__ out) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int n = blockIdx.z;
+    if (x >= w || y >= h) return;
+    WarpTap t = warp_taps(homos + 9 * n, x, y, Hs, Ws);
+    const size_t splane = (size_t)Hs * Ws, oplane = (size_t)h * w;
+    const float *img = images + (size_t)n * C * splane;
+    float *o = out + (size_t)n * C * oplane + (size_t)y * w + x;
+    for (int c = 0; c < C; ++c, img += splane, o += oplane) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (t.idx[i] >= 0) v += t.w[i] * img[t.idx[i]];
+        *o = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void warp_bwd_k(int C, int Hs, int Ws, int h, int w, const float *__restrict__ homos,
+                                                  const float *__restrict__ gout, float *__restrict__ gimg) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int n = blockIdx.z;
+    if (x >= w || y >= h) return;
+    WarpTap t = warp_taps(homos + 9 * n, x, y, Hs, Ws);
+    const size_t splane = (size_t)Hs * Ws, oplane = (size_t)h * w;
+    float *gi = gimg + (size_t)n * C * splane;
+    const float *go = gout + (size_t)n * C * oplane + (size_t)y * w + x;
+    for (int c = 0; c < C; ++c, gi += splane, go += oplane) {
+        const float g = *go;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (t.idx[i] >= 0) atomicAdd(gi + t.idx[i], t.w[i] * g);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// overcompose: alpha [P,D], content [P,D,C]; front = index 0 (utils_mpi.py:92-107)
+__global__ __launch_bounds__(256) void overcompose_fwd_k(int64_t P, int D, int C, const float *__restrict__ alpha,
+                                                         const float *__restrict__ content, float *__restrict__ rgb,
+                                                         float *__restrict__ bw) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const float *a = alpha + p * D;
+    const float *ct = content + p * D * C;
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    float Tr = 1.f;
+    for (int d = 0; d < D; ++d) {
+        const float ad = a[d];
+        const float w = ad * Tr;
+        bw[p * D + d] = w;
+        for (int c = 0; c < C; ++c) acc[c] += ct[d * C + c] * w;
+        Tr *= (1.f - ad);
+    }
+    for (int c = 0; c < C; ++c) rgb[p * C + c] = acc[c];
+}
+
+// Backward without any division: back-to-front recurrence R_{k-1} = a_k q'_k + (1-a_k) R_k is not possible
+// with a per-plane upstream gradient on the blend weights, so use the generic two-sweep form:
+//   w_k = a_k T_k ; given gw_k := dL/dw_k (= g_rgb . c_k + g_bw_k):
+//   dL/da_k = T_k gw_k - sum_{j>k} gw_j w_j / (1 - a_k)        (exact 0/0 -> handled by direct product below)
+// The suffix sum is accumulated back-to-front; (1-a_k)==0 falls back to an explicit product over planes.
+__global__ __launch_bounds__(256) void overcompose_bwd_k(int64_t P, int D, int C, const float *__restrict__ alpha,
+                                                         const float *__restrict__ content,
+                                                         const float *__restrict__ g_rgb, const float *__restrict__ g_bw,
+                                                         float *__restrict__ g_alpha, float *__restrict__ g_content) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const float *a = alpha + p * D;
+    const float *ct = content + p * D * C;
+    float G[8];
+    for (int c = 0; c < C; ++c) G[c] = g_rgb[p * C + c];
+    // forward sweep: T_D (total transmittance) and per-plane content grads
+    float Tr = 1.f;
+    for (int d = 0; d < D; ++d) {
+        const float w = a[d] * Tr;
+        for (int c = 0; c < C; ++c) g_content[(p * D + d) * C + c] = w * G[c];
+        Tr *= (1.f - a[d]);
+    }
+    // backward sweep: maintain T_{k} by dividing out (1-a_{k}) when safe, else recompute the prefix product
+    float suffix = 0.f;        // sum_{j>k} gw_j w_j
+    float Tk1 = Tr;            // T_{k+1}
+    for (int d = D - 1; d >= 0; --d) {
+        const float om = 1.f - a[d];
+        float Tk;
+        if (fabsf(om) > 1e-6f) {
+            Tk = Tk1 / om;
+        } else {
+            Tk = 1.f;
+            for (int j = 0; j < d; ++j) Tk *= (1.f - a[j]);
+        }
+        float gw = g_bw ? g_bw[p * D + d] : 0.f;
+        for (int c = 0; c < C; ++c) gw += G[c] * ct[d * C + c];
+        float behind;
+        if (fabsf(om) > 1e-6f) {
+            behind = suffix / om;
+        } else {   // d(sum_{j>k} gw_j w_j)/da_k = -T_k * sum_{j>k} gw_j a_j prod_{k<m<j}(1-a_m)
+            float r = 0.f, tt = 1.f;
+            for (int j = d + 1; j < D; ++j) {
+                float gwj = g_bw ? g_bw[p * D + j] : 0.f;
+                for (int c = 0; c < C; ++c) gwj += G[c] * ct[j * C + c];
+                r += gwj * a[j] * tt;
+                tt *= (1.f - a[j]);
+            }
+            behind = Tk * r;
+        }
+        g_alpha[p * D + d] = Tk * gw - behind;
+        suffix += gw * a[d] * Tk;
+        Tk1 = Tk;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// overcomposeNto0: front = LAST plane (utils_mpi.py:110-132). trans_k = prod_{j>k}(1-a_j).
+__global__ __launch_bounds__(256) void nto0_fwd_k(int D, int C, int64_t HW, const float *__restrict__ alpha, int64_t a_sb,
+                                                  int64_t a_sd, const float *__restrict__ content, int64_t c_sb, int64_t c_sd,
+                                                  int64_t c_sc, float *__restrict__ rgb, float *__restrict__ trans) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (p >= HW) return;
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    float Tr = 1.f;
+    for (int d = D - 1; d >= 0; --d) {
+        const float ad = alpha[b * a_sb + d * a_sd + p];
+        if (trans) trans[((int64_t)b * D + d) * HW + p] = Tr;
+        const float w = ad * Tr;
+        for (int c = 0; c < C; ++c) acc[c] += content[b * c_sb + d * c_sd + c * c_sc + p] * w;
+        Tr *= (1.f - ad);
+    }
+    for (int c = 0; c < C; ++c) rgb[((int64_t)b * C + c) * HW + p] = acc[c];
+}
+
+__global__ __launch_bounds__(256) void nto0_bwd_k(int D, int C, int64_t HW, const float *__restrict__ alpha, int64_t a_sb,
+                                                  int64_t a_sd, const float *__restrict__ content, int64_t c_sb, int64_t c_sd,
+                                                  int64_t c_sc, const float *__restrict__ g_rgb, float *__restrict__ g_alpha,
+                                                  float *__restrict__ g_content) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (p >= HW) return;
+    float G[8];
+    for (int c = 0; c < C; ++c) G[c] = g_rgb[((int64_t)b * C + c) * HW + p];
+    // S = sum_k w_k q_k (front-to-back = d descending), then single sweep with prefix P
+    float Tr = 1.f, S = 0.f;
+    for (int d = D - 1; d >= 0; --d) {
+        const float ad = alpha[b * a_sb + d * a_sd + p];
+        float q = 0.f;
+        for (int c = 0; c < C; ++c) q += G[c] * content[b * c_sb + d * c_sd + c * c_sc + p];
+        S += ad * Tr * q;
+        Tr *= (1.f - ad);
+    }
+    Tr = 1.f;
+    float Pf = 0.f;
+    for (int d = D - 1; d >= 0; --d) {
+        const float ad = alpha[b * a_sb + d * a_sd + p];
+        float q = 0.f;
+        for (int c = 0; c < C; ++c) q += G[c] * content[b * c_sb + d * c_sd + c * c_sc + p];
+        const float w = ad * Tr;
+        for (int c = 0; c < C; ++c) g_content[(((int64_t)b * D + d) * C + c) * HW + p] = w * G[c];
+        Pf += w * q;
+        const float om = 1.f - ad;
+        const float behind = (fabsf(om) > 1e-12f) ? (S - Pf) / om : 0.f;
+        g_alpha[((int64_t)b * D + d) * HW + p] = Tr * q - behind;
+        Tr *= om;
+    }
+}
+
+}  // namespace
+
+extern "C" int vl3d_warp_fwd(int32_t N, int32_t C, int32_t Hs, int32_t Ws, int32_t h, int32_t w, const float *homos,
+                             const float *images, float *out, vl3d_stream_t stream) {
+    VL3D_REQUIRE(N > 0 && C > 0 && Hs > 0 && Ws > 0 && h > 0 && w > 0, "vl3d_warp_fwd: non-positive dims");
+    VL3D_REQUIRE(N <= 65535, "vl3d_warp_fwd: B*D > 65535");
+    VL3D_REQUIRE(homos && images && out, "vl3d_warp_fwd: null pointer");
+    dim3 grid((w + 63) / 64, (h + 3) / 4, N);
+    hipLaunchKernelGGL(warp_fwd_k, grid, dim3(256), 0, (hipStream_t)stream, C, Hs, Ws, h, w, homos, images, out);
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
+extern "C" int vl3d_warp_bwd(int32_t N, int32_t C, int32_t Hs, int32_t Ws, int32_t h, int32_t w, const float *homos,
+                             const float *grad_out, float *grad_images, vl3d_stream_t stream) {
+    VL3D_REQUIRE(N > 0 && C > 0 && Hs > 0 && Ws > 0 && h > 0 && w > 0, "vl3d_warp_bwd: non-positive dims");
+    VL3D_REQUIRE(N <= 65535, "vl3d_warp_bwd: B*D > 65535");
+    VL3D_REQUIRE(homos && grad_out && grad_images, "vl3d_warp_bwd: null pointer");
+    VL3D_HIP(hipMemsetAsync(grad_images, 0, (size_t)N * C * Hs * Ws * sizeof(float), (hipStream_t)stream));
+    dim3 grid((w + 63) / 64, (h + 3) / 4, N);
+    hipLaunchKernelGGL(warp_bwd_k, grid, dim3(256), 0, (hipStream_t)stream, C, Hs, Ws, h, w, homos, grad_out, grad_images);
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
+extern "C" int vl3d_overcompose_fwd(int64_t P, int32_t D, int32_t C, const float *alpha, const float *content, float *rgb,
+                                    float *blendweight, vl3d_stream_t stream) {
+    VL3D_REQUIRE(P > 0 && D > 0 && C > 0 && C <= 8, "vl3d_overcompose_fwd: bad dims (need 1 <= C <= 8)");
+    VL3D_REQUIRE(alpha && content && rgb && blendweight, "vl3d_overcompose_fwd: null pointer");
+    hipLaunchKernelGGL(overcompose_fwd_k, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, (hipStream_t)stream, P, D, C,
+                       alpha, content, rgb, blendweight);
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
+extern "C" int vl3d_overcompose_bwd(int64_t P, int32_t D, int32_t C, const float *alpha, const float *content,
+                                    const float *grad_rgb, const float *grad_bw, float *grad_alpha, float *grad_content,
+                                    vl3d_stream_t stream) {
+    VL3D_REQUIRE(P > 0 && D > 0 && C > 0 && C <= 8, "vl3d_overcompose_bwd: bad dims (need 1 <= C <= 8)");
+    VL3D_REQUIRE(alpha && content && grad_rgb && grad_alpha && grad_content, "vl3d_overcompose_bwd: null pointer");
+    hipLaunchKernelGGL(overcompose_bwd_k, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, (hipStream_t)stream, P, D, C,
+                       alpha, content, grad_rgb, grad_bw, grad_alpha, grad_content);
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
+extern "C" int vl3d_overcompose_nto0_fwd(int32_t B, int32_t D, int32_t C, int64_t HW, const float *alpha, int64_t a_sb,
+                                         int64_t a_sd, const float *content, int64_t c_sb, int64_t c_sd, int64_t c_sc,
+                                         float *rgb, float *trans, vl3d_stream_t stream) {
+    VL3D_REQUIRE(B > 0 && B <= 65535 && D > 0 && C > 0 && C <= 8 && HW > 0, "vl3d_overcompose_nto0_fwd: bad dims");
+    VL3D_REQUIRE(alpha && content && rgb, "vl3d_overcompose_nto0_fwd: null pointer");
+    hipLaunchKernelGGL(nto0_fwd_k, dim3((unsigned)ceil_div64(HW, 256), B), dim3(256), 0, (hipStream_t)stream, D, C, HW, alpha,
+                       a_sb, a_sd, content, c_sb, c_sd, c_sc, rgb, trans);
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
+extern "C" int vl3d_overcompose_nto0_bwd(int32_t B, int32_t D, int32_t C, int64_t HW, const float *alpha, int64_t a_sb,
+                                         int64_t a_sd, const float *content, int64_t c_sb, int64_t c_sd, int64_t c_sc,
+                                         const float *grad_rgb, float *grad_alpha, float *grad_content,
+                                         vl3d_stream_t stream) {
+    VL3D_REQUIRE(B > 0 && B <= 65535 && D > 0 && C > 0 && C <= 8 && HW > 0, "vl3d_overcompose_nto0_bwd: bad dims");
+    VL3D_REQUIRE(alpha && content && grad_rgb && grad_alpha && grad_content, "vl3d_overcompose_nto0_bwd: null pointer");
+    hipLaunchKernelGGL(nto0_bwd_k, dim3((unsigned)ceil_div64(HW, 256), B), dim3(256), 0, (hipStream_t)stream, D, C, HW, alpha,
+                       a_sb, a_sd, content, c_sb, c_sd, c_sc, grad_rgb, grad_alpha, grad_content);
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}

@@ -1,0 +1,101 @@
+"""Row-band sharding of the render across the GPUs of one node.
+
+The reference has no distributed code (only independent scenes per GPU, run_all.sh:7-14).  This module adds the
+MI355X-native multi-GPU form of the hot path: the output frame is split into horizontal row bands exactly like the
+reference's training crops (shifted principal point, train_3dvid.py:60-66 / utils.py:196-200); every rank holds only
+the plane-stack rows its band can touch (band +- parallax halo), so stack gradients are owner-computed without any
+collective, and ONE all-gather over RCCL/xGMI assembles the composited frame.
+"""
+from dataclasses import dataclass
+from typing import List
+
+import torch
+
+from .render import RenderSpec, render_planes
+
+
+@dataclass(frozen=True)
+class Band:
+    rank: int
+    row0: int          # first output row of the band
+    rows: int          # number of output rows
+    src0: int          # first plane-stack row held by this rank
+    src1: int          # one past the last plane-stack row held
+
+
+def split_rows(H: int, world: int) -> List[tuple]:
+    """near-equal contiguous row ranges, every rank non-empty when H >= world."""
+    base, rem = divmod(H, world)
+    out, r = [], 0
+    for k in range(world):
+        n = base + (1 if k < rem else 0)
+        out.append((r, n))
+        r += n
+    return out
+
+
+def source_row_range(homos: torch.Tensor, row0: int, rows: int, W: int, Hs: int, spec: RenderSpec, margin: int = 2):
+    """Conservative [lo,hi) range of plane-stack rows touched by output rows [row0,row0+rows) over all planes.
+
+    A homography maps the band (a convex quad) to a convex quad on every plane, so the extreme source rows are reached
+    at the band's four corners (plus the bilinear +1 tap and a safety margin)."""
+    hm = homos.detach().double().cpu()
+    c = float(spec.pixel_center)
+    xs = torch.tensor([0.0 + c, W - 1.0 + c], dtype=torch.float64)
+    ys = torch.tensor([row0 + c, row0 + rows - 1.0 + c], dtype=torch.float64)
+    pts = torch.stack([xs[[0, 1, 0, 1]], ys[[0, 0, 1, 1]], torch.ones(4, dtype=torch.float64)], 0)   # 3,4
+    p = hm @ pts                                                                                  # D,3,4
+    if (p[:, 2] <= 0).any():
+        return 0, Hs        # degenerate view: keep everything
+    y_src = p[:, 1] / p[:, 2]
+    if spec.coord_mode == "utils_mpi":
+        ty = y_src * (Hs - 1) / Hs
+    else:
+        ty = y_src * spec.scale[1] + spec.offset[1]
+    lo = int(torch.floor(ty.min()).item()) - margin
+    hi = int(torch.ceil(ty.max()).item()) + 1 + margin
+    return max(0, lo), min(Hs, hi)
+
+
+def plan_bands(homos: torch.Tensor, H: int, W: int, Hs: int, world: int, spec: RenderSpec) -> List[Band]:
+    bands = []
+    for rank, (r0, n) in enumerate(split_rows(H, world)):
+        lo, hi = source_row_range(homos, r0, n, W, Hs, spec)
+        if hi <= lo:
+            lo, hi = 0, 1
+        bands.append(Band(rank, r0, n, lo, hi))
+    return bands
+
+
+def band_spec(spec: RenderSpec, band: Band, Hs: int) -> RenderSpec:
+    """Spec for rendering from the band-local stack rows [src0,src1): shift the texel row by -src0.
+    Needs the affine coordinate mode (the utils_mpi normalisation depends on the full Hs)."""
+    if spec.coord_mode == "utils_mpi":
+        raise RuntimeError("row-band sharding needs coord_mode='affine' (use RenderSpec.mpv() or an affine spec)")
+    return RenderSpec(pixel_center=spec.pixel_center, coord_mode="affine", scale=spec.scale,
+                      offset=(spec.offset[0], spec.offset[1] - band.src0), border=spec.border,
+                      act_order=spec.act_order, rgb_act=spec.rgb_act, alpha_act=spec.alpha_act, variant=spec.variant)
+
+
+def render_band(local_stack, homos, band: Band, W: int, Hs: int, spec: RenderSpec):
+    """Render this rank's band from its local stack rows.  local_stack: (D,T,src1-src0,Ws,4).
+
+    With border='hardcut' the quad-extent test uses the local row count; the halo guarantees no band pixel reaches a
+    local boundary that is not also a true plane boundary."""
+    assert local_stack.shape[2] == band.src1 - band.src0
+    return render_planes(local_stack, homos, band.rows, W, band_spec(spec, band, Hs), window=(band.row0, 0))
+
+
+def all_gather_frame(band_rgb: torch.Tensor, bands: List[Band], group=None) -> torch.Tensor:
+    """One all-gather of the composited bands [T,rows_r,W,C] -> full frame [T,H,W,C] on every rank.
+    Uses torch.distributed (backend 'nccl' == RCCL over xGMI on ROCm; 'gloo' in the CPU tests)."""
+    import torch.distributed as dist
+    T, _, W, C = band_rgb.shape
+    rows = [b.rows for b in bands]
+    if len(set(rows)) == 1:
+        out = torch.empty((len(bands), T, rows[0], W, C), dtype=band_rgb.dtype, device=band_rgb.device)
+        dist.all_gather_into_tensor(out, band_rgb.contiguous(), group=group)
+        return out.permute(1, 0, 2, 3, 4).reshape(T, sum(rows), W, C)
+    parts = [torch.empty((T, r, W, C), dtype=band_rgb.dtype, device=band_rgb.device) for r in rows]
+    dist.all_gather(parts, band_rgb.contiguous(), group=group)
+    return torch.cat(parts, dim=1)

@@ -1,0 +1,94 @@
+"""Fused differentiable MPI/MPV render (warp + sample + activate + composite) on the HIP kernels.
+
+Host-side mirror of the chain MPV.py:351-454 (planar geometry) / utils_mpi.py:159-176 + 92-107 of the
+reference, behind a torch.autograd.Function.  The arithmetic lives in csrc/vl3d_render.hip.
+"""
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib as L
+
+
+@dataclass(frozen=True)
+class RenderSpec:
+    """Sampling / compositing conventions (see oracle/mpi_oracle.py:RenderSpec for the CPU statement).
+
+    Defaults = the utils_mpi convention (sigmoid -> warp_homography -> over-composite).
+    `RenderSpec.mpv()` = the planar MPV.py convention (pixel centres at +0.5, hard-cut quad borders,
+    sample-then-activate)."""
+    pixel_center: float = 0.0
+    coord_mode: str = "utils_mpi"
+    scale: tuple = (1.0, 1.0)
+    offset: tuple = (0.0, 0.0)
+    border: str = "zeros"
+    act_order: str = "pre"
+    rgb_act: str = "sigmoid"
+    alpha_act: str = "sigmoid"
+    variant: int = 0
+
+    @staticmethod
+    def mpv(rgb_act="sigmoid", alpha_act="sigmoid", scale=(1.0, 1.0), offset=(0.0, 0.0), variant=0):
+        return RenderSpec(pixel_center=0.5, coord_mode="affine", scale=scale, offset=offset, border="hardcut",
+                          act_order="post", rgb_act=rgb_act, alpha_act=alpha_act, variant=variant)
+
+
+def _desc(stack, H, W, spec, row0, col0):
+    D, T, Hs, Ws, C4 = stack.shape
+    assert C4 == 4, "plane stack must be (D,T,Hs,Ws,4)"
+    d = L.RenderDesc()
+    d.D, d.T, d.Hs, d.Ws, d.H, d.W = D, T, Hs, Ws, int(H), int(W)
+    d.row0, d.col0 = int(row0), int(col0)
+    d.coord_mode = L.COORD[spec.coord_mode]
+    d.border_mode = L.BORDER[spec.border]
+    d.act_order = L.ACT_ORDER[spec.act_order]
+    d.rgb_act, d.alpha_act = L.ACT[spec.rgb_act], L.ACT[spec.alpha_act]
+    d.stack_dtype = 0
+    d.pixel_center = float(spec.pixel_center)
+    d.sx, d.sy = float(spec.scale[0]), float(spec.scale[1])
+    d.ox, d.oy = float(spec.offset[0]), float(spec.offset[1])
+    d.variant = int(spec.variant)
+    return d
+
+
+class _RenderPlanes(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, stack, homos, H, W, spec, row0, col0):
+        L.check_cuda(stack, homos)
+        if stack.dtype != torch.float32:
+            raise RuntimeError("plane stack must be float32")
+        stack = stack.contiguous()
+        homos = homos.detach().to(torch.float32).contiguous()
+        D, T = stack.shape[:2]
+        if homos.shape != (D, 3, 3):
+            raise RuntimeError(f"homos must be [D,3,3] = [{D},3,3], got {tuple(homos.shape)}")
+        rgb = torch.empty((T, H, W, 3), dtype=torch.float32, device=stack.device)
+        alpha = torch.empty((T, H, W), dtype=torch.float32, device=stack.device)
+        desc = _desc(stack, H, W, spec, row0, col0)
+        with torch.cuda.device(stack.device):
+            L.check(L.lib().vl3d_render_fwd(desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha),
+                                            L.stream_ptr(stack.device)), "vl3d_render_fwd")
+        ctx.save_for_backward(stack, homos, rgb, alpha)
+        ctx.desc = desc
+        return rgb, alpha
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_alpha):
+        stack, homos, rgb, alpha = ctx.saved_tensors
+        g_rgb = g_rgb.contiguous() if g_rgb is not None else torch.zeros_like(rgb)
+        g_alpha = g_alpha.contiguous() if g_alpha is not None else None
+        g_stack = torch.empty_like(stack)
+        with torch.cuda.device(stack.device):
+            L.check(L.lib().vl3d_render_bwd(ctx.desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha),
+                                            L.ptr(g_rgb), L.ptr(g_alpha), L.ptr(g_stack),
+                                            L.stream_ptr(stack.device)), "vl3d_render_bwd")
+        return g_stack, None, None, None, None, None, None
+
+
+def render_planes(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0)):
+    """stack (D,T,Hs,Ws,4) pre-activation fp32 (plane 0 = nearest), homos [D,3,3] (target pixel -> plane pixel).
+
+    Returns rgb [T,H,W,3], alpha [T,H,W].  `window=(row0,col0)` renders the H x W sub-window whose top-left
+    corner is frame pixel (row0,col0) -- used for row-band sharding (equivalent to utils.py:196-200
+    get_new_intrin on the target intrinsics)."""
+    return _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]))

@@ -1,0 +1,209 @@
+"""Drop-in mirror of the reference's utils_vid.py looping-loss operators.
+
+Same names / arguments / error behaviour as /root/reference/utils_vid.py.  The patch search, vote-fold and
+robust loss run in the HIP library (csrc/vl3d_loss.hip); patches are never materialised (no unfoldNd), and
+the macro-block loop of the reference (a pure memory cap that does not change the result, utils_vid.py:323-342)
+is not needed.
+"""
+import warnings
+
+import torch
+
+from . import _lib as L
+
+
+def robust_lossfun(x, rou, scale, epsilon=1e-6):
+    """utils_vid.py:10-26 (elementwise; the loss classes below use the fused HIP kernel instead)."""
+    if rou == 'mse':
+        return x ** 2
+    elif rou == 'abs':
+        return x.abs()
+    rou = float(rou)
+    s = (x / scale) ** 2
+    if rou == 0:
+        return torch.log1p(s * 0.5)
+    elif rou == 2:
+        return 0.5 * s
+    b = abs(rou - 2) + epsilon
+    d = rou + epsilon if rou >= 0 else rou - epsilon
+    return (b / d) * (torch.pow(s / b + 1., 0.5 * d) - 1.) * (scale * 10)
+
+
+def _rho_kind(rou):
+    if rou == 'mse':
+        return L.RHO["mse"], 0.0
+    if rou == 'abs':
+        return L.RHO["abs"], 0.0
+    return L.RHO["barron"], float(rou)
+
+
+def extract_3Dpatches(x, patch_size, tpatch_size, stride, tstride):
+    """utils_vid.py:60-69: 3-D im2col, [b,3,T,h,w] -> [b, 3*pt*ps*ps, d_out, h_out, w_out] with channel order
+    (c,kt,kh,kw).  Kept for API parity (evaluations/NNMSE.py:45 uses it); the loss path never calls it."""
+    b, c = x.shape[:2]
+    p = x.unfold(2, tpatch_size, tstride).unfold(3, patch_size, stride).unfold(4, patch_size, stride)
+    dT, dH, dW = p.shape[2:5]
+    return p.permute(0, 1, 5, 6, 7, 2, 3, 4).reshape(b, c * tpatch_size * patch_size * patch_size, dT, dH, dW)
+
+
+def _loss_desc(x, y, patch_size, patcht_size, stride, stridet, alpha):
+    """x [3,Tx,H,W], y [3,Ty,H,W] float32 CUDA tensors with unit column stride."""
+    d = L.LossDesc()
+    d.Tx, d.H, d.W = x.shape[1:]
+    d.Ty = y.shape[1]
+    d.ps, d.pt, d.stride, d.stridet = int(patch_size), int(patcht_size), int(stride), int(stridet)
+    d.use_alpha = 0 if alpha is None else 1
+    d.alpha = 0.0 if alpha is None else float(alpha)
+    d.x_sc, d.x_st, d.x_sr = x.stride(0), x.stride(1), x.stride(2)
+    d.y_sc, d.y_st, d.y_sr = y.stride(0), y.stride(1), y.stride(2)
+    d.variant = 0
+    return d
+
+
+def _as_video(v, name):
+    """[1,3,T,h,w] -> [3,T,h,w] float32 view with unit column stride (copy only if needed)."""
+    if v.dim() != 5 or v.shape[0] != 1 or v.shape[1] != 3:
+        raise RuntimeError(f"{name} must be [1,3,T,h,w], got {tuple(v.shape)}")
+    v = v[0]
+    if v.dtype != torch.float32:
+        v = v.float()
+    if v.stride(-1) != 1:
+        v = v.contiguous()
+    return v
+
+
+def find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha):
+    """Per-location temporal NN search on videos x,y [1,3,T,h,w] (already trimmed).  Returns int32 [h_o,w_o,n1]."""
+    L.check_cuda(x, y)
+    xv, yv = _as_video(x.detach(), "x"), _as_video(y.detach(), "y")
+    if xv.shape[2:] != yv.shape[2:]:
+        raise RuntimeError("x and y must have identical spatial size (patch grids must coincide)")
+    desc = _loss_desc(xv, yv, patch_size, patcht_size, stride, stridet, alpha)
+    h_o = (desc.H - desc.ps) // desc.stride + 1
+    w_o = (desc.W - desc.ps) // desc.stride + 1
+    n1 = (desc.Tx - desc.pt) // desc.stridet + 1
+    nn = torch.empty((h_o, w_o, n1), dtype=torch.int32, device=xv.device)
+    with torch.cuda.device(xv.device):
+        L.check(L.lib().vl3d_patchnn(desc, L.ptr(xv), L.ptr(yv), L.ptr(nn), None, L.stream_ptr(xv.device)),
+                "vl3d_patchnn")
+    return nn, desc, xv, yv
+
+
+def _nn_and_fold(x, y, patch_size, patcht_size, stride, stridet, alpha, normalize):
+    nn, desc, xv, yv = find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha)
+    s = torch.empty((1, 3, desc.Tx, desc.H, desc.W), dtype=torch.float32, device=xv.device)
+    w = torch.empty((1, 1, desc.Tx, desc.H, desc.W), dtype=torch.float32, device=xv.device)
+    with torch.cuda.device(xv.device):
+        L.check(L.lib().vl3d_vote_fold(desc, L.ptr(yv), L.ptr(nn), L.ptr(s), L.ptr(w), 1 if normalize else 0,
+                                       L.stream_ptr(xv.device)), "vl3d_vote_fold")
+    return s, w, nn
+
+
+def FindNNpatchAndMerge(x, y, patch_size=7, patcht_size=7, stride=1, stridet=1, alpha=1e10, dist_fn='mse', **kwargs):
+    """utils_vid.py:206-229 -> (y2x_sum [1,3,T,h,w], weight [1,1,T,h,w] clamped at 1e-10)."""
+    if dist_fn != 'mse':
+        raise RuntimeError("dist_fn other than 'mse' is not settable in the reference (config_parser.py:90-93)")
+    alpha = None if alpha > 100 else alpha
+    s, w, _ = _nn_and_fold(x, y, patch_size, patcht_size, stride, stridet, alpha, normalize=False)
+    return s, w
+
+
+class _RobustMean(torch.autograd.Function):
+    """loss = robust_lossfun(x - y2x, rou, scaling).mean()  (utils_vid.py:348), gradient to x only."""
+
+    @staticmethod
+    def forward(ctx, x, y2x, rou, scaling):
+        L.check_cuda(x, y2x)
+        xc = x.to(torch.float32).contiguous()
+        yc = y2x.contiguous()
+        kind, r = _rho_kind(rou)
+        acc = torch.empty((), dtype=torch.float64, device=xc.device)
+        n = xc.numel()
+        with torch.cuda.device(xc.device):
+            L.check(L.lib().vl3d_robust_fwd(n, L.ptr(xc), L.ptr(yc), kind, r, float(scaling), L.ptr(acc),
+                                            L.stream_ptr(xc.device)), "vl3d_robust_fwd")
+        ctx.save_for_backward(xc, yc)
+        ctx.cfg = (kind, r, float(scaling), n)
+        return (acc / n).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, yc = ctx.saved_tensors
+        kind, r, scaling, n = ctx.cfg
+        g = g.to(torch.float32).contiguous()
+        gx = torch.empty_like(xc)
+        with torch.cuda.device(xc.device):
+            L.check(L.lib().vl3d_robust_bwd(n, L.ptr(xc), L.ptr(yc), kind, r, scaling, L.ptr(g), 1.0 / n, L.ptr(gx),
+                                            L.stream_ptr(xc.device)), "vl3d_robust_bwd")
+        return gx, None, None, None
+
+
+class Patch3DGPNNDirectLoss:
+    """utils_vid.py:265-286."""
+
+    def __init__(self):
+        self.last_y2x = None
+        self.last_weight = None
+
+    def __call__(self, x, y, mask=None, same_input=False, rou=0, scaling=0.2, **kwargs):
+        if same_input:
+            weight, y2x = self.last_weight, self.last_y2x
+        else:
+            with torch.no_grad():
+                cfg = dict(patch_size=7, patcht_size=7, stride=1, stridet=1, alpha=1e10)
+                cfg.update({k: v for k, v in kwargs.items() if k in cfg})
+                alpha = None if cfg["alpha"] > 100 else cfg["alpha"]
+                y2x, weight, _ = _nn_and_fold(x, y, cfg["patch_size"], cfg["patcht_size"], cfg["stride"],
+                                              cfg["stridet"], alpha, normalize=True)
+                self.last_weight, self.last_y2x = weight, y2x
+        return _RobustMean.apply(x, y2x, rou, scaling)
+
+
+class Patch3DGPNNLowMemLoss:
+    """utils_vid.py:289-349.  `macro_block` is accepted and fitted (with the reference's warning) but no
+    macro-block loop is needed: the HIP path has no unfold memory to cap and the result is identical."""
+
+    def __init__(self):
+        self.last_y2x = None
+        self.last_weight = None
+
+    def __call__(self, x, y, mask=None, same_input=False, macro_block=64, patch_size=7, stride=2, patcht_size=7,
+                 stridet=2, rou=0, scaling=0.2, **kwargs):
+        if same_input:
+            weight, y2x = self.last_weight, self.last_y2x
+        else:
+            t, h, w = x.shape[-3:]
+
+            def fit_patch(s_, name, p_, st_):
+                if (s_ - p_) % st_ != 0:
+                    new_s_ = (s_ - p_) // st_ * st_ + p_
+                    warnings.warn(f'{name} doesnot satisfy ({name} - patch_size) % stride == 0. '
+                                  f'changing {name} from {s_} to {new_s_}')
+                    return new_s_
+                return s_
+
+            macro_block = fit_patch(macro_block, "macro_block", patch_size, stride)
+            h = fit_patch(h, "patch_height", patch_size, stride)
+            w = fit_patch(w, "patch_width", patch_size, stride)
+            t = fit_patch(t, "frame_num", patcht_size, stridet)
+            x = x[..., :t, :h, :w]
+            y = y[..., :h, :w]
+            with torch.no_grad():
+                alpha = kwargs.get("alpha", 1e10)
+                alpha = None if alpha > 100 else alpha
+                if kwargs.get("dist_fn", "mse") != "mse":
+                    raise RuntimeError("dist_fn other than 'mse' is not settable in the reference")
+                y2x, weight, _ = _nn_and_fold(x, y, patch_size, patcht_size, stride, stridet, alpha, normalize=True)
+                self.last_weight, self.last_y2x = weight, y2x
+        return _RobustMean.apply(x, y2x, rou, scaling)
+
+
+def Patch3DMSE(x, y, **kwargs):
+    """utils_vid.py:437-440."""
+    frm = min(x.shape[2], y.shape[2])
+    return ((x[:, :, :frm] - y[:, :, :frm]) ** 2).mean()
+
+
+def Patch3DAvg(x, y, **kwargs):
+    """utils_vid.py:443-445."""
+    return ((x.mean(dim=2) - y.mean(dim=2)) ** 2).mean()
