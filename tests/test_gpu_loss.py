@@ -93,7 +93,7 @@ def test_g8_lowmem_loss_value_and_grad(dev, golden, name, cfg):
     ((12, 20, 63, 71), dict(ps=11, pt=3, s=4, st=1, alpha=0.5)),       # ref-view shipped cfg
     ((12, 20, 63, 71), dict(ps=3, pt=3, s=2, st=1, alpha=None)),       # other-view shipped cfg
     ((3, 3, 11, 11), dict(ps=11, pt=3, s=4, st=1, alpha=None)),        # exactly one patch, n1 = n2 = 1
-    ((9, 5, 16, 19), dict(ps=4, pt=2, s=4, st=2, alpha=0.01)),         # stride == patch (no overlap), n2 < n1
+    ((8, 5, 16, 20), dict(ps=4, pt=2, s=4, st=2, alpha=0.01)),         # stride == patch (no overlap), n2 < n1
     ((6, 30, 9, 9), dict(ps=1, pt=1, s=1, st=1, alpha=None)),          # 1x1x1 patches
 ])
 def test_nn_and_fold_vs_oracle(dev, shape, cfg):

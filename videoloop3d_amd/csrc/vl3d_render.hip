@@ -32,6 +32,7 @@ struct RenderArgs {
 struct Taps {
     int idx[4];     // texel index (y*Ws+x) of each tap, -1 if out of range
     float w[4];     // bilinear weights
+    int x0, y0;     // top-left tap
     bool covered;   // plane contributes at this pixel
 };
 
@@ -55,11 +56,13 @@ __device__ __forceinline__ Taps make_taps(const float *__restrict__ h, float px,
     if (!cov) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { t.idx[i] = -1; t.w[i] = 0.0f; }
+        t.x0 = t.y0 = 0;
         return t;
     }
     float fx0 = floorf(tx), fy0 = floorf(ty);
     float fx = tx - fx0, fy = ty - fy0;
     int x0 = (int)fx0, y0 = (int)fy0;
+    t.x0 = x0; t.y0 = y0;
     bool xl = x0 >= 0, xr = x0 + 1 < Ws, yt = y0 >= 0, yb = y0 + 1 < Hs;
     int base = y0 * Ws + x0;
     t.idx[0] = (xl && yt) ? base : -1;
