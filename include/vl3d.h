@@ -69,10 +69,15 @@ int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, const float
 
 /* Backward of the above w.r.t. the stack (geometry is not differentiated: MPV.py:354).
  * rgb/alpha are the saved forward outputs; grad_alpha may be NULL (treated as 0).
- * grad_stack (D,T,Hs,Ws,4) fp32 is overwritten. */
+ * grad_stack (D,T,Hs,Ws,4) fp32 is overwritten.
+ * scratch: caller-owned device buffer of vl3d_render_bwd_scratch_bytes(desc) bytes (plan written and read on
+ * `stream`, no host sync); with scratch == NULL the universal global-atomics kernel is used.
+ * desc->variant: 0 auto (LDS-staged owner-computes kernel when its on-device feasibility plan allows, atomics
+ * kernel otherwise), 1 force atomics, 2/3 owner-computes kernel with 8-/16-row regions. */
+int64_t vl3d_render_bwd_scratch_bytes(const vl3d_render_desc *desc);
 int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, const float *homos,
                     const float *rgb, const float *alpha, const float *grad_rgb, const float *grad_alpha,
-                    float *grad_stack, vl3d_stream_t stream);
+                    float *grad_stack, void *scratch, int64_t scratch_bytes, vl3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Unfused operators (drop-ins for the reference's L3 functions).

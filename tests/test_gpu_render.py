@@ -235,3 +235,76 @@ def test_720p_window_vs_oracle(dev):
         assert maxabs(alpha[:, r0:r0 + h, c0:c0 + w], alpha_o) <= TOL
         assert maxabs(gs[:, :, lo_r:hi_r, lo_c:hi_c], gs_o[:, :, lo_r:hi_r, lo_c:hi_c]) <= TOL
         assert float(gs_o[:, :, lo_r:hi_r, lo_c:hi_c].abs().sum()) == pytest.approx(float(gs_o.abs().sum()))
+
+
+# ---- backward kernel variants ---------------------------------------------------------------------------
+def _tile_ran():
+    from videoloop3d_amd import render
+    return int(render.LAST_BWD_SCRATCH.view(torch.int32)[0].item())
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("spec_name", ["mpv", "utils_mpi", "hardcut_pre"])
+@pytest.mark.parametrize("shape", [(6, 2, 150, 200, 139, 187), (4, 1, 70, 300, 64, 280), (3, 1, 40, 40, 37, 35)])
+def test_bwd_variants_agree_with_oracle(dev, variant, spec_name, shape):
+    """variant 1 = global atomics, 2/3 = LDS-staged owner-computes (8-/16-row regions); near-unit-scale geometry with
+    rotation + perspective so the owner-computes plan is feasible, odd sizes so tiles are ragged."""
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    D, T, Hs, Ws, H, W = shape
+    kw_p, kw_o = SPECS[spec_name]
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=13)
+    th = math.radians(2.0)
+    Rz = torch.tensor([[math.cos(th) * 1.05, -math.sin(th), 3.0], [math.sin(th), math.cos(th) * 0.96, 2.5], [2e-5, -3e-5, 1.0]])
+    homos = bench_homos(D, H, W, scale=1.5) @ Rz
+    g_rgb = synth.hash_uniform((T, H, W, 3), seed=5) - 0.5
+    g_a = synth.hash_uniform((T, H, W), seed=6) - 0.5
+    s_cpu = stack.clone().requires_grad_(True)
+    rgb_o, alpha_o, _ = MO.render_planes(s_cpu, homos, H, W, MO.RenderSpec(**kw_o))
+    (gs_o,) = torch.autograd.grad([rgb_o, alpha_o], s_cpu, [g_rgb, g_a])
+    s_gpu = stack.to(dev).requires_grad_(True)
+    rgb, alpha = render_planes(s_gpu, homos.to(dev), H, W, RenderSpec(variant=variant, **kw_p))
+    (gs,) = torch.autograd.grad([rgb, alpha], s_gpu, [g_rgb.to(dev), g_a.to(dev)])
+    assert _tile_ran() == (0 if variant == 1 else 1)
+    assert maxabs(gs, gs_o) <= TOL * max(1.0, float(gs_o.abs().max()))
+    assert torch.isfinite(gs).all()
+
+
+def test_bwd_infeasible_geometry_falls_back_on_device(dev):
+    """2x magnification violates the 1-pixel-halo precondition: the on-device plan must route to the atomics kernel
+    (no host sync, same result)."""
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    D, T, Hs, Ws, H, W = 3, 1, 30, 40, 60, 80
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=1)
+    homos = torch.tensor([[0.5, 0, 0], [0, 0.5, 0], [0, 0, 1.0]]).repeat(D, 1, 1)
+    g = synth.hash_uniform((T, H, W, 3), seed=5) - 0.5
+    s_cpu = stack.clone().requires_grad_(True)
+    rgb_o, _, _ = MO.render_planes(s_cpu, homos, H, W, MO.RenderSpec())
+    (gs_o,) = torch.autograd.grad(rgb_o, s_cpu, g)
+    s_gpu = stack.to(dev).requires_grad_(True)
+    rgb, _ = render_planes(s_gpu, homos.to(dev), H, W, RenderSpec(variant=3))
+    (gs,) = torch.autograd.grad(rgb, s_gpu, g.to(dev))
+    assert _tile_ran() == 0
+    assert maxabs(gs, gs_o) <= TOL
+
+
+def test_bwd_tile_720p_matches_atomics(dev):
+    """cfg2 scale (720p, D=32, benchmark cameras): the owner-computes kernel equals the atomics kernel to fp32
+    summation-order noise, every texel of grad_stack is written (no holes: the buffer starts as NaN)."""
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    D, T, Hs, Ws, H, W = 32, 2, 720, 1280, 720, 1280
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=2, device=dev).requires_grad_(True)
+    homos = bench_homos(D, H, W).to(dev)
+    g = (synth.hash_uniform((T, H, W, 3), seed=5, device=dev) - 0.5)
+    out = {}
+    for variant in (1, 2, 3):
+        rgb, _ = render_planes(stack, homos, H, W, RenderSpec.mpv(variant=variant))
+        # poison the allocator's next block so unwritten texels would show up as NaN
+        poison = torch.full_like(stack, float("nan"))
+        del poison
+        (gs,) = torch.autograd.grad(rgb, stack, g)
+        assert _tile_ran() == (0 if variant == 1 else 1)
+        assert torch.isfinite(gs).all()
+        out[variant] = gs
+    scale = float(out[1].abs().max())
+    assert maxabs(out[2], out[1]) <= 2e-5 * max(1.0, scale)
+    assert maxabs(out[3], out[1]) <= 2e-5 * max(1.0, scale)

@@ -51,6 +51,11 @@ def _desc(stack, H, W, spec, row0, col0):
     return d
 
 
+# scratch (plan) buffer of the most recent backward: element 0 viewed as int32 is 1 when the LDS-staged
+# owner-computes kernel ran, 0 when the call fell back to the atomics kernel (read by tests / diagnostics only).
+LAST_BWD_SCRATCH = None
+
+
 class _RenderPlanes(torch.autograd.Function):
     @staticmethod
     def forward(ctx, stack, homos, H, W, spec, row0, col0):
@@ -79,9 +84,13 @@ class _RenderPlanes(torch.autograd.Function):
         g_alpha = g_alpha.contiguous() if g_alpha is not None else None
         g_stack = torch.empty_like(stack)
         with torch.cuda.device(stack.device):
+            nscratch = int(L.lib().vl3d_render_bwd_scratch_bytes(ctx.desc))
+            scratch = torch.zeros((nscratch + 3) // 4, dtype=torch.float32, device=stack.device)
             L.check(L.lib().vl3d_render_bwd(ctx.desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha),
-                                            L.ptr(g_rgb), L.ptr(g_alpha), L.ptr(g_stack),
+                                            L.ptr(g_rgb), L.ptr(g_alpha), L.ptr(g_stack), L.ptr(scratch), nscratch,
                                             L.stream_ptr(stack.device)), "vl3d_render_bwd")
+        global LAST_BWD_SCRATCH
+        LAST_BWD_SCRATCH = scratch
         return g_stack, None, None, None, None, None, None
 
 
