@@ -37,7 +37,7 @@ extern "C" void vl3d_set_error(const char *msg);
 // ---- activations (MPI.py:21-31) -----------------------------------------------------------------
 template <int ACT>
 __device__ __forceinline__ float act_fwd(float v) {
-    if constexpr (ACT == VL3D_ACT_SIGMOID) return 1.0f / (1.0f + __expf(-v));
+    if constexpr (ACT == VL3D_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.0f + __expf(-v));   // 4 instrs, ~1 ulp
     else if constexpr (ACT == VL3D_ACT_RELU) return fmaxf(v, 0.0f);
     else if constexpr (ACT == VL3D_ACT_CLAMP) return fminf(fmaxf(v, 0.0f), 1.0f);
     else if constexpr (ACT == VL3D_ACT_ABS) return fabsf(v);
@@ -61,8 +61,13 @@ __device__ __forceinline__ float act_bwd(float v, float o) {
 template <int COORD>
 __device__ __forceinline__ float texel_coord(float p, float half_size, float size_m1, float s, float o) {
     if constexpr (COORD == VL3D_COORD_UTILS_MPI) {
-        float g = p / half_size - 1.0f;
-        return ((g + 1.0f) / 2.0f) * size_m1;
+        // p / half_size by refined reciprocal + residual correction (matches the IEEE quotient of the reference)
+        float r = __builtin_amdgcn_rcpf(half_size);
+        r = fmaf(fmaf(-half_size, r, 1.0f), r, r);
+        float q = p * r;
+        q = fmaf(fmaf(-q, half_size, p), r, q);
+        float g = q - 1.0f;
+        return ((g + 1.0f) * 0.5f) * size_m1;
     } else {
         return p * s + o;
     }

@@ -8,11 +8,13 @@
 // wave of 64 consecutive output pixels reads ~65 consecutive texels (1 KiB, fully coalesced) per tap
 // row.  Output rgb (T,H,W,3), alpha (T,H,W).
 //
-// Variant 0 (this file, v1): one thread per output pixel, planes walked front-to-back in registers,
-// taps fetched straight through the vector L1 (texture-cache style; the 4x tap redundancy between
-// neighbouring pixels is absorbed by L1/L2).  Backward is a single front-to-back sweep that uses the
-// saved forward outputs:  sum_{j>k} w_j q_j = (G.C + gA.A) - sum_{j<=k} w_j q_j  (SURVEY §9.3), and
-// scatters into grad_stack with hardware fp32 atomics.
+// Forward (render_fwd2_k): one thread per output pixel, planes walked front-to-back in registers, taps fetched
+// straight through the vector L1 (texture-cache style; the 4x tap redundancy between neighbouring pixels is
+// absorbed by L1, vertical reuse by the tile height + XCD-aware tile order).
+// Backward: a single front-to-back sweep that uses the saved forward outputs,
+//   sum_{j>k} w_j q_j = (G.C + gA.A) - sum_{j<=k} w_j q_j   (SURVEY §9.3),
+// with the stack gradient produced either by the LDS-staged owner-computes gather kernel (render_bwd_tile_k, no
+// atomics) or, for geometry outside its preconditions, by the universal global-atomics kernel (render_bwd_k).
 #include "vl3d_common.h"
 
 namespace {
@@ -27,117 +29,106 @@ struct RenderArgs {
     float *g_stack;
     int D, T, Hs, Ws, H, W, row0, col0;
     float pc, sx, sy, ox, oy;
+    int fwd_variant;     // forward kernel selector (see launch<>)
     int ablate;          // measurement-only switches (bit0: skip LDS scatter, bit1: skip flush stores, bit2: skip tap loads)
     const float *plan;   // device scratch written by bwd_plan_k: [0] feasible flag, [16 + 9*d ..] inverse texel homographies
 };
 
-struct Taps {
-    int idx[4];     // texel index (y*Ws+x) of each tap, -1 if out of range
-    float w[4];     // bilinear weights
-    int x0, y0;     // top-left tap
-    float tx, ty;   // texel coordinates of the sample
-    bool covered;   // plane contributes at this pixel
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct Taps2 {
+    unsigned off[4];   // byte offsets of the 4 taps inside the frame (always valid addresses)
+    float w[4];        // bilinear weights, 0 for taps outside the plane
+    float cov;         // 1 if the plane covers this pixel else 0
+    float tx, ty;      // texel coordinates of the sample
 };
 
+__device__ __forceinline__ float fast_rcp(float z) {
+    float r = __builtin_amdgcn_rcpf(z);
+    float e = fmaf(-z, r, 1.0f);
+    return fmaf(r, e, r);
+}
+
+// (x, y) / z with one refined reciprocal and one residual correction per quotient: agrees with the IEEE quotients the
+// reference / oracle compute to within rounding of the last bit, at a third of the instruction count (packed math).
+__device__ __forceinline__ f2 fast_div2(f2 xy, float z) {
+    const float rz = fast_rcp(z);
+    f2 q = xy * rz;
+    const f2 e = xy - q * z;
+    return q + e * rz;
+}
+
 template <int COORD, int BORDER>
-__device__ __forceinline__ Taps make_taps(const float *__restrict__ h, float px, float py, int Hs, int Ws,
-                                          float sx, float sy, float ox, float oy) {
-    Taps t;
-    // p = H (x, y, 1), perspective divide (utils_mpi.py:171-172)
-    float X = h[0] * px + h[1] * py + h[2];
-    float Y = h[3] * px + h[4] * py + h[5];
-    float Z = h[6] * px + h[7] * py + h[8];
-    float xs = X / Z, ys = Y / Z;
-    float tx = texel_coord<COORD>(xs, (float)Ws / 2.0f, (float)(Ws - 1), sx, ox);
-    float ty = texel_coord<COORD>(ys, (float)Hs / 2.0f, (float)(Hs - 1), sy, oy);
-    bool cov;
-    if constexpr (BORDER == VL3D_BORDER_HARDCUT)
-        cov = (tx >= 0.0f) && (tx <= (float)(Ws - 1)) && (ty >= 0.0f) && (ty <= (float)(Hs - 1));
-    else
-        cov = (tx > -1.0f) && (tx < (float)Ws) && (ty > -1.0f) && (ty < (float)Hs);  // some tap in range
-    t.covered = cov;   // NaN/inf coordinates compare false -> uncovered
+__device__ __forceinline__ Taps2 make_taps2(const float *__restrict__ h, float px, float py, int Hs, int Ws,
+                                            float sx, float sy, float ox, float oy) {
+    Taps2 t;
+    const f2 XY = f2{h[0], h[3]} * px + (f2{h[1], h[4]} * py + f2{h[2], h[5]});
+    const float Z = h[6] * px + (h[7] * py + h[8]);
+    const f2 pxy = fast_div2(XY, Z);
+    const float tx = texel_coord<COORD>(pxy.x, (float)Ws / 2.0f, (float)(Ws - 1), sx, ox);
+    const float ty = texel_coord<COORD>(pxy.y, (float)Hs / 2.0f, (float)(Hs - 1), sy, oy);
     t.tx = tx; t.ty = ty;
-    if (!cov) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { t.idx[i] = -1; t.w[i] = 0.0f; }
-        t.x0 = t.y0 = 0;
-        return t;
+    const float wm1 = (float)(Ws - 1), hm1 = (float)(Hs - 1);
+    if constexpr (BORDER == VL3D_BORDER_HARDCUT) {
+        const bool cov = (tx >= 0.0f) && (tx <= wm1) && (ty >= 0.0f) && (ty <= hm1);
+        t.cov = cov ? 1.0f : 0.0f;
+        // covered => clamping is the identity; uncovered => any in-range address will do (its alpha is zeroed)
+        const float txc = __builtin_amdgcn_fmed3f(tx, 0.0f, wm1), tyc = __builtin_amdgcn_fmed3f(ty, 0.0f, hm1);
+        const float fx0 = floorf(txc), fy0 = floorf(tyc);
+        const float fx = txc - fx0, fy = tyc - fy0;
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        const int x1 = min(x0 + 1, Ws - 1), y1 = min(y0 + 1, Hs - 1);   // x0+1 == Ws only when fx == 0 (weight 0)
+        const float gx = 1.0f - fx, gy = 1.0f - fy;
+        t.w[0] = gx * gy; t.w[1] = fx * gy; t.w[2] = gx * fy; t.w[3] = fx * fy;
+        const unsigned r0 = (unsigned)(y0 * Ws), r1 = (unsigned)(y1 * Ws);
+        t.off[0] = (r0 + x0) * 16u; t.off[1] = (r0 + x1) * 16u; t.off[2] = (r1 + x0) * 16u; t.off[3] = (r1 + x1) * 16u;
+    } else {
+        const bool cov = (tx > -1.0f) && (tx < (float)Ws) && (ty > -1.0f) && (ty < (float)Hs);
+        t.cov = cov ? 1.0f : 0.0f;
+        const float txc = __builtin_amdgcn_fmed3f(tx, -1.0f, (float)Ws), tyc = __builtin_amdgcn_fmed3f(ty, -1.0f, (float)Hs);
+        const float fx0 = floorf(txc), fy0 = floorf(tyc);
+        const float fx = txc - fx0, fy = tyc - fy0;
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        // taps outside the plane contribute 0 (grid_sample zeros padding); their addresses are clamped into the plane
+        const float wx0 = (x0 >= 0 && x0 < Ws) ? 1.0f - fx : 0.0f, wx1 = (x0 + 1 < Ws) ? fx : 0.0f;
+        const float wy0 = (y0 >= 0 && y0 < Hs) ? 1.0f - fy : 0.0f, wy1 = (y0 + 1 < Hs) ? fy : 0.0f;
+        t.w[0] = wx0 * wy0; t.w[1] = wx1 * wy0; t.w[2] = wx0 * wy1; t.w[3] = wx1 * wy1;
+        const int x0c = min(max(x0, 0), Ws - 1), x1c = min(x0 + 1, Ws - 1);
+        const int y0c = min(max(y0, 0), Hs - 1), y1c = min(y0 + 1, Hs - 1);
+        const unsigned r0 = (unsigned)(y0c * Ws), r1 = (unsigned)(y1c * Ws);
+        t.off[0] = (r0 + x0c) * 16u; t.off[1] = (r0 + x1c) * 16u; t.off[2] = (r1 + x0c) * 16u; t.off[3] = (r1 + x1c) * 16u;
     }
-    float fx0 = floorf(tx), fy0 = floorf(ty);
-    float fx = tx - fx0, fy = ty - fy0;
-    int x0 = (int)fx0, y0 = (int)fy0;
-    t.x0 = x0; t.y0 = y0;
-    bool xl = x0 >= 0, xr = x0 + 1 < Ws, yt = y0 >= 0, yb = y0 + 1 < Hs;
-    int base = y0 * Ws + x0;
-    t.idx[0] = (xl && yt) ? base : -1;
-    t.idx[1] = (xr && yt) ? base + 1 : -1;
-    t.idx[2] = (xl && yb) ? base + Ws : -1;
-    t.idx[3] = (xr && yb) ? base + Ws + 1 : -1;
-    t.w[0] = (1.0f - fx) * (1.0f - fy);
-    t.w[1] = fx * (1.0f - fy);
-    t.w[2] = (1.0f - fx) * fy;
-    t.w[3] = fx * fy;
     return t;
 }
 
-__device__ __forceinline__ float4 ld_texel(const float *plane, int idx) {
-    return idx >= 0 ? *reinterpret_cast<const float4 *>(plane + (size_t)idx * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+__device__ __forceinline__ void load_taps2(const char *__restrict__ plane, const Taps2 &t, f4 v[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f4 *>(plane + t.off[i]);
 }
 
-// sample + activate one plane at one pixel -> c (rgb), a.  Keeps what backward needs.
+template <int RACT, int AACT>
+__device__ __forceinline__ f4 act4(f4 s) {
+    return f4{act_fwd<RACT>(s.x), act_fwd<RACT>(s.y), act_fwd<RACT>(s.z), act_fwd<AACT>(s.w)};
+}
+
+// bilinear blend + activation (vector types so the blend compiles to packed FMAs)
 template <int ORDER, int RACT, int AACT>
-__device__ __forceinline__ void shade(const float *plane, const Taps &t, float4 &out, float4 &pre, float4 tapv[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) tapv[i] = ld_texel(plane, t.idx[i]);
+__device__ __forceinline__ f4 shade2(const Taps2 &t, const f4 v[4], f4 *pre_out = nullptr) {
+    f4 s;
     if constexpr (ORDER == VL3D_ACT_POST) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v.x += t.w[i] * tapv[i].x; v.y += t.w[i] * tapv[i].y;
-            v.z += t.w[i] * tapv[i].z; v.w += t.w[i] * tapv[i].w;
-        }
-        pre = v;
-        out = make_float4(act_fwd<RACT>(v.x), act_fwd<RACT>(v.y), act_fwd<RACT>(v.z), act_fwd<AACT>(v.w));
+        s = v[0] * t.w[0] + (v[1] * t.w[1] + (v[2] * t.w[2] + v[3] * t.w[3]));
+        if (pre_out) *pre_out = s;
+        s = act4<RACT, AACT>(s);
     } else {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (t.idx[i] >= 0) {   // out-of-range taps contribute 0 (not act(0)): zeros padding of the ACTIVATED image
-                v.x += t.w[i] * act_fwd<RACT>(tapv[i].x); v.y += t.w[i] * act_fwd<RACT>(tapv[i].y);
-                v.z += t.w[i] * act_fwd<RACT>(tapv[i].z); v.w += t.w[i] * act_fwd<AACT>(tapv[i].w);
-            }
-        }
-        pre = v;
-        out = v;
+        s = act4<RACT, AACT>(v[0]) * t.w[0] + (act4<RACT, AACT>(v[1]) * t.w[1] + (act4<RACT, AACT>(v[2]) * t.w[2] + act4<RACT, AACT>(v[3]) * t.w[3]));
+        if (pre_out) *pre_out = s;
     }
+    s.w *= t.cov;    // uncovered: a = 0 (and c irrelevant) -> the plane drops out of the composite
+    return s;
 }
 
 constexpr int TILE_X = 64, TILE_Y = 4;
-
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT>
-__global__ __launch_bounds__(TILE_X *TILE_Y) void render_fwd_k(RenderArgs a) {
-    const int x = blockIdx.x * TILE_X + (threadIdx.x & (TILE_X - 1));
-    const int y = blockIdx.y * TILE_Y + (threadIdx.x / TILE_X);
-    const int t = blockIdx.z;
-    if (x >= a.W || y >= a.H) return;
-    const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
-    const size_t frame = (size_t)a.Hs * a.Ws * 4;
-    const float *plane = a.stack + (size_t)t * frame;
-    const size_t plane_stride = (size_t)a.T * frame;
-    float Tr = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, A = 0.f;
-    for (int d = 0; d < a.D; ++d, plane += plane_stride) {
-        Taps tp = make_taps<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-        if (!tp.covered) continue;
-        float4 o, pre, tv[4];
-        shade<ORDER, RACT, AACT>(plane, tp, o, pre, tv);
-        float w = o.w * Tr;             // blend weight a_k * T_k (utils_mpi.py:100-104)
-        cr += w * o.x; cg += w * o.y; cb += w * o.z; A += w;
-        Tr *= (1.0f - o.w);
-    }
-    const size_t pix = ((size_t)t * a.H + y) * a.W + x;
-    a.rgb[pix * 3 + 0] = cr; a.rgb[pix * 3 + 1] = cg; a.rgb[pix * 3 + 2] = cb;
-    a.alpha[pix] = A;
-}
 
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT>
 __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
@@ -149,54 +140,113 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
     const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
     const size_t frame = (size_t)a.Hs * a.Ws * 4;
     const size_t plane_stride = (size_t)a.T * frame;
-    const float *plane = a.stack + (size_t)t * frame;
-    float *gplane = a.g_stack + (size_t)t * frame;
+    const char *plane = reinterpret_cast<const char *>(a.stack + (size_t)t * frame);
+    char *gplane = reinterpret_cast<char *>(a.g_stack + (size_t)t * frame);
     const size_t pix = ((size_t)t * a.H + y) * a.W + x;
     const float Gr = a.g_rgb[pix * 3 + 0], Gg = a.g_rgb[pix * 3 + 1], Gb = a.g_rgb[pix * 3 + 2];
     const float gA = a.g_alpha ? a.g_alpha[pix] : 0.0f;
     // S = sum_k w_k q_k with q_k = G.c_k + gA  ==  G.C + gA*A from the saved forward outputs
     const float S = Gr * a.rgb[pix * 3 + 0] + Gg * a.rgb[pix * 3 + 1] + Gb * a.rgb[pix * 3 + 2] + gA * a.alpha[pix];
     float Tr = 1.0f, P = 0.0f;
-    for (int d = 0; d < a.D; ++d, plane += plane_stride, gplane += plane_stride) {
-        Taps tp = make_taps<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-        if (!tp.covered) continue;
-        float4 o, pre, tv[4];
-        shade<ORDER, RACT, AACT>(plane, tp, o, pre, tv);
+    for (int d = 0; d < a.D; ++d, plane += plane_stride * 4, gplane += plane_stride * 4) {
+        const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+        if (tp.cov == 0.0f) continue;
+        f4 tv[4], pre;
+        load_taps2(plane, tp, tv);
+        const f4 o = shade2<ORDER, RACT, AACT>(tp, tv, &pre);
         const float q = Gr * o.x + Gg * o.y + Gb * o.z + gA;
         const float w = o.w * Tr;
         P += w * q;
         const float om = 1.0f - o.w;
         // dL/da_k = T_k q_k - (sum_{j>k} w_j q_j)/(1-a_k); everything behind a fully opaque plane has zero weight
-        const float behind = (om > 1e-12f) ? (S - P) / om : 0.0f;
-        float4 go = make_float4(w * Gr, w * Gg, w * Gb, Tr * q - behind);   // grad wrt activated (c, a)
+        const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;
+        f4 go = f4{w * Gr, w * Gg, w * Gb, Tr * q - behind};   // grad wrt activated (c, a)
         Tr *= om;
-        if constexpr (ORDER == VL3D_ACT_POST) {
-            float4 gv = make_float4(go.x * act_bwd<RACT>(pre.x, o.x), go.y * act_bwd<RACT>(pre.y, o.y),
-                                    go.z * act_bwd<RACT>(pre.z, o.z), go.w * act_bwd<AACT>(pre.w, o.w));
+        if constexpr (ORDER == VL3D_ACT_POST)
+            go = f4{go.x * act_bwd<RACT>(pre.x, o.x), go.y * act_bwd<RACT>(pre.y, o.y), go.z * act_bwd<RACT>(pre.z, o.z),
+                    go.w * act_bwd<AACT>(pre.w, o.w)};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (tp.idx[i] >= 0) {
-                    float *g = gplane + (size_t)tp.idx[i] * 4;
-                    atomicAdd(g + 0, tp.w[i] * gv.x); atomicAdd(g + 1, tp.w[i] * gv.y);
-                    atomicAdd(g + 2, tp.w[i] * gv.z); atomicAdd(g + 3, tp.w[i] * gv.w);
+        for (int i = 0; i < 4; ++i) {
+            if (tp.w[i] != 0.0f) {
+                f4 c = go * tp.w[i];
+                if constexpr (ORDER == VL3D_ACT_PRE) {
+                    const f4 sv = tv[i];
+                    c = f4{c.x * act_bwd<RACT>(sv.x, act_fwd<RACT>(sv.x)), c.y * act_bwd<RACT>(sv.y, act_fwd<RACT>(sv.y)),
+                           c.z * act_bwd<RACT>(sv.z, act_fwd<RACT>(sv.z)), c.w * act_bwd<AACT>(sv.w, act_fwd<AACT>(sv.w))};
                 }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (tp.idx[i] >= 0) {
-                    float *g = gplane + (size_t)tp.idx[i] * 4;
-                    const float4 s = tv[i];
-                    atomicAdd(g + 0, tp.w[i] * go.x * act_bwd<RACT>(s.x, act_fwd<RACT>(s.x)));
-                    atomicAdd(g + 1, tp.w[i] * go.y * act_bwd<RACT>(s.y, act_fwd<RACT>(s.y)));
-                    atomicAdd(g + 2, tp.w[i] * go.z * act_bwd<RACT>(s.z, act_fwd<RACT>(s.z)));
-                    atomicAdd(g + 3, tp.w[i] * go.w * act_bwd<AACT>(s.w, act_fwd<AACT>(s.w)));
-                }
+                float *g = reinterpret_cast<float *>(gplane + tp.off[i]);
+                atomicAdd(g + 0, c.x); atomicAdd(g + 1, c.y); atomicAdd(g + 2, c.z); atomicAdd(g + 3, c.w);
             }
         }
     }
 }
 
+// =====================================================================================================
+// Forward, variant 2: same arithmetic as render_fwd_k with a leaner instruction stream
+//   - one Newton-refined reciprocal instead of two IEEE divisions for the perspective divide,
+//   - branch-free taps: addresses clamped into the plane, invalid taps get weight 0, uncovered planes get a = 0,
+//     so the plane loop has uniform control flow and the taps of plane d+1 are issued before plane d is shaded,
+//   - 32-bit byte offsets against a scalar plane base (global_load_dwordx4 v, s[base:base+1]),
+//   - taller tiles (TY rows: vertical tap reuse inside the workgroup) on a 1-D grid with an XCD-aware
+//     bijective remap so that vertically adjacent tiles share one XCD's L2.
+// bijective XCD remap (cdna guide T1): workgroup b runs on XCD b % 8; give every XCD a contiguous chunk of tiles
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool SWZ>
+__global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles_x, int tiles_y) {
+    int b = blockIdx.x;
+    if constexpr (SWZ) b = xcd_remap(b, gridDim.x);
+    const int tile_x = b % tiles_x, rest = b / tiles_x;
+    const int tile_y = rest % tiles_y, t = rest / tiles_y;
+    const int x = tile_x * 64 + (threadIdx.x & 63);
+    const int y = tile_y * TY + (threadIdx.x >> 6);
+    if (x >= a.W || y >= a.H) return;
+    const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
+    const size_t frame_b = (size_t)a.Hs * a.Ws * 16;
+    const size_t plane_stride_b = (size_t)a.T * frame_b;
+    const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * frame_b;
+    float Tr = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, A = 0.f;
+    // two register sets (A/B) so the taps of plane d+1 are in flight while plane d is shaded, without register copies
+    Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy), tB = tA;
+    f4 vA[4], vB[4];
+    load_taps2(plane, tA, vA);
+#define VL3D_COMPOSITE(T_, V_)                                        \
+    {                                                                 \
+        const f4 o = shade2<ORDER, RACT, AACT>(T_, V_);               \
+        const float w = o.w * Tr;                                     \
+        cr += w * o.x; cg += w * o.y; cb += w * o.z; A += w;          \
+        Tr *= (1.0f - o.w);                                           \
+    }
+    for (int d = 0;;) {
+        if (d + 1 < a.D) {
+            tB = make_taps2<COORD, BORDER>(a.homos + 9 * (d + 1), px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            load_taps2(plane + plane_stride_b, tB, vB);
+        }
+        VL3D_COMPOSITE(tA, vA)
+        if (++d >= a.D) break;
+        if (d + 1 < a.D) {
+            tA = make_taps2<COORD, BORDER>(a.homos + 9 * (d + 1), px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            load_taps2(plane + 2 * plane_stride_b, tA, vA);
+        }
+        VL3D_COMPOSITE(tB, vB)
+        if (++d >= a.D) break;
+        plane += 2 * plane_stride_b;
+    }
+#undef VL3D_COMPOSITE
+    const size_t pix = ((size_t)t * a.H + y) * a.W + x;
+    a.rgb[pix * 3 + 0] = cr; a.rgb[pix * 3 + 1] = cg; a.rgb[pix * 3 + 2] = cb;
+    a.alpha[pix] = A;
+}
+
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool SWZ>
+void launch_fwd2(const RenderArgs &a, hipStream_t s) {
+    const int tiles_x = (a.W + 63) / 64, tiles_y = (a.H + TY - 1) / TY;
+    hipLaunchKernelGGL((render_fwd2_k<COORD, BORDER, ORDER, RACT, AACT, TY, SWZ>), dim3((unsigned)(tiles_x * tiles_y * a.T)),
+                       dim3(64 * TY), 0, s, a, tiles_x, tiles_y);
+}
 
 // =====================================================================================================
 // Backward, variant "tile": LDS-staged owner-computes accumulation (no global atomics, no memset).
@@ -216,7 +266,8 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
 // (Z>0 over the frame, magnification < 1.4x, window fits); if they fail, these kernels exit and the
 // universal atomics kernel above runs instead -- no host synchronisation either way.
 constexpr int RW = 64;        // region width in pixels = one wave
-constexpr int PLAN_HDR = 16;  // floats before the per-plane matrices
+constexpr int PLAN_HDR = 16;  // floats before the per-plane records
+constexpr int PLAN_REC = 12;  // per plane: 9 floats inverse texel homography, 2 floats gather radius (x,y), 1 pad
 
 // texel-space homography  Ht = A_tex * H  (double), and its inverse
 template <int COORD>
@@ -247,7 +298,8 @@ __global__ void bwd_plan_k(RenderArgs a, int rows, float *plan) {
         I[3] = (M[5] * M[6] - M[3] * M[8]) / det; I[4] = (M[0] * M[8] - M[2] * M[6]) / det; I[5] = (M[2] * M[3] - M[0] * M[5]) / det;
         I[6] = (M[3] * M[7] - M[4] * M[6]) / det; I[7] = (M[1] * M[6] - M[0] * M[7]) / det; I[8] = (M[0] * M[4] - M[1] * M[3]) / det;
         // normalise so the pixel-space w of the frame centre is ~1 (keeps fp32 well scaled)
-        for (int i = 0; i < 9; ++i) plan[PLAN_HDR + 9 * d + i] = (float)I[i];
+        for (int i = 0; i < 9; ++i) plan[PLAN_HDR + PLAN_REC * d + i] = (float)I[i];
+        double rxm = 0.0, rym = 0.0;
         // geometric preconditions at a 3x3 grid of points of the (halo-extended) frame
         for (int gy = 0; gy < 3 && ok; ++gy)
             for (int gx = 0; gx < 3 && ok; ++gx) {
@@ -262,23 +314,29 @@ __global__ void bwd_plan_k(RenderArgs a, int rows, float *plan) {
                 // |J^-1|_inf < 1.4  (contributions to a texel stay within the 1-pixel halo of its owner pixel)
                 const double i_r0 = (fabs(j11) + fabs(j01)) / fabs(dj), i_r1 = (fabs(j10) + fabs(j00)) / fabs(dj);
                 if (!(i_r0 < 1.4 && i_r1 < 1.4)) ok = false;
+                rxm = fmax(rxm, i_r0); rym = fmax(rym, i_r1);
                 // keep the owned footprint of a tile a small multiple of the workgroup (pure efficiency guard)
                 if (!(fabs(j00) + fabs(j01) < 4.0 && fabs(j10) + fabs(j11) < 4.0)) ok = false;
             }
+        // gather radius per axis: a pixel p contributes to texel tau only if |p - H^-1 tau| < |J^-1|_inf-row (2% safety)
+        plan[PLAN_HDR + PLAN_REC * d + 9] = (float)fmin(1.02 * rxm + 1e-3, 1.45);
+        plan[PLAN_HDR + PLAN_REC * d + 10] = (float)fmin(1.02 * rym + 1e-3, 1.45);
         if (!ok) atomicAnd(&ok_all, 0);
     }
     __syncthreads();
     if (threadIdx.x == 0) reinterpret_cast<int *>(plan)[0] = ok_all;
 }
 
+__device__ __forceinline__ float fast_rcp(float z);
 // owner pixel (float, before rounding) of texel (tx,ty) on plane d, relative to this window's pixel origin
 __device__ __forceinline__ void owner_pixel(const float *__restrict__ hi, float tx, float ty, float pc, int col0, int row0,
                                             float &px, float &py) {
     const float X = hi[0] * tx + hi[1] * ty + hi[2];
     const float Y = hi[3] * tx + hi[4] * ty + hi[5];
     const float Z = hi[6] * tx + hi[7] * ty + hi[8];
-    px = X / Z - pc - (float)col0;
-    py = Y / Z - pc - (float)row0;
+    const float rz = fast_rcp(Z);
+    px = X * rz - pc - (float)col0;
+    py = Y * rz - pc - (float)row0;
 }
 
 __global__ __launch_bounds__(256) void bwd_zero_unowned_k(RenderArgs a) {
@@ -288,7 +346,7 @@ __global__ __launch_bounds__(256) void bwd_zero_unowned_k(RenderArgs a) {
     const int d = blockIdx.z;
     if (x >= a.Ws || y >= a.Hs) return;
     float px, py;
-    owner_pixel(a.plan + PLAN_HDR + 9 * d, (float)x, (float)y, a.pc, a.col0, a.row0, px, py);
+    owner_pixel(a.plan + PLAN_HDR + PLAN_REC * d, (float)x, (float)y, a.pc, a.col0, a.row0, px, py);
     const bool safe = (px > 0.5f) && (px < (float)a.W - 1.5f) && (py > 0.5f) && (py < (float)a.H - 1.5f);
     if (safe) return;      // owned (and written) by a tile with certainty
     const size_t frame = (size_t)a.Hs * a.Ws;
@@ -302,7 +360,7 @@ __global__ __launch_bounds__(256) void bwd_fill_zero_if_infeasible_k(float4 *g, 
 }
 
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS>
-__global__ __launch_bounds__(RW *ROWS) void render_bwd_tile_k(RenderArgs a) {
+__global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
     constexpr int NT = RW * ROWS;
     // per-plane staging of the region's pixels, double buffered so one barrier per plane suffices
@@ -344,32 +402,32 @@ __global__ __launch_bounds__(RW *ROWS) void render_bwd_tile_k(RenderArgs a) {
             s_c[buf][tid] = texel_coord<COORD>(X / Z, (float)a.Ws / 2.0f, (float)(a.Ws - 1), a.sx, a.ox);
             s_c[buf][4 + tid] = texel_coord<COORD>(Y / Z, (float)a.Hs / 2.0f, (float)(a.Hs - 1), a.sy, a.oy);
         }
-        // (2) sample this pixel on plane d, composite backward, stage (tx,ty,g) in LDS
+        // (2) sample this pixel on plane d, composite backward, stage (tx,ty,g) in LDS   (branch-free taps)
         float2 tc = make_float2(-1e30f, -1e30f);
         float4 gval = make_float4(0.f, 0.f, 0.f, 0.f);
         if (inimg) {
-            Taps tp = make_taps<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-            if (tp.covered) {
-                float4 o, pre, tv[4];
-                const float *src = plane;
-                if (a.ablate & 4) {   // measurement only: all taps from a 64 KiB cache-resident window
-                    src = a.stack;
+            Taps2 tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            const char *src = reinterpret_cast<const char *>(plane);
+            if (a.ablate & 4) {   // measurement only: all taps from a 64 KiB cache-resident window
+                src = reinterpret_cast<const char *>(a.stack);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) tp.idx[i] = tp.idx[i] >= 0 ? (tp.idx[i] & 4095) : -1;
-                }
-                shade<ORDER, RACT, AACT>(src, tp, o, pre, tv);
-                const float q = Gr * o.x + Gg * o.y + Gb * o.z + gA;
-                const float w = o.w * Tr;
-                P += w * q;
-                const float om = 1.0f - o.w;
-                const float behind = (om > 1e-12f) ? (S - P) / om : 0.0f;
-                gval = make_float4(w * Gr, w * Gg, w * Gb, Tr * q - behind);     // grad wrt activated (c, a)
-                Tr *= om;
-                if constexpr (ORDER == VL3D_ACT_POST)
-                    gval = make_float4(gval.x * act_bwd<RACT>(pre.x, o.x), gval.y * act_bwd<RACT>(pre.y, o.y),
-                                       gval.z * act_bwd<RACT>(pre.z, o.z), gval.w * act_bwd<AACT>(pre.w, o.w));
-                tc = make_float2(tp.tx, tp.ty);
+                for (int i = 0; i < 4; ++i) tp.off[i] &= 0xffffu;
             }
+            f4 tv[4], pre;
+            load_taps2(src, tp, tv);
+            const f4 o = shade2<ORDER, RACT, AACT>(tp, tv, &pre);        // o.w already 0 when the plane does not cover the pixel
+            const float q = Gr * o.x + Gg * o.y + Gb * o.z + gA;
+            const float w = o.w * Tr;
+            P += w * q;
+            const float om = 1.0f - o.w;
+            const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;
+            gval = make_float4(w * Gr, w * Gg, w * Gb, Tr * q - behind);     // grad wrt activated (c, a)
+            Tr *= om;
+            if constexpr (ORDER == VL3D_ACT_POST)
+                gval = make_float4(gval.x * act_bwd<RACT>(pre.x, o.x), gval.y * act_bwd<RACT>(pre.y, o.y),
+                                   gval.z * act_bwd<RACT>(pre.z, o.z), gval.w * act_bwd<AACT>(pre.w, o.w));
+            if (tp.cov > 0.0f) tc = make_float2(tp.tx, tp.ty);
+            else gval = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         s_t[buf][tid] = tc;
         s_g[buf][tid] = gval;
@@ -384,7 +442,8 @@ __global__ __launch_bounds__(RW *ROWS) void render_bwd_tile_k(RenderArgs a) {
         const int Y1 = min(a.Hs - 1, (int)floorf(fminf(mxy + 0.01f, (float)a.Hs)) + 1);
         const int ww = max(0, X1 - X0 + 1), wh = max(0, Y1 - Y0 + 1);
         const float inv_ww = 1.0f / (float)max(ww, 1);
-        const float *hi = a.plan + PLAN_HDR + 9 * d;
+        const float *hi = a.plan + PLAN_HDR + PLAN_REC * d;
+        const float grx = hi[9], gry = hi[10];
         if (a.ablate & 1) continue;
         for (int idx = tid; idx < ww * wh; idx += NT) {
             const int wy = (int)(((float)idx + 0.5f) * inv_ww), wx = idx - wy * ww;
@@ -395,20 +454,18 @@ __global__ __launch_bounds__(RW *ROWS) void render_bwd_tile_k(RenderArgs a) {
             const float rx = fminf(fmaxf(rintf(qx), 0.0f), (float)(a.W - 1));
             const float ry = fminf(fmaxf(rintf(qy), 0.0f), (float)(a.H - 1));
             if (!(rx >= (float)ix0 && rx <= (float)ix1 && ry >= (float)iy0 && ry <= (float)iy1)) continue;
-            const int lc = ((int)ry - ry0) * RW + ((int)rx - rx0);
+            // candidate pixels: |p - q| < gather radius per axis (2..3 per axis), clipped to the 3x3 around the owner
+            const int cx0 = max((int)rx - 1, (int)ceilf(qx - grx)), cx1 = min((int)rx + 1, (int)floorf(qx + grx));
+            const int cy0 = max((int)ry - 1, (int)ceilf(qy - gry)), cy1 = min((int)ry + 1, (int)floorf(qy + gry));
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int li = lc + dy * RW + dx;
+            for (int cy = cy0; cy <= cy1; ++cy)
+                for (int cx = cx0; cx <= cx1; ++cx) {
+                    const int li = (cy - ry0) * RW + (cx - rx0);
                     const float2 c = s_t[buf][li];
-                    const float wxx = 1.0f - fabsf(c.x - tauX), wyy = 1.0f - fabsf(c.y - tauY);
-                    if (wxx > 0.0f && wyy > 0.0f) {
-                        const float4 g = s_g[buf][li];
-                        const float w = wxx * wyy;
-                        acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w;
-                    }
+                    const float wxx = fmaxf(1.0f - fabsf(c.x - tauX), 0.0f), wyy = fmaxf(1.0f - fabsf(c.y - tauY), 0.0f);
+                    const float4 g = s_g[buf][li];
+                    const float w = wxx * wyy;
+                    acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w;
                 }
             const size_t toff = ((size_t)(Y0 + wy) * a.Ws + (X0 + wx)) * 4;
             if constexpr (ORDER == VL3D_ACT_PRE) {   // d act(s_tau)/d s_tau factors out of the tap sum
@@ -451,7 +508,15 @@ void launch(const RenderArgs &a, hipStream_t s) {
         }
         hipLaunchKernelGGL((render_bwd_k<COORD, BORDER, ORDER, RACT, AACT>), grid, block, 0, s, a);
     } else {
-        hipLaunchKernelGGL((render_fwd_k<COORD, BORDER, ORDER, RACT, AACT>), grid, block, 0, s, a);
+        // forward variant (desc->variant bits 8..11): 0 default; measurement variants for the shipped
+        // sigmoid/sigmoid activation only: 2 TY=4, 3 TY=8, 4 TY=16 (all XCD-remapped), 5 TY=8 without remap
+        const int fv = a.fwd_variant;
+        if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID) {
+            if (fv == 2) return launch_fwd2<COORD, BORDER, ORDER, RACT, AACT, 4, true>(a, s);
+            if (fv == 4) return launch_fwd2<COORD, BORDER, ORDER, RACT, AACT, 16, true>(a, s);
+            if (fv == 5) return launch_fwd2<COORD, BORDER, ORDER, RACT, AACT, 8, false>(a, s);
+        }
+        launch_fwd2<COORD, BORDER, ORDER, RACT, AACT, 8, true>(a, s);
     }
 }
 
@@ -521,6 +586,8 @@ extern "C" int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, 
     VL3D_REQUIRE(stack && homos && rgb && alpha, "null pointer passed to vl3d_render_fwd");
     RenderArgs a = make_args(desc);
     a.stack = (const float *)stack; a.homos = homos; a.rgb = rgb; a.alpha = alpha;
+    a.fwd_variant = (desc->variant >> 8) & 0xf;
+    VL3D_REQUIRE((int64_t)desc->Hs * desc->Ws * 16 < (1ll << 32), "frame too large for 32-bit byte offsets");
     rc = dispatch<false>(desc, a, (hipStream_t)stream);
     if (rc != VL3D_OK) return rc;
     VL3D_CHECK_LAUNCH();
@@ -529,7 +596,7 @@ extern "C" int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, 
 
 extern "C" int64_t vl3d_render_bwd_scratch_bytes(const vl3d_render_desc *desc) {
     if (!desc || desc->D <= 0) return 0;
-    return (int64_t)(PLAN_HDR + 9 * (int64_t)desc->D) * sizeof(float);
+    return (int64_t)(PLAN_HDR + PLAN_REC * (int64_t)desc->D) * sizeof(float);
 }
 
 extern "C" int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, const float *homos,
