@@ -328,6 +328,13 @@ __global__ void bwd_plan_k(RenderArgs a, int rows, float *plan) {
 }
 
 __device__ __forceinline__ float fast_rcp(float z);
+// bilinear tent weight max(0, 1 - |d|) in ONE VALU instruction (|.| and clamp are free VOP3 modifiers; hipcc emits
+// and/cmp/cndmask chains for the C form)
+__device__ __forceinline__ float tent_weight(float d) {
+    float w;
+    asm("v_sub_f32_e64 %0, 1.0, |%1| clamp" : "=v"(w) : "v"(d));
+    return w;
+}
 // owner pixel (float, before rounding) of texel (tx,ty) on plane d, relative to this window's pixel origin
 __device__ __forceinline__ void owner_pixel(const float *__restrict__ hi, float tx, float ty, float pc, int col0, int row0,
                                             float &px, float &py) {
@@ -443,7 +450,6 @@ __global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
         const int ww = max(0, X1 - X0 + 1), wh = max(0, Y1 - Y0 + 1);
         const float inv_ww = 1.0f / (float)max(ww, 1);
         const float *hi = a.plan + PLAN_HDR + PLAN_REC * d;
-        const float grx = hi[9], gry = hi[10];
         if (a.ablate & 1) continue;
         for (int idx = tid; idx < ww * wh; idx += NT) {
             const int wy = (int)(((float)idx + 0.5f) * inv_ww), wx = idx - wy * ww;
@@ -454,26 +460,28 @@ __global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
             const float rx = fminf(fmaxf(rintf(qx), 0.0f), (float)(a.W - 1));
             const float ry = fminf(fmaxf(rintf(qy), 0.0f), (float)(a.H - 1));
             if (!(rx >= (float)ix0 && rx <= (float)ix1 && ry >= (float)iy0 && ry <= (float)iy1)) continue;
-            // candidate pixels: |p - q| < gather radius per axis (2..3 per axis), clipped to the 3x3 around the owner
-            const int cx0 = max((int)rx - 1, (int)ceilf(qx - grx)), cx1 = min((int)rx + 1, (int)floorf(qx + grx));
-            const int cy0 = max((int)ry - 1, (int)ceilf(qy - gry)), cy1 = min((int)ry + 1, (int)floorf(qy + gry));
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int cy = cy0; cy <= cy1; ++cy)
-                for (int cx = cx0; cx <= cx1; ++cx) {
-                    const int li = (cy - ry0) * RW + (cx - rx0);
-                    const float2 c = s_t[buf][li];
-                    const float wxx = fmaxf(1.0f - fabsf(c.x - tauX), 0.0f), wyy = fmaxf(1.0f - fabsf(c.y - tauY), 0.0f);
-                    const float4 g = s_g[buf][li];
-                    const float w = wxx * wyy;
-                    acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w;
+            // taps come from the 3x3 pixels around the owner (|J^-1|_inf < 1.4): fixed trip count, constant LDS offsets,
+            // weights clamp to 0 for non-contributing pixels (bitwise the forward's (1-fx)(1-fy) products otherwise)
+            const int lc = ((int)ry - ry0) * RW + ((int)rx - rx0);
+            const f2 tau = f2{tauX, tauY};
+            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int li = lc + dy * RW + dx;
+                    const f2 c = *reinterpret_cast<const f2 *>(&s_t[buf][li]);
+                    f2 wv = 1.0f - __builtin_elementwise_abs(c - tau);
+                    wv = __builtin_elementwise_max(wv, f2{0.f, 0.f});
+                    acc += *reinterpret_cast<const f4 *>(&s_g[buf][li]) * (wv.x * wv.y);
                 }
             const size_t toff = ((size_t)(Y0 + wy) * a.Ws + (X0 + wx)) * 4;
             if constexpr (ORDER == VL3D_ACT_PRE) {   // d act(s_tau)/d s_tau factors out of the tap sum
-                const float4 sv = *reinterpret_cast<const float4 *>(plane + toff);
-                acc.x *= act_bwd<RACT>(sv.x, act_fwd<RACT>(sv.x)); acc.y *= act_bwd<RACT>(sv.y, act_fwd<RACT>(sv.y));
-                acc.z *= act_bwd<RACT>(sv.z, act_fwd<RACT>(sv.z)); acc.w *= act_bwd<AACT>(sv.w, act_fwd<AACT>(sv.w));
+                const f4 sv = *reinterpret_cast<const f4 *>(plane + toff);
+                acc = f4{acc.x * act_bwd<RACT>(sv.x, act_fwd<RACT>(sv.x)), acc.y * act_bwd<RACT>(sv.y, act_fwd<RACT>(sv.y)),
+                         acc.z * act_bwd<RACT>(sv.z, act_fwd<RACT>(sv.z)), acc.w * act_bwd<AACT>(sv.w, act_fwd<AACT>(sv.w))};
             }
-            if (!(a.ablate & 2)) *reinterpret_cast<float4 *>(gplane + toff) = acc;
+            if (!(a.ablate & 2)) *reinterpret_cast<f4 *>(gplane + toff) = acc;
         }
     }
 }
