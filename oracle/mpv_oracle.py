@@ -1,0 +1,85 @@
+"""CPU oracle for MPMeshVid.forward (planar geometry).  TEST INFRASTRUCTURE ONLY.
+
+Restates /root/reference/MPV.py:477-556 (forward) on top of the pinned operator oracles (mpi_oracle / vid_oracle).
+MPV.py itself cannot be imported here (pytorch3d, cv2, imageio, torchvision are absent) so this module is
+"parity unpinned" at the pytorch3d boundary: sampling positions are pinned through compute_homography (== ray-plane
+intersection), compositing through overcompose, the loss through G8; the +0.5 pixel centre and hard-cut borders are
+parameters.
+"""
+import numpy as np
+import torch
+
+from . import mpi_oracle as MO
+from . import vid_oracle as VO
+
+
+def mpv_forward(stack, args, H, W, ref_extrin, ref_intrin, near, far, h, w, tar_extrins, tar_intrins, ts=None, res=None,
+                losscfg=None, training=True, pixel_center=0.5):
+    """stack (D,T,mpi_h,mpi_w,4).  Returns (rgb [T',3,h,w] or None, extra dict) like MPV.py:553-556."""
+    D, T, mpi_h, mpi_w, _ = stack.shape
+    ref_extrin = torch.as_tensor(ref_extrin)
+    ref_intrin = torch.as_tensor(ref_intrin).float()
+    planedepth = MO.make_depths(D, near, far).flip(0)                                   # MPV.py:51
+    H_start, W_start = (mpi_h - H) // 2, (mpi_w - W) // 2                               # MPV.py:55
+    ref_intrin_mpi = MO.get_new_intrin(ref_intrin, -H_start, -W_start)
+    extrins = tar_extrins @ ref_extrin[None].inverse().to(tar_extrins.dtype)            # MPV.py:478
+    if ts is None:
+        ts = torch.arange(T)
+    eye = torch.eye(4, dtype=extrins.dtype)[None]
+    normal = torch.tensor([0., 0., 1.], dtype=extrins.dtype).expand(1, D, 3)
+    homos = MO.compute_homography(eye, ref_intrin_mpi[None].to(extrins.dtype), extrins, tar_intrins, normal,
+                                  planedepth[None].to(extrins.dtype))[0].float()
+    spec = MO.RenderSpec(pixel_center=pixel_center, coord_mode="affine", border="hardcut", act_order="post",
+                         rgb_act=args.rgb_activate, alpha_act=args.alpha_activate)
+    rgb, alpha, bw, mpi = MO.render_planes(stack[:, ts], homos, h, w, spec, return_layers=True)
+    if len(args.bg_color) > 0:                                                          # MPV.py:455-461
+        r, g, b = map(float, args.bg_color.split('#'))
+        bg = torch.tensor([r, g, b]).type_as(rgb)
+        rgb = rgb * alpha[..., None] + bg[None, None, None] * (1 - alpha[..., None])
+    rgb = rgb.permute(0, 3, 1, 2)
+    if not training:
+        return rgb, {}
+    extra = {}
+    rgb_pad = rgb
+    if args.mpv_isloop:
+        rgb_pad = torch.cat([rgb, rgb[:args.swd_patcht_size - 1]], 0)                   # MPV.py:490-492
+    cfg = {k: (v[0].item() if torch.is_tensor(v) else v[0]) for k, v in losscfg.items()}
+    loss_name = cfg.pop("loss_name")
+    loss_gain = cfg.pop("loss_gain", 1.0)
+    if args.scale_invariant:
+        res_avg = res[0].mean(dim=0)
+        rgb_avg = rgb.detach().mean(dim=0)
+        scale = torch.exp(torch.log((res_avg + 0.01) / (rgb_avg + 0.01)).mean())
+        rgb_pad = rgb_pad * ((scale + 3) / 4)
+    x = rgb_pad.permute(1, 0, 2, 3)[None]
+    y = res.permute(0, 2, 1, 3, 4)
+    if loss_name in ("gpnn", "gpnn_lm"):
+        cfg.pop("dist_fn", None)
+        if loss_name == "gpnn":
+            cfg = {"patch_size": 7, "patcht_size": 7, "stride": 1, "stridet": 1, "rou": 0, "scaling": 0.2, **cfg}
+        main, _, _ = VO.gpnn_loss(x, y, **cfg)
+    elif loss_name == "mse":
+        frm = min(x.shape[2], y.shape[2])
+        main = ((x[:, :, :frm] - y[:, :, :frm]) ** 2).mean()
+    else:
+        main = ((x.mean(dim=2) - y.mean(dim=2)) ** 2).mean()
+    extra["swd"] = main.reshape(1, -1) * loss_gain
+    if args.sparsity_loss_weight > 0:
+        a = mpi[..., -1]
+        sp = a.norm(dim=-1, p=1) / a.norm(dim=-1, p=2).clamp_min(1e-4)
+        extra["sparsity"] = (sp.mean() / np.sqrt(D) * loss_gain).reshape(1, -1)
+    if args.rgb_smooth_loss_weight > 0:
+        sm = mpi[..., :-1]
+        denorm = sm.shape[-2] / D
+        sx = (sm[:, :, :-1] - sm[:, :, 1:]).abs().mean()
+        sy = (sm[:, :-1] - sm[:, 1:]).abs().mean()
+        extra["rgb_smooth"] = ((sx + sy) * (loss_gain * denorm)).reshape(1, -1)
+    if args.a_smooth_loss_weight > 0:
+        sm = mpi[..., -1]
+        denorm = sm.shape[-1] / D
+        sx = (sm[:, :, :-1] - sm[:, :, 1:]).abs().mean()
+        sy = (sm[:, :-1] - sm[:, 1:]).abs().mean()
+        extra["a_smooth"] = ((sx + sy) * (loss_gain * denorm)).reshape(1, -1)
+    if args.density_loss_weight > 0:
+        extra["density"] = (alpha - 1).abs().mean().reshape(1, -1)
+    return None, extra

@@ -1,0 +1,116 @@
+"""MPMeshVid (module-level drop-in, MPV.py:26-556) on the HIP kernels vs the CPU oracle of MPV.forward."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mpv_oracle
+from videoloop3d_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    import __graft_entry__ as g
+    g.build()
+    return torch.device("cuda:0")
+
+
+def make_args(**kw):
+    a = dict(mpv_frm_num=6, mpv_isloop=True, mpi_h_scale=1.1, mpi_w_scale=1.1, mpi_d=6, atlas_grid_h=2, init_std=0.5,
+             rgb_mlp_type="direct", rgb_activate="sigmoid", alpha_activate="sigmoid", bg_color="", scale_invariant=True,
+             add_uv_noise=False, fp16=False, normalize_verts=False, atlas_cnl=4,
+             swd_patch_size=3, swd_patcht_size=3, swd_stride=2, swd_stridet=1,
+             sparsity_loss_weight=0.0, rgb_smooth_loss_weight=0.2, a_smooth_loss_weight=0.2, density_loss_weight=0.0,
+             d_smooth_loss_weight=0.0)
+    a.update(kw)
+    return types.SimpleNamespace(**a)
+
+
+def scene(H=44, W=60):
+    K = np.array([[0.9 * W, 0, W / 2], [0, 0.9 * W, H / 2], [0, 0, 1]], np.float64)
+    ref_extrin = np.eye(4)
+    ref_extrin[:3, 3] = [0.01, -0.02, 0.03]
+    a = np.radians(1.0)
+    tar = np.eye(4)
+    tar[:3, :3] = [[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]
+    tar[:3, 3] = [0.04, 0.015, 0.0]
+    return K, ref_extrin, tar
+
+
+def collate(cfg):
+    return {k: ([v] if isinstance(v, str) else torch.tensor([v])) for k, v in cfg.items()}
+
+
+@pytest.mark.parametrize("which", ["other", "ref"])
+@pytest.mark.parametrize("bg", ["", "0.2#0.4#0.6"])
+def test_forward_train_matches_oracle(dev, which, bg):
+    from videoloop3d_amd.MPV import MPMeshVid
+    H, W = 44, 60
+    K, ref_extrin, tar = scene(H, W)
+    args = make_args(bg_color=bg, sparsity_loss_weight=0.1 if bg else 0.0, density_loss_weight=0.05 if bg else 0.0)
+    torch.manual_seed(0)
+    model = MPMeshVid(args, H, W, ref_extrin, K, 1.0, 100.0).to(dev)
+    with torch.no_grad():
+        model.stack.copy_(synth.make_plane_stack(*model.stack.shape[:4], seed=5) * 0.7)
+    stack_cpu = model.stack.detach().cpu().clone().requires_grad_(True)
+    h, w = 33, 47   # a training crop: shifted principal point (train_3dvid.py:60-66)
+    Kc = K.copy(); Kc[0, 2] -= 6; Kc[1, 2] -= 5
+    tar_e = torch.tensor(tar)[None]
+    tar_k = torch.tensor(Kc)[None]
+    res = synth.hash_uniform((1, 9, 3, h, w), seed=8)
+    if which == "ref":
+        cfg = dict(loss_name="gpnn_lm", loss_gain=3.5, macro_block=21, patch_size=11, stride=4, patcht_size=3, stridet=1,
+                   alpha=0.5, dist_fn="mse", rou="-2", scaling=0.1)
+    else:
+        cfg = dict(loss_name="gpnn_lm", loss_gain=1.0, macro_block=21, patch_size=3, stride=2, patcht_size=3, stridet=1,
+                   alpha=10000, dist_fn="mse", rou="-2", scaling=0.1)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model.train()
+        none, extra = model(h, w, tar_e.to(dev), tar_k.to(dev), res=res.to(dev), losscfg=collate(cfg))
+        _, extra_o = mpv_oracle.mpv_forward(stack_cpu, args, H, W, ref_extrin, K, 1.0, 100.0, h, w, tar_e, tar_k, res=res,
+                                            losscfg=collate(cfg), training=True)
+    assert none is None
+    assert set(extra) == set(extra_o)
+    weights = {"swd": 1.0, "rgb_smooth": args.rgb_smooth_loss_weight, "a_smooth": args.a_smooth_loss_weight,
+               "sparsity": args.sparsity_loss_weight, "density": args.density_loss_weight}
+    tot = sum(extra[k].sum() * weights[k] for k in extra)
+    tot_o = sum(extra_o[k].sum() * weights[k] for k in extra_o)
+    for k in extra:
+        assert extra[k].shape == (1, 1)
+        assert abs(extra[k].item() - extra_o[k].item()) <= 2e-5 * max(1.0, abs(extra_o[k].item())), k
+    (g,) = torch.autograd.grad(tot, model.stack)
+    (g_o,) = torch.autograd.grad(tot_o, stack_cpu)
+    assert float((g.cpu() - g_o).abs().max()) <= 1e-4 * max(1.0, float(g_o.abs().max()))
+    assert float(g_o.abs().max()) > 0
+
+
+def test_forward_eval_and_frame_subset(dev):
+    from videoloop3d_amd.MPV import MPMeshVid
+    H, W = 44, 60
+    K, ref_extrin, tar = scene(H, W)
+    args = make_args(rgb_smooth_loss_weight=0.0, a_smooth_loss_weight=0.0)
+    model = MPMeshVid(args, H, W, ref_extrin, K, 1.0, 100.0).to(dev).eval()
+    with torch.no_grad():
+        model.stack.copy_(synth.make_plane_stack(*model.stack.shape[:4], seed=5))
+        tar_e, tar_k = torch.tensor(tar)[None], torch.tensor(K)[None]
+        for ts in (None, torch.tensor([4]), torch.tensor([5, 0, 2])):
+            rgb, extra = model(H, W, tar_e.to(dev), tar_k.to(dev), ts=None if ts is None else ts.to(dev))
+            rgb_o, _ = mpv_oracle.mpv_forward(model.stack.detach().cpu(), args, H, W, ref_extrin, K, 1.0, 100.0, H, W, tar_e, tar_k,
+                                              ts=ts, training=False)
+            assert extra == {} and rgb.shape == rgb_o.shape
+            assert float((rgb.cpu() - rgb_o).abs().max()) <= 1e-4
+
+
+def test_atlas_roundtrip():
+    from videoloop3d_amd.MPV import atlas_to_stack, stack_to_atlas
+    atlas = torch.arange(3 * 4 * 10 * 28, dtype=torch.float32).reshape(3, 4, 10, 28)   # T=3, grid 2x4 of 5x7 cells
+    st = atlas_to_stack(atlas, 8, 2)
+    assert st.shape == (8, 3, 5, 7, 4)
+    assert torch.equal(st[5, 1, 2, 3], atlas[1, :, 1 * 5 + 2, 1 * 7 + 3])             # plane 5 = cell (1, 1)
+    assert torch.equal(stack_to_atlas(st, 2), atlas)

@@ -1,0 +1,207 @@
+"""MPMeshVid on the MI355X-native render + looping-loss kernels: drop-in for the hot path of the reference's MPV.py.
+
+Mirrors /root/reference/MPV.py:26-138 (constructor), :351-475 (render) and :477-556 (forward) for PLANAR, un-deformed
+geometry -- which is all the shipped configs ever produce (vertices get no gradient: MPV.py:354; optimize_geo_start is
+"currently not used": config_parser.py:153-154).  Differences by design:
+  * the learnable texture is the dense plane stack `stack` (D,T,mpi_h,mpi_w,4) (one 16-byte rgba texel, coalesced HBM
+    reads) instead of the (T,4,Ah,Aw) atlas grid of cells of MPV.py:75-104; `atlas_to_stack`/`stack_to_atlas` convert.
+    Texel pitch is exactly 1 plane pixel (the atlas pitch of (Aw-1)/(gw*(mpi_w-1)) is available through `texel_scale`).
+  * no rasteriser: coverage and UVs of fronto-parallel quads are the analytic per-plane homography, with
+    the two pytorch3d-side constants exposed as `pixel_center` (0.5) and hard-cut borders.
+  * lod / init_from_mpi / save_* / optimizer bookkeeping are host-side and out of scope this round.
+"""
+import dataclasses
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .render import RenderSpec, render_planes
+from .utils_mpi import compute_homography, make_depths, warp_homography
+from .utils_vid import Patch3DAvg, Patch3DGPNNDirectLoss, Patch3DGPNNLowMemLoss, Patch3DMSE
+
+# activations the HIP kernels implement (subset of MPI.py:21-31; shipped configs use sigmoid/sigmoid)
+ACTIVATES = {'relu': torch.relu, 'sigmoid': torch.sigmoid, 'none': lambda x: x,
+             'clamp': lambda x: torch.clamp(x, 0, 1), 'abs': torch.abs}
+
+
+def get_new_intrin(old_intrin, new_h_start, new_w_start):
+    """utils.py:196-200."""
+    new_intrin = old_intrin.clone() if isinstance(old_intrin, torch.Tensor) else old_intrin.copy()
+    new_intrin[..., 0, 2] -= new_w_start
+    new_intrin[..., 1, 2] -= new_h_start
+    return new_intrin
+
+
+def atlas_to_stack(atlas_dyn, mpi_d, grid_h):
+    """(T,4,Ah,Aw) atlas of grid_h x grid_w plane cells (MPV.py:37-44,75-81: plane p <-> cell (p // grid_w, p % grid_w))
+    -> (D,T,mpi_h,mpi_w,4) stack."""
+    T, C, Ah, Aw = atlas_dyn.shape
+    grid_w = mpi_d // grid_h
+    mh, mw = Ah // grid_h, Aw // grid_w
+    cells = atlas_dyn.reshape(T, C, grid_h, mh, grid_w, mw).permute(2, 4, 0, 3, 5, 1)     # gh,gw,T,mh,mw,C
+    return cells.reshape(mpi_d, T, mh, mw, C).contiguous()
+
+
+def stack_to_atlas(stack, grid_h):
+    D, T, mh, mw, C = stack.shape
+    grid_w = D // grid_h
+    cells = stack.reshape(grid_h, grid_w, T, mh, mw, C).permute(2, 5, 0, 3, 1, 4)          # T,C,gh,mh,gw,mw
+    return cells.reshape(T, C, grid_h * mh, grid_w * mw).contiguous()
+
+
+class MPMeshVid(nn.Module):
+    def __init__(self, args, H, W, ref_extrin, ref_intrin, near, far, pixel_center=0.5, texel_scale=(1.0, 1.0)):
+        super().__init__()
+        self.args = args
+        self.frm_num = args.mpv_frm_num
+        self.isloop = args.mpv_isloop
+        mpi_h, mpi_w = int(args.mpi_h_scale * H), int(args.mpi_w_scale * W)
+        self.mpi_h, self.mpi_w = mpi_h, mpi_w
+        self.mpi_d, self.near, self.far = args.mpi_d, near, far
+        self.H, self.W = H, W
+        if getattr(args, "fp16", False):
+            raise RuntimeError("fp16 is marked 'do NOT use' in the reference (config_parser.py:32-33); fp32 only")
+        if getattr(args, "rgb_mlp_type", "direct") != "direct":
+            raise RuntimeError(f"rgbmlp_type = {args.rgb_mlp_type} not supported (shipped configs use 'direct', mpv_base.txt:28)")
+        ref_extrin, ref_intrin = np.asarray(ref_extrin), np.asarray(ref_intrin)
+        assert ref_extrin.shape == (4, 4) and ref_intrin.shape == (3, 3)
+        self.register_buffer("ref_extrin", torch.tensor(ref_extrin))
+        self.register_buffer("ref_intrin", torch.tensor(ref_intrin).float())
+        self.register_buffer("planedepth", make_depths(self.mpi_d, near, far).float().flip(0))   # plane 0 = nearest (MPV.py:51)
+        # intrinsics that map the whole (larger) MPI plane to plane pixels (MPV.py:55-56)
+        self.H_start, self.W_start = (mpi_h - H) // 2, (mpi_w - W) // 2
+        self.register_buffer("ref_intrin_mpi", get_new_intrin(self.ref_intrin, -self.H_start, -self.W_start))
+
+        stack = torch.randn((self.mpi_d, self.frm_num, mpi_h, mpi_w, 4)) * args.init_std          # MPV.py:84-85
+        stack[..., -1] = -2                                                                       # MPV.py:109-110
+        self.stack = nn.Parameter(stack, requires_grad=True)
+
+        if args.rgb_activate not in ACTIVATES or args.alpha_activate not in ACTIVATES:
+            raise RuntimeError(f"activation ({args.rgb_activate}, {args.alpha_activate}) not implemented by the HIP kernels")
+        self.rgb_activate, self.alpha_activate = ACTIVATES[args.rgb_activate], ACTIVATES[args.alpha_activate]
+        self.spec = dataclasses.replace(RenderSpec.mpv(rgb_act=args.rgb_activate, alpha_act=args.alpha_activate,
+                                                       scale=tuple(texel_scale)), pixel_center=float(pixel_center))
+
+        self.swd_patch_size, self.swd_patcht_size = args.swd_patch_size, args.swd_patcht_size
+        self.swd_stride, self.swd_stridet = args.swd_stride, args.swd_stridet
+        self.losses = {                                   # MPV.py:131-138 ('swd' is None there too; 'gpnn_down' is off-path)
+            'swd': None,
+            'gpnn': Patch3DGPNNDirectLoss(),
+            'gpnn_lm': Patch3DGPNNLowMemLoss(),
+            'mse': Patch3DMSE,
+            'avg': Patch3DAvg,
+        }
+
+    # ---- geometry ----------------------------------------------------------------------------------------------------
+    def plane_homographies(self, extrin, intrin):
+        """[D,3,3] target pixel -> plane pixel for the view `extrin` (ref -> target, [1,4,4]) / `intrin` [1,3,3]
+        (utils_mpi.py:240-273 with src = the reference camera, plane normal (0,0,1), distance = planedepth)."""
+        dev = extrin.device
+        eye = torch.eye(4, dtype=extrin.dtype, device=dev)[None]
+        normal = torch.tensor([0., 0., 1.], dtype=extrin.dtype, device=dev).expand(1, self.mpi_d, 3)
+        return compute_homography(eye, self.ref_intrin_mpi[None].to(extrin.dtype), extrin, intrin, normal,
+                                  self.planedepth[None].to(extrin.dtype))[0].float()
+
+    # ---- render ------------------------------------------------------------------------------------------------------
+    def _frames(self, ts):
+        if len(ts) == self.frm_num and bool((torch.as_tensor(ts).cpu() == torch.arange(self.frm_num)).all()):
+            return self.stack
+        return self.stack[:, torch.as_tensor(ts, device=self.stack.device).long()]
+
+    def render(self, H, W, extrin, intrin, ts, need_layers=False):
+        """MPV.py:351-475 -> (rgb [T',H,W,3], variables).  `variables['mpi']`/`['blend_weight']` (the warped per-layer
+        rgba, only consumed by the smoothness/sparsity regularisers) are materialised on demand with the unfused operators."""
+        stack = self._frames(ts)
+        homos = self.plane_homographies(extrin, intrin)
+        rgb, alpha = render_planes(stack, homos, H, W, self.spec)
+        variables = {"pix_to_face": None, "blend_weight": None, "mpi": None, "disp_norm": None, "alpha": alpha}
+        if need_layers:
+            mpi = self._layers(stack, homos, H, W)
+            variables["mpi"] = mpi
+        if len(self.args.bg_color) > 0:                                                     # MPV.py:455-461 (as written)
+            if self.args.bg_color == "random":
+                bg_color = torch.rand(3).type_as(rgb)
+            else:
+                r, g, b = map(float, self.args.bg_color.split('#'))
+                bg_color = torch.tensor([r, g, b]).type_as(rgb)
+            rgb = rgb * alpha[..., None] + bg_color[None, None, None] * (- alpha[..., None] + 1)
+        return rgb[..., :3], variables
+
+    def _layers(self, stack, homos, H, W):
+        """warped + activated per-layer rgba [T',H,W,D,4] (MPV.py:441-449) via the unfused warp kernel.
+        warp_homography samples at texel = p*(S-1)/S from integer pixels, so the MPV convention (pixel centre c,
+        texel = p*s + o) is folded into the homography:  H' = diag(Ws/(Ws-1), Hs/(Hs-1), 1) * A * H * shift(c)."""
+        D, T, Hs, Ws, _ = stack.shape
+        c = self.spec.pixel_center
+        sx, sy = self.spec.scale
+        ox, oy = self.spec.offset
+        dev = stack.device
+        A = torch.tensor([[sx * Ws / (Ws - 1), 0, ox * Ws / (Ws - 1)], [0, sy * Hs / (Hs - 1), oy * Hs / (Hs - 1)], [0, 0, 1.]], device=dev)
+        C = torch.tensor([[1., 0, c], [0, 1., c], [0, 0, 1.]], device=dev)
+        hm = (A @ homos.to(dev) @ C)
+        imgs = stack.permute(1, 0, 4, 2, 3)                                                  # T,D,4,Hs,Ws
+        samp = warp_homography(H, W, hm[None].expand(T, D, 3, 3), imgs)                      # T,D,4,H,W
+        # hard-cut coverage of the quad (MPV.py:389): texel coords inside [0,S-1]
+        y, x = torch.meshgrid(torch.arange(H, device=dev, dtype=torch.float32) + c,
+                              torch.arange(W, device=dev, dtype=torch.float32) + c, indexing="ij")
+        p = homos.to(dev)[:, None, None] @ torch.stack([x, y, torch.ones_like(x)], -1)[None, ..., None]   # D,H,W,3,1
+        tx = p[..., 0, 0] / p[..., 2, 0] * sx + ox
+        ty = p[..., 1, 0] / p[..., 2, 0] * sy + oy
+        cov = ((tx >= 0) & (tx <= Ws - 1) & (ty >= 0) & (ty <= Hs - 1)).to(samp.dtype)      # D,H,W
+        rgba = torch.cat([self.rgb_activate(samp[:, :, :3]), self.alpha_activate(samp[:, :, 3:])], dim=2)
+        rgba = rgba * cov[None, :, None]
+        return rgba.permute(0, 3, 4, 1, 2)                                                   # T,H,W,D,4
+
+    # ---- forward -----------------------------------------------------------------------------------------------------
+    def forward(self, h, w, tar_extrins, tar_intrins, ts=None, res=None, losscfg=None):
+        """MPV.py:477-556.  train -> (None, {'swd': [1,1], ...}); eval -> (rgb [T',3,h,w], {})."""
+        extrins = tar_extrins @ self.ref_extrin[None, ...].inverse().to(tar_extrins.dtype)
+        if ts is None:
+            ts = torch.arange(self.frm_num).long()
+        a = self.args
+        need_layers = self.training and (a.sparsity_loss_weight > 0 or a.rgb_smooth_loss_weight > 0 or a.a_smooth_loss_weight > 0)
+        rgb, variables = self.render(h, w, extrins, tar_intrins, ts, need_layers=need_layers)
+        rgb = rgb.permute(0, 3, 1, 2)
+        extra = {}
+        if not self.training:
+            return rgb, {}
+        assert res is not None
+        rgb_pad = rgb
+        if self.isloop:
+            pad_frame = self.swd_patcht_size - 1
+            rgb_pad = torch.cat([rgb, rgb[:pad_frame]], 0)
+        losscfg = {k: v[0].item() if torch.is_tensor(v) else v[0] for k, v in losscfg.items()}   # un-collate (MPV.py:494)
+        loss_name = losscfg.pop('loss_name')
+        loss_gain = losscfg.pop('loss_gain', 1.)
+        loss = self.losses[loss_name]
+        if a.scale_invariant and self.training:
+            res_avg = res[0].mean(dim=0)
+            rgb_avg = rgb.detach().mean(dim=0)
+            scale = torch.exp(torch.log((res_avg + 0.01) / (rgb_avg + 0.01)).mean())
+            scale = (scale + 3) / 4
+            rgb_pad = rgb_pad * scale
+        main_loss = loss(rgb_pad.permute(1, 0, 2, 3)[None], res.permute(0, 2, 1, 3, 4), **losscfg)
+        extra['swd'] = main_loss.reshape(1, -1) * loss_gain
+
+        if a.sparsity_loss_weight > 0:
+            alpha = variables["mpi"][..., -1]
+            sparsity = alpha.norm(dim=-1, p=1) / alpha.norm(dim=-1, p=2).clamp_min(1e-4)
+            extra["sparsity"] = (sparsity.mean() / np.sqrt(self.mpi_d) * loss_gain).reshape(1, -1)
+        if a.rgb_smooth_loss_weight > 0:
+            smooth = variables["mpi"][..., :-1]
+            denorm = smooth.shape[-2] / self.mpi_d
+            smoothx = (smooth[:, :, :-1] - smooth[:, :, 1:]).abs().mean()
+            smoothy = (smooth[:, :-1] - smooth[:, 1:]).abs().mean()
+            extra["rgb_smooth"] = ((smoothx + smoothy).reshape(1, -1) * (loss_gain * denorm)).reshape(1, -1)
+        if a.a_smooth_loss_weight > 0:
+            smooth = variables["mpi"][..., -1]
+            denorm = smooth.shape[-1] / self.mpi_d
+            smoothx = (smooth[:, :, :-1] - smooth[:, :, 1:]).abs().mean()
+            smoothy = (smooth[:, :-1] - smooth[:, 1:]).abs().mean()
+            extra["a_smooth"] = ((smoothx + smoothy) * (loss_gain * denorm)).reshape(1, -1)
+        if a.density_loss_weight > 0:
+            extra["density"] = (variables["alpha"] - 1).abs().mean().reshape(1, -1)
+        if getattr(a, "d_smooth_loss_weight", 0) > 0:
+            raise RuntimeError("d_smooth_loss_weight > 0 needs the rasteriser depth buffer (MPV.py:463-466); not on the planar path")
+        return None, extra

@@ -92,7 +92,7 @@ def all_gather_frame(band_rgb: torch.Tensor, bands: List[Band], group=None) -> t
     import torch.distributed as dist
     T, _, W, C = band_rgb.shape
     rows = [b.rows for b in bands]
-    if len(set(rows)) == 1:
+    if len(set(rows)) == 1 and band_rgb.is_cuda:
         out = torch.empty((len(bands), T, rows[0], W, C), dtype=band_rgb.dtype, device=band_rgb.device)
         dist.all_gather_into_tensor(out, band_rgb.contiguous(), group=group)
         return out.permute(1, 0, 2, 3, 4).reshape(T, sum(rows), W, C)
