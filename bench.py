@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-loss", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=1)
+    ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--loss-steps", type=int, default=5)
     return ap.parse_args()
 
@@ -52,7 +52,9 @@ def cpu_baseline(D, H, W, frames, spec_name):
     from oracle import mpi_oracle as MO
     from videoloop3d_amd import synth
     from videoloop3d_amd.utils_mpi import compute_homography, make_depths
-    cores = os.cpu_count() or 1
+    # threads: the oracle's index/gather-heavy torch ops peak at 32 threads on the 2x64-core EPYC host of the GPU box
+    # (profiles/cpu_threads.py: 16 -> 0.18, 32 -> 0.20, 64 -> 0.18, 128 -> 0.12, 256 -> 0.035 Mpix/s)
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     stack = synth.make_plane_stack(D, frames, H, W, seed=2).requires_grad_(True)
     ref_e, Kr, tar_e, Kt = synth.make_cameras(H, W)
@@ -66,7 +68,8 @@ def cpu_baseline(D, H, W, frames, spec_name):
     (gs,) = torch.autograd.grad(rgb, stack, g)
     dt = time.perf_counter() - t0
     return {"value": frames * H * W / dt / 1e6, "unit": "Mpix/s", "cores": cores, "kind": "port",
-            "sample": f"{frames} frame(s) of the D={D} {H}x{W} workload, fwd+bwd, torch CPU fp32 oracle ({dt:.1f} s)"}
+            "sample": f"{frames} frame(s) of the D={D} {H}x{W} workload, fwd+bwd, torch CPU fp32 oracle ({dt:.1f} s, "
+                      f"{cores} threads of {os.cpu_count()} logical cores)"}
 
 
 def loss_bench(dev, H, W, T, Ty, steps):
@@ -204,8 +207,8 @@ def main():
         ach = nbytes / (ms * 1e-3) / 1e9
         return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": None, "avg_ms": ms, "algorithmic_bytes": nbytes}
-    r_f = roof("render_fwd_k", fwd_bytes, f_ms)
-    r_b = roof("render_bwd_k(+grad memset)", bwd_bytes, b_ms)
+    r_f = roof("render_fwd2_k", fwd_bytes, f_ms)
+    r_b = roof("render_bwd_tile_k (+bwd_plan_k, bwd_zero_unowned_k)", bwd_bytes, b_ms)
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
