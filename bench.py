@@ -105,11 +105,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # VL3D_BENCH_BACKEND=gloo is a debugging aid: lets N ranks share one GPU to exercise the N>1 code path on a 1-GPU box
+    backend = os.environ.get("VL3D_BENCH_BACKEND", "nccl")
+    local_dev = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -164,7 +170,10 @@ def main():
         if band is not None:
             comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(comm_stream):
-                frame = all_gather_frame(rgb.detach(), bands)
+                if backend == "nccl":
+                    frame = all_gather_frame(rgb.detach(), bands)
+                else:   # debugging path only (gloo has no CUDA all_gather)
+                    frame = all_gather_frame(rgb.detach().cpu(), bands)
         (gs,) = torch.autograd.grad(rgb, stack, g_rgb)
         e2.record()
         if band is not None:
