@@ -120,6 +120,147 @@ __global__ __launch_bounds__(NN_THREADS) void patchnn_k(NNArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// K3 v2: the same frame-pair-energy formulation fed from a PIXEL-MAJOR copy of the videos.
+// video_to_pixel_major_k rewrites [3][T][H][W] (strided) as [H][W][3][TP] (TP = T padded to 4, zero filled) so that
+// everything a patch location needs -- all frames of its ps x ps x 3 pixels -- is ps contiguous runs of ps*3*TP floats:
+// the staging becomes fully coalesced float4 traffic (v1 gathered 44-byte row segments per frame: 13.0 ms at 720p for
+// the ref-view configuration, almost all of it in the staging loads).
+__global__ __launch_bounds__(256) void video_to_pixel_major_k(const float *__restrict__ v, int64_t sc, int64_t st, int64_t sr,
+                                                              int T, int TP, int H, int W, float *__restrict__ out) {
+    __shared__ float tile[64][65];      // [channel-frame chunk][pixel] (+1 pad: conflict-free transposed reads)
+    const int row = blockIdx.y, x0 = blockIdx.x * 64, tid = threadIdx.x;
+    const int CF = 3 * TP;
+    for (int cf0 = 0; cf0 < CF; cf0 += 64) {
+        // read: lanes over pixels (coalesced along the row), 4 (c,f) pairs per pass
+        for (int j = tid >> 6; j < 64; j += 4) {
+            const int cf = cf0 + j, c = cf / TP, f = cf - c * TP, x = x0 + (tid & 63);
+            float val = 0.f;
+            if (cf < CF && f < T && x < W) val = v[c * sc + f * st + (int64_t)row * sr + x];
+            tile[j][tid & 63] = val;
+        }
+        __syncthreads();
+        // write: lanes over (c,f) (contiguous in the pixel-major layout)
+        for (int p = tid >> 6; p < 64; p += 4) {
+            const int cf = cf0 + (tid & 63), x = x0 + p;
+            if (cf < CF && x < W) out[((size_t)row * W + x) * CF + cf] = tile[tid & 63][p];
+        }
+        __syncthreads();
+    }
+}
+
+struct NN2Args {
+    const float *xt, *yt;   // pixel-major [H][W][3][TxP] / [H][W][3][TyP]
+    int32_t *nn;
+    int W, ps, pt, stride, stridet, h_o, w_o, n1, n2;
+    int TxP, TyP, K, KC;
+    int use_alpha;
+    float alpha, dnorm;
+};
+
+// LDS layout (floats): Xs[KC][TxP] | Ys[KC][TyP] | E[TxP][TyP] | colmin[n2]
+__global__ __launch_bounds__(NN_THREADS) void patchnn2_k(NN2Args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Xs = smem;
+    float *Ys = Xs + (size_t)a.KC * a.TxP;
+    float *E = Ys + (size_t)a.KC * a.TyP;
+    float *colmin = E + (size_t)a.TxP * a.TyP;
+    const int b = blockIdx.x, by = b / a.w_o, bx = b % a.w_o;
+    const int r0 = by * a.stride, c0 = bx * a.stride, tid = threadIdx.x;
+    const int tiles_j = a.TyP / TJ, ntiles = (a.TxP / TI) * tiles_j;
+    const int rowk = a.ps * 3;                      // k = (r*ps + q)*3 + c : one patch row = rowk consecutive k, contiguous in memory
+    const int x4 = a.TxP / 4, y4 = a.TyP / 4;
+    for (int i = tid; i < a.TxP * a.TyP; i += NN_THREADS) E[i] = 0.f;
+    for (int k0 = 0; k0 < a.K; k0 += a.KC) {
+        const int kc = min(a.KC, a.K - k0);
+        __syncthreads();
+        for (int i = tid; i < kc * x4; i += NN_THREADS) {
+            const int kk = i / x4, f4 = i - kk * x4, k = k0 + kk, r = k / rowk, rem = k - r * rowk;
+            const float4 *src = reinterpret_cast<const float4 *>(a.xt + (((size_t)(r0 + r) * a.W + c0) * 3 + rem) * a.TxP);
+            reinterpret_cast<float4 *>(Xs + (size_t)kk * a.TxP)[f4] = src[f4];
+        }
+        for (int i = tid; i < kc * y4; i += NN_THREADS) {
+            const int kk = i / y4, f4 = i - kk * y4, k = k0 + kk, r = k / rowk, rem = k - r * rowk;
+            const float4 *src = reinterpret_cast<const float4 *>(a.yt + (((size_t)(r0 + r) * a.W + c0) * 3 + rem) * a.TyP);
+            reinterpret_cast<float4 *>(Ys + (size_t)kk * a.TyP)[f4] = src[f4];
+        }
+        __syncthreads();
+        for (int tile = tid; tile < ntiles; tile += NN_THREADS) {
+            const int ti = (tile / tiles_j) * TI, tj = (tile % tiles_j) * TJ;
+            float acc[TI][TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = 0.f;
+            for (int kk = 0; kk < kc; ++kk) {
+                const float4 xv = *reinterpret_cast<const float4 *>(Xs + kk * a.TxP + ti);
+                const float4 yv = *reinterpret_cast<const float4 *>(Ys + kk * a.TyP + tj);
+                const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, ya[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) {
+                        const float df = xa[i] - ya[j];
+                        acc[i][j] += df * df;
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) E[(ti + i) * a.TyP + tj + j] += acc[i][j];
+        }
+    }
+    __syncthreads();
+    // epilogue on all 256 threads: 4 lanes share one row (column) and scan a quarter each, then combine by shuffles.
+    // dist = sum_kt E[.][.] / d (utils_vid.py:82-84); normaliser alpha + min_i dist (:133-134); first minimum wins (:141).
+    const int sub = tid & 3;
+    if (a.use_alpha) {
+        for (int j = tid >> 2; j < a.n2; j += NN_THREADS / 4) {
+            float m = INFINITY;
+            for (int i = sub; i < a.n1; i += 4) {
+                float sacc = 0.f;
+                for (int kt = 0; kt < a.pt; ++kt) sacc += E[(i * a.stridet + kt) * a.TyP + j * a.stridet + kt];
+                m = fminf(m, sacc / a.dnorm);
+            }
+            m = fminf(m, __shfl_xor(m, 1, 64));
+            m = fminf(m, __shfl_xor(m, 2, 64));
+            if (sub == 0) colmin[j] = a.alpha + m;
+        }
+        __syncthreads();
+    }
+    for (int i0 = 0; i0 < a.n1; i0 += NN_THREADS / 4) {      // uniform trip count: every lane takes part in the shuffles
+        const int i = i0 + (tid >> 2);
+        const int q = (a.n2 + 3) / 4, j0 = sub * q, j1 = min(a.n2, j0 + q);
+        float best = INFINITY;
+        int bj = j0;
+        bool best_nan = false;
+        if (i < a.n1) {
+            for (int j = j0; j < j1; ++j) {
+                float sacc = 0.f;
+                for (int kt = 0; kt < a.pt; ++kt) sacc += E[(i * a.stridet + kt) * a.TyP + j * a.stridet + kt];
+                float v = sacc / a.dnorm;
+                if (a.use_alpha) v = v / colmin[j];           // utils_vid.py:140
+                const bool vn = (v != v);                      // torch.argmin: first minimum, NaN counts as minimal
+                if (!best_nan && (vn || v < best)) { best = v; bj = j; best_nan = vn; }
+            }
+        }
+        // combine the 4 quarters in ascending-j order so that ties keep the lowest index
+#pragma unroll
+        for (int step = 1; step <= 2; step <<= 1) {
+            const float ob = __shfl_xor(best, step, 64);
+            const int oj = __shfl_xor(bj, step, 64);
+            const int on = __shfl_xor((int)best_nan, step, 64);
+            const bool other_lower = (sub & step) != 0;      // the partner holds the lower-j range
+            bool take;
+            if (best_nan || on) take = on && (!best_nan || other_lower);
+            else take = (ob < best) || (ob == best && other_lower);
+            if (take) { best = ob; bj = oj; best_nan = on != 0; }
+        }
+        if (i < a.n1 && sub == 0) a.nn[(size_t)b * a.n1 + i] = bj;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 struct FoldArgs {
     const float *y;
@@ -164,6 +305,67 @@ __global__ __launch_bounds__(256) void vote_fold_k(FoldArgs a) {
     if (a.normalize) { s0 /= wgt; s1 /= wgt; s2 /= wgt; }
     a.sum[o] = s0; a.sum[cs + o] = s1; a.sum[2 * cs + o] = s2;
     a.weight[o] = wgt;
+}
+
+
+// vote-fold, LDS-staged: one workgroup = a FT_W x FT_H pixel tile of ONE channel.  The y columns of the tile (all Ty
+// frames) and the NN indices of every patch location covering the tile are staged in LDS once; each thread then produces
+// its pixel's whole temporal column (all Tx frames) from LDS: the gather of utils_vid.py:217 + FoldNd (:218-227) without
+// any scattered global access.  (v1 -- one thread per voxel reading y and nn through L2 -- measured 12.3 ms at 720p.)
+constexpr int FT_W = 32, FT_H = 8, FT_G = 4;    // tile of 32x8 pixels x 4 temporal groups = 1024 threads (16 waves hide the LDS chains)
+
+__global__ __launch_bounds__(FT_W *FT_H *FT_G) void vote_fold_lds_k(FoldArgs a, int Ty) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NP = FT_W * FT_H, NT = NP * FT_G;
+    float *ys = smem;                                            // [Ty][NP]
+    int *nns = reinterpret_cast<int *>(smem + (size_t)Ty * NP);   // [nby][nbx][n1]
+    const int tid = threadIdx.x, pix = tid % NP, grp = tid / NP, lx = pix % FT_W, ly = pix / FT_W;
+    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H, c = blockIdx.z;
+    const int xi = x0 + lx, eta = y0 + ly;
+    // patch locations covering any pixel of the tile
+    const int y1 = min(y0 + FT_H, a.H) - 1, x1 = min(x0 + FT_W, a.W) - 1;
+    const int tby0 = max(0, (y0 - a.ps + a.stride) / a.stride), tby1 = min(a.h_o - 1, y1 / a.stride);
+    const int tbx0 = max(0, (x0 - a.ps + a.stride) / a.stride), tbx1 = min(a.w_o - 1, x1 / a.stride);
+    const int nby = tby1 - tby0 + 1, nbx = tbx1 - tbx0 + 1;
+    // stage y[c, :, tile] (row segments of FT_W floats) and the nn indices
+    const bool inb = (xi < a.W) && (eta < a.H);
+    const float *ysrc = a.y + (int64_t)c * a.y_sc + (int64_t)min(eta, a.H - 1) * a.y_sr + min(xi, a.W - 1);
+#pragma unroll 4
+    for (int f = grp; f < Ty; f += FT_G) ys[f * NP + pix] = ysrc[(int64_t)f * a.y_st];
+    for (int i = tid; i < nby * nbx * a.n1; i += NT) {
+        const int ii = i % a.n1, b = i / a.n1;
+        const int bx = b % nbx, by = b / nbx;
+        nns[i] = a.nn[((size_t)(tby0 + by) * a.w_o + (tbx0 + bx)) * a.n1 + ii];
+    }
+    __syncthreads();
+    if (!inb) return;
+    const int by_hi = min(a.h_o - 1, eta / a.stride), by_lo = max(0, (eta - a.ps + a.stride) / a.stride);
+    const int bx_hi = min(a.w_o - 1, xi / a.stride), bx_lo = max(0, (xi - a.ps + a.stride) / a.stride);
+    const int npatch = (by_hi - by_lo + 1) * (bx_hi - bx_lo + 1);
+    const size_t cs = (size_t)a.Tx * a.H * a.W, fs = (size_t)a.H * a.W;
+    float *out = a.sum + (size_t)c * cs + (size_t)eta * a.W + xi;
+    float *wout = a.weight + (size_t)eta * a.W + xi;
+    const int *nn0 = nns + ((by_lo - tby0) * nbx + (bx_lo - tbx0)) * a.n1;
+    const float *ysp = ys + pix;
+    for (int tau = grp; tau < a.Tx; tau += FT_G) {
+        float s = 0.f;
+        int cnt = 0;
+        for (int kt = 0; kt < a.pt; ++kt) {
+            const int ts = tau - kt;
+            if (ts < 0 || (ts % a.stridet) != 0) continue;
+            const int i = ts / a.stridet;
+            if (i >= a.n1) continue;
+            const int *nrow = nn0 + i;
+            for (int by = by_lo; by <= by_hi; ++by, nrow += nbx * a.n1) {
+                const int *np = nrow;
+                for (int bx = bx_lo; bx <= bx_hi; ++bx, np += a.n1) s += ysp[(*np * a.stridet + kt) * NP];
+            }
+            cnt += npatch;
+        }
+        const float wgt = fmaxf((float)cnt, 1e-10f);                  // utils_vid.py:228
+        out[(size_t)tau * fs] = a.normalize ? s / wgt : s;
+        if (c == 0) wout[(size_t)tau * fs] = wgt;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -274,9 +476,15 @@ int plan_nn(const vl3d_loss_desc *d, NNArgs &a, size_t &lds) {
 
 }  // namespace
 
-extern "C" int64_t vl3d_patchnn_scratch_bytes(const vl3d_loss_desc *) { return 0; }
+static inline int pad4(int t) { return (t + 3) / 4 * 4; }
 
-extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const float *y, int32_t *nn, void *,
+extern "C" int64_t vl3d_patchnn_scratch_bytes(const vl3d_loss_desc *d) {
+    if (!d || d->H <= 0 || d->W <= 0) return 0;
+    const int TxU = ((d->Tx - d->pt) / d->stridet) * d->stridet + d->pt;
+    return (int64_t)d->H * d->W * 3 * (pad4(TxU) + pad4(d->Ty)) * (int64_t)sizeof(float);
+}
+
+extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const float *y, int32_t *nn, void *scratch,
                             vl3d_stream_t stream) {
     int rc = check_loss(desc);
     if (rc != VL3D_OK) return rc;
@@ -285,6 +493,29 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
     size_t lds = 0;
     rc = plan_nn(desc, a, lds);
     if (rc != VL3D_OK) return rc;
+    if (scratch != nullptr && desc->variant != 1) {
+        // v2: pixel-major copies in the caller's scratch, then the coalesced-staging kernel
+        hipStream_t s = (hipStream_t)stream;
+        float *xt = (float *)scratch;
+        float *yt = xt + (size_t)desc->H * desc->W * 3 * a.TxP;
+        dim3 tg((desc->W + 63) / 64, desc->H);
+        hipLaunchKernelGGL(video_to_pixel_major_k, tg, dim3(256), 0, s, x, desc->x_sc, desc->x_st, desc->x_sr, a.TxU, a.TxP,
+                           desc->H, desc->W, xt);
+        hipLaunchKernelGGL(video_to_pixel_major_k, tg, dim3(256), 0, s, y, desc->y_sc, desc->y_st, desc->y_sr, desc->Ty, a.TyP,
+                           desc->H, desc->W, yt);
+        NN2Args b{};
+        b.xt = xt; b.yt = yt; b.nn = nn; b.W = desc->W; b.ps = a.ps; b.pt = a.pt; b.stride = a.stride; b.stridet = a.stridet;
+        b.h_o = a.h_o; b.w_o = a.w_o; b.n1 = a.n1; b.n2 = a.n2; b.TxP = a.TxP; b.TyP = a.TyP; b.K = a.K; b.KC = a.KC;
+        b.use_alpha = a.use_alpha; b.alpha = a.alpha; b.dnorm = a.inv_d;
+        static bool attr2 = false;
+        if (!attr2) {
+            VL3D_HIP(hipFuncSetAttribute((const void *)patchnn2_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(patchnn2_k, dim3((unsigned)(a.h_o * a.w_o)), dim3(NN_THREADS), lds, s, b);
+        VL3D_CHECK_LAUNCH();
+        return VL3D_OK;
+    }
     a.x = x; a.y = y; a.nn = nn;
     static bool attr_set = false;
     if (!attr_set) {
@@ -311,8 +542,21 @@ extern "C" int vl3d_vote_fold(const vl3d_loss_desc *desc, const float *y, const 
     a.n1 = (desc->Tx - desc->pt) / desc->stridet + 1;
     a.y_sc = desc->y_sc; a.y_st = desc->y_st; a.y_sr = desc->y_sr;
     a.normalize = normalize;
-    dim3 grid((desc->W + 63) / 64, (desc->H + 3) / 4, desc->Tx);
-    hipLaunchKernelGGL(vote_fold_k, grid, dim3(256), 0, (hipStream_t)stream, a);
+    // LDS-staged kernel when the tile's y columns + nn indices fit (they do for every shipped configuration)
+    const int nby_max = (FT_H + desc->ps - 2) / desc->stride + 2, nbx_max = (FT_W + desc->ps - 2) / desc->stride + 2;
+    const size_t lds = ((size_t)desc->Ty * FT_W * FT_H + (size_t)nby_max * nbx_max * a.n1) * sizeof(float);
+    if (desc->variant != 1 && lds <= 150 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            VL3D_HIP(hipFuncSetAttribute((const void *)vote_fold_lds_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        dim3 grid((desc->W + FT_W - 1) / FT_W, (desc->H + FT_H - 1) / FT_H, 3);
+        hipLaunchKernelGGL(vote_fold_lds_k, grid, dim3(FT_W * FT_H * FT_G), lds, (hipStream_t)stream, a, desc->Ty);
+    } else {
+        dim3 grid((desc->W + 63) / 64, (desc->H + 3) / 4, desc->Tx);
+        hipLaunchKernelGGL(vote_fold_k, grid, dim3(256), 0, (hipStream_t)stream, a);
+    }
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
 }

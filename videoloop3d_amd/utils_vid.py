@@ -84,7 +84,9 @@ def find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha):
     n1 = (desc.Tx - desc.pt) // desc.stridet + 1
     nn = torch.empty((h_o, w_o, n1), dtype=torch.int32, device=xv.device)
     with torch.cuda.device(xv.device):
-        L.check(L.lib().vl3d_patchnn(desc, L.ptr(xv), L.ptr(yv), L.ptr(nn), None, L.stream_ptr(xv.device)),
+        nscratch = int(L.lib().vl3d_patchnn_scratch_bytes(desc))
+        scratch = torch.empty((nscratch + 3) // 4, dtype=torch.float32, device=xv.device) if nscratch > 0 else None
+        L.check(L.lib().vl3d_patchnn(desc, L.ptr(xv), L.ptr(yv), L.ptr(nn), L.ptr(scratch), L.stream_ptr(xv.device)),
                 "vl3d_patchnn")
     return nn, desc, xv, yv
 
