@@ -138,6 +138,12 @@ int64_t vl3d_patchnn_scratch_bytes(const vl3d_loss_desc *desc);
 int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const float *y, int32_t *nn,
                  void *scratch, vl3d_stream_t stream);
 
+/* get_NN_indices_low_memory(X[B,n1,...], Y[B,n2,...], alpha, chunksz, 'mse') on MATERIALISED patches
+ * (utils_vid.py:122-142; the caller evaluations/NNMSE.py:45-56 builds them with extract_3Dpatches).
+ * X [B,n1,d], Y [B,n2,d] dense fp32; nn int64 [B,n1] like the reference's torch.long. */
+int vl3d_nn_vectors(int64_t B, int32_t n1, int32_t n2, int32_t d, const float *X, const float *Y,
+                    int32_t use_alpha, float alpha, int64_t *nn, vl3d_stream_t stream);
+
 /* Gather the NN patches of y and vote-fold them onto x's grid (utils_vid.py:217-229):
  * sum [3,Tx,H,W] dense, weight [Tx,H,W] dense = vote count clamped at 1e-10.
  * normalize != 0 writes sum/weight (utils_vid.py:344) instead of the raw sum. */

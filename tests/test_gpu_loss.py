@@ -175,3 +175,19 @@ def test_native_crop_loss_property(dev):
         ct = cover(52, 3, 1)[:, None, None] * cover(h, ps, s)[None, :, None] * cover(w, ps, s)[None, None, :]
         assert torch.equal(lm.last_weight[0, 0].cpu(), ct.float())
         assert float(lm.last_y2x.min()) >= 0.0 and float(lm.last_y2x.max()) < 1.0
+
+
+def test_g6_get_nn_indices_low_memory(dev, golden):
+    """materialised-patch NN (utils_vid.py:122-142, used by evaluations/NNMSE.py) vs the reference golden G6."""
+    from videoloop3d_amd.utils_vid import extract_3Dpatches, get_NN_indices_low_memory
+    g = golden("g6_nn.npz")
+    X, Y = T_(g["X"]).to(dev), T_(g["Y"]).to(dev)
+    for alpha, key in ((None, "nn_none"), (0.5, "nn_alpha05"), (0.005, "nn_alpha0005")):
+        nn = get_NN_indices_low_memory(X, Y, alpha, 1024)
+        assert nn.dtype == torch.long and nn.shape == tuple(g[key].shape)
+        assert (nn.cpu().numpy() == g[key]).all()
+    # extract_3Dpatches keeps the reference's (c,kt,kh,kw) channel order (golden G5)
+    g5 = golden("g5_patches.npz")
+    ramp = torch.arange(3 * 5 * 9 * 9, dtype=torch.float32, device=dev).reshape(1, 3, 5, 9, 9)
+    assert maxabs(extract_3Dpatches(ramp, 3, 3, 2, 1), g5["p_3_3_2_1"]) == 0
+    assert maxabs(extract_3Dpatches(ramp, 5, 2, 4, 2), g5["p_5_2_4_2"]) == 0

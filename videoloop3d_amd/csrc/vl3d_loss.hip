@@ -261,6 +261,58 @@ __global__ __launch_bounds__(NN_THREADS) void patchnn2_k(NN2Args a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// get_NN_indices_low_memory on MATERIALISED patches (utils_vid.py:122-142; used by evaluations/NNMSE.py:45-56):
+// X [B,n1,d], Y [B,n2,d] dense.  One workgroup per batch entry b; dist[i][j] = sum_k (X[b,i,k]-Y[b,j,k])^2 / d kept in LDS.
+// API-parity kernel (the training loss never materialises patches); plain VALU, K staged in chunks.
+__global__ __launch_bounds__(256) void nn_vectors_k(const float *__restrict__ X, const float *__restrict__ Y, int n1, int n2, int d,
+                                                    int use_alpha, float alpha, int64_t *__restrict__ nn, int KC) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Xs = smem;                       // [n1][KC+1]
+    float *Ys = Xs + (size_t)n1 * (KC + 1); // [n2][KC+1]
+    float *E = Ys + (size_t)n2 * (KC + 1);  // [n1][n2]
+    float *colmin = E + (size_t)n1 * n2;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float *xb = X + (size_t)b * n1 * d, *yb = Y + (size_t)b * n2 * d;
+    for (int i = tid; i < n1 * n2; i += 256) E[i] = 0.f;
+    for (int k0 = 0; k0 < d; k0 += KC) {
+        const int kc = min(KC, d - k0);
+        __syncthreads();
+        for (int i = tid; i < n1 * kc; i += 256) { const int f = i / kc, k = i - f * kc; Xs[f * (KC + 1) + k] = xb[(size_t)f * d + k0 + k]; }
+        for (int i = tid; i < n2 * kc; i += 256) { const int f = i / kc, k = i - f * kc; Ys[f * (KC + 1) + k] = yb[(size_t)f * d + k0 + k]; }
+        __syncthreads();
+        for (int p = tid; p < n1 * n2; p += 256) {
+            const int i = p / n2, j = p - i * n2;
+            float acc = 0.f;
+            for (int k = 0; k < kc; ++k) { const float df = Xs[i * (KC + 1) + k] - Ys[j * (KC + 1) + k]; acc += df * df; }
+            E[p] += acc;
+        }
+    }
+    __syncthreads();
+    const float dn = (float)d;
+    if (use_alpha) {
+        for (int j = tid; j < n2; j += 256) {
+            float m = INFINITY;
+            for (int i = 0; i < n1; ++i) m = fminf(m, E[i * n2 + j] / dn);
+            colmin[j] = alpha + m;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n1; i += 256) {
+        float best = INFINITY;
+        int bj = 0;
+        bool best_nan = false;
+        for (int j = 0; j < n2; ++j) {
+            float v = E[i * n2 + j] / dn;
+            if (use_alpha) v = v / colmin[j];
+            const bool vn = (v != v);
+            if (!best_nan && (vn || v < best)) { best = v; bj = j; best_nan = vn; }
+        }
+        nn[(size_t)b * n1 + i] = bj;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 struct FoldArgs {
     const float *y;
@@ -580,6 +632,25 @@ extern "C" int vl3d_robust_bwd(int64_t n, const float *x, const float *y2x, int3
     const unsigned blocks = (unsigned)(ceil_div64(n, 256) < 4096 ? ceil_div64(n, 256) : 4096);
     hipLaunchKernelGGL(robust_bwd_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, x, y2x, make_rho(kind, rou, scale),
                        grad_out, inv_n, grad_x);
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
+extern "C" int vl3d_nn_vectors(int64_t B, int32_t n1, int32_t n2, int32_t d, const float *X, const float *Y, int32_t use_alpha,
+                               float alpha, int64_t *nn, vl3d_stream_t stream) {
+    VL3D_REQUIRE(B > 0 && B < (1ll << 31) && n1 > 0 && n2 > 0 && d > 0 && X && Y && nn, "vl3d_nn_vectors: bad arguments");
+    const size_t fixed = ((size_t)n1 * n2 + n2) * sizeof(float);
+    VL3D_REQUIRE(fixed + (size_t)(n1 + n2) * 5 * sizeof(float) <= 150 * 1024, "vl3d_nn_vectors: n1*n2 distance matrix does not fit in LDS");
+    int kc = (int)((150 * 1024 - fixed) / ((size_t)(n1 + n2) * sizeof(float))) - 1;
+    if (kc > 64) kc = 64;
+    if (kc > d) kc = d;
+    const size_t lds = fixed + (size_t)(n1 + n2) * (kc + 1) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        VL3D_HIP(hipFuncSetAttribute((const void *)nn_vectors_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(nn_vectors_k, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, X, Y, n1, n2, d, use_alpha, alpha, nn, kc);
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
 }

@@ -366,8 +366,8 @@ __global__ __launch_bounds__(256) void bwd_fill_zero_if_infeasible_k(float4 *g, 
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS>
-__global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool PF>
+__global__ __launch_bounds__(RW *ROWS, (PF ? 4 : 8)) void render_bwd_tile_k(RenderArgs a) {
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
     constexpr int NT = RW * ROWS;
     // per-plane staging of the region's pixels, double buffered so one barrier per plane suffices
@@ -394,6 +394,13 @@ __global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
         S = Gr * a.rgb[pix * 3 + 0] + Gg * a.rgb[pix * 3 + 1] + Gb * a.rgb[pix * 3 + 2] + gA * a.alpha[pix];
     }
     float Tr = 1.0f, P = 0.0f;
+    // PF: the taps of plane d+1 are issued before the barrier of plane d and stay in flight across its gather
+    Taps2 tp_n{};
+    f4 tv_n[4];
+    if (PF && inimg) {
+        tp_n = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+        load_taps2(reinterpret_cast<const char *>(plane), tp_n, tv_n);
+    }
     for (int d = 0; d < a.D; ++d, plane += plane_stride, gplane += plane_stride) {
         const float *h = a.homos + 9 * d;
         const int buf = d & 1;
@@ -413,15 +420,22 @@ __global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
         float2 tc = make_float2(-1e30f, -1e30f);
         float4 gval = make_float4(0.f, 0.f, 0.f, 0.f);
         if (inimg) {
-            Taps2 tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-            const char *src = reinterpret_cast<const char *>(plane);
-            if (a.ablate & 4) {   // measurement only: all taps from a 64 KiB cache-resident window
-                src = reinterpret_cast<const char *>(a.stack);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) tp.off[i] &= 0xffffu;
-            }
+            Taps2 tp;
             f4 tv[4], pre;
-            load_taps2(src, tp, tv);
+            if constexpr (PF) {
+                tp = tp_n;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tv[i] = tv_n[i];
+            } else {
+                tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+                const char *src = reinterpret_cast<const char *>(plane);
+                if (a.ablate & 4) {   // measurement only: all taps from a 64 KiB cache-resident window
+                    src = reinterpret_cast<const char *>(a.stack);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) tp.off[i] &= 0xffffu;
+                }
+                load_taps2(src, tp, tv);
+            }
             const f4 o = shade2<ORDER, RACT, AACT>(tp, tv, &pre);        // o.w already 0 when the plane does not cover the pixel
             const float q = Gr * o.x + Gg * o.y + Gb * o.z + gA;
             const float w = o.w * Tr;
@@ -438,6 +452,10 @@ __global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
         }
         s_t[buf][tid] = tc;
         s_g[buf][tid] = gval;
+        if (PF && inimg && d + 1 < a.D) {
+            tp_n = make_taps2<COORD, BORDER>(h + 9, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            load_taps2(reinterpret_cast<const char *>(plane + plane_stride), tp_n, tv_n);
+        }
         __syncthreads();   // staging of plane d visible (the other buffer may still be read by slower waves: not touched here)
         // (3) every texel owned by this tile gathers its taps from the 3x3 pixels around its owner pixel
         const float mnx = fminf(fminf(s_c[buf][0], s_c[buf][1]), fminf(s_c[buf][2], s_c[buf][3]));
@@ -487,10 +505,10 @@ __global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
 }
 
 // ---- dispatch over the compile-time conventions -------------------------------------------------------
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool PF>
 void launch_tile(const RenderArgs &a, hipStream_t s) {
     dim3 grid((a.W + RW - 3) / (RW - 2), (a.H + ROWS - 3) / (ROWS - 2), a.T);
-    hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS>), grid, dim3(RW * ROWS), 0, s, a);
+    hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, PF>), grid, dim3(RW * ROWS), 0, s, a);
 }
 
 // g_tile_rows: 0 = no tile path for this call, else the ROWS of the tile kernel to launch
@@ -501,18 +519,20 @@ void launch(const RenderArgs &a, hipStream_t s) {
     dim3 grid((a.W + TILE_X - 1) / TILE_X, (a.H + TILE_Y - 1) / TILE_Y, a.T), block(TILE_X * TILE_Y);
     if constexpr (BWD) {
         if (g_tile_rows) {
-            hipLaunchKernelGGL((bwd_plan_k<COORD>), dim3(1), dim3(64), 0, s, a, g_tile_rows, const_cast<float *>(a.plan));
+            hipLaunchKernelGGL((bwd_plan_k<COORD>), dim3(1), dim3(64), 0, s, a, g_tile_rows % 100, const_cast<float *>(a.plan));
             const size_t n4 = (size_t)a.D * a.T * a.Hs * a.Ws;
             hipLaunchKernelGGL(bwd_fill_zero_if_infeasible_k, dim3(4096), dim3(256), 0, s, reinterpret_cast<float4 *>(a.g_stack), n4, a.plan);
             hipLaunchKernelGGL(bwd_zero_unowned_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, a);
-            if (g_tile_rows == 8) {
-                if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID)
-                    launch_tile<COORD, BORDER, ORDER, RACT, AACT, 8>(a, s);
-                else
-                    launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16>(a, s);
-            } else {
-                launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16>(a, s);
+            bool done = false;
+            if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID) {   // measurement variants (shipped activations only)
+                done = true;
+                if (g_tile_rows == 8) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 8, false>(a, s);
+                else if (g_tile_rows == 108) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 8, true>(a, s);
+                else if (g_tile_rows == 112) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 12, true>(a, s);
+                else if (g_tile_rows == 116) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true>(a, s);
+                else done = false;
             }
+            if (!done) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, false>(a, s);
         }
         hipLaunchKernelGGL((render_bwd_k<COORD, BORDER, ORDER, RACT, AACT>), grid, block, 0, s, a);
     } else {
@@ -624,7 +644,9 @@ extern "C" int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, 
     a.ablate = (desc->variant >> 4) & 0xf;
     if (want_tile) {
         a.plan = (const float *)scratch;
-        g_tile_rows = ((desc->variant & 0xf) == 2) ? 8 : 16;
+        // variant & 0xf: 0/3 -> 16-row regions; 2 -> 8 rows; 4/5/6 -> 8/12/16 rows with tap prefetch across the barrier
+        const int bv = desc->variant & 0xf;
+        g_tile_rows = bv == 2 ? 8 : bv == 4 ? 108 : bv == 5 ? 112 : bv == 6 ? 116 : 16;
     } else {
         a.plan = nullptr;
         g_tile_rows = 0;

@@ -46,6 +46,26 @@ def extract_3Dpatches(x, patch_size, tpatch_size, stride, tstride):
     return p.permute(0, 1, 5, 6, 7, 2, 3, 4).reshape(b, c * tpatch_size * patch_size * patch_size, dT, dH, dW)
 
 
+def get_NN_indices_low_memory(X, Y, alpha, chunksz, dist_fn='mse'):
+    """utils_vid.py:122-142: nearest neighbour in Y for every X over materialised patches X [B,n1,...], Y [B,n2,...]
+    -> long [B,n1].  `chunksz` only bounds the reference's temporary and is ignored."""
+    if dist_fn != 'mse':
+        raise RuntimeError("dist_fn other than 'mse' is not settable in the reference (config_parser.py:90-93)")
+    L.check_cuda(X, Y)
+    B, n1 = X.shape[:2]
+    n2 = Y.shape[1]
+    Xf = X.reshape(B, n1, -1).to(torch.float32).contiguous()
+    Yf = Y.reshape(B, n2, -1).to(torch.float32).contiguous()
+    if Xf.shape[2] != Yf.shape[2] or Yf.shape[0] != B:
+        raise RuntimeError("X and Y must agree in batch and feature size")
+    nn = torch.empty((B, n1), dtype=torch.long, device=X.device)
+    with torch.cuda.device(X.device):
+        L.check(L.lib().vl3d_nn_vectors(B, n1, n2, Xf.shape[2], L.ptr(Xf), L.ptr(Yf), 0 if alpha is None else 1,
+                                        0.0 if alpha is None else float(alpha), L.ptr(nn), L.stream_ptr(X.device)),
+                "vl3d_nn_vectors")
+    return nn
+
+
 def _loss_desc(x, y, patch_size, patcht_size, stride, stridet, alpha):
     """x [3,Tx,H,W], y [3,Ty,H,W] float32 CUDA tensors with unit column stride."""
     d = L.LossDesc()
