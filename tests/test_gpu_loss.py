@@ -191,3 +191,20 @@ def test_g6_get_nn_indices_low_memory(dev, golden):
     ramp = torch.arange(3 * 5 * 9 * 9, dtype=torch.float32, device=dev).reshape(1, 3, 5, 9, 9)
     assert maxabs(extract_3Dpatches(ramp, 3, 3, 2, 1), g5["p_3_3_2_1"]) == 0
     assert maxabs(extract_3Dpatches(ramp, 5, 2, 4, 2), g5["p_5_2_4_2"]) == 0
+
+
+@pytest.mark.parametrize("variant", ["1", "2", "3"])
+def test_patchnn_kernel_variants_agree(dev, variant, monkeypatch):
+    """v1 (strided staging), v2 (pixel-major staging, VALU direct SSD, the default) and v3 (MFMA frame-Gram,
+    |x|^2+|y|^2-2G like the reference) pick the same neighbours up to exact-distance near-ties."""
+    from videoloop3d_amd.utils_vid import _nn_and_fold
+    monkeypatch.setenv("VL3D_LOSS_VARIANT", variant)
+    x = synth.make_video(12, 43, 51, seed=3)
+    y = synth.make_video(20, 43, 51, seed=4)
+    for ps, pt, s, st, alpha in ((11, 3, 4, 1, 0.5), (7, 3, 4, 1, None), (3, 3, 2, 1, None)):
+        so, wo, nno = VO.find_nn_and_merge(x, y, ps, pt, s, st, 1e10 if alpha is None else alpha, return_nn=True)
+        sg, wg, nng = _nn_and_fold(x.to(dev), y.to(dev), ps, pt, s, st, alpha, normalize=False)
+        nbad, unexplained = nn_mismatch_is_near_tie(x, y, ps, pt, s, st, alpha, nng)
+        assert unexplained == 0
+        if nbad == 0:
+            assert maxabs(sg, so) <= 1e-5

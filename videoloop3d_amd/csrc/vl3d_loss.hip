@@ -157,6 +157,7 @@ struct NN2Args {
     int TxP, TyP, K, KC;
     int use_alpha;
     float alpha, dnorm;
+    int ablate;   // measurement only: 1 skip epilogue, 2 skip compute, 4 skip staging loads
 };
 
 // LDS layout (floats): Xs[KC][TxP] | Ys[KC][TyP] | E[TxP][TyP] | colmin[n2]
@@ -261,6 +262,124 @@ __global__ __launch_bounds__(NN_THREADS) void patchnn2_k(NN2Args a) {
     }
 }
 
+
+
+// ---------------------------------------------------------------------------------------------------
+// K3 v3: frame-pair Gram on the matrix cores.  G[i',j'] = sum_k X[i',k] Y[j',k] over k = (pixel, channel) of the
+// location is a dense [Tx x K] x [K x Ty] contraction (K = 3 ps^2 = 363 for the ref-view configuration): it runs on
+// v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain, same rate as the f32 vector peak but 1 operand VGPR per 64 MACs instead
+// of 2 LDS reads per 16), then  E = |x|^2 + |y|^2 - 2G  like the reference's own |x|^2+|y|^2-2xy form
+// (utils_vid.py:82) but still per FRAME pair (the temporal diagonal sum follows in the shared epilogue).
+// Wave w owns the 16-row strip w of E and all TyP/16 column tiles; operands are read from the k-major LDS chunk.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int MF_MAXJT = 8;   // up to 128 y frames per location in this kernel
+
+__global__ __launch_bounds__(NN_THREADS) void patchnn3_k(NN2Args a, int TyT) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Xs = smem;                                   // [KC][TxP]   (KC multiple of 4)
+    float *Ys = Xs + (size_t)a.KC * a.TxP;              // [KC][TyP]
+    float *E = Ys + (size_t)a.KC * a.TyP;               // [64][TyT*16]  (padded tiles; also absorbs operand over-reads)
+    const int EP = TyT * 16;
+    float *colmin = E + (size_t)64 * EP;
+    float *nrm = colmin + a.n2;                         // [64 + EP] squared norms of the x / y frames
+    const int b = blockIdx.x, by = b / a.w_o, bx = b % a.w_o;
+    const int r0 = by * a.stride, c0 = bx * a.stride, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rowk = a.ps * 3, x4 = a.TxP / 4, y4 = a.TyP / 4;
+    f32x4_t acc[MF_MAXJT];
+#pragma unroll
+    for (int j = 0; j < MF_MAXJT; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float nacc = 0.f;                                    // thread tid < TxP: |x frame tid|^2 ; TxP <= tid < TxP+TyP: y frames
+    for (int k0 = 0; k0 < a.K; k0 += a.KC) {
+        const int kc = min(a.KC, a.K - k0), kc4 = (kc + 3) & ~3;
+        __syncthreads();
+        for (int i = tid; i < kc4 * x4; i += NN_THREADS) {
+            const int kk = i / x4, f4 = i - kk * x4, k = k0 + kk, r = k / rowk, rem = k - r * rowk;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kk < kc && !(a.ablate & 4)) v = reinterpret_cast<const float4 *>(a.xt + (((size_t)(r0 + r) * a.W + c0) * 3 + rem) * a.TxP)[f4];
+            reinterpret_cast<float4 *>(Xs + (size_t)kk * a.TxP)[f4] = v;
+        }
+        for (int i = tid; i < kc4 * y4; i += NN_THREADS) {
+            const int kk = i / y4, f4 = i - kk * y4, k = k0 + kk, r = k / rowk, rem = k - r * rowk;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kk < kc && !(a.ablate & 4)) v = reinterpret_cast<const float4 *>(a.yt + (((size_t)(r0 + r) * a.W + c0) * 3 + rem) * a.TyP)[f4];
+            reinterpret_cast<float4 *>(Ys + (size_t)kk * a.TyP)[f4] = v;
+        }
+        __syncthreads();
+        if (tid < a.TxP + a.TyP) {
+            const float *col = tid < a.TxP ? Xs + tid : Ys + (tid - a.TxP);
+            const int pitch = tid < a.TxP ? a.TxP : a.TyP;
+            for (int kk = 0; kk < kc; ++kk) { const float v = col[kk * pitch]; nacc += v * v; }
+        }
+        const float *xa = Xs + (lane >> 4) * a.TxP + wave * 16 + (lane & 15);
+        const float *yb = Ys + (lane >> 4) * a.TyP + (lane & 15);
+        if (!(a.ablate & 2))
+        for (int kk = 0; kk < kc4; kk += 4) {
+            const float av = xa[kk * a.TxP];
+#pragma unroll
+            for (int j = 0; j < MF_MAXJT; ++j)
+                if (j < TyT) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, yb[kk * a.TyP + j * 16], acc[j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (tid < a.TxP + a.TyP) nrm[tid < a.TxP ? tid : 64 + (tid - a.TxP)] = nacc;
+    __syncthreads();
+    // C/D layout of the 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int j = 0; j < MF_MAXJT; ++j)
+        if (j < TyT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wave * 16 + (lane >> 4) * 4 + r, col = j * 16 + (lane & 15);
+                E[row * EP + col] = fmaxf(nrm[row] + nrm[64 + col] - 2.0f * acc[j][r], 0.0f);
+            }
+        }
+    __syncthreads();
+    if (a.ablate & 1) { if (tid < a.n1) a.nn[(size_t)b * a.n1 + tid] = 0; return; }
+    const int sub = tid & 3;
+    if (a.use_alpha) {
+        for (int j = tid >> 2; j < a.n2; j += NN_THREADS / 4) {
+            float m = INFINITY;
+            for (int i = sub; i < a.n1; i += 4) {
+                float sacc = 0.f;
+                for (int kt = 0; kt < a.pt; ++kt) sacc += E[(i * a.stridet + kt) * EP + j * a.stridet + kt];
+                m = fminf(m, sacc / a.dnorm);
+            }
+            m = fminf(m, __shfl_xor(m, 1, 64));
+            m = fminf(m, __shfl_xor(m, 2, 64));
+            if (sub == 0) colmin[j] = a.alpha + m;
+        }
+        __syncthreads();
+    }
+    for (int i0 = 0; i0 < a.n1; i0 += NN_THREADS / 4) {
+        const int i = i0 + (tid >> 2);
+        const int q = (a.n2 + 3) / 4, j0 = sub * q, j1 = min(a.n2, j0 + q);
+        float best = INFINITY;
+        int bj = j0;
+        bool best_nan = false;
+        if (i < a.n1) {
+            for (int j = j0; j < j1; ++j) {
+                float sacc = 0.f;
+                for (int kt = 0; kt < a.pt; ++kt) sacc += E[(i * a.stridet + kt) * EP + j * a.stridet + kt];
+                float v = sacc / a.dnorm;
+                if (a.use_alpha) v = v / colmin[j];
+                const bool vn = (v != v);
+                if (!best_nan && (vn || v < best)) { best = v; bj = j; best_nan = vn; }
+            }
+        }
+#pragma unroll
+        for (int step = 1; step <= 2; step <<= 1) {
+            const float ob = __shfl_xor(best, step, 64);
+            const int oj = __shfl_xor(bj, step, 64);
+            const int on = __shfl_xor((int)best_nan, step, 64);
+            const bool other_lower = (sub & step) != 0;
+            bool take;
+            if (best_nan || on) take = on && (!best_nan || other_lower);
+            else take = (ob < best) || (ob == best && other_lower);
+            if (take) { best = ob; bj = oj; best_nan = on != 0; }
+        }
+        if (i < a.n1 && sub == 0) a.nn[(size_t)b * a.n1 + i] = bj;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------
 // get_NN_indices_low_memory on MATERIALISED patches (utils_vid.py:122-142; used by evaluations/NNMSE.py:45-56):
@@ -545,7 +664,7 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
     size_t lds = 0;
     rc = plan_nn(desc, a, lds);
     if (rc != VL3D_OK) return rc;
-    if (scratch != nullptr && desc->variant != 1) {
+    if (scratch != nullptr && (desc->variant & 0xf) != 1) {
         // v2: pixel-major copies in the caller's scratch, then the coalesced-staging kernel
         hipStream_t s = (hipStream_t)stream;
         float *xt = (float *)scratch;
@@ -559,12 +678,37 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
         b.xt = xt; b.yt = yt; b.nn = nn; b.W = desc->W; b.ps = a.ps; b.pt = a.pt; b.stride = a.stride; b.stridet = a.stridet;
         b.h_o = a.h_o; b.w_o = a.w_o; b.n1 = a.n1; b.n2 = a.n2; b.TxP = a.TxP; b.TyP = a.TyP; b.K = a.K; b.KC = a.KC;
         b.use_alpha = a.use_alpha; b.alpha = a.alpha; b.dnorm = a.inv_d;
+        b.ablate = (desc->variant >> 4) & 7;
         static bool attr2 = false;
         if (!attr2) {
             VL3D_HIP(hipFuncSetAttribute((const void *)patchnn2_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr2 = true;
         }
-        hipLaunchKernelGGL(patchnn2_k, dim3((unsigned)(a.h_o * a.w_o)), dim3(NN_THREADS), lds, s, b);
+        // default = VALU direct-SSD kernel (v2).  variant 3 selects the MFMA frame-Gram kernel (v3): measured at 720p /
+        // ref-view cfg 6.97 ms vs 6.47 ms for v2 -- at fp32 the matrix cores have no rate advantage (v_mfma_f32_16x16x4_f32
+        // = 64 FLOP/clk/SIMD = the f32 VALU peak) and the Gram form needs an extra |x|^2,|y|^2 pass and 64x80 padded tiles
+        // (ablation: MFMA loop 2.4 ms, staging 1.3 ms, epilogue 0.7 ms, transposes + rest 2.4 ms).
+        const int TyT = (a.TyP + 15) / 16;
+        const bool mf_ok = a.TxP <= 64 && TyT <= MF_MAXJT;
+        const int pv = desc->variant & 0xf;
+        const bool use_mf = mf_ok && pv == 3;
+        if (use_mf) {
+            const size_t fixed3 = ((size_t)64 * TyT * 16 + a.n2 + 64 + TyT * 16) * sizeof(float);
+            int kc3 = (int)((48 * 1024 > fixed3 + 16 * (a.TxP + a.TyP) * sizeof(float) ? 48 * 1024 - fixed3 : 16 * (a.TxP + a.TyP) * sizeof(float)) /
+                            ((size_t)(a.TxP + a.TyP) * sizeof(float)));
+            kc3 &= ~3;
+            if (kc3 > ((a.K + 3) & ~3)) kc3 = (a.K + 3) & ~3;
+            b.KC = kc3;
+            const size_t lds3 = fixed3 + (size_t)kc3 * (a.TxP + a.TyP) * sizeof(float);
+            static bool attr3 = false;
+            if (!attr3) {
+                VL3D_HIP(hipFuncSetAttribute((const void *)patchnn3_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr3 = true;
+            }
+            hipLaunchKernelGGL(patchnn3_k, dim3((unsigned)(a.h_o * a.w_o)), dim3(NN_THREADS), lds3, s, b, TyT);
+        } else {
+            hipLaunchKernelGGL(patchnn2_k, dim3((unsigned)(a.h_o * a.w_o)), dim3(NN_THREADS), lds, s, b);
+        }
         VL3D_CHECK_LAUNCH();
         return VL3D_OK;
     }

@@ -5,6 +5,7 @@ robust loss run in the HIP library (csrc/vl3d_loss.hip); patches are never mater
 the macro-block loop of the reference (a pure memory cap that does not change the result, utils_vid.py:323-342)
 is not needed.
 """
+import os
 import warnings
 
 import torch
@@ -76,7 +77,7 @@ def _loss_desc(x, y, patch_size, patcht_size, stride, stridet, alpha):
     d.alpha = 0.0 if alpha is None else float(alpha)
     d.x_sc, d.x_st, d.x_sr = x.stride(0), x.stride(1), x.stride(2)
     d.y_sc, d.y_st, d.y_sr = y.stride(0), y.stride(1), y.stride(2)
-    d.variant = 0
+    d.variant = int(os.environ.get("VL3D_LOSS_VARIANT", "0"))   # measurement hook (A/B of the patch-NN kernels)
     return d
 
 
