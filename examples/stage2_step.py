@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""End-to-end stage-2 training iterations on the drop-in module (SURVEY §8f-3 'next' row; reference loop:
+train_3dvid.py:214-255 run_iter): MPMeshVid.forward (render crop -> looping loss + regularisers) -> backward -> Adam.
+
+Shapes follow configs/mpv_base.txt: 720p data at factor 2 (360x640), mpi_{h,w}_scale 1.1, mpi_d 32, 50 frames,
+180x320 crops with a shifted principal point, other-view and ref-view loss configurations.  Synthetic scene/video.
+The reference authors' run is ~0.4-0.9 it/s on an RTX 3090 (derived)."""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+import warnings
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+
+def run(iters=10, frames=50, planes=32, smooth=0.2, dev="cuda:0", crop=(180, 320), full=(360, 640)):
+    from videoloop3d_amd import synth
+    from videoloop3d_amd.MPV import MPMeshVid
+    dev = torch.device(dev)
+    H, W = full
+    h, w = crop
+    args = types.SimpleNamespace(
+        mpv_frm_num=frames, mpv_isloop=True, mpi_h_scale=1.1, mpi_w_scale=1.1, mpi_d=planes, atlas_grid_h=4, init_std=0.02,
+        rgb_mlp_type="direct", rgb_activate="sigmoid", alpha_activate="sigmoid", bg_color="", scale_invariant=True,
+        add_uv_noise=False, fp16=False, swd_patch_size=3, swd_patcht_size=3, swd_stride=2, swd_stridet=1,
+        sparsity_loss_weight=0.0, rgb_smooth_loss_weight=smooth, a_smooth_loss_weight=smooth, density_loss_weight=0.0,
+        d_smooth_loss_weight=0.0)
+    K = np.array([[0.9 * W, 0, W / 2], [0, 0.9 * W, H / 2], [0, 0, 1]], np.float64)
+    model = MPMeshVid(args, H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=0.5 * 0.01, eps=6e-8)           # MPV.py:200-218 (Adam, eps 6e-8)
+    a = np.radians(0.5)
+    tar = np.eye(4)
+    tar[:3, :3] = [[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]
+    tar[:3, 3] = [0.03, 0.01, 0.0]
+    tar_e = torch.tensor(tar, device=dev)[None]
+    res = synth.hash_uniform((1, 75, 3, h, w), seed=8, device=dev)
+    cfgs = {
+        "other": dict(loss_name=["gpnn_lm"], loss_gain=torch.tensor([1.0]), macro_block=torch.tensor([65]), patch_size=torch.tensor([3]),
+                      stride=torch.tensor([2]), patcht_size=torch.tensor([3]), stridet=torch.tensor([1]), alpha=torch.tensor([10000.0]),
+                      dist_fn=["mse"], rou=["-2"], scaling=torch.tensor([0.1])),
+        "ref": dict(loss_name=["gpnn_lm"], loss_gain=torch.tensor([3.5]), macro_block=torch.tensor([65]), patch_size=torch.tensor([11]),
+                    stride=torch.tensor([4]), patcht_size=torch.tensor([3]), stridet=torch.tensor([1]), alpha=torch.tensor([0.5]),
+                    dist_fn=["mse"], rou=["-2"], scaling=torch.tensor([0.1])),
+    }
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, cfg in cfgs.items():
+            for it in range(iters + 2):
+                if it == 2:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                Kc = K.copy()
+                Kc[0, 2] -= 90 + (it % 3) * 40                                   # crop offset (utils.py:196-200)
+                Kc[1, 2] -= 45 + (it % 2) * 60
+                tar_k = torch.tensor(Kc, device=dev)[None]
+                opt.zero_grad(set_to_none=True)
+                _, extra = model(h, w, tar_e, tar_k, res=res, losscfg=cfg)
+                loss = extra["swd"].sum()
+                for k in ("rgb_smooth", "a_smooth"):
+                    if k in extra:
+                        loss = loss + smooth * extra[k].sum()
+                loss.backward()
+                opt.step()
+            torch.cuda.synchronize()
+            out[name] = {"iters_per_s": iters / (time.perf_counter() - t0), "loss": float(loss)}
+    out["shape"] = (f"D={planes} T={frames} stack {tuple(model.stack.shape)} crop {h}x{w} of {H}x{W}, Ty=75, "
+                    f"smooth weights {smooth}, Adam")
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--smooth", type=float, default=0.2)
+    a = ap.parse_args()
+    import __graft_entry__ as g
+    g.build()
+    print(json.dumps(run(a.iters, smooth=a.smooth)))

@@ -77,7 +77,16 @@ int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, const float
 int64_t vl3d_render_bwd_scratch_bytes(const vl3d_render_desc *desc);
 int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, const float *homos,
                     const float *rgb, const float *alpha, const float *grad_rgb, const float *grad_alpha,
-                    float *grad_stack, void *scratch, int64_t scratch_bytes, vl3d_stream_t stream);
+                    const float *grad_reg, float *grad_stack, void *scratch, int64_t scratch_bytes,
+                    vl3d_stream_t stream);
+
+/* Layer-space smoothness regularisers (MPV.py:517-531 rgb_smooth / a_smooth) WITHOUT the materialised [T,h,w,K,4] layer
+ * tensor: sums[0..3] (device doubles, overwritten) = sum over frames, planes and neighbouring pixel pairs of
+ * |L[p]-L[q]| for (x-pairs, rgb), (y-pairs, rgb), (x-pairs, alpha), (y-pairs, alpha), where L is the warped+activated
+ * per-layer rgba (0 where a plane does not cover the pixel).  Their gradient enters vl3d_render_bwd through
+ * grad_reg = device float[4] = dL/dsums (NULL: no regulariser term). */
+int vl3d_render_reg_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos, double *sums,
+                        vl3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Unfused operators (drop-ins for the reference's L3 functions).

@@ -306,8 +306,12 @@ def test_bwd_tile_720p_matches_atomics(dev):
         assert torch.isfinite(gs).all()
         out[variant] = gs
     scale = float(out[1].abs().max())
-    assert maxabs(out[2], out[1]) <= 2e-5 * max(1.0, scale)
-    assert maxabs(out[3], out[1]) <= 2e-5 * max(1.0, scale)
+    # the gather order of the owner-computes kernel is fixed per texel -> independent of the region height, bit for bit
+    assert torch.equal(out[2], out[3])
+    # vs the atomics kernel: a handful of texels (14 of 2.4e8 here) differ by up to 5e-5 -- the owner-computes result is the
+    # one that agrees with the CPU oracle there (profiles/debug_tile2.py: 1.8e-5 vs 5.2e-5), so only the tolerance is asserted
+    assert maxabs(out[3], out[1]) <= TOL * max(1.0, scale)
+    assert float(((out[3] - out[1]).abs() > 2e-5).float().mean()) <= 1e-6
 
 
 def test_render_band_from_local_rows_matches_full(dev):
@@ -332,3 +336,40 @@ def test_render_band_from_local_rows_matches_full(dev):
             (gl,) = torch.autograd.grad(rgb, local, g[:, b.row0:b.row0 + b.rows])
             g_acc[:, :, b.src0:b.src1] += gl
     assert maxabs(g_acc, g_full) <= 1e-5
+
+
+@pytest.mark.parametrize("feasible", [True, False])
+@pytest.mark.parametrize("spec_name", ["mpv", "utils_mpi"])
+def test_fused_smoothness_regularisers(dev, feasible, spec_name):
+    """rgb_smooth / a_smooth (MPV.py:517-531) from the fused kernels == finite differences of the materialised layers
+    (oracle), value and gradient; `feasible=False` uses 2x magnification so the backward falls back to the atomics kernel."""
+    from videoloop3d_amd.render import RenderSpec, render_planes_with_smoothness
+    D, T, Hs, Ws, H, W = 5, 2, 90, 130, 83, 121
+    kw_p, kw_o = SPECS[spec_name]
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=17) * 0.5
+    if feasible:
+        th = math.radians(1.5)
+        Rz = torch.tensor([[math.cos(th) * 1.03, -math.sin(th), 3.0], [math.sin(th), math.cos(th) * 0.98, 2.0], [1e-5, -2e-5, 1.0]])
+        homos = bench_homos(D, H, W, scale=1.5) @ Rz
+    else:
+        homos = torch.tensor([[0.5, 0, 10.0], [0, 0.5, 8.0], [0, 0, 1.0]]) @ bench_homos(D, H, W, scale=1.0)
+    g_rgb = synth.hash_uniform((T, H, W, 3), seed=5) - 0.5
+    coef = torch.tensor([0.7, -0.4, 1.3, 0.9])
+    s_cpu = stack.clone().requires_grad_(True)
+    rgb_o, alpha_o, _, L = MO.render_planes(s_cpu, homos, H, W, MO.RenderSpec(**kw_o), return_layers=True)   # L: T,H,W,D,4
+    sums_o = torch.stack([(L[:, :, :-1, :, :3] - L[:, :, 1:, :, :3]).abs().sum(), (L[:, :-1, :, :, :3] - L[:, 1:, :, :, :3]).abs().sum(),
+                          (L[:, :, :-1, :, 3] - L[:, :, 1:, :, 3]).abs().sum(), (L[:, :-1, :, :, 3] - L[:, 1:, :, :, 3]).abs().sum()])
+    loss_o = (rgb_o * g_rgb).sum() + (sums_o * coef).sum() * 1e-3
+    (gs_o,) = torch.autograd.grad(loss_o, s_cpu)
+    s_gpu = stack.to(dev).requires_grad_(True)
+    rgb, alpha, sums = render_planes_with_smoothness(s_gpu, homos.to(dev), H, W, RenderSpec(**kw_p))
+    loss = (rgb * g_rgb.to(dev)).sum() + (sums * coef.to(dev)).sum() * 1e-3
+    (gs,) = torch.autograd.grad(loss, s_gpu)
+    assert _tile_ran() == (1 if feasible else 0)
+    assert maxabs(sums, sums_o) <= 2e-5 * float(sums_o.abs().max())
+    assert maxabs(rgb, rgb_o) <= TOL
+    # sign() of near-zero layer differences may flip with 1-ulp sampling differences: compare with a robust criterion
+    diff = (gs.cpu() - gs_o).abs()
+    scale = float(gs_o.abs().max())
+    assert float((diff > 1e-4 * max(1.0, scale)).float().mean()) <= 1e-4
+    assert float(diff.max()) <= 5e-3 * max(1.0, scale)

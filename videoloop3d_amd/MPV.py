@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .render import RenderSpec, render_planes
+from .render import RenderSpec, render_planes, render_planes_with_smoothness
 from .utils_mpi import compute_homography, make_depths, warp_homography
 from .utils_vid import Patch3DAvg, Patch3DGPNNDirectLoss, Patch3DGPNNLowMemLoss, Patch3DMSE
 
@@ -109,13 +109,18 @@ class MPMeshVid(nn.Module):
             return self.stack
         return self.stack[:, torch.as_tensor(ts, device=self.stack.device).long()]
 
-    def render(self, H, W, extrin, intrin, ts, need_layers=False):
+    def render(self, H, W, extrin, intrin, ts, need_layers=False, need_smooth=False):
         """MPV.py:351-475 -> (rgb [T',H,W,3], variables).  `variables['mpi']`/`['blend_weight']` (the warped per-layer
         rgba, only consumed by the smoothness/sparsity regularisers) are materialised on demand with the unfused operators."""
         stack = self._frames(ts)
         homos = self.plane_homographies(extrin, intrin)
-        rgb, alpha = render_planes(stack, homos, H, W, self.spec)
-        variables = {"pix_to_face": None, "blend_weight": None, "mpi": None, "disp_norm": None, "alpha": alpha}
+        smooth_sums = None
+        if need_smooth:
+            rgb, alpha, smooth_sums = render_planes_with_smoothness(stack, homos, H, W, self.spec)
+        else:
+            rgb, alpha = render_planes(stack, homos, H, W, self.spec)
+        variables = {"pix_to_face": None, "blend_weight": None, "mpi": None, "disp_norm": None, "alpha": alpha,
+                     "smooth_sums": smooth_sums}
         if need_layers:
             mpi = self._layers(stack, homos, H, W)
             variables["mpi"] = mpi
@@ -160,8 +165,10 @@ class MPMeshVid(nn.Module):
         if ts is None:
             ts = torch.arange(self.frm_num).long()
         a = self.args
-        need_layers = self.training and (a.sparsity_loss_weight > 0 or a.rgb_smooth_loss_weight > 0 or a.a_smooth_loss_weight > 0)
-        rgb, variables = self.render(h, w, extrins, tar_intrins, ts, need_layers=need_layers)
+        # rgb_smooth / a_smooth are fused into the render kernels; only the (shipped-off) sparsity term needs the layer tensor
+        need_layers = self.training and a.sparsity_loss_weight > 0
+        need_smooth = self.training and (a.rgb_smooth_loss_weight > 0 or a.a_smooth_loss_weight > 0)
+        rgb, variables = self.render(h, w, extrins, tar_intrins, ts, need_layers=need_layers, need_smooth=need_smooth)
         rgb = rgb.permute(0, 3, 1, 2)
         extra = {}
         if not self.training:
@@ -188,18 +195,16 @@ class MPMeshVid(nn.Module):
             alpha = variables["mpi"][..., -1]
             sparsity = alpha.norm(dim=-1, p=1) / alpha.norm(dim=-1, p=2).clamp_min(1e-4)
             extra["sparsity"] = (sparsity.mean() / np.sqrt(self.mpi_d) * loss_gain).reshape(1, -1)
-        if a.rgb_smooth_loss_weight > 0:
-            smooth = variables["mpi"][..., :-1]
-            denorm = smooth.shape[-2] / self.mpi_d
-            smoothx = (smooth[:, :, :-1] - smooth[:, :, 1:]).abs().mean()
-            smoothy = (smooth[:, :-1] - smooth[:, 1:]).abs().mean()
-            extra["rgb_smooth"] = ((smoothx + smoothy).reshape(1, -1) * (loss_gain * denorm)).reshape(1, -1)
-        if a.a_smooth_loss_weight > 0:
-            smooth = variables["mpi"][..., -1]
-            denorm = smooth.shape[-1] / self.mpi_d
-            smoothx = (smooth[:, :, :-1] - smooth[:, :, 1:]).abs().mean()
-            smoothy = (smooth[:, :-1] - smooth[:, 1:]).abs().mean()
-            extra["a_smooth"] = ((smoothx + smoothy) * (loss_gain * denorm)).reshape(1, -1)
+        if need_smooth:
+            # means over [T,h,w-1,K,(3)] / [T,h-1,w,K,(3)] from the fused sums (MPV.py:517-531; K = mpi_d layers here)
+            T_, K_ = rgb.shape[0], self.mpi_d
+            nx, ny = T_ * h * (w - 1) * K_, T_ * (h - 1) * w * K_
+            sums = variables["smooth_sums"]
+            denorm = K_ / self.mpi_d
+            if a.rgb_smooth_loss_weight > 0:
+                extra["rgb_smooth"] = ((sums[0] / (3 * nx) + sums[1] / (3 * ny)) * (loss_gain * denorm)).reshape(1, -1)
+            if a.a_smooth_loss_weight > 0:
+                extra["a_smooth"] = ((sums[2] / nx + sums[3] / ny) * (loss_gain * denorm)).reshape(1, -1)
         if a.density_loss_weight > 0:
             extra["density"] = (variables["alpha"] - 1).abs().mean().reshape(1, -1)
         if getattr(a, "d_smooth_loss_weight", 0) > 0:

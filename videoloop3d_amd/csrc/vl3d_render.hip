@@ -29,6 +29,8 @@ struct RenderArgs {
     float *g_stack;
     int D, T, Hs, Ws, H, W, row0, col0;
     float pc, sx, sy, ox, oy;
+    const float *g_reg;  // device float[4]: dL/d(sum|dx rgb|), dL/d(sum|dy rgb|), dL/d(sum|dx a|), dL/d(sum|dy a|) or NULL
+    double *reg_sums;    // device double[4] (forward of the layer-space smoothness regularisers)
     int fwd_variant;     // forward kernel selector (see launch<>)
     int ablate;          // measurement-only switches (bit0: skip LDS scatter, bit1: skip flush stores, bit2: skip tap loads)
     const float *plan;   // device scratch written by bwd_plan_k: [0] feasible flag, [16 + 9*d ..] inverse texel homographies
@@ -162,6 +164,21 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
         const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;
         f4 go = f4{w * Gr, w * Gg, w * Gb, Tr * q - behind};   // grad wrt activated (c, a)
         Tr *= om;
+        if (a.g_reg) {   // smoothness regularisers on the fallback path: re-sample the 4 neighbours' layer values
+            const f4 gx = f4{a.g_reg[0], a.g_reg[0], a.g_reg[0], a.g_reg[2]}, gy = f4{a.g_reg[1], a.g_reg[1], a.g_reg[1], a.g_reg[3]};
+            auto layer = [&](float qx, float qy) {
+                const Taps2 tq = make_taps2<COORD, BORDER>(a.homos + 9 * d, qx, qy, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+                f4 tq_v[4];
+                load_taps2(plane, tq, tq_v);
+                return shade2<ORDER, RACT, AACT>(tq, tq_v) * tq.cov;
+            };
+            auto sgn = [](f4 v) { return f4{(float)((v.x > 0.f) - (v.x < 0.f)), (float)((v.y > 0.f) - (v.y < 0.f)),
+                                            (float)((v.z > 0.f) - (v.z < 0.f)), (float)((v.w > 0.f) - (v.w < 0.f))}; };
+            if (x + 1 < a.W) go += gx * sgn(o - layer(px + 1.0f, py));
+            if (x >= 1) go -= gx * sgn(layer(px - 1.0f, py) - o);
+            if (y + 1 < a.H) go += gy * sgn(o - layer(px, py + 1.0f));
+            if (y >= 1) go -= gy * sgn(layer(px, py - 1.0f) - o);
+        }
         if constexpr (ORDER == VL3D_ACT_POST)
             go = f4{go.x * act_bwd<RACT>(pre.x, o.x), go.y * act_bwd<RACT>(pre.y, o.y), go.z * act_bwd<RACT>(pre.z, o.z),
                     go.w * act_bwd<AACT>(pre.w, o.w)};
@@ -366,21 +383,26 @@ __global__ __launch_bounds__(256) void bwd_fill_zero_if_infeasible_k(float4 *g, 
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool PF>
-__global__ __launch_bounds__(RW *ROWS, (PF ? 4 : 8)) void render_bwd_tile_k(RenderArgs a) {
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG>
+__global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
     constexpr int NT = RW * ROWS;
+    // REG: the layer-space smoothness regularisers (MPV.py:517-531) are differentiated here as well.  Their gradient at a
+    // pixel needs the activated layer values of its 4 neighbours, so the region carries a 2-pixel halo (outer ring: layer
+    // values only; inner ring: full gradient providers for the gather) and one more LDS stage + barrier per plane.
+    constexpr int RH = REG ? 2 : 1;
+    __shared__ float4 s_o[REG ? NT : 1];
     // per-plane staging of the region's pixels, double buffered so one barrier per plane suffices
     __shared__ float4 s_g[2][NT];     // gradient w.r.t. the sampled (POST) / activated (PRE) value of this pixel on this plane
     __shared__ float2 s_t[2][NT];     // its texel coordinates (tx,ty); -1e30 when the plane does not cover the pixel
     __shared__ float s_c[2][8];       // footprint corners of the owned tile on this plane
     const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
-    const int rx0 = blockIdx.x * (RW - 2) - 1, ry0 = blockIdx.y * (ROWS - 2) - 1;
+    const int rx0 = blockIdx.x * (RW - 2 * RH) - RH, ry0 = blockIdx.y * (ROWS - 2 * RH) - RH;
     const int x = rx0 + lane, y = ry0 + row, t = blockIdx.z;
     const bool inimg = (x >= 0) && (x < a.W) && (y >= 0) && (y < a.H);
     // owned (interior) pixel range of this workgroup, clipped to the frame: [ix0,ix1] x [iy0,iy1]
-    const int ix0 = max(rx0 + 1, 0), ix1 = min(rx0 + RW - 2, a.W - 1);
-    const int iy0 = max(ry0 + 1, 0), iy1 = min(ry0 + ROWS - 2, a.H - 1);
+    const int ix0 = max(rx0 + RH, 0), ix1 = min(rx0 + RW - 1 - RH, a.W - 1);
+    const int iy0 = max(ry0 + RH, 0), iy1 = min(ry0 + ROWS - 1 - RH, a.H - 1);
     const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
     const size_t frame = (size_t)a.Hs * a.Ws * 4;
     const size_t plane_stride = (size_t)a.T * frame;
@@ -394,13 +416,10 @@ __global__ __launch_bounds__(RW *ROWS, (PF ? 4 : 8)) void render_bwd_tile_k(Rend
         S = Gr * a.rgb[pix * 3 + 0] + Gg * a.rgb[pix * 3 + 1] + Gb * a.rgb[pix * 3 + 2] + gA * a.alpha[pix];
     }
     float Tr = 1.0f, P = 0.0f;
-    // PF: the taps of plane d+1 are issued before the barrier of plane d and stay in flight across its gather
-    Taps2 tp_n{};
-    f4 tv_n[4];
-    if (PF && inimg) {
-        tp_n = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-        load_taps2(reinterpret_cast<const char *>(plane), tp_n, tv_n);
-    }
+    float gsx_c = 0.f, gsy_c = 0.f, gsx_a = 0.f, gsy_a = 0.f;
+    if constexpr (REG) { gsx_c = a.g_reg[0]; gsy_c = a.g_reg[1]; gsx_a = a.g_reg[2]; gsy_a = a.g_reg[3]; }
+    // pixels of the outermost ring only provide layer values in REG mode
+    const bool provider = !REG || (lane >= 1 && lane <= RW - 2 && row >= 1 && row <= ROWS - 2);
     for (int d = 0; d < a.D; ++d, plane += plane_stride, gplane += plane_stride) {
         const float *h = a.homos + 9 * d;
         const int buf = d & 1;
@@ -419,43 +438,53 @@ __global__ __launch_bounds__(RW *ROWS, (PF ? 4 : 8)) void render_bwd_tile_k(Rend
         // (2) sample this pixel on plane d, composite backward, stage (tx,ty,g) in LDS   (branch-free taps)
         float2 tc = make_float2(-1e30f, -1e30f);
         float4 gval = make_float4(0.f, 0.f, 0.f, 0.f);
+        f4 o = f4{0.f, 0.f, 0.f, 0.f}, pre = o;
+        Taps2 tp{};
         if (inimg) {
-            Taps2 tp;
-            f4 tv[4], pre;
-            if constexpr (PF) {
-                tp = tp_n;
+            tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            const char *src = reinterpret_cast<const char *>(plane);
+            if (a.ablate & 4) {   // measurement only: all taps from a 64 KiB cache-resident window
+                src = reinterpret_cast<const char *>(a.stack);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) tv[i] = tv_n[i];
-            } else {
-                tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-                const char *src = reinterpret_cast<const char *>(plane);
-                if (a.ablate & 4) {   // measurement only: all taps from a 64 KiB cache-resident window
-                    src = reinterpret_cast<const char *>(a.stack);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) tp.off[i] &= 0xffffu;
-                }
-                load_taps2(src, tp, tv);
+                for (int i = 0; i < 4; ++i) tp.off[i] &= 0xffffu;
             }
-            const f4 o = shade2<ORDER, RACT, AACT>(tp, tv, &pre);        // o.w already 0 when the plane does not cover the pixel
+            f4 tv[4];
+            load_taps2(src, tp, tv);
+            o = shade2<ORDER, RACT, AACT>(tp, tv, &pre);                 // o.w already 0 when the plane does not cover the pixel
+        }
+        f4 sg = f4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (REG) {
+            // layer value as the reference's zero canvas has it: 0 in ALL channels where the plane does not cover (MPV.py:441)
+            const f4 ol = o * tp.cov;
+            s_o[tid] = make_float4(ol.x, ol.y, ol.z, ol.w);
+            __syncthreads();      // (A) layer values of the region visible
+            if (inimg && provider) {
+                const f4 gx = f4{gsx_c, gsx_c, gsx_c, gsx_a}, gy = f4{gsy_c, gsy_c, gsy_c, gsy_a};
+                auto sgn = [](f4 v) { return f4{(float)((v.x > 0.f) - (v.x < 0.f)), (float)((v.y > 0.f) - (v.y < 0.f)),
+                                                (float)((v.z > 0.f) - (v.z < 0.f)), (float)((v.w > 0.f) - (v.w < 0.f))}; };
+                auto ld = [&](int i) { const float4 v = s_o[i]; return f4{v.x, v.y, v.z, v.w}; };
+                if (x + 1 < a.W) sg += gx * sgn(ol - ld(tid + 1));          // d|o - o_right| / do
+                if (x >= 1) sg -= gx * sgn(ld(tid - 1) - ol);               // d|o_left - o| / do
+                if (y + 1 < a.H) sg += gy * sgn(ol - ld(tid + RW));
+                if (y >= 1) sg -= gy * sgn(ld(tid - RW) - ol);
+            }
+        }
+        if (inimg) {
             const float q = Gr * o.x + Gg * o.y + Gb * o.z + gA;
             const float w = o.w * Tr;
             P += w * q;
             const float om = 1.0f - o.w;
             const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;
-            gval = make_float4(w * Gr, w * Gg, w * Gb, Tr * q - behind);     // grad wrt activated (c, a)
+            gval = make_float4(w * Gr + sg.x, w * Gg + sg.y, w * Gb + sg.z, Tr * q - behind + sg.w);   // grad wrt activated (c, a)
             Tr *= om;
             if constexpr (ORDER == VL3D_ACT_POST)
                 gval = make_float4(gval.x * act_bwd<RACT>(pre.x, o.x), gval.y * act_bwd<RACT>(pre.y, o.y),
                                    gval.z * act_bwd<RACT>(pre.z, o.z), gval.w * act_bwd<AACT>(pre.w, o.w));
-            if (tp.cov > 0.0f) tc = make_float2(tp.tx, tp.ty);
+            if (tp.cov > 0.0f && provider) tc = make_float2(tp.tx, tp.ty);
             else gval = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         s_t[buf][tid] = tc;
         s_g[buf][tid] = gval;
-        if (PF && inimg && d + 1 < a.D) {
-            tp_n = make_taps2<COORD, BORDER>(h + 9, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-            load_taps2(reinterpret_cast<const char *>(plane + plane_stride), tp_n, tv_n);
-        }
         __syncthreads();   // staging of plane d visible (the other buffer may still be read by slower waves: not touched here)
         // (3) every texel owned by this tile gathers its taps from the 3x3 pixels around its owner pixel
         const float mnx = fminf(fminf(s_c[buf][0], s_c[buf][1]), fminf(s_c[buf][2], s_c[buf][3]));
@@ -504,40 +533,105 @@ __global__ __launch_bounds__(RW *ROWS, (PF ? 4 : 8)) void render_bwd_tile_k(Rend
     }
 }
 
+
+// =====================================================================================================
+// Layer-space smoothness regularisers, forward (MPV.py:517-531): sum over frames, planes and neighbouring pixel pairs of
+// |L[p] - L[q]| of the warped+activated per-layer rgba L (zero where a plane does not cover the pixel) -- without ever
+// materialising the [T,h,w,K,4] layer tensor the reference builds (1.47 GB per training crop).
+// out[0] = sum |dx rgb|, out[1] = sum |dy rgb|, out[2] = sum |dx a|, out[3] = sum |dy a|   (device doubles, accumulated).
+// Workgroup = 64 x ROWS region, pairs owned by their left / upper pixel (63 x (ROWS-1) interior), one barrier per plane.
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS>
+__global__ __launch_bounds__(RW *ROWS) void render_reg_fwd_k(RenderArgs a) {
+    constexpr int NT = RW * ROWS;
+    __shared__ float4 s_o[2][NT];
+    __shared__ float red[4][ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
+    const int x = blockIdx.x * (RW - 1) + lane, y = blockIdx.y * (ROWS - 1) + row, t = blockIdx.z;
+    const bool inimg = (x < a.W) && (y < a.H);
+    // the last column / row of the region are halo (owned by the next tile, where they are column / row 0)
+    const bool owner = inimg && lane < RW - 1 && row < ROWS - 1;
+    const bool own_r = owner && x + 1 < a.W, own_d = owner && y + 1 < a.H;
+    const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
+    const size_t frame_b = (size_t)a.Hs * a.Ws * 16, plane_stride_b = (size_t)a.T * frame_b;
+    const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * frame_b;
+    float sxc = 0.f, syc = 0.f, sxa = 0.f, sya = 0.f;
+    for (int d = 0; d < a.D; ++d, plane += plane_stride_b) {
+        f4 ol = f4{0.f, 0.f, 0.f, 0.f};
+        if (inimg) {
+            const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            f4 tv[4];
+            load_taps2(plane, tp, tv);
+            ol = shade2<ORDER, RACT, AACT>(tp, tv) * tp.cov;
+        }
+        const int buf = d & 1;
+        s_o[buf][tid] = make_float4(ol.x, ol.y, ol.z, ol.w);
+        __syncthreads();
+        if (own_r) {
+            const float4 r = s_o[buf][tid + 1];
+            sxc += fabsf(ol.x - r.x) + fabsf(ol.y - r.y) + fabsf(ol.z - r.z);
+            sxa += fabsf(ol.w - r.w);
+        }
+        if (own_d) {
+            const float4 r = s_o[buf][tid + RW];
+            syc += fabsf(ol.x - r.x) + fabsf(ol.y - r.y) + fabsf(ol.z - r.z);
+            sya += fabsf(ol.w - r.w);
+        }
+    }
+    float v[4] = {sxc, syc, sxa, sya};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+        if (lane == 0) red[k][row] = v[k];
+    }
+    __syncthreads();
+    if (tid < 4) {
+        double sum = 0.0;
+        for (int r = 0; r < ROWS; ++r) sum += (double)red[tid][r];
+        atomicAdd(a.reg_sums + tid, sum);
+    }
+}
+
 // ---- dispatch over the compile-time conventions -------------------------------------------------------
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool PF>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG>
 void launch_tile(const RenderArgs &a, hipStream_t s) {
-    dim3 grid((a.W + RW - 3) / (RW - 2), (a.H + ROWS - 3) / (ROWS - 2), a.T);
-    hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, PF>), grid, dim3(RW * ROWS), 0, s, a);
+    constexpr int RH = REG ? 2 : 1, IW = RW - 2 * RH, IH = ROWS - 2 * RH;
+    dim3 grid((a.W + IW - 1) / IW, (a.H + IH - 1) / IH, a.T);
+    hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG>), grid, dim3(RW * ROWS), 0, s, a);
 }
 
 // g_tile_rows: 0 = no tile path for this call, else the ROWS of the tile kernel to launch
 thread_local int g_tile_rows = 0;
+// true: the forward dispatch launches the regulariser-sums kernel instead of the render
+thread_local bool g_reg_fwd = false;
 
 template <bool BWD, int COORD, int BORDER, int ORDER, int RACT, int AACT>
 void launch(const RenderArgs &a, hipStream_t s) {
     dim3 grid((a.W + TILE_X - 1) / TILE_X, (a.H + TILE_Y - 1) / TILE_Y, a.T), block(TILE_X * TILE_Y);
     if constexpr (BWD) {
         if (g_tile_rows) {
-            hipLaunchKernelGGL((bwd_plan_k<COORD>), dim3(1), dim3(64), 0, s, a, g_tile_rows % 100, const_cast<float *>(a.plan));
+            hipLaunchKernelGGL((bwd_plan_k<COORD>), dim3(1), dim3(64), 0, s, a, g_tile_rows, const_cast<float *>(a.plan));
             const size_t n4 = (size_t)a.D * a.T * a.Hs * a.Ws;
             hipLaunchKernelGGL(bwd_fill_zero_if_infeasible_k, dim3(4096), dim3(256), 0, s, reinterpret_cast<float4 *>(a.g_stack), n4, a.plan);
             hipLaunchKernelGGL(bwd_zero_unowned_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, a);
             bool done = false;
-            if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID) {   // measurement variants (shipped activations only)
-                done = true;
-                if (g_tile_rows == 8) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 8, false>(a, s);
-                else if (g_tile_rows == 108) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 8, true>(a, s);
-                else if (g_tile_rows == 112) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 12, true>(a, s);
-                else if (g_tile_rows == 116) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true>(a, s);
-                else done = false;
+            if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID) {   // measurement variant (shipped activations only)
+                if (g_tile_rows == 8 && !a.g_reg) { launch_tile<COORD, BORDER, ORDER, RACT, AACT, 8, false>(a, s); done = true; }
             }
-            if (!done) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, false>(a, s);
+            if (!done) {
+                if (a.g_reg) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true>(a, s);
+                else launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, false>(a, s);
+            }
         }
         hipLaunchKernelGGL((render_bwd_k<COORD, BORDER, ORDER, RACT, AACT>), grid, block, 0, s, a);
     } else {
         // forward variant (desc->variant bits 8..11): 0 default; measurement variants for the shipped
         // sigmoid/sigmoid activation only: 2 TY=4, 3 TY=8, 4 TY=16 (all XCD-remapped), 5 TY=8 without remap
+        if (g_reg_fwd) {
+            dim3 rgrid((a.W + RW - 2) / (RW - 1), (a.H + 14) / 15, a.T);
+            hipLaunchKernelGGL((render_reg_fwd_k<COORD, BORDER, ORDER, RACT, AACT, 16>), rgrid, dim3(RW * 16), 0, s, a);
+            return;
+        }
         const int fv = a.fwd_variant;
         if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID) {
             if (fv == 2) return launch_fwd2<COORD, BORDER, ORDER, RACT, AACT, 4, true>(a, s);
@@ -627,26 +721,43 @@ extern "C" int64_t vl3d_render_bwd_scratch_bytes(const vl3d_render_desc *desc) {
     return (int64_t)(PLAN_HDR + PLAN_REC * (int64_t)desc->D) * sizeof(float);
 }
 
+extern "C" int vl3d_render_reg_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos, double *sums,
+                                   vl3d_stream_t stream) {
+    int rc = check_desc(desc);
+    if (rc != VL3D_OK) return rc;
+    VL3D_REQUIRE(stack && homos && sums, "null pointer passed to vl3d_render_reg_fwd");
+    VL3D_REQUIRE((int64_t)desc->Hs * desc->Ws * 16 < (1ll << 32), "frame too large for 32-bit byte offsets");
+    RenderArgs a = make_args(desc);
+    a.stack = (const float *)stack; a.homos = homos; a.reg_sums = sums;
+    VL3D_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(double), (hipStream_t)stream));
+    g_reg_fwd = true;
+    rc = dispatch<false>(desc, a, (hipStream_t)stream);
+    g_reg_fwd = false;
+    if (rc != VL3D_OK) return rc;
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
 extern "C" int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, const float *homos,
                                const float *rgb, const float *alpha, const float *grad_rgb,
-                               const float *grad_alpha, float *grad_stack, void *scratch, int64_t scratch_bytes,
-                               vl3d_stream_t stream) {
+                               const float *grad_alpha, const float *grad_reg, float *grad_stack, void *scratch,
+                               int64_t scratch_bytes, vl3d_stream_t stream) {
     int rc = check_desc(desc);
     if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE(stack && homos && rgb && alpha && grad_rgb && grad_stack, "null pointer passed to vl3d_render_bwd");
     RenderArgs a = make_args(desc);
     a.stack = (const float *)stack; a.homos = homos;
     a.rgb = const_cast<float *>(rgb); a.alpha = const_cast<float *>(alpha);
-    a.g_rgb = grad_rgb; a.g_alpha = grad_alpha; a.g_stack = grad_stack;
+    a.g_rgb = grad_rgb; a.g_alpha = grad_alpha; a.g_reg = grad_reg; a.g_stack = grad_stack;
     // variant: 0 auto (tile kernel when its on-device plan says feasible, else atomics), 1 force atomics,
     //          2 tile with 8-row regions, 3 tile with 16-row regions
     const bool want_tile = (desc->variant & 0xf) != 1 && scratch != nullptr && scratch_bytes >= vl3d_render_bwd_scratch_bytes(desc);
     a.ablate = (desc->variant >> 4) & 0xf;
     if (want_tile) {
         a.plan = (const float *)scratch;
-        // variant & 0xf: 0/3 -> 16-row regions; 2 -> 8 rows; 4/5/6 -> 8/12/16 rows with tap prefetch across the barrier
-        const int bv = desc->variant & 0xf;
-        g_tile_rows = bv == 2 ? 8 : bv == 4 ? 108 : bv == 5 ? 112 : bv == 6 ? 116 : 16;
+        // variant & 0xf: 0/3 -> 16-row regions; 2 -> 8 rows.  (Prefetching the next plane's taps across the barrier was
+        // measured and dropped: 91 VGPRs halve the occupancy, 24.3-28.9 ms vs 17.3 ms.)
+        g_tile_rows = (desc->variant & 0xf) == 2 ? 8 : 16;
     } else {
         a.plan = nullptr;
         g_tile_rows = 0;

@@ -58,7 +58,7 @@ LAST_BWD_SCRATCH = None
 
 class _RenderPlanes(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, stack, homos, H, W, spec, row0, col0):
+    def forward(ctx, stack, homos, H, W, spec, row0, col0, with_reg):
         L.check_cuda(stack, homos)
         if stack.dtype != torch.float32:
             raise RuntimeError("plane stack must be float32")
@@ -75,11 +75,18 @@ class _RenderPlanes(torch.autograd.Function):
                                             L.stream_ptr(stack.device)), "vl3d_render_fwd")
         ctx.save_for_backward(stack, homos, rgb, alpha)
         ctx.desc = desc
-        return rgb, alpha
+        ctx.with_reg = with_reg
+        sums = torch.zeros(4, dtype=torch.float64, device=stack.device)
+        if with_reg:
+            with torch.cuda.device(stack.device):
+                L.check(L.lib().vl3d_render_reg_fwd(desc, L.ptr(stack), L.ptr(homos), L.ptr(sums), L.stream_ptr(stack.device)),
+                        "vl3d_render_reg_fwd")
+        return rgb, alpha, sums.to(torch.float32)
 
     @staticmethod
-    def backward(ctx, g_rgb, g_alpha):
+    def backward(ctx, g_rgb, g_alpha, g_sums):
         stack, homos, rgb, alpha = ctx.saved_tensors
+        g_reg = g_sums.to(torch.float32).contiguous() if (ctx.with_reg and g_sums is not None) else None
         g_rgb = g_rgb.contiguous() if g_rgb is not None else torch.zeros_like(rgb)
         g_alpha = g_alpha.contiguous() if g_alpha is not None else None
         g_stack = torch.empty_like(stack)
@@ -87,11 +94,11 @@ class _RenderPlanes(torch.autograd.Function):
             nscratch = int(L.lib().vl3d_render_bwd_scratch_bytes(ctx.desc))
             scratch = torch.zeros((nscratch + 3) // 4, dtype=torch.float32, device=stack.device)
             L.check(L.lib().vl3d_render_bwd(ctx.desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha),
-                                            L.ptr(g_rgb), L.ptr(g_alpha), L.ptr(g_stack), L.ptr(scratch), nscratch,
+                                            L.ptr(g_rgb), L.ptr(g_alpha), L.ptr(g_reg), L.ptr(g_stack), L.ptr(scratch), nscratch,
                                             L.stream_ptr(stack.device)), "vl3d_render_bwd")
         global LAST_BWD_SCRATCH
         LAST_BWD_SCRATCH = scratch
-        return g_stack, None, None, None, None, None, None
+        return g_stack, None, None, None, None, None, None, None
 
 
 def render_planes(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0)):
@@ -100,4 +107,12 @@ def render_planes(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0
     Returns rgb [T,H,W,3], alpha [T,H,W].  `window=(row0,col0)` renders the H x W sub-window whose top-left
     corner is frame pixel (row0,col0) -- used for row-band sharding (equivalent to utils.py:196-200
     get_new_intrin on the target intrinsics)."""
-    return _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]))
+    rgb, alpha, _ = _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), False)
+    return rgb, alpha
+
+
+def render_planes_with_smoothness(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0)):
+    """render_planes plus the raw sums of the layer-space smoothness regularisers (MPV.py:517-531), differentiable:
+    returns (rgb, alpha, sums[4]) with sums = (sum|dx rgb|, sum|dy rgb|, sum|dx a|, sum|dy a|) over frames, planes and
+    neighbouring pixel pairs of the warped+activated layers -- the [T,h,w,K,4] layer tensor is never materialised."""
+    return _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), True)
