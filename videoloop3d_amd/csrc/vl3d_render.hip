@@ -55,18 +55,21 @@ __device__ __forceinline__ float fast_rcp(float z) {
 // (x, y) / z with one refined reciprocal and one residual correction per quotient: agrees with the IEEE quotients the
 // reference / oracle compute to within rounding of the last bit, at a third of the instruction count (packed math).
 __device__ __forceinline__ f2 fast_div2(f2 xy, float z) {
+    // explicit FMAs: every kernel that inlines this gets the same instruction sequence, hence bit-identical coordinates
     const float rz = fast_rcp(z);
-    f2 q = xy * rz;
-    const f2 e = xy - q * z;
-    return q + e * rz;
+    const f2 rz2 = f2{rz, rz}, z2 = f2{z, z};
+    const f2 q = xy * rz2;
+    const f2 e = __builtin_elementwise_fma(-q, z2, xy);
+    return __builtin_elementwise_fma(e, rz2, q);
 }
 
 template <int COORD, int BORDER>
 __device__ __forceinline__ Taps2 make_taps2(const float *__restrict__ h, float px, float py, int Hs, int Ws,
                                             float sx, float sy, float ox, float oy) {
     Taps2 t;
-    const f2 XY = f2{h[0], h[3]} * px + (f2{h[1], h[4]} * py + f2{h[2], h[5]});
-    const float Z = h[6] * px + (h[7] * py + h[8]);
+    const f2 px2 = f2{px, px}, py2 = f2{py, py};
+    const f2 XY = __builtin_elementwise_fma(f2{h[0], h[3]}, px2, __builtin_elementwise_fma(f2{h[1], h[4]}, py2, f2{h[2], h[5]}));
+    const float Z = fmaf(h[6], px, fmaf(h[7], py, h[8]));
     const f2 pxy = fast_div2(XY, Z);
     const float tx = texel_coord<COORD>(pxy.x, (float)Ws / 2.0f, (float)(Ws - 1), sx, ox);
     const float ty = texel_coord<COORD>(pxy.y, (float)Hs / 2.0f, (float)(Hs - 1), sy, oy);
