@@ -39,8 +39,11 @@ def parse():
     ap.add_argument("--W", type=int, default=1280)
     ap.add_argument("--spec", default="mpv", choices=["mpv", "utils_mpi"])
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--stack-dtype", default="f32", choices=["f32", "f16"],
+                    help="storage type of the plane stack (f16 = cfg5 of BASELINE.json; arithmetic is fp32 either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-loss", action="store_true")
+    ap.add_argument("--no-stage2", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--loss-steps", type=int, default=5)
     return ap.parse_args()
@@ -137,7 +140,8 @@ def main():
 
     # ---- inputs resident in HBM before the timed region ------------------------------------------------------------------
     if world == 1:
-        stack = synth.make_plane_stack(D, T, Hs, Ws, seed=2, device=dev).requires_grad_(True)
+        stack = synth.make_plane_stack(D, T, Hs, Ws, seed=2, device=dev,
+                                       dtype=torch.float16 if a.stack_dtype == "f16" else torch.float32).requires_grad_(True)
         g_rgb = (synth.hash_uniform((T, H, W, 3), seed=5, device=dev) - 0.5)
         band = None
     else:
@@ -209,8 +213,9 @@ def main():
     b_ms = sum(s.elapsed_time(e) for s, e in bwd_ms) / len(bwd_ms)
     my_pix = T * (H if band is None else band.rows) * W
     # ALGORITHMIC bytes: fwd 16*D+12 B/pixel-frame, bwd 12 + 16*D (re-read) + 16*D (grad write) B/pixel-frame
-    fwd_bytes = my_pix * (16 * D + 12)
-    bwd_bytes = my_pix * (32 * D + 12)
+    tex = 8 if a.stack_dtype == "f16" else 16          # bytes per stack texel (the gradient is fp32 either way)
+    fwd_bytes = my_pix * (tex * D + 12)
+    bwd_bytes = my_pix * ((tex + 16) * D + 12)
 
     def roof(name, nbytes, ms):
         ach = nbytes / (ms * 1e-3) / 1e9
@@ -233,6 +238,7 @@ def main():
         "metric": "rendered Mpix/s (fwd+bwd) D=32 planes 720p", "value": value, "unit": "Mpix/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "stack_storage": a.stack_dtype,
         "config": {"workload": f"cfg3 stage-2 MPV render fwd+bwd: D={D} planes, T={T} frames, {H}x{W} (720p), "
                                f"{a.spec} convention, plane stack (D,T,H,W,4) fp32 resident in HBM",
                    "parallelism": "single GPU" if world == 1 else f"{world} row bands + 1 all-gather of the composited frame",
@@ -247,8 +253,18 @@ def main():
                 res["loss_native_crop"] = loss_bench(dev, 180, 320, T, 75, a.loss_steps)
             except Exception as e:   # the headline render number must still be reported
                 res["loss"] = {"error": repr(e)}
+        if not a.no_stage2:
+            try:    # end-to-end stage-2 iterations on the drop-in module (render crop + looping loss + fused regularisers + Adam)
+                stack = None
+                torch.cuda.empty_cache()
+                sys.path.insert(0, os.path.join(ROOT, "examples"))
+                import stage2_step
+                res["stage2_step"] = stage2_step.run(iters=10, dev=str(dev))
+                res["stage2_step"]["reference_estimate"] = "0.4-0.9 it/s on the authors' GPU (BASELINE.md, derived from README wall times)"
+            except Exception as e:
+                res["stage2_step"] = {"error": repr(e)}
         if not a.no_cpu_baseline:
-            del stack
+            stack = None
             torch.cuda.empty_cache()
             res["cpu_baseline"] = cpu_baseline(D, H, W, a.cpu_frames, a.spec)
         else:

@@ -371,3 +371,30 @@ def test_fused_smoothness_regularisers(dev, feasible, spec_name):
     scale = float(gs_o.abs().max())
     assert float((diff > 1e-4 * max(1.0, scale)).float().mean()) <= 1e-4
     assert float(diff.max()) <= 5e-3 * max(1.0, scale)
+
+
+@pytest.mark.parametrize("spec_name", ["mpv", "utils_mpi"])
+def test_fp16_plane_stack(dev, spec_name):
+    """cfg5 of BASELINE.json keeps the plane stack in fp16 (8-byte texels); arithmetic stays fp32, so the result equals the
+    fp32 path on the fp16-rounded stack (the reference's own --fp16 is 'do NOT use', config_parser.py:32-33: the oracle on
+    the rounded values is the parity definition)."""
+    from videoloop3d_amd.render import RenderSpec, render_planes, render_planes_with_smoothness
+    D, T, Hs, Ws, H, W = 6, 2, 100, 140, 93, 131
+    kw_p, kw_o = SPECS[spec_name]
+    stack16 = synth.make_plane_stack(D, T, Hs, Ws, seed=21).half()
+    homos = bench_homos(D, H, W, scale=1.5)
+    g_rgb = synth.hash_uniform((T, H, W, 3), seed=5) - 0.5
+    s_cpu = stack16.float().requires_grad_(True)
+    rgb_o, alpha_o, _ = MO.render_planes(s_cpu, homos, H, W, MO.RenderSpec(**kw_o))
+    (gs_o,) = torch.autograd.grad(rgb_o, s_cpu, g_rgb)
+    s_gpu = stack16.to(dev).requires_grad_(True)
+    rgb, alpha = render_planes(s_gpu, homos.to(dev), H, W, RenderSpec(**kw_p))
+    (gs,) = torch.autograd.grad(rgb, s_gpu, g_rgb.to(dev))
+    assert _tile_ran() == 1 and gs.dtype == torch.float16
+    assert maxabs(rgb, rgb_o) <= TOL and maxabs(alpha, alpha_o) <= TOL
+    assert maxabs(gs.float(), gs_o) <= 1e-3 * max(1e-3, float(gs_o.abs().max())) + 1e-6      # fp16 rounding of the returned gradient
+    # bit-identical to the fp32 kernels on the same (rounded) values, including the fused regulariser sums
+    s32 = stack16.float().to(dev).requires_grad_(True)
+    rgb32, _, sums32 = render_planes_with_smoothness(s32, homos.to(dev), H, W, RenderSpec(**kw_p))
+    rgb16, _, sums16 = render_planes_with_smoothness(s_gpu, homos.to(dev), H, W, RenderSpec(**kw_p))
+    assert torch.equal(rgb16, rgb32) and torch.equal(sums16, sums32)

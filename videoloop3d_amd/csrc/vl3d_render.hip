@@ -107,9 +107,19 @@ __device__ __forceinline__ Taps2 make_taps2(const float *__restrict__ h, float p
     return t;
 }
 
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+// one texel = 16 bytes (fp32 stack) or 8 bytes (fp16 stack, cfg5 of BASELINE.json; arithmetic stays fp32)
+template <bool F16>
+__device__ __forceinline__ f4 load_texel(const char *__restrict__ plane, unsigned off16) {
+    if constexpr (F16) return __builtin_convertvector(*reinterpret_cast<const h4 *>(plane + (off16 >> 1)), f4);
+    else return *reinterpret_cast<const f4 *>(plane + off16);
+}
+
+template <bool F16>
 __device__ __forceinline__ void load_taps2(const char *__restrict__ plane, const Taps2 &t, f4 v[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f4 *>(plane + t.off[i]);
+    for (int i = 0; i < 4; ++i) v[i] = load_texel<F16>(plane, t.off[i]);
 }
 
 template <int RACT, int AACT>
@@ -135,7 +145,7 @@ __device__ __forceinline__ f4 shade2(const Taps2 &t, const f4 v[4], f4 *pre_out 
 
 constexpr int TILE_X = 64, TILE_Y = 4;
 
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
 __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
     if (a.plan && reinterpret_cast<const int *>(a.plan)[0]) return;   // the tile path owns this call
     const int x = blockIdx.x * TILE_X + (threadIdx.x & (TILE_X - 1));
@@ -143,9 +153,10 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
     const int t = blockIdx.z;
     if (x >= a.W || y >= a.H) return;
     const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
+    constexpr size_t TEXB = F16 ? 8 : 16;
     const size_t frame = (size_t)a.Hs * a.Ws * 4;
     const size_t plane_stride = (size_t)a.T * frame;
-    const char *plane = reinterpret_cast<const char *>(a.stack + (size_t)t * frame);
+    const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * a.Hs * a.Ws * TEXB;
     char *gplane = reinterpret_cast<char *>(a.g_stack + (size_t)t * frame);
     const size_t pix = ((size_t)t * a.H + y) * a.W + x;
     const float Gr = a.g_rgb[pix * 3 + 0], Gg = a.g_rgb[pix * 3 + 1], Gb = a.g_rgb[pix * 3 + 2];
@@ -153,11 +164,11 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
     // S = sum_k w_k q_k with q_k = G.c_k + gA  ==  G.C + gA*A from the saved forward outputs
     const float S = Gr * a.rgb[pix * 3 + 0] + Gg * a.rgb[pix * 3 + 1] + Gb * a.rgb[pix * 3 + 2] + gA * a.alpha[pix];
     float Tr = 1.0f, P = 0.0f;
-    for (int d = 0; d < a.D; ++d, plane += plane_stride * 4, gplane += plane_stride * 4) {
+    for (int d = 0; d < a.D; ++d, plane += (size_t)a.T * a.Hs * a.Ws * TEXB, gplane += plane_stride * 4) {
         const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
         if (tp.cov == 0.0f) continue;
         f4 tv[4], pre;
-        load_taps2(plane, tp, tv);
+        load_taps2<F16>(plane, tp, tv);
         const f4 o = shade2<ORDER, RACT, AACT>(tp, tv, &pre);
         const float q = Gr * o.x + Gg * o.y + Gb * o.z + gA;
         const float w = o.w * Tr;
@@ -172,7 +183,7 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
             auto layer = [&](float qx, float qy) {
                 const Taps2 tq = make_taps2<COORD, BORDER>(a.homos + 9 * d, qx, qy, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
                 f4 tq_v[4];
-                load_taps2(plane, tq, tq_v);
+                load_taps2<F16>(plane, tq, tq_v);
                 return shade2<ORDER, RACT, AACT>(tq, tq_v) * tq.cov;
             };
             auto sgn = [](f4 v) { return f4{(float)((v.x > 0.f) - (v.x < 0.f)), (float)((v.y > 0.f) - (v.y < 0.f)),
@@ -215,7 +226,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool SWZ>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool SWZ, bool F16>
 __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles_x, int tiles_y) {
     int b = blockIdx.x;
     if constexpr (SWZ) b = xcd_remap(b, gridDim.x);
@@ -225,14 +236,14 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
     const int y = tile_y * TY + (threadIdx.x >> 6);
     if (x >= a.W || y >= a.H) return;
     const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
-    const size_t frame_b = (size_t)a.Hs * a.Ws * 16;
+    const size_t frame_b = (size_t)a.Hs * a.Ws * (F16 ? 8 : 16);
     const size_t plane_stride_b = (size_t)a.T * frame_b;
     const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * frame_b;
     float Tr = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, A = 0.f;
     // two register sets (A/B) so the taps of plane d+1 are in flight while plane d is shaded, without register copies
     Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy), tB = tA;
     f4 vA[4], vB[4];
-    load_taps2(plane, tA, vA);
+    load_taps2<F16>(plane, tA, vA);
 #define VL3D_COMPOSITE(T_, V_)                                        \
     {                                                                 \
         const f4 o = shade2<ORDER, RACT, AACT>(T_, V_);               \
@@ -243,13 +254,13 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
     for (int d = 0;;) {
         if (d + 1 < a.D) {
             tB = make_taps2<COORD, BORDER>(a.homos + 9 * (d + 1), px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-            load_taps2(plane + plane_stride_b, tB, vB);
+            load_taps2<F16>(plane + plane_stride_b, tB, vB);
         }
         VL3D_COMPOSITE(tA, vA)
         if (++d >= a.D) break;
         if (d + 1 < a.D) {
             tA = make_taps2<COORD, BORDER>(a.homos + 9 * (d + 1), px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-            load_taps2(plane + 2 * plane_stride_b, tA, vA);
+            load_taps2<F16>(plane + 2 * plane_stride_b, tA, vA);
         }
         VL3D_COMPOSITE(tB, vB)
         if (++d >= a.D) break;
@@ -261,10 +272,10 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
     a.alpha[pix] = A;
 }
 
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool SWZ>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool SWZ, bool F16 = false>
 void launch_fwd2(const RenderArgs &a, hipStream_t s) {
     const int tiles_x = (a.W + 63) / 64, tiles_y = (a.H + TY - 1) / TY;
-    hipLaunchKernelGGL((render_fwd2_k<COORD, BORDER, ORDER, RACT, AACT, TY, SWZ>), dim3((unsigned)(tiles_x * tiles_y * a.T)),
+    hipLaunchKernelGGL((render_fwd2_k<COORD, BORDER, ORDER, RACT, AACT, TY, SWZ, F16>), dim3((unsigned)(tiles_x * tiles_y * a.T)),
                        dim3(64 * TY), 0, s, a, tiles_x, tiles_y);
 }
 
@@ -386,7 +397,7 @@ __global__ __launch_bounds__(256) void bwd_fill_zero_if_infeasible_k(float4 *g, 
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16>
 __global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
     constexpr int NT = RW * ROWS;
@@ -407,9 +418,11 @@ __global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
     const int ix0 = max(rx0 + RH, 0), ix1 = min(rx0 + RW - 1 - RH, a.W - 1);
     const int iy0 = max(ry0 + RH, 0), iy1 = min(ry0 + ROWS - 1 - RH, a.H - 1);
     const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
+    constexpr size_t TEXB = F16 ? 8 : 16;
     const size_t frame = (size_t)a.Hs * a.Ws * 4;
     const size_t plane_stride = (size_t)a.T * frame;
-    const float *plane = a.stack + (size_t)t * frame;
+    const size_t plane_stride_b = (size_t)a.T * a.Hs * a.Ws * TEXB;
+    const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * a.Hs * a.Ws * TEXB;
     float *gplane = a.g_stack + (size_t)t * frame;
     float Gr = 0.f, Gg = 0.f, Gb = 0.f, gA = 0.f, S = 0.f;
     if (inimg) {
@@ -423,7 +436,7 @@ __global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
     if constexpr (REG) { gsx_c = a.g_reg[0]; gsy_c = a.g_reg[1]; gsx_a = a.g_reg[2]; gsy_a = a.g_reg[3]; }
     // pixels of the outermost ring only provide layer values in REG mode
     const bool provider = !REG || (lane >= 1 && lane <= RW - 2 && row >= 1 && row <= ROWS - 2);
-    for (int d = 0; d < a.D; ++d, plane += plane_stride, gplane += plane_stride) {
+    for (int d = 0; d < a.D; ++d, plane += plane_stride_b, gplane += plane_stride) {
         const float *h = a.homos + 9 * d;
         const int buf = d & 1;
         // (1) footprint of the owned tile on plane d from its four corners (convex image of a rectangle, Z>0).
@@ -445,14 +458,14 @@ __global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
         Taps2 tp{};
         if (inimg) {
             tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-            const char *src = reinterpret_cast<const char *>(plane);
+            const char *src = plane;
             if (a.ablate & 4) {   // measurement only: all taps from a 64 KiB cache-resident window
                 src = reinterpret_cast<const char *>(a.stack);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) tp.off[i] &= 0xffffu;
             }
             f4 tv[4];
-            load_taps2(src, tp, tv);
+            load_taps2<F16>(src, tp, tv);
             o = shade2<ORDER, RACT, AACT>(tp, tv, &pre);                 // o.w already 0 when the plane does not cover the pixel
         }
         f4 sg = f4{0.f, 0.f, 0.f, 0.f};
@@ -515,6 +528,7 @@ __global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
             const int lc = ((int)ry - ry0) * RW + ((int)rx - rx0);
             const f2 tau = f2{tauX, tauY};
             f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+            if (!(a.ablate & 8))
 #pragma unroll
             for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
@@ -527,7 +541,7 @@ __global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
                 }
             const size_t toff = ((size_t)(Y0 + wy) * a.Ws + (X0 + wx)) * 4;
             if constexpr (ORDER == VL3D_ACT_PRE) {   // d act(s_tau)/d s_tau factors out of the tap sum
-                const f4 sv = *reinterpret_cast<const f4 *>(plane + toff);
+                const f4 sv = load_texel<F16>(plane, (unsigned)(toff * 4));
                 acc = f4{acc.x * act_bwd<RACT>(sv.x, act_fwd<RACT>(sv.x)), acc.y * act_bwd<RACT>(sv.y, act_fwd<RACT>(sv.y)),
                          acc.z * act_bwd<RACT>(sv.z, act_fwd<RACT>(sv.z)), acc.w * act_bwd<AACT>(sv.w, act_fwd<AACT>(sv.w))};
             }
@@ -543,7 +557,7 @@ __global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
 // materialising the [T,h,w,K,4] layer tensor the reference builds (1.47 GB per training crop).
 // out[0] = sum |dx rgb|, out[1] = sum |dy rgb|, out[2] = sum |dx a|, out[3] = sum |dy a|   (device doubles, accumulated).
 // Workgroup = 64 x ROWS region, pairs owned by their left / upper pixel (63 x (ROWS-1) interior), one barrier per plane.
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool F16>
 __global__ __launch_bounds__(RW *ROWS) void render_reg_fwd_k(RenderArgs a) {
     constexpr int NT = RW * ROWS;
     __shared__ float4 s_o[2][NT];
@@ -555,7 +569,7 @@ __global__ __launch_bounds__(RW *ROWS) void render_reg_fwd_k(RenderArgs a) {
     const bool owner = inimg && lane < RW - 1 && row < ROWS - 1;
     const bool own_r = owner && x + 1 < a.W, own_d = owner && y + 1 < a.H;
     const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
-    const size_t frame_b = (size_t)a.Hs * a.Ws * 16, plane_stride_b = (size_t)a.T * frame_b;
+    const size_t frame_b = (size_t)a.Hs * a.Ws * (F16 ? 8 : 16), plane_stride_b = (size_t)a.T * frame_b;
     const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * frame_b;
     float sxc = 0.f, syc = 0.f, sxa = 0.f, sya = 0.f;
     for (int d = 0; d < a.D; ++d, plane += plane_stride_b) {
@@ -563,7 +577,7 @@ __global__ __launch_bounds__(RW *ROWS) void render_reg_fwd_k(RenderArgs a) {
         if (inimg) {
             const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
             f4 tv[4];
-            load_taps2(plane, tp, tv);
+            load_taps2<F16>(plane, tp, tv);
             ol = shade2<ORDER, RACT, AACT>(tp, tv) * tp.cov;
         }
         const int buf = d & 1;
@@ -596,11 +610,11 @@ __global__ __launch_bounds__(RW *ROWS) void render_reg_fwd_k(RenderArgs a) {
 }
 
 // ---- dispatch over the compile-time conventions -------------------------------------------------------
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16 = false>
 void launch_tile(const RenderArgs &a, hipStream_t s) {
     constexpr int RH = REG ? 2 : 1, IW = RW - 2 * RH, IH = ROWS - 2 * RH;
     dim3 grid((a.W + IW - 1) / IW, (a.H + IH - 1) / IH, a.T);
-    hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG>), grid, dim3(RW * ROWS), 0, s, a);
+    hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16>), grid, dim3(RW * ROWS), 0, s, a);
 }
 
 // g_tile_rows: 0 = no tile path for this call, else the ROWS of the tile kernel to launch
@@ -608,8 +622,11 @@ thread_local int g_tile_rows = 0;
 // true: the forward dispatch launches the regulariser-sums kernel instead of the render
 thread_local bool g_reg_fwd = false;
 
-template <bool BWD, int COORD, int BORDER, int ORDER, int RACT, int AACT>
-void launch(const RenderArgs &a, hipStream_t s) {
+// fp16 plane stacks (cfg5) are instantiated for the shipped (sigmoid, sigmoid) activations only
+thread_local bool g_f16 = false;
+
+template <bool BWD, int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
+void launch_t(const RenderArgs &a, hipStream_t s) {
     dim3 grid((a.W + TILE_X - 1) / TILE_X, (a.H + TILE_Y - 1) / TILE_Y, a.T), block(TILE_X * TILE_Y);
     if constexpr (BWD) {
         if (g_tile_rows) {
@@ -618,31 +635,39 @@ void launch(const RenderArgs &a, hipStream_t s) {
             hipLaunchKernelGGL(bwd_fill_zero_if_infeasible_k, dim3(4096), dim3(256), 0, s, reinterpret_cast<float4 *>(a.g_stack), n4, a.plan);
             hipLaunchKernelGGL(bwd_zero_unowned_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, a);
             bool done = false;
-            if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID) {   // measurement variant (shipped activations only)
-                if (g_tile_rows == 8 && !a.g_reg) { launch_tile<COORD, BORDER, ORDER, RACT, AACT, 8, false>(a, s); done = true; }
+            if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID && !F16) {   // measurement variant (shipped activations only)
+                if (g_tile_rows == 8 && !a.g_reg) { launch_tile<COORD, BORDER, ORDER, RACT, AACT, 8, false, false>(a, s); done = true; }
             }
             if (!done) {
-                if (a.g_reg) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true>(a, s);
-                else launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, false>(a, s);
+                if (a.g_reg) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, F16>(a, s);
+                else launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, false, F16>(a, s);
             }
         }
-        hipLaunchKernelGGL((render_bwd_k<COORD, BORDER, ORDER, RACT, AACT>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((render_bwd_k<COORD, BORDER, ORDER, RACT, AACT, F16>), grid, block, 0, s, a);
     } else {
         // forward variant (desc->variant bits 8..11): 0 default; measurement variants for the shipped
         // sigmoid/sigmoid activation only: 2 TY=4, 3 TY=8, 4 TY=16 (all XCD-remapped), 5 TY=8 without remap
         if (g_reg_fwd) {
             dim3 rgrid((a.W + RW - 2) / (RW - 1), (a.H + 14) / 15, a.T);
-            hipLaunchKernelGGL((render_reg_fwd_k<COORD, BORDER, ORDER, RACT, AACT, 16>), rgrid, dim3(RW * 16), 0, s, a);
+            hipLaunchKernelGGL((render_reg_fwd_k<COORD, BORDER, ORDER, RACT, AACT, 16, F16>), rgrid, dim3(RW * 16), 0, s, a);
             return;
         }
         const int fv = a.fwd_variant;
-        if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID) {
+        if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID && !F16) {
             if (fv == 2) return launch_fwd2<COORD, BORDER, ORDER, RACT, AACT, 4, true>(a, s);
             if (fv == 4) return launch_fwd2<COORD, BORDER, ORDER, RACT, AACT, 16, true>(a, s);
             if (fv == 5) return launch_fwd2<COORD, BORDER, ORDER, RACT, AACT, 8, false>(a, s);
         }
-        launch_fwd2<COORD, BORDER, ORDER, RACT, AACT, 8, true>(a, s);
+        launch_fwd2<COORD, BORDER, ORDER, RACT, AACT, 8, true, F16>(a, s);
     }
+}
+
+template <bool BWD, int COORD, int BORDER, int ORDER, int RACT, int AACT>
+void launch(const RenderArgs &a, hipStream_t s) {
+    if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID) {
+        if (g_f16) return launch_t<BWD, COORD, BORDER, ORDER, RACT, AACT, true>(a, s);
+    }
+    launch_t<BWD, COORD, BORDER, ORDER, RACT, AACT, false>(a, s);
 }
 
 template <bool BWD, int COORD, int BORDER, int ORDER>
@@ -690,7 +715,9 @@ int check_desc(const vl3d_render_desc *d) {
     VL3D_REQUIRE(d != nullptr, "null render desc");
     VL3D_REQUIRE(d->D > 0 && d->T > 0 && d->Hs > 0 && d->Ws > 0 && d->H > 0 && d->W > 0, "non-positive render dims");
     VL3D_REQUIRE((int64_t)d->Hs * d->Ws < (1ll << 31), "plane too large for 32-bit texel index");
-    VL3D_REQUIRE(d->stack_dtype == VL3D_F32, "only fp32 plane stacks are implemented in this round");
+    VL3D_REQUIRE(d->stack_dtype == VL3D_F32 || d->stack_dtype == VL3D_F16, "stack_dtype must be VL3D_F32 or VL3D_F16");
+    VL3D_REQUIRE(d->stack_dtype == VL3D_F32 || (d->rgb_act == VL3D_ACT_SIGMOID && d->alpha_act == VL3D_ACT_SIGMOID),
+                 "fp16 plane stacks are implemented for the shipped (sigmoid, sigmoid) activations only");
     return VL3D_OK;
 }
 
@@ -713,7 +740,9 @@ extern "C" int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, 
     a.stack = (const float *)stack; a.homos = homos; a.rgb = rgb; a.alpha = alpha;
     a.fwd_variant = (desc->variant >> 8) & 0xf;
     VL3D_REQUIRE((int64_t)desc->Hs * desc->Ws * 16 < (1ll << 32), "frame too large for 32-bit byte offsets");
+    g_f16 = desc->stack_dtype == VL3D_F16;
     rc = dispatch<false>(desc, a, (hipStream_t)stream);
+    g_f16 = false;
     if (rc != VL3D_OK) return rc;
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
@@ -734,8 +763,10 @@ extern "C" int vl3d_render_reg_fwd(const vl3d_render_desc *desc, const void *sta
     a.stack = (const float *)stack; a.homos = homos; a.reg_sums = sums;
     VL3D_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(double), (hipStream_t)stream));
     g_reg_fwd = true;
+    g_f16 = desc->stack_dtype == VL3D_F16;
     rc = dispatch<false>(desc, a, (hipStream_t)stream);
     g_reg_fwd = false;
+    g_f16 = false;
     if (rc != VL3D_OK) return rc;
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
@@ -767,8 +798,10 @@ extern "C" int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, 
         const size_t bytes = (size_t)desc->D * desc->T * desc->Hs * desc->Ws * 4 * sizeof(float);
         VL3D_HIP(hipMemsetAsync(grad_stack, 0, bytes, (hipStream_t)stream));
     }
+    g_f16 = desc->stack_dtype == VL3D_F16;
     rc = dispatch<true>(desc, a, (hipStream_t)stream);
     g_tile_rows = 0;
+    g_f16 = false;
     if (rc != VL3D_OK) return rc;
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;

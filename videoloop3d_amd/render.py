@@ -43,7 +43,7 @@ def _desc(stack, H, W, spec, row0, col0):
     d.border_mode = L.BORDER[spec.border]
     d.act_order = L.ACT_ORDER[spec.act_order]
     d.rgb_act, d.alpha_act = L.ACT[spec.rgb_act], L.ACT[spec.alpha_act]
-    d.stack_dtype = 0
+    d.stack_dtype = 1 if stack.dtype == torch.float16 else 0
     d.pixel_center = float(spec.pixel_center)
     d.sx, d.sy = float(spec.scale[0]), float(spec.scale[1])
     d.ox, d.oy = float(spec.offset[0]), float(spec.offset[1])
@@ -60,8 +60,8 @@ class _RenderPlanes(torch.autograd.Function):
     @staticmethod
     def forward(ctx, stack, homos, H, W, spec, row0, col0, with_reg):
         L.check_cuda(stack, homos)
-        if stack.dtype != torch.float32:
-            raise RuntimeError("plane stack must be float32")
+        if stack.dtype not in (torch.float32, torch.float16):
+            raise RuntimeError("plane stack must be float32 or float16 (arithmetic is fp32 either way)")
         stack = stack.contiguous()
         homos = homos.detach().to(torch.float32).contiguous()
         D, T = stack.shape[:2]
@@ -89,7 +89,7 @@ class _RenderPlanes(torch.autograd.Function):
         g_reg = g_sums.to(torch.float32).contiguous() if (ctx.with_reg and g_sums is not None) else None
         g_rgb = g_rgb.contiguous() if g_rgb is not None else torch.zeros_like(rgb)
         g_alpha = g_alpha.contiguous() if g_alpha is not None else None
-        g_stack = torch.empty_like(stack)
+        g_stack = torch.empty(stack.shape, dtype=torch.float32, device=stack.device)   # grad_stack is always fp32 in the ABI
         with torch.cuda.device(stack.device):
             nscratch = int(L.lib().vl3d_render_bwd_scratch_bytes(ctx.desc))
             scratch = torch.zeros((nscratch + 3) // 4, dtype=torch.float32, device=stack.device)
@@ -98,7 +98,7 @@ class _RenderPlanes(torch.autograd.Function):
                                             L.stream_ptr(stack.device)), "vl3d_render_bwd")
         global LAST_BWD_SCRATCH
         LAST_BWD_SCRATCH = scratch
-        return g_stack, None, None, None, None, None, None, None
+        return g_stack.to(stack.dtype), None, None, None, None, None, None, None
 
 
 def render_planes(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0)):
