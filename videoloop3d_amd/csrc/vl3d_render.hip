@@ -122,6 +122,14 @@ __device__ __forceinline__ void load_taps2(const char *__restrict__ plane, const
     for (int i = 0; i < 4; ++i) v[i] = load_texel<F16>(plane, t.off[i]);
 }
 
+// measurement only (fwd_variant 6): fetch the left column of taps only -- halves the L1/TA request traffic at unchanged HBM
+// traffic, to see how much of the forward's time is the vector-memory pipe (result is NOT the render)
+template <bool F16>
+__device__ __forceinline__ void load_taps2_half(const char *__restrict__ plane, const Taps2 &t, f4 v[4]) {
+    v[0] = load_texel<F16>(plane, t.off[0]); v[2] = load_texel<F16>(plane, t.off[2]);
+    v[1] = v[0]; v[3] = v[2];
+}
+
 template <int RACT, int AACT>
 __device__ __forceinline__ f4 act4(f4 s) {
     return f4{act_fwd<RACT>(s.x), act_fwd<RACT>(s.y), act_fwd<RACT>(s.z), act_fwd<AACT>(s.w)};
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
     // two register sets (A/B) so the taps of plane d+1 are in flight while plane d is shaded, without register copies
     Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy), tB = tA;
     f4 vA[4], vB[4];
-    load_taps2<F16>(plane, tA, vA);
+    if (a.ablate & 1) load_taps2_half<F16>(plane, tA, vA); else load_taps2<F16>(plane, tA, vA);
 #define VL3D_COMPOSITE(T_, V_)                                        \
     {                                                                 \
         const f4 o = shade2<ORDER, RACT, AACT>(T_, V_);               \
@@ -254,13 +262,13 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
     for (int d = 0;;) {
         if (d + 1 < a.D) {
             tB = make_taps2<COORD, BORDER>(a.homos + 9 * (d + 1), px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-            load_taps2<F16>(plane + plane_stride_b, tB, vB);
+            if (a.ablate & 1) load_taps2_half<F16>(plane + plane_stride_b, tB, vB); else load_taps2<F16>(plane + plane_stride_b, tB, vB);
         }
         VL3D_COMPOSITE(tA, vA)
         if (++d >= a.D) break;
         if (d + 1 < a.D) {
             tA = make_taps2<COORD, BORDER>(a.homos + 9 * (d + 1), px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-            load_taps2<F16>(plane + 2 * plane_stride_b, tA, vA);
+            if (a.ablate & 1) load_taps2_half<F16>(plane + 2 * plane_stride_b, tA, vA); else load_taps2<F16>(plane + 2 * plane_stride_b, tA, vA);
         }
         VL3D_COMPOSITE(tB, vB)
         if (++d >= a.D) break;
@@ -409,7 +417,7 @@ __global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
     // per-plane staging of the region's pixels, double buffered so one barrier per plane suffices
     __shared__ float4 s_g[2][NT];     // gradient w.r.t. the sampled (POST) / activated (PRE) value of this pixel on this plane
     __shared__ float2 s_t[2][NT];     // its texel coordinates (tx,ty); -1e30 when the plane does not cover the pixel
-    __shared__ float s_c[2][8];       // footprint corners of the owned tile on this plane
+    __shared__ int s_w[2][4];         // texel window of the owned tile on this plane: X0, Y0, width, height
     const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
     const int rx0 = blockIdx.x * (RW - 2 * RH) - RH, ry0 = blockIdx.y * (ROWS - 2 * RH) - RH;
     const int x = rx0 + lane, y = ry0 + row, t = blockIdx.z;
@@ -442,14 +450,27 @@ __global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
         // (1) footprint of the owned tile on plane d from its four corners (convex image of a rectangle, Z>0).
         //     Texels owned by this tile have their owner pixel inside it, i.e. H^-1(tau) within 0.5 px of the tile
         //     (any distance beyond a frame border, where only texels within the 1.4 px contribution range matter).
-        if (tid < 4) {
+        //     Wave 0 evaluates the corners (lane & 3), reduces them with two shuffles and publishes the integer window.
+        if (tid < 64) {
             const float el = (ix0 == 0) ? 1.6f : 0.6f, er = (ix1 == a.W - 1) ? 1.6f : 0.6f;
             const float et = (iy0 == 0) ? 1.6f : 0.6f, eb = (iy1 == a.H - 1) ? 1.6f : 0.6f;
             const float cx = (float)a.col0 + a.pc + ((tid & 1) ? (float)ix1 + er : (float)ix0 - el);
             const float cy = (float)a.row0 + a.pc + ((tid & 2) ? (float)iy1 + eb : (float)iy0 - et);
             const float X = h[0] * cx + h[1] * cy + h[2], Y = h[3] * cx + h[4] * cy + h[5], Z = h[6] * cx + h[7] * cy + h[8];
-            s_c[buf][tid] = texel_coord<COORD>(X / Z, (float)a.Ws / 2.0f, (float)(a.Ws - 1), a.sx, a.ox);
-            s_c[buf][4 + tid] = texel_coord<COORD>(Y / Z, (float)a.Hs / 2.0f, (float)(a.Hs - 1), a.sy, a.oy);
+            const float ctx = texel_coord<COORD>(X / Z, (float)a.Ws / 2.0f, (float)(a.Ws - 1), a.sx, a.ox);
+            const float cty = texel_coord<COORD>(Y / Z, (float)a.Hs / 2.0f, (float)(a.Hs - 1), a.sy, a.oy);
+            float mnx = ctx, mxx = ctx, mny = cty, mxy = cty;
+#pragma unroll
+            for (int m = 1; m <= 2; m <<= 1) {
+                mnx = fminf(mnx, __shfl_xor(mnx, m, 64)); mxx = fmaxf(mxx, __shfl_xor(mxx, m, 64));
+                mny = fminf(mny, __shfl_xor(mny, m, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, m, 64));
+            }
+            if (tid == 0) {
+                const int wX0 = max(0, (int)floorf(fmaxf(mnx - 0.01f, -2.0f))), wY0 = max(0, (int)floorf(fmaxf(mny - 0.01f, -2.0f)));
+                const int wX1 = min(a.Ws - 1, (int)floorf(fminf(mxx + 0.01f, (float)a.Ws)) + 1);
+                const int wY1 = min(a.Hs - 1, (int)floorf(fminf(mxy + 0.01f, (float)a.Hs)) + 1);
+                s_w[buf][0] = wX0; s_w[buf][1] = wY0; s_w[buf][2] = max(0, wX1 - wX0 + 1); s_w[buf][3] = max(0, wY1 - wY0 + 1);
+            }
         }
         // (2) sample this pixel on plane d, composite backward, stage (tx,ty,g) in LDS   (branch-free taps)
         float2 tc = make_float2(-1e30f, -1e30f);
@@ -503,14 +524,7 @@ __global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
         s_g[buf][tid] = gval;
         __syncthreads();   // staging of plane d visible (the other buffer may still be read by slower waves: not touched here)
         // (3) every texel owned by this tile gathers its taps from the 3x3 pixels around its owner pixel
-        const float mnx = fminf(fminf(s_c[buf][0], s_c[buf][1]), fminf(s_c[buf][2], s_c[buf][3]));
-        const float mxx = fmaxf(fmaxf(s_c[buf][0], s_c[buf][1]), fmaxf(s_c[buf][2], s_c[buf][3]));
-        const float mny = fminf(fminf(s_c[buf][4], s_c[buf][5]), fminf(s_c[buf][6], s_c[buf][7]));
-        const float mxy = fmaxf(fmaxf(s_c[buf][4], s_c[buf][5]), fmaxf(s_c[buf][6], s_c[buf][7]));
-        const int X0 = max(0, (int)floorf(fmaxf(mnx - 0.01f, -2.0f))), Y0 = max(0, (int)floorf(fmaxf(mny - 0.01f, -2.0f)));
-        const int X1 = min(a.Ws - 1, (int)floorf(fminf(mxx + 0.01f, (float)a.Ws)) + 1);
-        const int Y1 = min(a.Hs - 1, (int)floorf(fminf(mxy + 0.01f, (float)a.Hs)) + 1);
-        const int ww = max(0, X1 - X0 + 1), wh = max(0, Y1 - Y0 + 1);
+        const int X0 = s_w[buf][0], Y0 = s_w[buf][1], ww = s_w[buf][2], wh = s_w[buf][3];
         const float inv_ww = 1.0f / (float)max(ww, 1);
         const float *hi = a.plan + PLAN_HDR + PLAN_REC * d;
         if (a.ablate & 1) continue;
@@ -739,6 +753,7 @@ extern "C" int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, 
     RenderArgs a = make_args(desc);
     a.stack = (const float *)stack; a.homos = homos; a.rgb = rgb; a.alpha = alpha;
     a.fwd_variant = (desc->variant >> 8) & 0xf;
+    a.ablate = (desc->variant >> 4) & 0xf;
     VL3D_REQUIRE((int64_t)desc->Hs * desc->Ws * 16 < (1ll << 32), "frame too large for 32-bit byte offsets");
     g_f16 = desc->stack_dtype == VL3D_F16;
     rc = dispatch<false>(desc, a, (hipStream_t)stream);
