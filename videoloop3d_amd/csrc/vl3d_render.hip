@@ -31,6 +31,7 @@ struct RenderArgs {
     float pc, sx, sy, ox, oy;
     const float *g_reg;  // device float[4]: dL/d(sum|dx rgb|), dL/d(sum|dy rgb|), dL/d(sum|dx a|), dL/d(sum|dy a|) or NULL
     double *reg_sums;    // device double[4] (forward of the layer-space smoothness regularisers)
+    int tiles_x, tiles_y; // tile grid of the owner-computes backward
     int fwd_variant;     // forward kernel selector (see launch<>)
     int ablate;          // measurement-only switches (bit0: skip LDS scatter, bit1: skip flush stores, bit2: skip tap loads)
     const float *plan;   // device scratch written by bwd_plan_k: [0] feasible flag, [16 + 9*d ..] inverse texel homographies
@@ -419,8 +420,13 @@ __global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
     __shared__ float2 s_t[2][NT];     // its texel coordinates (tx,ty); -1e30 when the plane does not cover the pixel
     __shared__ int s_w[2][4];         // texel window of the owned tile on this plane: X0, Y0, width, height
     const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
-    const int rx0 = blockIdx.x * (RW - 2 * RH) - RH, ry0 = blockIdx.y * (ROWS - 2 * RH) - RH;
-    const int x = rx0 + lane, y = ry0 + row, t = blockIdx.z;
+    // 1-D grid, XCD-aware order: every XCD walks a contiguous run of tiles (row-major within a frame), so a tile's halo
+    // rows and its neighbours' taps hit the same L2
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_x = bid % a.tiles_x, rest = bid / a.tiles_x;
+    const int tile_y = rest % a.tiles_y, t = rest / a.tiles_y;
+    const int rx0 = tile_x * (RW - 2 * RH) - RH, ry0 = tile_y * (ROWS - 2 * RH) - RH;
+    const int x = rx0 + lane, y = ry0 + row;
     const bool inimg = (x >= 0) && (x < a.W) && (y >= 0) && (y < a.H);
     // owned (interior) pixel range of this workgroup, clipped to the frame: [ix0,ix1] x [iy0,iy1]
     const int ix0 = max(rx0 + RH, 0), ix1 = min(rx0 + RW - 1 - RH, a.W - 1);
@@ -627,8 +633,10 @@ __global__ __launch_bounds__(RW *ROWS) void render_reg_fwd_k(RenderArgs a) {
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16 = false>
 void launch_tile(const RenderArgs &a, hipStream_t s) {
     constexpr int RH = REG ? 2 : 1, IW = RW - 2 * RH, IH = ROWS - 2 * RH;
-    dim3 grid((a.W + IW - 1) / IW, (a.H + IH - 1) / IH, a.T);
-    hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16>), grid, dim3(RW * ROWS), 0, s, a);
+    RenderArgs b = a;
+    b.tiles_x = (a.W + IW - 1) / IW; b.tiles_y = (a.H + IH - 1) / IH;
+    hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16>),
+                       dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
 }
 
 // g_tile_rows: 0 = no tile path for this call, else the ROWS of the tile kernel to launch
