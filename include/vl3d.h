@@ -159,6 +159,11 @@ int vl3d_nn_vectors(int64_t B, int32_t n1, int32_t n2, int32_t d, const float *X
 int vl3d_vote_fold(const vl3d_loss_desc *desc, const float *y, const int32_t *nn,
                    float *sum, float *weight, int32_t normalize, vl3d_stream_t stream);
 
+/* NN-error metric support (evaluations/NNMSE.py:45-56): err[h_o*w_o] (overwritten) = per patch location the sum over its
+ * n1 patches and their 3*pt*ps*ps elements of |y patch at nn - x patch|; nn from vl3d_patchnn (use_alpha = 0). */
+int vl3d_patch_l1(const vl3d_loss_desc *desc, const float *x, const float *y, const int32_t *nn, float *err,
+                  vl3d_stream_t stream);
+
 /* robust_lossfun (utils_vid.py:10-26) fused with the mean (utils_vid.py:348).
  * kind: 0 'mse', 1 'abs', 2 general Barron with float rou (rou==0 and rou==2 special-cased as the reference).
  * loss_sum: device double, overwritten with sum over n elements of rho(x - y2x). */

@@ -123,3 +123,28 @@ def gpnn_loss(x, y, macro_block=64, patch_size=7, stride=2, patcht_size=7, strid
         s, wgt = find_nn_and_merge(x, y, patch_size, patcht_size, stride, stridet, alpha)
         y2x = s / wgt
     return robust_lossfun(x - y2x, rou, scaling).mean(), y2x, wgt
+
+
+def compute_nnerr(src, tar, patch_size=7, stride=2, patcht_size=7, stridet=2, macro_block=65):
+    """evaluations/NNMSE.py:7-58: mean over macro blocks of mean |NN patch of tar - patch of src| (plain NN, alpha None)."""
+    import numpy as np
+    t, h, w = src.shape[-3:]
+    macro_block = fit_patch(macro_block, "macro_block", patch_size, stride, False)
+    h = fit_patch(h, "patch_height", patch_size, stride, False)
+    w = fit_patch(w, "patch_width", patch_size, stride, False)
+    t = fit_patch(t, "frame_num", patcht_size, stridet, False)
+    src, tar = src[..., :t, :h, :w], tar[..., :h, :w]
+    ms = macro_block - patch_size + stride
+    errs = []
+    for hs in np.arange(0, h - macro_block + ms, ms):
+        for ws in np.arange(0, w - macro_block + ms, ms):
+            sc = src[..., hs:hs + macro_block, ws:ws + macro_block]
+            tc = tar[..., hs:hs + macro_block, ws:ws + macro_block]
+            ps_ = extract_3Dpatches(sc, patch_size, patcht_size, stride, stridet)
+            b, c, d, hh, ww = ps_.shape
+            B = b * hh * ww
+            X = _to_location_major(ps_, B, patcht_size, patch_size)
+            Y = _to_location_major(extract_3Dpatches(tc, patch_size, patcht_size, stride, stridet), B, patcht_size, patch_size)
+            nns = nn_indices(X, Y, None)
+            errs.append((Y[torch.arange(B)[:, None], nns] - X).abs().mean().item())
+    return float(np.array(errs).mean())

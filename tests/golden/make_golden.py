@@ -236,6 +236,15 @@ def main():
             g9[f"rou{rou}_s{sc}_grad"] = gr.numpy()
     sv("g9_robust.npz", **g9)
 
+    # ---- G10 evaluations/NNMSE.compute_nnerr -----------------------------------------
+    from evaluations.NNMSE import compute_nnerr
+    x10 = torch.from_numpy(rng.uniform(size=(1, 3, 9, 29, 37)).astype(np.float32))
+    y10 = torch.from_numpy(rng.uniform(size=(1, 3, 13, 29, 37)).astype(np.float32))
+    g10 = {"x": x10.numpy(), "y": y10.numpy()}
+    for (ps, s_, pt, st, mb) in [(5, 2, 3, 1, 13), (7, 2, 3, 2, 65), (3, 1, 3, 1, 9), (11, 4, 3, 1, 19)]:
+        g10[f"ps{ps}_s{s_}_pt{pt}_st{st}_mb{mb}"] = np.float64(compute_nnerr(x10, y10, ps, s_, pt, st, mb))
+    sv("g10_nnerr.npz", **g10)
+
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("golden fixtures written, total bytes:", tot)
 

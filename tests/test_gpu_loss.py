@@ -208,3 +208,16 @@ def test_patchnn_kernel_variants_agree(dev, variant, monkeypatch):
         assert unexplained == 0
         if nbad == 0:
             assert maxabs(sg, so) <= 1e-5
+
+
+def test_g10_compute_nnerr(dev, golden):
+    """evaluations/NNMSE.compute_nnerr on the HIP patch-NN path vs the reference golden G10."""
+    import warnings as _w
+    from videoloop3d_amd.evaluations import compute_nnerr
+    g = golden("g10_nnerr.npz")
+    x, y = T_(g["x"]).to(dev), T_(g["y"]).to(dev)
+    with _w.catch_warnings():
+        _w.simplefilter("ignore")
+        for (ps, s_, pt, st, mb) in [(5, 2, 3, 1, 13), (7, 2, 3, 2, 65), (3, 1, 3, 1, 9), (11, 4, 3, 1, 19)]:
+            v = compute_nnerr(x, y, ps, s_, pt, st, mb)
+            assert abs(v - float(g[f"ps{ps}_s{s_}_pt{pt}_st{st}_mb{mb}"])) <= 2e-6

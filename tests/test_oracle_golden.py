@@ -123,3 +123,10 @@ def test_g9_robust(golden):
             (gr,) = torch.autograd.grad(v.sum(), x)
             refg = g[f"rou{rou}_s{sc}_grad"]
             assert maxabs(gr, refg) <= 1e-5 * max(1.0, float(np.abs(refg).max()))
+
+
+def test_g10_nnerr(golden):
+    g = golden("g10_nnerr.npz")
+    for (ps, s_, pt, st, mb) in [(5, 2, 3, 1, 13), (7, 2, 3, 2, 65), (3, 1, 3, 1, 9), (11, 4, 3, 1, 19)]:
+        v = VO.compute_nnerr(T(g["x"]), T(g["y"]), ps, s_, pt, st, mb)
+        assert abs(v - float(g[f"ps{ps}_s{s_}_pt{pt}_st{st}_mb{mb}"])) <= 1e-6

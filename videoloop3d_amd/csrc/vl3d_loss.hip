@@ -798,3 +798,42 @@ extern "C" int vl3d_nn_vectors(int64_t B, int32_t n1, int32_t n2, int32_t d, con
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// NN-error metric support (evaluations/NNMSE.py:45-56): per patch location b
+//   err[b] = sum_i sum_{c,kt,kh,kw} | y[c, nn_b[i]*st+kt, .] - x[c, i*st+kt, .] |   (the caller normalises / groups by macro block)
+__global__ __launch_bounds__(256) void patch_l1_k(const float *__restrict__ x, const float *__restrict__ y, const int32_t *__restrict__ nn,
+                                                  int ps, int pt, int stride, int stridet, int w_o, int n1, int64_t x_sc, int64_t x_st,
+                                                  int64_t x_sr, int64_t y_sc, int64_t y_st, int64_t y_sr, float *__restrict__ err) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, by = b / w_o, bx = b % w_o, r0 = by * stride, c0 = bx * stride;
+    const int per = 3 * pt * ps * ps, total = n1 * per;
+    float acc = 0.f;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int i = e / per, k = e - i * per;
+        const int c = k / (pt * ps * ps), r1 = k - c * pt * ps * ps, kt = r1 / (ps * ps), r2 = r1 - kt * ps * ps, kh = r2 / ps, kw = r2 - kh * ps;
+        const int j = nn[(size_t)b * n1 + i];
+        const int64_t sp = (int64_t)(r0 + kh);
+        const float xv = x[c * x_sc + (int64_t)(i * stridet + kt) * x_st + sp * x_sr + c0 + kw];
+        const float yv = y[c * y_sc + (int64_t)(j * stridet + kt) * y_st + sp * y_sr + c0 + kw];
+        acc += fabsf(yv - xv);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) err[b] = red[0] + red[1] + red[2] + red[3];
+}
+
+extern "C" int vl3d_patch_l1(const vl3d_loss_desc *desc, const float *x, const float *y, const int32_t *nn, float *err,
+                             vl3d_stream_t stream) {
+    int rc = check_loss(desc);
+    if (rc != VL3D_OK) return rc;
+    VL3D_REQUIRE(x && y && nn && err, "vl3d_patch_l1: null pointer");
+    const int h_o = (desc->H - desc->ps) / desc->stride + 1, w_o = (desc->W - desc->ps) / desc->stride + 1;
+    const int n1 = (desc->Tx - desc->pt) / desc->stridet + 1;
+    hipLaunchKernelGGL(patch_l1_k, dim3((unsigned)(h_o * w_o)), dim3(256), 0, (hipStream_t)stream, x, y, nn, desc->ps, desc->pt,
+                       desc->stride, desc->stridet, w_o, n1, desc->x_sc, desc->x_st, desc->x_sr, desc->y_sc, desc->y_st, desc->y_sr, err);
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
