@@ -398,3 +398,29 @@ def test_fp16_plane_stack(dev, spec_name):
     rgb32, _, sums32 = render_planes_with_smoothness(s32, homos.to(dev), H, W, RenderSpec(**kw_p))
     rgb16, _, sums16 = render_planes_with_smoothness(s_gpu, homos.to(dev), H, W, RenderSpec(**kw_p))
     assert torch.equal(rgb16, rgb32) and torch.equal(sums16, sums32)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 4, 6, 3, 5), (2, 1, 9, 70, 1, 66), (1, 3, 40, 5, 33, 1), (3, 2, 17, 129, 16, 125)])
+def test_tiny_and_ragged_frames(dev, shape):
+    """degenerate sizes: single plane / frame, frames narrower than a wave, one-pixel rows and columns, tile-size +- 1."""
+    from videoloop3d_amd.render import RenderSpec, render_planes_with_smoothness
+    D, T, Hs, Ws, H, W = shape
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=4) * 0.5
+    homos = torch.tensor([[1.0, 0.01, 0.3], [-0.01, 1.0, 0.2], [0, 0, 1.0]]).repeat(D, 1, 1)
+    homos[:, 0, 2] += torch.arange(D) * 0.7
+    g_rgb = synth.hash_uniform((T, H, W, 3), seed=5) - 0.5
+    for kw in (dict(pixel_center=0.5, coord_mode="affine", border="hardcut", act_order="post"), dict()):
+        s_cpu = stack.clone().requires_grad_(True)
+        rgb_o, alpha_o, _, L = MO.render_planes(s_cpu, homos, H, W, MO.RenderSpec(**kw), return_layers=True)
+        sx = (L[:, :, :-1, :, :3] - L[:, :, 1:, :, :3]).abs().sum() if W > 1 else L.sum() * 0
+        sy = (L[:, :-1, :, :, :3] - L[:, 1:, :, :, :3]).abs().sum() if H > 1 else L.sum() * 0
+        loss_o = (rgb_o * g_rgb).sum() + 1e-2 * (sx - 0.5 * sy)
+        (gs_o,) = torch.autograd.grad(loss_o, s_cpu)
+        s_gpu = stack.to(dev).requires_grad_(True)
+        rgb, alpha, sums = render_planes_with_smoothness(s_gpu, homos.to(dev), H, W, RenderSpec(**kw))
+        loss = (rgb * g_rgb.to(dev)).sum() + 1e-2 * (sums[0] - 0.5 * sums[1])
+        (gs,) = torch.autograd.grad(loss, s_gpu)
+        assert maxabs(rgb, rgb_o) <= TOL and maxabs(alpha, alpha_o) <= TOL
+        assert maxabs(sums[0], sx) <= 1e-4 * max(1.0, float(sx)) and maxabs(sums[1], sy) <= 1e-4 * max(1.0, float(sy))
+        d = (gs.cpu() - gs_o).abs()
+        assert float(d.max()) <= 5e-3 and float((d > 1e-4).float().mean()) <= 2e-3
