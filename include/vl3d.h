@@ -64,11 +64,14 @@ typedef struct vl3d_render_desc {
     int32_t variant;       /* kernel variant selector for A/B measurements; 0 = default */
 } vl3d_render_desc;
 
+/* alpha_sums (optional, may be NULL): (T,H,W,2) per pixel (sum_k a_k, sum_k a_k^2) over the planes -- the two sums the
+ * sparsity regulariser (MPV.py:511-515 / MPI.py:599-603: |a|_1 / |a|_2 per pixel) is made of. */
 int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos,
-                    float *rgb, float *alpha, vl3d_stream_t stream);
+                    float *rgb, float *alpha, float *alpha_sums, vl3d_stream_t stream);
 
 /* Backward of the above w.r.t. the stack (geometry is not differentiated: MPV.py:354).
  * rgb/alpha are the saved forward outputs; grad_alpha may be NULL (treated as 0).
+ * grad_alpha_sums (optional): (T,H,W,2) gradient w.r.t. alpha_sums of the forward.
  * grad_stack (D,T,Hs,Ws,4) fp32 is overwritten.
  * scratch: caller-owned device buffer of vl3d_render_bwd_scratch_bytes(desc) bytes (plan written and read on
  * `stream`, no host sync); with scratch == NULL the universal global-atomics kernel is used.
@@ -77,8 +80,8 @@ int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, const float
 int64_t vl3d_render_bwd_scratch_bytes(const vl3d_render_desc *desc);
 int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, const float *homos,
                     const float *rgb, const float *alpha, const float *grad_rgb, const float *grad_alpha,
-                    const float *grad_reg, float *grad_stack, void *scratch, int64_t scratch_bytes,
-                    vl3d_stream_t stream);
+                    const float *grad_reg, const float *grad_alpha_sums, float *grad_stack, void *scratch,
+                    int64_t scratch_bytes, vl3d_stream_t stream);
 
 /* Layer-space smoothness regularisers (MPV.py:517-531 rgb_smooth / a_smooth) WITHOUT the materialised [T,h,w,K,4] layer
  * tensor: sums[0..3] (device doubles, overwritten) = sum over frames, planes and neighbouring pixel pairs of

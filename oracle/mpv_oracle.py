@@ -83,3 +83,56 @@ def mpv_forward(stack, args, H, W, ref_extrin, ref_intrin, near, far, h, w, tar_
     if args.density_loss_weight > 0:
         extra["density"] = (alpha - 1).abs().mean().reshape(1, -1)
     return None, extra
+
+
+def mpi_forward(stack, stack_mask, args, H, W, ref_extrin, ref_intrin, near, far, h, w, tar_extrins, tar_intrins,
+                training=True, pixel_center=0.5):
+    """MPMesh.forward (MPI.py:596-652) for planar geometry.  stack (D,1,mpi_h,mpi_w,4), stack_mask (D,1,mpi_h,mpi_w) or None.
+    Returns (rgbl [B,3|4,h,w], extra)."""
+    D, _, mpi_h, mpi_w, _ = stack.shape
+    ref_extrin = torch.as_tensor(ref_extrin)
+    ref_intrin = torch.as_tensor(ref_intrin).float()
+    planedepth = MO.make_depths(D, near, far).flip(0)
+    H_start, W_start = (mpi_h - H) // 2, (mpi_w - W) // 2
+    ref_intrin_mpi = MO.get_new_intrin(ref_intrin, -H_start, -W_start)
+    extrins = tar_extrins @ ref_extrin[None].inverse().to(tar_extrins.dtype)
+    spec = MO.RenderSpec(pixel_center=pixel_center, coord_mode="affine", border="hardcut", act_order="post",
+                         rgb_act=args.rgb_activate, alpha_act=args.alpha_activate)
+    outs, mpis, alphas = [], [], []
+    for b in range(len(extrins)):
+        eye = torch.eye(4, dtype=extrins.dtype)[None]
+        normal = torch.tensor([0., 0., 1.], dtype=extrins.dtype).expand(1, D, 3)
+        homos = MO.compute_homography(eye, ref_intrin_mpi[None].to(extrins.dtype), extrins[b:b + 1], tar_intrins[b:b + 1], normal,
+                                      planedepth[None].to(extrins.dtype))[0].float()
+        rgb, alpha, bw, mpi = MO.render_planes(stack, homos, h, w, spec, return_layers=True)        # mpi: 1,h,w,D,4
+        if len(args.bg_color) > 0:
+            r, g, b_ = map(float, args.bg_color.split('#'))
+            rgb = rgb * alpha[..., None] + torch.tensor([r, g, b_]).type_as(rgb)[None, None, None] * (1 - alpha[..., None])
+        if stack_mask is not None:                                                                   # MPI.py:568-583
+            mspec = MO.RenderSpec(pixel_center=pixel_center, coord_mode="affine", border="hardcut", act_order="post",
+                                  rgb_act="sigmoid", alpha_act="none")
+            m = stack_mask[..., None]
+            lab_layers = MO.render_planes(torch.cat([m, m, m, torch.zeros_like(m)], -1), homos, h, w, mspec, return_layers=True)[3]
+            label, _ = MO.overcompose(mpi[..., -1].detach(), lab_layers[..., :1])
+            rgb = torch.cat([rgb, label], dim=-1)
+        outs.append(rgb)
+        mpis.append(mpi)
+        alphas.append(alpha)
+    rgbl = torch.cat(outs, 0).permute(0, 3, 1, 2)
+    mpi = torch.cat(mpis, 0)
+    alpha = torch.cat(alphas, 0)
+    extra = {}
+    if training:
+        if args.sparsity_loss_weight > 0:
+            a = mpi[..., -1]
+            sp = a.norm(dim=-1, p=1) / a.norm(dim=-1, p=2).clamp_min(1e-6)
+            extra["sparsity"] = (sp.mean() / np.sqrt(D)).reshape(1, -1)
+        if args.rgb_smooth_loss_weight > 0:
+            sm = mpi[..., :-1]
+            extra["rgb_smooth"] = ((sm[:, :, :-1] - sm[:, :, 1:]).abs().mean() + (sm[:, :-1] - sm[:, 1:]).abs().mean()).reshape(1, -1)
+        if args.a_smooth_loss_weight > 0:
+            sm = mpi[..., -1]
+            extra["a_smooth"] = ((sm[:, :, :-1] - sm[:, :, 1:]).abs().mean() + (sm[:, :-1] - sm[:, 1:]).abs().mean()).reshape(1, -1)
+        if args.density_loss_weight > 0:
+            extra["density"] = (alpha - 1).abs().mean().reshape(1, -1)
+    return rgbl, extra

@@ -114,3 +114,68 @@ def test_atlas_roundtrip():
     assert st.shape == (8, 3, 5, 7, 4)
     assert torch.equal(st[5, 1, 2, 3], atlas[1, :, 1 * 5 + 2, 1 * 7 + 3])             # plane 5 = cell (1, 1)
     assert torch.equal(stack_to_atlas(st, 2), atlas)
+
+
+# ---- stage 1: MPMesh (MPI.py) -----------------------------------------------------------------------------------------
+def make_args_mpi(**kw):
+    a = dict(mpi_h_scale=1.3, mpi_w_scale=1.3, mpi_d=6, atlas_grid_h=2, rgb_mlp_type="direct", rgb_activate="sigmoid",
+             alpha_activate="sigmoid", bg_color="", learn_loop_mask=True, upsample_stage="",
+             sparsity_loss_weight=0.004, rgb_smooth_loss_weight=0.2, a_smooth_loss_weight=0.5, density_loss_weight=0.02,
+             d_smooth_loss_weight=0.0, l_smooth_loss_weight=0.0)
+    a.update(kw)
+    return types.SimpleNamespace(**a)
+
+
+@pytest.mark.parametrize("loop_mask", [True, False])
+def test_mpmesh_forward_train_matches_oracle(dev, loop_mask):
+    """stage-1 module (cfg2 caller): rgb + loop-mask channel + the four regularisers of configs/mpi_base.txt, value and grads,
+    two views in the batch."""
+    from videoloop3d_amd.MPI import MPMesh
+    H, W = 44, 60
+    K, ref_extrin, tar = scene(H, W)
+    args = make_args_mpi(learn_loop_mask=loop_mask)
+    model = MPMesh(args, H, W, ref_extrin, K, 1.0, 100.0).to(dev).train()
+    with torch.no_grad():
+        model.stack.copy_(synth.make_plane_stack(*model.stack.shape[:4], seed=5) * 0.7)
+        if loop_mask:
+            model.stack_mask.copy_(synth.hash_uniform(tuple(model.stack_mask.shape), seed=6) * 3 - 2)
+    stack_cpu = model.stack.detach().cpu().clone().requires_grad_(True)
+    mask_cpu = model.stack_mask.detach().cpu().clone().requires_grad_(True) if loop_mask else None
+    h, w = 33, 47
+    Kc = K.copy(); Kc[0, 2] -= 6; Kc[1, 2] -= 5
+    tar2 = tar.copy(); tar2[:3, 3] = [-0.03, 0.02, 0.01]
+    tar_e = torch.tensor(np.stack([tar, tar2]))
+    tar_k = torch.tensor(np.stack([Kc, Kc]))
+    rgbl, extra = model(h, w, tar_e.to(dev), tar_k.to(dev))
+    rgbl_o, extra_o = mpv_oracle.mpi_forward(stack_cpu, mask_cpu, args, H, W, ref_extrin, K, 1.0, 100.0, h, w, tar_e, tar_k)
+    assert rgbl.shape == rgbl_o.shape == (2, 4 if loop_mask else 3, h, w)
+    assert float((rgbl.cpu() - rgbl_o).abs().max()) <= 1e-4
+    assert set(extra) == set(extra_o) == {"sparsity", "rgb_smooth", "a_smooth", "density"}
+    for k in extra:
+        assert abs(extra[k].item() - extra_o[k].item()) <= 2e-5 * max(1.0, abs(extra_o[k].item())), k
+    g = synth.hash_uniform(tuple(rgbl.shape), seed=9) - 0.5
+    wts = {"sparsity": 0.004, "rgb_smooth": 0.2, "a_smooth": 0.5, "density": 0.02}
+    tot = (rgbl * g.to(dev)).sum() + sum(extra[k].sum() * wts[k] for k in extra) * 50
+    tot_o = (rgbl_o * g).sum() + sum(extra_o[k].sum() * wts[k] for k in extra_o) * 50
+    params = [model.stack] + ([model.stack_mask] if loop_mask else [])
+    params_o = [stack_cpu] + ([mask_cpu] if loop_mask else [])
+    grads = torch.autograd.grad(tot, params)
+    grads_o = torch.autograd.grad(tot_o, params_o)
+    for gg, go in zip(grads, grads_o):
+        d = (gg.cpu() - go).abs()
+        scale = max(1.0, float(go.abs().max()))
+        assert float(d.max()) <= 5e-3 * scale and float((d > 1e-4 * scale).float().mean()) <= 1e-3
+        assert float(go.abs().max()) > 0
+
+
+def test_mpmesh_eval(dev):
+    from videoloop3d_amd.MPI import MPMesh
+    H, W = 44, 60
+    K, ref_extrin, tar = scene(H, W)
+    args = make_args_mpi()
+    model = MPMesh(args, H, W, ref_extrin, K, 1.0, 100.0).to(dev).eval()
+    with torch.no_grad():
+        rgbl, extra = model(H, W, torch.tensor(tar)[None].to(dev), torch.tensor(K)[None].to(dev))
+        rgbl_o, _ = mpv_oracle.mpi_forward(model.stack.detach().cpu(), model.stack_mask.detach().cpu(), args, H, W, ref_extrin, K, 1.0,
+                                           100.0, H, W, torch.tensor(tar)[None], torch.tensor(K)[None], training=False)
+    assert extra == {} and float((rgbl.cpu() - rgbl_o).abs().max()) <= 1e-4

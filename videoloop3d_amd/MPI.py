@@ -1,0 +1,125 @@
+"""MPMesh (stage 1, static MPI) on the MI355X-native render kernels: drop-in for the hot path of the reference's MPI.py.
+
+Mirrors /root/reference/MPI.py:36-131 (constructor), :452-594 (render) and :596-652 (forward) for PLANAR, un-sparsified
+geometry with rgb_mlp_type = 'direct' (configs/mpi_base.txt).  As in videoloop3d_amd/MPV.py the texture is the dense plane
+stack `stack` (D,1,mpi_h,mpi_w,4) (+ `stack_mask` (D,1,mpi_h,mpi_w) for the learned loop mask, MPI.py:115-117) instead of the
+atlas grid, and coverage/UVs are the analytic per-plane homography instead of pytorch3d's rasteriser.
+The loop-mask channel (MPI.py:568-583: sigmoid(mask texture) composited with the DETACHED layer alphas) is a second pass of
+the fused renderer on (mask, mask, mask, alpha.detach()).  sparsify_faces / direct2sh / save_* / optimizer are host-side
+one-shot bookkeeping and out of scope; d_smooth needs the rasteriser's depth buffer (default weight 0).
+"""
+import dataclasses
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .MPV import ACTIVATES, get_new_intrin, sparsity_ratio
+from .render import RenderSpec, render_planes, render_planes_with_regularisers
+from .utils_mpi import compute_homography, make_depths
+
+ALPHA_INIT_VAL = -3.     # MPI.py:33
+
+
+class MPMesh(nn.Module):
+    def __init__(self, args, H, W, ref_extrin, ref_intrin, near, far, pixel_center=0.5, texel_scale=(1.0, 1.0)):
+        super().__init__()
+        self.args = args
+        mpi_h, mpi_w = int(args.mpi_h_scale * H), int(args.mpi_w_scale * W)
+        self.mpi_h, self.mpi_w = mpi_h, mpi_w
+        self.mpi_d, self.near, self.far = args.mpi_d, near, far
+        self.H, self.W = H, W
+        if getattr(args, "rgb_mlp_type", "direct") != "direct":
+            raise RuntimeError(f"rgbmlp_type = {args.rgb_mlp_type} not supported (shipped configs use 'direct', mpi_base.txt:28)")
+        ref_extrin, ref_intrin = np.asarray(ref_extrin), np.asarray(ref_intrin)
+        assert ref_extrin.shape == (4, 4) and ref_intrin.shape == (3, 3)
+        self.register_buffer("ref_extrin", torch.tensor(ref_extrin))
+        self.register_buffer("ref_intrin", torch.tensor(ref_intrin).float())
+        self.register_buffer("planedepth", make_depths(self.mpi_d, near, far).float().flip(0))     # MPI.py:57
+        self.H_start, self.W_start = (mpi_h - H) // 2, (mpi_w - W) // 2
+        self.register_buffer("ref_intrin_mpi", get_new_intrin(self.ref_intrin, -self.H_start, -self.W_start))
+        stack = torch.rand((self.mpi_d, 1, mpi_h, mpi_w, 4))                                       # MPI.py:102-103
+        stack[..., -1] = ALPHA_INIT_VAL
+        self.stack = nn.Parameter(stack, requires_grad=True)
+        self.learn_loop_mask = bool(getattr(args, "learn_loop_mask", False))
+        if self.learn_loop_mask:
+            self.stack_mask = nn.Parameter(torch.ones((self.mpi_d, 1, mpi_h, mpi_w)) * ALPHA_INIT_VAL, requires_grad=True)
+        if args.rgb_activate not in ACTIVATES or args.alpha_activate not in ACTIVATES:
+            raise RuntimeError(f"activation ({args.rgb_activate}, {args.alpha_activate}) not implemented by the HIP kernels")
+        self.spec = dataclasses.replace(RenderSpec.mpv(rgb_act=args.rgb_activate, alpha_act=args.alpha_activate,
+                                                       scale=tuple(texel_scale)), pixel_center=float(pixel_center))
+        # the loop-mask pass: label = sigmoid(mask), alpha = the (detached) layer alpha with the model's activation
+        self.spec_mask = dataclasses.replace(self.spec, rgb_act="sigmoid")
+
+    def plane_homographies(self, extrin, intrin):
+        dev = extrin.device
+        eye = torch.eye(4, dtype=extrin.dtype, device=dev)[None]
+        normal = torch.tensor([0., 0., 1.], dtype=extrin.dtype, device=dev).expand(1, self.mpi_d, 3)
+        return compute_homography(eye, self.ref_intrin_mpi[None].to(extrin.dtype), extrin, intrin, normal,
+                                  self.planedepth[None].to(extrin.dtype))[0].float()
+
+    def render(self, H, W, extrin, intrin, need_reg=False):
+        """MPI.py:452-594 -> (rgbl [B,H,W,3|4], variables).  One fused render per view (the kernels share one camera per call)."""
+        B = len(extrin)
+        rgbs, alphas, labels, ssums, asums = [], [], [], [], []
+        for b in range(B):
+            homos = self.plane_homographies(extrin[b:b + 1], intrin[b:b + 1])
+            if need_reg:
+                rgb, alpha, ss, asum = render_planes_with_regularisers(self.stack, homos, H, W, self.spec)
+                ssums.append(ss)
+                asums.append(asum)
+            else:
+                rgb, alpha = render_planes(self.stack, homos, H, W, self.spec)
+            if len(self.args.bg_color) > 0:                                                       # MPI.py:550-556
+                if self.args.bg_color == "random":
+                    bg = torch.rand(3).type_as(rgb)
+                else:
+                    r, g, b_ = map(float, self.args.bg_color.split('#'))
+                    bg = torch.tensor([r, g, b_]).type_as(rgb)
+                rgb = rgb * alpha[..., None] + bg[None, None, None] * (- alpha[..., None] + 1)
+            rgbs.append(rgb)
+            alphas.append(alpha)
+            if self.learn_loop_mask:                                                              # MPI.py:568-583
+                m = self.stack_mask[..., None]
+                mstack = torch.cat([m, m, m, self.stack[..., 3:].detach()], dim=-1)
+                lab, _ = render_planes(mstack, homos, H, W, self.spec_mask)
+                labels.append(lab[..., :1])
+        rgb = torch.cat(rgbs, 0)
+        rgbl = torch.cat([rgb, torch.cat(labels, 0)], dim=-1) if self.learn_loop_mask else rgb
+        variables = {"pix_to_face": None, "blend_weight": None, "mpi": None, "loopmask3d": None, "disp_norm": None,
+                     "alpha": torch.cat(alphas, 0),
+                     "smooth_sums": torch.stack(ssums).sum(0) if ssums else None,
+                     "alpha_sums": torch.cat(asums, 0) if asums else None}
+        return rgbl, variables
+
+    def forward(self, h, w, tar_extrins, tar_intrins):
+        """MPI.py:596-652 -> (rgbl [B,3|4,h,w], extra)."""
+        a = self.args
+        extrins = tar_extrins @ self.ref_extrin[None, ...].inverse().to(tar_extrins.dtype)
+        need_reg = self.training and (a.sparsity_loss_weight > 0 or a.rgb_smooth_loss_weight > 0 or a.a_smooth_loss_weight > 0)
+        rgbl, variables = self.render(h, w, extrins, tar_intrins, need_reg=need_reg)
+        B = rgbl.shape[0]
+        rgbl = rgbl.permute(0, 3, 1, 2)
+        extra = {}
+        if self.training:
+            K_ = self.mpi_d
+            denorm = K_ / self.mpi_d
+            if a.sparsity_loss_weight > 0:
+                if a.alpha_activate == "none":
+                    raise RuntimeError("the fused sparsity term needs a non-negative alpha activation")
+                sp = sparsity_ratio(variables["alpha_sums"], 1e-6)                                # MPI.py:599-603
+                extra["sparsity"] = (sp.mean() / np.sqrt(self.mpi_d)).reshape(1, -1)
+            if a.rgb_smooth_loss_weight > 0 or a.a_smooth_loss_weight > 0:
+                nx, ny = B * h * (w - 1) * K_, B * (h - 1) * w * K_
+                sums = variables["smooth_sums"]
+                if a.rgb_smooth_loss_weight > 0:                                                 # MPI.py:605-611
+                    extra["rgb_smooth"] = ((sums[0] / (3 * nx) + sums[1] / (3 * ny)) * denorm).reshape(1, -1)
+                if a.a_smooth_loss_weight > 0:                                                   # MPI.py:613-619
+                    extra["a_smooth"] = ((sums[2] / nx + sums[3] / ny) * denorm).reshape(1, -1)
+            if getattr(a, "d_smooth_loss_weight", 0) > 0:
+                raise RuntimeError("d_smooth_loss_weight > 0 needs the rasteriser depth buffer (MPI.py:563-566); not on the planar path")
+            if getattr(a, "l_smooth_loss_weight", 0) > 0:
+                raise RuntimeError("l_smooth_loss_weight > 0 (default 0, config_parser.py:169) is not fused yet")
+            if a.density_loss_weight > 0:                                                        # MPI.py:647-650
+                extra["density"] = (variables["alpha"] - 1).abs().mean().reshape(1, -1)
+        return rgbl, extra

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .render import RenderSpec, render_planes, render_planes_with_smoothness
+from .render import RenderSpec, render_planes, render_planes_with_regularisers
 from .utils_mpi import compute_homography, make_depths, warp_homography
 from .utils_vid import Patch3DAvg, Patch3DGPNNDirectLoss, Patch3DGPNNLowMemLoss, Patch3DMSE
 
@@ -31,6 +31,14 @@ def get_new_intrin(old_intrin, new_h_start, new_w_start):
     new_intrin[..., 0, 2] -= new_w_start
     new_intrin[..., 1, 2] -= new_h_start
     return new_intrin
+
+
+def sparsity_ratio(alpha_sums, eps):
+    """per-pixel |a|_1 / max(|a|_2, eps) over the planes from the fused sums (sum a, sum a^2) [..., 2]
+    (alphas are >= 0 for the supported activations, so |a|_1 = sum a)."""
+    n1, n2s = alpha_sums[..., 0], alpha_sums[..., 1]
+    n2 = n2s.clamp_min(1e-30).sqrt()          # keeps sqrt's gradient finite where no plane covers the pixel
+    return n1 / n2.clamp_min(eps)
 
 
 def atlas_to_stack(atlas_dyn, mpi_d, grid_h):
@@ -114,13 +122,13 @@ class MPMeshVid(nn.Module):
         rgba, only consumed by the smoothness/sparsity regularisers) are materialised on demand with the unfused operators."""
         stack = self._frames(ts)
         homos = self.plane_homographies(extrin, intrin)
-        smooth_sums = None
+        smooth_sums = alpha_sums = None
         if need_smooth:
-            rgb, alpha, smooth_sums = render_planes_with_smoothness(stack, homos, H, W, self.spec)
+            rgb, alpha, smooth_sums, alpha_sums = render_planes_with_regularisers(stack, homos, H, W, self.spec)
         else:
             rgb, alpha = render_planes(stack, homos, H, W, self.spec)
         variables = {"pix_to_face": None, "blend_weight": None, "mpi": None, "disp_norm": None, "alpha": alpha,
-                     "smooth_sums": smooth_sums}
+                     "smooth_sums": smooth_sums, "alpha_sums": alpha_sums}
         if need_layers:
             mpi = self._layers(stack, homos, H, W)
             variables["mpi"] = mpi
@@ -165,9 +173,9 @@ class MPMeshVid(nn.Module):
         if ts is None:
             ts = torch.arange(self.frm_num).long()
         a = self.args
-        # rgb_smooth / a_smooth are fused into the render kernels; only the (shipped-off) sparsity term needs the layer tensor
-        need_layers = self.training and a.sparsity_loss_weight > 0
-        need_smooth = self.training and (a.rgb_smooth_loss_weight > 0 or a.a_smooth_loss_weight > 0)
+        # rgb_smooth / a_smooth / sparsity are fused into the render kernels: the [T,h,w,K,4] layer tensor is never built
+        need_layers = False
+        need_smooth = self.training and (a.rgb_smooth_loss_weight > 0 or a.a_smooth_loss_weight > 0 or a.sparsity_loss_weight > 0)
         rgb, variables = self.render(h, w, extrins, tar_intrins, ts, need_layers=need_layers, need_smooth=need_smooth)
         rgb = rgb.permute(0, 3, 1, 2)
         extra = {}
@@ -192,8 +200,7 @@ class MPMeshVid(nn.Module):
         extra['swd'] = main_loss.reshape(1, -1) * loss_gain
 
         if a.sparsity_loss_weight > 0:
-            alpha = variables["mpi"][..., -1]
-            sparsity = alpha.norm(dim=-1, p=1) / alpha.norm(dim=-1, p=2).clamp_min(1e-4)
+            sparsity = sparsity_ratio(variables["alpha_sums"], 1e-4)                       # MPV.py:511-515
             extra["sparsity"] = (sparsity.mean() / np.sqrt(self.mpi_d) * loss_gain).reshape(1, -1)
         if need_smooth:
             # means over [T,h,w-1,K,(3)] / [T,h-1,w,K,(3)] from the fused sums (MPV.py:517-531; K = mpi_d layers here)

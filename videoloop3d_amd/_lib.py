@@ -43,9 +43,9 @@ _I32, _I64, _F = C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "vl3d_last_error": ([], C.c_char_p),
     "vl3d_version": ([], C.c_int),
-    "vl3d_render_fwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P], C.c_int),
+    "vl3d_render_fwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P, _P], C.c_int),
     "vl3d_render_bwd_scratch_bytes": ([C.POINTER(RenderDesc)], C.c_int64),
-    "vl3d_render_bwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
+    "vl3d_render_bwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
     "vl3d_render_reg_fwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P], C.c_int),
     "vl3d_warp_fwd": ([_I32] * 6 + [_P, _P, _P, _P], C.c_int),
     "vl3d_warp_bwd": ([_I32] * 6 + [_P, _P, _P, _P], C.c_int),

@@ -29,6 +29,8 @@ struct RenderArgs {
     float *g_stack;
     int D, T, Hs, Ws, H, W, row0, col0;
     float pc, sx, sy, ox, oy;
+    float *asum;          // forward out (optional): per pixel (sum_k a_k, sum_k a_k^2) for the sparsity regulariser (MPV.py:511-515)
+    const float *g_asum;  // backward in (optional): per pixel dL/d(sum a), dL/d(sum a^2)
     const float *g_reg;  // device float[4]: dL/d(sum|dx rgb|), dL/d(sum|dy rgb|), dL/d(sum|dx a|), dL/d(sum|dy a|) or NULL
     double *reg_sums;    // device double[4] (forward of the layer-space smoothness regularisers)
     int tiles_x, tiles_y; // tile grid of the owner-computes backward
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
     const float gA = a.g_alpha ? a.g_alpha[pix] : 0.0f;
     // S = sum_k w_k q_k with q_k = G.c_k + gA  ==  G.C + gA*A from the saved forward outputs
     const float S = Gr * a.rgb[pix * 3 + 0] + Gg * a.rgb[pix * 3 + 1] + Gb * a.rgb[pix * 3 + 2] + gA * a.alpha[pix];
+    const float gN1 = a.g_asum ? a.g_asum[pix * 2 + 0] : 0.0f, gN2 = a.g_asum ? 2.0f * a.g_asum[pix * 2 + 1] : 0.0f;
     float Tr = 1.0f, P = 0.0f;
     for (int d = 0; d < a.D; ++d, plane += (size_t)a.T * a.Hs * a.Ws * TEXB, gplane += plane_stride * 4) {
         const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
         const float om = 1.0f - o.w;
         // dL/da_k = T_k q_k - (sum_{j>k} w_j q_j)/(1-a_k); everything behind a fully opaque plane has zero weight
         const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;
-        f4 go = f4{w * Gr, w * Gg, w * Gb, Tr * q - behind};   // grad wrt activated (c, a)
+        f4 go = f4{w * Gr, w * Gg, w * Gb, Tr * q - behind + (gN1 + gN2 * o.w)};   // grad wrt activated (c, a)
         Tr *= om;
         if (a.g_reg) {   // smoothness regularisers on the fallback path: re-sample the 4 neighbours' layer values
             const f4 gx = f4{a.g_reg[0], a.g_reg[0], a.g_reg[0], a.g_reg[2]}, gy = f4{a.g_reg[1], a.g_reg[1], a.g_reg[1], a.g_reg[3]};
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
     const size_t frame_b = (size_t)a.Hs * a.Ws * (F16 ? 8 : 16);
     const size_t plane_stride_b = (size_t)a.T * frame_b;
     const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * frame_b;
-    float Tr = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, A = 0.f;
+    float Tr = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, A = 0.f, n1 = 0.f, n2 = 0.f;
     // two register sets (A/B) so the taps of plane d+1 are in flight while plane d is shaded, without register copies
     Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy), tB = tA;
     f4 vA[4], vB[4];
@@ -258,6 +261,7 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
         const f4 o = shade2<ORDER, RACT, AACT>(T_, V_);               \
         const float w = o.w * Tr;                                     \
         cr += w * o.x; cg += w * o.y; cb += w * o.z; A += w;          \
+        n1 += o.w; n2 = fmaf(o.w, o.w, n2);                           \
         Tr *= (1.0f - o.w);                                           \
     }
     for (int d = 0;;) {
@@ -279,6 +283,7 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
     const size_t pix = ((size_t)t * a.H + y) * a.W + x;
     a.rgb[pix * 3 + 0] = cr; a.rgb[pix * 3 + 1] = cg; a.rgb[pix * 3 + 2] = cb;
     a.alpha[pix] = A;
+    if (a.asum) { a.asum[pix * 2 + 0] = n1; a.asum[pix * 2 + 1] = n2; }
 }
 
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool SWZ, bool F16 = false>
@@ -438,12 +443,13 @@ __global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
     const size_t plane_stride_b = (size_t)a.T * a.Hs * a.Ws * TEXB;
     const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * a.Hs * a.Ws * TEXB;
     float *gplane = a.g_stack + (size_t)t * frame;
-    float Gr = 0.f, Gg = 0.f, Gb = 0.f, gA = 0.f, S = 0.f;
+    float Gr = 0.f, Gg = 0.f, Gb = 0.f, gA = 0.f, S = 0.f, gN1 = 0.f, gN2 = 0.f;   // gN1 + gN2*a_k = d(sparsity sums)/da_k
     if (inimg) {
         const size_t pix = ((size_t)t * a.H + y) * a.W + x;
         Gr = a.g_rgb[pix * 3 + 0]; Gg = a.g_rgb[pix * 3 + 1]; Gb = a.g_rgb[pix * 3 + 2];
         gA = a.g_alpha ? a.g_alpha[pix] : 0.0f;
         S = Gr * a.rgb[pix * 3 + 0] + Gg * a.rgb[pix * 3 + 1] + Gb * a.rgb[pix * 3 + 2] + gA * a.alpha[pix];
+        if (a.g_asum) { gN1 = a.g_asum[pix * 2 + 0]; gN2 = 2.0f * a.g_asum[pix * 2 + 1]; }
     }
     float Tr = 1.0f, P = 0.0f;
     float gsx_c = 0.f, gsy_c = 0.f, gsx_a = 0.f, gsy_a = 0.f;
@@ -518,7 +524,7 @@ __global__ __launch_bounds__(RW *ROWS, 8) void render_bwd_tile_k(RenderArgs a) {
             P += w * q;
             const float om = 1.0f - o.w;
             const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;
-            gval = make_float4(w * Gr + sg.x, w * Gg + sg.y, w * Gb + sg.z, Tr * q - behind + sg.w);   // grad wrt activated (c, a)
+            gval = make_float4(w * Gr + sg.x, w * Gg + sg.y, w * Gb + sg.z, Tr * q - behind + sg.w + (gN1 + gN2 * o.w));   // grad wrt activated (c, a)
             Tr *= om;
             if constexpr (ORDER == VL3D_ACT_POST)
                 gval = make_float4(gval.x * act_bwd<RACT>(pre.x, o.x), gval.y * act_bwd<RACT>(pre.y, o.y),
@@ -754,12 +760,12 @@ RenderArgs make_args(const vl3d_render_desc *d) {
 }  // namespace
 
 extern "C" int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos,
-                               float *rgb, float *alpha, vl3d_stream_t stream) {
+                               float *rgb, float *alpha, float *alpha_sums, vl3d_stream_t stream) {
     int rc = check_desc(desc);
     if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE(stack && homos && rgb && alpha, "null pointer passed to vl3d_render_fwd");
     RenderArgs a = make_args(desc);
-    a.stack = (const float *)stack; a.homos = homos; a.rgb = rgb; a.alpha = alpha;
+    a.stack = (const float *)stack; a.homos = homos; a.rgb = rgb; a.alpha = alpha; a.asum = alpha_sums;
     a.fwd_variant = (desc->variant >> 8) & 0xf;
     a.ablate = (desc->variant >> 4) & 0xf;
     VL3D_REQUIRE((int64_t)desc->Hs * desc->Ws * 16 < (1ll << 32), "frame too large for 32-bit byte offsets");
@@ -797,15 +803,15 @@ extern "C" int vl3d_render_reg_fwd(const vl3d_render_desc *desc, const void *sta
 
 extern "C" int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, const float *homos,
                                const float *rgb, const float *alpha, const float *grad_rgb,
-                               const float *grad_alpha, const float *grad_reg, float *grad_stack, void *scratch,
-                               int64_t scratch_bytes, vl3d_stream_t stream) {
+                               const float *grad_alpha, const float *grad_reg, const float *grad_alpha_sums,
+                               float *grad_stack, void *scratch, int64_t scratch_bytes, vl3d_stream_t stream) {
     int rc = check_desc(desc);
     if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE(stack && homos && rgb && alpha && grad_rgb && grad_stack, "null pointer passed to vl3d_render_bwd");
     RenderArgs a = make_args(desc);
     a.stack = (const float *)stack; a.homos = homos;
     a.rgb = const_cast<float *>(rgb); a.alpha = const_cast<float *>(alpha);
-    a.g_rgb = grad_rgb; a.g_alpha = grad_alpha; a.g_reg = grad_reg; a.g_stack = grad_stack;
+    a.g_rgb = grad_rgb; a.g_alpha = grad_alpha; a.g_reg = grad_reg; a.g_asum = grad_alpha_sums; a.g_stack = grad_stack;
     // variant: 0 auto (tile kernel when its on-device plan says feasible, else atomics), 1 force atomics,
     //          2 tile with 8-row regions, 3 tile with 16-row regions
     const bool want_tile = (desc->variant & 0xf) != 1 && scratch != nullptr && scratch_bytes >= vl3d_render_bwd_scratch_bytes(desc);

@@ -70,8 +70,9 @@ class _RenderPlanes(torch.autograd.Function):
         rgb = torch.empty((T, H, W, 3), dtype=torch.float32, device=stack.device)
         alpha = torch.empty((T, H, W), dtype=torch.float32, device=stack.device)
         desc = _desc(stack, H, W, spec, row0, col0)
+        asum = torch.empty((T, H, W, 2), dtype=torch.float32, device=stack.device) if with_reg else None
         with torch.cuda.device(stack.device):
-            L.check(L.lib().vl3d_render_fwd(desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha),
+            L.check(L.lib().vl3d_render_fwd(desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.ptr(asum),
                                             L.stream_ptr(stack.device)), "vl3d_render_fwd")
         ctx.save_for_backward(stack, homos, rgb, alpha)
         ctx.desc = desc
@@ -81,12 +82,15 @@ class _RenderPlanes(torch.autograd.Function):
             with torch.cuda.device(stack.device):
                 L.check(L.lib().vl3d_render_reg_fwd(desc, L.ptr(stack), L.ptr(homos), L.ptr(sums), L.stream_ptr(stack.device)),
                         "vl3d_render_reg_fwd")
-        return rgb, alpha, sums.to(torch.float32)
+        if asum is None:
+            asum = torch.zeros((0,), dtype=torch.float32, device=stack.device)
+        return rgb, alpha, sums.to(torch.float32), asum
 
     @staticmethod
-    def backward(ctx, g_rgb, g_alpha, g_sums):
+    def backward(ctx, g_rgb, g_alpha, g_sums, g_asum):
         stack, homos, rgb, alpha = ctx.saved_tensors
         g_reg = g_sums.to(torch.float32).contiguous() if (ctx.with_reg and g_sums is not None) else None
+        g_asum = g_asum.to(torch.float32).contiguous() if (ctx.with_reg and g_asum is not None) else None
         g_rgb = g_rgb.contiguous() if g_rgb is not None else torch.zeros_like(rgb)
         g_alpha = g_alpha.contiguous() if g_alpha is not None else None
         g_stack = torch.empty(stack.shape, dtype=torch.float32, device=stack.device)   # grad_stack is always fp32 in the ABI
@@ -94,7 +98,7 @@ class _RenderPlanes(torch.autograd.Function):
             nscratch = int(L.lib().vl3d_render_bwd_scratch_bytes(ctx.desc))
             scratch = torch.zeros((nscratch + 3) // 4, dtype=torch.float32, device=stack.device)
             L.check(L.lib().vl3d_render_bwd(ctx.desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha),
-                                            L.ptr(g_rgb), L.ptr(g_alpha), L.ptr(g_reg), L.ptr(g_stack), L.ptr(scratch), nscratch,
+                                            L.ptr(g_rgb), L.ptr(g_alpha), L.ptr(g_reg), L.ptr(g_asum), L.ptr(g_stack), L.ptr(scratch), nscratch,
                                             L.stream_ptr(stack.device)), "vl3d_render_bwd")
         global LAST_BWD_SCRATCH
         LAST_BWD_SCRATCH = scratch
@@ -107,7 +111,7 @@ def render_planes(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0
     Returns rgb [T,H,W,3], alpha [T,H,W].  `window=(row0,col0)` renders the H x W sub-window whose top-left
     corner is frame pixel (row0,col0) -- used for row-band sharding (equivalent to utils.py:196-200
     get_new_intrin on the target intrinsics)."""
-    rgb, alpha, _ = _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), False)
+    rgb, alpha, _, _ = _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), False)
     return rgb, alpha
 
 
@@ -115,4 +119,11 @@ def render_planes_with_smoothness(stack, homos, H, W, spec: RenderSpec = RenderS
     """render_planes plus the raw sums of the layer-space smoothness regularisers (MPV.py:517-531), differentiable:
     returns (rgb, alpha, sums[4]) with sums = (sum|dx rgb|, sum|dy rgb|, sum|dx a|, sum|dy a|) over frames, planes and
     neighbouring pixel pairs of the warped+activated layers -- the [T,h,w,K,4] layer tensor is never materialised."""
+    rgb, alpha, sums, _ = _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), True)
+    return rgb, alpha, sums
+
+
+def render_planes_with_regularisers(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0)):
+    """(rgb, alpha, smooth_sums[4], alpha_sums[T,H,W,2]): render_planes_with_smoothness plus the per-pixel (sum_k a_k,
+    sum_k a_k^2) the sparsity regulariser |a|_1/|a|_2 (MPV.py:511-515, MPI.py:599-603) is built from; all differentiable."""
     return _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), True)
