@@ -254,6 +254,22 @@ def main():
             except Exception as e:   # the headline render number must still be reported
                 res["loss"] = {"error": repr(e)}
         if not a.no_stage2:
+            try:    # cfg2 of BASELINE.json (stage-1 shape): ONE 720p frame, D=32 -- launch-latency regime, reported beside the headline
+                st1 = synth.make_plane_stack(D, 1, Hs, Ws, seed=2, device=dev).requires_grad_(True)
+                g1 = synth.hash_uniform((1, H, W, 3), seed=5, device=dev) - 0.5
+                for it in range(25):
+                    if it == 5:
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                    r1, _ = render_planes(st1, homos_d, H, W, spec)
+                    (gs1,) = torch.autograd.grad(r1, st1, g1)
+                torch.cuda.synchronize()
+                dt1 = (time.perf_counter() - t1) / 20
+                res["cfg2_single_frame"] = {"value": H * W / dt1 / 1e6, "unit": "Mpix/s", "ms_per_step": dt1 * 1e3,
+                                            "workload": f"D={D}, T=1, {H}x{W} render fwd+bwd (stage-1 shape)"}
+                del st1, gs1
+            except Exception as e:
+                res["cfg2_single_frame"] = {"error": repr(e)}
             try:    # end-to-end stage-2 iterations on the drop-in module (render crop + looping loss + fused regularisers + Adam)
                 stack = None
                 torch.cuda.empty_cache()
