@@ -381,6 +381,133 @@ __global__ __launch_bounds__(NN_THREADS) void patchnn3_k(NN2Args a, int TyT) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// K3 v4: NL = 4 neighbouring patch locations per workgroup, column-sum formulation.
+// The 4 locations (by, bx0..bx0+3) share a ps x (ps + 3*stride) pixel region.  Per region row, the row (all columns,
+// channels and frames: ONE contiguous run in the pixel-major layout) is staged once; for every region column q the
+// frame-pair energy of that column  C = sum_c (x - y)^2  is formed once per thread tile and added to the accumulators of
+// the (up to ceil(ps/stride)) locations whose window contains q.  Versus one location per workgroup (v2) this halves the
+// VALU work (ps=11, stride=4: 23 columns instead of 44 per row), halves the staging traffic and amortises the per-workgroup
+// fixed costs over 4 locations; E lives in registers for the whole K loop (no LDS read-modify-write per chunk).
+constexpr int NL4 = 4;
+
+__global__ __launch_bounds__(NN_THREADS) void patchnn4_k(NN2Args a, int H_unused, int groups_x) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int RWc = a.ps + (NL4 - 1) * a.stride;               // region width in pixels
+    float *Xs = smem;                                           // [RWc*3][TxP]
+    float *Ys = Xs + (size_t)RWc * 3 * a.TxP;                   // [RWc*3][TyP]
+    float *E = Ys + (size_t)RWc * 3 * a.TyP;                    // [TxP][TyP] (one location at a time, epilogue)
+    float *colmin = E + (size_t)a.TxP * a.TyP;
+    const int g = blockIdx.x, by = g / groups_x, bx0 = (g % groups_x) * NL4;
+    const int r0 = by * a.stride, c0 = bx0 * a.stride, tid = threadIdx.x;
+    const int cols = min(RWc, a.W - c0);                        // the last group of a row may be narrower
+    const int nloc = min(NL4, a.w_o - bx0);
+    const int tiles_j = a.TyP / TJ, ntiles = (a.TxP / TI) * tiles_j;
+    const bool has_tile = tid < ntiles;
+    const int ti = has_tile ? (tid / tiles_j) * TI : 0, tj = has_tile ? (tid % tiles_j) * TJ : 0;
+    float acc[NL4][TI * TJ];
+#pragma unroll
+    for (int l = 0; l < NL4; ++l)
+#pragma unroll
+        for (int e = 0; e < TI * TJ; ++e) acc[l][e] = 0.f;
+    const int x4 = cols * 3 * a.TxP / 4, y4 = cols * 3 * a.TyP / 4;
+    for (int r = 0; r < a.ps; ++r) {
+        __syncthreads();
+        const float4 *xsrc = reinterpret_cast<const float4 *>(a.xt + ((size_t)(r0 + r) * a.W + c0) * 3 * a.TxP);
+        const float4 *ysrc = reinterpret_cast<const float4 *>(a.yt + ((size_t)(r0 + r) * a.W + c0) * 3 * a.TyP);
+        for (int i = tid; i < x4; i += NN_THREADS) reinterpret_cast<float4 *>(Xs)[i] = xsrc[i];
+        for (int i = tid; i < y4; i += NN_THREADS) reinterpret_cast<float4 *>(Ys)[i] = ysrc[i];
+        __syncthreads();
+        if (has_tile) {
+            for (int q = 0; q < cols; ++q) {
+                float C[TI * TJ];
+#pragma unroll
+                for (int e = 0; e < TI * TJ; ++e) C[e] = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float4 xv = *reinterpret_cast<const float4 *>(Xs + (q * 3 + c) * a.TxP + ti);
+                    const float4 yv = *reinterpret_cast<const float4 *>(Ys + (q * 3 + c) * a.TyP + tj);
+                    const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, ya[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+                    for (int i = 0; i < TI; ++i)
+#pragma unroll
+                        for (int j = 0; j < TJ; ++j) {
+                            const float df = xa[i] - ya[j];
+                            C[i * TJ + j] = fmaf(df, df, C[i * TJ + j]);
+                        }
+                }
+#pragma unroll
+                for (int l = 0; l < NL4; ++l) {
+                    const int ql = q - l * a.stride;           // column inside location l's window?
+                    if (ql >= 0 && ql < a.ps) {
+#pragma unroll
+                        for (int e = 0; e < TI * TJ; ++e) acc[l][e] += C[e];
+                    }
+                }
+            }
+        }
+    }
+    // epilogue, one location at a time through the shared E buffer
+    const int sub = tid & 3;
+#pragma unroll
+    for (int l = 0; l < NL4; ++l) {
+        if (l >= nloc) break;                                    // uniform
+        __syncthreads();
+        if (has_tile) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) E[(ti + i) * a.TyP + tj + j] = acc[l][i * TJ + j];
+        }
+        __syncthreads();
+        const size_t b = (size_t)by * a.w_o + bx0 + l;
+        if (a.use_alpha) {
+            for (int j = tid >> 2; j < a.n2; j += NN_THREADS / 4) {
+                float m = INFINITY;
+                for (int i = sub; i < a.n1; i += 4) {
+                    float sacc = 0.f;
+                    for (int kt = 0; kt < a.pt; ++kt) sacc += E[(i * a.stridet + kt) * a.TyP + j * a.stridet + kt];
+                    m = fminf(m, sacc / a.dnorm);
+                }
+                m = fminf(m, __shfl_xor(m, 1, 64));
+                m = fminf(m, __shfl_xor(m, 2, 64));
+                if (sub == 0) colmin[j] = a.alpha + m;
+            }
+            __syncthreads();
+        }
+        for (int i0 = 0; i0 < a.n1; i0 += NN_THREADS / 4) {
+            const int i = i0 + (tid >> 2);
+            const int qn = (a.n2 + 3) / 4, j0 = sub * qn, j1 = min(a.n2, j0 + qn);
+            float best = INFINITY;
+            int bj = j0;
+            bool best_nan = false;
+            if (i < a.n1) {
+                for (int j = j0; j < j1; ++j) {
+                    float sacc = 0.f;
+                    for (int kt = 0; kt < a.pt; ++kt) sacc += E[(i * a.stridet + kt) * a.TyP + j * a.stridet + kt];
+                    float v = sacc / a.dnorm;
+                    if (a.use_alpha) v = v / colmin[j];
+                    const bool vn = (v != v);
+                    if (!best_nan && (vn || v < best)) { best = v; bj = j; best_nan = vn; }
+                }
+            }
+#pragma unroll
+            for (int step = 1; step <= 2; step <<= 1) {
+                const float ob = __shfl_xor(best, step, 64);
+                const int oj = __shfl_xor(bj, step, 64);
+                const int on = __shfl_xor((int)best_nan, step, 64);
+                const bool other_lower = (sub & step) != 0;
+                bool take;
+                if (best_nan || on) take = on && (!best_nan || other_lower);
+                else take = (ob < best) || (ob == best && other_lower);
+                if (take) { best = ob; bj = oj; best_nan = on != 0; }
+            }
+            if (i < a.n1 && sub == 0) a.nn[b * a.n1 + i] = bj;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // get_NN_indices_low_memory on MATERIALISED patches (utils_vid.py:122-142; used by evaluations/NNMSE.py:45-56):
 // X [B,n1,d], Y [B,n2,d] dense.  One workgroup per batch entry b; dist[i][j] = sum_k (X[b,i,k]-Y[b,j,k])^2 / d kept in LDS.
@@ -692,7 +819,20 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
         const bool mf_ok = a.TxP <= 64 && TyT <= MF_MAXJT;
         const int pv = desc->variant & 0xf;
         const bool use_mf = mf_ok && pv == 3;
-        if (use_mf) {
+        // v4 (4 locations per workgroup, column sums): default whenever one thread tile per frame-pair tile suffices
+        const int ntiles4 = (a.TxP / TI) * (a.TyP / TJ);
+        const int RWc4 = a.ps + (NL4 - 1) * a.stride;
+        const size_t lds4 = ((size_t)RWc4 * 3 * (a.TxP + a.TyP) + (size_t)a.TxP * a.TyP + a.n2) * sizeof(float);
+        const bool use_v4 = (pv == 0 || pv == 4) && ntiles4 <= NN_THREADS && lds4 <= 150 * 1024;
+        if (use_v4) {
+            static bool attr4 = false;
+            if (!attr4) {
+                VL3D_HIP(hipFuncSetAttribute((const void *)patchnn4_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr4 = true;
+            }
+            const int groups_x = (a.w_o + NL4 - 1) / NL4;
+            hipLaunchKernelGGL(patchnn4_k, dim3((unsigned)(groups_x * a.h_o)), dim3(NN_THREADS), lds4, s, b, desc->H, groups_x);
+        } else if (use_mf) {
             const size_t fixed3 = ((size_t)64 * TyT * 16 + a.n2 + 64 + TyT * 16) * sizeof(float);
             int kc3 = (int)((48 * 1024 > fixed3 + 16 * (a.TxP + a.TyP) * sizeof(float) ? 48 * 1024 - fixed3 : 16 * (a.TxP + a.TyP) * sizeof(float)) /
                             ((size_t)(a.TxP + a.TyP) * sizeof(float)));
