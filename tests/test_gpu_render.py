@@ -424,3 +424,27 @@ def test_tiny_and_ragged_frames(dev, shape):
         assert maxabs(sums[0], sx) <= 1e-4 * max(1.0, float(sx)) and maxabs(sums[1], sy) <= 1e-4 * max(1.0, float(sy))
         d = (gs.cpu() - gs_o).abs()
         assert float(d.max()) <= 5e-3 and float((d > 1e-4).float().mean()) <= 2e-3
+
+
+@pytest.mark.parametrize("logit_hi", [3.0, 6.0])
+def test_nearly_opaque_planes_gradient_envelope(dev, logit_hi):
+    """The backward uses sum_{j>k} w_j q_j = (G.C + gA.A) - sum_{j<=k} w_j q_j, divided by (1 - a_k): cancellation error is
+    amplified by 1/(1-a).  With alpha logits up to +6 (a = 0.9975, amplification 400x) the gradient must still agree with the
+    oracle's autograd (which divides by (1-a) as well, through cumprod's backward) to 1e-4 of the gradient scale."""
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    D, T, Hs, Ws, H, W = 12, 1, 70, 90, 64, 80
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=23)
+    stack[..., 3] = synth.hash_uniform((D, T, Hs, Ws), seed=24) * (logit_hi + 4.0) - 4.0
+    homos = (torch.tensor([[Ws / W, 0, 0], [0, Hs / H, 0], [0, 0, 1.0]]) @ bench_homos(D, H, W, scale=1.0))
+    g_rgb = synth.hash_uniform((T, H, W, 3), seed=5) - 0.5
+    g_a = synth.hash_uniform((T, H, W), seed=6) - 0.5
+    spec_o = MO.RenderSpec(pixel_center=0.5, coord_mode="affine", border="hardcut", act_order="post")
+    s_cpu = stack.clone().double().requires_grad_(True)      # fp64 oracle = ground truth for the envelope
+    rgb_o, alpha_o, _ = MO.render_planes(s_cpu, homos.double(), H, W, spec_o)
+    (gs_o,) = torch.autograd.grad([rgb_o, alpha_o], s_cpu, [g_rgb.double(), g_a.double()])
+    s_gpu = stack.to(dev).requires_grad_(True)
+    for variant in (0, 1):
+        rgb, alpha = render_planes(s_gpu, homos.to(dev), H, W, RenderSpec.mpv(variant=variant))
+        (gs,) = torch.autograd.grad([rgb, alpha], s_gpu, [g_rgb.to(dev), g_a.to(dev)])
+        assert maxabs(rgb, rgb_o) <= TOL
+        assert maxabs(gs, gs_o) <= TOL * max(1.0, float(gs_o.abs().max()))
