@@ -34,10 +34,24 @@ struct RenderArgs {
     const float *g_reg;  // device float[4]: dL/d(sum|dx rgb|), dL/d(sum|dy rgb|), dL/d(sum|dx a|), dL/d(sum|dy a|) or NULL
     double *reg_sums;    // device double[4] (forward of the layer-space smoothness regularisers)
     int tiles_x, tiles_y; // tile grid of the owner-computes backward
+    int use_window;       // 1: render_bwd_tilew_k is launched as well and takes the call when its window fits
     int fwd_variant;     // forward kernel selector (see launch<>)
     int ablate;          // measurement-only switches (bit0: skip LDS scatter, bit1: skip flush stores, bit2: skip tap loads)
-    const float *plan;   // device scratch written by bwd_plan_k: [0] feasible flag, [16 + 9*d ..] inverse texel homographies
+    const float *plan;   // device scratch written by bwd_plan_k: [0] feasible flag, [16 + 12*d ..] inverse texel homographies,
+                         // then (bwd_windows_k) one int4 texel window per (tile, plane)
 };
+
+// Uniform, read-only tables (homographies, plan records) are read through the constant address space: the loads become
+// s_load_* into SGPRs.  Through a generic pointer hipcc cannot prove them invariant across the gradient stores of the
+// loop and emits per-lane global_load + s_waitcnt vmcnt(0) -- a full memory latency in front of every plane's taps.
+typedef const __attribute__((address_space(4))) float *cfloat_p;
+typedef const __attribute__((address_space(4))) int *cint_p;
+template <int N>
+__device__ __forceinline__ void load_uniform(const float *p, float (&out)[N]) {
+    const cfloat_p c = (cfloat_p)p;
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = c[i];
+}
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -66,10 +80,18 @@ __device__ __forceinline__ f2 fast_div2(f2 xy, float z) {
     return __builtin_elementwise_fma(e, rz2, q);
 }
 
+// integer form of the taps: clamped tap coordinates (always inside the plane) + weights
+struct TapsI {
+    int x0, x1, y0, y1;
+    float w[4];        // bilinear weights, 0 for taps outside the plane
+    float cov;         // 1 if the plane covers this pixel else 0
+    float tx, ty;      // texel coordinates of the sample
+};
+
 template <int COORD, int BORDER>
-__device__ __forceinline__ Taps2 make_taps2(const float *__restrict__ h, float px, float py, int Hs, int Ws,
-                                            float sx, float sy, float ox, float oy) {
-    Taps2 t;
+__device__ __forceinline__ TapsI make_taps_i(const float *__restrict__ h, float px, float py, int Hs, int Ws,
+                                             float sx, float sy, float ox, float oy) {
+    TapsI t;
     const f2 px2 = f2{px, px}, py2 = f2{py, py};
     const f2 XY = __builtin_elementwise_fma(f2{h[0], h[3]}, px2, __builtin_elementwise_fma(f2{h[1], h[4]}, py2, f2{h[2], h[5]}));
     const float Z = fmaf(h[6], px, fmaf(h[7], py, h[8]));
@@ -85,12 +107,10 @@ __device__ __forceinline__ Taps2 make_taps2(const float *__restrict__ h, float p
         const float txc = __builtin_amdgcn_fmed3f(tx, 0.0f, wm1), tyc = __builtin_amdgcn_fmed3f(ty, 0.0f, hm1);
         const float fx0 = floorf(txc), fy0 = floorf(tyc);
         const float fx = txc - fx0, fy = tyc - fy0;
-        const int x0 = (int)fx0, y0 = (int)fy0;
-        const int x1 = min(x0 + 1, Ws - 1), y1 = min(y0 + 1, Hs - 1);   // x0+1 == Ws only when fx == 0 (weight 0)
+        t.x0 = (int)fx0; t.y0 = (int)fy0;
+        t.x1 = min(t.x0 + 1, Ws - 1); t.y1 = min(t.y0 + 1, Hs - 1);   // x0+1 == Ws only when fx == 0 (weight 0)
         const float gx = 1.0f - fx, gy = 1.0f - fy;
         t.w[0] = gx * gy; t.w[1] = fx * gy; t.w[2] = gx * fy; t.w[3] = fx * fy;
-        const unsigned r0 = (unsigned)(y0 * Ws), r1 = (unsigned)(y1 * Ws);
-        t.off[0] = (r0 + x0) * 16u; t.off[1] = (r0 + x1) * 16u; t.off[2] = (r1 + x0) * 16u; t.off[3] = (r1 + x1) * 16u;
     } else {
         const bool cov = (tx > -1.0f) && (tx < (float)Ws) && (ty > -1.0f) && (ty < (float)Hs);
         t.cov = cov ? 1.0f : 0.0f;
@@ -102,11 +122,22 @@ __device__ __forceinline__ Taps2 make_taps2(const float *__restrict__ h, float p
         const float wx0 = (x0 >= 0 && x0 < Ws) ? 1.0f - fx : 0.0f, wx1 = (x0 + 1 < Ws) ? fx : 0.0f;
         const float wy0 = (y0 >= 0 && y0 < Hs) ? 1.0f - fy : 0.0f, wy1 = (y0 + 1 < Hs) ? fy : 0.0f;
         t.w[0] = wx0 * wy0; t.w[1] = wx1 * wy0; t.w[2] = wx0 * wy1; t.w[3] = wx1 * wy1;
-        const int x0c = min(max(x0, 0), Ws - 1), x1c = min(x0 + 1, Ws - 1);
-        const int y0c = min(max(y0, 0), Hs - 1), y1c = min(y0 + 1, Hs - 1);
-        const unsigned r0 = (unsigned)(y0c * Ws), r1 = (unsigned)(y1c * Ws);
-        t.off[0] = (r0 + x0c) * 16u; t.off[1] = (r0 + x1c) * 16u; t.off[2] = (r1 + x0c) * 16u; t.off[3] = (r1 + x1c) * 16u;
+        t.x0 = min(max(x0, 0), Ws - 1); t.x1 = min(x0 + 1, Ws - 1);
+        t.y0 = min(max(y0, 0), Hs - 1); t.y1 = min(y0 + 1, Hs - 1);
     }
+    return t;
+}
+
+template <int COORD, int BORDER>
+__device__ __forceinline__ Taps2 make_taps2(const float *__restrict__ h, float px, float py, int Hs, int Ws,
+                                            float sx, float sy, float ox, float oy) {
+    const TapsI ti = make_taps_i<COORD, BORDER>(h, px, py, Hs, Ws, sx, sy, ox, oy);
+    Taps2 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.w[i] = ti.w[i];
+    t.cov = ti.cov; t.tx = ti.tx; t.ty = ti.ty;
+    const unsigned r0 = (unsigned)(ti.y0 * Ws), r1 = (unsigned)(ti.y1 * Ws);
+    t.off[0] = (r0 + ti.x0) * 16u; t.off[1] = (r0 + ti.x1) * 16u; t.off[2] = (r1 + ti.x0) * 16u; t.off[3] = (r1 + ti.x1) * 16u;
     return t;
 }
 
@@ -311,8 +342,12 @@ void launch_fwd2(const RenderArgs &a, hipStream_t s) {
 // (Z>0 over the frame, magnification < 1.4x, window fits); if they fail, these kernels exit and the
 // universal atomics kernel above runs instead -- no host synchronisation either way.
 constexpr int RW = 64;        // region width in pixels = one wave
+constexpr int TWP = 72, THM = 24;  // LDS texel window of render_bwd_tilew_k: pitch / max rows (texels)
 constexpr int PLAN_HDR = 16;  // floats before the per-plane records
 constexpr int PLAN_REC = 12;  // per plane: 9 floats inverse texel homography, 2 floats gather radius (x,y), 1 pad
+// after the per-plane records (16-byte aligned): one int4 per (tile, plane) = texel window of the tile's owned pixels on
+// that plane: X0, Y0, width | height << 16, float bits of 1/width
+__host__ __device__ inline int plan_win_off(int D) { return (PLAN_HDR + PLAN_REC * D + 3) & ~3; }
 
 // texel-space homography  Ht = A_tex * H  (double), and its inverse
 template <int COORD>
@@ -329,8 +364,8 @@ __device__ void texel_homography(const float *h, int Hs, int Ws, float sx, float
 
 template <int COORD>
 __global__ void bwd_plan_k(RenderArgs a, int rows, float *plan) {
-    __shared__ int ok_all;
-    if (threadIdx.x == 0) ok_all = 1;
+    __shared__ int ok_all, win_all;
+    if (threadIdx.x == 0) { ok_all = 1; win_all = 1; }
     __syncthreads();
     for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
         double M[9];
@@ -362,6 +397,10 @@ __global__ void bwd_plan_k(RenderArgs a, int rows, float *plan) {
                 rxm = fmax(rxm, i_r0); rym = fmax(rym, i_r1);
                 // keep the owned footprint of a tile a small multiple of the workgroup (pure efficiency guard)
                 if (!(fabs(j00) + fabs(j01) < 4.0 && fabs(j10) + fabs(j11) < 4.0)) ok = false;
+                // does the 64 x rows region's footprint (+ taps) fit the LDS texel window of render_bwd_tilew_k? (10% safety)
+                const double wreq = 1.10 * (fabs(j00) * (RW - 1) + fabs(j01) * (rows - 1)) + 4.0;
+                const double hreq = 1.10 * (fabs(j10) * (RW - 1) + fabs(j11) * (rows - 1)) + 4.0;
+                if (!(wreq <= TWP && hreq <= THM)) atomicAnd(&win_all, 0);
             }
         // gather radius per axis: a pixel p contributes to texel tau only if |p - H^-1 tau| < |J^-1|_inf-row (2% safety)
         plan[PLAN_HDR + PLAN_REC * d + 9] = (float)fmin(1.02 * rxm + 1e-3, 1.45);
@@ -369,7 +408,39 @@ __global__ void bwd_plan_k(RenderArgs a, int rows, float *plan) {
         if (!ok) atomicAnd(&ok_all, 0);
     }
     __syncthreads();
-    if (threadIdx.x == 0) reinterpret_cast<int *>(plan)[0] = ok_all;
+    if (threadIdx.x == 0) { reinterpret_cast<int *>(plan)[0] = ok_all; reinterpret_cast<int *>(plan)[1] = ok_all & win_all; }
+}
+
+// Texel window of every (tile, plane): the footprint of the tile's owned pixels, from the image of its four corners
+// (convex image of a rectangle, Z>0).  Texels owned by a tile have their owner pixel inside it, i.e. H^-1(tau) within 0.5 px
+// of the tile (0.55 here: the margin absorbs the fp32 error of the corner images); beyond a frame border the owner is the
+// clamped border pixel, so only texels within the 1.4 px contribution range matter (1.6).  Frame independent: computed
+// once per call here instead of by wave 0 of every workgroup for every plane (90 VALU instructions on the barrier path).
+template <int COORD>
+__global__ __launch_bounds__(256) void bwd_windows_k(RenderArgs a, int iw, int ih, int tiles_x, int tiles_y, int *win) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= tiles_x * tiles_y * a.D) return;
+    const int d = i % a.D, tile = i / a.D, tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+    const int ix0 = tile_x * iw, ix1 = min(ix0 + iw - 1, a.W - 1), iy0 = tile_y * ih, iy1 = min(iy0 + ih - 1, a.H - 1);
+    const float el = (ix0 == 0) ? 1.6f : 0.55f, er = (ix1 == a.W - 1) ? 1.6f : 0.55f;
+    const float et = (iy0 == 0) ? 1.6f : 0.55f, eb = (iy1 == a.H - 1) ? 1.6f : 0.55f;
+    const float *h = a.homos + 9 * d;
+    float mnx = 1e30f, mxx = -1e30f, mny = 1e30f, mxy = -1e30f;
+    for (int c = 0; c < 4; ++c) {
+        const float cx = (float)a.col0 + a.pc + ((c & 1) ? (float)ix1 + er : (float)ix0 - el);
+        const float cy = (float)a.row0 + a.pc + ((c & 2) ? (float)iy1 + eb : (float)iy0 - et);
+        const float X = h[0] * cx + h[1] * cy + h[2], Y = h[3] * cx + h[4] * cy + h[5], Z = h[6] * cx + h[7] * cy + h[8];
+        const float ctx = texel_coord<COORD>(X / Z, (float)a.Ws / 2.0f, (float)(a.Ws - 1), a.sx, a.ox);
+        const float cty = texel_coord<COORD>(Y / Z, (float)a.Hs / 2.0f, (float)(a.Hs - 1), a.sy, a.oy);
+        mnx = fminf(mnx, ctx); mxx = fmaxf(mxx, ctx); mny = fminf(mny, cty); mxy = fmaxf(mxy, cty);
+    }
+    const int wX0 = max(0, (int)ceilf(fmaxf(mnx - 0.01f, -2.0f))), wY0 = max(0, (int)ceilf(fmaxf(mny - 0.01f, -2.0f)));
+    const int wX1 = min(a.Ws - 1, (int)floorf(fminf(mxx + 0.01f, (float)a.Ws)));
+    const int wY1 = min(a.Hs - 1, (int)floorf(fminf(mxy + 0.01f, (float)a.Hs)));
+    const int ww = min(max(0, wX1 - wX0 + 1), 0xffff), wh = min(max(0, wY1 - wY0 + 1), 0x7fff);
+    int4 rec;
+    rec.x = wX0; rec.y = wY0; rec.z = ww | (wh << 16); rec.w = __float_as_int(1.0f / (float)max(ww, 1));
+    reinterpret_cast<int4 *>(win)[i] = rec;     // [tile][plane]: one contiguous run per workgroup
 }
 
 __device__ __forceinline__ float fast_rcp(float z);
@@ -414,6 +485,7 @@ __global__ __launch_bounds__(256) void bwd_fill_zero_if_infeasible_k(float4 *g, 
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16>
 __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(RenderArgs a) {
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
+    if (a.use_window && reinterpret_cast<const int *>(a.plan)[1]) return;     // render_bwd_tilew_k owns this call
     constexpr int NT = RW * ROWS;
     // REG: the layer-space smoothness regularisers (MPV.py:517-531) are differentiated here as well.  Their gradient at a
     // pixel needs the activated layer values of its 4 neighbours, so the region carries a 2-pixel halo (outer ring: layer
@@ -423,7 +495,6 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
     // per-plane staging of the region's pixels, double buffered so one barrier per plane suffices
     __shared__ float4 s_g[2][NT];     // gradient w.r.t. the sampled (POST) / activated (PRE) value of this pixel on this plane
     __shared__ float2 s_t[2][NT];     // its texel coordinates (tx,ty); -1e30 when the plane does not cover the pixel
-    __shared__ int s_w[2][4];         // texel window of the owned tile on this plane: X0, Y0, width, height
     const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
     // 1-D grid, XCD-aware order: every XCD walks a contiguous run of tiles (row-major within a frame), so a tile's halo
     // rows and its neighbours' taps hit the same L2
@@ -456,34 +527,12 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
     if constexpr (REG) { gsx_c = a.g_reg[0]; gsy_c = a.g_reg[1]; gsx_a = a.g_reg[2]; gsy_a = a.g_reg[3]; }
     // pixels of the outermost ring only provide layer values in REG mode
     const bool provider = !REG || (lane >= 1 && lane <= RW - 2 && row >= 1 && row <= ROWS - 2);
+    // this tile's texel windows, one int4 per plane (bwd_windows_k)
+    const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)(tile_y * a.tiles_x + tile_x) * a.D * 4;
     for (int d = 0; d < a.D; ++d, plane += plane_stride_b, gplane += plane_stride) {
-        const float *h = a.homos + 9 * d;
+        float h[9];
+        load_uniform(a.homos + 9 * d, h);
         const int buf = d & 1;
-        // (1) footprint of the owned tile on plane d from its four corners (convex image of a rectangle, Z>0).
-        //     Texels owned by this tile have their owner pixel inside it, i.e. H^-1(tau) within 0.5 px of the tile
-        //     (any distance beyond a frame border, where only texels within the 1.4 px contribution range matter).
-        //     Wave 0 evaluates the corners (lane & 3), reduces them with two shuffles and publishes the integer window.
-        if (tid < 64) {
-            const float el = (ix0 == 0) ? 1.6f : 0.6f, er = (ix1 == a.W - 1) ? 1.6f : 0.6f;
-            const float et = (iy0 == 0) ? 1.6f : 0.6f, eb = (iy1 == a.H - 1) ? 1.6f : 0.6f;
-            const float cx = (float)a.col0 + a.pc + ((tid & 1) ? (float)ix1 + er : (float)ix0 - el);
-            const float cy = (float)a.row0 + a.pc + ((tid & 2) ? (float)iy1 + eb : (float)iy0 - et);
-            const float X = h[0] * cx + h[1] * cy + h[2], Y = h[3] * cx + h[4] * cy + h[5], Z = h[6] * cx + h[7] * cy + h[8];
-            const float ctx = texel_coord<COORD>(X / Z, (float)a.Ws / 2.0f, (float)(a.Ws - 1), a.sx, a.ox);
-            const float cty = texel_coord<COORD>(Y / Z, (float)a.Hs / 2.0f, (float)(a.Hs - 1), a.sy, a.oy);
-            float mnx = ctx, mxx = ctx, mny = cty, mxy = cty;
-#pragma unroll
-            for (int m = 1; m <= 2; m <<= 1) {
-                mnx = fminf(mnx, __shfl_xor(mnx, m, 64)); mxx = fmaxf(mxx, __shfl_xor(mxx, m, 64));
-                mny = fminf(mny, __shfl_xor(mny, m, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, m, 64));
-            }
-            if (tid == 0) {
-                const int wX0 = max(0, (int)floorf(fmaxf(mnx - 0.01f, -2.0f))), wY0 = max(0, (int)floorf(fmaxf(mny - 0.01f, -2.0f)));
-                const int wX1 = min(a.Ws - 1, (int)floorf(fminf(mxx + 0.01f, (float)a.Ws)) + 1);
-                const int wY1 = min(a.Hs - 1, (int)floorf(fminf(mxy + 0.01f, (float)a.Hs)) + 1);
-                s_w[buf][0] = wX0; s_w[buf][1] = wY0; s_w[buf][2] = max(0, wX1 - wX0 + 1); s_w[buf][3] = max(0, wY1 - wY0 + 1);
-            }
-        }
         // (2) sample this pixel on plane d, composite backward, stage (tx,ty,g) in LDS   (branch-free taps)
         float2 tc = make_float2(-1e30f, -1e30f);
         float4 gval = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -536,9 +585,11 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
         s_g[buf][tid] = gval;
         __syncthreads();   // staging of plane d visible (the other buffer may still be read by slower waves: not touched here)
         // (3) every texel owned by this tile gathers its taps from the 3x3 pixels around its owner pixel
-        const int X0 = s_w[buf][0], Y0 = s_w[buf][1], ww = s_w[buf][2], wh = s_w[buf][3];
-        const float inv_ww = 1.0f / (float)max(ww, 1);
-        const float *hi = a.plan + PLAN_HDR + PLAN_REC * d;
+        const int X0 = wrec[4 * d], Y0 = wrec[4 * d + 1], wwh = wrec[4 * d + 2];
+        const int ww = wwh & 0xffff, wh = wwh >> 16;
+        const float inv_ww = __int_as_float(wrec[4 * d + 3]);
+        float hi[9];
+        load_uniform(a.plan + PLAN_HDR + PLAN_REC * d, hi);
         if (a.ablate & 1) continue;
         for (int idx = tid; idx < ww * wh; idx += NT) {
             const int wy = (int)(((float)idx + 0.5f) * inv_ww), wx = idx - wy * ww;
@@ -560,10 +611,8 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
 #pragma unroll
                 for (int dx = -1; dx <= 1; ++dx) {
                     const int li = lc + dy * RW + dx;
-                    const f2 c = *reinterpret_cast<const f2 *>(&s_t[buf][li]);
-                    f2 wv = 1.0f - __builtin_elementwise_abs(c - tau);
-                    wv = __builtin_elementwise_max(wv, f2{0.f, 0.f});
-                    acc += *reinterpret_cast<const f4 *>(&s_g[buf][li]) * (wv.x * wv.y);
+                    const f2 dc = *reinterpret_cast<const f2 *>(&s_t[buf][li]) - tau;
+                    acc += *reinterpret_cast<const f4 *>(&s_g[buf][li]) * (tent_weight(dc.x) * tent_weight(dc.y));
                 }
             const size_t toff = ((size_t)(Y0 + wy) * a.Ws + (X0 + wx)) * 4;
             if constexpr (ORDER == VL3D_ACT_PRE) {   // d act(s_tau)/d s_tau factors out of the tap sum
@@ -576,6 +625,172 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
     }
 }
 
+
+
+// =====================================================================================================
+// Backward, variant "tile + LDS texel window" (the north star's LDS-staged tile window, for the kernel where it pays):
+// same owner-computes gather as render_bwd_tile_k, but the taps of the sweep no longer come through the vector L1.
+// The region's footprint on plane d+1 (a ~66x18-texel window, each texel ONCE, coalesced rows) is fetched by the whole
+// workgroup right after the barrier of plane d with the LDS-DMA (global_load_lds_dwordx4: no VGPRs), lands while the gather
+// of plane d runs, and the sweep of plane d+1 reads its 4 taps from LDS: no global-memory latency in the critical path, and
+// the 4x tap redundancy + the halo pixels' taps cost LDS bandwidth instead of L1/TA requests.
+
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT>
+__global__ __launch_bounds__(RW * 16, 8) void render_bwd_tilew_k(RenderArgs a) {
+    const int *plan_i = reinterpret_cast<const int *>(a.plan);
+    if (!plan_i[0] || !plan_i[1]) return;
+    constexpr int ROWS = 16, NT = RW * ROWS, RH = 1;
+    __shared__ float4 s_g[NT];
+    __shared__ float2 s_t[NT];
+    __shared__ float4 s_win[TWP * THM];
+    __shared__ int s_w[4];            // owned-texel window of plane d
+    __shared__ int s_tw[2][4];        // tap window (X0, Y0, width, height) of plane d (parity)
+    const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_x = bid % a.tiles_x, rest = bid / a.tiles_x;
+    const int tile_y = rest % a.tiles_y, t = rest / a.tiles_y;
+    const int rx0 = tile_x * (RW - 2 * RH) - RH, ry0 = tile_y * (ROWS - 2 * RH) - RH;
+    const int x = rx0 + lane, y = ry0 + row;
+    const bool inimg = (x >= 0) && (x < a.W) && (y >= 0) && (y < a.H);
+    const int ix0 = max(rx0 + RH, 0), ix1 = min(rx0 + RW - 1 - RH, a.W - 1);
+    const int iy0 = max(ry0 + RH, 0), iy1 = min(ry0 + ROWS - 1 - RH, a.H - 1);
+    const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
+    const size_t frame = (size_t)a.Hs * a.Ws * 4;
+    const size_t plane_stride = (size_t)a.T * frame;
+    const float *plane = a.stack + (size_t)t * frame;
+    float *gplane = a.g_stack + (size_t)t * frame;
+    float Gr = 0.f, Gg = 0.f, Gb = 0.f, gA = 0.f, S = 0.f, gN1 = 0.f, gN2 = 0.f;
+    if (inimg) {
+        const size_t pix = ((size_t)t * a.H + y) * a.W + x;
+        Gr = a.g_rgb[pix * 3 + 0]; Gg = a.g_rgb[pix * 3 + 1]; Gb = a.g_rgb[pix * 3 + 2];
+        gA = a.g_alpha ? a.g_alpha[pix] : 0.0f;
+        S = Gr * a.rgb[pix * 3 + 0] + Gg * a.rgb[pix * 3 + 1] + Gb * a.rgb[pix * 3 + 2] + gA * a.alpha[pix];
+        if (a.g_asum) { gN1 = a.g_asum[pix * 2 + 0]; gN2 = 2.0f * a.g_asum[pix * 2 + 1]; }
+    }
+    // footprint window of a pixel rectangle [x_lo,x_hi] x [y_lo,y_hi] (+margins) on plane dd: wave 0, lane & 3 = corner
+    auto footprint = [&](int dd, float x_lo, float x_hi, float y_lo, float y_hi, int *out) {
+        const float *h = a.homos + 9 * dd;
+        const float cx = (float)a.col0 + a.pc + ((tid & 1) ? x_hi : x_lo);
+        const float cy = (float)a.row0 + a.pc + ((tid & 2) ? y_hi : y_lo);
+        const float X = h[0] * cx + h[1] * cy + h[2], Y = h[3] * cx + h[4] * cy + h[5], Z = h[6] * cx + h[7] * cy + h[8];
+        const float ctx = texel_coord<COORD>(X / Z, (float)a.Ws / 2.0f, (float)(a.Ws - 1), a.sx, a.ox);
+        const float cty = texel_coord<COORD>(Y / Z, (float)a.Hs / 2.0f, (float)(a.Hs - 1), a.sy, a.oy);
+        float mnx = ctx, mxx = ctx, mny = cty, mxy = cty;
+#pragma unroll
+        for (int m = 1; m <= 2; m <<= 1) {
+            mnx = fminf(mnx, __shfl_xor(mnx, m, 64)); mxx = fmaxf(mxx, __shfl_xor(mxx, m, 64));
+            mny = fminf(mny, __shfl_xor(mny, m, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, m, 64));
+        }
+        if (tid == 0) {
+            const int wX0 = max(0, (int)floorf(fmaxf(mnx - 0.01f, -2.0f))), wY0 = max(0, (int)floorf(fmaxf(mny - 0.01f, -2.0f)));
+            const int wX1 = min(a.Ws - 1, (int)floorf(fminf(mxx + 0.01f, (float)a.Ws)) + 1);
+            const int wY1 = min(a.Hs - 1, (int)floorf(fminf(mxy + 0.01f, (float)a.Hs)) + 1);
+            out[0] = wX0; out[1] = wY0; out[2] = max(0, wX1 - wX0 + 1); out[3] = max(0, wY1 - wY0 + 1);
+        }
+    };
+    // asynchronous fetch of the tap window of a plane straight into LDS (global_load_lds_dwordx4: no VGPRs, the data lands
+    // while the gather runs).  The window is stored DENSE (pitch = its width), so texel idx of the window is LDS slot idx
+    // and a wave's 64 consecutive idx are the 1 KiB contiguous destination the LDS-DMA writes (wave-uniform base + lane*16).
+    auto win_dma = [&](const float *pl, const int *tw) {
+        const int w_ = min(tw[2], TWP), n = min(w_ * min(tw[3], THM), TWP * THM);
+        const float inv = 1.0f / (float)max(w_, 1);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = tid + k * NT;
+            if (idx < n) {
+                const int wy = (int)(((float)idx + 0.5f) * inv), wx = idx - wy * w_;
+                const float *g = pl + ((size_t)(tw[1] + wy) * a.Ws + (tw[0] + wx)) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                 (__attribute__((address_space(3))) void *)(s_win + (idx - lane)), 16, 0, 0);
+            }
+        }
+    };
+    // region rectangle incl. halo, one more pixel of margin for the +1 taps is added by the floor()+1 of the window
+    const float rxl = (float)rx0, rxh = (float)(rx0 + RW - 1), ryl = (float)ry0, ryh = (float)(ry0 + ROWS - 1);
+    if (tid < 64) footprint(0, rxl, rxh, ryl, ryh, s_tw[0]);
+    __syncthreads();
+    win_dma(plane, s_tw[0]);
+    __syncthreads();      // (drains the LDS-DMA: hipcc emits vmcnt(0) in front of the barrier while a DMA is in flight)
+    float Tr = 1.0f, P = 0.0f;
+    for (int d = 0; d < a.D; ++d, plane += plane_stride, gplane += plane_stride) {
+        const float *h = a.homos + 9 * d;
+        const int par = d & 1;
+        if (tid < 64) {
+            const float el = (ix0 == 0) ? 1.6f : 0.6f, er = (ix1 == a.W - 1) ? 1.6f : 0.6f;
+            const float et = (iy0 == 0) ? 1.6f : 0.6f, eb = (iy1 == a.H - 1) ? 1.6f : 0.6f;
+            footprint(d, (float)ix0 - el, (float)ix1 + er, (float)iy0 - et, (float)iy1 + eb, s_w);
+            if (d + 1 < a.D) footprint(d + 1, rxl, rxh, ryl, ryh, s_tw[par ^ 1]);
+        }
+        // (2) sweep: taps from the LDS window
+        float2 tc = make_float2(-1e30f, -1e30f);
+        float4 gval = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int TX0 = s_tw[par][0], TY0 = s_tw[par][1], tw_ = min(s_tw[par][2], TWP), th_ = min(s_tw[par][3], THM);
+        if (inimg && tw_ > 0 && th_ > 0) {
+            const TapsI ti = make_taps_i<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            const int lx0 = min(max(ti.x0 - TX0, 0), tw_ - 1), lx1 = min(max(ti.x1 - TX0, 0), tw_ - 1);
+            const int ly0 = min(max(ti.y0 - TY0, 0), th_ - 1), ly1 = min(max(ti.y1 - TY0, 0), th_ - 1);
+            Taps2 tp;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tp.w[i] = ti.w[i];
+            tp.cov = ti.cov; tp.tx = ti.tx; tp.ty = ti.ty;
+            f4 tv[4], pre;
+            auto ldw = [&](int ly, int lx) { const float4 v = s_win[ly * tw_ + lx]; return f4{v.x, v.y, v.z, v.w}; };
+            tv[0] = ldw(ly0, lx0); tv[1] = ldw(ly0, lx1); tv[2] = ldw(ly1, lx0); tv[3] = ldw(ly1, lx1);
+            const f4 o = shade2<ORDER, RACT, AACT>(tp, tv, &pre);
+            const float q = Gr * o.x + Gg * o.y + Gb * o.z + gA;
+            const float w = o.w * Tr;
+            P += w * q;
+            const float om = 1.0f - o.w;
+            const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;
+            gval = make_float4(w * Gr, w * Gg, w * Gb, Tr * q - behind + (gN1 + gN2 * o.w));
+            Tr *= om;
+            if constexpr (ORDER == VL3D_ACT_POST)
+                gval = make_float4(gval.x * act_bwd<RACT>(pre.x, o.x), gval.y * act_bwd<RACT>(pre.y, o.y),
+                                   gval.z * act_bwd<RACT>(pre.z, o.z), gval.w * act_bwd<AACT>(pre.w, o.w));
+            if (tp.cov > 0.0f) tc = make_float2(tp.tx, tp.ty);
+            else gval = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        s_t[tid] = tc;
+        s_g[tid] = gval;
+        __syncthreads();   // (Y) staging visible, every sweep is done with the texel window, window geometries published
+        // start the LDS-DMA of the texel window of plane d+1 now: it lands while the gather runs
+        if (d + 1 < a.D) win_dma(plane + plane_stride, s_tw[par ^ 1]);
+        // (3) gather (identical to render_bwd_tile_k)
+        const int X0 = s_w[0], Y0 = s_w[1], ww = s_w[2], wh = s_w[3];
+        const float inv_ww = 1.0f / (float)max(ww, 1);
+        const float *hi = a.plan + PLAN_HDR + PLAN_REC * d;
+        for (int idx = tid; idx < ww * wh; idx += NT) {
+            const int wy = (int)(((float)idx + 0.5f) * inv_ww), wx = idx - wy * ww;
+            const float tauX = (float)(X0 + wx), tauY = (float)(Y0 + wy);
+            float qx, qy;
+            owner_pixel(hi, tauX, tauY, a.pc, a.col0, a.row0, qx, qy);
+            const float rx = fminf(fmaxf(rintf(qx), 0.0f), (float)(a.W - 1));
+            const float ry = fminf(fmaxf(rintf(qy), 0.0f), (float)(a.H - 1));
+            if (!(rx >= (float)ix0 && rx <= (float)ix1 && ry >= (float)iy0 && ry <= (float)iy1)) continue;
+            const int lc = ((int)ry - ry0) * RW + ((int)rx - rx0);
+            const f2 tau = f2{tauX, tauY};
+            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int li = lc + dy * RW + dx;
+                    const f2 c = *reinterpret_cast<const f2 *>(&s_t[li]);
+                    f2 wv = 1.0f - __builtin_elementwise_abs(c - tau);
+                    wv = __builtin_elementwise_max(wv, f2{0.f, 0.f});
+                    acc += *reinterpret_cast<const f4 *>(&s_g[li]) * (wv.x * wv.y);
+                }
+            const size_t toff = ((size_t)(Y0 + wy) * a.Ws + (X0 + wx)) * 4;
+            if constexpr (ORDER == VL3D_ACT_PRE) {
+                const f4 sv = *reinterpret_cast<const f4 *>(plane + toff);
+                acc = f4{acc.x * act_bwd<RACT>(sv.x, act_fwd<RACT>(sv.x)), acc.y * act_bwd<RACT>(sv.y, act_fwd<RACT>(sv.y)),
+                         acc.z * act_bwd<RACT>(sv.z, act_fwd<RACT>(sv.z)), acc.w * act_bwd<AACT>(sv.w, act_fwd<AACT>(sv.w))};
+            }
+            *reinterpret_cast<f4 *>(gplane + toff) = acc;
+        }
+        __syncthreads();   // (X) DMA drained (vmcnt(0) + barrier): texel window of plane d+1 in LDS; staging buffers free again
+    }
+}
 
 // =====================================================================================================
 // Layer-space smoothness regularisers, forward (MPV.py:517-531): sum over frames, planes and neighbouring pixel pairs of
@@ -641,6 +856,9 @@ void launch_tile(const RenderArgs &a, hipStream_t s) {
     constexpr int RH = REG ? 2 : 1, IW = RW - 2 * RH, IH = ROWS - 2 * RH;
     RenderArgs b = a;
     b.tiles_x = (a.W + IW - 1) / IW; b.tiles_y = (a.H + IH - 1) / IH;
+    const int nwin = b.tiles_x * b.tiles_y * a.D;
+    hipLaunchKernelGGL((bwd_windows_k<COORD>), dim3((nwin + 255) / 256), dim3(256), 0, s, b, IW, IH, b.tiles_x, b.tiles_y,
+                       reinterpret_cast<int *>(const_cast<float *>(a.plan)) + plan_win_off(a.D));
     hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16>),
                        dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
 }
@@ -652,6 +870,8 @@ thread_local bool g_reg_fwd = false;
 
 // fp16 plane stacks (cfg5) are instantiated for the shipped (sigmoid, sigmoid) activations only
 thread_local bool g_f16 = false;
+// backward: also launch the LDS-texel-window variant (takes the call when the on-device plan says its window fits)
+thread_local bool g_use_window = false;
 
 template <bool BWD, int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
 void launch_t(const RenderArgs &a, hipStream_t s) {
@@ -668,7 +888,17 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
             }
             if (!done) {
                 if (a.g_reg) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, F16>(a, s);
-                else launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, false, F16>(a, s);
+                else {
+                    RenderArgs aw = a;
+                    aw.use_window = (!F16 && g_use_window) ? 1 : 0;
+                    if (aw.use_window) {
+                        RenderArgs b = aw;
+                        b.tiles_x = (a.W + RW - 3) / (RW - 2); b.tiles_y = (a.H + 13) / 14;
+                        hipLaunchKernelGGL((render_bwd_tilew_k<COORD, BORDER, ORDER, RACT, AACT>),
+                                           dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * 16), 0, s, b);
+                    }
+                    launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, false, F16>(aw, s);
+                }
             }
         }
         hipLaunchKernelGGL((render_bwd_k<COORD, BORDER, ORDER, RACT, AACT, F16>), grid, block, 0, s, a);
@@ -778,8 +1008,10 @@ extern "C" int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, 
 }
 
 extern "C" int64_t vl3d_render_bwd_scratch_bytes(const vl3d_render_desc *desc) {
-    if (!desc || desc->D <= 0) return 0;
-    return (int64_t)(PLAN_HDR + PLAN_REC * (int64_t)desc->D) * sizeof(float);
+    if (!desc || desc->D <= 0 || desc->H <= 0 || desc->W <= 0) return 0;
+    // per-plane records + one int4 window per (tile, plane), sized for the smallest tile interior any variant uses (60 x 6)
+    const int64_t tiles = (int64_t)((desc->W + 59) / 60) * ((desc->H + 5) / 6);
+    return (int64_t)plan_win_off(desc->D) * sizeof(float) + tiles * desc->D * 16;
 }
 
 extern "C" int vl3d_render_reg_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos, double *sums,
@@ -821,6 +1053,7 @@ extern "C" int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, 
         // variant & 0xf: 0/3 -> 16-row regions; 2 -> 8 rows.  (Prefetching the next plane's taps across the barrier was
         // measured and dropped: 91 VGPRs halve the occupancy, 24.3-28.9 ms vs 17.3 ms.)
         g_tile_rows = (desc->variant & 0xf) == 2 ? 8 : 16;
+        g_use_window = (desc->variant & 0xf) == 6;
     } else {
         a.plan = nullptr;
         g_tile_rows = 0;
