@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvl3d_hip.so")
+# VL3D_LIB_PATH: measurement hook (A/B runs of two builds inside one GPU session, profiles/ab.sh); default = the in-tree build
+LIB_PATH = os.environ.get("VL3D_LIB_PATH") or os.path.join(_HERE, "lib", "libvl3d_hip.so")
 
 ACT = {"none": 0, "sigmoid": 1, "relu": 2, "clamp": 3, "abs": 4}
 COORD = {"utils_mpi": 0, "affine": 1}

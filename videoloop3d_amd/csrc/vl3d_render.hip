@@ -39,6 +39,8 @@ struct RenderArgs {
     int ablate;          // measurement-only switches (bit0: skip LDS scatter, bit1: skip flush stores, bit2: skip tap loads)
     const float *plan;   // device scratch written by bwd_plan_k: [0] feasible flag, [16 + 12*d ..] inverse texel homographies,
                          // then (bwd_windows_k) one int4 texel window per (tile, plane)
+    const unsigned *owner;   // device scratch written by bwd_owner_table_k: per (plane, texel) owner tile << 10 | owner pixel's
+                             // index in its tile's region
 };
 
 // Uniform, read-only tables (homographies, plan records) are read through the constant address space: the loads become
@@ -57,11 +59,18 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 struct Taps2 {
-    unsigned off[4];   // byte offsets of the 4 taps inside the frame (always valid addresses)
-    float w[4];        // bilinear weights, 0 for taps outside the plane
+    unsigned off;      // byte offset of tap (x0,y0) inside the frame for 16-byte texels; the taps are off + {0, dx, dy, dx+dy}
+    f4 w;              // bilinear weights, 0 for taps outside the plane (a vector, not an array: stays in registers)
     float cov;         // 1 if the plane covers this pixel else 0
     float tx, ty;      // texel coordinates of the sample
 };
+// uniform byte steps between the 4 taps of a sample (0 along an axis of size 1: its second tap has weight 0)
+struct TapStep { unsigned dx, dy; };
+template <bool F16>
+__device__ __forceinline__ TapStep make_tap_step(int Hs, int Ws) {
+    constexpr unsigned TEXB = F16 ? 8 : 16;
+    return TapStep{Ws > 1 ? TEXB : 0u, Hs > 1 ? (unsigned)Ws * TEXB : 0u};
+}
 
 __device__ __forceinline__ float fast_rcp(float z) {
     float r = __builtin_amdgcn_rcpf(z);
@@ -69,25 +78,38 @@ __device__ __forceinline__ float fast_rcp(float z) {
     return fmaf(r, e, r);
 }
 
-// (x, y) / z with one refined reciprocal and one residual correction per quotient: agrees with the IEEE quotients the
-// reference / oracle compute to within rounding of the last bit, at a third of the instruction count (packed math).
+// (x, y) / z from one hardware reciprocal and one residual correction per quotient: q = x*r, q += (x - q*z)*r.  The 1-ulp
+// error of v_rcp_f32 only enters through the correction term, so the result agrees with the IEEE quotients the reference /
+// oracle compute to within rounding of the last bit, at a quarter of the instruction count of the IEEE expansion.
 __device__ __forceinline__ f2 fast_div2(f2 xy, float z) {
     // explicit FMAs: every kernel that inlines this gets the same instruction sequence, hence bit-identical coordinates
-    const float rz = fast_rcp(z);
+    const float rz = __builtin_amdgcn_rcpf(z);
     const f2 rz2 = f2{rz, rz}, z2 = f2{z, z};
     const f2 q = xy * rz2;
     const f2 e = __builtin_elementwise_fma(-q, z2, xy);
     return __builtin_elementwise_fma(e, rz2, q);
 }
 
-// integer form of the taps: clamped tap coordinates (always inside the plane) + weights
+// bilinear tent weight max(0, 1 - |d|) in ONE full-rate VALU instruction (|.| and clamp are free VOP3 modifiers; the C form
+// compiles to and/sub/max, and v_max_f32 alone issues at half the rate of v_sub_f32 -- profiles/microbench/valu_rates)
+__device__ __forceinline__ float tent_weight(float d) {
+    float w;
+    asm("v_sub_f32_e64 %0, 1.0, |%1| clamp" : "=v"(w) : "v"(d));
+    return w;
+}
+
+// integer form of the taps: base tap (x0,y0) with x0 <= Ws-2, y0 <= Hs-2 (so the 2x2 block is inside the plane) + weights
 struct TapsI {
-    int x0, x1, y0, y1;
-    float w[4];        // bilinear weights, 0 for taps outside the plane
+    int x0, y0;
+    f4 w;              // bilinear weights, 0 for taps outside the plane (a vector, not an array: stays in registers)
     float cov;         // 1 if the plane covers this pixel else 0
     float tx, ty;      // texel coordinates of the sample
 };
 
+// Sample position -> base tap + weights.  The base tap is floor(t) clamped to [0, S-2], so all four taps are valid addresses
+// at constant steps from ONE offset, and each weight is the tent max(0, 1-|t - tap|): for the sample's two neighbours that is
+// (1-f, f); for a tap that is not a neighbour (sample within one texel outside the plane, or t == S-1) it is 0, which is
+// exactly grid_sample's zeros padding (utils_mpi.py:159-176) -- no per-tap validity selects, no per-tap address clamps.
 template <int COORD, int BORDER>
 __device__ __forceinline__ TapsI make_taps_i(const float *__restrict__ h, float px, float py, int Hs, int Ws,
                                              float sx, float sy, float ox, float oy) {
@@ -99,31 +121,19 @@ __device__ __forceinline__ TapsI make_taps_i(const float *__restrict__ h, float 
     const float tx = texel_coord<COORD>(pxy.x, (float)Ws / 2.0f, (float)(Ws - 1), sx, ox);
     const float ty = texel_coord<COORD>(pxy.y, (float)Hs / 2.0f, (float)(Hs - 1), sy, oy);
     t.tx = tx; t.ty = ty;
-    const float wm1 = (float)(Ws - 1), hm1 = (float)(Hs - 1);
-    if constexpr (BORDER == VL3D_BORDER_HARDCUT) {
-        const bool cov = (tx >= 0.0f) && (tx <= wm1) && (ty >= 0.0f) && (ty <= hm1);
+    const float x0f = __builtin_amdgcn_fmed3f(floorf(tx), 0.0f, (float)max(Ws - 2, 0));
+    const float y0f = __builtin_amdgcn_fmed3f(floorf(ty), 0.0f, (float)max(Hs - 2, 0));
+    t.x0 = (int)x0f; t.y0 = (int)y0f;
+    const float dx = tx - x0f, dy = ty - y0f;
+    // an axis of size 1 has no second tap: its tent is pushed to 0
+    const float wx0 = tent_weight(dx), wx1 = tent_weight(dx - (Ws > 1 ? 1.0f : 3e38f));
+    const float wy0 = tent_weight(dy), wy1 = tent_weight(dy - (Hs > 1 ? 1.0f : 3e38f));
+    t.w = f4{wx0, wx1, wx0, wx1} * f4{wy0, wy0, wy1, wy1};
+    if constexpr (BORDER == VL3D_BORDER_HARDCUT) {   // MPV.py:374-453: the plane quad ends at the outermost texel centres
+        const bool cov = (tx >= 0.0f) && (tx <= (float)(Ws - 1)) && (ty >= 0.0f) && (ty <= (float)(Hs - 1));
         t.cov = cov ? 1.0f : 0.0f;
-        // covered => clamping is the identity; uncovered => any in-range address will do (its alpha is zeroed)
-        const float txc = __builtin_amdgcn_fmed3f(tx, 0.0f, wm1), tyc = __builtin_amdgcn_fmed3f(ty, 0.0f, hm1);
-        const float fx0 = floorf(txc), fy0 = floorf(tyc);
-        const float fx = txc - fx0, fy = tyc - fy0;
-        t.x0 = (int)fx0; t.y0 = (int)fy0;
-        t.x1 = min(t.x0 + 1, Ws - 1); t.y1 = min(t.y0 + 1, Hs - 1);   // x0+1 == Ws only when fx == 0 (weight 0)
-        const float gx = 1.0f - fx, gy = 1.0f - fy;
-        t.w[0] = gx * gy; t.w[1] = fx * gy; t.w[2] = gx * fy; t.w[3] = fx * fy;
-    } else {
-        const bool cov = (tx > -1.0f) && (tx < (float)Ws) && (ty > -1.0f) && (ty < (float)Hs);
-        t.cov = cov ? 1.0f : 0.0f;
-        const float txc = __builtin_amdgcn_fmed3f(tx, -1.0f, (float)Ws), tyc = __builtin_amdgcn_fmed3f(ty, -1.0f, (float)Hs);
-        const float fx0 = floorf(txc), fy0 = floorf(tyc);
-        const float fx = txc - fx0, fy = tyc - fy0;
-        const int x0 = (int)fx0, y0 = (int)fy0;
-        // taps outside the plane contribute 0 (grid_sample zeros padding); their addresses are clamped into the plane
-        const float wx0 = (x0 >= 0 && x0 < Ws) ? 1.0f - fx : 0.0f, wx1 = (x0 + 1 < Ws) ? fx : 0.0f;
-        const float wy0 = (y0 >= 0 && y0 < Hs) ? 1.0f - fy : 0.0f, wy1 = (y0 + 1 < Hs) ? fy : 0.0f;
-        t.w[0] = wx0 * wy0; t.w[1] = wx1 * wy0; t.w[2] = wx0 * wy1; t.w[3] = wx1 * wy1;
-        t.x0 = min(max(x0, 0), Ws - 1); t.x1 = min(x0 + 1, Ws - 1);
-        t.y0 = min(max(y0, 0), Hs - 1); t.y1 = min(y0 + 1, Hs - 1);
+    } else {                                         // zeros padding: covered while any tap is inside, i.e. any weight > 0
+        t.cov = ((t.w[0] + t.w[1]) + (t.w[2] + t.w[3]) > 0.0f) ? 1.0f : 0.0f;
     }
     return t;
 }
@@ -133,35 +143,29 @@ __device__ __forceinline__ Taps2 make_taps2(const float *__restrict__ h, float p
                                             float sx, float sy, float ox, float oy) {
     const TapsI ti = make_taps_i<COORD, BORDER>(h, px, py, Hs, Ws, sx, sy, ox, oy);
     Taps2 t;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) t.w[i] = ti.w[i];
+    t.w = ti.w;
     t.cov = ti.cov; t.tx = ti.tx; t.ty = ti.ty;
-    const unsigned r0 = (unsigned)(ti.y0 * Ws), r1 = (unsigned)(ti.y1 * Ws);
-    t.off[0] = (r0 + ti.x0) * 16u; t.off[1] = (r0 + ti.x1) * 16u; t.off[2] = (r1 + ti.x0) * 16u; t.off[3] = (r1 + ti.x1) * 16u;
+    t.off = (__umul24((unsigned)ti.y0, (unsigned)Ws) + (unsigned)ti.x0) << 4;   // y0 < 2^24 (check_desc), full-rate multiply
     return t;
 }
 
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
-// one texel = 16 bytes (fp32 stack) or 8 bytes (fp16 stack, cfg5 of BASELINE.json; arithmetic stays fp32)
+// one texel = 16 bytes (fp32 stack) or 8 bytes (fp16 stack, cfg5 of BASELINE.json; arithmetic stays fp32).
+// `plane` is uniform and off16 a zero-extended 32-bit lane offset: global_load ... v_off, s[base:base+1]
 template <bool F16>
 __device__ __forceinline__ f4 load_texel(const char *__restrict__ plane, unsigned off16) {
-    if constexpr (F16) return __builtin_convertvector(*reinterpret_cast<const h4 *>(plane + (off16 >> 1)), f4);
-    else return *reinterpret_cast<const f4 *>(plane + off16);
+    if constexpr (F16) return __builtin_convertvector(*reinterpret_cast<const h4 *>(plane + (size_t)(off16 >> 1)), f4);
+    else return *reinterpret_cast<const f4 *>(plane + (size_t)off16);
 }
 
+// the four taps: one lane offset, four uniform bases (plane, +dx, +dy, +dx+dy) -- no per-tap address arithmetic
 template <bool F16>
-__device__ __forceinline__ void load_taps2(const char *__restrict__ plane, const Taps2 &t, f4 v[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = load_texel<F16>(plane, t.off[i]);
-}
-
-// measurement only (fwd_variant 6): fetch the left column of taps only -- halves the L1/TA request traffic at unchanged HBM
-// traffic, to see how much of the forward's time is the vector-memory pipe (result is NOT the render)
-template <bool F16>
-__device__ __forceinline__ void load_taps2_half(const char *__restrict__ plane, const Taps2 &t, f4 v[4]) {
-    v[0] = load_texel<F16>(plane, t.off[0]); v[2] = load_texel<F16>(plane, t.off[2]);
-    v[1] = v[0]; v[3] = v[2];
+__device__ __forceinline__ void load_taps2(const char *__restrict__ plane, const Taps2 &t, TapStep st, f4 v[4]) {
+    v[0] = load_texel<F16>(plane, t.off);
+    v[1] = load_texel<F16>(plane + st.dx, t.off);
+    v[2] = load_texel<F16>(plane + st.dy, t.off);
+    v[3] = load_texel<F16>(plane + st.dy + st.dx, t.off);
 }
 
 template <int RACT, int AACT>
@@ -207,11 +211,12 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
     const float S = Gr * a.rgb[pix * 3 + 0] + Gg * a.rgb[pix * 3 + 1] + Gb * a.rgb[pix * 3 + 2] + gA * a.alpha[pix];
     const float gN1 = a.g_asum ? a.g_asum[pix * 2 + 0] : 0.0f, gN2 = a.g_asum ? 2.0f * a.g_asum[pix * 2 + 1] : 0.0f;
     float Tr = 1.0f, P = 0.0f;
+    const TapStep st = make_tap_step<F16>(a.Hs, a.Ws), gst = make_tap_step<false>(a.Hs, a.Ws);
     for (int d = 0; d < a.D; ++d, plane += (size_t)a.T * a.Hs * a.Ws * TEXB, gplane += plane_stride * 4) {
         const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
         if (tp.cov == 0.0f) continue;
         f4 tv[4], pre;
-        load_taps2<F16>(plane, tp, tv);
+        load_taps2<F16>(plane, tp, st, tv);
         const f4 o = shade2<ORDER, RACT, AACT>(tp, tv, &pre);
         const float q = Gr * o.x + Gg * o.y + Gb * o.z + gA;
         const float w = o.w * Tr;
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
             auto layer = [&](float qx, float qy) {
                 const Taps2 tq = make_taps2<COORD, BORDER>(a.homos + 9 * d, qx, qy, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
                 f4 tq_v[4];
-                load_taps2<F16>(plane, tq, tq_v);
+                load_taps2<F16>(plane, tq, st, tq_v);
                 return shade2<ORDER, RACT, AACT>(tq, tq_v) * tq.cov;
             };
             auto sgn = [](f4 v) { return f4{(float)((v.x > 0.f) - (v.x < 0.f)), (float)((v.y > 0.f) - (v.y < 0.f)),
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
                     c = f4{c.x * act_bwd<RACT>(sv.x, act_fwd<RACT>(sv.x)), c.y * act_bwd<RACT>(sv.y, act_fwd<RACT>(sv.y)),
                            c.z * act_bwd<RACT>(sv.z, act_fwd<RACT>(sv.z)), c.w * act_bwd<AACT>(sv.w, act_fwd<AACT>(sv.w))};
                 }
-                float *g = reinterpret_cast<float *>(gplane + tp.off[i]);
+                float *g = reinterpret_cast<float *>(gplane + (size_t)tp.off + ((i & 1) ? gst.dx : 0u) + ((i & 2) ? gst.dy : 0u));
                 atomicAdd(g + 0, c.x); atomicAdd(g + 1, c.y); atomicAdd(g + 2, c.z); atomicAdd(g + 3, c.w);
             }
         }
@@ -286,7 +291,8 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
     // two register sets (A/B) so the taps of plane d+1 are in flight while plane d is shaded, without register copies
     Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy), tB = tA;
     f4 vA[4], vB[4];
-    if (a.ablate & 1) load_taps2_half<F16>(plane, tA, vA); else load_taps2<F16>(plane, tA, vA);
+    const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
+    load_taps2<F16>(plane, tA, st, vA);
 #define VL3D_COMPOSITE(T_, V_)                                        \
     {                                                                 \
         const f4 o = shade2<ORDER, RACT, AACT>(T_, V_);               \
@@ -295,20 +301,29 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
         n1 += o.w; n2 = fmaf(o.w, o.w, n2);                           \
         Tr *= (1.0f - o.w);                                           \
     }
-    for (int d = 0;;) {
-        if (d + 1 < a.D) {
-            tB = make_taps2<COORD, BORDER>(a.homos + 9 * (d + 1), px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-            if (a.ablate & 1) load_taps2_half<F16>(plane + plane_stride_b, tB, vB); else load_taps2<F16>(plane + plane_stride_b, tB, vB);
+    // The prefetch of the next plane is unconditional (past the end it re-reads the last plane): with a branch around the
+    // loads hipcc merges the two paths' counters and waits with vmcnt(0), i.e. for the taps it has just issued as well.
+    for (int d = 0;; d += 2) {
+        {
+            const int dn = min(d + 1, a.D - 1);
+            float h[9];
+            load_uniform(a.homos + 9 * dn, h);
+            tB = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            load_taps2<F16>(plane + (size_t)dn * plane_stride_b, tB, st, vB);
+            asm volatile("" ::: "memory");   // keep the loads here: hipcc otherwise sinks them below the composite
         }
         VL3D_COMPOSITE(tA, vA)
-        if (++d >= a.D) break;
-        if (d + 1 < a.D) {
-            tA = make_taps2<COORD, BORDER>(a.homos + 9 * (d + 1), px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-            if (a.ablate & 1) load_taps2_half<F16>(plane + 2 * plane_stride_b, tA, vA); else load_taps2<F16>(plane + 2 * plane_stride_b, tA, vA);
+        if (d + 1 >= a.D) break;
+        {
+            const int dn = min(d + 2, a.D - 1);
+            float h[9];
+            load_uniform(a.homos + 9 * dn, h);
+            tA = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            load_taps2<F16>(plane + (size_t)dn * plane_stride_b, tA, st, vA);
+            asm volatile("" ::: "memory");
         }
         VL3D_COMPOSITE(tB, vB)
-        if (++d >= a.D) break;
-        plane += 2 * plane_stride_b;
+        if (d + 2 >= a.D) break;
     }
 #undef VL3D_COMPOSITE
     const size_t pix = ((size_t)t * a.H + y) * a.W + x;
@@ -439,18 +454,11 @@ __global__ __launch_bounds__(256) void bwd_windows_k(RenderArgs a, int iw, int i
     const int wY1 = min(a.Hs - 1, (int)floorf(fminf(mxy + 0.01f, (float)a.Hs)));
     const int ww = min(max(0, wX1 - wX0 + 1), 0xffff), wh = min(max(0, wY1 - wY0 + 1), 0x7fff);
     int4 rec;
-    rec.x = wX0; rec.y = wY0; rec.z = ww | (wh << 16); rec.w = __float_as_int(1.0f / (float)max(ww, 1));
+    const bool empty = ww == 0 || wh == 0;    // keep the corner a valid texel: the gather prefetches relative to it
+    rec.x = empty ? 0 : wX0; rec.y = empty ? 0 : wY0; rec.z = empty ? 0 : (ww | (wh << 16)); rec.w = __float_as_int(1.0f / (float)max(ww, 1));
     reinterpret_cast<int4 *>(win)[i] = rec;     // [tile][plane]: one contiguous run per workgroup
 }
 
-__device__ __forceinline__ float fast_rcp(float z);
-// bilinear tent weight max(0, 1 - |d|) in ONE VALU instruction (|.| and clamp are free VOP3 modifiers; hipcc emits
-// and/cmp/cndmask chains for the C form)
-__device__ __forceinline__ float tent_weight(float d) {
-    float w;
-    asm("v_sub_f32_e64 %0, 1.0, |%1| clamp" : "=v"(w) : "v"(d));
-    return w;
-}
 // owner pixel (float, before rounding) of texel (tx,ty) on plane d, relative to this window's pixel origin
 __device__ __forceinline__ void owner_pixel(const float *__restrict__ hi, float tx, float ty, float pc, int col0, int row0,
                                             float &px, float &py) {
@@ -475,6 +483,26 @@ __global__ __launch_bounds__(256) void bwd_zero_unowned_k(RenderArgs a) {
     const size_t frame = (size_t)a.Hs * a.Ws;
     float4 *g = reinterpret_cast<float4 *>(a.g_stack) + (size_t)d * a.T * frame + (size_t)y * a.Ws + x;
     for (int t = 0; t < a.T; ++t, g += frame) *g = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// Owner table: for every texel of every plane, the tile that owns it (the tile of its owner pixel p0 = clamp_to_frame(
+// round(H_d^-1 tau))) and p0's index in that tile's pixel region, packed as tile << 10 | index.  Frame independent, so it
+// is built once per call (D*Hs*Ws entries) and read once per frame by the gather, which then needs no inverse homography,
+// reciprocal, rounding or range tests per texel (~200 of its ~400 VALU issue cycles, profiles/microbench/isa_cost.py).
+__global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, int ih, int rh, int tiles_x, unsigned *owner) {
+    if (!reinterpret_cast<const int *>(a.plan)[0]) return;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int d = blockIdx.z;
+    if (x >= a.Ws || y >= a.Hs) return;
+    float qx, qy;
+    owner_pixel(a.plan + PLAN_HDR + PLAN_REC * d, (float)x, (float)y, a.pc, a.col0, a.row0, qx, qy);
+    // owner = nearest FRAME pixel: texels just outside the frame still collect taps of the border pixels
+    const int rx = (int)fminf(fmaxf(rintf(qx), 0.0f), (float)(a.W - 1));
+    const int ry = (int)fminf(fmaxf(rintf(qy), 0.0f), (float)(a.H - 1));
+    const int tx = rx / iw, ty = ry / ih;
+    const unsigned lc = (unsigned)((ry - ty * ih + rh) * RW + (rx - tx * iw + rh));
+    owner[((size_t)d * a.Hs + y) * a.Ws + x] = ((unsigned)(ty * tiles_x + tx) << 10) | lc;
 }
 
 __global__ __launch_bounds__(256) void bwd_fill_zero_if_infeasible_k(float4 *g, size_t n, const float *plan) {
@@ -527,12 +555,24 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
     if constexpr (REG) { gsx_c = a.g_reg[0]; gsy_c = a.g_reg[1]; gsx_a = a.g_reg[2]; gsy_a = a.g_reg[3]; }
     // pixels of the outermost ring only provide layer values in REG mode
     const bool provider = !REG || (lane >= 1 && lane <= RW - 2 && row >= 1 && row <= ROWS - 2);
+    const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
     // this tile's texel windows, one int4 per plane (bwd_windows_k)
-    const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)(tile_y * a.tiles_x + tile_x) * a.D * 4;
+    const unsigned my_tile = (unsigned)(tile_y * a.tiles_x + tile_x);
+    const unsigned toff_thread = (unsigned)(row * a.Ws + lane);   // texel (lane, row) of a window, relative to its corner
+    const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)my_tile * a.D * 4;
     for (int d = 0; d < a.D; ++d, plane += plane_stride_b, gplane += plane_stride) {
         float h[9];
         load_uniform(a.homos + 9 * d, h);
         const int buf = d & 1;
+        // texel window of this tile on plane d (wave = window row, lane = window column)
+        const int X0 = wrec[4 * d], Y0 = wrec[4 * d + 1], wwh = wrec[4 * d + 2];
+        const int ww = wwh & 0xffff, wh = wwh >> 16;
+        const unsigned win0 = (unsigned)(Y0 * a.Ws + X0);          // frame texel index of the window's corner (uniform)
+        const unsigned *oplane = a.owner + (size_t)d * a.Hs * a.Ws;
+        // this thread's first owner-table entry, requested now so that it arrives in the shadow of the sweep.  Unconditional
+        // (threads outside the window read a neighbouring entry -- the table is padded by ROWS rows -- and ignore it): no
+        // branch around the load, so no merged wait counters.
+        const unsigned e0 = oplane[win0 + toff_thread];
         // (2) sample this pixel on plane d, composite backward, stage (tx,ty,g) in LDS   (branch-free taps)
         float2 tc = make_float2(-1e30f, -1e30f);
         float4 gval = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -543,11 +583,10 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
             const char *src = plane;
             if (a.ablate & 4) {   // measurement only: all taps from a 64 KiB cache-resident window
                 src = reinterpret_cast<const char *>(a.stack);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) tp.off[i] &= 0xffffu;
+                tp.off &= 0xfff0u;
             }
             f4 tv[4];
-            load_taps2<F16>(src, tp, tv);
+            load_taps2<F16>(src, tp, st, tv);
             o = shade2<ORDER, RACT, AACT>(tp, tv, &pre);                 // o.w already 0 when the plane does not cover the pixel
         }
         f4 sg = f4{0.f, 0.f, 0.f, 0.f};
@@ -584,26 +623,14 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
         s_t[buf][tid] = tc;
         s_g[buf][tid] = gval;
         __syncthreads();   // staging of plane d visible (the other buffer may still be read by slower waves: not touched here)
-        // (3) every texel owned by this tile gathers its taps from the 3x3 pixels around its owner pixel
-        const int X0 = wrec[4 * d], Y0 = wrec[4 * d + 1], wwh = wrec[4 * d + 2];
-        const int ww = wwh & 0xffff, wh = wwh >> 16;
-        const float inv_ww = __int_as_float(wrec[4 * d + 3]);
-        float hi[9];
-        load_uniform(a.plan + PLAN_HDR + PLAN_REC * d, hi);
+        // (3) every texel of this tile's window that the owner table assigns to this tile gathers its taps from the 3x3
+        //     pixels around its owner pixel.  Wave = window row, lane = window column: uniform row bases, no index arithmetic.
         if (a.ablate & 1) continue;
-        for (int idx = tid; idx < ww * wh; idx += NT) {
-            const int wy = (int)(((float)idx + 0.5f) * inv_ww), wx = idx - wy * ww;
-            const float tauX = (float)(X0 + wx), tauY = (float)(Y0 + wy);
-            float qx, qy;
-            owner_pixel(hi, tauX, tauY, a.pc, a.col0, a.row0, qx, qy);
-            // owner = nearest FRAME pixel: texels just outside the frame still collect taps of the border pixels
-            const float rx = fminf(fmaxf(rintf(qx), 0.0f), (float)(a.W - 1));
-            const float ry = fminf(fmaxf(rintf(qy), 0.0f), (float)(a.H - 1));
-            if (!(rx >= (float)ix0 && rx <= (float)ix1 && ry >= (float)iy0 && ry <= (float)iy1)) continue;
-            // taps come from the 3x3 pixels around the owner (|J^-1|_inf < 1.4): fixed trip count, constant LDS offsets,
-            // weights clamp to 0 for non-contributing pixels (bitwise the forward's (1-fx)(1-fy) products otherwise)
-            const int lc = ((int)ry - ry0) * RW + ((int)rx - rx0);
-            const f2 tau = f2{tauX, tauY};
+        auto gather = [&](unsigned e, int wx, int wy, unsigned tix) {   // tix = frame texel index of window texel (wx, wy)
+            if ((e >> 10) != my_tile) return;
+            // fixed trip count, constant LDS offsets; weights clamp to 0 for non-contributing pixels (|J^-1|_inf < 1.4)
+            const int lc = (int)(e & 1023u);
+            const f2 tau = f2{(float)(X0 + wx), (float)(Y0 + wy)};
             f4 acc = f4{0.f, 0.f, 0.f, 0.f};
             if (!(a.ablate & 8))
 #pragma unroll
@@ -614,14 +641,19 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
                     const f2 dc = *reinterpret_cast<const f2 *>(&s_t[buf][li]) - tau;
                     acc += *reinterpret_cast<const f4 *>(&s_g[buf][li]) * (tent_weight(dc.x) * tent_weight(dc.y));
                 }
-            const size_t toff = ((size_t)(Y0 + wy) * a.Ws + (X0 + wx)) * 4;
             if constexpr (ORDER == VL3D_ACT_PRE) {   // d act(s_tau)/d s_tau factors out of the tap sum
-                const f4 sv = load_texel<F16>(plane, (unsigned)(toff * 4));
+                const f4 sv = load_texel<F16>(plane, tix << 4);
                 acc = f4{acc.x * act_bwd<RACT>(sv.x, act_fwd<RACT>(sv.x)), acc.y * act_bwd<RACT>(sv.y, act_fwd<RACT>(sv.y)),
                          acc.z * act_bwd<RACT>(sv.z, act_fwd<RACT>(sv.z)), acc.w * act_bwd<AACT>(sv.w, act_fwd<AACT>(sv.w))};
             }
-            if (!(a.ablate & 2)) *reinterpret_cast<f4 *>(gplane + toff) = acc;
-        }
+            if (!(a.ablate & 2)) *reinterpret_cast<f4 *>(reinterpret_cast<char *>(gplane) + (size_t)(tix << 4)) = acc;
+        };
+        if (row < wh && lane < ww) gather(e0, lane, row, win0 + toff_thread);
+        for (int wy = row; wy < wh; wy += ROWS)      // rest of a window larger than 64 x ROWS (frame-border tiles, minification)
+            for (int wx = lane + (wy == row ? RW : 0); wx < ww; wx += RW) {
+                const unsigned tix = win0 + (unsigned)(wy * a.Ws + wx);
+                gather(oplane[tix], wx, wy, tix);
+            }
     }
 }
 
@@ -727,8 +759,8 @@ __global__ __launch_bounds__(RW * 16, 8) void render_bwd_tilew_k(RenderArgs a) {
         const int TX0 = s_tw[par][0], TY0 = s_tw[par][1], tw_ = min(s_tw[par][2], TWP), th_ = min(s_tw[par][3], THM);
         if (inimg && tw_ > 0 && th_ > 0) {
             const TapsI ti = make_taps_i<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-            const int lx0 = min(max(ti.x0 - TX0, 0), tw_ - 1), lx1 = min(max(ti.x1 - TX0, 0), tw_ - 1);
-            const int ly0 = min(max(ti.y0 - TY0, 0), th_ - 1), ly1 = min(max(ti.y1 - TY0, 0), th_ - 1);
+            const int lx0 = min(max(ti.x0 - TX0, 0), tw_ - 1), lx1 = min(max(ti.x0 + (a.Ws > 1) - TX0, 0), tw_ - 1);
+            const int ly0 = min(max(ti.y0 - TY0, 0), th_ - 1), ly1 = min(max(ti.y0 + (a.Hs > 1) - TY0, 0), th_ - 1);
             Taps2 tp;
 #pragma unroll
             for (int i = 0; i < 4; ++i) tp.w[i] = ti.w[i];
@@ -818,7 +850,7 @@ __global__ __launch_bounds__(RW *ROWS) void render_reg_fwd_k(RenderArgs a) {
         if (inimg) {
             const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
             f4 tv[4];
-            load_taps2<F16>(plane, tp, tv);
+            load_taps2<F16>(plane, tp, make_tap_step<F16>(a.Hs, a.Ws), tv);
             ol = shade2<ORDER, RACT, AACT>(tp, tv) * tp.cov;
         }
         const int buf = d & 1;
@@ -859,6 +891,8 @@ void launch_tile(const RenderArgs &a, hipStream_t s) {
     const int nwin = b.tiles_x * b.tiles_y * a.D;
     hipLaunchKernelGGL((bwd_windows_k<COORD>), dim3((nwin + 255) / 256), dim3(256), 0, s, b, IW, IH, b.tiles_x, b.tiles_y,
                        reinterpret_cast<int *>(const_cast<float *>(a.plan)) + plan_win_off(a.D));
+    hipLaunchKernelGGL(bwd_owner_table_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x,
+                       const_cast<unsigned *>(a.owner));
     hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16>),
                        dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
 }
@@ -973,6 +1007,7 @@ int check_desc(const vl3d_render_desc *d) {
     VL3D_REQUIRE(d != nullptr, "null render desc");
     VL3D_REQUIRE(d->D > 0 && d->T > 0 && d->Hs > 0 && d->Ws > 0 && d->H > 0 && d->W > 0, "non-positive render dims");
     VL3D_REQUIRE((int64_t)d->Hs * d->Ws < (1ll << 31), "plane too large for 32-bit texel index");
+    VL3D_REQUIRE(d->Hs < (1 << 24) && d->Ws < (1 << 24), "plane side too large (24-bit row arithmetic)");
     VL3D_REQUIRE(d->stack_dtype == VL3D_F32 || d->stack_dtype == VL3D_F16, "stack_dtype must be VL3D_F32 or VL3D_F16");
     VL3D_REQUIRE(d->stack_dtype == VL3D_F32 || (d->rgb_act == VL3D_ACT_SIGMOID && d->alpha_act == VL3D_ACT_SIGMOID),
                  "fp16 plane stacks are implemented for the shipped (sigmoid, sigmoid) activations only");
@@ -1007,11 +1042,18 @@ extern "C" int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, 
     return VL3D_OK;
 }
 
+// scratch layout: per-plane records | one int4 window per (tile, plane), sized for the smallest tile interior any variant
+// uses (60 x 6) | (256-byte aligned) owner table, one uint32 per (plane, texel)
+static int64_t owner_table_off(const vl3d_render_desc *desc) {
+    const int64_t tiles = (int64_t)((desc->W + 59) / 60) * ((desc->H + 5) / 6);
+    const int64_t b = (int64_t)plan_win_off(desc->D) * sizeof(float) + tiles * desc->D * 16;
+    return (b + 255) & ~(int64_t)255;
+}
+
 extern "C" int64_t vl3d_render_bwd_scratch_bytes(const vl3d_render_desc *desc) {
     if (!desc || desc->D <= 0 || desc->H <= 0 || desc->W <= 0) return 0;
-    // per-plane records + one int4 window per (tile, plane), sized for the smallest tile interior any variant uses (60 x 6)
-    const int64_t tiles = (int64_t)((desc->W + 59) / 60) * ((desc->H + 5) / 6);
-    return (int64_t)plan_win_off(desc->D) * sizeof(float) + tiles * desc->D * 16;
+    // + padding: the gather's unconditional prefetch reads up to 16 rows + 64 texels past a window's corner
+    return owner_table_off(desc) + ((int64_t)desc->D * desc->Hs * desc->Ws + 16 * (int64_t)desc->Ws + 64) * 4;
 }
 
 extern "C" int vl3d_render_reg_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos, double *sums,
@@ -1050,6 +1092,7 @@ extern "C" int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, 
     a.ablate = (desc->variant >> 4) & 0xf;
     if (want_tile) {
         a.plan = (const float *)scratch;
+        a.owner = reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(scratch) + owner_table_off(desc));
         // variant & 0xf: 0/3 -> 16-row regions; 2 -> 8 rows.  (Prefetching the next plane's taps across the barrier was
         // measured and dropped: 91 VGPRs halve the occupancy, 24.3-28.9 ms vs 17.3 ms.)
         g_tile_rows = (desc->variant & 0xf) == 2 ? 8 : 16;

@@ -96,7 +96,9 @@ class _RenderPlanes(torch.autograd.Function):
         g_stack = torch.empty(stack.shape, dtype=torch.float32, device=stack.device)   # grad_stack is always fp32 in the ABI
         with torch.cuda.device(stack.device):
             nscratch = int(L.lib().vl3d_render_bwd_scratch_bytes(ctx.desc))
-            scratch = torch.zeros((nscratch + 3) // 4, dtype=torch.float32, device=stack.device)
+            # every word the kernels read is written by the plan kernels of the same call; only the header is cleared (flags)
+            scratch = torch.empty((nscratch + 3) // 4, dtype=torch.float32, device=stack.device)
+            scratch[:16].zero_()
             L.check(L.lib().vl3d_render_bwd(ctx.desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha),
                                             L.ptr(g_rgb), L.ptr(g_alpha), L.ptr(g_reg), L.ptr(g_asum), L.ptr(g_stack), L.ptr(scratch), nscratch,
                                             L.stream_ptr(stack.device)), "vl3d_render_bwd")
