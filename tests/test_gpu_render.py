@@ -450,13 +450,11 @@ def test_nearly_opaque_planes_gradient_envelope(dev, logit_hi):
         assert maxabs(gs, gs_o) <= TOL * max(1.0, float(gs_o.abs().max()))
 
 
-@pytest.mark.parametrize("spec_name", ["mpv", "utils_mpi", "hardcut_pre"])
-@pytest.mark.parametrize("shape", [(6, 2, 150, 200, 139, 187), (4, 1, 70, 300, 64, 280), (3, 1, 40, 40, 37, 35)])
-def test_bwd_lds_window_variant(dev, spec_name, shape):
-    """variant 6 = owner-computes backward with the taps staged through an LDS texel window: identical result to the default
-    tile kernel (same arithmetic, taps only travel differently)."""
+@pytest.mark.parametrize("spec_name", ["mpv", "utils_mpi"])
+def test_bwd_tile_path_is_deterministic(dev, spec_name):
+    """The owner-computes backward writes every texel once in a fixed order: two runs are bitwise identical."""
     from videoloop3d_amd.render import RenderSpec, render_planes
-    D, T, Hs, Ws, H, W = shape
+    D, T, Hs, Ws, H, W = (6, 2, 150, 200, 139, 187)
     kw_p, _ = SPECS[spec_name]
     stack = synth.make_plane_stack(D, T, Hs, Ws, seed=13, device=dev).requires_grad_(True)
     th = math.radians(2.0)
@@ -465,8 +463,8 @@ def test_bwd_lds_window_variant(dev, spec_name, shape):
     g_rgb = (synth.hash_uniform((T, H, W, 3), seed=5) - 0.5).to(dev)
     g_a = (synth.hash_uniform((T, H, W), seed=6) - 0.5).to(dev)
     outs = []
-    for variant in (0, 6):
-        rgb, alpha = render_planes(stack, homos, H, W, RenderSpec(variant=variant, **kw_p))
+    for _ in range(2):
+        rgb, alpha = render_planes(stack, homos, H, W, RenderSpec(**kw_p))
         (gs,) = torch.autograd.grad([rgb, alpha], stack, [g_rgb, g_a])
         assert _tile_ran() == 1
         outs.append(gs)

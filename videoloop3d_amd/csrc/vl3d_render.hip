@@ -34,7 +34,6 @@ struct RenderArgs {
     const float *g_reg;  // device float[4]: dL/d(sum|dx rgb|), dL/d(sum|dy rgb|), dL/d(sum|dx a|), dL/d(sum|dy a|) or NULL
     double *reg_sums;    // device double[4] (forward of the layer-space smoothness regularisers)
     int tiles_x, tiles_y; // tile grid of the owner-computes backward
-    int use_window;       // 1: render_bwd_tilew_k is launched as well and takes the call when its window fits
     int fwd_variant;     // forward kernel selector (see launch<>)
     int ablate;          // measurement-only switches (bit0: skip LDS scatter, bit1: skip flush stores, bit2: skip tap loads)
     const float *plan;   // device scratch written by bwd_plan_k: [0] feasible flag, [16 + 12*d ..] inverse texel homographies,
@@ -357,7 +356,6 @@ void launch_fwd2(const RenderArgs &a, hipStream_t s) {
 // (Z>0 over the frame, magnification < 1.4x, window fits); if they fail, these kernels exit and the
 // universal atomics kernel above runs instead -- no host synchronisation either way.
 constexpr int RW = 64;        // region width in pixels = one wave
-constexpr int TWP = 72, THM = 24;  // LDS texel window of render_bwd_tilew_k: pitch / max rows (texels)
 constexpr int PLAN_HDR = 16;  // floats before the per-plane records
 constexpr int PLAN_REC = 12;  // per plane: 9 floats inverse texel homography, 2 floats gather radius (x,y), 1 pad
 // after the per-plane records (16-byte aligned): one int4 per (tile, plane) = texel window of the tile's owned pixels on
@@ -379,8 +377,8 @@ __device__ void texel_homography(const float *h, int Hs, int Ws, float sx, float
 
 template <int COORD>
 __global__ void bwd_plan_k(RenderArgs a, int rows, float *plan) {
-    __shared__ int ok_all, win_all;
-    if (threadIdx.x == 0) { ok_all = 1; win_all = 1; }
+    __shared__ int ok_all;
+    if (threadIdx.x == 0) ok_all = 1;
     __syncthreads();
     for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
         double M[9];
@@ -412,10 +410,6 @@ __global__ void bwd_plan_k(RenderArgs a, int rows, float *plan) {
                 rxm = fmax(rxm, i_r0); rym = fmax(rym, i_r1);
                 // keep the owned footprint of a tile a small multiple of the workgroup (pure efficiency guard)
                 if (!(fabs(j00) + fabs(j01) < 4.0 && fabs(j10) + fabs(j11) < 4.0)) ok = false;
-                // does the 64 x rows region's footprint (+ taps) fit the LDS texel window of render_bwd_tilew_k? (10% safety)
-                const double wreq = 1.10 * (fabs(j00) * (RW - 1) + fabs(j01) * (rows - 1)) + 4.0;
-                const double hreq = 1.10 * (fabs(j10) * (RW - 1) + fabs(j11) * (rows - 1)) + 4.0;
-                if (!(wreq <= TWP && hreq <= THM)) atomicAnd(&win_all, 0);
             }
         // gather radius per axis: a pixel p contributes to texel tau only if |p - H^-1 tau| < |J^-1|_inf-row (2% safety)
         plan[PLAN_HDR + PLAN_REC * d + 9] = (float)fmin(1.02 * rxm + 1e-3, 1.45);
@@ -423,7 +417,7 @@ __global__ void bwd_plan_k(RenderArgs a, int rows, float *plan) {
         if (!ok) atomicAnd(&ok_all, 0);
     }
     __syncthreads();
-    if (threadIdx.x == 0) { reinterpret_cast<int *>(plan)[0] = ok_all; reinterpret_cast<int *>(plan)[1] = ok_all & win_all; }
+    if (threadIdx.x == 0) { reinterpret_cast<int *>(plan)[0] = ok_all; reinterpret_cast<int *>(plan)[1] = 0; }
 }
 
 // Texel window of every (tile, plane): the footprint of the tile's owned pixels, from the image of its four corners
@@ -513,7 +507,6 @@ __global__ __launch_bounds__(256) void bwd_fill_zero_if_infeasible_k(float4 *g, 
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16>
 __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(RenderArgs a) {
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
-    if (a.use_window && reinterpret_cast<const int *>(a.plan)[1]) return;     // render_bwd_tilew_k owns this call
     constexpr int NT = RW * ROWS;
     // REG: the layer-space smoothness regularisers (MPV.py:517-531) are differentiated here as well.  Their gradient at a
     // pixel needs the activated layer values of its 4 neighbours, so the region carries a 2-pixel halo (outer ring: layer
@@ -660,171 +653,6 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
 
 
 // =====================================================================================================
-// Backward, variant "tile + LDS texel window" (the north star's LDS-staged tile window, for the kernel where it pays):
-// same owner-computes gather as render_bwd_tile_k, but the taps of the sweep no longer come through the vector L1.
-// The region's footprint on plane d+1 (a ~66x18-texel window, each texel ONCE, coalesced rows) is fetched by the whole
-// workgroup right after the barrier of plane d with the LDS-DMA (global_load_lds_dwordx4: no VGPRs), lands while the gather
-// of plane d runs, and the sweep of plane d+1 reads its 4 taps from LDS: no global-memory latency in the critical path, and
-// the 4x tap redundancy + the halo pixels' taps cost LDS bandwidth instead of L1/TA requests.
-
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT>
-__global__ __launch_bounds__(RW * 16, 8) void render_bwd_tilew_k(RenderArgs a) {
-    const int *plan_i = reinterpret_cast<const int *>(a.plan);
-    if (!plan_i[0] || !plan_i[1]) return;
-    constexpr int ROWS = 16, NT = RW * ROWS, RH = 1;
-    __shared__ float4 s_g[NT];
-    __shared__ float2 s_t[NT];
-    __shared__ float4 s_win[TWP * THM];
-    __shared__ int s_w[4];            // owned-texel window of plane d
-    __shared__ int s_tw[2][4];        // tap window (X0, Y0, width, height) of plane d (parity)
-    const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_x = bid % a.tiles_x, rest = bid / a.tiles_x;
-    const int tile_y = rest % a.tiles_y, t = rest / a.tiles_y;
-    const int rx0 = tile_x * (RW - 2 * RH) - RH, ry0 = tile_y * (ROWS - 2 * RH) - RH;
-    const int x = rx0 + lane, y = ry0 + row;
-    const bool inimg = (x >= 0) && (x < a.W) && (y >= 0) && (y < a.H);
-    const int ix0 = max(rx0 + RH, 0), ix1 = min(rx0 + RW - 1 - RH, a.W - 1);
-    const int iy0 = max(ry0 + RH, 0), iy1 = min(ry0 + ROWS - 1 - RH, a.H - 1);
-    const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
-    const size_t frame = (size_t)a.Hs * a.Ws * 4;
-    const size_t plane_stride = (size_t)a.T * frame;
-    const float *plane = a.stack + (size_t)t * frame;
-    float *gplane = a.g_stack + (size_t)t * frame;
-    float Gr = 0.f, Gg = 0.f, Gb = 0.f, gA = 0.f, S = 0.f, gN1 = 0.f, gN2 = 0.f;
-    if (inimg) {
-        const size_t pix = ((size_t)t * a.H + y) * a.W + x;
-        Gr = a.g_rgb[pix * 3 + 0]; Gg = a.g_rgb[pix * 3 + 1]; Gb = a.g_rgb[pix * 3 + 2];
-        gA = a.g_alpha ? a.g_alpha[pix] : 0.0f;
-        S = Gr * a.rgb[pix * 3 + 0] + Gg * a.rgb[pix * 3 + 1] + Gb * a.rgb[pix * 3 + 2] + gA * a.alpha[pix];
-        if (a.g_asum) { gN1 = a.g_asum[pix * 2 + 0]; gN2 = 2.0f * a.g_asum[pix * 2 + 1]; }
-    }
-    // footprint window of a pixel rectangle [x_lo,x_hi] x [y_lo,y_hi] (+margins) on plane dd: wave 0, lane & 3 = corner
-    auto footprint = [&](int dd, float x_lo, float x_hi, float y_lo, float y_hi, int *out) {
-        const float *h = a.homos + 9 * dd;
-        const float cx = (float)a.col0 + a.pc + ((tid & 1) ? x_hi : x_lo);
-        const float cy = (float)a.row0 + a.pc + ((tid & 2) ? y_hi : y_lo);
-        const float X = h[0] * cx + h[1] * cy + h[2], Y = h[3] * cx + h[4] * cy + h[5], Z = h[6] * cx + h[7] * cy + h[8];
-        const float ctx = texel_coord<COORD>(X / Z, (float)a.Ws / 2.0f, (float)(a.Ws - 1), a.sx, a.ox);
-        const float cty = texel_coord<COORD>(Y / Z, (float)a.Hs / 2.0f, (float)(a.Hs - 1), a.sy, a.oy);
-        float mnx = ctx, mxx = ctx, mny = cty, mxy = cty;
-#pragma unroll
-        for (int m = 1; m <= 2; m <<= 1) {
-            mnx = fminf(mnx, __shfl_xor(mnx, m, 64)); mxx = fmaxf(mxx, __shfl_xor(mxx, m, 64));
-            mny = fminf(mny, __shfl_xor(mny, m, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, m, 64));
-        }
-        if (tid == 0) {
-            const int wX0 = max(0, (int)floorf(fmaxf(mnx - 0.01f, -2.0f))), wY0 = max(0, (int)floorf(fmaxf(mny - 0.01f, -2.0f)));
-            const int wX1 = min(a.Ws - 1, (int)floorf(fminf(mxx + 0.01f, (float)a.Ws)) + 1);
-            const int wY1 = min(a.Hs - 1, (int)floorf(fminf(mxy + 0.01f, (float)a.Hs)) + 1);
-            out[0] = wX0; out[1] = wY0; out[2] = max(0, wX1 - wX0 + 1); out[3] = max(0, wY1 - wY0 + 1);
-        }
-    };
-    // asynchronous fetch of the tap window of a plane straight into LDS (global_load_lds_dwordx4: no VGPRs, the data lands
-    // while the gather runs).  The window is stored DENSE (pitch = its width), so texel idx of the window is LDS slot idx
-    // and a wave's 64 consecutive idx are the 1 KiB contiguous destination the LDS-DMA writes (wave-uniform base + lane*16).
-    auto win_dma = [&](const float *pl, const int *tw) {
-        const int w_ = min(tw[2], TWP), n = min(w_ * min(tw[3], THM), TWP * THM);
-        const float inv = 1.0f / (float)max(w_, 1);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int idx = tid + k * NT;
-            if (idx < n) {
-                const int wy = (int)(((float)idx + 0.5f) * inv), wx = idx - wy * w_;
-                const float *g = pl + ((size_t)(tw[1] + wy) * a.Ws + (tw[0] + wx)) * 4;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                                 (__attribute__((address_space(3))) void *)(s_win + (idx - lane)), 16, 0, 0);
-            }
-        }
-    };
-    // region rectangle incl. halo, one more pixel of margin for the +1 taps is added by the floor()+1 of the window
-    const float rxl = (float)rx0, rxh = (float)(rx0 + RW - 1), ryl = (float)ry0, ryh = (float)(ry0 + ROWS - 1);
-    if (tid < 64) footprint(0, rxl, rxh, ryl, ryh, s_tw[0]);
-    __syncthreads();
-    win_dma(plane, s_tw[0]);
-    __syncthreads();      // (drains the LDS-DMA: hipcc emits vmcnt(0) in front of the barrier while a DMA is in flight)
-    float Tr = 1.0f, P = 0.0f;
-    for (int d = 0; d < a.D; ++d, plane += plane_stride, gplane += plane_stride) {
-        const float *h = a.homos + 9 * d;
-        const int par = d & 1;
-        if (tid < 64) {
-            const float el = (ix0 == 0) ? 1.6f : 0.6f, er = (ix1 == a.W - 1) ? 1.6f : 0.6f;
-            const float et = (iy0 == 0) ? 1.6f : 0.6f, eb = (iy1 == a.H - 1) ? 1.6f : 0.6f;
-            footprint(d, (float)ix0 - el, (float)ix1 + er, (float)iy0 - et, (float)iy1 + eb, s_w);
-            if (d + 1 < a.D) footprint(d + 1, rxl, rxh, ryl, ryh, s_tw[par ^ 1]);
-        }
-        // (2) sweep: taps from the LDS window
-        float2 tc = make_float2(-1e30f, -1e30f);
-        float4 gval = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int TX0 = s_tw[par][0], TY0 = s_tw[par][1], tw_ = min(s_tw[par][2], TWP), th_ = min(s_tw[par][3], THM);
-        if (inimg && tw_ > 0 && th_ > 0) {
-            const TapsI ti = make_taps_i<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-            const int lx0 = min(max(ti.x0 - TX0, 0), tw_ - 1), lx1 = min(max(ti.x0 + (a.Ws > 1) - TX0, 0), tw_ - 1);
-            const int ly0 = min(max(ti.y0 - TY0, 0), th_ - 1), ly1 = min(max(ti.y0 + (a.Hs > 1) - TY0, 0), th_ - 1);
-            Taps2 tp;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) tp.w[i] = ti.w[i];
-            tp.cov = ti.cov; tp.tx = ti.tx; tp.ty = ti.ty;
-            f4 tv[4], pre;
-            auto ldw = [&](int ly, int lx) { const float4 v = s_win[ly * tw_ + lx]; return f4{v.x, v.y, v.z, v.w}; };
-            tv[0] = ldw(ly0, lx0); tv[1] = ldw(ly0, lx1); tv[2] = ldw(ly1, lx0); tv[3] = ldw(ly1, lx1);
-            const f4 o = shade2<ORDER, RACT, AACT>(tp, tv, &pre);
-            const float q = Gr * o.x + Gg * o.y + Gb * o.z + gA;
-            const float w = o.w * Tr;
-            P += w * q;
-            const float om = 1.0f - o.w;
-            const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;
-            gval = make_float4(w * Gr, w * Gg, w * Gb, Tr * q - behind + (gN1 + gN2 * o.w));
-            Tr *= om;
-            if constexpr (ORDER == VL3D_ACT_POST)
-                gval = make_float4(gval.x * act_bwd<RACT>(pre.x, o.x), gval.y * act_bwd<RACT>(pre.y, o.y),
-                                   gval.z * act_bwd<RACT>(pre.z, o.z), gval.w * act_bwd<AACT>(pre.w, o.w));
-            if (tp.cov > 0.0f) tc = make_float2(tp.tx, tp.ty);
-            else gval = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        s_t[tid] = tc;
-        s_g[tid] = gval;
-        __syncthreads();   // (Y) staging visible, every sweep is done with the texel window, window geometries published
-        // start the LDS-DMA of the texel window of plane d+1 now: it lands while the gather runs
-        if (d + 1 < a.D) win_dma(plane + plane_stride, s_tw[par ^ 1]);
-        // (3) gather (identical to render_bwd_tile_k)
-        const int X0 = s_w[0], Y0 = s_w[1], ww = s_w[2], wh = s_w[3];
-        const float inv_ww = 1.0f / (float)max(ww, 1);
-        const float *hi = a.plan + PLAN_HDR + PLAN_REC * d;
-        for (int idx = tid; idx < ww * wh; idx += NT) {
-            const int wy = (int)(((float)idx + 0.5f) * inv_ww), wx = idx - wy * ww;
-            const float tauX = (float)(X0 + wx), tauY = (float)(Y0 + wy);
-            float qx, qy;
-            owner_pixel(hi, tauX, tauY, a.pc, a.col0, a.row0, qx, qy);
-            const float rx = fminf(fmaxf(rintf(qx), 0.0f), (float)(a.W - 1));
-            const float ry = fminf(fmaxf(rintf(qy), 0.0f), (float)(a.H - 1));
-            if (!(rx >= (float)ix0 && rx <= (float)ix1 && ry >= (float)iy0 && ry <= (float)iy1)) continue;
-            const int lc = ((int)ry - ry0) * RW + ((int)rx - rx0);
-            const f2 tau = f2{tauX, tauY};
-            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int li = lc + dy * RW + dx;
-                    const f2 c = *reinterpret_cast<const f2 *>(&s_t[li]);
-                    f2 wv = 1.0f - __builtin_elementwise_abs(c - tau);
-                    wv = __builtin_elementwise_max(wv, f2{0.f, 0.f});
-                    acc += *reinterpret_cast<const f4 *>(&s_g[li]) * (wv.x * wv.y);
-                }
-            const size_t toff = ((size_t)(Y0 + wy) * a.Ws + (X0 + wx)) * 4;
-            if constexpr (ORDER == VL3D_ACT_PRE) {
-                const f4 sv = *reinterpret_cast<const f4 *>(plane + toff);
-                acc = f4{acc.x * act_bwd<RACT>(sv.x, act_fwd<RACT>(sv.x)), acc.y * act_bwd<RACT>(sv.y, act_fwd<RACT>(sv.y)),
-                         acc.z * act_bwd<RACT>(sv.z, act_fwd<RACT>(sv.z)), acc.w * act_bwd<AACT>(sv.w, act_fwd<AACT>(sv.w))};
-            }
-            *reinterpret_cast<f4 *>(gplane + toff) = acc;
-        }
-        __syncthreads();   // (X) DMA drained (vmcnt(0) + barrier): texel window of plane d+1 in LDS; staging buffers free again
-    }
-}
-
-// =====================================================================================================
 // Layer-space smoothness regularisers, forward (MPV.py:517-531): sum over frames, planes and neighbouring pixel pairs of
 // |L[p] - L[q]| of the warped+activated per-layer rgba L (zero where a plane does not cover the pixel) -- without ever
 // materialising the [T,h,w,K,4] layer tensor the reference builds (1.47 GB per training crop).
@@ -904,8 +732,6 @@ thread_local bool g_reg_fwd = false;
 
 // fp16 plane stacks (cfg5) are instantiated for the shipped (sigmoid, sigmoid) activations only
 thread_local bool g_f16 = false;
-// backward: also launch the LDS-texel-window variant (takes the call when the on-device plan says its window fits)
-thread_local bool g_use_window = false;
 
 template <bool BWD, int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
 void launch_t(const RenderArgs &a, hipStream_t s) {
@@ -923,15 +749,7 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
             if (!done) {
                 if (a.g_reg) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, F16>(a, s);
                 else {
-                    RenderArgs aw = a;
-                    aw.use_window = (!F16 && g_use_window) ? 1 : 0;
-                    if (aw.use_window) {
-                        RenderArgs b = aw;
-                        b.tiles_x = (a.W + RW - 3) / (RW - 2); b.tiles_y = (a.H + 13) / 14;
-                        hipLaunchKernelGGL((render_bwd_tilew_k<COORD, BORDER, ORDER, RACT, AACT>),
-                                           dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * 16), 0, s, b);
-                    }
-                    launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, false, F16>(aw, s);
+                    launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, false, F16>(a, s);
                 }
             }
         }
@@ -1096,7 +914,6 @@ extern "C" int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, 
         // variant & 0xf: 0/3 -> 16-row regions; 2 -> 8 rows.  (Prefetching the next plane's taps across the barrier was
         // measured and dropped: 91 VGPRs halve the occupancy, 24.3-28.9 ms vs 17.3 ms.)
         g_tile_rows = (desc->variant & 0xf) == 2 ? 8 : 16;
-        g_use_window = (desc->variant & 0xf) == 6;
     } else {
         a.plan = nullptr;
         g_tile_rows = 0;
