@@ -639,7 +639,7 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
                 acc = f4{acc.x * act_bwd<RACT>(sv.x, act_fwd<RACT>(sv.x)), acc.y * act_bwd<RACT>(sv.y, act_fwd<RACT>(sv.y)),
                          acc.z * act_bwd<RACT>(sv.z, act_fwd<RACT>(sv.z)), acc.w * act_bwd<AACT>(sv.w, act_fwd<AACT>(sv.w))};
             }
-            if (!(a.ablate & 2)) *reinterpret_cast<f4 *>(reinterpret_cast<char *>(gplane) + (size_t)(tix << 4)) = acc;
+            if (!(a.ablate & 2)) __builtin_nontemporal_store(acc, reinterpret_cast<f4 *>(reinterpret_cast<char *>(gplane) + (size_t)(tix << 4)));
         };
         if (row < wh && lane < ww) gather(e0, lane, row, win0 + toff_thread);
         for (int wy = row; wy < wh; wy += ROWS)      // rest of a window larger than 64 x ROWS (frame-border tiles, minification)
