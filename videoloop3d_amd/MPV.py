@@ -8,7 +8,8 @@ geometry -- which is all the shipped configs ever produce (vertices get no gradi
     Texel pitch is exactly 1 plane pixel (the atlas pitch of (Aw-1)/(gw*(mpi_w-1)) is available through `texel_scale`).
   * no rasteriser: coverage and UVs of fronto-parallel quads are the analytic per-plane homography, with
     the two pytorch3d-side constants exposed as `pixel_center` (0.5) and hard-cut borders.
-  * lod / init_from_mpi / save_* / optimizer bookkeeping are host-side and out of scope this round.
+  * lod / get_optimizer / get_lrate / update_step (the stage-2 driver's hooks, train_3dvid.py:264-281) act on the stack;
+    init_from_mpi / save_mesh / save_texture (sparse-tile checkpoints) are not provided.
 """
 import dataclasses
 
@@ -88,8 +89,10 @@ class MPMeshVid(nn.Module):
         if args.rgb_activate not in ACTIVATES or args.alpha_activate not in ACTIVATES:
             raise RuntimeError(f"activation ({args.rgb_activate}, {args.alpha_activate}) not implemented by the HIP kernels")
         self.rgb_activate, self.alpha_activate = ACTIVATES[args.rgb_activate], ACTIVATES[args.alpha_activate]
+        self.texel_scale = tuple(float(v) for v in texel_scale)
         self.spec = dataclasses.replace(RenderSpec.mpv(rgb_act=args.rgb_activate, alpha_act=args.alpha_activate,
-                                                       scale=tuple(texel_scale)), pixel_center=float(pixel_center))
+                                                       scale=self.texel_scale), pixel_center=float(pixel_center))
+        self.optimize_geometry = False
 
         self.swd_patch_size, self.swd_patcht_size = args.swd_patch_size, args.swd_patcht_size
         self.swd_stride, self.swd_stridet = args.swd_stride, args.swd_stridet
@@ -100,6 +103,49 @@ class MPMeshVid(nn.Module):
             'mse': Patch3DMSE,
             'avg': Patch3DAvg,
         }
+
+    # ---- driver hooks (train_3dvid.py:264-281) ------------------------------------------------------------------------
+    def lod(self, factor):
+        """MPV.py:140-197 (dense branch): resample the learnable texture to `factor` of its full resolution for one level of
+        the training pyramid.  Every plane of the stack is resized to (int(mpi_h*factor), int(mpi_w*factor)) with the same
+        antialiased bilinear filter torchvision's Resize applies to the atlas; the plane quads keep their extent, so the
+        plane-pixel -> texel scale of the render spec becomes (w'-1)/(mpi_w-1) (the reference gets this from its
+        normalised UVs, MPV.py:75-81)."""
+        h, w = max(int(self.mpi_h * factor), 2), max(int(self.mpi_w * factor), 2)
+        D, T, hs, ws, _ = self.stack.shape
+        print(f"MPV.lod:: Resizing the planes from {(hs, ws)} to {(h, w)}")
+        if (hs, ws) != (h, w):
+            with torch.no_grad():
+                planes = self.stack.data.permute(0, 1, 4, 2, 3).reshape(D * T, 4, hs, ws)
+                planes = torch.nn.functional.interpolate(planes, size=(h, w), mode="bilinear", align_corners=False, antialias=True)
+                new = planes.reshape(D, T, 4, h, w).permute(0, 1, 3, 4, 2).contiguous()
+            self.register_parameter("stack", nn.Parameter(new, requires_grad=True))
+        sx = self.texel_scale[0] * (w - 1) / max(self.mpi_w - 1, 1)
+        sy = self.texel_scale[1] * (h - 1) / max(self.mpi_h - 1, 1)
+        self.spec = dataclasses.replace(self.spec, scale=(sx, sy))
+        print("MPV.los:: Resizing successful !")
+
+    def get_lrate(self, step):
+        """MPV.py:216-225."""
+        args = self.args
+        scaling = 0.1 ** (step / (args.lrate_decay * 1000))
+        return [("lr", args.lrate * scaling), ("vertlr", args.lrate * getattr(args, "optimize_verts_gain", 1) * scaling)]
+
+    def get_optimizer(self, step):
+        """MPV.py:199-214.  The planar path has no vertex parameters, so there is one parameter group (the reference's
+        second group holds `_verts`, which never receive a gradient in the shipped configs)."""
+        (_, base_lr), _ = self.get_lrate(step)
+        params = [{'params': [p for _, p in self.named_parameters()]}]
+        if self.args.optimizer == 'adam':
+            return torch.optim.Adam(params=params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8)
+        if self.args.optimizer == 'sgd':
+            return torch.optim.SGD(params=params, lr=base_lr, momentum=0.9)
+        raise RuntimeError(f"Unrecongnized optimizer type {self.args.optimizer}")
+
+    def update_step(self, step):
+        """MPV.py:227-229; geometry optimisation itself is not on the planar path."""
+        if step >= getattr(self.args, "optimize_geo_start", 10000000):
+            self.optimize_geometry = True
 
     # ---- geometry ----------------------------------------------------------------------------------------------------
     def plane_homographies(self, extrin, intrin):
