@@ -233,3 +233,59 @@ def test_stage2_driver_trains(dev):
     assert all(np.isfinite(l) for _, l, _ in log) and log[0][2] == ["a_smooth", "rgb_smooth"]
     fine = [l for lvl, l, _ in log if lvl == 1]
     assert np.mean(fine[-8:]) < np.mean(fine[:8])
+
+
+def test_sparsified_mpi_to_video_training(dev):
+    """MPI.py:288-442 -> MPV.py:235-288 on the dense stack: after sparsify_faces + init_from_mpi, culled quads render nothing and
+    never change, static quads stay one texture shared by all frames through optimiser steps, dynamic quads become per-frame."""
+    from videoloop3d_amd import tiles
+    from videoloop3d_amd.MPI import MPMesh
+    from videoloop3d_amd.MPV import MPMeshVid
+    H, W = 44, 60
+    K, ref_extrin, tar = scene(H, W)
+    a1 = make_args_mpi(learn_loop_mask=True, mpi_h_verts=5, mpi_w_verts=7, sparsify_rmfirstlayer=0)
+    mpi = MPMesh(a1, H, W, ref_extrin, K, 1.0, 100.0).to(dev)
+    Hs, Ws = mpi.stack.shape[2:4]
+    with torch.no_grad():
+        mpi.stack[2, 0, 6:30, 8:50, 3] = 2.0
+        mpi.stack[4, 0, 10:40, 20:60, 3] = 1.0
+        mpi.stack_mask[4, 0, 15:30, 28:50] = 4.0
+    mpi.sparsify_faces(erode_num=1)
+    keep_t = tiles.quad_to_texel_mask(mpi.quad_keep, Hs, Ws)
+    dyn_t = tiles.quad_to_texel_mask(mpi.quad_dyn, Hs, Ws)
+    static_t = keep_t & ~dyn_t
+    assert bool(static_t.any()) and bool(dyn_t.any()) and bool((~keep_t).any())
+
+    a2 = make_args(mpv_frm_num=5, mpi_d=a1.mpi_d, mpi_h_scale=a1.mpi_h_scale, mpi_w_scale=a1.mpi_w_scale, rgb_smooth_loss_weight=0.0, a_smooth_loss_weight=0.0, lrate=0.05, lrate_decay=30,
+                   optimizer="adam", optimize_verts_gain=1)
+    vid = MPMeshVid(a2, H, W, ref_extrin, K, 1.0, 100.0).to(dev)
+    vid.init_from_mpi(mpi.state_dict())
+    start = vid.stack.detach().clone()
+    # culled quads are invisible: forcing their colours to an extreme value changes nothing, except for samples that fall in
+    # a culled quad within ~1e-3 px of a kept texel (the blended alpha logit w*(-1e4) + (1-w)*a is not yet -inf there)
+    tar_e, tar_k = torch.tensor(tar)[None].to(dev), torch.tensor(K)[None].to(dev)
+    vid.eval()
+    with torch.no_grad():
+        rgb0, _ = vid(H, W, tar_e, tar_k)
+        vid.stack[..., :3].masked_fill_((~keep_t)[:, None, :, :, None], 9.0)
+        rgb1, _ = vid(H, W, tar_e, tar_k)
+        diff = (rgb0 - rgb1).abs()
+        assert float((diff > 1e-6).float().mean()) < 2e-3 and float(diff.max()) < 0.5
+    # a few optimiser steps against a random video
+    vid.train()
+    opt = vid.get_optimizer(0)
+    res = synth.make_video(9, H, W, seed=31, device=dev)[0].permute(1, 0, 2, 3)[None].contiguous()      # [1,F,3,H,W]
+    cfg = collate({"loss_name": "gpnn_lm", "patch_size": 3, "patcht_size": 3, "stride": 2, "stridet": 1, "alpha": 10000.0,
+                   "rou": "-2", "scaling": 0.1, "macro_block": 65})
+    for _ in range(3):
+        _, extra = vid(H, W, tar_e, tar_k, res=res, losscfg=dict(cfg))
+        opt.zero_grad()
+        extra["swd"].mean().backward()
+        opt.step()
+    now = vid.stack.detach()
+    assert torch.equal(now[..., 3][(~keep_t)[:, None].expand_as(now[..., 3])], start[..., 3][(~keep_t)[:, None].expand_as(now[..., 3])])
+    st = static_t[:, None, :, :, None].expand_as(now)
+    assert torch.equal(now[:, :1].expand_as(now)[st], now[st])                       # static texels identical in every frame
+    assert not torch.equal(now[st], start[st])                                        # ... and they did learn
+    dy = dyn_t[:, None, :, :, None].expand_as(now)
+    assert not torch.equal(now[:, :1].expand_as(now)[dy], now[dy])                    # dynamic texels diverge between frames

@@ -5,8 +5,9 @@ geometry with rgb_mlp_type = 'direct' (configs/mpi_base.txt).  As in videoloop3d
 stack `stack` (D,1,mpi_h,mpi_w,4) (+ `stack_mask` (D,1,mpi_h,mpi_w) for the learned loop mask, MPI.py:115-117) instead of the
 atlas grid, and coverage/UVs are the analytic per-plane homography instead of pytorch3d's rasteriser.
 The loop-mask channel (MPI.py:568-583: sigmoid(mask texture) composited with the DETACHED layer alphas) is a second pass of
-the fused renderer on (mask, mask, mask, alpha.detach()).  sparsify_faces / direct2sh / save_* / optimizer are host-side
-one-shot bookkeeping and out of scope; d_smooth needs the rasteriser's depth buffer (default weight 0).
+the fused renderer on (mask, mask, mask, alpha.detach()).  sparsify_faces (MPI.py:288-442, the paper's tile culling) classifies the
+quads of the dense stack into culled / static / dynamic (videoloop3d_amd/tiles.py) instead of re-packing atlases; direct2sh /
+save_* are out of scope; d_smooth needs the rasteriser's depth buffer (default weight 0).
 """
 import dataclasses
 
@@ -14,6 +15,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import tiles
 from .MPV import ACTIVATES, get_new_intrin, sparsity_ratio
 from .render import RenderSpec, render_planes, render_planes_with_regularisers
 from .utils_mpi import compute_homography, make_depths
@@ -50,6 +52,49 @@ class MPMesh(nn.Module):
                                                        scale=tuple(texel_scale)), pixel_center=float(pixel_center))
         # the loop-mask pass: label = sigmoid(mask), alpha = the (detached) layer alpha with the model's activation
         self.spec_mask = dataclasses.replace(self.spec, rgb_act="sigmoid")
+        self.alpha_activate = ACTIVATES[args.alpha_activate]
+        # quads of the vertex grid (utils_mpi.py:80-89); classified by sparsify_faces
+        self.quad_h, self.quad_w = max(int(getattr(args, "mpi_h_verts", 12)) - 1, 1), max(int(getattr(args, "mpi_w_verts", 15)) - 1, 1)
+        self.is_sparse = False
+        self.has_dyn = False
+
+    @torch.no_grad()
+    def sparsify_faces(self, erode_num=2, alpha_thresh=0.03, loop_thresh=0.5):
+        """Tile Culling Algorithm of the paper (MPI.py:288-442) on the dense stack: quads whose (eroded, dilated) alpha never
+        exceeds `alpha_thresh` are culled, kept quads whose (eroded, dilated) loop mask exceeds `loop_thresh` are dynamic, the
+        rest static.  Registers `quad_keep`, `quad_dyn` [D,QH,QW] and writes the culling into the alpha logits."""
+        print("Sparsifying the faces")
+        a_logit = self.stack[:, 0, :, :, 3].detach().clone()
+        a_logit[a_logit == ALPHA_INIT_VAL] = -10                                                  # MPI.py:318
+        alpha = self.alpha_activate(a_logit)
+        loop = None
+        if self.learn_loop_mask:
+            m = self.stack_mask[:, 0].detach().clone()
+            m[m == ALPHA_INIT_VAL] = -10                                                          # MPI.py:321
+            loop = torch.sigmoid(m)
+        keep, dyn = tiles.classify_quads(alpha, loop, self.quad_h, self.quad_w, erode_num, alpha_thresh, loop_thresh,
+                                         int(getattr(self.args, "sparsify_rmfirstlayer", 0)))
+        n_quad, n_mask, n_dyn = keep.numel(), int(keep.sum()), int(dyn.sum())
+        print(f"mask {n_mask} / {n_quad} ({100 * n_mask / n_quad:.2f}%) quads")
+        print(f"   of {n_mask}, {n_dyn} ({100 * n_dyn / max(n_mask, 1):.2f}%) is dynamic quads")
+        self.register_buffer("quad_keep", keep)
+        self.register_buffer("quad_dyn", dyn)
+        tiles.cull_stack_(self.stack.data, keep)
+        self.is_sparse = True
+        self.has_dyn = True
+        self.args.learn_loop_mask = False                                                         # MPI.py:440-441
+        self.learn_loop_mask = False
+        if hasattr(self, "stack_mask"):
+            del self.stack_mask
+
+    def state_dict(self, *args, **kwargs):
+        """MPI.py-style: the tensors plus python scalars under "self.*" keys (consumed by MPMeshVid.init_from_mpi)."""
+        sd = super().state_dict(*args, **kwargs)
+        sd["self.is_sparse"] = self.is_sparse
+        sd["self.quad_h"], sd["self.quad_w"] = self.quad_h, self.quad_w
+        if self.has_dyn:
+            sd["self.has_dyn"] = self.has_dyn
+        return sd
 
     def plane_homographies(self, extrin, intrin):
         dev = extrin.device

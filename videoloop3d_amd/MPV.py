@@ -9,7 +9,10 @@ geometry -- which is all the shipped configs ever produce (vertices get no gradi
   * no rasteriser: coverage and UVs of fronto-parallel quads are the analytic per-plane homography, with
     the two pytorch3d-side constants exposed as `pixel_center` (0.5) and hard-cut borders.
   * lod / get_optimizer / get_lrate / update_step (the stage-2 driver's hooks, train_3dvid.py:264-281) act on the stack;
-    init_from_mpi / save_mesh / save_texture (sparse-tile checkpoints) are not provided.
+  * init_from_mpi takes the state_dict of videoloop3d_amd.MPI.MPMesh (dense stack + culled/static/dynamic quad maps of
+    its sparsify_faces, videoloop3d_amd/tiles.py); static quads stay one shared texture because their gradient is summed
+    over the frames.  The reference's packed-atlas checkpoints (uvs/faces/atlas tiles) and save_mesh / save_texture are
+    not provided.
 """
 import dataclasses
 
@@ -93,6 +96,10 @@ class MPMeshVid(nn.Module):
         self.spec = dataclasses.replace(RenderSpec.mpv(rgb_act=args.rgb_activate, alpha_act=args.alpha_activate,
                                                        scale=self.texel_scale), pixel_center=float(pixel_center))
         self.optimize_geometry = False
+        self.is_sparse, self.has_dyn = False, False
+        self.register_buffer("quad_keep", None)      # [D,QH,QW] bool maps of a sparsified stage-1 MPI (init_from_mpi)
+        self.register_buffer("quad_dyn", None)
+        self._tie_hook = None
 
         self.swd_patch_size, self.swd_patcht_size = args.swd_patch_size, args.swd_patcht_size
         self.swd_stride, self.swd_stridet = args.swd_stride, args.swd_stridet
@@ -103,6 +110,49 @@ class MPMeshVid(nn.Module):
             'mse': Patch3DMSE,
             'avg': Patch3DAvg,
         }
+
+    # ---- stage-1 -> stage-2 hand-over (MPV.py:235-304) ------------------------------------------------------------------
+    def init_from_mpi(self, state_dict):
+        """MPV.py:235-288 for the dense representation: take the stage-1 MPI (`MPMesh.state_dict()`) as the initial value of
+        every frame.  With a sparsified MPI the quad maps come along: culled quads stay invisible, static quads stay ONE
+        texture shared by all frames (their gradient is summed over the frames, as the reference's static atlas sees it),
+        dynamic quads are free per frame; without them everything is dynamic ("load static as dynamic", MPV.py:266-288)."""
+        self.ref_extrin.data = state_dict['ref_extrin'].type_as(self.ref_extrin)
+        self.ref_intrin.data = state_dict['ref_intrin'].type_as(self.ref_intrin)
+        self.planedepth.data = state_dict['planedepth'].type_as(self.planedepth)
+        self.ref_intrin_mpi.data = get_new_intrin(self.ref_intrin, -self.H_start, -self.W_start)
+        mpi = state_dict['stack']
+        if mpi.shape[0] != self.mpi_d or tuple(mpi.shape[2:4]) != (self.mpi_h, self.mpi_w):
+            raise RuntimeError(f"stage-1 stack {tuple(mpi.shape)} does not match mpi_d={self.mpi_d}, planes {(self.mpi_h, self.mpi_w)}")
+        with torch.no_grad():
+            new = mpi.type_as(self.stack).expand(-1, self.frm_num, -1, -1, -1).contiguous()
+        self.register_parameter("stack", nn.Parameter(new, requires_grad=True))
+        self.spec = dataclasses.replace(self.spec, scale=self.texel_scale)
+        self.is_sparse = bool(state_dict.get("self.is_sparse", False))
+        self.has_dyn = bool(state_dict.get("self.has_dyn", False))
+        if self.is_sparse:
+            self.register_buffer("quad_keep", state_dict["quad_keep"].to(self.stack.device).bool())
+            self.register_buffer("quad_dyn", state_dict["quad_dyn"].to(self.stack.device).bool())
+        else:
+            self.register_buffer("quad_keep", None)
+            self.register_buffer("quad_dyn", None)
+        self._install_tie_hook()
+
+    def _install_tie_hook(self):
+        """(re-)attach the gradient hook that keeps static quads one shared texture; the parameter object changes in lod()."""
+        if self._tie_hook is not None:
+            self._tie_hook.remove()
+            self._tie_hook = None
+        if self.is_sparse and self.quad_keep is not None:
+            from . import tiles
+            self._tie_hook = self.stack.register_hook(lambda g: tiles.tie_static_grad(g, self.quad_keep, self.quad_dyn))
+
+    def state_dict(self, *args, **kwargs):
+        """MPV.py:290-304: tensors + python scalars under "self.*" keys."""
+        sd = super().state_dict(*args, **kwargs)
+        sd["self.is_sparse"] = self.is_sparse
+        sd["self.has_dyn"] = self.has_dyn
+        return sd
 
     # ---- driver hooks (train_3dvid.py:264-281) ------------------------------------------------------------------------
     def lod(self, factor):
@@ -123,6 +173,7 @@ class MPMeshVid(nn.Module):
         sx = self.texel_scale[0] * (w - 1) / max(self.mpi_w - 1, 1)
         sy = self.texel_scale[1] * (h - 1) / max(self.mpi_h - 1, 1)
         self.spec = dataclasses.replace(self.spec, scale=(sx, sy))
+        self._install_tie_hook()
         print("MPV.los:: Resizing successful !")
 
     def get_lrate(self, step):

@@ -1,0 +1,105 @@
+"""Tile culling on the dense plane stack (first stage).
+
+The reference culls the quads (tiles) of its plane meshes whose alpha is negligible and splits the rest into STATIC tiles
+(one texture shared by all frames) and DYNAMIC tiles (a texture per frame) -- MPI.py:288-442 `sparsify_faces`, consumed by
+MPV.py:235-288 `init_from_mpi` -- and re-packs them into two atlases.  Here the texture stays the dense `(D,T,Hs,Ws,4)`
+stack (the layout the MI355X kernels stream), and the same three-way classification is carried as two small boolean quad
+maps `(D,QH,QW)`:
+  * culled quads: their texels get the alpha logit CULLED_ALPHA, so they render exactly nothing and receive no gradient
+    (sigmoid'(-1e4) == 0) -- the mesh of the reference simply has no face there;
+  * static quads: the T copies of their texels are kept identical by summing their gradient over the frames
+    (`tie_static_grad`): one shared texture with the summed gradient, as in the reference's static atlas;
+  * dynamic quads: free per frame.
+The memory saving of the packed atlases is not reproduced (288 GB of HBM hold the dense stack); skipping culled tiles in
+the kernels is the next step.  Quads are the (mpi_h_verts-1) x (mpi_w_verts-1) cells of the vertex grid
+(utils_mpi.py:80-89), each covering [(q)*c, (q+1)*c] plane pixels with c = (mpi-1)/(verts-1).
+"""
+import torch
+import torch.nn.functional as F
+
+CULLED_ALPHA = -1e4
+
+
+def dilate(alpha, kernelsz=3):
+    """utils.py:298-306: max filter, zero padding.  alpha [B,L,H,W]."""
+    pad = kernelsz // 2
+    return F.max_pool2d(F.pad(alpha, (pad, pad, pad, pad), value=0.0), kernelsz, stride=1)
+
+
+def erode(alpha, kernelsz=3):
+    """utils.py:309-317: min filter, zero padding (so the image border erodes)."""
+    pad = kernelsz // 2
+    return -F.max_pool2d(F.pad(-alpha, (pad, pad, pad, pad), value=0.0), kernelsz, stride=1)
+
+
+def quad_max(img, QH, QW):
+    """max of img [D,H,W] over the closed plane-pixel rectangle of every quad -> [D,QH,QW]."""
+    D, H, W = img.shape
+    ch, cw = (H - 1) / QH, (W - 1) / QW
+    out = img.new_empty((D, QH, QW))
+    for qy in range(QH):
+        y0, y1 = int(qy * ch), min(int(-(-(qy + 1) * ch // 1)), H - 1)
+        rows = img[:, y0:y1 + 1].amax(1)                       # D,W
+        for qx in range(QW):
+            x0, x1 = int(qx * cw), min(int(-(-(qx + 1) * cw // 1)), W - 1)
+            out[:, qy, qx] = rows[:, x0:x1 + 1].amax(1)
+    return out
+
+
+def classify_quads(alpha, loopmask, QH, QW, erode_num=2, alpha_thresh=0.03, loop_thresh=0.5, rmfirstlayer=0):
+    """MPI.py:319-356.  alpha, loopmask: activated [D,H,W] maps in [0,1] (loopmask may be None: everything kept is dynamic).
+    -> (keep, dyn) bool [D,QH,QW]."""
+    a = alpha[None]
+    for _ in range(erode_num):
+        a = erode(a)
+    for _ in range(erode_num + 2):
+        a = dilate(a)
+    qa = quad_max(a[0], QH, QW)
+    if rmfirstlayer > 0:
+        qa[:rmfirstlayer] = 0
+    keep = qa > alpha_thresh
+    if loopmask is None:
+        return keep, keep.clone()
+    m = loopmask[None]
+    for _ in range(erode_num):
+        m = erode(m)
+    for _ in range(erode_num):
+        m = dilate(m)
+    dyn = keep & (quad_max(m[0], QH, QW) > loop_thresh)
+    return keep, dyn
+
+
+def quad_to_texel_mask(qmask, Hs, Ws):
+    """[D,QH,QW] bool -> [D,Hs,Ws] bool: true for every texel a bilinear tap of a sample inside a true quad can read (the
+    quad's closed rectangle grown by one texel)."""
+    D, QH, QW = qmask.shape
+    dev = qmask.device
+    ch, cw = (Hs - 1) / QH, (Ws - 1) / QW
+    y = torch.arange(Hs, device=dev, dtype=torch.float64)
+    x = torch.arange(Ws, device=dev, dtype=torch.float64)
+    ylo = ((y - 1) / ch).floor().clamp(0, QH - 1).long()
+    yhi = ((y + 1) / ch).floor().clamp(0, QH - 1).long()
+    xlo = ((x - 1) / cw).floor().clamp(0, QW - 1).long()
+    xhi = ((x + 1) / cw).floor().clamp(0, QW - 1).long()
+    rows_lo, rows_hi = qmask[:, ylo], qmask[:, yhi]              # D,Hs,QW
+    return rows_lo[:, :, xlo] | rows_lo[:, :, xhi] | rows_hi[:, :, xlo] | rows_hi[:, :, xhi]
+
+
+def cull_stack_(stack, keep):
+    """write CULLED_ALPHA into the alpha logit of every texel no kept quad can read.  stack (D,T,Hs,Ws,4), in place."""
+    D, T, Hs, Ws, _ = stack.shape
+    dead = ~quad_to_texel_mask(keep, Hs, Ws)
+    stack[..., 3].masked_fill_(dead[:, None], CULLED_ALPHA)
+    return stack
+
+
+def tie_static_grad(grad, keep, dyn):
+    """gradient of the dense stack (D,T,Hs,Ws,4) -> the gradient the reference's (static atlas, dynamic atlas) pair would
+    see: texels only static quads read get the SUM over frames in every frame's copy; culled texels get 0."""
+    D, T, Hs, Ws, _ = grad.shape
+    keep_t = quad_to_texel_mask(keep, Hs, Ws)
+    dyn_t = quad_to_texel_mask(dyn, Hs, Ws)
+    static_t = (keep_t & ~dyn_t)[:, None, :, :, None]
+    tied = grad.sum(dim=1, keepdim=True)
+    out = torch.where(static_t, tied.expand_as(grad), grad)
+    return out * keep_t[:, None, :, :, None].to(grad.dtype)
