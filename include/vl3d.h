@@ -146,7 +146,10 @@ int64_t vl3d_patchnn_scratch_bytes(const vl3d_loss_desc *desc);
 /* Per spatial location b=(by,bx): dist[i,j] = |Px_i - Py_j|^2 / (3*pt*ps*ps) (utils_vid.py:72-86),
  * optional column-min normalisation (utils_vid.py:109-119,133-134), row argmin, first minimum wins
  * (utils_vid.py:139-141).  nn is int32 [h_o, w_o, n1].  Replaces extract_3Dpatches x2 +
- * get_NN_indices_low_memory (utils_vid.py:209-216). */
+ * get_NN_indices_low_memory (utils_vid.py:209-216).
+ * The kernel works on pixel-major copies of x and y kept in `scratch`.  desc->variant bit 8 (0x100): the y copy in `scratch`
+ * is still valid from the previous call with the same y, configuration and scratch buffer -- skip re-building it (the
+ * captured video y is constant over the iterations of a training loop; x, the render, is not). */
 int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const float *y, int32_t *nn,
                  void *scratch, vl3d_stream_t stream);
 
@@ -166,6 +169,14 @@ int vl3d_vote_fold(const vl3d_loss_desc *desc, const float *y, const int32_t *nn
  * n1 patches and their 3*pt*ps*ps elements of |y patch at nn - x patch|; nn from vl3d_patchnn (use_alpha = 0). */
 int vl3d_patch_l1(const vl3d_loss_desc *desc, const float *x, const float *y, const int32_t *nn, float *err,
                   vl3d_stream_t stream);
+
+/* Fused vote-fold + robust loss (utils_vid.py:217-229 + :344 + :348 in one pass): y2x = fold(y, nn) / weight is written
+ * (the loss classes cache it as last_y2x), and while it is in a register the robust loss of (x - y2x) is summed into
+ * loss_sum (device double, overwritten) and grad_x (3,Tx,H,W contiguous) receives d mean(rho)/dx = rho'(x - y2x) / (3 Tx H W).
+ * x uses the strides of desc.  Replaces vl3d_vote_fold(normalize=1) + vl3d_robust_fwd + vl3d_robust_bwd. */
+int vl3d_vote_fold_robust(const vl3d_loss_desc *desc, const float *y, const int32_t *nn, const float *x, int32_t rho_kind,
+                          float rou, float scale, float *y2x, float *weight, float *grad_x, double *loss_sum,
+                          vl3d_stream_t stream);
 
 /* robust_lossfun (utils_vid.py:10-26) fused with the mean (utils_vid.py:348).
  * kind: 0 'mse', 1 'abs', 2 general Barron with float rou (rou==0 and rou==2 special-cased as the reference).

@@ -221,3 +221,22 @@ def test_g10_compute_nnerr(dev, golden):
         for (ps, s_, pt, st, mb) in [(5, 2, 3, 1, 13), (7, 2, 3, 2, 65), (3, 1, 3, 1, 9), (11, 4, 3, 1, 19)]:
             v = compute_nnerr(x, y, ps, s_, pt, st, mb)
             assert abs(v - float(g[f"ps{ps}_s{s_}_pt{pt}_st{st}_mb{mb}"])) <= 2e-6
+
+
+def test_y_scratch_cache_is_invalidated_by_in_place_updates(dev):
+    """The NN kernel's pixel-major copy of y is reused across calls with the same y (utils_vid._patchnn_scratch); an in-place
+    change of y, a different view or a different tensor must rebuild it."""
+    from videoloop3d_amd import utils_vid as UV
+    x = synth.make_video(8, 21, 25, seed=3, device=dev)
+    y = synth.make_video(10, 21, 25, seed=4, device=dev)
+    y2 = synth.make_video(10, 21, 25, seed=9, device=dev)
+    ref = lambda yy: VO.find_nn_and_merge(x.cpu(), yy.cpu(), 5, 3, 2, 1, 1e10, return_nn=True)[2]
+    run = lambda yy: UV.find_nn_indices(x, yy, 5, 3, 2, 1, None)[0].cpu().long()
+    a = run(y)
+    assert torch.equal(run(y), a) and torch.equal(a, ref(y))            # second call: cache hit, same answer
+    y.copy_(y2)                                                         # in-place: version counter bumps
+    assert torch.equal(run(y), ref(y2))
+    assert torch.equal(run(y2.clone()), ref(y2))                        # another tensor
+    y3 = synth.make_video(12, 21, 25, seed=4, device=dev)
+    assert torch.equal(run(y3[:, :, 2:]), ref(y3[:, :, 2:]))            # a view with an offset
+    assert torch.equal(run(y3[:, :, :10]), ref(y3[:, :, :10]))          # same storage, different view

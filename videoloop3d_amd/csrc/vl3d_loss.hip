@@ -560,6 +560,51 @@ __global__ __launch_bounds__(256) void nn_vectors_k(const float *__restrict__ X,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------
+// robust loss (utils_vid.py:10-26)
+struct Rho {
+    int kind;      // 0 mse, 1 abs, 2 log1p (rou==0), 3 quadratic (rou==2), 4 general
+    float scale, b, d, coef;
+};
+
+__device__ __forceinline__ float rho_f(const Rho &r, float e) {
+    switch (r.kind) {
+        case 0: return e * e;
+        case 1: return fabsf(e);
+        case 2: { float s = (e / r.scale); return log1pf(s * s * 0.5f); }
+        case 3: { float s = (e / r.scale); return 0.5f * s * s; }
+        default: { float s = (e / r.scale); s = s * s; return r.coef * (powf(s / r.b + 1.0f, 0.5f * r.d) - 1.0f) * (r.scale * 10.0f); }
+    }
+}
+
+__device__ __forceinline__ float rho_g(const Rho &r, float e) {
+    switch (r.kind) {
+        case 0: return 2.0f * e;
+        case 1: return e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f);
+        case 2: { float s = e / r.scale; return (s / r.scale) / (1.0f + 0.5f * s * s); }
+        case 3: return e / (r.scale * r.scale);
+        default: {   // d/de (b/d)((s/b+1)^(d/2)-1)*10*scale, s=(e/scale)^2  ->  10*(e/scale)*(s/b+1)^(d/2-1)
+            float s = e / r.scale;
+            return 10.0f * s * powf(s * s / r.b + 1.0f, 0.5f * r.d - 1.0f);
+        }
+    }
+}
+
+// value and derivative together (the fused fold kernel): the general Barron case shares one log2/exp2 pair,
+// (s^2/b+1)^(d/2) = exp2(d/2 * log2(u)) and the derivative's power is that over u -- instead of two powf calls
+__device__ __forceinline__ void rho_fg(const Rho &r, float e, float &f, float &g) {
+    if (r.kind == 4) {
+        const float s = e / r.scale;
+        const float u = s * s / r.b + 1.0f;
+        const float p = __builtin_amdgcn_exp2f(0.5f * r.d * __builtin_amdgcn_logf(u));
+        f = r.coef * (p - 1.0f) * (r.scale * 10.0f);
+        g = 10.0f * s * p * __builtin_amdgcn_rcpf(u);
+    } else {
+        f = rho_f(r, e);
+        g = rho_g(r, e);
+    }
+}
+
 struct FoldArgs {
     const float *y;
     const int32_t *nn;
@@ -567,6 +612,14 @@ struct FoldArgs {
     int Tx, H, W, ps, pt, stride, stridet, h_o, w_o, n1;
     int64_t y_sc, y_st, y_sr;
     int normalize;
+    // fused robust loss (vl3d_vote_fold_robust): x (strided like the loss desc), per-element gradient rho'(x - y2x) * gscale and
+    // the loss sum, all optional (x == nullptr: plain fold)
+    const float *x;
+    int64_t x_sc, x_st, x_sr;
+    Rho rho;
+    float gscale;
+    float *gx;
+    double *loss_sum;
 };
 
 __global__ __launch_bounds__(256) void vote_fold_k(FoldArgs a) {
@@ -636,7 +689,8 @@ __global__ __launch_bounds__(FT_W *FT_H *FT_G) void vote_fold_lds_k(FoldArgs a, 
         nns[i] = a.nn[((size_t)(tby0 + by) * a.w_o + (tbx0 + bx)) * a.n1 + ii];
     }
     __syncthreads();
-    if (!inb) return;
+    float lacc = 0.f;
+    if (inb) {
     const int by_hi = min(a.h_o - 1, eta / a.stride), by_lo = max(0, (eta - a.ps + a.stride) / a.stride);
     const int bx_hi = min(a.w_o - 1, xi / a.stride), bx_lo = max(0, (xi - a.ps + a.stride) / a.stride);
     const int npatch = (by_hi - by_lo + 1) * (bx_hi - bx_lo + 1);
@@ -661,37 +715,28 @@ __global__ __launch_bounds__(FT_W *FT_H *FT_G) void vote_fold_lds_k(FoldArgs a, 
             cnt += npatch;
         }
         const float wgt = fmaxf((float)cnt, 1e-10f);                  // utils_vid.py:228
-        out[(size_t)tau * fs] = a.normalize ? s / wgt : s;
+        const float v = a.normalize ? s / wgt : s;
+        out[(size_t)tau * fs] = v;
         if (c == 0) wout[(size_t)tau * fs] = wgt;
+        if (a.x) {      // robust_lossfun(x - y2x) and its derivative while y2x is in a register (utils_vid.py:348)
+            const float e = a.x[(int64_t)c * a.x_sc + (int64_t)tau * a.x_st + (int64_t)eta * a.x_sr + xi] - v;
+            float f, g;
+            rho_fg(a.rho, e, f, g);
+            lacc += f;
+            a.gx[(size_t)c * cs + (size_t)tau * fs + (size_t)eta * a.W + xi] = g * a.gscale;
+        }
     }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// robust loss (utils_vid.py:10-26)
-struct Rho {
-    int kind;      // 0 mse, 1 abs, 2 log1p (rou==0), 3 quadratic (rou==2), 4 general
-    float scale, b, d, coef;
-};
-
-__device__ __forceinline__ float rho_f(const Rho &r, float e) {
-    switch (r.kind) {
-        case 0: return e * e;
-        case 1: return fabsf(e);
-        case 2: { float s = (e / r.scale); return log1pf(s * s * 0.5f); }
-        case 3: { float s = (e / r.scale); return 0.5f * s * s; }
-        default: { float s = (e / r.scale); s = s * s; return r.coef * (powf(s / r.b + 1.0f, 0.5f * r.d) - 1.0f) * (r.scale * 10.0f); }
     }
-}
-
-__device__ __forceinline__ float rho_g(const Rho &r, float e) {
-    switch (r.kind) {
-        case 0: return 2.0f * e;
-        case 1: return e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f);
-        case 2: { float s = e / r.scale; return (s / r.scale) / (1.0f + 0.5f * s * s); }
-        case 3: return e / (r.scale * r.scale);
-        default: {   // d/de (b/d)((s/b+1)^(d/2)-1)*10*scale, s=(e/scale)^2  ->  10*(e/scale)*(s/b+1)^(d/2-1)
-            float s = e / r.scale;
-            return 10.0f * s * powf(s * s / r.b + 1.0f, 0.5f * r.d - 1.0f);
+    if (a.x) {          // block sum of the loss -> one double atomic
+        __shared__ float red[FT_W * FT_H * FT_G / 64];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lacc += __shfl_down(lacc, off, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = lacc;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int i = 0; i < NT / 64; ++i) t += (double)red[i];
+            atomicAdd(a.loss_sum, t);
         }
     }
 }
@@ -799,8 +844,11 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
         dim3 tg((desc->W + 63) / 64, desc->H);
         hipLaunchKernelGGL(video_to_pixel_major_k, tg, dim3(256), 0, s, x, desc->x_sc, desc->x_st, desc->x_sr, a.TxU, a.TxP,
                            desc->H, desc->W, xt);
-        hipLaunchKernelGGL(video_to_pixel_major_k, tg, dim3(256), 0, s, y, desc->y_sc, desc->y_st, desc->y_sr, desc->Ty, a.TyP,
-                           desc->H, desc->W, yt);
+        // variant bit 8: the y half of the scratch still holds this y from the previous call (the captured video is constant
+        // over the iterations of the training loop; the caller keeps the scratch alive and vouches for it)
+        if (!(desc->variant & 0x100))
+            hipLaunchKernelGGL(video_to_pixel_major_k, tg, dim3(256), 0, s, y, desc->y_sc, desc->y_st, desc->y_sr, desc->Ty, a.TyP,
+                               desc->H, desc->W, yt);
         NN2Args b{};
         b.xt = xt; b.yt = yt; b.nn = nn; b.W = desc->W; b.ps = a.ps; b.pt = a.pt; b.stride = a.stride; b.stridet = a.stridet;
         b.h_o = a.h_o; b.w_o = a.w_o; b.n1 = a.n1; b.n2 = a.n2; b.TxP = a.TxP; b.TyP = a.TyP; b.K = a.K; b.KC = a.KC;
@@ -884,7 +932,7 @@ extern "C" int vl3d_vote_fold(const vl3d_loss_desc *desc, const float *y, const 
     if (desc->variant != 1 && lds <= 150 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
-            VL3D_HIP(hipFuncSetAttribute((const void *)vote_fold_lds_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            VL3D_HIP(hipFuncSetAttribute((const void *)vote_fold_lds_k, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
             attr_set = true;
         }
         dim3 grid((desc->W + FT_W - 1) / FT_W, (desc->H + FT_H - 1) / FT_H, 3);
@@ -893,6 +941,45 @@ extern "C" int vl3d_vote_fold(const vl3d_loss_desc *desc, const float *y, const 
         dim3 grid((desc->W + 63) / 64, (desc->H + 3) / 4, desc->Tx);
         hipLaunchKernelGGL(vote_fold_k, grid, dim3(256), 0, (hipStream_t)stream, a);
     }
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
+extern "C" int vl3d_vote_fold_robust(const vl3d_loss_desc *desc, const float *y, const int32_t *nn, const float *x, int32_t kind,
+                                     float rou, float scale, float *y2x, float *weight, float *grad_x, double *loss_sum,
+                                     vl3d_stream_t stream) {
+    int rc = check_loss(desc);
+    if (rc != VL3D_OK) return rc;
+    VL3D_REQUIRE(y && nn && x && y2x && weight && grad_x && loss_sum, "vl3d_vote_fold_robust: null pointer");
+    VL3D_REQUIRE(kind >= 0 && kind <= 2 && scale != 0.0f, "vl3d_vote_fold_robust: bad rho kind / scale");
+    VL3D_REQUIRE(desc->Tx <= 65535, "vl3d_vote_fold_robust: Tx > 65535");
+    FoldArgs a{};
+    a.y = y; a.nn = nn; a.sum = y2x; a.weight = weight;
+    a.Tx = desc->Tx; a.H = desc->H; a.W = desc->W; a.ps = desc->ps; a.pt = desc->pt;
+    a.stride = desc->stride; a.stridet = desc->stridet;
+    a.h_o = (desc->H - desc->ps) / desc->stride + 1;
+    a.w_o = (desc->W - desc->ps) / desc->stride + 1;
+    a.n1 = (desc->Tx - desc->pt) / desc->stridet + 1;
+    a.y_sc = desc->y_sc; a.y_st = desc->y_st; a.y_sr = desc->y_sr;
+    a.normalize = 1;
+    a.x = x; a.x_sc = desc->x_sc; a.x_st = desc->x_st; a.x_sr = desc->x_sr;
+    a.rho = make_rho(kind, rou, scale);
+    a.gscale = 1.0f / (3.0f * (float)desc->Tx * (float)desc->H * (float)desc->W);     // d(mean)/d(element)
+    a.gx = grad_x; a.loss_sum = loss_sum;
+    const int nby_max = (FT_H + desc->ps - 2) / desc->stride + 2, nbx_max = (FT_W + desc->ps - 2) / desc->stride + 2;
+    const size_t lds = ((size_t)desc->Ty * FT_W * FT_H + (size_t)nby_max * nbx_max * a.n1) * sizeof(float);
+    if (lds > 150 * 1024) {
+        vl3d_set_error("vl3d_vote_fold_robust: tile does not fit LDS; use vl3d_vote_fold + vl3d_robust_fwd/bwd");
+        return VL3D_EUNSUPPORTED;
+    }
+    VL3D_HIP(hipMemsetAsync(loss_sum, 0, sizeof(double), (hipStream_t)stream));
+    static bool attr_set = false;
+    if (!attr_set) {
+        VL3D_HIP(hipFuncSetAttribute((const void *)vote_fold_lds_k, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        attr_set = true;
+    }
+    dim3 grid((desc->W + FT_W - 1) / FT_W, (desc->H + FT_H - 1) / FT_H, 3);
+    hipLaunchKernelGGL(vote_fold_lds_k, grid, dim3(FT_W * FT_H * FT_G), lds, (hipStream_t)stream, a, desc->Ty);
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
 }

@@ -106,10 +106,34 @@ def find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha):
     nn = torch.empty((h_o, w_o, n1), dtype=torch.int32, device=xv.device)
     with torch.cuda.device(xv.device):
         nscratch = int(L.lib().vl3d_patchnn_scratch_bytes(desc))
-        scratch = torch.empty((nscratch + 3) // 4, dtype=torch.float32, device=xv.device) if nscratch > 0 else None
+        scratch, y_cached = _patchnn_scratch(nscratch, yv, desc, xv.device)
+        if y_cached:
+            desc.variant |= 0x100          # the y half of the scratch still holds this very y in pixel-major form
         L.check(L.lib().vl3d_patchnn(desc, L.ptr(xv), L.ptr(yv), L.ptr(nn), L.ptr(scratch), L.stream_ptr(xv.device)),
                 "vl3d_patchnn")
+        desc.variant &= ~0x100
     return nn, desc, xv, yv
+
+
+# One-entry cache of the NN kernel's scratch: y (the captured video) is the same tensor in every iteration of a loop over one
+# crop, so its pixel-major copy inside the scratch is reused while y's storage, version counter, view geometry and the loss
+# configuration are unchanged.  The cache holds a strong reference to that storage, so its address cannot be recycled for
+# other data while the entry is alive (one video's worth of memory stays pinned until the next different y arrives).
+# x (the render) changes every iteration and is always re-copied.
+_SCRATCH_CACHE = {"key": None, "buf": None, "storage": None}
+
+
+def _patchnn_scratch(nbytes, yv, desc, device):
+    if nbytes <= 0:
+        return None, False
+    st = yv.untyped_storage()
+    key = (st.data_ptr(), yv._version, yv.storage_offset(), tuple(yv.shape), tuple(yv.stride()), str(device), nbytes,
+           desc.Tx, desc.ps, desc.pt, desc.stride, desc.stridet, desc.variant & 0xff)
+    if _SCRATCH_CACHE["key"] == key:
+        return _SCRATCH_CACHE["buf"], True
+    buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+    _SCRATCH_CACHE.update(key=key, buf=buf, storage=st)
+    return buf, False
 
 
 def _nn_and_fold(x, y, patch_size, patcht_size, stride, stridet, alpha, normalize):
@@ -161,6 +185,49 @@ class _RobustMean(torch.autograd.Function):
         return gx, None, None, None
 
 
+class _FoldRobustMean(torch.autograd.Function):
+    """loss = robust_lossfun(x - fold(y, nn)/weight, rou, scaling).mean() in ONE pass over the video (vl3d_vote_fold_robust):
+    the NN search (no_grad in the reference, utils_vid.py:279,322), the vote-fold, the loss sum and d loss / d x.  Returns
+    (loss, y2x, weight); gradient flows to x only, through the loss."""
+
+    @staticmethod
+    def forward(ctx, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling):
+        nn, desc, xv, yv = find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha)
+        dev = xv.device
+        y2x = torch.empty((1, 3, desc.Tx, desc.H, desc.W), dtype=torch.float32, device=dev)
+        w = torch.empty((1, 1, desc.Tx, desc.H, desc.W), dtype=torch.float32, device=dev)
+        gx = torch.empty((1, 3, desc.Tx, desc.H, desc.W), dtype=torch.float32, device=dev)
+        acc = torch.empty((), dtype=torch.float64, device=dev)
+        kind, r = _rho_kind(rou)
+        with torch.cuda.device(dev):
+            L.check(L.lib().vl3d_vote_fold_robust(desc, L.ptr(yv), L.ptr(nn), L.ptr(xv), kind, r, float(scaling), L.ptr(y2x),
+                                                  L.ptr(w), L.ptr(gx), L.ptr(acc), L.stream_ptr(dev)), "vl3d_vote_fold_robust")
+        ctx.save_for_backward(gx)
+        ctx.x_shape = x.shape
+        ctx.mark_non_differentiable(y2x, w)
+        return (acc / gx.numel()).to(torch.float32), y2x, w
+
+    @staticmethod
+    def backward(ctx, g, _gy2x, _gw):
+        (gx,) = ctx.saved_tensors
+        return (gx * g.to(torch.float32)).reshape(ctx.x_shape), None, None, None, None, None, None, None, None
+
+
+def _gpnn_loss(holder, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling):
+    """NN search + vote-fold + robust mean, fused (one pass over the video for fold, loss and gradient); falls back to the
+    separate kernels when a fold tile does not fit LDS.  Caches y2x / weight on `holder` like the reference (utils_vid.py:345-346)."""
+    try:
+        loss, y2x, weight = _FoldRobustMean.apply(x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling)
+    except RuntimeError as e:
+        if "does not fit LDS" not in str(e):
+            raise
+        with torch.no_grad():
+            y2x, weight, _ = _nn_and_fold(x, y, patch_size, patcht_size, stride, stridet, alpha, normalize=True)
+        loss = _RobustMean.apply(x, y2x, rou, scaling)
+    holder.last_weight, holder.last_y2x = weight, y2x
+    return loss
+
+
 class Patch3DGPNNDirectLoss:
     """utils_vid.py:265-286."""
 
@@ -170,16 +237,11 @@ class Patch3DGPNNDirectLoss:
 
     def __call__(self, x, y, mask=None, same_input=False, rou=0, scaling=0.2, **kwargs):
         if same_input:
-            weight, y2x = self.last_weight, self.last_y2x
-        else:
-            with torch.no_grad():
-                cfg = dict(patch_size=7, patcht_size=7, stride=1, stridet=1, alpha=1e10)
-                cfg.update({k: v for k, v in kwargs.items() if k in cfg})
-                alpha = None if cfg["alpha"] > 100 else cfg["alpha"]
-                y2x, weight, _ = _nn_and_fold(x, y, cfg["patch_size"], cfg["patcht_size"], cfg["stride"],
-                                              cfg["stridet"], alpha, normalize=True)
-                self.last_weight, self.last_y2x = weight, y2x
-        return _RobustMean.apply(x, y2x, rou, scaling)
+            return _RobustMean.apply(x, self.last_y2x, rou, scaling)
+        cfg = dict(patch_size=7, patcht_size=7, stride=1, stridet=1, alpha=1e10)
+        cfg.update({k: v for k, v in kwargs.items() if k in cfg})
+        alpha = None if cfg["alpha"] > 100 else cfg["alpha"]
+        return _gpnn_loss(self, x, y, cfg["patch_size"], cfg["patcht_size"], cfg["stride"], cfg["stridet"], alpha, rou, scaling)
 
 
 class Patch3DGPNNLowMemLoss:
@@ -211,13 +273,11 @@ class Patch3DGPNNLowMemLoss:
             t = fit_patch(t, "frame_num", patcht_size, stridet)
             x = x[..., :t, :h, :w]
             y = y[..., :h, :w]
-            with torch.no_grad():
-                alpha = kwargs.get("alpha", 1e10)
-                alpha = None if alpha > 100 else alpha
-                if kwargs.get("dist_fn", "mse") != "mse":
-                    raise RuntimeError("dist_fn other than 'mse' is not settable in the reference")
-                y2x, weight, _ = _nn_and_fold(x, y, patch_size, patcht_size, stride, stridet, alpha, normalize=True)
-                self.last_weight, self.last_y2x = weight, y2x
+            alpha = kwargs.get("alpha", 1e10)
+            alpha = None if alpha > 100 else alpha
+            if kwargs.get("dist_fn", "mse") != "mse":
+                raise RuntimeError("dist_fn other than 'mse' is not settable in the reference")
+            return _gpnn_loss(self, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling)
         return _RobustMean.apply(x, y2x, rou, scaling)
 
 
