@@ -392,12 +392,15 @@ __global__ __launch_bounds__(NN_THREADS) void patchnn3_k(NN2Args a, int TyT) {
 // fixed costs over 4 locations; E lives in registers for the whole K loop (no LDS read-modify-write per chunk).
 constexpr int NL4 = 4;
 
+template <bool RUNSUM>
 __global__ __launch_bounds__(NN_THREADS) void patchnn4_k(NN2Args a, int H_unused, int groups_x) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int RWc = a.ps + (NL4 - 1) * a.stride;               // region width in pixels
     float *Xs = smem;                                           // [RWc*3][TxP]
     float *Ys = Xs + (size_t)RWc * 3 * a.TxP;                   // [RWc*3][TyP]
-    float *E = Ys + (size_t)RWc * 3 * a.TyP;                    // [TxP][TyP] (one location at a time, epilogue)
+    float *E = smem;                                            // [TxP][TyP], one location at a time in the epilogue: ALIASES the
+                                                                // staging buffers (dead by then) -> 35 KiB instead of 51 KiB of LDS
+                                                                // for the ref-view cfg = 4 workgroups per CU instead of 3
     float *colmin = E + (size_t)a.TxP * a.TyP;
     const int g = blockIdx.x, by = g / groups_x, bx0 = (g % groups_x) * NL4;
     const int r0 = by * a.stride, c0 = bx0 * a.stride, tid = threadIdx.x;
@@ -420,10 +423,24 @@ __global__ __launch_bounds__(NN_THREADS) void patchnn4_k(NN2Args a, int H_unused
         for (int i = tid; i < y4; i += NN_THREADS) reinterpret_cast<float4 *>(Ys)[i] = ysrc[i];
         __syncthreads();
         if (has_tile) {
-            for (int q = 0; q < cols; ++q) {
-                float C[TI * TJ];
+            // running sum R of the column energies along the row; location l's share of this row is R(window end) - R(before
+            // window start): 16 adds per column + two snapshots per location and row instead of 16 adds per (column, covering
+            // location).  R restarts every row, so the difference loses at most ~log2(23 columns) bits of a 24-bit sum.
+            float R[TI * TJ];
 #pragma unroll
-                for (int e = 0; e < TI * TJ; ++e) C[e] = 0.f;
+            for (int e = 0; e < TI * TJ; ++e) R[e] = 0.f;
+            for (int q = 0; q < cols; ++q) {
+                if constexpr (RUNSUM) {
+#pragma unroll
+                    for (int l = 0; l < NL4; ++l)
+                        if (q == l * a.stride) {               // window of location l starts at this column (uniform)
+#pragma unroll
+                            for (int e = 0; e < TI * TJ; ++e) acc[l][e] -= R[e];
+                        }
+                } else {                                       // few covering locations per column: plain per-column energy
+#pragma unroll
+                    for (int e = 0; e < TI * TJ; ++e) R[e] = 0.f;
+                }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float4 xv = *reinterpret_cast<const float4 *>(Xs + (q * 3 + c) * a.TxP + ti);
@@ -434,15 +451,24 @@ __global__ __launch_bounds__(NN_THREADS) void patchnn4_k(NN2Args a, int H_unused
 #pragma unroll
                         for (int j = 0; j < TJ; ++j) {
                             const float df = xa[i] - ya[j];
-                            C[i * TJ + j] = fmaf(df, df, C[i * TJ + j]);
+                            R[i * TJ + j] = fmaf(df, df, R[i * TJ + j]);
                         }
                 }
+                if constexpr (RUNSUM) {
 #pragma unroll
-                for (int l = 0; l < NL4; ++l) {
-                    const int ql = q - l * a.stride;           // column inside location l's window?
-                    if (ql >= 0 && ql < a.ps) {
+                    for (int l = 0; l < NL4; ++l)
+                        if (q == l * a.stride + a.ps - 1) {    // ... and ends at this one
 #pragma unroll
-                        for (int e = 0; e < TI * TJ; ++e) acc[l][e] += C[e];
+                            for (int e = 0; e < TI * TJ; ++e) acc[l][e] += R[e];
+                        }
+                } else {
+#pragma unroll
+                    for (int l = 0; l < NL4; ++l) {
+                        const int ql = q - l * a.stride;       // column inside location l's window?
+                        if (ql >= 0 && ql < a.ps) {
+#pragma unroll
+                            for (int e = 0; e < TI * TJ; ++e) acc[l][e] += R[e];
+                        }
                     }
                 }
             }
@@ -870,16 +896,22 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
         // v4 (4 locations per workgroup, column sums): default whenever one thread tile per frame-pair tile suffices
         const int ntiles4 = (a.TxP / TI) * (a.TyP / TJ);
         const int RWc4 = a.ps + (NL4 - 1) * a.stride;
-        const size_t lds4 = ((size_t)RWc4 * 3 * (a.TxP + a.TyP) + (size_t)a.TxP * a.TyP + a.n2) * sizeof(float);
+        const size_t stage4 = (size_t)RWc4 * 3 * (a.TxP + a.TyP), epi4 = (size_t)a.TxP * a.TyP + a.n2;   // the epilogue aliases the staging
+        const size_t lds4 = (stage4 > epi4 ? stage4 : epi4) * sizeof(float);
         const bool use_v4 = (pv == 0 || pv == 4) && ntiles4 <= NN_THREADS && lds4 <= 150 * 1024;
         if (use_v4) {
             static bool attr4 = false;
             if (!attr4) {
-                VL3D_HIP(hipFuncSetAttribute((const void *)patchnn4_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                VL3D_HIP(hipFuncSetAttribute((const void *)patchnn4_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                VL3D_HIP(hipFuncSetAttribute((const void *)patchnn4_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr4 = true;
             }
             const int groups_x = (a.w_o + NL4 - 1) / NL4;
-            hipLaunchKernelGGL(patchnn4_k, dim3((unsigned)(groups_x * a.h_o)), dim3(NN_THREADS), lds4, s, b, desc->H, groups_x);
+            // running sums pay when a column is shared by >= 2 locations on average (ps 11 / stride 4: 2.75; ps 3 / stride 2: 1.5)
+            if (a.ps >= 2 * a.stride)
+                hipLaunchKernelGGL(patchnn4_k<true>, dim3((unsigned)(groups_x * a.h_o)), dim3(NN_THREADS), lds4, s, b, desc->H, groups_x);
+            else
+                hipLaunchKernelGGL(patchnn4_k<false>, dim3((unsigned)(groups_x * a.h_o)), dim3(NN_THREADS), lds4, s, b, desc->H, groups_x);
         } else if (use_mf) {
             const size_t fixed3 = ((size_t)64 * TyT * 16 + a.n2 + 64 + TyT * 16) * sizeof(float);
             int kc3 = (int)((48 * 1024 > fixed3 + 16 * (a.TxP + a.TyP) * sizeof(float) ? 48 * 1024 - fixed3 : 16 * (a.TxP + a.TyP) * sizeof(float)) /
