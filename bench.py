@@ -270,6 +270,33 @@ def main():
                 del st1, gs1
             except Exception as e:
                 res["cfg2_single_frame"] = {"error": repr(e)}
+            try:    # tile culling (MPI.py:288-442): the same cfg3 render on a stack with ~20 % of its quads kept, with and without
+                    # the per-workgroup plane skipping (bit-identical results); in place on the resident stack, last use of it
+                from videoloop3d_amd import tiles
+                QH, QW = 35, 63                                     # configs/mpi_base.txt:14-15 (36 x 64 vertices)
+                qy, qx = torch.meshgrid(torch.arange(QH, device=dev), torch.arange(QW, device=dev), indexing="ij")
+                keep = torch.zeros((D, QH, QW), dtype=torch.bool, device=dev)
+                for d in range(D):                                  # one coherent blob per plane, ~20 % of its area
+                    cy, cx = (7 * d + 3) % QH, (11 * d + 5) % QW
+                    keep[d] = ((qy - cy).abs() <= QH // 5) & ((qx - cx).abs() <= QW // 4)
+                with torch.no_grad():
+                    tiles.cull_stack_(stack, keep)
+                times = {}
+                for name, qk in (("plain", None), ("culled", keep)):
+                    for it in range(6):
+                        if it == 2:
+                            torch.cuda.synchronize()
+                            t1 = time.perf_counter()
+                        r1, _ = render_planes(stack, homos_d, H, W, spec, quad_keep=qk)
+                        (gs1,) = torch.autograd.grad(r1, stack, g_rgb)
+                    torch.cuda.synchronize()
+                    times[name] = (time.perf_counter() - t1) / 4
+                    del r1, gs1
+                res["tile_culling"] = {"kept_quads": float(keep.float().mean()), "ms_plain": times["plain"] * 1e3,
+                                       "ms_culled": times["culled"] * 1e3, "value": T * H * W / times["culled"] / 1e6, "unit": "Mpix/s",
+                                       "workload": "cfg3 render fwd+bwd on a tile-culled stack (one blob of kept quads per plane), bit-identical outputs"}
+            except Exception as e:
+                res["tile_culling"] = {"error": repr(e)}
             try:    # end-to-end stage-2 iterations on the drop-in module (render crop + looping loss + fused regularisers + Adam)
                 stack = None
                 torch.cuda.empty_cache()

@@ -83,6 +83,24 @@ int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, const float
                     const float *grad_reg, const float *grad_alpha_sums, float *grad_stack, void *scratch,
                     int64_t scratch_bytes, vl3d_stream_t stream);
 
+/* Tile culling (MPI.py:288-442 "Tile Culling Algorithm": stage 2 renders only the quads that survived).  quad_keep is a device
+ * byte map [D][QH][QW] over the cells of each plane's vertex grid ((Ws-1)/QW x (Hs-1)/QH texels per quad), 1 = may be visible.
+ * PRECONDITION: every texel no kept quad can read (outside all kept quads' rectangles grown by one texel) has alpha exactly 0
+ * after activation (videoloop3d_amd/tiles.py writes the logit -1e4).  Under it the results are BIT-IDENTICAL to
+ * vl3d_render_fwd/bwd on the same stack: a workgroup walks only the planes whose footprint touches a kept quad (forward: a
+ * 64-bit plane mask per workgroup in SGPRs; backward: a flag in the tile's window record), the skipped planes would have
+ * contributed exactly 0, and the owned texels of skipped planes get their zero gradient written.  D <= 128.
+ * cull_scratch: vl3d_render_cull_scratch_bytes(desc) bytes (forward plan, rebuilt every call, no host sync); the backward
+ * keeps its plan in its own scratch. */
+int64_t vl3d_render_cull_scratch_bytes(const vl3d_render_desc *desc);
+int vl3d_render_fwd_culled(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep,
+                           int32_t QH, int32_t QW, void *cull_scratch, float *rgb, float *alpha, float *alpha_sums,
+                           vl3d_stream_t stream);
+int vl3d_render_bwd_culled(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep,
+                           int32_t QH, int32_t QW, const float *rgb, const float *alpha, const float *grad_rgb,
+                           const float *grad_alpha, const float *grad_reg, const float *grad_alpha_sums, float *grad_stack,
+                           void *scratch, int64_t scratch_bytes, vl3d_stream_t stream);
+
 /* Layer-space smoothness regularisers (MPV.py:517-531 rgb_smooth / a_smooth) WITHOUT the materialised [T,h,w,K,4] layer
  * tensor: sums[0..3] (device doubles, overwritten) = sum over frames, planes and neighbouring pixel pairs of
  * |L[p]-L[q]| for (x-pairs, rgb), (y-pairs, rgb), (x-pairs, alpha), (y-pairs, alpha), where L is the warped+activated

@@ -469,3 +469,35 @@ def test_bwd_tile_path_is_deterministic(dev, spec_name):
         assert _tile_ran() == 1
         outs.append(gs)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("spec_name", ["mpv", "utils_mpi"])
+@pytest.mark.parametrize("keep_frac", [0.0, 0.3, 1.0])
+def test_tile_culling_is_bit_identical(dev, spec_name, keep_frac):
+    """vl3d_render_fwd/bwd_culled (include/vl3d.h): on a stack whose culled texels have alpha exactly 0 (tiles.cull_stack_), skipping
+    the planes that touch no kept quad changes nothing -- forward outputs and the whole stack gradient are bitwise the same."""
+    from videoloop3d_amd import tiles
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    D, T, Hs, Ws, H, W = 7, 2, 150, 200, 139, 187
+    QH, QW = 6, 9
+    kw_p, _ = SPECS[spec_name]
+    torch.manual_seed(3)
+    keep = (torch.rand(D, QH, QW) < keep_frac).to(dev)
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=13, device=dev)
+    tiles.cull_stack_(stack, keep)
+    stack.requires_grad_(True)
+    th = math.radians(2.0)
+    Rz = torch.tensor([[math.cos(th) * 1.05, -math.sin(th), 3.0], [math.sin(th), math.cos(th) * 0.96, 2.5], [2e-5, -3e-5, 1.0]])
+    homos = (bench_homos(D, H, W, scale=1.5) @ Rz).to(dev)
+    g_rgb = (synth.hash_uniform((T, H, W, 3), seed=5) - 0.5).to(dev)
+    g_a = (synth.hash_uniform((T, H, W), seed=6) - 0.5).to(dev)
+    outs = []
+    for qk in (None, keep):
+        rgb, alpha = render_planes(stack, homos, H, W, RenderSpec(**kw_p), quad_keep=qk)
+        (gs,) = torch.autograd.grad([rgb, alpha], stack, [g_rgb, g_a])
+        assert _tile_ran() == 1
+        outs.append((rgb, alpha, gs))
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
+    if keep_frac == 0.0:
+        assert float(outs[1][1].abs().max()) == 0.0 and float(outs[1][2].abs().max()) == 0.0

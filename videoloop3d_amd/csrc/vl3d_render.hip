@@ -40,7 +40,27 @@ struct RenderArgs {
                          // then (bwd_windows_k) one int4 texel window per (tile, plane)
     const unsigned *owner;   // device scratch written by bwd_owner_table_k: per (plane, texel) owner tile << 10 | owner pixel's
                              // index in its tile's region
+    // tile culling (optional): quad_keep [D][QH][QW] bytes, 1 = the quad (cell of the plane's vertex grid) may be visible.
+    // cull_masks (forward): per 64x8-pixel workgroup two 64-bit words, bit d = plane d can contribute to the workgroup.
+    const unsigned char *quad_keep;
+    int QH, QW;
+    const unsigned long long *cull_masks;
 };
+
+// does the texel-space box [tnx,txx] x [tny,txy] (grown by 2 texels) touch a kept quad of plane d?  Quads are the QH x QW cells of
+// the plane's vertex grid, (Ws-1)/QW x (Hs-1)/QH texels each.  Conservative by construction: a workgroup skips a plane only
+// when every tap of every one of its pixels is a texel no kept quad can read, i.e. a culled texel whose alpha is exactly 0.
+__device__ __forceinline__ bool box_touches_kept_quad(const RenderArgs &a, int d, float tnx, float txx, float tny, float txy) {
+    if (!(txx >= -2.0f && tnx <= (float)a.Ws + 1.0f && txy >= -2.0f && tny <= (float)a.Hs + 1.0f)) return !(tnx == tnx && tny == tny);   // outside the plane (NaN: keep)
+    const float cw = (float)max(a.Ws - 1, 1) / (float)a.QW, ch = (float)max(a.Hs - 1, 1) / (float)a.QH;
+    const int qx0 = max(0, (int)floorf((tnx - 2.0f) / cw)), qx1 = min(a.QW - 1, (int)floorf((txx + 2.0f) / cw));
+    const int qy0 = max(0, (int)floorf((tny - 2.0f) / ch)), qy1 = min(a.QH - 1, (int)floorf((txy + 2.0f) / ch));
+    const unsigned char *k = a.quad_keep + (size_t)d * a.QH * a.QW;
+    for (int qy = qy0; qy <= qy1; ++qy)
+        for (int qx = qx0; qx <= qx1; ++qx)
+            if (k[qy * a.QW + qx]) return true;
+    return false;
+}
 
 // Uniform, read-only tables (homographies, plan records) are read through the constant address space: the loads become
 // s_load_* into SGPRs.  Through a generic pointer hipcc cannot prove them invariant across the gradient stores of the
@@ -273,7 +293,27 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool SWZ, bool F16>
+// forward plan of the tile culling: one thread per (64 x TY pixel workgroup, plane) projects the workgroup's corners and sets
+// the plane's bit when the footprint touches a kept quad.  Frame independent, once per call.
+template <int COORD>
+__global__ __launch_bounds__(256) void cull_fwd_plan_k(RenderArgs a, int TY, int tiles_x, int tiles_y, unsigned long long *masks) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= tiles_x * tiles_y * a.D) return;
+    const int d = i % a.D, tile = i / a.D, tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+    const int x0 = tile_x * 64, x1 = min(x0 + 63, a.W - 1), y0 = tile_y * TY, y1 = min(y0 + TY - 1, a.H - 1);
+    const float *h = a.homos + 9 * d;
+    float tnx = 1e30f, txx = -1e30f, tny = 1e30f, txy = -1e30f;
+    for (int c = 0; c < 4; ++c) {
+        const float cx = (float)a.col0 + a.pc + (float)((c & 1) ? x1 : x0), cy = (float)a.row0 + a.pc + (float)((c & 2) ? y1 : y0);
+        const float X = h[0] * cx + h[1] * cy + h[2], Y = h[3] * cx + h[4] * cy + h[5], Z = h[6] * cx + h[7] * cy + h[8];
+        const float ctx = texel_coord<COORD>(X / Z, (float)a.Ws / 2.0f, (float)(a.Ws - 1), a.sx, a.ox);
+        const float cty = texel_coord<COORD>(Y / Z, (float)a.Hs / 2.0f, (float)(a.Hs - 1), a.sy, a.oy);
+        tnx = fminf(tnx, ctx); txx = fmaxf(txx, ctx); tny = fminf(tny, cty); txy = fmaxf(txy, cty);
+    }
+    if (box_touches_kept_quad(a, d, tnx, txx, tny, txy)) atomicOr(masks + (size_t)tile * 2 + (d >> 6), 1ull << (d & 63));
+}
+
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool SWZ, bool F16, bool CULL = false>
 __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles_x, int tiles_y) {
     int b = blockIdx.x;
     if constexpr (SWZ) b = xcd_remap(b, gridDim.x);
@@ -287,11 +327,8 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
     const size_t plane_stride_b = (size_t)a.T * frame_b;
     const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * frame_b;
     float Tr = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, A = 0.f, n1 = 0.f, n2 = 0.f;
-    // two register sets (A/B) so the taps of plane d+1 are in flight while plane d is shaded, without register copies
-    Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy), tB = tA;
-    f4 vA[4], vB[4];
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
-    load_taps2<F16>(plane, tA, st, vA);
+    f4 vA[4], vB[4];
 #define VL3D_COMPOSITE(T_, V_)                                        \
     {                                                                 \
         const f4 o = shade2<ORDER, RACT, AACT>(T_, V_);               \
@@ -300,6 +337,45 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
         n1 += o.w; n2 = fmaf(o.w, o.w, n2);                           \
         Tr *= (1.0f - o.w);                                           \
     }
+    if constexpr (CULL) {
+        // tile culling: walk only the planes whose bit is set for this workgroup (two 64-bit words in SGPRs, scalar bit scans);
+        // the skipped planes' taps are all culled texels (alpha exactly 0), so the result is bit-identical to walking them
+        const unsigned long long *mk = a.cull_masks + (size_t)(tile_y * tiles_x + tile_x) * 2;
+        unsigned long long m0 = ((const __attribute__((address_space(4))) unsigned long long *)mk)[0];
+        unsigned long long m1 = ((const __attribute__((address_space(4))) unsigned long long *)mk)[1];
+        auto next = [&]() {
+            int d = -1;
+            if (m0) { d = __builtin_ctzll(m0); m0 &= m0 - 1; }
+            else if (m1) { d = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
+            return d;
+        };
+        auto fetch = [&](int d, Taps2 &t, f4 *v) {
+            float h[9];
+            load_uniform(a.homos + 9 * d, h);
+            t = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            load_taps2<F16>(plane + (size_t)d * plane_stride_b, t, st, v);
+            asm volatile("" ::: "memory");
+        };
+        int dA = next();
+        if (dA >= 0) {
+            Taps2 tA, tB;
+            fetch(dA, tA, vA);
+            for (;;) {
+                const int dB = next();
+                fetch(dB < 0 ? dA : dB, tB, vB);      // unconditional prefetch (re-reads the current plane past the end)
+                VL3D_COMPOSITE(tA, vA)
+                if (dB < 0) break;
+                const int dC = next();
+                fetch(dC < 0 ? dB : dC, tA, vA);
+                VL3D_COMPOSITE(tB, vB)
+                if (dC < 0) break;
+                dA = dC;
+            }
+        }
+    } else {
+    // two register sets (A/B) so the taps of plane d+1 are in flight while plane d is shaded, without register copies
+    Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy), tB = tA;
+    load_taps2<F16>(plane, tA, st, vA);
     // The prefetch of the next plane is unconditional (past the end it re-reads the last plane): with a branch around the
     // loads hipcc merges the two paths' counters and waits with vmcnt(0), i.e. for the taps it has just issued as well.
     for (int d = 0;; d += 2) {
@@ -324,6 +400,7 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
         VL3D_COMPOSITE(tB, vB)
         if (d + 2 >= a.D) break;
     }
+    }
 #undef VL3D_COMPOSITE
     const size_t pix = ((size_t)t * a.H + y) * a.W + x;
     a.rgb[pix * 3 + 0] = cr; a.rgb[pix * 3 + 1] = cg; a.rgb[pix * 3 + 2] = cb;
@@ -334,6 +411,15 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool SWZ, bool F16 = false>
 void launch_fwd2(const RenderArgs &a, hipStream_t s) {
     const int tiles_x = (a.W + 63) / 64, tiles_y = (a.H + TY - 1) / TY;
+    if (a.quad_keep && a.cull_masks) {       // tile culling: plan (frame independent), then the plane-list kernel
+        auto *masks = const_cast<unsigned long long *>(a.cull_masks);
+        (void)hipMemsetAsync(masks, 0, (size_t)tiles_x * tiles_y * 16, s);
+        const int n = tiles_x * tiles_y * a.D;
+        hipLaunchKernelGGL((cull_fwd_plan_k<COORD>), dim3((n + 255) / 256), dim3(256), 0, s, a, TY, tiles_x, tiles_y, masks);
+        hipLaunchKernelGGL((render_fwd2_k<COORD, BORDER, ORDER, RACT, AACT, TY, SWZ, F16, true>), dim3((unsigned)(tiles_x * tiles_y * a.T)),
+                           dim3(64 * TY), 0, s, a, tiles_x, tiles_y);
+        return;
+    }
     hipLaunchKernelGGL((render_fwd2_k<COORD, BORDER, ORDER, RACT, AACT, TY, SWZ, F16>), dim3((unsigned)(tiles_x * tiles_y * a.T)),
                        dim3(64 * TY), 0, s, a, tiles_x, tiles_y);
 }
@@ -426,7 +512,7 @@ __global__ void bwd_plan_k(RenderArgs a, int rows, float *plan) {
 // clamped border pixel, so only texels within the 1.4 px contribution range matter (1.6).  Frame independent: computed
 // once per call here instead of by wave 0 of every workgroup for every plane (90 VALU instructions on the barrier path).
 template <int COORD>
-__global__ __launch_bounds__(256) void bwd_windows_k(RenderArgs a, int iw, int ih, int tiles_x, int tiles_y, int *win) {
+__global__ __launch_bounds__(256) void bwd_windows_k(RenderArgs a, int iw, int ih, int rh, int tiles_x, int tiles_y, int *win) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= tiles_x * tiles_y * a.D) return;
     const int d = i % a.D, tile = i / a.D, tile_x = tile % tiles_x, tile_y = tile / tiles_x;
@@ -450,6 +536,21 @@ __global__ __launch_bounds__(256) void bwd_windows_k(RenderArgs a, int iw, int i
     int4 rec;
     const bool empty = ww == 0 || wh == 0;    // keep the corner a valid texel: the gather prefetches relative to it
     rec.x = empty ? 0 : wX0; rec.y = empty ? 0 : wY0; rec.z = empty ? 0 : (ww | (wh << 16)); rec.w = __float_as_int(1.0f / (float)max(ww, 1));
+    if (a.quad_keep) {
+        // tile culling: bit 31 of the size word = no pixel of the tile's region (interior + halo) can see a kept quad of this
+        // plane -> the tile kernel skips the plane's sweep and writes zeros to the texels it owns
+        const int qx0 = max(ix0 - rh, 0), qx1 = min(tile_x * iw + iw - 1 + rh, a.W - 1);
+        const int qy0 = max(iy0 - rh, 0), qy1 = min(tile_y * ih + ih - 1 + rh, a.H - 1);
+        float tnx = 1e30f, txx = -1e30f, tny = 1e30f, txy = -1e30f;
+        for (int c = 0; c < 4; ++c) {
+            const float cx = (float)a.col0 + a.pc + (float)((c & 1) ? qx1 : qx0), cy = (float)a.row0 + a.pc + (float)((c & 2) ? qy1 : qy0);
+            const float X = h[0] * cx + h[1] * cy + h[2], Y = h[3] * cx + h[4] * cy + h[5], Z = h[6] * cx + h[7] * cy + h[8];
+            const float ctx = texel_coord<COORD>(X / Z, (float)a.Ws / 2.0f, (float)(a.Ws - 1), a.sx, a.ox);
+            const float cty = texel_coord<COORD>(Y / Z, (float)a.Hs / 2.0f, (float)(a.Hs - 1), a.sy, a.oy);
+            tnx = fminf(tnx, ctx); txx = fmaxf(txx, ctx); tny = fminf(tny, cty); txy = fmaxf(txy, cty);
+        }
+        if (!box_touches_kept_quad(a, d, tnx, txx, tny, txy)) rec.z |= (int)0x80000000;
+    }
     reinterpret_cast<int4 *>(win)[i] = rec;     // [tile][plane]: one contiguous run per workgroup
 }
 
@@ -553,19 +654,37 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
     const unsigned my_tile = (unsigned)(tile_y * a.tiles_x + tile_x);
     const unsigned toff_thread = (unsigned)(row * a.Ws + lane);   // texel (lane, row) of a window, relative to its corner
     const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)my_tile * a.D * 4;
+    int nswept = 0;
     for (int d = 0; d < a.D; ++d, plane += plane_stride_b, gplane += plane_stride) {
         float h[9];
         load_uniform(a.homos + 9 * d, h);
-        const int buf = d & 1;
-        // texel window of this tile on plane d (wave = window row, lane = window column)
+        // texel window of this tile on plane d (wave = window row, lane = window column); bit 31: culled for this tile
         const int X0 = wrec[4 * d], Y0 = wrec[4 * d + 1], wwh = wrec[4 * d + 2];
-        const int ww = wwh & 0xffff, wh = wwh >> 16;
+        const int ww = wwh & 0xffff, wh = (wwh >> 16) & 0x7fff;
+        const bool culled = wwh < 0;
+        // staging buffer of this plane: alternates over the planes that are actually swept (a culled plane has no barrier)
+        const int buf = nswept & 1;
+        nswept += culled ? 0 : 1;
         const unsigned win0 = (unsigned)(Y0 * a.Ws + X0);          // frame texel index of the window's corner (uniform)
         const unsigned *oplane = a.owner + (size_t)d * a.Hs * a.Ws;
         // this thread's first owner-table entry, requested now so that it arrives in the shadow of the sweep.  Unconditional
         // (threads outside the window read a neighbouring entry -- the table is padded by ROWS rows -- and ignore it): no
         // branch around the load, so no merged wait counters.
         const unsigned e0 = oplane[win0 + toff_thread];
+        if (culled) {
+            // tile culling: no pixel of the region sees a kept quad of this plane -- its alpha is exactly 0 for all of them, the
+            // composite state does not move, and the texels this tile owns get a zero gradient (written: nothing memsets it)
+            const f4 z = f4{0.f, 0.f, 0.f, 0.f};
+            if (row < wh && lane < ww && (e0 >> 10) == my_tile)
+                __builtin_nontemporal_store(z, reinterpret_cast<f4 *>(reinterpret_cast<char *>(gplane) + (size_t)((win0 + toff_thread) << 4)));
+            for (int wy = row; wy < wh; wy += ROWS)
+                for (int wx = lane + (wy == row ? RW : 0); wx < ww; wx += RW) {
+                    const unsigned tix = win0 + (unsigned)(wy * a.Ws + wx);
+                    if ((oplane[tix] >> 10) == my_tile)
+                        __builtin_nontemporal_store(z, reinterpret_cast<f4 *>(reinterpret_cast<char *>(gplane) + (size_t)(tix << 4)));
+                }
+            continue;
+        }
         // (2) sample this pixel on plane d, composite backward, stage (tx,ty,g) in LDS   (branch-free taps)
         float2 tc = make_float2(-1e30f, -1e30f);
         float4 gval = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -717,7 +836,7 @@ void launch_tile(const RenderArgs &a, hipStream_t s) {
     RenderArgs b = a;
     b.tiles_x = (a.W + IW - 1) / IW; b.tiles_y = (a.H + IH - 1) / IH;
     const int nwin = b.tiles_x * b.tiles_y * a.D;
-    hipLaunchKernelGGL((bwd_windows_k<COORD>), dim3((nwin + 255) / 256), dim3(256), 0, s, b, IW, IH, b.tiles_x, b.tiles_y,
+    hipLaunchKernelGGL((bwd_windows_k<COORD>), dim3((nwin + 255) / 256), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x, b.tiles_y,
                        reinterpret_cast<int *>(const_cast<float *>(a.plan)) + plan_win_off(a.D));
     hipLaunchKernelGGL(bwd_owner_table_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x,
                        const_cast<unsigned *>(a.owner));
@@ -842,13 +961,30 @@ RenderArgs make_args(const vl3d_render_desc *d) {
 
 }  // namespace
 
-extern "C" int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos,
-                               float *rgb, float *alpha, float *alpha_sums, vl3d_stream_t stream) {
+static int check_cull(const vl3d_render_desc *desc, const uint8_t *quad_keep, int32_t QH, int32_t QW) {
+    if (!quad_keep) return VL3D_OK;
+    VL3D_REQUIRE(QH > 0 && QW > 0, "tile culling: non-positive quad grid");
+    VL3D_REQUIRE(desc->D <= 128, "tile culling supports at most 128 planes");
+    return VL3D_OK;
+}
+
+extern "C" int64_t vl3d_render_cull_scratch_bytes(const vl3d_render_desc *desc) {
+    if (!desc || desc->H <= 0 || desc->W <= 0) return 0;
+    // two 64-bit plane masks per forward workgroup, sized for the smallest workgroup any forward variant uses (64 x 4 pixels)
+    return (int64_t)((desc->W + 63) / 64) * ((desc->H + 3) / 4) * 16;
+}
+
+static int render_fwd_impl(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep, int32_t QH,
+                           int32_t QW, void *cull_scratch, float *rgb, float *alpha, float *alpha_sums, vl3d_stream_t stream) {
     int rc = check_desc(desc);
     if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE(stack && homos && rgb && alpha, "null pointer passed to vl3d_render_fwd");
+    rc = check_cull(desc, quad_keep, QH, QW);
+    if (rc != VL3D_OK) return rc;
+    VL3D_REQUIRE(!quad_keep || cull_scratch, "tile culling: the forward needs vl3d_render_cull_scratch_bytes() of scratch");
     RenderArgs a = make_args(desc);
     a.stack = (const float *)stack; a.homos = homos; a.rgb = rgb; a.alpha = alpha; a.asum = alpha_sums;
+    a.quad_keep = quad_keep; a.QH = QH; a.QW = QW; a.cull_masks = (const unsigned long long *)cull_scratch;
     a.fwd_variant = (desc->variant >> 8) & 0xf;
     a.ablate = (desc->variant >> 4) & 0xf;
     VL3D_REQUIRE((int64_t)desc->Hs * desc->Ws * 16 < (1ll << 32), "frame too large for 32-bit byte offsets");
@@ -858,6 +994,17 @@ extern "C" int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, 
     if (rc != VL3D_OK) return rc;
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
+}
+
+extern "C" int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos,
+                               float *rgb, float *alpha, float *alpha_sums, vl3d_stream_t stream) {
+    return render_fwd_impl(desc, stack, homos, nullptr, 0, 0, nullptr, rgb, alpha, alpha_sums, stream);
+}
+
+extern "C" int vl3d_render_fwd_culled(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep,
+                                      int32_t QH, int32_t QW, void *cull_scratch, float *rgb, float *alpha, float *alpha_sums,
+                                      vl3d_stream_t stream) {
+    return render_fwd_impl(desc, stack, homos, quad_keep, QH, QW, cull_scratch, rgb, alpha, alpha_sums, stream);
 }
 
 // scratch layout: per-plane records | one int4 window per (tile, plane), sized for the smallest tile interior any variant
@@ -893,17 +1040,41 @@ extern "C" int vl3d_render_reg_fwd(const vl3d_render_desc *desc, const void *sta
     return VL3D_OK;
 }
 
+static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep, int32_t QH,
+                           int32_t QW, const float *rgb, const float *alpha, const float *grad_rgb,
+                           const float *grad_alpha, const float *grad_reg, const float *grad_alpha_sums,
+                           float *grad_stack, void *scratch, int64_t scratch_bytes, vl3d_stream_t stream);
+
 extern "C" int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, const float *homos,
                                const float *rgb, const float *alpha, const float *grad_rgb,
                                const float *grad_alpha, const float *grad_reg, const float *grad_alpha_sums,
                                float *grad_stack, void *scratch, int64_t scratch_bytes, vl3d_stream_t stream) {
+    return render_bwd_impl(desc, stack, homos, nullptr, 0, 0, rgb, alpha, grad_rgb, grad_alpha, grad_reg, grad_alpha_sums, grad_stack,
+                           scratch, scratch_bytes, stream);
+}
+
+extern "C" int vl3d_render_bwd_culled(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep,
+                                      int32_t QH, int32_t QW, const float *rgb, const float *alpha, const float *grad_rgb,
+                                      const float *grad_alpha, const float *grad_reg, const float *grad_alpha_sums,
+                                      float *grad_stack, void *scratch, int64_t scratch_bytes, vl3d_stream_t stream) {
+    return render_bwd_impl(desc, stack, homos, quad_keep, QH, QW, rgb, alpha, grad_rgb, grad_alpha, grad_reg, grad_alpha_sums,
+                           grad_stack, scratch, scratch_bytes, stream);
+}
+
+static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep, int32_t QH,
+                           int32_t QW, const float *rgb, const float *alpha, const float *grad_rgb,
+                           const float *grad_alpha, const float *grad_reg, const float *grad_alpha_sums,
+                           float *grad_stack, void *scratch, int64_t scratch_bytes, vl3d_stream_t stream) {
     int rc = check_desc(desc);
+    if (rc != VL3D_OK) return rc;
+    rc = check_cull(desc, quad_keep, QH, QW);
     if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE(stack && homos && rgb && alpha && grad_rgb && grad_stack, "null pointer passed to vl3d_render_bwd");
     RenderArgs a = make_args(desc);
     a.stack = (const float *)stack; a.homos = homos;
     a.rgb = const_cast<float *>(rgb); a.alpha = const_cast<float *>(alpha);
     a.g_rgb = grad_rgb; a.g_alpha = grad_alpha; a.g_reg = grad_reg; a.g_asum = grad_alpha_sums; a.g_stack = grad_stack;
+    a.quad_keep = quad_keep; a.QH = QH; a.QW = QW;
     // variant: 0 auto (tile kernel when its on-device plan says feasible, else atomics), 1 force atomics,
     //          2 tile with 8-row regions, 3 tile with 16-row regions
     const bool want_tile = (desc->variant & 0xf) != 1 && scratch != nullptr && scratch_bytes >= vl3d_render_bwd_scratch_bytes(desc);

@@ -58,8 +58,15 @@ LAST_BWD_SCRATCH = None
 
 class _RenderPlanes(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, stack, homos, H, W, spec, row0, col0, with_reg):
+    def forward(ctx, stack, homos, H, W, spec, row0, col0, with_reg, quad_keep=None):
         L.check_cuda(stack, homos)
+        if quad_keep is not None:
+            L.check_cuda(quad_keep)
+            if quad_keep.dim() != 3 or quad_keep.shape[0] != stack.shape[0]:
+                raise RuntimeError(f"quad_keep must be [D,QH,QW] with D = {stack.shape[0]}, got {tuple(quad_keep.shape)}")
+            if with_reg:
+                raise RuntimeError("tile culling is not combined with the fused layer regularisers yet")
+            quad_keep = quad_keep.to(torch.uint8).contiguous()
         if stack.dtype not in (torch.float32, torch.float16):
             raise RuntimeError("plane stack must be float32 or float16 (arithmetic is fp32 either way)")
         stack = stack.contiguous()
@@ -72,9 +79,17 @@ class _RenderPlanes(torch.autograd.Function):
         desc = _desc(stack, H, W, spec, row0, col0)
         asum = torch.empty((T, H, W, 2), dtype=torch.float32, device=stack.device) if with_reg else None
         with torch.cuda.device(stack.device):
-            L.check(L.lib().vl3d_render_fwd(desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.ptr(asum),
-                                            L.stream_ptr(stack.device)), "vl3d_render_fwd")
+            if quad_keep is None:
+                L.check(L.lib().vl3d_render_fwd(desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.ptr(asum),
+                                                L.stream_ptr(stack.device)), "vl3d_render_fwd")
+            else:
+                ncull = int(L.lib().vl3d_render_cull_scratch_bytes(desc))
+                cull = torch.empty((ncull + 3) // 4, dtype=torch.float32, device=stack.device)
+                L.check(L.lib().vl3d_render_fwd_culled(desc, L.ptr(stack), L.ptr(homos), L.ptr(quad_keep), quad_keep.shape[1],
+                                                       quad_keep.shape[2], L.ptr(cull), L.ptr(rgb), L.ptr(alpha), L.ptr(asum),
+                                                       L.stream_ptr(stack.device)), "vl3d_render_fwd_culled")
         ctx.save_for_backward(stack, homos, rgb, alpha)
+        ctx.quad_keep = quad_keep
         ctx.desc = desc
         ctx.with_reg = with_reg
         sums = torch.zeros(4, dtype=torch.float64, device=stack.device)
@@ -99,21 +114,30 @@ class _RenderPlanes(torch.autograd.Function):
             # every word the kernels read is written by the plan kernels of the same call; only the header is cleared (flags)
             scratch = torch.empty((nscratch + 3) // 4, dtype=torch.float32, device=stack.device)
             scratch[:16].zero_()
-            L.check(L.lib().vl3d_render_bwd(ctx.desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha),
-                                            L.ptr(g_rgb), L.ptr(g_alpha), L.ptr(g_reg), L.ptr(g_asum), L.ptr(g_stack), L.ptr(scratch), nscratch,
-                                            L.stream_ptr(stack.device)), "vl3d_render_bwd")
+            qk = ctx.quad_keep
+            if qk is None:
+                L.check(L.lib().vl3d_render_bwd(ctx.desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha),
+                                                L.ptr(g_rgb), L.ptr(g_alpha), L.ptr(g_reg), L.ptr(g_asum), L.ptr(g_stack), L.ptr(scratch), nscratch,
+                                                L.stream_ptr(stack.device)), "vl3d_render_bwd")
+            else:
+                L.check(L.lib().vl3d_render_bwd_culled(ctx.desc, L.ptr(stack), L.ptr(homos), L.ptr(qk), qk.shape[1], qk.shape[2],
+                                                       L.ptr(rgb), L.ptr(alpha), L.ptr(g_rgb), L.ptr(g_alpha), L.ptr(g_reg), L.ptr(g_asum),
+                                                       L.ptr(g_stack), L.ptr(scratch), nscratch, L.stream_ptr(stack.device)),
+                        "vl3d_render_bwd_culled")
         global LAST_BWD_SCRATCH
         LAST_BWD_SCRATCH = scratch
-        return g_stack.to(stack.dtype), None, None, None, None, None, None, None
+        return g_stack.to(stack.dtype), None, None, None, None, None, None, None, None
 
 
-def render_planes(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0)):
+def render_planes(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0), quad_keep=None):
     """stack (D,T,Hs,Ws,4) pre-activation fp32 (plane 0 = nearest), homos [D,3,3] (target pixel -> plane pixel).
 
     Returns rgb [T,H,W,3], alpha [T,H,W].  `window=(row0,col0)` renders the H x W sub-window whose top-left
     corner is frame pixel (row0,col0) -- used for row-band sharding (equivalent to utils.py:196-200
-    get_new_intrin on the target intrinsics)."""
-    rgb, alpha, _, _ = _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), False)
+    get_new_intrin on the target intrinsics).
+    `quad_keep` [D,QH,QW] (bool/uint8, optional): tile culling map of a stack culled by videoloop3d_amd.tiles -- planes whose
+    footprint touches no kept quad are skipped per workgroup; bit-identical to the call without it (include/vl3d.h)."""
+    rgb, alpha, _, _ = _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), False, quad_keep)
     return rgb, alpha
 
 
