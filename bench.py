@@ -294,7 +294,7 @@ def main():
                     del r1, gs1
                 res["tile_culling"] = {"kept_quads": float(keep.float().mean()), "ms_plain": times["plain"] * 1e3,
                                        "ms_culled": times["culled"] * 1e3, "value": T * H * W / times["culled"] / 1e6, "unit": "Mpix/s",
-                                       "workload": "cfg3 render fwd+bwd on a tile-culled stack (one blob of kept quads per plane), bit-identical outputs"}
+                                       "workload": "cfg3 render fwd+bwd on a tile-culled stack (one blob of kept quads per plane): plain = without the quad map, culled = with it"}
             except Exception as e:
                 res["tile_culling"] = {"error": repr(e)}
             try:    # end-to-end stage-2 iterations on the drop-in module (render crop + looping loss + fused regularisers + Adam)

@@ -84,12 +84,12 @@ int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, const float
                     int64_t scratch_bytes, vl3d_stream_t stream);
 
 /* Tile culling (MPI.py:288-442 "Tile Culling Algorithm": stage 2 renders only the quads that survived).  quad_keep is a device
- * byte map [D][QH][QW] over the cells of each plane's vertex grid ((Ws-1)/QW x (Hs-1)/QH texels per quad), 1 = may be visible.
- * PRECONDITION: every texel no kept quad can read (outside all kept quads' rectangles grown by one texel) has alpha exactly 0
- * after activation (videoloop3d_amd/tiles.py writes the logit -1e4).  Under it the results are BIT-IDENTICAL to
- * vl3d_render_fwd/bwd on the same stack: a workgroup walks only the planes whose footprint touches a kept quad (forward: a
- * 64-bit plane mask per workgroup in SGPRs; backward: a flag in the tile's window record), the skipped planes would have
- * contributed exactly 0, and the owned texels of skipped planes get their zero gradient written.  D <= 128.
+ * byte map [D][QH][QW] over the cells of each plane's vertex grid ((Ws-1)/QW x (Hs-1)/QH texels per quad), 1 = the quad exists.
+ * A sample that falls into a culled quad of a plane is NOT COVERED by that plane (the reference's mesh has no face there):
+ * it contributes nothing and passes no gradient, whatever the texels hold; its layer value for the smoothness regularisers
+ * is 0 like any uncovered pixel (MPV.py:441).  On top of that rule, work is skipped where a whole workgroup sees no kept
+ * quad of a plane (forward: a 64-bit plane mask per workgroup walked with scalar bit scans; backward: a flag in the tile's
+ * window record -- no sweep, no barrier, zeros stored to the texels it owns), which changes no result.  D <= 128.
  * cull_scratch: vl3d_render_cull_scratch_bytes(desc) bytes (forward plan, rebuilt every call, no host sync); the backward
  * keeps its plan in its own scratch. */
 int64_t vl3d_render_cull_scratch_bytes(const vl3d_render_desc *desc);
@@ -108,6 +108,8 @@ int vl3d_render_bwd_culled(const vl3d_render_desc *desc, const void *stack, cons
  * grad_reg = device float[4] = dL/dsums (NULL: no regulariser term). */
 int vl3d_render_reg_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos, double *sums,
                         vl3d_stream_t stream);
+int vl3d_render_reg_fwd_culled(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep,
+                               int32_t QH, int32_t QW, double *sums, vl3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Unfused operators (drop-ins for the reference's L3 functions).

@@ -471,33 +471,62 @@ def test_bwd_tile_path_is_deterministic(dev, spec_name):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("spec_name", ["mpv", "utils_mpi"])
+@pytest.mark.parametrize("spec_name", ["mpv", "utils_mpi", "hardcut_pre"])
 @pytest.mark.parametrize("keep_frac", [0.0, 0.3, 1.0])
-def test_tile_culling_is_bit_identical(dev, spec_name, keep_frac):
-    """vl3d_render_fwd/bwd_culled (include/vl3d.h): on a stack whose culled texels have alpha exactly 0 (tiles.cull_stack_), skipping
-    the planes that touch no kept quad changes nothing -- forward outputs and the whole stack gradient are bitwise the same."""
+def test_tile_culling_matches_oracle(dev, spec_name, keep_frac):
+    """vl3d_render_fwd/bwd_culled (include/vl3d.h; MPI.py:288-442): samples in culled quads are uncovered -- outputs and the stack
+    gradient match the oracle's quad coverage, culled texels get exactly zero gradient, and a map that keeps everything is bitwise
+    the plain render."""
     from videoloop3d_amd import tiles
     from videoloop3d_amd.render import RenderSpec, render_planes
     D, T, Hs, Ws, H, W = 7, 2, 150, 200, 139, 187
     QH, QW = 6, 9
-    kw_p, _ = SPECS[spec_name]
+    kw_p, kw_o = SPECS[spec_name]
     torch.manual_seed(3)
-    keep = (torch.rand(D, QH, QW) < keep_frac).to(dev)
-    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=13, device=dev)
-    tiles.cull_stack_(stack, keep)
-    stack.requires_grad_(True)
+    keep = torch.rand(D, QH, QW) < keep_frac
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=13)
     th = math.radians(2.0)
     Rz = torch.tensor([[math.cos(th) * 1.05, -math.sin(th), 3.0], [math.sin(th), math.cos(th) * 0.96, 2.5], [2e-5, -3e-5, 1.0]])
-    homos = (bench_homos(D, H, W, scale=1.5) @ Rz).to(dev)
-    g_rgb = (synth.hash_uniform((T, H, W, 3), seed=5) - 0.5).to(dev)
-    g_a = (synth.hash_uniform((T, H, W), seed=6) - 0.5).to(dev)
-    outs = []
-    for qk in (None, keep):
-        rgb, alpha = render_planes(stack, homos, H, W, RenderSpec(**kw_p), quad_keep=qk)
-        (gs,) = torch.autograd.grad([rgb, alpha], stack, [g_rgb, g_a])
-        assert _tile_ran() == 1
-        outs.append((rgb, alpha, gs))
-    for a_, b_ in zip(*outs):
-        assert torch.equal(a_, b_)
-    if keep_frac == 0.0:
-        assert float(outs[1][1].abs().max()) == 0.0 and float(outs[1][2].abs().max()) == 0.0
+    homos = bench_homos(D, H, W, scale=1.5) @ Rz
+    g_rgb = synth.hash_uniform((T, H, W, 3), seed=5) - 0.5
+    g_a = synth.hash_uniform((T, H, W), seed=6) - 0.5
+    s_cpu = stack.clone().requires_grad_(True)
+    rgb_o, alpha_o, _ = MO.render_planes(s_cpu, homos, H, W, MO.RenderSpec(**kw_o), quad_keep=keep)
+    (gs_o,) = torch.autograd.grad([rgb_o, alpha_o], s_cpu, [g_rgb, g_a])
+    s_gpu = stack.to(dev).requires_grad_(True)
+    rgb, alpha = render_planes(s_gpu, homos.to(dev), H, W, RenderSpec(**kw_p), quad_keep=keep.to(dev))
+    (gs,) = torch.autograd.grad([rgb, alpha], s_gpu, [g_rgb.to(dev), g_a.to(dev)])
+    assert _tile_ran() == 1
+    assert maxabs(rgb, rgb_o) <= TOL and maxabs(alpha, alpha_o) <= TOL
+    assert maxabs(gs, gs_o) <= TOL * max(1.0, float(gs_o.abs().max()))
+    dead = ~tiles.quad_to_texel_mask(keep.to(dev), Hs, Ws)
+    assert float(gs[dead[:, None].expand(D, T, Hs, Ws)].abs().max() if dead.any() else 0.0) == 0.0
+    if keep_frac == 1.0:
+        rgb_p, alpha_p = render_planes(s_gpu, homos.to(dev), H, W, RenderSpec(**kw_p))
+        (gs_p,) = torch.autograd.grad([rgb_p, alpha_p], s_gpu, [g_rgb.to(dev), g_a.to(dev)])
+        assert torch.equal(rgb, rgb_p) and torch.equal(alpha, alpha_p) and torch.equal(gs, gs_p)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_tile_culling_with_regularisers_matches_oracle(dev, variant):
+    """culling + the fused layer regularisers (tile and atomics backward): culled samples have layer value 0 (MPV.py:441)."""
+    from videoloop3d_amd.render import RenderSpec, render_planes_with_regularisers
+    D, T, Hs, Ws, H, W = 5, 2, 90, 120, 83, 111
+    kw_p, kw_o = SPECS["mpv"]
+    torch.manual_seed(5)
+    keep = torch.rand(D, 4, 6) < 0.5
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=17)
+    homos = bench_homos(D, H, W, scale=1.2)
+    g_rgb = synth.hash_uniform((T, H, W, 3), seed=5) - 0.5
+    s_cpu = stack.clone().requires_grad_(True)
+    rgb_o, alpha_o, _, layers = MO.render_planes(s_cpu, homos, H, W, MO.RenderSpec(**kw_o), return_layers=True, quad_keep=keep)
+    sums_o = torch.stack([(layers[:, :, 1:, :, :3] - layers[:, :, :-1, :, :3]).abs().sum(), (layers[:, 1:, :, :, :3] - layers[:, :-1, :, :, :3]).abs().sum(),
+                          (layers[:, :, 1:, :, 3] - layers[:, :, :-1, :, 3]).abs().sum(), (layers[:, 1:, :, :, 3] - layers[:, :-1, :, :, 3]).abs().sum()])
+    wts = torch.tensor([1e-4, 2e-4, 3e-4, 4e-4])
+    (gs_o,) = torch.autograd.grad((rgb_o * g_rgb).sum() + (sums_o * wts).sum(), s_cpu)
+    s_gpu = stack.to(dev).requires_grad_(True)
+    rgb, alpha, sums, _ = render_planes_with_regularisers(s_gpu, homos.to(dev), H, W, RenderSpec(variant=variant, **kw_p), quad_keep=keep.to(dev))
+    (gs,) = torch.autograd.grad((rgb * g_rgb.to(dev)).sum() + (sums * wts.to(dev)).sum(), s_gpu)
+    assert maxabs(rgb, rgb_o) <= TOL
+    assert float(((sums.cpu() - sums_o).abs() / sums_o.abs().clamp_min(1.0)).max()) <= 1e-4
+    assert maxabs(gs, gs_o) <= TOL * max(1.0, float(gs_o.abs().max()))

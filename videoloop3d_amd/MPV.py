@@ -221,9 +221,10 @@ class MPMeshVid(nn.Module):
         homos = self.plane_homographies(extrin, intrin)
         smooth_sums = alpha_sums = None
         if need_smooth:
-            rgb, alpha, smooth_sums, alpha_sums = render_planes_with_regularisers(stack, homos, H, W, self.spec)
+            rgb, alpha, smooth_sums, alpha_sums = render_planes_with_regularisers(stack, homos, H, W, self.spec,
+                                                                                  quad_keep=self.quad_keep if self.is_sparse else None)
         else:
-            # a sparsified model renders with tile culling: planes that touch no kept quad are skipped per workgroup (bit-identical)
+            # a sparsified model renders with tile culling: samples in culled quads are uncovered, workgroups skip planes without kept quads
             rgb, alpha = render_planes(stack, homos, H, W, self.spec, quad_keep=self.quad_keep if self.is_sparse else None)
         variables = {"pix_to_face": None, "blend_weight": None, "mpi": None, "disp_norm": None, "alpha": alpha,
                      "smooth_sums": smooth_sums, "alpha_sums": alpha_sums}

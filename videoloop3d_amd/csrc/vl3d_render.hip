@@ -117,6 +117,18 @@ __device__ __forceinline__ float tent_weight(float d) {
     return w;
 }
 
+// Tile culling at sample level: a sample that falls into a culled quad of its plane is not covered (the reference's mesh has no
+// face there, MPI.py:288-442 / MPV.py:389-449) -- whatever the texels hold.  keep == nullptr: no culling.
+struct QuadCull {
+    const unsigned char *keep;   // [QH][QW] of THIS plane
+    int QH, QW;
+    float inv_cw, inv_ch;        // quads per texel along x / y: QW/(Ws-1), QH/(Hs-1)
+};
+__device__ __forceinline__ QuadCull plane_cull(const RenderArgs &a, int d) {
+    if (!a.quad_keep) return QuadCull{nullptr, 0, 0, 0.f, 0.f};
+    return QuadCull{a.quad_keep + (size_t)d * a.QH * a.QW, a.QH, a.QW, (float)a.QW / (float)max(a.Ws - 1, 1), (float)a.QH / (float)max(a.Hs - 1, 1)};
+}
+
 // integer form of the taps: base tap (x0,y0) with x0 <= Ws-2, y0 <= Hs-2 (so the 2x2 block is inside the plane) + weights
 struct TapsI {
     int x0, y0;
@@ -131,7 +143,7 @@ struct TapsI {
 // exactly grid_sample's zeros padding (utils_mpi.py:159-176) -- no per-tap validity selects, no per-tap address clamps.
 template <int COORD, int BORDER>
 __device__ __forceinline__ TapsI make_taps_i(const float *__restrict__ h, float px, float py, int Hs, int Ws,
-                                             float sx, float sy, float ox, float oy) {
+                                             float sx, float sy, float ox, float oy, QuadCull qc = QuadCull{nullptr, 0, 0, 0.f, 0.f}) {
     TapsI t;
     const f2 px2 = f2{px, px}, py2 = f2{py, py};
     const f2 XY = __builtin_elementwise_fma(f2{h[0], h[3]}, px2, __builtin_elementwise_fma(f2{h[1], h[4]}, py2, f2{h[2], h[5]}));
@@ -154,13 +166,17 @@ __device__ __forceinline__ TapsI make_taps_i(const float *__restrict__ h, float 
     } else {                                         // zeros padding: covered while any tap is inside, i.e. any weight > 0
         t.cov = ((t.w[0] + t.w[1]) + (t.w[2] + t.w[3]) > 0.0f) ? 1.0f : 0.0f;
     }
+    if (qc.keep) {      // uniform branch
+        const int qx = min(max((int)floorf(tx * qc.inv_cw), 0), qc.QW - 1), qy = min(max((int)floorf(ty * qc.inv_ch), 0), qc.QH - 1);
+        if (!qc.keep[qy * qc.QW + qx]) t.cov = 0.0f;
+    }
     return t;
 }
 
 template <int COORD, int BORDER>
 __device__ __forceinline__ Taps2 make_taps2(const float *__restrict__ h, float px, float py, int Hs, int Ws,
-                                            float sx, float sy, float ox, float oy) {
-    const TapsI ti = make_taps_i<COORD, BORDER>(h, px, py, Hs, Ws, sx, sy, ox, oy);
+                                            float sx, float sy, float ox, float oy, QuadCull qc = QuadCull{nullptr, 0, 0, 0.f, 0.f}) {
+    const TapsI ti = make_taps_i<COORD, BORDER>(h, px, py, Hs, Ws, sx, sy, ox, oy, qc);
     Taps2 t;
     t.w = ti.w;
     t.cov = ti.cov; t.tx = ti.tx; t.ty = ti.ty;
@@ -232,7 +248,7 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
     float Tr = 1.0f, P = 0.0f;
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws), gst = make_tap_step<false>(a.Hs, a.Ws);
     for (int d = 0; d < a.D; ++d, plane += (size_t)a.T * a.Hs * a.Ws * TEXB, gplane += plane_stride * 4) {
-        const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+        const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
         if (tp.cov == 0.0f) continue;
         f4 tv[4], pre;
         load_taps2<F16>(plane, tp, st, tv);
@@ -248,7 +264,7 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
         if (a.g_reg) {   // smoothness regularisers on the fallback path: re-sample the 4 neighbours' layer values
             const f4 gx = f4{a.g_reg[0], a.g_reg[0], a.g_reg[0], a.g_reg[2]}, gy = f4{a.g_reg[1], a.g_reg[1], a.g_reg[1], a.g_reg[3]};
             auto layer = [&](float qx, float qy) {
-                const Taps2 tq = make_taps2<COORD, BORDER>(a.homos + 9 * d, qx, qy, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+                const Taps2 tq = make_taps2<COORD, BORDER>(a.homos + 9 * d, qx, qy, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
                 f4 tq_v[4];
                 load_taps2<F16>(plane, tq, st, tq_v);
                 return shade2<ORDER, RACT, AACT>(tq, tq_v) * tq.cov;
@@ -352,7 +368,7 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
         auto fetch = [&](int d, Taps2 &t, f4 *v) {
             float h[9];
             load_uniform(a.homos + 9 * d, h);
-            t = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            t = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
             load_taps2<F16>(plane + (size_t)d * plane_stride_b, t, st, v);
             asm volatile("" ::: "memory");
         };
@@ -605,7 +621,7 @@ __global__ __launch_bounds__(256) void bwd_fill_zero_if_infeasible_k(float4 *g, 
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16, bool CULL = false>
 __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(RenderArgs a) {
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
     constexpr int NT = RW * ROWS;
@@ -661,17 +677,17 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
         // texel window of this tile on plane d (wave = window row, lane = window column); bit 31: culled for this tile
         const int X0 = wrec[4 * d], Y0 = wrec[4 * d + 1], wwh = wrec[4 * d + 2];
         const int ww = wwh & 0xffff, wh = (wwh >> 16) & 0x7fff;
-        const bool culled = wwh < 0;
+        const bool culled = CULL && wwh < 0;
         // staging buffer of this plane: alternates over the planes that are actually swept (a culled plane has no barrier)
-        const int buf = nswept & 1;
-        nswept += culled ? 0 : 1;
+        const int buf = CULL ? (nswept & 1) : (d & 1);
+        if constexpr (CULL) nswept += culled ? 0 : 1;
         const unsigned win0 = (unsigned)(Y0 * a.Ws + X0);          // frame texel index of the window's corner (uniform)
         const unsigned *oplane = a.owner + (size_t)d * a.Hs * a.Ws;
         // this thread's first owner-table entry, requested now so that it arrives in the shadow of the sweep.  Unconditional
         // (threads outside the window read a neighbouring entry -- the table is padded by ROWS rows -- and ignore it): no
         // branch around the load, so no merged wait counters.
         const unsigned e0 = oplane[win0 + toff_thread];
-        if (culled) {
+        if (CULL && culled) {
             // tile culling: no pixel of the region sees a kept quad of this plane -- its alpha is exactly 0 for all of them, the
             // composite state does not move, and the texels this tile owns get a zero gradient (written: nothing memsets it)
             const f4 z = f4{0.f, 0.f, 0.f, 0.f};
@@ -691,7 +707,8 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
         f4 o = f4{0.f, 0.f, 0.f, 0.f}, pre = o;
         Taps2 tp{};
         if (inimg) {
-            tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            if constexpr (CULL) tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
+            else tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
             const char *src = plane;
             if (a.ablate & 4) {   // measurement only: all taps from a 64 KiB cache-resident window
                 src = reinterpret_cast<const char *>(a.stack);
@@ -795,7 +812,7 @@ __global__ __launch_bounds__(RW *ROWS) void render_reg_fwd_k(RenderArgs a) {
     for (int d = 0; d < a.D; ++d, plane += plane_stride_b) {
         f4 ol = f4{0.f, 0.f, 0.f, 0.f};
         if (inimg) {
-            const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
             f4 tv[4];
             load_taps2<F16>(plane, tp, make_tap_step<F16>(a.Hs, a.Ws), tv);
             ol = shade2<ORDER, RACT, AACT>(tp, tv) * tp.cov;
@@ -840,8 +857,12 @@ void launch_tile(const RenderArgs &a, hipStream_t s) {
                        reinterpret_cast<int *>(const_cast<float *>(a.plan)) + plan_win_off(a.D));
     hipLaunchKernelGGL(bwd_owner_table_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x,
                        const_cast<unsigned *>(a.owner));
-    hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16>),
-                       dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
+    if (a.quad_keep)
+        hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16, true>),
+                           dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
+    else
+        hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16>),
+                           dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
 }
 
 // g_tile_rows: 0 = no tile path for this call, else the ROWS of the tile kernel to launch
@@ -1021,14 +1042,30 @@ extern "C" int64_t vl3d_render_bwd_scratch_bytes(const vl3d_render_desc *desc) {
     return owner_table_off(desc) + ((int64_t)desc->D * desc->Hs * desc->Ws + 16 * (int64_t)desc->Ws + 64) * 4;
 }
 
+static int render_reg_fwd_impl(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep, int32_t QH,
+                               int32_t QW, double *sums, vl3d_stream_t stream);
+
 extern "C" int vl3d_render_reg_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos, double *sums,
                                    vl3d_stream_t stream) {
+    return render_reg_fwd_impl(desc, stack, homos, nullptr, 0, 0, sums, stream);
+}
+
+extern "C" int vl3d_render_reg_fwd_culled(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep,
+                                          int32_t QH, int32_t QW, double *sums, vl3d_stream_t stream) {
+    return render_reg_fwd_impl(desc, stack, homos, quad_keep, QH, QW, sums, stream);
+}
+
+static int render_reg_fwd_impl(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep, int32_t QH,
+                               int32_t QW, double *sums, vl3d_stream_t stream) {
     int rc = check_desc(desc);
     if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE(stack && homos && sums, "null pointer passed to vl3d_render_reg_fwd");
+    rc = check_cull(desc, quad_keep, QH, QW);
+    if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE((int64_t)desc->Hs * desc->Ws * 16 < (1ll << 32), "frame too large for 32-bit byte offsets");
     RenderArgs a = make_args(desc);
     a.stack = (const float *)stack; a.homos = homos; a.reg_sums = sums;
+    a.quad_keep = quad_keep; a.QH = QH; a.QW = QW;
     VL3D_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(double), (hipStream_t)stream));
     g_reg_fwd = true;
     g_f16 = desc->stack_dtype == VL3D_F16;

@@ -64,8 +64,6 @@ class _RenderPlanes(torch.autograd.Function):
             L.check_cuda(quad_keep)
             if quad_keep.dim() != 3 or quad_keep.shape[0] != stack.shape[0]:
                 raise RuntimeError(f"quad_keep must be [D,QH,QW] with D = {stack.shape[0]}, got {tuple(quad_keep.shape)}")
-            if with_reg:
-                raise RuntimeError("tile culling is not combined with the fused layer regularisers yet")
             quad_keep = quad_keep.to(torch.uint8).contiguous()
         if stack.dtype not in (torch.float32, torch.float16):
             raise RuntimeError("plane stack must be float32 or float16 (arithmetic is fp32 either way)")
@@ -95,8 +93,13 @@ class _RenderPlanes(torch.autograd.Function):
         sums = torch.zeros(4, dtype=torch.float64, device=stack.device)
         if with_reg:
             with torch.cuda.device(stack.device):
-                L.check(L.lib().vl3d_render_reg_fwd(desc, L.ptr(stack), L.ptr(homos), L.ptr(sums), L.stream_ptr(stack.device)),
-                        "vl3d_render_reg_fwd")
+                if quad_keep is None:
+                    L.check(L.lib().vl3d_render_reg_fwd(desc, L.ptr(stack), L.ptr(homos), L.ptr(sums), L.stream_ptr(stack.device)),
+                            "vl3d_render_reg_fwd")
+                else:
+                    L.check(L.lib().vl3d_render_reg_fwd_culled(desc, L.ptr(stack), L.ptr(homos), L.ptr(quad_keep), quad_keep.shape[1],
+                                                               quad_keep.shape[2], L.ptr(sums), L.stream_ptr(stack.device)),
+                            "vl3d_render_reg_fwd_culled")
         if asum is None:
             asum = torch.zeros((0,), dtype=torch.float32, device=stack.device)
         return rgb, alpha, sums.to(torch.float32), asum
@@ -135,21 +138,21 @@ def render_planes(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0
     Returns rgb [T,H,W,3], alpha [T,H,W].  `window=(row0,col0)` renders the H x W sub-window whose top-left
     corner is frame pixel (row0,col0) -- used for row-band sharding (equivalent to utils.py:196-200
     get_new_intrin on the target intrinsics).
-    `quad_keep` [D,QH,QW] (bool/uint8, optional): tile culling map of a stack culled by videoloop3d_amd.tiles -- planes whose
-    footprint touches no kept quad are skipped per workgroup; bit-identical to the call without it (include/vl3d.h)."""
+    `quad_keep` [D,QH,QW] (bool/uint8, optional): tile culling map (videoloop3d_amd.tiles): a sample that falls into a culled quad
+    of a plane is not covered by it, and workgroups skip the planes of which they see no kept quad (include/vl3d.h)."""
     rgb, alpha, _, _ = _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), False, quad_keep)
     return rgb, alpha
 
 
-def render_planes_with_smoothness(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0)):
+def render_planes_with_smoothness(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0), quad_keep=None):
     """render_planes plus the raw sums of the layer-space smoothness regularisers (MPV.py:517-531), differentiable:
     returns (rgb, alpha, sums[4]) with sums = (sum|dx rgb|, sum|dy rgb|, sum|dx a|, sum|dy a|) over frames, planes and
     neighbouring pixel pairs of the warped+activated layers -- the [T,h,w,K,4] layer tensor is never materialised."""
-    rgb, alpha, sums, _ = _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), True)
+    rgb, alpha, sums, _ = _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), True, quad_keep)
     return rgb, alpha, sums
 
 
-def render_planes_with_regularisers(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0)):
+def render_planes_with_regularisers(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0), quad_keep=None):
     """(rgb, alpha, smooth_sums[4], alpha_sums[T,H,W,2]): render_planes_with_smoothness plus the per-pixel (sum_k a_k,
     sum_k a_k^2) the sparsity regulariser |a|_1/|a|_2 (MPV.py:511-515, MPI.py:599-603) is built from; all differentiable."""
-    return _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), True)
+    return _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), True, quad_keep)

@@ -5,14 +5,16 @@ The reference culls the quads (tiles) of its plane meshes whose alpha is negligi
 MPV.py:235-288 `init_from_mpi` -- and re-packs them into two atlases.  Here the texture stays the dense `(D,T,Hs,Ws,4)`
 stack (the layout the MI355X kernels stream), and the same three-way classification is carried as two small boolean quad
 maps `(D,QH,QW)`:
-  * culled quads: their texels get the alpha logit CULLED_ALPHA, so they render exactly nothing and receive no gradient
-    (sigmoid'(-1e4) == 0) -- the mesh of the reference simply has no face there;
+  * culled quads: the render kernels treat a sample that falls into one as NOT COVERED by that plane (`quad_keep` of
+    `render_planes`, include/vl3d.h "Tile culling") -- the mesh of the reference has no face there -- and skip, per workgroup,
+    the planes of which no kept quad is in sight.  Their texels additionally get the alpha logit CULLED_ALPHA, so code that
+    renders the stack without the map (evaluation scripts, the stage-1 model itself) sees them as transparent too;
   * static quads: the T copies of their texels are kept identical by summing their gradient over the frames
     (`tie_static_grad`): one shared texture with the summed gradient, as in the reference's static atlas;
   * dynamic quads: free per frame.
-The memory saving of the packed atlases is not reproduced (288 GB of HBM hold the dense stack); skipping culled tiles in
-the kernels is the next step.  Quads are the (mpi_h_verts-1) x (mpi_w_verts-1) cells of the vertex grid
-(utils_mpi.py:80-89), each covering [(q)*c, (q+1)*c] plane pixels with c = (mpi-1)/(verts-1).
+The memory saving of the packed atlases is not reproduced (288 GB of HBM hold the dense stack).  Quads are the
+(mpi_h_verts-1) x (mpi_w_verts-1) cells of the vertex grid (utils_mpi.py:80-89), each covering [(q)*c, (q+1)*c] plane pixels
+with c = (mpi-1)/(verts-1).
 """
 import torch
 import torch.nn.functional as F
