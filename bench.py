@@ -96,7 +96,7 @@ def loss_bench(dev, H, W, T, Ty, steps):
                 loss = lm(x, y, **cfg)
                 (gx,) = torch.autograd.grad(loss, x)
             torch.cuda.synchronize()
-        out[name] = {"iters_per_s": steps / (time.perf_counter() - t0), "loss": float(loss)}
+        out[name] = {"iters_per_s": steps / (time.perf_counter() - t0), "loss": float(loss.detach())}
     out["shape"] = f"x[1,3,{T + 2},{H},{W}] y[1,3,{Ty},{H},{W}]"
     return out
 
