@@ -4,26 +4,16 @@
 plain per-location temporal patch NN (alpha None), then mean |NN patch of tar - patch of src|, averaged per macro block
 and then over macro blocks (the reference's macro-block loop changes the result here -- it is a mean of block means --
 so the block structure of evaluations/NNMSE.py:31-58 is reproduced on the per-location errors)."""
-import warnings
-
 import numpy as np
 import torch
 
 from . import _lib as L
-from .utils_vid import find_nn_indices
+from .utils_vid import find_nn_indices, fit_patch
 
 
 def compute_nnerr(src, tar, patch_size=7, stride=2, patcht_size=7, stridet=2, macro_block=65):
     """evaluations/NNMSE.py:7-58.  src, tar: [1,3,f,h,w] on the MI355X -> python float."""
     t, h, w = src.shape[-3:]
-
-    def fit_patch(s_, name, p_, st_):
-        if (s_ - p_) % st_ != 0:
-            new_s_ = (s_ - p_) // st_ * st_ + p_
-            warnings.warn(f'{name} doesnot satisfy ({name} - patch_size) % stride == 0. '
-                          f'changing {name} from {s_} to {new_s_}')
-            return new_s_
-        return s_
 
     macro_block = fit_patch(macro_block, "macro_block", patch_size, stride)
     h = fit_patch(h, "patch_height", patch_size, stride)

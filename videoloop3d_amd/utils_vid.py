@@ -213,6 +213,15 @@ class _FoldRobustMean(torch.autograd.Function):
         return (gx * g.to(torch.float32)).reshape(ctx.x_shape), None, None, None, None, None, None, None, None
 
 
+def fit_patch(size, name, patch, step):
+    """Largest size' <= size with (size' - patch) % step == 0, warning with the reference's text when it trims
+    (utils_vid.py:307-313; evaluations/NNMSE.py uses the same rule)."""
+    trimmed = (size - patch) // step * step + patch
+    if trimmed != size:
+        warnings.warn(f'{name} doesnot satisfy ({name} - patch_size) % stride == 0. changing {name} from {size} to {trimmed}')
+    return trimmed
+
+
 def _gpnn_loss(holder, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling):
     """NN search + vote-fold + robust mean, fused (one pass over the video for fold, loss and gradient); falls back to the
     separate kernels when a fold tile does not fit LDS.  Caches y2x / weight on `holder` like the reference (utils_vid.py:345-346)."""
@@ -258,14 +267,6 @@ class Patch3DGPNNLowMemLoss:
             weight, y2x = self.last_weight, self.last_y2x
         else:
             t, h, w = x.shape[-3:]
-
-            def fit_patch(s_, name, p_, st_):
-                if (s_ - p_) % st_ != 0:
-                    new_s_ = (s_ - p_) // st_ * st_ + p_
-                    warnings.warn(f'{name} doesnot satisfy ({name} - patch_size) % stride == 0. '
-                                  f'changing {name} from {s_} to {new_s_}')
-                    return new_s_
-                return s_
 
             macro_block = fit_patch(macro_block, "macro_block", patch_size, stride)
             h = fit_patch(h, "patch_height", patch_size, stride)
