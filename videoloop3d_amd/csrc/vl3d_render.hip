@@ -38,8 +38,8 @@ struct RenderArgs {
     int ablate;          // measurement-only switches (bit0: skip LDS scatter, bit1: skip flush stores, bit2: skip tap loads)
     const float *plan;   // device scratch written by bwd_plan_k: [0] feasible flag, [16 + 12*d ..] inverse texel homographies,
                          // then (bwd_windows_k) one int4 texel window per (tile, plane)
-    const unsigned *owner;   // device scratch written by bwd_owner_table_k: per (plane, texel) owner tile << 10 | owner pixel's
-                             // index in its tile's region
+    const unsigned short *owner;   // device scratch written by bwd_owner_table_k: per (plane, texel) a 4-bit code of the owner
+                                   // tile (tile_y & 3, tile_x & 3) << 10 | the owner pixel's index in its tile's region
     // tile culling (optional): quad_keep [D][QH][QW] bytes, 1 = the quad (cell of the plane's vertex grid) may be visible.
     // cull_masks (forward): per 64x8-pixel workgroup two 64-bit words, bit d = plane d can contribute to the workgroup.
     const unsigned char *quad_keep;
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void bwd_zero_unowned_k(RenderArgs a) {
 // round(H_d^-1 tau))) and p0's index in that tile's pixel region, packed as tile << 10 | index.  Frame independent, so it
 // is built once per call (D*Hs*Ws entries) and read once per frame by the gather, which then needs no inverse homography,
 // reciprocal, rounding or range tests per texel (~200 of its ~400 VALU issue cycles, profiles/microbench/isa_cost.py).
-__global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, int ih, int rh, int tiles_x, unsigned *owner) {
+__global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, int ih, int rh, int tiles_x, unsigned short *owner) {
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -613,7 +613,9 @@ __global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, i
     const int ry = (int)fminf(fmaxf(rintf(qy), 0.0f), (float)(a.H - 1));
     const int tx = rx / iw, ty = ry / ih;
     const unsigned lc = (unsigned)((ry - ty * ih + rh) * RW + (rx - tx * iw + rh));
-    owner[((size_t)d * a.Hs + y) * a.Ws + x] = ((unsigned)(ty * tiles_x + tx) << 10) | lc;
+    // a tile's window only holds texels owned by itself or one of its 8 neighbours, which the two low bits of the tile
+    // coordinates tell apart: 14 bits per texel
+    owner[((size_t)d * a.Hs + y) * a.Ws + x] = (unsigned short)((((unsigned)(ty & 3) << 2 | (unsigned)(tx & 3)) << 10) | lc);
 }
 
 __global__ __launch_bounds__(256) void bwd_fill_zero_if_infeasible_k(float4 *g, size_t n, const float *plan) {
@@ -667,9 +669,10 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
     const bool provider = !REG || (lane >= 1 && lane <= RW - 2 && row >= 1 && row <= ROWS - 2);
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
     // this tile's texel windows, one int4 per plane (bwd_windows_k)
-    const unsigned my_tile = (unsigned)(tile_y * a.tiles_x + tile_x);
+    const unsigned my_tile_id = (unsigned)(tile_y * a.tiles_x + tile_x);
+    const unsigned my_tile = (unsigned)((tile_y & 3) << 2 | (tile_x & 3));      // the owner table's code of this tile
     const unsigned toff_thread = (unsigned)(row * a.Ws + lane);   // texel (lane, row) of a window, relative to its corner
-    const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)my_tile * a.D * 4;
+    const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)my_tile_id * a.D * 4;
     int nswept = 0;
     for (int d = 0; d < a.D; ++d, plane += plane_stride_b, gplane += plane_stride) {
         float h[9];
@@ -682,7 +685,7 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
         const int buf = CULL ? (nswept & 1) : (d & 1);
         if constexpr (CULL) nswept += culled ? 0 : 1;
         const unsigned win0 = (unsigned)(Y0 * a.Ws + X0);          // frame texel index of the window's corner (uniform)
-        const unsigned *oplane = a.owner + (size_t)d * a.Hs * a.Ws;
+        const unsigned short *oplane = a.owner + (size_t)d * a.Hs * a.Ws;
         // this thread's first owner-table entry, requested now so that it arrives in the shadow of the sweep.  Unconditional
         // (threads outside the window read a neighbouring entry -- the table is padded by ROWS rows -- and ignore it): no
         // branch around the load, so no merged wait counters.
@@ -856,7 +859,7 @@ void launch_tile(const RenderArgs &a, hipStream_t s) {
     hipLaunchKernelGGL((bwd_windows_k<COORD>), dim3((nwin + 255) / 256), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x, b.tiles_y,
                        reinterpret_cast<int *>(const_cast<float *>(a.plan)) + plan_win_off(a.D));
     hipLaunchKernelGGL(bwd_owner_table_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x,
-                       const_cast<unsigned *>(a.owner));
+                       const_cast<unsigned short *>(a.owner));
     if (a.quad_keep)
         hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16, true>),
                            dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
@@ -1029,7 +1032,7 @@ extern "C" int vl3d_render_fwd_culled(const vl3d_render_desc *desc, const void *
 }
 
 // scratch layout: per-plane records | one int4 window per (tile, plane), sized for the smallest tile interior any variant
-// uses (60 x 6) | (256-byte aligned) owner table, one uint32 per (plane, texel)
+// uses (60 x 6) | (256-byte aligned) owner table, one uint16 per (plane, texel)
 static int64_t owner_table_off(const vl3d_render_desc *desc) {
     const int64_t tiles = (int64_t)((desc->W + 59) / 60) * ((desc->H + 5) / 6);
     const int64_t b = (int64_t)plan_win_off(desc->D) * sizeof(float) + tiles * desc->D * 16;
@@ -1039,7 +1042,7 @@ static int64_t owner_table_off(const vl3d_render_desc *desc) {
 extern "C" int64_t vl3d_render_bwd_scratch_bytes(const vl3d_render_desc *desc) {
     if (!desc || desc->D <= 0 || desc->H <= 0 || desc->W <= 0) return 0;
     // + padding: the gather's unconditional prefetch reads up to 16 rows + 64 texels past a window's corner
-    return owner_table_off(desc) + ((int64_t)desc->D * desc->Hs * desc->Ws + 16 * (int64_t)desc->Ws + 64) * 4;
+    return owner_table_off(desc) + ((int64_t)desc->D * desc->Hs * desc->Ws + 16 * (int64_t)desc->Ws + 64) * 2;
 }
 
 static int render_reg_fwd_impl(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep, int32_t QH,
@@ -1118,7 +1121,7 @@ static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, cons
     a.ablate = (desc->variant >> 4) & 0xf;
     if (want_tile) {
         a.plan = (const float *)scratch;
-        a.owner = reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(scratch) + owner_table_off(desc));
+        a.owner = reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(scratch) + owner_table_off(desc));
         // variant & 0xf: 0/3 -> 16-row regions; 2 -> 8 rows.  (Prefetching the next plane's taps across the barrier was
         // measured and dropped: 91 VGPRs halve the occupancy, 24.3-28.9 ms vs 17.3 ms.)
         g_tile_rows = (desc->variant & 0xf) == 2 ? 8 : 16;
