@@ -725,9 +725,32 @@ __global__ __launch_bounds__(FT_W *FT_H *FT_G) void vote_fold_lds_k(FoldArgs a, 
     float *wout = a.weight + (size_t)eta * a.W + xi;
     const int *nn0 = nns + ((by_lo - tby0) * nbx + (bx_lo - tbx0)) * a.n1;
     const float *ysp = ys + pix;
-    for (int tau = grp; tau < a.Tx; tau += FT_G) {
+    // Each temporal group owns a contiguous run of frames.  With pt == 3 and stridet == 1 (every shipped configuration) the
+    // votes are accumulated patch-major: patch i votes for frames i, i+1, i+2, so its NN index is read from LDS ONCE and the
+    // three frame sums slide through registers (w0 = frame i, complete after patch i) -- a third of the index reads and of the
+    // address arithmetic of the frame-major form below, and the same summation order per frame (kt = 2, 1, 0 -> patches i-2, i-1, i).
+    const bool slide = (a.pt == 3 && a.stridet == 1);
+    const int chunk = (a.Tx + FT_G - 1) / FT_G, t0 = slide ? grp * chunk : grp, t1 = slide ? min(a.Tx, t0 + chunk) : a.Tx;
+    float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+    for (int tau = slide ? t0 - 2 : t0; tau < t1; tau += slide ? 1 : FT_G) {
         float s = 0.f;
         int cnt = 0;
+        if (slide) {
+            const int i = tau;                                     // patch index == first frame it votes for
+            if (i >= 0 && i < a.n1) {
+                const int *nrow = nn0 + i;
+                for (int by = by_lo; by <= by_hi; ++by, nrow += nbx * a.n1) {
+                    const int *np = nrow;
+                    for (int bx = bx_lo; bx <= bx_hi; ++bx, np += a.n1) {
+                        const float *yp = ysp + *np * NP;
+                        w0 += yp[0]; w1 += yp[NP]; w2 += yp[2 * NP];
+                    }
+                }
+            }
+            s = w0; w0 = w1; w1 = w2; w2 = 0.f;
+            if (tau < t0) continue;
+            cnt = npatch * (min(tau, a.n1 - 1) - max(tau - 2, 0) + 1);
+        } else {
         for (int kt = 0; kt < a.pt; ++kt) {
             const int ts = tau - kt;
             if (ts < 0 || (ts % a.stridet) != 0) continue;
@@ -739,6 +762,7 @@ __global__ __launch_bounds__(FT_W *FT_H *FT_G) void vote_fold_lds_k(FoldArgs a, 
                 for (int bx = bx_lo; bx <= bx_hi; ++bx, np += a.n1) s += ysp[(*np * a.stridet + kt) * NP];
             }
             cnt += npatch;
+        }
         }
         const float wgt = fmaxf((float)cnt, 1e-10f);                  // utils_vid.py:228
         const float v = a.normalize ? s / wgt : s;
