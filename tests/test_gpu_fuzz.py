@@ -1,0 +1,56 @@
+"""Randomised shapes / geometries / conventions of the fused render against the CPU oracle: small, odd and degenerate sizes
+(single-texel axes, one plane, windows), near-unit and far-from-unit scale (tile path and atomics fallback)."""
+import math
+
+import pytest
+import torch
+
+from oracle import mpi_oracle as MO
+from videoloop3d_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    import __graft_entry__ as g
+    g.build()
+    return torch.device("cuda:0")
+
+
+def _case(seed):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    u = lambda lo, hi: float(torch.rand(1, generator=g)) * (hi - lo) + lo
+    D, T = r(1, 5), r(1, 3)
+    Hs, Ws = (r(1, 3), r(1, 3)) if seed % 7 == 0 else (r(2, 90), r(2, 130))
+    H, W = r(1, 80), r(1, 140)
+    scale = u(0.6, 1.6) if seed % 3 else u(0.95, 1.05)
+    th = math.radians(u(-4, 4))
+    base = torch.tensor([[math.cos(th) * scale, -math.sin(th) * scale, u(-3, 3)], [math.sin(th) * scale, math.cos(th) * scale, u(-3, 3)],
+                         [u(-2e-4, 2e-4), u(-2e-4, 2e-4), 1.0]])
+    homos = torch.stack([base + torch.tensor([[0, 0, 0.7 * d], [0, 0, -0.4 * d], [0, 0, 0.0]]) for d in range(D)])
+    sx, sy = (Ws - 1) / max(W * scale, 1.0), (Hs - 1) / max(H * scale, 1.0)          # roughly map the frame onto the plane
+    homos = torch.diag(torch.tensor([max(sx, 1e-3) * scale, max(sy, 1e-3) * scale, 1.0])) @ homos if seed % 2 else homos
+    spec = [dict(), dict(pixel_center=0.5, coord_mode="affine", border="hardcut", act_order="post"),
+            dict(border="hardcut"), dict(pixel_center=0.5, coord_mode="affine", scale=(0.9, 1.1), offset=(0.3, -0.2), act_order="post")][seed % 4]
+    return D, T, Hs, Ws, H, W, homos, spec
+
+
+@pytest.mark.parametrize("seed", list(range(28)))
+def test_render_fuzz(dev, seed):
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    D, T, Hs, Ws, H, W, homos, kw = _case(seed)
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=100 + seed)
+    g_rgb = synth.hash_uniform((T, H, W, 3), seed=5) - 0.5
+    g_a = synth.hash_uniform((T, H, W), seed=6) - 0.5
+    s_cpu = stack.clone().requires_grad_(True)
+    rgb_o, alpha_o, _ = MO.render_planes(s_cpu, homos, H, W, MO.RenderSpec(**kw))
+    (gs_o,) = torch.autograd.grad([rgb_o, alpha_o], s_cpu, [g_rgb, g_a])
+    s_gpu = stack.to(dev).requires_grad_(True)
+    rgb, alpha = render_planes(s_gpu, homos.to(dev), H, W, RenderSpec(**kw))
+    (gs,) = torch.autograd.grad([rgb, alpha], s_gpu, [g_rgb.to(dev), g_a.to(dev)])
+    assert float((rgb.cpu() - rgb_o).abs().max()) <= TOL and float((alpha.cpu() - alpha_o).abs().max()) <= TOL
+    assert float((gs.cpu() - gs_o).abs().max()) <= TOL * max(1.0, float(gs_o.abs().max()))
