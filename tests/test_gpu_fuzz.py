@@ -54,3 +54,32 @@ def test_render_fuzz(dev, seed):
     (gs,) = torch.autograd.grad([rgb, alpha], s_gpu, [g_rgb.to(dev), g_a.to(dev)])
     assert float((rgb.cpu() - rgb_o).abs().max()) <= TOL and float((alpha.cpu() - alpha_o).abs().max()) <= TOL
     assert float((gs.cpu() - gs_o).abs().max()) <= TOL * max(1.0, float(gs_o.abs().max()))
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_loss_fuzz(dev, seed):
+    """fused NN + vote-fold + robust loss (vl3d_patchnn + vl3d_vote_fold_robust) against the oracle on random configurations:
+    y2x / weight / loss / gradient; NN ties are avoided by the hash-uniform inputs."""
+    from oracle import vid_oracle as VO
+    from videoloop3d_amd.utils_vid import Patch3DGPNNDirectLoss
+    g = torch.Generator().manual_seed(1000 + seed)
+    r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    ps, pt = [3, 5, 7, 11][seed % 4], [3, 3, 2, 4][seed % 4]
+    stride, stridet = r(1, 4), (1 if seed % 4 < 2 else r(1, 2))
+    h, w = ps + stride * r(1, 7), ps + stride * r(1, 9)
+    Tx, Ty = pt + stridet * r(0, 9), pt + stridet * r(0, 12)
+    rou, scaling = ["-2", "0", "2", "mse", "abs", "1"][seed % 6], [0.1, 0.2][seed % 2]
+    alpha = [1e10, 0.5][seed % 2]
+    x = synth.make_video(Tx, h, w, seed=3 + seed)
+    y = synth.make_video(Ty, h, w, seed=40 + seed)
+    xc = x.clone().requires_grad_(True)
+    loss_o, y2x_o, w_o = VO.gpnn_loss(xc, y, patch_size=ps, stride=stride, patcht_size=pt, stridet=stridet, rou=rou, scaling=scaling, alpha=alpha)
+    (gx_o,) = torch.autograd.grad(loss_o, xc)
+    xg = x.to(dev).requires_grad_(True)
+    L = Patch3DGPNNDirectLoss()
+    loss = L(xg, y.to(dev), patch_size=ps, stride=stride, patcht_size=pt, stridet=stridet, rou=rou, scaling=scaling, alpha=alpha)
+    (gx,) = torch.autograd.grad(loss, xg)
+    assert float((L.last_weight.cpu() - w_o).abs().max()) == 0.0
+    assert float((L.last_y2x.cpu() - y2x_o).abs().max()) <= 1e-5
+    assert abs(float(loss) - float(loss_o)) <= 1e-5 * max(1.0, abs(float(loss_o)))
+    assert float((gx.cpu() - gx_o).abs().max()) <= 1e-5 * max(1.0, float(gx_o.abs().max()))
