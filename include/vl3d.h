@@ -101,6 +101,13 @@ int vl3d_render_bwd_culled(const vl3d_render_desc *desc, const void *stack, cons
                            const float *grad_alpha, const float *grad_reg, const float *grad_alpha_sums, float *grad_stack,
                            void *scratch, int64_t scratch_bytes, vl3d_stream_t stream);
 
+/* Static tiles of a tile-culled VIDEO stack (MPV.py:235-288: one static atlas shared by all frames).  In place on the stack
+ * gradient (D,T,Hs,Ws,4): texels that only static quads can read get the sum over the T frames in every frame (the T copies
+ * then stay one texture under any optimiser), texels no kept quad can read get 0, texels a dynamic quad can read are left
+ * alone.  quad_keep / quad_dyn: device byte maps [D][QH][QW]. */
+int vl3d_tie_static_grad(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uint8_t *quad_keep, const uint8_t *quad_dyn,
+                         int32_t QH, int32_t QW, float *grad, vl3d_stream_t stream);
+
 /* Layer-space smoothness regularisers (MPV.py:517-531 rgb_smooth / a_smooth) WITHOUT the materialised [T,h,w,K,4] layer
  * tensor: sums[0..3] (device doubles, overwritten) = sum over frames, planes and neighbouring pixel pairs of
  * |L[p]-L[q]| for (x-pairs, rgb), (y-pairs, rgb), (x-pairs, alpha), (y-pairs, alpha), where L is the warped+activated

@@ -287,3 +287,17 @@ def test_sparsified_mpi_to_video_training(dev):
     assert not torch.equal(now[st], start[st])                                        # ... and they did learn
     dy = dyn_t[:, None, :, :, None].expand_as(now)
     assert not torch.equal(now[:, :1].expand_as(now)[dy], now[dy])                    # dynamic texels diverge between frames
+
+
+def test_tie_static_grad_kernel_matches_definition(dev):
+    """vl3d_tie_static_grad (in place, one kernel) == tiles.tie_static_grad (the rule in plain torch)."""
+    from videoloop3d_amd import tiles
+    torch.manual_seed(7)
+    for (D, T, Hs, Ws, QH, QW) in ((3, 4, 37, 53, 5, 7), (2, 1, 8, 9, 2, 2), (4, 5, 64, 130, 3, 11)):
+        keep = (torch.rand(D, QH, QW) < 0.6).to(dev)
+        dyn = keep & (torch.rand(D, QH, QW) < 0.5).to(dev)
+        g = torch.rand(D, T, Hs, Ws, 4, device=dev)
+        want = tiles.tie_static_grad(g.clone(), keep, dyn)
+        got = tiles.tie_static_grad_hip(g.clone(), keep, dyn)
+        assert float((got - want).abs().max()) <= 1e-6 * T
+        assert torch.equal(got == 0, want == 0)

@@ -145,7 +145,8 @@ class MPMeshVid(nn.Module):
             self._tie_hook = None
         if self.is_sparse and self.quad_keep is not None:
             from . import tiles
-            self._tie_hook = self.stack.register_hook(lambda g: tiles.tie_static_grad(g, self.quad_keep, self.quad_dyn))
+            tie = tiles.tie_static_grad_hip if self.stack.is_cuda else tiles.tie_static_grad     # (CPU: host-logic tests only)
+            self._tie_hook = self.stack.register_hook(lambda g: tie(g, self.quad_keep, self.quad_dyn))
 
     def state_dict(self, *args, **kwargs):
         """MPV.py:290-304: tensors + python scalars under "self.*" keys."""

@@ -95,9 +95,26 @@ def cull_stack_(stack, keep):
     return stack
 
 
+def tie_static_grad_hip(grad, keep, dyn):
+    """`tie_static_grad` as ONE in-place HIP kernel on the (fresh) gradient tensor of the stack -- the hook MPMeshVid installs
+    (vl3d_tie_static_grad): static texels read T frames and write T frames, dynamic texels are not touched."""
+    from . import _lib as L
+    L.check_cuda(grad, keep, dyn)
+    D, T, Hs, Ws, C4 = grad.shape
+    if C4 != 4 or grad.dtype != torch.float32:
+        raise RuntimeError("tie_static_grad_hip: gradient must be (D,T,Hs,Ws,4) float32")
+    g = grad if grad.is_contiguous() else grad.contiguous()
+    k8, d8 = keep.to(torch.uint8).contiguous(), dyn.to(torch.uint8).contiguous()
+    with torch.cuda.device(g.device):
+        L.check(L.lib().vl3d_tie_static_grad(D, T, Hs, Ws, L.ptr(k8), L.ptr(d8), keep.shape[1], keep.shape[2], L.ptr(g),
+                                             L.stream_ptr(g.device)), "vl3d_tie_static_grad")
+    return g
+
+
 def tie_static_grad(grad, keep, dyn):
-    """gradient of the dense stack (D,T,Hs,Ws,4) -> the gradient the reference's (static atlas, dynamic atlas) pair would
-    see: texels only static quads read get the SUM over frames in every frame's copy; culled texels get 0."""
+    """DEFINITION (plain torch, any device; used by the tests as the statement of the rule): gradient of the dense stack
+    (D,T,Hs,Ws,4) -> the gradient the reference's (static atlas, dynamic atlas) pair would see: texels only static quads
+    read get the SUM over frames in every frame's copy; culled texels get 0."""
     D, T, Hs, Ws, _ = grad.shape
     keep_t = quad_to_texel_mask(keep, Hs, Ws)
     dyn_t = quad_to_texel_mask(dyn, Hs, Ws)
