@@ -68,7 +68,43 @@ def run(iters=10, frames=50, planes=32, smooth=0.2, dev="cuda:0", crop=(180, 320
                 loss.backward()
                 opt.step()
             torch.cuda.synchronize()
-            out[name] = {"iters_per_s": iters / (time.perf_counter() - t0), "loss": float(loss)}
+            out[name] = {"iters_per_s": iters / (time.perf_counter() - t0), "loss": float(loss.detach())}
+        # the same iteration on a tile-culled model (what stage 2 sees after sparsify_faces, MPI.py:288-442): ~20 % of the quads kept,
+        # half of them dynamic; culled kernels + static tiles tied across frames (videoloop3d_amd/tiles.py)
+        from videoloop3d_amd import tiles
+        QH, QW = 35, 63
+        qy, qx = torch.meshgrid(torch.arange(QH, device=dev), torch.arange(QW, device=dev), indexing="ij")
+        keep = torch.zeros((planes, QH, QW), dtype=torch.bool, device=dev)
+        for d in range(planes):
+            cy, cx = (7 * d + 3) % QH, (11 * d + 5) % QW
+            keep[d] = ((qy - cy).abs() <= QH // 5) & ((qx - cx).abs() <= QW // 4)
+        model.register_buffer("quad_keep", keep)
+        model.register_buffer("quad_dyn", keep & ((qy + qx) % 2 == 0)[None])
+        model.is_sparse = model.has_dyn = True
+        with torch.no_grad():
+            tiles.cull_stack_(model.stack.data, keep)
+        model._install_tie_hook()
+        model.args.optimizer, model.args.lrate, model.args.lrate_decay = "adam", 0.5 * 0.01, 30
+        opt = model.get_optimizer(0)                       # TileAdam: the same Adam update on the kept texels only
+        cfg = cfgs["other"]
+        for it in range(iters + 2):
+            if it == 2:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            Kc = K.copy()
+            Kc[0, 2] -= 90 + (it % 3) * 40
+            Kc[1, 2] -= 45 + (it % 2) * 60
+            opt.zero_grad(set_to_none=True)
+            _, extra = model(h, w, tar_e, torch.tensor(Kc, device=dev)[None], res=res, losscfg=cfg)
+            loss = extra["swd"].sum()
+            for k in ("rgb_smooth", "a_smooth"):
+                if k in extra:
+                    loss = loss + smooth * extra[k].sum()
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        out["other_tile_culled"] = {"iters_per_s": iters / (time.perf_counter() - t0), "loss": float(loss.detach()),
+                                    "kept_quads": float(keep.float().mean())}
     out["shape"] = (f"D={planes} T={frames} stack {tuple(model.stack.shape)} crop {h}x{w} of {H}x{W}, Ty=75, "
                     f"smooth weights {smooth}, Adam")
     return out

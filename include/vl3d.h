@@ -108,6 +108,13 @@ int vl3d_render_bwd_culled(const vl3d_render_desc *desc, const void *stack, cons
 int vl3d_tie_static_grad(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uint8_t *quad_keep, const uint8_t *quad_dyn,
                          int32_t QH, int32_t QW, float *grad, vl3d_stream_t stream);
 
+/* torch.optim.Adam step (no amsgrad, no weight decay; MPV.py:199-214) on a stack parameter (D,T,Hs,Ws,4), in place on param /
+ * exp_avg / exp_avg_sq, restricted to the texels a kept quad can read (quad_keep NULL: all texels).  Culled texels have zero
+ * gradient and zero moments for ever, so skipping them is exact; `step` is the 1-based step count of this update. */
+int vl3d_adam_step_tiles(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uint8_t *quad_keep, int32_t QH, int32_t QW,
+                         float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float lr, float beta1, float beta2,
+                         float eps, int64_t step, vl3d_stream_t stream);
+
 /* Layer-space smoothness regularisers (MPV.py:517-531 rgb_smooth / a_smooth) WITHOUT the materialised [T,h,w,K,4] layer
  * tensor: sums[0..3] (device doubles, overwritten) = sum over frames, planes and neighbouring pixel pairs of
  * |L[p]-L[q]| for (x-pairs, rgb), (y-pairs, rgb), (x-pairs, alpha), (y-pairs, alpha), where L is the warped+activated

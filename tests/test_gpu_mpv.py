@@ -301,3 +301,29 @@ def test_tie_static_grad_kernel_matches_definition(dev):
         got = tiles.tie_static_grad_hip(g.clone(), keep, dyn)
         assert float((got - want).abs().max()) <= 1e-6 * T
         assert torch.equal(got == 0, want == 0)
+
+
+def test_tile_adam_matches_torch_adam(dev):
+    """TileAdam (vl3d_adam_step_tiles) == torch.optim.Adam on a tile-culled stack over several steps with changing lr; culled texels
+    (zero gradient) are not touched at all."""
+    from videoloop3d_amd import tiles
+    torch.manual_seed(11)
+    D, T, Hs, Ws, QH, QW = 3, 4, 37, 53, 5, 7
+    keep = (torch.rand(D, QH, QW) < 0.5).to(dev)
+    kt = tiles.quad_to_texel_mask(keep, Hs, Ws)[:, None, :, :, None].float()
+    p0 = torch.randn(D, T, Hs, Ws, 4, device=dev)
+    pa, pb = p0.clone().requires_grad_(True), p0.clone().requires_grad_(True)
+    oa = torch.optim.Adam([pa], lr=0.05, betas=(0.9, 0.999), eps=6e-8)
+    ob = tiles.TileAdam([pb], lr=0.05, betas=(0.9, 0.999), eps=6e-8, quad_keep=keep)
+    for it in range(5):
+        g = torch.randn_like(p0) * kt * (0.1 + it)
+        for o, p in ((oa, pa), (ob, pb)):
+            o.param_groups[0]["lr"] = 0.05 / (1 + it)
+            p.grad = g.clone()
+            o.step()
+        assert float((pa - pb).abs().max()) <= 2e-6
+    assert torch.equal(pb.detach() * (1 - kt), p0 * (1 - kt))
+    dense = tiles.TileAdam([p0.clone().requires_grad_(True)], lr=0.01, eps=6e-8)       # quad_keep None: every texel
+    dense.param_groups[0]["params"][0].grad = torch.ones_like(p0)
+    dense.step()
+    assert float((dense.param_groups[0]["params"][0] - (p0 - 0.01)).abs().max()) <= 1e-6

@@ -189,6 +189,10 @@ class MPMeshVid(nn.Module):
         (_, base_lr), _ = self.get_lrate(step)
         params = [{'params': [p for _, p in self.named_parameters()]}]
         if self.args.optimizer == 'adam':
+            if self.is_sparse and self.quad_keep is not None and self.stack.is_cuda:
+                # same update, restricted to the texels kept quads can read (culled texels never move under Adam)
+                from .tiles import TileAdam
+                return TileAdam(params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8, quad_keep=self.quad_keep)
             return torch.optim.Adam(params=params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8)
         if self.args.optimizer == 'sgd':
             return torch.optim.SGD(params=params, lr=base_lr, momentum=0.9)

@@ -122,3 +122,46 @@ def tie_static_grad(grad, keep, dyn):
     tied = grad.sum(dim=1, keepdim=True)
     out = torch.where(static_t, tied.expand_as(grad), grad)
     return out * keep_t[:, None, :, :, None].to(grad.dtype)
+
+
+class TileAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(betas, eps; no amsgrad / weight decay -- MPV.py:199-214) for plane-stack parameters (D,T,Hs,Ws,4) of a
+    tile-culled model: one HIP kernel per step that walks only the texels a kept quad can read (vl3d_adam_step_tiles).  Culled
+    texels never get a gradient, their moments stay zero and Adam would not move them, so the parameters after every step are
+    the ones torch.optim.Adam produces (to fp32 rounding of the fused update) while the 7 streams over the culled 80-95 % of the
+    stack disappear.  `quad_keep` may be replaced at any time through `.quad_keep` (None = dense)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, quad_keep=None):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.quad_keep = quad_keep
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import _lib as L
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        qk = None if self.quad_keep is None else self.quad_keep.to(torch.uint8).contiguous()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                L.check_cuda(p, p.grad)
+                if p.dim() != 5 or p.shape[-1] != 4 or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("TileAdam: parameters must be contiguous float32 plane stacks (D,T,Hs,Ws,4)")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                D, T, Hs, Ws, _ = p.shape
+                with torch.cuda.device(p.device):
+                    L.check(L.lib().vl3d_adam_step_tiles(D, T, Hs, Ws, L.ptr(qk), 0 if qk is None else qk.shape[1],
+                                                         0 if qk is None else qk.shape[2], L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]),
+                                                         L.ptr(st["exp_avg_sq"]), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                         st["step"], L.stream_ptr(p.device)), "vl3d_adam_step_tiles")
+        return loss
