@@ -32,7 +32,8 @@ def run(iters=10, frames=50, planes=32, smooth=0.2, dev="cuda:0", crop=(180, 320
         d_smooth_loss_weight=0.0)
     K = np.array([[0.9 * W, 0, W / 2], [0, 0.9 * W, H / 2], [0, 0, 1]], np.float64)
     model = MPMeshVid(args, H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
-    opt = torch.optim.Adam(model.parameters(), lr=0.5 * 0.01, eps=6e-8, fused=True)   # MPV.py:200-218 (Adam, eps 6e-8); one fused kernel
+    args.optimizer, args.lrate, args.lrate_decay = "adam", 0.5 * 0.01, 30
+    opt = model.get_optimizer(0)        # MPV.py:199-214 (Adam, betas (0.9, 0.999), eps 6e-8) as one HIP pass over (p, g, m, v)
     a = np.radians(0.5)
     tar = np.eye(4)
     tar[:3, :3] = [[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]
@@ -84,8 +85,7 @@ def run(iters=10, frames=50, planes=32, smooth=0.2, dev="cuda:0", crop=(180, 320
         with torch.no_grad():
             tiles.cull_stack_(model.stack.data, keep)
         model._install_tie_hook()
-        model.args.optimizer, model.args.lrate, model.args.lrate_decay = "adam", 0.5 * 0.01, 30
-        opt = model.get_optimizer(0)                       # TileAdam: the same Adam update on the kept texels only
+        opt = model.get_optimizer(0)                       # the same Adam update on the kept texels only
         cfg = cfgs["other"]
         for it in range(iters + 2):
             if it == 2:
