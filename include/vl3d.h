@@ -104,9 +104,10 @@ int vl3d_render_bwd_culled(const vl3d_render_desc *desc, const void *stack, cons
 /* Static tiles of a tile-culled VIDEO stack (MPV.py:235-288: one static atlas shared by all frames).  In place on the stack
  * gradient (D,T,Hs,Ws,4): texels that only static quads can read get the sum over the T frames in every frame (the T copies
  * then stay one texture under any optimiser), texels no kept quad can read get 0, texels a dynamic quad can read are left
- * alone.  quad_keep / quad_dyn: device byte maps [D][QH][QW]. */
+ * alone.  quad_keep / quad_dyn: device byte maps [D][QH][QW].  assume_culled_zero != 0: the gradient comes from the culled
+ * render (vl3d_render_bwd_culled), which leaves exactly 0 in culled texels -- they are not rewritten. */
 int vl3d_tie_static_grad(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uint8_t *quad_keep, const uint8_t *quad_dyn,
-                         int32_t QH, int32_t QW, float *grad, vl3d_stream_t stream);
+                         int32_t QH, int32_t QW, float *grad, int32_t assume_culled_zero, vl3d_stream_t stream);
 
 /* torch.optim.Adam step (no amsgrad, no weight decay; MPV.py:199-214) on a stack parameter (D,T,Hs,Ws,4), in place on param /
  * exp_avg / exp_avg_sq, restricted to the texels a kept quad can read (quad_keep NULL: all texels).  Culled texels have zero

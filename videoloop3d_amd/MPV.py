@@ -145,8 +145,11 @@ class MPMeshVid(nn.Module):
             self._tie_hook = None
         if self.is_sparse and self.quad_keep is not None:
             from . import tiles
-            tie = tiles.tie_static_grad_hip if self.stack.is_cuda else tiles.tie_static_grad     # (CPU: host-logic tests only)
-            self._tie_hook = self.stack.register_hook(lambda g: tie(g, self.quad_keep, self.quad_dyn))
+            if self.stack.is_cuda:    # the gradient comes from the culled render: culled texels already hold exact zeros
+                self._tie_hook = self.stack.register_hook(
+                    lambda g: tiles.tie_static_grad_hip(g, self.quad_keep, self.quad_dyn, assume_culled_zero=True))
+            else:                     # (CPU: host-logic tests only)
+                self._tie_hook = self.stack.register_hook(lambda g: tiles.tie_static_grad(g, self.quad_keep, self.quad_dyn))
 
     def state_dict(self, *args, **kwargs):
         """MPV.py:290-304: tensors + python scalars under "self.*" keys."""

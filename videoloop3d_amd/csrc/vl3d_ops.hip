@@ -299,7 +299,8 @@ extern "C" int vl3d_overcompose_nto0_bwd(int32_t B, int32_t D, int32_t C, int64_
 // can read -> 0; texels a dynamic quad can read -> untouched.  "Can read" = the quad's closed rectangle grown by one texel
 // (the bilinear taps of a sample inside it), as in videoloop3d_amd/tiles.py quad_to_texel_mask.
 __global__ __launch_bounds__(256) void tie_static_grad_k(int D, int T, int Hs, int Ws, const unsigned char *__restrict__ keep,
-                                                         const unsigned char *__restrict__ dyn, int QH, int QW, float4 *__restrict__ g) {
+                                                         const unsigned char *__restrict__ dyn, int QH, int QW, float4 *__restrict__ g,
+                                                         int assume_culled_zero) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), d = blockIdx.z;
     if (x >= Ws || y >= Hs) return;
     const double ch = (double)(Hs - 1) / QH, cw = (double)(Ws - 1) / QW;
@@ -308,24 +309,27 @@ __global__ __launch_bounds__(256) void tie_static_grad_k(int D, int T, int Hs, i
     const unsigned char *k = keep + (size_t)d * QH * QW, *m = dyn + (size_t)d * QH * QW;
     const bool kept = k[ylo * QW + xlo] | k[ylo * QW + xhi] | k[yhi * QW + xlo] | k[yhi * QW + xhi];
     const bool dynamic = m[ylo * QW + xlo] | m[ylo * QW + xhi] | m[yhi * QW + xlo] | m[yhi * QW + xhi];
-    if (kept && dynamic) return;
+    if (dynamic && kept) return;
     const size_t frame = (size_t)Hs * Ws;
     float4 *p = g + (size_t)d * T * frame + (size_t)y * Ws + x;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (kept)
+    if (!kept) {
+        if (assume_culled_zero) return;      // the culled render never writes anything but 0 there
+    } else {
         for (int t = 0; t < T; ++t) {
             const float4 v = p[(size_t)t * frame];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
+    }
     for (int t = 0; t < T; ++t) p[(size_t)t * frame] = s;
 }
 
 extern "C" int vl3d_tie_static_grad(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uint8_t *quad_keep, const uint8_t *quad_dyn,
-                                    int32_t QH, int32_t QW, float *grad, vl3d_stream_t stream) {
+                                    int32_t QH, int32_t QW, float *grad, int32_t assume_culled_zero, vl3d_stream_t stream) {
     VL3D_REQUIRE(D > 0 && T > 0 && Hs > 0 && Ws > 0 && QH > 0 && QW > 0 && D <= 65535, "vl3d_tie_static_grad: bad dims");
     VL3D_REQUIRE(quad_keep && quad_dyn && grad, "vl3d_tie_static_grad: null pointer");
     hipLaunchKernelGGL(tie_static_grad_k, dim3((Ws + 63) / 64, (Hs + 3) / 4, D), dim3(256), 0, (hipStream_t)stream, D, T, Hs, Ws, quad_keep,
-                       quad_dyn, QH, QW, reinterpret_cast<float4 *>(grad));
+                       quad_dyn, QH, QW, reinterpret_cast<float4 *>(grad), assume_culled_zero);
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
 }

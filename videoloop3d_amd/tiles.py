@@ -95,7 +95,7 @@ def cull_stack_(stack, keep):
     return stack
 
 
-def tie_static_grad_hip(grad, keep, dyn):
+def tie_static_grad_hip(grad, keep, dyn, assume_culled_zero=False):
     """`tie_static_grad` as ONE in-place HIP kernel on the (fresh) gradient tensor of the stack -- the hook MPMeshVid installs
     (vl3d_tie_static_grad): static texels read T frames and write T frames, dynamic texels are not touched."""
     from . import _lib as L
@@ -107,7 +107,7 @@ def tie_static_grad_hip(grad, keep, dyn):
     k8, d8 = keep.to(torch.uint8).contiguous(), dyn.to(torch.uint8).contiguous()
     with torch.cuda.device(g.device):
         L.check(L.lib().vl3d_tie_static_grad(D, T, Hs, Ws, L.ptr(k8), L.ptr(d8), keep.shape[1], keep.shape[2], L.ptr(g),
-                                             L.stream_ptr(g.device)), "vl3d_tie_static_grad")
+                                             1 if assume_culled_zero else 0, L.stream_ptr(g.device)), "vl3d_tie_static_grad")
     return g
 
 
