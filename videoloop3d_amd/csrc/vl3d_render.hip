@@ -609,9 +609,10 @@ __global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, i
     float qx, qy;
     owner_pixel(a.plan + PLAN_HDR + PLAN_REC * d, (float)x, (float)y, a.pc, a.col0, a.row0, qx, qy);
     // owner = nearest FRAME pixel: texels just outside the frame still collect taps of the border pixels
-    const int rx = (int)fminf(fmaxf(rintf(qx), 0.0f), (float)(a.W - 1));
-    const int ry = (int)fminf(fmaxf(rintf(qy), 0.0f), (float)(a.H - 1));
-    const int tx = rx / iw, ty = ry / ih;
+    const float rxf = fminf(fmaxf(rintf(qx), 0.0f), (float)(a.W - 1)), ryf = fminf(fmaxf(rintf(qy), 0.0f), (float)(a.H - 1));
+    const int rx = (int)rxf, ry = (int)ryf;
+    // tile of the owner pixel: floor((r + 0.5) / size) in fp32 is exact for frame coordinates (< 2^22) -- no integer division
+    const int tx = (int)((rxf + 0.5f) * (1.0f / (float)iw)), ty = (int)((ryf + 0.5f) * (1.0f / (float)ih));
     const unsigned lc = (unsigned)((ry - ty * ih + rh) * RW + (rx - tx * iw + rh));
     // a tile's window only holds texels owned by itself or one of its 8 neighbours, which the two low bits of the tile
     // coordinates tell apart: 14 bits per texel
