@@ -813,7 +813,30 @@ __global__ __launch_bounds__(RW *ROWS) void render_reg_fwd_k(RenderArgs a) {
     const size_t frame_b = (size_t)a.Hs * a.Ws * (F16 ? 8 : 16), plane_stride_b = (size_t)a.T * frame_b;
     const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * frame_b;
     float sxc = 0.f, syc = 0.f, sxa = 0.f, sya = 0.f;
+    // tile culling: the workgroup builds its own plane mask (thread d projects the region's corners onto plane d and tests the
+    // touched quads) and walks only the set bits; a skipped plane has layer value 0 everywhere in the region, i.e. adds nothing
+    __shared__ unsigned long long s_mask[2];
+    if (a.quad_keep) {
+        if (tid < 2) s_mask[tid] = 0ull;
+        __syncthreads();
+        if (tid < a.D) {
+            const int x0 = blockIdx.x * (RW - 1), x1 = min(x0 + RW - 1, a.W - 1), y0 = blockIdx.y * (ROWS - 1), y1 = min(y0 + ROWS - 1, a.H - 1);
+            const float *h = a.homos + 9 * tid;
+            float tnx = 1e30f, txx = -1e30f, tny = 1e30f, txy = -1e30f;
+            for (int c = 0; c < 4; ++c) {
+                const float cx = (float)a.col0 + a.pc + (float)((c & 1) ? x1 : x0), cy = (float)a.row0 + a.pc + (float)((c & 2) ? y1 : y0);
+                const float X = h[0] * cx + h[1] * cy + h[2], Y = h[3] * cx + h[4] * cy + h[5], Z = h[6] * cx + h[7] * cy + h[8];
+                const float ctx = texel_coord<COORD>(X / Z, (float)a.Ws / 2.0f, (float)(a.Ws - 1), a.sx, a.ox);
+                const float cty = texel_coord<COORD>(Y / Z, (float)a.Hs / 2.0f, (float)(a.Hs - 1), a.sy, a.oy);
+                tnx = fminf(tnx, ctx); txx = fmaxf(txx, ctx); tny = fminf(tny, cty); txy = fmaxf(txy, cty);
+            }
+            if (box_touches_kept_quad(a, tid, tnx, txx, tny, txy)) atomicOr(&s_mask[tid >> 6], 1ull << (tid & 63));
+        }
+        __syncthreads();
+    }
+    int nact = 0;
     for (int d = 0; d < a.D; ++d, plane += plane_stride_b) {
+        if (a.quad_keep && !((s_mask[d >> 6] >> (d & 63)) & 1ull)) continue;      // uniform
         f4 ol = f4{0.f, 0.f, 0.f, 0.f};
         if (inimg) {
             const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
@@ -821,7 +844,7 @@ __global__ __launch_bounds__(RW *ROWS) void render_reg_fwd_k(RenderArgs a) {
             load_taps2<F16>(plane, tp, make_tap_step<F16>(a.Hs, a.Ws), tv);
             ol = shade2<ORDER, RACT, AACT>(tp, tv) * tp.cov;
         }
-        const int buf = d & 1;
+        const int buf = (nact++) & 1;        // alternates over the planes actually walked (a skipped plane has no barrier)
         s_o[buf][tid] = make_float4(ol.x, ol.y, ol.z, ol.w);
         __syncthreads();
         if (own_r) {
