@@ -224,9 +224,19 @@ def test_stage2_driver_trains(dev):
     cfg = {"loss_name": "gpnn_lm", "patch_size": 3, "patcht_size": 3, "stride": 2, "stridet": 1, "alpha": 10000,
            "rou": "-2", "scaling": 0.1, "dist_fn": "mse", "macro_block": 65, "factor": 1}
     log = []
+    import tempfile, os
+    save_dir = tempfile.mkdtemp()
+    args.i_weights = 2
     n = drv.train(model, args, vids, poses, intr, [cfg, dict(cfg, loss_gain=2.0)], H, W, device=dev,
                   on_step=lambda lvl, ep, it, loss, swd, extra: log.append((lvl, float(loss), sorted(extra))),
-                  generator=torch.Generator().manual_seed(1))
+                  generator=torch.Generator().manual_seed(1), save_dir=save_dir)
+    # checkpoints every 2 epochs with the reference's keys (train_3dvid.py:295-306); the last one reloads into a fresh model
+    assert sorted(os.listdir(save_dir)) == ["l0_epoch_0001.tar", "l1_epoch_0000.tar", "l1_epoch_0002.tar"]
+    ck = torch.load(os.path.join(save_dir, "l1_epoch_0002.tar"), weights_only=False)
+    assert {"epoch_i", "epoch_total_step", "iter_total_step", "pyr_i", "train_factor", "hw", "network_state_dict"} <= set(ck)
+    fresh = MPMeshVid(args, H, W, ref_extrin, K, 1.0, 100.0).to(dev)
+    fresh.init_from_mpi(ck["network_state_dict"])
+    assert fresh.stack.shape == model.stack.shape
     # level 0: 20x28 frames < crop -> 1 crop x 2 views x 3 epochs; level 1: 40x56 -> 2x2 crops x 2 views x 4 epochs
     assert n == 2 * 3 + 8 * 4 == len(log)
     assert model.stack.shape[2:4] == (model.mpi_h, model.mpi_w)

@@ -116,3 +116,22 @@ def test_sparsify_and_init_from_mpi():
     # lod keeps the tying alive on the resized parameter
     vid.lod(0.5)
     assert vid._tie_hook is not None and vid.stack.shape[2:4] == (20, 30)
+
+
+def test_stage2_checkpoint_roundtrip(tmp_path):
+    """train_3dvid.py:295-306 / scripts/script_render_video.py:116-119: a saved MPMeshVid state_dict (incl. the "self.*" scalars and
+    the quad maps, possibly at a pyramid level) is loaded back with init_from_mpi."""
+    from videoloop3d_amd.MPV import MPMeshVid
+    H, W = 40, 60
+    K = np.array([[50., 0, 30], [0, 50., 20], [0, 0, 1]])
+    a = MPMeshVid(_args(), H, W, np.eye(4), K, 1.0, 100.0)
+    a.register_buffer("quad_keep", torch.rand(3, 4, 6) < 0.5)
+    a.register_buffer("quad_dyn", a.quad_keep & (torch.rand(3, 4, 6) < 0.5))
+    a.is_sparse = a.has_dyn = True
+    a.lod(0.5)
+    torch.save({"epoch_i": 3, "network_state_dict": a.state_dict()}, tmp_path / "l0_epoch_0003.tar")
+    ck = torch.load(tmp_path / "l0_epoch_0003.tar", weights_only=False)
+    b = MPMeshVid(_args(mpv_frm_num=7), H, W, np.eye(4), K, 1.0, 100.0)
+    b.init_from_mpi(ck["network_state_dict"])
+    assert b.frm_num == 4 and torch.equal(b.stack.detach(), a.stack.detach()) and b.spec.scale == a.spec.scale
+    assert b.is_sparse and torch.equal(b.quad_keep, a.quad_keep) and torch.equal(b.quad_dyn, a.quad_dyn) and b._tie_hook is not None

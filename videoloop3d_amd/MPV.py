@@ -122,12 +122,18 @@ class MPMeshVid(nn.Module):
         self.planedepth.data = state_dict['planedepth'].type_as(self.planedepth)
         self.ref_intrin_mpi.data = get_new_intrin(self.ref_intrin, -self.H_start, -self.W_start)
         mpi = state_dict['stack']
-        if mpi.shape[0] != self.mpi_d or tuple(mpi.shape[2:4]) != (self.mpi_h, self.mpi_w):
-            raise RuntimeError(f"stage-1 stack {tuple(mpi.shape)} does not match mpi_d={self.mpi_d}, planes {(self.mpi_h, self.mpi_w)}")
+        if mpi.dim() != 5 or mpi.shape[0] != self.mpi_d or mpi.shape[-1] != 4:
+            raise RuntimeError(f"checkpoint stack {tuple(mpi.shape)} does not match mpi_d={self.mpi_d}")
+        if mpi.shape[1] not in (1, self.frm_num):        # a stage-2 checkpoint with another frame count (MPV.py:262-265)
+            print(f"Warnining, inconsistent frame number detected, change from {self.frm_num} to {mpi.shape[1]}")
+            self.frm_num = int(mpi.shape[1])
         with torch.no_grad():
             new = mpi.type_as(self.stack).expand(-1, self.frm_num, -1, -1, -1).contiguous()
         self.register_parameter("stack", nn.Parameter(new, requires_grad=True))
-        self.spec = dataclasses.replace(self.spec, scale=self.texel_scale)
+        # planes saved at a pyramid level (lod) keep their extent: the plane-pixel -> texel scale follows the texture size
+        hs, ws = new.shape[2:4]
+        self.spec = dataclasses.replace(self.spec, scale=(self.texel_scale[0] * (ws - 1) / max(self.mpi_w - 1, 1),
+                                                          self.texel_scale[1] * (hs - 1) / max(self.mpi_h - 1, 1)))
         self.is_sparse = bool(state_dict.get("self.is_sparse", False))
         self.has_dyn = bool(state_dict.get("self.has_dyn", False))
         if self.is_sparse:

@@ -135,9 +135,11 @@ def run_iter(nerf, optimizer, item, args, device):
     return loss.detach(), swd_loss.detach(), {k: v.detach() for k, v in extra_losses.items()}
 
 
-def train(nerf, args, videos, poses, intrins, loss_cfgs, H, W, device="cuda:0", on_step=None, generator=None):
-    """train_3dvid.py:262-290: pyramid levels x epochs x shuffled crops.  `nerf` is the MPMeshVid (or an object exposing
-    `.module`); returns the number of iterations run.  No host synchronisation inside the loop unless `on_step` reads values."""
+def train(nerf, args, videos, poses, intrins, loss_cfgs, H, W, device="cuda:0", on_step=None, generator=None, save_dir=None):
+    """train_3dvid.py:262-306: pyramid levels x epochs x shuffled crops.  `nerf` is the MPMeshVid (or an object exposing
+    `.module`); returns the number of iterations run.  No host synchronisation inside the loop unless `on_step` reads values.
+    `save_dir`: every `args.i_weights` epochs write `l{level}_epoch_{epoch:04d}.tar` with the reference's keys (:295-306);
+    such a file is loaded back with `MPMeshVid.init_from_mpi(ckpt['network_state_dict'])` like the reference's scripts do."""
     module = getattr(nerf, "module", nerf)
     factors, hws, epochs = pyramid_schedule(args, H, W)
     epoch_total_step = iter_total_step = 0
@@ -159,5 +161,10 @@ def train(nerf, args, videos, poses, intrins, loss_cfgs, H, W, device="cuda:0", 
                 if on_step is not None:
                     on_step(pyr_i, epoch_i, iter_total_step, *out)
                 iter_total_step += 1
+            if save_dir is not None and (epoch_total_step + 1) % max(int(getattr(args, "i_weights", 1)), 1) == 0:
+                import os
+                torch.save({'epoch_i': epoch_i, 'epoch_total_step': epoch_total_step, 'iter_total_step': iter_total_step,
+                            'pyr_i': pyr_i, 'train_factor': factor, 'hw': hw, 'network_state_dict': module.state_dict()},
+                           os.path.join(save_dir, f'l{pyr_i}_epoch_{epoch_i:04d}.tar'))
             epoch_total_step += 1
     return iter_total_step
