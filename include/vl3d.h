@@ -72,7 +72,8 @@ int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, const float
 /* Backward of the above w.r.t. the stack (geometry is not differentiated: MPV.py:354).
  * rgb/alpha are the saved forward outputs; grad_alpha may be NULL (treated as 0).
  * grad_alpha_sums (optional): (T,H,W,2) gradient w.r.t. alpha_sums of the forward.
- * grad_stack (D,T,Hs,Ws,4) fp32 is overwritten.
+ * grad_stack (D,T,Hs,Ws,4) is overwritten; it has the dtype of the stack (fp32, or fp16 for stack_dtype == VL3D_F16 -- the
+ * cfg5 shards only fit with an 8-byte gradient texel).
  * scratch: caller-owned device buffer of vl3d_render_bwd_scratch_bytes(desc) bytes (plan written and read on
  * `stream`, no host sync); with scratch == NULL the universal global-atomics kernel is used.
  * desc->variant: 0 auto (LDS-staged owner-computes kernel when its on-device feasibility plan allows, atomics

@@ -393,6 +393,11 @@ def test_fp16_plane_stack(dev, spec_name):
     assert _tile_ran() == 1 and gs.dtype == torch.float16
     assert maxabs(rgb, rgb_o) <= TOL and maxabs(alpha, alpha_o) <= TOL
     assert maxabs(gs.float(), gs_o) <= 1e-3 * max(1e-3, float(gs_o.abs().max())) + 1e-6      # fp16 rounding of the returned gradient
+    # the atomics fallback accumulates straight into the fp16 gradient (packed-half atomics): a few roundings per texel
+    rgb_a, _ = render_planes(s_gpu, homos.to(dev), H, W, RenderSpec(variant=1, **kw_p))
+    (gs_a,) = torch.autograd.grad(rgb_a, s_gpu, g_rgb.to(dev))
+    assert _tile_ran() == 0 and gs_a.dtype == torch.float16
+    assert maxabs(gs_a.float(), gs_o) <= 4e-3 * max(1e-3, float(gs_o.abs().max())) + 1e-5
     # bit-identical to the fp32 kernels on the same (rounded) values, including the fused regulariser sums
     s32 = stack16.float().to(dev).requires_grad_(True)
     rgb32, _, sums32 = render_planes_with_smoothness(s32, homos.to(dev), H, W, RenderSpec(**kw_p))

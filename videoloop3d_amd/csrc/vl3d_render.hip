@@ -42,6 +42,7 @@ struct RenderArgs {
                                    // tile (tile_y & 3, tile_x & 3) << 10 | the owner pixel's index in its tile's region
     // tile culling (optional): quad_keep [D][QH][QW] bytes, 1 = the quad (cell of the plane's vertex grid) may be visible.
     // cull_masks (forward): per 64x8-pixel workgroup two 64-bit words, bit d = plane d can contribute to the workgroup.
+    int g_f16;               // the stack gradient is fp16 (8-byte texels), as the stack
     const unsigned char *quad_keep;
     int QH, QW;
     const unsigned long long *cull_masks;
@@ -194,6 +195,26 @@ __device__ __forceinline__ f4 load_texel(const char *__restrict__ plane, unsigne
     else return *reinterpret_cast<const f4 *>(plane + (size_t)off16);
 }
 
+// The stack gradient has the dtype of the stack (8-byte fp16 texels for cfg5: 96 GB of stack + 96 GB of gradient per GPU fit
+// in 288 GB; an fp32 gradient would not).  `tex16` is the byte offset the texel would have with 16-byte texels.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+template <bool F16>
+__device__ __forceinline__ void store_grad_texel(char *gplane, unsigned tex16, f4 v) {
+    if constexpr (F16) __builtin_nontemporal_store(__builtin_convertvector(v, h4), reinterpret_cast<h4 *>(gplane + (size_t)(tex16 >> 1)));
+    else __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(gplane + (size_t)tex16));
+}
+template <bool F16>
+__device__ __forceinline__ void atomic_add_grad_texel(char *gplane, size_t tex16, f4 c) {
+    if constexpr (F16) {     // packed-half atomics (global_atomic_pk_add_f16); fallback path only
+        auto *g = (__attribute__((address_space(1))) h2 *)(gplane + (tex16 >> 1));
+        __builtin_amdgcn_global_atomic_fadd_v2f16(g, h2{(_Float16)c.x, (_Float16)c.y});
+        __builtin_amdgcn_global_atomic_fadd_v2f16(g + 1, h2{(_Float16)c.z, (_Float16)c.w});
+    } else {
+        float *g = reinterpret_cast<float *>(gplane + tex16);
+        atomicAdd(g + 0, c.x); atomicAdd(g + 1, c.y); atomicAdd(g + 2, c.z); atomicAdd(g + 3, c.w);
+    }
+}
+
 // the four taps: one lane offset, four uniform bases (plane, +dx, +dy, +dx+dy) -- no per-tap address arithmetic
 template <bool F16>
 __device__ __forceinline__ void load_taps2(const char *__restrict__ plane, const Taps2 &t, TapStep st, f4 v[4]) {
@@ -238,7 +259,7 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
     const size_t frame = (size_t)a.Hs * a.Ws * 4;
     const size_t plane_stride = (size_t)a.T * frame;
     const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * a.Hs * a.Ws * TEXB;
-    char *gplane = reinterpret_cast<char *>(a.g_stack + (size_t)t * frame);
+    char *gplane = reinterpret_cast<char *>(a.g_stack) + (size_t)t * a.Hs * a.Ws * TEXB;     // gradient texels = stack texels
     const size_t pix = ((size_t)t * a.H + y) * a.W + x;
     const float Gr = a.g_rgb[pix * 3 + 0], Gg = a.g_rgb[pix * 3 + 1], Gb = a.g_rgb[pix * 3 + 2];
     const float gA = a.g_alpha ? a.g_alpha[pix] : 0.0f;
@@ -247,7 +268,7 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
     const float gN1 = a.g_asum ? a.g_asum[pix * 2 + 0] : 0.0f, gN2 = a.g_asum ? 2.0f * a.g_asum[pix * 2 + 1] : 0.0f;
     float Tr = 1.0f, P = 0.0f;
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws), gst = make_tap_step<false>(a.Hs, a.Ws);
-    for (int d = 0; d < a.D; ++d, plane += (size_t)a.T * a.Hs * a.Ws * TEXB, gplane += plane_stride * 4) {
+    for (int d = 0; d < a.D; ++d, plane += (size_t)a.T * a.Hs * a.Ws * TEXB, gplane += (size_t)a.T * a.Hs * a.Ws * TEXB) {
         const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
         if (tp.cov == 0.0f) continue;
         f4 tv[4], pre;
@@ -288,8 +309,7 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
                     c = f4{c.x * act_bwd<RACT>(sv.x, act_fwd<RACT>(sv.x)), c.y * act_bwd<RACT>(sv.y, act_fwd<RACT>(sv.y)),
                            c.z * act_bwd<RACT>(sv.z, act_fwd<RACT>(sv.z)), c.w * act_bwd<AACT>(sv.w, act_fwd<AACT>(sv.w))};
                 }
-                float *g = reinterpret_cast<float *>(gplane + (size_t)tp.off + ((i & 1) ? gst.dx : 0u) + ((i & 2) ? gst.dy : 0u));
-                atomicAdd(g + 0, c.x); atomicAdd(g + 1, c.y); atomicAdd(g + 2, c.z); atomicAdd(g + 3, c.w);
+                atomic_add_grad_texel<F16>(gplane, (size_t)tp.off + ((i & 1) ? gst.dx : 0u) + ((i & 2) ? gst.dy : 0u), c);
             }
         }
     }
@@ -592,8 +612,13 @@ __global__ __launch_bounds__(256) void bwd_zero_unowned_k(RenderArgs a) {
     const bool safe = (px > 0.5f) && (px < (float)a.W - 1.5f) && (py > 0.5f) && (py < (float)a.H - 1.5f);
     if (safe) return;      // owned (and written) by a tile with certainty
     const size_t frame = (size_t)a.Hs * a.Ws;
-    float4 *g = reinterpret_cast<float4 *>(a.g_stack) + (size_t)d * a.T * frame + (size_t)y * a.Ws + x;
-    for (int t = 0; t < a.T; ++t, g += frame) *g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.g_f16) {
+        float2 *g = reinterpret_cast<float2 *>(a.g_stack) + (size_t)d * a.T * frame + (size_t)y * a.Ws + x;
+        for (int t = 0; t < a.T; ++t, g += frame) *g = make_float2(0.f, 0.f);
+    } else {
+        float4 *g = reinterpret_cast<float4 *>(a.g_stack) + (size_t)d * a.T * frame + (size_t)y * a.Ws + x;
+        for (int t = 0; t < a.T; ++t, g += frame) *g = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
 // Owner table: for every texel of every plane, the tile that owns it (the tile of its owner pixel p0 = clamp_to_frame(
@@ -619,9 +644,9 @@ __global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, i
     owner[((size_t)d * a.Hs + y) * a.Ws + x] = (unsigned short)((((unsigned)(ty & 3) << 2 | (unsigned)(tx & 3)) << 10) | lc);
 }
 
-__global__ __launch_bounds__(256) void bwd_fill_zero_if_infeasible_k(float4 *g, size_t n, const float *plan) {
+__global__ __launch_bounds__(256) void bwd_fill_zero_if_infeasible_k(float2 *g, size_t n8, const float *plan) {      // n8: 8-byte units
     if (reinterpret_cast<const int *>(plan)[0]) return;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) g[i] = make_float2(0.f, 0.f);
 }
 
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16, bool CULL = false>
@@ -654,7 +679,7 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
     const size_t plane_stride = (size_t)a.T * frame;
     const size_t plane_stride_b = (size_t)a.T * a.Hs * a.Ws * TEXB;
     const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * a.Hs * a.Ws * TEXB;
-    float *gplane = a.g_stack + (size_t)t * frame;
+    char *gplane = reinterpret_cast<char *>(a.g_stack) + (size_t)t * a.Hs * a.Ws * TEXB;       // gradient texels = stack texels
     float Gr = 0.f, Gg = 0.f, Gb = 0.f, gA = 0.f, S = 0.f, gN1 = 0.f, gN2 = 0.f;   // gN1 + gN2*a_k = d(sparsity sums)/da_k
     if (inimg) {
         const size_t pix = ((size_t)t * a.H + y) * a.W + x;
@@ -675,7 +700,7 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
     const unsigned toff_thread = (unsigned)(row * a.Ws + lane);   // texel (lane, row) of a window, relative to its corner
     const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)my_tile_id * a.D * 4;
     int nswept = 0;
-    for (int d = 0; d < a.D; ++d, plane += plane_stride_b, gplane += plane_stride) {
+    for (int d = 0; d < a.D; ++d, plane += plane_stride_b, gplane += plane_stride_b) {
         float h[9];
         load_uniform(a.homos + 9 * d, h);
         // texel window of this tile on plane d (wave = window row, lane = window column); bit 31: culled for this tile
@@ -696,12 +721,12 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
             // composite state does not move, and the texels this tile owns get a zero gradient (written: nothing memsets it)
             const f4 z = f4{0.f, 0.f, 0.f, 0.f};
             if (row < wh && lane < ww && (e0 >> 10) == my_tile)
-                __builtin_nontemporal_store(z, reinterpret_cast<f4 *>(reinterpret_cast<char *>(gplane) + (size_t)((win0 + toff_thread) << 4)));
+                store_grad_texel<F16>(gplane, (win0 + toff_thread) << 4, z);
             for (int wy = row; wy < wh; wy += ROWS)
                 for (int wx = lane + (wy == row ? RW : 0); wx < ww; wx += RW) {
                     const unsigned tix = win0 + (unsigned)(wy * a.Ws + wx);
                     if ((oplane[tix] >> 10) == my_tile)
-                        __builtin_nontemporal_store(z, reinterpret_cast<f4 *>(reinterpret_cast<char *>(gplane) + (size_t)(tix << 4)));
+                        store_grad_texel<F16>(gplane, tix << 4, z);
                 }
             continue;
         }
@@ -779,7 +804,7 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
                 acc = f4{acc.x * act_bwd<RACT>(sv.x, act_fwd<RACT>(sv.x)), acc.y * act_bwd<RACT>(sv.y, act_fwd<RACT>(sv.y)),
                          acc.z * act_bwd<RACT>(sv.z, act_fwd<RACT>(sv.z)), acc.w * act_bwd<AACT>(sv.w, act_fwd<AACT>(sv.w))};
             }
-            if (!(a.ablate & 2)) __builtin_nontemporal_store(acc, reinterpret_cast<f4 *>(reinterpret_cast<char *>(gplane) + (size_t)(tix << 4)));
+            if (!(a.ablate & 2)) store_grad_texel<F16>(gplane, tix << 4, acc);
         };
         if (row < wh && lane < ww) gather(e0, lane, row, win0 + toff_thread);
         for (int wy = row; wy < wh; wy += ROWS)      // rest of a window larger than 64 x ROWS (frame-border tiles, minification)
@@ -906,8 +931,8 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
     if constexpr (BWD) {
         if (g_tile_rows) {
             hipLaunchKernelGGL((bwd_plan_k<COORD>), dim3(1), dim3(64), 0, s, a, g_tile_rows, const_cast<float *>(a.plan));
-            const size_t n4 = (size_t)a.D * a.T * a.Hs * a.Ws;
-            hipLaunchKernelGGL(bwd_fill_zero_if_infeasible_k, dim3(4096), dim3(256), 0, s, reinterpret_cast<float4 *>(a.g_stack), n4, a.plan);
+            const size_t n8 = (size_t)a.D * a.T * a.Hs * a.Ws * (a.g_f16 ? 1 : 2);          // fp16 texels are 8 bytes, fp32 ones 16
+            hipLaunchKernelGGL(bwd_fill_zero_if_infeasible_k, dim3(4096), dim3(256), 0, s, reinterpret_cast<float2 *>(a.g_stack), n8, a.plan);
             hipLaunchKernelGGL(bwd_zero_unowned_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, a);
             bool done = false;
             if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID && !F16) {   // measurement variant (shipped activations only)
@@ -1139,6 +1164,7 @@ static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, cons
     a.rgb = const_cast<float *>(rgb); a.alpha = const_cast<float *>(alpha);
     a.g_rgb = grad_rgb; a.g_alpha = grad_alpha; a.g_reg = grad_reg; a.g_asum = grad_alpha_sums; a.g_stack = grad_stack;
     a.quad_keep = quad_keep; a.QH = QH; a.QW = QW;
+    a.g_f16 = desc->stack_dtype == VL3D_F16;
     // variant: 0 auto (tile kernel when its on-device plan says feasible, else atomics), 1 force atomics,
     //          2 tile with 8-row regions, 3 tile with 16-row regions
     const bool want_tile = (desc->variant & 0xf) != 1 && scratch != nullptr && scratch_bytes >= vl3d_render_bwd_scratch_bytes(desc);
@@ -1152,7 +1178,7 @@ static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, cons
     } else {
         a.plan = nullptr;
         g_tile_rows = 0;
-        const size_t bytes = (size_t)desc->D * desc->T * desc->Hs * desc->Ws * 4 * sizeof(float);
+        const size_t bytes = (size_t)desc->D * desc->T * desc->Hs * desc->Ws * (desc->stack_dtype == VL3D_F16 ? 8 : 16);
         VL3D_HIP(hipMemsetAsync(grad_stack, 0, bytes, (hipStream_t)stream));
     }
     g_f16 = desc->stack_dtype == VL3D_F16;

@@ -111,7 +111,7 @@ class _RenderPlanes(torch.autograd.Function):
         g_asum = g_asum.to(torch.float32).contiguous() if (ctx.with_reg and g_asum is not None) else None
         g_rgb = g_rgb.contiguous() if g_rgb is not None else torch.zeros_like(rgb)
         g_alpha = g_alpha.contiguous() if g_alpha is not None else None
-        g_stack = torch.empty(stack.shape, dtype=torch.float32, device=stack.device)   # grad_stack is always fp32 in the ABI
+        g_stack = torch.empty(stack.shape, dtype=stack.dtype, device=stack.device)     # the gradient has the stack's dtype in the ABI
         with torch.cuda.device(stack.device):
             nscratch = int(L.lib().vl3d_render_bwd_scratch_bytes(ctx.desc))
             # every word the kernels read is written by the plan kernels of the same call; only the header is cleared (flags)
@@ -129,7 +129,7 @@ class _RenderPlanes(torch.autograd.Function):
                         "vl3d_render_bwd_culled")
         global LAST_BWD_SCRATCH
         LAST_BWD_SCRATCH = scratch
-        return g_stack.to(stack.dtype), None, None, None, None, None, None, None, None
+        return g_stack, None, None, None, None, None, None, None, None
 
 
 def render_planes(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0), quad_keep=None):
