@@ -270,6 +270,21 @@ def main():
                 del st1, gs1
             except Exception as e:
                 res["cfg2_single_frame"] = {"error": repr(e)}
+            try:    # cfg5's storage format on the cfg3 geometry: fp16 stack AND fp16 gradient (8-byte texels), fp32 arithmetic
+                st16 = stack.detach().half().requires_grad_(True)
+                for it in range(6):
+                    if it == 2:
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                    r1, _ = render_planes(st16, homos_d, H, W, spec)
+                    (gs1,) = torch.autograd.grad(r1, st16, g_rgb)
+                torch.cuda.synchronize()
+                dt16 = (time.perf_counter() - t1) / 4
+                res["fp16_stack_storage"] = {"value": T * H * W / dt16 / 1e6, "unit": "Mpix/s", "ms_per_step": dt16 * 1e3,
+                                             "workload": "cfg3 geometry with the plane stack and its gradient stored as fp16 (cfg5's format); fp32 arithmetic"}
+                del st16, r1, gs1
+            except Exception as e:
+                res["fp16_stack_storage"] = {"error": repr(e)}
             try:    # tile culling (MPI.py:288-442): the same cfg3 render on a stack with ~20 % of its quads kept, with and without
                     # the per-workgroup plane skipping (bit-identical results); in place on the resident stack, last use of it
                 from videoloop3d_amd import tiles
