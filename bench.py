@@ -247,6 +247,9 @@ def main():
         "fwd_bwd_algorithmic_frac": (fwd_bytes + bwd_bytes) / ((f_ms + b_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
     }
     if rank == 0:
+        # the extra legs (loss, stage-1 shape, storage / culling variants, end-to-end iteration, CPU baseline) run at N = 1 only
+        if world > 1:
+            a.no_loss = a.no_stage2 = a.no_cpu_baseline = True
         if not a.no_loss:
             try:
                 res["loss"] = loss_bench(dev, H, W, T, 75, a.loss_steps)
