@@ -135,3 +135,40 @@ def test_stage2_checkpoint_roundtrip(tmp_path):
     b.init_from_mpi(ck["network_state_dict"])
     assert b.frm_num == 4 and torch.equal(b.stack.detach(), a.stack.detach()) and b.spec.scale == a.spec.scale
     assert b.is_sparse and torch.equal(b.quad_keep, a.quad_keep) and torch.equal(b.quad_dyn, a.quad_dyn) and b._tie_hook is not None
+
+
+def test_reference_checkpoint_is_read_onto_the_dense_stack():
+    """MPV.py:235-288 on a checkpoint in the REFERENCE's format (face lists + packed static / dynamic atlases, restated by
+    oracle/ckpt_oracle.py from MPI.py:296-436): the tiles land on the right texels of the dense stack, the quad maps come back,
+    static content is shared by all frames."""
+    from oracle.ckpt_oracle import pack_reference_state
+    from videoloop3d_amd.MPV import MPMeshVid
+    torch.manual_seed(0)
+    D, T, hv, wv = 3, 4, 4, 5
+    H, W = 1 + 8 * (hv - 1), 1 + 8 * (wv - 1)
+    keep = torch.rand(D, hv - 1, wv - 1) < 0.7
+    dyn = keep & (torch.rand(D, hv - 1, wv - 1) < 0.5)
+
+    def closed(mask):                                   # closed plane-pixel rectangles of the quads of a map
+        m = torch.zeros(D, H, W, dtype=torch.bool)
+        for d_, qy, qx in mask.nonzero().tolist():
+            m[d_, 8 * qy:8 * qy + 9, 8 * qx:8 * qx + 9] = True
+        return m
+
+    stack = torch.randn(D, T, H, W, 4)
+    static_only = (closed(keep & ~dyn) & ~closed(dyn))[:, None, :, :, None]
+    stack = torch.where(static_only, stack[:, :1].expand_as(stack), stack)       # static tiles hold ONE frame (MPI.py:380-395)
+    sd = pack_reference_state(stack, keep, dyn, hv, wv, torch.linspace(1, 2, D))
+    assert "stack" not in sd and sd["atlas"].shape[0] == 1 and sd["atlas_dyn"].shape[0] == T
+    s2, k2, d2 = tiles.stack_from_reference_state(sd, H, W, hv, wv, T)
+    assert torch.equal(k2, keep) and torch.equal(d2, dyn)
+    ck = closed(keep)
+    assert float((s2 - stack).abs().amax((1, 4))[ck].max()) <= 1e-4
+    assert bool((s2[..., 3][(~ck)[:, None].expand(D, T, H, W)] == tiles.CULLED_ALPHA).all())
+    # through the module: frame count taken from the dynamic atlas, maps registered, static tying installed
+    a = _args(mpi_d=D, mpv_frm_num=2, mpi_h_verts=hv, mpi_w_verts=wv)
+    vid = MPMeshVid(a, H, W, np.eye(4), np.array([[30., 0, W / 2], [0, 30., H / 2], [0, 0, 1]]), 1.0, 100.0)
+    vid.init_from_mpi(sd)
+    assert vid.frm_num == T and vid.stack.shape == (D, T, H, W, 4) and vid.is_sparse and vid._tie_hook is not None
+    assert torch.equal(vid.quad_keep, keep) and torch.equal(vid.quad_dyn, dyn)
+    assert torch.allclose(vid.planedepth, torch.linspace(1, 2, D))

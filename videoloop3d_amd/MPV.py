@@ -9,10 +9,10 @@ geometry -- which is all the shipped configs ever produce (vertices get no gradi
   * no rasteriser: coverage and UVs of fronto-parallel quads are the analytic per-plane homography, with
     the two pytorch3d-side constants exposed as `pixel_center` (0.5) and hard-cut borders.
   * lod / get_optimizer / get_lrate / update_step (the stage-2 driver's hooks, train_3dvid.py:264-281) act on the stack;
-  * init_from_mpi takes the state_dict of videoloop3d_amd.MPI.MPMesh (dense stack + culled/static/dynamic quad maps of
-    its sparsify_faces, videoloop3d_amd/tiles.py); static quads stay one shared texture because their gradient is summed
-    over the frames.  The reference's packed-atlas checkpoints (uvs/faces/atlas tiles) and save_mesh / save_texture are
-    not provided.
+  * init_from_mpi takes the state_dict of videoloop3d_amd.MPI.MPMesh / MPMeshVid (dense stack + culled/static/dynamic quad
+    maps, videoloop3d_amd/tiles.py) AND the reference's own checkpoints (plane meshes + packed atlases: their tiles are
+    resampled onto the dense stack, tiles.stack_from_reference_state); static quads stay one shared texture because their
+    gradient is summed over the frames.  save_mesh / save_texture are not provided.
 """
 import dataclasses
 
@@ -117,6 +117,16 @@ class MPMeshVid(nn.Module):
         every frame.  With a sparsified MPI the quad maps come along: culled quads stay invisible, static quads stay ONE
         texture shared by all frames (their gradient is summed over the frames, as the reference's static atlas sees it),
         dynamic quads are free per frame; without them everything is dynamic ("load static as dynamic", MPV.py:266-288)."""
+        if "stack" not in state_dict and ("atlas" in state_dict or "atlas_dyn" in state_dict):
+            # a checkpoint of the REFERENCE (plane meshes + packed texture atlases, MPI.py:207-221 / MPV.py:290-304): resample its
+            # tiles onto the dense stack and recover the culled / static / dynamic quad maps from its face lists
+            from . import tiles
+            hv, wv = int(self.args.mpi_h_verts), int(self.args.mpi_w_verts)
+            st, keep, dyn = tiles.stack_from_reference_state(state_dict, self.mpi_h, self.mpi_w, hv, wv, self.frm_num)
+            sparse = bool(state_dict.get("self.is_sparse", False))
+            state_dict = {"ref_extrin": state_dict["ref_extrin"], "ref_intrin": state_dict["ref_intrin"],
+                          "planedepth": state_dict["planedepth"], "stack": st, "quad_keep": keep, "quad_dyn": dyn,
+                          "self.is_sparse": sparse, "self.has_dyn": sparse}
         self.ref_extrin.data = state_dict['ref_extrin'].type_as(self.ref_extrin)
         self.ref_intrin.data = state_dict['ref_intrin'].type_as(self.ref_intrin)
         self.planedepth.data = state_dict['planedepth'].type_as(self.planedepth)

@@ -165,3 +165,89 @@ class TileAdam(torch.optim.Optimizer):
                                                          L.ptr(st["exp_avg_sq"]), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                                          st["step"], L.stream_ptr(p.device)), "vl3d_adam_step_tiles")
         return loss
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Reading the REFERENCE's checkpoints (MPI.py:207-221 / MPV.py:290-304 state_dicts): plane meshes + texture atlases -> dense stack.
+#
+# Format (MPV.py:56-104, MPI.py:288-442, utils_mpi.py:80-89): `_verts` is a D x hv x wv vertex grid; every quad of the grid that
+# exists is two triangles in `faces` / `faces_dyn` ((v0,v1,v3),(v3,v2,v0), v0 = top-left vertex) with the same two triangles over
+# atlas corners in `uvfaces*` -> `uvs*` (normalised [-1,1] coordinates into `atlas` [1,4,Ah,Aw] / `atlas_dyn` [1|T,4,Ah',Aw'],
+# sampled with grid_sample(align_corners=True), MPV.py:425-427).  A plane pixel inside a quad maps affinely between the quad's
+# corner UVs (barycentric interpolation over two coplanar triangles of an axis-aligned rectangle, MPV.py:394-405).
+# Unpinned: no checkpoint of the reference is available here; the reader follows the code cited above and is tested against a
+# restatement of the reference's packing (oracle/ckpt_oracle.py).
+
+def _decode_quads(faces, uvfaces, uvs, hv, wv):
+    """-> (d, vy, vx) of every quad and its top-left / bottom-right atlas UV."""
+    if faces.numel() == 0:
+        z = torch.zeros(0, dtype=torch.long)
+        return z, z, z, torch.zeros(0, 2), torch.zeros(0, 2)
+    quads = faces.reshape(-1, 2, 3).long().cpu()
+    v0 = quads[:, 0, 0]
+    d, rem = v0 // (hv * wv), v0 % (hv * wv)
+    uq = uvfaces.reshape(-1, 2, 3).long().cpu()
+    uvs = uvs.detach().float().cpu()
+    return d, rem // wv, rem % wv, uvs[uq[:, 0, 0]], uvs[uq[:, 0, 2]]
+
+
+def stack_from_reference_state(sd, mpi_h, mpi_w, hv, wv, frm_num):
+    """Reference state_dict (stage-1 MPMesh or stage-2 MPMeshVid, sparsified or not) -> (stack (D,T,mpi_h,mpi_w,4) float32 on CPU,
+    quad_keep, quad_dyn [D,hv-1,wv-1] bool).  Static quads are written into every frame, culled texels get CULLED_ALPHA."""
+    D = int(sd["planedepth"].numel())
+    QH, QW = hv - 1, wv - 1
+    ch, cw = (mpi_h - 1) / QH, (mpi_w - 1) / QW
+    has_dyn_lists = "faces_dyn" in sd
+    parts = [("static", sd.get("faces"), sd.get("uvfaces"), sd.get("uvs"), sd.get("atlas"))]
+    if has_dyn_lists:
+        parts.append(("dyn", sd["faces_dyn"], sd["uvfaces_dyn"], sd["uvs_dyn"], sd["atlas_dyn"]))
+    T = frm_num
+    if has_dyn_lists and sd["atlas_dyn"].shape[0] > 1:
+        T = int(sd["atlas_dyn"].shape[0])
+    stack = torch.zeros((D, T, mpi_h, mpi_w, 4), dtype=torch.float32)
+    stack[..., 3] = CULLED_ALPHA
+    keep = torch.zeros((D, QH, QW), dtype=torch.bool)
+    dyn = torch.zeros((D, QH, QW), dtype=torch.bool)
+    y = torch.arange(mpi_h, dtype=torch.float64)
+    x = torch.arange(mpi_w, dtype=torch.float64)
+    # a texel on a quad border belongs to both neighbours: candidates floor(t/c) and ceil(t/c)-1 (equal off the borders)
+    qy_c = [(y / ch).floor().clamp(0, QH - 1).long(), ((y / ch).ceil() - 1).clamp(0, QH - 1).long()]
+    qx_c = [(x / cw).floor().clamp(0, QW - 1).long(), ((x / cw).ceil() - 1).clamp(0, QW - 1).long()]
+    for kind, faces, uvfaces, uvs, atlas in parts:
+        if faces is None or faces.numel() == 0:
+            continue
+        d, vy, vx, uv0, uv3 = _decode_quads(faces, uvfaces, uvs, hv, wv)
+        qid = torch.full((D, QH, QW), -1, dtype=torch.long)
+        qid[d, vy, vx] = torch.arange(len(d))
+        keep[d, vy, vx] = True
+        if kind == "dyn":
+            dyn[d, vy, vx] = True
+        atlas = atlas.detach().float().cpu()
+        for p in range(D):
+            if not (qid[p] >= 0).any():
+                continue
+            # per texel: the first candidate quad that exists in this list
+            q = torch.full((mpi_h, mpi_w), -1, dtype=torch.long)
+            fy = torch.zeros((mpi_h, mpi_w), dtype=torch.float64)
+            fx = torch.zeros((mpi_h, mpi_w), dtype=torch.float64)
+            for qy in qy_c:
+                for qx in qx_c:
+                    cand = qid[p][qy][:, qx]
+                    take = (q < 0) & (cand >= 0)
+                    q = torch.where(take, cand, q)
+                    fy = torch.where(take, ((y - qy.double() * ch) / ch)[:, None].expand(mpi_h, mpi_w), fy)
+                    fx = torch.where(take, ((x - qx.double() * cw) / cw)[None, :].expand(mpi_h, mpi_w), fx)
+            valid = q >= 0
+            qq = q.clamp_min(0)
+            u = uv0[qq, 0].double() + fx * (uv3[qq, 0] - uv0[qq, 0]).double()
+            v = uv0[qq, 1].double() + fy * (uv3[qq, 1] - uv0[qq, 1]).double()
+            grid = torch.stack([u, v], dim=-1).float()[None]                                  # 1,H,W,2
+            samp = F.grid_sample(atlas, grid.expand(atlas.shape[0], -1, -1, -1), mode="bilinear", padding_mode="zeros", align_corners=True)
+            samp = samp.permute(0, 2, 3, 1)                                                       # A,H,W,4
+            if samp.shape[0] == 1:
+                samp = samp.expand(T, -1, -1, -1)
+            m = valid[None, :, :, None]
+            stack[p] = torch.where(m, samp, stack[p])
+    if not has_dyn_lists:            # a stage-1 checkpoint: everything kept is static here; MPV loads it as dynamic (MPV.py:266-288)
+        dyn = keep.clone() if not bool(sd.get("self.is_sparse", False)) else dyn
+    return stack, keep, dyn
