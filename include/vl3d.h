@@ -105,15 +105,20 @@ int vl3d_render_bwd_culled(const vl3d_render_desc *desc, const void *stack, cons
 /* Static tiles of a tile-culled VIDEO stack (MPV.py:235-288: one static atlas shared by all frames).  In place on the stack
  * gradient (D,T,Hs,Ws,4): texels that only static quads can read get the sum over the T frames in every frame (the T copies
  * then stay one texture under any optimiser), texels no kept quad can read get 0, texels a dynamic quad can read are left
- * alone.  quad_keep / quad_dyn: device byte maps [D][QH][QW].  assume_culled_zero != 0: the gradient comes from the culled
- * render (vl3d_render_bwd_culled), which leaves exactly 0 in culled texels -- they are not rewritten. */
+ * alone.  quad_keep / quad_dyn: device byte maps [D][QH][QW].  mode bit 0: the gradient comes from the culled render
+ * (vl3d_render_bwd_culled), which leaves exactly 0 in culled texels -- they are not rewritten.  mode bit 1: the consumer is
+ * vl3d_adam_step_tiles with the same quad_dyn, which reads a static texel's gradient from frame 0 only -- the sum is written
+ * to frame 0 alone (the other frames keep their per-frame values and must not be used). */
 int vl3d_tie_static_grad(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uint8_t *quad_keep, const uint8_t *quad_dyn,
-                         int32_t QH, int32_t QW, float *grad, int32_t assume_culled_zero, vl3d_stream_t stream);
+                         int32_t QH, int32_t QW, float *grad, int32_t mode, vl3d_stream_t stream);
 
 /* torch.optim.Adam step (no amsgrad, no weight decay; MPV.py:199-214) on a stack parameter (D,T,Hs,Ws,4), in place on param /
  * exp_avg / exp_avg_sq, restricted to the texels a kept quad can read (quad_keep NULL: all texels).  Culled texels have zero
- * gradient and zero moments for ever, so skipping them is exact; `step` is the 1-based step count of this update. */
-int vl3d_adam_step_tiles(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uint8_t *quad_keep, int32_t QH, int32_t QW,
+ * gradient and zero moments for ever, so skipping them is exact; `step` is the 1-based step count of this update.
+ * quad_dyn (optional, with quad_keep): texels only static quads can read are ONE parameter with T identical copies -- the
+ * update is computed once from frame 0 (gradient = the frame sum vl3d_tie_static_grad leaves there; moments live in frame 0)
+ * and the new value is written to all T copies. */
+int vl3d_adam_step_tiles(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uint8_t *quad_keep, const uint8_t *quad_dyn, int32_t QH, int32_t QW,
                          float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float lr, float beta1, float beta2,
                          float eps, int64_t step, vl3d_stream_t stream);
 

@@ -337,3 +337,27 @@ def test_tile_adam_matches_torch_adam(dev):
     dense.param_groups[0]["params"][0].grad = torch.ones_like(p0)
     dense.step()
     assert float((dense.param_groups[0]["params"][0] - (p0 - 0.01)).abs().max()) <= 1e-6
+
+
+def test_tile_adam_static_texels_are_one_parameter(dev):
+    """TileAdam with quad_dyn: a static texel is updated once from frame 0 (frame-summed gradient left there by
+    tie_static_grad_hip(frame0_only=True)) and the value is written to all T copies == torch.optim.Adam on the fully tied gradient."""
+    from videoloop3d_amd import tiles
+    torch.manual_seed(12)
+    D, T, Hs, Ws, QH, QW = 3, 5, 37, 53, 5, 7
+    keep = (torch.rand(D, QH, QW) < 0.6).to(dev)
+    dyn = keep & (torch.rand(D, QH, QW) < 0.5).to(dev)
+    kt = tiles.quad_to_texel_mask(keep, Hs, Ws)[:, None, :, :, None].float()
+    p0 = torch.randn(D, 1, Hs, Ws, 4, device=dev).expand(D, T, Hs, Ws, 4).contiguous()      # all copies equal at the start
+    pa, pb = p0.clone().requires_grad_(True), p0.clone().requires_grad_(True)
+    oa = torch.optim.Adam([pa], lr=0.05, betas=(0.9, 0.999), eps=6e-8)
+    ob = tiles.TileAdam([pb], lr=0.05, betas=(0.9, 0.999), eps=6e-8, quad_keep=keep, quad_dyn=dyn)
+    for it in range(4):
+        g = torch.randn_like(p0) * kt
+        pa.grad = tiles.tie_static_grad(g.clone(), keep, dyn)                                  # the rule, fully tied
+        pb.grad = tiles.tie_static_grad_hip(g.clone(), keep, dyn, assume_culled_zero=True, frame0_only=True)
+        oa.step()
+        ob.step()
+        assert float((pa - pb).abs().max()) <= 2e-6
+    static_t = (tiles.quad_to_texel_mask(keep, Hs, Ws) & ~tiles.quad_to_texel_mask(dyn, Hs, Ws))[:, None, :, :, None].expand_as(p0)
+    assert torch.equal(pb.detach()[:, :1].expand_as(p0)[static_t], pb.detach()[static_t])    # the copies stayed identical

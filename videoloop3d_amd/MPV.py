@@ -100,6 +100,7 @@ class MPMeshVid(nn.Module):
         self.register_buffer("quad_keep", None)      # [D,QH,QW] bool maps of a sparsified stage-1 MPI (init_from_mpi)
         self.register_buffer("quad_dyn", None)
         self._tie_hook = None
+        self._static_compact = False
 
         self.swd_patch_size, self.swd_patcht_size = args.swd_patch_size, args.swd_patcht_size
         self.swd_stride, self.swd_stridet = args.swd_stride, args.swd_stridet
@@ -162,8 +163,10 @@ class MPMeshVid(nn.Module):
         if self.is_sparse and self.quad_keep is not None:
             from . import tiles
             if self.stack.is_cuda:    # the gradient comes from the culled render: culled texels already hold exact zeros
+                # frame0_only once get_optimizer has handed out the tile-aware Adam, which reads static gradients from frame 0
                 self._tie_hook = self.stack.register_hook(
-                    lambda g: tiles.tie_static_grad_hip(g, self.quad_keep, self.quad_dyn, assume_culled_zero=True))
+                    lambda g: tiles.tie_static_grad_hip(g, self.quad_keep, self.quad_dyn, assume_culled_zero=True,
+                                                        frame0_only=self._static_compact))
             else:                     # (CPU: host-logic tests only)
                 self._tie_hook = self.stack.register_hook(lambda g: tiles.tie_static_grad(g, self.quad_keep, self.quad_dyn))
 
@@ -212,7 +215,9 @@ class MPMeshVid(nn.Module):
                 # the same update as torch.optim.Adam in ONE pass over (p, g, m, v) -- 8.5 ms for the 7 GB stage-2 stack vs 12.4 ms
                 # (torch fused) / 29 ms (torch default) -- and, for a sparsified model, only over the texels kept quads can read
                 from .tiles import TileAdam
-                return TileAdam(params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8, quad_keep=self.quad_keep if self.is_sparse else None)
+                self._static_compact = bool(self.is_sparse)     # from now on static gradients are summed into frame 0 only
+                return TileAdam(params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8, quad_keep=self.quad_keep if self.is_sparse else None,
+                                quad_dyn=self.quad_dyn if self.is_sparse else None)
             return torch.optim.Adam(params=params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8)
         if self.args.optimizer == 'sgd':
             return torch.optim.SGD(params=params, lr=base_lr, momentum=0.9)

@@ -314,14 +314,16 @@ __global__ __launch_bounds__(256) void tie_static_grad_k(int D, int T, int Hs, i
     float4 *p = g + (size_t)d * T * frame + (size_t)y * Ws + x;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!kept) {
-        if (assume_culled_zero) return;      // the culled render never writes anything but 0 there
+        if (assume_culled_zero & 1) return;  // the culled render never writes anything but 0 there
     } else {
         for (int t = 0; t < T; ++t) {
             const float4 v = p[(size_t)t * frame];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     }
-    for (int t = 0; t < T; ++t) p[(size_t)t * frame] = s;
+    // bit 1 of the mode: the consumer is the tile-aware Adam, which reads a static texel's gradient from frame 0 only
+    const int tw = (kept && (assume_culled_zero & 2)) ? 1 : T;
+    for (int t = 0; t < tw; ++t) p[(size_t)t * frame] = s;
 }
 
 extern "C" int vl3d_tie_static_grad(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uint8_t *quad_keep, const uint8_t *quad_dyn,
@@ -339,17 +341,23 @@ extern "C" int vl3d_tie_static_grad(int32_t D, int32_t T, int32_t Hs, int32_t Ws
 // the texels a kept quad can read.  Culled texels never receive a gradient, so their moments stay 0 and Adam would leave them
 // unchanged anyway -- skipping them removes 7 streams over the culled part of the stack (the optimiser is 2/3 of a stage-2
 // iteration on the dense stack).  m, v, p are updated in place; bc1 = 1 - beta1^step, bc2s = sqrt(1 - beta2^step).
-__global__ __launch_bounds__(256) void adam_tiles_k(int T, int Hs, int Ws, const unsigned char *__restrict__ keep, int QH, int QW,
+__global__ __launch_bounds__(256) void adam_tiles_k(int T, int Hs, int Ws, const unsigned char *__restrict__ keep,
+                                                    const unsigned char *__restrict__ dyn, int QH, int QW,
                                                     float4 *__restrict__ p, const float4 *__restrict__ g, float4 *__restrict__ m,
                                                     float4 *__restrict__ v, float lr_bc1, float beta1, float beta2, float eps, float bc2s) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), d = blockIdx.z;
     if (x >= Ws || y >= Hs) return;
+    bool is_static = false;
     if (keep) {
         const double ch = (double)(Hs - 1) / QH, cw = (double)(Ws - 1) / QW;
         auto q = [](double val, double c, int n) { const int i = (int)floor(val / c); return i < 0 ? 0 : (i > n - 1 ? n - 1 : i); };
         const int ylo = q(y - 1.0, ch, QH), yhi = q(y + 1.0, ch, QH), xlo = q(x - 1.0, cw, QW), xhi = q(x + 1.0, cw, QW);
         const unsigned char *k = keep + (size_t)d * QH * QW;
         if (!(k[ylo * QW + xlo] | k[ylo * QW + xhi] | k[yhi * QW + xlo] | k[yhi * QW + xhi])) return;
+        if (dyn) {
+            const unsigned char *m_ = dyn + (size_t)d * QH * QW;
+            is_static = !(m_[ylo * QW + xlo] | m_[ylo * QW + xhi] | m_[yhi * QW + xlo] | m_[yhi * QW + xhi]);
+        }
     }
     const size_t frame = (size_t)Hs * Ws;
     size_t o = (size_t)d * T * frame + (size_t)y * Ws + x;
@@ -358,6 +366,16 @@ __global__ __launch_bounds__(256) void adam_tiles_k(int T, int Hs, int Ws, const
         vv = beta2 * vv + (1.0f - beta2) * gg * gg;      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
         pp -= lr_bc1 * (mm / (sqrtf(vv) / bc2s + eps));  // param.addcdiv_(exp_avg, sqrt(exp_avg_sq)/sqrt(bc2) + eps, value=-lr/bc1)
     };
+    if (is_static) {
+        // a static texel is ONE parameter with T identical copies (its gradient was summed over the frames into frame 0 by
+        // vl3d_tie_static_grad): update it once from frame 0's (p, g, m, v) and write the value to every copy
+        float4 pp = p[o], mm = m[o], vv = v[o];
+        const float4 gg = g[o];
+        upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
+        m[o] = mm; v[o] = vv;
+        for (int t = 0; t < T; ++t, o += frame) p[o] = pp;
+        return;
+    }
     for (int t = 0; t < T; ++t, o += frame) {
         float4 pp = p[o], mm = m[o], vv = v[o];
         const float4 gg = g[o];
@@ -366,14 +384,16 @@ __global__ __launch_bounds__(256) void adam_tiles_k(int T, int Hs, int Ws, const
     }
 }
 
-extern "C" int vl3d_adam_step_tiles(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uint8_t *quad_keep, int32_t QH, int32_t QW,
+extern "C" int vl3d_adam_step_tiles(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uint8_t *quad_keep, const uint8_t *quad_dyn,
+                                    int32_t QH, int32_t QW,
                                     float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float lr, float beta1,
                                     float beta2, float eps, int64_t step, vl3d_stream_t stream) {
     VL3D_REQUIRE(D > 0 && D <= 65535 && T > 0 && Hs > 0 && Ws > 0 && step >= 1, "vl3d_adam_step_tiles: bad dims / step");
     VL3D_REQUIRE(param && grad && exp_avg && exp_avg_sq, "vl3d_adam_step_tiles: null pointer");
     VL3D_REQUIRE(!quad_keep || (QH > 0 && QW > 0), "vl3d_adam_step_tiles: bad quad grid");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adam_tiles_k, dim3((Ws + 63) / 64, (Hs + 3) / 4, D), dim3(256), 0, (hipStream_t)stream, T, Hs, Ws, quad_keep, QH, QW,
+    hipLaunchKernelGGL(adam_tiles_k, dim3((Ws + 63) / 64, (Hs + 3) / 4, D), dim3(256), 0, (hipStream_t)stream, T, Hs, Ws, quad_keep,
+                       quad_keep ? quad_dyn : nullptr, QH, QW,
                        reinterpret_cast<float4 *>(param), reinterpret_cast<const float4 *>(grad), reinterpret_cast<float4 *>(exp_avg),
                        reinterpret_cast<float4 *>(exp_avg_sq), (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2));
     VL3D_CHECK_LAUNCH();

@@ -95,7 +95,7 @@ def cull_stack_(stack, keep):
     return stack
 
 
-def tie_static_grad_hip(grad, keep, dyn, assume_culled_zero=False):
+def tie_static_grad_hip(grad, keep, dyn, assume_culled_zero=False, frame0_only=False):
     """`tie_static_grad` as ONE in-place HIP kernel on the (fresh) gradient tensor of the stack -- the hook MPMeshVid installs
     (vl3d_tie_static_grad): static texels read T frames and write T frames, dynamic texels are not touched."""
     from . import _lib as L
@@ -107,7 +107,8 @@ def tie_static_grad_hip(grad, keep, dyn, assume_culled_zero=False):
     k8, d8 = keep.to(torch.uint8).contiguous(), dyn.to(torch.uint8).contiguous()
     with torch.cuda.device(g.device):
         L.check(L.lib().vl3d_tie_static_grad(D, T, Hs, Ws, L.ptr(k8), L.ptr(d8), keep.shape[1], keep.shape[2], L.ptr(g),
-                                             1 if assume_culled_zero else 0, L.stream_ptr(g.device)), "vl3d_tie_static_grad")
+                                             (1 if assume_culled_zero else 0) | (2 if frame0_only else 0), L.stream_ptr(g.device)),
+                "vl3d_tie_static_grad")
     return g
 
 
@@ -131,9 +132,13 @@ class TileAdam(torch.optim.Optimizer):
     the ones torch.optim.Adam produces (to fp32 rounding of the fused update) while the 7 streams over the culled 80-95 % of the
     stack disappear.  `quad_keep` may be replaced at any time through `.quad_keep` (None = dense)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, quad_keep=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, quad_keep=None, quad_dyn=None):
+        """quad_dyn (with quad_keep): static texels are treated as ONE parameter with T copies -- their gradient is read from
+        frame 0 (where tie_static_grad_hip(..., frame0_only=True) leaves the frame sum), their moments live in frame 0, and the
+        new value is written to all copies."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.quad_keep = quad_keep
+        self.quad_dyn = quad_dyn
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -143,6 +148,7 @@ class TileAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         qk = None if self.quad_keep is None else self.quad_keep.to(torch.uint8).contiguous()
+        qd = None if (qk is None or self.quad_dyn is None) else self.quad_dyn.to(torch.uint8).contiguous()
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -160,7 +166,7 @@ class TileAdam(torch.optim.Optimizer):
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 D, T, Hs, Ws, _ = p.shape
                 with torch.cuda.device(p.device):
-                    L.check(L.lib().vl3d_adam_step_tiles(D, T, Hs, Ws, L.ptr(qk), 0 if qk is None else qk.shape[1],
+                    L.check(L.lib().vl3d_adam_step_tiles(D, T, Hs, Ws, L.ptr(qk), L.ptr(qd), 0 if qk is None else qk.shape[1],
                                                          0 if qk is None else qk.shape[2], L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]),
                                                          L.ptr(st["exp_avg_sq"]), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                                          st["step"], L.stream_ptr(p.device)), "vl3d_adam_step_tiles")
