@@ -38,8 +38,8 @@ struct RenderArgs {
     int ablate;          // measurement-only switches (bit0: skip LDS scatter, bit1: skip flush stores, bit2: skip tap loads)
     const float *plan;   // device scratch written by bwd_plan_k: [0] feasible flag, [16 + 12*d ..] inverse texel homographies,
                          // then (bwd_windows_k) one int4 texel window per (tile, plane)
-    const unsigned short *owner;   // device scratch written by bwd_owner_table_k: per (plane, texel) a 4-bit code of the owner
-                                   // tile (tile_y & 3, tile_x & 3) << 10 | the owner pixel's index in its tile's region
+    const unsigned short *owner;   // device scratch written by bwd_owner_table_k: per (plane, texel) a 6-bit code of the owner
+                                   // tile (tile_y & 7, tile_x & 7) << 10 | the owner pixel's index in its tile's region
     // tile culling (optional): quad_keep [D][QH][QW] bytes, 1 = the quad (cell of the plane's vertex grid) may be visible.
     // cull_masks (forward): per 64x8-pixel workgroup two 64-bit words, bit d = plane d can contribute to the workgroup.
     int g_f16;               // the stack gradient is fp16 (8-byte texels), as the stack
@@ -639,9 +639,10 @@ __global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, i
     // tile of the owner pixel: floor((r + 0.5) / size) in fp32 is exact for frame coordinates (< 2^22) -- no integer division
     const int tx = (int)((rxf + 0.5f) * (1.0f / (float)iw)), ty = (int)((ryf + 0.5f) * (1.0f / (float)ih));
     const unsigned lc = (unsigned)((ry - ty * ih + rh) * RW + (rx - tx * iw + rh));
-    // a tile's window only holds texels owned by itself or one of its 8 neighbours, which the two low bits of the tile
-    // coordinates tell apart: 14 bits per texel
-    owner[((size_t)d * a.Hs + y) * a.Ws + x] = (unsigned short)((((unsigned)(ty & 3) << 2 | (unsigned)(tx & 3)) << 10) | lc);
+    // a tile's window only holds texels owned by itself or tiles a few steps away (the window is the bounding box of the tile's
+    // image; under the plan's rotation / magnification limits its corners reach < 4 tiles), which the three low bits of each
+    // tile coordinate tell apart: 16 bits per texel
+    owner[((size_t)d * a.Hs + y) * a.Ws + x] = (unsigned short)((((unsigned)(ty & 7) << 3 | (unsigned)(tx & 7)) << 10) | lc);
 }
 
 __global__ __launch_bounds__(256) void bwd_fill_zero_if_infeasible_k(float2 *g, size_t n8, const float *plan) {      // n8: 8-byte units
@@ -696,7 +697,7 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
     // this tile's texel windows, one int4 per plane (bwd_windows_k)
     const unsigned my_tile_id = (unsigned)(tile_y * a.tiles_x + tile_x);
-    const unsigned my_tile = (unsigned)((tile_y & 3) << 2 | (tile_x & 3));      // the owner table's code of this tile
+    const unsigned my_tile = (unsigned)((tile_y & 7) << 3 | (tile_x & 7));      // the owner table's code of this tile
     const unsigned toff_thread = (unsigned)(row * a.Ws + lane);   // texel (lane, row) of a window, relative to its corner
     const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)my_tile_id * a.D * 4;
     int nswept = 0;
