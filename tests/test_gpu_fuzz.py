@@ -83,3 +83,31 @@ def test_loss_fuzz(dev, seed):
     assert float((L.last_y2x.cpu() - y2x_o).abs().max()) <= 1e-5
     assert abs(float(loss) - float(loss_o)) <= 1e-5 * max(1.0, abs(float(loss_o)))
     assert float((gx.cpu() - gx_o).abs().max()) <= 1e-5 * max(1.0, float(gx_o.abs().max()))
+
+
+@pytest.mark.parametrize("deg", [12.0, 25.0, -33.0])
+def test_rotated_views_take_the_tile_path(dev, deg):
+    """strongly rotated views (|cos|+|sin| < 1.4 keeps the owner-computes plan feasible): a tile's texel window is the bounding box
+    of a rotated rectangle and reaches texels owned by tiles several steps away -- the owner table's tile codes must tell them apart."""
+    from videoloop3d_amd import render as R
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    D, T, Hs, Ws, H, W = 3, 1, 230, 260, 200, 240
+    th = math.radians(deg)
+    c, s = math.cos(th), math.sin(th)
+    # rotate about the frame centre, then map onto the plane centre
+    Tc = torch.tensor([[1.0, 0, -W / 2], [0, 1.0, -H / 2], [0, 0, 1.0]])
+    Rm = torch.tensor([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+    Tp = torch.tensor([[1.0, 0, Ws / 2], [0, 1.0, Hs / 2], [0, 0, 1.0]])
+    homos = torch.stack([Tp @ Rm @ Tc + torch.tensor([[0, 0, 1.5 * d], [0, 0, -0.7 * d], [0, 0, 0.0]]) for d in range(D)])
+    kw = dict(pixel_center=0.5, coord_mode="affine", border="hardcut", act_order="post")
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=77)
+    g_rgb = synth.hash_uniform((T, H, W, 3), seed=5) - 0.5
+    s_cpu = stack.clone().requires_grad_(True)
+    rgb_o, alpha_o, _ = MO.render_planes(s_cpu, homos, H, W, MO.RenderSpec(**kw))
+    (gs_o,) = torch.autograd.grad(rgb_o, s_cpu, g_rgb)
+    s_gpu = stack.to(dev).requires_grad_(True)
+    rgb, alpha = render_planes(s_gpu, homos.to(dev), H, W, RenderSpec(**kw))
+    (gs,) = torch.autograd.grad(rgb, s_gpu, g_rgb.to(dev))
+    assert int(R.LAST_BWD_SCRATCH[:1].view(torch.int32).item()) == 1          # the owner-computes path ran
+    assert float((rgb.cpu() - rgb_o).abs().max()) <= TOL
+    assert float((gs.cpu() - gs_o).abs().max()) <= TOL * max(1.0, float(gs_o.abs().max()))
