@@ -111,3 +111,21 @@ def test_band_spec_requires_affine():
     from videoloop3d_amd.dist import Band
     with pytest.raises(RuntimeError, match="affine"):
         band_spec(RenderSpec(), Band(0, 0, 4, 0, 8), 16)
+
+
+def test_loss_band_rows_cover_every_patch_of_the_owned_rows():
+    """videoloop3d_amd/dist.py loss_band_rows: the sub-image a rank needs starts on the global patch grid, satisfies the trimming rule,
+    contains every patch that covers an owned row, and the owned rows of all ranks tile the frame."""
+    from videoloop3d_amd.dist import loss_band_rows
+    for H, ps, s in ((179, 11, 4), (719, 11, 4), (65, 3, 2), (40, 5, 5), (23, 7, 1)):
+        assert (H - ps) % s == 0
+        h_o = (H - ps) // s + 1
+        for world in (1, 2, 3, 8):
+            rows = split_rows(H, world)
+            assert rows[0][0] == 0 and sum(r for _, r in rows) == H
+            for row0, n in rows:
+                a, b = loss_band_rows(row0, n, H, ps, s)
+                assert a % s == 0 and (b - a - ps) % s == 0 and 0 <= a <= row0 and row0 + n <= b <= H
+                for eta in (row0, row0 + n - 1):
+                    covering = [by for by in range(h_o) if by * s <= eta < by * s + ps]
+                    assert covering and all(a <= by * s and by * s + ps <= b for by in covering)

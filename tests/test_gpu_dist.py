@@ -47,3 +47,33 @@ def test_rccl_world1_band_render_and_all_gather():
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cfg", [dict(patch_size=11, stride=4, patcht_size=3, stridet=1, rou="-2", scaling=0.1, alpha=0.5),
+                                 dict(patch_size=3, stride=2, patcht_size=3, stridet=1, rou="-2", scaling=0.1, alpha=10000.0)])
+@pytest.mark.parametrize("world", [2, 3])
+def test_looping_loss_on_row_bands_equals_the_full_loss(cfg, world):
+    """the looping loss sharded over the render's row bands (every rank: NN of the patch rows covering its rows, loss over
+    its rows) sums to the single-GPU loss, and each rank's gradient lives on its own rows only (ranks run one after the other here)."""
+    import __graft_entry__ as g
+    g.build()
+    from videoloop3d_amd.dist import looping_loss_band, split_rows
+    from videoloop3d_amd.utils_vid import Patch3DGPNNLowMemLoss
+    dev = torch.device("cuda:0")
+    H, W = 62, 45
+    x = synth.make_video(9, H, W, seed=3, device=dev).requires_grad_(True)
+    y = synth.make_video(14, H, W, seed=4, device=dev)
+    full = Patch3DGPNNLowMemLoss()(x, y, macro_block=65, **cfg)
+    (g_full,) = torch.autograd.grad(full, x)
+    total, count, g_sum = 0.0, 0, torch.zeros_like(x)
+    for row0, rows in split_rows(H, world):
+        s, n = looping_loss_band(x, y, row0, rows, **cfg)
+        if n:
+            (gr,) = torch.autograd.grad(s, x)
+            outside = torch.ones(H, dtype=torch.bool, device=dev)
+            outside[row0:row0 + rows] = False
+            assert float(gr[..., outside, :].abs().max()) == 0.0            # nothing leaks into the neighbours' bands
+            g_sum += gr
+            total, count = total + float(s), count + n
+    assert abs(total / count - float(full)) <= 1e-6 * max(1.0, abs(float(full)))
+    assert float((g_sum / count - g_full).abs().max()) <= 1e-7 + 1e-5 * float(g_full.abs().max())

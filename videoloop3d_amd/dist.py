@@ -99,3 +99,44 @@ def all_gather_frame(band_rgb: torch.Tensor, bands: List[Band], group=None) -> t
     parts = [torch.empty((T, r, W, C), dtype=band_rgb.dtype, device=band_rgb.device) for r in rows]
     dist.all_gather(parts, band_rgb.contiguous(), group=group)
     return torch.cat(parts, dim=1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Looping loss on row bands: every spatial patch location is independent but needs all frames, so the loss is
+# sharded over pixel rows like the render.  After the all-gather every rank holds the full composited frame; rank r owns the pixel
+# rows of ITS render band, needs the NN of every patch row that covers one of them (a halo of < ps rows of the neighbours' bands,
+# recomputed rather than exchanged) and sums the robust loss over its own rows only.  x enters the loss only through the residual
+# at owned rows (y2x is built under no_grad, utils_vid.py:322), so d loss / d frame is non-zero on the rank's own band only: no
+# gradient exchange, one scalar all-reduce.
+
+def loss_band_rows(row0: int, rows: int, H: int, ps: int, stride: int):
+    """Pixel rows [a, b) of the (already trimmed, (H-ps) % stride == 0) frame a rank needs so that every patch row covering one of
+    its owned rows [row0, row0+rows) is complete; the sub-image's own patch grid coincides with the global one."""
+    h_o = (H - ps) // stride + 1
+    r1 = min(row0 + rows, H)
+    by_lo = max(0, -((-(row0 - ps + 1)) // stride))            # ceil((row0 - ps + 1) / stride)
+    by_hi = min(h_o - 1, (r1 - 1) // stride)
+    return by_lo * stride, by_hi * stride + ps
+
+
+def looping_loss_band(x, y, row0, rows, patch_size=7, stride=2, patcht_size=7, stridet=2, rou=0, scaling=0.2, alpha=1e10, **_):
+    """Rank-local part of Patch3DGPNNLowMemLoss (utils_vid.py:289-349) for the owned pixel rows [row0, row0+rows) of the full frame
+    x [1,3,T,H,W] / y [1,3,F,H,W]: returns (sum of robust losses over the owned rows of the trimmed frame, their element count).
+    The global loss is all_reduce(sum) / all_reduce(count); the gradient reaches x on the owned rows only."""
+    from .utils_vid import _RobustMean, _nn_and_fold, fit_patch
+    t, h, w = x.shape[-3:]
+    h = fit_patch(h, "patch_height", patch_size, stride)
+    w = fit_patch(w, "patch_width", patch_size, stride)
+    t = fit_patch(t, "frame_num", patcht_size, stridet)
+    r1 = min(row0 + rows, h)                                    # rows trimmed off the frame belong to nobody
+    if r1 <= row0:
+        return x.new_zeros(()), 0
+    a, b = loss_band_rows(row0, r1 - row0, h, patch_size, stride)
+    xs, ys = x[..., :t, a:b, :w], y[..., a:b, :w]
+    al = None if alpha > 100 else alpha
+    with torch.no_grad():
+        y2x, _, _ = _nn_and_fold(xs, ys, patch_size, patcht_size, stride, stridet, al, normalize=True)
+    x_own = xs[..., row0 - a:r1 - a, :]
+    y2x_own = y2x[..., row0 - a:r1 - a, :]
+    n = x_own.numel()
+    return _RobustMean.apply(x_own, y2x_own, rou, scaling) * n, n
