@@ -113,10 +113,10 @@ def test_rotated_views_take_the_tile_path(dev, deg):
     assert float((gs.cpu() - gs_o).abs().max()) <= TOL * max(1.0, float(gs_o.abs().max()))
 
 
-@pytest.mark.parametrize("Tx,Ty", [(82, 150), (122, 121)])
+@pytest.mark.parametrize("Tx,Ty", [(82, 150), (122, 121), (52, 400), (30, 800)])
 def test_loss_long_videos_fall_back_gracefully(dev, Tx, Ty):
-    """cfg4 / cfg5 frame counts: the fused fold tile (Ty frames x 256 pixels in LDS) and the 4-location NN kernel no longer fit;
-    the loss classes must take the unfused / one-location kernels and still match the oracle."""
+    """cfg4 / cfg5 frame counts and beyond: the 32x8 fold tile (Ty frames x 256 pixels in LDS) and the 4-location NN kernel no longer
+    fit; the loss classes must take the narrower fold tiles / the unfused kernels / the one-location NN kernel and still match."""
     from oracle import vid_oracle as VO
     from videoloop3d_amd.utils_vid import Patch3DGPNNLowMemLoss
     h, w = 15, 19

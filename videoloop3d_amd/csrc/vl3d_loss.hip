@@ -689,11 +689,13 @@ __global__ __launch_bounds__(256) void vote_fold_k(FoldArgs a) {
 // frames) and the NN indices of every patch location covering the tile are staged in LDS once; each thread then produces
 // its pixel's whole temporal column (all Tx frames) from LDS: the gather of utils_vid.py:217 + FoldNd (:218-227) without
 // any scattered global access.  (v1 -- one thread per voxel reading y and nn through L2 -- measured 12.3 ms at 720p.)
-constexpr int FT_W = 32, FT_H = 8, FT_G = 4;    // tile of 32x8 pixels x 4 temporal groups = 1024 threads (16 waves hide the LDS chains)
+constexpr int FT_H = 8, FT_NT = 1024;   // tile of FT_W x 8 pixels x FT_G temporal groups = 1024 threads (16 waves hide the LDS chains)
+// FT_W = 32 (x 4 groups) by default; 16 / 8 (x 8 / 16 groups) when Ty frames of a 32-wide tile do not fit LDS (cfg4 / cfg5 clips)
 
-__global__ __launch_bounds__(FT_W *FT_H *FT_G) void vote_fold_lds_k(FoldArgs a, int Ty) {
+template <int FT_W>
+__global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NP = FT_W * FT_H, NT = NP * FT_G;
+    constexpr int NP = FT_W * FT_H, FT_G = FT_NT / NP, NT = FT_NT;
     float *ys = smem;                                            // [Ty][NP]
     int *nns = reinterpret_cast<int *>(smem + (size_t)Ty * NP);   // [nby][nbx][n1]
     const int tid = threadIdx.x, pix = tid % NP, grp = tid / NP, lx = pix % FT_W, ly = pix / FT_W;
@@ -778,7 +780,7 @@ __global__ __launch_bounds__(FT_W *FT_H *FT_G) void vote_fold_lds_k(FoldArgs a, 
     }
     }
     if (a.x) {          // block sum of the loss -> one double atomic
-        __shared__ float red[FT_W * FT_H * FT_G / 64];
+        __shared__ float red[FT_NT / 64];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) lacc += __shfl_down(lacc, off, 64);
         if ((tid & 63) == 0) red[tid >> 6] = lacc;
@@ -967,6 +969,31 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
     return VL3D_OK;
 }
 
+// LDS-staged fold: widest tile whose y columns (all Ty frames) + nn indices fit; 0 = none does
+static size_t fold_lds_bytes(const vl3d_loss_desc *desc, int n1, int fw) {
+    const int nby_max = (FT_H + desc->ps - 2) / desc->stride + 2, nbx_max = (fw + desc->ps - 2) / desc->stride + 2;
+    return ((size_t)desc->Ty * fw * FT_H + (size_t)nby_max * nbx_max * n1) * sizeof(float);
+}
+static int fold_tile_width(const vl3d_loss_desc *desc, int n1) {
+    for (int fw : {32, 16, 8})
+        if (fold_lds_bytes(desc, n1, fw) <= 150 * 1024) return fw;
+    return 0;
+}
+template <int FW>
+static int launch_fold_lds(const vl3d_loss_desc *desc, const FoldArgs &a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        VL3D_HIP(hipFuncSetAttribute((const void *)vote_fold_lds_k<FW>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        attr_set = true;
+    }
+    dim3 grid((desc->W + FW - 1) / FW, (desc->H + FT_H - 1) / FT_H, 3);
+    hipLaunchKernelGGL(vote_fold_lds_k<FW>, grid, dim3(FT_NT), fold_lds_bytes(desc, a.n1, FW), s, a, desc->Ty);
+    return VL3D_OK;
+}
+static int launch_fold_lds_w(int fw, const vl3d_loss_desc *desc, const FoldArgs &a, hipStream_t s) {
+    return fw == 32 ? launch_fold_lds<32>(desc, a, s) : (fw == 16 ? launch_fold_lds<16>(desc, a, s) : launch_fold_lds<8>(desc, a, s));
+}
+
 extern "C" int vl3d_vote_fold(const vl3d_loss_desc *desc, const float *y, const int32_t *nn, float *sum, float *weight,
                               int32_t normalize, vl3d_stream_t stream) {
     int rc = check_loss(desc);
@@ -982,17 +1009,11 @@ extern "C" int vl3d_vote_fold(const vl3d_loss_desc *desc, const float *y, const 
     a.n1 = (desc->Tx - desc->pt) / desc->stridet + 1;
     a.y_sc = desc->y_sc; a.y_st = desc->y_st; a.y_sr = desc->y_sr;
     a.normalize = normalize;
-    // LDS-staged kernel when the tile's y columns + nn indices fit (they do for every shipped configuration)
-    const int nby_max = (FT_H + desc->ps - 2) / desc->stride + 2, nbx_max = (FT_W + desc->ps - 2) / desc->stride + 2;
-    const size_t lds = ((size_t)desc->Ty * FT_W * FT_H + (size_t)nby_max * nbx_max * a.n1) * sizeof(float);
-    if (desc->variant != 1 && lds <= 150 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            VL3D_HIP(hipFuncSetAttribute((const void *)vote_fold_lds_k, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-            attr_set = true;
-        }
-        dim3 grid((desc->W + FT_W - 1) / FT_W, (desc->H + FT_H - 1) / FT_H, 3);
-        hipLaunchKernelGGL(vote_fold_lds_k, grid, dim3(FT_W * FT_H * FT_G), lds, (hipStream_t)stream, a, desc->Ty);
+    // LDS-staged kernel when a tile's y columns + nn indices fit (32 wide for every shipped configuration, narrower for long clips)
+    const int fw = fold_tile_width(desc, a.n1);
+    if (desc->variant != 1 && fw) {
+        rc = launch_fold_lds_w(fw, desc, a, (hipStream_t)stream);
+        if (rc != VL3D_OK) return rc;
     } else {
         dim3 grid((desc->W + 63) / 64, (desc->H + 3) / 4, desc->Tx);
         hipLaunchKernelGGL(vote_fold_k, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -1022,20 +1043,14 @@ extern "C" int vl3d_vote_fold_robust(const vl3d_loss_desc *desc, const float *y,
     a.rho = make_rho(kind, rou, scale);
     a.gscale = 1.0f / (3.0f * (float)desc->Tx * (float)desc->H * (float)desc->W);     // d(mean)/d(element)
     a.gx = grad_x; a.loss_sum = loss_sum;
-    const int nby_max = (FT_H + desc->ps - 2) / desc->stride + 2, nbx_max = (FT_W + desc->ps - 2) / desc->stride + 2;
-    const size_t lds = ((size_t)desc->Ty * FT_W * FT_H + (size_t)nby_max * nbx_max * a.n1) * sizeof(float);
-    if (lds > 150 * 1024) {
+    const int fw = fold_tile_width(desc, a.n1);
+    if (!fw) {
         vl3d_set_error("vl3d_vote_fold_robust: tile does not fit LDS; use vl3d_vote_fold + vl3d_robust_fwd/bwd");
         return VL3D_EUNSUPPORTED;
     }
     VL3D_HIP(hipMemsetAsync(loss_sum, 0, sizeof(double), (hipStream_t)stream));
-    static bool attr_set = false;
-    if (!attr_set) {
-        VL3D_HIP(hipFuncSetAttribute((const void *)vote_fold_lds_k, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-        attr_set = true;
-    }
-    dim3 grid((desc->W + FT_W - 1) / FT_W, (desc->H + FT_H - 1) / FT_H, 3);
-    hipLaunchKernelGGL(vote_fold_lds_k, grid, dim3(FT_W * FT_H * FT_G), lds, (hipStream_t)stream, a, desc->Ty);
+    rc = launch_fold_lds_w(fw, desc, a, (hipStream_t)stream);
+    if (rc != VL3D_OK) return rc;
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
 }
