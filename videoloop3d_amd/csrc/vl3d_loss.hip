@@ -392,8 +392,9 @@ __global__ __launch_bounds__(NN_THREADS) void patchnn3_k(NN2Args a, int TyT) {
 // fixed costs over 4 locations; E lives in registers for the whole K loop (no LDS read-modify-write per chunk).
 constexpr int NL4 = 4;
 
-template <bool RUNSUM>
-__global__ __launch_bounds__(NN_THREADS) void patchnn4_k(NN2Args a, int H_unused, int groups_x) {
+// NTHR: 256 threads for the shipped clips (one 4x4 frame-pair tile per thread), 512 / 1024 for longer ones (cfg4 / cfg5)
+template <bool RUNSUM, int NTHR = NN_THREADS>
+__global__ __launch_bounds__(NTHR) void patchnn4_k(NN2Args a, int H_unused, int groups_x) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int RWc = a.ps + (NL4 - 1) * a.stride;               // region width in pixels
     float *Xs = smem;                                           // [RWc*3][TxP]
@@ -419,8 +420,8 @@ __global__ __launch_bounds__(NN_THREADS) void patchnn4_k(NN2Args a, int H_unused
         __syncthreads();
         const float4 *xsrc = reinterpret_cast<const float4 *>(a.xt + ((size_t)(r0 + r) * a.W + c0) * 3 * a.TxP);
         const float4 *ysrc = reinterpret_cast<const float4 *>(a.yt + ((size_t)(r0 + r) * a.W + c0) * 3 * a.TyP);
-        for (int i = tid; i < x4; i += NN_THREADS) reinterpret_cast<float4 *>(Xs)[i] = xsrc[i];
-        for (int i = tid; i < y4; i += NN_THREADS) reinterpret_cast<float4 *>(Ys)[i] = ysrc[i];
+        for (int i = tid; i < x4; i += NTHR) reinterpret_cast<float4 *>(Xs)[i] = xsrc[i];
+        for (int i = tid; i < y4; i += NTHR) reinterpret_cast<float4 *>(Ys)[i] = ysrc[i];
         __syncthreads();
         if (has_tile) {
             // running sum R of the column energies along the row; location l's share of this row is R(window end) - R(before
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(NN_THREADS) void patchnn4_k(NN2Args a, int H_unused
         __syncthreads();
         const size_t b = (size_t)by * a.w_o + bx0 + l;
         if (a.use_alpha) {
-            for (int j = tid >> 2; j < a.n2; j += NN_THREADS / 4) {
+            for (int j = tid >> 2; j < a.n2; j += NTHR / 4) {
                 float m = INFINITY;
                 for (int i = sub; i < a.n1; i += 4) {
                     float sacc = 0.f;
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(NN_THREADS) void patchnn4_k(NN2Args a, int H_unused
             }
             __syncthreads();
         }
-        for (int i0 = 0; i0 < a.n1; i0 += NN_THREADS / 4) {
+        for (int i0 = 0; i0 < a.n1; i0 += NTHR / 4) {
             const int i = i0 + (tid >> 2);
             const int qn = (a.n2 + 3) / 4, j0 = sub * qn, j1 = min(a.n2, j0 + qn);
             float best = INFINITY;
@@ -924,20 +925,27 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
         const int RWc4 = a.ps + (NL4 - 1) * a.stride;
         const size_t stage4 = (size_t)RWc4 * 3 * (a.TxP + a.TyP), epi4 = (size_t)a.TxP * a.TyP + a.n2;   // the epilogue aliases the staging
         const size_t lds4 = (stage4 > epi4 ? stage4 : epi4) * sizeof(float);
-        const bool use_v4 = (pv == 0 || pv == 4) && ntiles4 <= NN_THREADS && lds4 <= 150 * 1024;
+        const bool use_v4 = (pv == 0 || pv == 4) && ntiles4 <= 1024 && lds4 <= 150 * 1024;
         if (use_v4) {
             static bool attr4 = false;
             if (!attr4) {
-                VL3D_HIP(hipFuncSetAttribute((const void *)patchnn4_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                VL3D_HIP(hipFuncSetAttribute((const void *)patchnn4_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define VL3D_ATTR4(R, N) VL3D_HIP(hipFuncSetAttribute((const void *)patchnn4_k<R, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+                VL3D_ATTR4(true, 256); VL3D_ATTR4(false, 256); VL3D_ATTR4(true, 512); VL3D_ATTR4(false, 512);
+                VL3D_ATTR4(true, 1024); VL3D_ATTR4(false, 1024);
+#undef VL3D_ATTR4
                 attr4 = true;
             }
             const int groups_x = (a.w_o + NL4 - 1) / NL4;
-            // running sums pay when a column is shared by >= 2 locations on average (ps 11 / stride 4: 2.75; ps 3 / stride 2: 1.5)
-            if (a.ps >= 2 * a.stride)
-                hipLaunchKernelGGL(patchnn4_k<true>, dim3((unsigned)(groups_x * a.h_o)), dim3(NN_THREADS), lds4, s, b, desc->H, groups_x);
-            else
-                hipLaunchKernelGGL(patchnn4_k<false>, dim3((unsigned)(groups_x * a.h_o)), dim3(NN_THREADS), lds4, s, b, desc->H, groups_x);
+            const dim3 grid4((unsigned)(groups_x * a.h_o));
+            // running sums pay when a column is shared by >= 2 locations on average (ps 11 / stride 4: 2.75; ps 3 / stride 2: 1.5);
+            // one frame-pair tile per thread: 256 threads for the shipped clips, 512 / 1024 for longer ones
+            const bool runsum = a.ps >= 2 * a.stride;
+            const int nthr = ntiles4 <= 256 ? 256 : (ntiles4 <= 512 ? 512 : 1024);
+#define VL3D_LAUNCH4(R, N) hipLaunchKernelGGL((patchnn4_k<R, N>), grid4, dim3(N), lds4, s, b, desc->H, groups_x)
+            if (nthr == 256) { if (runsum) VL3D_LAUNCH4(true, 256); else VL3D_LAUNCH4(false, 256); }
+            else if (nthr == 512) { if (runsum) VL3D_LAUNCH4(true, 512); else VL3D_LAUNCH4(false, 512); }
+            else { if (runsum) VL3D_LAUNCH4(true, 1024); else VL3D_LAUNCH4(false, 1024); }
+#undef VL3D_LAUNCH4
         } else if (use_mf) {
             const size_t fixed3 = ((size_t)64 * TyT * 16 + a.n2 + 64 + TyT * 16) * sizeof(float);
             int kc3 = (int)((48 * 1024 > fixed3 + 16 * (a.TxP + a.TyP) * sizeof(float) ? 48 * 1024 - fixed3 : 16 * (a.TxP + a.TyP) * sizeof(float)) /
