@@ -240,3 +240,23 @@ def test_y_scratch_cache_is_invalidated_by_in_place_updates(dev):
     y3 = synth.make_video(12, 21, 25, seed=4, device=dev)
     assert torch.equal(run(y3[:, :, 2:]), ref(y3[:, :, 2:]))            # a view with an offset
     assert torch.equal(run(y3[:, :, :10]), ref(y3[:, :, :10]))          # same storage, different view
+
+
+@pytest.mark.parametrize("case", ["video_smaller_than_patch", "clip_shorter_than_patch", "spatial_mismatch", "target_shorter_than_patch"])
+def test_loss_refuses_what_the_reference_refuses(dev, case):
+    """inputs no patch fits into, or patch grids that do not coincide: the reference's unfold / bmm raise RuntimeError
+    (utils_vid.py:60-69, 213-217); here the ABI status becomes a RuntimeError as well -- no crash, no silent zero loss."""
+    from videoloop3d_amd.utils_vid import Patch3DGPNNLowMemLoss, FindNNpatchAndMerge
+    shapes = {"video_smaller_than_patch": ((1, 3, 6, 5, 9), (1, 3, 8, 5, 9)),
+              "clip_shorter_than_patch": ((1, 3, 2, 15, 15), (1, 3, 8, 15, 15)),
+              "spatial_mismatch": ((1, 3, 6, 15, 15), (1, 3, 8, 15, 19)),
+              "target_shorter_than_patch": ((1, 3, 6, 15, 15), (1, 3, 2, 15, 15))}[case]
+    x = synth.hash_uniform(shapes[0], seed=1).to(dev).requires_grad_(True)
+    y = synth.hash_uniform(shapes[1], seed=2).to(dev)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(RuntimeError):
+            FindNNpatchAndMerge(x, y, 7, 3, 2, 1)
+        if case != "spatial_mismatch":                     # the loss class crops y to x's trimmed size first (utils_vid.py:319-320)
+            with pytest.raises(RuntimeError):
+                Patch3DGPNNLowMemLoss()(x, y, macro_block=15, patch_size=7, stride=2, patcht_size=3, stridet=1, rou="-2", scaling=0.1)

@@ -535,3 +535,42 @@ def test_tile_culling_with_regularisers_matches_oracle(dev, variant):
     assert maxabs(rgb, rgb_o) <= TOL
     assert float(((sums.cpu() - sums_o).abs() / sums_o.abs().clamp_min(1.0)).max()) <= 1e-4
     assert maxabs(gs, gs_o) <= TOL * max(1.0, float(gs_o.abs().max()))
+
+
+@pytest.mark.parametrize("empty", ["frames", "rows", "cols"])
+def test_empty_render_is_empty_like_the_reference(dev, empty):
+    """an empty `ts` / zero-area crop gives empty outputs and a zero stack gradient (grid_sample + cumprod on empty tensors,
+    MPV.py:425-454), on every wrapper; the ABI itself refuses non-positive dims (test below)."""
+    from videoloop3d_amd.render import RenderSpec, render_planes, render_planes_with_regularisers
+    D, Hs, Ws = 3, 12, 20
+    T, H, W = (0, 8, 10) if empty == "frames" else ((2, 0, 10) if empty == "rows" else (2, 8, 0))
+    stack = (synth.make_plane_stack(D, max(T, 1), Hs, Ws, seed=3)[:, :T]).to(dev).requires_grad_(True)
+    homos = torch.eye(3).repeat(D, 1, 1).to(dev)
+    rgb, alpha = render_planes(stack, homos, H, W, RenderSpec.mpv())
+    assert rgb.shape == (T, H, W, 3) and alpha.shape == (T, H, W) and rgb.numel() == 0
+    rgb, alpha, sums, asum = render_planes_with_regularisers(stack, homos, H, W)
+    assert asum.shape == (T, H, W, 2) and float(sums.detach().abs().sum()) == 0.0
+    (g,) = torch.autograd.grad(rgb.sum() + alpha.sum() + sums.sum() + asum.sum(), stack)
+    assert g.shape == stack.shape and float(g.abs().sum()) == 0.0
+
+
+def test_abi_refuses_bad_dims_with_a_status_not_a_crash(dev):
+    """SURVEY §8b 'Errors': the native side returns an int status that the wrapper turns into RuntimeError; never aborts."""
+    from videoloop3d_amd import _lib as L
+    from videoloop3d_amd.render import RenderSpec, _desc
+    stack = synth.make_plane_stack(2, 1, 8, 8, seed=1).to(dev)
+    homos = torch.eye(3).repeat(2, 1, 1).to(dev)
+    out = torch.empty((1, 4, 4, 3), device=dev)
+    al = torch.empty((1, 4, 4), device=dev)
+    d = _desc(stack, 4, 4, RenderSpec(), 0, 0)
+    for field in ("D", "T", "Hs", "Ws", "H", "W"):
+        keep = getattr(d, field)
+        setattr(d, field, 0)
+        rc = L.lib().vl3d_render_fwd(d, L.ptr(stack), L.ptr(homos), L.ptr(out), L.ptr(al), None, L.stream_ptr(dev))
+        assert rc == 1                                                       # VL3D_EINVAL
+        with pytest.raises(RuntimeError, match="non-positive render dims"):
+            L.check(rc, "vl3d_render_fwd")
+        setattr(d, field, keep)
+    assert L.lib().vl3d_render_fwd(d, None, L.ptr(homos), L.ptr(out), L.ptr(al), None, L.stream_ptr(dev)) == 1
+    d.stack_dtype = 7
+    assert L.lib().vl3d_render_fwd(d, L.ptr(stack), L.ptr(homos), L.ptr(out), L.ptr(al), None, L.stream_ptr(dev)) == 1

@@ -74,6 +74,14 @@ class _RenderPlanes(torch.autograd.Function):
             raise RuntimeError(f"homos must be [D,3,3] = [{D},3,3], got {tuple(homos.shape)}")
         rgb = torch.empty((T, H, W, 3), dtype=torch.float32, device=stack.device)
         alpha = torch.empty((T, H, W), dtype=torch.float32, device=stack.device)
+        ctx.nothing_to_render = T == 0 or H == 0 or W == 0
+        if ctx.nothing_to_render:
+            # an empty `ts` / zero-area crop: grid_sample + cumprod of the reference return empty tensors (MPV.py:425-454); the
+            # ABI refuses non-positive dims, so the empty case never reaches it
+            ctx.save_for_backward(stack)
+            z = torch.zeros
+            return (rgb, alpha, z(4, dtype=torch.float32, device=stack.device),
+                    z((T, H, W, 2) if with_reg else (0,), dtype=torch.float32, device=stack.device))
         desc = _desc(stack, H, W, spec, row0, col0)
         asum = torch.empty((T, H, W, 2), dtype=torch.float32, device=stack.device) if with_reg else None
         with torch.cuda.device(stack.device):
@@ -106,6 +114,8 @@ class _RenderPlanes(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_alpha, g_sums, g_asum):
+        if ctx.nothing_to_render:
+            return (torch.zeros_like(ctx.saved_tensors[0]),) + (None,) * 8
         stack, homos, rgb, alpha = ctx.saved_tensors
         g_reg = g_sums.to(torch.float32).contiguous() if (ctx.with_reg and g_sums is not None) else None
         g_asum = g_asum.to(torch.float32).contiguous() if (ctx.with_reg and g_asum is not None) else None
