@@ -148,12 +148,14 @@ def test_errors_are_python_exceptions(dev):
         FindNNpatchAndMerge(x, x, 5, 3, 2, 1, dist_fn='ssim')
 
 
-def test_native_crop_loss_property(dev):
-    """native training crop 180x320 (trimmed to 179x319), T=50+2, Ty=75: properties that need no oracle:
+@pytest.mark.parametrize("H,W", [(180, 320), (720, 1280)])
+def test_native_crop_loss_property(dev, H, W):
+    """native training crop 180x320 (trimmed to 179x319) and the full 720p frame of the bench's loss leg, T=50+2, Ty=75:
+    properties that need no oracle:
     vote counts equal the analytic patch-cover count; y2x values are convex combinations of y (within its range);
     x == a time-shifted copy of y gives zero loss with the exact shift recovered."""
     from videoloop3d_amd.utils_vid import Patch3DGPNNLowMemLoss, _nn_and_fold
-    y = synth.make_video(75, 180, 320, seed=4, device=dev)
+    y = synth.make_video(75, H, W, seed=4, device=dev)
     x = y[:, :, 7:59].clone().requires_grad_(True)            # 52 frames = y shifted by 7
     for cfg in (dict(macro_block=65, patch_size=11, stride=4, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=10000),
                 dict(macro_block=65, patch_size=3, stride=2, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=10000)):
@@ -163,7 +165,7 @@ def test_native_crop_loss_property(dev):
             loss = lm(x, y, **cfg)
         assert loss.item() <= 1e-12
         ps, s = cfg["patch_size"], cfg["stride"]
-        h, w = (180 - ps) // s * s + ps, (320 - ps) // s * s + ps
+        h, w = (H - ps) // s * s + ps, (W - ps) // s * s + ps
         _, _, nn = _nn_and_fold(x.detach()[..., :h, :w], y[..., :h, :w], ps, 3, s, 1, None, True)
         assert (nn == (torch.arange(50, device=dev, dtype=torch.int32) + 7)).all()
         # analytic cover count along one axis

@@ -574,3 +574,37 @@ def test_abi_refuses_bad_dims_with_a_status_not_a_crash(dev):
     assert L.lib().vl3d_render_fwd(d, None, L.ptr(homos), L.ptr(out), L.ptr(al), None, L.stream_ptr(dev)) == 1
     d.stack_dtype = 7
     assert L.lib().vl3d_render_fwd(d, L.ptr(stack), L.ptr(homos), L.ptr(out), L.ptr(al), None, L.stream_ptr(dev)) == 1
+
+
+def test_cfg3_full_size_frame_independence_and_linearity(dev):
+    """BASELINE.json's metric configuration at FULL size (D=32, T=50, 720p: a 23.6 GB stack and as much gradient), through
+    size-independent properties: frames are independent (utils_mpi.py:159-176 has no cross-frame term), so a stack whose 50
+    frames are copies of one frame renders 50 bit-identical images and receives 50 bit-identical gradient frames, each
+    bit-equal to a T=1 call (pinned against the oracle at this size by test_720p_window_vs_oracle); and the backward is
+    linear in the incoming gradient.  Catches 32-bit offset overflow and frame-stride mistakes no small case can show."""
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 120 * 2**30:
+        pytest.skip("needs 120 GiB of free HBM")
+    D, T, Hs, Ws, H, W = 32, 50, 720, 1280, 720, 1280
+    one = synth.make_plane_stack(D, 1, Hs, Ws, seed=2, device=dev)
+    homos = bench_homos(D, H, W).to(dev)
+    g1 = synth.hash_uniform((1, H, W, 3), seed=5, device=dev) - 0.5
+    g2 = synth.hash_uniform((1, H, W, 3), seed=6, device=dev) - 0.5
+    s1 = one.clone().requires_grad_(True)
+    rgb1, _ = render_planes(s1, homos, H, W, RenderSpec.mpv())
+    (gs1,) = torch.autograd.grad(rgb1, s1, g1, retain_graph=True)
+    (gs2,) = torch.autograd.grad(rgb1, s1, g2, retain_graph=True)
+    (gs12,) = torch.autograd.grad(rgb1, s1, g1 + 0.5 * g2)
+    assert _tile_ran() == 1
+    lin = (gs12 - (gs1 + 0.5 * gs2)).abs().max()
+    assert float(lin) <= 2e-6 * max(1.0, float(gs12.abs().max()))
+    del gs2, gs12
+    full = one.expand(D, T, Hs, Ws, 4).contiguous().requires_grad_(True)
+    assert full.numel() * 4 > 2**34                                       # really beyond 32-bit byte offsets
+    rgb, alpha = render_planes(full, homos, H, W, RenderSpec.mpv())
+    assert torch.equal(rgb, rgb1.expand(T, H, W, 3))
+    (gs,) = torch.autograd.grad(rgb, full, g1.expand(T, H, W, 3).contiguous())
+    assert _tile_ran() == 1
+    for t0 in range(0, T, 10):                                            # compare in slabs to bound the temporaries
+        assert torch.equal(gs[:, t0:t0 + 10], gs1.expand(D, 10, Hs, Ws, 4))
