@@ -8,8 +8,12 @@ import torch
 from oracle import mpi_oracle as MO
 from videoloop3d_amd import synth
 
+import os
+
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+# VL3D_FUZZ_EXTRA=n widens both fuzzers by n more seeds (soak runs; the default suite stays short)
+_EXTRA = int(os.environ.get("VL3D_FUZZ_EXTRA", "0"))
 
 
 @pytest.fixture(scope="module")
@@ -39,7 +43,7 @@ def _case(seed):
     return D, T, Hs, Ws, H, W, homos, spec
 
 
-@pytest.mark.parametrize("seed", list(range(28)))
+@pytest.mark.parametrize("seed", list(range(28 + _EXTRA)))
 def test_render_fuzz(dev, seed):
     from videoloop3d_amd.render import RenderSpec, render_planes
     D, T, Hs, Ws, H, W, homos, kw = _case(seed)
@@ -56,7 +60,7 @@ def test_render_fuzz(dev, seed):
     assert float((gs.cpu() - gs_o).abs().max()) <= TOL * max(1.0, float(gs_o.abs().max()))
 
 
-@pytest.mark.parametrize("seed", list(range(16)))
+@pytest.mark.parametrize("seed", list(range(16 + _EXTRA)))
 def test_loss_fuzz(dev, seed):
     """fused NN + vote-fold + robust loss (vl3d_patchnn + vl3d_vote_fold_robust) against the oracle on random configurations:
     y2x / weight / loss / gradient; NN ties are avoided by the hash-uniform inputs."""
@@ -156,3 +160,62 @@ def test_loss_long_videos_fall_back_gracefully(dev, Tx, Ty):
     (gx_r,) = torch.autograd.grad(loss_r, xr)
     assert abs(float(loss.detach()) - float(loss_r)) <= 1e-5 * max(1.0, abs(float(loss_r)))
     assert float((gx.cpu() - gx_r).abs().max()) <= 1e-5 * max(1.0, float(gx_r.abs().max()))
+
+
+@pytest.mark.parametrize("seed", list(range(18 + _EXTRA)))
+def test_render_feature_fuzz(dev, seed):
+    """multi-tile frames with the features a stage-2 iteration combines, in random combinations: tile-culling maps of random
+    density and quad grid, a row/column window (band sharding), the fused layer regularisers and the alpha-sum outputs, both
+    backward kernels (variant 1 = atomics), against the oracle's materialised layers."""
+    from videoloop3d_amd.render import RenderSpec, render_planes_with_regularisers
+    g = torch.Generator().manual_seed(7000 + seed)
+    r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    u = lambda lo, hi: float(torch.rand(1, generator=g)) * (hi - lo) + lo
+    D, T = r(1, 9), r(1, 2)
+    Hf, Wf = r(20, 150), r(30, 260)                                    # full frame; the rendered window is a part of it
+    row0, col0 = (r(0, Hf // 2), r(0, Wf // 2)) if seed % 2 else (0, 0)
+    H, W = r(1, Hf - row0), r(1, Wf - col0)
+    mag = u(1.0, 1.25)
+    Hs, Ws = max(2, int(Hf * mag)), max(2, int(Wf * mag))
+    th = math.radians(u(-3, 3))
+    base = torch.tensor([[math.cos(th) * mag, -math.sin(th) * mag, u(-2, 2)], [math.sin(th) * mag, math.cos(th) * mag, u(-2, 2)],
+                         [u(-5e-5, 5e-5), u(-5e-5, 5e-5), 1.0]])
+    homos = torch.stack([base + torch.tensor([[0, 0, 1.3 * d], [0, 0, -0.6 * d], [0, 0, 0.0]]) for d in range(D)])
+    kw = [dict(pixel_center=0.5, coord_mode="affine", border="hardcut", act_order="post"), dict(),
+          dict(border="hardcut")][seed % 3]
+    keep = None
+    if seed % 4 != 3:
+        keep = torch.rand(D, r(1, 7), r(1, 9), generator=g) < u(0.0, 1.0)
+    variant = 1 if seed % 5 == 4 else 0
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=300 + seed)
+    g_rgb = synth.hash_uniform((T, H, W, 3), seed=5) - 0.5
+    g_a = synth.hash_uniform((T, H, W), seed=6) - 0.5
+    wts = torch.tensor([1e-3, 2e-3, 3e-3, 4e-3]) * (seed % 2)
+    # oracle: render the FULL frame's window by shifting the homographies (utils.py:196-200 on the target intrinsics)
+    shift = torch.tensor([[1.0, 0, col0], [0, 1.0, row0], [0, 0, 1.0]])
+    s_cpu = stack.clone().requires_grad_(True)
+    rgb_o, alpha_o, _, layers = MO.render_planes(s_cpu, homos @ shift, H, W, MO.RenderSpec(**kw), return_layers=True, quad_keep=keep)
+    la = layers[..., 3]
+    asum_o = torch.stack([la.sum(-1), (la * la).sum(-1)], -1)
+    dx = lambda c: (layers[:, :, 1:, :, c] - layers[:, :, :-1, :, c]).abs().sum()
+    dy = lambda c: (layers[:, 1:, :, :, c] - layers[:, :-1, :, :, c]).abs().sum()
+    sums_o = torch.stack([dx(slice(0, 3)), dy(slice(0, 3)), dx(3), dy(3)])
+    sparsity_o = (asum_o[..., 0] / asum_o[..., 1].clamp_min(1e-6).sqrt()).mean()
+    (gs_o,) = torch.autograd.grad((rgb_o * g_rgb).sum() + (alpha_o * g_a).sum() + (sums_o * wts).sum() + 0.1 * sparsity_o, s_cpu, retain_graph=True)
+    s_gpu = stack.to(dev).requires_grad_(True)
+    rgb, alpha, sums, asum = render_planes_with_regularisers(s_gpu, homos.to(dev), H, W, RenderSpec(variant=variant, **kw),
+                                                             window=(row0, col0), quad_keep=None if keep is None else keep.to(dev))
+    sparsity = (asum[..., 0] / asum[..., 1].clamp_min(1e-6).sqrt()).mean()
+    (gs,) = torch.autograd.grad((rgb * g_rgb.to(dev)).sum() + (alpha * g_a.to(dev)).sum() + (sums * wts.to(dev)).sum() + 0.1 * sparsity, s_gpu, retain_graph=True)
+    assert float((rgb.detach().cpu() - rgb_o.detach()).abs().max()) <= TOL and float((alpha.detach().cpu() - alpha_o.detach()).abs().max()) <= TOL
+    assert float((asum.detach().cpu() - asum_o).abs().max()) <= TOL * max(1.0, D / 4)
+    assert float(((sums.detach().cpu() - sums_o).abs() / sums_o.abs().clamp_min(1.0)).max()) <= 1e-4
+    d = (gs.cpu() - gs_o).abs()
+    tol = TOL * max(1.0, float(gs_o.abs().max()))
+    if float(wts.max()) == 0.0:
+        assert float(d.max()) <= tol
+    else:
+        # |L[p] - L[q]| has a kink at 0: where two neighbouring layer values agree to fp32 noise the sign -- and with it the
+        # gradient of the (at most 4) taps of both pixels -- is decided by rounding.  Such pairs are isolated and each moves a
+        # texel by at most 2 * weight (profiles/debug_fuzz.py prints them); everything else has to match.
+        assert float(d.max()) <= 2.0 * float(wts.max()) + tol and int((d > tol).sum()) <= 64
