@@ -77,7 +77,8 @@ int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, const float
  * scratch: caller-owned device buffer of vl3d_render_bwd_scratch_bytes(desc) bytes (plan written and read on
  * `stream`, no host sync); with scratch == NULL the universal global-atomics kernel is used.
  * desc->variant: 0 auto (LDS-staged owner-computes kernel when its on-device feasibility plan allows, atomics
- * kernel otherwise), 1 force atomics, 2/3 owner-computes kernel with 8-/16-row regions. */
+ * kernel otherwise), 1 force atomics, 2/3 owner-computes kernel with 8-/16-row regions, 4 = 3 with the 3x3 gather everywhere
+ * (reference for the 2x2 gather of no-minification tiles, which must equal it bit for bit). */
 int64_t vl3d_render_bwd_scratch_bytes(const vl3d_render_desc *desc);
 int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, const float *homos,
                     const float *rgb, const float *alpha, const float *grad_rgb, const float *grad_alpha,

@@ -608,3 +608,31 @@ def test_cfg3_full_size_frame_independence_and_linearity(dev):
     assert _tile_ran() == 1
     for t0 in range(0, T, 10):                                            # compare in slabs to bound the temporaries
         assert torch.equal(gs[:, t0:t0 + 10], gs1.expand(D, 10, Hs, Ws, 4))
+
+
+@pytest.mark.parametrize("stack_scale", [1.0, 1.1, 1.35])
+@pytest.mark.parametrize("spec_name", ["mpv", "utils_mpi"])
+def test_bwd_2x2_gather_equals_3x3_gather_bitwise(dev, spec_name, stack_scale):
+    """tiles on which pixels are >= 1 texel apart (no minification: the reference stores its stacks at 1.1x the frame,
+    configs/mpv_base.txt:10-11) gather from the 2x2 staged pixels towards the texel instead of 3x3: the five pixels left out
+    have tent weight exactly 0, so the gradient must equal the 3x3 gather's (variant 4) bit for bit -- at 1.0 (benchmark
+    cameras: about half of the tiles qualify), 1.1 and 1.35 (all qualify), with plane borders inside the frame."""
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    D, T, H, W = 6, 2, 300, 500
+    Hs, Ws = int(H * stack_scale) - 7, int(W * stack_scale) - 11          # a little smaller than the footprint: borders in view
+    kw_p, _ = SPECS[spec_name]
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=21, device=dev).requires_grad_(True)
+    homos = bench_homos(D, H, W).to(dev)
+    if spec_name == "mpv":
+        kw_p = dict(kw_p, scale=(stack_scale, stack_scale), offset=(-2.0, -3.0))
+    else:
+        homos = torch.diag(torch.tensor([Ws / W, Hs / H, 1.0])).to(dev) @ homos
+    g = synth.hash_uniform((T, H, W, 3), seed=5, device=dev) - 0.5
+    out = {}
+    for variant in (0, 4):
+        rgb, _ = render_planes(stack, homos, H, W, RenderSpec(variant=variant, **kw_p))
+        (gs,) = torch.autograd.grad(rgb, stack, g)
+        assert _tile_ran() == 1
+        out[variant] = gs
+    assert torch.equal(out[0], out[4])
+    assert float(out[0].abs().max()) > 1e-3

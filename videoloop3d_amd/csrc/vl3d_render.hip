@@ -36,6 +36,7 @@ struct RenderArgs {
     int tiles_x, tiles_y; // tile grid of the owner-computes backward
     int fwd_variant;     // forward kernel selector (see launch<>)
     int ablate;          // measurement-only switches (bit0: skip LDS scatter, bit1: skip flush stores, bit2: skip tap loads)
+    int gather9;         // 1: never take the 2x2 gather (variant 4; the 3x3 gather is the definition the 2x2 one must equal bit for bit)
     const float *plan;   // device scratch written by bwd_plan_k: [0] feasible flag, [16 + 12*d ..] inverse texel homographies,
                          // then (bwd_windows_k) one int4 texel window per (tile, plane)
     const unsigned short *owner;   // device scratch written by bwd_owner_table_k: per (plane, texel) a 6-bit code of the owner
@@ -224,6 +225,31 @@ __device__ __forceinline__ void load_taps2(const char *__restrict__ plane, const
     v[3] = load_texel<F16>(plane + st.dy + st.dx, t.off);
 }
 
+// fp16 stacks in sample-then-activate order keep their taps packed (2 VGPRs per tap instead of 4) and convert inside the
+// blend's FMAs: v_fma_mix_f32 reads an f16 half as one source and computes in fp32, i.e. exactly cvt + fma, in one plain-rate
+// instruction.  The 16 v_cvt_f32_f16 per pixel and plane this removes were ~20 % of the fp16 forward's VALU issue time.
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+template <bool F16, int ORDER> struct TapVal { typedef f4 type; };
+template <> struct TapVal<true, VL3D_ACT_POST> { typedef u2 type; };
+
+template <bool F16>
+__device__ __forceinline__ void load_taps2(const char *__restrict__ plane, const Taps2 &t, TapStep st, u2 v[4]) {
+    static_assert(F16, "packed taps are fp16 texels");
+    const size_t o = (size_t)(t.off >> 1);
+    v[0] = *reinterpret_cast<const u2 *>(plane + o);
+    v[1] = *reinterpret_cast<const u2 *>(plane + st.dx + o);
+    v[2] = *reinterpret_cast<const u2 *>(plane + st.dy + o);
+    v[3] = *reinterpret_cast<const u2 *>(plane + st.dy + st.dx + o);
+}
+
+template <int HI>
+__device__ __forceinline__ float fma_mix(unsigned hpair, float w, float acc) {      // (float)half[HI] * w + acc
+    float r;
+    if constexpr (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(w), "v"(acc));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(w), "v"(acc));
+    return r;
+}
+
 template <int RACT, int AACT>
 __device__ __forceinline__ f4 act4(f4 s) {
     return f4{act_fwd<RACT>(s.x), act_fwd<RACT>(s.y), act_fwd<RACT>(s.z), act_fwd<AACT>(s.w)};
@@ -242,6 +268,21 @@ __device__ __forceinline__ f4 shade2(const Taps2 &t, const f4 v[4], f4 *pre_out 
         if (pre_out) *pre_out = s;
     }
     s.w *= t.cov;    // uncovered: a = 0 (and c irrelevant) -> the plane drops out of the composite
+    return s;
+}
+
+// the same blend (same association: v3 w3, then fma v2, v1, v0 -- bit-identical to the f4 overload on the converted values)
+template <int ORDER, int RACT, int AACT>
+__device__ __forceinline__ f4 shade2(const Taps2 &t, const u2 v[4], f4 *pre_out = nullptr) {
+    static_assert(ORDER == VL3D_ACT_POST, "packed taps: sample-then-activate only");
+    f4 s;
+    s.x = fma_mix<0>(v[0].x, t.w[0], fma_mix<0>(v[1].x, t.w[1], fma_mix<0>(v[2].x, t.w[2], fma_mix<0>(v[3].x, t.w[3], 0.0f))));
+    s.y = fma_mix<1>(v[0].x, t.w[0], fma_mix<1>(v[1].x, t.w[1], fma_mix<1>(v[2].x, t.w[2], fma_mix<1>(v[3].x, t.w[3], 0.0f))));
+    s.z = fma_mix<0>(v[0].y, t.w[0], fma_mix<0>(v[1].y, t.w[1], fma_mix<0>(v[2].y, t.w[2], fma_mix<0>(v[3].y, t.w[3], 0.0f))));
+    s.w = fma_mix<1>(v[0].y, t.w[0], fma_mix<1>(v[1].y, t.w[1], fma_mix<1>(v[2].y, t.w[2], fma_mix<1>(v[3].y, t.w[3], 0.0f))));
+    if (pre_out) *pre_out = s;
+    s = act4<RACT, AACT>(s);
+    s.w *= t.cov;
     return s;
 }
 
@@ -271,7 +312,8 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
     for (int d = 0; d < a.D; ++d, plane += (size_t)a.T * a.Hs * a.Ws * TEXB, gplane += (size_t)a.T * a.Hs * a.Ws * TEXB) {
         const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
         if (tp.cov == 0.0f) continue;
-        f4 tv[4], pre;
+        typename TapVal<F16, ORDER>::type tv[4];
+        f4 pre;
         load_taps2<F16>(plane, tp, st, tv);
         const f4 o = shade2<ORDER, RACT, AACT>(tp, tv, &pre);
         const float q = Gr * o.x + Gg * o.y + Gb * o.z + gA;
@@ -286,7 +328,7 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
             const f4 gx = f4{a.g_reg[0], a.g_reg[0], a.g_reg[0], a.g_reg[2]}, gy = f4{a.g_reg[1], a.g_reg[1], a.g_reg[1], a.g_reg[3]};
             auto layer = [&](float qx, float qy) {
                 const Taps2 tq = make_taps2<COORD, BORDER>(a.homos + 9 * d, qx, qy, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
-                f4 tq_v[4];
+                typename TapVal<F16, ORDER>::type tq_v[4];
                 load_taps2<F16>(plane, tq, st, tq_v);
                 return shade2<ORDER, RACT, AACT>(tq, tq_v) * tq.cov;
             };
@@ -364,7 +406,8 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
     const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * frame_b;
     float Tr = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, A = 0.f, n1 = 0.f, n2 = 0.f;
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
-    f4 vA[4], vB[4];
+    typedef typename TapVal<F16, ORDER>::type tapv_t;
+    tapv_t vA[4], vB[4];
 #define VL3D_COMPOSITE(T_, V_)                                        \
     {                                                                 \
         const f4 o = shade2<ORDER, RACT, AACT>(T_, V_);               \
@@ -385,7 +428,7 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
             else if (m1) { d = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
             return d;
         };
-        auto fetch = [&](int d, Taps2 &t, f4 *v) {
+        auto fetch = [&](int d, Taps2 &t, tapv_t *v) {
             float h[9];
             load_uniform(a.homos + 9 * d, h);
             t = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
@@ -568,10 +611,31 @@ __global__ __launch_bounds__(256) void bwd_windows_k(RenderArgs a, int iw, int i
     const int wX0 = max(0, (int)ceilf(fmaxf(mnx - 0.01f, -2.0f))), wY0 = max(0, (int)ceilf(fmaxf(mny - 0.01f, -2.0f)));
     const int wX1 = min(a.Ws - 1, (int)floorf(fminf(mxx + 0.01f, (float)a.Ws)));
     const int wY1 = min(a.Hs - 1, (int)floorf(fminf(mxy + 0.01f, (float)a.Hs)));
-    const int ww = min(max(0, wX1 - wX0 + 1), 0xffff), wh = min(max(0, wY1 - wY0 + 1), 0x7fff);
+    const int ww = min(max(0, wX1 - wX0 + 1), 0xffff), wh = min(max(0, wY1 - wY0 + 1), 0x3fff);
     int4 rec;
     const bool empty = ww == 0 || wh == 0;    // keep the corner a valid texel: the gather prefetches relative to it
     rec.x = empty ? 0 : wX0; rec.y = empty ? 0 : wY0; rec.z = empty ? 0 : (ww | (wh << 16)); rec.w = __float_as_int(1.0f / (float)max(ww, 1));
+    // bit 30: "pixels are at least a texel apart" on this tile -- J = d texel / d pixel has J00 - |J01| >= 1 and J11 - |J10| >= 1
+    // on the tile's region.  Then, for a texel tau with owner pixel p0 and u = tau - t(p0), the pixel p0 + e with e_x = -sign(u_x)
+    // lies at |t_x(p0+e) - tau_x| = J00 + |u_x| -/+ J01 e_y >= 1, i.e. has tent weight exactly 0 (same along y): only the 2x2
+    // block of p0 towards tau contributes, and the gather reads 4 staged pixels instead of 9 (no-minification views, e.g.
+    // stacks stored at >= the frame's resolution as the reference's are: mpi_h/w_scale 1.1, configs/mpv_base.txt:10-11).
+    {
+        float ax, ay;
+        if constexpr (COORD == VL3D_COORD_UTILS_MPI) { ax = (float)(a.Ws - 1) / (float)a.Ws; ay = (float)(a.Hs - 1) / (float)a.Hs; }
+        else { ax = a.sx; ay = a.sy; }
+        bool apart = !a.gather9;
+        for (int c = 0; c < 4; ++c) {     // region corners (tile + halo); J is monotone enough over <= 70 pixels for the 1e-3 margin
+            const float cx = (float)a.col0 + a.pc + (float)((c & 1) ? tile_x * iw + iw - 1 + rh + 1 : ix0 - rh - 1);
+            const float cy = (float)a.row0 + a.pc + (float)((c & 2) ? tile_y * ih + ih - 1 + rh + 1 : iy0 - rh - 1);
+            const float X = h[0] * cx + h[1] * cy + h[2], Y = h[3] * cx + h[4] * cy + h[5], Z = h[6] * cx + h[7] * cy + h[8];
+            const float iz2 = 1.0f / (Z * Z);
+            const float j00 = ax * (h[0] * Z - X * h[6]) * iz2, j01 = ax * (h[1] * Z - X * h[7]) * iz2;
+            const float j10 = ay * (h[3] * Z - Y * h[6]) * iz2, j11 = ay * (h[4] * Z - Y * h[7]) * iz2;
+            apart = apart && (Z > 0.0f) && (j00 - fabsf(j01) >= 1.001f) && (j11 - fabsf(j10) >= 1.001f);
+        }
+        if (apart && !empty) rec.z |= 0x40000000;
+    }
     if (a.quad_keep) {
         // tile culling: bit 31 of the size word = no pixel of the tile's region (interior + halo) can see a kept quad of this
         // plane -> the tile kernel skips the plane's sweep and writes zeros to the texels it owns
@@ -661,7 +725,7 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
     __shared__ float4 s_o[REG ? NT : 1];
     // per-plane staging of the region's pixels, double buffered so one barrier per plane suffices
     __shared__ float4 s_g[2][NT];     // gradient w.r.t. the sampled (POST) / activated (PRE) value of this pixel on this plane
-    __shared__ float2 s_t[2][NT];     // its texel coordinates (tx,ty); -1e30 when the plane does not cover the pixel
+    __shared__ float2 s_t[2][NT];     // its texel coordinates (tx,ty) (true ones also where the plane does not cover it: then g = 0)
     const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
     // 1-D grid, XCD-aware order: every XCD walks a contiguous run of tiles (row-major within a frame), so a tile's halo
     // rows and its neighbours' taps hit the same L2
@@ -706,8 +770,9 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
         load_uniform(a.homos + 9 * d, h);
         // texel window of this tile on plane d (wave = window row, lane = window column); bit 31: culled for this tile
         const int X0 = wrec[4 * d], Y0 = wrec[4 * d + 1], wwh = wrec[4 * d + 2];
-        const int ww = wwh & 0xffff, wh = (wwh >> 16) & 0x7fff;
+        const int ww = wwh & 0xffff, wh = (wwh >> 16) & 0x3fff;
         const bool culled = CULL && wwh < 0;
+        const bool apart = (wwh & 0x40000000) != 0;      // pixels >= 1 texel apart on this tile: 2x2 gather (bwd_windows_k)
         // staging buffer of this plane: alternates over the planes that are actually swept (a culled plane has no barrier)
         const int buf = CULL ? (nswept & 1) : (d & 1);
         if constexpr (CULL) nswept += culled ? 0 : 1;
@@ -732,7 +797,7 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
             continue;
         }
         // (2) sample this pixel on plane d, composite backward, stage (tx,ty,g) in LDS   (branch-free taps)
-        float2 tc = make_float2(-1e30f, -1e30f);
+        float2 tc = make_float2(0.f, 0.f);        // pixels outside the frame: any finite coordinate (their gradient is 0)
         float4 gval = make_float4(0.f, 0.f, 0.f, 0.f);
         f4 o = f4{0.f, 0.f, 0.f, 0.f}, pre = o;
         Taps2 tp{};
@@ -744,7 +809,7 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
                 src = reinterpret_cast<const char *>(a.stack);
                 tp.off &= 0xfff0u;
             }
-            f4 tv[4];
+            typename TapVal<F16, ORDER>::type tv[4];
             load_taps2<F16>(src, tp, st, tv);
             o = shade2<ORDER, RACT, AACT>(tp, tv, &pre);                 // o.w already 0 when the plane does not cover the pixel
         }
@@ -776,8 +841,10 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
             if constexpr (ORDER == VL3D_ACT_POST)
                 gval = make_float4(gval.x * act_bwd<RACT>(pre.x, o.x), gval.y * act_bwd<RACT>(pre.y, o.y),
                                    gval.z * act_bwd<RACT>(pre.z, o.z), gval.w * act_bwd<AACT>(pre.w, o.w));
-            if (tp.cov > 0.0f && provider) tc = make_float2(tp.tx, tp.ty);
-            else gval = make_float4(0.f, 0.f, 0.f, 0.f);
+            // every frame pixel stages its true coordinates (the 2x2 gather picks its block from the owner pixel's); a pixel the
+            // plane does not cover, or a layer-only halo pixel, provides a zero gradient instead of a zero weight
+            tc = make_float2(tp.tx, tp.ty);
+            if (!(tp.cov > 0.0f && provider)) gval = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         s_t[buf][tid] = tc;
         s_g[buf][tid] = gval;
@@ -791,7 +858,19 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
             const int lc = (int)(e & 1023u);
             const f2 tau = f2{(float)(X0 + wx), (float)(Y0 + wy)};
             f4 acc = f4{0.f, 0.f, 0.f, 0.f};
-            if (!(a.ablate & 8))
+            if (a.ablate & 8) {
+            } else if (apart) {
+                // 2x2 block of the owner pixel towards tau, summed in the 3x3 loop's order: the five pixels left out have weight
+                // exactly 0 there, so both gathers give the same bits
+                const f2 c0 = *reinterpret_cast<const f2 *>(&s_t[buf][lc]);
+                const int li0 = lc - (tau.x < c0.x ? 1 : 0) - (tau.y < c0.y ? RW : 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int li = li0 + (k >> 1) * RW + (k & 1);
+                    const f2 dc = *reinterpret_cast<const f2 *>(&s_t[buf][li]) - tau;
+                    acc += *reinterpret_cast<const f4 *>(&s_g[buf][li]) * (tent_weight(dc.x) * tent_weight(dc.y));
+                }
+            } else {
 #pragma unroll
             for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
@@ -800,6 +879,7 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
                     const f2 dc = *reinterpret_cast<const f2 *>(&s_t[buf][li]) - tau;
                     acc += *reinterpret_cast<const f4 *>(&s_g[buf][li]) * (tent_weight(dc.x) * tent_weight(dc.y));
                 }
+            }
             if constexpr (ORDER == VL3D_ACT_PRE) {   // d act(s_tau)/d s_tau factors out of the tap sum
                 const f4 sv = load_texel<F16>(plane, tix << 4);
                 acc = f4{acc.x * act_bwd<RACT>(sv.x, act_fwd<RACT>(sv.x)), acc.y * act_bwd<RACT>(sv.y, act_fwd<RACT>(sv.y)),
@@ -866,7 +946,7 @@ __global__ __launch_bounds__(RW *ROWS) void render_reg_fwd_k(RenderArgs a) {
         f4 ol = f4{0.f, 0.f, 0.f, 0.f};
         if (inimg) {
             const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
-            f4 tv[4];
+            typename TapVal<F16, ORDER>::type tv[4];
             load_taps2<F16>(plane, tp, make_tap_step<F16>(a.Hs, a.Ws), tv);
             ol = shade2<ORDER, RACT, AACT>(tp, tv) * tp.cov;
         }
@@ -1167,9 +1247,10 @@ static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, cons
     a.quad_keep = quad_keep; a.QH = QH; a.QW = QW;
     a.g_f16 = desc->stack_dtype == VL3D_F16;
     // variant: 0 auto (tile kernel when its on-device plan says feasible, else atomics), 1 force atomics,
-    //          2 tile with 8-row regions, 3 tile with 16-row regions
+    //          2 tile with 8-row regions, 3 tile with 16-row regions, 4 = 3 without the 2x2 gather
     const bool want_tile = (desc->variant & 0xf) != 1 && scratch != nullptr && scratch_bytes >= vl3d_render_bwd_scratch_bytes(desc);
     a.ablate = (desc->variant >> 4) & 0xf;
+    a.gather9 = (desc->variant & 0xf) == 4;
     if (want_tile) {
         a.plan = (const float *)scratch;
         a.owner = reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(scratch) + owner_table_off(desc));
