@@ -636,3 +636,24 @@ def test_bwd_2x2_gather_equals_3x3_gather_bitwise(dev, spec_name, stack_scale):
         out[variant] = gs
     assert torch.equal(out[0], out[4])
     assert float(out[0].abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("T", [2, 5])
+@pytest.mark.parametrize("spec_name", ["mpv", "utils_mpi", "hardcut_pre"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_fwd_frame_pair_kernel_equals_single_frame_kernel_bitwise(dev, spec_name, T, dtype):
+    """render_fwd2x_k composites frames t and t+1 per thread (the coordinate half of the instruction stream is paid once): same
+    per-frame arithmetic as render_fwd2_k (forward variant 6) -> same bits, for even and odd T (last pair = one frame), with the
+    sparsity sums, fp32 and fp16 stacks."""
+    from videoloop3d_amd.render import RenderSpec, render_planes_with_regularisers
+    D, Hs, Ws, H, W = 5, 70, 150, 61, 139
+    kw_p, _ = SPECS[spec_name]
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=31, device=dev, dtype=dtype)
+    homos = bench_homos(D, H, W, scale=2.0).to(dev)
+    outs = []
+    for variant in (0, 0x600):
+        rgb, alpha, sums, asum = render_planes_with_regularisers(stack, homos, H, W, RenderSpec(variant=variant, **kw_p))
+        outs.append((rgb, alpha, asum))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert float(outs[0][0].abs().max()) > 0.01
