@@ -670,6 +670,7 @@ __global__ void bwd_plan_k(RenderArgs a, int rows, float *plan) {
     }
     __syncthreads();
     if (threadIdx.x == 0) { reinterpret_cast<int *>(plan)[0] = ok_all; reinterpret_cast<int *>(plan)[1] = 0; }
+    if (threadIdx.x < 4) plan[4 + threadIdx.x] = 0.0f;     // four zero floats: stand-in for g_reg when only the sparsity sums have a gradient
 }
 
 // Texel window of every (tile, plane): the footprint of the tile's owned pixels, from the image of its four corners
@@ -838,7 +839,8 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
         Gr = a.g_rgb[pix * 3 + 0]; Gg = a.g_rgb[pix * 3 + 1]; Gb = a.g_rgb[pix * 3 + 2];
         gA = a.g_alpha ? a.g_alpha[pix] : 0.0f;
         S = Gr * a.rgb[pix * 3 + 0] + Gg * a.rgb[pix * 3 + 1] + Gb * a.rgb[pix * 3 + 2] + gA * a.alpha[pix];
-        if (a.g_asum) { gN1 = a.g_asum[pix * 2 + 0]; gN2 = 2.0f * a.g_asum[pix * 2 + 1]; }
+        // the sparsity-sum gradients ride in the REG instantiation only (launch_t): the plain one is at its 64-VGPR budget
+        if constexpr (REG) if (a.g_asum) { gN1 = a.g_asum[pix * 2 + 0]; gN2 = 2.0f * a.g_asum[pix * 2 + 1]; }
     }
     float Tr = 1.0f, P = 0.0f;
     float gsx_c = 0.f, gsy_c = 0.f, gsx_a = 0.f, gsy_a = 0.f;
@@ -923,7 +925,7 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
             P += w * q;
             const float om = 1.0f - o.w;
             const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;
-            gval = make_float4(w * Gr + sg.x, w * Gg + sg.y, w * Gb + sg.z, Tr * q - behind + sg.w + (gN1 + gN2 * o.w));   // grad wrt activated (c, a)
+            gval = make_float4(w * Gr + sg.x, w * Gg + sg.y, w * Gb + sg.z, Tr * q - behind + sg.w + (REG ? gN1 + gN2 * o.w : 0.0f));   // grad wrt activated (c, a)
             Tr *= om;
             if constexpr (ORDER == VL3D_ACT_POST)
                 gval = make_float4(gval.x * act_bwd<RACT>(pre.x, o.x), gval.y * act_bwd<RACT>(pre.y, o.y),
@@ -1104,11 +1106,14 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
             hipLaunchKernelGGL(bwd_zero_unowned_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, a);
             bool done = false;
             if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID && !F16) {   // measurement variant (shipped activations only)
-                if (g_tile_rows == 8 && !a.g_reg) { launch_tile<COORD, BORDER, ORDER, RACT, AACT, 8, false, false>(a, s); done = true; }
+                if (g_tile_rows == 8 && !a.g_reg && !a.g_asum) { launch_tile<COORD, BORDER, ORDER, RACT, AACT, 8, false, false>(a, s); done = true; }
             }
             if (!done) {
-                if (a.g_reg) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, F16>(a, s);
-                else {
+                if (a.g_reg || a.g_asum) {     // layer regularisers and / or sparsity sums: the REG instantiation (128-VGPR budget)
+                    RenderArgs ar = a;
+                    if (!ar.g_reg) ar.g_reg = a.plan + 4;      // zeros written by bwd_plan_k
+                    launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, F16>(ar, s);
+                } else {
                     launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, false, F16>(a, s);
                 }
             }
