@@ -977,8 +977,28 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
             if (!(a.ablate & 2)) store_grad_texel<F16>(gplane, tix << 4, acc);
         };
         if (row < wh && lane < ww) gather(e0, lane, row, win0 + toff_thread);
-        for (int wy = row; wy < wh; wy += ROWS)      // rest of a window larger than 64 x ROWS (frame-border tiles, minification)
-            for (int wx = lane + (wy == row ? RW : 0); wx < ww; wx += RW) {
+        // rest of a window larger than 64 x ROWS (stacks stored above the frame's resolution, frame-border tiles, rotations)
+        const int nec = ww - RW;                     // columns right of the first 64 (uniform)
+        if (nec > 0 && nec <= RW) {
+            // right strip of the first ROWS rows, packed: 64 >> sh rows per wave (sh = ceil log2 of its width), so a 6-texel strip
+            // of 16 rows is 2 wave passes instead of 16 passes with 6 active lanes each
+            const int sh = nec > 1 ? 32 - __builtin_clz((unsigned)(nec - 1)) : 0, rpw = RW >> sh, rmain = min(wh, ROWS);
+            const int c = lane & ((1 << sh) - 1), r = lane >> sh;
+            for (int wy0 = row * rpw; wy0 < rmain; wy0 += ROWS * rpw) {
+                const int wy = wy0 + r, wx = RW + c;
+                if (c < nec && wy < rmain) {
+                    const unsigned tix = win0 + (unsigned)(wy * a.Ws + wx);
+                    gather(oplane[tix], wx, wy, tix);
+                }
+            }
+        } else if (nec > RW) {
+            for (int wx = lane + RW; wx < ww && row < wh; wx += RW) {
+                const unsigned tix = win0 + (unsigned)(row * a.Ws + wx);
+                gather(oplane[tix], wx, row, tix);
+            }
+        }
+        for (int wy = row + ROWS; wy < wh; wy += ROWS)      // rows below the first ROWS: one wave per row
+            for (int wx = lane; wx < ww; wx += RW) {
                 const unsigned tix = win0 + (unsigned)(wy * a.Ws + wx);
                 gather(oplane[tix], wx, wy, tix);
             }
