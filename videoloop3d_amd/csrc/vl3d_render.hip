@@ -36,6 +36,7 @@ struct RenderArgs {
     int tiles_x, tiles_y; // tile grid of the owner-computes backward
     int fwd_variant;     // forward kernel selector (see launch<>)
     int ablate;          // measurement-only switches (bit0: skip LDS scatter, bit1: skip flush stores, bit2: skip tap loads)
+    float q_inv_cw, q_inv_ch;   // tile culling: quads per texel along x / y = QW/(Ws-1), QH/(Hs-1) (float division done once, on the host)
     int gather9;         // 1: never take the 2x2 gather (variant 4; the 3x3 gather is the definition the 2x2 one must equal bit for bit)
     const float *plan;   // device scratch written by bwd_plan_k: [0] feasible flag, [16 + 12*d ..] inverse texel homographies,
                          // then (bwd_windows_k) one int4 texel window per (tile, plane)
@@ -128,7 +129,7 @@ struct QuadCull {
 };
 __device__ __forceinline__ QuadCull plane_cull(const RenderArgs &a, int d) {
     if (!a.quad_keep) return QuadCull{nullptr, 0, 0, 0.f, 0.f};
-    return QuadCull{a.quad_keep + (size_t)d * a.QH * a.QW, a.QH, a.QW, (float)a.QW / (float)max(a.Ws - 1, 1), (float)a.QH / (float)max(a.Hs - 1, 1)};
+    return QuadCull{a.quad_keep + (size_t)d * a.QH * a.QW, a.QH, a.QW, a.q_inv_cw, a.q_inv_ch};     // the two quotients come from the host: uniform, in SGPRs
 }
 
 // integer form of the taps: base tap (x0,y0) with x0 <= Ws-2, y0 <= Hs-2 (so the 2x2 block is inside the plane) + weights
@@ -1254,7 +1255,8 @@ static int render_fwd_impl(const vl3d_render_desc *desc, const void *stack, cons
     VL3D_REQUIRE(!quad_keep || cull_scratch, "tile culling: the forward needs vl3d_render_cull_scratch_bytes() of scratch");
     RenderArgs a = make_args(desc);
     a.stack = (const float *)stack; a.homos = homos; a.rgb = rgb; a.alpha = alpha; a.asum = alpha_sums;
-    a.quad_keep = quad_keep; a.QH = QH; a.QW = QW; a.cull_masks = (const unsigned long long *)cull_scratch;
+    a.quad_keep = quad_keep; a.QH = QH; a.QW = QW;
+    a.q_inv_cw = (float)QW / (float)(desc->Ws > 1 ? desc->Ws - 1 : 1); a.q_inv_ch = (float)QH / (float)(desc->Hs > 1 ? desc->Hs - 1 : 1); a.cull_masks = (const unsigned long long *)cull_scratch;
     a.fwd_variant = (desc->variant >> 8) & 0xf;
     a.ablate = (desc->variant >> 4) & 0xf;
     VL3D_REQUIRE((int64_t)desc->Hs * desc->Ws * 16 < (1ll << 32), "frame too large for 32-bit byte offsets");
@@ -1315,6 +1317,7 @@ static int render_reg_fwd_impl(const vl3d_render_desc *desc, const void *stack, 
     RenderArgs a = make_args(desc);
     a.stack = (const float *)stack; a.homos = homos; a.reg_sums = sums;
     a.quad_keep = quad_keep; a.QH = QH; a.QW = QW;
+    a.q_inv_cw = (float)QW / (float)(desc->Ws > 1 ? desc->Ws - 1 : 1); a.q_inv_ch = (float)QH / (float)(desc->Hs > 1 ? desc->Hs - 1 : 1);
     VL3D_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(double), (hipStream_t)stream));
     g_reg_fwd = true;
     g_f16 = desc->stack_dtype == VL3D_F16;
@@ -1361,6 +1364,7 @@ static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, cons
     a.rgb = const_cast<float *>(rgb); a.alpha = const_cast<float *>(alpha);
     a.g_rgb = grad_rgb; a.g_alpha = grad_alpha; a.g_reg = grad_reg; a.g_asum = grad_alpha_sums; a.g_stack = grad_stack;
     a.quad_keep = quad_keep; a.QH = QH; a.QW = QW;
+    a.q_inv_cw = (float)QW / (float)(desc->Ws > 1 ? desc->Ws - 1 : 1); a.q_inv_ch = (float)QH / (float)(desc->Hs > 1 ? desc->Hs - 1 : 1);
     a.g_f16 = desc->stack_dtype == VL3D_F16;
     // variant: 0 auto (tile kernel when its on-device plan says feasible, else atomics), 1 force atomics,
     //          2 tile with 8-row regions, 3 tile with 16-row regions, 4 = 3 without the 2x2 gather
