@@ -58,10 +58,13 @@ typedef struct vl3d_render_desc {
     int32_t H, W;
     int32_t row0, col0;
     int32_t coord_mode, border_mode, act_order, rgb_act, alpha_act;
-    int32_t stack_dtype;   /* VL3D_F32 | VL3D_F16 (grad_stack is always fp32) */
+    int32_t stack_dtype;   /* VL3D_F32 | VL3D_F16 (grad_stack has the same dtype) */
     float pixel_center;    /* 0 (utils_mpi) or 0.5 (pytorch3d pixel centres) */
     float sx, sy, ox, oy;  /* VL3D_COORD_AFFINE only */
-    int32_t variant;       /* kernel variant selector for A/B measurements; 0 = default */
+    int32_t variant;       /* kernel variant selector for A/B measurements and bitwise cross-checks; 0 = default.  Bits 0-3: backward
+                            * (see vl3d_render_bwd); bits 4-7: timing-only ablations (wrong results); bits 8-11: forward -- 6 = one frame
+                            * per thread (default for the shipped activations and T >= 2: two frames per thread, same bits), 2/4/5 =
+                            * workgroup shapes 64x4 / 64x16 / no XCD remap */
 } vl3d_render_desc;
 
 /* alpha_sums (optional, may be NULL): (T,H,W,2) per pixel (sum_k a_k, sum_k a_k^2) over the planes -- the two sums the
