@@ -657,3 +657,32 @@ def test_fwd_frame_pair_kernel_equals_single_frame_kernel_bitwise(dev, spec_name
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     assert float(outs[0][0].abs().max()) > 0.01
+
+
+@pytest.mark.parametrize("T", [2, 5])
+@pytest.mark.parametrize("spec_name,stack_scale", [("mpv", 1.0), ("mpv", 1.1), ("utils_mpi", 1.0), ("hardcut_pre", 1.35)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_bwd_frame_pair_kernel_equals_tile_kernel_bitwise(dev, spec_name, stack_scale, T, dtype):
+    """render_bwd_pair_k sweeps and gathers frames t and t+1 per thread (coordinates, owner decode and tent weights are paid
+    once): per frame the arithmetic of render_bwd_tile_k (variant 3) in the same order -> the same gradient bits, for even and
+    odd T, fp32 and fp16 stacks, windows wider than the 32-texel region (strip pass) and plane borders inside the frame."""
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    D, H, W = 5, 150, 260
+    Hs, Ws = int(H * stack_scale) - 5, int(W * stack_scale) - 9
+    kw_p, _ = SPECS[spec_name]
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=41, device=dev, dtype=dtype).requires_grad_(True)
+    homos = bench_homos(D, H, W).to(dev)
+    if spec_name == "mpv":
+        kw_p = dict(kw_p, scale=(stack_scale, stack_scale), offset=(-1.5, -2.5))
+    else:
+        homos = torch.diag(torch.tensor([Ws / W, Hs / H, 1.0])).to(dev) @ homos
+    g_rgb = synth.hash_uniform((T, H, W, 3), seed=5, device=dev) - 0.5
+    g_a = synth.hash_uniform((T, H, W), seed=6, device=dev) - 0.5
+    out = {}
+    for variant in (0, 3):
+        rgb, alpha = render_planes(stack, homos, H, W, RenderSpec(variant=variant, **kw_p))
+        (gs,) = torch.autograd.grad([rgb, alpha], stack, [g_rgb, g_a])
+        assert _tile_ran() == 1
+        out[variant] = gs
+    assert torch.equal(out[0], out[3])
+    assert float(out[0].float().abs().max()) > 1e-3

@@ -255,6 +255,12 @@ __device__ __forceinline__ float fma_mix(unsigned hpair, float w, float acc) {  
     return r;
 }
 
+// The composite's scalar chains with their fused multiply-adds spelt out: under -ffp-contract=fast hipcc picks a different
+// grouping in every kernel it inlines them into, and the backward kernels (tile / frame pairs / atomics) are compared bit for bit.
+__device__ __forceinline__ float dot3p(float a0, float b0, float a1, float b1, float a2, float b2, float c) {
+    return fmaf(a0, b0, fmaf(a1, b1, fmaf(a2, b2, c)));
+}
+
 template <int RACT, int AACT>
 __device__ __forceinline__ f4 act4(f4 s) {
     return f4{act_fwd<RACT>(s.x), act_fwd<RACT>(s.y), act_fwd<RACT>(s.z), act_fwd<AACT>(s.w)};
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
     const float Gr = a.g_rgb[pix * 3 + 0], Gg = a.g_rgb[pix * 3 + 1], Gb = a.g_rgb[pix * 3 + 2];
     const float gA = a.g_alpha ? a.g_alpha[pix] : 0.0f;
     // S = sum_k w_k q_k with q_k = G.c_k + gA  ==  G.C + gA*A from the saved forward outputs
-    const float S = Gr * a.rgb[pix * 3 + 0] + Gg * a.rgb[pix * 3 + 1] + Gb * a.rgb[pix * 3 + 2] + gA * a.alpha[pix];
+    const float S = dot3p(Gr, a.rgb[pix * 3 + 0], Gg, a.rgb[pix * 3 + 1], Gb, a.rgb[pix * 3 + 2], gA * a.alpha[pix]);
     const float gN1 = a.g_asum ? a.g_asum[pix * 2 + 0] : 0.0f, gN2 = a.g_asum ? 2.0f * a.g_asum[pix * 2 + 1] : 0.0f;
     float Tr = 1.0f, P = 0.0f;
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws), gst = make_tap_step<false>(a.Hs, a.Ws);
@@ -321,13 +327,13 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
         f4 pre;
         load_taps2<F16>(plane, tp, st, tv);
         const f4 o = shade2<ORDER, RACT, AACT>(tp, tv, &pre);
-        const float q = Gr * o.x + Gg * o.y + Gb * o.z + gA;
+        const float q = dot3p(Gr, o.x, Gg, o.y, Gb, o.z, gA);
         const float w = o.w * Tr;
-        P += w * q;
+        P = fmaf(w, q, P);
         const float om = 1.0f - o.w;
         // dL/da_k = T_k q_k - (sum_{j>k} w_j q_j)/(1-a_k); everything behind a fully opaque plane has zero weight
         const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;
-        f4 go = f4{w * Gr, w * Gg, w * Gb, Tr * q - behind + (gN1 + gN2 * o.w)};   // grad wrt activated (c, a)
+        f4 go = f4{w * Gr, w * Gg, w * Gb, fmaf(Tr, q, -behind) + fmaf(gN2, o.w, gN1)};   // grad wrt activated (c, a)
         Tr *= om;
         if (a.g_reg) {   // smoothness regularisers on the fallback path: re-sample the 4 neighbours' layer values
             const f4 gx = f4{a.g_reg[0], a.g_reg[0], a.g_reg[0], a.g_reg[2]}, gy = f4{a.g_reg[1], a.g_reg[1], a.g_reg[1], a.g_reg[3]};
@@ -778,7 +784,7 @@ __global__ __launch_bounds__(256) void bwd_zero_unowned_k(RenderArgs a) {
 // round(H_d^-1 tau))) and p0's index in that tile's pixel region, packed as tile << 10 | index.  Frame independent, so it
 // is built once per call (D*Hs*Ws entries) and read once per frame by the gather, which then needs no inverse homography,
 // reciprocal, rounding or range tests per texel (~200 of its ~400 VALU issue cycles, profiles/microbench/isa_cost.py).
-__global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, int ih, int rh, int tiles_x, unsigned short *owner) {
+__global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, int ih, int rh, int tiles_x, unsigned short *owner, int rw = 64) {
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -791,7 +797,7 @@ __global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, i
     const int rx = (int)rxf, ry = (int)ryf;
     // tile of the owner pixel: floor((r + 0.5) / size) in fp32 is exact for frame coordinates (< 2^22) -- no integer division
     const int tx = (int)((rxf + 0.5f) * (1.0f / (float)iw)), ty = (int)((ryf + 0.5f) * (1.0f / (float)ih));
-    const unsigned lc = (unsigned)((ry - ty * ih + rh) * RW + (rx - tx * iw + rh));
+    const unsigned lc = (unsigned)((ry - ty * ih + rh) * rw + (rx - tx * iw + rh));     // rw: the tile kernel's region width
     // a tile's window only holds texels owned by itself or tiles a few steps away (the window is the bounding box of the tile's
     // image; under the plan's rotation / magnification limits its corners reach < 4 tiles), which the three low bits of each
     // tile coordinate tell apart: 16 bits per texel
@@ -839,7 +845,7 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
         const size_t pix = ((size_t)t * a.H + y) * a.W + x;
         Gr = a.g_rgb[pix * 3 + 0]; Gg = a.g_rgb[pix * 3 + 1]; Gb = a.g_rgb[pix * 3 + 2];
         gA = a.g_alpha ? a.g_alpha[pix] : 0.0f;
-        S = Gr * a.rgb[pix * 3 + 0] + Gg * a.rgb[pix * 3 + 1] + Gb * a.rgb[pix * 3 + 2] + gA * a.alpha[pix];
+        S = dot3p(Gr, a.rgb[pix * 3 + 0], Gg, a.rgb[pix * 3 + 1], Gb, a.rgb[pix * 3 + 2], gA * a.alpha[pix]);
         // the sparsity-sum gradients ride in the REG instantiation only (launch_t): the plain one is at its 64-VGPR budget
         if constexpr (REG) if (a.g_asum) { gN1 = a.g_asum[pix * 2 + 0]; gN2 = 2.0f * a.g_asum[pix * 2 + 1]; }
     }
@@ -921,12 +927,12 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
             }
         }
         if (inimg) {
-            const float q = Gr * o.x + Gg * o.y + Gb * o.z + gA;
+            const float q = dot3p(Gr, o.x, Gg, o.y, Gb, o.z, gA);
             const float w = o.w * Tr;
-            P += w * q;
+            P = fmaf(w, q, P);
             const float om = 1.0f - o.w;
             const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;
-            gval = make_float4(w * Gr + sg.x, w * Gg + sg.y, w * Gb + sg.z, Tr * q - behind + sg.w + (REG ? gN1 + gN2 * o.w : 0.0f));   // grad wrt activated (c, a)
+            gval = make_float4(w * Gr + sg.x, w * Gg + sg.y, w * Gb + sg.z, fmaf(Tr, q, -behind) + sg.w + (REG ? fmaf(gN2, o.w, gN1) : 0.0f));   // grad wrt activated (c, a)
             Tr *= om;
             if constexpr (ORDER == VL3D_ACT_POST)
                 gval = make_float4(gval.x * act_bwd<RACT>(pre.x, o.x), gval.y * act_bwd<RACT>(pre.y, o.y),
@@ -1007,6 +1013,174 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
 }
 
 
+
+// =====================================================================================================
+// Backward, two frames per thread (dense stacks, no layer regularisers).  render_bwd_tile_k is VALU-issue bound, and almost
+// half of its instruction stream does not depend on the frame: the sweep's homography / divide / base tap / tents / coverage /
+// offset, the gather's owner decode and all of its tent weights.  A workgroup of this kernel owns a 30 x 14-pixel tile of
+// frames t and t+1 (32 x 16 region, 512 threads, 2 workgroups per CU at <= 128 VGPRs): one set of coordinates and weights,
+// two composite states, two staged gradients, two accumulators, two stores.  Per frame the arithmetic is that of
+// render_bwd_tile_k in the same order (same bits).  Pre-pass kernels, owner table and window records are shared (region
+// width 32 in the owner table's slots).
+constexpr int PW = 32, PROWS = 16, PNT = PW * PROWS;
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
+__global__ __launch_bounds__(PNT, 2) void render_bwd_pair_k(RenderArgs a) {
+    if (!reinterpret_cast<const int *>(a.plan)[0]) return;
+    __shared__ float4 s_g[2][2][PNT];   // [buffer][frame][pixel]
+    __shared__ float2 s_t[2][PNT];
+    const int tid = threadIdx.x, col = tid & (PW - 1), row = tid >> 5;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_x = bid % a.tiles_x, rest = bid / a.tiles_x;
+    const int tile_y = rest % a.tiles_y, t0 = (rest / a.tiles_y) * 2;
+    const bool has1 = t0 + 1 < a.T;          // odd T: the last pair sweeps frame t0 twice and stores it once
+    const int rx0 = tile_x * (PW - 2) - 1, ry0 = tile_y * (PROWS - 2) - 1;
+    const int x = rx0 + col, y = ry0 + row;
+    const bool inimg = (x >= 0) && (x < a.W) && (y >= 0) && (y < a.H);
+    const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
+    constexpr size_t TEXB = F16 ? 8 : 16;
+    const size_t frame_b = (size_t)a.Hs * a.Ws * TEXB;
+    const size_t plane_stride_b = (size_t)a.T * frame_b;
+    const char *plane0 = reinterpret_cast<const char *>(a.stack) + (size_t)t0 * frame_b;
+    char *gplane0 = reinterpret_cast<char *>(a.g_stack) + (size_t)t0 * frame_b;
+    const size_t f1 = has1 ? frame_b : 0;
+    float Gr0 = 0.f, Gg0 = 0.f, Gb0 = 0.f, gA0 = 0.f, S0 = 0.f, Gr1 = 0.f, Gg1 = 0.f, Gb1 = 0.f, gA1 = 0.f, S1 = 0.f;
+    if (inimg) {
+        size_t pix = ((size_t)t0 * a.H + y) * a.W + x;
+        Gr0 = a.g_rgb[pix * 3 + 0]; Gg0 = a.g_rgb[pix * 3 + 1]; Gb0 = a.g_rgb[pix * 3 + 2];
+        gA0 = a.g_alpha ? a.g_alpha[pix] : 0.0f;
+        S0 = dot3p(Gr0, a.rgb[pix * 3 + 0], Gg0, a.rgb[pix * 3 + 1], Gb0, a.rgb[pix * 3 + 2], gA0 * a.alpha[pix]);
+        if (has1) pix += (size_t)a.H * a.W;
+        Gr1 = a.g_rgb[pix * 3 + 0]; Gg1 = a.g_rgb[pix * 3 + 1]; Gb1 = a.g_rgb[pix * 3 + 2];
+        gA1 = a.g_alpha ? a.g_alpha[pix] : 0.0f;
+        S1 = dot3p(Gr1, a.rgb[pix * 3 + 0], Gg1, a.rgb[pix * 3 + 1], Gb1, a.rgb[pix * 3 + 2], gA1 * a.alpha[pix]);
+    }
+    float Tr0 = 1.0f, P0 = 0.0f, Tr1 = 1.0f, P1 = 0.0f;
+    const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
+    const unsigned my_tile_id = (unsigned)(tile_y * a.tiles_x + tile_x);
+    const unsigned my_tile = (unsigned)((tile_y & 7) << 3 | (tile_x & 7));
+    const unsigned toff_thread = (unsigned)(row * a.Ws + col);
+    const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)my_tile_id * a.D * 4;
+    typedef typename TapVal<F16, ORDER>::type tapv_t;
+    for (int d = 0; d < a.D; ++d, plane0 += plane_stride_b, gplane0 += plane_stride_b) {
+        float h[9];
+        load_uniform(a.homos + 9 * d, h);
+        const int X0 = wrec[4 * d], Y0 = wrec[4 * d + 1], wwh = wrec[4 * d + 2];
+        const int ww = wwh & 0xffff, wh = (wwh >> 16) & 0x3fff;
+        const bool apart = (wwh & 0x40000000) != 0;
+        const int buf = d & 1;
+        const unsigned win0 = (unsigned)(Y0 * a.Ws + X0);
+        const unsigned short *oplane = a.owner + (size_t)d * a.Hs * a.Ws;
+        const unsigned e0 = oplane[win0 + toff_thread];          // unconditional (padded table), arrives in the shadow of the sweep
+        // (2) sweep: one set of taps, two frames
+        float2 tc = make_float2(0.f, 0.f);
+        float4 gv0 = make_float4(0.f, 0.f, 0.f, 0.f), gv1 = gv0;
+        if (inimg) {
+            const Taps2 tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            tapv_t tv0[4], tv1[4];
+            load_taps2<F16>(plane0, tp, st, tv0);
+            load_taps2<F16>(plane0 + f1, tp, st, tv1);
+            f4 pre0, pre1;
+            const f4 o0 = shade2<ORDER, RACT, AACT>(tp, tv0, &pre0);
+            const f4 o1 = shade2<ORDER, RACT, AACT>(tp, tv1, &pre1);
+#define VL3D_PAIR_GRAD(o, pre, Gr, Gg, Gb, gA, S, P, Tr, gv)                                                                   \
+            {                                                                                                                      \
+                const float q = dot3p(Gr, o.x, Gg, o.y, Gb, o.z, gA);                                                              \
+                const float w = o.w * Tr;                                                                                          \
+                P = fmaf(w, q, P);                                                                                                 \
+                const float om = 1.0f - o.w;                                                                                       \
+                const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;                                                \
+                gv = make_float4(w * Gr, w * Gg, w * Gb, fmaf(Tr, q, -behind));                                                    \
+                Tr *= om;                                                                                                          \
+                if constexpr (ORDER == VL3D_ACT_POST)                                                                              \
+                    gv = make_float4(gv.x * act_bwd<RACT>(pre.x, o.x), gv.y * act_bwd<RACT>(pre.y, o.y),                          \
+                                     gv.z * act_bwd<RACT>(pre.z, o.z), gv.w * act_bwd<AACT>(pre.w, o.w));                          \
+            }
+            VL3D_PAIR_GRAD(o0, pre0, Gr0, Gg0, Gb0, gA0, S0, P0, Tr0, gv0)
+            VL3D_PAIR_GRAD(o1, pre1, Gr1, Gg1, Gb1, gA1, S1, P1, Tr1, gv1)
+#undef VL3D_PAIR_GRAD
+            tc = make_float2(tp.tx, tp.ty);
+            if (!(tp.cov > 0.0f)) { gv0 = make_float4(0.f, 0.f, 0.f, 0.f); gv1 = gv0; }
+        }
+        s_t[buf][tid] = tc;
+        s_g[buf][0][tid] = gv0;
+        s_g[buf][1][tid] = gv1;
+        __syncthreads();
+        // (3) gather: one set of weights, two accumulators
+        auto gather = [&](unsigned e, int wx, int wy, unsigned tix) {
+            if ((e >> 10) != my_tile) return;
+            const int lc = (int)(e & 1023u);
+            const f2 tau = f2{(float)(X0 + wx), (float)(Y0 + wy)};
+            f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            if (apart) {
+                const f2 c0 = *reinterpret_cast<const f2 *>(&s_t[buf][lc]);
+                const int li0 = lc - (tau.x < c0.x ? 1 : 0) - (tau.y < c0.y ? PW : 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int li = li0 + (k >> 1) * PW + (k & 1);
+                    const f2 dc = *reinterpret_cast<const f2 *>(&s_t[buf][li]) - tau;
+                    const float wgt = tent_weight(dc.x) * tent_weight(dc.y);
+                    acc0 += *reinterpret_cast<const f4 *>(&s_g[buf][0][li]) * wgt;
+                    acc1 += *reinterpret_cast<const f4 *>(&s_g[buf][1][li]) * wgt;
+                }
+            } else {
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int li = lc + dy * PW + dx;
+                        const f2 dc = *reinterpret_cast<const f2 *>(&s_t[buf][li]) - tau;
+                        const float wgt = tent_weight(dc.x) * tent_weight(dc.y);
+                        acc0 += *reinterpret_cast<const f4 *>(&s_g[buf][0][li]) * wgt;
+                        acc1 += *reinterpret_cast<const f4 *>(&s_g[buf][1][li]) * wgt;
+                    }
+            }
+            if constexpr (ORDER == VL3D_ACT_PRE) {
+                const f4 sv0 = load_texel<F16>(plane0, tix << 4), sv1 = load_texel<F16>(plane0 + f1, tix << 4);
+                acc0 = f4{acc0.x * act_bwd<RACT>(sv0.x, act_fwd<RACT>(sv0.x)), acc0.y * act_bwd<RACT>(sv0.y, act_fwd<RACT>(sv0.y)),
+                          acc0.z * act_bwd<RACT>(sv0.z, act_fwd<RACT>(sv0.z)), acc0.w * act_bwd<AACT>(sv0.w, act_fwd<AACT>(sv0.w))};
+                acc1 = f4{acc1.x * act_bwd<RACT>(sv1.x, act_fwd<RACT>(sv1.x)), acc1.y * act_bwd<RACT>(sv1.y, act_fwd<RACT>(sv1.y)),
+                          acc1.z * act_bwd<RACT>(sv1.z, act_fwd<RACT>(sv1.z)), acc1.w * act_bwd<AACT>(sv1.w, act_fwd<AACT>(sv1.w))};
+            }
+            store_grad_texel<F16>(gplane0, tix << 4, acc0);
+            if (has1) store_grad_texel<F16>(gplane0 + frame_b, tix << 4, acc1);
+        };
+        if (row < wh && col < ww) gather(e0, col, row, win0 + toff_thread);
+        // rest of a window larger than 32 x 16: columns beyond 32 as a packed strip, rows beyond 16 one half-wave per row
+        const int nec = ww - PW;
+        if (nec > 0) {
+            const int necp = min(nec, PW);
+            const int sh = necp > 1 ? 32 - __builtin_clz((unsigned)(necp - 1)) : 0, rpg = PW >> sh, rmain = min(wh, PROWS);
+            const int c = col & ((1 << sh) - 1), r = col >> sh;          // a 32-thread row group takes rpg window rows of the strip
+            for (int wxb = PW; wxb < ww; wxb += (1 << sh))
+                for (int wy0 = row * rpg; wy0 < rmain; wy0 += PROWS * rpg) {
+                    const int wy = wy0 + r, wx = wxb + c;
+                    if (c < necp && wx < ww && wy < rmain) {
+                        const unsigned tix = win0 + (unsigned)(wy * a.Ws + wx);
+                        gather(oplane[tix], wx, wy, tix);
+                    }
+                }
+        }
+        for (int wy = row + PROWS; wy < wh; wy += PROWS)
+            for (int wx = col; wx < ww; wx += PW) {
+                const unsigned tix = win0 + (unsigned)(wy * a.Ws + wx);
+                gather(oplane[tix], wx, wy, tix);
+            }
+    }
+}
+
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
+void launch_pair(const RenderArgs &a, hipStream_t s) {
+    constexpr int IW = PW - 2, IH = PROWS - 2;
+    RenderArgs b = a;
+    b.tiles_x = (a.W + IW - 1) / IW; b.tiles_y = (a.H + IH - 1) / IH;
+    const int nwin = b.tiles_x * b.tiles_y * a.D;
+    hipLaunchKernelGGL((bwd_windows_k<COORD>), dim3((nwin + 255) / 256), dim3(256), 0, s, b, IW, IH, 1, b.tiles_x, b.tiles_y,
+                       reinterpret_cast<int *>(const_cast<float *>(a.plan)) + plan_win_off(a.D));
+    hipLaunchKernelGGL(bwd_owner_table_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, b, IW, IH, 1, b.tiles_x,
+                       const_cast<unsigned short *>(a.owner), PW);
+    hipLaunchKernelGGL((render_bwd_pair_k<COORD, BORDER, ORDER, RACT, AACT, F16>),
+                       dim3((unsigned)(b.tiles_x * b.tiles_y * ((a.T + 1) / 2))), dim3(PNT), 0, s, b);
+}
 
 // =====================================================================================================
 // Layer-space smoothness regularisers, forward (MPV.py:517-531): sum over frames, planes and neighbouring pixel pairs of
@@ -1128,6 +1302,18 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
             bool done = false;
             if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID && !F16) {   // measurement variant (shipped activations only)
                 if (g_tile_rows == 8 && !a.g_reg && !a.g_asum) { launch_tile<COORD, BORDER, ORDER, RACT, AACT, 8, false, false>(a, s); done = true; }
+            }
+            if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID) {
+                // two frames per thread: dense stacks without layer regularisers (g_tile_rows 17 = "16 rows, pairs allowed"), when a
+                // 30 x 14-pixel tile's texel window fits the 32 x 16 threads of its workgroup -- judged by the sizes alone (the
+                // homographies live on the device): a stack of at most the frame's resolution (+7 %).  Beyond that the extra gather
+                // passes of the small tiles cost more than the pairs save (1.1x: 13.3 ms tile kernel, 13.9 ms pairs) -- crops and
+                // row bands of a larger stack, and the reference's 1.1x stacks, keep the 64 x 16 tile kernel.
+                const bool fits = (int64_t)a.Hs * a.Ws * 100 <= (int64_t)a.H * a.W * 107;
+                if (!done && g_tile_rows == 17 && a.T >= 2 && !a.g_reg && !a.g_asum && !a.quad_keep && fits) {
+                    launch_pair<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
+                    done = true;
+                }
             }
             if (!done) {
                 if (a.g_reg || a.g_asum) {     // layer regularisers and / or sparsity sums: the REG instantiation (128-VGPR budget)
@@ -1282,7 +1468,9 @@ extern "C" int vl3d_render_fwd_culled(const vl3d_render_desc *desc, const void *
 // scratch layout: per-plane records | one int4 window per (tile, plane), sized for the smallest tile interior any variant
 // uses (60 x 6) | (256-byte aligned) owner table, one uint16 per (plane, texel)
 static int64_t owner_table_off(const vl3d_render_desc *desc) {
-    const int64_t tiles = (int64_t)((desc->W + 59) / 60) * ((desc->H + 5) / 6);
+    // window records: the largest tile count of any backward kernel (60 x 6 interiors of the 8-row regulariser variant, 30 x 14 of the pairs)
+    const int64_t t8 = (int64_t)((desc->W + 59) / 60) * ((desc->H + 5) / 6), tp = (int64_t)((desc->W + 29) / 30) * ((desc->H + 13) / 14);
+    const int64_t tiles = t8 > tp ? t8 : tp;
     const int64_t b = (int64_t)plan_win_off(desc->D) * sizeof(float) + tiles * desc->D * 16;
     return (b + 255) & ~(int64_t)255;
 }
@@ -1376,7 +1564,7 @@ static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, cons
         a.owner = reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(scratch) + owner_table_off(desc));
         // variant & 0xf: 0/3 -> 16-row regions; 2 -> 8 rows.  (Prefetching the next plane's taps across the barrier was
         // measured and dropped: 91 VGPRs halve the occupancy, 24.3-28.9 ms vs 17.3 ms.)
-        g_tile_rows = (desc->variant & 0xf) == 2 ? 8 : 16;
+        g_tile_rows = (desc->variant & 0xf) == 2 ? 8 : ((desc->variant & 0xf) == 0 ? 17 : 16);     // 17: 16 rows, frame-pair kernel allowed
     } else {
         a.plan = nullptr;
         g_tile_rows = 0;
