@@ -1306,10 +1306,11 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
             if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID) {
                 // two frames per thread: dense stacks without layer regularisers (g_tile_rows 17 = "16 rows, pairs allowed"), when a
                 // 30 x 14-pixel tile's texel window fits the 32 x 16 threads of its workgroup -- judged by the sizes alone (the
-                // homographies live on the device): a stack of at most the frame's resolution (+7 %).  Beyond that the extra gather
-                // passes of the small tiles cost more than the pairs save (1.1x: 13.3 ms tile kernel, 13.9 ms pairs) -- crops and
-                // row bands of a larger stack, and the reference's 1.1x stacks, keep the 64 x 16 tile kernel.
-                const bool fits = (int64_t)a.Hs * a.Ws * 100 <= (int64_t)a.H * a.W * 107;
+                // homographies live on the device): along one axis at least the stack is no larger than the frame (+7 %) -- full frames
+                // and row bands (dist.render_band: full width, rows = band + halo) of a stack at the frame's resolution.  Beyond that
+                // the extra gather passes of the small tiles cost more than the pairs save (1.1x: 13.3 ms tile kernel, 13.9 ms
+                // pairs): crops of a larger stack and the reference's 1.1x stacks keep the 64 x 16 tile kernel.
+                const bool fits = (int64_t)a.Hs * 100 <= (int64_t)a.H * 107 || (int64_t)a.Ws * 100 <= (int64_t)a.W * 107;
                 if (!done && g_tile_rows == 17 && a.T >= 2 && !a.g_reg && !a.g_asum && !a.quad_keep && fits) {
                     launch_pair<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
                     done = true;
