@@ -504,7 +504,7 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
 // arithmetic is that of render_fwd2_k instruction for instruction (same results bit for bit); the 8 tap loads per plane and
 // thread also replace occupancy as the source of memory parallelism (<= 128 VGPRs, 4 waves per SIMD).
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool F16>
-__global__ __launch_bounds__(64 * TY, 2) void render_fwd2x_k(RenderArgs a, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(64 * TY, 4) void render_fwd2x_k(RenderArgs a, int tiles_x, int tiles_y) {      // >= 4 waves per SIMD: <= 128 VGPRs
     const int b = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_x = b % tiles_x, rest = b / tiles_x;
     const int tile_y = rest % tiles_y, t0 = (rest / tiles_y) * 2;
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
 // width 32 in the owner table's slots).
 constexpr int PW = 32, PROWS = 16, PNT = PW * PROWS;
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
-__global__ __launch_bounds__(PNT, 2) void render_bwd_pair_k(RenderArgs a) {
+__global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {      // >= 4 waves per SIMD (2 workgroups per CU): <= 128 VGPRs
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
     __shared__ float4 s_g[2][2][PNT];   // [buffer][frame][pixel]
     __shared__ float2 s_t[2][PNT];
