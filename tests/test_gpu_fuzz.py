@@ -219,3 +219,32 @@ def test_render_feature_fuzz(dev, seed):
         # gradient of the (at most 4) taps of both pixels -- is decided by rounding.  Such pairs are isolated and each moves a
         # texel by at most 2 * weight (profiles/debug_fuzz.py prints them); everything else has to match.
         assert float(d.max()) <= 2.0 * float(wts.max()) + tol and int((d > tol).sum()) <= 64
+
+
+@pytest.mark.parametrize("seed", list(range(12 + _EXTRA)))
+def test_fp16_stack_fuzz_equals_fp32_kernels_on_rounded_values(dev, seed):
+    """fp16 plane stacks (cfg5's storage format: packed taps, one 16-byte load per tap row, v_fma_mix blend, fp16 gradient
+    stores) against the fp32 kernels on the same values rounded to fp16: fp32 arithmetic either way -> identical images and a
+    gradient that is the fp32 one rounded to half, bit for bit, on random shapes / frame counts / geometries / conventions."""
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    D, T, Hs, Ws, H, W, homos, kw = _case(500 + seed)
+    if seed % 2:
+        T += 1
+    stack16 = synth.make_plane_stack(D, T, Hs, Ws, seed=900 + seed, device=dev, dtype=torch.float16).requires_grad_(True)
+    stack32 = stack16.detach().float().requires_grad_(True)
+    g_rgb = synth.hash_uniform((T, H, W, 3), seed=5, device=dev) - 0.5
+    g_a = synth.hash_uniform((T, H, W), seed=6, device=dev) - 0.5
+    out = []
+    for st in (stack16, stack32):
+        rgb, alpha = render_planes(st, homos.to(dev), H, W, RenderSpec(**kw))
+        (gs,) = torch.autograd.grad([rgb, alpha], st, [g_rgb, g_a])
+        out.append((rgb.detach(), alpha.detach(), gs))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert out[0][2].dtype == torch.float16
+    # the atomics fallback (infeasible plans: far-from-unit scale) accumulates in fp16 -> compare with a tolerance there
+    from videoloop3d_amd import render as R
+    if int(R.LAST_BWD_SCRATCH[:1].view(torch.int32).item()) == 1:
+        assert torch.equal(out[0][2], out[1][2].half())
+    else:
+        # (fp16 atomics round after every addition: thousands of pixels folding into one texel of a degenerate 1 x 1 plane drift by %)
+        assert float((out[0][2].float() - out[1][2]).abs().max()) <= 3e-2 * max(1e-3, float(out[1][2].abs().max())) + 1e-4
