@@ -222,7 +222,7 @@ def main():
         return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": None, "avg_ms": ms, "algorithmic_bytes": nbytes}
     r_f = roof("render_fwd2x_k", fwd_bytes, f_ms)
-    r_b = roof("render_bwd_pair_k (+bwd_plan_k, bwd_zero_unowned_k, bwd_owner_table_k, bwd_windows_k)", bwd_bytes, b_ms)
+    r_b = roof("render_bwd_pair_k (+bwd_plan_k, bwd_owner_table_k, bwd_windows_k)", bwd_bytes, b_ms)
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:

@@ -610,7 +610,7 @@ void launch_fwd2(const RenderArgs &a, hipStream_t s) {
 // |J^-1|_inf + 0.5 < 2 of its owner pixel, i.e. from the tile + 1-pixel halo, so each texel is written exactly
 // once with its complete sum, in a fixed order (bitwise reproducible; no atomics at all -- a first version
 // that scattered with ds_add_f32 into an LDS window measured 158 ms vs 30 ms without the LDS atomics).  Texels whose owner pixel is outside the
-// frame are zero-filled by bwd_zero_unowned_k (run first; it also zeroes a 1-pixel safety band that the
+// frame are zero-filled by bwd_owner_table_k (run first; it also zeroes a 1-pixel safety band that the
 // tile kernel then overwrites).  bwd_plan_k checks the geometric preconditions per call ON DEVICE
 // (Z>0 over the frame, magnification < 1.4x, window fits); if they fail, these kernels exit and the
 // universal atomics kernel above runs instead -- no host synchronisation either way.
@@ -760,26 +760,6 @@ __device__ __forceinline__ void owner_pixel(const float *__restrict__ hi, float 
     py = Y * rz - pc - (float)row0;
 }
 
-__global__ __launch_bounds__(256) void bwd_zero_unowned_k(RenderArgs a) {
-    if (!reinterpret_cast<const int *>(a.plan)[0]) return;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int d = blockIdx.z;
-    if (x >= a.Ws || y >= a.Hs) return;
-    float px, py;
-    owner_pixel(a.plan + PLAN_HDR + PLAN_REC * d, (float)x, (float)y, a.pc, a.col0, a.row0, px, py);
-    const bool safe = (px > 0.5f) && (px < (float)a.W - 1.5f) && (py > 0.5f) && (py < (float)a.H - 1.5f);
-    if (safe) return;      // owned (and written) by a tile with certainty
-    const size_t frame = (size_t)a.Hs * a.Ws;
-    if (a.g_f16) {
-        float2 *g = reinterpret_cast<float2 *>(a.g_stack) + (size_t)d * a.T * frame + (size_t)y * a.Ws + x;
-        for (int t = 0; t < a.T; ++t, g += frame) *g = make_float2(0.f, 0.f);
-    } else {
-        float4 *g = reinterpret_cast<float4 *>(a.g_stack) + (size_t)d * a.T * frame + (size_t)y * a.Ws + x;
-        for (int t = 0; t < a.T; ++t, g += frame) *g = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
-
 // Owner table: for every texel of every plane, the tile that owns it (the tile of its owner pixel p0 = clamp_to_frame(
 // round(H_d^-1 tau))) and p0's index in that tile's pixel region, packed as tile << 10 | index.  Frame independent, so it
 // is built once per call (D*Hs*Ws entries) and read once per frame by the gather, which then needs no inverse homography,
@@ -802,6 +782,19 @@ __global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, i
     // image; under the plan's rotation / magnification limits its corners reach < 4 tiles), which the three low bits of each
     // tile coordinate tell apart: 16 bits per texel
     owner[((size_t)d * a.Hs + y) * a.Ws + x] = (unsigned short)((((unsigned)(ty & 7) << 3 | (unsigned)(tx & 7)) << 10) | lc);
+    // same pass (it already has the texel's owner pixel): texels no tile is certain to own -- owner pixel on or outside the frame's
+    // border ring -- are zero-filled for all T frames here, so nothing memsets the gradient; the tile kernel runs after this
+    // kernel and overwrites the border ring's texels it does own
+    const bool safe = (qx > 0.5f) && (qx < (float)a.W - 1.5f) && (qy > 0.5f) && (qy < (float)a.H - 1.5f);
+    if (safe) return;
+    const size_t frame = (size_t)a.Hs * a.Ws;
+    if (a.g_f16) {
+        float2 *g = reinterpret_cast<float2 *>(a.g_stack) + (size_t)d * a.T * frame + (size_t)y * a.Ws + x;
+        for (int t = 0; t < a.T; ++t, g += frame) *g = make_float2(0.f, 0.f);
+    } else {
+        float4 *g = reinterpret_cast<float4 *>(a.g_stack) + (size_t)d * a.T * frame + (size_t)y * a.Ws + x;
+        for (int t = 0; t < a.T; ++t, g += frame) *g = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
 __global__ __launch_bounds__(256) void bwd_fill_zero_if_infeasible_k(float2 *g, size_t n8, const float *plan) {      // n8: 8-byte units
@@ -1298,7 +1291,6 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
             hipLaunchKernelGGL((bwd_plan_k<COORD>), dim3(1), dim3(64), 0, s, a, g_tile_rows, const_cast<float *>(a.plan));
             const size_t n8 = (size_t)a.D * a.T * a.Hs * a.Ws * (a.g_f16 ? 1 : 2);          // fp16 texels are 8 bytes, fp32 ones 16
             hipLaunchKernelGGL(bwd_fill_zero_if_infeasible_k, dim3(4096), dim3(256), 0, s, reinterpret_cast<float2 *>(a.g_stack), n8, a.plan);
-            hipLaunchKernelGGL(bwd_zero_unowned_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, a);
             bool done = false;
             if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID && !F16) {   // measurement variant (shipped activations only)
                 if (g_tile_rows == 8 && !a.g_reg && !a.g_asum) { launch_tile<COORD, BORDER, ORDER, RACT, AACT, 8, false, false>(a, s); done = true; }
