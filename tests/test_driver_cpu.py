@@ -106,3 +106,34 @@ def test_mpmeshvid_driver_hooks():
     assert torch.equal(m.stack.detach(), ref)
     m.lod(1.0)
     assert m.stack.shape == (2, 3, 20, 32, 4) and m.spec.scale == pytest.approx((1.0, 1.0))
+
+
+# ---- product helpers against the reference goldens (plain torch: run on the CPU) ------------------------------------------------
+def test_product_geometry_helpers_match_the_reference_goldens(golden):
+    """videoloop3d_amd.utils_mpi.make_depths / compute_homography against G1 and gen_mpi_vertices against G12 -- the PRODUCT
+    functions directly (the oracle's copies are checked in test_oracle_golden.py)."""
+    import numpy as np
+    import torch
+    from videoloop3d_amd import utils_mpi as U
+    T = lambda a: torch.from_numpy(np.asarray(a))
+    g = golden("g1_homography.npz")
+    assert float((U.make_depths(8, 1.0, 100.0) - T(g["depths"])).abs().max()) == 0
+    for ci in range(2):
+        h = U.compute_homography(T(g[f"c{ci}_src_ext"]), T(g[f"c{ci}_src_K"]), T(g[f"c{ci}_tar_ext"]), T(g[f"c{ci}_tar_K"]),
+                                 T(g[f"c{ci}_normal"]), T(g[f"c{ci}_dist"]))
+        assert float((h - T(g[f"c{ci}_homo"])).abs().max()) <= 1e-6
+    g = golden("g12_helpers.npz")
+    v = U.gen_mpi_vertices(40, 60, T(g["K"]), 5, 7, T(g["planedepth"]))
+    assert v.shape == tuple(g["verts"].shape) and float((v - T(g["verts"])).abs().max()) <= 1e-6
+
+
+def test_patch3d_mse_and_avg_match_the_reference_goldens(golden):
+    """utils_vid.py:437-445 (the two loss_name alternatives that stay in PyTorch)."""
+    import numpy as np
+    import torch
+    from videoloop3d_amd.utils_vid import Patch3DAvg, Patch3DMSE
+    g = golden("g12_helpers.npz")
+    xa, ya = torch.from_numpy(g["xa"]), torch.from_numpy(g["ya"])
+    assert abs(float(Patch3DMSE(xa, ya)) - float(g["mse"])) <= 1e-7
+    assert abs(float(Patch3DMSE(ya, xa)) - float(g["mse_rev"])) <= 1e-7
+    assert abs(float(Patch3DAvg(xa, ya)) - float(g["avg"])) <= 1e-7

@@ -39,7 +39,7 @@ def _case(seed):
     sx, sy = (Ws - 1) / max(W * scale, 1.0), (Hs - 1) / max(H * scale, 1.0)          # roughly map the frame onto the plane
     homos = torch.diag(torch.tensor([max(sx, 1e-3) * scale, max(sy, 1e-3) * scale, 1.0])) @ homos if seed % 2 else homos
     spec = [dict(), dict(pixel_center=0.5, coord_mode="affine", border="hardcut", act_order="post"),
-            dict(border="hardcut"), dict(pixel_center=0.5, coord_mode="affine", scale=(0.9, 1.1), offset=(0.3, -0.2), act_order="post")][seed % 4]
+            dict(border="hardcut"), dict(pixel_center=0.5, coord_mode="affine", scale=(0.9, 1.1), offset=(0.3, -0.2), border="hardcut", act_order="post")][seed % 4]
     return D, T, Hs, Ws, H, W, homos, spec
 
 

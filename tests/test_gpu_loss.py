@@ -24,6 +24,24 @@ def maxabs(a, b):
     return float((a.detach().double().cpu() - torch.as_tensor(b).double().cpu()).abs().max())
 
 
+def exact_distances(X, Y, max_bytes=1 << 30):
+    """fp64 patch distances [B,n1,n2] for the top-2 gap criterion.  The direct form mean((x-y)^2) needs B*n1*n2*d doubles (82 MB per
+    LOCATION at the cfg4 clip length with ps = 11 -- tens of TB for a 1080p strip: it once took a GPU box down with it), so beyond
+    `max_bytes` the fp64 Gram form is used, chunked over locations: its cancellation error (~1e-13 here) is far below the 1e-5 gap."""
+    B, n1 = X.shape[:2]
+    n2 = Y.shape[1]
+    d = X[0, 0].numel()
+    if B * n1 * n2 * d * 8 <= max_bytes:
+        return VO.patch_distances_exact(X, Y)
+    out = torch.empty((B, n1, n2), dtype=torch.float64)
+    step = max(1, int(max_bytes // max(1, (n1 + n2) * d * 8 * 3)))
+    for b0 in range(0, B, step):
+        x = X[b0:b0 + step].reshape(-1, n1, d).double()
+        y = Y[b0:b0 + step].reshape(-1, n2, d).double()
+        out[b0:b0 + step] = ((x * x).sum(-1)[:, :, None] + (y * y).sum(-1)[:, None, :] - 2.0 * (x @ y.transpose(1, 2))) / d
+    return out
+
+
 def nn_mismatch_is_near_tie(x, y, ps, pt, s, st, alpha, nn_gpu, rel_gap=1e-5):
     """NN parity criterion (SURVEY §7 'NN argmin parity'): indices must be identical wherever the top-2 gap of the
     exact (fp64) objective exceeds rel_gap * scale; returns (#mismatches, #unexplained)."""
@@ -32,7 +50,7 @@ def nn_mismatch_is_near_tie(x, y, ps, pt, s, st, alpha, nn_gpu, rel_gap=1e-5):
     B = h * w
     X = VO._to_location_major(px, B, pt, ps)
     Y = VO._to_location_major(VO.extract_3Dpatches(y, ps, pt, s, st), B, pt, ps)
-    dist = VO.patch_distances_exact(X, Y)
+    dist = exact_distances(X, Y)
     if alpha is not None:
         dist = dist / (alpha + dist.min(1)[0][:, None])
     ref = torch.argmin(dist, dim=2)
@@ -142,8 +160,10 @@ def test_errors_are_python_exceptions(dev):
     x = synth.make_video(8, 17, 17, seed=3, device=dev)
     with pytest.raises(RuntimeError, match="identical spatial size"):
         FindNNpatchAndMerge(x, synth.make_video(8, 17, 19, seed=4, device=dev), 5, 3, 2, 1)
+    # the raw ABI wants x on the patch grid (the Python direct path floors it like UnfoldNd, test_g11_*)
+    from videoloop3d_amd.utils_vid import _nn_and_fold
     with pytest.raises(RuntimeError, match="not trimmed"):
-        FindNNpatchAndMerge(x[..., :16], synth.make_video(8, 17, 16, seed=4, device=dev), 5, 3, 2, 1)
+        _nn_and_fold(x[..., :16], synth.make_video(8, 17, 16, seed=4, device=dev), 5, 3, 2, 1, None, False)
     with pytest.raises(RuntimeError, match="dist_fn"):
         FindNNpatchAndMerge(x, x, 5, 3, 2, 1, dist_fn='ssim')
 
@@ -225,15 +245,45 @@ def test_g10_compute_nnerr(dev, golden):
             assert abs(v - float(g[f"ps{ps}_s{s_}_pt{pt}_st{st}_mb{mb}"])) <= 2e-6
 
 
-def test_y_scratch_cache_is_invalidated_by_in_place_updates(dev):
-    """The NN kernel's pixel-major copy of y is reused across calls with the same y (utils_vid._patchnn_scratch); an in-place
-    change of y, a different view or a different tensor must rebuild it."""
+@pytest.mark.parametrize("ps,pt,s,st,al", [(5, 3, 2, 1, 1e10), (3, 2, 2, 2, 0.5), (4, 3, 3, 1, 1e10)])
+def test_g11_direct_path_takes_any_size(dev, golden, ps, pt, s, st, al):
+    """`loss_name='gpnn'` is the parser default and its direct path takes x of any size (UnfoldNd floors the patch grid, FoldNd
+    fills the full x.shape: utils_vid.py:206-229, 265-286) -- e.g. an even crop with the default stride 2.  Golden from the
+    reference itself: outputs keep x's shape, uncovered voxels have y2x = 0 and weight 1e-10, the loss averages over all of x."""
+    from videoloop3d_amd.utils_vid import FindNNpatchAndMerge, Patch3DGPNNDirectLoss
+    g = golden("g11_direct_anysize.npz")
+    key = f"ps{ps}_pt{pt}_s{s}_st{st}_a{al:g}"
+    x = T_(g["x"]).to(dev).requires_grad_(True)
+    y = T_(g["y"]).to(dev)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                   # the direct path does not warn (it does not trim)
+        sm, w = FindNNpatchAndMerge(x, y, patch_size=ps, patcht_size=pt, stride=s, stridet=st, alpha=al)
+        L = Patch3DGPNNDirectLoss()
+        loss = L(x, y, rou="-2", scaling=0.1, patch_size=ps, patcht_size=pt, stride=s, stridet=st, alpha=al)
+    assert sm.shape == tuple(g[key + "_sum"].shape) and w.shape == tuple(g[key + "_weight"].shape)
+    assert maxabs(w, g[key + "_weight"]) == 0
+    assert maxabs(sm, g[key + "_sum"]) <= 1e-5
+    assert maxabs(L.last_y2x, g[key + "_y2x"]) <= 1e-5 and L.last_y2x.shape == x.shape
+    assert abs(float(loss.detach()) - float(g[key + "_loss"])) <= 1e-5 * max(1.0, abs(float(g[key + "_loss"])))
+    (gx,) = torch.autograd.grad(loss, x)
+    assert maxabs(gx, g[key + "_grad"]) <= 1e-8 + 1e-5 * float(np.abs(g[key + "_grad"]).max())
+
+
+def test_y_scratch_cache_is_opt_in_and_invalidated_by_in_place_updates(dev):
+    """The NN kernel's pixel-major copy of y is reused across calls only when the caller opts in with y_is_constant=True
+    (utils_vid._patchnn_scratch); then an in-place change of y, a different view or a different tensor must rebuild it.  Without
+    the opt-in every call re-copies y, so even writes that bypass the version counter (y.data.copy_) are seen."""
     from videoloop3d_amd import utils_vid as UV
     x = synth.make_video(8, 21, 25, seed=3, device=dev)
     y = synth.make_video(10, 21, 25, seed=4, device=dev)
     y2 = synth.make_video(10, 21, 25, seed=9, device=dev)
     ref = lambda yy: VO.find_nn_and_merge(x.cpu(), yy.cpu(), 5, 3, 2, 1, 1e10, return_nn=True)[2]
-    run = lambda yy: UV.find_nn_indices(x, yy, 5, 3, 2, 1, None)[0].cpu().long()
+    plain = lambda yy: UV.find_nn_indices(x, yy, 5, 3, 2, 1, None)[0].cpu().long()
+    yb = y.clone()
+    assert torch.equal(plain(yb), ref(y))
+    yb.data.copy_(y2)                                                   # bypasses the version counter
+    assert torch.equal(plain(yb), ref(y2))
+    run = lambda yy: UV.find_nn_indices(x, yy, 5, 3, 2, 1, None, y_is_constant=True)[0].cpu().long()
     a = run(y)
     assert torch.equal(run(y), a) and torch.equal(a, ref(y))            # second call: cache hit, same answer
     y.copy_(y2)                                                         # in-place: version counter bumps

@@ -112,6 +112,25 @@ def test_g8_loss(golden, name, cfg):
         assert abs(float(g[name + "_direct_loss"]) - float(g[name + "_loss"])) <= 1e-6
 
 
+G11_CFGS = [(5, 3, 2, 1, 1e10), (3, 2, 2, 2, 0.5), (4, 3, 3, 1, 1e10)]
+
+
+@pytest.mark.parametrize("ps,pt,s,st,al", G11_CFGS)
+def test_g11_direct_path_any_size(golden, ps, pt, s, st, al):
+    """the reference's direct path on inputs that do not fit the patch grid (UnfoldNd floors, FoldNd fills the full x.shape):
+    uncovered voxels get sum 0 / weight 1e-10, and the loss mean runs over all of x (utils_vid.py:206-229, 265-286)."""
+    g = golden("g11_direct_anysize.npz")
+    key = f"ps{ps}_pt{pt}_s{s}_st{st}_a{al:g}"
+    x = T(g["x"]).requires_grad_(True)
+    sm, w = VO.find_nn_and_merge(x.detach(), T(g["y"]), patch_size=ps, patcht_size=pt, stride=s, stridet=st, alpha=al)
+    assert maxabs(w, g[key + "_weight"]) == 0 and float(w.min()) == pytest.approx(1e-10)
+    assert maxabs(sm, g[key + "_sum"]) <= 1e-5
+    loss = VO.robust_lossfun(x - sm / w, "-2", 0.1).mean()
+    assert abs(loss.item() - float(g[key + "_loss"])) <= 1e-6 * max(1.0, abs(float(g[key + "_loss"])))
+    (gx,) = torch.autograd.grad(loss, x)
+    assert maxabs(gx, g[key + "_grad"]) <= 1e-8 + 1e-5 * float(np.abs(g[key + "_grad"]).max())
+
+
 def test_g9_robust(golden):
     g = golden("g9_robust.npz")
     for rou in ['mse', 'abs', '0', '2', '-2', '1']:

@@ -118,6 +118,42 @@ def test_sparsify_and_init_from_mpi():
     assert vid._tie_hook is not None and vid.stack.shape[2:4] == (20, 30)
 
 
+def test_lod_of_a_sparsified_model_does_not_bleed_culled_logits():
+    """MPV.py:157-164 resizes every tile on its own; on the dense stack the culled texels hold CULLED_ALPHA (-1e4), so lod() must
+    resample with the kept-texel mask as the weight: at every level of the shipped pyramid (down to ~0.2x and back up) the texels
+    kept quads can read hold convex combinations of KEPT values only, and the culling is re-applied at the new resolution."""
+    from videoloop3d_amd.MPV import MPMeshVid
+    H, W = 80, 120
+    K = np.array([[100., 0, 60], [0, 100., 40], [0, 0, 1]])
+    vid = MPMeshVid(_args(mpv_frm_num=2), H, W, np.eye(4), K, 1.0, 100.0)
+    torch.manual_seed(1)
+    keep = torch.zeros(3, 4, 6, dtype=torch.bool)
+    keep[0, 1:3, 1:4] = True            # a kept block with culled quads all around it
+    keep[2] = torch.rand(4, 6) < 0.5
+    vid.register_buffer("quad_keep", keep)
+    vid.register_buffer("quad_dyn", keep.clone())
+    vid.is_sparse = vid.has_dyn = True
+    with torch.no_grad():
+        vid.stack.uniform_(-3.0, 3.0)
+        tiles.cull_stack_(vid.stack.data, keep)
+    lo, hi = -3.0, 3.0
+    for factor in (0.25, 0.5, 1.0, 0.2, 0.75):
+        vid.lod(factor)
+        D, T, hs, ws, _ = vid.stack.shape
+        kept_t = tiles.quad_to_texel_mask(keep, hs, ws)[:, None].expand(D, T, hs, ws)
+        v = vid.stack.detach()
+        assert bool(torch.isfinite(v).all())
+        assert float(v[kept_t].min()) >= lo - 1e-4 and float(v[kept_t].max()) <= hi + 1e-4, factor     # no -37 / -7509 logits
+        assert bool((v[..., 3][~kept_t] == tiles.CULLED_ALPHA).all())                                    # culling re-applied
+        assert vid._tie_hook is not None
+    # an un-sparsified model takes the plain antialiased filter (torchvision Resize semantics), untouched by the fix
+    dense = MPMeshVid(_args(mpv_frm_num=2), H, W, np.eye(4), K, 1.0, 100.0)
+    ref = torch.nn.functional.interpolate(dense.stack.detach().permute(0, 1, 4, 2, 3).reshape(6, 4, 80, 120), size=(40, 60),
+                                          mode="bilinear", align_corners=False, antialias=True).reshape(3, 2, 4, 40, 60).permute(0, 1, 3, 4, 2)
+    dense.lod(0.5)
+    assert torch.allclose(dense.stack.detach(), ref, atol=1e-6)
+
+
 def test_stage2_checkpoint_roundtrip(tmp_path):
     """train_3dvid.py:295-306 / scripts/script_render_video.py:116-119: a saved MPMeshVid state_dict (incl. the "self.*" scalars and
     the quad maps, possibly at a pyramid level) is loaded back with init_from_mpi."""

@@ -188,10 +188,29 @@ class MPMeshVid(nn.Module):
         D, T, hs, ws, _ = self.stack.shape
         print(f"MPV.lod:: Resizing the planes from {(hs, ws)} to {(h, w)}")
         if (hs, ws) != (h, w):
+            sparse = self.is_sparse and self.quad_keep is not None
             with torch.no_grad():
-                planes = self.stack.data.permute(0, 1, 4, 2, 3).reshape(D * T, 4, hs, ws)
-                planes = torch.nn.functional.interpolate(planes, size=(h, w), mode="bilinear", align_corners=False, antialias=True)
-                new = planes.reshape(D, T, 4, h, w).permute(0, 1, 3, 4, 2).contiguous()
+                new = torch.empty((D, T, h, w, 4), dtype=self.stack.dtype, device=self.stack.device)
+                if sparse:
+                    # The reference resizes every tile on its own (MPV.py:157-164), so nothing bleeds between tiles.  On the dense
+                    # stack the culled texels hold the alpha logit CULLED_ALPHA (-1e4): a plain filter would pull the logits of
+                    # kept texels next to a culled region to -1e3..-1e4 (sigmoid = 0, zero gradient: dead for good).  Resample
+                    # with the kept-texel mask as the weight -- interpolate(v * m) / interpolate(m), a convex combination of
+                    # KEPT values only -- and re-apply the culling at the new resolution.
+                    from . import tiles
+                    kept = tiles.quad_to_texel_mask(self.quad_keep, hs, ws).to(self.stack.dtype)            # D,hs,ws
+                for d in range(D):      # plane by plane: bounds the temporaries at stage-2 sizes
+                    planes = self.stack.data[d].permute(0, 3, 1, 2)                                          # T,4,hs,ws
+                    if sparse:
+                        m = kept[d][None, None]                                                              # 1,1,hs,ws
+                        num = torch.nn.functional.interpolate(planes * m, size=(h, w), mode="bilinear", align_corners=False, antialias=True)
+                        den = torch.nn.functional.interpolate(m, size=(h, w), mode="bilinear", align_corners=False, antialias=True)
+                        planes = num / den.clamp_min(1e-6)
+                    else:
+                        planes = torch.nn.functional.interpolate(planes, size=(h, w), mode="bilinear", align_corners=False, antialias=True)
+                    new[d] = planes.permute(0, 2, 3, 1)
+                if sparse:
+                    tiles.cull_stack_(new, self.quad_keep)
             self.register_parameter("stack", nn.Parameter(new, requires_grad=True))
         sx = self.texel_scale[0] * (w - 1) / max(self.mpi_w - 1, 1)
         sy = self.texel_scale[1] * (h - 1) / max(self.mpi_h - 1, 1)
@@ -210,12 +229,15 @@ class MPMeshVid(nn.Module):
         second group holds `_verts`, which never receive a gradient in the shipped configs)."""
         (_, base_lr), _ = self.get_lrate(step)
         params = [{'params': [p for _, p in self.named_parameters()]}]
+        self._static_compact = False
         if self.args.optimizer == 'adam':
             if self.stack.is_cuda:
                 # the same update as torch.optim.Adam in ONE pass over (p, g, m, v) -- 8.5 ms for the 7 GB stage-2 stack vs 12.4 ms
                 # (torch fused) / 29 ms (torch default) -- and, for a sparsified model, only over the texels kept quads can read
                 from .tiles import TileAdam
-                self._static_compact = bool(self.is_sparse)     # from now on static gradients are summed into frame 0 only
+                # static gradients are summed into frame 0 only WHILE the optimiser handed out last is the tile-aware Adam, which
+                # reads them there; any other optimiser (below) sees the frame sum in every copy again
+                self._static_compact = bool(self.is_sparse)
                 return TileAdam(params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8, quad_keep=self.quad_keep if self.is_sparse else None,
                                 quad_dyn=self.quad_dyn if self.is_sparse else None)
             return torch.optim.Adam(params=params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8)

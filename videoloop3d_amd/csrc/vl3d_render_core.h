@@ -1,0 +1,1356 @@
+// Fused MPI/MPV render for gfx950: per-plane homography warp + bilinear sample + activation +
+// front-to-back over-composite across D planes, forward and backward.
+//
+// Replaces (reference, /root/reference): MPV.py:351-454 (planar geometry) ==
+// utils_mpi.py:159-176 (warp_homography) + utils_mpi.py:92-107 (overcompose), and their autograd.
+//
+// Data layout in HBM: plane stack (D,T,Hs,Ws,4) fp32 -- one texel = one 16-byte rgba vector, so a
+// wave of 64 consecutive output pixels reads ~65 consecutive texels (1 KiB, fully coalesced) per tap
+// row.  Output rgb (T,H,W,3), alpha (T,H,W).
+//
+// Forward (render_fwd2_k): one thread per output pixel, planes walked front-to-back in registers, taps fetched
+// straight through the vector L1 (texture-cache style; the 4x tap redundancy between neighbouring pixels is
+// absorbed by L1, vertical reuse by the tile height + XCD-aware tile order).
+// Backward: a single front-to-back sweep that uses the saved forward outputs,
+//   sum_{j>k} w_j q_j = (G.C + gA.A) - sum_{j<=k} w_j q_j   (SURVEY §9.3),
+// with the stack gradient produced either by the LDS-staged owner-computes gather kernel (render_bwd_tile_k, no
+// atomics) or, for geometry outside its preconditions, by the universal global-atomics kernel (render_bwd_k).
+//
+// This header holds every render kernel and its launch template; it is compiled once per sampling / compositing convention
+// (vl3d_render_conv.inc, included by the vl3d_render_c*.hip stubs) so that the conventions build in parallel.
+#pragma once
+#include "vl3d_common.h"
+
+namespace vl3d_render_detail {
+
+struct RenderArgs {
+    const float *stack;
+    const float *homos;
+    float *rgb;
+    float *alpha;
+    const float *g_rgb;
+    const float *g_alpha;
+    float *g_stack;
+    int D, T, Hs, Ws, H, W, row0, col0;
+    float pc, sx, sy, ox, oy;
+    float *asum;          // forward out (optional): per pixel (sum_k a_k, sum_k a_k^2) for the sparsity regulariser (MPV.py:511-515)
+    const float *g_asum;  // backward in (optional): per pixel dL/d(sum a), dL/d(sum a^2)
+    const float *g_reg;  // device float[4]: dL/d(sum|dx rgb|), dL/d(sum|dy rgb|), dL/d(sum|dx a|), dL/d(sum|dy a|) or NULL
+    double *reg_sums;    // device double[4] (forward of the layer-space smoothness regularisers)
+    int tiles_x, tiles_y; // tile grid of the owner-computes backward
+    int fwd_variant;     // forward kernel selector (see launch<>)
+    int ablate;          // measurement-only switches (bit0: skip LDS scatter, bit1: skip flush stores, bit2: skip tap loads)
+    float q_inv_cw, q_inv_ch;   // tile culling: quads per texel along x / y = QW/(Ws-1), QH/(Hs-1) (float division done once, on the host)
+    int gather9;         // 1: never take the 2x2 gather (variant 4; the 3x3 gather is the definition the 2x2 one must equal bit for bit)
+    const float *plan;   // device scratch written by bwd_plan_k: [0] feasible flag, [16 + 12*d ..] inverse texel homographies,
+                         // then (bwd_windows_k) one int4 texel window per (tile, plane)
+    const unsigned short *owner;   // device scratch written by bwd_owner_table_k: per (plane, texel) a 6-bit code of the owner
+                                   // tile (tile_y & 7, tile_x & 7) << 10 | the owner pixel's index in its tile's region
+    // tile culling (optional): quad_keep [D][QH][QW] bytes, 1 = the quad (cell of the plane's vertex grid) may be visible.
+    // cull_masks (forward): per 64x8-pixel workgroup two 64-bit words, bit d = plane d can contribute to the workgroup.
+    int g_f16;               // the stack is fp16 (8-byte texels) and so is its gradient
+    const unsigned char *quad_keep;
+    int QH, QW;
+    const unsigned long long *cull_masks;
+    // dispatch options (plain arguments: the ABI is re-entrant from any number of host threads / streams)
+    int tile_rows;           // backward: 0 = no owner-computes path for this call (atomics kernel only); 16 = tile kernel; 17 = 16 rows,
+                             // frame-pair kernels allowed
+    int reg_fwd;             // forward dispatch launches the regulariser-sums kernel instead of the render
+};
+
+// one entry point per compiled convention (coord_mode, border_mode, act_order): vl3d_render_c*.hip
+int conv_utils_zeros_pre(bool bwd, const vl3d_render_desc *d, const RenderArgs &a, hipStream_t s);
+int conv_utils_zeros_post(bool bwd, const vl3d_render_desc *d, const RenderArgs &a, hipStream_t s);
+int conv_utils_hardcut_pre(bool bwd, const vl3d_render_desc *d, const RenderArgs &a, hipStream_t s);
+int conv_affine_hardcut_post_sig(bool bwd, const vl3d_render_desc *d, const RenderArgs &a, hipStream_t s);
+int conv_affine_hardcut_post_other(bool bwd, const vl3d_render_desc *d, const RenderArgs &a, hipStream_t s);
+
+}  // namespace vl3d_render_detail
+
+namespace {
+using vl3d_render_detail::RenderArgs;
+
+// does the texel-space box [tnx,txx] x [tny,txy] (grown by 2 texels) touch a kept quad of plane d?  Quads are the QH x QW cells of
+// the plane's vertex grid, (Ws-1)/QW x (Hs-1)/QH texels each.  Conservative by construction: a workgroup skips a plane only
+// when every tap of every one of its pixels is a texel no kept quad can read, i.e. a culled texel whose alpha is exactly 0.
+__device__ __forceinline__ bool box_touches_kept_quad(const RenderArgs &a, int d, float tnx, float txx, float tny, float txy) {
+    if (!(txx >= -2.0f && tnx <= (float)a.Ws + 1.0f && txy >= -2.0f && tny <= (float)a.Hs + 1.0f)) return !(tnx == tnx && tny == tny);   // outside the plane (NaN: keep)
+    const float cw = (float)max(a.Ws - 1, 1) / (float)a.QW, ch = (float)max(a.Hs - 1, 1) / (float)a.QH;
+    const int qx0 = max(0, (int)floorf((tnx - 2.0f) / cw)), qx1 = min(a.QW - 1, (int)floorf((txx + 2.0f) / cw));
+    const int qy0 = max(0, (int)floorf((tny - 2.0f) / ch)), qy1 = min(a.QH - 1, (int)floorf((txy + 2.0f) / ch));
+    const unsigned char *k = a.quad_keep + (size_t)d * a.QH * a.QW;
+    for (int qy = qy0; qy <= qy1; ++qy)
+        for (int qx = qx0; qx <= qx1; ++qx)
+            if (k[qy * a.QW + qx]) return true;
+    return false;
+}
+
+// Uniform, read-only tables (homographies, plan records) are read through the constant address space: the loads become
+// s_load_* into SGPRs.  Through a generic pointer hipcc cannot prove them invariant across the gradient stores of the
+// loop and emits per-lane global_load + s_waitcnt vmcnt(0) -- a full memory latency in front of every plane's taps.
+typedef const __attribute__((address_space(4))) float *cfloat_p;
+typedef const __attribute__((address_space(4))) int *cint_p;
+template <int N>
+__device__ __forceinline__ void load_uniform(const float *p, float (&out)[N]) {
+    const cfloat_p c = (cfloat_p)p;
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = c[i];
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct Taps2 {
+    unsigned off;      // byte offset of tap (x0,y0) inside the frame for 16-byte texels; the taps are off + {0, dx, dy, dx+dy}
+    f4 w;              // bilinear weights, 0 for taps outside the plane (a vector, not an array: stays in registers)
+    float cov;         // 1 if the plane covers this pixel else 0
+    float tx, ty;      // texel coordinates of the sample
+};
+// uniform byte steps between the 4 taps of a sample (0 along an axis of size 1: its second tap has weight 0)
+struct TapStep { unsigned dx, dy; };
+template <bool F16>
+__device__ __forceinline__ TapStep make_tap_step(int Hs, int Ws) {
+    constexpr unsigned TEXB = F16 ? 8 : 16;
+    return TapStep{Ws > 1 ? TEXB : 0u, Hs > 1 ? (unsigned)Ws * TEXB : 0u};
+}
+
+__device__ __forceinline__ float fast_rcp(float z) {
+    float r = __builtin_amdgcn_rcpf(z);
+    float e = fmaf(-z, r, 1.0f);
+    return fmaf(r, e, r);
+}
+
+// (x, y) / z from one hardware reciprocal and one residual correction per quotient: q = x*r, q += (x - q*z)*r.  The 1-ulp
+// error of v_rcp_f32 only enters through the correction term, so the result agrees with the IEEE quotients the reference /
+// oracle compute to within rounding of the last bit, at a quarter of the instruction count of the IEEE expansion.
+__device__ __forceinline__ f2 fast_div2(f2 xy, float z) {
+    // explicit FMAs: every kernel that inlines this gets the same instruction sequence, hence bit-identical coordinates
+    const float rz = __builtin_amdgcn_rcpf(z);
+    const f2 rz2 = f2{rz, rz}, z2 = f2{z, z};
+    const f2 q = xy * rz2;
+    const f2 e = __builtin_elementwise_fma(-q, z2, xy);
+    return __builtin_elementwise_fma(e, rz2, q);
+}
+
+// bilinear tent weight max(0, 1 - |d|) in ONE full-rate VALU instruction (|.| and clamp are free VOP3 modifiers; the C form
+// compiles to and/sub/max, and v_max_f32 alone issues at half the rate of v_sub_f32 -- profiles/microbench/valu_rates)
+__device__ __forceinline__ float tent_weight(float d) {
+    float w;
+    asm("v_sub_f32_e64 %0, 1.0, |%1| clamp" : "=v"(w) : "v"(d));
+    return w;
+}
+
+// Tile culling at sample level: a sample that falls into a culled quad of its plane is not covered (the reference's mesh has no
+// face there, MPI.py:288-442 / MPV.py:389-449) -- whatever the texels hold.  keep == nullptr: no culling.
+struct QuadCull {
+    const unsigned char *keep;   // [QH][QW] of THIS plane
+    int QH, QW;
+    float inv_cw, inv_ch;        // quads per texel along x / y: QW/(Ws-1), QH/(Hs-1)
+};
+__device__ __forceinline__ QuadCull plane_cull(const RenderArgs &a, int d) {
+    if (!a.quad_keep) return QuadCull{nullptr, 0, 0, 0.f, 0.f};
+    return QuadCull{a.quad_keep + (size_t)d * a.QH * a.QW, a.QH, a.QW, a.q_inv_cw, a.q_inv_ch};     // the two quotients come from the host: uniform, in SGPRs
+}
+
+// integer form of the taps: base tap (x0,y0) with x0 <= Ws-2, y0 <= Hs-2 (so the 2x2 block is inside the plane) + weights
+struct TapsI {
+    int x0, y0;
+    f4 w;              // bilinear weights, 0 for taps outside the plane (a vector, not an array: stays in registers)
+    float cov;         // 1 if the plane covers this pixel else 0
+    float tx, ty;      // texel coordinates of the sample
+};
+
+// Sample position -> base tap + weights.  The base tap is floor(t) clamped to [0, S-2], so all four taps are valid addresses
+// at constant steps from ONE offset, and each weight is the tent max(0, 1-|t - tap|): for the sample's two neighbours that is
+// (1-f, f); for a tap that is not a neighbour (sample within one texel outside the plane, or t == S-1) it is 0, which is
+// exactly grid_sample's zeros padding (utils_mpi.py:159-176) -- no per-tap validity selects, no per-tap address clamps.
+template <int COORD, int BORDER>
+__device__ __forceinline__ TapsI make_taps_i(const float *__restrict__ h, float px, float py, int Hs, int Ws,
+                                             float sx, float sy, float ox, float oy, QuadCull qc = QuadCull{nullptr, 0, 0, 0.f, 0.f}) {
+    TapsI t;
+    const f2 px2 = f2{px, px}, py2 = f2{py, py};
+    const f2 XY = __builtin_elementwise_fma(f2{h[0], h[3]}, px2, __builtin_elementwise_fma(f2{h[1], h[4]}, py2, f2{h[2], h[5]}));
+    const float Z = fmaf(h[6], px, fmaf(h[7], py, h[8]));
+    const f2 pxy = fast_div2(XY, Z);
+    const float tx = texel_coord<COORD>(pxy.x, (float)Ws / 2.0f, (float)(Ws - 1), sx, ox);
+    const float ty = texel_coord<COORD>(pxy.y, (float)Hs / 2.0f, (float)(Hs - 1), sy, oy);
+    t.tx = tx; t.ty = ty;
+    const float x0f = __builtin_amdgcn_fmed3f(floorf(tx), 0.0f, (float)max(Ws - 2, 0));
+    const float y0f = __builtin_amdgcn_fmed3f(floorf(ty), 0.0f, (float)max(Hs - 2, 0));
+    t.x0 = (int)x0f; t.y0 = (int)y0f;
+    const float dx = tx - x0f, dy = ty - y0f;
+    // an axis of size 1 has no second tap: its tent is pushed to 0
+    const float wx0 = tent_weight(dx), wx1 = tent_weight(dx - (Ws > 1 ? 1.0f : 3e38f));
+    const float wy0 = tent_weight(dy), wy1 = tent_weight(dy - (Hs > 1 ? 1.0f : 3e38f));
+    t.w = f4{wx0, wx1, wx0, wx1} * f4{wy0, wy0, wy1, wy1};
+    if constexpr (BORDER == VL3D_BORDER_HARDCUT) {   // MPV.py:374-453: the plane quad ends at the outermost texel centres
+        const bool cov = (tx >= 0.0f) && (tx <= (float)(Ws - 1)) && (ty >= 0.0f) && (ty <= (float)(Hs - 1));
+        t.cov = cov ? 1.0f : 0.0f;
+    } else {                                         // zeros padding: covered while any tap is inside, i.e. any weight > 0
+        t.cov = ((t.w[0] + t.w[1]) + (t.w[2] + t.w[3]) > 0.0f) ? 1.0f : 0.0f;
+    }
+    if (qc.keep) {      // uniform branch
+        const int qx = min(max((int)floorf(tx * qc.inv_cw), 0), qc.QW - 1), qy = min(max((int)floorf(ty * qc.inv_ch), 0), qc.QH - 1);
+        if (!qc.keep[qy * qc.QW + qx]) t.cov = 0.0f;
+    }
+    return t;
+}
+
+template <int COORD, int BORDER>
+__device__ __forceinline__ Taps2 make_taps2(const float *__restrict__ h, float px, float py, int Hs, int Ws,
+                                            float sx, float sy, float ox, float oy, QuadCull qc = QuadCull{nullptr, 0, 0, 0.f, 0.f}) {
+    const TapsI ti = make_taps_i<COORD, BORDER>(h, px, py, Hs, Ws, sx, sy, ox, oy, qc);
+    Taps2 t;
+    t.w = ti.w;
+    t.cov = ti.cov; t.tx = ti.tx; t.ty = ti.ty;
+    t.off = (__umul24((unsigned)ti.y0, (unsigned)Ws) + (unsigned)ti.x0) << 4;   // y0 < 2^24 (check_desc), full-rate multiply
+    return t;
+}
+
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+// one texel = 16 bytes (fp32 stack) or 8 bytes (fp16 stack, cfg5 of BASELINE.json; arithmetic stays fp32).
+// `plane` is uniform and off16 a zero-extended 32-bit lane offset: global_load ... v_off, s[base:base+1]
+template <bool F16>
+__device__ __forceinline__ f4 load_texel(const char *__restrict__ plane, unsigned off16) {
+    if constexpr (F16) return __builtin_convertvector(*reinterpret_cast<const h4 *>(plane + (size_t)(off16 >> 1)), f4);
+    else return *reinterpret_cast<const f4 *>(plane + (size_t)off16);
+}
+
+// The stack gradient has the dtype of the stack (8-byte fp16 texels for cfg5: 96 GB of stack + 96 GB of gradient per GPU fit
+// in 288 GB; an fp32 gradient would not).  `tex16` is the byte offset the texel would have with 16-byte texels.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+template <bool F16>
+__device__ __forceinline__ void store_grad_texel(char *gplane, unsigned tex16, f4 v) {
+    if constexpr (F16) __builtin_nontemporal_store(__builtin_convertvector(v, h4), reinterpret_cast<h4 *>(gplane + (size_t)(tex16 >> 1)));
+    else __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(gplane + (size_t)tex16));
+}
+template <bool F16>
+__device__ __forceinline__ void atomic_add_grad_texel(char *gplane, size_t tex16, f4 c) {
+    if constexpr (F16) {     // packed-half atomics (global_atomic_pk_add_f16); fallback path only
+        auto *g = (__attribute__((address_space(1))) h2 *)(gplane + (tex16 >> 1));
+        __builtin_amdgcn_global_atomic_fadd_v2f16(g, h2{(_Float16)c.x, (_Float16)c.y});
+        __builtin_amdgcn_global_atomic_fadd_v2f16(g + 1, h2{(_Float16)c.z, (_Float16)c.w});
+    } else {
+        float *g = reinterpret_cast<float *>(gplane + tex16);
+        atomicAdd(g + 0, c.x); atomicAdd(g + 1, c.y); atomicAdd(g + 2, c.z); atomicAdd(g + 3, c.w);
+    }
+}
+
+// the four taps: one lane offset, four uniform bases (plane, +dx, +dy, +dx+dy) -- no per-tap address arithmetic
+template <bool F16>
+__device__ __forceinline__ void load_taps2(const char *__restrict__ plane, const Taps2 &t, TapStep st, f4 v[4]) {
+    v[0] = load_texel<F16>(plane, t.off);
+    v[1] = load_texel<F16>(plane + st.dx, t.off);
+    v[2] = load_texel<F16>(plane + st.dy, t.off);
+    v[3] = load_texel<F16>(plane + st.dy + st.dx, t.off);
+}
+
+// fp16 stacks in sample-then-activate order keep their taps packed (2 VGPRs per tap instead of 4) and convert inside the
+// blend's FMAs: v_fma_mix_f32 reads an f16 half as one source and computes in fp32, i.e. exactly cvt + fma, in one plain-rate
+// instruction.  The 16 v_cvt_f32_f16 per pixel and plane this removes were ~20 % of the fp16 forward's VALU issue time.
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+template <bool F16, int ORDER> struct TapVal { typedef f4 type; };
+template <> struct TapVal<true, VL3D_ACT_POST> { typedef u2 type; };
+
+template <bool F16>
+__device__ __forceinline__ void load_taps2(const char *__restrict__ plane, const Taps2 &t, TapStep st, u2 v[4]) {
+    static_assert(F16, "packed taps are fp16 texels");
+    const size_t o = (size_t)(t.off >> 1);
+    // texels x0 and x0+1 of a row are 16 contiguous bytes: ONE 16-byte load per row (8-byte aligned) instead of two 8-byte ones.
+    // The fp16 forward was bound by the rate of tap-load instructions (~20 clk per wave-load per CU): 4.10 -> 3.12 ms.
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    typedef u4 u4_a8 __attribute__((aligned(8)));
+    const u4 r0 = *reinterpret_cast<const u4_a8 *>(plane + o);
+    const u4 r1 = *reinterpret_cast<const u4_a8 *>(plane + st.dy + o);
+    v[0] = u2{r0.x, r0.y}; v[1] = u2{r0.z, r0.w};
+    v[2] = u2{r1.x, r1.y}; v[3] = u2{r1.z, r1.w};
+}
+
+template <int HI>
+__device__ __forceinline__ float fma_mix(unsigned hpair, float w, float acc) {      // (float)half[HI] * w + acc
+    float r;
+    if constexpr (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(w), "v"(acc));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(w), "v"(acc));
+    return r;
+}
+
+// The composite's scalar chains with their fused multiply-adds spelt out: under -ffp-contract=fast hipcc picks a different
+// grouping in every kernel it inlines them into, and the backward kernels (tile / frame pairs / atomics) are compared bit for bit.
+__device__ __forceinline__ float dot3p(float a0, float b0, float a1, float b1, float a2, float b2, float c) {
+    return fmaf(a0, b0, fmaf(a1, b1, fmaf(a2, b2, c)));
+}
+
+template <int RACT, int AACT>
+__device__ __forceinline__ f4 act4(f4 s) {
+    return f4{act_fwd<RACT>(s.x), act_fwd<RACT>(s.y), act_fwd<RACT>(s.z), act_fwd<AACT>(s.w)};
+}
+
+// bilinear blend + activation (vector types so the blend compiles to packed FMAs)
+template <int ORDER, int RACT, int AACT>
+__device__ __forceinline__ f4 shade2(const Taps2 &t, const f4 v[4], f4 *pre_out = nullptr) {
+    f4 s;
+    if constexpr (ORDER == VL3D_ACT_POST) {
+        s = v[0] * t.w[0] + (v[1] * t.w[1] + (v[2] * t.w[2] + v[3] * t.w[3]));
+        if (pre_out) *pre_out = s;
+        s = act4<RACT, AACT>(s);
+    } else {
+        s = act4<RACT, AACT>(v[0]) * t.w[0] + (act4<RACT, AACT>(v[1]) * t.w[1] + (act4<RACT, AACT>(v[2]) * t.w[2] + act4<RACT, AACT>(v[3]) * t.w[3]));
+        if (pre_out) *pre_out = s;
+    }
+    s.w *= t.cov;    // uncovered: a = 0 (and c irrelevant) -> the plane drops out of the composite
+    return s;
+}
+
+// the same blend (same association: v3 w3, then fma v2, v1, v0 -- bit-identical to the f4 overload on the converted values)
+template <int ORDER, int RACT, int AACT>
+__device__ __forceinline__ f4 shade2(const Taps2 &t, const u2 v[4], f4 *pre_out = nullptr) {
+    static_assert(ORDER == VL3D_ACT_POST, "packed taps: sample-then-activate only");
+    f4 s;
+    s.x = fma_mix<0>(v[0].x, t.w[0], fma_mix<0>(v[1].x, t.w[1], fma_mix<0>(v[2].x, t.w[2], fma_mix<0>(v[3].x, t.w[3], 0.0f))));
+    s.y = fma_mix<1>(v[0].x, t.w[0], fma_mix<1>(v[1].x, t.w[1], fma_mix<1>(v[2].x, t.w[2], fma_mix<1>(v[3].x, t.w[3], 0.0f))));
+    s.z = fma_mix<0>(v[0].y, t.w[0], fma_mix<0>(v[1].y, t.w[1], fma_mix<0>(v[2].y, t.w[2], fma_mix<0>(v[3].y, t.w[3], 0.0f))));
+    s.w = fma_mix<1>(v[0].y, t.w[0], fma_mix<1>(v[1].y, t.w[1], fma_mix<1>(v[2].y, t.w[2], fma_mix<1>(v[3].y, t.w[3], 0.0f))));
+    if (pre_out) *pre_out = s;
+    s = act4<RACT, AACT>(s);
+    s.w *= t.cov;
+    return s;
+}
+
+constexpr int TILE_X = 64, TILE_Y = 4;
+
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
+__global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
+    if (a.plan && reinterpret_cast<const int *>(a.plan)[0]) return;   // the tile path owns this call
+    const int x = blockIdx.x * TILE_X + (threadIdx.x & (TILE_X - 1));
+    const int y = blockIdx.y * TILE_Y + (threadIdx.x / TILE_X);
+    const int t = blockIdx.z;
+    if (x >= a.W || y >= a.H) return;
+    const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
+    constexpr size_t TEXB = F16 ? 8 : 16;
+    const size_t frame = (size_t)a.Hs * a.Ws * 4;
+    const size_t plane_stride = (size_t)a.T * frame;
+    const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * a.Hs * a.Ws * TEXB;
+    char *gplane = reinterpret_cast<char *>(a.g_stack) + (size_t)t * a.Hs * a.Ws * TEXB;     // gradient texels = stack texels
+    const size_t pix = ((size_t)t * a.H + y) * a.W + x;
+    const float Gr = a.g_rgb[pix * 3 + 0], Gg = a.g_rgb[pix * 3 + 1], Gb = a.g_rgb[pix * 3 + 2];
+    const float gA = a.g_alpha ? a.g_alpha[pix] : 0.0f;
+    // S = sum_k w_k q_k with q_k = G.c_k + gA  ==  G.C + gA*A from the saved forward outputs
+    const float S = dot3p(Gr, a.rgb[pix * 3 + 0], Gg, a.rgb[pix * 3 + 1], Gb, a.rgb[pix * 3 + 2], gA * a.alpha[pix]);
+    const float gN1 = a.g_asum ? a.g_asum[pix * 2 + 0] : 0.0f, gN2 = a.g_asum ? 2.0f * a.g_asum[pix * 2 + 1] : 0.0f;
+    float Tr = 1.0f, P = 0.0f;
+    const TapStep st = make_tap_step<F16>(a.Hs, a.Ws), gst = make_tap_step<false>(a.Hs, a.Ws);
+    for (int d = 0; d < a.D; ++d, plane += (size_t)a.T * a.Hs * a.Ws * TEXB, gplane += (size_t)a.T * a.Hs * a.Ws * TEXB) {
+        const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
+        if (tp.cov == 0.0f) continue;
+        typename TapVal<F16, ORDER>::type tv[4];
+        f4 pre;
+        load_taps2<F16>(plane, tp, st, tv);
+        const f4 o = shade2<ORDER, RACT, AACT>(tp, tv, &pre);
+        const float q = dot3p(Gr, o.x, Gg, o.y, Gb, o.z, gA);
+        const float w = o.w * Tr;
+        P = fmaf(w, q, P);
+        const float om = 1.0f - o.w;
+        // dL/da_k = T_k q_k - (sum_{j>k} w_j q_j)/(1-a_k); everything behind a fully opaque plane has zero weight
+        const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;
+        f4 go = f4{w * Gr, w * Gg, w * Gb, fmaf(Tr, q, -behind) + fmaf(gN2, o.w, gN1)};   // grad wrt activated (c, a)
+        Tr *= om;
+        if (a.g_reg) {   // smoothness regularisers on the fallback path: re-sample the 4 neighbours' layer values
+            const f4 gx = f4{a.g_reg[0], a.g_reg[0], a.g_reg[0], a.g_reg[2]}, gy = f4{a.g_reg[1], a.g_reg[1], a.g_reg[1], a.g_reg[3]};
+            auto layer = [&](float qx, float qy) {
+                const Taps2 tq = make_taps2<COORD, BORDER>(a.homos + 9 * d, qx, qy, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
+                typename TapVal<F16, ORDER>::type tq_v[4];
+                load_taps2<F16>(plane, tq, st, tq_v);
+                return shade2<ORDER, RACT, AACT>(tq, tq_v) * tq.cov;
+            };
+            auto sgn = [](f4 v) { return f4{(float)((v.x > 0.f) - (v.x < 0.f)), (float)((v.y > 0.f) - (v.y < 0.f)),
+                                            (float)((v.z > 0.f) - (v.z < 0.f)), (float)((v.w > 0.f) - (v.w < 0.f))}; };
+            if (x + 1 < a.W) go += gx * sgn(o - layer(px + 1.0f, py));
+            if (x >= 1) go -= gx * sgn(layer(px - 1.0f, py) - o);
+            if (y + 1 < a.H) go += gy * sgn(o - layer(px, py + 1.0f));
+            if (y >= 1) go -= gy * sgn(layer(px, py - 1.0f) - o);
+        }
+        if constexpr (ORDER == VL3D_ACT_POST)
+            go = f4{go.x * act_bwd<RACT>(pre.x, o.x), go.y * act_bwd<RACT>(pre.y, o.y), go.z * act_bwd<RACT>(pre.z, o.z),
+                    go.w * act_bwd<AACT>(pre.w, o.w)};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (tp.w[i] != 0.0f) {
+                f4 c = go * tp.w[i];
+                if constexpr (ORDER == VL3D_ACT_PRE) {
+                    const f4 sv = tv[i];
+                    c = f4{c.x * act_bwd<RACT>(sv.x, act_fwd<RACT>(sv.x)), c.y * act_bwd<RACT>(sv.y, act_fwd<RACT>(sv.y)),
+                           c.z * act_bwd<RACT>(sv.z, act_fwd<RACT>(sv.z)), c.w * act_bwd<AACT>(sv.w, act_fwd<AACT>(sv.w))};
+                }
+                atomic_add_grad_texel<F16>(gplane, (size_t)tp.off + ((i & 1) ? gst.dx : 0u) + ((i & 2) ? gst.dy : 0u), c);
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// Forward, variant 2: same arithmetic as render_fwd_k with a leaner instruction stream
+//   - one Newton-refined reciprocal instead of two IEEE divisions for the perspective divide,
+//   - branch-free taps: addresses clamped into the plane, invalid taps get weight 0, uncovered planes get a = 0,
+//     so the plane loop has uniform control flow and the taps of plane d+1 are issued before plane d is shaded,
+//   - 32-bit byte offsets against a scalar plane base (global_load_dwordx4 v, s[base:base+1]),
+//   - taller tiles (TY rows: vertical tap reuse inside the workgroup) on a 1-D grid with an XCD-aware
+//     bijective remap so that vertically adjacent tiles share one XCD's L2.
+// bijective XCD remap (cdna guide T1): workgroup b runs on XCD b % 8; give every XCD a contiguous chunk of tiles
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+// forward plan of the tile culling: one thread per (64 x TY pixel workgroup, plane) projects the workgroup's corners and sets
+// the plane's bit when the footprint touches a kept quad.  Frame independent, once per call.
+template <int COORD>
+__global__ __launch_bounds__(256) void cull_fwd_plan_k(RenderArgs a, int TY, int tiles_x, int tiles_y, unsigned long long *masks) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= tiles_x * tiles_y * a.D) return;
+    const int d = i % a.D, tile = i / a.D, tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+    const int x0 = tile_x * 64, x1 = min(x0 + 63, a.W - 1), y0 = tile_y * TY, y1 = min(y0 + TY - 1, a.H - 1);
+    const float *h = a.homos + 9 * d;
+    float tnx = 1e30f, txx = -1e30f, tny = 1e30f, txy = -1e30f;
+    for (int c = 0; c < 4; ++c) {
+        const float cx = (float)a.col0 + a.pc + (float)((c & 1) ? x1 : x0), cy = (float)a.row0 + a.pc + (float)((c & 2) ? y1 : y0);
+        const float X = h[0] * cx + h[1] * cy + h[2], Y = h[3] * cx + h[4] * cy + h[5], Z = h[6] * cx + h[7] * cy + h[8];
+        const float ctx = texel_coord<COORD>(X / Z, (float)a.Ws / 2.0f, (float)(a.Ws - 1), a.sx, a.ox);
+        const float cty = texel_coord<COORD>(Y / Z, (float)a.Hs / 2.0f, (float)(a.Hs - 1), a.sy, a.oy);
+        tnx = fminf(tnx, ctx); txx = fmaxf(txx, ctx); tny = fminf(tny, cty); txy = fmaxf(txy, cty);
+    }
+    if (box_touches_kept_quad(a, d, tnx, txx, tny, txy)) atomicOr(masks + (size_t)tile * 2 + (d >> 6), 1ull << (d & 63));
+}
+
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool SWZ, bool F16, bool CULL = false>
+__global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles_x, int tiles_y) {
+    int b = blockIdx.x;
+    if constexpr (SWZ) b = xcd_remap(b, gridDim.x);
+    const int tile_x = b % tiles_x, rest = b / tiles_x;
+    const int tile_y = rest % tiles_y, t = rest / tiles_y;
+    const int x = tile_x * 64 + (threadIdx.x & 63);
+    const int y = tile_y * TY + (threadIdx.x >> 6);
+    if (x >= a.W || y >= a.H) return;
+    const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
+    const size_t frame_b = (size_t)a.Hs * a.Ws * (F16 ? 8 : 16);
+    const size_t plane_stride_b = (size_t)a.T * frame_b;
+    const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * frame_b;
+    float Tr = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, A = 0.f, n1 = 0.f, n2 = 0.f;
+    const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
+    typedef typename TapVal<F16, ORDER>::type tapv_t;
+    tapv_t vA[4], vB[4];
+#define VL3D_COMPOSITE(T_, V_)                                        \
+    {                                                                 \
+        const f4 o = shade2<ORDER, RACT, AACT>(T_, V_);               \
+        const float w = o.w * Tr;                                     \
+        cr += w * o.x; cg += w * o.y; cb += w * o.z; A += w;          \
+        n1 += o.w; n2 = fmaf(o.w, o.w, n2);                           \
+        Tr *= (1.0f - o.w);                                           \
+    }
+    if constexpr (CULL) {
+        // tile culling: walk only the planes whose bit is set for this workgroup (two 64-bit words in SGPRs, scalar bit scans);
+        // the skipped planes' taps are all culled texels (alpha exactly 0), so the result is bit-identical to walking them
+        const unsigned long long *mk = a.cull_masks + (size_t)(tile_y * tiles_x + tile_x) * 2;
+        unsigned long long m0 = ((const __attribute__((address_space(4))) unsigned long long *)mk)[0];
+        unsigned long long m1 = ((const __attribute__((address_space(4))) unsigned long long *)mk)[1];
+        auto next = [&]() {
+            int d = -1;
+            if (m0) { d = __builtin_ctzll(m0); m0 &= m0 - 1; }
+            else if (m1) { d = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
+            return d;
+        };
+        auto fetch = [&](int d, Taps2 &t, tapv_t *v) {
+            float h[9];
+            load_uniform(a.homos + 9 * d, h);
+            t = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
+            load_taps2<F16>(plane + (size_t)d * plane_stride_b, t, st, v);
+            asm volatile("" ::: "memory");
+        };
+        int dA = next();
+        if (dA >= 0) {
+            Taps2 tA, tB;
+            fetch(dA, tA, vA);
+            for (;;) {
+                const int dB = next();
+                fetch(dB < 0 ? dA : dB, tB, vB);      // unconditional prefetch (re-reads the current plane past the end)
+                VL3D_COMPOSITE(tA, vA)
+                if (dB < 0) break;
+                const int dC = next();
+                fetch(dC < 0 ? dB : dC, tA, vA);
+                VL3D_COMPOSITE(tB, vB)
+                if (dC < 0) break;
+                dA = dC;
+            }
+        }
+    } else {
+    // two register sets (A/B) so the taps of plane d+1 are in flight while plane d is shaded, without register copies
+    Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy), tB = tA;
+    load_taps2<F16>(plane, tA, st, vA);
+    // The prefetch of the next plane is unconditional (past the end it re-reads the last plane): with a branch around the
+    // loads hipcc merges the two paths' counters and waits with vmcnt(0), i.e. for the taps it has just issued as well.
+    for (int d = 0;; d += 2) {
+        {
+            const int dn = min(d + 1, a.D - 1);
+            float h[9];
+            load_uniform(a.homos + 9 * dn, h);
+            tB = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            load_taps2<F16>(plane + (size_t)dn * plane_stride_b, tB, st, vB);
+            asm volatile("" ::: "memory");   // keep the loads here: hipcc otherwise sinks them below the composite
+        }
+        VL3D_COMPOSITE(tA, vA)
+        if (d + 1 >= a.D) break;
+        {
+            const int dn = min(d + 2, a.D - 1);
+            float h[9];
+            load_uniform(a.homos + 9 * dn, h);
+            tA = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            load_taps2<F16>(plane + (size_t)dn * plane_stride_b, tA, st, vA);
+            asm volatile("" ::: "memory");
+        }
+        VL3D_COMPOSITE(tB, vB)
+        if (d + 2 >= a.D) break;
+    }
+    }
+#undef VL3D_COMPOSITE
+    const size_t pix = ((size_t)t * a.H + y) * a.W + x;
+    a.rgb[pix * 3 + 0] = cr; a.rgb[pix * 3 + 1] = cg; a.rgb[pix * 3 + 2] = cb;
+    a.alpha[pix] = A;
+    if (a.asum) { a.asum[pix * 2 + 0] = n1; a.asum[pix * 2 + 1] = n2; }
+}
+
+// Forward, two frames per thread.  Both render kernels are VALU-issue bound, and half of the forward's instruction
+// stream depends on the plane and the pixel only -- homography, perspective divide, base tap, tent weights, coverage, tap offset --
+// not on the frame: a thread that composites frames t and t+1 of its pixel side by side pays for it once.  The per-frame
+// arithmetic is that of render_fwd2_k instruction for instruction (same results bit for bit); the 8 tap loads per plane and
+// thread also replace occupancy as the source of memory parallelism (<= 128 VGPRs, 4 waves per SIMD).
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool F16>
+__global__ __launch_bounds__(64 * TY, 4) void render_fwd2x_k(RenderArgs a, int tiles_x, int tiles_y) {      // >= 4 waves per SIMD: <= 128 VGPRs
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_x = b % tiles_x, rest = b / tiles_x;
+    const int tile_y = rest % tiles_y, t0 = (rest / tiles_y) * 2;
+    const bool has1 = t0 + 1 < a.T;          // odd T: the last pair composites frame t0 twice and stores it once
+    const int x = tile_x * 64 + (threadIdx.x & 63);
+    const int y = tile_y * TY + (threadIdx.x >> 6);
+    if (x >= a.W || y >= a.H) return;
+    const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
+    const size_t frame_b = (size_t)a.Hs * a.Ws * (F16 ? 8 : 16);
+    const size_t plane_stride_b = (size_t)a.T * frame_b;
+    const char *plane0 = reinterpret_cast<const char *>(a.stack) + (size_t)t0 * frame_b;
+    const char *plane1 = plane0 + (has1 ? frame_b : 0);
+    float Tr0 = 1.0f, cr0 = 0.f, cg0 = 0.f, cb0 = 0.f, A0 = 0.f, n10 = 0.f, n20 = 0.f;
+    float Tr1 = 1.0f, cr1 = 0.f, cg1 = 0.f, cb1 = 0.f, A1 = 0.f, n11 = 0.f, n21 = 0.f;
+    const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
+    typedef typename TapVal<F16, ORDER>::type tapv_t;
+    tapv_t vA0[4], vA1[4], vB0[4], vB1[4];
+#define VL3D_COMPOSITE2(T_, V0_, V1_)                                        \
+    {                                                                        \
+        const f4 o0 = shade2<ORDER, RACT, AACT>(T_, V0_);                    \
+        const f4 o1 = shade2<ORDER, RACT, AACT>(T_, V1_);                    \
+        const float w0 = o0.w * Tr0, w1 = o1.w * Tr1;                        \
+        cr0 += w0 * o0.x; cg0 += w0 * o0.y; cb0 += w0 * o0.z; A0 += w0;      \
+        cr1 += w1 * o1.x; cg1 += w1 * o1.y; cb1 += w1 * o1.z; A1 += w1;      \
+        n10 += o0.w; n20 = fmaf(o0.w, o0.w, n20);                            \
+        n11 += o1.w; n21 = fmaf(o1.w, o1.w, n21);                            \
+        Tr0 *= (1.0f - o0.w); Tr1 *= (1.0f - o1.w);                          \
+    }
+    Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy), tB = tA;
+    load_taps2<F16>(plane0, tA, st, vA0);
+    load_taps2<F16>(plane1, tA, st, vA1);
+    for (int d = 0;; d += 2) {
+        {
+            const int dn = min(d + 1, a.D - 1);
+            float h[9];
+            load_uniform(a.homos + 9 * dn, h);
+            tB = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            load_taps2<F16>(plane0 + (size_t)dn * plane_stride_b, tB, st, vB0);
+            load_taps2<F16>(plane1 + (size_t)dn * plane_stride_b, tB, st, vB1);
+            asm volatile("" ::: "memory");
+        }
+        VL3D_COMPOSITE2(tA, vA0, vA1)
+        if (d + 1 >= a.D) break;
+        {
+            const int dn = min(d + 2, a.D - 1);
+            float h[9];
+            load_uniform(a.homos + 9 * dn, h);
+            tA = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            load_taps2<F16>(plane0 + (size_t)dn * plane_stride_b, tA, st, vA0);
+            load_taps2<F16>(plane1 + (size_t)dn * plane_stride_b, tA, st, vA1);
+            asm volatile("" ::: "memory");
+        }
+        VL3D_COMPOSITE2(tB, vB0, vB1)
+        if (d + 2 >= a.D) break;
+    }
+#undef VL3D_COMPOSITE2
+    size_t pix = ((size_t)t0 * a.H + y) * a.W + x;
+    a.rgb[pix * 3 + 0] = cr0; a.rgb[pix * 3 + 1] = cg0; a.rgb[pix * 3 + 2] = cb0;
+    a.alpha[pix] = A0;
+    if (a.asum) { a.asum[pix * 2 + 0] = n10; a.asum[pix * 2 + 1] = n20; }
+    if (has1) {
+        pix += (size_t)a.H * a.W;
+        a.rgb[pix * 3 + 0] = cr1; a.rgb[pix * 3 + 1] = cg1; a.rgb[pix * 3 + 2] = cb1;
+        a.alpha[pix] = A1;
+        if (a.asum) { a.asum[pix * 2 + 0] = n11; a.asum[pix * 2 + 1] = n21; }
+    }
+}
+
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
+void launch_fwd2x(const RenderArgs &a, hipStream_t s) {
+    constexpr int TY = 8;
+    const int tiles_x = (a.W + 63) / 64, tiles_y = (a.H + TY - 1) / TY;
+    hipLaunchKernelGGL((render_fwd2x_k<COORD, BORDER, ORDER, RACT, AACT, TY, F16>), dim3((unsigned)(tiles_x * tiles_y * ((a.T + 1) / 2))),
+                       dim3(64 * TY), 0, s, a, tiles_x, tiles_y);
+}
+
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool SWZ, bool F16 = false>
+void launch_fwd2(const RenderArgs &a, hipStream_t s) {
+    const int tiles_x = (a.W + 63) / 64, tiles_y = (a.H + TY - 1) / TY;
+    if (a.quad_keep && a.cull_masks) {       // tile culling: plan (frame independent), then the plane-list kernel
+        auto *masks = const_cast<unsigned long long *>(a.cull_masks);
+        (void)hipMemsetAsync(masks, 0, (size_t)tiles_x * tiles_y * 16, s);
+        const int n = tiles_x * tiles_y * a.D;
+        hipLaunchKernelGGL((cull_fwd_plan_k<COORD>), dim3((n + 255) / 256), dim3(256), 0, s, a, TY, tiles_x, tiles_y, masks);
+        hipLaunchKernelGGL((render_fwd2_k<COORD, BORDER, ORDER, RACT, AACT, TY, SWZ, F16, true>), dim3((unsigned)(tiles_x * tiles_y * a.T)),
+                           dim3(64 * TY), 0, s, a, tiles_x, tiles_y);
+        return;
+    }
+    hipLaunchKernelGGL((render_fwd2_k<COORD, BORDER, ORDER, RACT, AACT, TY, SWZ, F16>), dim3((unsigned)(tiles_x * tiles_y * a.T)),
+                       dim3(64 * TY), 0, s, a, tiles_x, tiles_y);
+}
+
+// =====================================================================================================
+// Backward, variant "tile": LDS-staged owner-computes accumulation (no global atomics, no memset).
+//
+// A workgroup owns an output tile of (RW-2) x (ROWS-2) pixels and additionally recomputes a 1-pixel halo
+// ring (RW x ROWS pixel region, one wave per region row).  Planes are walked front to back with the
+// per-pixel composite state in registers; for every plane each pixel of the region stages its texel
+// coordinates and its 4-channel gradient in LDS (plain ds_write), then every texel whose OWNER pixel
+//     p0(tau) = clamp_to_frame(round(H_d^-1 tau))
+// lies inside this workgroup's tile GATHERS its bilinear taps from the 3x3 staged pixels around p0 and is
+// written with one coalesced 16-byte store.  All contributions to a texel come from pixels within
+// |J^-1|_inf + 0.5 < 2 of its owner pixel, i.e. from the tile + 1-pixel halo, so each texel is written exactly
+// once with its complete sum, in a fixed order (bitwise reproducible; no atomics at all -- a first version
+// that scattered with ds_add_f32 into an LDS window measured 158 ms vs 30 ms without the LDS atomics).  Texels whose owner pixel is outside the
+// frame are zero-filled by bwd_owner_table_k (run first; it also zeroes a 1-pixel safety band that the
+// tile kernel then overwrites).  bwd_plan_k checks the geometric preconditions per call ON DEVICE
+// (Z>0 over the frame, magnification < 1.4x, window fits); if they fail, these kernels exit and the
+// universal atomics kernel above runs instead -- no host synchronisation either way.
+constexpr int RW = 64;        // region width in pixels = one wave
+constexpr int PLAN_HDR = 16;  // floats before the per-plane records
+constexpr int PLAN_REC = 12;  // per plane: 9 floats inverse texel homography, 2 floats gather radius (x,y), 1 pad
+// after the per-plane records (16-byte aligned): one int4 per (tile, plane) = texel window of the tile's owned pixels on
+// that plane: X0, Y0, width | height << 16, float bits of 1/width
+__host__ __device__ inline int plan_win_off(int D) { return (PLAN_HDR + PLAN_REC * D + 3) & ~3; }
+
+// texel-space homography  Ht = A_tex * H  (double), and its inverse
+template <int COORD>
+__device__ void texel_homography(const float *h, int Hs, int Ws, float sx, float sy, float ox, float oy, double M[9]) {
+    double ax, ay, bx, by;
+    if constexpr (COORD == VL3D_COORD_UTILS_MPI) { ax = (double)(Ws - 1) / Ws; ay = (double)(Hs - 1) / Hs; bx = by = 0.0; }
+    else { ax = sx; ay = sy; bx = ox; by = oy; }
+    for (int j = 0; j < 3; ++j) {
+        M[0 + j] = ax * h[0 + j] + bx * h[6 + j];
+        M[3 + j] = ay * h[3 + j] + by * h[6 + j];
+        M[6 + j] = h[6 + j];
+    }
+}
+
+template <int COORD>
+__global__ void bwd_plan_k(RenderArgs a, int rows, float *plan) {
+    __shared__ int ok_all;
+    if (threadIdx.x == 0) ok_all = 1;
+    __syncthreads();
+    for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
+        double M[9];
+        texel_homography<COORD>(a.homos + 9 * d, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, M);
+        const double det = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
+                           M[2] * (M[3] * M[7] - M[4] * M[6]);
+        bool ok = (det == det) && fabs(det) > 1e-30;
+        double I[9];
+        I[0] = (M[4] * M[8] - M[5] * M[7]) / det; I[1] = (M[2] * M[7] - M[1] * M[8]) / det; I[2] = (M[1] * M[5] - M[2] * M[4]) / det;
+        I[3] = (M[5] * M[6] - M[3] * M[8]) / det; I[4] = (M[0] * M[8] - M[2] * M[6]) / det; I[5] = (M[2] * M[3] - M[0] * M[5]) / det;
+        I[6] = (M[3] * M[7] - M[4] * M[6]) / det; I[7] = (M[1] * M[6] - M[0] * M[7]) / det; I[8] = (M[0] * M[4] - M[1] * M[3]) / det;
+        // normalise so the pixel-space w of the frame centre is ~1 (keeps fp32 well scaled)
+        for (int i = 0; i < 9; ++i) plan[PLAN_HDR + PLAN_REC * d + i] = (float)I[i];
+        double rxm = 0.0, rym = 0.0;
+        // geometric preconditions at a 3x3 grid of points of the (halo-extended) frame
+        for (int gy = 0; gy < 3 && ok; ++gy)
+            for (int gx = 0; gx < 3 && ok; ++gx) {
+                const double x = a.col0 + a.pc + (gx == 0 ? -2.0 : (gx == 1 ? 0.5 * a.W : a.W + 1.0));
+                const double y = a.row0 + a.pc + (gy == 0 ? -2.0 : (gy == 1 ? 0.5 * a.H : a.H + 1.0));
+                const double X = M[0] * x + M[1] * y + M[2], Y = M[3] * x + M[4] * y + M[5], Z = M[6] * x + M[7] * y + M[8];
+                if (!(Z > 1e-20)) { ok = false; break; }
+                const double j00 = (M[0] * Z - X * M[6]) / (Z * Z), j01 = (M[1] * Z - X * M[7]) / (Z * Z);
+                const double j10 = (M[3] * Z - Y * M[6]) / (Z * Z), j11 = (M[4] * Z - Y * M[7]) / (Z * Z);
+                const double dj = j00 * j11 - j01 * j10;
+                if (!(fabs(dj) > 1e-12)) { ok = false; break; }
+                // |J^-1|_inf < 1.4  (contributions to a texel stay within the 1-pixel halo of its owner pixel)
+                const double i_r0 = (fabs(j11) + fabs(j01)) / fabs(dj), i_r1 = (fabs(j10) + fabs(j00)) / fabs(dj);
+                if (!(i_r0 < 1.4 && i_r1 < 1.4)) ok = false;
+                rxm = fmax(rxm, i_r0); rym = fmax(rym, i_r1);
+                // keep the owned footprint of a tile a small multiple of the workgroup (pure efficiency guard)
+                if (!(fabs(j00) + fabs(j01) < 4.0 && fabs(j10) + fabs(j11) < 4.0)) ok = false;
+            }
+        // gather radius per axis: a pixel p contributes to texel tau only if |p - H^-1 tau| < |J^-1|_inf-row (2% safety)
+        plan[PLAN_HDR + PLAN_REC * d + 9] = (float)fmin(1.02 * rxm + 1e-3, 1.45);
+        plan[PLAN_HDR + PLAN_REC * d + 10] = (float)fmin(1.02 * rym + 1e-3, 1.45);
+        if (!ok) atomicAnd(&ok_all, 0);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { reinterpret_cast<int *>(plan)[0] = ok_all; reinterpret_cast<int *>(plan)[1] = 0; }
+    if (threadIdx.x < 4) plan[4 + threadIdx.x] = 0.0f;     // four zero floats: stand-in for g_reg when only the sparsity sums have a gradient
+}
+
+// Texel window of every (tile, plane): the footprint of the tile's owned pixels, from the image of its four corners
+// (convex image of a rectangle, Z>0).  Texels owned by a tile have their owner pixel inside it, i.e. H^-1(tau) within 0.5 px
+// of the tile (0.55 here: the margin absorbs the fp32 error of the corner images); beyond a frame border the owner is the
+// clamped border pixel, so only texels within the 1.4 px contribution range matter (1.6).  Frame independent: computed
+// once per call here instead of by wave 0 of every workgroup for every plane (90 VALU instructions on the barrier path).
+template <int COORD>
+__global__ __launch_bounds__(256) void bwd_windows_k(RenderArgs a, int iw, int ih, int rh, int tiles_x, int tiles_y, int *win) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= tiles_x * tiles_y * a.D) return;
+    const int d = i % a.D, tile = i / a.D, tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+    const int ix0 = tile_x * iw, ix1 = min(ix0 + iw - 1, a.W - 1), iy0 = tile_y * ih, iy1 = min(iy0 + ih - 1, a.H - 1);
+    const float el = (ix0 == 0) ? 1.6f : 0.55f, er = (ix1 == a.W - 1) ? 1.6f : 0.55f;
+    const float et = (iy0 == 0) ? 1.6f : 0.55f, eb = (iy1 == a.H - 1) ? 1.6f : 0.55f;
+    const float *h = a.homos + 9 * d;
+    float mnx = 1e30f, mxx = -1e30f, mny = 1e30f, mxy = -1e30f;
+    for (int c = 0; c < 4; ++c) {
+        const float cx = (float)a.col0 + a.pc + ((c & 1) ? (float)ix1 + er : (float)ix0 - el);
+        const float cy = (float)a.row0 + a.pc + ((c & 2) ? (float)iy1 + eb : (float)iy0 - et);
+        const float X = h[0] * cx + h[1] * cy + h[2], Y = h[3] * cx + h[4] * cy + h[5], Z = h[6] * cx + h[7] * cy + h[8];
+        const float ctx = texel_coord<COORD>(X / Z, (float)a.Ws / 2.0f, (float)(a.Ws - 1), a.sx, a.ox);
+        const float cty = texel_coord<COORD>(Y / Z, (float)a.Hs / 2.0f, (float)(a.Hs - 1), a.sy, a.oy);
+        mnx = fminf(mnx, ctx); mxx = fmaxf(mxx, ctx); mny = fminf(mny, cty); mxy = fmaxf(mxy, cty);
+    }
+    const int wX0 = max(0, (int)ceilf(fmaxf(mnx - 0.01f, -2.0f))), wY0 = max(0, (int)ceilf(fmaxf(mny - 0.01f, -2.0f)));
+    const int wX1 = min(a.Ws - 1, (int)floorf(fminf(mxx + 0.01f, (float)a.Ws)));
+    const int wY1 = min(a.Hs - 1, (int)floorf(fminf(mxy + 0.01f, (float)a.Hs)));
+    const int ww = min(max(0, wX1 - wX0 + 1), 0xffff), wh = min(max(0, wY1 - wY0 + 1), 0x3fff);
+    int4 rec;
+    const bool empty = ww == 0 || wh == 0;    // keep the corner a valid texel: the gather prefetches relative to it
+    rec.x = empty ? 0 : wX0; rec.y = empty ? 0 : wY0; rec.z = empty ? 0 : (ww | (wh << 16)); rec.w = __float_as_int(1.0f / (float)max(ww, 1));
+    // bit 30: "pixels are at least a texel apart" on this tile -- J = d texel / d pixel has J00 - |J01| >= 1 and J11 - |J10| >= 1
+    // on the tile's region.  Then, for a texel tau with owner pixel p0 and u = tau - t(p0), the pixel p0 + e with e_x = -sign(u_x)
+    // lies at |t_x(p0+e) - tau_x| = J00 + |u_x| -/+ J01 e_y >= 1, i.e. has tent weight exactly 0 (same along y): only the 2x2
+    // block of p0 towards tau contributes, and the gather reads 4 staged pixels instead of 9 (no-minification views, e.g.
+    // stacks stored at >= the frame's resolution as the reference's are: mpi_h/w_scale 1.1, configs/mpv_base.txt:10-11).
+    {
+        float ax, ay;
+        if constexpr (COORD == VL3D_COORD_UTILS_MPI) { ax = (float)(a.Ws - 1) / (float)a.Ws; ay = (float)(a.Hs - 1) / (float)a.Hs; }
+        else { ax = a.sx; ay = a.sy; }
+        bool apart = !a.gather9;
+        for (int c = 0; c < 4; ++c) {     // region corners (tile + halo); J is monotone enough over <= 70 pixels for the 1e-3 margin
+            const float cx = (float)a.col0 + a.pc + (float)((c & 1) ? tile_x * iw + iw - 1 + rh + 1 : ix0 - rh - 1);
+            const float cy = (float)a.row0 + a.pc + (float)((c & 2) ? tile_y * ih + ih - 1 + rh + 1 : iy0 - rh - 1);
+            const float X = h[0] * cx + h[1] * cy + h[2], Y = h[3] * cx + h[4] * cy + h[5], Z = h[6] * cx + h[7] * cy + h[8];
+            const float iz2 = 1.0f / (Z * Z);
+            const float j00 = ax * (h[0] * Z - X * h[6]) * iz2, j01 = ax * (h[1] * Z - X * h[7]) * iz2;
+            const float j10 = ay * (h[3] * Z - Y * h[6]) * iz2, j11 = ay * (h[4] * Z - Y * h[7]) * iz2;
+            apart = apart && (Z > 0.0f) && (j00 - fabsf(j01) >= 1.001f) && (j11 - fabsf(j10) >= 1.001f);
+        }
+        if (apart && !empty) rec.z |= 0x40000000;
+    }
+    if (a.quad_keep) {
+        // tile culling: bit 31 of the size word = no pixel of the tile's region (interior + halo) can see a kept quad of this
+        // plane -> the tile kernel skips the plane's sweep and writes zeros to the texels it owns
+        const int qx0 = max(ix0 - rh, 0), qx1 = min(tile_x * iw + iw - 1 + rh, a.W - 1);
+        const int qy0 = max(iy0 - rh, 0), qy1 = min(tile_y * ih + ih - 1 + rh, a.H - 1);
+        float tnx = 1e30f, txx = -1e30f, tny = 1e30f, txy = -1e30f;
+        for (int c = 0; c < 4; ++c) {
+            const float cx = (float)a.col0 + a.pc + (float)((c & 1) ? qx1 : qx0), cy = (float)a.row0 + a.pc + (float)((c & 2) ? qy1 : qy0);
+            const float X = h[0] * cx + h[1] * cy + h[2], Y = h[3] * cx + h[4] * cy + h[5], Z = h[6] * cx + h[7] * cy + h[8];
+            const float ctx = texel_coord<COORD>(X / Z, (float)a.Ws / 2.0f, (float)(a.Ws - 1), a.sx, a.ox);
+            const float cty = texel_coord<COORD>(Y / Z, (float)a.Hs / 2.0f, (float)(a.Hs - 1), a.sy, a.oy);
+            tnx = fminf(tnx, ctx); txx = fmaxf(txx, ctx); tny = fminf(tny, cty); txy = fmaxf(txy, cty);
+        }
+        if (!box_touches_kept_quad(a, d, tnx, txx, tny, txy)) rec.z |= (int)0x80000000;
+    }
+    reinterpret_cast<int4 *>(win)[i] = rec;     // [tile][plane]: one contiguous run per workgroup
+}
+
+// owner pixel (float, before rounding) of texel (tx,ty) on plane d, relative to this window's pixel origin
+__device__ __forceinline__ void owner_pixel(const float *__restrict__ hi, float tx, float ty, float pc, int col0, int row0,
+                                            float &px, float &py) {
+    const float X = hi[0] * tx + hi[1] * ty + hi[2];
+    const float Y = hi[3] * tx + hi[4] * ty + hi[5];
+    const float Z = hi[6] * tx + hi[7] * ty + hi[8];
+    const float rz = fast_rcp(Z);
+    px = X * rz - pc - (float)col0;
+    py = Y * rz - pc - (float)row0;
+}
+
+// Owner table: for every texel of every plane, the tile that owns it (the tile of its owner pixel p0 = clamp_to_frame(
+// round(H_d^-1 tau))) and p0's index in that tile's pixel region, packed as tile << 10 | index.  Frame independent, so it
+// is built once per call (D*Hs*Ws entries) and read once per frame by the gather, which then needs no inverse homography,
+// reciprocal, rounding or range tests per texel (~200 of its ~400 VALU issue cycles, profiles/microbench/isa_cost.py).
+__global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, int ih, int rh, int tiles_x, unsigned short *owner, int rw = 64) {
+    if (!reinterpret_cast<const int *>(a.plan)[0]) return;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int d = blockIdx.z;
+    if (x >= a.Ws || y >= a.Hs) return;
+    float qx, qy;
+    owner_pixel(a.plan + PLAN_HDR + PLAN_REC * d, (float)x, (float)y, a.pc, a.col0, a.row0, qx, qy);
+    // owner = nearest FRAME pixel: texels just outside the frame still collect taps of the border pixels
+    const float rxf = fminf(fmaxf(rintf(qx), 0.0f), (float)(a.W - 1)), ryf = fminf(fmaxf(rintf(qy), 0.0f), (float)(a.H - 1));
+    const int rx = (int)rxf, ry = (int)ryf;
+    // tile of the owner pixel: floor((r + 0.5) / size) in fp32 is exact for frame coordinates (< 2^22) -- no integer division
+    const int tx = (int)((rxf + 0.5f) * (1.0f / (float)iw)), ty = (int)((ryf + 0.5f) * (1.0f / (float)ih));
+    const unsigned lc = (unsigned)((ry - ty * ih + rh) * rw + (rx - tx * iw + rh));     // rw: the tile kernel's region width
+    // a tile's window only holds texels owned by itself or tiles a few steps away (the window is the bounding box of the tile's
+    // image; under the plan's rotation / magnification limits its corners reach < 4 tiles), which the three low bits of each
+    // tile coordinate tell apart: 16 bits per texel
+    owner[((size_t)d * a.Hs + y) * a.Ws + x] = (unsigned short)((((unsigned)(ty & 7) << 3 | (unsigned)(tx & 7)) << 10) | lc);
+    // same pass (it already has the texel's owner pixel): texels no tile is certain to own -- owner pixel on or outside the frame's
+    // border ring -- are zero-filled for all T frames here, so nothing memsets the gradient; the tile kernel runs after this
+    // kernel and overwrites the border ring's texels it does own
+    const bool safe = (qx > 0.5f) && (qx < (float)a.W - 1.5f) && (qy > 0.5f) && (qy < (float)a.H - 1.5f);
+    if (safe) return;
+    const size_t frame = (size_t)a.Hs * a.Ws;
+    if (a.g_f16) {
+        float2 *g = reinterpret_cast<float2 *>(a.g_stack) + (size_t)d * a.T * frame + (size_t)y * a.Ws + x;
+        for (int t = 0; t < a.T; ++t, g += frame) *g = make_float2(0.f, 0.f);
+    } else {
+        float4 *g = reinterpret_cast<float4 *>(a.g_stack) + (size_t)d * a.T * frame + (size_t)y * a.Ws + x;
+        for (int t = 0; t < a.T; ++t, g += frame) *g = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void bwd_fill_zero_if_infeasible_k(float2 *g, size_t n8, const float *plan) {      // n8: 8-byte units
+    if (reinterpret_cast<const int *>(plan)[0]) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) g[i] = make_float2(0.f, 0.f);
+}
+
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16, bool CULL = false>
+__global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(RenderArgs a) {
+    if (!reinterpret_cast<const int *>(a.plan)[0]) return;
+    constexpr int NT = RW * ROWS;
+    // REG: the layer-space smoothness regularisers (MPV.py:517-531) are differentiated here as well.  Their gradient at a
+    // pixel needs the activated layer values of its 4 neighbours, so the region carries a 2-pixel halo (outer ring: layer
+    // values only; inner ring: full gradient providers for the gather) and one more LDS stage + barrier per plane.
+    constexpr int RH = REG ? 2 : 1;
+    __shared__ float4 s_o[REG ? NT : 1];
+    // per-plane staging of the region's pixels, double buffered so one barrier per plane suffices
+    __shared__ float4 s_g[2][NT];     // gradient w.r.t. the sampled (POST) / activated (PRE) value of this pixel on this plane
+    __shared__ float2 s_t[2][NT];     // its texel coordinates (tx,ty) (true ones also where the plane does not cover it: then g = 0)
+    const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
+    // 1-D grid, XCD-aware order: every XCD walks a contiguous run of tiles (row-major within a frame), so a tile's halo
+    // rows and its neighbours' taps hit the same L2
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_x = bid % a.tiles_x, rest = bid / a.tiles_x;
+    const int tile_y = rest % a.tiles_y, t = rest / a.tiles_y;
+    const int rx0 = tile_x * (RW - 2 * RH) - RH, ry0 = tile_y * (ROWS - 2 * RH) - RH;
+    const int x = rx0 + lane, y = ry0 + row;
+    const bool inimg = (x >= 0) && (x < a.W) && (y >= 0) && (y < a.H);
+    // owned (interior) pixel range of this workgroup, clipped to the frame: [ix0,ix1] x [iy0,iy1]
+    const int ix0 = max(rx0 + RH, 0), ix1 = min(rx0 + RW - 1 - RH, a.W - 1);
+    const int iy0 = max(ry0 + RH, 0), iy1 = min(ry0 + ROWS - 1 - RH, a.H - 1);
+    const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
+    constexpr size_t TEXB = F16 ? 8 : 16;
+    const size_t frame = (size_t)a.Hs * a.Ws * 4;
+    const size_t plane_stride = (size_t)a.T * frame;
+    const size_t plane_stride_b = (size_t)a.T * a.Hs * a.Ws * TEXB;
+    const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * a.Hs * a.Ws * TEXB;
+    char *gplane = reinterpret_cast<char *>(a.g_stack) + (size_t)t * a.Hs * a.Ws * TEXB;       // gradient texels = stack texels
+    float Gr = 0.f, Gg = 0.f, Gb = 0.f, gA = 0.f, S = 0.f, gN1 = 0.f, gN2 = 0.f;   // gN1 + gN2*a_k = d(sparsity sums)/da_k
+    if (inimg) {
+        const size_t pix = ((size_t)t * a.H + y) * a.W + x;
+        Gr = a.g_rgb[pix * 3 + 0]; Gg = a.g_rgb[pix * 3 + 1]; Gb = a.g_rgb[pix * 3 + 2];
+        gA = a.g_alpha ? a.g_alpha[pix] : 0.0f;
+        S = dot3p(Gr, a.rgb[pix * 3 + 0], Gg, a.rgb[pix * 3 + 1], Gb, a.rgb[pix * 3 + 2], gA * a.alpha[pix]);
+        // the sparsity-sum gradients ride in the REG instantiation only (launch_t): the plain one is at its 64-VGPR budget
+        if constexpr (REG) if (a.g_asum) { gN1 = a.g_asum[pix * 2 + 0]; gN2 = 2.0f * a.g_asum[pix * 2 + 1]; }
+    }
+    float Tr = 1.0f, P = 0.0f;
+    float gsx_c = 0.f, gsy_c = 0.f, gsx_a = 0.f, gsy_a = 0.f;
+    if constexpr (REG) { gsx_c = a.g_reg[0]; gsy_c = a.g_reg[1]; gsx_a = a.g_reg[2]; gsy_a = a.g_reg[3]; }
+    // pixels of the outermost ring only provide layer values in REG mode
+    const bool provider = !REG || (lane >= 1 && lane <= RW - 2 && row >= 1 && row <= ROWS - 2);
+    const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
+    // this tile's texel windows, one int4 per plane (bwd_windows_k)
+    const unsigned my_tile_id = (unsigned)(tile_y * a.tiles_x + tile_x);
+    const unsigned my_tile = (unsigned)((tile_y & 7) << 3 | (tile_x & 7));      // the owner table's code of this tile
+    const unsigned toff_thread = (unsigned)(row * a.Ws + lane);   // texel (lane, row) of a window, relative to its corner
+    const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)my_tile_id * a.D * 4;
+    int nswept = 0;
+    for (int d = 0; d < a.D; ++d, plane += plane_stride_b, gplane += plane_stride_b) {
+        float h[9];
+        load_uniform(a.homos + 9 * d, h);
+        // texel window of this tile on plane d (wave = window row, lane = window column); bit 31: culled for this tile
+        const int X0 = wrec[4 * d], Y0 = wrec[4 * d + 1], wwh = wrec[4 * d + 2];
+        const int ww = wwh & 0xffff, wh = (wwh >> 16) & 0x3fff;
+        const bool culled = CULL && wwh < 0;
+        const bool apart = (wwh & 0x40000000) != 0;      // pixels >= 1 texel apart on this tile: 2x2 gather (bwd_windows_k)
+        // staging buffer of this plane: alternates over the planes that are actually swept (a culled plane has no barrier)
+        const int buf = CULL ? (nswept & 1) : (d & 1);
+        if constexpr (CULL) nswept += culled ? 0 : 1;
+        const unsigned win0 = (unsigned)(Y0 * a.Ws + X0);          // frame texel index of the window's corner (uniform)
+        const unsigned short *oplane = a.owner + (size_t)d * a.Hs * a.Ws;
+        // this thread's first owner-table entry, requested now so that it arrives in the shadow of the sweep.  Unconditional
+        // (threads outside the window read a neighbouring entry -- the table is padded by ROWS rows -- and ignore it): no
+        // branch around the load, so no merged wait counters.
+        const unsigned e0 = oplane[win0 + toff_thread];
+        if (CULL && culled) {
+            // tile culling: no pixel of the region sees a kept quad of this plane -- its alpha is exactly 0 for all of them, the
+            // composite state does not move, and the texels this tile owns get a zero gradient (written: nothing memsets it)
+            const f4 z = f4{0.f, 0.f, 0.f, 0.f};
+            if (row < wh && lane < ww && (e0 >> 10) == my_tile)
+                store_grad_texel<F16>(gplane, (win0 + toff_thread) << 4, z);
+            for (int wy = row; wy < wh; wy += ROWS)
+                for (int wx = lane + (wy == row ? RW : 0); wx < ww; wx += RW) {
+                    const unsigned tix = win0 + (unsigned)(wy * a.Ws + wx);
+                    if ((oplane[tix] >> 10) == my_tile)
+                        store_grad_texel<F16>(gplane, tix << 4, z);
+                }
+            continue;
+        }
+        // (2) sample this pixel on plane d, composite backward, stage (tx,ty,g) in LDS   (branch-free taps)
+        float2 tc = make_float2(0.f, 0.f);        // pixels outside the frame: any finite coordinate (their gradient is 0)
+        float4 gval = make_float4(0.f, 0.f, 0.f, 0.f);
+        f4 o = f4{0.f, 0.f, 0.f, 0.f}, pre = o;
+        Taps2 tp{};
+        if (inimg) {
+            if constexpr (CULL) tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
+            else tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            const char *src = plane;
+            if (a.ablate & 4) {   // measurement only: all taps from a 64 KiB cache-resident window
+                src = reinterpret_cast<const char *>(a.stack);
+                tp.off &= 0xfff0u;
+            }
+            typename TapVal<F16, ORDER>::type tv[4];
+            load_taps2<F16>(src, tp, st, tv);
+            o = shade2<ORDER, RACT, AACT>(tp, tv, &pre);                 // o.w already 0 when the plane does not cover the pixel
+        }
+        f4 sg = f4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (REG) {
+            // layer value as the reference's zero canvas has it: 0 in ALL channels where the plane does not cover (MPV.py:441)
+            const f4 ol = o * tp.cov;
+            s_o[tid] = make_float4(ol.x, ol.y, ol.z, ol.w);
+            __syncthreads();      // (A) layer values of the region visible
+            if (inimg && provider) {
+                const f4 gx = f4{gsx_c, gsx_c, gsx_c, gsx_a}, gy = f4{gsy_c, gsy_c, gsy_c, gsy_a};
+                auto sgn = [](f4 v) { return f4{(float)((v.x > 0.f) - (v.x < 0.f)), (float)((v.y > 0.f) - (v.y < 0.f)),
+                                                (float)((v.z > 0.f) - (v.z < 0.f)), (float)((v.w > 0.f) - (v.w < 0.f))}; };
+                auto ld = [&](int i) { const float4 v = s_o[i]; return f4{v.x, v.y, v.z, v.w}; };
+                if (x + 1 < a.W) sg += gx * sgn(ol - ld(tid + 1));          // d|o - o_right| / do
+                if (x >= 1) sg -= gx * sgn(ld(tid - 1) - ol);               // d|o_left - o| / do
+                if (y + 1 < a.H) sg += gy * sgn(ol - ld(tid + RW));
+                if (y >= 1) sg -= gy * sgn(ld(tid - RW) - ol);
+            }
+        }
+        if (inimg) {
+            const float q = dot3p(Gr, o.x, Gg, o.y, Gb, o.z, gA);
+            const float w = o.w * Tr;
+            P = fmaf(w, q, P);
+            const float om = 1.0f - o.w;
+            const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;
+            gval = make_float4(w * Gr + sg.x, w * Gg + sg.y, w * Gb + sg.z, fmaf(Tr, q, -behind) + sg.w + (REG ? fmaf(gN2, o.w, gN1) : 0.0f));   // grad wrt activated (c, a)
+            Tr *= om;
+            if constexpr (ORDER == VL3D_ACT_POST)
+                gval = make_float4(gval.x * act_bwd<RACT>(pre.x, o.x), gval.y * act_bwd<RACT>(pre.y, o.y),
+                                   gval.z * act_bwd<RACT>(pre.z, o.z), gval.w * act_bwd<AACT>(pre.w, o.w));
+            // every frame pixel stages its true coordinates (the 2x2 gather picks its block from the owner pixel's); a pixel the
+            // plane does not cover, or a layer-only halo pixel, provides a zero gradient instead of a zero weight
+            tc = make_float2(tp.tx, tp.ty);
+            if (!(tp.cov > 0.0f && provider)) gval = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        s_t[buf][tid] = tc;
+        s_g[buf][tid] = gval;
+        __syncthreads();   // staging of plane d visible (the other buffer may still be read by slower waves: not touched here)
+        // (3) every texel of this tile's window that the owner table assigns to this tile gathers its taps from the 3x3
+        //     pixels around its owner pixel.  Wave = window row, lane = window column: uniform row bases, no index arithmetic.
+        if (a.ablate & 1) continue;
+        auto gather = [&](unsigned e, int wx, int wy, unsigned tix) {   // tix = frame texel index of window texel (wx, wy)
+            if ((e >> 10) != my_tile) return;
+            // fixed trip count, constant LDS offsets; weights clamp to 0 for non-contributing pixels (|J^-1|_inf < 1.4)
+            const int lc = (int)(e & 1023u);
+            const f2 tau = f2{(float)(X0 + wx), (float)(Y0 + wy)};
+            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+            if (a.ablate & 8) {
+            } else if (apart) {
+                // 2x2 block of the owner pixel towards tau, summed in the 3x3 loop's order: the five pixels left out have weight
+                // exactly 0 there, so both gathers give the same bits
+                const f2 c0 = *reinterpret_cast<const f2 *>(&s_t[buf][lc]);
+                const int li0 = lc - (tau.x < c0.x ? 1 : 0) - (tau.y < c0.y ? RW : 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int li = li0 + (k >> 1) * RW + (k & 1);
+                    const f2 dc = *reinterpret_cast<const f2 *>(&s_t[buf][li]) - tau;
+                    acc += *reinterpret_cast<const f4 *>(&s_g[buf][li]) * (tent_weight(dc.x) * tent_weight(dc.y));
+                }
+            } else {
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int li = lc + dy * RW + dx;
+                    const f2 dc = *reinterpret_cast<const f2 *>(&s_t[buf][li]) - tau;
+                    acc += *reinterpret_cast<const f4 *>(&s_g[buf][li]) * (tent_weight(dc.x) * tent_weight(dc.y));
+                }
+            }
+            if constexpr (ORDER == VL3D_ACT_PRE) {   // d act(s_tau)/d s_tau factors out of the tap sum
+                const f4 sv = load_texel<F16>(plane, tix << 4);
+                acc = f4{acc.x * act_bwd<RACT>(sv.x, act_fwd<RACT>(sv.x)), acc.y * act_bwd<RACT>(sv.y, act_fwd<RACT>(sv.y)),
+                         acc.z * act_bwd<RACT>(sv.z, act_fwd<RACT>(sv.z)), acc.w * act_bwd<AACT>(sv.w, act_fwd<AACT>(sv.w))};
+            }
+            if (!(a.ablate & 2)) store_grad_texel<F16>(gplane, tix << 4, acc);
+        };
+        if (row < wh && lane < ww) gather(e0, lane, row, win0 + toff_thread);
+        // rest of a window larger than 64 x ROWS (stacks stored above the frame's resolution, frame-border tiles, rotations)
+        const int nec = ww - RW;                     // columns right of the first 64 (uniform)
+        if (nec > 0 && nec <= RW) {
+            // right strip of the first ROWS rows, packed: 64 >> sh rows per wave (sh = ceil log2 of its width), so a 6-texel strip
+            // of 16 rows is 2 wave passes instead of 16 passes with 6 active lanes each
+            const int sh = nec > 1 ? 32 - __builtin_clz((unsigned)(nec - 1)) : 0, rpw = RW >> sh, rmain = min(wh, ROWS);
+            const int c = lane & ((1 << sh) - 1), r = lane >> sh;
+            for (int wy0 = row * rpw; wy0 < rmain; wy0 += ROWS * rpw) {
+                const int wy = wy0 + r, wx = RW + c;
+                if (c < nec && wy < rmain) {
+                    const unsigned tix = win0 + (unsigned)(wy * a.Ws + wx);
+                    gather(oplane[tix], wx, wy, tix);
+                }
+            }
+        } else if (nec > RW) {
+            for (int wx = lane + RW; wx < ww && row < wh; wx += RW) {
+                const unsigned tix = win0 + (unsigned)(row * a.Ws + wx);
+                gather(oplane[tix], wx, row, tix);
+            }
+        }
+        for (int wy = row + ROWS; wy < wh; wy += ROWS)      // rows below the first ROWS: one wave per row
+            for (int wx = lane; wx < ww; wx += RW) {
+                const unsigned tix = win0 + (unsigned)(wy * a.Ws + wx);
+                gather(oplane[tix], wx, wy, tix);
+            }
+    }
+}
+
+
+
+// =====================================================================================================
+// Backward, two frames per thread (dense stacks, no layer regularisers).  render_bwd_tile_k is VALU-issue bound, and almost
+// half of its instruction stream does not depend on the frame: the sweep's homography / divide / base tap / tents / coverage /
+// offset, the gather's owner decode and all of its tent weights.  A workgroup of this kernel owns a 30 x 14-pixel tile of
+// frames t and t+1 (32 x 16 region, 512 threads, 2 workgroups per CU at <= 128 VGPRs): one set of coordinates and weights,
+// two composite states, two staged gradients, two accumulators, two stores.  Per frame the arithmetic is that of
+// render_bwd_tile_k in the same order (same bits).  Pre-pass kernels, owner table and window records are shared (region
+// width 32 in the owner table's slots).
+constexpr int PW = 32, PROWS = 16, PNT = PW * PROWS;
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
+__global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {      // >= 4 waves per SIMD (2 workgroups per CU): <= 128 VGPRs
+    if (!reinterpret_cast<const int *>(a.plan)[0]) return;
+    __shared__ float4 s_g[2][2][PNT];   // [buffer][frame][pixel]
+    __shared__ float2 s_t[2][PNT];
+    const int tid = threadIdx.x, col = tid & (PW - 1), row = tid >> 5;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_x = bid % a.tiles_x, rest = bid / a.tiles_x;
+    const int tile_y = rest % a.tiles_y, t0 = (rest / a.tiles_y) * 2;
+    const bool has1 = t0 + 1 < a.T;          // odd T: the last pair sweeps frame t0 twice and stores it once
+    const int rx0 = tile_x * (PW - 2) - 1, ry0 = tile_y * (PROWS - 2) - 1;
+    const int x = rx0 + col, y = ry0 + row;
+    const bool inimg = (x >= 0) && (x < a.W) && (y >= 0) && (y < a.H);
+    const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
+    constexpr size_t TEXB = F16 ? 8 : 16;
+    const size_t frame_b = (size_t)a.Hs * a.Ws * TEXB;
+    const size_t plane_stride_b = (size_t)a.T * frame_b;
+    const char *plane0 = reinterpret_cast<const char *>(a.stack) + (size_t)t0 * frame_b;
+    char *gplane0 = reinterpret_cast<char *>(a.g_stack) + (size_t)t0 * frame_b;
+    const size_t f1 = has1 ? frame_b : 0;
+    float Gr0 = 0.f, Gg0 = 0.f, Gb0 = 0.f, gA0 = 0.f, S0 = 0.f, Gr1 = 0.f, Gg1 = 0.f, Gb1 = 0.f, gA1 = 0.f, S1 = 0.f;
+    if (inimg) {
+        size_t pix = ((size_t)t0 * a.H + y) * a.W + x;
+        Gr0 = a.g_rgb[pix * 3 + 0]; Gg0 = a.g_rgb[pix * 3 + 1]; Gb0 = a.g_rgb[pix * 3 + 2];
+        gA0 = a.g_alpha ? a.g_alpha[pix] : 0.0f;
+        S0 = dot3p(Gr0, a.rgb[pix * 3 + 0], Gg0, a.rgb[pix * 3 + 1], Gb0, a.rgb[pix * 3 + 2], gA0 * a.alpha[pix]);
+        if (has1) pix += (size_t)a.H * a.W;
+        Gr1 = a.g_rgb[pix * 3 + 0]; Gg1 = a.g_rgb[pix * 3 + 1]; Gb1 = a.g_rgb[pix * 3 + 2];
+        gA1 = a.g_alpha ? a.g_alpha[pix] : 0.0f;
+        S1 = dot3p(Gr1, a.rgb[pix * 3 + 0], Gg1, a.rgb[pix * 3 + 1], Gb1, a.rgb[pix * 3 + 2], gA1 * a.alpha[pix]);
+    }
+    float Tr0 = 1.0f, P0 = 0.0f, Tr1 = 1.0f, P1 = 0.0f;
+    const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
+    const unsigned my_tile_id = (unsigned)(tile_y * a.tiles_x + tile_x);
+    const unsigned my_tile = (unsigned)((tile_y & 7) << 3 | (tile_x & 7));
+    const unsigned toff_thread = (unsigned)(row * a.Ws + col);
+    const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)my_tile_id * a.D * 4;
+    typedef typename TapVal<F16, ORDER>::type tapv_t;
+    for (int d = 0; d < a.D; ++d, plane0 += plane_stride_b, gplane0 += plane_stride_b) {
+        float h[9];
+        load_uniform(a.homos + 9 * d, h);
+        const int X0 = wrec[4 * d], Y0 = wrec[4 * d + 1], wwh = wrec[4 * d + 2];
+        const int ww = wwh & 0xffff, wh = (wwh >> 16) & 0x3fff;
+        const bool apart = (wwh & 0x40000000) != 0;
+        const int buf = d & 1;
+        const unsigned win0 = (unsigned)(Y0 * a.Ws + X0);
+        const unsigned short *oplane = a.owner + (size_t)d * a.Hs * a.Ws;
+        const unsigned e0 = oplane[win0 + toff_thread];          // unconditional (padded table), arrives in the shadow of the sweep
+        // (2) sweep: one set of taps, two frames
+        float2 tc = make_float2(0.f, 0.f);
+        float4 gv0 = make_float4(0.f, 0.f, 0.f, 0.f), gv1 = gv0;
+        if (inimg) {
+            const Taps2 tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            tapv_t tv0[4], tv1[4];
+            load_taps2<F16>(plane0, tp, st, tv0);
+            load_taps2<F16>(plane0 + f1, tp, st, tv1);
+            f4 pre0, pre1;
+            const f4 o0 = shade2<ORDER, RACT, AACT>(tp, tv0, &pre0);
+            const f4 o1 = shade2<ORDER, RACT, AACT>(tp, tv1, &pre1);
+#define VL3D_PAIR_GRAD(o, pre, Gr, Gg, Gb, gA, S, P, Tr, gv)                                                                   \
+            {                                                                                                                      \
+                const float q = dot3p(Gr, o.x, Gg, o.y, Gb, o.z, gA);                                                              \
+                const float w = o.w * Tr;                                                                                          \
+                P = fmaf(w, q, P);                                                                                                 \
+                const float om = 1.0f - o.w;                                                                                       \
+                const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;                                                \
+                gv = make_float4(w * Gr, w * Gg, w * Gb, fmaf(Tr, q, -behind));                                                    \
+                Tr *= om;                                                                                                          \
+                if constexpr (ORDER == VL3D_ACT_POST)                                                                              \
+                    gv = make_float4(gv.x * act_bwd<RACT>(pre.x, o.x), gv.y * act_bwd<RACT>(pre.y, o.y),                          \
+                                     gv.z * act_bwd<RACT>(pre.z, o.z), gv.w * act_bwd<AACT>(pre.w, o.w));                          \
+            }
+            VL3D_PAIR_GRAD(o0, pre0, Gr0, Gg0, Gb0, gA0, S0, P0, Tr0, gv0)
+            VL3D_PAIR_GRAD(o1, pre1, Gr1, Gg1, Gb1, gA1, S1, P1, Tr1, gv1)
+#undef VL3D_PAIR_GRAD
+            tc = make_float2(tp.tx, tp.ty);
+            if (!(tp.cov > 0.0f)) { gv0 = make_float4(0.f, 0.f, 0.f, 0.f); gv1 = gv0; }
+        }
+        s_t[buf][tid] = tc;
+        s_g[buf][0][tid] = gv0;
+        s_g[buf][1][tid] = gv1;
+        __syncthreads();
+        // (3) gather: one set of weights, two accumulators
+        auto gather = [&](unsigned e, int wx, int wy, unsigned tix) {
+            if ((e >> 10) != my_tile) return;
+            const int lc = (int)(e & 1023u);
+            const f2 tau = f2{(float)(X0 + wx), (float)(Y0 + wy)};
+            f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            if (apart) {
+                const f2 c0 = *reinterpret_cast<const f2 *>(&s_t[buf][lc]);
+                const int li0 = lc - (tau.x < c0.x ? 1 : 0) - (tau.y < c0.y ? PW : 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int li = li0 + (k >> 1) * PW + (k & 1);
+                    const f2 dc = *reinterpret_cast<const f2 *>(&s_t[buf][li]) - tau;
+                    const float wgt = tent_weight(dc.x) * tent_weight(dc.y);
+                    acc0 += *reinterpret_cast<const f4 *>(&s_g[buf][0][li]) * wgt;
+                    acc1 += *reinterpret_cast<const f4 *>(&s_g[buf][1][li]) * wgt;
+                }
+            } else {
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int li = lc + dy * PW + dx;
+                        const f2 dc = *reinterpret_cast<const f2 *>(&s_t[buf][li]) - tau;
+                        const float wgt = tent_weight(dc.x) * tent_weight(dc.y);
+                        acc0 += *reinterpret_cast<const f4 *>(&s_g[buf][0][li]) * wgt;
+                        acc1 += *reinterpret_cast<const f4 *>(&s_g[buf][1][li]) * wgt;
+                    }
+            }
+            if constexpr (ORDER == VL3D_ACT_PRE) {
+                const f4 sv0 = load_texel<F16>(plane0, tix << 4), sv1 = load_texel<F16>(plane0 + f1, tix << 4);
+                acc0 = f4{acc0.x * act_bwd<RACT>(sv0.x, act_fwd<RACT>(sv0.x)), acc0.y * act_bwd<RACT>(sv0.y, act_fwd<RACT>(sv0.y)),
+                          acc0.z * act_bwd<RACT>(sv0.z, act_fwd<RACT>(sv0.z)), acc0.w * act_bwd<AACT>(sv0.w, act_fwd<AACT>(sv0.w))};
+                acc1 = f4{acc1.x * act_bwd<RACT>(sv1.x, act_fwd<RACT>(sv1.x)), acc1.y * act_bwd<RACT>(sv1.y, act_fwd<RACT>(sv1.y)),
+                          acc1.z * act_bwd<RACT>(sv1.z, act_fwd<RACT>(sv1.z)), acc1.w * act_bwd<AACT>(sv1.w, act_fwd<AACT>(sv1.w))};
+            }
+            store_grad_texel<F16>(gplane0, tix << 4, acc0);
+            if (has1) store_grad_texel<F16>(gplane0 + frame_b, tix << 4, acc1);
+        };
+        if (row < wh && col < ww) gather(e0, col, row, win0 + toff_thread);
+        // rest of a window larger than 32 x 16: columns beyond 32 as a packed strip, rows beyond 16 one half-wave per row
+        const int nec = ww - PW;
+        if (nec > 0) {
+            const int necp = min(nec, PW);
+            const int sh = necp > 1 ? 32 - __builtin_clz((unsigned)(necp - 1)) : 0, rpg = PW >> sh, rmain = min(wh, PROWS);
+            const int c = col & ((1 << sh) - 1), r = col >> sh;          // a 32-thread row group takes rpg window rows of the strip
+            for (int wxb = PW; wxb < ww; wxb += (1 << sh))
+                for (int wy0 = row * rpg; wy0 < rmain; wy0 += PROWS * rpg) {
+                    const int wy = wy0 + r, wx = wxb + c;
+                    if (c < necp && wx < ww && wy < rmain) {
+                        const unsigned tix = win0 + (unsigned)(wy * a.Ws + wx);
+                        gather(oplane[tix], wx, wy, tix);
+                    }
+                }
+        }
+        for (int wy = row + PROWS; wy < wh; wy += PROWS)
+            for (int wx = col; wx < ww; wx += PW) {
+                const unsigned tix = win0 + (unsigned)(wy * a.Ws + wx);
+                gather(oplane[tix], wx, wy, tix);
+            }
+    }
+}
+
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
+void launch_pair(const RenderArgs &a, hipStream_t s) {
+    constexpr int IW = PW - 2, IH = PROWS - 2;
+    RenderArgs b = a;
+    b.tiles_x = (a.W + IW - 1) / IW; b.tiles_y = (a.H + IH - 1) / IH;
+    const int nwin = b.tiles_x * b.tiles_y * a.D;
+    hipLaunchKernelGGL((bwd_windows_k<COORD>), dim3((nwin + 255) / 256), dim3(256), 0, s, b, IW, IH, 1, b.tiles_x, b.tiles_y,
+                       reinterpret_cast<int *>(const_cast<float *>(a.plan)) + plan_win_off(a.D));
+    hipLaunchKernelGGL(bwd_owner_table_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, b, IW, IH, 1, b.tiles_x,
+                       const_cast<unsigned short *>(a.owner), PW);
+    hipLaunchKernelGGL((render_bwd_pair_k<COORD, BORDER, ORDER, RACT, AACT, F16>),
+                       dim3((unsigned)(b.tiles_x * b.tiles_y * ((a.T + 1) / 2))), dim3(PNT), 0, s, b);
+}
+
+// =====================================================================================================
+// Layer-space smoothness regularisers, forward (MPV.py:517-531): sum over frames, planes and neighbouring pixel pairs of
+// |L[p] - L[q]| of the warped+activated per-layer rgba L (zero where a plane does not cover the pixel) -- without ever
+// materialising the [T,h,w,K,4] layer tensor the reference builds (1.47 GB per training crop).
+// out[0] = sum |dx rgb|, out[1] = sum |dy rgb|, out[2] = sum |dx a|, out[3] = sum |dy a|   (device doubles, accumulated).
+// Workgroup = 64 x ROWS region, pairs owned by their left / upper pixel (63 x (ROWS-1) interior), one barrier per plane.
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool F16>
+__global__ __launch_bounds__(RW *ROWS) void render_reg_fwd_k(RenderArgs a) {
+    constexpr int NT = RW * ROWS;
+    __shared__ float4 s_o[2][NT];
+    __shared__ float red[4][ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
+    const int x = blockIdx.x * (RW - 1) + lane, y = blockIdx.y * (ROWS - 1) + row, t = blockIdx.z;
+    const bool inimg = (x < a.W) && (y < a.H);
+    // the last column / row of the region are halo (owned by the next tile, where they are column / row 0)
+    const bool owner = inimg && lane < RW - 1 && row < ROWS - 1;
+    const bool own_r = owner && x + 1 < a.W, own_d = owner && y + 1 < a.H;
+    const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
+    const size_t frame_b = (size_t)a.Hs * a.Ws * (F16 ? 8 : 16), plane_stride_b = (size_t)a.T * frame_b;
+    const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * frame_b;
+    float sxc = 0.f, syc = 0.f, sxa = 0.f, sya = 0.f;
+    // tile culling: the workgroup builds its own plane mask (thread d projects the region's corners onto plane d and tests the
+    // touched quads) and walks only the set bits; a skipped plane has layer value 0 everywhere in the region, i.e. adds nothing
+    __shared__ unsigned long long s_mask[2];
+    if (a.quad_keep) {
+        if (tid < 2) s_mask[tid] = 0ull;
+        __syncthreads();
+        if (tid < a.D) {
+            const int x0 = blockIdx.x * (RW - 1), x1 = min(x0 + RW - 1, a.W - 1), y0 = blockIdx.y * (ROWS - 1), y1 = min(y0 + ROWS - 1, a.H - 1);
+            const float *h = a.homos + 9 * tid;
+            float tnx = 1e30f, txx = -1e30f, tny = 1e30f, txy = -1e30f;
+            for (int c = 0; c < 4; ++c) {
+                const float cx = (float)a.col0 + a.pc + (float)((c & 1) ? x1 : x0), cy = (float)a.row0 + a.pc + (float)((c & 2) ? y1 : y0);
+                const float X = h[0] * cx + h[1] * cy + h[2], Y = h[3] * cx + h[4] * cy + h[5], Z = h[6] * cx + h[7] * cy + h[8];
+                const float ctx = texel_coord<COORD>(X / Z, (float)a.Ws / 2.0f, (float)(a.Ws - 1), a.sx, a.ox);
+                const float cty = texel_coord<COORD>(Y / Z, (float)a.Hs / 2.0f, (float)(a.Hs - 1), a.sy, a.oy);
+                tnx = fminf(tnx, ctx); txx = fmaxf(txx, ctx); tny = fminf(tny, cty); txy = fmaxf(txy, cty);
+            }
+            if (box_touches_kept_quad(a, tid, tnx, txx, tny, txy)) atomicOr(&s_mask[tid >> 6], 1ull << (tid & 63));
+        }
+        __syncthreads();
+    }
+    int nact = 0;
+    for (int d = 0; d < a.D; ++d, plane += plane_stride_b) {
+        if (a.quad_keep && !((s_mask[d >> 6] >> (d & 63)) & 1ull)) continue;      // uniform
+        f4 ol = f4{0.f, 0.f, 0.f, 0.f};
+        if (inimg) {
+            const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
+            typename TapVal<F16, ORDER>::type tv[4];
+            load_taps2<F16>(plane, tp, make_tap_step<F16>(a.Hs, a.Ws), tv);
+            ol = shade2<ORDER, RACT, AACT>(tp, tv) * tp.cov;
+        }
+        const int buf = (nact++) & 1;        // alternates over the planes actually walked (a skipped plane has no barrier)
+        s_o[buf][tid] = make_float4(ol.x, ol.y, ol.z, ol.w);
+        __syncthreads();
+        if (own_r) {
+            const float4 r = s_o[buf][tid + 1];
+            sxc += fabsf(ol.x - r.x) + fabsf(ol.y - r.y) + fabsf(ol.z - r.z);
+            sxa += fabsf(ol.w - r.w);
+        }
+        if (own_d) {
+            const float4 r = s_o[buf][tid + RW];
+            syc += fabsf(ol.x - r.x) + fabsf(ol.y - r.y) + fabsf(ol.z - r.z);
+            sya += fabsf(ol.w - r.w);
+        }
+    }
+    float v[4] = {sxc, syc, sxa, sya};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+        if (lane == 0) red[k][row] = v[k];
+    }
+    __syncthreads();
+    if (tid < 4) {
+        double sum = 0.0;
+        for (int r = 0; r < ROWS; ++r) sum += (double)red[tid][r];
+        atomicAdd(a.reg_sums + tid, sum);
+    }
+}
+
+// ---- launch templates ---------------------------------------------------------------------------------------------
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16 = false>
+void launch_tile(const RenderArgs &a, hipStream_t s) {
+    constexpr int RH = REG ? 2 : 1, IW = RW - 2 * RH, IH = ROWS - 2 * RH;
+    RenderArgs b = a;
+    b.tiles_x = (a.W + IW - 1) / IW; b.tiles_y = (a.H + IH - 1) / IH;
+    const int nwin = b.tiles_x * b.tiles_y * a.D;
+    hipLaunchKernelGGL((bwd_windows_k<COORD>), dim3((nwin + 255) / 256), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x, b.tiles_y,
+                       reinterpret_cast<int *>(const_cast<float *>(a.plan)) + plan_win_off(a.D));
+    hipLaunchKernelGGL(bwd_owner_table_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x,
+                       const_cast<unsigned short *>(a.owner));
+    if (a.quad_keep)
+        hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16, true>),
+                           dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
+    else
+        hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16>),
+                           dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
+}
+
+template <bool BWD, int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
+void launch_t(const RenderArgs &a, hipStream_t s) {
+    dim3 grid((a.W + TILE_X - 1) / TILE_X, (a.H + TILE_Y - 1) / TILE_Y, a.T), block(TILE_X * TILE_Y);
+    if constexpr (BWD) {
+        if (a.tile_rows) {
+            hipLaunchKernelGGL((bwd_plan_k<COORD>), dim3(1), dim3(64), 0, s, a, 16, const_cast<float *>(a.plan));
+            const size_t n8 = (size_t)a.D * a.T * a.Hs * a.Ws * (a.g_f16 ? 1 : 2);          // fp16 texels are 8 bytes, fp32 ones 16
+            hipLaunchKernelGGL(bwd_fill_zero_if_infeasible_k, dim3(4096), dim3(256), 0, s, reinterpret_cast<float2 *>(a.g_stack), n8, a.plan);
+            bool done = false;
+            if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID) {
+                // two frames per thread: dense stacks without layer regularisers (tile_rows 17 = "16 rows, pairs allowed"), when a
+                // 30 x 14-pixel tile's texel window fits the 32 x 16 threads of its workgroup -- judged by the sizes alone (the
+                // homographies live on the device): along one axis at least the stack is no larger than the frame (+7 %) -- full frames
+                // and row bands (dist.render_band: full width, rows = band + halo) of a stack at the frame's resolution.  Beyond that
+                // the extra gather passes of the small tiles cost more than the pairs save (1.1x: 13.3 ms tile kernel, 13.9 ms
+                // pairs): crops of a larger stack and the reference's 1.1x stacks keep the 64 x 16 tile kernel.
+                const bool fits = (int64_t)a.Hs * 100 <= (int64_t)a.H * 107 || (int64_t)a.Ws * 100 <= (int64_t)a.W * 107;
+                if (a.tile_rows == 17 && a.T >= 2 && !a.g_reg && !a.g_asum && !a.quad_keep && fits) {
+                    launch_pair<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
+                    done = true;
+                }
+            }
+            if (!done) {
+                if (a.g_reg || a.g_asum) {     // layer regularisers and / or sparsity sums: the REG instantiation (128-VGPR budget)
+                    RenderArgs ar = a;
+                    if (!ar.g_reg) ar.g_reg = a.plan + 4;      // zeros written by bwd_plan_k
+                    launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, F16>(ar, s);
+                } else {
+                    launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, false, F16>(a, s);
+                }
+            }
+        }
+        hipLaunchKernelGGL((render_bwd_k<COORD, BORDER, ORDER, RACT, AACT, F16>), grid, block, 0, s, a);
+    } else {
+        if (a.reg_fwd) {
+            dim3 rgrid((a.W + RW - 2) / (RW - 1), (a.H + 14) / 15, a.T);
+            hipLaunchKernelGGL((render_reg_fwd_k<COORD, BORDER, ORDER, RACT, AACT, 16, F16>), rgrid, dim3(RW * 16), 0, s, a);
+            return;
+        }
+        // frame pairs (shipped activations, dense stacks, T >= 2); forward variant 6 (desc->variant bits 8..11) keeps the one-frame
+        // kernel (A/B, bitwise tests).  The workgroup-shape variants of round 1 (64x4, 64x16, no XCD remap) measured within the
+        // noise of the default and are no longer built.
+        if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID) {
+            if (a.T >= 2 && a.fwd_variant != 6 && !(a.quad_keep && a.cull_masks)) return launch_fwd2x<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
+        }
+        launch_fwd2<COORD, BORDER, ORDER, RACT, AACT, 8, true, F16>(a, s);
+    }
+}
+
+// fp16 plane stacks (cfg5) are instantiated for the shipped (sigmoid, sigmoid) activations only
+template <bool BWD, int COORD, int BORDER, int ORDER, int RACT, int AACT>
+void launch(const RenderArgs &a, hipStream_t s) {
+    if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID) {
+        if (a.g_f16) return launch_t<BWD, COORD, BORDER, ORDER, RACT, AACT, true>(a, s);
+    }
+    launch_t<BWD, COORD, BORDER, ORDER, RACT, AACT, false>(a, s);
+}
+
+}  // namespace

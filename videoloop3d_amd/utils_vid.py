@@ -93,8 +93,10 @@ def _as_video(v, name):
     return v
 
 
-def find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha):
-    """Per-location temporal NN search on videos x,y [1,3,T,h,w] (already trimmed).  Returns int32 [h_o,w_o,n1]."""
+def find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha, y_is_constant=False):
+    """Per-location temporal NN search on videos x,y [1,3,T,h,w] (already trimmed).  Returns int32 [h_o,w_o,n1].
+    y_is_constant: the caller vouches that y's bytes have not changed since the previous call with the same y tensor, so its
+    pixel-major copy inside the scratch may be reused (see _patchnn_scratch)."""
     L.check_cuda(x, y)
     xv, yv = _as_video(x.detach(), "x"), _as_video(y.detach(), "y")
     if xv.shape[2:] != yv.shape[2:]:
@@ -106,7 +108,7 @@ def find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha):
     nn = torch.empty((h_o, w_o, n1), dtype=torch.int32, device=xv.device)
     with torch.cuda.device(xv.device):
         nscratch = int(L.lib().vl3d_patchnn_scratch_bytes(desc))
-        scratch, y_cached = _patchnn_scratch(nscratch, yv, desc, xv.device)
+        scratch, y_cached = _patchnn_scratch(nscratch, yv, desc, xv.device, y_is_constant)
         if y_cached:
             desc.variant |= 0x100          # the y half of the scratch still holds this very y in pixel-major form
         L.check(L.lib().vl3d_patchnn(desc, L.ptr(xv), L.ptr(yv), L.ptr(nn), L.ptr(scratch), L.stream_ptr(xv.device)),
@@ -115,29 +117,39 @@ def find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha):
     return nn, desc, xv, yv
 
 
-# One-entry cache of the NN kernel's scratch: y (the captured video) is the same tensor in every iteration of a loop over one
-# crop, so its pixel-major copy inside the scratch is reused while y's storage, version counter, view geometry and the loss
-# configuration are unchanged.  The cache holds a strong reference to that storage, so its address cannot be recycled for
-# other data while the entry is alive (one video's worth of memory stays pinned until the next different y arrives).
-# x (the render) changes every iteration and is always re-copied.
+# One-entry cache of the NN kernel's scratch buffer.  The buffer itself is always reused when its size fits (no allocation per
+# iteration); the pixel-major copy of y inside it is reused ONLY when the caller opts in with `y_is_constant=True` (the loss
+# classes forward that keyword): then y's storage, version counter, view geometry, the loss configuration and the stream that
+# built the copy are the key.  Without the opt-in y is re-copied on every call -- a version counter cannot see writes that
+# bypass it (`y.data.copy_()`, a HIP kernel or a dataloader refilling a pinned buffer), and in the reference's training loop
+# every iteration brings another crop anyway (train_3dvid.py:214-244).  The cache holds a strong reference to the keyed
+# storage, so its address cannot be recycled for other data while the entry is alive.  x (the render) is always re-copied.
 _SCRATCH_CACHE = {"key": None, "buf": None, "storage": None}
 
 
-def _patchnn_scratch(nbytes, yv, desc, device):
+def _patchnn_scratch(nbytes, yv, desc, device, y_is_constant=False):
     if nbytes <= 0:
         return None, False
+    stream = torch.cuda.current_stream(device).cuda_stream
+    buf = _SCRATCH_CACHE["buf"]
+    fits = buf is not None and buf.device == torch.device(device) and buf.numel() * 4 >= nbytes and _SCRATCH_CACHE.get("stream") == stream
+    if not y_is_constant:
+        if not fits:
+            buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _SCRATCH_CACHE.update(key=None, buf=buf, storage=None, stream=stream)
+        return buf, False
     st = yv.untyped_storage()
-    key = (st.data_ptr(), yv._version, yv.storage_offset(), tuple(yv.shape), tuple(yv.stride()), str(device), nbytes,
+    key = (st.data_ptr(), yv._version, yv.storage_offset(), tuple(yv.shape), tuple(yv.stride()), str(device), nbytes, stream,
            desc.Tx, desc.ps, desc.pt, desc.stride, desc.stridet, desc.variant & 0xff)
-    if _SCRATCH_CACHE["key"] == key:
-        return _SCRATCH_CACHE["buf"], True
+    if fits and _SCRATCH_CACHE["key"] == key:
+        return buf, True
     buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
-    _SCRATCH_CACHE.update(key=key, buf=buf, storage=st)
+    _SCRATCH_CACHE.update(key=key, buf=buf, storage=st, stream=stream)
     return buf, False
 
 
-def _nn_and_fold(x, y, patch_size, patcht_size, stride, stridet, alpha, normalize):
-    nn, desc, xv, yv = find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha)
+def _nn_and_fold(x, y, patch_size, patcht_size, stride, stridet, alpha, normalize, y_is_constant=False):
+    nn, desc, xv, yv = find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha, y_is_constant)
     s = torch.empty((1, 3, desc.Tx, desc.H, desc.W), dtype=torch.float32, device=xv.device)
     w = torch.empty((1, 1, desc.Tx, desc.H, desc.W), dtype=torch.float32, device=xv.device)
     with torch.cuda.device(xv.device):
@@ -146,12 +158,38 @@ def _nn_and_fold(x, y, patch_size, patcht_size, stride, stridet, alpha, normaliz
     return s, w, nn
 
 
+def _floored(size, patch, step):
+    """extent covered by the floored patch grid UnfoldNd / FoldNd use (utils_vid.py:60-69, 218-227): no warning, no trimming of
+    the outputs -- the direct path keeps x's full shape and leaves the uncovered voxels empty."""
+    return (size - patch) // step * step + patch if size >= patch else size
+
+
+def _nn_and_fold_any_size(x, y, patch_size, patcht_size, stride, stridet, alpha, normalize, y_is_constant=False):
+    """_nn_and_fold for x of ANY size, as the reference's direct path handles it: UnfoldNd floors the patch grid and FoldNd writes
+    into the full x.shape, so voxels beyond the last whole patch receive no vote -- sum 0 and weight 1e-10 (after the clamp,
+    utils_vid.py:228), i.e. y2x = 0 there.  The kernels run on the covered extent; the rest is filled here."""
+    t, h, w = x.shape[-3:]
+    tf, hf, wf = _floored(t, patcht_size, stridet), _floored(h, patch_size, stride), _floored(w, patch_size, stride)
+    if (tf, hf, wf) == (t, h, w):
+        return _nn_and_fold(x, y, patch_size, patcht_size, stride, stridet, alpha, normalize, y_is_constant)
+    if y.shape[-2:] != x.shape[-2:]:
+        raise RuntimeError("x and y must have identical spatial size (patch grids must coincide)")
+    sc, wc, nn = _nn_and_fold(x[..., :tf, :hf, :wf], y[..., :hf, :wf], patch_size, patcht_size, stride, stridet, alpha, normalize,
+                              y_is_constant)
+    s = x.new_zeros((1, 3, t, h, w), dtype=torch.float32)
+    wgt = x.new_full((1, 1, t, h, w), 1e-10, dtype=torch.float32)
+    s[..., :tf, :hf, :wf] = sc
+    wgt[..., :tf, :hf, :wf] = wc
+    return s, wgt, nn
+
+
 def FindNNpatchAndMerge(x, y, patch_size=7, patcht_size=7, stride=1, stridet=1, alpha=1e10, dist_fn='mse', **kwargs):
-    """utils_vid.py:206-229 -> (y2x_sum [1,3,T,h,w], weight [1,1,T,h,w] clamped at 1e-10)."""
+    """utils_vid.py:206-229 -> (y2x_sum [1,3,T,h,w], weight [1,1,T,h,w] clamped at 1e-10); x of any size (floored patch grid)."""
     if dist_fn != 'mse':
         raise RuntimeError("dist_fn other than 'mse' is not settable in the reference (config_parser.py:90-93)")
     alpha = None if alpha > 100 else alpha
-    s, w, _ = _nn_and_fold(x, y, patch_size, patcht_size, stride, stridet, alpha, normalize=False)
+    s, w, _ = _nn_and_fold_any_size(x, y, patch_size, patcht_size, stride, stridet, alpha, normalize=False,
+                                    y_is_constant=bool(kwargs.get("y_is_constant", False)))
     return s, w
 
 
@@ -191,8 +229,8 @@ class _FoldRobustMean(torch.autograd.Function):
     (loss, y2x, weight); gradient flows to x only, through the loss."""
 
     @staticmethod
-    def forward(ctx, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling):
-        nn, desc, xv, yv = find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha)
+    def forward(ctx, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant=False):
+        nn, desc, xv, yv = find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha, y_is_constant)
         dev = xv.device
         y2x = torch.empty((1, 3, desc.Tx, desc.H, desc.W), dtype=torch.float32, device=dev)
         w = torch.empty((1, 1, desc.Tx, desc.H, desc.W), dtype=torch.float32, device=dev)
@@ -210,7 +248,7 @@ class _FoldRobustMean(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gy2x, _gw):
         (gx,) = ctx.saved_tensors
-        return (gx * g.to(torch.float32)).reshape(ctx.x_shape), None, None, None, None, None, None, None, None
+        return (gx * g.to(torch.float32)).reshape(ctx.x_shape), None, None, None, None, None, None, None, None, None
 
 
 def fit_patch(size, name, patch, step):
@@ -222,23 +260,33 @@ def fit_patch(size, name, patch, step):
     return trimmed
 
 
-def _gpnn_loss(holder, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling):
+def _gpnn_loss(holder, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant=False):
     """NN search + vote-fold + robust mean, fused (one pass over the video for fold, loss and gradient); falls back to the
-    separate kernels when a fold tile does not fit LDS.  Caches y2x / weight on `holder` like the reference (utils_vid.py:345-346)."""
+    separate kernels when a fold tile does not fit LDS, or when x does not fit the patch grid (direct path only: the LowMem class
+    trims first).  Caches y2x / weight on `holder` like the reference (utils_vid.py:345-346)."""
+    t, h, w = x.shape[-3:]
+    fits_grid = (_floored(t, patcht_size, stridet), _floored(h, patch_size, stride), _floored(w, patch_size, stride)) == (t, h, w)
     try:
-        loss, y2x, weight = _FoldRobustMean.apply(x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling)
+        if not fits_grid:
+            raise RuntimeError("x does not fit the patch grid: unfused path")
+        loss, y2x, weight = _FoldRobustMean.apply(x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant)
     except RuntimeError as e:
-        if "does not fit LDS" not in str(e):
+        if "does not fit LDS" not in str(e) and "does not fit the patch grid" not in str(e):
             raise
         with torch.no_grad():
-            y2x, weight, _ = _nn_and_fold(x, y, patch_size, patcht_size, stride, stridet, alpha, normalize=True)
+            y2x, weight, _ = _nn_and_fold_any_size(x, y, patch_size, patcht_size, stride, stridet, alpha, normalize=True,
+                                                   y_is_constant=y_is_constant)
         loss = _RobustMean.apply(x, y2x, rou, scaling)
     holder.last_weight, holder.last_y2x = weight, y2x
     return loss
 
 
 class Patch3DGPNNDirectLoss:
-    """utils_vid.py:265-286."""
+    """utils_vid.py:265-286.  Like the reference's, this path takes x of ANY size: UnfoldNd floors the patch grid and FoldNd
+    leaves the voxels beyond the last whole patch without a vote (y2x = 0, weight 1e-10), and the loss mean runs over all of x
+    -- `loss_name='gpnn'` is the parser default and an even crop size with the default stride 2 is legal there.
+    Extra keyword (ignored by the reference through **kwargs): y_is_constant=True lets the NN kernel reuse its pixel-major copy
+    of y from the previous call with the same tensor."""
 
     def __init__(self):
         self.last_y2x = None
@@ -250,7 +298,10 @@ class Patch3DGPNNDirectLoss:
         cfg = dict(patch_size=7, patcht_size=7, stride=1, stridet=1, alpha=1e10)
         cfg.update({k: v for k, v in kwargs.items() if k in cfg})
         alpha = None if cfg["alpha"] > 100 else cfg["alpha"]
-        return _gpnn_loss(self, x, y, cfg["patch_size"], cfg["patcht_size"], cfg["stride"], cfg["stridet"], alpha, rou, scaling)
+        if kwargs.get("dist_fn", "mse") != "mse":
+            raise RuntimeError("dist_fn other than 'mse' is not settable in the reference")
+        return _gpnn_loss(self, x, y, cfg["patch_size"], cfg["patcht_size"], cfg["stride"], cfg["stridet"], alpha, rou, scaling,
+                          bool(kwargs.get("y_is_constant", False)))
 
 
 class Patch3DGPNNLowMemLoss:
@@ -278,7 +329,8 @@ class Patch3DGPNNLowMemLoss:
             alpha = None if alpha > 100 else alpha
             if kwargs.get("dist_fn", "mse") != "mse":
                 raise RuntimeError("dist_fn other than 'mse' is not settable in the reference")
-            return _gpnn_loss(self, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling)
+            return _gpnn_loss(self, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling,
+                              bool(kwargs.get("y_is_constant", False)))
         return _RobustMean.apply(x, y2x, rou, scaling)
 
 
