@@ -55,6 +55,86 @@ __global__ __launch_bounds__(512) void render_like_k(const f4 *__restrict__ src,
     }
 }
 
+// the backward's memory pattern without its arithmetic: a workgroup owns an (RX-2) x (RY-2) pixel tile of FR frames, its RX x RY
+// threads each read TAPS taps per plane and frame (offsets 0, +1 texel, +1 row, +1 row +1 texel: the L1 absorbs the overlap),
+// the interior threads write one gradient texel per plane and frame (non-temporal), plus a 2-byte owner-table entry per plane.
+// STORE: 0 non-temporal stores of the interior (ragged row segments, as the owner-computes backward writes them), 1 the same with
+// plain write-back stores (the L2 may merge the partial lines of horizontally adjacent tiles), 2 non-temporal stores of row segments
+// ALIGNED to SNAP texels (ownership snapped to SNAP-texel columns: what aligned ownership would give), 3 = 2 with plain stores
+template <int RX, int RY, int FR, int TAPS, bool OWNER, int STORE = 0, int SNAP = 8>
+__global__ __launch_bounds__(RX *RY) void bwd_like_k(const f4 *__restrict__ src, f4 *__restrict__ dst, const unsigned short *__restrict__ owner, int D,
+                                                     int T, int Hs, int Ws, int tiles_x, int tiles_y) {
+    const int b = blockIdx.x;
+    const int q = gridDim.x >> 3, r = gridDim.x & 7, xcd = b & 7, k = b >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    const int tile_x = bid % tiles_x, rest = bid / tiles_x, tile_y = rest % tiles_y, t0 = (rest / tiles_y) * FR;
+    const int lx = threadIdx.x % RX, ly = threadIdx.x / RX;
+    const int x = min(max(tile_x * (RX - 2) - 1 + lx, 0), Ws - 2), y = min(max(tile_y * (RY - 2) - 1 + ly, 0), Hs - 2);
+    bool interior = lx >= 1 && lx < RX - 1 && ly >= 1 && ly < RY - 1 && tile_x * (RX - 2) - 1 + lx < Ws && tile_y * (RY - 2) - 1 + ly < Hs;
+    if constexpr (STORE >= 2) {      // owned columns [snap(tile_x * IW), snap((tile_x + 1) * IW)): every column owned exactly once, SNAP-aligned ends
+        const int gx = tile_x * (RX - 2) - 1 + lx;
+        const int l = (tile_x * (RX - 2) + SNAP / 2) / SNAP * SNAP, rr = ((tile_x + 1) * (RX - 2) + SNAP / 2) / SNAP * SNAP;
+        interior = gx >= l && gx < rr && gx < Ws && ly >= 1 && ly < RY - 1 && tile_y * (RY - 2) - 1 + ly < Hs && gx >= 0;
+    }
+    const size_t frame = (size_t)Hs * Ws, plane = (size_t)T * frame;
+    size_t o = (size_t)t0 * frame + (size_t)y * Ws + x;
+    size_t oo = (size_t)y * Ws + x;
+    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < D; ++d, o += plane, oo += frame) {
+        f4 v[FR];
+        unsigned e = 0;
+        if constexpr (OWNER) e = owner[oo];
+#pragma unroll
+        for (int f = 0; f < FR; ++f) {
+            v[f] = src[o + f * frame];
+            if constexpr (TAPS == 4) v[f] += src[o + f * frame + 1] + src[o + f * frame + Ws] + src[o + f * frame + Ws + 1];
+        }
+        if (interior) {
+#pragma unroll
+            for (int f = 0; f < FR; ++f) {
+                if constexpr (STORE == 0 || STORE == 2) __builtin_nontemporal_store(v[f] + acc, &dst[o + f * frame]);
+                else dst[o + f * frame] = v[f] + acc;
+            }
+        }
+        acc.x += (float)e;
+    }
+}
+
+// the same pattern on a FRAME-PAIR INTERLEAVED layout (D, T/2, Hs, Ws, 2 frames, 4): a thread's two frames are 32 contiguous bytes,
+// a wave's row segment is 2 KiB (region 64 wide) or 1 KiB (32 wide) -- what a pair kernel would stream if the stack were stored so.
+template <int RX, int RY, bool OWNER, int STORE, int SNAP>
+__global__ __launch_bounds__(RX *RY) void bwd_like_il_k(const f4 *__restrict__ src, f4 *__restrict__ dst, const unsigned short *__restrict__ owner, int D,
+                                                        int T, int Hs, int Ws, int tiles_x, int tiles_y) {
+    const int b = blockIdx.x;
+    const int q = gridDim.x >> 3, r = gridDim.x & 7, xcd = b & 7, k = b >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    const int tile_x = bid % tiles_x, rest = bid / tiles_x, tile_y = rest % tiles_y, tp = rest / tiles_y;
+    const int lx = threadIdx.x % RX, ly = threadIdx.x / RX;
+    const int x = min(max(tile_x * (RX - 2) - 1 + lx, 0), Ws - 2), y = min(max(tile_y * (RY - 2) - 1 + ly, 0), Hs - 2);
+    bool interior = lx >= 1 && lx < RX - 1 && ly >= 1 && ly < RY - 1 && tile_x * (RX - 2) - 1 + lx < Ws && tile_y * (RY - 2) - 1 + ly < Hs;
+    if constexpr (STORE >= 2) {
+        const int gx = tile_x * (RX - 2) - 1 + lx;
+        const int l = (tile_x * (RX - 2) + SNAP / 2) / SNAP * SNAP, rr = ((tile_x + 1) * (RX - 2) + SNAP / 2) / SNAP * SNAP;
+        interior = gx >= l && gx < rr && gx < Ws && ly >= 1 && ly < RY - 1 && tile_y * (RY - 2) - 1 + ly < Hs && gx >= 0;
+    }
+    const size_t frame2 = (size_t)Hs * Ws * 2, plane = (size_t)(T / 2) * frame2;      // in f4 units
+    size_t o = (size_t)tp * frame2 + ((size_t)y * Ws + x) * 2;
+    size_t oo = (size_t)y * Ws + x;
+    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < D; ++d, o += plane, oo += (size_t)Hs * Ws) {
+        unsigned e = 0;
+        if constexpr (OWNER) e = owner[oo];
+        f4 v0 = src[o], v1 = src[o + 1];
+        v0 += src[o + 2] + src[o + 2 * Ws] + src[o + 2 * Ws + 2];
+        v1 += src[o + 3] + src[o + 2 * Ws + 1] + src[o + 2 * Ws + 3];
+        if (interior) {
+            __builtin_nontemporal_store(v0 + acc, &dst[o]);
+            __builtin_nontemporal_store(v1 + acc, &dst[o + 1]);
+        }
+        acc.x += (float)e;
+    }
+}
+
 template <typename F>
 static void run(const char *name, F launch, double bytes) {
     hipEvent_t e0, e1;
@@ -98,6 +178,44 @@ int main() {
         run("render_like  nt-store  2 planes in flight", [&] { hipLaunchKernelGGL((render_like_k<true, 2>), dim3(grid), dim3(512), 0, 0, src, dst, D, T, Hs, Ws, tx, ty); }, bytes);
         run("render_like  nt-store  4 planes in flight", [&] { hipLaunchKernelGGL((render_like_k<true, 4>), dim3(grid), dim3(512), 0, 0, src, dst, D, T, Hs, Ws, tx, ty); }, bytes);
         run("render_like  store     2 planes in flight", [&] { hipLaunchKernelGGL((render_like_k<false, 2>), dim3(grid), dim3(512), 0, 0, src, dst, D, T, Hs, Ws, tx, ty); }, bytes);
+    }
+    // the backward's pattern: region shape x frames per workgroup x taps, cfg3 geometry with T = 12 frames
+    {
+        const int D = 32, T = 12, Hs = 720, Ws = 1280;
+        const double bytes = 2.0 * D * T * Hs * Ws * 16;      // algorithmic: every texel read once, every gradient texel written once
+        unsigned short *owner;
+        hipMalloc(&owner, (size_t)D * Hs * Ws * 2 + 4096);
+        hipMemset(owner, 0, (size_t)D * Hs * Ws * 2 + 4096);
+#define BL(RX, RY, FR, TAPS, OWN)                                                                                              \
+        {                                                                                                                      \
+            const int tx = (Ws + RX - 3) / (RX - 2), ty = (Hs + RY - 3) / (RY - 2);                                            \
+            snprintf(name, sizeof name, "bwd_like  region %3d x %2d  frames %d  taps %d  owner %d  (halo x%.2f)", RX, RY, FR, TAPS, OWN,         \
+                     (double)RX * RY / ((RX - 2) * (RY - 2)));                                                                 \
+            run(name, [&] { hipLaunchKernelGGL((bwd_like_k<RX, RY, FR, TAPS, OWN>), dim3((unsigned)(tx * ty * (T / FR))), dim3(RX * RY), 0, 0, src, dst, \
+                                               owner, D, T, Hs, Ws, tx, ty); }, bytes);                                        \
+        }
+        BL(32, 16, 2, 1, false) BL(32, 16, 2, 4, false) BL(32, 16, 2, 4, true)
+        BL(64, 8, 2, 4, true) BL(64, 16, 1, 4, true) BL(64, 16, 2, 4, true) BL(32, 32, 1, 4, true) BL(32, 32, 2, 4, true)
+        BL(128, 4, 2, 4, true) BL(16, 32, 2, 4, true) BL(64, 8, 1, 4, true) BL(32, 16, 1, 4, true) BL(32, 8, 2, 4, true) BL(32, 16, 4, 4, true)
+#define BLS(RX, RY, FR, ST, SNAP)                                                                                              \
+        {                                                                                                                      \
+            const int tx = (Ws + RX - 3) / (RX - 2), ty = (Hs + RY - 3) / (RY - 2);                                            \
+            snprintf(name, sizeof name, "bwd_like  region %3d x %2d  frames %d  store mode %d  snap %d", RX, RY, FR, ST, SNAP);                 \
+            run(name, [&] { hipLaunchKernelGGL((bwd_like_k<RX, RY, FR, 4, true, ST, SNAP>), dim3((unsigned)(tx * ty * (T / FR))), dim3(RX * RY), 0, 0, src, dst, \
+                                               owner, D, T, Hs, Ws, tx, ty); }, bytes);                                        \
+        }
+#define BLI(RX, RY, ST, SNAP)                                                                                                  \
+        {                                                                                                                      \
+            const int tx = (Ws + RX - 3) / (RX - 2), ty = (Hs + RY - 3) / (RY - 2);                                            \
+            snprintf(name, sizeof name, "bwd_like INTERLEAVED pairs  region %3d x %2d  store mode %d  snap %d", RX, RY, ST, SNAP);               \
+            run(name, [&] { hipLaunchKernelGGL((bwd_like_il_k<RX, RY, true, ST, SNAP>), dim3((unsigned)(tx * ty * (T / 2))), dim3(RX * RY), 0, 0, src, dst, \
+                                               owner, D, T, Hs, Ws, tx, ty); }, bytes);                                        \
+        }
+        BLI(32, 16, 0, 8) BLI(32, 16, 2, 4) BLI(64, 8, 0, 8) BLI(64, 8, 2, 4) BLI(64, 16, 0, 8) BLI(32, 8, 0, 8) BLI(32, 8, 2, 4) BLI(128, 4, 0, 8)
+        BLS(32, 16, 2, 0, 8) BLS(32, 16, 2, 1, 8) BLS(32, 16, 2, 2, 4) BLS(32, 16, 2, 2, 8) BLS(32, 16, 2, 3, 8) BLS(32, 16, 2, 2, 16)
+        BLS(64, 8, 2, 0, 8) BLS(64, 8, 2, 1, 8) BLS(64, 8, 2, 2, 4) BLS(64, 8, 2, 2, 8) BLS(64, 8, 2, 3, 8) BLS(64, 8, 2, 2, 16)
+        BLS(64, 16, 1, 0, 8) BLS(64, 16, 1, 1, 8) BLS(64, 16, 1, 2, 8) BLS(64, 16, 1, 3, 8)
+        BLS(64, 8, 1, 0, 8) BLS(64, 8, 1, 1, 8) BLS(64, 8, 1, 2, 8) BLS(128, 8, 1, 0, 8) BLS(128, 8, 1, 2, 8) BLS(128, 4, 1, 0, 8) BLS(128, 4, 1, 2, 8)
     }
     return 0;
 }

@@ -102,6 +102,7 @@ def test_g4_cfg1_fused_vs_reference_golden(dev, golden):
     assert abs(float(gs.double().abs().sum()) - s[1]) <= 1e-4 * s[1]
 
 
+MPV_KW = dict(pixel_center=0.5, coord_mode="affine", border="hardcut", act_order="post")
 SPECS = {
     "utils_mpi": (dict(), dict()),
     "mpv": (dict(pixel_center=0.5, coord_mode="affine", border="hardcut", act_order="post"),) * 2,
@@ -699,12 +700,12 @@ def test_bwd_frame_pair_kernel_equals_tile_kernel_bitwise(dev, spec_name, stack_
     g_rgb = synth.hash_uniform((T, H, W, 3), seed=5, device=dev) - 0.5
     g_a = synth.hash_uniform((T, H, W), seed=6, device=dev) - 0.5
     out = {}
-    for variant in (0, 3):
+    for variant in (0, 3, 5, 6, 7):    # 0: pairs on 64 x 8 regions, 5: pairs on 32 x 16 regions, 6 / 7: the same with the L2 prefetch, 3: one frame per thread
         rgb, alpha = render_planes(stack, homos, H, W, RenderSpec(variant=variant, **kw_p))
         (gs,) = torch.autograd.grad([rgb, alpha], stack, [g_rgb, g_a])
         assert _tile_ran() == 1
         out[variant] = gs
-    assert torch.equal(out[0], out[3])
+    assert all(torch.equal(out[v], out[3]) for v in (0, 5, 6, 7))
     assert float(out[0].float().abs().max()) > 1e-3
 
 
@@ -764,3 +765,43 @@ def test_abi_is_reentrant_across_host_threads_and_streams(dev):
                     assert maxabs(gs_s, gs_c) <= 2e-6 * max(1.0, float(gs_s.abs().max()))
                 else:
                     assert torch.equal(gs_s, gs_c), (idx, rep)
+
+
+@pytest.mark.parametrize("T", [2, 3])
+@pytest.mark.parametrize("stack_scale", [1.0, 1.1])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_bwd_pair_reg_kernel_vs_oracle_and_tile_kernel(dev, T, stack_scale, dtype):
+    """render_bwd_pair_reg_k (frame pairs WITH the layer regularisers: sampling software-pipelined one plane ahead, one barrier per
+    plane) -- what a shipped stage-2 iteration runs (rgb_smooth / a_smooth 0.2 on a 1.1x stack, configs/mpv_base.txt:10-11,33-34):
+    gradient vs the oracle's materialised layers (smoothness sums + sparsity sums + composite), and per frame the same bits as the
+    one-frame REG tile kernel (variant 3), even and odd T, multi-tile frames with ragged borders."""
+    from videoloop3d_amd.render import RenderSpec, render_planes_with_regularisers
+    D, H, W = 5, 150, 260
+    Hs, Ws = int(H * stack_scale) - 3, int(W * stack_scale) - 5
+    kw = dict(MPV_KW, scale=(stack_scale, stack_scale), offset=(-1.0, -2.0))
+    stack = (synth.make_plane_stack(D, T, Hs, Ws, seed=43) * 0.6).to(dtype)
+    homos = bench_homos(D, H, W, scale=1.3)
+    g_rgb = synth.hash_uniform((T, H, W, 3), seed=5) - 0.5
+    wts = torch.tensor([1e-3, 2e-3, 3e-3, 1.5e-3])
+    g_as = (synth.hash_uniform((T, H, W, 2), seed=8) - 0.5) * 1e-2
+    s_cpu = stack.float().requires_grad_(True)
+    rgb_o, alpha_o, bw_o, layers = MO.render_planes(s_cpu, homos, H, W, MO.RenderSpec(**kw), return_layers=True)
+    sums_o = torch.stack([(layers[:, :, 1:, :, :3] - layers[:, :, :-1, :, :3]).abs().sum(), (layers[:, 1:, :, :, :3] - layers[:, :-1, :, :, :3]).abs().sum(),
+                          (layers[:, :, 1:, :, 3] - layers[:, :, :-1, :, 3]).abs().sum(), (layers[:, 1:, :, :, 3] - layers[:, :-1, :, :, 3]).abs().sum()])
+    asum_o = torch.stack([layers[..., 3].sum(-1), (layers[..., 3] ** 2).sum(-1)], -1)
+    (gs_o,) = torch.autograd.grad((rgb_o * g_rgb).sum() + (sums_o * wts).sum() + (asum_o * g_as).sum(), s_cpu)
+    out = {}
+    for variant in (0, 3):
+        s_gpu = stack.to(dev).requires_grad_(True)
+        rgb, alpha, sums, asum = render_planes_with_regularisers(s_gpu, homos.to(dev), H, W, RenderSpec(variant=variant, **kw))
+        (gs,) = torch.autograd.grad((rgb * g_rgb.to(dev)).sum() + (sums * wts.to(dev)).sum() + (asum * g_as.to(dev)).sum(), s_gpu)
+        assert _tile_ran() == 1
+        out[variant] = gs
+    tol = TOL * max(1.0, float(gs_o.abs().max())) if dtype == torch.float32 else 1e-3 * max(1e-3, float(gs_o.abs().max())) + 1e-6
+    # |o - o_neighbour| has a kink: where two neighbouring layer values agree to rounding the sign of their difference is decided by
+    # the last bit, and a flipped sign moves a texel's gradient by up to 2 * weight * tap weight.  Those few texels aside (the
+    # weights here are 10x the other tests' so that a wrong smoothness term could not hide under the tolerance), everything agrees.
+    err = (out[0].float().cpu() - gs_o).abs()
+    assert float((err > tol).float().mean()) <= 2e-4
+    assert float(err.max()) <= 8 * float(wts.max()) + tol
+    assert torch.equal(out[0], out[3])

@@ -784,7 +784,8 @@ __device__ __forceinline__ void owner_pixel(const float *__restrict__ hi, float 
 // round(H_d^-1 tau))) and p0's index in that tile's pixel region, packed as tile << 10 | index.  Frame independent, so it
 // is built once per call (D*Hs*Ws entries) and read once per frame by the gather, which then needs no inverse homography,
 // reciprocal, rounding or range tests per texel (~200 of its ~400 VALU issue cycles, profiles/microbench/isa_cost.py).
-__global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, int ih, int rh, int tiles_x, unsigned short *owner, int rw = 64) {
+__global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, int ih, int rh, int tiles_x, unsigned short *owner, int rw = 64,
+                                                         int slot_bits = 10) {
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -799,9 +800,11 @@ __global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, i
     const int tx = (int)((rxf + 0.5f) * (1.0f / (float)iw)), ty = (int)((ryf + 0.5f) * (1.0f / (float)ih));
     const unsigned lc = (unsigned)((ry - ty * ih + rh) * rw + (rx - tx * iw + rh));     // rw: the tile kernel's region width
     // a tile's window only holds texels owned by itself or tiles a few steps away (the window is the bounding box of the tile's
-    // image; under the plan's rotation / magnification limits its corners reach < 4 tiles), which the three low bits of each
-    // tile coordinate tell apart: 16 bits per texel
-    owner[((size_t)d * a.Hs + y) * a.Ws + x] = (unsigned short)((((unsigned)(ty & 7) << 3 | (unsigned)(tx & 7)) << 10) | lc);
+    // image; under the plan's rotation / magnification limits its corners reach < 4 tiles of the 16-row regions, < 8 of the flat
+    // 64 x 8 ones along y), which the low bits of each tile coordinate tell apart: 16 bits per texel = slot_bits for the slot
+    // (10 for the 1024-thread tile kernel, 9 for the 512-thread pair kernels), the rest for (tile_y & 7 | 15, tile_x & 7)
+    const unsigned ymask = slot_bits == 9 ? 15u : 7u;
+    owner[((size_t)d * a.Hs + y) * a.Ws + x] = (unsigned short)(((((unsigned)ty & ymask) << 3 | (unsigned)(tx & 7)) << slot_bits) | lc);
     // same pass (it already has the texel's owner pixel): texels no tile is certain to own -- owner pixel on or outside the frame's
     // border ring -- are zero-filled for all T frames here, so nothing memsets the gradient; the tile kernel runs after this
     // kernel and overwrites the border ring's texels it does own
@@ -945,7 +948,9 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
             P = fmaf(w, q, P);
             const float om = 1.0f - o.w;
             const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;
-            gval = make_float4(w * Gr + sg.x, w * Gg + sg.y, w * Gb + sg.z, fmaf(Tr, q, -behind) + sg.w + (REG ? fmaf(gN2, o.w, gN1) : 0.0f));   // grad wrt activated (c, a)
+            // grad wrt activated (c, a); spelt exactly like VL3D_PAIR_GRAD of the frame-pair kernels (compared bit for bit)
+            if constexpr (REG) sg.w += fmaf(gN2, o.w, gN1);
+            gval = make_float4(fmaf(w, Gr, sg.x), fmaf(w, Gg, sg.y), fmaf(w, Gb, sg.z), fmaf(Tr, q, -behind) + sg.w);
             Tr *= om;
             if constexpr (ORDER == VL3D_ACT_POST)
                 gval = make_float4(gval.x * act_bwd<RACT>(pre.x, o.x), gval.y * act_bwd<RACT>(pre.y, o.y),
@@ -1035,7 +1040,98 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
 // two composite states, two staged gradients, two accumulators, two stores.  Per frame the arithmetic is that of
 // render_bwd_tile_k in the same order (same bits).  Pre-pass kernels, owner table and window records are shared (region
 // width 32 in the owner table's slots).
-constexpr int PW = 32, PROWS = 16, PNT = PW * PROWS;
+//
+// Region shape: 32 x 16 pixels (30 x 14 owned).  Round 2 measured the flat 64 x 8 alternative in process on one resident stack
+// (profiles/ab_inproc.py): the memory pattern alone prefers 1-KiB row segments (profiles/microbench/rw_bw.hip `bwd_like`: 4.51 vs
+// 4.18 TB/s of algorithmic bytes), but its halo (x1.38 instead of x1.22 pixels swept per pixel owned) costs more than that:
+// 12.58 vs 11.96 ms.  An L2 prefetch of the next plane's tap rows in front of the barrier (4-byte LDS-DMA loads): +0.5 ms.
+constexpr int PNT = 512, PW = 32, PROWS = 16;
+
+// gather of one plane for a frame pair: every texel of the tile's window that the owner table assigns to this tile sums its taps
+// from the 3 x 3 (or, where pixels are >= 1 texel apart, 2 x 2) staged pixels around its owner pixel -- one set of weights, two
+// accumulators, two stores.  sg0 / sg1: staged gradients of frames t and t+1, st: staged texel coordinates (this plane's buffers).
+template <int ORDER, int RACT, int AACT, bool F16>
+__device__ __forceinline__ void pair_gather_plane(const RenderArgs &a, const float4 *sg0, const float4 *sg1, const float2 *st, int X0, int Y0,
+                                                  int ww, int wh, bool apart, unsigned my_tile, unsigned e0, const unsigned short *oplane,
+                                                  const char *plane0, char *gplane0, size_t f1, size_t frame_b, bool has1, int col, int row) {
+    const unsigned win0 = (unsigned)(Y0 * a.Ws + X0);
+    auto gather = [&](unsigned e, int wx, int wy, unsigned tix) {
+        if ((e >> 9) != my_tile) return;
+        const int lc = (int)(e & 511u);
+        const f2 tau = f2{(float)(X0 + wx), (float)(Y0 + wy)};
+        f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        if (apart) {
+            const f2 c0 = *reinterpret_cast<const f2 *>(&st[lc]);
+            const int li0 = lc - (tau.x < c0.x ? 1 : 0) - (tau.y < c0.y ? PW : 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int li = li0 + (k >> 1) * PW + (k & 1);
+                const f2 dc = *reinterpret_cast<const f2 *>(&st[li]) - tau;
+                const float wgt = tent_weight(dc.x) * tent_weight(dc.y);
+                acc0 += *reinterpret_cast<const f4 *>(&sg0[li]) * wgt;
+                acc1 += *reinterpret_cast<const f4 *>(&sg1[li]) * wgt;
+            }
+        } else {
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int li = lc + dy * PW + dx;
+                    const f2 dc = *reinterpret_cast<const f2 *>(&st[li]) - tau;
+                    const float wgt = tent_weight(dc.x) * tent_weight(dc.y);
+                    acc0 += *reinterpret_cast<const f4 *>(&sg0[li]) * wgt;
+                    acc1 += *reinterpret_cast<const f4 *>(&sg1[li]) * wgt;
+                }
+        }
+        if constexpr (ORDER == VL3D_ACT_PRE) {
+            const f4 sv0 = load_texel<F16>(plane0, tix << 4), sv1 = load_texel<F16>(plane0 + f1, tix << 4);
+            acc0 = f4{acc0.x * act_bwd<RACT>(sv0.x, act_fwd<RACT>(sv0.x)), acc0.y * act_bwd<RACT>(sv0.y, act_fwd<RACT>(sv0.y)),
+                      acc0.z * act_bwd<RACT>(sv0.z, act_fwd<RACT>(sv0.z)), acc0.w * act_bwd<AACT>(sv0.w, act_fwd<AACT>(sv0.w))};
+            acc1 = f4{acc1.x * act_bwd<RACT>(sv1.x, act_fwd<RACT>(sv1.x)), acc1.y * act_bwd<RACT>(sv1.y, act_fwd<RACT>(sv1.y)),
+                      acc1.z * act_bwd<RACT>(sv1.z, act_fwd<RACT>(sv1.z)), acc1.w * act_bwd<AACT>(sv1.w, act_fwd<AACT>(sv1.w))};
+        }
+        store_grad_texel<F16>(gplane0, tix << 4, acc0);
+        if (has1) store_grad_texel<F16>(gplane0 + frame_b, tix << 4, acc1);
+    };
+    if (row < wh && col < ww) gather(e0, col, row, win0 + (unsigned)(row * a.Ws + col));
+    // rest of a window larger than 32 x 16: columns beyond 32 as a packed strip, rows beyond 16 one half-wave per row
+    const int nec = ww - PW;
+    if (nec > 0) {
+        const int necp = min(nec, PW);
+        const int sh = necp > 1 ? 32 - __builtin_clz((unsigned)(necp - 1)) : 0, rpg = PW >> sh, rmain = min(wh, PROWS);
+        const int c = col & ((1 << sh) - 1), r = col >> sh;          // a 32-thread row group takes rpg window rows of the strip
+        for (int wxb = PW; wxb < ww; wxb += (1 << sh))
+            for (int wy0 = row * rpg; wy0 < rmain; wy0 += PROWS * rpg) {
+                const int wy = wy0 + r, wx = wxb + c;
+                if (c < necp && wx < ww && wy < rmain) {
+                    const unsigned tix = win0 + (unsigned)(wy * a.Ws + wx);
+                    gather(oplane[tix], wx, wy, tix);
+                }
+            }
+    }
+    for (int wy = row + PROWS; wy < wh; wy += PROWS)
+        for (int wx = col; wx < ww; wx += PW) {
+            const unsigned tix = win0 + (unsigned)(wy * a.Ws + wx);
+            gather(oplane[tix], wx, wy, tix);
+        }
+}
+
+// composite backward of one plane for one frame: o = activated sample (alpha already 0 where uncovered), pre = the
+// value before the activation, extra = the regularisers' part of the gradient w.r.t. the activated layer value (0 without them)
+#define VL3D_PAIR_GRAD(o, pre, Gr, Gg, Gb, gA, S, P, Tr, gv, ex)                                                               \
+    {                                                                                                                          \
+        const float q = dot3p(Gr, o.x, Gg, o.y, Gb, o.z, gA);                                                                  \
+        const float w = o.w * Tr;                                                                                              \
+        P = fmaf(w, q, P);                                                                                                     \
+        const float om = 1.0f - o.w;                                                                                           \
+        const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;                                                    \
+        gv = make_float4(fmaf(w, Gr, ex.x), fmaf(w, Gg, ex.y), fmaf(w, Gb, ex.z), fmaf(Tr, q, -behind) + ex.w);                \
+        Tr *= om;                                                                                                              \
+        if constexpr (ORDER == VL3D_ACT_POST)                                                                                  \
+            gv = make_float4(gv.x * act_bwd<RACT>(pre.x, o.x), gv.y * act_bwd<RACT>(pre.y, o.y),                              \
+                             gv.z * act_bwd<RACT>(pre.z, o.z), gv.w * act_bwd<AACT>(pre.w, o.w));                              \
+    }
+
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
 __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {      // >= 4 waves per SIMD (2 workgroups per CU): <= 128 VGPRs
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
@@ -1070,10 +1166,11 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
     float Tr0 = 1.0f, P0 = 0.0f, Tr1 = 1.0f, P1 = 0.0f;
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
     const unsigned my_tile_id = (unsigned)(tile_y * a.tiles_x + tile_x);
-    const unsigned my_tile = (unsigned)((tile_y & 7) << 3 | (tile_x & 7));
+    const unsigned my_tile = (unsigned)((tile_y & 15) << 3 | (tile_x & 7));     // 9-bit slots: 4 + 3 bits of tile code (bwd_owner_table_k)
     const unsigned toff_thread = (unsigned)(row * a.Ws + col);
     const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)my_tile_id * a.D * 4;
     typedef typename TapVal<F16, ORDER>::type tapv_t;
+    const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
     for (int d = 0; d < a.D; ++d, plane0 += plane_stride_b, gplane0 += plane_stride_b) {
         float h[9];
         load_uniform(a.homos + 9 * d, h);
@@ -1081,9 +1178,8 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
         const int ww = wwh & 0xffff, wh = (wwh >> 16) & 0x3fff;
         const bool apart = (wwh & 0x40000000) != 0;
         const int buf = d & 1;
-        const unsigned win0 = (unsigned)(Y0 * a.Ws + X0);
         const unsigned short *oplane = a.owner + (size_t)d * a.Hs * a.Ws;
-        const unsigned e0 = oplane[win0 + toff_thread];          // unconditional (padded table), arrives in the shadow of the sweep
+        const unsigned e0 = oplane[(unsigned)(Y0 * a.Ws + X0) + toff_thread];     // unconditional (padded table), arrives in the shadow of the sweep
         // (2) sweep: one set of taps, two frames
         float2 tc = make_float2(0.f, 0.f);
         float4 gv0 = make_float4(0.f, 0.f, 0.f, 0.f), gv1 = gv0;
@@ -1095,22 +1191,8 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
             f4 pre0, pre1;
             const f4 o0 = shade2<ORDER, RACT, AACT>(tp, tv0, &pre0);
             const f4 o1 = shade2<ORDER, RACT, AACT>(tp, tv1, &pre1);
-#define VL3D_PAIR_GRAD(o, pre, Gr, Gg, Gb, gA, S, P, Tr, gv)                                                                   \
-            {                                                                                                                      \
-                const float q = dot3p(Gr, o.x, Gg, o.y, Gb, o.z, gA);                                                              \
-                const float w = o.w * Tr;                                                                                          \
-                P = fmaf(w, q, P);                                                                                                 \
-                const float om = 1.0f - o.w;                                                                                       \
-                const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;                                                \
-                gv = make_float4(w * Gr, w * Gg, w * Gb, fmaf(Tr, q, -behind));                                                    \
-                Tr *= om;                                                                                                          \
-                if constexpr (ORDER == VL3D_ACT_POST)                                                                              \
-                    gv = make_float4(gv.x * act_bwd<RACT>(pre.x, o.x), gv.y * act_bwd<RACT>(pre.y, o.y),                          \
-                                     gv.z * act_bwd<RACT>(pre.z, o.z), gv.w * act_bwd<AACT>(pre.w, o.w));                          \
-            }
-            VL3D_PAIR_GRAD(o0, pre0, Gr0, Gg0, Gb0, gA0, S0, P0, Tr0, gv0)
-            VL3D_PAIR_GRAD(o1, pre1, Gr1, Gg1, Gb1, gA1, S1, P1, Tr1, gv1)
-#undef VL3D_PAIR_GRAD
+            VL3D_PAIR_GRAD(o0, pre0, Gr0, Gg0, Gb0, gA0, S0, P0, Tr0, gv0, zero4)
+            VL3D_PAIR_GRAD(o1, pre1, Gr1, Gg1, Gb1, gA1, S1, P1, Tr1, gv1, zero4)
             tc = make_float2(tp.tx, tp.ty);
             if (!(tp.cov > 0.0f)) { gv0 = make_float4(0.f, 0.f, 0.f, 0.f); gv1 = gv0; }
         }
@@ -1119,80 +1201,169 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
         s_g[buf][1][tid] = gv1;
         __syncthreads();
         // (3) gather: one set of weights, two accumulators
-        auto gather = [&](unsigned e, int wx, int wy, unsigned tix) {
-            if ((e >> 10) != my_tile) return;
-            const int lc = (int)(e & 1023u);
-            const f2 tau = f2{(float)(X0 + wx), (float)(Y0 + wy)};
-            f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-            if (apart) {
-                const f2 c0 = *reinterpret_cast<const f2 *>(&s_t[buf][lc]);
-                const int li0 = lc - (tau.x < c0.x ? 1 : 0) - (tau.y < c0.y ? PW : 0);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int li = li0 + (k >> 1) * PW + (k & 1);
-                    const f2 dc = *reinterpret_cast<const f2 *>(&s_t[buf][li]) - tau;
-                    const float wgt = tent_weight(dc.x) * tent_weight(dc.y);
-                    acc0 += *reinterpret_cast<const f4 *>(&s_g[buf][0][li]) * wgt;
-                    acc1 += *reinterpret_cast<const f4 *>(&s_g[buf][1][li]) * wgt;
-                }
-            } else {
-#pragma unroll
-                for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        const int li = lc + dy * PW + dx;
-                        const f2 dc = *reinterpret_cast<const f2 *>(&s_t[buf][li]) - tau;
-                        const float wgt = tent_weight(dc.x) * tent_weight(dc.y);
-                        acc0 += *reinterpret_cast<const f4 *>(&s_g[buf][0][li]) * wgt;
-                        acc1 += *reinterpret_cast<const f4 *>(&s_g[buf][1][li]) * wgt;
-                    }
-            }
-            if constexpr (ORDER == VL3D_ACT_PRE) {
-                const f4 sv0 = load_texel<F16>(plane0, tix << 4), sv1 = load_texel<F16>(plane0 + f1, tix << 4);
-                acc0 = f4{acc0.x * act_bwd<RACT>(sv0.x, act_fwd<RACT>(sv0.x)), acc0.y * act_bwd<RACT>(sv0.y, act_fwd<RACT>(sv0.y)),
-                          acc0.z * act_bwd<RACT>(sv0.z, act_fwd<RACT>(sv0.z)), acc0.w * act_bwd<AACT>(sv0.w, act_fwd<AACT>(sv0.w))};
-                acc1 = f4{acc1.x * act_bwd<RACT>(sv1.x, act_fwd<RACT>(sv1.x)), acc1.y * act_bwd<RACT>(sv1.y, act_fwd<RACT>(sv1.y)),
-                          acc1.z * act_bwd<RACT>(sv1.z, act_fwd<RACT>(sv1.z)), acc1.w * act_bwd<AACT>(sv1.w, act_fwd<AACT>(sv1.w))};
-            }
-            store_grad_texel<F16>(gplane0, tix << 4, acc0);
-            if (has1) store_grad_texel<F16>(gplane0 + frame_b, tix << 4, acc1);
-        };
-        if (row < wh && col < ww) gather(e0, col, row, win0 + toff_thread);
-        // rest of a window larger than 32 x 16: columns beyond 32 as a packed strip, rows beyond 16 one half-wave per row
-        const int nec = ww - PW;
-        if (nec > 0) {
-            const int necp = min(nec, PW);
-            const int sh = necp > 1 ? 32 - __builtin_clz((unsigned)(necp - 1)) : 0, rpg = PW >> sh, rmain = min(wh, PROWS);
-            const int c = col & ((1 << sh) - 1), r = col >> sh;          // a 32-thread row group takes rpg window rows of the strip
-            for (int wxb = PW; wxb < ww; wxb += (1 << sh))
-                for (int wy0 = row * rpg; wy0 < rmain; wy0 += PROWS * rpg) {
-                    const int wy = wy0 + r, wx = wxb + c;
-                    if (c < necp && wx < ww && wy < rmain) {
-                        const unsigned tix = win0 + (unsigned)(wy * a.Ws + wx);
-                        gather(oplane[tix], wx, wy, tix);
-                    }
-                }
-        }
-        for (int wy = row + PROWS; wy < wh; wy += PROWS)
-            for (int wx = col; wx < ww; wx += PW) {
-                const unsigned tix = win0 + (unsigned)(wy * a.Ws + wx);
-                gather(oplane[tix], wx, wy, tix);
-            }
+        pair_gather_plane<ORDER, RACT, AACT, F16>(a, s_g[buf][0], s_g[buf][1], s_t[buf], X0, Y0, ww, wh, apart, my_tile, e0, oplane, plane0, gplane0,
+                                                  f1, frame_b, has1, col, row);
     }
 }
 
+// Frame pairs WITH the layer regularisers (MPV.py:511-531: rgb_smooth / a_smooth / sparsity -- what a shipped stage-2 iteration
+// runs, configs/mpv_base.txt:33-34).  The smoothness gradient at a pixel needs the activated layer values of its 4 neighbours, so
+// the region carries a 2-pixel halo (28 x 12 owned of 32 x 16; outer ring: layer values only, inner ring: gradient providers for
+// the gather) and the values go through LDS before the gradient can be formed: two dependent exchanges per plane (layer values ->
+// gradients -> gather).  The one-frame REG instantiation of render_bwd_tile_k pays them as two barriers per plane on ONE resident
+// workgroup per CU (1024 threads at > 64 VGPRs): 26.9 ms at cfg3 against 12 ms without the regularisers.  Here the sampling is
+// software-pipelined one plane ahead: iteration d forms the gradients of plane d (layer values staged by iteration d-1) and
+// samples plane d+1 in the same phase -- its tap loads are issued first and land while the gradient arithmetic of plane d runs --
+// so ONE barrier per plane separates [gradients of d, layer values of d+1] from [gather of d].  What crosses the barrier in
+// registers is the shaded sample of the next plane (2 x 8 + 3 values), not its 32 tap registers.  72 KiB of LDS, 2 workgroups per CU.
+// Per frame the arithmetic is that of render_bwd_tile_k<REG> in the same order.
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
+__global__ __launch_bounds__(PNT, 4) void render_bwd_pair_reg_k(RenderArgs a) {
+    if (!reinterpret_cast<const int *>(a.plan)[0]) return;
+    constexpr int RH = 2;
+    __shared__ float4 s_o[2][2][PNT];   // [buffer][frame][pixel]: activated layer values, 0 in ALL channels where the plane does not cover (MPV.py:441)
+    __shared__ float4 s_g[2][2][PNT];
+    __shared__ float2 s_t[2][PNT];
+    const int tid = threadIdx.x, col = tid & (PW - 1), row = tid >> 5;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_x = bid % a.tiles_x, rest = bid / a.tiles_x;
+    const int tile_y = rest % a.tiles_y, t0 = (rest / a.tiles_y) * 2;
+    const bool has1 = t0 + 1 < a.T;
+    const int rx0 = tile_x * (PW - 2 * RH) - RH, ry0 = tile_y * (PROWS - 2 * RH) - RH;
+    const int x = rx0 + col, y = ry0 + row;
+    const bool inimg = (x >= 0) && (x < a.W) && (y >= 0) && (y < a.H);
+    const bool provider = col >= 1 && col <= PW - 2 && row >= 1 && row <= PROWS - 2;     // the outermost ring only provides layer values
+    const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
+    constexpr size_t TEXB = F16 ? 8 : 16;
+    const size_t frame_b = (size_t)a.Hs * a.Ws * TEXB;
+    const size_t plane_stride_b = (size_t)a.T * frame_b;
+    const char *plane0 = reinterpret_cast<const char *>(a.stack) + (size_t)t0 * frame_b;
+    char *gplane0 = reinterpret_cast<char *>(a.g_stack) + (size_t)t0 * frame_b;
+    const size_t f1 = has1 ? frame_b : 0;
+    float Gr0 = 0.f, Gg0 = 0.f, Gb0 = 0.f, gA0 = 0.f, S0 = 0.f, Gr1 = 0.f, Gg1 = 0.f, Gb1 = 0.f, gA1 = 0.f, S1 = 0.f;
+    float gN10 = 0.f, gN20 = 0.f, gN11 = 0.f, gN21 = 0.f;      // gN1 + gN2 * a_k = d(sparsity sums) / d a_k
+    if (inimg) {
+        size_t pix = ((size_t)t0 * a.H + y) * a.W + x;
+        Gr0 = a.g_rgb[pix * 3 + 0]; Gg0 = a.g_rgb[pix * 3 + 1]; Gb0 = a.g_rgb[pix * 3 + 2];
+        gA0 = a.g_alpha ? a.g_alpha[pix] : 0.0f;
+        S0 = dot3p(Gr0, a.rgb[pix * 3 + 0], Gg0, a.rgb[pix * 3 + 1], Gb0, a.rgb[pix * 3 + 2], gA0 * a.alpha[pix]);
+        if (a.g_asum) { gN10 = a.g_asum[pix * 2 + 0]; gN20 = 2.0f * a.g_asum[pix * 2 + 1]; }
+        if (has1) pix += (size_t)a.H * a.W;
+        Gr1 = a.g_rgb[pix * 3 + 0]; Gg1 = a.g_rgb[pix * 3 + 1]; Gb1 = a.g_rgb[pix * 3 + 2];
+        gA1 = a.g_alpha ? a.g_alpha[pix] : 0.0f;
+        S1 = dot3p(Gr1, a.rgb[pix * 3 + 0], Gg1, a.rgb[pix * 3 + 1], Gb1, a.rgb[pix * 3 + 2], gA1 * a.alpha[pix]);
+        if (a.g_asum) { gN11 = a.g_asum[pix * 2 + 0]; gN21 = 2.0f * a.g_asum[pix * 2 + 1]; }
+    }
+    const float gsx_c = a.g_reg[0], gsy_c = a.g_reg[1], gsx_a = a.g_reg[2], gsy_a = a.g_reg[3];
+    const f4 gx = f4{gsx_c, gsx_c, gsx_c, gsx_a}, gy = f4{gsy_c, gsy_c, gsy_c, gsy_a};
+    float Tr0 = 1.0f, P0 = 0.0f, Tr1 = 1.0f, P1 = 0.0f;
+    const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
+    const unsigned my_tile_id = (unsigned)(tile_y * a.tiles_x + tile_x);
+    const unsigned my_tile = (unsigned)((tile_y & 15) << 3 | (tile_x & 7));
+    const unsigned toff_thread = (unsigned)(row * a.Ws + col);
+    const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)my_tile_id * a.D * 4;
+    typedef typename TapVal<F16, ORDER>::type tapv_t;
+    auto sgn = [](f4 v) { return f4{(float)((v.x > 0.f) - (v.x < 0.f)), (float)((v.y > 0.f) - (v.y < 0.f)),
+                                    (float)((v.z > 0.f) - (v.z < 0.f)), (float)((v.w > 0.f) - (v.w < 0.f))}; };
+    // prologue: sample plane 0 and publish its layer values
+    f4 o0 = f4{0.f, 0.f, 0.f, 0.f}, o1 = o0, pre0 = o0, pre1 = o0;
+    float ctx = 0.f, cty = 0.f, ccov = 0.f;
+    if (inimg) {
+        float h[9];
+        load_uniform(a.homos, h);
+        const Taps2 tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+        tapv_t tv0[4], tv1[4];
+        load_taps2<F16>(plane0, tp, st, tv0);
+        load_taps2<F16>(plane0 + f1, tp, st, tv1);
+        o0 = shade2<ORDER, RACT, AACT>(tp, tv0, &pre0);
+        o1 = shade2<ORDER, RACT, AACT>(tp, tv1, &pre1);
+        ctx = tp.tx; cty = tp.ty; ccov = tp.cov;
+    }
+    {
+        const f4 l0 = o0 * ccov, l1 = o1 * ccov;
+        s_o[0][0][tid] = make_float4(l0.x, l0.y, l0.z, l0.w);
+        s_o[0][1][tid] = make_float4(l1.x, l1.y, l1.z, l1.w);
+    }
+    __syncthreads();
+    for (int d = 0; d < a.D; ++d, plane0 += plane_stride_b, gplane0 += plane_stride_b) {
+        const int X0 = wrec[4 * d], Y0 = wrec[4 * d + 1], wwh = wrec[4 * d + 2];
+        const int ww = wwh & 0xffff, wh = (wwh >> 16) & 0x3fff;
+        const bool apart = (wwh & 0x40000000) != 0;
+        const int buf = d & 1;
+        const unsigned short *oplane = a.owner + (size_t)d * a.Hs * a.Ws;
+        const unsigned e0 = oplane[(unsigned)(Y0 * a.Ws + X0) + toff_thread];
+        // (1) taps of plane d+1: issued first, they land while the gradients of plane d are formed (past the last plane the last one is
+        //     sampled again and dropped: no branch around the loads)
+        const int dn = min(d + 1, a.D - 1);
+        Taps2 tpn{};
+        tapv_t tn0[4], tn1[4];
+        if (inimg) {
+            float h[9];
+            load_uniform(a.homos + 9 * dn, h);
+            tpn = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            const char *pn = plane0 + (size_t)(dn - d) * plane_stride_b;
+            load_taps2<F16>(pn, tpn, st, tn0);
+            load_taps2<F16>(pn + f1, tpn, st, tn1);
+            asm volatile("" ::: "memory");     // keep the loads here
+        }
+        // (2) gradients of plane d: smoothness terms from the neighbours' layer values, then the composite backward
+        float2 tc = make_float2(0.f, 0.f);
+        float4 gv0 = make_float4(0.f, 0.f, 0.f, 0.f), gv1 = gv0;
+        if (inimg) {
+            f4 sg0 = f4{0.f, 0.f, 0.f, 0.f}, sg1 = sg0;
+            if (provider) {
+                const f4 l0 = o0 * ccov, l1 = o1 * ccov;
+                auto ld = [&](int f, int i) { const float4 v = s_o[buf][f][i]; return f4{v.x, v.y, v.z, v.w}; };
+                if (x + 1 < a.W) { sg0 += gx * sgn(l0 - ld(0, tid + 1)); sg1 += gx * sgn(l1 - ld(1, tid + 1)); }          // d|o - o_right| / do
+                if (x >= 1) { sg0 -= gx * sgn(ld(0, tid - 1) - l0); sg1 -= gx * sgn(ld(1, tid - 1) - l1); }               // d|o_left - o| / do
+                if (y + 1 < a.H) { sg0 += gy * sgn(l0 - ld(0, tid + PW)); sg1 += gy * sgn(l1 - ld(1, tid + PW)); }
+                if (y >= 1) { sg0 -= gy * sgn(ld(0, tid - PW) - l0); sg1 -= gy * sgn(ld(1, tid - PW) - l1); }
+            }
+            sg0.w += fmaf(gN20, o0.w, gN10);
+            sg1.w += fmaf(gN21, o1.w, gN11);
+            VL3D_PAIR_GRAD(o0, pre0, Gr0, Gg0, Gb0, gA0, S0, P0, Tr0, gv0, sg0)
+            VL3D_PAIR_GRAD(o1, pre1, Gr1, Gg1, Gb1, gA1, S1, P1, Tr1, gv1, sg1)
+            tc = make_float2(ctx, cty);
+            if (!(ccov > 0.0f && provider)) { gv0 = make_float4(0.f, 0.f, 0.f, 0.f); gv1 = gv0; }
+        }
+        s_t[buf][tid] = tc;
+        s_g[buf][0][tid] = gv0;
+        s_g[buf][1][tid] = gv1;
+        // (3) shade plane d+1 and publish its layer values (the other s_o buffer: its readers finished before the previous barrier)
+        if (inimg) {
+            o0 = shade2<ORDER, RACT, AACT>(tpn, tn0, &pre0);
+            o1 = shade2<ORDER, RACT, AACT>(tpn, tn1, &pre1);
+            ctx = tpn.tx; cty = tpn.ty; ccov = tpn.cov;
+        }
+        {
+            const f4 l0 = o0 * ccov, l1 = o1 * ccov;
+            s_o[buf ^ 1][0][tid] = make_float4(l0.x, l0.y, l0.z, l0.w);
+            s_o[buf ^ 1][1][tid] = make_float4(l1.x, l1.y, l1.z, l1.w);
+        }
+        __syncthreads();
+        // (4) gather of plane d
+        pair_gather_plane<ORDER, RACT, AACT, F16>(a, s_g[buf][0], s_g[buf][1], s_t[buf], X0, Y0, ww, wh, apart, my_tile, e0, oplane, plane0, gplane0,
+                                                  f1, frame_b, has1, col, row);
+    }
+}
+#undef VL3D_PAIR_GRAD
+
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool REG = false>
 void launch_pair(const RenderArgs &a, hipStream_t s) {
-    constexpr int IW = PW - 2, IH = PROWS - 2;
+    constexpr int RH = REG ? 2 : 1, IW = PW - 2 * RH, IH = PROWS - 2 * RH;
     RenderArgs b = a;
     b.tiles_x = (a.W + IW - 1) / IW; b.tiles_y = (a.H + IH - 1) / IH;
     const int nwin = b.tiles_x * b.tiles_y * a.D;
-    hipLaunchKernelGGL((bwd_windows_k<COORD>), dim3((nwin + 255) / 256), dim3(256), 0, s, b, IW, IH, 1, b.tiles_x, b.tiles_y,
+    hipLaunchKernelGGL((bwd_windows_k<COORD>), dim3((nwin + 255) / 256), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x, b.tiles_y,
                        reinterpret_cast<int *>(const_cast<float *>(a.plan)) + plan_win_off(a.D));
-    hipLaunchKernelGGL(bwd_owner_table_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, b, IW, IH, 1, b.tiles_x,
-                       const_cast<unsigned short *>(a.owner), PW);
-    hipLaunchKernelGGL((render_bwd_pair_k<COORD, BORDER, ORDER, RACT, AACT, F16>),
-                       dim3((unsigned)(b.tiles_x * b.tiles_y * ((a.T + 1) / 2))), dim3(PNT), 0, s, b);
+    hipLaunchKernelGGL(bwd_owner_table_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x,
+                       const_cast<unsigned short *>(a.owner), PW, 9);
+    if constexpr (REG)
+        hipLaunchKernelGGL((render_bwd_pair_reg_k<COORD, BORDER, ORDER, RACT, AACT, F16>),
+                           dim3((unsigned)(b.tiles_x * b.tiles_y * ((a.T + 1) / 2))), dim3(PNT), 0, s, b);
+    else
+        hipLaunchKernelGGL((render_bwd_pair_k<COORD, BORDER, ORDER, RACT, AACT, F16>),
+                           dim3((unsigned)(b.tiles_x * b.tiles_y * ((a.T + 1) / 2))), dim3(PNT), 0, s, b);
 }
 
 // =====================================================================================================
@@ -1314,6 +1485,15 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
                 const bool fits = (int64_t)a.Hs * 100 <= (int64_t)a.H * 107 || (int64_t)a.Ws * 100 <= (int64_t)a.W * 107;
                 if (a.tile_rows == 17 && a.T >= 2 && !a.g_reg && !a.g_asum && !a.quad_keep && fits) {
                     launch_pair<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
+                    done = true;
+                }
+                // with the layer regularisers the pipelined pair kernel wins at every stack size (one barrier per plane and two
+                // resident workgroups against two barriers on one); sample-then-activate conventions only (activate-then-sample keeps
+                // 8 activated taps per frame live and would spill at the 128-VGPR budget: the tile kernel stays in charge there)
+                if (!done && ORDER == VL3D_ACT_POST && a.tile_rows == 17 && a.T >= 2 && (a.g_reg || a.g_asum) && !a.quad_keep) {
+                    RenderArgs ar = a;
+                    if (!ar.g_reg) ar.g_reg = a.plan + 4;      // zeros written by bwd_plan_k
+                    if constexpr (ORDER == VL3D_ACT_POST) launch_pair<COORD, BORDER, ORDER, RACT, AACT, F16, true>(ar, s);
                     done = true;
                 }
             }
