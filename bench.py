@@ -46,6 +46,11 @@ def parse():
     ap.add_argument("--no-stage2", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--loss-steps", type=int, default=5)
+    ap.add_argument("--gather-algo", default="auto", choices=["auto", "ring", "direct"],
+                    help="N > 1: RCCL all_gather (ring) or grouped all-peers send/recv (direct), videoloop3d_amd.dist.all_gather_frame")
+    ap.add_argument("--exchange-halo-grads", action="store_true",
+                    help="N > 1: also sum the gradient of the replicated halo rows with the neighbours inside the step (training-complete)")
+    ap.add_argument("--loss-band", action="store_true", help="N > 1: extra leg, the looping loss on this rank's rows of the gathered frame")
     return ap.parse_args()
 
 
@@ -135,7 +140,7 @@ def main():
     if world > 1:
         dist.barrier()
     from videoloop3d_amd import synth
-    from videoloop3d_amd.dist import all_gather_frame, plan_bands, render_band
+    from videoloop3d_amd.dist import all_gather_frame, exchange_halo_grads, halo_overlaps, plan_bands, render_band
     from videoloop3d_amd.render import RenderSpec, render_planes
     from videoloop3d_amd.utils_mpi import compute_homography, make_depths
 
@@ -172,6 +177,8 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)
     fwd_ms, bwd_ms = [], []
 
+    last = {}
+
     def step(timed):
         e0, e1, e2 = ev(), ev(), ev()
         e0.record()
@@ -180,20 +187,24 @@ def main():
         else:
             rgb, alpha = render_band(stack, homos_d, band, W, Hs, spec)
         e1.record()
+        frame = rgb.detach()
         if band is not None:
             comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(comm_stream):
                 if backend == "nccl":
-                    frame = all_gather_frame(rgb.detach(), bands)
-                else:   # debugging path only (gloo has no CUDA all_gather)
-                    frame = all_gather_frame(rgb.detach().cpu(), bands)
+                    frame = all_gather_frame(rgb.detach(), bands, algo=a.gather_algo)
+                else:   # debugging path only (gloo moves host tensors)
+                    frame = all_gather_frame(rgb.detach().cpu(), bands, algo=a.gather_algo)
         (gs,) = torch.autograd.grad(rgb, stack, g_rgb)
+        if band is not None and a.exchange_halo_grads:
+            gs = exchange_halo_grads(gs, bands) if backend == "nccl" else exchange_halo_grads(gs.cpu(), bands).to(dev)
         e2.record()
         if band is not None:
             torch.cuda.current_stream().wait_stream(comm_stream)
         if timed:
             fwd_ms.append((e0, e1))
             bwd_ms.append((e1, e2))
+        last["rgb"], last["frame"] = rgb.detach(), frame
         return gs
 
     def fence():
@@ -213,6 +224,23 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    # ---- what was gathered is what was rendered: per-band checksums travel beside the frame, and the frame's own checksum is the
+    #      same number at every N (band renders are bit-identical to the full render: tests/test_gpu_render.py row-band tests)
+    def bits_sum(t):
+        return int(t.contiguous().view(torch.int32).to(torch.int64).sum().item())
+    frame = last["frame"]
+    frame_checksum = bits_sum(frame)
+    gather_check = None
+    if world > 1:
+        mine = bits_sum(last["rgb"])
+        sums = [None] * world
+        dist.all_gather_object(sums, mine)
+        ok = all(bits_sum(frame[:, b.row0:b.row0 + b.rows]) == sums[b.rank] for b in bands)
+        okt = torch.tensor([1 if ok else 0], device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        gather_check = bool(int(okt.item()))
+        assert gather_check, "the gathered frame differs from the rendered bands"
 
     ms_per_step = dt / a.steps * 1e3
     pix_per_step = T * H * W
@@ -254,7 +282,41 @@ def main():
                    "variant": a.variant},
         "roofline": dominant, "roofline_fwd": r_f, "roofline_bwd": r_b,
         "fwd_bwd_algorithmic_frac": (fwd_bytes + bwd_bytes) / ((f_ms + b_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "frame_checksum": frame_checksum,       # sum of the frame's bit patterns: identical at N = 1, 2, 4, 8
     }
+    if world > 1:
+        band_bytes = T * max(b.rows for b in bands) * W * 3 * 4
+        algo = a.gather_algo if a.gather_algo != "auto" else ("direct" if (world > 2 and backend == "nccl") else "ring")
+        ov = halo_overlaps(bands, rank)
+        res["collective"] = {
+            "op": "all-gather of the composited bands", "algo": algo, "verified": gather_check, "bytes_per_rank_sent": band_bytes * (world - 1) if algo == "direct" else band_bytes,
+            "frame_bytes": T * H * W * 3 * 4,
+            # xGMI: point to point, ~153 GB/s per link and direction, 7 links per GPU (MI355X_MICROARCH.md)
+            "expected_ms_ring": (world - 1) * band_bytes / 153e9 * 1e3, "expected_ms_direct": band_bytes / 153e9 * 1e3,
+            "halo_grad_exchange": {"in_step": bool(a.exchange_halo_grads), "peers": len(ov),
+                                   "bytes_sent": sum((hi - lo) for _, lo, hi in ov) * D * T * Ws * 16},
+        }
+    if world > 1 and a.loss_band:
+        # the looping loss on this rank's rows of the gathered frame (dist.looping_loss_band): halo patch rows recomputed, one scalar
+        # all-reduce; x = the gathered frame (T + 2 loop-padded frames), y = a synthetic captured clip
+        from videoloop3d_amd.dist import looping_loss_band
+        import warnings
+        fr = last["frame"].to(dev).permute(3, 0, 1, 2)[None]                      # [1,3,T,H,W]
+        x = torch.cat([fr, fr[:, :, :2]], 2).contiguous().requires_grad_(True)
+        y = synth.make_video(75, H, W, seed=4, device=dev)
+        cfg = dict(patch_size=3, stride=2, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=10000)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for it in range(4):
+                if it == 1:
+                    fence()
+                    tl = time.perf_counter()
+                ls, n = looping_loss_band(x, y, band.row0, band.rows, **cfg)
+                (gx,) = torch.autograd.grad(ls, x)
+                tot = torch.tensor([float(ls.detach()), float(n)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(tot)
+            fence()
+        res["loss_band"] = {"iters_per_s": 3 / (time.perf_counter() - tl), "loss": float(tot[0] / tot[1]), "cfg": "other (ps 3, stride 2), Ty = 75"}
     if rank == 0:
         # the extra legs (loss, stage-1 shape, storage / culling variants, end-to-end iteration, CPU baseline) run at N = 1 only
         if world > 1:

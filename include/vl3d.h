@@ -31,7 +31,12 @@ enum { VL3D_OK = 0, VL3D_EINVAL = 1, VL3D_ELAUNCH = 2, VL3D_EUNSUPPORTED = 3 };
 enum { VL3D_ACT_NONE = 0, VL3D_ACT_SIGMOID = 1, VL3D_ACT_RELU = 2, VL3D_ACT_CLAMP = 3, VL3D_ACT_ABS = 4 };
 /* texel-coordinate convention.  UTILS_MPI: g = p/[Ws/2,Hs/2]-1 then grid_sample(align_corners=True),
  * i.e. texel = p*(size-1)/size (utils_mpi.py:173-175).  AFFINE: texel = p*s + o (MPV.py atlas-cell UV). */
-enum { VL3D_COORD_UTILS_MPI = 0, VL3D_COORD_AFFINE = 1 };
+enum { VL3D_COORD_UTILS_MPI = 0, VL3D_COORD_AFFINE = 1, VL3D_COORD_AFFINE_PLANES = 2 };
+/* AFFINE_PLANES (with BORDER_HARDCUT, ACT_POST, sigmoid/sigmoid): every plane has its OWN affine texel transform and quad extent --
+ * the reference's atlas-cell layout, where plane p of an atlas of grid_h x grid_w cells samples at xm*pitch - (p % grid_w)/grid_w
+ * with pitch = (Aw-1)/(grid_w*(mpi_w-1)) and is covered while 0 <= xm <= mpi_w-1 (MPV.py:75-81, 394-439).  `homos` is then
+ * (D,16): per plane the 3x3 matrix target pixel -> TEXEL coordinate (the plane's transform already folded in), then the coverage
+ * box x0, x1, y0, y1 in texel coordinates (inclusive), 3 floats of padding; desc->sx = sy = 1, ox = oy = 0. */
 /* ZEROS: grid_sample padding_mode='zeros' (utils_mpi.py:174).  HARDCUT: quad extent, uncovered -> 0 after
  * activation (MPV.py:389,441-447). */
 enum { VL3D_BORDER_ZEROS = 0, VL3D_BORDER_HARDCUT = 1 };

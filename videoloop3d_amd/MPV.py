@@ -63,8 +63,15 @@ def stack_to_atlas(stack, grid_h):
 
 
 class MPMeshVid(nn.Module):
-    def __init__(self, args, H, W, ref_extrin, ref_intrin, near, far, pixel_center=0.5, texel_scale=(1.0, 1.0)):
+    def __init__(self, args, H, W, ref_extrin, ref_intrin, near, far, pixel_center=0.5, texel_scale=(1.0, 1.0), atlas_exact=False):
+        """atlas_exact=True: sample the stack exactly like the reference samples its atlas of plane cells (MPV.py:75-81, 394-439:
+        pitch (Aw-1)/(gw*(mpi_w-1)), per-cell sub-texel origin, neighbour-cell bleed at cell edges) -- videoloop3d_amd/atlas.py.
+        A parity mode for weights that come from / go to the reference (atlas_to_stack / stack_to_atlas); needs args.atlas_grid_h."""
         super().__init__()
+        self.atlas_exact = bool(atlas_exact)
+        self.atlas_grid_h = int(getattr(args, "atlas_grid_h", 1))
+        if self.atlas_exact and args.mpi_d % self.atlas_grid_h != 0:
+            raise RuntimeError("mpi_d and atlas_grid_h should match")                                    # MPV.py:38
         self.args = args
         self.frm_num = args.mpv_frm_num
         self.isloop = args.mpv_isloop
@@ -272,7 +279,13 @@ class MPMeshVid(nn.Module):
         stack = self._frames(ts)
         homos = self.plane_homographies(extrin, intrin)
         smooth_sums = alpha_sums = None
-        if need_smooth:
+        if self.atlas_exact:
+            if need_smooth or self.is_sparse or tuple(stack.shape[2:4]) != (self.mpi_h, self.mpi_w):
+                raise RuntimeError("atlas_exact renders the dense full-resolution stack without the fused regularisers / tile culling / lod")
+            from .atlas import render_atlas_exact
+            rgb, alpha = render_atlas_exact(stack, homos, H, W, self.atlas_grid_h, pixel_center=self.spec.pixel_center,
+                                            rgb_act=self.spec.rgb_act, alpha_act=self.spec.alpha_act)
+        elif need_smooth:
             rgb, alpha, smooth_sums, alpha_sums = render_planes_with_regularisers(stack, homos, H, W, self.spec,
                                                                                   quad_keep=self.quad_keep if self.is_sparse else None)
         else:

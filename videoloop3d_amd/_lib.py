@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VL3D_LIB_PATH") or os.path.join(_HERE, "lib", "libvl3d_hip.so")
 
 ACT = {"none": 0, "sigmoid": 1, "relu": 2, "clamp": 3, "abs": 4}
-COORD = {"utils_mpi": 0, "affine": 1}
+COORD = {"utils_mpi": 0, "affine": 1, "affine_planes": 2}
 BORDER = {"zeros": 0, "hardcut": 1}
 ACT_ORDER = {"pre": 0, "post": 1}
 RHO = {"mse": 0, "abs": 1, "barron": 2}

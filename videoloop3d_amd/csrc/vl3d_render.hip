@@ -12,6 +12,7 @@ namespace {
 // conventions a caller can reach (every other combination of the three enums returns VL3D_EUNSUPPORTED):
 //   (UTILS_MPI, ZEROS,   PRE )  the reference's utils_mpi chain                       sigmoid/sigmoid, none/none, none/sigmoid
 //   (AFFINE,    HARDCUT, POST)  the reference's MPV.py planar convention              all nine activation pairs
+//   (AFFINE_PLANES, HARDCUT, POST)  MPV.py atlas-cell sampling: per-plane texel transform + quad extent   sigmoid/sigmoid
 //   (UTILS_MPI, ZEROS,   POST), (UTILS_MPI, HARDCUT, PRE)  cross-check conventions     sigmoid/sigmoid
 int dispatch(bool bwd, const vl3d_render_desc *d, const RenderArgs &a, hipStream_t s) {
     using namespace vl3d_render_detail;
@@ -19,6 +20,7 @@ int dispatch(bool bwd, const vl3d_render_desc *d, const RenderArgs &a, hipStream
     if (c == VL3D_COORD_UTILS_MPI && b == VL3D_BORDER_ZEROS && o == VL3D_ACT_PRE) return conv_utils_zeros_pre(bwd, d, a, s);
     if (c == VL3D_COORD_UTILS_MPI && b == VL3D_BORDER_ZEROS && o == VL3D_ACT_POST) return conv_utils_zeros_post(bwd, d, a, s);
     if (c == VL3D_COORD_UTILS_MPI && b == VL3D_BORDER_HARDCUT && o == VL3D_ACT_PRE) return conv_utils_hardcut_pre(bwd, d, a, s);
+    if (c == VL3D_COORD_AFFINE_PLANES && b == VL3D_BORDER_HARDCUT && o == VL3D_ACT_POST) return conv_affine_planes_hardcut_post(bwd, d, a, s);
     if (c == VL3D_COORD_AFFINE && b == VL3D_BORDER_HARDCUT && o == VL3D_ACT_POST) {
         if (d->rgb_act == VL3D_ACT_SIGMOID && d->alpha_act == VL3D_ACT_SIGMOID) return conv_affine_hardcut_post_sig(bwd, d, a, s);
         return conv_affine_hardcut_post_other(bwd, d, a, s);
@@ -34,6 +36,8 @@ int check_desc(const vl3d_render_desc *d) {
     VL3D_REQUIRE((int64_t)d->Hs * d->Ws < (1ll << 31), "plane too large for 32-bit texel index");
     VL3D_REQUIRE(d->Hs < (1 << 24) && d->Ws < (1 << 24), "plane side too large (24-bit row arithmetic)");
     VL3D_REQUIRE(d->stack_dtype == VL3D_F32 || d->stack_dtype == VL3D_F16, "stack_dtype must be VL3D_F32 or VL3D_F16");
+    VL3D_REQUIRE(d->coord_mode != VL3D_COORD_AFFINE_PLANES || (d->sx == 1.0f && d->sy == 1.0f && d->ox == 0.0f && d->oy == 0.0f),
+                 "VL3D_COORD_AFFINE_PLANES: the texel transforms live in the per-plane records (sx = sy = 1, ox = oy = 0)");
     VL3D_REQUIRE(d->stack_dtype == VL3D_F32 || (d->rgb_act == VL3D_ACT_SIGMOID && d->alpha_act == VL3D_ACT_SIGMOID),
                  "fp16 plane stacks are implemented for the shipped (sigmoid, sigmoid) activations only");
     // the packed fp16 tap load fetches texels x0 and x0+1 of a row with one 16-byte read (load_taps2): a row needs two texels
@@ -53,6 +57,7 @@ RenderArgs make_args(const vl3d_render_desc *d) {
 
 static int check_cull(const vl3d_render_desc *desc, const uint8_t *quad_keep, int32_t QH, int32_t QW) {
     if (!quad_keep) return VL3D_OK;
+    VL3D_REQUIRE(desc->coord_mode != VL3D_COORD_AFFINE_PLANES, "tile culling is not available with per-plane texel transforms");
     VL3D_REQUIRE(QH > 0 && QW > 0, "tile culling: non-positive quad grid");
     VL3D_REQUIRE(desc->D <= 128, "tile culling supports at most 128 planes");
     return VL3D_OK;

@@ -21,6 +21,15 @@
 #pragma once
 #include "vl3d_common.h"
 
+// per-plane records of the homography table: 9 floats (the 3x3 matrix) by default; the VL3D_COORD_AFFINE_PLANES convention
+// (vl3d_render_c5_mpv_planes.hip) carries 16 per plane -- matrix, then the hard-cut coverage box (x0, x1, y0, y1) in texel
+// coordinates, 3 pad -- so that every plane can have its own affine texel transform (folded into its matrix by the host) and its own
+// quad extent: the reference's atlas-cell layout (MPV.py:75-81: plane p samples at xm*pitch - (p % grid_w)/grid_w, include/vl3d.h).
+#ifndef VL3D_HS
+#define VL3D_HS 9
+#define VL3D_HN 9
+#endif
+
 namespace vl3d_render_detail {
 
 struct RenderArgs {
@@ -64,6 +73,7 @@ int conv_utils_zeros_post(bool bwd, const vl3d_render_desc *d, const RenderArgs 
 int conv_utils_hardcut_pre(bool bwd, const vl3d_render_desc *d, const RenderArgs &a, hipStream_t s);
 int conv_affine_hardcut_post_sig(bool bwd, const vl3d_render_desc *d, const RenderArgs &a, hipStream_t s);
 int conv_affine_hardcut_post_other(bool bwd, const vl3d_render_desc *d, const RenderArgs &a, hipStream_t s);
+int conv_affine_planes_hardcut_post(bool bwd, const vl3d_render_desc *d, const RenderArgs &a, hipStream_t s);
 
 }  // namespace vl3d_render_detail
 
@@ -183,7 +193,10 @@ __device__ __forceinline__ TapsI make_taps_i(const float *__restrict__ h, float 
     const float wx0 = tent_weight(dx), wx1 = tent_weight(dx - (Ws > 1 ? 1.0f : 3e38f));
     const float wy0 = tent_weight(dy), wy1 = tent_weight(dy - (Hs > 1 ? 1.0f : 3e38f));
     t.w = f4{wx0, wx1, wx0, wx1} * f4{wy0, wy0, wy1, wy1};
-    if constexpr (BORDER == VL3D_BORDER_HARDCUT) {   // MPV.py:374-453: the plane quad ends at the outermost texel centres
+    if constexpr (BORDER == VL3D_BORDER_HARDCUT && VL3D_HN == 13) {   // per-plane quad extent (atlas cells: the box is not the texel range)
+        const bool cov = (tx >= h[9]) && (tx <= h[10]) && (ty >= h[11]) && (ty <= h[12]);
+        t.cov = cov ? 1.0f : 0.0f;
+    } else if constexpr (BORDER == VL3D_BORDER_HARDCUT) {   // MPV.py:374-453: the plane quad ends at the outermost texel centres
         const bool cov = (tx >= 0.0f) && (tx <= (float)(Ws - 1)) && (ty >= 0.0f) && (ty <= (float)(Hs - 1));
         t.cov = cov ? 1.0f : 0.0f;
     } else {                                         // zeros padding: covered while any tap is inside, i.e. any weight > 0
@@ -341,7 +354,7 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
     float Tr = 1.0f, P = 0.0f;
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws), gst = make_tap_step<false>(a.Hs, a.Ws);
     for (int d = 0; d < a.D; ++d, plane += (size_t)a.T * a.Hs * a.Ws * TEXB, gplane += (size_t)a.T * a.Hs * a.Ws * TEXB) {
-        const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
+        const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + VL3D_HS * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
         if (tp.cov == 0.0f) continue;
         typename TapVal<F16, ORDER>::type tv[4];
         f4 pre;
@@ -358,7 +371,7 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
         if (a.g_reg) {   // smoothness regularisers on the fallback path: re-sample the 4 neighbours' layer values
             const f4 gx = f4{a.g_reg[0], a.g_reg[0], a.g_reg[0], a.g_reg[2]}, gy = f4{a.g_reg[1], a.g_reg[1], a.g_reg[1], a.g_reg[3]};
             auto layer = [&](float qx, float qy) {
-                const Taps2 tq = make_taps2<COORD, BORDER>(a.homos + 9 * d, qx, qy, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
+                const Taps2 tq = make_taps2<COORD, BORDER>(a.homos + VL3D_HS * d, qx, qy, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
                 typename TapVal<F16, ORDER>::type tq_v[4];
                 load_taps2<F16>(plane, tq, st, tq_v);
                 return shade2<ORDER, RACT, AACT>(tq, tq_v) * tq.cov;
@@ -410,7 +423,7 @@ __global__ __launch_bounds__(256) void cull_fwd_plan_k(RenderArgs a, int TY, int
     if (i >= tiles_x * tiles_y * a.D) return;
     const int d = i % a.D, tile = i / a.D, tile_x = tile % tiles_x, tile_y = tile / tiles_x;
     const int x0 = tile_x * 64, x1 = min(x0 + 63, a.W - 1), y0 = tile_y * TY, y1 = min(y0 + TY - 1, a.H - 1);
-    const float *h = a.homos + 9 * d;
+    const float *h = a.homos + VL3D_HS * d;
     float tnx = 1e30f, txx = -1e30f, tny = 1e30f, txy = -1e30f;
     for (int c = 0; c < 4; ++c) {
         const float cx = (float)a.col0 + a.pc + (float)((c & 1) ? x1 : x0), cy = (float)a.row0 + a.pc + (float)((c & 2) ? y1 : y0);
@@ -460,8 +473,8 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
             return d;
         };
         auto fetch = [&](int d, Taps2 &t, tapv_t *v) {
-            float h[9];
-            load_uniform(a.homos + 9 * d, h);
+            float h[VL3D_HN];
+            load_uniform(a.homos + VL3D_HS * d, h);
             t = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
             load_taps2<F16>(plane + (size_t)d * plane_stride_b, t, st, v);
             asm volatile("" ::: "memory");
@@ -491,8 +504,8 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
     for (int d = 0;; d += 2) {
         {
             const int dn = min(d + 1, a.D - 1);
-            float h[9];
-            load_uniform(a.homos + 9 * dn, h);
+            float h[VL3D_HN];
+            load_uniform(a.homos + VL3D_HS * dn, h);
             tB = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
             load_taps2<F16>(plane + (size_t)dn * plane_stride_b, tB, st, vB);
             asm volatile("" ::: "memory");   // keep the loads here: hipcc otherwise sinks them below the composite
@@ -501,8 +514,8 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
         if (d + 1 >= a.D) break;
         {
             const int dn = min(d + 2, a.D - 1);
-            float h[9];
-            load_uniform(a.homos + 9 * dn, h);
+            float h[VL3D_HN];
+            load_uniform(a.homos + VL3D_HS * dn, h);
             tA = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
             load_taps2<F16>(plane + (size_t)dn * plane_stride_b, tA, st, vA);
             asm volatile("" ::: "memory");
@@ -559,8 +572,8 @@ __global__ __launch_bounds__(64 * TY, 4) void render_fwd2x_k(RenderArgs a, int t
     for (int d = 0;; d += 2) {
         {
             const int dn = min(d + 1, a.D - 1);
-            float h[9];
-            load_uniform(a.homos + 9 * dn, h);
+            float h[VL3D_HN];
+            load_uniform(a.homos + VL3D_HS * dn, h);
             tB = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
             load_taps2<F16>(plane0 + (size_t)dn * plane_stride_b, tB, st, vB0);
             load_taps2<F16>(plane1 + (size_t)dn * plane_stride_b, tB, st, vB1);
@@ -570,8 +583,8 @@ __global__ __launch_bounds__(64 * TY, 4) void render_fwd2x_k(RenderArgs a, int t
         if (d + 1 >= a.D) break;
         {
             const int dn = min(d + 2, a.D - 1);
-            float h[9];
-            load_uniform(a.homos + 9 * dn, h);
+            float h[VL3D_HN];
+            load_uniform(a.homos + VL3D_HS * dn, h);
             tA = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
             load_taps2<F16>(plane0 + (size_t)dn * plane_stride_b, tA, st, vA0);
             load_taps2<F16>(plane1 + (size_t)dn * plane_stride_b, tA, st, vA1);
@@ -661,7 +674,7 @@ __global__ void bwd_plan_k(RenderArgs a, int rows, float *plan) {
     __syncthreads();
     for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
         double M[9];
-        texel_homography<COORD>(a.homos + 9 * d, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, M);
+        texel_homography<COORD>(a.homos + VL3D_HS * d, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, M);
         const double det = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
                            M[2] * (M[3] * M[7] - M[4] * M[6]);
         bool ok = (det == det) && fabs(det) > 1e-30;
@@ -713,7 +726,7 @@ __global__ __launch_bounds__(256) void bwd_windows_k(RenderArgs a, int iw, int i
     const int ix0 = tile_x * iw, ix1 = min(ix0 + iw - 1, a.W - 1), iy0 = tile_y * ih, iy1 = min(iy0 + ih - 1, a.H - 1);
     const float el = (ix0 == 0) ? 1.6f : 0.55f, er = (ix1 == a.W - 1) ? 1.6f : 0.55f;
     const float et = (iy0 == 0) ? 1.6f : 0.55f, eb = (iy1 == a.H - 1) ? 1.6f : 0.55f;
-    const float *h = a.homos + 9 * d;
+    const float *h = a.homos + VL3D_HS * d;
     float mnx = 1e30f, mxx = -1e30f, mny = 1e30f, mxy = -1e30f;
     for (int c = 0; c < 4; ++c) {
         const float cx = (float)a.col0 + a.pc + ((c & 1) ? (float)ix1 + er : (float)ix0 - el);
@@ -878,8 +891,8 @@ __global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(Ren
     const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)my_tile_id * a.D * 4;
     int nswept = 0;
     for (int d = 0; d < a.D; ++d, plane += plane_stride_b, gplane += plane_stride_b) {
-        float h[9];
-        load_uniform(a.homos + 9 * d, h);
+        float h[VL3D_HN];
+        load_uniform(a.homos + VL3D_HS * d, h);
         // texel window of this tile on plane d (wave = window row, lane = window column); bit 31: culled for this tile
         const int X0 = wrec[4 * d], Y0 = wrec[4 * d + 1], wwh = wrec[4 * d + 2];
         const int ww = wwh & 0xffff, wh = (wwh >> 16) & 0x3fff;
@@ -1172,8 +1185,8 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
     typedef typename TapVal<F16, ORDER>::type tapv_t;
     const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
     for (int d = 0; d < a.D; ++d, plane0 += plane_stride_b, gplane0 += plane_stride_b) {
-        float h[9];
-        load_uniform(a.homos + 9 * d, h);
+        float h[VL3D_HN];
+        load_uniform(a.homos + VL3D_HS * d, h);
         const int X0 = wrec[4 * d], Y0 = wrec[4 * d + 1], wwh = wrec[4 * d + 2];
         const int ww = wwh & 0xffff, wh = (wwh >> 16) & 0x3fff;
         const bool apart = (wwh & 0x40000000) != 0;
@@ -1269,7 +1282,7 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_reg_k(RenderArgs a) {
     f4 o0 = f4{0.f, 0.f, 0.f, 0.f}, o1 = o0, pre0 = o0, pre1 = o0;
     float ctx = 0.f, cty = 0.f, ccov = 0.f;
     if (inimg) {
-        float h[9];
+        float h[VL3D_HN];
         load_uniform(a.homos, h);
         const Taps2 tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
         tapv_t tv0[4], tv1[4];
@@ -1298,8 +1311,8 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_reg_k(RenderArgs a) {
         Taps2 tpn{};
         tapv_t tn0[4], tn1[4];
         if (inimg) {
-            float h[9];
-            load_uniform(a.homos + 9 * dn, h);
+            float h[VL3D_HN];
+            load_uniform(a.homos + VL3D_HS * dn, h);
             tpn = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
             const char *pn = plane0 + (size_t)(dn - d) * plane_stride_b;
             load_taps2<F16>(pn, tpn, st, tn0);
@@ -1395,7 +1408,7 @@ __global__ __launch_bounds__(RW *ROWS) void render_reg_fwd_k(RenderArgs a) {
         __syncthreads();
         if (tid < a.D) {
             const int x0 = blockIdx.x * (RW - 1), x1 = min(x0 + RW - 1, a.W - 1), y0 = blockIdx.y * (ROWS - 1), y1 = min(y0 + ROWS - 1, a.H - 1);
-            const float *h = a.homos + 9 * tid;
+            const float *h = a.homos + VL3D_HS * tid;
             float tnx = 1e30f, txx = -1e30f, tny = 1e30f, txy = -1e30f;
             for (int c = 0; c < 4; ++c) {
                 const float cx = (float)a.col0 + a.pc + (float)((c & 1) ? x1 : x0), cy = (float)a.row0 + a.pc + (float)((c & 2) ? y1 : y0);
@@ -1413,7 +1426,7 @@ __global__ __launch_bounds__(RW *ROWS) void render_reg_fwd_k(RenderArgs a) {
         if (a.quad_keep && !((s_mask[d >> 6] >> (d & 63)) & 1ull)) continue;      // uniform
         f4 ol = f4{0.f, 0.f, 0.f, 0.f};
         if (inimg) {
-            const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + 9 * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
+            const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + VL3D_HS * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
             typename TapVal<F16, ORDER>::type tv[4];
             load_taps2<F16>(plane, tp, make_tap_step<F16>(a.Hs, a.Ws), tv);
             ol = shade2<ORDER, RACT, AACT>(tp, tv) * tp.cov;

@@ -70,7 +70,12 @@ class _RenderPlanes(torch.autograd.Function):
         stack = stack.contiguous()
         homos = homos.detach().to(torch.float32).contiguous()
         D, T = stack.shape[:2]
-        if homos.shape != (D, 3, 3):
+        if spec.coord_mode == "affine_planes":
+            if homos.shape != (D, 16):
+                raise RuntimeError(f"coord_mode 'affine_planes' takes per-plane records [D,16] = [{D},16] (atlas.plane_records), got {tuple(homos.shape)}")
+            if quad_keep is not None:
+                raise RuntimeError("tile culling is not available with per-plane texel transforms")
+        elif homos.shape != (D, 3, 3):
             raise RuntimeError(f"homos must be [D,3,3] = [{D},3,3], got {tuple(homos.shape)}")
         rgb = torch.empty((T, H, W, 3), dtype=torch.float32, device=stack.device)
         alpha = torch.empty((T, H, W), dtype=torch.float32, device=stack.device)
