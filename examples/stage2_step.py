@@ -33,12 +33,13 @@ def run(iters=10, frames=50, planes=32, smooth=0.2, dev="cuda:0", crop=(180, 320
     K = np.array([[0.9 * W, 0, W / 2], [0, 0.9 * W, H / 2], [0, 0, 1]], np.float64)
     model = MPMeshVid(args, H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
     args.optimizer, args.lrate, args.lrate_decay = "adam", 0.5 * 0.01, 30
-    opt = model.get_optimizer(0)        # MPV.py:199-214 (Adam, betas (0.9, 0.999), eps 6e-8) as one HIP pass over (p, g, m, v)
+    opt = model.get_optimizer(0)        # MPV.py:199-214 (Adam, betas (0.9, 0.999), eps 6e-8): the crop-aware WindowAdam on a dense model
     a = np.radians(0.5)
     tar = np.eye(4)
     tar[:3, :3] = [[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]
     tar[:3, 3] = [0.03, 0.01, 0.0]
-    tar_e = torch.tensor(tar, device=dev)[None]
+    tar_e = torch.tensor(tar)[None]          # poses stay on the host, as the DataLoader yields them (train_3dvid.py:214-216): the module
+                                             # turns them into homographies there and uploads 1 KiB -- no device round trip per iteration
     res = synth.hash_uniform((1, 75, 3, h, w), seed=8, device=dev)
     cfgs = {
         "other": dict(loss_name=["gpnn_lm"], loss_gain=torch.tensor([1.0]), macro_block=torch.tensor([65]), patch_size=torch.tensor([3]),
@@ -59,7 +60,7 @@ def run(iters=10, frames=50, planes=32, smooth=0.2, dev="cuda:0", crop=(180, 320
                 Kc = K.copy()
                 Kc[0, 2] -= 90 + (it % 3) * 40                                   # crop offset (utils.py:196-200)
                 Kc[1, 2] -= 45 + (it % 2) * 60
-                tar_k = torch.tensor(Kc, device=dev)[None]
+                tar_k = torch.tensor(Kc)[None]
                 opt.zero_grad(set_to_none=True)
                 _, extra = model(h, w, tar_e, tar_k, res=res, losscfg=cfg)
                 loss = extra["swd"].sum()
@@ -95,7 +96,7 @@ def run(iters=10, frames=50, planes=32, smooth=0.2, dev="cuda:0", crop=(180, 320
             Kc[0, 2] -= 90 + (it % 3) * 40
             Kc[1, 2] -= 45 + (it % 2) * 60
             opt.zero_grad(set_to_none=True)
-            _, extra = model(h, w, tar_e, torch.tensor(Kc, device=dev)[None], res=res, losscfg=cfg)
+            _, extra = model(h, w, tar_e, torch.tensor(Kc)[None], res=res, losscfg=cfg)
             loss = extra["swd"].sum()
             for k in ("rgb_smooth", "a_smooth"):
                 if k in extra:

@@ -131,6 +131,27 @@ int vl3d_adam_step_tiles(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uin
                          float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float lr, float beta1, float beta2,
                          float eps, int64_t step, vl3d_stream_t stream);
 
+/* Crop-aware Adam for the DENSE stack (csrc/vl3d_optim.hip; the optimiser of train_3dvid.py:263-290 / MPV.py:199-214).  A training
+ * iteration renders one crop, so only the texels of the crop's parallax window (y0, x0, wh, ww; aligned to
+ * vl3d_adam_window_tile() = 16-texel tiles, or ending at the plane border) receive a gradient; the zero-gradient Adam steps of all
+ * other texels (m <- b1 m, v <- b2 v, p <- p - lr_t m^/(sqrt(v^) + eps)) are deferred and replayed exactly, per tile, when a tile is
+ * next needed.  last_step: device int32 [D][ceil(Hs/16)][ceil(Ws/16)], the step each tile is current for (0 initially).
+ * hist: device float2 [steps+1], entry t = (lr_t / (1 - beta1^t), sqrt(1 - beta2^t)) as vl3d_adam_step_scalars computes them,
+ * written by the caller when step t is taken.
+ *   vl3d_adam_window_catchup: bring the window's tiles current for step `upto` (replaying steps last_step+1 .. upto with g = 0) and,
+ *     if compact != NULL, write the window's parameters to the compact (D,T,wh,ww,4) buffer the render then reads.
+ *   vl3d_adam_window_step: the Adam update of step `step` on the window from the compact gradient (D,T,wh,ww,4); the window's tiles
+ *     must be current for step-1 (catch-up first).  Everything outside the window stays deferred.
+ * A catch-up with the full plane as the window makes the whole stack current (checkpoints, lod, evaluation renders). */
+int32_t vl3d_adam_window_tile(void);
+int vl3d_adam_window_catchup(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
+                             float *param, float *exp_avg, float *exp_avg_sq, int32_t *last_step, const float *hist, int32_t upto,
+                             float beta1, float beta2, float eps, float *compact, vl3d_stream_t stream);
+int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
+                          float *param, const float *grad_compact, float *exp_avg, float *exp_avg_sq, int32_t *last_step, float lr,
+                          float beta1, float beta2, float eps, int64_t step, vl3d_stream_t stream);
+void vl3d_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, float *lr_bc1, float *bc2s);
+
 /* Layer-space smoothness regularisers (MPV.py:517-531 rgb_smooth / a_smooth) WITHOUT the materialised [T,h,w,K,4] layer
  * tensor: sums[0..3] (device doubles, overwritten) = sum over frames, planes and neighbouring pixel pairs of
  * |L[p]-L[q]| for (x-pairs, rgb), (y-pairs, rgb), (x-pairs, alpha), (y-pairs, alpha), where L is the warped+activated

@@ -108,6 +108,7 @@ class MPMeshVid(nn.Module):
         self.register_buffer("quad_dyn", None)
         self._tie_hook = None
         self._static_compact = False
+        self._window_opt = None          # the crop-aware Adam handed out by get_optimizer (dense CUDA models)
 
         self.swd_patch_size, self.swd_patcht_size = args.swd_patch_size, args.swd_patcht_size
         self.swd_stride, self.swd_stridet = args.swd_stride, args.swd_stridet
@@ -179,6 +180,7 @@ class MPMeshVid(nn.Module):
 
     def state_dict(self, *args, **kwargs):
         """MPV.py:290-304: tensors + python scalars under "self.*" keys."""
+        self._flush_deferred_updates()
         sd = super().state_dict(*args, **kwargs)
         sd["self.is_sparse"] = self.is_sparse
         sd["self.has_dyn"] = self.has_dyn
@@ -191,6 +193,8 @@ class MPMeshVid(nn.Module):
         antialiased bilinear filter torchvision's Resize applies to the atlas; the plane quads keep their extent, so the
         plane-pixel -> texel scale of the render spec becomes (w'-1)/(mpi_w-1) (the reference gets this from its
         normalised UVs, MPV.py:75-81)."""
+        self._flush_deferred_updates()
+        self._window_opt = None          # the parameter object changes: the driver asks for a new optimiser (train_3dvid.py:264-265)
         h, w = max(int(self.mpi_h * factor), 2), max(int(self.mpi_w * factor), 2)
         D, T, hs, ws, _ = self.stack.shape
         print(f"MPV.lod:: Resizing the planes from {(hs, ws)} to {(h, w)}")
@@ -225,6 +229,28 @@ class MPMeshVid(nn.Module):
         self._install_tie_hook()
         print("MPV.los:: Resizing successful !")
 
+    def _flush_deferred_updates(self):
+        """the crop-aware Adam defers the zero-gradient updates of texels outside the current crop's window: replay them before
+        anything reads the whole stack (checkpoints, lod, evaluation renders)."""
+        if self._window_opt is not None:
+            self._window_opt.flush()
+
+    def crop_window(self, homos, H, W, margin=3):
+        """texel window (y0, x0, wh, ww), aligned to the optimiser's 16-texel tiles, that contains every tap of every pixel of the
+        H x W view on every plane: the image of the view's corners under the plane homographies (convex: extremes at the corners),
+        plus the +1 bilinear tap and a margin.  homos [D,3,3] on the HOST (float64)."""
+        from .optim import align_window
+        c = float(self.spec.pixel_center)
+        pts = torch.tensor([[c, W - 1 + c, c, W - 1 + c], [c, c, H - 1 + c, H - 1 + c], [1.0, 1.0, 1.0, 1.0]], dtype=torch.float64)
+        q = homos.double() @ pts                                                                  # D,3,4
+        Hs, Ws = self.stack.shape[2:4]
+        if bool((q[:, 2] <= 1e-9).any()):
+            return 0, 0, Hs, Ws
+        tx = q[:, 0] / q[:, 2] * self.spec.scale[0] + self.spec.offset[0]
+        ty = q[:, 1] / q[:, 2] * self.spec.scale[1] + self.spec.offset[1]
+        return align_window(int(torch.floor(ty.min())) - margin, int(torch.ceil(ty.max())) + 2 + margin,
+                            int(torch.floor(tx.min())) - margin, int(torch.ceil(tx.max())) + 2 + margin, Hs, Ws)
+
     def get_lrate(self, step):
         """MPV.py:216-225."""
         args = self.args
@@ -237,16 +263,22 @@ class MPMeshVid(nn.Module):
         (_, base_lr), _ = self.get_lrate(step)
         params = [{'params': [p for _, p in self.named_parameters()]}]
         self._static_compact = False
+        self._window_opt = None
         if self.args.optimizer == 'adam':
-            if self.stack.is_cuda:
-                # the same update as torch.optim.Adam in ONE pass over (p, g, m, v) -- 8.5 ms for the 7 GB stage-2 stack vs 12.4 ms
-                # (torch fused) / 29 ms (torch default) -- and, for a sparsified model, only over the texels kept quads can read
+            if self.stack.is_cuda and self.is_sparse:
+                # the same update as torch.optim.Adam in ONE pass over (p, g, m, v), only over the texels kept quads can read
                 from .tiles import TileAdam
                 # static gradients are summed into frame 0 only WHILE the optimiser handed out last is the tile-aware Adam, which
                 # reads them there; any other optimiser (below) sees the frame sum in every copy again
-                self._static_compact = bool(self.is_sparse)
-                return TileAdam(params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8, quad_keep=self.quad_keep if self.is_sparse else None,
-                                quad_dyn=self.quad_dyn if self.is_sparse else None)
+                self._static_compact = True
+                return TileAdam(params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8, quad_keep=self.quad_keep, quad_dyn=self.quad_dyn)
+            if self.stack.is_cuda and not self.atlas_exact:
+                # dense model: crop-aware Adam -- the render reads a compact copy of the crop's texel window, the backward writes a
+                # compact gradient, the step touches the window only; the zero-gradient updates of everything else are deferred and
+                # replayed exactly (videoloop3d_amd/optim.py).  While it is attached, training renders go through its window.
+                from .optim import WindowAdam
+                self._window_opt = WindowAdam(params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8)
+                return self._window_opt
             return torch.optim.Adam(params=params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8)
         if self.args.optimizer == 'sgd':
             return torch.optim.SGD(params=params, lr=base_lr, momentum=0.9)
@@ -264,8 +296,20 @@ class MPMeshVid(nn.Module):
         dev = extrin.device
         eye = torch.eye(4, dtype=extrin.dtype, device=dev)[None]
         normal = torch.tensor([0., 0., 1.], dtype=extrin.dtype, device=dev).expand(1, self.mpi_d, 3)
-        return compute_homography(eye, self.ref_intrin_mpi[None].to(extrin.dtype), extrin, intrin, normal,
-                                  self.planedepth[None].to(extrin.dtype))[0].float()
+        return compute_homography(eye, self._on(dev, "ref_intrin_mpi")[None].to(extrin.dtype), extrin, intrin.to(dev), normal,
+                                  self._on(dev, "planedepth")[None].to(extrin.dtype))[0].float()
+
+    def _on(self, dev, name):
+        """the (small, constant) camera buffers on the device of the pose tensors: poses that arrive on the HOST (as the DataLoader
+        produces them, train_3dvid.py:214-216) are turned into homographies there, with no device round trip."""
+        buf = getattr(self, name)
+        if buf.device == dev:
+            return buf
+        cache = self.__dict__.setdefault("_host_mirrors", {})
+        key = (name, str(dev), buf.data_ptr(), buf._version)
+        if cache.get(name, (None,))[0] != key:
+            cache[name] = (key, buf.detach().to(dev))
+        return cache[name][1]
 
     # ---- render ------------------------------------------------------------------------------------------------------
     def _frames(self, ts):
@@ -279,6 +323,18 @@ class MPMeshVid(nn.Module):
         stack = self._frames(ts)
         homos = self.plane_homographies(extrin, intrin)
         smooth_sums = alpha_sums = None
+        spec = self.spec
+        if self._window_opt is not None:
+            if self.training and torch.is_grad_enabled() and stack is self.stack and not self.is_sparse:
+                # crop-aware training step: render from a compact, up-to-date copy of the texel window this view can reach
+                # (homographies on the host: a few hundred bytes; CPU inputs cost nothing, device inputs one small sync)
+                y0, x0, wh, ww = self.crop_window(homos.detach().cpu(), H, W)
+                if wh > 0 and ww > 0:
+                    stack = self._window_opt.window_leaf((y0, x0, wh, ww))
+                    spec = dataclasses.replace(spec, offset=(spec.offset[0] - x0, spec.offset[1] - y0))
+            else:
+                self._flush_deferred_updates()
+        homos = homos.to(self.stack.device)
         if self.atlas_exact:
             if need_smooth or self.is_sparse or tuple(stack.shape[2:4]) != (self.mpi_h, self.mpi_w):
                 raise RuntimeError("atlas_exact renders the dense full-resolution stack without the fused regularisers / tile culling / lod")
@@ -286,11 +342,11 @@ class MPMeshVid(nn.Module):
             rgb, alpha = render_atlas_exact(stack, homos, H, W, self.atlas_grid_h, pixel_center=self.spec.pixel_center,
                                             rgb_act=self.spec.rgb_act, alpha_act=self.spec.alpha_act)
         elif need_smooth:
-            rgb, alpha, smooth_sums, alpha_sums = render_planes_with_regularisers(stack, homos, H, W, self.spec,
+            rgb, alpha, smooth_sums, alpha_sums = render_planes_with_regularisers(stack, homos, H, W, spec,
                                                                                   quad_keep=self.quad_keep if self.is_sparse else None)
         else:
             # a sparsified model renders with tile culling: samples in culled quads are uncovered, workgroups skip planes without kept quads
-            rgb, alpha = render_planes(stack, homos, H, W, self.spec, quad_keep=self.quad_keep if self.is_sparse else None)
+            rgb, alpha = render_planes(stack, homos, H, W, spec, quad_keep=self.quad_keep if self.is_sparse else None)
         variables = {"pix_to_face": None, "blend_weight": None, "mpi": None, "disp_norm": None, "alpha": alpha,
                      "smooth_sums": smooth_sums, "alpha_sums": alpha_sums}
         if need_layers:
@@ -333,7 +389,7 @@ class MPMeshVid(nn.Module):
     # ---- forward -----------------------------------------------------------------------------------------------------
     def forward(self, h, w, tar_extrins, tar_intrins, ts=None, res=None, losscfg=None):
         """MPV.py:477-556.  train -> (None, {'swd': [1,1], ...}); eval -> (rgb [T',3,h,w], {})."""
-        extrins = tar_extrins @ self.ref_extrin[None, ...].inverse().to(tar_extrins.dtype)
+        extrins = tar_extrins @ self._on(tar_extrins.device, "ref_extrin")[None, ...].inverse().to(tar_extrins.dtype)
         if ts is None:
             ts = torch.arange(self.frm_num).long()
         a = self.args

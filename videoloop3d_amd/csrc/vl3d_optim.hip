@@ -1,0 +1,137 @@
+// Crop-aware Adam for the dense plane stack: the optimiser half of a stage-2 iteration (train_3dvid.py:263-290, MPV.py:199-214).
+//
+// A training iteration renders ONE crop (180 x 320 of 360 x 640, configs/mpv_base.txt:21-24): only the texels inside the crop's
+// parallax footprint -- about a quarter of every plane -- receive a gradient.  torch.optim.Adam still streams (p, g, m, v) over the
+// whole stack, because a texel with zero gradient keeps moving on its momentum: m <- b1 m, v <- b2 v, p <- p - lr_t m^/(sqrt(v^)+eps).
+// That tail is a pure function of (p, m, v) and the per-step scalars, so it can be applied LATER, exactly: every 16 x 16-texel tile
+// of every plane remembers the last step it is current for, and
+//   * adam_window_catchup_k (before the render) replays, in registers, the zero-gradient steps the tiles of the coming crop's
+//     window have missed -- the same fp32 operations in the same order as the dense update with g = 0 -- and hands the render a
+//     compact copy of the window (the render then writes a compact gradient: no zero fill of the other 3/4 either);
+//   * adam_window_step_k (after the backward) applies the current step to the window from the compact gradient;
+//   * a catch-up over the full stack brings everything current (checkpoints, lod(), evaluation renders).
+// Per-step scalars (lr / (1 - b1^t), sqrt(1 - b2^t)) come from a device table written by the host when the step is taken, so a
+// changing learning rate (train_3dvid.py:263-277) is replayed as it was.
+#include "vl3d_common.h"
+
+namespace {
+
+constexpr int TS = 16;      // tile side in texels (the bookkeeping granularity)
+
+__device__ __forceinline__ void adam_upd(float &pp, float gg, float &mm, float &vv, float lr_bc1, float beta1, float beta2, float eps, float bc2s) {
+    mm = beta1 * mm + (1.0f - beta1) * gg;           // exp_avg.lerp_(grad, 1 - beta1)
+    vv = beta2 * vv + (1.0f - beta2) * gg * gg;      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    pp -= lr_bc1 * (mm / (sqrtf(vv) / bc2s + eps));  // param.addcdiv_(exp_avg, sqrt(exp_avg_sq)/sqrt(bc2) + eps, value=-lr/bc1)
+}
+
+struct Win { int y0, x0, wh, ww; };
+
+// one thread per window texel and plane, looping over the frames.  `upto`: the step the window must be current for (the
+// step about to be taken minus one).  compact (optional): (D,T,wh,ww,4) copy of the window's parameters after the catch-up.
+__global__ __launch_bounds__(256) void adam_window_catchup_k(int T, int Hs, int Ws, Win w, float4 *__restrict__ p, float4 *__restrict__ m,
+                                                             float4 *__restrict__ v, const int *__restrict__ last_step, int tiles_y, int tiles_x,
+                                                             const float2 *__restrict__ hist, int upto, float beta1, float beta2, float eps,
+                                                             float4 *__restrict__ compact) {
+    const int lx = blockIdx.x * 64 + (threadIdx.x & 63), ly = blockIdx.y * 4 + (threadIdx.x >> 6), d = blockIdx.z;
+    if (lx >= w.ww || ly >= w.wh) return;
+    const int x = w.x0 + lx, y = w.y0 + ly;
+    const int from = last_step[((size_t)d * tiles_y + y / TS) * tiles_x + x / TS];
+    const size_t frame = (size_t)Hs * Ws, cframe = (size_t)w.wh * w.ww;
+    size_t o = (size_t)d * T * frame + (size_t)y * Ws + x, oc = (size_t)d * T * cframe + (size_t)ly * w.ww + lx;
+    if (from >= upto) {       // current already: copy only
+        if (compact)
+            for (int t = 0; t < T; ++t, o += frame, oc += cframe) compact[oc] = p[o];
+        return;
+    }
+    for (int t = 0; t < T; ++t, o += frame, oc += cframe) {
+        float4 pp = p[o], mm = m[o], vv = v[o];
+        for (int s = from + 1; s <= upto; ++s) {
+            const float2 h = hist[s];         // uniform: (lr / bc1, sqrt(bc2)) of step s
+            adam_upd(pp.x, 0.0f, mm.x, vv.x, h.x, beta1, beta2, eps, h.y);
+            adam_upd(pp.y, 0.0f, mm.y, vv.y, h.x, beta1, beta2, eps, h.y);
+            adam_upd(pp.z, 0.0f, mm.z, vv.z, h.x, beta1, beta2, eps, h.y);
+            adam_upd(pp.w, 0.0f, mm.w, vv.w, h.x, beta1, beta2, eps, h.y);
+        }
+        p[o] = pp; m[o] = mm; v[o] = vv;
+        if (compact) compact[oc] = pp;
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_window_step_k(int T, int Hs, int Ws, Win w, float4 *__restrict__ p, const float4 *__restrict__ g,
+                                                          float4 *__restrict__ m, float4 *__restrict__ v, float lr_bc1, float beta1, float beta2,
+                                                          float eps, float bc2s) {
+    const int lx = blockIdx.x * 64 + (threadIdx.x & 63), ly = blockIdx.y * 4 + (threadIdx.x >> 6), d = blockIdx.z;
+    if (lx >= w.ww || ly >= w.wh) return;
+    const size_t frame = (size_t)Hs * Ws, cframe = (size_t)w.wh * w.ww;
+    size_t o = (size_t)d * T * frame + (size_t)(w.y0 + ly) * Ws + (w.x0 + lx), oc = (size_t)d * T * cframe + (size_t)ly * w.ww + lx;
+    for (int t = 0; t < T; ++t, o += frame, oc += cframe) {
+        float4 pp = p[o], mm = m[o], vv = v[o];
+        const float4 gg = g[oc];
+        adam_upd(pp.x, gg.x, mm.x, vv.x, lr_bc1, beta1, beta2, eps, bc2s);
+        adam_upd(pp.y, gg.y, mm.y, vv.y, lr_bc1, beta1, beta2, eps, bc2s);
+        adam_upd(pp.z, gg.z, mm.z, vv.z, lr_bc1, beta1, beta2, eps, bc2s);
+        adam_upd(pp.w, gg.w, mm.w, vv.w, lr_bc1, beta1, beta2, eps, bc2s);
+        p[o] = pp; m[o] = mm; v[o] = vv;
+    }
+}
+
+__global__ __launch_bounds__(256) void mark_tiles_k(int *last_step, int tiles_y, int tiles_x, int ty0, int tx0, int nty, int ntx, int D, int step) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= D * nty * ntx) return;
+    const int tx = i % ntx, ty = (i / ntx) % nty, d = i / (ntx * nty);
+    last_step[((size_t)d * tiles_y + ty0 + ty) * tiles_x + tx0 + tx] = step;
+}
+
+int check_window(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww) {
+    VL3D_REQUIRE(D > 0 && D <= 65535 && T > 0 && Hs > 0 && Ws > 0, "adam window: bad dims");
+    VL3D_REQUIRE(y0 >= 0 && x0 >= 0 && wh > 0 && ww > 0 && y0 + wh <= Hs && x0 + ww <= Ws, "adam window: window outside the plane");
+    VL3D_REQUIRE(y0 % TS == 0 && x0 % TS == 0 && ((y0 + wh) % TS == 0 || y0 + wh == Hs) && ((x0 + ww) % TS == 0 || x0 + ww == Ws),
+                 "adam window: the window must be aligned to the 16-texel bookkeeping tiles (or end at the plane border)");
+    return VL3D_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t vl3d_adam_window_tile(void) { return TS; }
+
+extern "C" int vl3d_adam_window_catchup(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
+                                        float *param, float *exp_avg, float *exp_avg_sq, int32_t *last_step, const float *hist,
+                                        int32_t upto, float beta1, float beta2, float eps, float *compact, vl3d_stream_t stream) {
+    int rc = check_window(D, T, Hs, Ws, y0, x0, wh, ww);
+    if (rc != VL3D_OK) return rc;
+    VL3D_REQUIRE(param && exp_avg && exp_avg_sq && last_step && hist && upto >= 0, "vl3d_adam_window_catchup: null pointer / negative step");
+    const int tiles_y = (Hs + TS - 1) / TS, tiles_x = (Ws + TS - 1) / TS;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_window_catchup_k, dim3((ww + 63) / 64, (wh + 3) / 4, D), dim3(256), 0, s, T, Hs, Ws, Win{y0, x0, wh, ww},
+                       reinterpret_cast<float4 *>(param), reinterpret_cast<float4 *>(exp_avg), reinterpret_cast<float4 *>(exp_avg_sq), last_step,
+                       tiles_y, tiles_x, reinterpret_cast<const float2 *>(hist), upto, beta1, beta2, eps, reinterpret_cast<float4 *>(compact));
+    const int nty = (y0 + wh + TS - 1) / TS - y0 / TS, ntx = (x0 + ww + TS - 1) / TS - x0 / TS;
+    hipLaunchKernelGGL(mark_tiles_k, dim3((D * nty * ntx + 255) / 256), dim3(256), 0, s, last_step, tiles_y, tiles_x, y0 / TS, x0 / TS, nty, ntx, D, upto);
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
+extern "C" int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
+                                     float *param, const float *grad_compact, float *exp_avg, float *exp_avg_sq, int32_t *last_step,
+                                     float lr, float beta1, float beta2, float eps, int64_t step, vl3d_stream_t stream) {
+    int rc = check_window(D, T, Hs, Ws, y0, x0, wh, ww);
+    if (rc != VL3D_OK) return rc;
+    VL3D_REQUIRE(param && grad_compact && exp_avg && exp_avg_sq && last_step && step >= 1, "vl3d_adam_window_step: null pointer / bad step");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const int tiles_y = (Hs + TS - 1) / TS, tiles_x = (Ws + TS - 1) / TS;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_window_step_k, dim3((ww + 63) / 64, (wh + 3) / 4, D), dim3(256), 0, s, T, Hs, Ws, Win{y0, x0, wh, ww},
+                       reinterpret_cast<float4 *>(param), reinterpret_cast<const float4 *>(grad_compact), reinterpret_cast<float4 *>(exp_avg),
+                       reinterpret_cast<float4 *>(exp_avg_sq), (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2));
+    const int nty = (y0 + wh + TS - 1) / TS - y0 / TS, ntx = (x0 + ww + TS - 1) / TS - x0 / TS;
+    hipLaunchKernelGGL(mark_tiles_k, dim3((D * nty * ntx + 255) / 256), dim3(256), 0, s, last_step, tiles_y, tiles_x, y0 / TS, x0 / TS, nty, ntx, D, (int)step);
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
+// the per-step scalars of the table, computed exactly like vl3d_adam_window_step / vl3d_adam_step_tiles compute theirs
+extern "C" void vl3d_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, float *lr_bc1, float *bc2s) {
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    *lr_bc1 = (float)((double)lr / bc1);
+    *bc2s = (float)sqrt(bc2);
+}

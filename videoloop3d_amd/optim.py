@@ -1,0 +1,138 @@
+"""Crop-aware Adam for the dense plane stack (csrc/vl3d_optim.hip; the optimiser of train_3dvid.py:263-290 / MPV.py:199-214).
+
+`WindowAdam` produces the parameters torch.optim.Adam(betas, eps; no amsgrad / weight decay) would produce -- to fp32 rounding of
+the one-pass update -- while touching only the texels the current training crop can reach:
+
+  forward   `window_leaf(p, window)` brings the window's 16 x 16-texel tiles up to date (replaying, in registers, the zero-gradient
+            Adam steps they have missed: momentum keeps moving a texel after its gradient is gone) and returns a compact
+            (D,T,wh,ww,4) copy of the window as an autograd LEAF; the render reads it and the backward fills its .grad --
+            a compact gradient, no zero fill of the rest of the stack.
+  step()    applies the step to the window from that compact gradient; every other tile's update is deferred.
+  flush()   replays everything outstanding (before checkpoints, lod(), evaluation renders; MPMeshVid calls it).
+
+Without a pending window (someone filled `p.grad` densely) step() falls back to the dense update: flush + full-window step.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def align_window(y0, y1, x0, x1, Hs, Ws):
+    """[y0,y1) x [x0,x1) clamped to the plane and grown to the bookkeeping tiles -> (y0, x0, wh, ww)."""
+    ts = 16
+    y0, x0 = max(0, y0) // ts * ts, max(0, x0) // ts * ts
+    y1, x1 = min(Hs, -(-min(Hs, y1) // ts) * ts), min(Ws, -(-min(Ws, x1) // ts) * ts)
+    return y0, x0, max(y1 - y0, 0), max(x1 - x0, 0)
+
+
+class WindowAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        ps = [p for g in self.param_groups for p in g["params"]]
+        if len(ps) != 1:
+            raise RuntimeError("WindowAdam drives exactly one parameter: the plane stack (D,T,Hs,Ws,4)")
+        self.p = ps[0]
+        self.pending = None          # (window, compact leaf) of the forward since the last step
+        self.t = 0
+
+    # ---- state ----------------------------------------------------------------------------------------------------------
+    def _st(self):
+        p = self.p
+        L.check_cuda(p)
+        if p.dim() != 5 or p.shape[-1] != 4 or p.dtype != torch.float32 or not p.is_contiguous():
+            raise RuntimeError("WindowAdam: the parameter must be a contiguous float32 plane stack (D,T,Hs,Ws,4)")
+        st = self.state[p]
+        if not st:
+            D, T, Hs, Ws, _ = p.shape
+            st["exp_avg"] = torch.zeros_like(p)
+            st["exp_avg_sq"] = torch.zeros_like(p)
+            st["last_step"] = torch.zeros((D, (Hs + 15) // 16, (Ws + 15) // 16), dtype=torch.int32, device=p.device)
+            st["hist"] = torch.zeros((1024, 2), dtype=torch.float32, device=p.device)
+        return st
+
+    def _catchup(self, window, upto, compact):
+        st, p = self._st(), self.p
+        D, T, Hs, Ws, _ = p.shape
+        y0, x0, wh, ww = window
+        b1, b2 = self.param_groups[0]["betas"]
+        with torch.cuda.device(p.device):
+            L.check(L.lib().vl3d_adam_window_catchup(D, T, Hs, Ws, y0, x0, wh, ww, L.ptr(p), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
+                                                     L.ptr(st["last_step"]), L.ptr(st["hist"]), int(upto), float(b1), float(b2),
+                                                     float(self.param_groups[0]["eps"]), L.ptr(compact), L.stream_ptr(p.device)),
+                    "vl3d_adam_window_catchup")
+
+    # ---- forward side ---------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def window_leaf(self, window):
+        """window = (y0, x0, wh, ww), tile aligned (align_window) -> compact (D,T,wh,ww,4) leaf (requires_grad) holding the CURRENT
+        parameters of the window.  At most one window per step; a second forward before step() takes the dense path."""
+        p = self.p
+        D, T, Hs, Ws, _ = p.shape
+        y0, x0, wh, ww = window
+        compact = torch.empty((D, T, wh, ww, 4), dtype=p.dtype, device=p.device)
+        self._catchup(window, self.t, compact)
+        compact.requires_grad_(True)
+        if self.pending is not None:
+            self.pending = "multiple"
+        else:
+            self.pending = (window, compact)
+        return compact
+
+    @torch.no_grad()
+    def flush(self):
+        """make the whole stack current for the steps taken so far (exact replay of the deferred zero-gradient updates)."""
+        if self.t == 0 or not self.state.get(self.p):
+            return
+        D, T, Hs, Ws, _ = self.p.shape
+        self._catchup((0, 0, Hs, Ws), self.t, None)
+
+    def zero_grad(self, set_to_none=True):
+        super().zero_grad(set_to_none)
+        if self.pending is not None and self.pending != "multiple" and self.pending[1].grad is not None:
+            self.pending[1].grad = None
+
+    # ---- the step -------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        st, p = self._st(), self.p
+        grp = self.param_groups[0]
+        b1, b2 = grp["betas"]
+        lr, eps = float(grp["lr"]), float(grp["eps"])
+        pending, self.pending = self.pending, None
+        if pending == "multiple":
+            raise RuntimeError("WindowAdam: two windowed forwards before one step(); accumulate through the dense path (model.stack.grad) instead")
+        dense = pending is None
+        if dense and p.grad is None:
+            return loss                                   # nothing flowed: the step does not count (like torch.optim.Adam)
+        if not dense and pending[1].grad is None:
+            if p.grad is None:
+                return loss
+            dense = True                                   # the graph went around the window leaf
+        t = self.t + 1
+        if t >= st["hist"].shape[0]:
+            st["hist"] = torch.cat([st["hist"], torch.zeros_like(st["hist"])])
+        a, b = C.c_float(), C.c_float()
+        L.lib().vl3d_adam_step_scalars(lr, float(b1), float(b2), t, C.byref(a), C.byref(b))
+        st["hist"][t, 0].fill_(a.value)                   # scalars travel as kernel arguments: no host-to-device copy, no sync
+        st["hist"][t, 1].fill_(b.value)
+        D, T, Hs, Ws, _ = p.shape
+        if dense:
+            self._catchup((0, 0, Hs, Ws), self.t, None)
+            window, g = (0, 0, Hs, Ws), (p.grad if p.grad.is_contiguous() else p.grad.contiguous())
+        else:
+            window, g = pending[0], pending[1].grad
+            if p.grad is not None:
+                raise RuntimeError("WindowAdam: both the window leaf and the dense parameter received a gradient in one step")
+        y0, x0, wh, ww = window
+        with torch.cuda.device(p.device):
+            L.check(L.lib().vl3d_adam_window_step(D, T, Hs, Ws, y0, x0, wh, ww, L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
+                                                  L.ptr(st["last_step"]), lr, float(b1), float(b2), eps, t, L.stream_ptr(p.device)),
+                    "vl3d_adam_window_step")
+        self.t = t
+        return loss
