@@ -111,6 +111,37 @@ def loss_bench(dev, H, W, T, Ty, steps):
                 (gx,) = torch.autograd.grad(loss, x)
             torch.cuda.synchronize()
         out[name] = {"iters_per_s": steps / (time.perf_counter() - t0), "loss": float(loss.detach())}
+        # roofline of the NN search (K3, the dominant kernel of the loss): HIP events around the search alone
+        from videoloop3d_amd.utils_vid import find_nn_indices, fit_patch
+        ps, st_, pt = cfg["patch_size"], cfg["stride"], cfg["patcht_size"]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            h_, w_ = fit_patch(H, "h", ps, st_), fit_patch(W, "w", ps, st_)
+        xs, ys = x.detach()[..., :h_, :w_], y[..., :h_, :w_]
+        al = None if cfg["alpha"] > 100 else cfg["alpha"]
+        find_nn_indices(xs, ys, ps, pt, st_, 1, al)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            find_nn_indices(xs, ys, ps, pt, st_, 1, al)
+        e1.record()
+        torch.cuda.synchronize()
+        nn_ms = e0.elapsed_time(e1) / 3
+        B = ((h_ - ps) // st_ + 1) * ((w_ - ps) // st_ + 1)
+        n1, n2, d = T + 2 - pt + 1, Ty - pt + 1, 3 * pt * ps * ps
+        ref_flops = 2.0 * B * n1 * n2 * d                                    # as the reference performs them (utils_vid.py:82)
+        # what the kernel performs: per 4 locations the frame-pair energies of a ps x (ps + 3 stride) region, (sub, fma) = 3 flop per
+        # (column, channel, frame pair): the temporal diagonal sum makes the patch distance out of them
+        TxP, TyP = -(-(T + 2) // 4) * 4, -(-Ty // 4) * 4
+        own_flops = 3.0 * (B / 4) * ps * (ps + 3 * st_) * 3 * TxP * TyP
+        VALU_PEAK = 256 * 4 * 16 * 2 * 2.4e9 / 1e12                           # fp32 FMA, one per lane and clock: 78.6 TFLOP/s
+        out[name]["roofline_nn"] = {"kernel": "patchnn4_k (+ video_to_pixel_major_k x2)", "bound": "valu-fp32", "avg_ms": nn_ms,
+                                    "flops_as_reference": ref_flops, "achieved_as_reference": ref_flops / (nn_ms * 1e-3) / 1e12,
+                                    "flops_performed": own_flops, "achieved": own_flops / (nn_ms * 1e-3) / 1e12, "peak": VALU_PEAK,
+                                    "unit": "TFLOP/s", "frac": own_flops / (nn_ms * 1e-3) / 1e12 / VALU_PEAK,
+                                    "separable_lower_bound_flops": 2.0 * 3 * (T + 2) * Ty * H * W}
+    # compulsory bytes of one loss iteration: read x and y, write y2x / weight / grad, x again for the residual
+    out["compulsory_bytes"] = 4.0 * H * W * (3 * (T + 2) * 4 + 3 * Ty + (T + 2))
     out["shape"] = f"x[1,3,{T + 2},{H},{W}] y[1,3,{Ty},{H},{W}]"
     return out
 
@@ -386,6 +417,46 @@ def main():
                                        "workload": "cfg3 render fwd+bwd on a tile-culled stack (one blob of kept quads per plane): plain = without the quad map, culled = with it"}
             except Exception as e:
                 res["tile_culling"] = {"error": repr(e)}
+            try:    # the geometry a shipped stage-2 iteration renders (configs/mpv_base.txt:10-11,33-34): stack stored at 1.1x the frame,
+                    # rgb_smooth / a_smooth on -> forward = render + regulariser sums, backward = frame-pair kernel WITH the regularisers
+                stack = None
+                torch.cuda.empty_cache()
+                from videoloop3d_amd.render import render_planes_with_smoothness
+                Hs2, Ws2 = int(H * 1.1), int(W * 1.1)
+                shift = torch.tensor([[1.0, 0, (Ws2 - W) // 2], [0, 1.0, (Hs2 - H) // 2], [0, 0, 1.0]])          # MPV.py:55-56
+                h2 = (shift @ homos).to(dev)
+                st2 = synth.make_plane_stack(D, T, Hs2, Ws2, seed=2, device=dev).requires_grad_(True)
+                tf, tb = [], []
+                for it in range(7):
+                    q0, q1, q2 = ev(), ev(), ev()
+                    q0.record()
+                    r2, _, sums2 = render_planes_with_smoothness(st2, h2, H, W, spec)
+                    obj = (r2 * g_rgb).sum() + 1e-6 * sums2.sum()
+                    q1.record()
+                    (gs2,) = torch.autograd.grad(obj, st2)
+                    q2.record()
+                    torch.cuda.synchronize()
+                    if it >= 2:
+                        tf.append(q0.elapsed_time(q1)); tb.append(q1.elapsed_time(q2))
+                    del gs2, r2, sums2, obj
+                f2, b2 = sum(tf) / len(tf), sum(tb) / len(tb)
+                px = T * H * W
+                tex = T * Hs2 * Ws2
+                res["reference_geometry"] = {
+                    "workload": f"cfg3 frames from a {Hs2}x{Ws2} stack (mpi_h/w_scale 1.1) with the smoothness regularisers on: D={D}, T={T}",
+                    "value": px / ((f2 + b2) * 1e-3) / 1e6, "unit": "Mpix/s", "fwd_ms": f2, "bwd_ms": b2,
+                    "roofline_bwd": {"kernel": "render_bwd_pair_reg_k (+ pre-pass)", "bound": "hbm", "avg_ms": b2,
+                                     "achieved": px * (32 * D + 12) / (b2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": px * (32 * D + 12) / (b2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "algorithmic_bytes": px * (32 * D + 12),
+                                     "texel_footprint_bytes": tex * 32 * D + px * 12,      # every texel of the 1.1x stack is read and its gradient written
+                                     "frac_texel_footprint": (tex * 32 * D + px * 12) / (b2 * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                    "roofline_fwd": {"kernel": "render_fwd2x_k + render_reg_fwd_k", "bound": "hbm", "avg_ms": f2,
+                                     "achieved": px * (16 * D + 12) / (f2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": px * (16 * D + 12) / (f2 * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                del st2
+            except Exception as e:
+                res["reference_geometry"] = {"error": repr(e)}
             try:    # end-to-end stage-2 iterations on the drop-in module (render crop + looping loss + fused regularisers + Adam)
                 stack = None
                 torch.cuda.empty_cache()

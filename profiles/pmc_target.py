@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Profile target for the rocprofv3 passes of profiles/run_profiles_r02.sh: two iterations each of
+  (1) cfg3 render fwd+bwd at 1.0x (render_fwd2x_k, render_bwd_pair_k),
+  (2) the reference geometry: 1.1x stack + smoothness regularisers (render_reg_fwd_k, render_bwd_pair_reg_k),
+  (3) the looping loss at 720p, both shipped configurations (patchnn4_k, vote_fold_lds_k, video_to_pixel_major_k).
+Usage: python profiles/pmc_target.py [T=50]"""
+import os
+import sys
+import warnings
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+import __graft_entry__ as ge  # noqa: E402
+ge.build()
+from videoloop3d_amd import synth  # noqa: E402
+from videoloop3d_amd.render import RenderSpec, render_planes, render_planes_with_smoothness  # noqa: E402
+from videoloop3d_amd.utils_mpi import compute_homography, make_depths  # noqa: E402
+from videoloop3d_amd.utils_vid import Patch3DGPNNLowMemLoss  # noqa: E402
+
+dev = torch.device("cuda:0")
+D, H, W = 32, 720, 1280
+ref_e, Kr, tar_e, Kt = synth.make_cameras(H, W)
+homos = compute_homography(ref_e[None], Kr[None], tar_e[None], Kt[None], torch.tensor([0., 0., 1.]).expand(1, D, 3),
+                           make_depths(D, 1.0, 100.0).flip(0)[None])[0]
+g = synth.hash_uniform((T, H, W, 3), seed=5, device=dev) - 0.5
+spec = RenderSpec.mpv()
+# (1)
+stack = synth.make_plane_stack(D, T, H, W, seed=2, device=dev).requires_grad_(True)
+for _ in range(2):
+    rgb, _ = render_planes(stack, homos.to(dev), H, W, spec)
+    (gs,) = torch.autograd.grad(rgb, stack, g)
+    del gs, rgb
+del stack
+torch.cuda.empty_cache()
+# (2)
+Hs, Ws = int(H * 1.1), int(W * 1.1)
+shift = torch.tensor([[1.0, 0, (Ws - W) // 2], [0, 1.0, (Hs - H) // 2], [0, 0, 1.0]])
+stack = synth.make_plane_stack(D, T, Hs, Ws, seed=2, device=dev).requires_grad_(True)
+for _ in range(2):
+    rgb, _, sums = render_planes_with_smoothness(stack, (shift @ homos).to(dev), H, W, spec)
+    (gs,) = torch.autograd.grad((rgb * g).sum() + 1e-6 * sums.sum(), stack)
+    del gs, rgb, sums
+del stack
+torch.cuda.empty_cache()
+# (3)
+x = synth.make_video(T + 2, H, W, seed=3, device=dev).requires_grad_(True)
+y = synth.make_video(75, H, W, seed=4, device=dev)
+cfgs = [dict(macro_block=65, patch_size=11, stride=4, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=0.5),
+        dict(macro_block=65, patch_size=3, stride=2, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=10000)]
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    for cfg in cfgs:
+        for _ in range(2):
+            loss = Patch3DGPNNLowMemLoss()(x, y, **cfg)
+            (gx,) = torch.autograd.grad(loss, x)
+torch.cuda.synchronize()
+print("pmc target done")

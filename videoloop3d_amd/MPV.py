@@ -12,7 +12,8 @@ geometry -- which is all the shipped configs ever produce (vertices get no gradi
   * init_from_mpi takes the state_dict of videoloop3d_amd.MPI.MPMesh / MPMeshVid (dense stack + culled/static/dynamic quad
     maps, videoloop3d_amd/tiles.py) AND the reference's own checkpoints (plane meshes + packed atlases: their tiles are
     resampled onto the dense stack, tiles.stack_from_reference_state); static quads stay one shared texture because their
-    gradient is summed over the frames.  save_mesh / save_texture are not provided.
+    gradient is summed over the frames.  reference_state_dict / save_mesh / save_texture export back to the reference's layout
+    (videoloop3d_amd/export.py).
 """
 import dataclasses
 
@@ -250,6 +251,23 @@ class MPMeshVid(nn.Module):
         ty = q[:, 1] / q[:, 2] * self.spec.scale[1] + self.spec.offset[1]
         return align_window(int(torch.floor(ty.min())) - margin, int(torch.ceil(ty.max())) + 2 + margin,
                             int(torch.floor(tx.min())) - margin, int(torch.ceil(tx.max())) + 2 + margin, Hs, Ws)
+
+    # ---- export to the reference's layout (MPV.py:290-341) ------------------------------------------------------------------
+    def reference_state_dict(self):
+        """the state_dict of the REFERENCE's MPMeshVid for these weights: plane meshes + packed static / dynamic atlases."""
+        self._flush_deferred_updates()
+        from .export import reference_state_dict
+        return reference_state_dict(self)
+
+    def save_mesh(self, prefix):
+        """MPV.py:306-323."""
+        from .export import save_mesh
+        return save_mesh(self, prefix, self.reference_state_dict())
+
+    def save_texture(self, prefix):
+        """MPV.py:325-341 (dynamic frames as PNG files: no imageio / ffmpeg here)."""
+        from .export import save_texture
+        return save_texture(self, prefix, self.reference_state_dict())
 
     def get_lrate(self, step):
         """MPV.py:216-225."""
