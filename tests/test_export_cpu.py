@@ -31,10 +31,18 @@ def _sparse_model(H=41, W=61):
     keep = torch.rand(3, 4, 6) < 0.6
     keep[1] = False
     dyn = keep & (torch.rand(3, 4, 6) < 0.5)
+    def closed(mask):                                   # closed plane-pixel rectangles of the quads of a map
+        out = torch.zeros((3, H, W), dtype=torch.bool)
+        for d, qy, qx in mask.nonzero().tolist():
+            out[d, qy * 10:qy * 10 + 11, qx * 10:qx * 10 + 11] = True
+        return out
     with torch.no_grad():
         m.stack.uniform_(-2.0, 2.0)
-        static_t = (tiles.quad_to_texel_mask(keep, H, W) & ~tiles.quad_to_texel_mask(dyn, H, W))[:, None, :, :, None]
-        m.stack.data = torch.where(static_t, m.stack.data[:, :1], m.stack.data)          # static texels: one texture over the frames
+        # the reference's layout is per QUAD: a static quad's tile is one texture for all frames, a texel on the border line it
+        # shares with a dynamic quad lives in both tiles.  (The dense model classifies per TEXEL and leaves one more texel row next
+        # to a dynamic quad free per frame, tiles.tie_static_grad; an export keeps frame 0 of those.)
+        static_t = (closed(keep & ~dyn) & ~closed(dyn))[:, None, :, :, None]
+        m.stack.data = torch.where(static_t, m.stack.data[:, :1], m.stack.data)
         tiles.cull_stack_(m.stack.data, keep)
     m.register_buffer("quad_keep", keep)
     m.register_buffer("quad_dyn", dyn)
@@ -65,14 +73,15 @@ def test_export_then_read_roundtrip():
     for d, qy, qx in keep.nonzero().tolist():
         closed[d, qy * 10:qy * 10 + 11, qx * 10:qx * 10 + 11] = True
     sel = closed[:, None].expand(3, 3, 41, 61)
-    assert float((b.stack.detach()[sel] - m.stack.detach()[sel]).abs().max()) <= 1e-4      # two fp32 grid_sample passes on values in [-2, 2]
+    assert float((b.stack.detach()[sel] - m.stack.detach()[sel]).abs().max()) <= 3e-4      # two fp32 grid_sample passes; a culled neighbour (logit clamped to -30) bleeds ~4e-6 * 30
     assert bool((b.stack.detach()[..., 3][~inside[:, None].expand(3, 3, 41, 61)] == tiles.CULLED_ALPHA).all())
 
 
 def test_packer_agrees_with_the_restated_reference_packing():
     m, keep, dyn = _sparse_model()
     sd = m.reference_state_dict()
-    ref = CO.pack_reference_state(m.stack.detach(), keep, dyn, 5, 7, m.planedepth)
+    src = torch.cat([m.stack.detach()[..., :3], m.stack.detach()[..., 3:].clamp_min(-30.0)], -1)     # what the export samples (see export.py)
+    ref = CO.pack_reference_state(src, keep, dyn, 5, 7, m.planedepth)
     for k in ("faces", "faces_dyn"):
         assert torch.equal(sd[k], ref[k])
     # tile contents per quad (the two packers may choose different atlas grids): read both back onto a stack

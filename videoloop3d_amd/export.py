@@ -84,6 +84,11 @@ def reference_state_dict(model, tile_texels=None):
     """model: videoloop3d_amd MPMeshVid / MPMesh (dense or sparsified).  tile_texels=(ih, iw) overrides the tile size (default:
     one sample per texel of the quad, round(quad extent) + 1, the choice oracle/ckpt_oracle.py pins the reader with)."""
     stack = model.stack.detach()
+    if bool(getattr(model, "is_sparse", False)):
+        # texels no kept quad can read hold the alpha logit CULLED_ALPHA (-1e4, tiles.py); a tile's border samples sit exactly on
+        # texel centres, but their fp32 coordinates carry ~1e-6 texels of rounding, which would pull 1e-6 * (-1e4) of a culled
+        # neighbour into an exported kept texel.  -30 is as transparent (sigmoid = 1e-13) and bleeds nothing.
+        stack = torch.cat([stack[..., :3], stack[..., 3:].clamp_min(-30.0)], dim=-1)
     D, T, H, W, _ = stack.shape
     hv, wv = int(model.args.mpi_h_verts), int(model.args.mpi_w_verts)
     QH, QW = hv - 1, wv - 1
