@@ -159,6 +159,10 @@ void vl3d_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, fl
  * grad_reg = device float[4] = dL/dsums (NULL: no regulariser term). */
 int vl3d_render_reg_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos, double *sums,
                         vl3d_stream_t stream);
+/* vl3d_render_fwd and vl3d_render_reg_fwd in ONE pass over the stack (dense stacks): what MPMeshVid.forward needs per training step
+ * when rgb_smooth / a_smooth are on (configs/mpv_base.txt:33-34).  rgb / alpha / alpha_sums bit-identical to vl3d_render_fwd. */
+int vl3d_render_fwd_reg(const vl3d_render_desc *desc, const void *stack, const float *homos, float *rgb, float *alpha,
+                        float *alpha_sums, double *sums, vl3d_stream_t stream);
 int vl3d_render_reg_fwd_culled(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep,
                                int32_t QH, int32_t QW, double *sums, vl3d_stream_t stream);
 

@@ -805,3 +805,23 @@ def test_bwd_pair_reg_kernel_vs_oracle_and_tile_kernel(dev, T, stack_scale, dtyp
     assert float((err > tol).float().mean()) <= 2e-4
     assert float(err.max()) <= 8 * float(wts.max()) + tol
     assert torch.equal(out[0], out[3])
+
+
+@pytest.mark.parametrize("spec_name", ["mpv", "utils_mpi"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", [(5, 3, 150, 260, 139, 251), (3, 1, 40, 70, 9, 130), (4, 2, 64, 64, 63, 64)])
+def test_fused_forward_with_regularisers_equals_the_two_pass_forward(dev, spec_name, dtype, shape):
+    """vl3d_render_fwd_reg (render + smoothness sums in ONE sweep over the stack) against vl3d_render_fwd followed by
+    vl3d_render_reg_fwd (variant 0x1000): image, alpha and alpha sums bit for bit, the four sums to double-summation order."""
+    from videoloop3d_amd.render import RenderSpec, render_planes_with_regularisers
+    D, T, Hs, Ws, H, W = shape
+    kw_p, _ = SPECS[spec_name]
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=29, device=dev, dtype=dtype)
+    homos = (torch.diag(torch.tensor([Ws / W, Hs / H, 1.0])) @ bench_homos(D, H, W, scale=1.5)).to(dev)
+    out = {}
+    for variant in (0, 0x1000):
+        out[variant] = render_planes_with_regularisers(stack, homos, H, W, RenderSpec(variant=variant, **kw_p))
+    for k in (0, 1, 3):
+        assert torch.equal(out[0][k], out[0x1000][k]), k
+    assert float(((out[0][2] - out[0x1000][2]).abs() / out[0x1000][2].abs().clamp_min(1.0)).max()) <= 1e-6
+    assert float(out[0][2].abs().min()) > 0

@@ -59,6 +59,7 @@ SIGNATURES = {
     "vl3d_render_fwd_culled": ([C.POINTER(RenderDesc), _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P], C.c_int),
     "vl3d_render_bwd_culled": ([C.POINTER(RenderDesc), _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
     "vl3d_render_reg_fwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P], C.c_int),
+    "vl3d_render_fwd_reg": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "vl3d_warp_fwd": ([_I32] * 6 + [_P, _P, _P, _P], C.c_int),
     "vl3d_warp_bwd": ([_I32] * 6 + [_P, _P, _P, _P], C.c_int),
     "vl3d_overcompose_fwd": ([_I64, _I32, _I32, _P, _P, _P, _P, _P], C.c_int),

@@ -123,6 +123,23 @@ extern "C" int64_t vl3d_render_bwd_scratch_bytes(const vl3d_render_desc *desc) {
 static int render_reg_fwd_impl(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep, int32_t QH,
                                int32_t QW, double *sums, vl3d_stream_t stream);
 
+extern "C" int vl3d_render_fwd_reg(const vl3d_render_desc *desc, const void *stack, const float *homos, float *rgb, float *alpha,
+                                   float *alpha_sums, double *sums, vl3d_stream_t stream) {
+    int rc = check_desc(desc);
+    if (rc != VL3D_OK) return rc;
+    VL3D_REQUIRE(stack && homos && rgb && alpha && sums, "null pointer passed to vl3d_render_fwd_reg");
+    VL3D_REQUIRE((int64_t)desc->Hs * desc->Ws * 16 < (1ll << 32), "frame too large for 32-bit byte offsets");
+    RenderArgs a = make_args(desc);
+    a.stack = (const float *)stack; a.homos = homos; a.rgb = rgb; a.alpha = alpha; a.asum = alpha_sums; a.reg_sums = sums;
+    a.g_f16 = desc->stack_dtype == VL3D_F16;
+    a.reg_fwd = 2;
+    VL3D_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(double), (hipStream_t)stream));
+    rc = dispatch(false, desc, a, (hipStream_t)stream);
+    if (rc != VL3D_OK) return rc;
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
 extern "C" int vl3d_render_reg_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos, double *sums,
                                    vl3d_stream_t stream) {
     return render_reg_fwd_impl(desc, stack, homos, nullptr, 0, 0, sums, stream);

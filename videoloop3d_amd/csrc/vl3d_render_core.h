@@ -64,7 +64,7 @@ struct RenderArgs {
     // dispatch options (plain arguments: the ABI is re-entrant from any number of host threads / streams)
     int tile_rows;           // backward: 0 = no owner-computes path for this call (atomics kernel only); 16 = tile kernel; 17 = 16 rows,
                              // frame-pair kernels allowed
-    int reg_fwd;             // forward dispatch launches the regulariser-sums kernel instead of the render
+    int reg_fwd;             // forward dispatch: 1 = the regulariser-sums kernel instead of the render, 2 = render AND sums in one pass
 };
 
 // one entry point per compiled convention (coord_mode, border_mode, act_order): vl3d_render_c*.hip
@@ -1234,6 +1234,10 @@ template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
 __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_reg_k(RenderArgs a) {
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
     constexpr int RH = 2;
+    // the derivative of every activation but |.| is a function of the activated value alone (sigmoid: o(1-o); relu / clamp: o > 0,
+    // 0 < o < 1 say the same as v > 0, 0 < v < 1), so the pre-activation samples need not cross the barrier: 8 VGPRs, which is what
+    // stands between this kernel and its 128-register budget
+    constexpr bool NEED_PRE = RACT == VL3D_ACT_ABS || AACT == VL3D_ACT_ABS;
     __shared__ float4 s_o[2][2][PNT];   // [buffer][frame][pixel]: activated layer values, 0 in ALL channels where the plane does not cover (MPV.py:441)
     __shared__ float4 s_g[2][2][PNT];
     __shared__ float2 s_t[2][PNT];
@@ -1290,6 +1294,7 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_reg_k(RenderArgs a) {
         load_taps2<F16>(plane0 + f1, tp, st, tv1);
         o0 = shade2<ORDER, RACT, AACT>(tp, tv0, &pre0);
         o1 = shade2<ORDER, RACT, AACT>(tp, tv1, &pre1);
+        if constexpr (!NEED_PRE) { pre0 = o0; pre1 = o1; }
         ctx = tp.tx; cty = tp.ty; ccov = tp.cov;
     }
     {
@@ -1346,6 +1351,7 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_reg_k(RenderArgs a) {
         if (inimg) {
             o0 = shade2<ORDER, RACT, AACT>(tpn, tn0, &pre0);
             o1 = shade2<ORDER, RACT, AACT>(tpn, tn1, &pre1);
+            if constexpr (!NEED_PRE) { pre0 = o0; pre1 = o1; }
             ctx = tpn.tx; cty = tpn.ty; ccov = tpn.cov;
         }
         {
@@ -1460,6 +1466,102 @@ __global__ __launch_bounds__(RW *ROWS) void render_reg_fwd_k(RenderArgs a) {
     }
 }
 
+// =====================================================================================================
+// Forward WITH the layer regularisers in one pass: the render (rgb, alpha, alpha sums) and the four smoothness sums
+// (MPV.py:517-531) from ONE sweep over the stack.  render_fwd2(x)_k + render_reg_fwd_k read every texel twice (5.1 + 7.1 ms at
+// cfg3 for what a shipped stage-2 iteration calls once per step); here a workgroup is a 64 x 8-pixel region whose last column and
+// row are halo (63 x 7 pixels owned: their outputs and the |o - o_right|, |o - o_down| pairs), each plane's activated layer values
+// go through a double-buffered LDS tile (one barrier per plane), and the taps of plane d+1 are in flight across that barrier (two
+// register sets, as in render_fwd2_k).  Per pixel the composite is render_fwd2_k's, instruction for instruction (same bits).
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
+__global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_x, int tiles_y) {
+    constexpr int FW = 64, FH = 8, NT = FW * FH;
+    __shared__ float4 s_o[2][NT];
+    __shared__ float red[4][FH];
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_x = b % tiles_x, rest = b / tiles_x;
+    const int tile_y = rest % tiles_y, t = rest / tiles_y;
+    const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
+    const int x = tile_x * (FW - 1) + lane, y = tile_y * (FH - 1) + row;
+    const bool inimg = (x < a.W) && (y < a.H);
+    const bool owner = inimg && lane < FW - 1 && row < FH - 1;        // the last column / row are owned by the next tile (its column / row 0)
+    const bool own_r = owner && x + 1 < a.W, own_d = owner && y + 1 < a.H;
+    // pixels outside the frame sample the frame's last pixel (valid addresses, results dropped): no branch around the loads
+    const float px = (float)(a.col0 + min(x, a.W - 1)) + a.pc, py = (float)(a.row0 + min(y, a.H - 1)) + a.pc;
+    const size_t frame_b = (size_t)a.Hs * a.Ws * (F16 ? 8 : 16), plane_stride_b = (size_t)a.T * frame_b;
+    const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * frame_b;
+    float Tr = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, A = 0.f, n1 = 0.f, n2 = 0.f;
+    float sxc = 0.f, syc = 0.f, sxa = 0.f, sya = 0.f;
+    const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
+    typedef typename TapVal<F16, ORDER>::type tapv_t;
+    tapv_t vA[4], vB[4];
+#define VL3D_PLANE(T_, V_, BUF_)                                                                          \
+    {                                                                                                     \
+        const f4 o = shade2<ORDER, RACT, AACT>(T_, V_);                                                   \
+        const f4 ol = inimg ? o * T_.cov : f4{0.f, 0.f, 0.f, 0.f};                                        \
+        s_o[BUF_][tid] = make_float4(ol.x, ol.y, ol.z, ol.w);                                             \
+        const float w = o.w * Tr;                                                                         \
+        cr += w * o.x; cg += w * o.y; cb += w * o.z; A += w;                                              \
+        n1 += o.w; n2 = fmaf(o.w, o.w, n2);                                                               \
+        Tr *= (1.0f - o.w);                                                                               \
+        __syncthreads();                                                                                  \
+        if (own_r) {                                                                                      \
+            const float4 r = s_o[BUF_][tid + 1];                                                          \
+            sxc += fabsf(ol.x - r.x) + fabsf(ol.y - r.y) + fabsf(ol.z - r.z);                             \
+            sxa += fabsf(ol.w - r.w);                                                                     \
+        }                                                                                                 \
+        if (own_d) {                                                                                      \
+            const float4 r = s_o[BUF_][tid + FW];                                                         \
+            syc += fabsf(ol.x - r.x) + fabsf(ol.y - r.y) + fabsf(ol.z - r.z);                             \
+            sya += fabsf(ol.w - r.w);                                                                     \
+        }                                                                                                 \
+    }
+    Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy), tB = tA;
+    load_taps2<F16>(plane, tA, st, vA);
+    for (int d = 0;; d += 2) {
+        {
+            const int dn = min(d + 1, a.D - 1);
+            float h[VL3D_HN];
+            load_uniform(a.homos + VL3D_HS * dn, h);
+            tB = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            load_taps2<F16>(plane + (size_t)dn * plane_stride_b, tB, st, vB);
+            asm volatile("" ::: "memory");
+        }
+        VL3D_PLANE(tA, vA, 0)
+        if (d + 1 >= a.D) break;
+        {
+            const int dn = min(d + 2, a.D - 1);
+            float h[VL3D_HN];
+            load_uniform(a.homos + VL3D_HS * dn, h);
+            tA = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            load_taps2<F16>(plane + (size_t)dn * plane_stride_b, tA, st, vA);
+            asm volatile("" ::: "memory");
+        }
+        VL3D_PLANE(tB, vB, 1)
+        if (d + 2 >= a.D) break;
+    }
+#undef VL3D_PLANE
+    if (owner) {
+        const size_t pix = ((size_t)t * a.H + y) * a.W + x;
+        a.rgb[pix * 3 + 0] = cr; a.rgb[pix * 3 + 1] = cg; a.rgb[pix * 3 + 2] = cb;
+        a.alpha[pix] = A;
+        if (a.asum) { a.asum[pix * 2 + 0] = n1; a.asum[pix * 2 + 1] = n2; }
+    }
+    float v[4] = {sxc, syc, sxa, sya};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+        if (lane == 0) red[k][row] = v[k];
+    }
+    __syncthreads();
+    if (tid < 4) {
+        double sum = 0.0;
+        for (int r = 0; r < FH; ++r) sum += (double)red[tid][r];
+        atomicAdd(a.reg_sums + tid, sum);
+    }
+}
+
 // ---- launch templates ---------------------------------------------------------------------------------------------
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16 = false>
 void launch_tile(const RenderArgs &a, hipStream_t s) {
@@ -1502,11 +1604,12 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
                 }
                 // with the layer regularisers the pipelined pair kernel wins at every stack size (one barrier per plane and two
                 // resident workgroups against two barriers on one); sample-then-activate conventions only (activate-then-sample keeps
-                // 8 activated taps per frame live and would spill at the 128-VGPR budget: the tile kernel stays in charge there)
-                if (!done && ORDER == VL3D_ACT_POST && a.tile_rows == 17 && a.T >= 2 && (a.g_reg || a.g_asum) && !a.quad_keep) {
+                // 8 activated taps per frame live and would spill at the 128-VGPR budget, as do the 13-float plane records of the per-plane
+                // convention: the tile kernel stays in charge there)
+                if (!done && ORDER == VL3D_ACT_POST && VL3D_HN == 9 && a.tile_rows == 17 && a.T >= 2 && (a.g_reg || a.g_asum) && !a.quad_keep) {
                     RenderArgs ar = a;
                     if (!ar.g_reg) ar.g_reg = a.plan + 4;      // zeros written by bwd_plan_k
-                    if constexpr (ORDER == VL3D_ACT_POST) launch_pair<COORD, BORDER, ORDER, RACT, AACT, F16, true>(ar, s);
+                    if constexpr (ORDER == VL3D_ACT_POST && VL3D_HN == 9) launch_pair<COORD, BORDER, ORDER, RACT, AACT, F16, true>(ar, s);
                     done = true;
                 }
             }
@@ -1522,6 +1625,11 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
         }
         hipLaunchKernelGGL((render_bwd_k<COORD, BORDER, ORDER, RACT, AACT, F16>), grid, block, 0, s, a);
     } else {
+        if (a.reg_fwd == 2) {       // render + regulariser sums in one pass (dense stacks)
+            const int tx = (a.W + 62) / 63, ty = (a.H + 6) / 7;
+            hipLaunchKernelGGL((render_fwd_reg_k<COORD, BORDER, ORDER, RACT, AACT, F16>), dim3((unsigned)(tx * ty * a.T)), dim3(512), 0, s, a, tx, ty);
+            return;
+        }
         if (a.reg_fwd) {
             dim3 rgrid((a.W + RW - 2) / (RW - 1), (a.H + 14) / 15, a.T);
             hipLaunchKernelGGL((render_reg_fwd_k<COORD, BORDER, ORDER, RACT, AACT, 16, F16>), rgrid, dim3(RW * 16), 0, s, a);

@@ -89,8 +89,14 @@ class _RenderPlanes(torch.autograd.Function):
                     z((T, H, W, 2) if with_reg else (0,), dtype=torch.float32, device=stack.device))
         desc = _desc(stack, H, W, spec, row0, col0)
         asum = torch.empty((T, H, W, 2), dtype=torch.float32, device=stack.device) if with_reg else None
+        sums = torch.zeros(4, dtype=torch.float64, device=stack.device)
+        # variant bits 12-15: 1 = keep the two-pass forward with regularisers (render, then the sums kernel) for A/B and cross-checks
+        fused_reg = with_reg and quad_keep is None and ((int(spec.variant) >> 12) & 0xf) != 1
         with torch.cuda.device(stack.device):
-            if quad_keep is None:
+            if fused_reg:         # render + smoothness sums in ONE sweep over the stack
+                L.check(L.lib().vl3d_render_fwd_reg(desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.ptr(asum), L.ptr(sums),
+                                                    L.stream_ptr(stack.device)), "vl3d_render_fwd_reg")
+            elif quad_keep is None:
                 L.check(L.lib().vl3d_render_fwd(desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.ptr(asum),
                                                 L.stream_ptr(stack.device)), "vl3d_render_fwd")
             else:
@@ -103,8 +109,7 @@ class _RenderPlanes(torch.autograd.Function):
         ctx.quad_keep = quad_keep
         ctx.desc = desc
         ctx.with_reg = with_reg
-        sums = torch.zeros(4, dtype=torch.float64, device=stack.device)
-        if with_reg:
+        if with_reg and not fused_reg:
             with torch.cuda.device(stack.device):
                 if quad_keep is None:
                     L.check(L.lib().vl3d_render_reg_fwd(desc, L.ptr(stack), L.ptr(homos), L.ptr(sums), L.stream_ptr(stack.device)),
