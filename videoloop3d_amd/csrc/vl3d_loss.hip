@@ -931,7 +931,7 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
             if (!attr4) {
 #define VL3D_ATTR4(R, N) VL3D_HIP(hipFuncSetAttribute((const void *)patchnn4_k<R, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
                 VL3D_ATTR4(true, 256); VL3D_ATTR4(false, 256); VL3D_ATTR4(true, 512); VL3D_ATTR4(false, 512);
-                VL3D_ATTR4(true, 1024); VL3D_ATTR4(false, 1024);
+                VL3D_ATTR4(false, 1024);
 #undef VL3D_ATTR4
                 attr4 = true;
             }
@@ -944,7 +944,7 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
 #define VL3D_LAUNCH4(R, N) hipLaunchKernelGGL((patchnn4_k<R, N>), grid4, dim3(N), lds4, s, b, desc->H, groups_x)
             if (nthr == 256) { if (runsum) VL3D_LAUNCH4(true, 256); else VL3D_LAUNCH4(false, 256); }
             else if (nthr == 512) { if (runsum) VL3D_LAUNCH4(true, 512); else VL3D_LAUNCH4(false, 512); }
-            else { if (runsum) VL3D_LAUNCH4(true, 1024); else VL3D_LAUNCH4(false, 1024); }
+            else VL3D_LAUNCH4(false, 1024);       // the running-sum form needs 6 registers more than the 128 a 1024-thread workgroup has: per-column adds here
 #undef VL3D_LAUNCH4
         } else if (use_mf) {
             const size_t fixed3 = ((size_t)64 * TyT * 16 + a.n2 + 64 + TyT * 16) * sizeof(float);

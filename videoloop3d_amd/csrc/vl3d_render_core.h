@@ -839,7 +839,9 @@ __global__ __launch_bounds__(256) void bwd_fill_zero_if_infeasible_k(float2 *g, 
 }
 
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16, bool CULL = false>
-__global__ __launch_bounds__(RW *ROWS, (REG ? 4 : 8)) void render_bwd_tile_k(RenderArgs a) {
+// (the culled instantiation of the utils_mpi coordinate convention -- a cross-check convention, its texel coordinates cost a
+// reciprocal more -- does not fit 64 VGPRs: it takes the 128-register budget (one workgroup per CU) rather than spill)
+__global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTILS_MPI)) ? 4 : 8)) void render_bwd_tile_k(RenderArgs a) {
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
     constexpr int NT = RW * ROWS;
     // REG: the layer-space smoothness regularisers (MPV.py:517-531) are differentiated here as well.  Their gradient at a
