@@ -70,6 +70,10 @@ typedef struct vl3d_render_desc {
                             * (see vl3d_render_bwd); bits 4-7: timing-only ablations (wrong results); bits 8-11: forward -- 6 = one frame
                             * per thread (default for the shipped activations and T >= 2: two frames per thread, same bits), 2/4/5 =
                             * workgroup shapes 64x4 / 64x16 / no XCD remap */
+    /* tile culling on a WINDOW of the stack (vl3d_render_*_culled only; all 0 = the stack is the whole plane): the stack passed in is
+     * the texel window [cull_row0, cull_row0+Hs) x [cull_col0, cull_col0+Ws) of a cull_Hs x cull_Ws plane, and the quad grid of
+     * quad_keep lies over that whole plane. */
+    int32_t cull_row0, cull_col0, cull_Hs, cull_Ws;
 } vl3d_render_desc;
 
 /* alpha_sums (optional, may be NULL): (T,H,W,2) per pixel (sum_k a_k, sum_k a_k^2) over the planes -- the two sums the
@@ -142,14 +146,21 @@ int vl3d_adam_step_tiles(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uin
  *     if compact != NULL, write the window's parameters to the compact (D,T,wh,ww,4) buffer the render then reads.
  *   vl3d_adam_window_step: the Adam update of step `step` on the window from the compact gradient (D,T,wh,ww,4); the window's tiles
  *     must be current for step-1 (catch-up first).  Everything outside the window stays deferred.
- * A catch-up with the full plane as the window makes the whole stack current (checkpoints, lod, evaluation renders). */
+ * A catch-up with the full plane as the window makes the whole stack current (checkpoints, lod, evaluation renders).
+ * Tile-culled models (quad_keep / quad_dyn != NULL, device byte maps [D][QH][QW]): culled texels are no parameters (the compact copy
+ * shows them as (0, 0, 0, culled_alpha)); a texel only static quads can read is ONE parameter stored in frame 0 -- the compact copy
+ * shows it in every frame, the step sums its compact gradient over the frames and writes frame 0 only; mirror_static != 0 makes a
+ * catch-up refresh the other frames' slots of static texels (so that the dense stack reads consistently: flush); static_tied != 0
+ * tells the step that frame 0 of the gradient already holds a static texel's frame sum (vl3d_tie_static_grad ran on it). */
 int32_t vl3d_adam_window_tile(void);
 int vl3d_adam_window_catchup(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
                              float *param, float *exp_avg, float *exp_avg_sq, int32_t *last_step, const float *hist, int32_t upto,
-                             float beta1, float beta2, float eps, float *compact, vl3d_stream_t stream);
+                             float beta1, float beta2, float eps, float *compact, const uint8_t *quad_keep, const uint8_t *quad_dyn,
+                             int32_t QH, int32_t QW, float culled_alpha, int32_t mirror_static, vl3d_stream_t stream);
 int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
                           float *param, const float *grad_compact, float *exp_avg, float *exp_avg_sq, int32_t *last_step, float lr,
-                          float beta1, float beta2, float eps, int64_t step, vl3d_stream_t stream);
+                          float beta1, float beta2, float eps, int64_t step, const uint8_t *quad_keep, const uint8_t *quad_dyn,
+                          int32_t QH, int32_t QW, int32_t static_tied, vl3d_stream_t stream);
 void vl3d_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, float *lr_bc1, float *bc2s);
 
 /* Layer-space smoothness regularisers (MPV.py:517-531 rgb_smooth / a_smooth) WITHOUT the materialised [T,h,w,K,4] layer

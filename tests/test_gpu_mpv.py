@@ -290,7 +290,9 @@ def test_sparsified_mpi_to_video_training(dev):
         opt.zero_grad()
         extra["swd"].mean().backward()
         opt.step()
-    now = vid.stack.detach()
+    # a static texel is ONE parameter stored in frame 0 while training (optim.WindowAdam); reading the whole stack goes through
+    # state_dict(), which replays the deferred updates and refreshes the other frames' slots
+    now = vid.state_dict()["stack"].detach()
     assert torch.equal(now[..., 3][(~keep_t)[:, None].expand_as(now[..., 3])], start[..., 3][(~keep_t)[:, None].expand_as(now[..., 3])])
     st = static_t[:, None, :, :, None].expand_as(now)
     assert torch.equal(now[:, :1].expand_as(now)[st], now[st])                       # static texels identical in every frame

@@ -132,3 +132,129 @@ def test_crop_aware_training_equals_dense_training(dev):
     ra, _ = A(H, W, torch.tensor(tar, device=dev)[None], torch.tensor(K, device=dev)[None])
     rb, _ = B(H, W, torch.tensor(tar, device=dev)[None], torch.tensor(K, device=dev)[None])
     assert float((ra - rb).abs().max()) <= 2e-4
+
+
+def test_window_adam_with_quad_maps_stores_static_texels_once(dev):
+    """tile-culled model: culled texels are no parameters, a texel only static quads read is ONE parameter (frame 0; gradient summed
+    over the frames inside the step), dynamic texels one per frame -- equal to torch.optim.Adam on the TIED dense gradient
+    (tiles.tie_static_grad, the definition), windows shuffled, after flush() also in the mirrored frames."""
+    from videoloop3d_amd import tiles
+    from videoloop3d_amd.optim import WindowAdam, align_window
+    D, T, Hs, Ws, QH, QW = 3, 3, 75, 101, 6, 8
+    g = torch.Generator().manual_seed(21)
+    keep = torch.rand((D, QH, QW), generator=g) < 0.6
+    dyn = keep & (torch.rand((D, QH, QW), generator=g) < 0.5)
+    keep_t = tiles.quad_to_texel_mask(keep, Hs, Ws)
+    static_t = keep_t & ~tiles.quad_to_texel_mask(dyn, Hs, Ws)
+    p0 = (torch.rand((D, T, Hs, Ws, 4), generator=g) - 0.5)
+    p0 = torch.where(static_t[:, None, :, :, None], p0[:, :1], p0)               # static texels start as one texture
+    tiles.cull_stack_(p0, keep)
+    pa = torch.nn.Parameter(p0.clone().to(dev))
+    pb = torch.nn.Parameter(p0.clone().to(dev))
+    oa = torch.optim.Adam([pa], lr=5e-3, betas=(0.9, 0.999), eps=6e-8)
+    ob = WindowAdam([pb], lr=5e-3, betas=(0.9, 0.999), eps=6e-8, quad_keep=keep.to(dev), quad_dyn=dyn.to(dev), culled_alpha=tiles.CULLED_ALPHA)
+    r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    for step in range(25):
+        for o in (oa, ob):
+            o.param_groups[0]["lr"] = 5e-3 * 0.97 ** step
+        y0, x0 = r(0, Hs - 20), r(0, Ws - 20)
+        wy, wx, wh, ww = align_window(y0, y0 + r(10, 40), x0, x0 + r(10, 50), Hs, Ws)
+        leaf = ob.window_leaf((wy, wx, wh, ww))
+        kt = keep_t[:, wy:wy + wh, wx:wx + ww].to(dev)
+        stt = static_t[:, wy:wy + wh, wx:wx + ww].to(dev)
+        assert bool((leaf.detach()[..., 3][~kt[:, None].expand(D, T, wh, ww)] == tiles.CULLED_ALPHA).all())      # culled: transparent
+        assert torch.equal(leaf.detach()[:, 1][stt], leaf.detach()[:, 0][stt])                                      # static: one texture
+        gc = (torch.rand((D, T, wh, ww, 4), generator=g) - 0.5).to(dev) * kt[:, None, :, :, None]                  # the culled render leaves 0 there
+        leaf.grad = gc
+        G = torch.zeros_like(pa)
+        G[:, :, wy:wy + wh, wx:wx + ww] = gc
+        pa.grad = tiles.tie_static_grad(G, keep.to(dev), dyn.to(dev))
+        oa.step(); ob.step()
+        pa.grad = None
+    ob.flush()
+    kept = keep_t[:, None, :, :, None].expand_as(pa).to(dev)
+    assert float((pa.detach() - pb.detach())[kept].abs().max()) <= 2e-6
+    assert torch.equal(pb.detach()[~kept], p0.to(dev)[~kept])                    # culled texels were never written
+
+
+def test_culled_render_from_a_window_of_the_stack(dev):
+    """vl3d_render_*_culled with desc->cull_* : the stack is a texel window of the plane the quad grid lies over -- same image and
+    gradient (on the window) as the culled render of the whole stack."""
+    from videoloop3d_amd.render import RenderSpec, render_planes_with_regularisers
+    import dataclasses
+    D, T, Hs, Ws, H, W, QH, QW = 5, 2, 150, 200, 60, 90, 7, 9
+    torch.manual_seed(4)
+    keep = (torch.rand(D, QH, QW) < 0.5).to(dev)
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=13, device=dev)
+    from test_gpu_render import bench_homos
+    homos = (torch.tensor([[1.0, 0, 50.0], [0, 1.0, 40.0], [0, 0, 1.0]]) @ bench_homos(D, H, W, scale=1.5)).to(dev)
+    spec = RenderSpec.mpv()
+    full = stack.clone().requires_grad_(True)
+    out_f = render_planes_with_regularisers(full, homos, H, W, spec, quad_keep=keep)
+    g = synth.hash_uniform((T, H, W, 3), seed=5, device=dev) - 0.5
+    obj = lambda o: (o[0] * g).sum() + 1e-4 * o[2].sum() + 1e-3 * o[3].sum()
+    (g_f,) = torch.autograd.grad(obj(out_f), full)
+    y0, x0, wh, ww = 32, 32, 96, 144
+    assert float(g_f.abs().sum()) == pytest.approx(float(g_f[:, :, y0:y0 + wh, x0:x0 + ww].abs().sum()))      # the window holds the whole footprint
+    win = stack[:, :, y0:y0 + wh, x0:x0 + ww].contiguous().requires_grad_(True)
+    out_w = render_planes_with_regularisers(win, homos, H, W, dataclasses.replace(spec, offset=(-float(x0), -float(y0))), quad_keep=keep,
+                                            cull_window=(y0, x0, Hs, Ws))
+    (g_w,) = torch.autograd.grad(obj(out_w), win)
+    assert float((out_w[0] - out_f[0]).abs().max()) <= 1e-5 and float((out_w[1] - out_f[1]).abs().max()) <= 1e-5
+    assert float(((out_w[2] - out_f[2]).abs() / out_f[2].abs().clamp_min(1.0)).max()) <= 1e-5
+    assert float((g_w - g_f[:, :, y0:y0 + wh, x0:x0 + ww]).abs().max()) <= 1e-5 * max(1.0, float(g_f.abs().max()))
+    assert float(out_f[0].abs().max()) > 0.01
+
+
+def test_sparsified_model_trains_through_the_window_path(dev):
+    """MPMeshVid of a sparsified MPI: the crop-aware path (WindowAdam with the quad maps, static texels stored once) against the
+    round-1 path (TileAdam over the whole stack + tie hook, args.tile_adam): same losses, same kept texels after the flush."""
+    import warnings
+    from videoloop3d_amd import tiles
+    from videoloop3d_amd.MPV import MPMeshVid
+    from videoloop3d_amd.optim import WindowAdam
+    H, W, h, w = 96, 128, 48, 64
+    K = np.array([[0.9 * W, 0, W / 2], [0, 0.9 * W, H / 2], [0, 0, 1]], np.float64)
+    torch.manual_seed(6)
+    keep = torch.rand(5, 8, 11) < 0.6
+    dyn = keep & (torch.rand(5, 8, 11) < 0.5)
+    models = []
+    for tile_adam in (True, False):
+        torch.manual_seed(7)
+        m = MPMeshVid(_args(mpi_h_verts=9, mpi_w_verts=12, tile_adam=tile_adam), H, W, np.eye(4), K, 1.0, 100.0)
+        with torch.no_grad():
+            st = tiles.quad_to_texel_mask(keep, m.mpi_h, m.mpi_w) & ~tiles.quad_to_texel_mask(dyn, m.mpi_h, m.mpi_w)
+            m.stack.data = torch.where(st[:, None, :, :, None], m.stack.data[:, :1], m.stack.data)
+            tiles.cull_stack_(m.stack.data, keep)
+        m.register_buffer("quad_keep", keep.clone())
+        m.register_buffer("quad_dyn", dyn.clone())
+        m.is_sparse = m.has_dyn = True
+        m = m.to(dev).train()
+        m._install_tie_hook()
+        models.append((m, m.get_optimizer(0)))
+    assert isinstance(models[1][1], WindowAdam) and not isinstance(models[0][1], WindowAdam)
+    tar = np.eye(4)
+    tar[:3, 3] = [0.03, 0.01, 0.0]
+    res = synth.hash_uniform((1, 9, 3, h, w), seed=8, device=dev)
+    cfg = dict(loss_name=["gpnn_lm"], loss_gain=torch.tensor([1.0]), macro_block=torch.tensor([65]), patch_size=torch.tensor([3]),
+               stride=torch.tensor([2]), patcht_size=torch.tensor([3]), stridet=torch.tensor([1]), alpha=torch.tensor([10000.0]),
+               dist_fn=["mse"], rou=["-2"], scaling=torch.tensor([0.1]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for it, (oy, ox) in enumerate([(0, 0), (40, 60), (10, 30), (48, 64), (0, 64), (40, 0)]):
+            Kc = K.copy()
+            Kc[0, 2] -= ox
+            Kc[1, 2] -= oy
+            losses = []
+            for model, opt in models:
+                opt.zero_grad(set_to_none=True)
+                _, extra = model(h, w, torch.tensor(tar)[None], torch.tensor(Kc)[None], res=res, losscfg=dict(cfg))
+                loss = extra["swd"].sum() + 0.2 * extra["rgb_smooth"].sum() + 0.2 * extra["a_smooth"].sum()
+                loss.backward()
+                opt.step()
+                losses.append(float(loss.detach()))
+            assert abs(losses[0] - losses[1]) <= 2e-5 * max(1.0, abs(losses[0])), (it, losses)
+    sa, sb = models[0][0].state_dict()["stack"], models[1][0].state_dict()["stack"]
+    kept = tiles.quad_to_texel_mask(keep, *sa.shape[2:4]).to(dev)[:, None, :, :, None].expand_as(sa)
+    diff = (sa - sb)[kept].abs()
+    assert float((diff > 2e-5).float().mean()) <= 1e-3 and float(diff.max()) <= 2e-3 and float(diff.mean()) <= 1e-6

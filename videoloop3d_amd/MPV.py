@@ -283,13 +283,21 @@ class MPMeshVid(nn.Module):
         self._static_compact = False
         self._window_opt = None
         if self.args.optimizer == 'adam':
-            if self.stack.is_cuda and self.is_sparse:
-                # the same update as torch.optim.Adam in ONE pass over (p, g, m, v), only over the texels kept quads can read
+            if self.stack.is_cuda and self.is_sparse and getattr(self.args, "tile_adam", False):
+                # (the round-1 optimiser of sparsified models, kept selectable: one pass over the kept texels of the WHOLE stack, static
+                # gradients summed into frame 0 by the tie hook while it is the optimiser handed out last)
                 from .tiles import TileAdam
-                # static gradients are summed into frame 0 only WHILE the optimiser handed out last is the tile-aware Adam, which
-                # reads them there; any other optimiser (below) sees the frame sum in every copy again
                 self._static_compact = True
                 return TileAdam(params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8, quad_keep=self.quad_keep, quad_dyn=self.quad_dyn)
+            if self.stack.is_cuda and self.is_sparse and not self.atlas_exact:
+                # sparsified model: the crop-aware Adam with the quad maps -- culled texels are no parameters, a static texel is ONE
+                # parameter stored once (frame 0; the window copy shows it in every frame, its gradient is summed over the frames inside
+                # the step), dynamic texels one per frame; only the crop's window is touched per step
+                from .optim import WindowAdam
+                from .tiles import CULLED_ALPHA
+                self._window_opt = WindowAdam(params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8, quad_keep=self.quad_keep,
+                                              quad_dyn=self.quad_dyn, culled_alpha=CULLED_ALPHA)
+                return self._window_opt
             if self.stack.is_cuda and not self.atlas_exact:
                 # dense model: crop-aware Adam -- the render reads a compact copy of the crop's texel window, the backward writes a
                 # compact gradient, the step touches the window only; the zero-gradient updates of everything else are deferred and
@@ -342,12 +350,14 @@ class MPMeshVid(nn.Module):
         homos = self.plane_homographies(extrin, intrin)
         smooth_sums = alpha_sums = None
         spec = self.spec
+        cull_window = None
         if self._window_opt is not None:
-            if self.training and torch.is_grad_enabled() and stack is self.stack and not self.is_sparse:
+            if self.training and torch.is_grad_enabled() and stack is self.stack:
                 # crop-aware training step: render from a compact, up-to-date copy of the texel window this view can reach
                 # (homographies on the host: a few hundred bytes; CPU inputs cost nothing, device inputs one small sync)
                 y0, x0, wh, ww = self.crop_window(homos.detach().cpu(), H, W)
                 if wh > 0 and ww > 0:
+                    cull_window = (y0, x0) + tuple(self.stack.shape[2:4])
                     stack = self._window_opt.window_leaf((y0, x0, wh, ww))
                     spec = dataclasses.replace(spec, offset=(spec.offset[0] - x0, spec.offset[1] - y0))
             else:
@@ -361,10 +371,11 @@ class MPMeshVid(nn.Module):
                                             rgb_act=self.spec.rgb_act, alpha_act=self.spec.alpha_act)
         elif need_smooth:
             rgb, alpha, smooth_sums, alpha_sums = render_planes_with_regularisers(stack, homos, H, W, spec,
-                                                                                  quad_keep=self.quad_keep if self.is_sparse else None)
+                                                                                  quad_keep=self.quad_keep if self.is_sparse else None,
+                                                                                  cull_window=cull_window)
         else:
             # a sparsified model renders with tile culling: samples in culled quads are uncovered, workgroups skip planes without kept quads
-            rgb, alpha = render_planes(stack, homos, H, W, spec, quad_keep=self.quad_keep if self.is_sparse else None)
+            rgb, alpha = render_planes(stack, homos, H, W, spec, quad_keep=self.quad_keep if self.is_sparse else None, cull_window=cull_window)
         variables = {"pix_to_face": None, "blend_weight": None, "mpi": None, "disp_norm": None, "alpha": alpha,
                      "smooth_sums": smooth_sums, "alpha_sums": alpha_sums}
         if need_layers:

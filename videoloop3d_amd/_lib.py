@@ -25,7 +25,8 @@ class RenderDesc(C.Structure):
                 ("coord_mode", C.c_int32), ("border_mode", C.c_int32), ("act_order", C.c_int32),
                 ("rgb_act", C.c_int32), ("alpha_act", C.c_int32), ("stack_dtype", C.c_int32),
                 ("pixel_center", C.c_float), ("sx", C.c_float), ("sy", C.c_float), ("ox", C.c_float),
-                ("oy", C.c_float), ("variant", C.c_int32)]
+                ("oy", C.c_float), ("variant", C.c_int32),
+                ("cull_row0", C.c_int32), ("cull_col0", C.c_int32), ("cull_Hs", C.c_int32), ("cull_Ws", C.c_int32)]
 
 
 class LossDesc(C.Structure):
@@ -52,8 +53,8 @@ SIGNATURES = {
     "vl3d_adam_step_tiles": ([_I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _I64, _P],
                              C.c_int),
     "vl3d_adam_window_tile": ([], C.c_int32),
-    "vl3d_adam_window_catchup": ([_I32] * 8 + [_P, _P, _P, _P, _P, _I32, _F, _F, _F, _P, _P], C.c_int),
-    "vl3d_adam_window_step": ([_I32] * 8 + [_P, _P, _P, _P, _P, _F, _F, _F, _F, _I64, _P], C.c_int),
+    "vl3d_adam_window_catchup": ([_I32] * 8 + [_P, _P, _P, _P, _P, _I32, _F, _F, _F, _P, _P, _P, _I32, _I32, _F, _I32, _P], C.c_int),
+    "vl3d_adam_window_step": ([_I32] * 8 + [_P, _P, _P, _P, _P, _F, _F, _F, _F, _I64, _P, _P, _I32, _I32, _I32, _P], C.c_int),
     "vl3d_adam_step_scalars": ([_F, _F, _F, _I64, C.POINTER(C.c_float), C.POINTER(C.c_float)], None),
     "vl3d_render_cull_scratch_bytes": ([C.POINTER(RenderDesc)], C.c_int64),
     "vl3d_render_fwd_culled": ([C.POINTER(RenderDesc), _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P], C.c_int),

@@ -73,4 +73,13 @@ __device__ __forceinline__ float texel_coord(float p, float half_size, float siz
     }
 }
 
+// quad index of texel coordinate a (an integer, possibly -1 or S) on an axis of S texels and n quads: floor(a * n / (S - 1)), clamped --
+// in INTEGER arithmetic, so that a texel exactly on a quad border lands on the same side in every kernel and in tiles.py
+__host__ __device__ inline int quad_index(int a, int S, int n) {
+    const int den = S > 1 ? S - 1 : 1;
+    const long long num = (long long)a * n;
+    int i = (int)(num >= 0 ? num / den : -((-num + den - 1) / den));
+    return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+}
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -303,9 +303,7 @@ __global__ __launch_bounds__(256) void tie_static_grad_k(int D, int T, int Hs, i
                                                          int assume_culled_zero) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), d = blockIdx.z;
     if (x >= Ws || y >= Hs) return;
-    const double ch = (double)(Hs - 1) / QH, cw = (double)(Ws - 1) / QW;
-    auto q = [](double v, double c, int n) { const int i = (int)floor(v / c); return i < 0 ? 0 : (i > n - 1 ? n - 1 : i); };
-    const int ylo = q(y - 1.0, ch, QH), yhi = q(y + 1.0, ch, QH), xlo = q(x - 1.0, cw, QW), xhi = q(x + 1.0, cw, QW);
+    const int ylo = quad_index(y - 1, Hs, QH), yhi = quad_index(y + 1, Hs, QH), xlo = quad_index(x - 1, Ws, QW), xhi = quad_index(x + 1, Ws, QW);
     const unsigned char *k = keep + (size_t)d * QH * QW, *m = dyn + (size_t)d * QH * QW;
     const bool kept = k[ylo * QW + xlo] | k[ylo * QW + xhi] | k[yhi * QW + xlo] | k[yhi * QW + xhi];
     const bool dynamic = m[ylo * QW + xlo] | m[ylo * QW + xhi] | m[yhi * QW + xlo] | m[yhi * QW + xhi];
@@ -349,9 +347,7 @@ __global__ __launch_bounds__(256) void adam_tiles_k(int T, int Hs, int Ws, const
     if (x >= Ws || y >= Hs) return;
     bool is_static = false;
     if (keep) {
-        const double ch = (double)(Hs - 1) / QH, cw = (double)(Ws - 1) / QW;
-        auto q = [](double val, double c, int n) { const int i = (int)floor(val / c); return i < 0 ? 0 : (i > n - 1 ? n - 1 : i); };
-        const int ylo = q(y - 1.0, ch, QH), yhi = q(y + 1.0, ch, QH), xlo = q(x - 1.0, cw, QW), xhi = q(x + 1.0, cw, QW);
+        const int ylo = quad_index(y - 1, Hs, QH), yhi = quad_index(y + 1, Hs, QH), xlo = quad_index(x - 1, Ws, QW), xhi = quad_index(x + 1, Ws, QW);
         const unsigned char *k = keep + (size_t)d * QH * QW;
         if (!(k[ylo * QW + xlo] | k[ylo * QW + xhi] | k[yhi * QW + xlo] | k[yhi * QW + xhi])) return;
         if (dyn) {

@@ -26,18 +26,57 @@ __device__ __forceinline__ void adam_upd(float &pp, float gg, float &mm, float &
 
 struct Win { int y0, x0, wh, ww; };
 
+// tile-culled models (quad maps keep / dyn [D][QH][QW], MPI.py:288-442): 0 = culled texel (no kept quad can read it: no parameter),
+// 1 = dynamic (a parameter per frame), 2 = static (only static quads can read it: ONE parameter, living in frame 0 -- the reference's
+// static atlas, MPV.py:235-288).  Same classification as tiles.quad_to_texel_mask / adam_tiles_k.  keep == NULL: everything dynamic.
+struct Quads { const unsigned char *keep, *dyn; int QH, QW; };
+__device__ __forceinline__ int texel_class(const Quads &q, int d, int x, int y, int Hs, int Ws) {
+    if (!q.keep) return 1;
+    const int ylo = quad_index(y - 1, Hs, q.QH), yhi = quad_index(y + 1, Hs, q.QH), xlo = quad_index(x - 1, Ws, q.QW), xhi = quad_index(x + 1, Ws, q.QW);
+    const unsigned char *k = q.keep + (size_t)d * q.QH * q.QW;
+    if (!(k[ylo * q.QW + xlo] | k[ylo * q.QW + xhi] | k[yhi * q.QW + xlo] | k[yhi * q.QW + xhi])) return 0;
+    if (!q.dyn) return 1;
+    const unsigned char *m = q.dyn + (size_t)d * q.QH * q.QW;
+    return (m[ylo * q.QW + xlo] | m[ylo * q.QW + xhi] | m[yhi * q.QW + xlo] | m[yhi * q.QW + xhi]) ? 1 : 2;
+}
+
 // one thread per window texel and plane, looping over the frames.  `upto`: the step the window must be current for (the
 // step about to be taken minus one).  compact (optional): (D,T,wh,ww,4) copy of the window's parameters after the catch-up.
 __global__ __launch_bounds__(256) void adam_window_catchup_k(int T, int Hs, int Ws, Win w, float4 *__restrict__ p, float4 *__restrict__ m,
                                                              float4 *__restrict__ v, const int *__restrict__ last_step, int tiles_y, int tiles_x,
                                                              const float2 *__restrict__ hist, int upto, float beta1, float beta2, float eps,
-                                                             float4 *__restrict__ compact) {
+                                                             float4 *__restrict__ compact, Quads q, float culled_alpha, int mirror) {
     const int lx = blockIdx.x * 64 + (threadIdx.x & 63), ly = blockIdx.y * 4 + (threadIdx.x >> 6), d = blockIdx.z;
     if (lx >= w.ww || ly >= w.wh) return;
     const int x = w.x0 + lx, y = w.y0 + ly;
     const int from = last_step[((size_t)d * tiles_y + y / TS) * tiles_x + x / TS];
     const size_t frame = (size_t)Hs * Ws, cframe = (size_t)w.wh * w.ww;
     size_t o = (size_t)d * T * frame + (size_t)y * Ws + x, oc = (size_t)d * T * cframe + (size_t)ly * w.ww + lx;
+    const int cls = texel_class(q, d, x, y, Hs, Ws);
+    if (cls == 0) {           // culled: not a parameter; the render must see it transparent (and finite)
+        if (compact)
+            for (int t = 0; t < T; ++t, oc += cframe) compact[oc] = make_float4(0.f, 0.f, 0.f, culled_alpha);
+        return;
+    }
+    if (cls == 2) {           // static: the one parameter lives in frame 0; every frame of the compact copy shows it
+        float4 pp = p[o];
+        if (from < upto) {
+            float4 mm = m[o], vv = v[o];
+            for (int s = from + 1; s <= upto; ++s) {
+                const float2 h = hist[s];
+                adam_upd(pp.x, 0.0f, mm.x, vv.x, h.x, beta1, beta2, eps, h.y);
+                adam_upd(pp.y, 0.0f, mm.y, vv.y, h.x, beta1, beta2, eps, h.y);
+                adam_upd(pp.z, 0.0f, mm.z, vv.z, h.x, beta1, beta2, eps, h.y);
+                adam_upd(pp.w, 0.0f, mm.w, vv.w, h.x, beta1, beta2, eps, h.y);
+            }
+            p[o] = pp; m[o] = mm; v[o] = vv;
+        }
+        if (compact)
+            for (int t = 0; t < T; ++t, oc += cframe) compact[oc] = pp;
+        if (mirror)           // flush: refresh the other frames' slots so that the dense stack reads consistently everywhere
+            for (int t = 1; t < T; ++t) p[o + (size_t)t * frame] = pp;
+        return;
+    }
     if (from >= upto) {       // current already: copy only
         if (compact)
             for (int t = 0; t < T; ++t, o += frame, oc += cframe) compact[oc] = p[o];
@@ -59,11 +98,27 @@ __global__ __launch_bounds__(256) void adam_window_catchup_k(int T, int Hs, int 
 
 __global__ __launch_bounds__(256) void adam_window_step_k(int T, int Hs, int Ws, Win w, float4 *__restrict__ p, const float4 *__restrict__ g,
                                                           float4 *__restrict__ m, float4 *__restrict__ v, float lr_bc1, float beta1, float beta2,
-                                                          float eps, float bc2s) {
+                                                          float eps, float bc2s, Quads q, int static_tied) {
     const int lx = blockIdx.x * 64 + (threadIdx.x & 63), ly = blockIdx.y * 4 + (threadIdx.x >> 6), d = blockIdx.z;
     if (lx >= w.ww || ly >= w.wh) return;
     const size_t frame = (size_t)Hs * Ws, cframe = (size_t)w.wh * w.ww;
     size_t o = (size_t)d * T * frame + (size_t)(w.y0 + ly) * Ws + (w.x0 + lx), oc = (size_t)d * T * cframe + (size_t)ly * w.ww + lx;
+    const int cls = texel_class(q, d, w.x0 + lx, w.y0 + ly, Hs, Ws);
+    if (cls == 0) return;
+    if (cls == 2) {           // static: gradient = the sum over the frames (frame order: deterministic), one update, one write
+        float4 gg = g[oc];
+        for (int t = 1; t < T && !static_tied; ++t) {        // static_tied: frame 0 already holds the frame sum (tie_static_grad)
+            const float4 gt = g[oc + (size_t)t * cframe];
+            gg.x += gt.x; gg.y += gt.y; gg.z += gt.z; gg.w += gt.w;
+        }
+        float4 pp = p[o], mm = m[o], vv = v[o];
+        adam_upd(pp.x, gg.x, mm.x, vv.x, lr_bc1, beta1, beta2, eps, bc2s);
+        adam_upd(pp.y, gg.y, mm.y, vv.y, lr_bc1, beta1, beta2, eps, bc2s);
+        adam_upd(pp.z, gg.z, mm.z, vv.z, lr_bc1, beta1, beta2, eps, bc2s);
+        adam_upd(pp.w, gg.w, mm.w, vv.w, lr_bc1, beta1, beta2, eps, bc2s);
+        p[o] = pp; m[o] = mm; v[o] = vv;
+        return;
+    }
     for (int t = 0; t < T; ++t, o += frame, oc += cframe) {
         float4 pp = p[o], mm = m[o], vv = v[o];
         const float4 gg = g[oc];
@@ -96,15 +151,19 @@ extern "C" int32_t vl3d_adam_window_tile(void) { return TS; }
 
 extern "C" int vl3d_adam_window_catchup(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
                                         float *param, float *exp_avg, float *exp_avg_sq, int32_t *last_step, const float *hist,
-                                        int32_t upto, float beta1, float beta2, float eps, float *compact, vl3d_stream_t stream) {
+                                        int32_t upto, float beta1, float beta2, float eps, float *compact, const uint8_t *quad_keep,
+                                        const uint8_t *quad_dyn, int32_t QH, int32_t QW, float culled_alpha, int32_t mirror_static,
+                                        vl3d_stream_t stream) {
     int rc = check_window(D, T, Hs, Ws, y0, x0, wh, ww);
     if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE(param && exp_avg && exp_avg_sq && last_step && hist && upto >= 0, "vl3d_adam_window_catchup: null pointer / negative step");
+    VL3D_REQUIRE(!quad_keep || (QH > 0 && QW > 0), "vl3d_adam_window_catchup: bad quad grid");
     const int tiles_y = (Hs + TS - 1) / TS, tiles_x = (Ws + TS - 1) / TS;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_window_catchup_k, dim3((ww + 63) / 64, (wh + 3) / 4, D), dim3(256), 0, s, T, Hs, Ws, Win{y0, x0, wh, ww},
                        reinterpret_cast<float4 *>(param), reinterpret_cast<float4 *>(exp_avg), reinterpret_cast<float4 *>(exp_avg_sq), last_step,
-                       tiles_y, tiles_x, reinterpret_cast<const float2 *>(hist), upto, beta1, beta2, eps, reinterpret_cast<float4 *>(compact));
+                       tiles_y, tiles_x, reinterpret_cast<const float2 *>(hist), upto, beta1, beta2, eps, reinterpret_cast<float4 *>(compact),
+                       Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW}, culled_alpha, mirror_static);
     const int nty = (y0 + wh + TS - 1) / TS - y0 / TS, ntx = (x0 + ww + TS - 1) / TS - x0 / TS;
     hipLaunchKernelGGL(mark_tiles_k, dim3((D * nty * ntx + 255) / 256), dim3(256), 0, s, last_step, tiles_y, tiles_x, y0 / TS, x0 / TS, nty, ntx, D, upto);
     VL3D_CHECK_LAUNCH();
@@ -113,7 +172,8 @@ extern "C" int vl3d_adam_window_catchup(int32_t D, int32_t T, int32_t Hs, int32_
 
 extern "C" int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
                                      float *param, const float *grad_compact, float *exp_avg, float *exp_avg_sq, int32_t *last_step,
-                                     float lr, float beta1, float beta2, float eps, int64_t step, vl3d_stream_t stream) {
+                                     float lr, float beta1, float beta2, float eps, int64_t step, const uint8_t *quad_keep,
+                                     const uint8_t *quad_dyn, int32_t QH, int32_t QW, int32_t static_tied, vl3d_stream_t stream) {
     int rc = check_window(D, T, Hs, Ws, y0, x0, wh, ww);
     if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE(param && grad_compact && exp_avg && exp_avg_sq && last_step && step >= 1, "vl3d_adam_window_step: null pointer / bad step");
@@ -122,7 +182,8 @@ extern "C" int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t W
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_window_step_k, dim3((ww + 63) / 64, (wh + 3) / 4, D), dim3(256), 0, s, T, Hs, Ws, Win{y0, x0, wh, ww},
                        reinterpret_cast<float4 *>(param), reinterpret_cast<const float4 *>(grad_compact), reinterpret_cast<float4 *>(exp_avg),
-                       reinterpret_cast<float4 *>(exp_avg_sq), (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2));
+                       reinterpret_cast<float4 *>(exp_avg_sq), (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2),
+                       Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW}, static_tied);
     const int nty = (y0 + wh + TS - 1) / TS - y0 / TS, ntx = (x0 + ww + TS - 1) / TS - x0 / TS;
     hipLaunchKernelGGL(mark_tiles_k, dim3((D * nty * ntx + 255) / 256), dim3(256), 0, s, last_step, tiles_y, tiles_x, y0 / TS, x0 / TS, nty, ntx, D, (int)step);
     VL3D_CHECK_LAUNCH();

@@ -55,10 +55,25 @@ RenderArgs make_args(const vl3d_render_desc *d) {
 
 }  // namespace
 
+// the quad grid is laid over the whole plane; the stack may be a texel window of it (desc->cull_*: crop-aware training renders
+// from a compact copy of the window the crop can reach, videoloop3d_amd/optim.py)
+static void set_cull_geometry(RenderArgs &a, const vl3d_render_desc *desc, int32_t QH, int32_t QW) {
+    const bool win = desc->cull_Hs > 0 && desc->cull_Ws > 0;
+    a.q_Hs = win ? desc->cull_Hs : desc->Hs;
+    a.q_Ws = win ? desc->cull_Ws : desc->Ws;
+    a.q_x0 = win ? (float)desc->cull_col0 : 0.0f;
+    a.q_y0 = win ? (float)desc->cull_row0 : 0.0f;
+    a.q_inv_cw = (float)QW / (float)(a.q_Ws > 1 ? a.q_Ws - 1 : 1);
+    a.q_inv_ch = (float)QH / (float)(a.q_Hs > 1 ? a.q_Hs - 1 : 1);
+}
+
 static int check_cull(const vl3d_render_desc *desc, const uint8_t *quad_keep, int32_t QH, int32_t QW) {
     if (!quad_keep) return VL3D_OK;
     VL3D_REQUIRE(desc->coord_mode != VL3D_COORD_AFFINE_PLANES, "tile culling is not available with per-plane texel transforms");
     VL3D_REQUIRE(QH > 0 && QW > 0, "tile culling: non-positive quad grid");
+    VL3D_REQUIRE((desc->cull_Hs == 0 && desc->cull_Ws == 0) ||
+                     (desc->cull_row0 >= 0 && desc->cull_col0 >= 0 && desc->cull_row0 + desc->Hs <= desc->cull_Hs && desc->cull_col0 + desc->Ws <= desc->cull_Ws),
+                 "tile culling: the stack window (cull_row0, cull_col0) + (Hs, Ws) leaves the plane (cull_Hs, cull_Ws)");
     VL3D_REQUIRE(desc->D <= 128, "tile culling supports at most 128 planes");
     return VL3D_OK;
 }
@@ -80,7 +95,7 @@ static int render_fwd_impl(const vl3d_render_desc *desc, const void *stack, cons
     RenderArgs a = make_args(desc);
     a.stack = (const float *)stack; a.homos = homos; a.rgb = rgb; a.alpha = alpha; a.asum = alpha_sums;
     a.quad_keep = quad_keep; a.QH = QH; a.QW = QW;
-    a.q_inv_cw = (float)QW / (float)(desc->Ws > 1 ? desc->Ws - 1 : 1); a.q_inv_ch = (float)QH / (float)(desc->Hs > 1 ? desc->Hs - 1 : 1); a.cull_masks = (const unsigned long long *)cull_scratch;
+    set_cull_geometry(a, desc, QH, QW); a.cull_masks = (const unsigned long long *)cull_scratch;
     a.fwd_variant = (desc->variant >> 8) & 0xf;
     a.ablate = (desc->variant >> 4) & 0xf;
     VL3D_REQUIRE((int64_t)desc->Hs * desc->Ws * 16 < (1ll << 32), "frame too large for 32-bit byte offsets");
@@ -161,7 +176,7 @@ static int render_reg_fwd_impl(const vl3d_render_desc *desc, const void *stack, 
     RenderArgs a = make_args(desc);
     a.stack = (const float *)stack; a.homos = homos; a.reg_sums = sums;
     a.quad_keep = quad_keep; a.QH = QH; a.QW = QW;
-    a.q_inv_cw = (float)QW / (float)(desc->Ws > 1 ? desc->Ws - 1 : 1); a.q_inv_ch = (float)QH / (float)(desc->Hs > 1 ? desc->Hs - 1 : 1);
+    set_cull_geometry(a, desc, QH, QW);
     VL3D_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(double), (hipStream_t)stream));
     a.reg_fwd = 1;
     a.g_f16 = desc->stack_dtype == VL3D_F16;
@@ -206,7 +221,7 @@ static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, cons
     a.rgb = const_cast<float *>(rgb); a.alpha = const_cast<float *>(alpha);
     a.g_rgb = grad_rgb; a.g_alpha = grad_alpha; a.g_reg = grad_reg; a.g_asum = grad_alpha_sums; a.g_stack = grad_stack;
     a.quad_keep = quad_keep; a.QH = QH; a.QW = QW;
-    a.q_inv_cw = (float)QW / (float)(desc->Ws > 1 ? desc->Ws - 1 : 1); a.q_inv_ch = (float)QH / (float)(desc->Hs > 1 ? desc->Hs - 1 : 1);
+    set_cull_geometry(a, desc, QH, QW);
     a.g_f16 = desc->stack_dtype == VL3D_F16;
     // variant: 0 auto (tile kernel when its on-device plan says feasible, else atomics), 1 force atomics,
     //          3 tile kernel (16-row regions, one frame per thread), 4 = 3 without the 2x2 gather   (2, the 8-row regions of round 1,

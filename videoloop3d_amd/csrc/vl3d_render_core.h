@@ -50,6 +50,8 @@ struct RenderArgs {
     int fwd_variant;     // forward kernel selector (see launch<>)
     int ablate;          // measurement-only switches (bit0: skip LDS scatter, bit1: skip flush stores, bit2: skip tap loads)
     float q_inv_cw, q_inv_ch;   // tile culling: quads per texel along x / y = QW/(Ws-1), QH/(Hs-1) (float division done once, on the host)
+    float q_x0, q_y0;           // ... with the stack being the texel window [q_y0, q_y0+Hs) x [q_x0, q_x0+Ws) of a q_Hs x q_Ws plane the
+    int q_Hs, q_Ws;             // quad grid is laid over (desc->cull_*; the whole plane by default)
     int gather9;         // 1: never take the 2x2 gather (variant 4; the 3x3 gather is the definition the 2x2 one must equal bit for bit)
     const float *plan;   // device scratch written by bwd_plan_k: [0] feasible flag, [16 + 12*d ..] inverse texel homographies,
                          // then (bwd_windows_k) one int4 texel window per (tile, plane)
@@ -84,8 +86,9 @@ using vl3d_render_detail::RenderArgs;
 // the plane's vertex grid, (Ws-1)/QW x (Hs-1)/QH texels each.  Conservative by construction: a workgroup skips a plane only
 // when every tap of every one of its pixels is a texel no kept quad can read, i.e. a culled texel whose alpha is exactly 0.
 __device__ __forceinline__ bool box_touches_kept_quad(const RenderArgs &a, int d, float tnx, float txx, float tny, float txy) {
-    if (!(txx >= -2.0f && tnx <= (float)a.Ws + 1.0f && txy >= -2.0f && tny <= (float)a.Hs + 1.0f)) return !(tnx == tnx && tny == tny);   // outside the plane (NaN: keep)
-    const float cw = (float)max(a.Ws - 1, 1) / (float)a.QW, ch = (float)max(a.Hs - 1, 1) / (float)a.QH;
+    tnx += a.q_x0; txx += a.q_x0; tny += a.q_y0; txy += a.q_y0;       // window-local -> plane texel coordinates
+    if (!(txx >= -2.0f && tnx <= (float)a.q_Ws + 1.0f && txy >= -2.0f && tny <= (float)a.q_Hs + 1.0f)) return !(tnx == tnx && tny == tny);   // outside the plane (NaN: keep)
+    const float cw = (float)max(a.q_Ws - 1, 1) / (float)a.QW, ch = (float)max(a.q_Hs - 1, 1) / (float)a.QH;
     const int qx0 = max(0, (int)floorf((tnx - 2.0f) / cw)), qx1 = min(a.QW - 1, (int)floorf((txx + 2.0f) / cw));
     const int qy0 = max(0, (int)floorf((tny - 2.0f) / ch)), qy1 = min(a.QH - 1, (int)floorf((txy + 2.0f) / ch));
     const unsigned char *k = a.quad_keep + (size_t)d * a.QH * a.QW;
@@ -156,10 +159,11 @@ struct QuadCull {
     const unsigned char *keep;   // [QH][QW] of THIS plane
     int QH, QW;
     float inv_cw, inv_ch;        // quads per texel along x / y: QW/(Ws-1), QH/(Hs-1)
+    float x0, y0;                // texel origin of the stack window inside the plane (0 for a whole plane)
 };
 __device__ __forceinline__ QuadCull plane_cull(const RenderArgs &a, int d) {
-    if (!a.quad_keep) return QuadCull{nullptr, 0, 0, 0.f, 0.f};
-    return QuadCull{a.quad_keep + (size_t)d * a.QH * a.QW, a.QH, a.QW, a.q_inv_cw, a.q_inv_ch};     // the two quotients come from the host: uniform, in SGPRs
+    if (!a.quad_keep) return QuadCull{nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f};
+    return QuadCull{a.quad_keep + (size_t)d * a.QH * a.QW, a.QH, a.QW, a.q_inv_cw, a.q_inv_ch, a.q_x0, a.q_y0};     // the two quotients come from the host: uniform, in SGPRs
 }
 
 // integer form of the taps: base tap (x0,y0) with x0 <= Ws-2, y0 <= Hs-2 (so the 2x2 block is inside the plane) + weights
@@ -176,7 +180,7 @@ struct TapsI {
 // exactly grid_sample's zeros padding (utils_mpi.py:159-176) -- no per-tap validity selects, no per-tap address clamps.
 template <int COORD, int BORDER>
 __device__ __forceinline__ TapsI make_taps_i(const float *__restrict__ h, float px, float py, int Hs, int Ws,
-                                             float sx, float sy, float ox, float oy, QuadCull qc = QuadCull{nullptr, 0, 0, 0.f, 0.f}) {
+                                             float sx, float sy, float ox, float oy, QuadCull qc = QuadCull{nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f}) {
     TapsI t;
     const f2 px2 = f2{px, px}, py2 = f2{py, py};
     const f2 XY = __builtin_elementwise_fma(f2{h[0], h[3]}, px2, __builtin_elementwise_fma(f2{h[1], h[4]}, py2, f2{h[2], h[5]}));
@@ -203,7 +207,7 @@ __device__ __forceinline__ TapsI make_taps_i(const float *__restrict__ h, float 
         t.cov = ((t.w[0] + t.w[1]) + (t.w[2] + t.w[3]) > 0.0f) ? 1.0f : 0.0f;
     }
     if (qc.keep) {      // uniform branch
-        const int qx = min(max((int)floorf(tx * qc.inv_cw), 0), qc.QW - 1), qy = min(max((int)floorf(ty * qc.inv_ch), 0), qc.QH - 1);
+        const int qx = min(max((int)floorf((tx + qc.x0) * qc.inv_cw), 0), qc.QW - 1), qy = min(max((int)floorf((ty + qc.y0) * qc.inv_ch), 0), qc.QH - 1);
         if (!qc.keep[qy * qc.QW + qx]) t.cov = 0.0f;
     }
     return t;
@@ -211,7 +215,7 @@ __device__ __forceinline__ TapsI make_taps_i(const float *__restrict__ h, float 
 
 template <int COORD, int BORDER>
 __device__ __forceinline__ Taps2 make_taps2(const float *__restrict__ h, float px, float py, int Hs, int Ws,
-                                            float sx, float sy, float ox, float oy, QuadCull qc = QuadCull{nullptr, 0, 0, 0.f, 0.f}) {
+                                            float sx, float sy, float ox, float oy, QuadCull qc = QuadCull{nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f}) {
     const TapsI ti = make_taps_i<COORD, BORDER>(h, px, py, Hs, Ws, sx, sy, ox, oy, qc);
     Taps2 t;
     t.w = ti.w;

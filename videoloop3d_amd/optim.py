@@ -28,8 +28,15 @@ def align_window(y0, y1, x0, x1, Hs, Ws):
 
 
 class WindowAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, quad_keep=None, quad_dyn=None, culled_alpha=-1e4):
+        """quad_keep / quad_dyn [D,QH,QW] (a tile-culled model, videoloop3d_amd/tiles.py): culled texels are no parameters, a texel only
+        static quads can read is ONE parameter stored in frame 0 of the stack (the reference's static atlas, MPV.py:235-288) -- the
+        window copy shows it in every frame, the step sums its gradient over the frames and writes that one copy; flush() refreshes
+        the other frames' slots so that the dense stack reads consistently."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.quad_keep = None if quad_keep is None else quad_keep.to(torch.uint8).contiguous()
+        self.quad_dyn = None if (quad_keep is None or quad_dyn is None) else quad_dyn.to(torch.uint8).contiguous()
+        self.culled_alpha = float(culled_alpha)
         ps = [p for g in self.param_groups for p in g["params"]]
         if len(ps) != 1:
             raise RuntimeError("WindowAdam drives exactly one parameter: the plane stack (D,T,Hs,Ws,4)")
@@ -52,15 +59,21 @@ class WindowAdam(torch.optim.Optimizer):
             st["hist"] = torch.zeros((1024, 2), dtype=torch.float32, device=p.device)
         return st
 
-    def _catchup(self, window, upto, compact):
+    def _quads(self):
+        qk, qd = self.quad_keep, self.quad_dyn
+        return L.ptr(qk), L.ptr(qd), (0 if qk is None else qk.shape[1]), (0 if qk is None else qk.shape[2])
+
+    def _catchup(self, window, upto, compact, mirror=False):
         st, p = self._st(), self.p
         D, T, Hs, Ws, _ = p.shape
         y0, x0, wh, ww = window
         b1, b2 = self.param_groups[0]["betas"]
+        qk, qd, QH, QW = self._quads()
         with torch.cuda.device(p.device):
             L.check(L.lib().vl3d_adam_window_catchup(D, T, Hs, Ws, y0, x0, wh, ww, L.ptr(p), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
                                                      L.ptr(st["last_step"]), L.ptr(st["hist"]), int(upto), float(b1), float(b2),
-                                                     float(self.param_groups[0]["eps"]), L.ptr(compact), L.stream_ptr(p.device)),
+                                                     float(self.param_groups[0]["eps"]), L.ptr(compact), qk, qd, QH, QW, self.culled_alpha,
+                                                     1 if mirror else 0, L.stream_ptr(p.device)),
                     "vl3d_adam_window_catchup")
 
     # ---- forward side ---------------------------------------------------------------------------------------------------
@@ -86,7 +99,7 @@ class WindowAdam(torch.optim.Optimizer):
         if self.t == 0 or not self.state.get(self.p):
             return
         D, T, Hs, Ws, _ = self.p.shape
-        self._catchup((0, 0, Hs, Ws), self.t, None)
+        self._catchup((0, 0, Hs, Ws), self.t, None, mirror=self.quad_keep is not None)
 
     def zero_grad(self, set_to_none=True):
         super().zero_grad(set_to_none)
@@ -130,9 +143,12 @@ class WindowAdam(torch.optim.Optimizer):
             if p.grad is not None:
                 raise RuntimeError("WindowAdam: both the window leaf and the dense parameter received a gradient in one step")
         y0, x0, wh, ww = window
+        qk, qd, QH, QW = self._quads()
         with torch.cuda.device(p.device):
             L.check(L.lib().vl3d_adam_window_step(D, T, Hs, Ws, y0, x0, wh, ww, L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
-                                                  L.ptr(st["last_step"]), lr, float(b1), float(b2), eps, t, L.stream_ptr(p.device)),
+                                                  L.ptr(st["last_step"]), lr, float(b1), float(b2), eps, t, qk, qd, QH, QW,
+                                                  1 if (dense and qk is not None) else 0,      # a dense p.grad of a sparsified model went through the tie hook
+                                                  L.stream_ptr(p.device)),
                     "vl3d_adam_window_step")
         self.t = t
         return loss

@@ -33,7 +33,7 @@ class RenderSpec:
                           act_order="post", rgb_act=rgb_act, alpha_act=alpha_act, variant=variant)
 
 
-def _desc(stack, H, W, spec, row0, col0):
+def _desc(stack, H, W, spec, row0, col0, cull_window=None):
     D, T, Hs, Ws, C4 = stack.shape
     assert C4 == 4, "plane stack must be (D,T,Hs,Ws,4)"
     d = L.RenderDesc()
@@ -48,6 +48,8 @@ def _desc(stack, H, W, spec, row0, col0):
     d.sx, d.sy = float(spec.scale[0]), float(spec.scale[1])
     d.ox, d.oy = float(spec.offset[0]), float(spec.offset[1])
     d.variant = int(spec.variant)
+    if cull_window is not None:        # the stack is the texel window (y0, x0) of a (Hs_plane, Ws_plane) plane the quad grid lies over
+        d.cull_row0, d.cull_col0, d.cull_Hs, d.cull_Ws = (int(v) for v in cull_window)
     return d
 
 
@@ -58,7 +60,7 @@ LAST_BWD_SCRATCH = None
 
 class _RenderPlanes(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, stack, homos, H, W, spec, row0, col0, with_reg, quad_keep=None):
+    def forward(ctx, stack, homos, H, W, spec, row0, col0, with_reg, quad_keep=None, cull_window=None):
         L.check_cuda(stack, homos)
         if quad_keep is not None:
             L.check_cuda(quad_keep)
@@ -87,7 +89,7 @@ class _RenderPlanes(torch.autograd.Function):
             z = torch.zeros
             return (rgb, alpha, z(4, dtype=torch.float32, device=stack.device),
                     z((T, H, W, 2) if with_reg else (0,), dtype=torch.float32, device=stack.device))
-        desc = _desc(stack, H, W, spec, row0, col0)
+        desc = _desc(stack, H, W, spec, row0, col0, cull_window if quad_keep is not None else None)
         asum = torch.empty((T, H, W, 2), dtype=torch.float32, device=stack.device) if with_reg else None
         sums = torch.zeros(4, dtype=torch.float64, device=stack.device)
         # variant bits 12-15: 1 = keep the two-pass forward with regularisers (render, then the sums kernel) for A/B and cross-checks
@@ -125,7 +127,7 @@ class _RenderPlanes(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_alpha, g_sums, g_asum):
         if ctx.nothing_to_render:
-            return (torch.zeros_like(ctx.saved_tensors[0]),) + (None,) * 8
+            return (torch.zeros_like(ctx.saved_tensors[0]),) + (None,) * 9
         stack, homos, rgb, alpha = ctx.saved_tensors
         g_reg = g_sums.to(torch.float32).contiguous() if (ctx.with_reg and g_sums is not None) else None
         g_asum = g_asum.to(torch.float32).contiguous() if (ctx.with_reg and g_asum is not None) else None
@@ -149,18 +151,20 @@ class _RenderPlanes(torch.autograd.Function):
                         "vl3d_render_bwd_culled")
         global LAST_BWD_SCRATCH
         LAST_BWD_SCRATCH = scratch
-        return g_stack, None, None, None, None, None, None, None, None
+        return g_stack, None, None, None, None, None, None, None, None, None
 
 
-def render_planes(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0), quad_keep=None):
+def render_planes(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0), quad_keep=None, cull_window=None):
     """stack (D,T,Hs,Ws,4) pre-activation fp32 (plane 0 = nearest), homos [D,3,3] (target pixel -> plane pixel).
 
     Returns rgb [T,H,W,3], alpha [T,H,W].  `window=(row0,col0)` renders the H x W sub-window whose top-left
     corner is frame pixel (row0,col0) -- used for row-band sharding (equivalent to utils.py:196-200
     get_new_intrin on the target intrinsics).
     `quad_keep` [D,QH,QW] (bool/uint8, optional): tile culling map (videoloop3d_amd.tiles): a sample that falls into a culled quad
-    of a plane is not covered by it, and workgroups skip the planes of which they see no kept quad (include/vl3d.h)."""
-    rgb, alpha, _, _ = _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), False, quad_keep)
+    of a plane is not covered by it, and workgroups skip the planes of which they see no kept quad (include/vl3d.h).
+    `cull_window` (y0, x0, Hs_plane, Ws_plane), with quad_keep: `stack` is the texel window at (y0, x0) of a plane of that size and the
+    quad grid lies over the whole plane (crop-aware training renders from a compact copy of the window, optim.WindowAdam)."""
+    rgb, alpha, _, _ = _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), False, quad_keep, cull_window)
     return rgb, alpha
 
 
@@ -172,7 +176,7 @@ def render_planes_with_smoothness(stack, homos, H, W, spec: RenderSpec = RenderS
     return rgb, alpha, sums
 
 
-def render_planes_with_regularisers(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0), quad_keep=None):
+def render_planes_with_regularisers(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0), quad_keep=None, cull_window=None):
     """(rgb, alpha, smooth_sums[4], alpha_sums[T,H,W,2]): render_planes_with_smoothness plus the per-pixel (sum_k a_k,
     sum_k a_k^2) the sparsity regulariser |a|_1/|a|_2 (MPV.py:511-515, MPI.py:599-603) is built from; all differentiable."""
-    return _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), True, quad_keep)
+    return _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), True, quad_keep, cull_window)

@@ -76,13 +76,13 @@ def quad_to_texel_mask(qmask, Hs, Ws):
     quad's closed rectangle grown by one texel)."""
     D, QH, QW = qmask.shape
     dev = qmask.device
-    ch, cw = (Hs - 1) / QH, (Ws - 1) / QW
-    y = torch.arange(Hs, device=dev, dtype=torch.float64)
-    x = torch.arange(Ws, device=dev, dtype=torch.float64)
-    ylo = ((y - 1) / ch).floor().clamp(0, QH - 1).long()
-    yhi = ((y + 1) / ch).floor().clamp(0, QH - 1).long()
-    xlo = ((x - 1) / cw).floor().clamp(0, QW - 1).long()
-    xhi = ((x + 1) / cw).floor().clamp(0, QW - 1).long()
+    y = torch.arange(Hs, device=dev, dtype=torch.int64)
+    x = torch.arange(Ws, device=dev, dtype=torch.int64)
+
+    def qi(a, S, n):        # floor(a * n / (S - 1)) clamped, in INTEGER arithmetic: the same side of a quad border as every HIP kernel
+        return torch.div(a * n, max(S - 1, 1), rounding_mode="floor").clamp(0, n - 1)
+    ylo, yhi = qi(y - 1, Hs, QH), qi(y + 1, Hs, QH)
+    xlo, xhi = qi(x - 1, Ws, QW), qi(x + 1, Ws, QW)
     rows_lo, rows_hi = qmask[:, ylo], qmask[:, yhi]              # D,Hs,QW
     return rows_lo[:, :, xlo] | rows_lo[:, :, xhi] | rows_hi[:, :, xlo] | rows_hi[:, :, xhi]
 
