@@ -7,8 +7,10 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 R=${1:-r02}
 O=gpurun_out/$R
 mkdir -p $O
+if [ "$2" != "pmc-only" ]; then
 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/trace.log 2>&1
+fi
 B="python profiles/pmc_target.py 50"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ttrace -o t -- $B > $O/ttrace.log 2>&1
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o p -- $B > $O/fetch.log 2>&1
@@ -19,6 +21,6 @@ timeout 400 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES
 for f in $O/*/p_counter_collection.csv; do head -1 $f > $f.tmp; grep -E "render_|bwd_|patchnn|vote_fold|robust_|video_to_pixel|adam_" $f >> $f.tmp; mv $f.tmp $f; done
 python profiles/summarize_pmc.py $O "" > $O/pmc_summary.txt
 rm -f $O/*/p_kernel_trace.csv $O/trace/t_kernel_trace.csv $O/ttrace/t_kernel_trace.csv $O/*/p_agent_info.csv $O/*/t_agent_info.csv
-cp $O/trace/t_kernel_stats.csv $O/kernel_stats_bench.csv
+[ -f $O/trace/t_kernel_stats.csv ] && cp $O/trace/t_kernel_stats.csv $O/kernel_stats_bench.csv
 cp $O/ttrace/t_kernel_stats.csv $O/kernel_stats_target.csv
-tail -c 1500 $O/bench.json
+ls $O/*/; tail -30 $O/pmc_summary.txt

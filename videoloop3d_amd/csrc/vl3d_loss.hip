@@ -409,7 +409,13 @@ __global__ __launch_bounds__(NTHR) void patchnn4_k(NN2Args a, int H_unused, int 
     const int nloc = min(NL4, a.w_o - bx0);
     const int tiles_j = a.TyP / TJ, ntiles = (a.TxP / TI) * tiles_j;
     const bool has_tile = tid < ntiles;
-    const int ti = has_tile ? (tid / tiles_j) * TI : 0, tj = has_tile ? (tid % tiles_j) * TJ : 0;
+    // thread -> frame-pair tile: y tiles fastest.  (19 y tiles for the shipped 75-frame clips put slots 16..18 of a ds_read_b128 lane
+    // group on the banks of slots 0..2 -- SQ_LDS_BANK_CONFLICT is 0.75-0.85 of the LDS-active cycles, profiles/r02_pmc_summary.txt --
+    // but the conflict-free alternative, x tiles fastest (13 <= 16), measured 1-3 % SLOWER in process (profiles/ab_loss.py, variant
+    // 0x80: ref 3.99 vs 3.96 ms, other 3.16 vs 3.07 ms): the LDS is not what this kernel waits for.  Kept selectable for A/B.)
+    const int tiles_i = a.TxP / TI;
+    const bool i_fast = (a.ablate & 8) && tiles_i <= 16 && tiles_j > 16;
+    const int ti = has_tile ? (i_fast ? tid % tiles_i : tid / tiles_j) * TI : 0, tj = has_tile ? (i_fast ? tid / tiles_i : tid % tiles_j) * TJ : 0;
     float acc[NL4][TI * TJ];
 #pragma unroll
     for (int l = 0; l < NL4; ++l)
@@ -906,7 +912,7 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
         b.xt = xt; b.yt = yt; b.nn = nn; b.W = desc->W; b.ps = a.ps; b.pt = a.pt; b.stride = a.stride; b.stridet = a.stridet;
         b.h_o = a.h_o; b.w_o = a.w_o; b.n1 = a.n1; b.n2 = a.n2; b.TxP = a.TxP; b.TyP = a.TyP; b.K = a.K; b.KC = a.KC;
         b.use_alpha = a.use_alpha; b.alpha = a.alpha; b.dnorm = a.inv_d;
-        b.ablate = (desc->variant >> 4) & 7;
+        b.ablate = (desc->variant >> 4) & 15;
         static bool attr2 = false;
         if (!attr2) {
             VL3D_HIP(hipFuncSetAttribute((const void *)patchnn2_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
