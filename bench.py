@@ -25,7 +25,7 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (measured here: 6.4 TB/s read-only and one-shot copy streams, profiles/microbench)
 
 
 def parse():
@@ -451,7 +451,7 @@ def main():
                                      "algorithmic_bytes": px * (32 * D + 12),
                                      "texel_footprint_bytes": tex * 32 * D + px * 12,      # every texel of the 1.1x stack is read and its gradient written
                                      "frac_texel_footprint": (tex * 32 * D + px * 12) / (b2 * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                    "roofline_fwd": {"kernel": "render_fwd2x_k + render_reg_fwd_k", "bound": "hbm", "avg_ms": f2,
+                    "roofline_fwd": {"kernel": "render_fwd_reg_k (render + regulariser sums in one pass)", "bound": "hbm", "avg_ms": f2,
                                      "achieved": px * (16 * D + 12) / (f2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": px * (16 * D + 12) / (f2 * 1e-3) / 1e9 / HBM_PEAK_GBS}}
                 del st2

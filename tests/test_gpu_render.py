@@ -700,12 +700,12 @@ def test_bwd_frame_pair_kernel_equals_tile_kernel_bitwise(dev, spec_name, stack_
     g_rgb = synth.hash_uniform((T, H, W, 3), seed=5, device=dev) - 0.5
     g_a = synth.hash_uniform((T, H, W), seed=6, device=dev) - 0.5
     out = {}
-    for variant in (0, 3, 5, 6, 7):    # 0: pairs on 64 x 8 regions, 5: pairs on 32 x 16 regions, 6 / 7: the same with the L2 prefetch, 3: one frame per thread
+    for variant in (0, 3, 5):          # 0: frame pairs, 5: frame pairs with the sampling pipelined one plane ahead, 3: one frame per thread
         rgb, alpha = render_planes(stack, homos, H, W, RenderSpec(variant=variant, **kw_p))
         (gs,) = torch.autograd.grad([rgb, alpha], stack, [g_rgb, g_a])
         assert _tile_ran() == 1
         out[variant] = gs
-    assert all(torch.equal(out[v], out[3]) for v in (0, 5, 6, 7))
+    assert all(torch.equal(out[v], out[3]) for v in (0, 5))
     assert float(out[0].float().abs().max()) > 1e-3
 
 

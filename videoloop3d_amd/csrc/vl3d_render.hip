@@ -232,7 +232,9 @@ static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, cons
     if (want_tile) {
         a.plan = (const float *)scratch;
         a.owner = reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(scratch) + owner_table_off(desc));
-        a.tile_rows = (desc->variant & 0xf) == 0 ? 17 : 16;     // 17: 16 rows, frame-pair kernels allowed
+        const int bv = desc->variant & 0xf;
+        a.tile_rows = (bv == 0 || bv == 5) ? 17 : 16;     // 17: 16 rows, frame-pair kernels allowed
+        a.pair_pipe = bv == 5;
     } else {
         a.plan = nullptr;
         a.tile_rows = 0;
