@@ -142,10 +142,11 @@ int vl3d_adam_step_tiles(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uin
  * next needed.  last_step: device int32 [D][ceil(Hs/16)][ceil(Ws/16)], the step each tile is current for (0 initially).
  * hist: device float2 [steps+1], entry t = (lr_t / (1 - beta1^t), sqrt(1 - beta2^t)) as vl3d_adam_step_scalars computes them,
  * written by the caller when step t is taken.
- *   vl3d_adam_window_catchup: bring the window's tiles current for step `upto` (replaying steps last_step+1 .. upto with g = 0) and,
- *     if compact != NULL, write the window's parameters to the compact (D,T,wh,ww,4) buffer the render then reads.
- *   vl3d_adam_window_step: the Adam update of step `step` on the window from the compact gradient (D,T,wh,ww,4); the window's tiles
- *     must be current for step-1 (catch-up first).  Everything outside the window stays deferred.
+ *   vl3d_adam_window_catchup: the window's parameters as of step `upto` (steps last_step+1 .. upto replayed with g = 0).  With
+ *     compact != NULL they are written to the compact (D,T,wh,ww,4) buffer the render then reads and the stack is left untouched;
+ *     with compact == NULL (a flush) they are written back and the tiles marked current.
+ *   vl3d_adam_window_step: replays the missed steps of the window's tiles up to step-1, then the Adam update of step `step` from the
+ *     compact gradient (D,T,wh,ww,4), writes (p, m, v) and marks the tiles.  Everything outside the window stays deferred.
  * A catch-up with the full plane as the window makes the whole stack current (checkpoints, lod, evaluation renders).
  * Tile-culled models (quad_keep / quad_dyn != NULL, device byte maps [D][QH][QW]): culled texels are no parameters (the compact copy
  * shows them as (0, 0, 0, culled_alpha)); a texel only static quads can read is ONE parameter stored in frame 0 -- the compact copy
@@ -158,8 +159,9 @@ int vl3d_adam_window_catchup(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32
                              float beta1, float beta2, float eps, float *compact, const uint8_t *quad_keep, const uint8_t *quad_dyn,
                              int32_t QH, int32_t QW, float culled_alpha, int32_t mirror_static, vl3d_stream_t stream);
 int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
-                          float *param, const float *grad_compact, float *exp_avg, float *exp_avg_sq, int32_t *last_step, float lr,
-                          float beta1, float beta2, float eps, int64_t step, const uint8_t *quad_keep, const uint8_t *quad_dyn,
+                          float *param, const float *grad_compact, float *exp_avg, float *exp_avg_sq, int32_t *last_step,
+                          const float *hist, float lr, float beta1, float beta2, float eps, int64_t step, const uint8_t *quad_keep,
+                          const uint8_t *quad_dyn,
                           int32_t QH, int32_t QW, int32_t static_tied, vl3d_stream_t stream);
 void vl3d_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, float *lr_bc1, float *bc2s);
 

@@ -49,7 +49,8 @@ def test_window_adam_equals_torch_adam_over_a_shuffled_window_schedule(dev):
         win = align_window(y0, y0 + r(10, 40), x0, x0 + r(10, 50), Hs, Ws)
         wy, wx, wh, ww = win
         leaf = ob.window_leaf(win)
-        assert torch.equal(leaf.detach(), pb.detach()[:, :, wy:wy + wh, wx:wx + ww])          # the leaf holds CURRENT parameters
+        # the leaf holds the CURRENT parameters (what torch's Adam has there now), the stack itself is not written before the step
+        assert float((leaf.detach() - pa.detach()[:, :, wy:wy + wh, wx:wx + ww]).abs().max()) <= 2e-6
         gc = (torch.rand((D, T, wh, ww, 4), generator=g) - 0.5).to(dev)
         gc[:, :, :3] = 0                     # texels with a zero gradient inside the window as well
         leaf.grad = gc

@@ -7,8 +7,10 @@
 // of every plane remembers the last step it is current for, and
 //   * adam_window_catchup_k (before the render) replays, in registers, the zero-gradient steps the tiles of the coming crop's
 //     window have missed -- the same fp32 operations in the same order as the dense update with g = 0 -- and hands the render a
-//     compact copy of the window (the render then writes a compact gradient: no zero fill of the other 3/4 either);
-//   * adam_window_step_k (after the backward) applies the current step to the window from the compact gradient;
+//     compact copy of the window with the CURRENT parameters (the render then writes a compact gradient: no zero fill of the
+//     other 3/4 either); nothing is written back to the stack at this point;
+//   * adam_window_step_k (after the backward) replays the same missed steps again (registers) and applies the current step to
+//     the window from the compact gradient: one read and one write of (p, m, v) per iteration;
 //   * a catch-up over the full stack brings everything current (checkpoints, lod(), evaluation renders).
 // Per-step scalars (lr / (1 - b1^t), sqrt(1 - b2^t)) come from a device table written by the host when the step is taken, so a
 // changing learning rate (train_3dvid.py:263-277) is replayed as it was.
@@ -25,6 +27,18 @@ __device__ __forceinline__ void adam_upd(float &pp, float gg, float &mm, float &
 }
 
 struct Win { int y0, x0, wh, ww; };
+
+// the zero-gradient steps from+1 .. upto of one texel, in registers (the dense update's operations with g = 0, in its order)
+__device__ __forceinline__ void replay(float4 &pp, float4 &mm, float4 &vv, const float2 *__restrict__ hist, int from, int upto, float beta1,
+                                       float beta2, float eps) {
+    for (int s = from + 1; s <= upto; ++s) {
+        const float2 h = hist[s];         // uniform: (lr / bc1, sqrt(bc2)) of step s
+        adam_upd(pp.x, 0.0f, mm.x, vv.x, h.x, beta1, beta2, eps, h.y);
+        adam_upd(pp.y, 0.0f, mm.y, vv.y, h.x, beta1, beta2, eps, h.y);
+        adam_upd(pp.z, 0.0f, mm.z, vv.z, h.x, beta1, beta2, eps, h.y);
+        adam_upd(pp.w, 0.0f, mm.w, vv.w, h.x, beta1, beta2, eps, h.y);
+    }
+}
 
 // tile-culled models (quad maps keep / dyn [D][QH][QW], MPI.py:288-442): 0 = culled texel (no kept quad can read it: no parameter),
 // 1 = dynamic (a parameter per frame), 2 = static (only static quads can read it: ONE parameter, living in frame 0 -- the reference's
@@ -45,7 +59,8 @@ __device__ __forceinline__ int texel_class(const Quads &q, int d, int x, int y, 
 __global__ __launch_bounds__(256) void adam_window_catchup_k(int T, int Hs, int Ws, Win w, float4 *__restrict__ p, float4 *__restrict__ m,
                                                              float4 *__restrict__ v, const int *__restrict__ last_step, int tiles_y, int tiles_x,
                                                              const float2 *__restrict__ hist, int upto, float beta1, float beta2, float eps,
-                                                             float4 *__restrict__ compact, Quads q, float culled_alpha, int mirror) {
+                                                             float4 *__restrict__ compact, Quads q, float culled_alpha, int mirror,
+                                                             int writeback) {
     const int lx = blockIdx.x * 64 + (threadIdx.x & 63), ly = blockIdx.y * 4 + (threadIdx.x >> 6), d = blockIdx.z;
     if (lx >= w.ww || ly >= w.wh) return;
     const int x = w.x0 + lx, y = w.y0 + ly;
@@ -62,14 +77,8 @@ __global__ __launch_bounds__(256) void adam_window_catchup_k(int T, int Hs, int 
         float4 pp = p[o];
         if (from < upto) {
             float4 mm = m[o], vv = v[o];
-            for (int s = from + 1; s <= upto; ++s) {
-                const float2 h = hist[s];
-                adam_upd(pp.x, 0.0f, mm.x, vv.x, h.x, beta1, beta2, eps, h.y);
-                adam_upd(pp.y, 0.0f, mm.y, vv.y, h.x, beta1, beta2, eps, h.y);
-                adam_upd(pp.z, 0.0f, mm.z, vv.z, h.x, beta1, beta2, eps, h.y);
-                adam_upd(pp.w, 0.0f, mm.w, vv.w, h.x, beta1, beta2, eps, h.y);
-            }
-            p[o] = pp; m[o] = mm; v[o] = vv;
+            replay(pp, mm, vv, hist, from, upto, beta1, beta2, eps);
+            if (writeback) { p[o] = pp; m[o] = mm; v[o] = vv; }
         }
         if (compact)
             for (int t = 0; t < T; ++t, oc += cframe) compact[oc] = pp;
@@ -84,23 +93,21 @@ __global__ __launch_bounds__(256) void adam_window_catchup_k(int T, int Hs, int 
     }
     for (int t = 0; t < T; ++t, o += frame, oc += cframe) {
         float4 pp = p[o], mm = m[o], vv = v[o];
-        for (int s = from + 1; s <= upto; ++s) {
-            const float2 h = hist[s];         // uniform: (lr / bc1, sqrt(bc2)) of step s
-            adam_upd(pp.x, 0.0f, mm.x, vv.x, h.x, beta1, beta2, eps, h.y);
-            adam_upd(pp.y, 0.0f, mm.y, vv.y, h.x, beta1, beta2, eps, h.y);
-            adam_upd(pp.z, 0.0f, mm.z, vv.z, h.x, beta1, beta2, eps, h.y);
-            adam_upd(pp.w, 0.0f, mm.w, vv.w, h.x, beta1, beta2, eps, h.y);
-        }
-        p[o] = pp; m[o] = mm; v[o] = vv;
+        replay(pp, mm, vv, hist, from, upto, beta1, beta2, eps);
+        if (writeback) { p[o] = pp; m[o] = mm; v[o] = vv; }
         if (compact) compact[oc] = pp;
     }
 }
 
 __global__ __launch_bounds__(256) void adam_window_step_k(int T, int Hs, int Ws, Win w, float4 *__restrict__ p, const float4 *__restrict__ g,
                                                           float4 *__restrict__ m, float4 *__restrict__ v, float lr_bc1, float beta1, float beta2,
-                                                          float eps, float bc2s, Quads q, int static_tied) {
+                                                          float eps, float bc2s, Quads q, int static_tied, const int *__restrict__ last_step,
+                                                          int tiles_y, int tiles_x, const float2 *__restrict__ hist, int step) {
     const int lx = blockIdx.x * 64 + (threadIdx.x & 63), ly = blockIdx.y * 4 + (threadIdx.x >> 6), d = blockIdx.z;
     if (lx >= w.ww || ly >= w.wh) return;
+    // the zero-gradient steps this texel's tile has not seen yet are replayed HERE, in front of the real step: the catch-up before
+    // the render only computed the current parameters for the compact copy and wrote nothing back (3 write streams fewer)
+    const int from = last_step[((size_t)d * tiles_y + (w.y0 + ly) / TS) * tiles_x + (w.x0 + lx) / TS];
     const size_t frame = (size_t)Hs * Ws, cframe = (size_t)w.wh * w.ww;
     size_t o = (size_t)d * T * frame + (size_t)(w.y0 + ly) * Ws + (w.x0 + lx), oc = (size_t)d * T * cframe + (size_t)ly * w.ww + lx;
     const int cls = texel_class(q, d, w.x0 + lx, w.y0 + ly, Hs, Ws);
@@ -112,6 +119,7 @@ __global__ __launch_bounds__(256) void adam_window_step_k(int T, int Hs, int Ws,
             gg.x += gt.x; gg.y += gt.y; gg.z += gt.z; gg.w += gt.w;
         }
         float4 pp = p[o], mm = m[o], vv = v[o];
+        replay(pp, mm, vv, hist, from, step - 1, beta1, beta2, eps);
         adam_upd(pp.x, gg.x, mm.x, vv.x, lr_bc1, beta1, beta2, eps, bc2s);
         adam_upd(pp.y, gg.y, mm.y, vv.y, lr_bc1, beta1, beta2, eps, bc2s);
         adam_upd(pp.z, gg.z, mm.z, vv.z, lr_bc1, beta1, beta2, eps, bc2s);
@@ -121,6 +129,7 @@ __global__ __launch_bounds__(256) void adam_window_step_k(int T, int Hs, int Ws,
     }
     for (int t = 0; t < T; ++t, o += frame, oc += cframe) {
         float4 pp = p[o], mm = m[o], vv = v[o];
+        replay(pp, mm, vv, hist, from, step - 1, beta1, beta2, eps);
         const float4 gg = g[oc];
         adam_upd(pp.x, gg.x, mm.x, vv.x, lr_bc1, beta1, beta2, eps, bc2s);
         adam_upd(pp.y, gg.y, mm.y, vv.y, lr_bc1, beta1, beta2, eps, bc2s);
@@ -163,27 +172,31 @@ extern "C" int vl3d_adam_window_catchup(int32_t D, int32_t T, int32_t Hs, int32_
     hipLaunchKernelGGL(adam_window_catchup_k, dim3((ww + 63) / 64, (wh + 3) / 4, D), dim3(256), 0, s, T, Hs, Ws, Win{y0, x0, wh, ww},
                        reinterpret_cast<float4 *>(param), reinterpret_cast<float4 *>(exp_avg), reinterpret_cast<float4 *>(exp_avg_sq), last_step,
                        tiles_y, tiles_x, reinterpret_cast<const float2 *>(hist), upto, beta1, beta2, eps, reinterpret_cast<float4 *>(compact),
-                       Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW}, culled_alpha, mirror_static);
-    const int nty = (y0 + wh + TS - 1) / TS - y0 / TS, ntx = (x0 + ww + TS - 1) / TS - x0 / TS;
-    hipLaunchKernelGGL(mark_tiles_k, dim3((D * nty * ntx + 255) / 256), dim3(256), 0, s, last_step, tiles_y, tiles_x, y0 / TS, x0 / TS, nty, ntx, D, upto);
+                       Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW}, culled_alpha, mirror_static, compact ? 0 : 1);
+    if (!compact) {      // a flush writes the replayed state back and marks the tiles; a catch-up for a render only fills the compact copy
+        const int nty = (y0 + wh + TS - 1) / TS - y0 / TS, ntx = (x0 + ww + TS - 1) / TS - x0 / TS;
+        hipLaunchKernelGGL(mark_tiles_k, dim3((D * nty * ntx + 255) / 256), dim3(256), 0, s, last_step, tiles_y, tiles_x, y0 / TS, x0 / TS, nty, ntx, D, upto);
+    }
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
 }
 
 extern "C" int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
                                      float *param, const float *grad_compact, float *exp_avg, float *exp_avg_sq, int32_t *last_step,
-                                     float lr, float beta1, float beta2, float eps, int64_t step, const uint8_t *quad_keep,
-                                     const uint8_t *quad_dyn, int32_t QH, int32_t QW, int32_t static_tied, vl3d_stream_t stream) {
+                                     const float *hist, float lr, float beta1, float beta2, float eps, int64_t step,
+                                     const uint8_t *quad_keep, const uint8_t *quad_dyn, int32_t QH, int32_t QW, int32_t static_tied,
+                                     vl3d_stream_t stream) {
     int rc = check_window(D, T, Hs, Ws, y0, x0, wh, ww);
     if (rc != VL3D_OK) return rc;
-    VL3D_REQUIRE(param && grad_compact && exp_avg && exp_avg_sq && last_step && step >= 1, "vl3d_adam_window_step: null pointer / bad step");
+    VL3D_REQUIRE(param && grad_compact && exp_avg && exp_avg_sq && last_step && hist && step >= 1, "vl3d_adam_window_step: null pointer / bad step");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     const int tiles_y = (Hs + TS - 1) / TS, tiles_x = (Ws + TS - 1) / TS;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_window_step_k, dim3((ww + 63) / 64, (wh + 3) / 4, D), dim3(256), 0, s, T, Hs, Ws, Win{y0, x0, wh, ww},
                        reinterpret_cast<float4 *>(param), reinterpret_cast<const float4 *>(grad_compact), reinterpret_cast<float4 *>(exp_avg),
                        reinterpret_cast<float4 *>(exp_avg_sq), (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2),
-                       Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW}, static_tied);
+                       Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW}, static_tied, last_step, tiles_y, tiles_x,
+                       reinterpret_cast<const float2 *>(hist), (int)step);
     const int nty = (y0 + wh + TS - 1) / TS - y0 / TS, ntx = (x0 + ww + TS - 1) / TS - x0 / TS;
     hipLaunchKernelGGL(mark_tiles_k, dim3((D * nty * ntx + 255) / 256), dim3(256), 0, s, last_step, tiles_y, tiles_x, y0 / TS, x0 / TS, nty, ntx, D, (int)step);
     VL3D_CHECK_LAUNCH();

@@ -3,11 +3,12 @@
 `WindowAdam` produces the parameters torch.optim.Adam(betas, eps; no amsgrad / weight decay) would produce -- to fp32 rounding of
 the one-pass update -- while touching only the texels the current training crop can reach:
 
-  forward   `window_leaf(p, window)` brings the window's 16 x 16-texel tiles up to date (replaying, in registers, the zero-gradient
-            Adam steps they have missed: momentum keeps moving a texel after its gradient is gone) and returns a compact
-            (D,T,wh,ww,4) copy of the window as an autograd LEAF; the render reads it and the backward fills its .grad --
-            a compact gradient, no zero fill of the rest of the stack.
-  step()    applies the step to the window from that compact gradient; every other tile's update is deferred.
+  forward   `window_leaf(window)` computes the window's CURRENT parameters (replaying, in registers, the zero-gradient Adam steps its
+            16 x 16-texel tiles have missed: momentum keeps moving a texel after its gradient is gone) into a compact (D,T,wh,ww,4)
+            copy, an autograd LEAF; the render reads it and the backward fills its .grad -- a compact gradient, no zero fill of the
+            rest of the stack.  The stack itself is not written.
+  step()    replays the same missed steps again and applies the step to the window from that compact gradient: (p, m, v) of the
+            window are read once and written once per iteration; every other tile's update stays deferred.
   flush()   replays everything outstanding (before checkpoints, lod(), evaluation renders; MPMeshVid calls it).
 
 Without a pending window (someone filled `p.grad` densely) step() falls back to the dense update: flush + full-window step.
@@ -135,8 +136,7 @@ class WindowAdam(torch.optim.Optimizer):
         st["hist"][t, 0].fill_(a.value)                   # scalars travel as kernel arguments: no host-to-device copy, no sync
         st["hist"][t, 1].fill_(b.value)
         D, T, Hs, Ws, _ = p.shape
-        if dense:
-            self._catchup((0, 0, Hs, Ws), self.t, None)
+        if dense:        # (the step kernel replays what is outstanding itself: no flush needed first)
             window, g = (0, 0, Hs, Ws), (p.grad if p.grad.is_contiguous() else p.grad.contiguous())
         else:
             window, g = pending[0], pending[1].grad
@@ -146,7 +146,7 @@ class WindowAdam(torch.optim.Optimizer):
         qk, qd, QH, QW = self._quads()
         with torch.cuda.device(p.device):
             L.check(L.lib().vl3d_adam_window_step(D, T, Hs, Ws, y0, x0, wh, ww, L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
-                                                  L.ptr(st["last_step"]), lr, float(b1), float(b2), eps, t, qk, qd, QH, QW,
+                                                  L.ptr(st["last_step"]), L.ptr(st["hist"]), lr, float(b1), float(b2), eps, t, qk, qd, QH, QW,
                                                   1 if (dense and qk is not None) else 0,      # a dense p.grad of a sparsified model went through the tie hook
                                                   L.stream_ptr(p.device)),
                     "vl3d_adam_window_step")
