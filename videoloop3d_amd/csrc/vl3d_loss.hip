@@ -11,6 +11,7 @@
 // dist[i,j] = sum_kt E[i*st+kt, j*st+kt] / (3*pt*ps^2): pt-fold fewer flops than the patch-level Gram and
 // no |x|^2+|y|^2-2xy cancellation (never negative).
 #include "vl3d_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -696,10 +697,9 @@ __global__ __launch_bounds__(256) void vote_fold_k(FoldArgs a) {
 // frames) and the NN indices of every patch location covering the tile are staged in LDS once; each thread then produces
 // its pixel's whole temporal column (all Tx frames) from LDS: the gather of utils_vid.py:217 + FoldNd (:218-227) without
 // any scattered global access.  (v1 -- one thread per voxel reading y and nn through L2 -- measured 12.3 ms at 720p.)
-constexpr int FT_H = 8, FT_NT = 1024;   // tile of FT_W x 8 pixels x FT_G temporal groups = 1024 threads (16 waves hide the LDS chains)
-// FT_W = 32 (x 4 groups) by default; 16 / 8 (x 8 / 16 groups) when Ty frames of a 32-wide tile do not fit LDS (cfg4 / cfg5 clips)
+// Tile shapes (FT_W x FT_H pixels, FT_NT threads = pixels x FT_G temporal groups): see fold_shapes[] below.
 
-template <int FT_W>
+template <int FT_W, int FT_H, int FT_NT>
 __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NP = FT_W * FT_H, FT_G = FT_NT / NP, NT = FT_NT;
@@ -716,12 +716,21 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
     // stage y[c, :, tile] (row segments of FT_W floats) and the nn indices
     const bool inb = (xi < a.W) && (eta < a.H);
     const float *ysrc = a.y + (int64_t)c * a.y_sc + (int64_t)min(eta, a.H - 1) * a.y_sr + min(xi, a.W - 1);
-#pragma unroll 4
+    // Each temporal group owns a contiguous run of frames (see below).  The x values the fused loss needs do not depend on the
+    // staging: the first four of this thread's column are requested BEFORE it and the rest stay four frames ahead of their use, so
+    // the column's global reads are never exposed one by one between the LDS chains.
+    const bool slide = (a.pt == 3 && a.stridet == 1);
+    const int chunk = (a.Tx + FT_G - 1) / FT_G, t0 = slide ? grp * chunk : grp, t1 = slide ? min(a.Tx, t0 + chunk) : a.Tx;
+    const int tstep = slide ? 1 : FT_G;
+    const float *xsrc = a.x ? a.x + (int64_t)c * a.x_sc + (int64_t)min(eta, a.H - 1) * a.x_sr + min(xi, a.W - 1) : nullptr;
+    auto xload = [&](int t) -> float { return (xsrc && t < t1) ? xsrc[(int64_t)t * a.x_st] : 0.f; };
+    float xq0 = xload(t0), xq1 = xload(t0 + tstep), xq2 = xload(t0 + 2 * tstep), xq3 = xload(t0 + 3 * tstep);
+#pragma unroll 8
     for (int f = grp; f < Ty; f += FT_G) ys[f * NP + pix] = ysrc[(int64_t)f * a.y_st];
     for (int i = tid; i < nby * nbx * a.n1; i += NT) {
         const int ii = i % a.n1, b = i / a.n1;
         const int bx = b % nbx, by = b / nbx;
-        nns[i] = a.nn[((size_t)(tby0 + by) * a.w_o + (tbx0 + bx)) * a.n1 + ii];
+        nns[i] = a.nn[((size_t)(tby0 + by) * a.w_o + (tbx0 + bx)) * a.n1 + ii] * (slide ? NP : 1);
     }
     __syncthreads();
     float lacc = 0.f;
@@ -738,10 +747,8 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
     // votes are accumulated patch-major: patch i votes for frames i, i+1, i+2, so its NN index is read from LDS ONCE and the
     // three frame sums slide through registers (w0 = frame i, complete after patch i) -- a third of the index reads and of the
     // address arithmetic of the frame-major form below, and the same summation order per frame (kt = 2, 1, 0 -> patches i-2, i-1, i).
-    const bool slide = (a.pt == 3 && a.stridet == 1);
-    const int chunk = (a.Tx + FT_G - 1) / FT_G, t0 = slide ? grp * chunk : grp, t1 = slide ? min(a.Tx, t0 + chunk) : a.Tx;
     float w0 = 0.f, w1 = 0.f, w2 = 0.f;
-    for (int tau = slide ? t0 - 2 : t0; tau < t1; tau += slide ? 1 : FT_G) {
+    for (int tau = slide ? t0 - 2 : t0; tau < t1; tau += tstep) {
         float s = 0.f;
         int cnt = 0;
         if (slide) {
@@ -751,7 +758,7 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
                 for (int by = by_lo; by <= by_hi; ++by, nrow += nbx * a.n1) {
                     const int *np = nrow;
                     for (int bx = bx_lo; bx <= bx_hi; ++bx, np += a.n1) {
-                        const float *yp = ysp + *np * NP;
+                        const float *yp = ysp + *np;                    // staged as index * NP
                         w0 += yp[0]; w1 += yp[NP]; w2 += yp[2 * NP];
                     }
                 }
@@ -778,7 +785,8 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
         out[(size_t)tau * fs] = v;
         if (c == 0) wout[(size_t)tau * fs] = wgt;
         if (a.x) {      // robust_lossfun(x - y2x) and its derivative while y2x is in a register (utils_vid.py:348)
-            const float e = a.x[(int64_t)c * a.x_sc + (int64_t)tau * a.x_st + (int64_t)eta * a.x_sr + xi] - v;
+            const float e = xq0 - v;
+            xq0 = xq1; xq1 = xq2; xq2 = xq3; xq3 = xload(tau + 4 * tstep);
             float f, g;
             rho_fg(a.rho, e, f, g);
             lacc += f;
@@ -983,29 +991,57 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
     return VL3D_OK;
 }
 
-// LDS-staged fold: widest tile whose y columns (all Ty frames) + nn indices fit; 0 = none does
-static size_t fold_lds_bytes(const vl3d_loss_desc *desc, int n1, int fw) {
-    const int nby_max = (FT_H + desc->ps - 2) / desc->stride + 2, nbx_max = (fw + desc->ps - 2) / desc->stride + 2;
-    return ((size_t)desc->Ty * fw * FT_H + (size_t)nby_max * nbx_max * n1) * sizeof(float);
+// LDS-staged fold: tile shapes {FT_W, FT_H, threads}.  The whole Ty column of a tile has to sit in LDS (an NN index may point at
+// any frame), so the tile area sets the LDS footprint and with it how many workgroups share a CU.  A 32x8 tile of a 75-frame clip
+// (77 KiB + indices) runs ONE workgroup per CU, whose staging and voting phases never overlap with another's: 1.55 ms at 720p.
+// 64x2 (three workgroups per CU, 256-byte row segments) measured 1.20 ms, 32x4 1.27, 32x2 1.28, 64x1 1.60 in one process
+// (profiles/ab_fold.py; outputs bit-equal across shapes).  The narrower shapes are for clips whose columns do not fit otherwise.
+struct FoldShape { int fw, fh, nt; };
+static const FoldShape fold_shapes[] = {{64, 2, 512}, {32, 4, 512}, {32, 2, 256}, {64, 1, 256}, {32, 1, 256}};
+constexpr int N_FOLD_SHAPES = sizeof(fold_shapes) / sizeof(fold_shapes[0]);
+// most patch locations b (b*stride <= last, b*stride + ps - 1 >= first) covering a span of f pixels that starts at a multiple of f
+static int fold_cover(int f, int ps, int stride) {
+    int most = 0;
+    for (int k = 0; k < stride; ++k) {
+        const int first = (k + stride * ps) * f, last = first + f - 1;      // every residue of the tile origin, away from the border
+        most = std::max(most, last / stride - (first - ps + stride) / stride + 1);
+    }
+    return most;
 }
-static int fold_tile_width(const vl3d_loss_desc *desc, int n1) {
-    for (int fw : {32, 16, 8})
-        if (fold_lds_bytes(desc, n1, fw) <= 150 * 1024) return fw;
-    return 0;
+static size_t fold_lds_bytes(const vl3d_loss_desc *desc, int n1, const FoldShape &sh) {
+    const int nby_max = fold_cover(sh.fh, desc->ps, desc->stride), nbx_max = fold_cover(sh.fw, desc->ps, desc->stride);
+    return ((size_t)desc->Ty * sh.fw * sh.fh + (size_t)nby_max * nbx_max * n1) * sizeof(float);
 }
-template <int FW>
-static int launch_fold_lds(const vl3d_loss_desc *desc, const FoldArgs &a, hipStream_t s) {
+// -1 = no shape fits.  First choice: the first shape that leaves room for three workgroups per CU, then two, then one.
+// variant bits 12-15 (measurement hook): shape index + 1
+static int fold_shape(const vl3d_loss_desc *desc, int n1) {
+    const int forced = ((desc->variant >> 12) & 15) - 1;
+    if (forced >= 0 && forced < N_FOLD_SHAPES && fold_lds_bytes(desc, n1, fold_shapes[forced]) <= 150 * 1024) return forced;
+    for (size_t budget : {53 * 1024, 79 * 1024, 150 * 1024})
+        for (int i = 0; i < N_FOLD_SHAPES; ++i)
+            if (fold_lds_bytes(desc, n1, fold_shapes[i]) <= budget) return i;
+    return -1;
+}
+template <int FW, int FH, int NT>
+static int launch_fold_lds(const vl3d_loss_desc *desc, const FoldArgs &a, size_t lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        VL3D_HIP(hipFuncSetAttribute((const void *)vote_fold_lds_k<FW>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        VL3D_HIP(hipFuncSetAttribute((const void *)vote_fold_lds_k<FW, FH, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
         attr_set = true;
     }
-    dim3 grid((desc->W + FW - 1) / FW, (desc->H + FT_H - 1) / FT_H, 3);
-    hipLaunchKernelGGL(vote_fold_lds_k<FW>, grid, dim3(FT_NT), fold_lds_bytes(desc, a.n1, FW), s, a, desc->Ty);
+    dim3 grid((desc->W + FW - 1) / FW, (desc->H + FH - 1) / FH, 3);
+    hipLaunchKernelGGL((vote_fold_lds_k<FW, FH, NT>), grid, dim3(NT), lds, s, a, desc->Ty);
     return VL3D_OK;
 }
-static int launch_fold_lds_w(int fw, const vl3d_loss_desc *desc, const FoldArgs &a, hipStream_t s) {
-    return fw == 32 ? launch_fold_lds<32>(desc, a, s) : (fw == 16 ? launch_fold_lds<16>(desc, a, s) : launch_fold_lds<8>(desc, a, s));
+static int launch_fold_lds_w(int shape, const vl3d_loss_desc *desc, const FoldArgs &a, hipStream_t s) {
+    const size_t lds = fold_lds_bytes(desc, a.n1, fold_shapes[shape]);
+    switch (shape) {
+    case 0: return launch_fold_lds<64, 2, 512>(desc, a, lds, s);
+    case 1: return launch_fold_lds<32, 4, 512>(desc, a, lds, s);
+    case 2: return launch_fold_lds<32, 2, 256>(desc, a, lds, s);
+    case 3: return launch_fold_lds<64, 1, 256>(desc, a, lds, s);
+    default: return launch_fold_lds<32, 1, 256>(desc, a, lds, s);
+    }
 }
 
 extern "C" int vl3d_vote_fold(const vl3d_loss_desc *desc, const float *y, const int32_t *nn, float *sum, float *weight,
@@ -1024,9 +1060,9 @@ extern "C" int vl3d_vote_fold(const vl3d_loss_desc *desc, const float *y, const 
     a.y_sc = desc->y_sc; a.y_st = desc->y_st; a.y_sr = desc->y_sr;
     a.normalize = normalize;
     // LDS-staged kernel when a tile's y columns + nn indices fit (32 wide for every shipped configuration, narrower for long clips)
-    const int fw = fold_tile_width(desc, a.n1);
-    if (desc->variant != 1 && fw) {
-        rc = launch_fold_lds_w(fw, desc, a, (hipStream_t)stream);
+    const int shape = fold_shape(desc, a.n1);
+    if ((desc->variant & 0xf) != 1 && shape >= 0) {
+        rc = launch_fold_lds_w(shape, desc, a, (hipStream_t)stream);
         if (rc != VL3D_OK) return rc;
     } else {
         dim3 grid((desc->W + 63) / 64, (desc->H + 3) / 4, desc->Tx);
@@ -1057,13 +1093,13 @@ extern "C" int vl3d_vote_fold_robust(const vl3d_loss_desc *desc, const float *y,
     a.rho = make_rho(kind, rou, scale);
     a.gscale = 1.0f / (3.0f * (float)desc->Tx * (float)desc->H * (float)desc->W);     // d(mean)/d(element)
     a.gx = grad_x; a.loss_sum = loss_sum;
-    const int fw = fold_tile_width(desc, a.n1);
-    if (!fw) {
+    const int shape = fold_shape(desc, a.n1);
+    if (shape < 0) {
         vl3d_set_error("vl3d_vote_fold_robust: tile does not fit LDS; use vl3d_vote_fold + vl3d_robust_fwd/bwd");
         return VL3D_EUNSUPPORTED;
     }
     VL3D_HIP(hipMemsetAsync(loss_sum, 0, sizeof(double), (hipStream_t)stream));
-    rc = launch_fold_lds_w(fw, desc, a, (hipStream_t)stream);
+    rc = launch_fold_lds_w(shape, desc, a, (hipStream_t)stream);
     if (rc != VL3D_OK) return rc;
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
