@@ -215,10 +215,11 @@ def test_g6_get_nn_indices_low_memory(dev, golden):
     assert maxabs(extract_3Dpatches(ramp, 5, 2, 4, 2), g5["p_5_2_4_2"]) == 0
 
 
-@pytest.mark.parametrize("variant", ["1", "2", "3"])
+@pytest.mark.parametrize("variant", ["1", "2", "3", "4"])
 def test_patchnn_kernel_variants_agree(dev, variant, monkeypatch):
-    """v1 (strided staging), v2 (pixel-major staging, VALU direct SSD, the default) and v3 (MFMA frame-Gram,
-    |x|^2+|y|^2-2G like the reference) pick the same neighbours up to exact-distance near-ties."""
+    """v1 (strided staging), v2 (pixel-major staging, one location per workgroup), v4 (four locations per workgroup, VALU direct SSD)
+    and v5 = variant 3 (the same workgroup on the matrix cores, |x|^2+|y|^2-2x.y like the reference; the default where it applies)
+    pick the same neighbours up to exact-distance near-ties."""
     from videoloop3d_amd.utils_vid import _nn_and_fold
     monkeypatch.setenv("VL3D_LOSS_VARIANT", variant)
     x = synth.make_video(12, 43, 51, seed=3)

@@ -265,123 +265,83 @@ __global__ __launch_bounds__(NN_THREADS) void patchnn2_k(NN2Args a) {
 
 
 
-// ---------------------------------------------------------------------------------------------------
-// K3 v3: frame-pair Gram on the matrix cores.  G[i',j'] = sum_k X[i',k] Y[j',k] over k = (pixel, channel) of the
-// location is a dense [Tx x K] x [K x Ty] contraction (K = 3 ps^2 = 363 for the ref-view configuration): it runs on
-// v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain, same rate as the f32 vector peak but 1 operand VGPR per 64 MACs instead
-// of 2 LDS reads per 16), then  E = |x|^2 + |y|^2 - 2G  like the reference's own |x|^2+|y|^2-2xy form
-// (utils_vid.py:82) but still per FRAME pair (the temporal diagonal sum follows in the shared epilogue).
-// Wave w owns the 16-row strip w of E and all TyP/16 column tiles; operands are read from the k-major LDS chunk.
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-constexpr int MF_MAXJT = 8;   // up to 128 y frames per location in this kernel
-
-__global__ __launch_bounds__(NN_THREADS) void patchnn3_k(NN2Args a, int TyT) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Xs = smem;                                   // [KC][TxP]   (KC multiple of 4)
-    float *Ys = Xs + (size_t)a.KC * a.TxP;              // [KC][TyP]
-    float *E = Ys + (size_t)a.KC * a.TyP;               // [64][TyT*16]  (padded tiles; also absorbs operand over-reads)
-    const int EP = TyT * 16;
-    float *colmin = E + (size_t)64 * EP;
-    float *nrm = colmin + a.n2;                         // [64 + EP] squared norms of the x / y frames
-    const int b = blockIdx.x, by = b / a.w_o, bx = b % a.w_o;
-    const int r0 = by * a.stride, c0 = bx * a.stride, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rowk = a.ps * 3, x4 = a.TxP / 4, y4 = a.TyP / 4;
-    f32x4_t acc[MF_MAXJT];
-#pragma unroll
-    for (int j = 0; j < MF_MAXJT; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float nacc = 0.f;                                    // thread tid < TxP: |x frame tid|^2 ; TxP <= tid < TxP+TyP: y frames
-    for (int k0 = 0; k0 < a.K; k0 += a.KC) {
-        const int kc = min(a.KC, a.K - k0), kc4 = (kc + 3) & ~3;
-        __syncthreads();
-        for (int i = tid; i < kc4 * x4; i += NN_THREADS) {
-            const int kk = i / x4, f4 = i - kk * x4, k = k0 + kk, r = k / rowk, rem = k - r * rowk;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kk < kc && !(a.ablate & 4)) v = reinterpret_cast<const float4 *>(a.xt + (((size_t)(r0 + r) * a.W + c0) * 3 + rem) * a.TxP)[f4];
-            reinterpret_cast<float4 *>(Xs + (size_t)kk * a.TxP)[f4] = v;
-        }
-        for (int i = tid; i < kc4 * y4; i += NN_THREADS) {
-            const int kk = i / y4, f4 = i - kk * y4, k = k0 + kk, r = k / rowk, rem = k - r * rowk;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kk < kc && !(a.ablate & 4)) v = reinterpret_cast<const float4 *>(a.yt + (((size_t)(r0 + r) * a.W + c0) * 3 + rem) * a.TyP)[f4];
-            reinterpret_cast<float4 *>(Ys + (size_t)kk * a.TyP)[f4] = v;
-        }
-        __syncthreads();
-        if (tid < a.TxP + a.TyP) {
-            const float *col = tid < a.TxP ? Xs + tid : Ys + (tid - a.TxP);
-            const int pitch = tid < a.TxP ? a.TxP : a.TyP;
-            for (int kk = 0; kk < kc; ++kk) { const float v = col[kk * pitch]; nacc += v * v; }
-        }
-        const float *xa = Xs + (lane >> 4) * a.TxP + wave * 16 + (lane & 15);
-        const float *yb = Ys + (lane >> 4) * a.TyP + (lane & 15);
-        if (!(a.ablate & 2))
-        for (int kk = 0; kk < kc4; kk += 4) {
-            const float av = xa[kk * a.TxP];
-#pragma unroll
-            for (int j = 0; j < MF_MAXJT; ++j)
-                if (j < TyT) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, yb[kk * a.TyP + j * 16], acc[j], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    if (tid < a.TxP + a.TyP) nrm[tid < a.TxP ? tid : 64 + (tid - a.TxP)] = nacc;
-    __syncthreads();
-    // C/D layout of the 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg
-#pragma unroll
-    for (int j = 0; j < MF_MAXJT; ++j)
-        if (j < TyT) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wave * 16 + (lane >> 4) * 4 + r, col = j * 16 + (lane & 15);
-                E[row * EP + col] = fmaxf(nrm[row] + nrm[64 + col] - 2.0f * acc[j][r], 0.0f);
-            }
-        }
-    __syncthreads();
-    if (a.ablate & 1) { if (tid < a.n1) a.nn[(size_t)b * a.n1 + tid] = 0; return; }
-    const int sub = tid & 3;
+// colmin + argmin over one location's frame-pair energies E [TxP][TyP] in LDS (utils_vid.py:133-141): with s(i, j) = sum_kt E(i + kt, j + kt),
+// the reference's score is (s / d) / (alpha + min_i s / d); first minimum wins, NaN counts as minimal (torch.argmin).  Scaling by a
+// positive constant commutes with min and argmin, so the column minimum is taken over the raw sums and each column gets ONE weight
+// w_j = (1 / d) / (alpha + min_i s / d): a score is s * w_j -- three LDS reads, two adds and a multiply per frame pair instead of two
+// fp32 divisions (which were most of the epilogue's instructions).  Without alpha the raw sums are compared.  The rounding differs
+// from the reference's two divisions by an ulp, i.e. only between exact near-ties.  Whole workgroup, 4 lanes per row / column.
+template <int NTHR>
+__device__ __forceinline__ void nn_epilogue(const NN2Args &a, const float *E, float *colw, size_t b, int tid, int sub) {
     if (a.use_alpha) {
-        for (int j = tid >> 2; j < a.n2; j += NN_THREADS / 4) {
+        const float inv_d = 1.0f / a.dnorm;
+        for (int j = tid >> 2; j < a.n2; j += NTHR / 4) {
             float m = INFINITY;
-            for (int i = sub; i < a.n1; i += 4) {
+            const float *e0 = E + j * a.stridet;
+            // four rows per batch: their LDS reads are in flight together (the workgroup is four waves: nothing else hides the latency)
+            int i = sub;
+            for (; i + 12 < a.n1; i += 16) {
+                float sa[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int kt = 0; kt < a.pt; ++kt)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) sa[u] += e0[((i + 4 * u) * a.stridet + kt) * a.TyP + kt];
+                m = fminf(fminf(m, fminf(sa[0], sa[1])), fminf(sa[2], sa[3]));
+            }
+            for (; i < a.n1; i += 4) {
                 float sacc = 0.f;
-                for (int kt = 0; kt < a.pt; ++kt) sacc += E[(i * a.stridet + kt) * EP + j * a.stridet + kt];
-                m = fminf(m, sacc / a.dnorm);
+                for (int kt = 0; kt < a.pt; ++kt) sacc += e0[(i * a.stridet + kt) * a.TyP + kt];
+                m = fminf(m, sacc);
             }
             m = fminf(m, __shfl_xor(m, 1, 64));
             m = fminf(m, __shfl_xor(m, 2, 64));
-            if (sub == 0) colmin[j] = a.alpha + m;
+            if (sub == 0) colw[j] = inv_d / (a.alpha + m / a.dnorm);
         }
         __syncthreads();
     }
-    for (int i0 = 0; i0 < a.n1; i0 += NN_THREADS / 4) {
+    for (int i0 = 0; i0 < a.n1; i0 += NTHR / 4) {      // uniform trip count: every lane takes part in the shuffles
         const int i = i0 + (tid >> 2);
-        const int q = (a.n2 + 3) / 4, j0 = sub * q, j1 = min(a.n2, j0 + q);
+        const int qn = (a.n2 + 3) / 4, j0 = sub * qn, j1 = min(a.n2, j0 + qn);
         float best = INFINITY;
         int bj = j0;
         bool best_nan = false;
         if (i < a.n1) {
-            for (int j = j0; j < j1; ++j) {
+            const float *e0 = E + (i * a.stridet) * a.TyP;
+            int j = j0;
+            for (; j + 3 < j1; j += 4) {                       // four columns per batch, compared in ascending order
+                float sa[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int kt = 0; kt < a.pt; ++kt)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) sa[u] += e0[kt * a.TyP + (j + u) * a.stridet + kt];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float v = a.use_alpha ? sa[u] * colw[j + u] : sa[u];
+                    const bool vn = (v != v);
+                    if (!best_nan && (vn || v < best)) { best = v; bj = j + u; best_nan = vn; }
+                }
+            }
+            for (; j < j1; ++j) {
                 float sacc = 0.f;
-                for (int kt = 0; kt < a.pt; ++kt) sacc += E[(i * a.stridet + kt) * EP + j * a.stridet + kt];
-                float v = sacc / a.dnorm;
-                if (a.use_alpha) v = v / colmin[j];
+                for (int kt = 0; kt < a.pt; ++kt) sacc += e0[kt * a.TyP + j * a.stridet + kt];
+                const float v = a.use_alpha ? sacc * colw[j] : sacc;
                 const bool vn = (v != v);
                 if (!best_nan && (vn || v < best)) { best = v; bj = j; best_nan = vn; }
             }
         }
+        // combine the 4 quarters in ascending-j order so that ties keep the lowest index
 #pragma unroll
         for (int step = 1; step <= 2; step <<= 1) {
             const float ob = __shfl_xor(best, step, 64);
             const int oj = __shfl_xor(bj, step, 64);
             const int on = __shfl_xor((int)best_nan, step, 64);
-            const bool other_lower = (sub & step) != 0;
+            const bool other_lower = (sub & step) != 0;      // the partner holds the lower-j range
             bool take;
             if (best_nan || on) take = on && (!best_nan || other_lower);
             else take = (ob < best) || (ob == best && other_lower);
             if (take) { best = ob; bj = oj; best_nan = on != 0; }
         }
-        if (i < a.n1 && sub == 0) a.nn[(size_t)b * a.n1 + i] = bj;
+        if (i < a.n1 && sub == 0) a.nn[b * a.n1 + i] = bj;
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------------
 // K3 v4: NL = 4 neighbouring patch locations per workgroup, column-sum formulation.
@@ -496,49 +456,215 @@ __global__ __launch_bounds__(NTHR) void patchnn4_k(NN2Args a, int H_unused, int 
         }
         __syncthreads();
         const size_t b = (size_t)by * a.w_o + bx0 + l;
-        if (a.use_alpha) {
-            for (int j = tid >> 2; j < a.n2; j += NTHR / 4) {
-                float m = INFINITY;
-                for (int i = sub; i < a.n1; i += 4) {
-                    float sacc = 0.f;
-                    for (int kt = 0; kt < a.pt; ++kt) sacc += E[(i * a.stridet + kt) * a.TyP + j * a.stridet + kt];
-                    m = fminf(m, sacc / a.dnorm);
-                }
-                m = fminf(m, __shfl_xor(m, 1, 64));
-                m = fminf(m, __shfl_xor(m, 2, 64));
-                if (sub == 0) colmin[j] = a.alpha + m;
-            }
-            __syncthreads();
+        nn_epilogue<NTHR>(a, E, colmin, b, tid, sub);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3 v5: the v4 workgroup (NL neighbouring locations, one staged region row at a time, running sums along the row, E through the
+// shared epilogue) with the frame-pair energies on the matrix cores.  The reference forms its distances as |x|^2 + |y|^2 - 2 x.y in
+// fp32 (utils_vid.py:82); per frame pair and region column q that is, over the channels c,
+//     e_q(ti, tj) = sum_c u_c(ti)^2  +  sum_c v_c(tj)^2  -  2 sum_c u_c(ti) v_c(tj),      u = x - 1/2, v = y - 1/2
+// (the shift cancels in x - y and keeps the three terms four times smaller for data in [0, 1]).  v_mfma_f32_16x16x4_f32 contracts
+// FOUR k per issue and a pixel has three channels: the fourth slot carries A = sum_c u_c^2, B = 1, so that ONE issue per column and
+// 16x16 frame-pair tile accumulates  s_x - 2 u.v  exactly as an fp32 FMA chain -- 64 frame pairs x 3 channels per lane-cycle slot
+// that the VALU form spends on one subtract + one FMA per pair and channel.  The y term depends on tj only: TyP threads keep its
+// window sums on the side (one LDS read + add per column) and it is added when E is written out.
+// gram-major scratch: x [H][W][TxP][4] = (u0, u1, u2, u.u), y [H][W][TyP][4] = (-2 v0, -2 v1, -2 v2, v.v): an operand fragment
+// (lane = frame + 16 * slot) is 64 consecutive floats of a staged column.  Wave w owns frames 16w..16w+15 of x and all TYT tiles of y.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <bool IS_Y>
+__global__ __launch_bounds__(256) void video_to_gram_major_k(const float *__restrict__ v, int64_t sc, int64_t st, int64_t sr,
+                                                             int T, int TP, int H, int W, float4 *__restrict__ out) {
+    __shared__ float tile[3][16][65];      // [channel][frame of the chunk][pixel] (+1 pad: conflict-free transposed reads)
+    const int row = blockIdx.y, x0 = blockIdx.x * 64, tid = threadIdx.x;
+    for (int f0 = 0; f0 < TP; f0 += 16) {
+        // read: lanes over pixels (coalesced along the row), 4 (channel, frame) pairs per pass
+        for (int j = tid >> 6; j < 48; j += 4) {
+            const int c = j >> 4, f = f0 + (j & 15), x = x0 + (tid & 63);
+            float val = 0.5f;                                                   // padding frames: u = v = 0
+            if (f < T && x < W) val = v[c * sc + f * st + (int64_t)row * sr + x];
+            tile[c][j & 15][tid & 63] = val - 0.5f;
         }
-        for (int i0 = 0; i0 < a.n1; i0 += NTHR / 4) {
-            const int i = i0 + (tid >> 2);
-            const int qn = (a.n2 + 3) / 4, j0 = sub * qn, j1 = min(a.n2, j0 + qn);
-            float best = INFINITY;
-            int bj = j0;
-            bool best_nan = false;
-            if (i < a.n1) {
-                for (int j = j0; j < j1; ++j) {
-                    float sacc = 0.f;
-                    for (int kt = 0; kt < a.pt; ++kt) sacc += E[(i * a.stridet + kt) * a.TyP + j * a.stridet + kt];
-                    float v = sacc / a.dnorm;
-                    if (a.use_alpha) v = v / colmin[j];
-                    const bool vn = (v != v);
-                    if (!best_nan && (vn || v < best)) { best = v; bj = j; best_nan = vn; }
+        __syncthreads();
+        // write: 16 lanes = the chunk's frames of one pixel (256 contiguous bytes), 4 pixels per wave
+        for (int p = tid >> 4; p < 64; p += 16) {
+            const int f = f0 + (tid & 15), x = x0 + p;
+            if (f < TP && x < W) {
+                const float a0 = tile[0][tid & 15][p], a1 = tile[1][tid & 15][p], a2 = tile[2][tid & 15][p];
+                const float n = fmaf(a2, a2, fmaf(a1, a1, a0 * a0));
+                out[((size_t)row * W + x) * TP + f] = IS_Y ? make_float4(-2.f * a0, -2.f * a1, -2.f * a2, n) : make_float4(a0, a1, a2, n);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Staging: a region row is staged in chunks of CH columns through TWO LDS buffers filled by LDS-DMA (global_load_lds_dwordx4: a wave
+// moves 1 KiB of the contiguous gram-major run per instruction, no staging registers, no ds_write pass); the chunk after the one being
+// contracted is in flight during the MFMA loop, one barrier per chunk.
+__device__ __forceinline__ void lds_dma16(const float4 *g, float *lds_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_uniform, 16, 0, 0);
+}
+
+// (two waves per SIMD at least: with at most 256 registers a wave the compiler keeps the MFMA accumulators in VGPRs; allowed the
+// full 512 it put R in AGPRs and copied it to VGPRs and back around every MFMA -- 41 % matrix-core utilisation)
+template <int TYT, int NL>
+__global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, int CH) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int RWc = a.ps + (NL - 1) * a.stride;                 // region width in pixels
+    const int ybase = CH * a.TxP * 4;                           // a stage buffer: x [CH][TxP][4] | y [CH][TyP][4] | 64 floats (the last tile's over-read)
+    const int bufF = CH * (a.TxP + a.TyP) * 4 + 64;
+    float *E = smem;                                            // [TxP][TyP], one location at a time in the epilogue: aliases the staging
+    float *colw = E + (size_t)a.TxP * a.TyP;
+    float *sy = colw + a.n2;                                    // [TyP] y term of the location being written out
+    const int g = blockIdx.x, by = g / groups_x, bx0 = (g % groups_x) * NL;
+    const int r0 = by * a.stride, c0 = bx0 * a.stride, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cols = min(RWc, a.W - c0);                        // the last group of a row may be narrower
+    const int nloc = min(NL, a.w_o - bx0);
+    f32x4_t acc[NL][TYT], R[TYT];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int j = 0; j < TYT; ++j) acc[l][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < TYT; ++j) R[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float an[NL], Rn = 0.f;                                     // tid < TyP: window sums of v.v for frame tid
+#pragma unroll
+    for (int l = 0; l < NL; ++l) an[l] = 0.f;
+    const int nch = (cols + CH - 1) / CH, S = a.ps * nch;       // stages = (row, chunk)
+    auto issue = [&](int st) {
+        const int r = st / nch, q0 = (st - r * nch) * CH, nc = min(CH, cols - q0);
+        float *dst = smem + (st & 1) * bufF;
+        const float4 *xsrc = reinterpret_cast<const float4 *>(a.xt) + ((size_t)(r0 + r) * a.W + c0 + q0) * a.TxP;
+        const float4 *ysrc = reinterpret_cast<const float4 *>(a.yt) + ((size_t)(r0 + r) * a.W + c0 + q0) * a.TyP;
+        const int nx = nc * a.TxP, ny = nc * a.TyP;            // float4 per part
+        for (int p = wave; p * 64 < nx; p += 4)
+            if (p * 64 + lane < nx) lds_dma16(xsrc + p * 64 + lane, dst + p * 256);
+        for (int p = wave; p * 64 < ny; p += 4)
+            if (p * 64 + lane < ny) lds_dma16(ysrc + p * 64 + lane, dst + ybase + p * 256);
+    };
+    // operand fragments: lane -> (frame = lane & 15, slot = lane >> 4); over-reads past TxP / TyP land in tile rows / columns that
+    // are never written out
+    const int xoff = (wave * 16 + (lane & 15)) * 4 + (lane >> 4), yoff = ybase + (lane & 15) * 4 + (lane >> 4);
+    const bool one = lane >= 48;                                 // B slot 3 = 1
+    const bool side = tid < a.TyP;
+    if (!(a.ablate & 4)) issue(0);
+    for (int st = 0; st < S; ++st) {
+        __syncthreads();                                         // stage st has landed; everyone is done with the other buffer
+        if (st + 1 < S && !(a.ablate & 4)) issue(st + 1);
+        if (a.ablate & 2) continue;
+        const int r = st / nch, q0 = (st - r * nch) * CH, q1 = min(cols, q0 + CH);
+        const float *buf = smem + (st & 1) * bufF;
+        if (q0 == 0) {                                           // running sums along the row restart every row: location l's share of a
+#pragma unroll                                                   // row is R(window end) - R(before window start)
+            for (int j = 0; j < TYT; ++j) R[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            Rn = 0.f;
+        }
+        // the columns are walked in runs between window boundaries, so that the matrix-core loop touches R through MFMAs only
+        for (int q = q0; q < q1;) {
+            int qn = q1;                                         // end (exclusive) of the run that starts at q
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const int ws = l * a.stride, we = ws + a.ps - 1;
+                if (q == ws && !(a.ablate & 8)) {                // window of location l starts at this column (uniform)
+#pragma unroll
+                    for (int j = 0; j < TYT; ++j) acc[l][j] -= R[j];
+                    an[l] -= Rn;
+                }
+                if (ws > q) qn = min(qn, ws);
+                if (we >= q) qn = min(qn, we + 1);
+            }
+            const float *xq = buf + xoff + (q - q0) * a.TxP * 4, *yq = buf + yoff + (q - q0) * a.TyP * 4;
+            const float *nq = buf + ybase + ((q - q0) * a.TyP + (side ? tid : 0)) * 4 + 3;
+            // Operands one column ahead of the MFMAs that use them, in two register sets used alternately: the reads of column qq + 1
+            // are issued, column qq is contracted, THEN the reads are waited for.  (The read past the run's last column stays inside the
+            // stage buffer and is dropped.)  hipcc folds such reads back to the top of the iteration that uses them, or waits for them
+            // with lgkmcnt(0) right after issuing them -- 55 % matrix-core utilisation -- so for the shipped tile count the reads and
+            // their wait are two asm statements (the wait hands the registers on, so nothing that uses them can move above it) fenced
+            // by scheduling barriers; other tile counts take the plain loop.
+            if constexpr (TYT == 5) {
+                unsigned xad = (unsigned)reinterpret_cast<uintptr_t>(xq), yad = (unsigned)reinterpret_cast<uintptr_t>(yq);
+                unsigned nad = (unsigned)reinterpret_cast<uintptr_t>(nq);
+                const unsigned xstep = a.TxP * 16, ystep = a.TyP * 16;
+                float a0, n0, b00, b01, b02, b03, b04, a1, n1, b10, b11, b12, b13, b14;
+#define VL3D_NN5_ISSUE(A, N, B0, B1, B2, B3, B4)                                                          \
+    asm volatile("ds_read_b32 %0, %7\n\tds_read_b32 %1, %8\n\tds_read_b32 %2, %9\n\tds_read_b32 %3, %9 offset:256\n\t" \
+                 "ds_read_b32 %4, %9 offset:512\n\tds_read_b32 %5, %9 offset:768\n\tds_read_b32 %6, %9 offset:1024"       \
+                 : "=&v"(A), "=&v"(N), "=&v"(B0), "=&v"(B1), "=&v"(B2), "=&v"(B3), "=&v"(B4)               \
+                 : "v"(xad), "v"(nad), "v"(yad)                                                          \
+                 : "memory");                                                                            \
+    __builtin_amdgcn_sched_barrier(0)
+#define VL3D_NN5_WAIT(A, N, B0, B1, B2, B3, B4)                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A), "+v"(N), "+v"(B0), "+v"(B1), "+v"(B2), "+v"(B3), "+v"(B4)::"memory")
+#define VL3D_NN5_MMA(A, N, B0, B1, B2, B3, B4)                                                            \
+    R[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, one ? 1.0f : B0, R[0], 0, 0, 0);                       \
+    R[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, one ? 1.0f : B1, R[1], 0, 0, 0);                       \
+    R[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, one ? 1.0f : B2, R[2], 0, 0, 0);                       \
+    R[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, one ? 1.0f : B3, R[3], 0, 0, 0);                       \
+    R[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, one ? 1.0f : B4, R[4], 0, 0, 0);                       \
+    Rn += N
+#define VL3D_NN5_NEXT(QQ)                                                                                 \
+    if ((QQ) + 1 < q1) { xad += xstep; yad += ystep; nad += ystep; }
+                VL3D_NN5_ISSUE(a0, n0, b00, b01, b02, b03, b04);
+                VL3D_NN5_WAIT(a0, n0, b00, b01, b02, b03, b04);
+                int qq = q;
+                for (; qq + 1 < qn; qq += 2) {
+                    VL3D_NN5_NEXT(qq);
+                    VL3D_NN5_ISSUE(a1, n1, b10, b11, b12, b13, b14);
+                    VL3D_NN5_MMA(a0, n0, b00, b01, b02, b03, b04);
+                    VL3D_NN5_WAIT(a1, n1, b10, b11, b12, b13, b14);
+                    VL3D_NN5_NEXT(qq + 1);
+                    VL3D_NN5_ISSUE(a0, n0, b00, b01, b02, b03, b04);
+                    VL3D_NN5_MMA(a1, n1, b10, b11, b12, b13, b14);
+                    VL3D_NN5_WAIT(a0, n0, b00, b01, b02, b03, b04);
+                }
+                if (qq < qn) { VL3D_NN5_MMA(a0, n0, b00, b01, b02, b03, b04); }
+#undef VL3D_NN5_ISSUE
+#undef VL3D_NN5_WAIT
+#undef VL3D_NN5_MMA
+#undef VL3D_NN5_NEXT
+            } else {
+                for (int qq = q; qq < qn; ++qq, xq += a.TxP * 4, yq += a.TyP * 4, nq += a.TyP * 4) {
+                    const float av = *xq, nv = *nq;
+#pragma unroll
+                    for (int j = 0; j < TYT; ++j) R[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, one ? 1.0f : yq[j * 64], R[j], 0, 0, 0);
+                    Rn += nv;
                 }
             }
 #pragma unroll
-            for (int step = 1; step <= 2; step <<= 1) {
-                const float ob = __shfl_xor(best, step, 64);
-                const int oj = __shfl_xor(bj, step, 64);
-                const int on = __shfl_xor((int)best_nan, step, 64);
-                const bool other_lower = (sub & step) != 0;
-                bool take;
-                if (best_nan || on) take = on && (!best_nan || other_lower);
-                else take = (ob < best) || (ob == best && other_lower);
-                if (take) { best = ob; bj = oj; best_nan = on != 0; }
-            }
-            if (i < a.n1 && sub == 0) a.nn[b * a.n1 + i] = bj;
+            for (int l = 0; l < NL; ++l)
+                if (qn - 1 == l * a.stride + a.ps - 1 && !(a.ablate & 8)) {         // ... and ends at the run's last one
+#pragma unroll
+                    for (int j = 0; j < TYT; ++j) acc[l][j] += R[j];
+                    an[l] += Rn;
+                }
+            q = qn;
         }
+    }
+    // epilogue, one location at a time through the shared E buffer.  C/D layout of a 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg
+    const int sub = tid & 3;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        if (l >= nloc) break;                                    // uniform
+        __syncthreads();
+        if (tid < a.TyP) sy[tid] = an[l];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TYT; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = wave * 16 + (lane >> 4) * 4 + rr, col = j * 16 + (lane & 15);
+                if (row < a.TxP && col < a.TyP) E[row * a.TyP + col] = fmaxf(acc[l][j][rr] + sy[col], 0.0f);
+            }
+        __syncthreads();
+        const size_t b = (size_t)by * a.w_o + bx0 + l;
+        if (a.ablate & 1) { if (tid < a.n1) a.nn[b * a.n1 + tid] = 0; continue; }
+        nn_epilogue<256>(a, E, colw, b, tid, sub);
     }
 }
 
@@ -891,7 +1017,7 @@ static inline int pad4(int t) { return (t + 3) / 4 * 4; }
 extern "C" int64_t vl3d_patchnn_scratch_bytes(const vl3d_loss_desc *d) {
     if (!d || d->H <= 0 || d->W <= 0) return 0;
     const int TxU = ((d->Tx - d->pt) / d->stridet) * d->stridet + d->pt;
-    return (int64_t)d->H * d->W * 3 * (pad4(TxU) + pad4(d->Ty)) * (int64_t)sizeof(float);
+    return (int64_t)d->H * d->W * 4 * (pad4(TxU) + pad4(d->Ty)) * (int64_t)sizeof(float);     // the gram-major form (v5): 4 floats per pixel and frame
 }
 
 extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const float *y, int32_t *nn, void *scratch,
@@ -904,18 +1030,39 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
     rc = plan_nn(desc, a, lds);
     if (rc != VL3D_OK) return rc;
     if (scratch != nullptr && (desc->variant & 0xf) != 1) {
-        // v2: pixel-major copies in the caller's scratch, then the coalesced-staging kernel
+        // pixel-major (v2 / v4) or gram-major (v5) copies in the caller's scratch, then the coalesced-staging kernel
         hipStream_t s = (hipStream_t)stream;
+        const int pv = desc->variant & 0xf;
+        // v5 (matrix cores) whenever x's frames fit the four waves' 16-row strips and y's its column tiles
+        const int TyT = (a.TyP + 15) / 16;
+        const int nl5 = TyT <= 5 ? 4 : 2;
+        const int RWc5 = a.ps + (nl5 - 1) * a.stride;
+        // chunk = the most columns whose two stage buffers leave room for three workgroups per CU (at least 4 columns)
+        int ch5 = (int)((53 * 1024 / 2 - 64 * sizeof(float)) / ((size_t)4 * (a.TxP + a.TyP) * sizeof(float)));
+        ch5 = ch5 < 4 ? 4 : (ch5 > RWc5 ? RWc5 : ch5);
+        ch5 = (RWc5 + (RWc5 + ch5 - 1) / ch5 - 1) / ((RWc5 + ch5 - 1) / ch5);        // even chunks
+        const size_t stage5 = 2 * ((size_t)ch5 * 4 * (a.TxP + a.TyP) + 64), epi5 = (size_t)a.TxP * a.TyP + a.n2 + a.TyP;
+        const size_t lds5 = (stage5 > epi5 ? stage5 : epi5) * sizeof(float);
+        const bool use_v5 = (pv == 0 || pv == 3) && a.TxP <= 64 && TyT <= 8 && lds5 <= 150 * 1024;
+        const int ch = use_v5 ? 4 : 3;
         float *xt = (float *)scratch;
-        float *yt = xt + (size_t)desc->H * desc->W * 3 * a.TxP;
+        float *yt = xt + (size_t)desc->H * desc->W * ch * a.TxP;
         dim3 tg((desc->W + 63) / 64, desc->H);
-        hipLaunchKernelGGL(video_to_pixel_major_k, tg, dim3(256), 0, s, x, desc->x_sc, desc->x_st, desc->x_sr, a.TxU, a.TxP,
-                           desc->H, desc->W, xt);
         // variant bit 8: the y half of the scratch still holds this y from the previous call (the captured video is constant
         // over the iterations of the training loop; the caller keeps the scratch alive and vouches for it)
-        if (!(desc->variant & 0x100))
-            hipLaunchKernelGGL(video_to_pixel_major_k, tg, dim3(256), 0, s, y, desc->y_sc, desc->y_st, desc->y_sr, desc->Ty, a.TyP,
-                               desc->H, desc->W, yt);
+        if (use_v5) {
+            hipLaunchKernelGGL(video_to_gram_major_k<false>, tg, dim3(256), 0, s, x, desc->x_sc, desc->x_st, desc->x_sr, a.TxU, a.TxP,
+                               desc->H, desc->W, (float4 *)xt);
+            if (!(desc->variant & 0x100))
+                hipLaunchKernelGGL(video_to_gram_major_k<true>, tg, dim3(256), 0, s, y, desc->y_sc, desc->y_st, desc->y_sr, desc->Ty, a.TyP,
+                                   desc->H, desc->W, (float4 *)yt);
+        } else {
+            hipLaunchKernelGGL(video_to_pixel_major_k, tg, dim3(256), 0, s, x, desc->x_sc, desc->x_st, desc->x_sr, a.TxU, a.TxP,
+                               desc->H, desc->W, xt);
+            if (!(desc->variant & 0x100))
+                hipLaunchKernelGGL(video_to_pixel_major_k, tg, dim3(256), 0, s, y, desc->y_sc, desc->y_st, desc->y_sr, desc->Ty, a.TyP,
+                                   desc->H, desc->W, yt);
+        }
         NN2Args b{};
         b.xt = xt; b.yt = yt; b.nn = nn; b.W = desc->W; b.ps = a.ps; b.pt = a.pt; b.stride = a.stride; b.stridet = a.stridet;
         b.h_o = a.h_o; b.w_o = a.w_o; b.n1 = a.n1; b.n2 = a.n2; b.TxP = a.TxP; b.TyP = a.TyP; b.K = a.K; b.KC = a.KC;
@@ -926,21 +1073,24 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
             VL3D_HIP(hipFuncSetAttribute((const void *)patchnn2_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr2 = true;
         }
-        // default = VALU direct-SSD kernel (v2).  variant 3 selects the MFMA frame-Gram kernel (v3): measured at 720p /
-        // ref-view cfg 6.97 ms vs 6.47 ms for v2 -- at fp32 the matrix cores have no rate advantage (v_mfma_f32_16x16x4_f32
-        // = 64 FLOP/clk/SIMD = the f32 VALU peak) and the Gram form needs an extra |x|^2,|y|^2 pass and 64x80 padded tiles
-        // (ablation: MFMA loop 2.4 ms, staging 1.3 ms, epilogue 0.7 ms, transposes + rest 2.4 ms).
-        const int TyT = (a.TyP + 15) / 16;
-        const bool mf_ok = a.TxP <= 64 && TyT <= MF_MAXJT;
-        const int pv = desc->variant & 0xf;
-        const bool use_mf = mf_ok && pv == 3;
         // v4 (4 locations per workgroup, column sums): default whenever one thread tile per frame-pair tile suffices
         const int ntiles4 = (a.TxP / TI) * (a.TyP / TJ);
         const int RWc4 = a.ps + (NL4 - 1) * a.stride;
         const size_t stage4 = (size_t)RWc4 * 3 * (a.TxP + a.TyP), epi4 = (size_t)a.TxP * a.TyP + a.n2;   // the epilogue aliases the staging
         const size_t lds4 = (stage4 > epi4 ? stage4 : epi4) * sizeof(float);
         const bool use_v4 = (pv == 0 || pv == 4) && ntiles4 <= 1024 && lds4 <= 150 * 1024;
-        if (use_v4) {
+        if (use_v5) {
+            static bool attr5 = false;
+            if (!attr5) {
+                VL3D_HIP(hipFuncSetAttribute((const void *)patchnn5_k<5, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                VL3D_HIP(hipFuncSetAttribute((const void *)patchnn5_k<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr5 = true;
+            }
+            const int groups_x = (a.w_o + nl5 - 1) / nl5;
+            const dim3 grid5((unsigned)(groups_x * a.h_o));
+            if (nl5 == 4) hipLaunchKernelGGL((patchnn5_k<5, 4>), grid5, dim3(256), lds5, s, b, groups_x, ch5);
+            else hipLaunchKernelGGL((patchnn5_k<8, 2>), grid5, dim3(256), lds5, s, b, groups_x, ch5);
+        } else if (use_v4) {
             static bool attr4 = false;
             if (!attr4) {
 #define VL3D_ATTR4(R, N) VL3D_HIP(hipFuncSetAttribute((const void *)patchnn4_k<R, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
@@ -960,20 +1110,6 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
             else if (nthr == 512) { if (runsum) VL3D_LAUNCH4(true, 512); else VL3D_LAUNCH4(false, 512); }
             else VL3D_LAUNCH4(false, 1024);       // the running-sum form needs 6 registers more than the 128 a 1024-thread workgroup has: per-column adds here
 #undef VL3D_LAUNCH4
-        } else if (use_mf) {
-            const size_t fixed3 = ((size_t)64 * TyT * 16 + a.n2 + 64 + TyT * 16) * sizeof(float);
-            int kc3 = (int)((48 * 1024 > fixed3 + 16 * (a.TxP + a.TyP) * sizeof(float) ? 48 * 1024 - fixed3 : 16 * (a.TxP + a.TyP) * sizeof(float)) /
-                            ((size_t)(a.TxP + a.TyP) * sizeof(float)));
-            kc3 &= ~3;
-            if (kc3 > ((a.K + 3) & ~3)) kc3 = (a.K + 3) & ~3;
-            b.KC = kc3;
-            const size_t lds3 = fixed3 + (size_t)kc3 * (a.TxP + a.TyP) * sizeof(float);
-            static bool attr3 = false;
-            if (!attr3) {
-                VL3D_HIP(hipFuncSetAttribute((const void *)patchnn3_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr3 = true;
-            }
-            hipLaunchKernelGGL(patchnn3_k, dim3((unsigned)(a.h_o * a.w_o)), dim3(NN_THREADS), lds3, s, b, TyT);
         } else {
             hipLaunchKernelGGL(patchnn2_k, dim3((unsigned)(a.h_o * a.w_o)), dim3(NN_THREADS), lds, s, b);
         }
