@@ -233,6 +233,21 @@ def test_patchnn_kernel_variants_agree(dev, variant, monkeypatch):
             assert maxabs(sg, so) <= 1e-5
 
 
+@pytest.mark.parametrize("tx,ty,ps,s,alpha", [(12, 100, 5, 2, 0.5), (62, 128, 7, 3, None), (50, 75, 11, 4, 0.5), (9, 17, 4, 1, 0.005)])
+def test_patchnn_matrix_core_tile_counts(dev, tx, ty, ps, s, alpha, monkeypatch):
+    """The matrix-core kernel at both of its instantiations (<= 80 target frames: four locations per workgroup, hand-pipelined operand
+    reads; <= 128: two locations, plain loop), at the largest clips it takes, with a narrow last group and with alpha."""
+    from videoloop3d_amd.utils_vid import _nn_and_fold
+    monkeypatch.setenv("VL3D_LOSS_VARIANT", "3")
+    H, W = ps + 5 * s, ps + 9 * s                        # 6 x 10 patch locations: the last group of a row is two locations wide
+    x = synth.make_video(tx, H, W, seed=5)
+    y = synth.make_video(ty, H, W, seed=6)
+    sg, wg, nng = _nn_and_fold(x.to(dev), y.to(dev), ps, 3, s, 1, alpha, normalize=False)
+    nbad, unexplained = nn_mismatch_is_near_tie(x, y, ps, 3, s, 1, alpha, nng)
+    assert unexplained == 0
+    assert nbad <= nng.numel() // 100
+
+
 def test_g10_compute_nnerr(dev, golden):
     """evaluations/NNMSE.compute_nnerr on the HIP patch-NN path vs the reference golden G10."""
     import warnings as _w

@@ -273,6 +273,81 @@ __global__ __launch_bounds__(NN_THREADS) void patchnn2_k(NN2Args a) {
 // from the reference's two divisions by an ulp, i.e. only between exact near-ties.  Whole workgroup, 4 lanes per row / column.
 template <int NTHR>
 __device__ __forceinline__ void nn_epilogue(const NN2Args &a, const float *E, float *colw, size_t b, int tid, int sub) {
+    if (a.pt == 3 && a.stridet == 1 && !(a.ablate & 8)) {
+        // every shipped configuration: three-frame patches at temporal stride 1.  s(i, j..j+3) needs E(i, j..j+3), E(i+1, j+1..j+4) and
+        // E(i+2, j+2..j+5): whole 16-byte LDS reads (the rows are 16-byte aligned, TyP is a multiple of 4), the upper halves carried
+        // from one group of four columns to the next -- 3/4 of an LDS read per frame pair instead of 3, same additions in the same order.
+        const int TyP = a.TyP;
+        const float4 *E4 = reinterpret_cast<const float4 *>(E);
+        if (a.use_alpha) {
+            // column minima: a thread takes four adjacent columns of every nrg-th row; the row groups meet in an LDS integer min
+            // (the sums are >= +0 or NaN: their bit patterns order like the values and NaN never wins, as with fminf)
+            int *cmi = reinterpret_cast<int *>(colw);
+            for (int j = tid; j < a.n2; j += NTHR) cmi[j] = 0x7f800000;
+            __syncthreads();
+            const int ngrp = TyP / 4, nrg = NTHR / ngrp, jg = tid % ngrp, ig = tid / ngrp;
+            if (ig < nrg) {
+                float m0 = INFINITY, m1 = INFINITY, m2 = INFINITY, m3 = INFINITY;
+                for (int i = ig; i < a.n1; i += nrg) {
+                    const float4 *p = E4 + (i * TyP) / 4 + jg;
+                    const float4 c0 = p[0], l1 = p[TyP / 4], h1 = p[TyP / 4 + 1], l2 = p[TyP / 2], h2 = p[TyP / 2 + 1];
+                    m0 = fminf(m0, (c0.x + l1.y) + l2.z);
+                    m1 = fminf(m1, (c0.y + l1.z) + l2.w);
+                    m2 = fminf(m2, (c0.z + l1.w) + h2.x);
+                    m3 = fminf(m3, (c0.w + h1.x) + h2.y);
+                }
+                const int j = jg * 4;
+                if (j < a.n2) atomicMin(cmi + j, __float_as_int(m0));
+                if (j + 1 < a.n2) atomicMin(cmi + j + 1, __float_as_int(m1));
+                if (j + 2 < a.n2) atomicMin(cmi + j + 2, __float_as_int(m2));
+                if (j + 3 < a.n2) atomicMin(cmi + j + 3, __float_as_int(m3));
+            }
+            __syncthreads();
+            const float inv_d = 1.0f / a.dnorm;
+            for (int j = tid; j < a.n2; j += NTHR) colw[j] = inv_d / (a.alpha + colw[j] / a.dnorm);
+            __syncthreads();
+        }
+        const int q4 = ((a.n2 + 3) / 4 + 3) & ~3, j0 = sub * q4, j1 = min(a.n2, j0 + q4);     // quarters of whole column groups
+        for (int i0 = 0; i0 < a.n1; i0 += NTHR / 4) {      // uniform trip count: every lane takes part in the shuffles
+            const int i = i0 + (tid >> 2);
+            float best = INFINITY;
+            int bj = j0;
+            bool best_nan = false;
+            if (i < a.n1 && j0 < j1) {
+                const float4 *p = E4 + (i * TyP + j0) / 4;
+                float4 l1 = p[TyP / 4], l2 = p[TyP / 2];
+                for (int jb = j0; jb < j1; jb += 4, ++p) {
+                    const float4 c0 = p[0], h1 = p[TyP / 4 + 1], h2 = p[TyP / 2 + 1];
+                    float sa[4] = {(c0.x + l1.y) + l2.z, (c0.y + l1.z) + l2.w, (c0.z + l1.w) + h2.x, (c0.w + h1.x) + h2.y};
+                    if (a.use_alpha) {
+                        const float4 w = *reinterpret_cast<const float4 *>(colw + jb);
+                        sa[0] *= w.x; sa[1] *= w.y; sa[2] *= w.z; sa[3] *= w.w;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float v = sa[u];
+                        const bool vn = (v != v);
+                        if (jb + u < j1 && !best_nan && (vn || v < best)) { best = v; bj = jb + u; best_nan = vn; }
+                    }
+                    l1 = h1; l2 = h2;
+                }
+            }
+            // combine the 4 quarters in ascending-j order so that ties keep the lowest index
+#pragma unroll
+            for (int step = 1; step <= 2; step <<= 1) {
+                const float ob = __shfl_xor(best, step, 64);
+                const int oj = __shfl_xor(bj, step, 64);
+                const int on = __shfl_xor((int)best_nan, step, 64);
+                const bool other_lower = (sub & step) != 0;      // the partner holds the lower-j range
+                bool take;
+                if (best_nan || on) take = on && (!best_nan || other_lower);
+                else take = (ob < best) || (ob == best && other_lower);
+                if (take) { best = ob; bj = oj; best_nan = on != 0; }
+            }
+            if (i < a.n1 && sub == 0) a.nn[b * a.n1 + i] = bj;
+        }
+        return;
+    }
     if (a.use_alpha) {
         const float inv_d = 1.0f / a.dnorm;
         for (int j = tid >> 2; j < a.n2; j += NTHR / 4) {
@@ -479,31 +554,50 @@ __global__ __launch_bounds__(256) void video_to_gram_major_k(const float *__rest
                                                              int T, int TP, int H, int W, float4 *__restrict__ out) {
     __shared__ float tile[3][16][65];      // [channel][frame of the chunk][pixel] (+1 pad: conflict-free transposed reads)
     const int row = blockIdx.y, x0 = blockIdx.x * 64, tid = threadIdx.x;
+    // read: lanes over pixels (coalesced along the row), 12 (channel, frame) pairs per thread and 16-frame chunk; the NEXT chunk's reads
+    // are issued before this chunk is written out, so that they are in flight across the write phase and its barriers
+    float pre[12];
+    const int x = x0 + (tid & 63);
+    const float *src = v + (int64_t)row * sr + min(x, W - 1);
+    auto load = [&](int f0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int j = (tid >> 6) + 4 * k, c = j >> 4, f = f0 + (j & 15);
+            pre[k] = f < T ? src[c * sc + f * st] : 0.5f;                       // padding frames: u = v = 0
+        }
+    };
+    load(0);
     for (int f0 = 0; f0 < TP; f0 += 16) {
-        // read: lanes over pixels (coalesced along the row), 4 (channel, frame) pairs per pass
-        for (int j = tid >> 6; j < 48; j += 4) {
-            const int c = j >> 4, f = f0 + (j & 15), x = x0 + (tid & 63);
-            float val = 0.5f;                                                   // padding frames: u = v = 0
-            if (f < T && x < W) val = v[c * sc + f * st + (int64_t)row * sr + x];
-            tile[c][j & 15][tid & 63] = val - 0.5f;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int j = (tid >> 6) + 4 * k;
+            tile[j >> 4][j & 15][tid & 63] = pre[k] - 0.5f;
         }
         __syncthreads();
+        if (f0 + 16 < TP) load(f0 + 16);
         // write: 16 lanes = the chunk's frames of one pixel (256 contiguous bytes), 4 pixels per wave
         for (int p = tid >> 4; p < 64; p += 16) {
-            const int f = f0 + (tid & 15), x = x0 + p;
-            if (f < TP && x < W) {
+            const int f = f0 + (tid & 15), xp = x0 + p;
+            if (f < TP && xp < W) {
                 const float a0 = tile[0][tid & 15][p], a1 = tile[1][tid & 15][p], a2 = tile[2][tid & 15][p];
                 const float n = fmaf(a2, a2, fmaf(a1, a1, a0 * a0));
-                out[((size_t)row * W + x) * TP + f] = IS_Y ? make_float4(-2.f * a0, -2.f * a1, -2.f * a2, n) : make_float4(a0, a1, a2, n);
+                out[((size_t)row * W + xp) * TP + f] = IS_Y ? make_float4(-2.f * a0, -2.f * a1, -2.f * a2, n) : make_float4(a0, a1, a2, n);
             }
         }
         __syncthreads();
     }
 }
 
-// Staging: a region row is staged in chunks of CH columns through TWO LDS buffers filled by LDS-DMA (global_load_lds_dwordx4: a wave
-// moves 1 KiB of the contiguous gram-major run per instruction, no staging registers, no ds_write pass); the chunk after the one being
-// contracted is in flight during the MFMA loop, one barrier per chunk.
+// Staging and order of the contraction: a STAGE is CHC region columns x all ps rows (x [CHC][ps][TxP][4] | y [CHC][ps][TyP][4]), moved by
+// LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction straight into LDS, each lane from its own row -- no staging registers,
+// no ds_write pass) into one of TWO buffers: the stage after the one being contracted is in flight during the MFMA loop, one barrier
+// per stage.  Within a stage a column's ps rows are contracted back to back, so the running sum R (a prefix over COLUMNS, each with all
+// its rows) meets a window boundary once per boundary column of the whole region -- 2 NL times per workgroup -- instead of once per
+// row: the accumulator traffic R -> acc[l] and the operand pipeline's warm-up are paid per column, not per row segment.
+// floor(n / d) for 0 <= n < 2^16, 0 < d < 2^12 through the hardware reciprocal: (n + 1/2) / d is at least 1 / (2 d) away from any
+// integer, far more than the reciprocal's relative error times the quotient
+__device__ __forceinline__ int fdiv_small(int n, int d) { return (int)(((float)n + 0.5f) * __builtin_amdgcn_rcpf((float)d)); }
+
 __device__ __forceinline__ void lds_dma16(const float4 *g, float *lds_wave_uniform) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)lds_wave_uniform, 16, 0, 0);
@@ -512,11 +606,12 @@ __device__ __forceinline__ void lds_dma16(const float4 *g, float *lds_wave_unifo
 // (two waves per SIMD at least: with at most 256 registers a wave the compiler keeps the MFMA accumulators in VGPRs; allowed the
 // full 512 it put R in AGPRs and copied it to VGPRs and back around every MFMA -- 41 % matrix-core utilisation)
 template <int TYT, int NL>
-__global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, int CH) {
+__global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, int CHC) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KX = 4, KY = 2 * TYT > 7 ? 7 : 2 * TYT;       // DMA pieces per wave and stage at most (x: 13 * 64 / 64 / 4, y: 13 * 128 / 64 / 4)
     const int RWc = a.ps + (NL - 1) * a.stride;                 // region width in pixels
-    const int ybase = CH * a.TxP * 4;                           // a stage buffer: x [CH][TxP][4] | y [CH][TyP][4] | 64 floats (the last tile's over-read)
-    const int bufF = CH * (a.TxP + a.TyP) * 4 + 64;
+    const int xs4 = CHC * a.ps * a.TxP, ys4 = CHC * a.ps * a.TyP;   // float4 per stage and part
+    const int ybase = xs4 * 4, bufF = (xs4 + ys4) * 4 + 64;     // (+ 64 floats: the last tile's over-read)
     float *E = smem;                                            // [TxP][TyP], one location at a time in the epilogue: aliases the staging
     float *colw = E + (size_t)a.TxP * a.TyP;
     float *sy = colw + a.n2;                                    // [TyP] y term of the location being written out
@@ -535,17 +630,31 @@ __global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, in
     float an[NL], Rn = 0.f;                                     // tid < TyP: window sums of v.v for frame tid
 #pragma unroll
     for (int l = 0; l < NL; ++l) an[l] = 0.f;
-    const int nch = (cols + CH - 1) / CH, S = a.ps * nch;       // stages = (row, chunk)
+    // per-lane DMA sources: float4 slot idx = piece * 64 + lane of a stage part is (column cc, row r, frame f); its source, relative to
+    // the stage's first column in row r0, is (r * W + cc) * TP + f.  The same for every stage: kept in registers (cc in the top byte).
+    int offx[KX], offy[KY];
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        const int idx = (wave + 4 * k) * 64 + lane, cc = fdiv_small(idx, a.ps * a.TxP), rem = idx - cc * a.ps * a.TxP, r = fdiv_small(rem, a.TxP);
+        offx[k] = idx < xs4 ? ((r * a.W + cc) * a.TxP + (rem - r * a.TxP)) | (cc << 24) : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < KY; ++k) {
+        const int idx = (wave + 4 * k) * 64 + lane, cc = fdiv_small(idx, a.ps * a.TyP), rem = idx - cc * a.ps * a.TyP, r = fdiv_small(rem, a.TyP);
+        offy[k] = idx < ys4 ? ((r * a.W + cc) * a.TyP + (rem - r * a.TyP)) | (cc << 24) : -1;
+    }
+    const int S = (cols + CHC - 1) / CHC;                       // stages
     auto issue = [&](int st) {
-        const int r = st / nch, q0 = (st - r * nch) * CH, nc = min(CH, cols - q0);
+        const int q0 = st * CHC, nc = min(CHC, cols - q0);
         float *dst = smem + (st & 1) * bufF;
-        const float4 *xsrc = reinterpret_cast<const float4 *>(a.xt) + ((size_t)(r0 + r) * a.W + c0 + q0) * a.TxP;
-        const float4 *ysrc = reinterpret_cast<const float4 *>(a.yt) + ((size_t)(r0 + r) * a.W + c0 + q0) * a.TyP;
-        const int nx = nc * a.TxP, ny = nc * a.TyP;            // float4 per part
-        for (int p = wave; p * 64 < nx; p += 4)
-            if (p * 64 + lane < nx) lds_dma16(xsrc + p * 64 + lane, dst + p * 256);
-        for (int p = wave; p * 64 < ny; p += 4)
-            if (p * 64 + lane < ny) lds_dma16(ysrc + p * 64 + lane, dst + ybase + p * 256);
+        const float4 *xsrc = reinterpret_cast<const float4 *>(a.xt) + ((size_t)r0 * a.W + c0 + q0) * a.TxP;
+        const float4 *ysrc = reinterpret_cast<const float4 *>(a.yt) + ((size_t)r0 * a.W + c0 + q0) * a.TyP;
+#pragma unroll
+        for (int k = 0; k < KX; ++k)
+            if (offx[k] >= 0 && (offx[k] >> 24) < nc) lds_dma16(xsrc + (offx[k] & 0xffffff), dst + (wave + 4 * k) * 256);
+#pragma unroll
+        for (int k = 0; k < KY; ++k)
+            if (offy[k] >= 0 && (offy[k] >> 24) < nc) lds_dma16(ysrc + (offy[k] & 0xffffff), dst + ybase + (wave + 4 * k) * 256);
     };
     // operand fragments: lane -> (frame = lane & 15, slot = lane >> 4); over-reads past TxP / TyP land in tile rows / columns that
     // are never written out
@@ -557,35 +666,24 @@ __global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, in
         __syncthreads();                                         // stage st has landed; everyone is done with the other buffer
         if (st + 1 < S && !(a.ablate & 4)) issue(st + 1);
         if (a.ablate & 2) continue;
-        const int r = st / nch, q0 = (st - r * nch) * CH, q1 = min(cols, q0 + CH);
+        const int q0 = st * CHC, nc = min(CHC, cols - q0);
         const float *buf = smem + (st & 1) * bufF;
-        if (q0 == 0) {                                           // running sums along the row restart every row: location l's share of a
-#pragma unroll                                                   // row is R(window end) - R(before window start)
-            for (int j = 0; j < TYT; ++j) R[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            Rn = 0.f;
-        }
-        // the columns are walked in runs between window boundaries, so that the matrix-core loop touches R through MFMAs only
-        for (int q = q0; q < q1;) {
-            int qn = q1;                                         // end (exclusive) of the run that starts at q
+        for (int cc = 0; cc < nc; ++cc) {
+            const int q = q0 + cc;
 #pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                const int ws = l * a.stride, we = ws + a.ps - 1;
-                if (q == ws && !(a.ablate & 8)) {                // window of location l starts at this column (uniform)
+            for (int l = 0; l < NL; ++l)
+                if (q == l * a.stride && !(a.ablate & 8)) {      // window of location l starts at this column (uniform): acc = R(end) - R(before start)
 #pragma unroll
                     for (int j = 0; j < TYT; ++j) acc[l][j] -= R[j];
                     an[l] -= Rn;
                 }
-                if (ws > q) qn = min(qn, ws);
-                if (we >= q) qn = min(qn, we + 1);
-            }
-            const float *xq = buf + xoff + (q - q0) * a.TxP * 4, *yq = buf + yoff + (q - q0) * a.TyP * 4;
-            const float *nq = buf + ybase + ((q - q0) * a.TyP + (side ? tid : 0)) * 4 + 3;
-            // Operands one column ahead of the MFMAs that use them, in two register sets used alternately: the reads of column qq + 1
-            // are issued, column qq is contracted, THEN the reads are waited for.  (The read past the run's last column stays inside the
-            // stage buffer and is dropped.)  hipcc folds such reads back to the top of the iteration that uses them, or waits for them
-            // with lgkmcnt(0) right after issuing them -- 55 % matrix-core utilisation -- so for the shipped tile count the reads and
-            // their wait are two asm statements (the wait hands the registers on, so nothing that uses them can move above it) fenced
-            // by scheduling barriers; other tile counts take the plain loop.
+            const float *xq = buf + xoff + cc * a.ps * a.TxP * 4, *yq = buf + yoff + cc * a.ps * a.TyP * 4;
+            const float *nq = buf + ybase + (cc * a.ps * a.TyP + (side ? tid : 0)) * 4 + 3;
+            // Operands one row ahead of the MFMAs that use them, in two register sets used alternately: the reads of row r + 1 are issued,
+            // row r is contracted, THEN the reads are waited for.  (The read past the column's last row stays put and is dropped.)  hipcc
+            // folds such reads back to the top of the iteration that uses them, or waits for them with lgkmcnt(0) right after issuing
+            // them, so for the shipped tile count the reads and their wait are two asm statements (the wait hands the registers on, so
+            // nothing that uses them can move above it) fenced by scheduling barriers; other tile counts take the plain loop.
             if constexpr (TYT == 5) {
                 unsigned xad = (unsigned)reinterpret_cast<uintptr_t>(xq), yad = (unsigned)reinterpret_cast<uintptr_t>(yq);
                 unsigned nad = (unsigned)reinterpret_cast<uintptr_t>(nq);
@@ -608,28 +706,28 @@ __global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, in
     R[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, one ? 1.0f : B3, R[3], 0, 0, 0);                       \
     R[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, one ? 1.0f : B4, R[4], 0, 0, 0);                       \
     Rn += N
-#define VL3D_NN5_NEXT(QQ)                                                                                 \
-    if ((QQ) + 1 < q1) { xad += xstep; yad += ystep; nad += ystep; }
+#define VL3D_NN5_NEXT(RR)                                                                                 \
+    if ((RR) + 1 < a.ps) { xad += xstep; yad += ystep; nad += ystep; }
                 VL3D_NN5_ISSUE(a0, n0, b00, b01, b02, b03, b04);
                 VL3D_NN5_WAIT(a0, n0, b00, b01, b02, b03, b04);
-                int qq = q;
-                for (; qq + 1 < qn; qq += 2) {
-                    VL3D_NN5_NEXT(qq);
+                int r = 0;
+                for (; r + 1 < a.ps; r += 2) {
+                    VL3D_NN5_NEXT(r);
                     VL3D_NN5_ISSUE(a1, n1, b10, b11, b12, b13, b14);
                     VL3D_NN5_MMA(a0, n0, b00, b01, b02, b03, b04);
                     VL3D_NN5_WAIT(a1, n1, b10, b11, b12, b13, b14);
-                    VL3D_NN5_NEXT(qq + 1);
+                    VL3D_NN5_NEXT(r + 1);
                     VL3D_NN5_ISSUE(a0, n0, b00, b01, b02, b03, b04);
                     VL3D_NN5_MMA(a1, n1, b10, b11, b12, b13, b14);
                     VL3D_NN5_WAIT(a0, n0, b00, b01, b02, b03, b04);
                 }
-                if (qq < qn) { VL3D_NN5_MMA(a0, n0, b00, b01, b02, b03, b04); }
+                if (r < a.ps) { VL3D_NN5_MMA(a0, n0, b00, b01, b02, b03, b04); }
 #undef VL3D_NN5_ISSUE
 #undef VL3D_NN5_WAIT
 #undef VL3D_NN5_MMA
 #undef VL3D_NN5_NEXT
             } else {
-                for (int qq = q; qq < qn; ++qq, xq += a.TxP * 4, yq += a.TyP * 4, nq += a.TyP * 4) {
+                for (int r = 0; r < a.ps; ++r, xq += a.TxP * 4, yq += a.TyP * 4, nq += a.TyP * 4) {
                     const float av = *xq, nv = *nq;
 #pragma unroll
                     for (int j = 0; j < TYT; ++j) R[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, one ? 1.0f : yq[j * 64], R[j], 0, 0, 0);
@@ -638,12 +736,11 @@ __global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, in
             }
 #pragma unroll
             for (int l = 0; l < NL; ++l)
-                if (qn - 1 == l * a.stride + a.ps - 1 && !(a.ablate & 8)) {         // ... and ends at the run's last one
+                if (q == l * a.stride + a.ps - 1 && !(a.ablate & 8)) {   // ... and ends at this one
 #pragma unroll
                     for (int j = 0; j < TYT; ++j) acc[l][j] += R[j];
                     an[l] += Rn;
                 }
-            q = qn;
         }
     }
     // epilogue, one location at a time through the shared E buffer.  C/D layout of a 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -1037,13 +1134,15 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
         const int TyT = (a.TyP + 15) / 16;
         const int nl5 = TyT <= 5 ? 4 : 2;
         const int RWc5 = a.ps + (nl5 - 1) * a.stride;
-        // chunk = the most columns whose two stage buffers leave room for three workgroups per CU (at least 4 columns)
-        int ch5 = (int)((53 * 1024 / 2 - 64 * sizeof(float)) / ((size_t)4 * (a.TxP + a.TyP) * sizeof(float)));
-        ch5 = ch5 < 4 ? 4 : (ch5 > RWc5 ? RWc5 : ch5);
-        ch5 = (RWc5 + (RWc5 + ch5 - 1) / ch5 - 1) / ((RWc5 + ch5 - 1) / ch5);        // even chunks
-        const size_t stage5 = 2 * ((size_t)ch5 * 4 * (a.TxP + a.TyP) + 64), epi5 = (size_t)a.TxP * a.TyP + a.n2 + a.TyP;
+        // stage = the most columns (all ps rows each) whose two buffers leave room for three workgroups per CU: 13 pixel columns
+        int ch5 = (int)((53 * 1024 / 2 - 64 * sizeof(float)) / ((size_t)4 * (a.TxP + a.TyP) * sizeof(float))) / a.ps;
+        ch5 = ch5 < 1 ? 1 : (ch5 > RWc5 ? RWc5 : ch5);
+        const size_t stage5 = 2 * ((size_t)ch5 * a.ps * 4 * (a.TxP + a.TyP) + 64), epi5 = (size_t)a.TxP * a.TyP + a.n2 + a.TyP;
         const size_t lds5 = (stage5 > epi5 ? stage5 : epi5) * sizeof(float);
-        const bool use_v5 = (pv == 0 || pv == 3) && a.TxP <= 64 && TyT <= 8 && lds5 <= 150 * 1024;
+        const bool fits5 = (size_t)ch5 * a.ps * a.TxP <= 4 * 4 * 64 && (size_t)ch5 * a.ps * a.TyP <= 7 * 4 * 64;     // KX / KY pieces per wave
+        // (by default where a column is shared by >= 2 locations on average -- ps 11 / stride 4: 2.64 vs 3.58 ms for v4 at 720p; for 3-pixel
+        // patches at stride 2 the two are within 3 % (2.63 vs 2.54) and v4 needs a quarter less scratch)
+        const bool use_v5 = (pv == 3 || (pv == 0 && a.ps >= 2 * a.stride)) && a.TxP <= 64 && TyT <= 8 && lds5 <= 150 * 1024 && fits5;
         const int ch = use_v5 ? 4 : 3;
         float *xt = (float *)scratch;
         float *yt = xt + (size_t)desc->H * desc->W * ch * a.TxP;
