@@ -130,15 +130,27 @@ def loss_bench(dev, H, W, T, Ty, steps):
         B = ((h_ - ps) // st_ + 1) * ((w_ - ps) // st_ + 1)
         n1, n2, d = T + 2 - pt + 1, Ty - pt + 1, 3 * pt * ps * ps
         ref_flops = 2.0 * B * n1 * n2 * d                                    # as the reference performs them (utils_vid.py:82)
-        # what the kernel performs: per 4 locations the frame-pair energies of a ps x (ps + 3 stride) region, (sub, fma) = 3 flop per
-        # (column, channel, frame pair): the temporal diagonal sum makes the patch distance out of them
+        # what the kernel performs: per 4 locations the frame-pair energies of a ps x (ps + 3 stride) region; the temporal diagonal sum
+        # makes the patch distance out of them
         TxP, TyP = -(-(T + 2) // 4) * 4, -(-Ty // 4) * 4
-        own_flops = 3.0 * (B / 4) * ps * (ps + 3 * st_) * 3 * TxP * TyP
-        VALU_PEAK = 256 * 4 * 16 * 2 * 2.4e9 / 1e12                           # fp32 FMA, one per lane and clock: 78.6 TFLOP/s
-        out[name]["roofline_nn"] = {"kernel": "patchnn4_k (+ video_to_pixel_major_k x2)", "bound": "valu-fp32", "avg_ms": nn_ms,
+        cells = (B / 4) * ps * (ps + 3 * st_)                                  # (row, column) cells of the regions
+        if ps >= 2 * st_ and TxP <= 64 and TyP <= 80:
+            # v5, matrix cores: one v_mfma_f32_16x16x4_f32 per cell and 16x16 frame-pair tile, 4 x 5 tiles, k = 3 channels + the |x|^2 slot.
+            # `achieved` counts the useful multiply-adds only (3 channels x the real TxP x TyP frame pairs), `issued` what the tiles cost.
+            own_flops = 2.0 * cells * 3 * TxP * TyP
+            issued = 2.0 * cells * 4 * 64 * 80
+            PEAK = 256 * 4 * 64 * 2.4e9 / 1e12                                 # fp32 MFMA: 64 flop per clock and SIMD = 157.3 TFLOP/s
+            kern, bound = "patchnn5_k (+ video_to_gram_major_k x2)", "mfma-fp32"
+        else:
+            # v4, vector ALUs: (sub, fma) = 3 flop per (cell, channel, frame pair)
+            own_flops = issued = 3.0 * cells * 3 * TxP * TyP
+            PEAK = 256 * 4 * 16 * 2 * 2.4e9 / 1e12                             # fp32 FMA, one per lane and clock: 78.6 TFLOP/s (157.3 packed)
+            kern, bound = "patchnn4_k (+ video_to_pixel_major_k x2)", "valu-fp32"
+        out[name]["roofline_nn"] = {"kernel": kern, "bound": bound, "avg_ms": nn_ms,
                                     "flops_as_reference": ref_flops, "achieved_as_reference": ref_flops / (nn_ms * 1e-3) / 1e12,
-                                    "flops_performed": own_flops, "achieved": own_flops / (nn_ms * 1e-3) / 1e12, "peak": VALU_PEAK,
-                                    "unit": "TFLOP/s", "frac": own_flops / (nn_ms * 1e-3) / 1e12 / VALU_PEAK,
+                                    "flops_performed": own_flops, "flops_issued": issued, "achieved": own_flops / (nn_ms * 1e-3) / 1e12,
+                                    "peak": PEAK, "unit": "TFLOP/s", "frac": own_flops / (nn_ms * 1e-3) / 1e12 / PEAK,
+                                    "frac_issued": issued / (nn_ms * 1e-3) / 1e12 / PEAK,
                                     "separable_lower_bound_flops": 2.0 * 3 * (T + 2) * Ty * H * W}
     # compulsory bytes of one loss iteration: read x and y, write y2x / weight / grad, x again for the residual
     out["compulsory_bytes"] = 4.0 * H * W * (3 * (T + 2) * 4 + 3 * Ty + (T + 2))
