@@ -156,6 +156,7 @@ struct NN2Args {
     int32_t *nn;
     int W, ps, pt, stride, stridet, h_o, w_o, n1, n2;
     int TxP, TyP, K, KC;
+    int PX, PY;             // v5: frames per pixel of the gram-major copies (padded to whole 16-frame groups)
     int use_alpha;
     float alpha, dnorm;
     int ablate;   // measurement only: 1 skip epilogue, 2 skip compute, 4 skip staging loads
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(NN_THREADS) void patchnn2_k(NN2Args a) {
 // from the reference's two divisions by an ulp, i.e. only between exact near-ties.  Whole workgroup, 4 lanes per row / column.
 template <int NTHR>
 __device__ __forceinline__ void nn_epilogue(const NN2Args &a, const float *E, float *colw, size_t b, int tid, int sub) {
-    if (a.pt == 3 && a.stridet == 1 && !(a.ablate & 8)) {
+    if (a.pt == 3 && a.stridet == 1) {
         // every shipped configuration: three-frame patches at temporal stride 1.  s(i, j..j+3) needs E(i, j..j+3), E(i+1, j+1..j+4) and
         // E(i+2, j+2..j+5): whole 16-byte LDS reads (the rows are 16-byte aligned, TyP is a multiple of 4), the upper halves carried
         // from one group of four columns to the next -- 3/4 of an LDS read per frame pair instead of 3, same additions in the same order.
@@ -545,44 +546,43 @@ __global__ __launch_bounds__(NTHR) void patchnn4_k(NN2Args a, int H_unused, int 
 // 16x16 frame-pair tile accumulates  s_x - 2 u.v  exactly as an fp32 FMA chain -- 64 frame pairs x 3 channels per lane-cycle slot
 // that the VALU form spends on one subtract + one FMA per pair and channel.  The y term depends on tj only: TyP threads keep its
 // window sums on the side (one LDS read + add per column) and it is added when E is written out.
-// gram-major scratch: x [H][W][TxP][4] = (u0, u1, u2, u.u), y [H][W][TyP][4] = (-2 v0, -2 v1, -2 v2, v.v): an operand fragment
-// (lane = frame + 16 * slot) is 64 consecutive floats of a staged column.  Wave w owns frames 16w..16w+15 of x and all TYT tiles of y.
+// gram-major scratch: per pixel the frames in groups of 16, [group][slot][frame], slots x = (u0, u1, u2, u.u), y = (-2 v0, -2 v1, -2 v2, v.v):
+// the operand fragment of a 16-frame tile (lane = frame + 16 * slot) is the group's 64 consecutive floats.  Wave w owns group w of x and
+// all TYT groups of y.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 template <bool IS_Y>
 __global__ __launch_bounds__(256) void video_to_gram_major_k(const float *__restrict__ v, int64_t sc, int64_t st, int64_t sr,
-                                                             int T, int TP, int H, int W, float4 *__restrict__ out) {
-    __shared__ float tile[3][16][65];      // [channel][frame of the chunk][pixel] (+1 pad: conflict-free transposed reads)
-    const int row = blockIdx.y, x0 = blockIdx.x * 64, tid = threadIdx.x;
-    // read: lanes over pixels (coalesced along the row), 12 (channel, frame) pairs per thread and 16-frame chunk; the NEXT chunk's reads
-    // are issued before this chunk is written out, so that they are in flight across the write phase and its barriers
+                                                             int T, int G, int H, int W, float *__restrict__ out) {
+    __shared__ float tile[3][16][65];      // [channel][frame of the group][pixel] (+1 pad: conflict-free transposed reads)
+    const int row = blockIdx.y, x0 = blockIdx.x * 64, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // read: lanes over pixels (coalesced along the row), 12 (channel, frame) pairs per thread and 16-frame group; the NEXT group's reads
+    // are issued before this group is written out, so that they are in flight across the write phase and its barriers
     float pre[12];
-    const int x = x0 + (tid & 63);
-    const float *src = v + (int64_t)row * sr + min(x, W - 1);
+    const float *src = v + (int64_t)row * sr + min(x0 + lane, W - 1);
     auto load = [&](int f0) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
-            const int j = (tid >> 6) + 4 * k, c = j >> 4, f = f0 + (j & 15);
+            const int j = wave + 4 * k, c = j >> 4, f = f0 + (j & 15);
             pre[k] = f < T ? src[c * sc + f * st] : 0.5f;                       // padding frames: u = v = 0
         }
     };
     load(0);
-    for (int f0 = 0; f0 < TP; f0 += 16) {
+    for (int g = 0; g < G; ++g) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
-            const int j = (tid >> 6) + 4 * k;
-            tile[j >> 4][j & 15][tid & 63] = pre[k] - 0.5f;
+            const int j = wave + 4 * k;
+            tile[j >> 4][j & 15][lane] = pre[k] - 0.5f;
         }
         __syncthreads();
-        if (f0 + 16 < TP) load(f0 + 16);
-        // write: 16 lanes = the chunk's frames of one pixel (256 contiguous bytes), 4 pixels per wave
-        for (int p = tid >> 4; p < 64; p += 16) {
-            const int f = f0 + (tid & 15), xp = x0 + p;
-            if (f < TP && xp < W) {
-                const float a0 = tile[0][tid & 15][p], a1 = tile[1][tid & 15][p], a2 = tile[2][tid & 15][p];
-                const float n = fmaf(a2, a2, fmaf(a1, a1, a0 * a0));
-                out[((size_t)row * W + xp) * TP + f] = IS_Y ? make_float4(-2.f * a0, -2.f * a1, -2.f * a2, n) : make_float4(a0, a1, a2, n);
-            }
+        if (g + 1 < G) load((g + 1) * 16);
+        // write: a wave = one pixel's group, 64 contiguous floats = [slot][frame]; 16 pixels per wave
+        const int k = lane >> 4, m = lane & 15;
+        for (int p = wave; p < 64 && x0 + p < W; p += 4) {
+            const float a0 = tile[0][m][p], a1 = tile[1][m][p], a2 = tile[2][m][p];
+            float val = k == 0 ? a0 : (k == 1 ? a1 : (k == 2 ? a2 : fmaf(a2, a2, fmaf(a1, a1, a0 * a0))));
+            if (IS_Y && k < 3) val *= -2.f;
+            out[(((size_t)row * W + x0 + p) * G + g) * 64 + lane] = val;
         }
         __syncthreads();
     }
@@ -610,8 +610,9 @@ __global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, in
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KX = 4, KY = 2 * TYT > 7 ? 7 : 2 * TYT;       // DMA pieces per wave and stage at most (x: 13 * 64 / 64 / 4, y: 13 * 128 / 64 / 4)
     const int RWc = a.ps + (NL - 1) * a.stride;                 // region width in pixels
-    const int xs4 = CHC * a.ps * a.TxP, ys4 = CHC * a.ps * a.TyP;   // float4 per stage and part
-    const int ybase = xs4 * 4, bufF = (xs4 + ys4) * 4 + 64;     // (+ 64 floats: the last tile's over-read)
+    const int PX = a.PX, PY = a.PY, GX = PX >> 4, GY = PY >> 4;   // frames per pixel (whole 16-frame groups) of x / y
+    const int xs4 = CHC * a.ps * PX, ys4 = CHC * a.ps * PY;       // float4 per stage and part
+    const int ybase = xs4 * 4, bufF = (xs4 + ys4) * 4 + (TYT - GY) * 64;   // (+ the over-read of tiles past y's last group)
     float *E = smem;                                            // [TxP][TyP], one location at a time in the epilogue: aliases the staging
     float *colw = E + (size_t)a.TxP * a.TyP;
     float *sy = colw + a.n2;                                    // [TyP] y term of the location being written out
@@ -635,20 +636,20 @@ __global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, in
     int offx[KX], offy[KY];
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
-        const int idx = (wave + 4 * k) * 64 + lane, cc = fdiv_small(idx, a.ps * a.TxP), rem = idx - cc * a.ps * a.TxP, r = fdiv_small(rem, a.TxP);
-        offx[k] = idx < xs4 ? ((r * a.W + cc) * a.TxP + (rem - r * a.TxP)) | (cc << 24) : -1;
+        const int idx = (wave + 4 * k) * 64 + lane, cc = fdiv_small(idx, a.ps * PX), rem = idx - cc * a.ps * PX, r = fdiv_small(rem, PX);
+        offx[k] = idx < xs4 ? ((r * a.W + cc) * PX + (rem - r * PX)) | (cc << 24) : -1;
     }
 #pragma unroll
     for (int k = 0; k < KY; ++k) {
-        const int idx = (wave + 4 * k) * 64 + lane, cc = fdiv_small(idx, a.ps * a.TyP), rem = idx - cc * a.ps * a.TyP, r = fdiv_small(rem, a.TyP);
-        offy[k] = idx < ys4 ? ((r * a.W + cc) * a.TyP + (rem - r * a.TyP)) | (cc << 24) : -1;
+        const int idx = (wave + 4 * k) * 64 + lane, cc = fdiv_small(idx, a.ps * PY), rem = idx - cc * a.ps * PY, r = fdiv_small(rem, PY);
+        offy[k] = idx < ys4 ? ((r * a.W + cc) * PY + (rem - r * PY)) | (cc << 24) : -1;
     }
     const int S = (cols + CHC - 1) / CHC;                       // stages
     auto issue = [&](int st) {
         const int q0 = st * CHC, nc = min(CHC, cols - q0);
         float *dst = smem + (st & 1) * bufF;
-        const float4 *xsrc = reinterpret_cast<const float4 *>(a.xt) + ((size_t)r0 * a.W + c0 + q0) * a.TxP;
-        const float4 *ysrc = reinterpret_cast<const float4 *>(a.yt) + ((size_t)r0 * a.W + c0 + q0) * a.TyP;
+        const float4 *xsrc = reinterpret_cast<const float4 *>(a.xt) + ((size_t)r0 * a.W + c0 + q0) * PX;
+        const float4 *ysrc = reinterpret_cast<const float4 *>(a.yt) + ((size_t)r0 * a.W + c0 + q0) * PY;
 #pragma unroll
         for (int k = 0; k < KX; ++k)
             if (offx[k] >= 0 && (offx[k] >> 24) < nc) lds_dma16(xsrc + (offx[k] & 0xffffff), dst + (wave + 4 * k) * 256);
@@ -656,9 +657,10 @@ __global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, in
         for (int k = 0; k < KY; ++k)
             if (offy[k] >= 0 && (offy[k] >> 24) < nc) lds_dma16(ysrc + (offy[k] & 0xffffff), dst + ybase + (wave + 4 * k) * 256);
     };
-    // operand fragments: lane -> (frame = lane & 15, slot = lane >> 4); over-reads past TxP / TyP land in tile rows / columns that
-    // are never written out
-    const int xoff = (wave * 16 + (lane & 15)) * 4 + (lane >> 4), yoff = ybase + (lane & 15) * 4 + (lane >> 4);
+    // operand fragments: a pixel's frames are stored in groups of 16, [group][slot][frame]: the fragment of a 16-frame tile (lane = frame
+    // + 16 * slot) is the group's 64 consecutive floats -- one conflict-free ds_read_b32 per tile.  (With [frame][slot] the two half-waves
+    // of a read met on the same banks: SQ_LDS_BANK_CONFLICT was twice the LDS-active cycles and the matrix cores 51 % busy.)
+    const int xoff = min(wave, GX - 1) * 64 + lane, yoff = ybase + lane;
     const bool one = lane >= 48;                                 // B slot 3 = 1
     const bool side = tid < a.TyP;
     if (!(a.ablate & 4)) issue(0);
@@ -672,13 +674,13 @@ __global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, in
             const int q = q0 + cc;
 #pragma unroll
             for (int l = 0; l < NL; ++l)
-                if (q == l * a.stride && !(a.ablate & 8)) {      // window of location l starts at this column (uniform): acc = R(end) - R(before start)
+                if (q == l * a.stride) {      // window of location l starts at this column (uniform): acc = R(end) - R(before start)
 #pragma unroll
                     for (int j = 0; j < TYT; ++j) acc[l][j] -= R[j];
                     an[l] -= Rn;
                 }
-            const float *xq = buf + xoff + cc * a.ps * a.TxP * 4, *yq = buf + yoff + cc * a.ps * a.TyP * 4;
-            const float *nq = buf + ybase + (cc * a.ps * a.TyP + (side ? tid : 0)) * 4 + 3;
+            const float *xq = buf + xoff + cc * a.ps * PX * 4, *yq = buf + yoff + cc * a.ps * PY * 4;
+            const float *nq = buf + ybase + cc * a.ps * PY * 4 + (side ? (tid >> 4) * 64 + 48 + (tid & 15) : 48);
             // Operands one row ahead of the MFMAs that use them, in two register sets used alternately: the reads of row r + 1 are issued,
             // row r is contracted, THEN the reads are waited for.  (The read past the column's last row stays put and is dropped.)  hipcc
             // folds such reads back to the top of the iteration that uses them, or waits for them with lgkmcnt(0) right after issuing
@@ -687,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, in
             if constexpr (TYT == 5) {
                 unsigned xad = (unsigned)reinterpret_cast<uintptr_t>(xq), yad = (unsigned)reinterpret_cast<uintptr_t>(yq);
                 unsigned nad = (unsigned)reinterpret_cast<uintptr_t>(nq);
-                const unsigned xstep = a.TxP * 16, ystep = a.TyP * 16;
+                const unsigned xstep = PX * 16, ystep = PY * 16;
                 float a0, n0, b00, b01, b02, b03, b04, a1, n1, b10, b11, b12, b13, b14;
 #define VL3D_NN5_ISSUE(A, N, B0, B1, B2, B3, B4)                                                          \
     asm volatile("ds_read_b32 %0, %7\n\tds_read_b32 %1, %8\n\tds_read_b32 %2, %9\n\tds_read_b32 %3, %9 offset:256\n\t" \
@@ -727,7 +729,7 @@ __global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, in
 #undef VL3D_NN5_MMA
 #undef VL3D_NN5_NEXT
             } else {
-                for (int r = 0; r < a.ps; ++r, xq += a.TxP * 4, yq += a.TyP * 4, nq += a.TyP * 4) {
+                for (int r = 0; r < a.ps; ++r, xq += PX * 4, yq += PY * 4, nq += PY * 4) {
                     const float av = *xq, nv = *nq;
 #pragma unroll
                     for (int j = 0; j < TYT; ++j) R[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, one ? 1.0f : yq[j * 64], R[j], 0, 0, 0);
@@ -736,7 +738,7 @@ __global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, in
             }
 #pragma unroll
             for (int l = 0; l < NL; ++l)
-                if (q == l * a.stride + a.ps - 1 && !(a.ablate & 8)) {   // ... and ends at this one
+                if (q == l * a.stride + a.ps - 1) {   // ... and ends at this one
 #pragma unroll
                     for (int j = 0; j < TYT; ++j) acc[l][j] += R[j];
                     an[l] += Rn;
@@ -1110,11 +1112,12 @@ int plan_nn(const vl3d_loss_desc *d, NNArgs &a, size_t &lds) {
 }  // namespace
 
 static inline int pad4(int t) { return (t + 3) / 4 * 4; }
+static inline int pad16(int t) { return (t + 15) / 16 * 16; }
 
 extern "C" int64_t vl3d_patchnn_scratch_bytes(const vl3d_loss_desc *d) {
     if (!d || d->H <= 0 || d->W <= 0) return 0;
     const int TxU = ((d->Tx - d->pt) / d->stridet) * d->stridet + d->pt;
-    return (int64_t)d->H * d->W * 4 * (pad4(TxU) + pad4(d->Ty)) * (int64_t)sizeof(float);     // the gram-major form (v5): 4 floats per pixel and frame
+    return (int64_t)d->H * d->W * 4 * (pad16(TxU) + pad16(d->Ty)) * (int64_t)sizeof(float);   // the gram-major form (v5): 4 floats per pixel and frame, whole 16-frame groups
 }
 
 extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const float *y, int32_t *nn, void *scratch,
@@ -1130,31 +1133,33 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
         // pixel-major (v2 / v4) or gram-major (v5) copies in the caller's scratch, then the coalesced-staging kernel
         hipStream_t s = (hipStream_t)stream;
         const int pv = desc->variant & 0xf;
-        // v5 (matrix cores) whenever x's frames fit the four waves' 16-row strips and y's its column tiles
-        const int TyT = (a.TyP + 15) / 16;
-        const int nl5 = TyT <= 5 ? 4 : 2;
+        // v5 (matrix cores) whenever x's frames fit the four waves' 16-frame groups and y's its column tiles
+        const int PX = pad16(a.TxU), PY = pad16(desc->Ty), TyT = PY / 16;
+        // (8 / 6 locations per workgroup -- 4.9 / 5.2 instead of 5.75 region columns per location -- need 237 / 195 registers = two workgroups
+        // per CU: 2.81 / 2.87 ms against 2.68 in one process)
+        const int nl5 = TyT <= 5 ? 4 : 2, tyt5 = TyT <= 5 ? 5 : 8;
         const int RWc5 = a.ps + (nl5 - 1) * a.stride;
-        // stage = the most columns (all ps rows each) whose two buffers leave room for three workgroups per CU: 13 pixel columns
-        int ch5 = (int)((53 * 1024 / 2 - 64 * sizeof(float)) / ((size_t)4 * (a.TxP + a.TyP) * sizeof(float))) / a.ps;
+        const size_t pad5 = (size_t)(tyt5 - TyT) * 64 * sizeof(float);
+        // stage = the most columns (all ps rows each) whose two buffers leave room for three workgroups per CU
+        int ch5 = (int)((53 * 1024 / 2 - pad5) / ((size_t)4 * (PX + PY) * sizeof(float))) / a.ps;
         ch5 = ch5 < 1 ? 1 : (ch5 > RWc5 ? RWc5 : ch5);
-        const size_t stage5 = 2 * ((size_t)ch5 * a.ps * 4 * (a.TxP + a.TyP) + 64), epi5 = (size_t)a.TxP * a.TyP + a.n2 + a.TyP;
-        const size_t lds5 = (stage5 > epi5 ? stage5 : epi5) * sizeof(float);
-        const bool fits5 = (size_t)ch5 * a.ps * a.TxP <= 4 * 4 * 64 && (size_t)ch5 * a.ps * a.TyP <= 7 * 4 * 64;     // KX / KY pieces per wave
+        const size_t stage5 = 2 * ((size_t)ch5 * a.ps * 4 * (PX + PY) * sizeof(float) + pad5), epi5 = ((size_t)a.TxP * a.TyP + a.n2 + a.TyP) * sizeof(float);
+        const size_t lds5 = stage5 > epi5 ? stage5 : epi5;
+        const bool fits5 = (size_t)ch5 * a.ps * PX <= 4 * 4 * 64 && (size_t)ch5 * a.ps * PY <= 7 * 4 * 64;     // KX / KY pieces per wave
         // (by default where a column is shared by >= 2 locations on average -- ps 11 / stride 4: 2.64 vs 3.58 ms for v4 at 720p; for 3-pixel
-        // patches at stride 2 the two are within 3 % (2.63 vs 2.54) and v4 needs a quarter less scratch)
-        const bool use_v5 = (pv == 3 || (pv == 0 && a.ps >= 2 * a.stride)) && a.TxP <= 64 && TyT <= 8 && lds5 <= 150 * 1024 && fits5;
-        const int ch = use_v5 ? 4 : 3;
+        // patches at stride 2 the two are within 3 % (2.63 vs 2.54) and v4 needs less scratch)
+        const bool use_v5 = (pv == 3 || (pv == 0 && a.ps >= 2 * a.stride)) && PX <= 64 && TyT <= 8 && lds5 <= 150 * 1024 && fits5;
         float *xt = (float *)scratch;
-        float *yt = xt + (size_t)desc->H * desc->W * ch * a.TxP;
+        float *yt = xt + (size_t)desc->H * desc->W * (use_v5 ? 4 * PX : 3 * a.TxP);
         dim3 tg((desc->W + 63) / 64, desc->H);
         // variant bit 8: the y half of the scratch still holds this y from the previous call (the captured video is constant
         // over the iterations of the training loop; the caller keeps the scratch alive and vouches for it)
         if (use_v5) {
-            hipLaunchKernelGGL(video_to_gram_major_k<false>, tg, dim3(256), 0, s, x, desc->x_sc, desc->x_st, desc->x_sr, a.TxU, a.TxP,
-                               desc->H, desc->W, (float4 *)xt);
+            hipLaunchKernelGGL(video_to_gram_major_k<false>, tg, dim3(256), 0, s, x, desc->x_sc, desc->x_st, desc->x_sr, a.TxU, PX / 16,
+                               desc->H, desc->W, xt);
             if (!(desc->variant & 0x100))
-                hipLaunchKernelGGL(video_to_gram_major_k<true>, tg, dim3(256), 0, s, y, desc->y_sc, desc->y_st, desc->y_sr, desc->Ty, a.TyP,
-                                   desc->H, desc->W, (float4 *)yt);
+                hipLaunchKernelGGL(video_to_gram_major_k<true>, tg, dim3(256), 0, s, y, desc->y_sc, desc->y_st, desc->y_sr, desc->Ty, PY / 16,
+                                   desc->H, desc->W, yt);
         } else {
             hipLaunchKernelGGL(video_to_pixel_major_k, tg, dim3(256), 0, s, x, desc->x_sc, desc->x_st, desc->x_sr, a.TxU, a.TxP,
                                desc->H, desc->W, xt);
@@ -1166,6 +1171,7 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
         b.xt = xt; b.yt = yt; b.nn = nn; b.W = desc->W; b.ps = a.ps; b.pt = a.pt; b.stride = a.stride; b.stridet = a.stridet;
         b.h_o = a.h_o; b.w_o = a.w_o; b.n1 = a.n1; b.n2 = a.n2; b.TxP = a.TxP; b.TyP = a.TyP; b.K = a.K; b.KC = a.KC;
         b.use_alpha = a.use_alpha; b.alpha = a.alpha; b.dnorm = a.inv_d;
+        b.PX = PX; b.PY = PY;
         b.ablate = (desc->variant >> 4) & 15;
         static bool attr2 = false;
         if (!attr2) {
