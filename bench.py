@@ -221,6 +221,7 @@ def main():
     fwd_ms, bwd_ms = [], []
 
     last = {}
+    gather_algo = [a.gather_algo]
 
     def step(timed):
         e0, e1, e2 = ev(), ev(), ev()
@@ -235,7 +236,14 @@ def main():
             comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(comm_stream):
                 if backend == "nccl":
-                    frame = all_gather_frame(rgb.detach(), bands, algo=a.gather_algo)
+                    try:
+                        frame = all_gather_frame(rgb.detach(), bands, algo=gather_algo[0])
+                    except RuntimeError as ex:      # an all-peers gather this RCCL build refuses: every rank sees the same error -> ring
+                        if gather_algo[0] == "ring":
+                            raise
+                        print(f"[bench] rank {rank}: gather algo {gather_algo[0]!r} failed ({ex}); falling back to RCCL's all_gather", file=sys.stderr)
+                        gather_algo[0] = "ring"
+                        frame = all_gather_frame(rgb.detach(), bands, algo="ring")
                 else:   # debugging path only (gloo moves host tensors)
                     frame = all_gather_frame(rgb.detach().cpu(), bands, algo=a.gather_algo)
         (gs,) = torch.autograd.grad(rgb, stack, g_rgb)
@@ -329,7 +337,7 @@ def main():
     }
     if world > 1:
         band_bytes = T * max(b.rows for b in bands) * W * 3 * 4
-        algo = a.gather_algo if a.gather_algo != "auto" else ("direct" if (world > 2 and backend == "nccl") else "ring")
+        algo = gather_algo[0] if gather_algo[0] != "auto" else ("direct" if (world > 2 and backend == "nccl") else "ring")
         ov = halo_overlaps(bands, rank)
         res["collective"] = {
             "op": "all-gather of the composited bands", "algo": algo, "verified": gather_check, "bytes_per_rank_sent": band_bytes * (world - 1) if algo == "direct" else band_bytes,
