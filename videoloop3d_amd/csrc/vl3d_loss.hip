@@ -1145,7 +1145,8 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
         ch5 = ch5 < 1 ? 1 : (ch5 > RWc5 ? RWc5 : ch5);
         const size_t stage5 = 2 * ((size_t)ch5 * a.ps * 4 * (PX + PY) * sizeof(float) + pad5), epi5 = ((size_t)a.TxP * a.TyP + a.n2 + a.TyP) * sizeof(float);
         const size_t lds5 = stage5 > epi5 ? stage5 : epi5;
-        const bool fits5 = (size_t)ch5 * a.ps * PX <= 4 * 4 * 64 && (size_t)ch5 * a.ps * PY <= 7 * 4 * 64;     // KX / KY pieces per wave
+        const bool fits5 = (size_t)ch5 * a.ps * PX <= 4 * 4 * 64 && (size_t)ch5 * a.ps * PY <= 7 * 4 * 64 &&  // KX / KY pieces per wave
+                           ((size_t)a.ps * desc->W + ch5) * (PX > PY ? PX : PY) < (1u << 24);                  // 24-bit DMA source offsets
         // (by default where a column is shared by >= 2 locations on average -- ps 11 / stride 4: 2.64 vs 3.58 ms for v4 at 720p; for 3-pixel
         // patches at stride 2 the two are within 3 % (2.63 vs 2.54) and v4 needs less scratch)
         const bool use_v5 = (pv == 3 || (pv == 0 && a.ps >= 2 * a.stride)) && PX <= 64 && TyT <= 8 && lds5 <= 150 * 1024 && fits5;
