@@ -225,7 +225,11 @@ typedef struct vl3d_loss_desc {
     float alpha;           /* utils_vid.py:133-134 normaliser offset */
     int64_t x_sc, x_st, x_sr;
     int64_t y_sc, y_st, y_sr;
-    int32_t variant;       /* kernel variant selector; 0 = default */
+    int32_t variant;       /* kernel variant selector for A/B measurements and cross-checks; 0 = default.  Bits 0-3, vl3d_patchnn: 1 strided
+                            * staging (no scratch), 2 one location per workgroup, 3 the fp32 matrix-core kernel, 4 the vector-ALU kernel
+                            * (0 picks 3 where a region column is shared by >= 2 locations, ps >= 2 stride, else 4); vl3d_vote_fold: 1 = the
+                            * unstaged kernel.  Bits 4-7: ablation switches (timing only, results invalid).  Bit 8: see vl3d_patchnn.
+                            * Bits 12-15, vl3d_vote_fold*: tile shape index + 1. */
 } vl3d_loss_desc;
 
 /* bytes of device scratch vl3d_patchnn needs for this problem (0 if none). */
@@ -235,7 +239,8 @@ int64_t vl3d_patchnn_scratch_bytes(const vl3d_loss_desc *desc);
  * optional column-min normalisation (utils_vid.py:109-119,133-134), row argmin, first minimum wins
  * (utils_vid.py:139-141).  nn is int32 [h_o, w_o, n1].  Replaces extract_3Dpatches x2 +
  * get_NN_indices_low_memory (utils_vid.py:209-216).
- * The kernel works on pixel-major copies of x and y kept in `scratch`.  desc->variant bit 8 (0x100): the y copy in `scratch`
+ * The kernel works on pixel-major copies of x and y kept in `scratch` (their layout belongs to the kernel variant: a scratch filled
+ * under one variant is not valid for another).  desc->variant bit 8 (0x100): the y copy in `scratch`
  * is still valid from the previous call with the same y, configuration and scratch buffer -- skip re-building it (the
  * captured video y is constant over the iterations of a training loop; x, the render, is not). */
 int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const float *y, int32_t *nn,
