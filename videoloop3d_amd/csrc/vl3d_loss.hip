@@ -272,7 +272,8 @@ __global__ __launch_bounds__(NN_THREADS) void patchnn2_k(NN2Args a) {
 // w_j = (1 / d) / (alpha + min_i s / d): a score is s * w_j -- three LDS reads, two adds and a multiply per frame pair instead of two
 // fp32 divisions (which were most of the epilogue's instructions).  Without alpha the raw sums are compared.  The rounding differs
 // from the reference's two divisions by an ulp, i.e. only between exact near-ties.  Whole workgroup, 4 lanes per row / column.
-template <int NTHR>
+// PREINIT: the caller has set colw[0..n2) to +inf (bit pattern) behind a barrier already
+template <int NTHR, bool PREINIT = false>
 __device__ __forceinline__ void nn_epilogue(const NN2Args &a, const float *E, float *colw, size_t b, int tid, int sub) {
     if (a.pt == 3 && a.stridet == 1) {
         // every shipped configuration: three-frame patches at temporal stride 1.  s(i, j..j+3) needs E(i, j..j+3), E(i+1, j+1..j+4) and
@@ -284,8 +285,10 @@ __device__ __forceinline__ void nn_epilogue(const NN2Args &a, const float *E, fl
             // column minima: a thread takes four adjacent columns of every nrg-th row; the row groups meet in an LDS integer min
             // (the sums are >= +0 or NaN: their bit patterns order like the values and NaN never wins, as with fminf)
             int *cmi = reinterpret_cast<int *>(colw);
-            for (int j = tid; j < a.n2; j += NTHR) cmi[j] = 0x7f800000;
-            __syncthreads();
+            if (!PREINIT) {
+                for (int j = tid; j < a.n2; j += NTHR) cmi[j] = 0x7f800000;
+                __syncthreads();
+            }
             const int ngrp = TyP / 4, nrg = NTHR / ngrp, jg = tid % ngrp, ig = tid / ngrp;
             if (ig < nrg) {
                 float m0 = INFINITY, m1 = INFINITY, m2 = INFINITY, m3 = INFINITY;
@@ -615,7 +618,8 @@ __global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, in
     const int ybase = xs4 * 4, bufF = (xs4 + ys4) * 4 + (TYT - GY) * 64;   // (+ the over-read of tiles past y's last group)
     float *E = smem;                                            // [TxP][TyP], one location at a time in the epilogue: aliases the staging
     float *colw = E + (size_t)a.TxP * a.TyP;
-    float *sy = colw + a.n2;                                    // [TyP] y term of the location being written out
+    const int n2p = (a.n2 + 3) & ~3;                            // (16-byte aligned weight rows: the epilogue reads them four at a time)
+    float *sy = colw + NL * n2p;                                // [NL][TyP] y terms of the locations   (colw: [NL][n2p])
     const int g = blockIdx.x, by = g / groups_x, bx0 = (g % groups_x) * NL;
     const int r0 = by * a.stride, c0 = bx0 * a.stride, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -747,23 +751,27 @@ __global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, in
     }
     // epilogue, one location at a time through the shared E buffer.  C/D layout of a 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg
     const int sub = tid & 3;
+    __syncthreads();                                             // the staging buffers are dead from here on
+    if (tid < a.TyP) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) sy[l * a.TyP + tid] = an[l];
+    }
+    for (int j = tid; j < NL * n2p; j += 256) reinterpret_cast<int *>(colw)[j] = 0x7f800000;     // column minima start at +inf
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
         if (l >= nloc) break;                                    // uniform
-        __syncthreads();
-        if (tid < a.TyP) sy[tid] = an[l];
-        __syncthreads();
+        __syncthreads();                                         // sy written / the previous location's E read
 #pragma unroll
         for (int j = 0; j < TYT; ++j)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int row = wave * 16 + (lane >> 4) * 4 + rr, col = j * 16 + (lane & 15);
-                if (row < a.TxP && col < a.TyP) E[row * a.TyP + col] = fmaxf(acc[l][j][rr] + sy[col], 0.0f);
+                if (row < a.TxP && col < a.TyP) E[row * a.TyP + col] = fmaxf(acc[l][j][rr] + sy[l * a.TyP + col], 0.0f);
             }
         __syncthreads();
         const size_t b = (size_t)by * a.w_o + bx0 + l;
         if (a.ablate & 1) { if (tid < a.n1) a.nn[b * a.n1 + tid] = 0; continue; }
-        nn_epilogue<256>(a, E, colw, b, tid, sub);
+        nn_epilogue<256, true>(a, E, colw + l * n2p, b, tid, sub);
     }
 }
 
@@ -1143,7 +1151,7 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
         // stage = the most columns (all ps rows each) whose two buffers leave room for three workgroups per CU
         int ch5 = (int)((53 * 1024 / 2 - pad5) / ((size_t)4 * (PX + PY) * sizeof(float))) / a.ps;
         ch5 = ch5 < 1 ? 1 : (ch5 > RWc5 ? RWc5 : ch5);
-        const size_t stage5 = 2 * ((size_t)ch5 * a.ps * 4 * (PX + PY) * sizeof(float) + pad5), epi5 = ((size_t)a.TxP * a.TyP + a.n2 + a.TyP) * sizeof(float);
+        const size_t stage5 = 2 * ((size_t)ch5 * a.ps * 4 * (PX + PY) * sizeof(float) + pad5), epi5 = ((size_t)a.TxP * a.TyP + 4 * (a.n2 + 3 + a.TyP)) * sizeof(float);
         const size_t lds5 = stage5 > epi5 ? stage5 : epi5;
         const bool fits5 = (size_t)ch5 * a.ps * PX <= 4 * 4 * 64 && (size_t)ch5 * a.ps * PY <= 7 * 4 * 64 &&  // KX / KY pieces per wave
                            ((size_t)a.ps * desc->W + ch5) * (PX > PY ? PX : PY) < (1u << 24);                  // 24-bit DMA source offsets
