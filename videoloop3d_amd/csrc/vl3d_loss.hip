@@ -761,12 +761,15 @@ __global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, in
     for (int l = 0; l < NL; ++l) {
         if (l >= nloc) break;                                    // uniform
         __syncthreads();                                         // sy written / the previous location's E read
+        float syv[TYT];                                          // the y terms of this lane's columns: read together, ahead of the stores
+#pragma unroll
+        for (int j = 0; j < TYT; ++j) syv[j] = sy[l * a.TyP + min(j * 16 + (lane & 15), a.TyP - 1)];
 #pragma unroll
         for (int j = 0; j < TYT; ++j)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int row = wave * 16 + (lane >> 4) * 4 + rr, col = j * 16 + (lane & 15);
-                if (row < a.TxP && col < a.TyP) E[row * a.TyP + col] = fmaxf(acc[l][j][rr] + sy[l * a.TyP + col], 0.0f);
+                if (row < a.TxP && col < a.TyP) E[row * a.TyP + col] = fmaxf(acc[l][j][rr] + syv[j], 0.0f);
             }
         __syncthreads();
         const size_t b = (size_t)by * a.w_o + bx0 + l;
