@@ -134,7 +134,7 @@ def loss_bench(dev, H, W, T, Ty, steps):
         # makes the patch distance out of them
         TxP, TyP = -(-(T + 2) // 4) * 4, -(-Ty // 4) * 4
         cells = (B / 4) * ps * (ps + 3 * st_)                                  # (row, column) cells of the regions
-        if ps >= 2 * st_ and TxP <= 64 and TyP <= 80:
+        if TxP <= 64 and TyP <= 80:
             # v5, matrix cores: one v_mfma_f32_16x16x4_f32 per cell and 16x16 frame-pair tile, 4 x 5 tiles, k = 3 channels + the |x|^2 slot.
             # `achieved` counts the useful multiply-adds only (3 channels x the real TxP x TyP frame pairs), `issued` what the tiles cost.
             own_flops = 2.0 * cells * 3 * TxP * TyP

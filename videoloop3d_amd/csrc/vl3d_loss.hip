@@ -1158,9 +1158,9 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
         const size_t lds5 = stage5 > epi5 ? stage5 : epi5;
         const bool fits5 = (size_t)ch5 * a.ps * PX <= 4 * 4 * 64 && (size_t)ch5 * a.ps * PY <= 7 * 4 * 64 &&  // KX / KY pieces per wave
                            ((size_t)a.ps * desc->W + ch5) * (PX > PY ? PX : PY) < (1u << 24);                  // 24-bit DMA source offsets
-        // (by default where a column is shared by >= 2 locations on average -- ps 11 / stride 4: 2.64 vs 3.58 ms for v4 at 720p; for 3-pixel
-        // patches at stride 2 the two are within 3 % (2.63 vs 2.54) and v4 needs less scratch)
-        const bool use_v5 = (pv == 3 || (pv == 0 && a.ps >= 2 * a.stride)) && PX <= 64 && TyT <= 8 && lds5 <= 150 * 1024 && fits5;
+        // (the default wherever it applies: 2.52 vs 3.55 ms for v4 at 720p with 11-pixel patches at stride 4, 2.45 vs 2.54 ms with 3-pixel
+        // patches at stride 2, profiles/ab_loss.py)
+        const bool use_v5 = (pv == 3 || pv == 0) && PX <= 64 && TyT <= 8 && lds5 <= 150 * 1024 && fits5;
         float *xt = (float *)scratch;
         float *yt = xt + (size_t)desc->H * desc->W * (use_v5 ? 4 * PX : 3 * a.TxP);
         dim3 tg((desc->W + 63) / 64, desc->H);
