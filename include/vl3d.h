@@ -271,6 +271,14 @@ int vl3d_vote_fold_robust(const vl3d_loss_desc *desc, const float *y, const int3
                           float rou, float scale, float *y2x, float *weight, float *grad_x, double *loss_sum,
                           vl3d_stream_t stream);
 
+/* The same with grad_x addressed through strides (elements): channel, frame, row; unit column stride.  The reference trims x to the
+ * patch grid by slicing before the loss (utils_vid.py:307-320), so the gradient of the untrimmed x is zero outside the trimmed box:
+ * the caller hands a zero-filled buffer of x's FULL shape and its strides, and the slice's backward (a zero fill and a copy per sliced
+ * axis) never runs. */
+int vl3d_vote_fold_robust_strided(const vl3d_loss_desc *desc, const float *y, const int32_t *nn, const float *x, int32_t rho_kind,
+                                  float rou, float scale, float *y2x, float *weight, float *grad_x, int64_t gx_sc, int64_t gx_st,
+                                  int64_t gx_sr, double *loss_sum, vl3d_stream_t stream);
+
 /* robust_lossfun (utils_vid.py:10-26) fused with the mean (utils_vid.py:348).
  * kind: 0 'mse', 1 'abs', 2 general Barron with float rou (rou==0 and rou==2 special-cased as the reference).
  * loss_sum: device double, overwritten with sum over n elements of rho(x - y2x). */

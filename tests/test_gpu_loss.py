@@ -248,6 +248,27 @@ def test_patchnn_matrix_core_tile_counts(dev, tx, ty, ps, s, alpha, monkeypatch)
     assert nbad <= nng.numel() // 100
 
 
+def test_lowmem_loss_trims_inside_the_fused_op(dev):
+    """The LowMem class trims x to the patch grid (utils_vid.py:307-320).  Here the fused op does it on the untrimmed tensor and writes
+    the gradient in x's full shape: same loss and same gradient as slicing first (bit for bit), exact zeros outside the trimmed box."""
+    from videoloop3d_amd.utils_vid import Patch3DGPNNLowMemLoss
+    cfg = dict(macro_block=65, patch_size=5, stride=3, patcht_size=3, stridet=2, rou='-2', scaling=0.1, alpha=0.5)
+    x0 = synth.make_video(10, 25, 31, seed=11).to(dev)            # trims to t 9, h 23, w 29
+    y = synth.make_video(14, 25, 31, seed=12).to(dev)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        xa = x0.clone().requires_grad_(True)
+        la = Patch3DGPNNLowMemLoss()(xa, y, **cfg)
+        (ga,) = torch.autograd.grad(la, xa)
+        xb = x0.clone().requires_grad_(True)
+        lb = Patch3DGPNNLowMemLoss()(xb[..., :9, :23, :29], y, **cfg)     # the caller slices: autograd's slice backward pads the gradient
+        (gb,) = torch.autograd.grad(lb, xb)
+    assert float(la) == float(lb)
+    assert torch.equal(ga, gb)
+    assert float(ga[..., 9:, :, :].abs().max()) == 0 and float(ga[..., 23:, :].abs().max()) == 0 and float(ga[..., 29:].abs().max()) == 0
+    assert float(ga.abs().max()) > 0
+
+
 def test_g10_compute_nnerr(dev, golden):
     """evaluations/NNMSE.compute_nnerr on the HIP patch-NN path vs the reference golden G10."""
     import warnings as _w

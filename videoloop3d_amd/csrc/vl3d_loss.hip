@@ -889,6 +889,7 @@ struct FoldArgs {
     Rho rho;
     float gscale;
     float *gx;
+    int64_t gx_sc, gx_st, gx_sr;      // strides of gx (channel, frame, row), unit column stride
     double *loss_sum;
 };
 
@@ -1026,7 +1027,7 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
             float f, g;
             rho_fg(a.rho, e, f, g);
             lacc += f;
-            a.gx[(size_t)c * cs + (size_t)tau * fs + (size_t)eta * a.W + xi] = g * a.gscale;
+            a.gx[(int64_t)c * a.gx_sc + (int64_t)tau * a.gx_st + (int64_t)eta * a.gx_sr + xi] = g * a.gscale;
         }
     }
     }
@@ -1325,13 +1326,14 @@ extern "C" int vl3d_vote_fold(const vl3d_loss_desc *desc, const float *y, const 
     return VL3D_OK;
 }
 
-extern "C" int vl3d_vote_fold_robust(const vl3d_loss_desc *desc, const float *y, const int32_t *nn, const float *x, int32_t kind,
-                                     float rou, float scale, float *y2x, float *weight, float *grad_x, double *loss_sum,
-                                     vl3d_stream_t stream) {
+extern "C" int vl3d_vote_fold_robust_strided(const vl3d_loss_desc *desc, const float *y, const int32_t *nn, const float *x, int32_t kind,
+                                             float rou, float scale, float *y2x, float *weight, float *grad_x, int64_t gx_sc,
+                                             int64_t gx_st, int64_t gx_sr, double *loss_sum, vl3d_stream_t stream) {
     int rc = check_loss(desc);
     if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE(y && nn && x && y2x && weight && grad_x && loss_sum, "vl3d_vote_fold_robust: null pointer");
     VL3D_REQUIRE(kind >= 0 && kind <= 2 && scale != 0.0f, "vl3d_vote_fold_robust: bad rho kind / scale");
+    VL3D_REQUIRE(gx_sr >= desc->W && gx_st >= 0 && gx_sc >= 0, "vl3d_vote_fold_robust: bad grad_x strides");
     VL3D_REQUIRE(desc->Tx <= 65535, "vl3d_vote_fold_robust: Tx > 65535");
     FoldArgs a{};
     a.y = y; a.nn = nn; a.sum = y2x; a.weight = weight;
@@ -1345,7 +1347,7 @@ extern "C" int vl3d_vote_fold_robust(const vl3d_loss_desc *desc, const float *y,
     a.x = x; a.x_sc = desc->x_sc; a.x_st = desc->x_st; a.x_sr = desc->x_sr;
     a.rho = make_rho(kind, rou, scale);
     a.gscale = 1.0f / (3.0f * (float)desc->Tx * (float)desc->H * (float)desc->W);     // d(mean)/d(element)
-    a.gx = grad_x; a.loss_sum = loss_sum;
+    a.gx = grad_x; a.gx_sc = gx_sc; a.gx_st = gx_st; a.gx_sr = gx_sr; a.loss_sum = loss_sum;
     const int shape = fold_shape(desc, a.n1);
     if (shape < 0) {
         vl3d_set_error("vl3d_vote_fold_robust: tile does not fit LDS; use vl3d_vote_fold + vl3d_robust_fwd/bwd");
@@ -1356,6 +1358,14 @@ extern "C" int vl3d_vote_fold_robust(const vl3d_loss_desc *desc, const float *y,
     if (rc != VL3D_OK) return rc;
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
+}
+
+extern "C" int vl3d_vote_fold_robust(const vl3d_loss_desc *desc, const float *y, const int32_t *nn, const float *x, int32_t kind,
+                                     float rou, float scale, float *y2x, float *weight, float *grad_x, double *loss_sum,
+                                     vl3d_stream_t stream) {
+    if (!desc) { vl3d_set_error("vl3d_vote_fold_robust: null descriptor"); return VL3D_EINVAL; }
+    const int64_t fs = (int64_t)desc->H * desc->W;
+    return vl3d_vote_fold_robust_strided(desc, y, nn, x, kind, rou, scale, y2x, weight, grad_x, fs * desc->Tx, fs, desc->W, loss_sum, stream);
 }
 
 extern "C" int vl3d_robust_fwd(int64_t n, const float *x, const float *y2x, int32_t kind, float rou, float scale,

@@ -226,29 +226,37 @@ class _RobustMean(torch.autograd.Function):
 class _FoldRobustMean(torch.autograd.Function):
     """loss = robust_lossfun(x - fold(y, nn)/weight, rou, scaling).mean() in ONE pass over the video (vl3d_vote_fold_robust):
     the NN search (no_grad in the reference, utils_vid.py:279,322), the vote-fold, the loss sum and d loss / d x.  Returns
-    (loss, y2x, weight); gradient flows to x only, through the loss."""
+    (loss, y2x, weight); gradient flows to x only, through the loss.
+    trim = (t, h, w): x arrives UNTRIMMED and the op works on x[..., :t, :h, :w] like the reference's slicing (utils_vid.py:307-320);
+    its gradient is written straight into a zero-filled buffer of x's full shape, so the three slice backwards (a zero fill and a
+    copy of the whole video each) never run."""
 
     @staticmethod
-    def forward(ctx, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant=False):
-        nn, desc, xv, yv = find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha, y_is_constant)
+    def forward(ctx, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant=False, trim=None):
+        xs = x if trim is None else x[..., :trim[0], :trim[1], :trim[2]]
+        nn, desc, xv, yv = find_nn_indices(xs, y, patch_size, patcht_size, stride, stridet, alpha, y_is_constant)
         dev = xv.device
         y2x = torch.empty((1, 3, desc.Tx, desc.H, desc.W), dtype=torch.float32, device=dev)
         w = torch.empty((1, 1, desc.Tx, desc.H, desc.W), dtype=torch.float32, device=dev)
-        gx = torch.empty((1, 3, desc.Tx, desc.H, desc.W), dtype=torch.float32, device=dev)
+        if tuple(xs.shape) == tuple(x.shape):
+            gx = torch.empty((1, 3, desc.Tx, desc.H, desc.W), dtype=torch.float32, device=dev)
+        else:
+            gx = torch.zeros(x.shape, dtype=torch.float32, device=dev)
         acc = torch.empty((), dtype=torch.float64, device=dev)
         kind, r = _rho_kind(rou)
         with torch.cuda.device(dev):
-            L.check(L.lib().vl3d_vote_fold_robust(desc, L.ptr(yv), L.ptr(nn), L.ptr(xv), kind, r, float(scaling), L.ptr(y2x),
-                                                  L.ptr(w), L.ptr(gx), L.ptr(acc), L.stream_ptr(dev)), "vl3d_vote_fold_robust")
+            L.check(L.lib().vl3d_vote_fold_robust_strided(desc, L.ptr(yv), L.ptr(nn), L.ptr(xv), kind, r, float(scaling), L.ptr(y2x),
+                                                          L.ptr(w), L.ptr(gx), gx.stride(1), gx.stride(2), gx.stride(3), L.ptr(acc),
+                                                          L.stream_ptr(dev)), "vl3d_vote_fold_robust_strided")
         ctx.save_for_backward(gx)
-        ctx.x_shape = x.shape
+        ctx.x_dtype = x.dtype
         ctx.mark_non_differentiable(y2x, w)
-        return (acc / gx.numel()).to(torch.float32), y2x, w
+        return (acc / (3 * desc.Tx * desc.H * desc.W)).to(torch.float32), y2x, w
 
     @staticmethod
     def backward(ctx, g, _gy2x, _gw):
         (gx,) = ctx.saved_tensors
-        return (gx * g.to(torch.float32)).reshape(ctx.x_shape), None, None, None, None, None, None, None, None, None
+        return (gx * g.to(torch.float32)).to(ctx.x_dtype), None, None, None, None, None, None, None, None, None, None
 
 
 def fit_patch(size, name, patch, step):
@@ -260,19 +268,21 @@ def fit_patch(size, name, patch, step):
     return trimmed
 
 
-def _gpnn_loss(holder, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant=False):
+def _gpnn_loss(holder, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant=False, trim=None):
     """NN search + vote-fold + robust mean, fused (one pass over the video for fold, loss and gradient); falls back to the
     separate kernels when a fold tile does not fit LDS, or when x does not fit the patch grid (direct path only: the LowMem class
     trims first).  Caches y2x / weight on `holder` like the reference (utils_vid.py:345-346)."""
-    t, h, w = x.shape[-3:]
+    t, h, w = x.shape[-3:] if trim is None else trim
     fits_grid = (_floored(t, patcht_size, stridet), _floored(h, patch_size, stride), _floored(w, patch_size, stride)) == (t, h, w)
     try:
         if not fits_grid:
             raise RuntimeError("x does not fit the patch grid: unfused path")
-        loss, y2x, weight = _FoldRobustMean.apply(x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant)
+        loss, y2x, weight = _FoldRobustMean.apply(x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant, trim)
     except RuntimeError as e:
         if "does not fit LDS" not in str(e) and "does not fit the patch grid" not in str(e):
             raise
+        if trim is not None:
+            x = x[..., :t, :h, :w]
         with torch.no_grad():
             y2x, weight, _ = _nn_and_fold_any_size(x, y, patch_size, patcht_size, stride, stridet, alpha, normalize=True,
                                                    y_is_constant=y_is_constant)
@@ -323,14 +333,15 @@ class Patch3DGPNNLowMemLoss:
             h = fit_patch(h, "patch_height", patch_size, stride)
             w = fit_patch(w, "patch_width", patch_size, stride)
             t = fit_patch(t, "frame_num", patcht_size, stridet)
-            x = x[..., :t, :h, :w]
             y = y[..., :h, :w]
             alpha = kwargs.get("alpha", 1e10)
             alpha = None if alpha > 100 else alpha
             if kwargs.get("dist_fn", "mse") != "mse":
                 raise RuntimeError("dist_fn other than 'mse' is not settable in the reference")
+            # x is trimmed INSIDE the fused op (same values as slicing here, utils_vid.py:318): its gradient comes back in x's full shape
+            trim = None if (t, h, w) == tuple(x.shape[-3:]) else (t, h, w)
             return _gpnn_loss(self, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling,
-                              bool(kwargs.get("y_is_constant", False)))
+                              bool(kwargs.get("y_is_constant", False)), trim)
         return _RobustMean.apply(x, y2x, rou, scaling)
 
 
