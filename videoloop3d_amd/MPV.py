@@ -237,7 +237,7 @@ class MPMeshVid(nn.Module):
             self._window_opt.flush()
 
     def crop_window(self, homos, H, W, margin=3):
-        """texel window (y0, x0, wh, ww), aligned to the optimiser's 16-texel tiles, that contains every tap of every pixel of the
+        """texel window (y0, x0, wh, ww), aligned to the optimiser's bookkeeping tiles, that contains every tap of every pixel of the
         H x W view on every plane: the image of the view's corners under the plane homographies (convex: extremes at the corners),
         plus the +1 bilinear tap and a margin.  homos [D,3,3] on the HOST (float64)."""
         from .optim import align_window

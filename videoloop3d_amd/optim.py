@@ -4,7 +4,7 @@
 the one-pass update -- while touching only the texels the current training crop can reach:
 
   forward   `window_leaf(window)` computes the window's CURRENT parameters (replaying, in registers, the zero-gradient Adam steps its
-            16 x 16-texel tiles have missed: momentum keeps moving a texel after its gradient is gone) into a compact (D,T,wh,ww,4)
+            bookkeeping tiles (8 x 8 texels) have missed: momentum keeps moving a texel after its gradient is gone) into a compact (D,T,wh,ww,4)
             copy, an autograd LEAF; the render reads it and the backward fills its .grad -- a compact gradient, no zero fill of the
             rest of the stack.  The stack itself is not written.
   step()    replays the same missed steps again and applies the step to the window from that compact gradient: (p, m, v) of the
@@ -20,9 +20,14 @@ import torch
 from . import _lib as L
 
 
+def tile_side():
+    """side of the optimiser's bookkeeping tiles in texels (a constant of the HIP library)."""
+    return int(L.lib().vl3d_adam_window_tile())
+
+
 def align_window(y0, y1, x0, x1, Hs, Ws):
     """[y0,y1) x [x0,x1) clamped to the plane and grown to the bookkeeping tiles -> (y0, x0, wh, ww)."""
-    ts = 16
+    ts = tile_side()
     y0, x0 = max(0, y0) // ts * ts, max(0, x0) // ts * ts
     y1, x1 = min(Hs, -(-min(Hs, y1) // ts) * ts), min(Ws, -(-min(Ws, x1) // ts) * ts)
     return y0, x0, max(y1 - y0, 0), max(x1 - x0, 0)
@@ -56,7 +61,8 @@ class WindowAdam(torch.optim.Optimizer):
             D, T, Hs, Ws, _ = p.shape
             st["exp_avg"] = torch.zeros_like(p)
             st["exp_avg_sq"] = torch.zeros_like(p)
-            st["last_step"] = torch.zeros((D, (Hs + 15) // 16, (Ws + 15) // 16), dtype=torch.int32, device=p.device)
+            ts = tile_side()
+            st["last_step"] = torch.zeros((D, (Hs + ts - 1) // ts, (Ws + ts - 1) // ts), dtype=torch.int32, device=p.device)
             st["hist"] = torch.zeros((1024, 2), dtype=torch.float32, device=p.device)
         return st
 
