@@ -137,7 +137,7 @@ int vl3d_adam_step_tiles(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uin
 
 /* Crop-aware Adam for the DENSE stack (csrc/vl3d_optim.hip; the optimiser of train_3dvid.py:263-290 / MPV.py:199-214).  A training
  * iteration renders one crop, so only the texels of the crop's parallax window (y0, x0, wh, ww; aligned to
- * vl3d_adam_window_tile() = 16-texel tiles, or ending at the plane border) receive a gradient; the zero-gradient Adam steps of all
+ * vl3d_adam_window_tile()-texel tiles, or ending at the plane border) receive a gradient; the zero-gradient Adam steps of all
  * other texels (m <- b1 m, v <- b2 v, p <- p - lr_t m^/(sqrt(v^) + eps)) are deferred and replayed exactly, per tile, when a tile is
  * next needed.  last_step: device int32 [D][ceil(Hs/16)][ceil(Ws/16)], the step each tile is current for (0 initially).
  * hist: device float2 [steps+1], entry t = (lr_t / (1 - beta1^t), sqrt(1 - beta2^t)) as vl3d_adam_step_scalars computes them,
@@ -163,6 +163,22 @@ int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t 
                           const float *hist, float lr, float beta1, float beta2, float eps, int64_t step, const uint8_t *quad_keep,
                           const uint8_t *quad_dyn,
                           int32_t QH, int32_t QW, int32_t static_tied, vl3d_stream_t stream);
+
+/* The same two with per-plane boxes: plane_boxes [D][4] = (y0, y1, x0, x1) in plane texels, tile aligned, inside the window, in HOST
+ * memory -- 16 bytes per plane that travel in the kernel arguments, no copy, no synchronisation (NULL, or more than 128 planes: the whole
+ * window for every plane).  The window of a crop is the union of the planes' footprints; texels of the window outside
+ * their own plane's box cannot be sampled in this iteration, their gradient is exactly zero and their update stays deferred like that of
+ * every texel outside the window: the catch-up leaves their slots of the compact copy unwritten (never read), the step skips them. */
+int vl3d_adam_window_catchup_boxes(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
+                                   float *param, float *exp_avg, float *exp_avg_sq, int32_t *last_step, const float *hist, int32_t upto,
+                                   float beta1, float beta2, float eps, float *compact, const uint8_t *quad_keep, const uint8_t *quad_dyn,
+                                   int32_t QH, int32_t QW, float culled_alpha, int32_t mirror_static, const int32_t *plane_boxes,
+                                   vl3d_stream_t stream);
+int vl3d_adam_window_step_boxes(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
+                                float *param, const float *grad_compact, float *exp_avg, float *exp_avg_sq, int32_t *last_step,
+                                const float *hist, float lr, float beta1, float beta2, float eps, int64_t step, const uint8_t *quad_keep,
+                                const uint8_t *quad_dyn, int32_t QH, int32_t QW, int32_t static_tied, const int32_t *plane_boxes,
+                                vl3d_stream_t stream);
 void vl3d_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, float *lr_bc1, float *bc2s);
 
 /* Layer-space smoothness regularisers (MPV.py:517-531 rgb_smooth / a_smooth) WITHOUT the materialised [T,h,w,K,4] layer

@@ -19,11 +19,14 @@ def dev():
     return torch.device("cuda:0")
 
 
-def test_window_adam_equals_torch_adam_over_a_shuffled_window_schedule(dev):
+@pytest.mark.parametrize("with_boxes", [False, True])
+def test_window_adam_equals_torch_adam_over_a_shuffled_window_schedule(dev, with_boxes):
     """the optimiser alone, on identical gradients: torch.optim.Adam sees the dense gradient (zero outside the step's window),
     WindowAdam the compact one; windows jump around, overlap, leave tiles untouched for many steps, the learning rate changes
-    every step (train_3dvid.py:263-277), and one step has no window at all (dense fallback).  After flush(): equal to 2e-6."""
-    from videoloop3d_amd.optim import WindowAdam, align_window
+    every step (train_3dvid.py:263-277), and one step has no window at all (dense fallback).  After flush(): equal to 2e-6.
+    with_boxes: every plane has its own box inside the window (what a crop's parallax leaves of the union window for one plane): the
+    gradient is zero outside it, the leaf shows zeros there, and those texels' updates stay deferred like the rest of the plane."""
+    from videoloop3d_amd.optim import WindowAdam, align_window, tile_side
     D, T, Hs, Ws = 3, 2, 75, 101
     g = torch.Generator().manual_seed(11)
     p0 = (torch.rand((D, T, Hs, Ws, 4), generator=g) - 0.5).to(dev)
@@ -48,10 +51,24 @@ def test_window_adam_equals_torch_adam_over_a_shuffled_window_schedule(dev):
         y0, x0 = r(0, Hs - 20), r(0, Ws - 20)
         win = align_window(y0, y0 + r(10, 40), x0, x0 + r(10, 50), Hs, Ws)
         wy, wx, wh, ww = win
-        leaf = ob.window_leaf(win)
+        inside = torch.ones((D, 1, wh, ww, 1), dtype=torch.bool)
+        boxes = None
+        if with_boxes:
+            ts, boxes = tile_side(), []
+            for d in range(D):               # a tile-aligned sub-box of the window per plane (one plane gets an empty one now and then)
+                by0, by1 = sorted((wy + r(0, wh // ts) * ts, wy + r(0, wh // ts) * ts))
+                bx0, bx1 = sorted((wx + r(0, ww // ts) * ts, wx + r(0, ww // ts) * ts))
+                by1, bx1 = min(by1, wy + wh), min(bx1, wx + ww)
+                boxes.append((by0, by1, bx0, bx1))
+                inside[d] = False
+                inside[d, :, by0 - wy:by1 - wy, bx0 - wx:bx1 - wx] = True
+        inside = inside.to(dev)
+        leaf = ob.window_leaf(win, boxes)
         # the leaf holds the CURRENT parameters (what torch's Adam has there now), the stack itself is not written before the step
-        assert float((leaf.detach() - pa.detach()[:, :, wy:wy + wh, wx:wx + ww]).abs().max()) <= 2e-6
-        gc = (torch.rand((D, T, wh, ww, 4), generator=g) - 0.5).to(dev)
+        cur = pa.detach()[:, :, wy:wy + wh, wx:wx + ww]
+        assert float(((leaf.detach() - cur) * inside).abs().max()) <= 2e-6
+        assert float((leaf.detach() * ~inside).abs().max()) == 0
+        gc = (torch.rand((D, T, wh, ww, 4), generator=g) - 0.5).to(dev) * inside
         gc[:, :, :3] = 0                     # texels with a zero gradient inside the window as well
         leaf.grad = gc
         G = torch.zeros_like(pa)

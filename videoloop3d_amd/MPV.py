@@ -236,21 +236,37 @@ class MPMeshVid(nn.Module):
         if self._window_opt is not None:
             self._window_opt.flush()
 
-    def crop_window(self, homos, H, W, margin=3):
+    def crop_window(self, homos, H, W, margin=3, per_plane=False):
         """texel window (y0, x0, wh, ww), aligned to the optimiser's bookkeeping tiles, that contains every tap of every pixel of the
         H x W view on every plane: the image of the view's corners under the plane homographies (convex: extremes at the corners),
-        plus the +1 bilinear tap and a margin.  homos [D,3,3] on the HOST (float64)."""
-        from .optim import align_window
+        plus the +1 bilinear tap and a margin.  homos [D,3,3] on the HOST (float64).
+        per_plane: also return the planes' own boxes [D,4] = (y0, y1, x0, x1) (same rule per plane; the window is their union), or None
+        when a plane has the view behind it."""
+        from .optim import align_window, tile_side
         c = float(self.spec.pixel_center)
         pts = torch.tensor([[c, W - 1 + c, c, W - 1 + c], [c, c, H - 1 + c, H - 1 + c], [1.0, 1.0, 1.0, 1.0]], dtype=torch.float64)
         q = homos.double() @ pts                                                                  # D,3,4
         Hs, Ws = self.stack.shape[2:4]
         if bool((q[:, 2] <= 1e-9).any()):
-            return 0, 0, Hs, Ws
+            return ((0, 0, Hs, Ws), None) if per_plane else (0, 0, Hs, Ws)
         tx = q[:, 0] / q[:, 2] * self.spec.scale[0] + self.spec.offset[0]
         ty = q[:, 1] / q[:, 2] * self.spec.scale[1] + self.spec.offset[1]
-        return align_window(int(torch.floor(ty.min())) - margin, int(torch.ceil(ty.max())) + 2 + margin,
-                            int(torch.floor(tx.min())) - margin, int(torch.ceil(tx.max())) + 2 + margin, Hs, Ws)
+        win = align_window(int(torch.floor(ty.min())) - margin, int(torch.ceil(ty.max())) + 2 + margin,
+                           int(torch.floor(tx.min())) - margin, int(torch.ceil(tx.max())) + 2 + margin, Hs, Ws)
+        if not per_plane:
+            return win
+        # the planes' boxes by the same rule, vectorised (align_window per plane).  numpy, not torch: a dozen tiny torch CPU ops cost 2 ms
+        # per call on a 256-core host (thread-pool wake-ups) and starve the launch thread -- the iteration fell from 168 to 30 it/s
+        ts = tile_side()
+        tyn, txn = ty.numpy(), tx.numpy()
+        ylo = np.maximum(np.floor(tyn.min(1)).astype(np.int64) - margin, 0) // ts * ts
+        xlo = np.maximum(np.floor(txn.min(1)).astype(np.int64) - margin, 0) // ts * ts
+        yhi = np.minimum(np.ceil(tyn.max(1)).astype(np.int64) + 2 + margin, Hs)
+        xhi = np.minimum(np.ceil(txn.max(1)).astype(np.int64) + 2 + margin, Ws)
+        yhi = np.minimum(-(-yhi // ts) * ts, Hs)
+        xhi = np.minimum(-(-xhi // ts) * ts, Ws)
+        boxes = np.stack([ylo, np.maximum(yhi, ylo), xlo, np.maximum(xhi, xlo)], axis=1).astype(np.int32)
+        return win, boxes
 
     # ---- export to the reference's layout (MPV.py:290-341) ------------------------------------------------------------------
     def reference_state_dict(self):
@@ -355,14 +371,19 @@ class MPMeshVid(nn.Module):
             if self.training and torch.is_grad_enabled() and stack is self.stack:
                 # crop-aware training step: render from a compact, up-to-date copy of the texel window this view can reach
                 # (homographies on the host: a few hundred bytes; CPU inputs cost nothing, device inputs one small sync)
-                y0, x0, wh, ww = self.crop_window(homos.detach().cpu(), H, W)
+                (y0, x0, wh, ww), boxes = self.crop_window(homos.detach().cpu(), H, W, per_plane=True)
                 if wh > 0 and ww > 0:
                     cull_window = (y0, x0) + tuple(self.stack.shape[2:4])
-                    stack = self._window_opt.window_leaf((y0, x0, wh, ww))
+                    stack = self._window_opt.window_leaf((y0, x0, wh, ww), boxes)
                     spec = dataclasses.replace(spec, offset=(spec.offset[0] - x0, spec.offset[1] - y0))
             else:
                 self._flush_deferred_updates()
-        homos = homos.to(self.stack.device)
+        if homos.device.type == "cpu" and self.stack.is_cuda:
+            # host homographies (a few hundred bytes): through a pinned staging buffer and an asynchronous copy -- a pageable upload is a
+            # full host-device synchronisation in the middle of the forward, after which the GPU idles while the launches catch up
+            homos = homos.pin_memory().to(self.stack.device, non_blocking=True)
+        else:
+            homos = homos.to(self.stack.device)
         if self.atlas_exact:
             if need_smooth or self.is_sparse or tuple(stack.shape[2:4]) != (self.mpi_h, self.mpi_w):
                 raise RuntimeError("atlas_exact renders the dense full-resolution stack without the fused regularisers / tile culling / lod")

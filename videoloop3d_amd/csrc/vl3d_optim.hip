@@ -29,6 +29,25 @@ __device__ __forceinline__ void adam_upd(float &pp, float gg, float &mm, float &
 
 struct Win { int y0, x0, wh, ww; };
 
+// Per-plane boxes (optional, [D] x (y0, y1, x0, x1) in plane texels, tile aligned, inside the window): the window of a crop is ONE box
+// for all planes, the union of their footprints; a plane's own footprint is smaller by the parallax between the planes.  Texels of the
+// window outside their plane's box cannot be sampled in this iteration: their gradient is exactly zero, so their update stays deferred
+// like that of every texel outside the window.  The table travels in the kernel arguments (16 bytes per plane, read through the scalar
+// cache with the uniform plane index): no device buffer, no host-to-device copy, no synchronisation in the training loop.
+constexpr int MAX_BOX_PLANES = 128;
+struct BoxTable { int n; int4 b[MAX_BOX_PLANES]; };
+__device__ __forceinline__ bool outside_box(const BoxTable &boxes, int d, int x, int y) {
+    if (!boxes.n) return false;
+    const int4 b = boxes.b[d];
+    return y < b.x || y >= b.y || x < b.z || x >= b.w;
+}
+static BoxTable make_boxes(const int32_t *host_boxes, int D) {
+    BoxTable t;
+    t.n = (host_boxes && D <= MAX_BOX_PLANES) ? D : 0;       // more planes than the table holds: the whole window for every plane
+    for (int d = 0; d < t.n; ++d) t.b[d] = make_int4(host_boxes[4 * d], host_boxes[4 * d + 1], host_boxes[4 * d + 2], host_boxes[4 * d + 3]);
+    return t;
+}
+
 // the zero-gradient steps from+1 .. upto of one texel, in registers (the dense update's operations with g = 0, in its order)
 __device__ __forceinline__ void replay(float4 &pp, float4 &mm, float4 &vv, const float2 *__restrict__ hist, int from, int upto, float beta1,
                                        float beta2, float eps) {
@@ -61,10 +80,17 @@ __global__ __launch_bounds__(256) void adam_window_catchup_k(int T, int Hs, int 
                                                              float4 *__restrict__ v, const int *__restrict__ last_step, int tiles_y, int tiles_x,
                                                              const float2 *__restrict__ hist, int upto, float beta1, float beta2, float eps,
                                                              float4 *__restrict__ compact, Quads q, float culled_alpha, int mirror,
-                                                             int writeback) {
+                                                             int writeback, const BoxTable boxes) {
     const int lx = blockIdx.x * 64 + (threadIdx.x & 63), ly = blockIdx.y * 4 + (threadIdx.x >> 6), d = blockIdx.z;
     if (lx >= w.ww || ly >= w.wh) return;
     const int x = w.x0 + lx, y = w.y0 + ly;
+    if (outside_box(boxes, d, x, y)) {           // this plane's taps cannot reach the texel: its slots of the compact copy are never read
+        if (compact) {                           // (zeros all the same: nothing uninitialised for a later reader to trip over)
+            size_t oc = (size_t)d * T * w.wh * w.ww + (size_t)ly * w.ww + lx;
+            for (int t = 0; t < T; ++t, oc += (size_t)w.wh * w.ww) compact[oc] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
     const int from = last_step[((size_t)d * tiles_y + y / TS) * tiles_x + x / TS];
     const size_t frame = (size_t)Hs * Ws, cframe = (size_t)w.wh * w.ww;
     size_t o = (size_t)d * T * frame + (size_t)y * Ws + x, oc = (size_t)d * T * cframe + (size_t)ly * w.ww + lx;
@@ -103,9 +129,11 @@ __global__ __launch_bounds__(256) void adam_window_catchup_k(int T, int Hs, int 
 __global__ __launch_bounds__(256) void adam_window_step_k(int T, int Hs, int Ws, Win w, float4 *__restrict__ p, const float4 *__restrict__ g,
                                                           float4 *__restrict__ m, float4 *__restrict__ v, float lr_bc1, float beta1, float beta2,
                                                           float eps, float bc2s, Quads q, int static_tied, const int *__restrict__ last_step,
-                                                          int tiles_y, int tiles_x, const float2 *__restrict__ hist, int step) {
+                                                          int tiles_y, int tiles_x, const float2 *__restrict__ hist, int step,
+                                                          const BoxTable boxes) {
     const int lx = blockIdx.x * 64 + (threadIdx.x & 63), ly = blockIdx.y * 4 + (threadIdx.x >> 6), d = blockIdx.z;
     if (lx >= w.ww || ly >= w.wh) return;
+    if (outside_box(boxes, d, w.x0 + lx, w.y0 + ly)) return;     // zero gradient by construction: the update stays deferred
     // the zero-gradient steps this texel's tile has not seen yet are replayed HERE, in front of the real step: the catch-up before
     // the render only computed the current parameters for the compact copy and wrote nothing back (3 write streams fewer)
     const int from = last_step[((size_t)d * tiles_y + (w.y0 + ly) / TS) * tiles_x + (w.x0 + lx) / TS];
@@ -140,10 +168,12 @@ __global__ __launch_bounds__(256) void adam_window_step_k(int T, int Hs, int Ws,
     }
 }
 
-__global__ __launch_bounds__(256) void mark_tiles_k(int *last_step, int tiles_y, int tiles_x, int ty0, int tx0, int nty, int ntx, int D, int step) {
+__global__ __launch_bounds__(256) void mark_tiles_k(int *last_step, int tiles_y, int tiles_x, int ty0, int tx0, int nty, int ntx, int D, int step,
+                                                    const BoxTable boxes) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= D * nty * ntx) return;
     const int tx = i % ntx, ty = (i / ntx) % nty, d = i / (ntx * nty);
+    if (outside_box(boxes, d, (tx0 + tx) * TS, (ty0 + ty) * TS)) return;
     last_step[((size_t)d * tiles_y + ty0 + ty) * tiles_x + tx0 + tx] = step;
 }
 
@@ -159,25 +189,59 @@ int check_window(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32
 
 extern "C" int32_t vl3d_adam_window_tile(void) { return TS; }
 
-extern "C" int vl3d_adam_window_catchup(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
-                                        float *param, float *exp_avg, float *exp_avg_sq, int32_t *last_step, const float *hist,
-                                        int32_t upto, float beta1, float beta2, float eps, float *compact, const uint8_t *quad_keep,
-                                        const uint8_t *quad_dyn, int32_t QH, int32_t QW, float culled_alpha, int32_t mirror_static,
-                                        vl3d_stream_t stream) {
+extern "C" int vl3d_adam_window_catchup_boxes(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
+                                              float *param, float *exp_avg, float *exp_avg_sq, int32_t *last_step, const float *hist,
+                                              int32_t upto, float beta1, float beta2, float eps, float *compact, const uint8_t *quad_keep,
+                                              const uint8_t *quad_dyn, int32_t QH, int32_t QW, float culled_alpha, int32_t mirror_static,
+                                              const int32_t *plane_boxes, vl3d_stream_t stream) {
     int rc = check_window(D, T, Hs, Ws, y0, x0, wh, ww);
     if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE(param && exp_avg && exp_avg_sq && last_step && hist && upto >= 0, "vl3d_adam_window_catchup: null pointer / negative step");
     VL3D_REQUIRE(!quad_keep || (QH > 0 && QW > 0), "vl3d_adam_window_catchup: bad quad grid");
+    const BoxTable boxes = make_boxes(plane_boxes, D);
     const int tiles_y = (Hs + TS - 1) / TS, tiles_x = (Ws + TS - 1) / TS;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_window_catchup_k, dim3((ww + 63) / 64, (wh + 3) / 4, D), dim3(256), 0, s, T, Hs, Ws, Win{y0, x0, wh, ww},
                        reinterpret_cast<float4 *>(param), reinterpret_cast<float4 *>(exp_avg), reinterpret_cast<float4 *>(exp_avg_sq), last_step,
                        tiles_y, tiles_x, reinterpret_cast<const float2 *>(hist), upto, beta1, beta2, eps, reinterpret_cast<float4 *>(compact),
-                       Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW}, culled_alpha, mirror_static, compact ? 0 : 1);
+                       Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW}, culled_alpha, mirror_static, compact ? 0 : 1,
+                       boxes);
     if (!compact) {      // a flush writes the replayed state back and marks the tiles; a catch-up for a render only fills the compact copy
         const int nty = (y0 + wh + TS - 1) / TS - y0 / TS, ntx = (x0 + ww + TS - 1) / TS - x0 / TS;
-        hipLaunchKernelGGL(mark_tiles_k, dim3((D * nty * ntx + 255) / 256), dim3(256), 0, s, last_step, tiles_y, tiles_x, y0 / TS, x0 / TS, nty, ntx, D, upto);
+        hipLaunchKernelGGL(mark_tiles_k, dim3((D * nty * ntx + 255) / 256), dim3(256), 0, s, last_step, tiles_y, tiles_x, y0 / TS, x0 / TS, nty, ntx, D, upto, boxes);
     }
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
+extern "C" int vl3d_adam_window_catchup(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
+                                        float *param, float *exp_avg, float *exp_avg_sq, int32_t *last_step, const float *hist,
+                                        int32_t upto, float beta1, float beta2, float eps, float *compact, const uint8_t *quad_keep,
+                                        const uint8_t *quad_dyn, int32_t QH, int32_t QW, float culled_alpha, int32_t mirror_static,
+                                        vl3d_stream_t stream) {
+    return vl3d_adam_window_catchup_boxes(D, T, Hs, Ws, y0, x0, wh, ww, param, exp_avg, exp_avg_sq, last_step, hist, upto, beta1, beta2, eps,
+                                          compact, quad_keep, quad_dyn, QH, QW, culled_alpha, mirror_static, nullptr, stream);
+}
+
+extern "C" int vl3d_adam_window_step_boxes(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
+                                           float *param, const float *grad_compact, float *exp_avg, float *exp_avg_sq, int32_t *last_step,
+                                           const float *hist, float lr, float beta1, float beta2, float eps, int64_t step,
+                                           const uint8_t *quad_keep, const uint8_t *quad_dyn, int32_t QH, int32_t QW, int32_t static_tied,
+                                           const int32_t *plane_boxes, vl3d_stream_t stream) {
+    int rc = check_window(D, T, Hs, Ws, y0, x0, wh, ww);
+    if (rc != VL3D_OK) return rc;
+    VL3D_REQUIRE(param && grad_compact && exp_avg && exp_avg_sq && last_step && hist && step >= 1, "vl3d_adam_window_step: null pointer / bad step");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const int tiles_y = (Hs + TS - 1) / TS, tiles_x = (Ws + TS - 1) / TS;
+    const BoxTable boxes = make_boxes(plane_boxes, D);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_window_step_k, dim3((ww + 63) / 64, (wh + 3) / 4, D), dim3(256), 0, s, T, Hs, Ws, Win{y0, x0, wh, ww},
+                       reinterpret_cast<float4 *>(param), reinterpret_cast<const float4 *>(grad_compact), reinterpret_cast<float4 *>(exp_avg),
+                       reinterpret_cast<float4 *>(exp_avg_sq), (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2),
+                       Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW}, static_tied, last_step, tiles_y, tiles_x,
+                       reinterpret_cast<const float2 *>(hist), (int)step, boxes);
+    const int nty = (y0 + wh + TS - 1) / TS - y0 / TS, ntx = (x0 + ww + TS - 1) / TS - x0 / TS;
+    hipLaunchKernelGGL(mark_tiles_k, dim3((D * nty * ntx + 255) / 256), dim3(256), 0, s, last_step, tiles_y, tiles_x, y0 / TS, x0 / TS, nty, ntx, D, (int)step, boxes);
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
 }
@@ -187,21 +251,8 @@ extern "C" int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t W
                                      const float *hist, float lr, float beta1, float beta2, float eps, int64_t step,
                                      const uint8_t *quad_keep, const uint8_t *quad_dyn, int32_t QH, int32_t QW, int32_t static_tied,
                                      vl3d_stream_t stream) {
-    int rc = check_window(D, T, Hs, Ws, y0, x0, wh, ww);
-    if (rc != VL3D_OK) return rc;
-    VL3D_REQUIRE(param && grad_compact && exp_avg && exp_avg_sq && last_step && hist && step >= 1, "vl3d_adam_window_step: null pointer / bad step");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    const int tiles_y = (Hs + TS - 1) / TS, tiles_x = (Ws + TS - 1) / TS;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(adam_window_step_k, dim3((ww + 63) / 64, (wh + 3) / 4, D), dim3(256), 0, s, T, Hs, Ws, Win{y0, x0, wh, ww},
-                       reinterpret_cast<float4 *>(param), reinterpret_cast<const float4 *>(grad_compact), reinterpret_cast<float4 *>(exp_avg),
-                       reinterpret_cast<float4 *>(exp_avg_sq), (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2),
-                       Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW}, static_tied, last_step, tiles_y, tiles_x,
-                       reinterpret_cast<const float2 *>(hist), (int)step);
-    const int nty = (y0 + wh + TS - 1) / TS - y0 / TS, ntx = (x0 + ww + TS - 1) / TS - x0 / TS;
-    hipLaunchKernelGGL(mark_tiles_k, dim3((D * nty * ntx + 255) / 256), dim3(256), 0, s, last_step, tiles_y, tiles_x, y0 / TS, x0 / TS, nty, ntx, D, (int)step);
-    VL3D_CHECK_LAUNCH();
-    return VL3D_OK;
+    return vl3d_adam_window_step_boxes(D, T, Hs, Ws, y0, x0, wh, ww, param, grad_compact, exp_avg, exp_avg_sq, last_step, hist, lr, beta1, beta2,
+                                       eps, step, quad_keep, quad_dyn, QH, QW, static_tied, nullptr, stream);
 }
 
 // the per-step scalars of the table, computed exactly like vl3d_adam_window_step / vl3d_adam_step_tiles compute theirs

@@ -70,34 +70,41 @@ class WindowAdam(torch.optim.Optimizer):
         qk, qd = self.quad_keep, self.quad_dyn
         return L.ptr(qk), L.ptr(qd), (0 if qk is None else qk.shape[1]), (0 if qk is None else qk.shape[2])
 
-    def _catchup(self, window, upto, compact, mirror=False):
+    def _catchup(self, window, upto, compact, mirror=False, boxes=None):
         st, p = self._st(), self.p
         D, T, Hs, Ws, _ = p.shape
         y0, x0, wh, ww = window
         b1, b2 = self.param_groups[0]["betas"]
         qk, qd, QH, QW = self._quads()
         with torch.cuda.device(p.device):
-            L.check(L.lib().vl3d_adam_window_catchup(D, T, Hs, Ws, y0, x0, wh, ww, L.ptr(p), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
-                                                     L.ptr(st["last_step"]), L.ptr(st["hist"]), int(upto), float(b1), float(b2),
-                                                     float(self.param_groups[0]["eps"]), L.ptr(compact), qk, qd, QH, QW, self.culled_alpha,
-                                                     1 if mirror else 0, L.stream_ptr(p.device)),
+            L.check(L.lib().vl3d_adam_window_catchup_boxes(D, T, Hs, Ws, y0, x0, wh, ww, L.ptr(p), L.ptr(st["exp_avg"]),
+                                                           L.ptr(st["exp_avg_sq"]), L.ptr(st["last_step"]), L.ptr(st["hist"]), int(upto),
+                                                           float(b1), float(b2), float(self.param_groups[0]["eps"]), L.ptr(compact), qk, qd,
+                                                           QH, QW, self.culled_alpha, 1 if mirror else 0, None if boxes is None else boxes.ctypes.data,
+                                                           L.stream_ptr(p.device)),
                     "vl3d_adam_window_catchup")
 
     # ---- forward side ---------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def window_leaf(self, window):
+    def window_leaf(self, window, plane_boxes=None):
         """window = (y0, x0, wh, ww), tile aligned (align_window) -> compact (D,T,wh,ww,4) leaf (requires_grad) holding the CURRENT
-        parameters of the window.  At most one window per step; a second forward before step() takes the dense path."""
+        parameters of the window.  At most one window per step; a second forward before step() takes the dense path.
+        plane_boxes (optional): int32 [D,4] = (y0, y1, x0, x1) per plane in plane texels, tile aligned, inside the window -- the part of the
+        window this plane's taps can reach.  Outside its box a plane's texels get no gradient in this iteration by construction: their
+        slots of the leaf are zeros, their update stays deferred."""
         p = self.p
         D, T, Hs, Ws, _ = p.shape
         y0, x0, wh, ww = window
+        if plane_boxes is not None:                       # stays on the HOST (numpy int32 [D,4]): the table travels in the kernel arguments
+            import numpy as np
+            plane_boxes = np.ascontiguousarray(np.asarray(plane_boxes, dtype=np.int32).reshape(D, 4))
         compact = torch.empty((D, T, wh, ww, 4), dtype=p.dtype, device=p.device)
-        self._catchup(window, self.t, compact)
+        self._catchup(window, self.t, compact, boxes=plane_boxes)
         compact.requires_grad_(True)
         if self.pending is not None:
             self.pending = "multiple"
         else:
-            self.pending = (window, compact)
+            self.pending = (window, compact, plane_boxes)
         return compact
 
     @torch.no_grad()
@@ -143,18 +150,19 @@ class WindowAdam(torch.optim.Optimizer):
         st["hist"][t, 1].fill_(b.value)
         D, T, Hs, Ws, _ = p.shape
         if dense:        # (the step kernel replays what is outstanding itself: no flush needed first)
-            window, g = (0, 0, Hs, Ws), (p.grad if p.grad.is_contiguous() else p.grad.contiguous())
+            window, g, boxes = (0, 0, Hs, Ws), (p.grad if p.grad.is_contiguous() else p.grad.contiguous()), None
         else:
-            window, g = pending[0], pending[1].grad
+            window, g, boxes = pending[0], pending[1].grad, pending[2]
             if p.grad is not None:
                 raise RuntimeError("WindowAdam: both the window leaf and the dense parameter received a gradient in one step")
         y0, x0, wh, ww = window
         qk, qd, QH, QW = self._quads()
         with torch.cuda.device(p.device):
-            L.check(L.lib().vl3d_adam_window_step(D, T, Hs, Ws, y0, x0, wh, ww, L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
-                                                  L.ptr(st["last_step"]), L.ptr(st["hist"]), lr, float(b1), float(b2), eps, t, qk, qd, QH, QW,
-                                                  1 if (dense and qk is not None) else 0,      # a dense p.grad of a sparsified model went through the tie hook
-                                                  L.stream_ptr(p.device)),
+            L.check(L.lib().vl3d_adam_window_step_boxes(D, T, Hs, Ws, y0, x0, wh, ww, L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]),
+                                                        L.ptr(st["exp_avg_sq"]), L.ptr(st["last_step"]), L.ptr(st["hist"]), lr, float(b1),
+                                                        float(b2), eps, t, qk, qd, QH, QW,
+                                                        1 if (dense and qk is not None) else 0,  # a dense p.grad of a sparsified model went through the tie hook
+                                                        None if boxes is None else boxes.ctypes.data, L.stream_ptr(p.device)),
                     "vl3d_adam_window_step")
         self.t = t
         return loss
