@@ -16,6 +16,7 @@ geometry -- which is all the shipped configs ever produce (vertices get no gradi
     (videoloop3d_amd/export.py).
 """
 import dataclasses
+import os
 
 import numpy as np
 import torch
@@ -374,7 +375,7 @@ class MPMeshVid(nn.Module):
                 (y0, x0, wh, ww), boxes = self.crop_window(homos.detach().cpu(), H, W, per_plane=True)
                 if wh > 0 and ww > 0:
                     cull_window = (y0, x0) + tuple(self.stack.shape[2:4])
-                    stack = self._window_opt.window_leaf((y0, x0, wh, ww), boxes)
+                    stack = self._window_opt.window_leaf((y0, x0, wh, ww), None if os.environ.get("VL3D_NO_PLANE_BOXES") else boxes)
                     spec = dataclasses.replace(spec, offset=(spec.offset[0] - x0, spec.offset[1] - y0))
             else:
                 self._flush_deferred_updates()
