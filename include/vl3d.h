@@ -243,7 +243,7 @@ typedef struct vl3d_loss_desc {
     int64_t y_sc, y_st, y_sr;
     int32_t variant;       /* kernel variant selector for A/B measurements and cross-checks; 0 = default.  Bits 0-3, vl3d_patchnn: 1 strided
                             * staging (no scratch), 2 one location per workgroup, 3 the fp32 matrix-core kernel, 4 the vector-ALU kernel
-                            * (0 picks 3 wherever the clip lengths allow it -- x <= 64, y <= 128 frames -- else 4); vl3d_vote_fold: 1 = the
+                            * (0 picks 3 wherever the clip lengths allow it -- x <= 128, y <= 192 frames -- and 4 otherwise); vl3d_vote_fold: 1 = the
                             * unstaged kernel.  Bits 4-7: ablation switches (timing only, results invalid).  Bit 8: see vl3d_patchnn.
                             * Bits 12-15, vl3d_vote_fold*: tile shape index + 1. */
 } vl3d_loss_desc;

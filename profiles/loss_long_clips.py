@@ -4,10 +4,12 @@ from videoloop3d_amd import synth
 from videoloop3d_amd.utils_vid import Patch3DGPNNLowMemLoss
 dev = torch.device("cuda:0")
 H, W = 719, 1279
-for Tx, Ty in ((82, 75), (82, 150)):
+clips = [tuple(int(v) for v in c.split("x")) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [(82, 75), (82, 150)]
+variants = sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "2"]
+for Tx, Ty in clips:
     x = synth.make_video(Tx, H, W, seed=3, device=dev).requires_grad_(True)
     y = synth.make_video(Ty, H, W, seed=4, device=dev)
-    for variant in ("0", "2"):
+    for variant in variants:
         os.environ["VL3D_LOSS_VARIANT"] = variant
         L = Patch3DGPNNLowMemLoss()
         def step():

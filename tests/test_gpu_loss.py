@@ -233,10 +233,12 @@ def test_patchnn_kernel_variants_agree(dev, variant, monkeypatch):
             assert maxabs(sg, so) <= 1e-5
 
 
-@pytest.mark.parametrize("tx,ty,ps,s,alpha", [(12, 100, 5, 2, 0.5), (62, 128, 7, 3, None), (50, 75, 11, 4, 0.5), (9, 17, 4, 1, 0.005)])
+@pytest.mark.parametrize("tx,ty,ps,s,alpha", [(12, 100, 5, 2, 0.5), (62, 128, 7, 3, None), (50, 75, 11, 4, 0.5), (9, 17, 4, 1, 0.005),
+                                               (82, 75, 5, 2, 0.5), (82, 122, 11, 4, 0.5), (122, 182, 7, 4, None), (126, 190, 3, 2, 0.5), (30, 192, 5, 3, None)])
 def test_patchnn_matrix_core_tile_counts(dev, tx, ty, ps, s, alpha, monkeypatch):
-    """The matrix-core kernel at both of its instantiations (<= 80 target frames: four locations per workgroup, hand-pipelined operand
-    reads; <= 128: two locations, plain loop), at the largest clips it takes, with a narrow last group and with alpha."""
+    """The matrix-core kernel at all of its instantiations (<= 80 target frames: four locations per workgroup, hand-pipelined operand
+    reads; <= 128: two locations; <= 192: one; x clips of <= 64 frames on four waves, <= 128 on eight -- cfg4's 80 / 120 and cfg5's
+    120 / 180 frames), at the largest clips it takes, with a narrow last group and with alpha."""
     from videoloop3d_amd.utils_vid import _nn_and_fold
     monkeypatch.setenv("VL3D_LOSS_VARIANT", "3")
     H, W = ps + 5 * s, ps + 9 * s                        # 6 x 10 patch locations: the last group of a row is two locations wide

@@ -608,8 +608,10 @@ __device__ __forceinline__ void lds_dma16(const float4 *g, float *lds_wave_unifo
 
 // (two waves per SIMD at least: with at most 256 registers a wave the compiler keeps the MFMA accumulators in VGPRs; allowed the
 // full 512 it put R in AGPRs and copied it to VGPRs and back around every MFMA -- 41 % matrix-core utilisation)
-template <int TYT, int NL>
-__global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, int CHC) {
+// NW waves = x's 16-frame groups: 4 (<= 64 frames, the shipped clips) or 8 (<= 128 frames: cfg4 / cfg5 clip lengths)
+template <int TYT, int NL, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void patchnn5_k(NN2Args a, int groups_x, int CHC) {
+    constexpr int NTHR = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KX = 4, KY = 2 * TYT > 7 ? 7 : 2 * TYT;       // DMA pieces per wave and stage at most (x: 13 * 64 / 64 / 4, y: 13 * 128 / 64 / 4)
     const int RWc = a.ps + (NL - 1) * a.stride;                 // region width in pixels
@@ -640,12 +642,12 @@ __global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, in
     int offx[KX], offy[KY];
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
-        const int idx = (wave + 4 * k) * 64 + lane, cc = fdiv_small(idx, a.ps * PX), rem = idx - cc * a.ps * PX, r = fdiv_small(rem, PX);
+        const int idx = (wave + NW * k) * 64 + lane, cc = fdiv_small(idx, a.ps * PX), rem = idx - cc * a.ps * PX, r = fdiv_small(rem, PX);
         offx[k] = idx < xs4 ? ((r * a.W + cc) * PX + (rem - r * PX)) | (cc << 24) : -1;
     }
 #pragma unroll
     for (int k = 0; k < KY; ++k) {
-        const int idx = (wave + 4 * k) * 64 + lane, cc = fdiv_small(idx, a.ps * PY), rem = idx - cc * a.ps * PY, r = fdiv_small(rem, PY);
+        const int idx = (wave + NW * k) * 64 + lane, cc = fdiv_small(idx, a.ps * PY), rem = idx - cc * a.ps * PY, r = fdiv_small(rem, PY);
         offy[k] = idx < ys4 ? ((r * a.W + cc) * PY + (rem - r * PY)) | (cc << 24) : -1;
     }
     const int S = (cols + CHC - 1) / CHC;                       // stages
@@ -656,10 +658,10 @@ __global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, in
         const float4 *ysrc = reinterpret_cast<const float4 *>(a.yt) + ((size_t)r0 * a.W + c0 + q0) * PY;
 #pragma unroll
         for (int k = 0; k < KX; ++k)
-            if (offx[k] >= 0 && (offx[k] >> 24) < nc) lds_dma16(xsrc + (offx[k] & 0xffffff), dst + (wave + 4 * k) * 256);
+            if (offx[k] >= 0 && (offx[k] >> 24) < nc) lds_dma16(xsrc + (offx[k] & 0xffffff), dst + (wave + NW * k) * 256);
 #pragma unroll
         for (int k = 0; k < KY; ++k)
-            if (offy[k] >= 0 && (offy[k] >> 24) < nc) lds_dma16(ysrc + (offy[k] & 0xffffff), dst + ybase + (wave + 4 * k) * 256);
+            if (offy[k] >= 0 && (offy[k] >> 24) < nc) lds_dma16(ysrc + (offy[k] & 0xffffff), dst + ybase + (wave + NW * k) * 256);
     };
     // operand fragments: a pixel's frames are stored in groups of 16, [group][slot][frame]: the fragment of a 16-frame tile (lane = frame
     // + 16 * slot) is the group's 64 consecutive floats -- one conflict-free ds_read_b32 per tile.  (With [frame][slot] the two half-waves
@@ -756,7 +758,7 @@ __global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, in
 #pragma unroll
         for (int l = 0; l < NL; ++l) sy[l * a.TyP + tid] = an[l];
     }
-    for (int j = tid; j < NL * n2p; j += 256) reinterpret_cast<int *>(colw)[j] = 0x7f800000;     // column minima start at +inf
+    for (int j = tid; j < NL * n2p; j += NTHR) reinterpret_cast<int *>(colw)[j] = 0x7f800000;     // column minima start at +inf
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
         if (l >= nloc) break;                                    // uniform
@@ -774,7 +776,7 @@ __global__ __launch_bounds__(256, 2) void patchnn5_k(NN2Args a, int groups_x, in
         __syncthreads();
         const size_t b = (size_t)by * a.w_o + bx0 + l;
         if (a.ablate & 1) { if (tid < a.n1) a.nn[b * a.n1 + tid] = 0; continue; }
-        nn_epilogue<256, true>(a, E, colw + l * n2p, b, tid, sub);
+        nn_epilogue<NTHR, true>(a, E, colw + l * n2p, b, tid, sub);
     }
 }
 
@@ -1145,23 +1147,29 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
         // pixel-major (v2 / v4) or gram-major (v5) copies in the caller's scratch, then the coalesced-staging kernel
         hipStream_t s = (hipStream_t)stream;
         const int pv = desc->variant & 0xf;
-        // v5 (matrix cores) whenever x's frames fit the four waves' 16-frame groups and y's its column tiles
+        // v5 (matrix cores) whenever x's frames fit the waves' 16-frame groups (4 waves: <= 64 frames, 8 waves: <= 128) and y's its column
+        // tiles (5 tiles x 4 locations, 8 x 2, 12 x 1 per wave)
         const int PX = pad16(a.TxU), PY = pad16(desc->Ty), TyT = PY / 16;
         // (8 / 6 locations per workgroup -- 4.9 / 5.2 instead of 5.75 region columns per location -- need 237 / 195 registers = two workgroups
         // per CU: 2.81 / 2.87 ms against 2.68 in one process)
-        const int nl5 = TyT <= 5 ? 4 : 2, tyt5 = TyT <= 5 ? 5 : 8;
+        const int nw5 = PX <= 64 ? 4 : 8;
+        const int tyt5 = TyT <= 5 ? 5 : (TyT <= 8 ? 8 : 12), nl5 = tyt5 == 5 ? 4 : (tyt5 == 8 ? 2 : 1);
         const int RWc5 = a.ps + (nl5 - 1) * a.stride;
         const size_t pad5 = (size_t)(tyt5 - TyT) * 64 * sizeof(float);
-        // stage = the most columns (all ps rows each) whose two buffers leave room for three workgroups per CU
+        // stage = the most columns (all ps rows each) whose two buffers leave room for three workgroups per CU (or fit at all)
         int ch5 = (int)((53 * 1024 / 2 - pad5) / ((size_t)4 * (PX + PY) * sizeof(float))) / a.ps;
         ch5 = ch5 < 1 ? 1 : (ch5 > RWc5 ? RWc5 : ch5);
         const size_t stage5 = 2 * ((size_t)ch5 * a.ps * 4 * (PX + PY) * sizeof(float) + pad5), epi5 = ((size_t)a.TxP * a.TyP + 4 * (a.n2 + 3 + a.TyP)) * sizeof(float);
         const size_t lds5 = stage5 > epi5 ? stage5 : epi5;
-        const bool fits5 = (size_t)ch5 * a.ps * PX <= 4 * 4 * 64 && (size_t)ch5 * a.ps * PY <= 7 * 4 * 64 &&  // KX / KY pieces per wave
+        const bool fits5 = (size_t)ch5 * a.ps * PX <= (size_t)4 * nw5 * 64 && (size_t)ch5 * a.ps * PY <= (size_t)7 * nw5 * 64 &&  // KX / KY pieces per wave
                            ((size_t)a.ps * desc->W + ch5) * (PX > PY ? PX : PY) < (1u << 24);                  // 24-bit DMA source offsets
         // (the default wherever it applies: 2.52 vs 3.55 ms for v4 at 720p with 11-pixel patches at stride 4, 2.45 vs 2.54 ms with 3-pixel
         // patches at stride 2, profiles/ab_loss.py)
-        const bool use_v5 = (pv == 3 || pv == 0) && PX <= 64 && TyT <= 8 && lds5 <= 150 * 1024 && fits5;
+        // (... and for the long clips of cfg4 / cfg5, 720p, it/s of a loss iteration v5 | v4: 82 x 75 frames 118 | 92, 82 x 120: 72 | 68,
+        // 122 x 180: 38 | 14, 52 x 120: 124 | 93; the one-location instantiation loses to v4's running sums where v4 still has a tile per
+        // thread: 82 x 150: 41 | 56 -- v4 there)
+        const bool v4_has_tiles = (size_t)(a.TxP / TI) * (a.TyP / TJ) <= 1024;
+        const bool use_v5 = (pv == 3 || (pv == 0 && !(nl5 == 1 && v4_has_tiles))) && PX <= 128 && TyT <= 12 && lds5 <= 150 * 1024 && fits5;
         float *xt = (float *)scratch;
         float *yt = xt + (size_t)desc->H * desc->W * (use_v5 ? 4 * PX : 3 * a.TxP);
         dim3 tg((desc->W + 63) / 64, desc->H);
@@ -1198,16 +1206,23 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
         const size_t lds4 = (stage4 > epi4 ? stage4 : epi4) * sizeof(float);
         const bool use_v4 = (pv == 0 || pv == 4) && ntiles4 <= 1024 && lds4 <= 150 * 1024;
         if (use_v5) {
-            static bool attr5 = false;
-            if (!attr5) {
-                VL3D_HIP(hipFuncSetAttribute((const void *)patchnn5_k<5, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                VL3D_HIP(hipFuncSetAttribute((const void *)patchnn5_k<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr5 = true;
-            }
             const int groups_x = (a.w_o + nl5 - 1) / nl5;
             const dim3 grid5((unsigned)(groups_x * a.h_o));
-            if (nl5 == 4) hipLaunchKernelGGL((patchnn5_k<5, 4>), grid5, dim3(256), lds5, s, b, groups_x, ch5);
-            else hipLaunchKernelGGL((patchnn5_k<8, 2>), grid5, dim3(256), lds5, s, b, groups_x, ch5);
+#define VL3D_LAUNCH5(TYT_, NL_, NW_)                                                                                               \
+    {                                                                                                                              \
+        static bool attr = false;                                                                                                  \
+        if (!attr) {                                                                                                               \
+            VL3D_HIP(hipFuncSetAttribute((const void *)patchnn5_k<TYT_, NL_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr = true;                                                                                                           \
+        }                                                                                                                          \
+        hipLaunchKernelGGL((patchnn5_k<TYT_, NL_, NW_>), grid5, dim3(64 * NW_), lds5, s, b, groups_x, ch5);                          \
+    }
+            if (nw5 == 4) {
+                if (tyt5 == 5) VL3D_LAUNCH5(5, 4, 4) else if (tyt5 == 8) VL3D_LAUNCH5(8, 2, 4) else VL3D_LAUNCH5(12, 1, 4)
+            } else {
+                if (tyt5 == 5) VL3D_LAUNCH5(5, 4, 8) else if (tyt5 == 8) VL3D_LAUNCH5(8, 2, 8) else VL3D_LAUNCH5(12, 1, 8)
+            }
+#undef VL3D_LAUNCH5
         } else if (use_v4) {
             static bool attr4 = false;
             if (!attr4) {
