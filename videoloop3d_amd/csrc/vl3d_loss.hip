@@ -12,6 +12,7 @@
 // no |x|^2+|y|^2-2xy cancellation (never negative).
 #include "vl3d_common.h"
 #include <algorithm>
+#include <utility>
 
 namespace {
 
@@ -601,6 +602,16 @@ __global__ __launch_bounds__(256) void video_to_gram_major_k(const float *__rest
 // integer, far more than the reciprocal's relative error times the quotient
 __device__ __forceinline__ int fdiv_small(int n, int d) { return (int)(((float)n + 0.5f) * __builtin_amdgcn_rcpf((float)d)); }
 
+// one ds_read_b32 per 16-frame tile of y, tile J at byte offset J * 256 of the cell (the offset is an instruction immediate)
+template <int J>
+__device__ __forceinline__ void nn5_issue_tile(float &dst, unsigned addr) {
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(J * 256) : "memory");
+}
+template <int N, int... Js>
+__device__ __forceinline__ void nn5_issue_tiles(float (&b)[N], unsigned addr, std::integer_sequence<int, Js...>) {
+    (nn5_issue_tile<Js>(b[Js], addr), ...);
+}
+
 __device__ __forceinline__ void lds_dma16(const float4 *g, float *lds_wave_uniform) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)lds_wave_uniform, 16, 0, 0);
@@ -690,57 +701,45 @@ __global__ __launch_bounds__(64 * NW, 2) void patchnn5_k(NN2Args a, int groups_x
             // Operands one row ahead of the MFMAs that use them, in two register sets used alternately: the reads of row r + 1 are issued,
             // row r is contracted, THEN the reads are waited for.  (The read past the column's last row stays put and is dropped.)  hipcc
             // folds such reads back to the top of the iteration that uses them, or waits for them with lgkmcnt(0) right after issuing
-            // them, so for the shipped tile count the reads and their wait are two asm statements (the wait hands the registers on, so
-            // nothing that uses them can move above it) fenced by scheduling barriers; other tile counts take the plain loop.
-            if constexpr (TYT == 5) {
+            // them, so the reads and their wait are asm statements (the wait hands the registers on, so nothing that uses them can
+            // move above it) fenced by scheduling barriers.
+            {
                 unsigned xad = (unsigned)reinterpret_cast<uintptr_t>(xq), yad = (unsigned)reinterpret_cast<uintptr_t>(yq);
                 unsigned nad = (unsigned)reinterpret_cast<uintptr_t>(nq);
                 const unsigned xstep = PX * 16, ystep = PY * 16;
-                float a0, n0, b00, b01, b02, b03, b04, a1, n1, b10, b11, b12, b13, b14;
-#define VL3D_NN5_ISSUE(A, N, B0, B1, B2, B3, B4)                                                          \
-    asm volatile("ds_read_b32 %0, %7\n\tds_read_b32 %1, %8\n\tds_read_b32 %2, %9\n\tds_read_b32 %3, %9 offset:256\n\t" \
-                 "ds_read_b32 %4, %9 offset:512\n\tds_read_b32 %5, %9 offset:768\n\tds_read_b32 %6, %9 offset:1024"       \
-                 : "=&v"(A), "=&v"(N), "=&v"(B0), "=&v"(B1), "=&v"(B2), "=&v"(B3), "=&v"(B4)               \
-                 : "v"(xad), "v"(nad), "v"(yad)                                                          \
-                 : "memory");                                                                            \
+                float a0, n0, b0[TYT], a1, n1, b1[TYT];
+                constexpr auto tiles = std::make_integer_sequence<int, TYT>{};
+#define VL3D_NN5_ISSUE(A, N, B)                                                                           \
+    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=&v"(A), "=&v"(N) : "v"(xad), "v"(nad) : "memory"); \
+    nn5_issue_tiles(B, yad, tiles);                                                                       \
     __builtin_amdgcn_sched_barrier(0)
-#define VL3D_NN5_WAIT(A, N, B0, B1, B2, B3, B4)                                                           \
+#define VL3D_NN5_WAIT(A, N, B)                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A), "+v"(N), "+v"(B0), "+v"(B1), "+v"(B2), "+v"(B3), "+v"(B4)::"memory")
-#define VL3D_NN5_MMA(A, N, B0, B1, B2, B3, B4)                                                            \
-    R[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, one ? 1.0f : B0, R[0], 0, 0, 0);                       \
-    R[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, one ? 1.0f : B1, R[1], 0, 0, 0);                       \
-    R[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, one ? 1.0f : B2, R[2], 0, 0, 0);                       \
-    R[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, one ? 1.0f : B3, R[3], 0, 0, 0);                       \
-    R[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, one ? 1.0f : B4, R[4], 0, 0, 0);                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A), "+v"(N)::"memory");                                    \
+    _Pragma("unroll") for (int j = 0; j < TYT; ++j) asm volatile("" : "+v"(B[j])::"memory")
+#define VL3D_NN5_MMA(A, N, B)                                                                             \
+    _Pragma("unroll") for (int j = 0; j < TYT; ++j) R[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, one ? 1.0f : B[j], R[j], 0, 0, 0); \
     Rn += N
 #define VL3D_NN5_NEXT(RR)                                                                                 \
     if ((RR) + 1 < a.ps) { xad += xstep; yad += ystep; nad += ystep; }
-                VL3D_NN5_ISSUE(a0, n0, b00, b01, b02, b03, b04);
-                VL3D_NN5_WAIT(a0, n0, b00, b01, b02, b03, b04);
+                VL3D_NN5_ISSUE(a0, n0, b0);
+                VL3D_NN5_WAIT(a0, n0, b0);
                 int r = 0;
                 for (; r + 1 < a.ps; r += 2) {
                     VL3D_NN5_NEXT(r);
-                    VL3D_NN5_ISSUE(a1, n1, b10, b11, b12, b13, b14);
-                    VL3D_NN5_MMA(a0, n0, b00, b01, b02, b03, b04);
-                    VL3D_NN5_WAIT(a1, n1, b10, b11, b12, b13, b14);
+                    VL3D_NN5_ISSUE(a1, n1, b1);
+                    VL3D_NN5_MMA(a0, n0, b0);
+                    VL3D_NN5_WAIT(a1, n1, b1);
                     VL3D_NN5_NEXT(r + 1);
-                    VL3D_NN5_ISSUE(a0, n0, b00, b01, b02, b03, b04);
-                    VL3D_NN5_MMA(a1, n1, b10, b11, b12, b13, b14);
-                    VL3D_NN5_WAIT(a0, n0, b00, b01, b02, b03, b04);
+                    VL3D_NN5_ISSUE(a0, n0, b0);
+                    VL3D_NN5_MMA(a1, n1, b1);
+                    VL3D_NN5_WAIT(a0, n0, b0);
                 }
-                if (r < a.ps) { VL3D_NN5_MMA(a0, n0, b00, b01, b02, b03, b04); }
+                if (r < a.ps) { VL3D_NN5_MMA(a0, n0, b0); }
 #undef VL3D_NN5_ISSUE
 #undef VL3D_NN5_WAIT
 #undef VL3D_NN5_MMA
 #undef VL3D_NN5_NEXT
-            } else {
-                for (int r = 0; r < a.ps; ++r, xq += PX * 4, yq += PY * 4, nq += PY * 4) {
-                    const float av = *xq, nv = *nq;
-#pragma unroll
-                    for (int j = 0; j < TYT; ++j) R[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, one ? 1.0f : yq[j * 64], R[j], 0, 0, 0);
-                    Rn += nv;
-                }
             }
 #pragma unroll
             for (int l = 0; l < NL; ++l)
