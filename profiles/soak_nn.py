@@ -19,8 +19,8 @@ for seed in range(first, first + n):
     rnd = random.Random(seed)
     ps = rnd.choice([2, 3, 4, 5, 7, 9, 11, 13])
     s = rnd.randint(1, min(ps, 5))
-    tx = rnd.randint(3, 62)
-    ty = rnd.randint(3, 128)
+    tx = rnd.randint(3, 126)
+    ty = rnd.randint(3, 192)
     alpha = rnd.choice([None, 0.5, 0.005, 10.0])
     ny, nx = rnd.randint(1, 4), rnd.randint(1, 11)
     H, W = ps + (ny - 1) * s, ps + (nx - 1) * s
