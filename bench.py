@@ -96,7 +96,7 @@ def loss_bench(dev, H, W, T, Ty, steps):
     import warnings
     x = synth.make_video(T + 2, H, W, seed=3, device=dev).requires_grad_(True)
     y = synth.make_video(Ty, H, W, seed=4, device=dev)
-    cfgs = {"ref": dict(macro_block=65, patch_size=11, stride=4, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=0.5),
+    cfgs = {"ref": dict(macro_block=65, patch_size=11, stride=4, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=0),     # swd_alpha_ref = 0, as shipped (configs/mpv_base.txt:52)
             "other": dict(macro_block=65, patch_size=3, stride=2, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=10000)}
     out = {}
     for name, cfg in cfgs.items():

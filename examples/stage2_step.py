@@ -46,7 +46,7 @@ def run(iters=10, frames=50, planes=32, smooth=0.2, dev="cuda:0", crop=(180, 320
                       stride=torch.tensor([2]), patcht_size=torch.tensor([3]), stridet=torch.tensor([1]), alpha=torch.tensor([10000.0]),
                       dist_fn=["mse"], rou=["-2"], scaling=torch.tensor([0.1])),
         "ref": dict(loss_name=["gpnn_lm"], loss_gain=torch.tensor([3.5]), macro_block=torch.tensor([65]), patch_size=torch.tensor([11]),
-                    stride=torch.tensor([4]), patcht_size=torch.tensor([3]), stridet=torch.tensor([1]), alpha=torch.tensor([0.5]),
+                    stride=torch.tensor([4]), patcht_size=torch.tensor([3]), stridet=torch.tensor([1]), alpha=torch.tensor([0.0]),
                     dist_fn=["mse"], rou=["-2"], scaling=torch.tensor([0.1])),
     }
     out = {}

@@ -13,7 +13,7 @@ rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = torch.device("cuda:0")
 x = synth.make_video(52, 719, 1279, seed=3, device=dev)
 y = synth.make_video(75, 719, 1279, seed=4, device=dev)
-for name, (ps, s, al) in {"ref": (11, 4, 0.5), "other": (3, 2, None)}.items():
+for name, (ps, s, al) in {"ref": (11, 4, 0.0), "other": (3, 2, None)}.items():
     res = {v: [] for v in variants}
     for r in range(rounds + 1):
         for v in variants:

@@ -50,7 +50,7 @@ def nn_mismatch_is_near_tie(x, y, ps, pt, s, st, alpha, nn_gpu, rel_gap=1e-5):
     B = h * w
     X = VO._to_location_major(px, B, pt, ps)
     Y = VO._to_location_major(VO.extract_3Dpatches(y, ps, pt, s, st), B, pt, ps)
-    dist = exact_distances(X, Y)
+    dist = raw = exact_distances(X, Y)
     if alpha is not None:
         dist = dist / (alpha + dist.min(1)[0][:, None])
     ref = torch.argmin(dist, dim=2)
@@ -60,7 +60,15 @@ def nn_mismatch_is_near_tie(x, y, ps, pt, s, st, alpha, nn_gpu, rel_gap=1e-5):
     for bi, i in bad.tolist():
         row = dist[bi, i]
         gap = abs(float(row[got[bi, i]] - row[ref[bi, i]]))
-        if gap > rel_gap * max(float(row.abs().max()), 1e-12):
+        # gap == 0 is an EXACT tie of the objective (alpha = 0: every column minimum scores q / q = 1.0, in fp64 as in fp32), which the
+        # reference settles by torch.argmin's first-minimum rule: the other index is wrong, not a rounding matter
+        # -- unless that column's minimum is itself a near-tie between two rows (then fp32 may hand the column to the other row)
+        if gap == 0.0 and alpha is not None:
+            col = raw[bi, :, ref[bi, i]]
+            two = torch.topk(col, min(2, col.numel()), largest=False)[0]
+            if two.numel() < 2 or float(two[1] - two[0]) > rel_gap * max(float(col.abs().max()), 1e-12):
+                unexplained += 1
+        elif gap > rel_gap * max(float(row.abs().max()), 1e-12):
             unexplained += 1
     return len(bad), unexplained
 
@@ -351,3 +359,118 @@ def test_loss_refuses_what_the_reference_refuses(dev, case):
         if case != "spatial_mismatch":                     # the loss class crops y to x's trimmed size first (utils_vid.py:319-320)
             with pytest.raises(RuntimeError):
                 Patch3DGPNNLowMemLoss()(x, y, macro_block=15, patch_size=7, stride=2, patcht_size=3, stridet=1, rou="-2", scaling=0.1)
+
+
+# ---- the shipped ref-view normaliser alpha = 0 (configs/mpv_base.txt:52 swd_alpha_ref = 0; utils_vid.py:122-142), golden G13 ---------------
+def test_g13_alpha0_get_nn_indices_low_memory(dev, golden):
+    from videoloop3d_amd.utils_vid import get_NN_indices_low_memory
+    g6, g = golden("g6_nn.npz"), golden("g13_alpha0.npz")
+    nn = get_NN_indices_low_memory(T_(g6["X"]).to(dev), T_(g6["Y"]).to(dev), 0, 1024)
+    assert (nn.cpu().numpy() == g["a_nn_alpha0"]).all()
+
+
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4"])
+@pytest.mark.parametrize("ps,pt,s,st", [(5, 3, 2, 1), (3, 3, 2, 1), (3, 2, 1, 2)])
+def test_g13_alpha0_find_nn_and_merge(dev, golden, ps, pt, s, st, variant, monkeypatch):
+    from videoloop3d_amd.utils_vid import FindNNpatchAndMerge
+    monkeypatch.setenv("VL3D_LOSS_VARIANT", variant)
+    g7, g = golden("g7_merge.npz"), golden("g13_alpha0.npz")
+    sm, w = FindNNpatchAndMerge(T_(g7["x"]).to(dev), T_(g7["y"]).to(dev), patch_size=ps, patcht_size=pt, stride=s, stridet=st, alpha=0)
+    assert maxabs(w, g[f"b_ps{ps}_pt{pt}_s{s}_st{st}_weight"]) == 0
+    assert maxabs(sm, g[f"b_ps{ps}_pt{pt}_s{s}_st{st}_sum"]) <= 1e-5
+
+
+@pytest.mark.parametrize("variant", ["0", "3", "4"])
+def test_g13_alpha0_shipped_ref_view_loss_value_and_grad(dev, golden, variant, monkeypatch):
+    """Patch3DGPNNLowMemLoss with the SHIPPED ref-view kwargs (ps 11, stride 4, pt 3, alpha = 0, rou '-2', scaling 0.1) against the reference."""
+    from videoloop3d_amd.utils_vid import Patch3DGPNNDirectLoss, Patch3DGPNNLowMemLoss, find_nn_indices
+    monkeypatch.setenv("VL3D_LOSS_VARIANT", variant)
+    g8, g = golden("g8_loss.npz"), golden("g13_alpha0.npz")
+    x, y = T_(g8["x"]).to(dev).requires_grad_(True), T_(g8["y"]).to(dev)
+    cfg = dict(macro_block=19, patch_size=11, stride=4, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=0, dist_fn='mse')
+    lm = Patch3DGPNNLowMemLoss()
+    loss = lm(x, y, **cfg)
+    (gx,) = torch.autograd.grad(loss, x)
+    ref = float(g["c_loss"])
+    assert abs(loss.item() - ref) <= 1e-5 * max(1.0, abs(ref))
+    assert maxabs(lm.last_weight, g["c_weight"]) == 0 and maxabs(lm.last_y2x, g["c_y2x"]) <= 1e-5
+    assert maxabs(gx, g["c_grad"]) <= 1e-8 + 1e-4 * float(np.abs(g["c_grad"]).max())
+    dl = Patch3DGPNNDirectLoss()(x.detach(), y, **{k: v for k, v in cfg.items() if k != "macro_block"})
+    assert abs(dl.item() - ref) <= 1e-5 * max(1.0, abs(ref))
+    nn, *_ = find_nn_indices(x.detach(), y, 11, 3, 4, 1, 0)
+    assert (nn.cpu().numpy() == g["c_nn"]).all()
+
+
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4"])
+@pytest.mark.parametrize("ps,s", [(11, 4), (3, 2)])
+def test_g13_alpha0_exact_ties_take_the_first_minimum(dev, golden, ps, s, variant, monkeypatch):
+    """n2 > n1 at alpha = 0: most rows are decided by an EXACT tie at score 1.0 (the row is the minimum of several columns) and the
+    reference keeps the first such column.  The kernels' per-column weight form scores a column minimum through its tie value."""
+    from videoloop3d_amd.utils_vid import Patch3DGPNNLowMemLoss, find_nn_indices
+    monkeypatch.setenv("VL3D_LOSS_VARIANT", variant)
+    g = golden("g13_alpha0.npz")
+    x, y = T_(g["d_x"]).to(dev), T_(g["d_y"]).to(dev)
+    nn, *_ = find_nn_indices(x, y, ps, 3, s, 1, 0)
+    nbad, unexplained = nn_mismatch_is_near_tie(x.cpu(), y.cpu(), ps, 3, s, 1, 0, nn)
+    assert unexplained == 0
+    assert (nn.cpu().numpy() == g[f"d_ps{ps}_nn"]).all()
+    xr = x.clone().requires_grad_(True)
+    lm = Patch3DGPNNLowMemLoss()
+    loss = lm(xr, y, macro_block=ps + 2 * s, patch_size=ps, stride=s, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=0)
+    (gx,) = torch.autograd.grad(loss, xr)
+    ref = float(g[f"d_ps{ps}_loss"])
+    assert abs(loss.item() - ref) <= 1e-5 * max(1.0, abs(ref)) and maxabs(lm.last_y2x, g[f"d_ps{ps}_y2x"]) <= 1e-5
+    assert maxabs(gx, g[f"d_ps{ps}_grad"]) <= 1e-8 + 1e-4 * float(np.abs(g[f"d_ps{ps}_grad"]).max())
+
+
+@pytest.mark.parametrize("tx,ty,ps,s", [(52, 75, 11, 4), (52, 50, 11, 4), (82, 122, 11, 4), (122, 182, 7, 4), (52, 75, 3, 2)])
+def test_alpha0_at_the_configured_clip_lengths(dev, tx, ty, ps, s):
+    """alpha = 0 at the clip lengths of cfg3 (50 + 2 render frames vs 75 / 50 captured), cfg4 (80 / 120) and cfg5 (120 / 180), default
+    kernel choice: exact ties follow the first-minimum rule, every other difference is a near-tie of the fp64 objective."""
+    from videoloop3d_amd.utils_vid import _nn_and_fold
+    H, W = ps + 5 * s, ps + 9 * s
+    x, y = synth.make_video(tx, H, W, seed=7), synth.make_video(ty, H, W, seed=8)
+    sg, wg, nng = _nn_and_fold(x.to(dev), y.to(dev), ps, 3, s, 1, 0, normalize=False)
+    nbad, unexplained = nn_mismatch_is_near_tie(x, y, ps, 3, s, 1, 0, nng)
+    assert unexplained == 0 and nbad <= nng.numel() // 100
+    assert torch.isfinite(sg).all()
+
+
+@pytest.mark.parametrize("variant", ["0", "4"])
+def test_g13_alpha0_degenerate_input_documented_behaviour(dev, golden, variant, monkeypatch):
+    """y holds exact copies of x frames (golden G13e records what the reference does there: negative column minima, NaN / +-inf scores,
+    indices that follow cancellation noise).  DECISION for the HIP path: distances are never negative (direct SSD in v4, clamped Gram in v5),
+    so a column whose minimum is exactly 0 scores NaN for the row(s) at distance 0 -- minimal, like torch.argmin -- and +inf for every
+    other row; nothing is negative, the indices are valid and the loss is finite.  With the exact-SSD kernel (variant 4) every x patch
+    that has an exact copy in y therefore picks its first copy."""
+    from videoloop3d_amd.utils_vid import Patch3DGPNNLowMemLoss, find_nn_indices
+    monkeypatch.setenv("VL3D_LOSS_VARIANT", variant)
+    g = golden("g13_alpha0.npz")
+    x, y = T_(g["e_x"]).to(dev), T_(g["e_y"]).to(dev)
+    nn, *_ = find_nn_indices(x, y, 5, 3, 2, 1, 0)
+    n2 = y.shape[2] - 2
+    assert int(nn.min()) >= 0 and int(nn.max()) < n2
+    lm = Patch3DGPNNLowMemLoss()
+    loss = lm(x.clone().requires_grad_(True), y, macro_block=9, patch_size=5, stride=2, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=0)
+    assert np.isfinite(loss.item()) and torch.isfinite(lm.last_y2x).all()
+    if variant == "4":
+        # x patches 1..4 are y patches 4..7 (y = [4 random frames, x[1:7], 3 random frames], pt = 3)
+        assert (nn[:, :, 1:5].cpu() == torch.arange(4, 8, dtype=torch.int32)).all()
+
+
+def test_alpha0_full_720p_frame_windows(dev):
+    """cfg3's loss shapes (52 x 75 frames, 720p, shipped ref-view kwargs incl. alpha = 0) on the whole frame: the indices of three windows of
+    6 x 10 patch locations (a location only sees its own pixels) obey the parity criterion; votes are finite and inside y's range."""
+    from videoloop3d_amd.utils_vid import _nn_and_fold
+    ps, s = 11, 4
+    H, W = (720 - ps) // s * s + ps, (1280 - ps) // s * s + ps
+    x, y = synth.make_video(52, H, W, seed=3, device=dev), synth.make_video(75, H, W, seed=4, device=dev)
+    y2x, w, nn = _nn_and_fold(x, y, ps, 3, s, 1, 0, normalize=True)
+    assert int(nn.min()) >= 0 and int(nn.max()) < 73 and torch.isfinite(y2x).all()
+    assert float(y2x.min()) >= 0.0 and float(y2x.max()) < 1.0
+    for by, bx in ((0, 0), (87, 151), (172, 308)):
+        r0, c0 = by * s, bx * s
+        xc = x[..., r0:r0 + ps + 5 * s, c0:c0 + ps + 9 * s].cpu()
+        yc = y[..., r0:r0 + ps + 5 * s, c0:c0 + ps + 9 * s].cpu()
+        nbad, unexplained = nn_mismatch_is_near_tie(xc, yc, ps, 3, s, 1, 0, nn[by:by + 6, bx:bx + 10].contiguous())
+        assert unexplained == 0 and nbad <= 30

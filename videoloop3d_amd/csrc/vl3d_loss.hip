@@ -272,10 +272,17 @@ __global__ __launch_bounds__(NN_THREADS) void patchnn2_k(NN2Args a) {
 // positive constant commutes with min and argmin, so the column minimum is taken over the raw sums and each column gets ONE weight
 // w_j = (1 / d) / (alpha + min_i s / d): a score is s * w_j -- three LDS reads, two adds and a multiply per frame pair instead of two
 // fp32 divisions (which were most of the epilogue's instructions).  Without alpha the raw sums are compared.  The rounding differs
-// from the reference's two divisions by an ulp, i.e. only between exact near-ties.  Whole workgroup, 4 lanes per row / column.
+// from the reference's two divisions by an ulp, i.e. only between exact near-ties -- EXCEPT at the column minimum itself: there the
+// reference's score is q / (alpha + q) with q = m / d bit-identical in numerator and denominator, which for the shipped ref-view
+// alpha = 0 (configs/mpv_base.txt:52) is EXACTLY 1.0 in every column, the smallest score a row can have; a row that is the minimum of
+// several columns (certain when n2 > n1) is decided by torch.argmin's first-minimum rule among exact ties.  s * w_j is 1 +- an ulp, so
+// an entry equal to its column's minimum takes the tie score t_j = (m / d) / (alpha + m / d) formed with true divisions instead
+// (1.0 at alpha = 0; NaN = minimal for m = 0, as 0 / 0 is in the reference).  colw: [3][n2p] = weights | minima | tie scores.
+// Whole workgroup, 4 lanes per row / column.
 // PREINIT: the caller has set colw[0..n2) to +inf (bit pattern) behind a barrier already
 template <int NTHR, bool PREINIT = false>
-__device__ __forceinline__ void nn_epilogue(const NN2Args &a, const float *E, float *colw, size_t b, int tid, int sub) {
+__device__ __forceinline__ void nn_epilogue(const NN2Args &a, const float *E, float *colw, int n2p, size_t b, int tid, int sub) {
+    float *colm = colw + n2p, *colt = colw + 2 * n2p;
     if (a.pt == 3 && a.stridet == 1) {
         // every shipped configuration: three-frame patches at temporal stride 1.  s(i, j..j+3) needs E(i, j..j+3), E(i+1, j+1..j+4) and
         // E(i+2, j+2..j+5): whole 16-byte LDS reads (the rows are 16-byte aligned, TyP is a multiple of 4), the upper halves carried
@@ -309,7 +316,12 @@ __device__ __forceinline__ void nn_epilogue(const NN2Args &a, const float *E, fl
             }
             __syncthreads();
             const float inv_d = 1.0f / a.dnorm;
-            for (int j = tid; j < a.n2; j += NTHR) colw[j] = inv_d / (a.alpha + colw[j] / a.dnorm);
+            for (int j = tid; j < a.n2; j += NTHR) {
+                const float m = colw[j], q = m / a.dnorm;
+                colm[j] = m;
+                colt[j] = q / (a.alpha + q);
+                colw[j] = inv_d / (a.alpha + q);
+            }
             __syncthreads();
         }
         const int q4 = ((a.n2 + 3) / 4 + 3) & ~3, j0 = sub * q4, j1 = min(a.n2, j0 + q4);     // quarters of whole column groups
@@ -325,8 +337,10 @@ __device__ __forceinline__ void nn_epilogue(const NN2Args &a, const float *E, fl
                     const float4 c0 = p[0], h1 = p[TyP / 4 + 1], h2 = p[TyP / 2 + 1];
                     float sa[4] = {(c0.x + l1.y) + l2.z, (c0.y + l1.z) + l2.w, (c0.z + l1.w) + h2.x, (c0.w + h1.x) + h2.y};
                     if (a.use_alpha) {
-                        const float4 w = *reinterpret_cast<const float4 *>(colw + jb);
-                        sa[0] *= w.x; sa[1] *= w.y; sa[2] *= w.z; sa[3] *= w.w;
+                        const float4 w = *reinterpret_cast<const float4 *>(colw + jb), m = *reinterpret_cast<const float4 *>(colm + jb);
+                        const float4 t = *reinterpret_cast<const float4 *>(colt + jb);
+                        sa[0] = sa[0] == m.x ? t.x : sa[0] * w.x; sa[1] = sa[1] == m.y ? t.y : sa[1] * w.y;
+                        sa[2] = sa[2] == m.z ? t.z : sa[2] * w.z; sa[3] = sa[3] == m.w ? t.w : sa[3] * w.w;
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -374,7 +388,12 @@ __device__ __forceinline__ void nn_epilogue(const NN2Args &a, const float *E, fl
             }
             m = fminf(m, __shfl_xor(m, 1, 64));
             m = fminf(m, __shfl_xor(m, 2, 64));
-            if (sub == 0) colw[j] = inv_d / (a.alpha + m / a.dnorm);
+            if (sub == 0) {
+                const float q = m / a.dnorm;
+                colm[j] = m;
+                colt[j] = q / (a.alpha + q);
+                colw[j] = inv_d / (a.alpha + q);
+            }
         }
         __syncthreads();
     }
@@ -394,7 +413,7 @@ __device__ __forceinline__ void nn_epilogue(const NN2Args &a, const float *E, fl
                     for (int u = 0; u < 4; ++u) sa[u] += e0[kt * a.TyP + (j + u) * a.stridet + kt];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const float v = a.use_alpha ? sa[u] * colw[j + u] : sa[u];
+                    const float v = a.use_alpha ? (sa[u] == colm[j + u] ? colt[j + u] : sa[u] * colw[j + u]) : sa[u];
                     const bool vn = (v != v);
                     if (!best_nan && (vn || v < best)) { best = v; bj = j + u; best_nan = vn; }
                 }
@@ -402,7 +421,7 @@ __device__ __forceinline__ void nn_epilogue(const NN2Args &a, const float *E, fl
             for (; j < j1; ++j) {
                 float sacc = 0.f;
                 for (int kt = 0; kt < a.pt; ++kt) sacc += e0[kt * a.TyP + j * a.stridet + kt];
-                const float v = a.use_alpha ? sacc * colw[j] : sacc;
+                const float v = a.use_alpha ? (sacc == colm[j] ? colt[j] : sacc * colw[j]) : sacc;
                 const bool vn = (v != v);
                 if (!best_nan && (vn || v < best)) { best = v; bj = j; best_nan = vn; }
             }
@@ -532,11 +551,11 @@ __global__ __launch_bounds__(NTHR) void patchnn4_k(NN2Args a, int H_unused, int 
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) E[(ti + i) * a.TyP + tj + j] = acc[l][i * TJ + j];
+                for (int j = 0; j < TJ; ++j) E[(ti + i) * a.TyP + tj + j] = fmaxf(acc[l][i * TJ + j], 0.0f);   // (a difference of running sums: >= -rounding)
         }
         __syncthreads();
         const size_t b = (size_t)by * a.w_o + bx0 + l;
-        nn_epilogue<NTHR>(a, E, colmin, b, tid, sub);
+        nn_epilogue<NTHR>(a, E, colmin, (a.n2 + 3) & ~3, b, tid, sub);
     }
 }
 
@@ -632,7 +651,7 @@ __global__ __launch_bounds__(64 * NW, 2) void patchnn5_k(NN2Args a, int groups_x
     float *E = smem;                                            // [TxP][TyP], one location at a time in the epilogue: aliases the staging
     float *colw = E + (size_t)a.TxP * a.TyP;
     const int n2p = (a.n2 + 3) & ~3;                            // (16-byte aligned weight rows: the epilogue reads them four at a time)
-    float *sy = colw + NL * n2p;                                // [NL][TyP] y terms of the locations   (colw: [NL][n2p])
+    float *sy = colw + NL * 3 * n2p;                            // [NL][TyP] y terms of the locations   (colw: [NL][3][n2p])
     const int g = blockIdx.x, by = g / groups_x, bx0 = (g % groups_x) * NL;
     const int r0 = by * a.stride, c0 = bx0 * a.stride, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -757,7 +776,7 @@ __global__ __launch_bounds__(64 * NW, 2) void patchnn5_k(NN2Args a, int groups_x
 #pragma unroll
         for (int l = 0; l < NL; ++l) sy[l * a.TyP + tid] = an[l];
     }
-    for (int j = tid; j < NL * n2p; j += NTHR) reinterpret_cast<int *>(colw)[j] = 0x7f800000;     // column minima start at +inf
+    for (int j = tid; j < NL * n2p; j += NTHR) reinterpret_cast<int *>(colw)[(j / n2p) * 3 * n2p + j % n2p] = 0x7f800000;     // column minima start at +inf
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
         if (l >= nloc) break;                                    // uniform
@@ -775,7 +794,7 @@ __global__ __launch_bounds__(64 * NW, 2) void patchnn5_k(NN2Args a, int groups_x
         __syncthreads();
         const size_t b = (size_t)by * a.w_o + bx0 + l;
         if (a.ablate & 1) { if (tid < a.n1) a.nn[b * a.n1 + tid] = 0; continue; }
-        nn_epilogue<NTHR, true>(a, E, colw + l * n2p, b, tid, sub);
+        nn_epilogue<NTHR, true>(a, E, colw + l * 3 * n2p, n2p, b, tid, sub);
     }
 }
 
@@ -1158,7 +1177,7 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
         // stage = the most columns (all ps rows each) whose two buffers leave room for three workgroups per CU (or fit at all)
         int ch5 = (int)((53 * 1024 / 2 - pad5) / ((size_t)4 * (PX + PY) * sizeof(float))) / a.ps;
         ch5 = ch5 < 1 ? 1 : (ch5 > RWc5 ? RWc5 : ch5);
-        const size_t stage5 = 2 * ((size_t)ch5 * a.ps * 4 * (PX + PY) * sizeof(float) + pad5), epi5 = ((size_t)a.TxP * a.TyP + 4 * (a.n2 + 3 + a.TyP)) * sizeof(float);
+        const size_t stage5 = 2 * ((size_t)ch5 * a.ps * 4 * (PX + PY) * sizeof(float) + pad5), epi5 = ((size_t)a.TxP * a.TyP + 4 * (3 * (a.n2 + 3) + a.TyP)) * sizeof(float);
         const size_t lds5 = stage5 > epi5 ? stage5 : epi5;
         const bool fits5 = (size_t)ch5 * a.ps * PX <= (size_t)4 * nw5 * 64 && (size_t)ch5 * a.ps * PY <= (size_t)7 * nw5 * 64 &&  // KX / KY pieces per wave
                            ((size_t)a.ps * desc->W + ch5) * (PX > PY ? PX : PY) < (1u << 24);                  // 24-bit DMA source offsets
@@ -1201,7 +1220,7 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
         // v4 (4 locations per workgroup, column sums): default whenever one thread tile per frame-pair tile suffices
         const int ntiles4 = (a.TxP / TI) * (a.TyP / TJ);
         const int RWc4 = a.ps + (NL4 - 1) * a.stride;
-        const size_t stage4 = (size_t)RWc4 * 3 * (a.TxP + a.TyP), epi4 = (size_t)a.TxP * a.TyP + a.n2;   // the epilogue aliases the staging
+        const size_t stage4 = (size_t)RWc4 * 3 * (a.TxP + a.TyP), epi4 = (size_t)a.TxP * a.TyP + 3 * (a.n2 + 3);   // the epilogue aliases the staging
         const size_t lds4 = (stage4 > epi4 ? stage4 : epi4) * sizeof(float);
         const bool use_v4 = (pv == 0 || pv == 4) && ntiles4 <= 1024 && lds4 <= 150 * 1024;
         if (use_v5) {
