@@ -94,7 +94,7 @@ int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, const float
 int64_t vl3d_render_bwd_scratch_bytes(const vl3d_render_desc *desc);
 int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, const float *homos,
                     const float *rgb, const float *alpha, const float *grad_rgb, const float *grad_alpha,
-                    const float *grad_reg, const float *grad_alpha_sums, float *grad_stack, void *scratch,
+                    const float *grad_reg, const void *reg_state, const float *grad_alpha_sums, float *grad_stack, void *scratch,
                     int64_t scratch_bytes, vl3d_stream_t stream);
 
 /* Tile culling (MPI.py:288-442 "Tile Culling Algorithm": stage 2 renders only the quads that survived).  quad_keep is a device
@@ -112,8 +112,8 @@ int vl3d_render_fwd_culled(const vl3d_render_desc *desc, const void *stack, cons
                            vl3d_stream_t stream);
 int vl3d_render_bwd_culled(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep,
                            int32_t QH, int32_t QW, const float *rgb, const float *alpha, const float *grad_rgb,
-                           const float *grad_alpha, const float *grad_reg, const float *grad_alpha_sums, float *grad_stack,
-                           void *scratch, int64_t scratch_bytes, vl3d_stream_t stream);
+                           const float *grad_alpha, const float *grad_reg, const void *reg_state, const float *grad_alpha_sums,
+                           float *grad_stack, void *scratch, int64_t scratch_bytes, vl3d_stream_t stream);
 
 /* Static tiles of a tile-culled VIDEO stack (MPV.py:235-288: one static atlas shared by all frames).  In place on the stack
  * gradient (D,T,Hs,Ws,4): texels that only static quads can read get the sum over the T frames in every frame (the T copies
@@ -181,19 +181,24 @@ int vl3d_adam_window_step_boxes(int32_t D, int32_t T, int32_t Hs, int32_t Ws, in
                                 vl3d_stream_t stream);
 void vl3d_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, float *lr_bc1, float *bc2s);
 
-/* Layer-space smoothness regularisers (MPV.py:517-531 rgb_smooth / a_smooth) WITHOUT the materialised [T,h,w,K,4] layer
- * tensor: sums[0..3] (device doubles, overwritten) = sum over frames, planes and neighbouring pixel pairs of
- * |L[p]-L[q]| for (x-pairs, rgb), (y-pairs, rgb), (x-pairs, alpha), (y-pairs, alpha), where L is the warped+activated
- * per-layer rgba (0 where a plane does not cover the pixel).  Their gradient enters vl3d_render_bwd through
- * grad_reg = device float[4] = dL/dsums (NULL: no regulariser term). */
-int vl3d_render_reg_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos, double *sums,
+/* Layer-space smoothness regularisers (MPV.py:517-531 rgb_smooth / a_smooth; MPI.py:608-622) WITHOUT the materialised [T,h,w,K,4]
+ * layer tensor: sums[0..3] (device doubles, overwritten) = sum over frames, layer SLOTS and neighbouring pixel pairs of |L[p]-L[q]|
+ * for (x-pairs, rgb), (y-pairs, rgb), (x-pairs, alpha), (y-pairs, alpha).  L is the reference's `mpi` tensor: slot k of a pixel holds
+ * the warped+activated rgba of the k-th nearest plane that COVERS it (masked_scatter over the rasteriser's z-sorted pix_to_face,
+ * MPV.py:386-392, 441-449; unused slots 0) -- equal to plane k only where both pixels of a pair are covered by the same planes.
+ * reg_state: caller-owned device buffer of vl3d_render_reg_state_bytes(desc) bytes, written by these forwards (per-pixel coverage
+ * masks and pair flags; per (plane, frame, pixel) the signs of the four differences its layer value takes part in) and read by
+ * vl3d_render_bwd, which takes the gradient w.r.t. the four sums as grad_reg = device float[4] (NULL: no regulariser term;
+ * non-NULL requires the reg_state of the matching forward).  At most 128 planes. */
+int64_t vl3d_render_reg_state_bytes(const vl3d_render_desc *desc);
+int vl3d_render_reg_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos, double *sums, void *reg_state,
                         vl3d_stream_t stream);
 /* vl3d_render_fwd and vl3d_render_reg_fwd in ONE pass over the stack (dense stacks): what MPMeshVid.forward needs per training step
  * when rgb_smooth / a_smooth are on (configs/mpv_base.txt:33-34).  rgb / alpha / alpha_sums bit-identical to vl3d_render_fwd. */
 int vl3d_render_fwd_reg(const vl3d_render_desc *desc, const void *stack, const float *homos, float *rgb, float *alpha,
-                        float *alpha_sums, double *sums, vl3d_stream_t stream);
+                        float *alpha_sums, double *sums, void *reg_state, vl3d_stream_t stream);
 int vl3d_render_reg_fwd_culled(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep,
-                               int32_t QH, int32_t QW, double *sums, vl3d_stream_t stream);
+                               int32_t QH, int32_t QW, double *sums, void *reg_state, vl3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Unfused operators (drop-ins for the reference's L3 functions).

@@ -4,7 +4,9 @@ Restates /root/reference/MPV.py:477-556 (forward) on top of the pinned operator 
 MPV.py itself cannot be imported here (pytorch3d, cv2, imageio, torchvision are absent) so this module is
 "parity unpinned" at the pytorch3d boundary: sampling positions are pinned through compute_homography (== ray-plane
 intersection), compositing through overcompose, the loss through G8; the +0.5 pixel centre and hard-cut borders are
-parameters.
+parameters.  A third unpinned item is not a constant but a semantic: the layer tensor `mpi` the regularisers read
+is HIT-SLOT indexed (slot k = the k-th nearest face the rasteriser hit at that pixel, MPV.py:386-392, 441-449, utils.py:64-69),
+restated by mpi_oracle.layers_to_slots from the source; the un-vendored rasteriser's z-sort is taken to be depth order.
 """
 import numpy as np
 import torch
@@ -119,7 +121,8 @@ def mpi_forward(stack, stack_mask, args, H, W, ref_extrin, ref_intrin, near, far
         mpis.append(mpi)
         alphas.append(alpha)
     rgbl = torch.cat(outs, 0).permute(0, 3, 1, 2)
-    mpi = torch.cat(mpis, 0)
+    kmax = max(m.shape[3] for m in mpis)             # the B views are rasterised in one call: K = the deepest pixel of the batch
+    mpi = torch.cat([torch.nn.functional.pad(m, (0, 0, 0, kmax - m.shape[3])) for m in mpis], 0)
     alpha = torch.cat(alphas, 0)
     extra = {}
     if training:
@@ -127,12 +130,14 @@ def mpi_forward(stack, stack_mask, args, H, W, ref_extrin, ref_intrin, near, far
             a = mpi[..., -1]
             sp = a.norm(dim=-1, p=1) / a.norm(dim=-1, p=2).clamp_min(1e-6)
             extra["sparsity"] = (sp.mean() / np.sqrt(D)).reshape(1, -1)
-        if args.rgb_smooth_loss_weight > 0:
+        if args.rgb_smooth_loss_weight > 0:                                                          # MPI.py:605-612
             sm = mpi[..., :-1]
-            extra["rgb_smooth"] = ((sm[:, :, :-1] - sm[:, :, 1:]).abs().mean() + (sm[:, :-1] - sm[:, 1:]).abs().mean()).reshape(1, -1)
-        if args.a_smooth_loss_weight > 0:
+            denorm = sm.shape[-2] / D
+            extra["rgb_smooth"] = (((sm[:, :, :-1] - sm[:, :, 1:]).abs().mean() + (sm[:, :-1] - sm[:, 1:]).abs().mean()) * denorm).reshape(1, -1)
+        if args.a_smooth_loss_weight > 0:                                                            # MPI.py:614-620
             sm = mpi[..., -1]
-            extra["a_smooth"] = ((sm[:, :, :-1] - sm[:, :, 1:]).abs().mean() + (sm[:, :-1] - sm[:, 1:]).abs().mean()).reshape(1, -1)
+            denorm = sm.shape[-1] / D
+            extra["a_smooth"] = (((sm[:, :, :-1] - sm[:, :, 1:]).abs().mean() + (sm[:, :-1] - sm[:, 1:]).abs().mean()) * denorm).reshape(1, -1)
         if args.density_loss_weight > 0:
             extra["density"] = (alpha - 1).abs().mean().reshape(1, -1)
     return rgbl, extra

@@ -321,7 +321,7 @@ def test_bwd_tile_720p_matches_atomics(dev):
         gs = torch.full_like(stack, float("nan")).detach()
         nscratch = int(L.lib().vl3d_render_bwd_scratch_bytes(d))
         scratch = torch.zeros((nscratch + 3) // 4, dtype=torch.float32, device=dev)
-        L.check(L.lib().vl3d_render_bwd(d, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.ptr(g), None, None, None, L.ptr(gs),
+        L.check(L.lib().vl3d_render_bwd(d, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.ptr(g), None, None, None, None, L.ptr(gs),
                                         L.ptr(scratch), nscratch, L.stream_ptr(dev)), "vl3d_render_bwd")
         assert int(scratch.view(torch.int32)[0].item()) == (0 if variant == 1 else 1)
         assert torch.isfinite(gs).all()
@@ -825,3 +825,57 @@ def test_fused_forward_with_regularisers_equals_the_two_pass_forward(dev, spec_n
         assert torch.equal(out[0][k], out[0x1000][k]), k
     assert float(((out[0][2] - out[0x1000][2]).abs() / out[0x1000][2].abs().clamp_min(1.0)).max()) <= 1e-6
     assert float(out[0][2].abs().min()) > 0
+
+
+@pytest.mark.parametrize("T", [1, 2, 3])
+@pytest.mark.parametrize("mode", ["dense_plane_edges", "sparsified", "sparsified_atomics", "sparsified_f16"])
+def test_smoothness_regularisers_are_hit_slot_indexed(dev, mode, T):
+    """The reference's layer tensor is indexed by HIT SLOT (MPV.py:386-392, 441-449; utils.py:64-69): slot k of a pixel is its k-th
+    nearest COVERED plane, and rgb_smooth / a_smooth difference neighbours per slot (MPV.py:517-531).  Where neighbours are covered
+    by different planes -- a plane's edge inside the view (stack 1.1x the frame, off-centre crop) or the quad borders of a sparsified
+    model -- that is NOT the per-plane difference.  Sums and stack gradient against the slot oracle; the plane-indexed reading of the
+    same layers differs by far more than the tolerance, so the test tells the two apart.  T = 1: one-frame tile kernel, T = 2 / 3:
+    frame pairs (even / odd)."""
+    from videoloop3d_amd.render import RenderSpec, render_planes_with_regularisers
+    D, Hs, Ws, H, W = 7, 66, 88, 60, 80
+    kw_p, kw_o = SPECS["mpv"]
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=31)
+    if mode == "sparsified_f16":
+        stack = stack.half().float()
+    # the crop looks past the stack's upper left corner: the NEAR planes end inside the view while the far ones still cover it, so
+    # behind a near plane's edge every slot holds another plane than next to it
+    shift = torch.tensor([[1.0, 0, -8.0], [0, 1.0, -6.0], [0, 0, 1.0]])
+    homos = bench_homos(D, H, W, scale=2.5) @ shift
+    keep = None
+    if mode != "dense_plane_edges":
+        torch.manual_seed(11)
+        keep = torch.rand(D, 6, 8) < 0.45
+    g_rgb = synth.hash_uniform((T, H, W, 3), seed=5) - 0.5
+    wts = torch.tensor([1.1e-3, 0.7e-3, 1.6e-3, 0.9e-3])
+
+    def sums_of(L):
+        return torch.stack([(L[:, :, 1:, :, :3] - L[:, :, :-1, :, :3]).abs().sum(), (L[:, 1:, :, :, :3] - L[:, :-1, :, :, :3]).abs().sum(),
+                            (L[:, :, 1:, :, 3] - L[:, :, :-1, :, 3]).abs().sum(), (L[:, 1:, :, :, 3] - L[:, :-1, :, :, 3]).abs().sum()])
+    s_cpu = stack.clone().requires_grad_(True)
+    rgb_o, alpha_o, _, slots = MO.render_planes(s_cpu, homos, H, W, MO.RenderSpec(**kw_o), return_layers=True, quad_keep=keep)
+    sums_o = sums_of(slots)
+    (gs_o,) = torch.autograd.grad((rgb_o * g_rgb).sum() + (sums_o * wts).sum(), s_cpu)
+    with torch.no_grad():
+        planes = MO.render_planes(stack, homos, H, W, MO.RenderSpec(**kw_o), return_layers=True, quad_keep=keep, layer_order="plane")[3]
+        # the two readings are far apart here (plane edges are lines, quad borders are everywhere)
+        assert float(((sums_of(planes) - sums_o).abs() / sums_o).max()) > (0.003 if keep is None else 0.02)
+    variant = 1 if mode == "sparsified_atomics" else 0
+    s_gpu = (stack.half() if mode == "sparsified_f16" else stack).to(dev).requires_grad_(True)
+    rgb, alpha, sums, _ = render_planes_with_regularisers(s_gpu, homos.to(dev), H, W, RenderSpec(variant=variant, **kw_p),
+                                                          quad_keep=None if keep is None else keep.to(dev))
+    (gs,) = torch.autograd.grad((rgb * g_rgb.to(dev)).sum() + (sums * wts.to(dev)).sum(), s_gpu)
+    assert _tile_ran() == (0 if variant == 1 else 1)
+    assert maxabs(rgb, rgb_o) <= TOL and maxabs(alpha, alpha_o) <= TOL
+    assert float(((sums.cpu() - sums_o).abs() / sums_o.abs().clamp_min(1.0)).max()) <= 1e-4
+    diff = (gs.float().cpu() - gs_o).abs()
+    scale = max(1.0, float(gs_o.abs().max()))
+    if mode == "sparsified_f16":
+        assert float(diff.max()) <= 4e-3 * scale
+    else:
+        # the sign of a near-zero layer difference may flip with a 1-ulp sampling difference: robust criterion
+        assert float((diff > TOL * scale).float().mean()) <= 1e-4 and float(diff.max()) <= 5e-3 * scale

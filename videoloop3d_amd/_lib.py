@@ -47,8 +47,9 @@ SIGNATURES = {
     "vl3d_version": ([], C.c_int),
     "vl3d_render_fwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P, _P], C.c_int),
     "vl3d_render_bwd_scratch_bytes": ([C.POINTER(RenderDesc)], C.c_int64),
-    "vl3d_render_bwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
-    "vl3d_render_reg_fwd_culled": ([C.POINTER(RenderDesc), _P, _P, _P, _I32, _I32, _P, _P], C.c_int),
+    "vl3d_render_bwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
+    "vl3d_render_reg_state_bytes": ([C.POINTER(RenderDesc)], C.c_int64),
+    "vl3d_render_reg_fwd_culled": ([C.POINTER(RenderDesc), _P, _P, _P, _I32, _I32, _P, _P, _P], C.c_int),
     "vl3d_tie_static_grad": ([_I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _I32, _P], C.c_int),
     "vl3d_adam_step_tiles": ([_I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _I64, _P],
                              C.c_int),
@@ -60,9 +61,9 @@ SIGNATURES = {
     "vl3d_adam_step_scalars": ([_F, _F, _F, _I64, C.POINTER(C.c_float), C.POINTER(C.c_float)], None),
     "vl3d_render_cull_scratch_bytes": ([C.POINTER(RenderDesc)], C.c_int64),
     "vl3d_render_fwd_culled": ([C.POINTER(RenderDesc), _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P], C.c_int),
-    "vl3d_render_bwd_culled": ([C.POINTER(RenderDesc), _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
-    "vl3d_render_reg_fwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P], C.c_int),
-    "vl3d_render_fwd_reg": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    "vl3d_render_bwd_culled": ([C.POINTER(RenderDesc), _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
+    "vl3d_render_reg_fwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P], C.c_int),
+    "vl3d_render_fwd_reg": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "vl3d_warp_fwd": ([_I32] * 6 + [_P, _P, _P, _P], C.c_int),
     "vl3d_warp_bwd": ([_I32] * 6 + [_P, _P, _P, _P], C.c_int),
     "vl3d_overcompose_fwd": ([_I64, _I32, _I32, _P, _P, _P, _P, _P], C.c_int),

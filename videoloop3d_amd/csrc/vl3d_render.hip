@@ -136,16 +136,43 @@ extern "C" int64_t vl3d_render_bwd_scratch_bytes(const vl3d_render_desc *desc) {
 }
 
 static int render_reg_fwd_impl(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep, int32_t QH,
-                               int32_t QW, double *sums, vl3d_stream_t stream);
+                               int32_t QW, double *sums, void *reg_state, vl3d_stream_t stream);
+
+// reg_state: flags [H][W] u8 | coverage masks [H][W][2] u64 | sign words [D][T][H][W] u16 | patch words [D][T][H][W] u16 (256-byte aligned parts)
+struct RegLayout { int64_t masks, signs, patch, total; };
+static RegLayout reg_layout(const vl3d_render_desc *d) {
+    auto up = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
+    const int64_t px = (int64_t)d->H * d->W, words = (int64_t)d->D * d->T * px * 2;
+    RegLayout l;
+    l.masks = up(px);
+    l.signs = l.masks + up(px * 16);
+    l.patch = l.signs + up(words);
+    l.total = l.patch + up(words);
+    return l;
+}
+static void set_reg_state(RenderArgs &a, const vl3d_render_desc *d, const void *reg_state) {
+    char *b = reinterpret_cast<char *>(const_cast<void *>(reg_state));
+    const RegLayout l = reg_layout(d);
+    a.reg_flags = reinterpret_cast<unsigned char *>(b);
+    a.reg_masks = reinterpret_cast<unsigned long long *>(b + l.masks);
+    a.reg_signs = reinterpret_cast<unsigned short *>(b + l.signs);
+    a.reg_patch = reinterpret_cast<unsigned short *>(b + l.patch);
+}
+extern "C" int64_t vl3d_render_reg_state_bytes(const vl3d_render_desc *desc) {
+    if (!desc || desc->D <= 0 || desc->T <= 0 || desc->H <= 0 || desc->W <= 0) return 0;
+    return reg_layout(desc).total;
+}
 
 extern "C" int vl3d_render_fwd_reg(const vl3d_render_desc *desc, const void *stack, const float *homos, float *rgb, float *alpha,
-                                   float *alpha_sums, double *sums, vl3d_stream_t stream) {
+                                   float *alpha_sums, double *sums, void *reg_state, vl3d_stream_t stream) {
     int rc = check_desc(desc);
     if (rc != VL3D_OK) return rc;
-    VL3D_REQUIRE(stack && homos && rgb && alpha && sums, "null pointer passed to vl3d_render_fwd_reg");
+    VL3D_REQUIRE(stack && homos && rgb && alpha && sums && reg_state, "null pointer passed to vl3d_render_fwd_reg");
+    VL3D_REQUIRE(desc->D <= 128, "the layer regularisers support at most 128 planes (coverage masks)");
     VL3D_REQUIRE((int64_t)desc->Hs * desc->Ws * 16 < (1ll << 32), "frame too large for 32-bit byte offsets");
     RenderArgs a = make_args(desc);
     a.stack = (const float *)stack; a.homos = homos; a.rgb = rgb; a.alpha = alpha; a.asum = alpha_sums; a.reg_sums = sums;
+    set_reg_state(a, desc, reg_state);
     a.g_f16 = desc->stack_dtype == VL3D_F16;
     a.reg_fwd = 2;
     VL3D_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(double), (hipStream_t)stream));
@@ -155,21 +182,22 @@ extern "C" int vl3d_render_fwd_reg(const vl3d_render_desc *desc, const void *sta
     return VL3D_OK;
 }
 
-extern "C" int vl3d_render_reg_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos, double *sums,
+extern "C" int vl3d_render_reg_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos, double *sums, void *reg_state,
                                    vl3d_stream_t stream) {
-    return render_reg_fwd_impl(desc, stack, homos, nullptr, 0, 0, sums, stream);
+    return render_reg_fwd_impl(desc, stack, homos, nullptr, 0, 0, sums, reg_state, stream);
 }
 
 extern "C" int vl3d_render_reg_fwd_culled(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep,
-                                          int32_t QH, int32_t QW, double *sums, vl3d_stream_t stream) {
-    return render_reg_fwd_impl(desc, stack, homos, quad_keep, QH, QW, sums, stream);
+                                          int32_t QH, int32_t QW, double *sums, void *reg_state, vl3d_stream_t stream) {
+    return render_reg_fwd_impl(desc, stack, homos, quad_keep, QH, QW, sums, reg_state, stream);
 }
 
 static int render_reg_fwd_impl(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep, int32_t QH,
-                               int32_t QW, double *sums, vl3d_stream_t stream) {
+                               int32_t QW, double *sums, void *reg_state, vl3d_stream_t stream) {
     int rc = check_desc(desc);
     if (rc != VL3D_OK) return rc;
-    VL3D_REQUIRE(stack && homos && sums, "null pointer passed to vl3d_render_reg_fwd");
+    VL3D_REQUIRE(stack && homos && sums && reg_state, "null pointer passed to vl3d_render_reg_fwd");
+    VL3D_REQUIRE(desc->D <= 128, "the layer regularisers support at most 128 planes (coverage masks)");
     rc = check_cull(desc, quad_keep, QH, QW);
     if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE((int64_t)desc->Hs * desc->Ws * 16 < (1ll << 32), "frame too large for 32-bit byte offsets");
@@ -177,6 +205,7 @@ static int render_reg_fwd_impl(const vl3d_render_desc *desc, const void *stack, 
     a.stack = (const float *)stack; a.homos = homos; a.reg_sums = sums;
     a.quad_keep = quad_keep; a.QH = QH; a.QW = QW;
     set_cull_geometry(a, desc, QH, QW);
+    set_reg_state(a, desc, reg_state);
     VL3D_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(double), (hipStream_t)stream));
     a.reg_fwd = 1;
     a.g_f16 = desc->stack_dtype == VL3D_F16;
@@ -188,35 +217,37 @@ static int render_reg_fwd_impl(const vl3d_render_desc *desc, const void *stack, 
 
 static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep, int32_t QH,
                            int32_t QW, const float *rgb, const float *alpha, const float *grad_rgb,
-                           const float *grad_alpha, const float *grad_reg, const float *grad_alpha_sums,
+                           const float *grad_alpha, const float *grad_reg, const void *reg_state, const float *grad_alpha_sums,
                            float *grad_stack, void *scratch, int64_t scratch_bytes, vl3d_stream_t stream);
 
 extern "C" int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, const float *homos,
                                const float *rgb, const float *alpha, const float *grad_rgb,
-                               const float *grad_alpha, const float *grad_reg, const float *grad_alpha_sums,
+                               const float *grad_alpha, const float *grad_reg, const void *reg_state, const float *grad_alpha_sums,
                                float *grad_stack, void *scratch, int64_t scratch_bytes, vl3d_stream_t stream) {
-    return render_bwd_impl(desc, stack, homos, nullptr, 0, 0, rgb, alpha, grad_rgb, grad_alpha, grad_reg, grad_alpha_sums, grad_stack,
+    return render_bwd_impl(desc, stack, homos, nullptr, 0, 0, rgb, alpha, grad_rgb, grad_alpha, grad_reg, reg_state, grad_alpha_sums, grad_stack,
                            scratch, scratch_bytes, stream);
 }
 
 extern "C" int vl3d_render_bwd_culled(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep,
                                       int32_t QH, int32_t QW, const float *rgb, const float *alpha, const float *grad_rgb,
-                                      const float *grad_alpha, const float *grad_reg, const float *grad_alpha_sums,
+                                      const float *grad_alpha, const float *grad_reg, const void *reg_state, const float *grad_alpha_sums,
                                       float *grad_stack, void *scratch, int64_t scratch_bytes, vl3d_stream_t stream) {
-    return render_bwd_impl(desc, stack, homos, quad_keep, QH, QW, rgb, alpha, grad_rgb, grad_alpha, grad_reg, grad_alpha_sums,
+    return render_bwd_impl(desc, stack, homos, quad_keep, QH, QW, rgb, alpha, grad_rgb, grad_alpha, grad_reg, reg_state, grad_alpha_sums,
                            grad_stack, scratch, scratch_bytes, stream);
 }
 
 static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep, int32_t QH,
                            int32_t QW, const float *rgb, const float *alpha, const float *grad_rgb,
-                           const float *grad_alpha, const float *grad_reg, const float *grad_alpha_sums,
+                           const float *grad_alpha, const float *grad_reg, const void *reg_state, const float *grad_alpha_sums,
                            float *grad_stack, void *scratch, int64_t scratch_bytes, vl3d_stream_t stream) {
     int rc = check_desc(desc);
     if (rc != VL3D_OK) return rc;
     rc = check_cull(desc, quad_keep, QH, QW);
     if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE(stack && homos && rgb && alpha && grad_rgb && grad_stack, "null pointer passed to vl3d_render_bwd");
+    VL3D_REQUIRE(!grad_reg || reg_state, "vl3d_render_bwd: grad_reg needs the reg_state the forward with regularisers filled");
     RenderArgs a = make_args(desc);
+    if (grad_reg) set_reg_state(a, desc, reg_state);
     a.stack = (const float *)stack; a.homos = homos;
     a.rgb = const_cast<float *>(rgb); a.alpha = const_cast<float *>(alpha);
     a.g_rgb = grad_rgb; a.g_alpha = grad_alpha; a.g_reg = grad_reg; a.g_asum = grad_alpha_sums; a.g_stack = grad_stack;

@@ -68,6 +68,12 @@ struct RenderArgs {
                              // frame-pair kernels allowed
     int reg_fwd;             // forward dispatch: 1 = the regulariser-sums kernel instead of the render, 2 = render AND sums in one pass
     int pair_pipe;           // backward variant 5: the pipelined frame-pair kernel (A/B)
+    // hit-slot layer order of the smoothness regularisers (see "Layer regularisers in hit-slot order" below): the caller's reg_state
+    // buffer, written by the forward with regularisers and read by the backward
+    unsigned char *reg_flags;          // [H][W]      bit 0/1/2/3: the pair with the right / lower / left / upper neighbour is IRREGULAR
+    unsigned long long *reg_masks;     // [H][W][2]   bit d: plane d covers the pixel (frame independent)
+    unsigned short *reg_signs;         // [D][T][H][W] sign codes of (this pixel's layer value - right neighbour's) | (... - lower) << 8
+    unsigned short *reg_patch;         // [D][T][H][W] the same towards the left | upper neighbour, irregular pairs only
 };
 
 // one entry point per compiled convention (coord_mode, border_mode, act_order): vl3d_render_c*.hip
@@ -335,6 +341,181 @@ __device__ __forceinline__ f4 shade2(const Taps2 &t, const u2 v[4], f4 *pre_out 
     return s;
 }
 
+
+// =====================================================================================================
+// Layer regularisers in hit-slot order (MPV.py:386-392, 441-449, 517-531; MPI.py:553-566, 608-622; utils.py:51-69).
+// The reference's layer tensor mpi[T,h,w,K,4] is indexed by HIT SLOT: slot k of a pixel is the k-th nearest face the rasteriser hit
+// there (masked_scatter over the z-sorted pix_to_face), i.e. its k-th nearest COVERED plane, and rgb_smooth / a_smooth difference
+// neighbouring pixels per slot.  Where two neighbours are covered by the same planes that is the difference per plane; where they
+// are not (a plane's edge inside the view; every quad border of a tile-culled model) every deeper slot pairs two DIFFERENT planes.
+//   * reg_masks_k / reg_flags_k (frame independent, once per forward): per pixel the 128-bit coverage mask over the planes and four
+//     flags "the pair with my right / lower / left / upper neighbour is irregular" (the two masks differ).
+//   * the forward kernels with regularisers form the differences of REGULAR pairs plane by plane (both pixels covered by the same
+//     planes: slot k is the same plane on both sides) exactly as before, and store their signs: 2 bits per channel, two's complement
+//     (+1 = 01, -1 = 11, 0 = 00 -- equal values have gradient 0 like torch's abs), right pair in bits 0-7, lower pair in bits 8-15
+//     of one uint16 per (plane, frame, pixel).  Irregular pairs are left out there (code 0) ...
+//   * ... and taken by reg_patch_fwd_k, one thread per (pixel with an irregular pair, frame): it walks the pixel's covered planes in
+//     depth order, samples ITS k-th plane and the neighbour's k-th plane in place, adds |difference| of the pairs it owns (right,
+//     lower; plus the slots only the neighbour has) to the sums, ORs the signs of its right / lower pairs into its sign word and
+//     writes those of its left / upper pairs to the patch word of that (plane, frame, pixel).
+//   * the backward kernels never see layer values of neighbours any more: d sum / d layer value = gx (s_right + s_left) + gy (s_down
+//     + s_up), the four signs decoded from this pixel's word, the left / upper neighbours' words of the same plane (regular pairs:
+//     sign(left - me) is the left pixel's right-pair code) or this pixel's patch word (irregular pairs).  No LDS exchange, no second
+//     barrier, no 2-pixel halo: the kernels with regularisers are the plain ones plus 2-4 two-byte loads and a decode per plane.
+__device__ __forceinline__ unsigned reg_code(float diff) {     // sign as a 2-bit two's complement field
+    return (unsigned)(int)__builtin_amdgcn_fmed3f(diff * 3e38f, -1.0f, 1.0f) & 3u;
+}
+__device__ __forceinline__ unsigned reg_codes4(f4 diff) {
+    return reg_code(diff.x) | reg_code(diff.y) << 2 | reg_code(diff.z) << 4 | reg_code(diff.w) << 6;
+}
+// gradient of the four smoothness sums w.r.t. this pixel's activated layer value on one plane and frame.
+// w_own / w_left / w_up: sign words of this pixel, its left and its upper neighbour (0 where that neighbour does not exist);
+// w_patch: this pixel's patch word (read when a left / upper pair is irregular); fl: the pixel's flags
+__device__ __forceinline__ f4 reg_grad(unsigned w_own, unsigned w_left, unsigned w_up, unsigned w_patch, unsigned fl, f4 gx, f4 gy) {
+    const int o = (int)w_own, l = (fl & 4u) ? (int)w_patch : (int)w_left, u = (fl & 8u) ? (int)(w_patch >> 8) : (int)(w_up >> 8);
+    const int ls = (fl & 4u) ? 1 : -1, us = (fl & 8u) ? 1 : -1;      // a neighbour's word holds sign(neighbour - me), the patch word sign(me - neighbour)
+    f4 r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ix = __builtin_amdgcn_sbfe(o, 2 * c, 2) + ls * __builtin_amdgcn_sbfe(l, 2 * c, 2);
+        const int iy = __builtin_amdgcn_sbfe(o, 8 + 2 * c, 2) + us * __builtin_amdgcn_sbfe(u, 2 * c, 2);
+        r[c] = fmaf(gy[c], (float)iy, gx[c] * (float)ix);
+    }
+    return r;
+}
+
+template <int COORD, int BORDER>
+__global__ __launch_bounds__(256) void reg_masks_k(RenderArgs a) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.W || y >= a.H) return;
+    const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
+    unsigned long long m0 = 0ull, m1 = 0ull;
+    for (int d = 0; d < a.D; ++d) {
+        float h[VL3D_HN];
+        load_uniform(a.homos + VL3D_HS * d, h);
+        const TapsI t = make_taps_i<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
+        if (t.cov > 0.0f) { if (d < 64) m0 |= 1ull << d; else m1 |= 1ull << (d - 64); }
+    }
+    a.reg_masks[2 * ((size_t)y * a.W + x)] = m0;
+    a.reg_masks[2 * ((size_t)y * a.W + x) + 1] = m1;
+}
+
+__global__ __launch_bounds__(256) void reg_flags_k(RenderArgs a) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.W || y >= a.H) return;
+    const size_t p = (size_t)y * a.W + x;
+    const unsigned long long *M = a.reg_masks;
+    const unsigned long long m0 = M[2 * p], m1 = M[2 * p + 1];
+    auto differs = [&](size_t q) { return M[2 * q] != m0 || M[2 * q + 1] != m1; };
+    unsigned f = 0;
+    if (x + 1 < a.W && differs(p + 1)) f |= 1u;
+    if (y + 1 < a.H && differs(p + a.W)) f |= 2u;
+    if (x >= 1 && differs(p - 1)) f |= 4u;
+    if (y >= 1 && differs(p - a.W)) f |= 8u;
+    a.reg_flags[p] = (unsigned char)f;
+}
+
+// lowest set bit of a 128-bit mask, removed from it; -1 when empty
+__device__ __forceinline__ int reg_pop_plane(unsigned long long &m0, unsigned long long &m1) {
+    if (m0) { const int d = __builtin_ctzll(m0); m0 &= m0 - 1; return d; }
+    if (m1) { const int d = __builtin_ctzll(m1); m1 &= m1 - 1; return 64 + d; }
+    return -1;
+}
+
+// activated layer value of pixel (px, py) on plane d in frame t, sampled in place (plane and pixel vary per lane)
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
+__device__ __forceinline__ f4 reg_sample(const RenderArgs &a, float px, float py, int d, int t) {
+    float h[VL3D_HN];
+#pragma unroll
+    for (int i = 0; i < VL3D_HN; ++i) h[i] = a.homos[VL3D_HS * d + i];
+    const Taps2 tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
+    const char *plane = reinterpret_cast<const char *>(a.stack) + ((size_t)d * a.T + t) * ((size_t)a.Hs * a.Ws * (F16 ? 8 : 16));
+    typename TapVal<F16, ORDER>::type tv[4];
+    load_taps2<F16>(plane, tp, make_tap_step<F16>(a.Hs, a.Ws), tv);
+    return shade2<ORDER, RACT, AACT>(tp, tv) * tp.cov;
+}
+
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
+__global__ __launch_bounds__(256) void reg_patch_fwd_k(RenderArgs a) {
+    __shared__ float red[4][4];
+    const int lane = threadIdx.x & 63, row = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * 4 + row, t = blockIdx.z;
+    const bool in = x < a.W && y < a.H;
+    const size_t p = (size_t)y * a.W + x;
+    const unsigned f = in ? a.reg_flags[p] : 0u;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};      // sum |dx rgb|, |dy rgb|, |dx a|, |dy a|
+    if (f) {
+        const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
+        unsigned long long mp0 = a.reg_masks[2 * p], mp1 = a.reg_masks[2 * p + 1];
+        unsigned long long mn0[4], mn1[4];
+        const int dx[4] = {1, 0, -1, 0}, dy[4] = {0, 1, 0, -1};
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const size_t q = (size_t)((int64_t)p + dx[n] + (int64_t)dy[n] * a.W);
+            mn0[n] = ((f >> n) & 1u) ? a.reg_masks[2 * q] : 0ull;
+            mn1[n] = ((f >> n) & 1u) ? a.reg_masks[2 * q + 1] : 0ull;
+        }
+        const size_t plane_px = (size_t)a.T * a.H * a.W;
+        for (int d = reg_pop_plane(mp0, mp1); d >= 0; d = reg_pop_plane(mp0, mp1)) {      // my slots, near -> far
+            const f4 v = reg_sample<COORD, BORDER, ORDER, RACT, AACT, F16>(a, px, py, d, t);
+            unsigned wrd = 0u, wlu = 0u;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if (!((f >> n) & 1u)) continue;
+                const int dn = reg_pop_plane(mn0[n], mn1[n]);      // the neighbour's plane in the same slot (none: its slot is empty = 0)
+                f4 u = f4{0.f, 0.f, 0.f, 0.f};
+                if (dn >= 0) u = reg_sample<COORD, BORDER, ORDER, RACT, AACT, F16>(a, px + (float)dx[n], py + (float)dy[n], dn, t);
+                const f4 df = v - u;
+                const unsigned c = reg_codes4(df);
+                if (n < 2) {
+                    s[n] += fabsf(df.x) + fabsf(df.y) + fabsf(df.z);
+                    s[2 + n] += fabsf(df.w);
+                    wrd |= c << (8 * n);
+                } else {
+                    wlu |= c << (8 * (n - 2));
+                }
+            }
+            const size_t idx = (size_t)d * plane_px + ((size_t)t * a.H + y) * a.W + x;
+            if (f & 3u) a.reg_signs[idx] |= (unsigned short)wrd;      // the plane-by-plane kernel left code 0 in the irregular pairs' fields
+            if (f & 12u) a.reg_patch[idx] = (unsigned short)wlu;
+        }
+        // slots only the right / lower neighbour has: |0 - its value| belongs to the pair I own
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            for (int dn = reg_pop_plane(mn0[n], mn1[n]); dn >= 0; dn = reg_pop_plane(mn0[n], mn1[n])) {
+                const f4 u = reg_sample<COORD, BORDER, ORDER, RACT, AACT, F16>(a, px + (float)dx[n], py + (float)dy[n], dn, t);
+                s[n] += fabsf(u.x) + fabsf(u.y) + fabsf(u.z);
+                s[2 + n] += fabsf(u.w);
+            }
+    }
+    if (!__syncthreads_or(f != 0u)) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v = s[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[k][row] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int k = threadIdx.x;
+        const double sum = (double)red[k][0] + (double)red[k][1] + (double)red[k][2] + (double)red[k][3];
+        // sums order of the ABI: 0 = x pairs rgb, 1 = y pairs rgb, 2 = x pairs alpha, 3 = y pairs alpha  (s[] has the same order)
+        if (sum != 0.0) atomicAdd(a.reg_sums + k, sum);
+    }
+}
+
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
+void launch_reg_prepass(const RenderArgs &a, hipStream_t s) {
+    const dim3 g((a.W + 63) / 64, (a.H + 3) / 4);
+    hipLaunchKernelGGL((reg_masks_k<COORD, BORDER>), g, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(reg_flags_k, g, dim3(256), 0, s, a);
+}
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
+void launch_reg_patch(const RenderArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL((reg_patch_fwd_k<COORD, BORDER, ORDER, RACT, AACT, F16>), dim3((a.W + 63) / 64, (a.H + 3) / 4, a.T), dim3(256), 0, s, a);
+}
+
 constexpr int TILE_X = 64, TILE_Y = 4;
 
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
@@ -356,6 +537,7 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
     // S = sum_k w_k q_k with q_k = G.c_k + gA  ==  G.C + gA*A from the saved forward outputs
     const float S = dot3p(Gr, a.rgb[pix * 3 + 0], Gg, a.rgb[pix * 3 + 1], Gb, a.rgb[pix * 3 + 2], gA * a.alpha[pix]);
     const float gN1 = a.g_asum ? a.g_asum[pix * 2 + 0] : 0.0f, gN2 = a.g_asum ? 2.0f * a.g_asum[pix * 2 + 1] : 0.0f;
+    const unsigned fl = a.g_reg ? a.reg_flags[(size_t)y * a.W + x] : 0u;
     float Tr = 1.0f, P = 0.0f;
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws), gst = make_tap_step<false>(a.Hs, a.Ws);
     for (int d = 0; d < a.D; ++d, plane += (size_t)a.T * a.Hs * a.Ws * TEXB, gplane += (size_t)a.T * a.Hs * a.Ws * TEXB) {
@@ -373,20 +555,11 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
         const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;
         f4 go = f4{w * Gr, w * Gg, w * Gb, fmaf(Tr, q, -behind) + fmaf(gN2, o.w, gN1)};   // grad wrt activated (c, a)
         Tr *= om;
-        if (a.g_reg) {   // smoothness regularisers on the fallback path: re-sample the 4 neighbours' layer values
+        if (a.g_reg) {   // smoothness regularisers: the signs the forward stored (hit-slot order)
             const f4 gx = f4{a.g_reg[0], a.g_reg[0], a.g_reg[0], a.g_reg[2]}, gy = f4{a.g_reg[1], a.g_reg[1], a.g_reg[1], a.g_reg[3]};
-            auto layer = [&](float qx, float qy) {
-                const Taps2 tq = make_taps2<COORD, BORDER>(a.homos + VL3D_HS * d, qx, qy, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
-                typename TapVal<F16, ORDER>::type tq_v[4];
-                load_taps2<F16>(plane, tq, st, tq_v);
-                return shade2<ORDER, RACT, AACT>(tq, tq_v) * tq.cov;
-            };
-            auto sgn = [](f4 v) { return f4{(float)((v.x > 0.f) - (v.x < 0.f)), (float)((v.y > 0.f) - (v.y < 0.f)),
-                                            (float)((v.z > 0.f) - (v.z < 0.f)), (float)((v.w > 0.f) - (v.w < 0.f))}; };
-            if (x + 1 < a.W) go += gx * sgn(o - layer(px + 1.0f, py));
-            if (x >= 1) go -= gx * sgn(layer(px - 1.0f, py) - o);
-            if (y + 1 < a.H) go += gy * sgn(o - layer(px, py + 1.0f));
-            if (y >= 1) go -= gy * sgn(layer(px, py - 1.0f) - o);
+            const size_t idx = (((size_t)d * a.T + t) * a.H + y) * a.W + x;
+            const unsigned w_left = x >= 1 ? a.reg_signs[idx - 1] : 0u, w_up = y >= 1 ? a.reg_signs[idx - a.W] : 0u;
+            go += reg_grad(a.reg_signs[idx], w_left, w_up, (fl & 12u) ? a.reg_patch[idx] : 0u, fl, gx, gy);
         }
         if constexpr (ORDER == VL3D_ACT_POST)
             go = f4{go.x * act_bwd<RACT>(pre.x, o.x), go.y * act_bwd<RACT>(pre.y, o.y), go.z * act_bwd<RACT>(pre.z, o.z),
@@ -849,11 +1022,10 @@ template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool R
 __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTILS_MPI)) ? 4 : 8)) void render_bwd_tile_k(RenderArgs a) {
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
     constexpr int NT = RW * ROWS;
-    // REG: the layer-space smoothness regularisers (MPV.py:517-531) are differentiated here as well.  Their gradient at a
-    // pixel needs the activated layer values of its 4 neighbours, so the region carries a 2-pixel halo (outer ring: layer
-    // values only; inner ring: full gradient providers for the gather) and one more LDS stage + barrier per plane.
-    constexpr int RH = REG ? 2 : 1;
-    __shared__ float4 s_o[REG ? NT : 1];
+    // REG: the layer-space smoothness regularisers (MPV.py:517-531) are differentiated here as well: their gradient at a pixel is
+    // decoded from the sign words the forward stored (reg_grad) -- no neighbours' layer values, no extra halo.  The sparsity-sum
+    // gradients ride in this instantiation too (g_reg == NULL: sparsity only).
+    constexpr int RH = 1;
     // per-plane staging of the region's pixels, double buffered so one barrier per plane suffices
     __shared__ float4 s_g[2][NT];     // gradient w.r.t. the sampled (POST) / activated (PRE) value of this pixel on this plane
     __shared__ float2 s_t[2][NT];     // its texel coordinates (tx,ty) (true ones also where the plane does not cover it: then g = 0)
@@ -887,9 +1059,18 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTI
     }
     float Tr = 1.0f, P = 0.0f;
     float gsx_c = 0.f, gsy_c = 0.f, gsx_a = 0.f, gsy_a = 0.f;
-    if constexpr (REG) { gsx_c = a.g_reg[0]; gsy_c = a.g_reg[1]; gsx_a = a.g_reg[2]; gsy_a = a.g_reg[3]; }
-    // pixels of the outermost ring only provide layer values in REG mode
-    const bool provider = !REG || (lane >= 1 && lane <= RW - 2 && row >= 1 && row <= ROWS - 2);
+    unsigned fl = 0u;
+    const unsigned short *sgp = nullptr;      // this pixel's sign word of plane 0 (clamped into the frame: the loads are unconditional)
+    const bool has_l = inimg && x >= 1, has_u = inimg && y >= 1;
+    const bool reg_on = REG && a.g_reg != nullptr;
+    if constexpr (REG) if (reg_on) {
+        gsx_c = a.g_reg[0]; gsy_c = a.g_reg[1]; gsx_a = a.g_reg[2]; gsy_a = a.g_reg[3];
+        const int xc = min(max(x, 0), a.W - 1), yc = min(max(y, 0), a.H - 1);
+        sgp = a.reg_signs + ((size_t)t * a.H + yc) * a.W + xc;
+        if (inimg) fl = a.reg_flags[(size_t)y * a.W + x];
+    }
+    const size_t sg_plane = (size_t)a.T * a.H * a.W;
+    constexpr bool provider = true;
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
     // this tile's texel windows, one int4 per plane (bwd_windows_k)
     const unsigned my_tile_id = (unsigned)(tile_y * a.tiles_x + tile_x);
@@ -946,21 +1127,11 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTI
             o = shade2<ORDER, RACT, AACT>(tp, tv, &pre);                 // o.w already 0 when the plane does not cover the pixel
         }
         f4 sg = f4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (REG) {
-            // layer value as the reference's zero canvas has it: 0 in ALL channels where the plane does not cover (MPV.py:441)
-            const f4 ol = o * tp.cov;
-            s_o[tid] = make_float4(ol.x, ol.y, ol.z, ol.w);
-            __syncthreads();      // (A) layer values of the region visible
-            if (inimg && provider) {
-                const f4 gx = f4{gsx_c, gsx_c, gsx_c, gsx_a}, gy = f4{gsy_c, gsy_c, gsy_c, gsy_a};
-                auto sgn = [](f4 v) { return f4{(float)((v.x > 0.f) - (v.x < 0.f)), (float)((v.y > 0.f) - (v.y < 0.f)),
-                                                (float)((v.z > 0.f) - (v.z < 0.f)), (float)((v.w > 0.f) - (v.w < 0.f))}; };
-                auto ld = [&](int i) { const float4 v = s_o[i]; return f4{v.x, v.y, v.z, v.w}; };
-                if (x + 1 < a.W) sg += gx * sgn(ol - ld(tid + 1));          // d|o - o_right| / do
-                if (x >= 1) sg -= gx * sgn(ld(tid - 1) - ol);               // d|o_left - o| / do
-                if (y + 1 < a.H) sg += gy * sgn(ol - ld(tid + RW));
-                if (y >= 1) sg -= gy * sgn(ld(tid - RW) - ol);
-            }
+        if constexpr (REG) if (reg_on) {      // uniform
+            const unsigned short *w = sgp + (size_t)d * sg_plane;
+            const unsigned w_own = w[0], w_l = w[has_l ? -1 : 0], w_u = w[has_u ? -(ptrdiff_t)a.W : 0];
+            const unsigned w_p = (fl & 12u) ? a.reg_patch[(w - a.reg_signs)] : 0u;
+            sg = reg_grad(w_own, has_l ? w_l : 0u, has_u ? w_u : 0u, w_p, fl, f4{gsx_c, gsx_c, gsx_c, gsx_a}, f4{gsy_c, gsy_c, gsy_c, gsy_a});
         }
         if (inimg) {
             const float q = dot3p(Gr, o.x, Gg, o.y, Gb, o.z, gA);
@@ -1152,7 +1323,12 @@ __device__ __forceinline__ void pair_gather_plane(const RenderArgs &a, const flo
                              gv.z * act_bwd<RACT>(pre.z, o.z), gv.w * act_bwd<AACT>(pre.w, o.w));                              \
     }
 
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
+// REG: with the layer regularisers (MPV.py:511-531: rgb_smooth / a_smooth / sparsity -- what a shipped stage-2 iteration runs,
+// configs/mpv_base.txt:33-34): the smoothness gradient is decoded from the sign words the forward stored (reg_grad), the
+// sparsity-sum gradient is gN1 + gN2 a_k.  Until round 3 this was a kernel of its own (render_bwd_pair_reg_k: 2-pixel halo, the
+// neighbours' layer values through a second LDS stage, sampling pipelined one plane ahead, 128 VGPRs, 18.2 ms at cfg3 against 12.0
+// without the regularisers -- VALU bound on re-deriving signs the forward had already formed).
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool REG = false>
 __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {      // >= 4 waves per SIMD (2 workgroups per CU): <= 128 VGPRs
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
     __shared__ float4 s_g[2][2][PNT];   // [buffer][frame][pixel]
@@ -1183,6 +1359,28 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
         gA1 = a.g_alpha ? a.g_alpha[pix] : 0.0f;
         S1 = dot3p(Gr1, a.rgb[pix * 3 + 0], Gg1, a.rgb[pix * 3 + 1], Gb1, a.rgb[pix * 3 + 2], gA1 * a.alpha[pix]);
     }
+    // layer regularisers: sparsity-sum gradients gN1 + gN2 a_k, smoothness coefficients, this pixel's flags and sign words
+    float gN10 = 0.f, gN20 = 0.f, gN11 = 0.f, gN21 = 0.f;
+    f4 gx = f4{0.f, 0.f, 0.f, 0.f}, gy = gx;
+    unsigned fl = 0u;
+    const unsigned short *sgp = nullptr;
+    const bool has_l = inimg && x >= 1, has_u = inimg && y >= 1;
+    const bool reg_on = REG && a.g_reg != nullptr;
+    const size_t sg_plane = (size_t)a.T * a.H * a.W, sg_f1 = has1 ? (size_t)a.H * a.W : 0;
+    if constexpr (REG) {
+        if (inimg && a.g_asum) {
+            size_t pix = ((size_t)t0 * a.H + y) * a.W + x;
+            gN10 = a.g_asum[pix * 2 + 0]; gN20 = 2.0f * a.g_asum[pix * 2 + 1];
+            pix += sg_f1;
+            gN11 = a.g_asum[pix * 2 + 0]; gN21 = 2.0f * a.g_asum[pix * 2 + 1];
+        }
+        if (reg_on) {
+            gx = f4{a.g_reg[0], a.g_reg[0], a.g_reg[0], a.g_reg[2]}; gy = f4{a.g_reg[1], a.g_reg[1], a.g_reg[1], a.g_reg[3]};
+            const int xc = min(max(x, 0), a.W - 1), yc = min(max(y, 0), a.H - 1);
+            sgp = a.reg_signs + ((size_t)t0 * a.H + yc) * a.W + xc;      // clamped into the frame: the loads below are unconditional
+            if (inimg) fl = a.reg_flags[(size_t)y * a.W + x];
+        }
+    }
     float Tr0 = 1.0f, P0 = 0.0f, Tr1 = 1.0f, P1 = 0.0f;
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
     const unsigned my_tile_id = (unsigned)(tile_y * a.tiles_x + tile_x);
@@ -1190,7 +1388,6 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
     const unsigned toff_thread = (unsigned)(row * a.Ws + col);
     const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)my_tile_id * a.D * 4;
     typedef typename TapVal<F16, ORDER>::type tapv_t;
-    const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
     for (int d = 0; d < a.D; ++d, plane0 += plane_stride_b, gplane0 += plane_stride_b) {
         float h[VL3D_HN];
         load_uniform(a.homos + VL3D_HS * d, h);
@@ -1200,6 +1397,14 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
         const int buf = d & 1;
         const unsigned short *oplane = a.owner + (size_t)d * a.Hs * a.Ws;
         const unsigned e0 = oplane[(unsigned)(Y0 * a.Ws + X0) + toff_thread];     // unconditional (padded table), arrives in the shadow of the sweep
+        // sign words of this plane (own, left, upper; two frames): requested with the taps
+        unsigned wo0 = 0u, wl0 = 0u, wu0 = 0u, wo1 = 0u, wl1 = 0u, wu1 = 0u;
+        if constexpr (REG) if (reg_on) {      // uniform
+            const unsigned short *w = sgp + (size_t)d * sg_plane;
+            const ptrdiff_t ol = has_l ? -1 : 0, ou = has_u ? -(ptrdiff_t)a.W : 0;
+            wo0 = w[0]; wl0 = w[ol]; wu0 = w[ou];
+            wo1 = w[sg_f1]; wl1 = w[sg_f1 + ol]; wu1 = w[sg_f1 + ou];
+        }
         // (2) sweep: one set of taps, two frames
         float2 tc = make_float2(0.f, 0.f);
         float4 gv0 = make_float4(0.f, 0.f, 0.f, 0.f), gv1 = gv0;
@@ -1211,8 +1416,22 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
             f4 pre0, pre1;
             const f4 o0 = shade2<ORDER, RACT, AACT>(tp, tv0, &pre0);
             const f4 o1 = shade2<ORDER, RACT, AACT>(tp, tv1, &pre1);
-            VL3D_PAIR_GRAD(o0, pre0, Gr0, Gg0, Gb0, gA0, S0, P0, Tr0, gv0, zero4)
-            VL3D_PAIR_GRAD(o1, pre1, Gr1, Gg1, Gb1, gA1, S1, P1, Tr1, gv1, zero4)
+            f4 ex0 = f4{0.f, 0.f, 0.f, 0.f}, ex1 = ex0;
+            if constexpr (REG) {
+                if (reg_on) {
+                    unsigned wp0 = 0u, wp1 = 0u;
+                    if (fl & 12u) {
+                        const size_t pi = (size_t)(sgp - a.reg_signs) + (size_t)d * sg_plane;
+                        wp0 = a.reg_patch[pi]; wp1 = a.reg_patch[pi + sg_f1];
+                    }
+                    ex0 = reg_grad(wo0, has_l ? wl0 : 0u, has_u ? wu0 : 0u, wp0, fl, gx, gy);
+                    ex1 = reg_grad(wo1, has_l ? wl1 : 0u, has_u ? wu1 : 0u, wp1, fl, gx, gy);
+                }
+                ex0.w += fmaf(gN20, o0.w, gN10);
+                ex1.w += fmaf(gN21, o1.w, gN11);
+            }
+            VL3D_PAIR_GRAD(o0, pre0, Gr0, Gg0, Gb0, gA0, S0, P0, Tr0, gv0, ex0)
+            VL3D_PAIR_GRAD(o1, pre1, Gr1, Gg1, Gb1, gA1, S1, P1, Tr1, gv1, ex1)
             tc = make_float2(tp.tx, tp.ty);
             if (!(tp.cov > 0.0f)) { gv0 = make_float4(0.f, 0.f, 0.f, 0.f); gv1 = gv0; }
         }
@@ -1325,167 +1544,11 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_pipe_k(RenderArgs a) {
     }
 }
 
-// Frame pairs WITH the layer regularisers (MPV.py:511-531: rgb_smooth / a_smooth / sparsity -- what a shipped stage-2 iteration
-// runs, configs/mpv_base.txt:33-34).  The smoothness gradient at a pixel needs the activated layer values of its 4 neighbours, so
-// the region carries a 2-pixel halo (28 x 12 owned of 32 x 16; outer ring: layer values only, inner ring: gradient providers for
-// the gather) and the values go through LDS before the gradient can be formed: two dependent exchanges per plane (layer values ->
-// gradients -> gather).  The one-frame REG instantiation of render_bwd_tile_k pays them as two barriers per plane on ONE resident
-// workgroup per CU (1024 threads at > 64 VGPRs): 26.9 ms at cfg3 against 12 ms without the regularisers.  Here the sampling is
-// software-pipelined one plane ahead: iteration d forms the gradients of plane d (layer values staged by iteration d-1) and
-// samples plane d+1 in the same phase -- its tap loads are issued first and land while the gradient arithmetic of plane d runs --
-// so ONE barrier per plane separates [gradients of d, layer values of d+1] from [gather of d].  What crosses the barrier in
-// registers is the shaded sample of the next plane (2 x 8 + 3 values), not its 32 tap registers.  72 KiB of LDS, 2 workgroups per CU.
-// Per frame the arithmetic is that of render_bwd_tile_k<REG> in the same order.
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
-__global__ __launch_bounds__(PNT, 4) void render_bwd_pair_reg_k(RenderArgs a) {
-    if (!reinterpret_cast<const int *>(a.plan)[0]) return;
-    constexpr int RH = 2;
-    // the derivative of every activation but |.| is a function of the activated value alone (sigmoid: o(1-o); relu / clamp: o > 0,
-    // 0 < o < 1 say the same as v > 0, 0 < v < 1), so the pre-activation samples need not cross the barrier: 8 VGPRs, which is what
-    // stands between this kernel and its 128-register budget
-    constexpr bool NEED_PRE = RACT == VL3D_ACT_ABS || AACT == VL3D_ACT_ABS;
-    __shared__ float4 s_o[2][2][PNT];   // [buffer][frame][pixel]: activated layer values, 0 in ALL channels where the plane does not cover (MPV.py:441)
-    __shared__ float4 s_g[2][2][PNT];
-    __shared__ float2 s_t[2][PNT];
-    const int tid = threadIdx.x, col = tid & (PW - 1), row = tid >> 5;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_x = bid % a.tiles_x, rest = bid / a.tiles_x;
-    const int tile_y = rest % a.tiles_y, t0 = (rest / a.tiles_y) * 2;
-    const bool has1 = t0 + 1 < a.T;
-    const int rx0 = tile_x * (PW - 2 * RH) - RH, ry0 = tile_y * (PROWS - 2 * RH) - RH;
-    const int x = rx0 + col, y = ry0 + row;
-    const bool inimg = (x >= 0) && (x < a.W) && (y >= 0) && (y < a.H);
-    const bool provider = col >= 1 && col <= PW - 2 && row >= 1 && row <= PROWS - 2;     // the outermost ring only provides layer values
-    const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
-    constexpr size_t TEXB = F16 ? 8 : 16;
-    const size_t frame_b = (size_t)a.Hs * a.Ws * TEXB;
-    const size_t plane_stride_b = (size_t)a.T * frame_b;
-    const char *plane0 = reinterpret_cast<const char *>(a.stack) + (size_t)t0 * frame_b;
-    char *gplane0 = reinterpret_cast<char *>(a.g_stack) + (size_t)t0 * frame_b;
-    const size_t f1 = has1 ? frame_b : 0;
-    float Gr0 = 0.f, Gg0 = 0.f, Gb0 = 0.f, gA0 = 0.f, S0 = 0.f, Gr1 = 0.f, Gg1 = 0.f, Gb1 = 0.f, gA1 = 0.f, S1 = 0.f;
-    float gN10 = 0.f, gN20 = 0.f, gN11 = 0.f, gN21 = 0.f;      // gN1 + gN2 * a_k = d(sparsity sums) / d a_k
-    if (inimg) {
-        size_t pix = ((size_t)t0 * a.H + y) * a.W + x;
-        Gr0 = a.g_rgb[pix * 3 + 0]; Gg0 = a.g_rgb[pix * 3 + 1]; Gb0 = a.g_rgb[pix * 3 + 2];
-        gA0 = a.g_alpha ? a.g_alpha[pix] : 0.0f;
-        S0 = dot3p(Gr0, a.rgb[pix * 3 + 0], Gg0, a.rgb[pix * 3 + 1], Gb0, a.rgb[pix * 3 + 2], gA0 * a.alpha[pix]);
-        if (a.g_asum) { gN10 = a.g_asum[pix * 2 + 0]; gN20 = 2.0f * a.g_asum[pix * 2 + 1]; }
-        if (has1) pix += (size_t)a.H * a.W;
-        Gr1 = a.g_rgb[pix * 3 + 0]; Gg1 = a.g_rgb[pix * 3 + 1]; Gb1 = a.g_rgb[pix * 3 + 2];
-        gA1 = a.g_alpha ? a.g_alpha[pix] : 0.0f;
-        S1 = dot3p(Gr1, a.rgb[pix * 3 + 0], Gg1, a.rgb[pix * 3 + 1], Gb1, a.rgb[pix * 3 + 2], gA1 * a.alpha[pix]);
-        if (a.g_asum) { gN11 = a.g_asum[pix * 2 + 0]; gN21 = 2.0f * a.g_asum[pix * 2 + 1]; }
-    }
-    const float gsx_c = a.g_reg[0], gsy_c = a.g_reg[1], gsx_a = a.g_reg[2], gsy_a = a.g_reg[3];
-    const f4 gx = f4{gsx_c, gsx_c, gsx_c, gsx_a}, gy = f4{gsy_c, gsy_c, gsy_c, gsy_a};
-    float Tr0 = 1.0f, P0 = 0.0f, Tr1 = 1.0f, P1 = 0.0f;
-    const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
-    const unsigned my_tile_id = (unsigned)(tile_y * a.tiles_x + tile_x);
-    const unsigned my_tile = (unsigned)((tile_y & 15) << 3 | (tile_x & 7));
-    const unsigned toff_thread = (unsigned)(row * a.Ws + col);
-    const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)my_tile_id * a.D * 4;
-    typedef typename TapVal<F16, ORDER>::type tapv_t;
-    // which of its four neighbour pairs this pixel differentiates (0: the pair does not exist -- frame border, or this pixel only
-    // provides layer values); LDS reads of a non-provider stay inside the arrays (clamped index), their result is multiplied by 0
-    const bool prov = inimg && provider;
-    const float m_r = (prov && x + 1 < a.W) ? 3e38f : 0.0f, m_l = (prov && x >= 1) ? 3e38f : 0.0f;
-    const float m_d = (prov && y + 1 < a.H) ? 3e38f : 0.0f, m_u = (prov && y >= 1) ? 3e38f : 0.0f;
-    const int i_r = min(tid + 1, PNT - 1), i_l = max(tid - 1, 0), i_d = min(tid + PW, PNT - 1), i_u = max(tid - PW, 0);
-    // prologue: sample plane 0 and publish its layer values
-    f4 o0 = f4{0.f, 0.f, 0.f, 0.f}, o1 = o0, pre0 = o0, pre1 = o0;
-    float ctx = 0.f, cty = 0.f, ccov = 0.f;
-    if (inimg) {
-        float h[VL3D_HN];
-        load_uniform(a.homos, h);
-        const Taps2 tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-        tapv_t tv0[4], tv1[4];
-        load_taps2<F16>(plane0, tp, st, tv0);
-        load_taps2<F16>(plane0 + f1, tp, st, tv1);
-        o0 = shade2<ORDER, RACT, AACT>(tp, tv0, &pre0);
-        o1 = shade2<ORDER, RACT, AACT>(tp, tv1, &pre1);
-        if constexpr (!NEED_PRE) { pre0 = o0; pre1 = o1; }
-        ctx = tp.tx; cty = tp.ty; ccov = tp.cov;
-    }
-    {
-        const f4 l0 = o0 * ccov, l1 = o1 * ccov;
-        s_o[0][0][tid] = make_float4(l0.x, l0.y, l0.z, l0.w);
-        s_o[0][1][tid] = make_float4(l1.x, l1.y, l1.z, l1.w);
-    }
-    __syncthreads();
-    for (int d = 0; d < a.D; ++d, plane0 += plane_stride_b, gplane0 += plane_stride_b) {
-        const int X0 = wrec[4 * d], Y0 = wrec[4 * d + 1], wwh = wrec[4 * d + 2];
-        const int ww = wwh & 0xffff, wh = (wwh >> 16) & 0x3fff;
-        const bool apart = (wwh & 0x40000000) != 0;
-        const int buf = d & 1;
-        const unsigned short *oplane = a.owner + (size_t)d * a.Hs * a.Ws;
-        const unsigned e0 = oplane[(unsigned)(Y0 * a.Ws + X0) + toff_thread];
-        // (1) taps of plane d+1: issued first, they land while the gradients of plane d are formed (past the last plane the last one is
-        //     sampled again and dropped: no branch around the loads)
-        const int dn = min(d + 1, a.D - 1);
-        Taps2 tpn{};
-        tapv_t tn0[4], tn1[4];
-        if (inimg) {
-            float h[VL3D_HN];
-            load_uniform(a.homos + VL3D_HS * dn, h);
-            tpn = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-            const char *pn = plane0 + (size_t)(dn - d) * plane_stride_b;
-            load_taps2<F16>(pn, tpn, st, tn0);
-            load_taps2<F16>(pn + f1, tpn, st, tn1);
-            asm volatile("" ::: "memory");     // keep the loads here
-        }
-        // (2) gradients of plane d: smoothness terms from the neighbours' layer values, then the composite backward
-        float2 tc = make_float2(0.f, 0.f);
-        float4 gv0 = make_float4(0.f, 0.f, 0.f, 0.f), gv1 = gv0;
-        if (inimg) {
-            f4 sg0 = f4{0.f, 0.f, 0.f, 0.f}, sg1 = sg0;
-            {
-                // d|o - o_nb| / do = sgn(o - o_nb), as ONE clamp: med3(diff * m, -1, 1) with m = 3e38 where the pair exists (inside the
-                // frame, gradient provider) and 0 where it does not -- +-inf clamps to +-1, an exact zero difference (two uncovered
-                // pixels) stays 0.  4 instructions per channel and neighbour where (v > 0) - (v < 0) takes 7: the smoothness terms were
-                // half of this kernel's instruction stream (SQ_INSTS_VALU 8.6e9 against 3.4e9 without them, VALU active 94 %).
-                const f4 l0 = o0 * ccov, l1 = o1 * ccov;
-                auto ld = [&](int f, int i) { const float4 v = s_o[buf][f][i]; return f4{v.x, v.y, v.z, v.w}; };
-                auto sg = [](f4 v, float m) { return f4{__builtin_amdgcn_fmed3f(v.x * m, -1.0f, 1.0f), __builtin_amdgcn_fmed3f(v.y * m, -1.0f, 1.0f),
-                                                       __builtin_amdgcn_fmed3f(v.z * m, -1.0f, 1.0f), __builtin_amdgcn_fmed3f(v.w * m, -1.0f, 1.0f)}; };
-                sg0 += gx * sg(l0 - ld(0, i_r), m_r); sg1 += gx * sg(l1 - ld(1, i_r), m_r);          // d|o - o_right| / do
-                sg0 -= gx * sg(ld(0, i_l) - l0, m_l); sg1 -= gx * sg(ld(1, i_l) - l1, m_l);          // d|o_left - o| / do
-                sg0 += gy * sg(l0 - ld(0, i_d), m_d); sg1 += gy * sg(l1 - ld(1, i_d), m_d);
-                sg0 -= gy * sg(ld(0, i_u) - l0, m_u); sg1 -= gy * sg(ld(1, i_u) - l1, m_u);
-            }
-            sg0.w += fmaf(gN20, o0.w, gN10);
-            sg1.w += fmaf(gN21, o1.w, gN11);
-            VL3D_PAIR_GRAD(o0, pre0, Gr0, Gg0, Gb0, gA0, S0, P0, Tr0, gv0, sg0)
-            VL3D_PAIR_GRAD(o1, pre1, Gr1, Gg1, Gb1, gA1, S1, P1, Tr1, gv1, sg1)
-            tc = make_float2(ctx, cty);
-            if (!(ccov > 0.0f && provider)) { gv0 = make_float4(0.f, 0.f, 0.f, 0.f); gv1 = gv0; }
-        }
-        s_t[buf][tid] = tc;
-        s_g[buf][0][tid] = gv0;
-        s_g[buf][1][tid] = gv1;
-        // (3) shade plane d+1 and publish its layer values (the other s_o buffer: its readers finished before the previous barrier)
-        if (inimg) {
-            o0 = shade2<ORDER, RACT, AACT>(tpn, tn0, &pre0);
-            o1 = shade2<ORDER, RACT, AACT>(tpn, tn1, &pre1);
-            if constexpr (!NEED_PRE) { pre0 = o0; pre1 = o1; }
-            ctx = tpn.tx; cty = tpn.ty; ccov = tpn.cov;
-        }
-        {
-            const f4 l0 = o0 * ccov, l1 = o1 * ccov;
-            s_o[buf ^ 1][0][tid] = make_float4(l0.x, l0.y, l0.z, l0.w);
-            s_o[buf ^ 1][1][tid] = make_float4(l1.x, l1.y, l1.z, l1.w);
-        }
-        __syncthreads();
-        // (4) gather of plane d
-        pair_gather_plane<ORDER, RACT, AACT, F16>(a, s_g[buf][0], s_g[buf][1], s_t[buf], X0, Y0, ww, wh, apart, my_tile, e0, oplane, plane0, gplane0,
-                                                  f1, frame_b, has1, col, row);
-    }
-}
 #undef VL3D_PAIR_GRAD
 
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool REG = false, bool PIPE = false>
 void launch_pair(const RenderArgs &a, hipStream_t s) {
-    constexpr int RH = REG ? 2 : 1, IW = PW - 2 * RH, IH = PROWS - 2 * RH;
+    constexpr int RH = 1, IW = PW - 2 * RH, IH = PROWS - 2 * RH;
     RenderArgs b = a;
     b.tiles_x = (a.W + IW - 1) / IW; b.tiles_y = (a.H + IH - 1) / IH;
     const int nwin = b.tiles_x * b.tiles_y * a.D;
@@ -1494,7 +1557,7 @@ void launch_pair(const RenderArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(bwd_owner_table_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x,
                        const_cast<unsigned short *>(a.owner), PW, 9);
     if constexpr (REG)
-        hipLaunchKernelGGL((render_bwd_pair_reg_k<COORD, BORDER, ORDER, RACT, AACT, F16>),
+        hipLaunchKernelGGL((render_bwd_pair_k<COORD, BORDER, ORDER, RACT, AACT, F16, true>),
                            dim3((unsigned)(b.tiles_x * b.tiles_y * ((a.T + 1) / 2))), dim3(PNT), 0, s, b);
     else if constexpr (PIPE)
         hipLaunchKernelGGL((render_bwd_pair_pipe_k<COORD, BORDER, ORDER, RACT, AACT, F16>),
@@ -1520,10 +1583,14 @@ __global__ __launch_bounds__(RW *ROWS) void render_reg_fwd_k(RenderArgs a) {
     const bool inimg = (x < a.W) && (y < a.H);
     // the last column / row of the region are halo (owned by the next tile, where they are column / row 0)
     const bool owner = inimg && lane < RW - 1 && row < ROWS - 1;
-    const bool own_r = owner && x + 1 < a.W, own_d = owner && y + 1 < a.H;
+    // pairs whose two pixels are covered by different planes are not formed here (reg_patch_fwd_k takes them, slot by slot)
+    const unsigned fl = owner ? a.reg_flags[(size_t)y * a.W + x] : 0u;
+    const bool own_r = owner && x + 1 < a.W && !(fl & 1u), own_d = owner && y + 1 < a.H && !(fl & 2u);
     const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
     const size_t frame_b = (size_t)a.Hs * a.Ws * (F16 ? 8 : 16), plane_stride_b = (size_t)a.T * frame_b;
     const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * frame_b;
+    const size_t sg_plane = (size_t)a.T * a.H * a.W;
+    unsigned short *sgp = a.reg_signs + ((size_t)t * a.H + min(y, a.H - 1)) * a.W + min(x, a.W - 1);
     float sxc = 0.f, syc = 0.f, sxa = 0.f, sya = 0.f;
     // tile culling: the workgroup builds its own plane mask (thread d projects the region's corners onto plane d and tests the
     // touched quads) and walks only the set bits; a skipped plane has layer value 0 everywhere in the region, i.e. adds nothing
@@ -1547,8 +1614,8 @@ __global__ __launch_bounds__(RW *ROWS) void render_reg_fwd_k(RenderArgs a) {
         __syncthreads();
     }
     int nact = 0;
-    for (int d = 0; d < a.D; ++d, plane += plane_stride_b) {
-        if (a.quad_keep && !((s_mask[d >> 6] >> (d & 63)) & 1ull)) continue;      // uniform
+    for (int d = 0; d < a.D; ++d, plane += plane_stride_b, sgp += sg_plane) {
+        if (a.quad_keep && !((s_mask[d >> 6] >> (d & 63)) & 1ull)) continue;      // uniform (no pixel of the region is covered: its sign words are never read)
         f4 ol = f4{0.f, 0.f, 0.f, 0.f};
         if (inimg) {
             const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + VL3D_HS * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
@@ -1559,16 +1626,22 @@ __global__ __launch_bounds__(RW *ROWS) void render_reg_fwd_k(RenderArgs a) {
         const int buf = (nact++) & 1;        // alternates over the planes actually walked (a skipped plane has no barrier)
         s_o[buf][tid] = make_float4(ol.x, ol.y, ol.z, ol.w);
         __syncthreads();
+        unsigned code = 0u;
         if (own_r) {
             const float4 r = s_o[buf][tid + 1];
-            sxc += fabsf(ol.x - r.x) + fabsf(ol.y - r.y) + fabsf(ol.z - r.z);
-            sxa += fabsf(ol.w - r.w);
+            const f4 df = ol - f4{r.x, r.y, r.z, r.w};
+            sxc += fabsf(df.x) + fabsf(df.y) + fabsf(df.z);
+            sxa += fabsf(df.w);
+            code = reg_codes4(df);
         }
         if (own_d) {
             const float4 r = s_o[buf][tid + RW];
-            syc += fabsf(ol.x - r.x) + fabsf(ol.y - r.y) + fabsf(ol.z - r.z);
-            sya += fabsf(ol.w - r.w);
+            const f4 df = ol - f4{r.x, r.y, r.z, r.w};
+            syc += fabsf(df.x) + fabsf(df.y) + fabsf(df.z);
+            sya += fabsf(df.w);
+            code |= reg_codes4(df) << 8;
         }
+        if (owner) *sgp = (unsigned short)code;
     }
     float v[4] = {sxc, syc, sxa, sya};
 #pragma unroll
@@ -1604,7 +1677,11 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
     const int x = tile_x * (FW - 1) + lane, y = tile_y * (FH - 1) + row;
     const bool inimg = (x < a.W) && (y < a.H);
     const bool owner = inimg && lane < FW - 1 && row < FH - 1;        // the last column / row are owned by the next tile (its column / row 0)
-    const bool own_r = owner && x + 1 < a.W, own_d = owner && y + 1 < a.H;
+    // pairs whose two pixels are covered by different planes are not formed here (reg_patch_fwd_k takes them, slot by slot)
+    const unsigned fl = owner ? a.reg_flags[(size_t)y * a.W + x] : 0u;
+    const bool own_r = owner && x + 1 < a.W && !(fl & 1u), own_d = owner && y + 1 < a.H && !(fl & 2u);
+    const size_t sg_plane = (size_t)a.T * a.H * a.W;
+    unsigned short *const sg0 = a.reg_signs + ((size_t)t * a.H + min(y, a.H - 1)) * a.W + min(x, a.W - 1);
     // pixels outside the frame sample the frame's last pixel (valid addresses, results dropped): no branch around the loads
     const float px = (float)(a.col0 + min(x, a.W - 1)) + a.pc, py = (float)(a.row0 + min(y, a.H - 1)) + a.pc;
     const size_t frame_b = (size_t)a.Hs * a.Ws * (F16 ? 8 : 16), plane_stride_b = (size_t)a.T * frame_b;
@@ -1614,7 +1691,7 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
     typedef typename TapVal<F16, ORDER>::type tapv_t;
     tapv_t vA[4], vB[4];
-#define VL3D_PLANE(T_, V_, BUF_)                                                                          \
+#define VL3D_PLANE(T_, V_, BUF_, D_)                                                                      \
     {                                                                                                     \
         const f4 o = shade2<ORDER, RACT, AACT>(T_, V_);                                                   \
         const f4 ol = inimg ? o * T_.cov : f4{0.f, 0.f, 0.f, 0.f};                                        \
@@ -1624,16 +1701,22 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
         n1 += o.w; n2 = fmaf(o.w, o.w, n2);                                                               \
         Tr *= (1.0f - o.w);                                                                               \
         __syncthreads();                                                                                  \
+        unsigned code = 0u;                                                                               \
         if (own_r) {                                                                                      \
             const float4 r = s_o[BUF_][tid + 1];                                                          \
-            sxc += fabsf(ol.x - r.x) + fabsf(ol.y - r.y) + fabsf(ol.z - r.z);                             \
-            sxa += fabsf(ol.w - r.w);                                                                     \
+            const f4 df = ol - f4{r.x, r.y, r.z, r.w};                                                    \
+            sxc += fabsf(df.x) + fabsf(df.y) + fabsf(df.z);                                               \
+            sxa += fabsf(df.w);                                                                           \
+            code = reg_codes4(df);                                                                        \
         }                                                                                                 \
         if (own_d) {                                                                                      \
             const float4 r = s_o[BUF_][tid + FW];                                                         \
-            syc += fabsf(ol.x - r.x) + fabsf(ol.y - r.y) + fabsf(ol.z - r.z);                             \
-            sya += fabsf(ol.w - r.w);                                                                     \
+            const f4 df = ol - f4{r.x, r.y, r.z, r.w};                                                    \
+            syc += fabsf(df.x) + fabsf(df.y) + fabsf(df.z);                                               \
+            sya += fabsf(df.w);                                                                           \
+            code |= reg_codes4(df) << 8;                                                                  \
         }                                                                                                 \
+        if (owner) sg0[(size_t)(D_) * sg_plane] = (unsigned short)code;                                   \
     }
     Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy), tB = tA;
     load_taps2<F16>(plane, tA, st, vA);
@@ -1646,7 +1729,7 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
             load_taps2<F16>(plane + (size_t)dn * plane_stride_b, tB, st, vB);
             asm volatile("" ::: "memory");
         }
-        VL3D_PLANE(tA, vA, 0)
+        VL3D_PLANE(tA, vA, 0, d)
         if (d + 1 >= a.D) break;
         {
             const int dn = min(d + 2, a.D - 1);
@@ -1656,7 +1739,7 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
             load_taps2<F16>(plane + (size_t)dn * plane_stride_b, tA, st, vA);
             asm volatile("" ::: "memory");
         }
-        VL3D_PLANE(tB, vB, 1)
+        VL3D_PLANE(tB, vB, 1, d + 1)
         if (d + 2 >= a.D) break;
     }
 #undef VL3D_PLANE
@@ -1684,7 +1767,7 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
 // ---- launch templates ---------------------------------------------------------------------------------------------
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16 = false>
 void launch_tile(const RenderArgs &a, hipStream_t s) {
-    constexpr int RH = REG ? 2 : 1, IW = RW - 2 * RH, IH = ROWS - 2 * RH;
+    constexpr int RH = 1, IW = RW - 2 * RH, IH = ROWS - 2 * RH;
     RenderArgs b = a;
     b.tiles_x = (a.W + IW - 1) / IW; b.tiles_y = (a.H + IH - 1) / IH;
     const int nwin = b.tiles_x * b.tiles_y * a.D;
@@ -1728,18 +1811,14 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
                 // resident workgroups against two barriers on one); sample-then-activate conventions only (activate-then-sample keeps
                 // 8 activated taps per frame live and would spill at the 128-VGPR budget, as do the 13-float plane records of the per-plane
                 // convention: the tile kernel stays in charge there)
-                if (!done && ORDER == VL3D_ACT_POST && VL3D_HN == 9 && a.tile_rows == 17 && a.T >= 2 && (a.g_reg || a.g_asum) && !a.quad_keep) {
-                    RenderArgs ar = a;
-                    if (!ar.g_reg) ar.g_reg = a.plan + 4;      // zeros written by bwd_plan_k
-                    if constexpr (ORDER == VL3D_ACT_POST && VL3D_HN == 9) launch_pair<COORD, BORDER, ORDER, RACT, AACT, F16, true>(ar, s);
+                if (!done && a.tile_rows == 17 && a.T >= 2 && (a.g_reg || a.g_asum) && !a.quad_keep) {
+                    launch_pair<COORD, BORDER, ORDER, RACT, AACT, F16, true>(a, s);
                     done = true;
                 }
             }
             if (!done) {
                 if (a.g_reg || a.g_asum) {     // layer regularisers and / or sparsity sums: the REG instantiation (128-VGPR budget)
-                    RenderArgs ar = a;
-                    if (!ar.g_reg) ar.g_reg = a.plan + 4;      // zeros written by bwd_plan_k
-                    launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, F16>(ar, s);
+                    launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, F16>(a, s);
                 } else {
                     launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, false, F16>(a, s);
                 }
@@ -1747,14 +1826,20 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
         }
         hipLaunchKernelGGL((render_bwd_k<COORD, BORDER, ORDER, RACT, AACT, F16>), grid, block, 0, s, a);
     } else {
+        // with the regularisers: coverage masks + pair flags (frame independent), the plane-by-plane kernel over the regular pairs,
+        // then the slot-by-slot kernel over the irregular ones
         if (a.reg_fwd == 2) {       // render + regulariser sums in one pass (dense stacks)
+            launch_reg_prepass<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
             const int tx = (a.W + 62) / 63, ty = (a.H + 6) / 7;
             hipLaunchKernelGGL((render_fwd_reg_k<COORD, BORDER, ORDER, RACT, AACT, F16>), dim3((unsigned)(tx * ty * a.T)), dim3(512), 0, s, a, tx, ty);
+            launch_reg_patch<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
             return;
         }
         if (a.reg_fwd) {
+            launch_reg_prepass<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
             dim3 rgrid((a.W + RW - 2) / (RW - 1), (a.H + 14) / 15, a.T);
             hipLaunchKernelGGL((render_reg_fwd_k<COORD, BORDER, ORDER, RACT, AACT, 16, F16>), rgrid, dim3(RW * 16), 0, s, a);
+            launch_reg_patch<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
             return;
         }
         // frame pairs (shipped activations, dense stacks, T >= 2); forward variant 6 (desc->variant bits 8..11) keeps the one-frame

@@ -92,12 +92,17 @@ class _RenderPlanes(torch.autograd.Function):
         desc = _desc(stack, H, W, spec, row0, col0, cull_window if quad_keep is not None else None)
         asum = torch.empty((T, H, W, 2), dtype=torch.float32, device=stack.device) if with_reg else None
         sums = torch.zeros(4, dtype=torch.float64, device=stack.device)
+        reg_state = None
+        if with_reg:
+            # coverage masks / pair flags / sign words of the layer differences: written by the forward, read by the backward (include/vl3d.h)
+            with torch.cuda.device(stack.device):
+                reg_state = torch.empty(int(L.lib().vl3d_render_reg_state_bytes(desc)), dtype=torch.uint8, device=stack.device)
         # variant bits 12-15: 1 = keep the two-pass forward with regularisers (render, then the sums kernel) for A/B and cross-checks
         fused_reg = with_reg and quad_keep is None and ((int(spec.variant) >> 12) & 0xf) != 1
         with torch.cuda.device(stack.device):
             if fused_reg:         # render + smoothness sums in ONE sweep over the stack
                 L.check(L.lib().vl3d_render_fwd_reg(desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.ptr(asum), L.ptr(sums),
-                                                    L.stream_ptr(stack.device)), "vl3d_render_fwd_reg")
+                                                    L.ptr(reg_state), L.stream_ptr(stack.device)), "vl3d_render_fwd_reg")
             elif quad_keep is None:
                 L.check(L.lib().vl3d_render_fwd(desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.ptr(asum),
                                                 L.stream_ptr(stack.device)), "vl3d_render_fwd")
@@ -109,16 +114,17 @@ class _RenderPlanes(torch.autograd.Function):
                                                        L.stream_ptr(stack.device)), "vl3d_render_fwd_culled")
         ctx.save_for_backward(stack, homos, rgb, alpha)
         ctx.quad_keep = quad_keep
+        ctx.reg_state = reg_state
         ctx.desc = desc
         ctx.with_reg = with_reg
         if with_reg and not fused_reg:
             with torch.cuda.device(stack.device):
                 if quad_keep is None:
-                    L.check(L.lib().vl3d_render_reg_fwd(desc, L.ptr(stack), L.ptr(homos), L.ptr(sums), L.stream_ptr(stack.device)),
+                    L.check(L.lib().vl3d_render_reg_fwd(desc, L.ptr(stack), L.ptr(homos), L.ptr(sums), L.ptr(reg_state), L.stream_ptr(stack.device)),
                             "vl3d_render_reg_fwd")
                 else:
                     L.check(L.lib().vl3d_render_reg_fwd_culled(desc, L.ptr(stack), L.ptr(homos), L.ptr(quad_keep), quad_keep.shape[1],
-                                                               quad_keep.shape[2], L.ptr(sums), L.stream_ptr(stack.device)),
+                                                               quad_keep.shape[2], L.ptr(sums), L.ptr(reg_state), L.stream_ptr(stack.device)),
                             "vl3d_render_reg_fwd_culled")
         if asum is None:
             asum = torch.zeros((0,), dtype=torch.float32, device=stack.device)
@@ -142,11 +148,11 @@ class _RenderPlanes(torch.autograd.Function):
             qk = ctx.quad_keep
             if qk is None:
                 L.check(L.lib().vl3d_render_bwd(ctx.desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha),
-                                                L.ptr(g_rgb), L.ptr(g_alpha), L.ptr(g_reg), L.ptr(g_asum), L.ptr(g_stack), L.ptr(scratch), nscratch,
+                                                L.ptr(g_rgb), L.ptr(g_alpha), L.ptr(g_reg), L.ptr(ctx.reg_state), L.ptr(g_asum), L.ptr(g_stack), L.ptr(scratch), nscratch,
                                                 L.stream_ptr(stack.device)), "vl3d_render_bwd")
             else:
                 L.check(L.lib().vl3d_render_bwd_culled(ctx.desc, L.ptr(stack), L.ptr(homos), L.ptr(qk), qk.shape[1], qk.shape[2],
-                                                       L.ptr(rgb), L.ptr(alpha), L.ptr(g_rgb), L.ptr(g_alpha), L.ptr(g_reg), L.ptr(g_asum),
+                                                       L.ptr(rgb), L.ptr(alpha), L.ptr(g_rgb), L.ptr(g_alpha), L.ptr(g_reg), L.ptr(ctx.reg_state), L.ptr(g_asum),
                                                        L.ptr(g_stack), L.ptr(scratch), nscratch, L.stream_ptr(stack.device)),
                         "vl3d_render_bwd_culled")
         global LAST_BWD_SCRATCH
