@@ -138,11 +138,11 @@ extern "C" int64_t vl3d_render_bwd_scratch_bytes(const vl3d_render_desc *desc) {
 static int render_reg_fwd_impl(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep, int32_t QH,
                                int32_t QW, double *sums, void *reg_state, vl3d_stream_t stream);
 
-// reg_state: flags [H][W] u8 | coverage masks [H][W][2] u64 | sign words [D][T][H][W] u16 | patch words [D][T][H][W] u16 (256-byte aligned parts)
+// reg_state: flags [H][W] u8 | coverage masks [H][W][2] u64 | sign words [ceil(D/4)][T][H][W][4] u16 | patch words (same shape) (256-byte aligned parts)
 struct RegLayout { int64_t masks, signs, patch, total; };
 static RegLayout reg_layout(const vl3d_render_desc *d) {
     auto up = [](int64_t v) { return (v + 255) & ~(int64_t)255; };
-    const int64_t px = (int64_t)d->H * d->W, words = (int64_t)d->D * d->T * px * 2;
+    const int64_t px = (int64_t)d->H * d->W, words = (int64_t)((d->D + 3) / 4) * d->T * px * 8;      // groups of four planes
     RegLayout l;
     l.masks = up(px);
     l.signs = l.masks + up(px * 16);

@@ -72,8 +72,11 @@ struct RenderArgs {
     // buffer, written by the forward with regularisers and read by the backward
     unsigned char *reg_flags;          // [H][W]      bit 0/1/2/3: the pair with the right / lower / left / upper neighbour is IRREGULAR
     unsigned long long *reg_masks;     // [H][W][2]   bit d: plane d covers the pixel (frame independent)
-    unsigned short *reg_signs;         // [D][T][H][W] sign codes of (this pixel's layer value - right neighbour's) | (... - lower) << 8
-    unsigned short *reg_patch;         // [D][T][H][W] the same towards the left | upper neighbour, irregular pairs only
+    // sign words: one uint16 per (plane, frame, pixel), stored in GROUPS OF FOUR PLANES as one uint64 -- [ceil(D/4)][T][H][W][4] -- so that
+    // a forward thread stores 8 bytes every fourth plane and a backward thread loads 8 bytes every fourth plane (2-byte stores of 126-byte
+    // row segments measured +1.6 ms on the 7.4 ms forward at cfg3: every cache line was written in parts)
+    unsigned short *reg_signs;         // signs of (this pixel's layer value - right neighbour's) | (... - lower neighbour's) << 8
+    unsigned short *reg_patch;         // the same towards the left | upper neighbour, irregular pairs only
 };
 
 // one entry point per compiled convention (coord_mode, border_mode, act_order): vl3d_render_c*.hip
@@ -354,31 +357,38 @@ __device__ __forceinline__ f4 shade2(const Taps2 &t, const u2 v[4], f4 *pre_out 
 //     planes: slot k is the same plane on both sides) exactly as before, and store their signs: 2 bits per channel, two's complement
 //     (+1 = 01, -1 = 11, 0 = 00 -- equal values have gradient 0 like torch's abs), right pair in bits 0-7, lower pair in bits 8-15
 //     of one uint16 per (plane, frame, pixel).  Irregular pairs are left out there (code 0) ...
-//   * ... and taken by reg_patch_fwd_k, one thread per (pixel with an irregular pair, frame): it walks the pixel's covered planes in
-//     depth order, samples ITS k-th plane and the neighbour's k-th plane in place, adds |difference| of the pairs it owns (right,
-//     lower; plus the slots only the neighbour has) to the sums, ORs the signs of its right / lower pairs into its sign word and
-//     writes those of its left / upper pairs to the patch word of that (plane, frame, pixel).
+//   * ... and taken by reg_slot_fwd_k (below), whose threads walk their own covered planes slot by slot: it adds |difference| of the
+//     irregular pairs (including the slots only one of the two pixels has) to the sums, adds their signs to the owner's sign word of
+//     ITS plane and writes the negated signs to the neighbour's patch word of the NEIGHBOUR's plane.  For tile-culled models, where
+//     most pairs are irregular, the same kernel forms ALL pairs and the plane-by-plane kernel is not run at all.
 //   * the backward kernels never see layer values of neighbours any more: d sum / d layer value = gx (s_right + s_left) + gy (s_down
 //     + s_up), the four signs decoded from this pixel's word, the left / upper neighbours' words of the same plane (regular pairs:
 //     sign(left - me) is the left pixel's right-pair code) or this pixel's patch word (irregular pairs).  No LDS exchange, no second
 //     barrier, no 2-pixel halo: the kernels with regularisers are the plain ones plus 2-4 two-byte loads and a decode per plane.
-__device__ __forceinline__ unsigned reg_code(float diff) {     // sign as a 2-bit two's complement field
-    return (unsigned)(int)__builtin_amdgcn_fmed3f(diff * 3e38f, -1.0f, 1.0f) & 3u;
+__device__ __forceinline__ int xcd_remap(int b, int nb);      // (defined with the forward kernels below)
+// Sign fields: 2 bits per channel holding sign + 1 (0: negative, 1: zero -- equal values have gradient 0 like torch's abs --, 2: positive).
+// Encoding four of them: the float's bit pattern clamped to [-1, 1] as an INTEGER is its sign (one v_med3_i32: positive floats are
+// positive integers, +0 is 0 and x - x is +0); sum c_k 4^k + 0b01010101 = sum (c_k + 1) 4^k has no borrows, so a byte costs four
+// clamps and three shift-adds (the bias is added by the caller, once per word).
+__device__ __forceinline__ int reg_sign(float v) { return min(max(__float_as_int(v), -1), 1); }
+__device__ __forceinline__ int reg_signs4(f4 diff) {      // sum c_k 4^k, WITHOUT the bias
+    return reg_sign(diff.x) + (reg_sign(diff.y) << 2) + (reg_sign(diff.z) << 4) + (reg_sign(diff.w) << 6);
 }
-__device__ __forceinline__ unsigned reg_codes4(f4 diff) {
-    return reg_code(diff.x) | reg_code(diff.y) << 2 | reg_code(diff.z) << 4 | reg_code(diff.w) << 6;
-}
+constexpr int REG_BIAS = 0x55;            // + 1 in each of a byte's four fields
+constexpr unsigned REG_ZERO = 0x5555u;    // a word whose eight signs are all 0
 // gradient of the four smoothness sums w.r.t. this pixel's activated layer value on one plane and frame.
-// w_own / w_left / w_up: sign words of this pixel, its left and its upper neighbour (0 where that neighbour does not exist);
-// w_patch: this pixel's patch word (read when a left / upper pair is irregular); fl: the pixel's flags
+// w_own / w_left / w_up: sign words of this pixel, its left and its upper neighbour (REG_ZERO where that neighbour does not exist);
+// w_patch: this pixel's patch word (read when a left / upper pair is irregular); fl: the pixel's flags.
+// A neighbour's word holds sign(neighbour - me) (its right / lower pair), the patch word sign(me - neighbour).
 __device__ __forceinline__ f4 reg_grad(unsigned w_own, unsigned w_left, unsigned w_up, unsigned w_patch, unsigned fl, f4 gx, f4 gy) {
-    const int o = (int)w_own, l = (fl & 4u) ? (int)w_patch : (int)w_left, u = (fl & 8u) ? (int)(w_patch >> 8) : (int)(w_up >> 8);
-    const int ls = (fl & 4u) ? 1 : -1, us = (fl & 8u) ? 1 : -1;      // a neighbour's word holds sign(neighbour - me), the patch word sign(me - neighbour)
+    const unsigned l = (fl & 4u) ? w_patch : w_left, u = (fl & 8u) ? (w_patch >> 8) : (w_up >> 8);
+    // u_R - 1 -+ (u_L - 1): with the neighbour's word the biases cancel, with the patch word they add up to -2
+    const int ls = (fl & 4u) ? 1 : -1, us = (fl & 8u) ? 1 : -1, lo = (fl & 4u) ? -2 : 0, uo = (fl & 8u) ? -2 : 0;
     f4 r;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const int ix = __builtin_amdgcn_sbfe(o, 2 * c, 2) + ls * __builtin_amdgcn_sbfe(l, 2 * c, 2);
-        const int iy = __builtin_amdgcn_sbfe(o, 8 + 2 * c, 2) + us * __builtin_amdgcn_sbfe(u, 2 * c, 2);
+        const int ix = (int)__builtin_amdgcn_ubfe(w_own, 2 * c, 2) + ls * (int)__builtin_amdgcn_ubfe(l, 2 * c, 2) + lo;
+        const int iy = (int)__builtin_amdgcn_ubfe(w_own, 8 + 2 * c, 2) + us * (int)__builtin_amdgcn_ubfe(u, 2 * c, 2) + uo;
         r[c] = fmaf(gy[c], (float)iy, gx[c] * (float)ix);
     }
     return r;
@@ -435,73 +445,114 @@ __device__ __forceinline__ f4 reg_sample(const RenderArgs &a, float px, float py
     return shade2<ORDER, RACT, AACT>(tp, tv) * tp.cov;
 }
 
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
-__global__ __launch_bounds__(256) void reg_patch_fwd_k(RenderArgs a) {
-    __shared__ float red[4][4];
-    const int lane = threadIdx.x & 63, row = threadIdx.x >> 6;
-    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * 4 + row, t = blockIdx.z;
-    const bool in = x < a.W && y < a.H;
-    const size_t p = (size_t)y * a.W + x;
-    const unsigned f = in ? a.reg_flags[p] : 0u;
-    float s[4] = {0.f, 0.f, 0.f, 0.f};      // sum |dx rgb|, |dy rgb|, |dx a|, |dy a|
-    if (f) {
-        const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
-        unsigned long long mp0 = a.reg_masks[2 * p], mp1 = a.reg_masks[2 * p + 1];
-        unsigned long long mn0[4], mn1[4];
-        const int dx[4] = {1, 0, -1, 0}, dy[4] = {0, 1, 0, -1};
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const size_t q = (size_t)((int64_t)p + dx[n] + (int64_t)dy[n] * a.W);
-            mn0[n] = ((f >> n) & 1u) ? a.reg_masks[2 * q] : 0ull;
-            mn1[n] = ((f >> n) & 1u) ? a.reg_masks[2 * q + 1] : 0ull;
+// Slot-synchronous regulariser forward.  A workgroup is a 64 x 8-pixel region whose last column / row are halo (63 x 7 pixels own their
+// right / lower pairs); every thread walks ITS OWN covered planes near -> far, so iteration k handles slot k of every pixel: the
+// layer value (and its plane) goes through a double-buffered LDS tile, one barrier per slot, and the pair owner reads its
+// neighbour's slot-k value next to its own -- exactly the reference's per-slot difference, with no resampling.  Per slot it
+//   - adds |difference| to the four sums,
+//   - puts the pair's signs into its own sign word of ITS plane (right pair: bits 0-7, lower pair: bits 8-15),
+//   - and, for an irregular pair, writes the negated signs into the NEIGHBOUR's patch word of the NEIGHBOUR's plane (one byte:
+//     left field for the right neighbour, upper field for the lower one), including the slots only the neighbour has.
+// PATCH = false: every pair of the frame (the whole regulariser forward: tile-culled models, where most pairs are irregular, and the
+//   two-pass forward of dense ones); sign words are written whole, four planes per 8-byte store.
+// PATCH = true: only the irregular pairs, after render_fwd_reg_k took the regular ones plane by plane: regions without an irregular
+//   pair return at once; the signs are ADDED to the words that kernel wrote (it left sign 0 in those fields).
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool PATCH>
+__global__ __launch_bounds__(512) void reg_slot_fwd_k(RenderArgs a, int tiles_x, int tiles_y) {
+    constexpr int FW = 64, FH = 8, NT = FW * FH;
+    __shared__ float4 s_v[2][NT];
+    __shared__ int s_d[2][NT];
+    __shared__ float red[4][FH];
+    __shared__ int s_kmax;
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_x = b % tiles_x, rest = b / tiles_x;
+    const int tile_y = rest % tiles_y, t = rest / tiles_y;
+    const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
+    const int x = tile_x * (FW - 1) + lane, y = tile_y * (FH - 1) + row;
+    const bool inimg = (x < a.W) && (y < a.H);
+    const bool owner = inimg && lane < FW - 1 && row < FH - 1;
+    const size_t p = (size_t)min(y, a.H - 1) * a.W + min(x, a.W - 1);
+    const unsigned fl = owner ? a.reg_flags[p] : 0u;
+    if (PATCH && !__syncthreads_or((fl & 3u) != 0u)) return;
+    // pairs this thread forms: its right / lower one, when it exists (and, in patch mode, is irregular)
+    const bool irr_r = (fl & 1u) != 0u, irr_d = (fl & 2u) != 0u;
+    const bool own_r = owner && x + 1 < a.W && (!PATCH || irr_r), own_d = owner && y + 1 < a.H && (!PATCH || irr_d);
+    unsigned long long m0 = inimg ? a.reg_masks[2 * p] : 0ull, m1 = inimg ? a.reg_masks[2 * p + 1] : 0ull;
+    if (tid == 0) s_kmax = 0;
+    __syncthreads();
+    atomicMax(&s_kmax, __builtin_popcountll(m0) + __builtin_popcountll(m1));
+    __syncthreads();
+    const int kmax = s_kmax;
+    const float px = (float)(a.col0 + min(x, a.W - 1)) + a.pc, py = (float)(a.row0 + min(y, a.H - 1)) + a.pc;
+    const size_t plane_px = (size_t)a.T * a.H * a.W, fpix = ((size_t)t * a.H + min(y, a.H - 1)) * a.W + min(x, a.W - 1);
+    unsigned long long *const sg64 = reinterpret_cast<unsigned long long *>(a.reg_signs);
+    unsigned char *const patch8 = reinterpret_cast<unsigned char *>(a.reg_patch);
+    float sxc = 0.f, syc = 0.f, sxa = 0.f, sya = 0.f;
+    unsigned long long sgw = 0ull;      // (full mode) sign words of the group of four planes being filled
+    int sgg = -1;                       // ... and its index
+    for (int k = 0; k < kmax; ++k) {
+        const int buf = k & 1;
+        const int d = reg_pop_plane(m0, m1);      // my plane in slot k (-1: I have no slot k)
+        f4 v = f4{0.f, 0.f, 0.f, 0.f};
+        if (d >= 0) v = reg_sample<COORD, BORDER, ORDER, RACT, AACT, F16>(a, px, py, d, t);
+        s_v[buf][tid] = make_float4(v.x, v.y, v.z, v.w);
+        s_d[buf][tid] = d;
+        __syncthreads();
+        int code = PATCH ? 0 : (int)REG_ZERO;
+        if (own_r) {
+            const float4 r = s_v[buf][tid + 1];
+            const int dn = s_d[buf][tid + 1];
+            if (d >= 0 || dn >= 0) {
+                const f4 df = v - f4{r.x, r.y, r.z, r.w};
+                sxc += fabsf(df.x) + fabsf(df.y) + fabsf(df.z);
+                sxa += fabsf(df.w);
+                const int c = reg_signs4(df);
+                code += c;
+                if (irr_r && dn >= 0)      // the right neighbour's left field on ITS plane: sign(it - me)
+                    patch8[((((size_t)(dn >> 2) * plane_px + fpix + 1) << 2) + (dn & 3)) * 2] = (unsigned char)(REG_BIAS - c);
+            }
         }
-        const size_t plane_px = (size_t)a.T * a.H * a.W;
-        for (int d = reg_pop_plane(mp0, mp1); d >= 0; d = reg_pop_plane(mp0, mp1)) {      // my slots, near -> far
-            const f4 v = reg_sample<COORD, BORDER, ORDER, RACT, AACT, F16>(a, px, py, d, t);
-            unsigned wrd = 0u, wlu = 0u;
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                if (!((f >> n) & 1u)) continue;
-                const int dn = reg_pop_plane(mn0[n], mn1[n]);      // the neighbour's plane in the same slot (none: its slot is empty = 0)
-                f4 u = f4{0.f, 0.f, 0.f, 0.f};
-                if (dn >= 0) u = reg_sample<COORD, BORDER, ORDER, RACT, AACT, F16>(a, px + (float)dx[n], py + (float)dy[n], dn, t);
-                const f4 df = v - u;
-                const unsigned c = reg_codes4(df);
-                if (n < 2) {
-                    s[n] += fabsf(df.x) + fabsf(df.y) + fabsf(df.z);
-                    s[2 + n] += fabsf(df.w);
-                    wrd |= c << (8 * n);
-                } else {
-                    wlu |= c << (8 * (n - 2));
+        if (own_d) {
+            const float4 r = s_v[buf][tid + FW];
+            const int dn = s_d[buf][tid + FW];
+            if (d >= 0 || dn >= 0) {
+                const f4 df = v - f4{r.x, r.y, r.z, r.w};
+                syc += fabsf(df.x) + fabsf(df.y) + fabsf(df.z);
+                sya += fabsf(df.w);
+                const int c = reg_signs4(df);
+                code += c << 8;
+                if (irr_d && dn >= 0)      // the lower neighbour's upper field on ITS plane
+                    patch8[((((size_t)(dn >> 2) * plane_px + fpix + a.W) << 2) + (dn & 3)) * 2 + 1] = (unsigned char)(REG_BIAS - c);
+            }
+        }
+        if (owner && d >= 0) {
+            if constexpr (PATCH) {
+                if (code) {
+                    unsigned short *w = a.reg_signs + ((((size_t)(d >> 2) * plane_px + fpix) << 2) + (d & 3));
+                    *w = (unsigned short)((int)*w + code);
                 }
+            } else {
+                if ((d >> 2) != sgg) {
+                    if (sgg >= 0) sg64[(size_t)sgg * plane_px + fpix] = sgw;
+                    sgg = d >> 2; sgw = 0ull;
+                }
+                sgw |= (unsigned long long)(unsigned)code << (16 * (d & 3));
             }
-            const size_t idx = (size_t)d * plane_px + ((size_t)t * a.H + y) * a.W + x;
-            if (f & 3u) a.reg_signs[idx] |= (unsigned short)wrd;      // the plane-by-plane kernel left code 0 in the irregular pairs' fields
-            if (f & 12u) a.reg_patch[idx] = (unsigned short)wlu;
         }
-        // slots only the right / lower neighbour has: |0 - its value| belongs to the pair I own
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-            for (int dn = reg_pop_plane(mn0[n], mn1[n]); dn >= 0; dn = reg_pop_plane(mn0[n], mn1[n])) {
-                const f4 u = reg_sample<COORD, BORDER, ORDER, RACT, AACT, F16>(a, px + (float)dx[n], py + (float)dy[n], dn, t);
-                s[n] += fabsf(u.x) + fabsf(u.y) + fabsf(u.z);
-                s[2 + n] += fabsf(u.w);
-            }
     }
-    if (!__syncthreads_or(f != 0u)) return;
+    if (!PATCH && owner && sgg >= 0) sg64[(size_t)sgg * plane_px + fpix] = sgw;
+    float v4[4] = {sxc, syc, sxa, sya};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float v = s[k];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) red[k][row] = v;
+        for (int off = 32; off > 0; off >>= 1) v4[k] += __shfl_down(v4[k], off, 64);
+        if (lane == 0) red[k][row] = v4[k];
     }
     __syncthreads();
-    if (threadIdx.x < 4) {
-        const int k = threadIdx.x;
-        const double sum = (double)red[k][0] + (double)red[k][1] + (double)red[k][2] + (double)red[k][3];
-        // sums order of the ABI: 0 = x pairs rgb, 1 = y pairs rgb, 2 = x pairs alpha, 3 = y pairs alpha  (s[] has the same order)
-        if (sum != 0.0) atomicAdd(a.reg_sums + k, sum);
+    if (tid < 4) {
+        double sum = 0.0;
+        for (int r = 0; r < FH; ++r) sum += (double)red[tid][r];
+        if (sum != 0.0) atomicAdd(a.reg_sums + tid, sum);
     }
 }
 
@@ -511,9 +562,10 @@ void launch_reg_prepass(const RenderArgs &a, hipStream_t s) {
     hipLaunchKernelGGL((reg_masks_k<COORD, BORDER>), g, dim3(256), 0, s, a);
     hipLaunchKernelGGL(reg_flags_k, g, dim3(256), 0, s, a);
 }
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
-void launch_reg_patch(const RenderArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL((reg_patch_fwd_k<COORD, BORDER, ORDER, RACT, AACT, F16>), dim3((a.W + 63) / 64, (a.H + 3) / 4, a.T), dim3(256), 0, s, a);
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool PATCH>
+void launch_reg_slots(const RenderArgs &a, hipStream_t s) {
+    const int tx = (a.W + 62) / 63, ty = (a.H + 6) / 7;
+    hipLaunchKernelGGL((reg_slot_fwd_k<COORD, BORDER, ORDER, RACT, AACT, F16, PATCH>), dim3((unsigned)(tx * ty * a.T)), dim3(512), 0, s, a, tx, ty);
 }
 
 constexpr int TILE_X = 64, TILE_Y = 4;
@@ -557,8 +609,8 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
         Tr *= om;
         if (a.g_reg) {   // smoothness regularisers: the signs the forward stored (hit-slot order)
             const f4 gx = f4{a.g_reg[0], a.g_reg[0], a.g_reg[0], a.g_reg[2]}, gy = f4{a.g_reg[1], a.g_reg[1], a.g_reg[1], a.g_reg[3]};
-            const size_t idx = (((size_t)d * a.T + t) * a.H + y) * a.W + x;
-            const unsigned w_left = x >= 1 ? a.reg_signs[idx - 1] : 0u, w_up = y >= 1 ? a.reg_signs[idx - a.W] : 0u;
+            const size_t idx = (((((size_t)(d >> 2) * a.T + t) * a.H + y) * a.W + x) << 2) + (d & 3);
+            const unsigned w_left = x >= 1 ? a.reg_signs[idx - 4] : REG_ZERO, w_up = y >= 1 ? a.reg_signs[idx - 4 * (size_t)a.W] : REG_ZERO;
             go += reg_grad(a.reg_signs[idx], w_left, w_up, (fl & 12u) ? a.reg_patch[idx] : 0u, fl, gx, gy);
         }
         if constexpr (ORDER == VL3D_ACT_POST)
@@ -1060,13 +1112,15 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTI
     float Tr = 1.0f, P = 0.0f;
     float gsx_c = 0.f, gsy_c = 0.f, gsx_a = 0.f, gsy_a = 0.f;
     unsigned fl = 0u;
-    const unsigned short *sgp = nullptr;      // this pixel's sign word of plane 0 (clamped into the frame: the loads are unconditional)
+    const unsigned long long *sgp = nullptr;      // this pixel's sign words of planes 0-3 (clamped into the frame: the loads are unconditional)
+    unsigned long long wg_own = 0ull, wg_l = 0ull, wg_u = 0ull, wg_p = 0ull;      // sign words of the current group of four planes
+    int wg_idx = -1;
     const bool has_l = inimg && x >= 1, has_u = inimg && y >= 1;
     const bool reg_on = REG && a.g_reg != nullptr;
     if constexpr (REG) if (reg_on) {
         gsx_c = a.g_reg[0]; gsy_c = a.g_reg[1]; gsx_a = a.g_reg[2]; gsy_a = a.g_reg[3];
         const int xc = min(max(x, 0), a.W - 1), yc = min(max(y, 0), a.H - 1);
-        sgp = a.reg_signs + ((size_t)t * a.H + yc) * a.W + xc;
+        sgp = reinterpret_cast<const unsigned long long *>(a.reg_signs) + ((size_t)t * a.H + yc) * a.W + xc;
         if (inimg) fl = a.reg_flags[(size_t)y * a.W + x];
     }
     const size_t sg_plane = (size_t)a.T * a.H * a.W;
@@ -1128,10 +1182,16 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTI
         }
         f4 sg = f4{0.f, 0.f, 0.f, 0.f};
         if constexpr (REG) if (reg_on) {      // uniform
-            const unsigned short *w = sgp + (size_t)d * sg_plane;
-            const unsigned w_own = w[0], w_l = w[has_l ? -1 : 0], w_u = w[has_u ? -(ptrdiff_t)a.W : 0];
-            const unsigned w_p = (fl & 12u) ? a.reg_patch[(w - a.reg_signs)] : 0u;
-            sg = reg_grad(w_own, has_l ? w_l : 0u, has_u ? w_u : 0u, w_p, fl, f4{gsx_c, gsx_c, gsx_c, gsx_a}, f4{gsy_c, gsy_c, gsy_c, gsy_a});
+            if ((d >> 2) != wg_idx) {      // (not "d & 3 == 0": a culled plane skips this block)
+                wg_idx = d >> 2;
+                const unsigned long long *w = sgp + (size_t)(d >> 2) * sg_plane;
+                wg_own = w[0]; wg_l = w[has_l ? -1 : 0]; wg_u = w[has_u ? -(ptrdiff_t)a.W : 0];
+                if (fl & 12u) wg_p = reinterpret_cast<const unsigned long long *>(a.reg_patch)[w - reinterpret_cast<const unsigned long long *>(a.reg_signs)];
+            }
+            const int sh = 16 * (d & 3);
+            sg = reg_grad((unsigned)(wg_own >> sh) & 0xffffu, has_l ? (unsigned)(wg_l >> sh) & 0xffffu : REG_ZERO,
+                          has_u ? (unsigned)(wg_u >> sh) & 0xffffu : REG_ZERO, (unsigned)(wg_p >> sh) & 0xffffu, fl,
+                          f4{gsx_c, gsx_c, gsx_c, gsx_a}, f4{gsy_c, gsy_c, gsy_c, gsy_a});
         }
         if (inimg) {
             const float q = dot3p(Gr, o.x, Gg, o.y, Gb, o.z, gA);
@@ -1363,7 +1423,8 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
     float gN10 = 0.f, gN20 = 0.f, gN11 = 0.f, gN21 = 0.f;
     f4 gx = f4{0.f, 0.f, 0.f, 0.f}, gy = gx;
     unsigned fl = 0u;
-    const unsigned short *sgp = nullptr;
+    const unsigned long long *sgp = nullptr;
+    unsigned long long go0 = 0ull, gl0 = 0ull, gu0 = 0ull, gp0 = 0ull, go1 = 0ull, gl1 = 0ull, gu1 = 0ull, gp1 = 0ull;   // the group's sign words
     const bool has_l = inimg && x >= 1, has_u = inimg && y >= 1;
     const bool reg_on = REG && a.g_reg != nullptr;
     const size_t sg_plane = (size_t)a.T * a.H * a.W, sg_f1 = has1 ? (size_t)a.H * a.W : 0;
@@ -1377,7 +1438,7 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
         if (reg_on) {
             gx = f4{a.g_reg[0], a.g_reg[0], a.g_reg[0], a.g_reg[2]}; gy = f4{a.g_reg[1], a.g_reg[1], a.g_reg[1], a.g_reg[3]};
             const int xc = min(max(x, 0), a.W - 1), yc = min(max(y, 0), a.H - 1);
-            sgp = a.reg_signs + ((size_t)t0 * a.H + yc) * a.W + xc;      // clamped into the frame: the loads below are unconditional
+            sgp = reinterpret_cast<const unsigned long long *>(a.reg_signs) + ((size_t)t0 * a.H + yc) * a.W + xc;      // clamped into the frame: the loads below are unconditional
             if (inimg) fl = a.reg_flags[(size_t)y * a.W + x];
         }
     }
@@ -1397,13 +1458,16 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
         const int buf = d & 1;
         const unsigned short *oplane = a.owner + (size_t)d * a.Hs * a.Ws;
         const unsigned e0 = oplane[(unsigned)(Y0 * a.Ws + X0) + toff_thread];     // unconditional (padded table), arrives in the shadow of the sweep
-        // sign words of this plane (own, left, upper; two frames): requested with the taps
-        unsigned wo0 = 0u, wl0 = 0u, wu0 = 0u, wo1 = 0u, wl1 = 0u, wu1 = 0u;
-        if constexpr (REG) if (reg_on) {      // uniform
-            const unsigned short *w = sgp + (size_t)d * sg_plane;
+        // sign words of this group of four planes (own, left, upper; two frames): requested with the taps of its first plane
+        if constexpr (REG) if (reg_on && (d & 3) == 0) {      // uniform
+            const unsigned long long *w = sgp + (size_t)(d >> 2) * sg_plane;
             const ptrdiff_t ol = has_l ? -1 : 0, ou = has_u ? -(ptrdiff_t)a.W : 0;
-            wo0 = w[0]; wl0 = w[ol]; wu0 = w[ou];
-            wo1 = w[sg_f1]; wl1 = w[sg_f1 + ol]; wu1 = w[sg_f1 + ou];
+            go0 = w[0]; gl0 = w[ol]; gu0 = w[ou];
+            go1 = w[sg_f1]; gl1 = w[sg_f1 + ol]; gu1 = w[sg_f1 + ou];
+            if (fl & 12u) {
+                const unsigned long long *pw = reinterpret_cast<const unsigned long long *>(a.reg_patch) + (w - reinterpret_cast<const unsigned long long *>(a.reg_signs));
+                gp0 = pw[0]; gp1 = pw[sg_f1];
+            }
         }
         // (2) sweep: one set of taps, two frames
         float2 tc = make_float2(0.f, 0.f);
@@ -1419,13 +1483,10 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
             f4 ex0 = f4{0.f, 0.f, 0.f, 0.f}, ex1 = ex0;
             if constexpr (REG) {
                 if (reg_on) {
-                    unsigned wp0 = 0u, wp1 = 0u;
-                    if (fl & 12u) {
-                        const size_t pi = (size_t)(sgp - a.reg_signs) + (size_t)d * sg_plane;
-                        wp0 = a.reg_patch[pi]; wp1 = a.reg_patch[pi + sg_f1];
-                    }
-                    ex0 = reg_grad(wo0, has_l ? wl0 : 0u, has_u ? wu0 : 0u, wp0, fl, gx, gy);
-                    ex1 = reg_grad(wo1, has_l ? wl1 : 0u, has_u ? wu1 : 0u, wp1, fl, gx, gy);
+                    const int sh = 16 * (d & 3);
+                    auto fld = [sh](unsigned long long g) { return (unsigned)(g >> sh) & 0xffffu; };
+                    ex0 = reg_grad(fld(go0), has_l ? fld(gl0) : REG_ZERO, has_u ? fld(gu0) : REG_ZERO, fld(gp0), fl, gx, gy);
+                    ex1 = reg_grad(fld(go1), has_l ? fld(gl1) : REG_ZERO, has_u ? fld(gu1) : REG_ZERO, fld(gp1), fl, gx, gy);
                 }
                 ex0.w += fmaf(gN20, o0.w, gN10);
                 ex1.w += fmaf(gN21, o1.w, gN11);
@@ -1568,99 +1629,8 @@ void launch_pair(const RenderArgs &a, hipStream_t s) {
 }
 
 // =====================================================================================================
-// Layer-space smoothness regularisers, forward (MPV.py:517-531): sum over frames, planes and neighbouring pixel pairs of
-// |L[p] - L[q]| of the warped+activated per-layer rgba L (zero where a plane does not cover the pixel) -- without ever
-// materialising the [T,h,w,K,4] layer tensor the reference builds (1.47 GB per training crop).
-// out[0] = sum |dx rgb|, out[1] = sum |dy rgb|, out[2] = sum |dx a|, out[3] = sum |dy a|   (device doubles, accumulated).
-// Workgroup = 64 x ROWS region, pairs owned by their left / upper pixel (63 x (ROWS-1) interior), one barrier per plane.
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool F16>
-__global__ __launch_bounds__(RW *ROWS) void render_reg_fwd_k(RenderArgs a) {
-    constexpr int NT = RW * ROWS;
-    __shared__ float4 s_o[2][NT];
-    __shared__ float red[4][ROWS];
-    const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
-    const int x = blockIdx.x * (RW - 1) + lane, y = blockIdx.y * (ROWS - 1) + row, t = blockIdx.z;
-    const bool inimg = (x < a.W) && (y < a.H);
-    // the last column / row of the region are halo (owned by the next tile, where they are column / row 0)
-    const bool owner = inimg && lane < RW - 1 && row < ROWS - 1;
-    // pairs whose two pixels are covered by different planes are not formed here (reg_patch_fwd_k takes them, slot by slot)
-    const unsigned fl = owner ? a.reg_flags[(size_t)y * a.W + x] : 0u;
-    const bool own_r = owner && x + 1 < a.W && !(fl & 1u), own_d = owner && y + 1 < a.H && !(fl & 2u);
-    const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
-    const size_t frame_b = (size_t)a.Hs * a.Ws * (F16 ? 8 : 16), plane_stride_b = (size_t)a.T * frame_b;
-    const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * frame_b;
-    const size_t sg_plane = (size_t)a.T * a.H * a.W;
-    unsigned short *sgp = a.reg_signs + ((size_t)t * a.H + min(y, a.H - 1)) * a.W + min(x, a.W - 1);
-    float sxc = 0.f, syc = 0.f, sxa = 0.f, sya = 0.f;
-    // tile culling: the workgroup builds its own plane mask (thread d projects the region's corners onto plane d and tests the
-    // touched quads) and walks only the set bits; a skipped plane has layer value 0 everywhere in the region, i.e. adds nothing
-    __shared__ unsigned long long s_mask[2];
-    if (a.quad_keep) {
-        if (tid < 2) s_mask[tid] = 0ull;
-        __syncthreads();
-        if (tid < a.D) {
-            const int x0 = blockIdx.x * (RW - 1), x1 = min(x0 + RW - 1, a.W - 1), y0 = blockIdx.y * (ROWS - 1), y1 = min(y0 + ROWS - 1, a.H - 1);
-            const float *h = a.homos + VL3D_HS * tid;
-            float tnx = 1e30f, txx = -1e30f, tny = 1e30f, txy = -1e30f;
-            for (int c = 0; c < 4; ++c) {
-                const float cx = (float)a.col0 + a.pc + (float)((c & 1) ? x1 : x0), cy = (float)a.row0 + a.pc + (float)((c & 2) ? y1 : y0);
-                const float X = h[0] * cx + h[1] * cy + h[2], Y = h[3] * cx + h[4] * cy + h[5], Z = h[6] * cx + h[7] * cy + h[8];
-                const float ctx = texel_coord<COORD>(X / Z, (float)a.Ws / 2.0f, (float)(a.Ws - 1), a.sx, a.ox);
-                const float cty = texel_coord<COORD>(Y / Z, (float)a.Hs / 2.0f, (float)(a.Hs - 1), a.sy, a.oy);
-                tnx = fminf(tnx, ctx); txx = fmaxf(txx, ctx); tny = fminf(tny, cty); txy = fmaxf(txy, cty);
-            }
-            if (box_touches_kept_quad(a, tid, tnx, txx, tny, txy)) atomicOr(&s_mask[tid >> 6], 1ull << (tid & 63));
-        }
-        __syncthreads();
-    }
-    int nact = 0;
-    for (int d = 0; d < a.D; ++d, plane += plane_stride_b, sgp += sg_plane) {
-        if (a.quad_keep && !((s_mask[d >> 6] >> (d & 63)) & 1ull)) continue;      // uniform (no pixel of the region is covered: its sign words are never read)
-        f4 ol = f4{0.f, 0.f, 0.f, 0.f};
-        if (inimg) {
-            const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + VL3D_HS * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
-            typename TapVal<F16, ORDER>::type tv[4];
-            load_taps2<F16>(plane, tp, make_tap_step<F16>(a.Hs, a.Ws), tv);
-            ol = shade2<ORDER, RACT, AACT>(tp, tv) * tp.cov;
-        }
-        const int buf = (nact++) & 1;        // alternates over the planes actually walked (a skipped plane has no barrier)
-        s_o[buf][tid] = make_float4(ol.x, ol.y, ol.z, ol.w);
-        __syncthreads();
-        unsigned code = 0u;
-        if (own_r) {
-            const float4 r = s_o[buf][tid + 1];
-            const f4 df = ol - f4{r.x, r.y, r.z, r.w};
-            sxc += fabsf(df.x) + fabsf(df.y) + fabsf(df.z);
-            sxa += fabsf(df.w);
-            code = reg_codes4(df);
-        }
-        if (own_d) {
-            const float4 r = s_o[buf][tid + RW];
-            const f4 df = ol - f4{r.x, r.y, r.z, r.w};
-            syc += fabsf(df.x) + fabsf(df.y) + fabsf(df.z);
-            sya += fabsf(df.w);
-            code |= reg_codes4(df) << 8;
-        }
-        if (owner) *sgp = (unsigned short)code;
-    }
-    float v[4] = {sxc, syc, sxa, sya};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
-        if (lane == 0) red[k][row] = v[k];
-    }
-    __syncthreads();
-    if (tid < 4) {
-        double sum = 0.0;
-        for (int r = 0; r < ROWS; ++r) sum += (double)red[tid][r];
-        atomicAdd(a.reg_sums + tid, sum);
-    }
-}
-
-// =====================================================================================================
 // Forward WITH the layer regularisers in one pass: the render (rgb, alpha, alpha sums) and the four smoothness sums
-// (MPV.py:517-531) from ONE sweep over the stack.  render_fwd2(x)_k + render_reg_fwd_k read every texel twice (5.1 + 7.1 ms at
+// (MPV.py:517-531) from ONE sweep over the stack.  render_fwd2(x)_k + a separate sums kernel read every texel twice (5.1 + 7.1 ms at
 // cfg3 for what a shipped stage-2 iteration calls once per step); here a workgroup is a 64 x 8-pixel region whose last column and
 // row are halo (63 x 7 pixels owned: their outputs and the |o - o_right|, |o - o_down| pairs), each plane's activated layer values
 // go through a double-buffered LDS tile (one barrier per plane), and the taps of plane d+1 are in flight across that barrier (two
@@ -1677,11 +1647,12 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
     const int x = tile_x * (FW - 1) + lane, y = tile_y * (FH - 1) + row;
     const bool inimg = (x < a.W) && (y < a.H);
     const bool owner = inimg && lane < FW - 1 && row < FH - 1;        // the last column / row are owned by the next tile (its column / row 0)
-    // pairs whose two pixels are covered by different planes are not formed here (reg_patch_fwd_k takes them, slot by slot)
+    // pairs whose two pixels are covered by different planes are not formed here (reg_slot_fwd_k takes them, slot by slot)
     const unsigned fl = owner ? a.reg_flags[(size_t)y * a.W + x] : 0u;
     const bool own_r = owner && x + 1 < a.W && !(fl & 1u), own_d = owner && y + 1 < a.H && !(fl & 2u);
     const size_t sg_plane = (size_t)a.T * a.H * a.W;
-    unsigned short *const sg0 = a.reg_signs + ((size_t)t * a.H + min(y, a.H - 1)) * a.W + min(x, a.W - 1);
+    unsigned long long *const sg0 = reinterpret_cast<unsigned long long *>(a.reg_signs) + ((size_t)t * a.H + min(y, a.H - 1)) * a.W + min(x, a.W - 1);
+    unsigned long long sgw = 0ull;      // sign words of the current group of four planes
     // pixels outside the frame sample the frame's last pixel (valid addresses, results dropped): no branch around the loads
     const float px = (float)(a.col0 + min(x, a.W - 1)) + a.pc, py = (float)(a.row0 + min(y, a.H - 1)) + a.pc;
     const size_t frame_b = (size_t)a.Hs * a.Ws * (F16 ? 8 : 16), plane_stride_b = (size_t)a.T * frame_b;
@@ -1701,22 +1672,23 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
         n1 += o.w; n2 = fmaf(o.w, o.w, n2);                                                               \
         Tr *= (1.0f - o.w);                                                                               \
         __syncthreads();                                                                                  \
-        unsigned code = 0u;                                                                               \
+        int code = (int)REG_ZERO;                                                                         \
         if (own_r) {                                                                                      \
             const float4 r = s_o[BUF_][tid + 1];                                                          \
             const f4 df = ol - f4{r.x, r.y, r.z, r.w};                                                    \
             sxc += fabsf(df.x) + fabsf(df.y) + fabsf(df.z);                                               \
             sxa += fabsf(df.w);                                                                           \
-            code = reg_codes4(df);                                                                        \
+            code += reg_signs4(df);                                                                       \
         }                                                                                                 \
         if (own_d) {                                                                                      \
             const float4 r = s_o[BUF_][tid + FW];                                                         \
             const f4 df = ol - f4{r.x, r.y, r.z, r.w};                                                    \
             syc += fabsf(df.x) + fabsf(df.y) + fabsf(df.z);                                               \
             sya += fabsf(df.w);                                                                           \
-            code |= reg_codes4(df) << 8;                                                                  \
+            code += reg_signs4(df) << 8;                                                                  \
         }                                                                                                 \
-        if (owner) sg0[(size_t)(D_) * sg_plane] = (unsigned short)code;                                   \
+        sgw |= (unsigned long long)(unsigned)code << (16 * ((D_) & 3));                                   \
+        if ((((D_) & 3) == 3 || (D_) == a.D - 1) && owner) { sg0[(size_t)((D_) >> 2) * sg_plane] = sgw; sgw = 0ull; }   \
     }
     Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy), tB = tA;
     load_taps2<F16>(plane, tA, st, vA);
@@ -1832,14 +1804,12 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
             launch_reg_prepass<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
             const int tx = (a.W + 62) / 63, ty = (a.H + 6) / 7;
             hipLaunchKernelGGL((render_fwd_reg_k<COORD, BORDER, ORDER, RACT, AACT, F16>), dim3((unsigned)(tx * ty * a.T)), dim3(512), 0, s, a, tx, ty);
-            launch_reg_patch<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
+            launch_reg_slots<COORD, BORDER, ORDER, RACT, AACT, F16, true>(a, s);
             return;
         }
-        if (a.reg_fwd) {
+        if (a.reg_fwd) {        // the sums alone (tile-culled models; the two-pass forward of dense ones): every pair slot by slot
             launch_reg_prepass<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
-            dim3 rgrid((a.W + RW - 2) / (RW - 1), (a.H + 14) / 15, a.T);
-            hipLaunchKernelGGL((render_reg_fwd_k<COORD, BORDER, ORDER, RACT, AACT, 16, F16>), rgrid, dim3(RW * 16), 0, s, a);
-            launch_reg_patch<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
+            launch_reg_slots<COORD, BORDER, ORDER, RACT, AACT, F16, false>(a, s);
             return;
         }
         // frame pairs (shipped activations, dense stacks, T >= 2); forward variant 6 (desc->variant bits 8..11) keeps the one-frame
