@@ -465,13 +465,13 @@ def main():
                 res["reference_geometry"] = {
                     "workload": f"cfg3 frames from a {Hs2}x{Ws2} stack (mpi_h/w_scale 1.1) with the smoothness regularisers on: D={D}, T={T}",
                     "value": px / ((f2 + b2) * 1e-3) / 1e6, "unit": "Mpix/s", "fwd_ms": f2, "bwd_ms": b2,
-                    "roofline_bwd": {"kernel": "render_bwd_pair_reg_k (+ pre-pass)", "bound": "hbm", "avg_ms": b2,
+                    "roofline_bwd": {"kernel": "render_bwd_pair_k<REG> (sign words of the forward; + pre-pass)", "bound": "hbm", "avg_ms": b2,
                                      "achieved": px * (32 * D + 12) / (b2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": px * (32 * D + 12) / (b2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                      "algorithmic_bytes": px * (32 * D + 12),
                                      "texel_footprint_bytes": tex * 32 * D + px * 12,      # every texel of the 1.1x stack is read and its gradient written
                                      "frac_texel_footprint": (tex * 32 * D + px * 12) / (b2 * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                    "roofline_fwd": {"kernel": "render_fwd_reg_k (render + regulariser sums in one pass)", "bound": "hbm", "avg_ms": f2,
+                    "roofline_fwd": {"kernel": "render_fwd_reg_k (render + regulariser sums + sign words in one pass; + reg_masks_k, reg_flags_k, reg_slot_fwd_k)", "bound": "hbm", "avg_ms": f2,
                                      "achieved": px * (16 * D + 12) / (f2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": px * (16 * D + 12) / (f2 * 1e-3) / 1e9 / HBM_PEAK_GBS}}
                 del st2

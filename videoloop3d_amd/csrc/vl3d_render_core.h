@@ -370,7 +370,11 @@ __device__ __forceinline__ int xcd_remap(int b, int nb);      // (defined with t
 // Encoding four of them: the float's bit pattern clamped to [-1, 1] as an INTEGER is its sign (one v_med3_i32: positive floats are
 // positive integers, +0 is 0 and x - x is +0); sum c_k 4^k + 0b01010101 = sum (c_k + 1) 4^k has no borrows, so a byte costs four
 // clamps and three shift-adds (the bias is added by the caller, once per word).
-__device__ __forceinline__ int reg_sign(float v) { return min(max(__float_as_int(v), -1), 1); }
+__device__ __forceinline__ int reg_sign(float v) {      // (min(max()) compiles to two compares and two selects)
+    int r;
+    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(__float_as_int(v)));
+    return r;
+}
 __device__ __forceinline__ int reg_signs4(f4 diff) {      // sum c_k 4^k, WITHOUT the bias
     return reg_sign(diff.x) + (reg_sign(diff.y) << 2) + (reg_sign(diff.z) << 4) + (reg_sign(diff.w) << 6);
 }
@@ -1651,8 +1655,8 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
     const unsigned fl = owner ? a.reg_flags[(size_t)y * a.W + x] : 0u;
     const bool own_r = owner && x + 1 < a.W && !(fl & 1u), own_d = owner && y + 1 < a.H && !(fl & 2u);
     const size_t sg_plane = (size_t)a.T * a.H * a.W;
-    unsigned long long *const sg0 = reinterpret_cast<unsigned long long *>(a.reg_signs) + ((size_t)t * a.H + min(y, a.H - 1)) * a.W + min(x, a.W - 1);
-    unsigned long long sgw = 0ull;      // sign words of the current group of four planes
+    uint2 *sgq = reinterpret_cast<uint2 *>(a.reg_signs) + ((size_t)t * a.H + min(y, a.H - 1)) * a.W + min(x, a.W - 1);
+    unsigned sg_lo = 0u, sg_hi = 0u;      // sign words of the current group of four planes (planes 0, 1 | 2, 3)
     // pixels outside the frame sample the frame's last pixel (valid addresses, results dropped): no branch around the loads
     const float px = (float)(a.col0 + min(x, a.W - 1)) + a.pc, py = (float)(a.row0 + min(y, a.H - 1)) + a.pc;
     const size_t frame_b = (size_t)a.Hs * a.Ws * (F16 ? 8 : 16), plane_stride_b = (size_t)a.T * frame_b;
@@ -1662,7 +1666,7 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
     typedef typename TapVal<F16, ORDER>::type tapv_t;
     tapv_t vA[4], vB[4];
-#define VL3D_PLANE(T_, V_, BUF_, D_)                                                                      \
+#define VL3D_PLANE(T_, V_, BUF_, S_)                                                                      \
     {                                                                                                     \
         const f4 o = shade2<ORDER, RACT, AACT>(T_, V_);                                                   \
         const f4 ol = inimg ? o * T_.cov : f4{0.f, 0.f, 0.f, 0.f};                                        \
@@ -1687,33 +1691,44 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
             sya += fabsf(df.w);                                                                           \
             code += reg_signs4(df) << 8;                                                                  \
         }                                                                                                 \
-        sgw |= (unsigned long long)(unsigned)code << (16 * ((D_) & 3));                                   \
-        if ((((D_) & 3) == 3 || (D_) == a.D - 1) && owner) { sg0[(size_t)((D_) >> 2) * sg_plane] = sgw; sgw = 0ull; }   \
+        if (S_ == 0) sg_lo = (unsigned)code;                                                              \
+        else if (S_ == 1) sg_lo |= (unsigned)code << 16;                                                  \
+        else if (S_ == 2) sg_hi = (unsigned)code;                                                         \
+        else {                                                                                            \
+            sg_hi |= (unsigned)code << 16;                                                                \
+            if (owner) *sgq = make_uint2(sg_lo, sg_hi);                                                   \
+            sgq += sg_plane;                                                                              \
+        }                                                                                                 \
     }
     Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy), tB = tA;
     load_taps2<F16>(plane, tA, st, vA);
-    for (int d = 0;; d += 2) {
-        {
-            const int dn = min(d + 1, a.D - 1);
-            float h[VL3D_HN];
-            load_uniform(a.homos + VL3D_HS * dn, h);
-            tB = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-            load_taps2<F16>(plane + (size_t)dn * plane_stride_b, tB, st, vB);
-            asm volatile("" ::: "memory");
-        }
-        VL3D_PLANE(tA, vA, 0, d)
-        if (d + 1 >= a.D) break;
-        {
-            const int dn = min(d + 2, a.D - 1);
-            float h[VL3D_HN];
-            load_uniform(a.homos + VL3D_HS * dn, h);
-            tA = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-            load_taps2<F16>(plane + (size_t)dn * plane_stride_b, tA, st, vA);
-            asm volatile("" ::: "memory");
-        }
-        VL3D_PLANE(tB, vB, 1, d + 1)
-        if (d + 2 >= a.D) break;
+#define VL3D_FETCH(T_, V_, DN_)                                                                           \
+    {                                                                                                     \
+        const int dn = min(DN_, a.D - 1);                                                                 \
+        float h[VL3D_HN];                                                                                 \
+        load_uniform(a.homos + VL3D_HS * dn, h);                                                          \
+        T_ = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);                    \
+        load_taps2<F16>(plane + (size_t)dn * plane_stride_b, T_, st, V_);                                 \
+        asm volatile("" ::: "memory");                                                                    \
     }
+    // four planes per trip: the slot of a plane inside its group of sign words is a compile-time constant
+    int d = 0;
+    for (;; d += 4) {
+        VL3D_FETCH(tB, vB, d + 1)
+        VL3D_PLANE(tA, vA, 0, 0)
+        if (d + 1 >= a.D) break;
+        VL3D_FETCH(tA, vA, d + 2)
+        VL3D_PLANE(tB, vB, 1, 1)
+        if (d + 2 >= a.D) break;
+        VL3D_FETCH(tB, vB, d + 3)
+        VL3D_PLANE(tA, vA, 0, 2)
+        if (d + 3 >= a.D) break;
+        VL3D_FETCH(tA, vA, d + 4)
+        VL3D_PLANE(tB, vB, 1, 3)
+        if (d + 4 >= a.D) break;
+    }
+    if ((a.D & 3) && owner) *sgq = make_uint2(sg_lo, (a.D & 3) == 3 ? sg_hi : 0u);      // the last, partial group
+#undef VL3D_FETCH
 #undef VL3D_PLANE
     if (owner) {
         const size_t pix = ((size_t)t * a.H + y) * a.W + x;
