@@ -267,6 +267,18 @@ int64_t vl3d_patchnn_scratch_bytes(const vl3d_loss_desc *desc);
 int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const float *y, int32_t *nn,
                  void *scratch, vl3d_stream_t stream);
 
+/* The captured clip y is constant training data (train_3dvid.py:22-66 crops it per iteration, MPV.py:506 hands the crop to the loss):
+ * vl3d_video_to_gram_major rewrites a whole clip [3,T,H,W] (element strides per channel / frame / row, unit column stride) ONCE into
+ * the NN kernel's own form (vl3d_gram_major_bytes(T, H, W) bytes), and vl3d_patchnn_prepared searches against the crop
+ * (y_row0, y_col0) + (desc->H, desc->W) of that buffer (rows of y_pitch pixels, y_rows of them; desc->Ty = T) without touching y again
+ * -- the y half of the per-iteration layout change (0.4 of the 2.7 ms of a 720p search) leaves the iteration.  Matrix-core kernel only
+ * (x <= 128, y <= 192 frames): VL3D_EUNSUPPORTED otherwise, and the caller falls back to vl3d_patchnn.  `scratch` as for vl3d_patchnn. */
+int64_t vl3d_gram_major_bytes(int32_t T, int32_t H, int32_t W);
+int vl3d_video_to_gram_major(const float *y, int64_t sc, int64_t st, int64_t sr, int32_t T, int32_t H, int32_t W, float *out,
+                             vl3d_stream_t stream);
+int vl3d_patchnn_prepared(const vl3d_loss_desc *desc, const float *x, const float *y_gram, int32_t y_pitch, int32_t y_rows,
+                          int32_t y_row0, int32_t y_col0, int32_t *nn, void *scratch, vl3d_stream_t stream);
+
 /* get_NN_indices_low_memory(X[B,n1,...], Y[B,n2,...], alpha, chunksz, 'mse') on MATERIALISED patches
  * (utils_vid.py:122-142; the caller evaluations/NNMSE.py:45-56 builds them with extract_3Dpatches).
  * X [B,n1,d], Y [B,n2,d] dense fp32; nn int64 [B,n1] like the reference's torch.long. */
@@ -296,6 +308,8 @@ int vl3d_vote_fold_robust(const vl3d_loss_desc *desc, const float *y, const int3
  * patch grid by slicing before the loss (utils_vid.py:307-320), so the gradient of the untrimmed x is zero outside the trimmed box:
  * the caller hands a zero-filled buffer of x's FULL shape and its strides, and the slice's backward (a zero fill and a copy per sliced
  * axis) never runs. */
+/* y2x and weight may both be NULL: the vote average then stays in registers (767 MB of stores less per 720p iteration; the loss
+ * classes materialise last_y2x / last_weight on first access through vl3d_vote_fold). */
 int vl3d_vote_fold_robust_strided(const vl3d_loss_desc *desc, const float *y, const int32_t *nn, const float *x, int32_t rho_kind,
                                   float rou, float scale, float *y2x, float *weight, float *grad_x, int64_t gx_sc, int64_t gx_st,
                                   int64_t gx_sr, double *loss_sum, vl3d_stream_t stream);

@@ -9,7 +9,7 @@ from videoloop3d_amd.utils_vid import Patch3DGPNNLowMemLoss
 dev = torch.device("cuda:0")
 x = torch.empty((1, 3, 52, 720, 1280), device=dev).uniform_().requires_grad_(True)
 y = torch.empty((1, 3, 75, 720, 1280), device=dev).uniform_()
-cfg = dict(macro_block=65, patch_size=11, stride=4, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=0.5)
+cfg = dict(macro_block=65, patch_size=11, stride=4, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=0)
 lm = Patch3DGPNNLowMemLoss()
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")

@@ -474,3 +474,28 @@ def test_alpha0_full_720p_frame_windows(dev):
         yc = y[..., r0:r0 + ps + 5 * s, c0:c0 + ps + 9 * s].cpu()
         nbad, unexplained = nn_mismatch_is_near_tie(xc, yc, ps, 3, s, 1, 0, nn[by:by + 6, bx:bx + 10].contiguous())
         assert unexplained == 0 and nbad <= 30
+
+
+def test_prepared_clip_crops_give_the_same_indices_and_loss(dev):
+    """PreparedClip: the captured clip rewritten once into the NN kernel's form; a crop is named by its origin.  Indices, loss and gradient
+    equal the per-call path bit for bit (same kernel, same operands), for crops at several origins incl. the clip's last rows / columns,
+    both shipped patch shapes; last_y2x / last_weight materialise on demand."""
+    from videoloop3d_amd.utils_vid import Patch3DGPNNLowMemLoss, PreparedClip, find_nn_indices
+    Ty, Hf, Wf, h, w = 20, 61, 90, 35, 47
+    clip = synth.make_video(Ty, Hf, Wf, seed=9, device=dev)
+    pc = PreparedClip(clip)
+    for (h0, w0) in ((0, 0), (13, 22), (Hf - h, Wf - w)):
+        y = clip[..., h0:h0 + h, w0:w0 + w]
+        x = synth.make_video(12, h, w, seed=10 + h0, device=dev).requires_grad_(True)
+        for ps, s, al in ((11, 4, 0), (3, 2, 10000)):
+            cfg = dict(macro_block=ps + 2 * s, patch_size=ps, stride=s, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=al)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                la, lb = Patch3DGPNNLowMemLoss(), Patch3DGPNNLowMemLoss()
+                a = la(x, y, **cfg)
+                b = lb(x, y, y_prepared=pc.crop(h0, w0), **cfg)
+            (ga,), (gb,) = torch.autograd.grad(a, x), torch.autograd.grad(b, x)
+            assert float(a) == float(b) and torch.equal(ga, gb)
+            assert torch.equal(la.last_y2x, lb.last_y2x) and torch.equal(la.last_weight, lb.last_weight)
+    with pytest.raises(RuntimeError, match="leaves the prepared clip"):
+        find_nn_indices(x.detach()[..., :35, :47], clip[..., :35, :47], 3, 3, 2, 1, None, y_prepared=pc.crop(Hf - 10, 0))

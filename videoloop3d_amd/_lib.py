@@ -72,6 +72,9 @@ SIGNATURES = {
     "vl3d_overcompose_nto0_bwd": ([_I32, _I32, _I32, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _P, _P], C.c_int),
     "vl3d_patchnn_scratch_bytes": ([C.POINTER(LossDesc)], C.c_int64),
     "vl3d_patchnn": ([C.POINTER(LossDesc), _P, _P, _P, _P, _P], C.c_int),
+    "vl3d_gram_major_bytes": ([_I32, _I32, _I32], C.c_int64),
+    "vl3d_video_to_gram_major": ([_P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _P], C.c_int),
+    "vl3d_patchnn_prepared": ([C.POINTER(LossDesc), _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P], C.c_int),
     "vl3d_nn_vectors": ([_I64, _I32, _I32, _I32, _P, _P, _I32, _F, _P, _P], C.c_int),
     "vl3d_patch_l1": ([C.POINTER(LossDesc), _P, _P, _P, _P, _P], C.c_int),
     "vl3d_vote_fold": ([C.POINTER(LossDesc), _P, _P, _P, _P, _I32, _P], C.c_int),

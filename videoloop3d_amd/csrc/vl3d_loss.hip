@@ -158,6 +158,7 @@ struct NN2Args {
     int W, ps, pt, stride, stridet, h_o, w_o, n1, n2;
     int TxP, TyP, K, KC;
     int PX, PY;             // v5: frames per pixel of the gram-major copies (padded to whole 16-frame groups)
+    int Wy;                 // v5: pixels per row of the gram-major y (== W, or the full frame's width when y is a crop of a prepared clip)
     int use_alpha;
     float alpha, dnorm;
     int ablate;   // measurement only: 1 skip epilogue, 2 skip compute, 4 skip staging loads
@@ -678,14 +679,14 @@ __global__ __launch_bounds__(64 * NW, 2) void patchnn5_k(NN2Args a, int groups_x
 #pragma unroll
     for (int k = 0; k < KY; ++k) {
         const int idx = (wave + NW * k) * 64 + lane, cc = fdiv_small(idx, a.ps * PY), rem = idx - cc * a.ps * PY, r = fdiv_small(rem, PY);
-        offy[k] = idx < ys4 ? ((r * a.W + cc) * PY + (rem - r * PY)) | (cc << 24) : -1;
+        offy[k] = idx < ys4 ? ((r * a.Wy + cc) * PY + (rem - r * PY)) | (cc << 24) : -1;
     }
     const int S = (cols + CHC - 1) / CHC;                       // stages
     auto issue = [&](int st) {
         const int q0 = st * CHC, nc = min(CHC, cols - q0);
         float *dst = smem + (st & 1) * bufF;
         const float4 *xsrc = reinterpret_cast<const float4 *>(a.xt) + ((size_t)r0 * a.W + c0 + q0) * PX;
-        const float4 *ysrc = reinterpret_cast<const float4 *>(a.yt) + ((size_t)r0 * a.W + c0 + q0) * PY;
+        const float4 *ysrc = reinterpret_cast<const float4 *>(a.yt) + ((size_t)r0 * a.Wy + c0 + q0) * PY;
 #pragma unroll
         for (int k = 0; k < KX; ++k)
             if (offx[k] >= 0 && (offx[k] >> 24) < nc) lds_dma16(xsrc + (offx[k] & 0xffffff), dst + (wave + NW * k) * 256);
@@ -996,7 +997,7 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
     const int bx_hi = min(a.w_o - 1, xi / a.stride), bx_lo = max(0, (xi - a.ps + a.stride) / a.stride);
     const int npatch = (by_hi - by_lo + 1) * (bx_hi - bx_lo + 1);
     const size_t cs = (size_t)a.Tx * a.H * a.W, fs = (size_t)a.H * a.W;
-    float *out = a.sum + (size_t)c * cs + (size_t)eta * a.W + xi;
+    float *out = a.sum + (size_t)c * cs + (size_t)eta * a.W + xi;      // (a.sum == nullptr, fused loss only: y2x / weight stay in registers)
     float *wout = a.weight + (size_t)eta * a.W + xi;
     const int *nn0 = nns + ((by_lo - tby0) * nbx + (bx_lo - tbx0)) * a.n1;
     const float *ysp = ys + pix;
@@ -1039,8 +1040,10 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
         }
         const float wgt = fmaxf((float)cnt, 1e-10f);                  // utils_vid.py:228
         const float v = a.normalize ? s / wgt : s;
-        out[(size_t)tau * fs] = v;
-        if (c == 0) wout[(size_t)tau * fs] = wgt;
+        if (a.sum) {      // uniform
+            out[(size_t)tau * fs] = v;
+            if (c == 0) wout[(size_t)tau * fs] = wgt;
+        }
         if (a.x) {      // robust_lossfun(x - y2x) and its derivative while y2x is in a register (utils_vid.py:348)
             const float e = xq0 - v;
             xq0 = xq1; xq1 = xq2; xq2 = xq3; xq3 = xload(tau + 4 * tstep);
@@ -1152,16 +1155,20 @@ extern "C" int64_t vl3d_patchnn_scratch_bytes(const vl3d_loss_desc *d) {
     return (int64_t)d->H * d->W * 4 * (pad16(TxU) + pad16(d->Ty)) * (int64_t)sizeof(float);   // the gram-major form (v5): 4 floats per pixel and frame, whole 16-frame groups
 }
 
-extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const float *y, int32_t *nn, void *scratch,
-                            vl3d_stream_t stream) {
+// y_gram != nullptr: y arrives in the NN kernel's own gram-major form (vl3d_video_to_gram_major), as the crop at (y_row0, y_col0) of a
+// clip whose rows are y_pitch pixels long -- the captured video is constant training data, so it is rewritten once per pyramid level and
+// not once per iteration
+static int patchnn_impl(const vl3d_loss_desc *desc, const float *x, const float *y, const float *y_gram, int32_t y_pitch, int32_t y_row0,
+                        int32_t y_col0, int32_t *nn, void *scratch, vl3d_stream_t stream) {
     int rc = check_loss(desc);
     if (rc != VL3D_OK) return rc;
-    VL3D_REQUIRE(x && y && nn, "vl3d_patchnn: null pointer");
+    VL3D_REQUIRE(x && (y || y_gram) && nn, "vl3d_patchnn: null pointer");
     NNArgs a{};
     size_t lds = 0;
     rc = plan_nn(desc, a, lds);
     if (rc != VL3D_OK) return rc;
-    if (scratch != nullptr && (desc->variant & 0xf) != 1) {
+    VL3D_REQUIRE(!y_gram || scratch, "vl3d_patchnn_prepared: needs the scratch buffer (x's gram-major copy)");
+    if (scratch != nullptr && ((desc->variant & 0xf) != 1 || y_gram)) {
         // pixel-major (v2 / v4) or gram-major (v5) copies in the caller's scratch, then the coalesced-staging kernel
         hipStream_t s = (hipStream_t)stream;
         const int pv = desc->variant & 0xf;
@@ -1187,16 +1194,23 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
         // 122 x 180: 38 | 14, 52 x 120: 124 | 93; the one-location instantiation loses to v4's running sums where v4 still has a tile per
         // thread: 82 x 150: 41 | 56 -- v4 there)
         const bool v4_has_tiles = (size_t)(a.TxP / TI) * (a.TyP / TJ) <= 1024;
-        const bool use_v5 = (pv == 3 || (pv == 0 && !(nl5 == 1 && v4_has_tiles))) && PX <= 128 && TyT <= 12 && lds5 <= 150 * 1024 && fits5;
+        const int Wy = y_gram ? y_pitch : desc->W;
+        const bool fits5y = ((size_t)a.ps * Wy + ch5) * (size_t)PY < (1u << 24);
+        const bool use_v5 = (y_gram || pv == 3 || (pv == 0 && !(nl5 == 1 && v4_has_tiles))) && PX <= 128 && TyT <= 12 && lds5 <= 150 * 1024 && fits5 && fits5y;
+        if (y_gram && !use_v5) {
+            vl3d_set_error("vl3d_patchnn_prepared: these clip lengths / this frame width are outside the matrix-core kernel's range; use vl3d_patchnn");
+            return VL3D_EUNSUPPORTED;
+        }
         float *xt = (float *)scratch;
-        float *yt = xt + (size_t)desc->H * desc->W * (use_v5 ? 4 * PX : 3 * a.TxP);
+        float *yt = y_gram ? const_cast<float *>(y_gram) + ((size_t)y_row0 * Wy + y_col0) * 4 * PY
+                           : xt + (size_t)desc->H * desc->W * (use_v5 ? 4 * PX : 3 * a.TxP);
         dim3 tg((desc->W + 63) / 64, desc->H);
         // variant bit 8: the y half of the scratch still holds this y from the previous call (the captured video is constant
         // over the iterations of the training loop; the caller keeps the scratch alive and vouches for it)
         if (use_v5) {
             hipLaunchKernelGGL(video_to_gram_major_k<false>, tg, dim3(256), 0, s, x, desc->x_sc, desc->x_st, desc->x_sr, a.TxU, PX / 16,
                                desc->H, desc->W, xt);
-            if (!(desc->variant & 0x100))
+            if (!y_gram && !(desc->variant & 0x100))
                 hipLaunchKernelGGL(video_to_gram_major_k<true>, tg, dim3(256), 0, s, y, desc->y_sc, desc->y_st, desc->y_sr, desc->Ty, PY / 16,
                                    desc->H, desc->W, yt);
         } else {
@@ -1210,7 +1224,7 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
         b.xt = xt; b.yt = yt; b.nn = nn; b.W = desc->W; b.ps = a.ps; b.pt = a.pt; b.stride = a.stride; b.stridet = a.stridet;
         b.h_o = a.h_o; b.w_o = a.w_o; b.n1 = a.n1; b.n2 = a.n2; b.TxP = a.TxP; b.TyP = a.TyP; b.K = a.K; b.KC = a.KC;
         b.use_alpha = a.use_alpha; b.alpha = a.alpha; b.dnorm = a.inv_d;
-        b.PX = PX; b.PY = PY;
+        b.PX = PX; b.PY = PY; b.Wy = Wy;
         b.ablate = (desc->variant >> 4) & 15;
         static bool attr2 = false;
         if (!attr2) {
@@ -1276,6 +1290,32 @@ extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const fl
     hipLaunchKernelGGL(patchnn_k, dim3((unsigned)(a.h_o * a.w_o)), dim3(NN_THREADS), lds, (hipStream_t)stream, a);
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
+}
+
+extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const float *y, int32_t *nn, void *scratch,
+                            vl3d_stream_t stream) {
+    return patchnn_impl(desc, x, y, nullptr, 0, 0, 0, nn, scratch, stream);
+}
+
+extern "C" int64_t vl3d_gram_major_bytes(int32_t T, int32_t H, int32_t W) {
+    if (T <= 0 || H <= 0 || W <= 0) return 0;
+    return (int64_t)H * W * 4 * pad16(T) * (int64_t)sizeof(float);
+}
+
+extern "C" int vl3d_video_to_gram_major(const float *y, int64_t sc, int64_t st, int64_t sr, int32_t T, int32_t H, int32_t W, float *out,
+                                        vl3d_stream_t stream) {
+    VL3D_REQUIRE(y && out && T > 0 && H > 0 && W > 0, "vl3d_video_to_gram_major: null pointer / non-positive dims");
+    hipLaunchKernelGGL(video_to_gram_major_k<true>, dim3((W + 63) / 64, H), dim3(256), 0, (hipStream_t)stream, y, sc, st, sr, T, pad16(T) / 16, H, W, out);
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
+extern "C" int vl3d_patchnn_prepared(const vl3d_loss_desc *desc, const float *x, const float *y_gram, int32_t y_pitch, int32_t y_rows,
+                                     int32_t y_row0, int32_t y_col0, int32_t *nn, void *scratch, vl3d_stream_t stream) {
+    VL3D_REQUIRE(desc && y_gram, "vl3d_patchnn_prepared: null pointer");
+    VL3D_REQUIRE(y_row0 >= 0 && y_col0 >= 0 && y_row0 + desc->H <= y_rows && y_col0 + desc->W <= y_pitch,
+                 "vl3d_patchnn_prepared: the crop (y_row0, y_col0) + (H, W) leaves the prepared clip (y_rows, y_pitch)");
+    return patchnn_impl(desc, x, nullptr, y_gram, y_pitch, y_row0, y_col0, nn, scratch, stream);
 }
 
 // LDS-staged fold: tile shapes {FT_W, FT_H, threads}.  The whole Ty column of a tile has to sit in LDS (an NN index may point at
@@ -1364,7 +1404,8 @@ extern "C" int vl3d_vote_fold_robust_strided(const vl3d_loss_desc *desc, const f
                                              int64_t gx_st, int64_t gx_sr, double *loss_sum, vl3d_stream_t stream) {
     int rc = check_loss(desc);
     if (rc != VL3D_OK) return rc;
-    VL3D_REQUIRE(y && nn && x && y2x && weight && grad_x && loss_sum, "vl3d_vote_fold_robust: null pointer");
+    VL3D_REQUIRE(y && nn && x && grad_x && loss_sum, "vl3d_vote_fold_robust: null pointer");
+    VL3D_REQUIRE((y2x == nullptr) == (weight == nullptr), "vl3d_vote_fold_robust: y2x and weight are written together or not at all");
     VL3D_REQUIRE(kind >= 0 && kind <= 2 && scale != 0.0f, "vl3d_vote_fold_robust: bad rho kind / scale");
     VL3D_REQUIRE(gx_sr >= desc->W && gx_st >= 0 && gx_sc >= 0, "vl3d_vote_fold_robust: bad grad_x strides");
     VL3D_REQUIRE(desc->Tx <= 65535, "vl3d_vote_fold_robust: Tx > 65535");

@@ -71,7 +71,7 @@ class MVVidPatchDataset:
     """train_3dvid.py:22-66 on resident tensors.  `videos`: list of [F,3,h_raw,w_raw] float tensors in [0,1] (any device);
     `poses` [V,3|4,4], `intrins` [V,3,3] for the raw resolution.  Items are (w_start, h_start, pose, intrin, crop, cfg)."""
 
-    def __init__(self, resize_hw, videos, patch_size, patch_stride, poses, intrins, loss_configs=None):
+    def __init__(self, resize_hw, videos, patch_size, patch_stride, poses, intrins, loss_configs=None, prepare=True):
         h_raw, w_raw = videos[0].shape[-2:]
         self.h, self.w = resize_hw
         self.v = len(videos)
@@ -93,6 +93,12 @@ class MVVidPatchDataset:
             if vid.shape[-2:] != (self.h, self.w):
                 vid = torchf.interpolate(vid, size=(self.h, self.w), mode="bilinear", align_corners=False)
             self.videos.append(torchf.pad(vid, pad_info))
+        # the captured clips are constant over a pyramid level: their layout change for the NN search happens HERE, once per view,
+        # and an iteration names its crop by origin (utils_vid.PreparedClip; videos resident on the GPU only)
+        self.prepared = None
+        if prepare and all(v.is_cuda for v in self.videos):
+            from .utils_vid import PreparedClip
+            self.prepared = [PreparedClip(v.permute(1, 0, 2, 3)) for v in self.videos]
         print(f"Dataset: generate {len(self)} patches for training, pad {pad_info} to videos")
 
     def __len__(self):
@@ -103,7 +109,10 @@ class MVVidPatchDataset:
         vi = self.view_index[item]
         intrin = get_new_intrin(self.intrins[vi], h_start, w_start).float()
         crop = self.videos[vi][..., h_start:h_start + self.patch_h_size, w_start:w_start + self.patch_w_size]
-        return w_start, h_start, self.poses[vi], intrin, crop, deepcopy(self.loss_configs[vi])
+        cfg = deepcopy(self.loss_configs[vi])
+        if self.prepared is not None and str(cfg.get("loss_name", "")).startswith("gpnn"):
+            cfg["y_prepared"] = self.prepared[vi].crop(h_start, w_start)      # (the loss classes take it; the others ignore it via **kwargs)
+        return w_start, h_start, self.poses[vi], intrin, crop, cfg
 
 
 def _collate1(cfg):

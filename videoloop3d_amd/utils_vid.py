@@ -93,10 +93,41 @@ def _as_video(v, name):
     return v
 
 
-def find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha, y_is_constant=False):
+class PreparedClip:
+    """A captured clip in the NN kernel's own (gram-major) form, built ONCE: y is constant training data (the reference crops it per
+    iteration, train_3dvid.py:22-66, and hands the crop to the loss, MPV.py:506), so its layout change belongs to the dataset, not to
+    the iteration.  `clip` [1,3,T,H,W] (or [3,T,H,W]) float32 on the GPU; `crop(h0, w0)` names a crop origin: pass it to the loss
+    classes as keyword `y_prepared` NEXT TO the crop tensor itself (the vote-fold still reads the original layout through strides).
+    The caller vouches that the clip's bytes do not change afterwards."""
+
+    def __init__(self, clip):
+        v = clip[0] if clip.dim() == 5 else clip
+        L.check_cuda(v)
+        if v.dim() != 4 or v.shape[0] != 3:
+            raise RuntimeError(f"clip must be [1,3,T,H,W] or [3,T,H,W], got {tuple(clip.shape)}")
+        v = v.float()
+        if v.stride(-1) != 1:
+            v = v.contiguous()
+        self.T, self.H, self.W = (int(n) for n in v.shape[1:])
+        with torch.cuda.device(v.device):
+            self.gram = torch.empty(int(L.lib().vl3d_gram_major_bytes(self.T, self.H, self.W)) // 4, dtype=torch.float32, device=v.device)
+            L.check(L.lib().vl3d_video_to_gram_major(L.ptr(v), v.stride(0), v.stride(1), v.stride(2), self.T, self.H, self.W, L.ptr(self.gram),
+                                                     L.stream_ptr(v.device)), "vl3d_video_to_gram_major")
+
+    def crop(self, h0, w0):
+        return ClipCrop(self, int(h0), int(w0))
+
+
+class ClipCrop:
+    def __init__(self, clip, h0, w0):
+        self.clip, self.h0, self.w0 = clip, h0, w0
+
+
+def find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha, y_is_constant=False, y_prepared=None):
     """Per-location temporal NN search on videos x,y [1,3,T,h,w] (already trimmed).  Returns int32 [h_o,w_o,n1].
     y_is_constant: the caller vouches that y's bytes have not changed since the previous call with the same y tensor, so its
-    pixel-major copy inside the scratch may be reused (see _patchnn_scratch)."""
+    pixel-major copy inside the scratch may be reused (see _patchnn_scratch).
+    y_prepared: a ClipCrop -- y is the crop at that origin of a PreparedClip, whose gram-major form is read in place."""
     L.check_cuda(x, y)
     xv, yv = _as_video(x.detach(), "x"), _as_video(y.detach(), "y")
     if xv.shape[2:] != yv.shape[2:]:
@@ -106,6 +137,19 @@ def find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha, y_is_
     w_o = (desc.W - desc.ps) // desc.stride + 1
     n1 = (desc.Tx - desc.pt) // desc.stridet + 1
     nn = torch.empty((h_o, w_o, n1), dtype=torch.int32, device=xv.device)
+    if y_prepared is not None:
+        c = y_prepared.clip
+        if c.T != desc.Ty or c.gram.device != xv.device:
+            raise RuntimeError("y_prepared does not belong to this y (frames / device)")
+        with torch.cuda.device(xv.device):
+            nscratch = int(L.lib().vl3d_patchnn_scratch_bytes(desc))
+            scratch, _ = _patchnn_scratch(nscratch, yv, desc, xv.device, False)
+            rc = L.lib().vl3d_patchnn_prepared(desc, L.ptr(xv), L.ptr(c.gram), c.W, c.H, y_prepared.h0, y_prepared.w0, L.ptr(nn), L.ptr(scratch),
+                                               L.stream_ptr(xv.device))
+        if rc == 0:
+            return nn, desc, xv, yv
+        if rc != 3:          # VL3D_EUNSUPPORTED: clip lengths outside the matrix-core kernel -> the general path below
+            L.check(rc, "vl3d_patchnn_prepared")
     with torch.cuda.device(xv.device):
         nscratch = int(L.lib().vl3d_patchnn_scratch_bytes(desc))
         scratch, y_cached = _patchnn_scratch(nscratch, yv, desc, xv.device, y_is_constant)
@@ -232,31 +276,41 @@ class _FoldRobustMean(torch.autograd.Function):
     copy of the whole video each) never run."""
 
     @staticmethod
-    def forward(ctx, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant=False, trim=None):
+    def forward(ctx, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant=False, trim=None, holder=None,
+                y_prepared=None):
         xs = x if trim is None else x[..., :trim[0], :trim[1], :trim[2]]
-        nn, desc, xv, yv = find_nn_indices(xs, y, patch_size, patcht_size, stride, stridet, alpha, y_is_constant)
+        nn, desc, xv, yv = find_nn_indices(xs, y, patch_size, patcht_size, stride, stridet, alpha, y_is_constant, y_prepared)
         dev = xv.device
-        y2x = torch.empty((1, 3, desc.Tx, desc.H, desc.W), dtype=torch.float32, device=dev)
-        w = torch.empty((1, 1, desc.Tx, desc.H, desc.W), dtype=torch.float32, device=dev)
-        if tuple(xs.shape) == tuple(x.shape):
-            gx = torch.empty((1, 3, desc.Tx, desc.H, desc.W), dtype=torch.float32, device=dev)
-        else:
-            gx = torch.zeros(x.shape, dtype=torch.float32, device=dev)
+        gx = torch.empty(x.shape, dtype=torch.float32, device=dev)
+        if tuple(xs.shape) != tuple(x.shape):
+            # the gradient of the untrimmed x is zero outside the trimmed box: only that border is filled (a fill of the whole
+            # video was 0.12 ms of a 720p iteration)
+            gx[..., trim[0]:, :, :] = 0
+            gx[..., :, trim[1]:, :] = 0
+            gx[..., :, :, trim[2]:] = 0
         acc = torch.empty((), dtype=torch.float64, device=dev)
         kind, r = _rho_kind(rou)
         with torch.cuda.device(dev):
-            L.check(L.lib().vl3d_vote_fold_robust_strided(desc, L.ptr(yv), L.ptr(nn), L.ptr(xv), kind, r, float(scaling), L.ptr(y2x),
-                                                          L.ptr(w), L.ptr(gx), gx.stride(1), gx.stride(2), gx.stride(3), L.ptr(acc),
+            # y2x / weight are NOT written here (767 MB of stores per 720p iteration that no caller of the reference reads:
+            # utils_vid.py:345-346 caches them for `same_input`, which nothing sets); `holder` recomputes them on first access
+            L.check(L.lib().vl3d_vote_fold_robust_strided(desc, L.ptr(yv), L.ptr(nn), L.ptr(xv), kind, r, float(scaling), None,
+                                                          None, L.ptr(gx), gx.stride(1), gx.stride(2), gx.stride(3), L.ptr(acc),
                                                           L.stream_ptr(dev)), "vl3d_vote_fold_robust_strided")
+        if holder is not None:
+            holder._lazy = (desc, yv, nn)
         ctx.save_for_backward(gx)
         ctx.x_dtype = x.dtype
-        ctx.mark_non_differentiable(y2x, w)
-        return (acc / (3 * desc.Tx * desc.H * desc.W)).to(torch.float32), y2x, w
+        return (acc / (3 * desc.Tx * desc.H * desc.W)).to(torch.float32)
 
     @staticmethod
-    def backward(ctx, g, _gy2x, _gw):
+    def backward(ctx, g):
         (gx,) = ctx.saved_tensors
-        return (gx * g.to(torch.float32)).to(ctx.x_dtype), None, None, None, None, None, None, None, None, None, None
+        # scaled IN PLACE (the buffer belongs to this node; an out-of-place product is one more pass over the video, 0.2 ms at 720p),
+        # so the node can be differentiated once
+        if getattr(ctx, "consumed", False):
+            raise RuntimeError("the fused looping loss keeps its gradient buffer in place: backward through it a second time needs a new forward")
+        ctx.consumed = True
+        return gx.mul_(g.to(torch.float32)).to(ctx.x_dtype), None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def fit_patch(size, name, patch, step):
@@ -268,7 +322,7 @@ def fit_patch(size, name, patch, step):
     return trimmed
 
 
-def _gpnn_loss(holder, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant=False, trim=None):
+def _gpnn_loss(holder, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant=False, trim=None, y_prepared=None):
     """NN search + vote-fold + robust mean, fused (one pass over the video for fold, loss and gradient); falls back to the
     separate kernels when a fold tile does not fit LDS, or when x does not fit the patch grid (direct path only: the LowMem class
     trims first).  Caches y2x / weight on `holder` like the reference (utils_vid.py:345-346)."""
@@ -277,7 +331,9 @@ def _gpnn_loss(holder, x, y, patch_size, patcht_size, stride, stridet, alpha, ro
     try:
         if not fits_grid:
             raise RuntimeError("x does not fit the patch grid: unfused path")
-        loss, y2x, weight = _FoldRobustMean.apply(x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant, trim)
+        loss = _FoldRobustMean.apply(x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant, trim, holder, y_prepared)
+        holder._y2x = holder._weight = None
+        return loss
     except RuntimeError as e:
         if "does not fit LDS" not in str(e) and "does not fit the patch grid" not in str(e):
             raise
@@ -291,7 +347,43 @@ def _gpnn_loss(holder, x, y, patch_size, patcht_size, stride, stridet, alpha, ro
     return loss
 
 
-class Patch3DGPNNDirectLoss:
+class _LazyVotes:
+    """last_y2x / last_weight of the loss classes (utils_vid.py:345-346).  The fused kernel keeps the vote average in registers; the
+    two tensors are produced from the saved NN indices on first access (vl3d_vote_fold, the same kernel without the loss)."""
+    _lazy = None
+    _y2x = None
+    _weight = None
+
+    def _materialise(self):
+        if self._y2x is None and self._lazy is not None:
+            desc, yv, nn = self._lazy
+            dev = yv.device
+            s = torch.empty((1, 3, desc.Tx, desc.H, desc.W), dtype=torch.float32, device=dev)
+            w = torch.empty((1, 1, desc.Tx, desc.H, desc.W), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                L.check(L.lib().vl3d_vote_fold(desc, L.ptr(yv), L.ptr(nn), L.ptr(s), L.ptr(w), 1, L.stream_ptr(dev)), "vl3d_vote_fold")
+            self._y2x, self._weight = s, w
+
+    @property
+    def last_y2x(self):
+        self._materialise()
+        return self._y2x
+
+    @last_y2x.setter
+    def last_y2x(self, v):
+        self._y2x, self._lazy = v, None
+
+    @property
+    def last_weight(self):
+        self._materialise()
+        return self._weight
+
+    @last_weight.setter
+    def last_weight(self, v):
+        self._weight = v
+
+
+class Patch3DGPNNDirectLoss(_LazyVotes):
     """utils_vid.py:265-286.  Like the reference's, this path takes x of ANY size: UnfoldNd floors the patch grid and FoldNd
     leaves the voxels beyond the last whole patch without a vote (y2x = 0, weight 1e-10), and the loss mean runs over all of x
     -- `loss_name='gpnn'` is the parser default and an even crop size with the default stride 2 is legal there.
@@ -299,8 +391,7 @@ class Patch3DGPNNDirectLoss:
     of y from the previous call with the same tensor."""
 
     def __init__(self):
-        self.last_y2x = None
-        self.last_weight = None
+        self._lazy = self._y2x = self._weight = None
 
     def __call__(self, x, y, mask=None, same_input=False, rou=0, scaling=0.2, **kwargs):
         if same_input:
@@ -311,16 +402,15 @@ class Patch3DGPNNDirectLoss:
         if kwargs.get("dist_fn", "mse") != "mse":
             raise RuntimeError("dist_fn other than 'mse' is not settable in the reference")
         return _gpnn_loss(self, x, y, cfg["patch_size"], cfg["patcht_size"], cfg["stride"], cfg["stridet"], alpha, rou, scaling,
-                          bool(kwargs.get("y_is_constant", False)))
+                          bool(kwargs.get("y_is_constant", False)), None, kwargs.get("y_prepared"))
 
 
-class Patch3DGPNNLowMemLoss:
+class Patch3DGPNNLowMemLoss(_LazyVotes):
     """utils_vid.py:289-349.  `macro_block` is accepted and fitted (with the reference's warning) but no
     macro-block loop is needed: the HIP path has no unfold memory to cap and the result is identical."""
 
     def __init__(self):
-        self.last_y2x = None
-        self.last_weight = None
+        self._lazy = self._y2x = self._weight = None
 
     def __call__(self, x, y, mask=None, same_input=False, macro_block=64, patch_size=7, stride=2, patcht_size=7,
                  stridet=2, rou=0, scaling=0.2, **kwargs):
@@ -341,7 +431,7 @@ class Patch3DGPNNLowMemLoss:
             # x is trimmed INSIDE the fused op (same values as slicing here, utils_vid.py:318): its gradient comes back in x's full shape
             trim = None if (t, h, w) == tuple(x.shape[-3:]) else (t, h, w)
             return _gpnn_loss(self, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling,
-                              bool(kwargs.get("y_is_constant", False)), trim)
+                              bool(kwargs.get("y_is_constant", False)), trim, kwargs.get("y_prepared"))
         return _RobustMean.apply(x, y2x, rou, scaling)
 
 
