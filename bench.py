@@ -316,7 +316,7 @@ def main():
     def roof(name, nbytes, ms):
         ach = nbytes / (ms * 1e-3) / 1e9
         return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": None, "avg_ms": ms, "algorithmic_bytes": nbytes}
+                "traffic": None, "traffic_source": None, "avg_ms": ms, "algorithmic_bytes": nbytes}
     r_f = roof("render_fwd2x_k", fwd_bytes, f_ms)
     r_b = roof("render_bwd_pair_k (+bwd_plan_k, bwd_owner_table_k, bwd_windows_k)", bwd_bytes, b_ms)
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -326,6 +326,8 @@ def main():
             key = f"D{D}_T{T}_{H}x{W}_{a.spec}_v{a.variant}"
             if key in tr and world == 1:
                 r_f["traffic"], r_b["traffic"] = tr[key].get("fwd"), tr[key].get("bwd")
+                # NOT a measurement of this run: the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs) of the same command
+                r_f["traffic_source"] = r_b["traffic_source"] = "profiles/pmc_traffic.json (" + str(tr.get("_source", "rocprofv3 --pmc passes, profiles/run_profiles.sh")) + ")"
         except Exception:
             pass
     dominant = r_b if b_ms >= f_ms else r_f

@@ -107,6 +107,43 @@ def test_forward_eval_and_frame_subset(dev):
             assert float((rgb.cpu() - rgb_o).abs().max()) <= 1e-4
 
 
+def test_render_variables_on_request(dev):
+    """render(..., need_layers=True): `mpi` in the reference's hit-slot order (MPV.py:441-449) and `blend_weight` (MPV.py:451-453), whose
+    composite is the fused kernel's image and whose sum is `alpha` (MPV.py:454); off-centre camera so plane edges cross the view."""
+    from oracle import mpi_oracle as MO
+    from videoloop3d_amd.MPV import MPMeshVid
+    H, W = 44, 60
+    K, ref_extrin, tar = scene(H, W)
+    tar = tar.copy()
+    tar[:3, 3] = [0.35, 0.2, 0.0]
+    model = MPMeshVid(make_args(), H, W, ref_extrin, K, 1.0, 100.0).to(dev).eval()
+    with torch.no_grad():
+        model.stack.copy_(synth.make_plane_stack(*model.stack.shape[:4], seed=5))
+        extr = torch.tensor(tar)[None].to(dev) @ torch.tensor(ref_extrin)[None].inverse().to(dev)
+        rgb, v = model.render(H, W, extr, torch.tensor(K)[None].to(dev), torch.arange(model.frm_num), need_layers=True)
+        homos = model.plane_homographies(extr, torch.tensor(K)[None].to(dev)).cpu().float()
+    spec = MO.RenderSpec(pixel_center=0.5, coord_mode="affine", border="hardcut", act_order="post")
+    rgb_o, alpha_o, bw_o, slots = MO.render_planes(model.stack.detach().cpu(), homos, H, W, spec, return_layers=True)
+    assert v["mpi"].shape == slots.shape and float((v["mpi"].cpu() - slots).abs().max()) <= 1e-4
+    bw = v["blend_weight"]
+    assert float(((bw[..., None] * v["mpi"][..., :3]).sum(-2) - rgb).abs().max()) <= 1e-4
+    assert float((bw.sum(-1) - v["alpha"]).abs().max()) <= 1e-4
+    assert float((slots[..., 3] == 0).float().mean()) > 0.02      # some slots are empty: plane edges are inside the view
+
+
+def test_product_library_refuses_timing_only_variants(dev):
+    """desc->variant bits 4-7 (ablations that skip parts of a kernel: wrong results) exist only in a -DVL3D_VARIANTS measurement
+    build; the product returns VL3D_EINVAL for them on every entry point that takes a descriptor."""
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    stack = synth.make_plane_stack(2, 1, 8, 8, seed=1).to(dev)
+    with pytest.raises(RuntimeError, match="VL3D_VARIANTS"):
+        render_planes(stack, torch.eye(3).repeat(2, 1, 1).to(dev), 4, 4, RenderSpec.mpv(variant=0x10))
+    from videoloop3d_amd import _lib as L
+    d = L.LossDesc()
+    d.Tx, d.Ty, d.H, d.W, d.ps, d.pt, d.stride, d.stridet, d.variant = 4, 4, 8, 8, 3, 3, 1, 1, 0x40
+    assert L.lib().vl3d_patchnn(d, None, None, None, None, L.stream_ptr(dev)) == 1
+
+
 def test_atlas_roundtrip():
     from videoloop3d_amd.MPV import atlas_to_stack, stack_to_atlas
     atlas = torch.arange(3 * 4 * 10 * 28, dtype=torch.float32).reshape(3, 4, 10, 28)   # T=3, grid 2x4 of 5x7 cells

@@ -16,14 +16,13 @@ geometry -- which is all the shipped configs ever produce (vertices get no gradi
     (videoloop3d_amd/export.py).
 """
 import dataclasses
-import os
 
 import numpy as np
 import torch
 import torch.nn as nn
 
 from .render import RenderSpec, render_planes, render_planes_with_regularisers
-from .utils_mpi import compute_homography, make_depths, warp_homography
+from .utils_mpi import compute_homography, make_depths, overcompose, warp_homography
 from .utils_vid import Patch3DAvg, Patch3DGPNNDirectLoss, Patch3DGPNNLowMemLoss, Patch3DMSE
 
 # activations the HIP kernels implement (subset of MPI.py:21-31; shipped configs use sigmoid/sigmoid)
@@ -71,6 +70,7 @@ class MPMeshVid(nn.Module):
         A parity mode for weights that come from / go to the reference (atlas_to_stack / stack_to_atlas); needs args.atlas_grid_h."""
         super().__init__()
         self.atlas_exact = bool(atlas_exact)
+        self.per_plane_boxes = True      # crop-aware optimiser: each plane's own texel box inside the crop's window (optim.WindowAdam); False = the union window for every plane
         self.atlas_grid_h = int(getattr(args, "atlas_grid_h", 1))
         if self.atlas_exact and args.mpi_d % self.atlas_grid_h != 0:
             raise RuntimeError("mpi_d and atlas_grid_h should match")                                    # MPV.py:38
@@ -375,7 +375,7 @@ class MPMeshVid(nn.Module):
                 (y0, x0, wh, ww), boxes = self.crop_window(homos.detach().cpu(), H, W, per_plane=True)
                 if wh > 0 and ww > 0:
                     cull_window = (y0, x0) + tuple(self.stack.shape[2:4])
-                    stack = self._window_opt.window_leaf((y0, x0, wh, ww), None if os.environ.get("VL3D_NO_PLANE_BOXES") else boxes)
+                    stack = self._window_opt.window_leaf((y0, x0, wh, ww), boxes if self.per_plane_boxes else None)
                     spec = dataclasses.replace(spec, offset=(spec.offset[0] - x0, spec.offset[1] - y0))
             else:
                 self._flush_deferred_updates()
@@ -401,8 +401,13 @@ class MPMeshVid(nn.Module):
         variables = {"pix_to_face": None, "blend_weight": None, "mpi": None, "disp_norm": None, "alpha": alpha,
                      "smooth_sums": smooth_sums, "alpha_sums": alpha_sums}
         if need_layers:
+            # the reference's `mpi` [T',H,W,K,4] (hit-slot order, MPV.py:441-449) and `blend_weight` [T',H,W,K] (MPV.py:451-453), on request
+            # only: materialised with the unfused operators (no shipped configuration reads them; the fused kernels never build them)
+            if cull_window is not None:
+                raise RuntimeError("need_layers renders from the full stack: call render() under torch.no_grad() or in eval mode")
             mpi = self._layers(stack, homos, H, W)
             variables["mpi"] = mpi
+            variables["blend_weight"] = overcompose(mpi[..., -1], mpi[..., :-1])[1]
         if len(self.args.bg_color) > 0:                                                     # MPV.py:455-461 (as written)
             if self.args.bg_color == "random":
                 bg_color = torch.rand(3).type_as(rgb)
@@ -433,9 +438,20 @@ class MPMeshVid(nn.Module):
         tx = p[..., 0, 0] / p[..., 2, 0] * sx + ox
         ty = p[..., 1, 0] / p[..., 2, 0] * sy + oy
         cov = ((tx >= 0) & (tx <= Ws - 1) & (ty >= 0) & (ty <= Hs - 1)).to(samp.dtype)      # D,H,W
+        if self.is_sparse:      # a sample inside a culled quad is not covered (no face there, MPV.py:389-392)
+            QH, QW = self.quad_keep.shape[1:]
+            qx = torch.floor(tx * (QW / max(Ws - 1, 1))).clamp(0, QW - 1).long()
+            qy = torch.floor(ty * (QH / max(Hs - 1, 1))).clamp(0, QH - 1).long()
+            cov = cov * self.quad_keep.to(dev)[torch.arange(D, device=dev)[:, None, None], qy, qx].to(cov.dtype)
         rgba = torch.cat([self.rgb_activate(samp[:, :, :3]), self.alpha_activate(samp[:, :, 3:])], dim=2)
-        rgba = rgba * cov[None, :, None]
-        return rgba.permute(0, 3, 4, 1, 2)                                                   # T,H,W,D,4
+        rgba = (rgba * cov[None, :, None]).permute(0, 3, 4, 1, 2)                            # T,H,W,D,4, plane-indexed
+        # hit-slot order: slot k of a pixel = its k-th nearest covered plane (masked_scatter over the z-sorted pix_to_face, MPV.py:441-449),
+        # K = the deepest pixel (utils.py:64-69)
+        covp = cov.permute(1, 2, 0) > 0                                                      # H,W,D
+        K = max(int(covp.sum(-1).max()), 1)
+        slot = (torch.cumsum(covp.long(), -1) - 1).clamp(min=0)[None, ..., None].expand(T, H, W, D, 4)
+        out = torch.zeros((T, H, W, max(K, D), 4), dtype=rgba.dtype, device=dev).scatter_add(3, slot, rgba)
+        return out[:, :, :, :K]
 
     # ---- forward -----------------------------------------------------------------------------------------------------
     def forward(self, h, w, tar_extrins, tar_intrins, ts=None, res=None, losscfg=None):

@@ -34,6 +34,25 @@ extern "C" void vl3d_set_error(const char *msg);
         }                                                    \
     } while (0)
 
+// Timing-only ablation switches (skip the gather, the stores, the tap loads ...: WRONG RESULTS, used to price the parts of a kernel) exist
+// only in a measurement build (-DVL3D_VARIANTS, profiles/build_variant.sh).  In the product they are compile-time false and the ABI
+// refuses desc->variant bits 4-7 (vl3d_check_variant).
+#ifdef VL3D_VARIANTS
+#define VL3D_ABLATE(word, bit) (((word) & (bit)) != 0)
+#else
+#define VL3D_ABLATE(word, bit) (false)
+#endif
+static inline int vl3d_check_variant(int variant) {
+#ifndef VL3D_VARIANTS
+    if (variant & 0xf0) {
+        vl3d_set_error("desc->variant bits 4-7 select timing-only ablations (wrong results): they exist only in a -DVL3D_VARIANTS measurement build");
+        return VL3D_EINVAL;
+    }
+#endif
+    (void)variant;
+    return VL3D_OK;
+}
+
 // ---- activations (MPI.py:21-31) -----------------------------------------------------------------
 template <int ACT>
 __device__ __forceinline__ float act_fwd(float v) {

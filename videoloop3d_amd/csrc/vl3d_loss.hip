@@ -475,7 +475,7 @@ __global__ __launch_bounds__(NTHR) void patchnn4_k(NN2Args a, int H_unused, int 
     // but the conflict-free alternative, x tiles fastest (13 <= 16), measured 1-3 % SLOWER in process (profiles/ab_loss.py, variant
     // 0x80: ref 3.99 vs 3.96 ms, other 3.16 vs 3.07 ms): the LDS is not what this kernel waits for.  Kept selectable for A/B.)
     const int tiles_i = a.TxP / TI;
-    const bool i_fast = (a.ablate & 8) && tiles_i <= 16 && tiles_j > 16;
+    const bool i_fast = VL3D_ABLATE(a.ablate, 8) && tiles_i <= 16 && tiles_j > 16;
     const int ti = has_tile ? (i_fast ? tid % tiles_i : tid / tiles_j) * TI : 0, tj = has_tile ? (i_fast ? tid / tiles_i : tid % tiles_j) * TJ : 0;
     float acc[NL4][TI * TJ];
 #pragma unroll
@@ -700,11 +700,11 @@ __global__ __launch_bounds__(64 * NW, 2) void patchnn5_k(NN2Args a, int groups_x
     const int xoff = min(wave, GX - 1) * 64 + lane, yoff = ybase + lane;
     const bool one = lane >= 48;                                 // B slot 3 = 1
     const bool side = tid < a.TyP;
-    if (!(a.ablate & 4)) issue(0);
+    if (!VL3D_ABLATE(a.ablate, 4)) issue(0);
     for (int st = 0; st < S; ++st) {
         __syncthreads();                                         // stage st has landed; everyone is done with the other buffer
-        if (st + 1 < S && !(a.ablate & 4)) issue(st + 1);
-        if (a.ablate & 2) continue;
+        if (st + 1 < S && !VL3D_ABLATE(a.ablate, 4)) issue(st + 1);
+        if VL3D_ABLATE(a.ablate, 2) continue;
         const int q0 = st * CHC, nc = min(CHC, cols - q0);
         const float *buf = smem + (st & 1) * bufF;
         for (int cc = 0; cc < nc; ++cc) {
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(64 * NW, 2) void patchnn5_k(NN2Args a, int groups_x
             }
         __syncthreads();
         const size_t b = (size_t)by * a.w_o + bx0 + l;
-        if (a.ablate & 1) { if (tid < a.n1) a.nn[b * a.n1 + tid] = 0; continue; }
+        if VL3D_ABLATE(a.ablate, 1) { if (tid < a.n1) a.nn[b * a.n1 + tid] = 0; continue; }
         nn_epilogue<NTHR, true>(a, E, colw + l * 3 * n2p, n2p, b, tid, sub);
     }
 }
@@ -1108,6 +1108,7 @@ Rho make_rho(int kind, float rou, float scale) {
 
 int check_loss(const vl3d_loss_desc *d) {
     VL3D_REQUIRE(d != nullptr, "null loss desc");
+    if (vl3d_check_variant(d->variant) != VL3D_OK) return VL3D_EINVAL;
     VL3D_REQUIRE(d->Tx > 0 && d->Ty > 0 && d->H > 0 && d->W > 0, "loss: non-positive dims");
     VL3D_REQUIRE(d->ps > 0 && d->pt > 0 && d->stride > 0 && d->stridet > 0, "loss: non-positive patch config");
     VL3D_REQUIRE(d->H >= d->ps && d->W >= d->ps && d->Tx >= d->pt && d->Ty >= d->pt, "loss: input smaller than one patch");

@@ -32,6 +32,7 @@ int dispatch(bool bwd, const vl3d_render_desc *d, const RenderArgs &a, hipStream
 
 int check_desc(const vl3d_render_desc *d) {
     VL3D_REQUIRE(d != nullptr, "null render desc");
+    if (vl3d_check_variant(d->variant) != VL3D_OK) return VL3D_EINVAL;
     VL3D_REQUIRE(d->D > 0 && d->T > 0 && d->Hs > 0 && d->Ws > 0 && d->H > 0 && d->W > 0, "non-positive render dims");
     VL3D_REQUIRE((int64_t)d->Hs * d->Ws < (1ll << 31), "plane too large for 32-bit texel index");
     VL3D_REQUIRE(d->Hs < (1 << 24) && d->Ws < (1 << 24), "plane side too large (24-bit row arithmetic)");

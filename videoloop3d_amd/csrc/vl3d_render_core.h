@@ -1176,7 +1176,7 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTI
             if constexpr (CULL) tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
             else tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
             const char *src = plane;
-            if (a.ablate & 4) {   // measurement only: all taps from a 64 KiB cache-resident window
+            if VL3D_ABLATE(a.ablate, 4) {   // measurement only: all taps from a 64 KiB cache-resident window
                 src = reinterpret_cast<const char *>(a.stack);
                 tp.off &= 0xfff0u;
             }
@@ -1220,14 +1220,14 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTI
         __syncthreads();   // staging of plane d visible (the other buffer may still be read by slower waves: not touched here)
         // (3) every texel of this tile's window that the owner table assigns to this tile gathers its taps from the 3x3
         //     pixels around its owner pixel.  Wave = window row, lane = window column: uniform row bases, no index arithmetic.
-        if (a.ablate & 1) continue;
+        if VL3D_ABLATE(a.ablate, 1) continue;
         auto gather = [&](unsigned e, int wx, int wy, unsigned tix) {   // tix = frame texel index of window texel (wx, wy)
             if ((e >> 10) != my_tile) return;
             // fixed trip count, constant LDS offsets; weights clamp to 0 for non-contributing pixels (|J^-1|_inf < 1.4)
             const int lc = (int)(e & 1023u);
             const f2 tau = f2{(float)(X0 + wx), (float)(Y0 + wy)};
             f4 acc = f4{0.f, 0.f, 0.f, 0.f};
-            if (a.ablate & 8) {
+            if VL3D_ABLATE(a.ablate, 8) {
             } else if (apart) {
                 // 2x2 block of the owner pixel towards tau, summed in the 3x3 loop's order: the five pixels left out have weight
                 // exactly 0 there, so both gathers give the same bits
@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTI
                 acc = f4{acc.x * act_bwd<RACT>(sv.x, act_fwd<RACT>(sv.x)), acc.y * act_bwd<RACT>(sv.y, act_fwd<RACT>(sv.y)),
                          acc.z * act_bwd<RACT>(sv.z, act_fwd<RACT>(sv.z)), acc.w * act_bwd<AACT>(sv.w, act_fwd<AACT>(sv.w))};
             }
-            if (!(a.ablate & 2)) store_grad_texel<F16>(gplane, tix << 4, acc);
+            if (!VL3D_ABLATE(a.ablate, 2)) store_grad_texel<F16>(gplane, tix << 4, acc);
         };
         if (row < wh && lane < ww) gather(e0, lane, row, win0 + toff_thread);
         // rest of a window larger than 64 x ROWS (stacks stored above the frame's resolution, frame-border tiles, rotations)

@@ -77,7 +77,9 @@ def _loss_desc(x, y, patch_size, patcht_size, stride, stridet, alpha):
     d.alpha = 0.0 if alpha is None else float(alpha)
     d.x_sc, d.x_st, d.x_sr = x.stride(0), x.stride(1), x.stride(2)
     d.y_sc, d.y_st, d.y_sr = y.stride(0), y.stride(1), y.stride(2)
-    d.variant = int(os.environ.get("VL3D_LOSS_VARIANT", "0"))   # measurement hook (A/B of the patch-NN kernels)
+    # kernel-variant selector for cross-checks (bits 0-3 pick one of the four patch-NN kernels, every one of them exact; bits 12-15 a
+    # fold tile shape): the timing-only bits 4-7 never leave this module (the product library refuses them anyway)
+    d.variant = int(os.environ.get("VL3D_LOSS_VARIANT", "0"), 0) & ~0xf0
     return d
 
 
