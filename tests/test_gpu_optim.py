@@ -276,3 +276,38 @@ def test_sparsified_model_trains_through_the_window_path(dev):
     kept = tiles.quad_to_texel_mask(keep, *sa.shape[2:4]).to(dev)[:, None, :, :, None].expand_as(sa)
     diff = (sa - sb)[kept].abs()
     assert float((diff > 2e-5).float().mean()) <= 1e-3 and float(diff.max()) <= 2e-3 and float(diff.mean()) <= 1e-6
+
+
+def test_window_adam_state_dict_round_trip(dev):
+    """state_dict() flushes and saves torch.optim.Adam's layout (exp_avg, exp_avg_sq, step); a fresh WindowAdam that loads it continues
+    exactly like the original (the deferral bookkeeping restarts at `step`)."""
+    from videoloop3d_amd.optim import WindowAdam, align_window
+    torch.manual_seed(3)
+    D, T, Hs, Ws = 3, 2, 40, 56
+    pa = torch.nn.Parameter(torch.randn(D, T, Hs, Ws, 4, device=dev) * 0.1)
+    oa = WindowAdam([pa], lr=1e-2, betas=(0.9, 0.999), eps=6e-8)
+    wins = [align_window(0, 17, 8, 30, Hs, Ws), align_window(16, 40, 24, 56, Hs, Ws), align_window(8, 24, 0, 24, Hs, Ws)]
+
+    def steps(opt, p, k0, k1):
+        for k in range(k0, k1):
+            w = wins[k % len(wins)]
+            leaf = opt.window_leaf(w)
+            g = torch.Generator(device=dev).manual_seed(100 + k)
+            leaf.grad = torch.randn(leaf.shape, device=dev, generator=g)
+            opt.step()
+    steps(oa, pa, 0, 5)
+    import io
+    buf = io.BytesIO()
+    torch.save(oa.state_dict(), buf)          # through a file image, like a checkpoint (load_state_dict aliases same-device tensors)
+    buf.seek(0)
+    sd = torch.load(buf)
+    assert set(next(iter(sd["state"].values())).keys()) == {"exp_avg", "exp_avg_sq", "step"}
+    pb = torch.nn.Parameter(pa.detach().clone())
+    ob = WindowAdam([pb], lr=1e-2, betas=(0.9, 0.999), eps=6e-8)
+    ob.load_state_dict(sd)
+    assert ob.t == 5
+    steps(oa, pa, 5, 9)
+    steps(ob, pb, 5, 9)
+    oa.flush(); ob.flush()
+    assert torch.equal(pa.detach(), pb.detach())
+    assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"])

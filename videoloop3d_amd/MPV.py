@@ -297,6 +297,7 @@ class MPMeshVid(nn.Module):
         second group holds `_verts`, which never receive a gradient in the shipped configs)."""
         (_, base_lr), _ = self.get_lrate(step)
         params = [{'params': [p for _, p in self.named_parameters()]}]
+        self._flush_deferred_updates()      # the optimiser handed out before may still hold deferred zero-gradient updates: they belong to the stack
         self._static_compact = False
         self._window_opt = None
         if self.args.optimizer == 'adam':

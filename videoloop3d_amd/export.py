@@ -64,8 +64,16 @@ def _pack_tiles(stack, mask, frames, tile_hw):
     xs = vx[:, None].double() * cw + torch.linspace(0, cw, iw, dtype=torch.float64)[None]
     gy, gx = (ys / (H - 1) * 2 - 1).float(), (xs / (W - 1) * 2 - 1).float()
     grid = torch.stack([gx[:, None, :].expand(n, ih, iw), gy[:, :, None].expand(n, ih, iw)], -1).to(stack.device)
-    tiles = torch.stack([F.grid_sample(stack[d, t].permute(0, 3, 1, 2).float(), grid, mode="bilinear", align_corners=True)
-                         for t in range(frames)], 0)                                            # frames,n,4,ih,iw
+    # plane by plane, all frames and all of the plane's tiles in one call (the tiles' grids stacked along the rows): indexing
+    # stack[d, t] with one plane index per TILE materialised a whole (H,W,4) plane per tile -- 174 GB at the shipped size
+    tiles = stack.new_empty((frames, n, 4, ih, iw), dtype=torch.float32)
+    dd = d.to(stack.device)
+    for plane in torch.unique(d).tolist():
+        sel = (dd == plane).nonzero()[:, 0]
+        g = grid[sel].reshape(1, len(sel) * ih, iw, 2).expand(frames, -1, -1, -1)
+        img = stack[plane, :frames].permute(0, 3, 1, 2).float()                                 # frames,4,H,W
+        out = F.grid_sample(img, g, mode="bilinear", align_corners=True)                        # frames,4,len(sel)*ih,iw
+        tiles[:, sel] = out.reshape(frames, 4, len(sel), ih, iw).permute(0, 2, 1, 3, 4)
     gh, gw, pad = atlas_grid(n)
     tiles = torch.cat([tiles, tiles[:, -1:].expand(-1, pad, -1, -1, -1)], 1)                    # MPI.py:392
     atlas = tiles.reshape(frames, gh, gw, 4, ih, iw).permute(0, 3, 1, 4, 2, 5).reshape(frames, 4, gh * ih, gw * iw)
@@ -106,6 +114,9 @@ def reference_state_dict(model, tile_texels=None):
     intrin_mpi = model.ref_intrin_mpi.detach().cpu().float()
     mh, mw = model.mpi_h, model.mpi_w
     verts = gen_mpi_vertices(mh, mw, intrin_mpi, hv, wv, model.planedepth.detach().cpu().float())
+    if bool(getattr(model.args, "normalize_verts", False)):
+        # the reference stores `_verts` divided by the plane depth under this flag and multiplies it back in its `verts` property (MPV.py:62-64)
+        verts = (verts.reshape(D, -1, 3) / model.planedepth.detach().cpu().float().reshape(D, 1, 1)).reshape(verts.shape)
     return {
         "_verts": verts, "planedepth": model.planedepth.detach().cpu().clone(), "ref_extrin": model.ref_extrin.detach().cpu().clone(),
         "ref_intrin": model.ref_intrin.detach().cpu().clone(),

@@ -115,6 +115,29 @@ class WindowAdam(torch.optim.Optimizer):
         D, T, Hs, Ws, _ = self.p.shape
         self._catchup((0, 0, Hs, Ws), self.t, None, mirror=self.quad_keep is not None)
 
+    # ---- checkpointing -------------------------------------------------------------------------------------------------
+    def state_dict(self):
+        """torch.optim.Adam's layout after a flush(): exp_avg / exp_avg_sq / step per parameter.  The deferral bookkeeping (per-tile
+        step table, per-step scalar history) is not state once everything is current: load_state_dict() restarts it at `step`."""
+        self.flush()
+        sd = super().state_dict()
+        # (the packed state shares its inner dicts with the live optimiser: build new ones)
+        sd["state"] = {k: {**{kk: vv for kk, vv in st.items() if kk not in ("last_step", "hist")}, "step": torch.tensor(float(self.t))}
+                       for k, st in sd["state"].items()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self.pending = None
+        st = self.state.get(self.p)
+        if st:
+            self.t = int(st.pop("step", torch.tensor(0.0)).item())
+            D, T, Hs, Ws, _ = self.p.shape
+            ts = tile_side()
+            # every tile is current for step t (the saved moments came out of a flush); the scalars of steps <= t are never replayed again
+            st["last_step"] = torch.full((D, (Hs + ts - 1) // ts, (Ws + ts - 1) // ts), self.t, dtype=torch.int32, device=self.p.device)
+            st["hist"] = torch.zeros((max(1024, 2 * (self.t + 1)), 2), dtype=torch.float32, device=self.p.device)
+
     def zero_grad(self, set_to_none=True):
         super().zero_grad(set_to_none)
         if self.pending is not None and self.pending != "multiple" and self.pending[1].grad is not None:
@@ -153,6 +176,9 @@ class WindowAdam(torch.optim.Optimizer):
             window, g, boxes = (0, 0, Hs, Ws), (p.grad if p.grad.is_contiguous() else p.grad.contiguous()), None
         else:
             window, g, boxes = pending[0], pending[1].grad, pending[2]
+            if g.dtype != torch.float32 or tuple(g.shape) != (D, T, window[2], window[3], 4) or not g.is_contiguous():
+                raise RuntimeError(f"WindowAdam: the window leaf's gradient must be contiguous float32 {(D, T, window[2], window[3], 4)}, "
+                                   f"got {g.dtype} {tuple(g.shape)}")
             if p.grad is not None:
                 raise RuntimeError("WindowAdam: both the window leaf and the dense parameter received a gradient in one step")
         y0, x0, wh, ww = window
