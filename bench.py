@@ -48,10 +48,19 @@ def parse():
     ap.add_argument("--loss-steps", type=int, default=5)
     ap.add_argument("--gather-algo", default="auto", choices=["auto", "ring", "direct"],
                     help="N > 1: RCCL all_gather (ring) or grouped all-peers send/recv (direct), videoloop3d_amd.dist.all_gather_frame")
-    ap.add_argument("--exchange-halo-grads", action="store_true",
-                    help="N > 1: also sum the gradient of the replicated halo rows with the neighbours inside the step (training-complete)")
-    ap.add_argument("--loss-band", action="store_true", help="N > 1: extra leg, the looping loss on this rank's rows of the gathered frame")
-    return ap.parse_args()
+    ap.add_argument("--config", default=None, choices=["cfg3", "cfg4", "cfg5"],
+                    help="BASELINE.json shorthand: cfg3 = D32 T50 720p fp32 (default shapes), cfg4 = D64 T80 1080p fp32 (8 GPUs), "
+                         "cfg5 = D96 T120 2160p fp16 stack (8 GPUs); overrides --D/--T/--H/--W/--stack-dtype")
+    ap.add_argument("--no-exchange-halo-grads", dest="exchange_halo_grads", action="store_false",
+                    help="N > 1: leave out the sum of the replicated halo rows' gradient with the neighbours (on by default: the step is "
+                         "training-complete, every replica of a stack row ends the step with the single-GPU gradient)")
+    ap.add_argument("--no-loss-band", dest="loss_band", action="store_false",
+                    help="N > 1: leave out the extra (untimed) leg, the looping loss on this rank's rows of the gathered frame")
+    a = ap.parse_args()
+    if a.config:
+        a.D, a.T, a.H, a.W, a.stack_dtype = {"cfg3": (32, 50, 720, 1280, "f32"), "cfg4": (64, 80, 1080, 1920, "f32"),
+                                              "cfg5": (96, 120, 2160, 3840, "f16")}[a.config]
+    return a
 
 
 def cpu_baseline(D, H, W, frames, spec_name, passes=3):
@@ -213,13 +222,15 @@ def main():
         bands = plan_bands(homos, H, W, Hs, world, spec)
         band = bands[rank]
         full_rows = band.src1 - band.src0
-        stack = torch.empty((D, T, full_rows, Ws, 4), dtype=torch.float32, device=dev)
+        sdt = torch.float16 if a.stack_dtype == "f16" else torch.float32
+        stack = torch.empty((D, T, full_rows, Ws, 4), dtype=sdt, device=dev)
         per_plane = T * Hs * Ws * 4
-        for d in range(D):      # same bytes as the single-GPU stack, rows [src0,src1) only
+        for d in range(D):      # same values as the single-GPU stack (fp32 hash, then the storage type), rows [src0,src1) only
             for t in range(T):
                 off = d * per_plane + (t * Hs + band.src0) * Ws * 4
-                stack[d, t] = (synth.hash_uniform((full_rows, Ws, 4), 2, device=dev, offset=off) * 4.0 - 2.0)
-        stack[..., 3] -= 2.0
+                sl = synth.hash_uniform((full_rows, Ws, 4), 2, device=dev, offset=off) * 4.0 - 2.0
+                sl[..., 3] -= 2.0
+                stack[d, t] = sl.to(sdt)
         stack.requires_grad_(True)
         g_full_off = lambda t: (t * H + band.row0) * W * 3
         g_rgb = torch.stack([synth.hash_uniform((band.rows, W, 3), 5, device=dev, offset=g_full_off(t)) for t in range(T)]) - 0.5
@@ -333,17 +344,21 @@ def main():
     dominant = r_b if b_ms >= f_ms else r_f
 
     res = {
-        "metric": "rendered Mpix/s (fwd+bwd) D=32 planes 720p", "value": value, "unit": "Mpix/s",
+        "metric": f"rendered Mpix/s (fwd+bwd) D={D} planes {H}p", "value": value, "unit": "Mpix/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "stack_storage": a.stack_dtype,
-        "config": {"workload": f"cfg3 stage-2 MPV render fwd+bwd: D={D} planes, T={T} frames, {H}x{W} (720p), "
-                               f"{a.spec} convention, plane stack (D,T,H,W,4) fp32 resident in HBM",
+        "config": {"workload": f"{a.config or 'cfg3'} stage-2 MPV render fwd+bwd: D={D} planes, T={T} frames, {H}x{W}, "
+                               f"{a.spec} convention, plane stack (D,T,H,W,4) {a.stack_dtype} resident in HBM",
                    "parallelism": "single GPU" if world == 1 else f"{world} row bands + 1 all-gather of the composited frame",
                    "variant": a.variant},
         "roofline": dominant, "roofline_fwd": r_f, "roofline_bwd": r_b,
         "fwd_bwd_algorithmic_frac": (fwd_bytes + bwd_bytes) / ((f_ms + b_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "frame_checksum": frame_checksum,       # sum of the frame's bit patterns: identical at N = 1, 2, 4, 8
+        # what this rank keeps in HBM for the step: its rows of the stack, the gradient of the same size and type, frame-sized buffers
+        "resident_bytes_per_rank": {"stack": stack.numel() * stack.element_size(), "grad_stack": stack.numel() * stack.element_size(),
+                                    "frames": int(last["frame"].numel() * 4 + g_rgb.numel() * 4 + last["rgb"].numel() * 4),
+                                    "torch_peak_allocated": int(torch.cuda.max_memory_allocated(dev))},
     }
     if world > 1:
         band_bytes = T * max(b.rows for b in bands) * W * 3 * 4
