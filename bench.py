@@ -511,6 +511,14 @@ def main():
                 res["stage2_step"]["reference_estimate"] = "0.4-0.9 it/s on the authors' GPU (BASELINE.md, derived from README wall times)"
             except Exception as e:
                 res["stage2_step"] = {"error": repr(e)}
+            try:    # the same iteration on the REFERENCE'S SCHEDULE (train_3dvid.py:22-66, 263-290): 8 views with their own poses, the
+                    # {4, 4, 9} crops per view of the last three pyramid levels, shuffled -- a crop's texel window comes back after 32-72
+                    # other crops, which is what the crop-aware optimiser's deferral has to live with (examples/stage2_schedule.py)
+                torch.cuda.empty_cache()
+                import stage2_schedule
+                res["stage2_schedule"] = {"dense": stage2_schedule.run(dev=str(dev)), "tile_culled": stage2_schedule.run(dev=str(dev), sparsify=True)}
+            except Exception as e:
+                res["stage2_schedule"] = {"error": repr(e)}
         if not a.no_cpu_baseline:
             stack = None
             torch.cuda.empty_cache()

@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Stage-2 training on the REFERENCE'S SCHEDULE (train_3dvid.py:22-66, 103-119, 262-290; configs/mpv_base.txt): V views with distinct
+poses, the crops of `generate_patchinfo` (180 x 320, stride 90 x 160) at the last three pyramid levels of a 360 x 640 frame -- 4, 4 and
+9 crops per view --, shuffled per epoch, adaptive learning rate, the crop-aware optimiser re-created at every level after `lod`.
+`examples/stage2_step.py` cycles six overlapping crops under ONE pose, where a tile's deferred-update depth never exceeds a few steps;
+here a crop's texel window comes back once per epoch, i.e. after len(dataset) = 32 ... 72 iterations, which is what the deferral of
+`optim.WindowAdam` (replayed zero-gradient updates, O(depth) per texel, twice per iteration) has to live with in real training.
+
+Reports iterations per second per level and overall (dataset construction and `lod` outside the timed loops: the reference does
+them once per 50 epochs), and from a second, instrumented pass the histogram of catch-up depths (steps a window tile had missed when
+its crop came back).  `profiles/kstats.sh` over this script gives the catch-up / step kernel times."""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+import warnings
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+
+def make_views(V, H, W, frames, dev):
+    """V cameras on a small arc around the reference view (hand-held capture: translations of a few percent of the nearest plane's depth,
+    rotations of about a degree), 3 x 4 camera-to-world poses like the dataloader's, and V synthetic clips [F,3,H,W]."""
+    from videoloop3d_amd import synth
+    poses, vids = [], []
+    for v in range(V):
+        a, b = np.radians(1.2 * np.cos(2 * np.pi * v / V)), np.radians(0.8 * np.sin(2 * np.pi * v / V))
+        Ry = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+        t = np.array([0.06 * np.cos(2 * np.pi * v / V), 0.04 * np.sin(2 * np.pi * v / V), 0.01 * (v % 3 - 1)])
+        if v == 0:
+            Ry, Rx, t = np.eye(3), np.eye(3), np.zeros(3)           # view 0 is the reference view (loss_ref_idx = 0)
+        poses.append(np.concatenate([Ry @ Rx, t[:, None]], 1))
+        vids.append(synth.hash_uniform((frames, 3, H, W), seed=20 + v, device=dev))
+    K = np.array([[0.9 * W, 0, W / 2], [0, 0.9 * W, H / 2], [0, 0, 1]], np.float64)
+    return torch.tensor(np.stack(poses), dtype=torch.float32), torch.tensor(K, dtype=torch.float32)[None].repeat(V, 1, 1), vids
+
+
+def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, dev="cuda:0", sparsify=False):
+    from videoloop3d_amd.MPV import MPMeshVid
+    from videoloop3d_amd.train_3dvid import MVVidPatchDataset, run_iter
+    dev = torch.device(dev)
+    H, W = 360, 640
+    args = types.SimpleNamespace(
+        mpv_frm_num=frames, mpv_isloop=True, mpi_h_scale=1.1, mpi_w_scale=1.1, mpi_d=planes, atlas_grid_h=4, init_std=0.02,
+        rgb_mlp_type="direct", rgb_activate="sigmoid", alpha_activate="sigmoid", bg_color="", scale_invariant=True,
+        add_uv_noise=False, fp16=False, swd_patch_size=3, swd_patcht_size=3, swd_stride=2, swd_stridet=1,
+        sparsity_loss_weight=0.0, rgb_smooth_loss_weight=smooth, a_smooth_loss_weight=smooth, density_loss_weight=0.0,
+        d_smooth_loss_weight=0.0, swd_loss_weight=1.0, optimizer="adam", lrate=0.5, lrate_decay=100, lrate_adaptive=True,
+        add_intrin_noise=True, mpi_h_verts=36, mpi_w_verts=64)
+    poses, intrins, vids = make_views(views, H, W, clip, dev)
+    K = intrins[0].numpy()
+    model = MPMeshVid(args, H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
+    other = dict(loss_name="gpnn_lm", patch_size=3, patcht_size=3, stride=2, stridet=1, alpha=10000.0, rou="-2", scaling=0.1, dist_fn="mse",
+                 macro_block=65)
+    ref = dict(loss_name="gpnn_lm", loss_gain=3.5, patch_size=11, patcht_size=3, stride=4, stridet=1, alpha=0.0, rou="-2", scaling=0.1,
+               dist_fn="mse", macro_block=65)
+    cfgs = [ref] + [other] * (views - 1)
+    if sparsify:      # what stage 2 starts from after sparsify_faces: ~16 % of the quads, half of them dynamic
+        from videoloop3d_amd import tiles
+        QH, QW = 35, 63
+        qy, qx = torch.meshgrid(torch.arange(QH, device=dev), torch.arange(QW, device=dev), indexing="ij")
+        keep = torch.zeros((planes, QH, QW), dtype=torch.bool, device=dev)
+        for d in range(planes):
+            cy, cx = (7 * d + 3) % QH, (11 * d + 5) % QW
+            keep[d] = ((qy - cy).abs() <= QH // 5) & ((qx - cx).abs() <= QW // 4)
+        model.register_buffer("quad_keep", keep)
+        model.register_buffer("quad_dyn", keep & ((qy + qx) % 2 == 0)[None])
+        model.is_sparse = model.has_dyn = True
+        with torch.no_grad():
+            tiles.cull_stack_(model.stack.data, keep)
+        model._install_tie_hook()
+    factors = [0.75 ** i for i in range(levels)][::-1]
+    gen = torch.Generator().manual_seed(2)
+    out = {"levels": []}
+    total_it, total_s = 0, 0.0
+    depth_hist = np.zeros(0, np.int64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for li, f in enumerate(factors):
+            hw = (int(H * f), int(W * f))
+            model.lod(f)
+            opt = model.get_optimizer(step=0)
+            ds = MVVidPatchDataset(hw, vids, (180, 320), (90, 160), poses, intrins, loss_configs=cfgs)
+            order = [i for _ in range(epochs + 1) for i in torch.randperm(len(ds), generator=gen).tolist()]
+
+            def one(i, epoch):
+                for (_, lr), g in zip(model.get_lrate(epoch), opt.param_groups):
+                    g["lr"] = lr / len(ds)                                     # lrate_adaptive (train_3dvid.py:281-287)
+                run_iter(model, opt, ds[i], args, dev)
+            for k in range(8):                                                 # warm-up (allocator, first-call set-up)
+                one(order[k], 0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            timed = order[8:8 + epochs * len(ds)]
+            for k, i in enumerate(timed):
+                one(i, k // len(ds))
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            total_it += len(timed)
+            total_s += dt
+            out["levels"].append({"frame": hw, "crops_per_view": len(ds) // views, "crops": len(ds), "iters": len(timed),
+                                  "iters_per_s": len(timed) / dt, "stack": tuple(model.stack.shape[2:4])})
+            # instrumented pass (synchronising; not timed): how many steps had each tile of the crop's window missed?
+            if hasattr(opt, "state") and getattr(model, "_window_opt", None) is opt:
+                import videoloop3d_amd.optim as O
+                ts = O.tile_side()
+                orig = opt.window_leaf
+
+                def spy(window, plane_boxes=None):
+                    nonlocal depth_hist
+                    st = opt.state.get(opt.p)
+                    if st:
+                        y0, x0, wh, ww = window
+                        sub = st["last_step"][:, y0 // ts:-(-(y0 + wh) // ts), x0 // ts:-(-(x0 + ww) // ts)]
+                        dep = np.bincount((opt.t - sub).clamp(min=0).flatten().cpu().numpy())
+                        if len(dep) > len(depth_hist):
+                            depth_hist = np.pad(depth_hist, (0, len(dep) - len(depth_hist)))
+                        depth_hist[:len(dep)] += dep
+                    return orig(window, plane_boxes)
+                opt.window_leaf = spy
+                for i in torch.randperm(len(ds), generator=gen).tolist():
+                    one(i, epochs)
+                opt.window_leaf = orig
+    out["iters_per_s"] = total_it / total_s
+    out["iters"] = total_it
+    if depth_hist.sum() > 0:
+        c = np.cumsum(depth_hist) / depth_hist.sum()
+        out["catchup_depth"] = {"mean": float((np.arange(len(depth_hist)) * depth_hist).sum() / depth_hist.sum()),
+                                "p50": int(np.searchsorted(c, 0.5)), "p90": int(np.searchsorted(c, 0.9)), "max": int(len(depth_hist) - 1),
+                                "histogram_by_8": [int(depth_hist[i:i + 8].sum()) for i in range(0, len(depth_hist), 8)]}
+    out["shape"] = (f"V={views} views, D={planes}, T={frames}, clips of {clip} frames, 360x640 frames, crops 180x320 stride 90x160 at the last "
+                    f"{levels} pyramid levels, {epochs} epochs per level, smooth {smooth}, {'tile-culled' if sparsify else 'dense'} model")
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--epochs", type=int, default=2)
+    ap.add_argument("--sparsify", action="store_true")
+    a = ap.parse_args()
+    import __graft_entry__ as g
+    g.build()
+    print(json.dumps(run(a.views, a.epochs, sparsify=a.sparsify)))

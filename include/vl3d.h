@@ -179,6 +179,12 @@ int vl3d_adam_window_step_boxes(int32_t D, int32_t T, int32_t Hs, int32_t Ws, in
                                 const float *hist, float lr, float beta1, float beta2, float eps, int64_t step, const uint8_t *quad_keep,
                                 const uint8_t *quad_dyn, int32_t QH, int32_t QW, int32_t static_tied, const int32_t *plane_boxes,
                                 vl3d_stream_t stream);
+/* Bound on the deferral: every bookkeeping tile that has missed at least min_depth steps is replayed up to `upto`, written back and marked
+ * (the others are left alone).  Run after each step it keeps what a returning crop window has to replay below min_depth steps per texel
+ * -- the reference shuffles 32-72 crops x views per epoch (train_3dvid.py:263-290), so a window comes back after that many steps. */
+int vl3d_adam_flush_older(int32_t D, int32_t T, int32_t Hs, int32_t Ws, float *param, float *exp_avg, float *exp_avg_sq, int32_t *last_step,
+                          const float *hist, int32_t upto, int32_t min_depth, float beta1, float beta2, float eps, const uint8_t *quad_keep,
+                          const uint8_t *quad_dyn, int32_t QH, int32_t QW, vl3d_stream_t stream);
 void vl3d_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, float *lr_bc1, float *bc2s);
 
 /* Layer-space smoothness regularisers (MPV.py:517-531 rgb_smooth / a_smooth; MPI.py:608-622) WITHOUT the materialised [T,h,w,K,4]

@@ -21,10 +21,17 @@ namespace {
 constexpr int TS = 8;       // tile side in texels (the bookkeeping granularity: a crop's window is grown to whole tiles, 8 instead of 16
                             // texels cut ~7 % off the window of a 180 x 320 crop; the step table is 4 bytes per tile)
 
+// One Adam step of one value.  The square root and the two quotients are the hardware's v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the
+// correctly rounded expansions (~40 instructions per value and step): the deferred zero-gradient steps are REPLAYED through this very
+// function -- on the reference's schedule a returning window replays 2-4 steps per texel, twice per iteration, and with the IEEE forms
+// that arithmetic, not the 7 memory streams, set the time of the catch-up and step kernels (2.5 + 3.5 ms against 1.0 + 2.0 at depth ~1).
+// Every path (dense step, window step, catch-up, flush) goes through it, so deferring stays bit-identical to not deferring; against
+// torch.optim.Adam the update term differs by <= 3 ulp per step (tests/test_gpu_optim.py: <= 2e-6 on the parameters after 40 steps).
 __device__ __forceinline__ void adam_upd(float &pp, float gg, float &mm, float &vv, float lr_bc1, float beta1, float beta2, float eps, float bc2s) {
     mm = beta1 * mm + (1.0f - beta1) * gg;           // exp_avg.lerp_(grad, 1 - beta1)
     vv = beta2 * vv + (1.0f - beta2) * gg * gg;      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-    pp -= lr_bc1 * (mm / (sqrtf(vv) / bc2s + eps));  // param.addcdiv_(exp_avg, sqrt(exp_avg_sq)/sqrt(bc2) + eps, value=-lr/bc1)
+    const float den = __builtin_amdgcn_sqrtf(vv) * __builtin_amdgcn_rcpf(bc2s) + eps;      // sqrt(exp_avg_sq)/sqrt(bc2) + eps
+    pp -= lr_bc1 * (mm * __builtin_amdgcn_rcpf(den));                                      // param.addcdiv_(exp_avg, den, value=-lr/bc1)
 }
 
 struct Win { int y0, x0, wh, ww; };
@@ -187,7 +194,51 @@ int check_window(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32
 
 }  // namespace
 
+// Bound on the deferral: one wave per (plane, bookkeeping tile of TS x TS texels); a tile that has missed at least `min_depth` steps is
+// brought up to `upto` (replayed, written back, marked), every other wave returns after one 4-byte read.  Run after every step, it keeps
+// the replay a returning crop window pays (twice: catch-up for the render, then again in front of the real update) below min_depth
+// steps per texel, for stack_bytes * 6 / min_depth of extra traffic per step.  On the reference's schedule (72 crops per epoch at the
+// last pyramid level, examples/stage2_schedule.py) windows came back after 30-220 steps: catch-up + step 6.0 ms per iteration
+// against 3.0 ms with six cycling crops.
+__global__ __launch_bounds__(64) void adam_flush_older_k(int T, int Hs, int Ws, float4 *__restrict__ p, float4 *__restrict__ m,
+                                                         float4 *__restrict__ v, int *__restrict__ last_step, int tiles_y, int tiles_x,
+                                                         const float2 *__restrict__ hist, int upto, int min_depth, float beta1, float beta2,
+                                                         float eps, Quads q) {
+    const int tile = blockIdx.x, d = blockIdx.y, ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    int *ls = last_step + ((size_t)d * tiles_y + ty) * tiles_x + tx;
+    const int from = *ls;
+    if (upto - from < min_depth) return;                     // uniform
+    const int x = tx * TS + (threadIdx.x % TS), y = ty * TS + (threadIdx.x / TS);
+    if (x < Ws && y < Hs) {
+        const size_t frame = (size_t)Hs * Ws;
+        size_t o = (size_t)d * T * frame + (size_t)y * Ws + x;
+        const int cls = texel_class(q, d, x, y, Hs, Ws);
+        const int nt = cls == 0 ? 0 : (cls == 2 ? 1 : T);    // culled: no parameter; static: the one copy in frame 0
+        for (int t = 0; t < nt; ++t, o += frame) {
+            float4 pp = p[o], mm = m[o], vv = v[o];
+            replay(pp, mm, vv, hist, from, upto, beta1, beta2, eps);
+            p[o] = pp; m[o] = mm; v[o] = vv;
+        }
+    }
+    if (threadIdx.x == 0) *ls = upto;                         // this wave is the tile's only reader and writer in this launch
+}
+
 extern "C" int32_t vl3d_adam_window_tile(void) { return TS; }
+
+extern "C" int vl3d_adam_flush_older(int32_t D, int32_t T, int32_t Hs, int32_t Ws, float *param, float *exp_avg, float *exp_avg_sq,
+                                     int32_t *last_step, const float *hist, int32_t upto, int32_t min_depth, float beta1, float beta2, float eps,
+                                     const uint8_t *quad_keep, const uint8_t *quad_dyn, int32_t QH, int32_t QW, vl3d_stream_t stream) {
+    VL3D_REQUIRE(D > 0 && D <= 65535 && T > 0 && Hs > 0 && Ws > 0, "vl3d_adam_flush_older: bad dims");
+    VL3D_REQUIRE(param && exp_avg && exp_avg_sq && last_step && hist && upto >= 0 && min_depth >= 1, "vl3d_adam_flush_older: null pointer / bad step");
+    VL3D_REQUIRE(!quad_keep || (QH > 0 && QW > 0), "vl3d_adam_flush_older: bad quad grid");
+    static_assert(TS * TS == 64, "one wave per bookkeeping tile");
+    const int tiles_y = (Hs + TS - 1) / TS, tiles_x = (Ws + TS - 1) / TS;
+    hipLaunchKernelGGL(adam_flush_older_k, dim3(tiles_y * tiles_x, D), dim3(64), 0, (hipStream_t)stream, T, Hs, Ws, reinterpret_cast<float4 *>(param),
+                       reinterpret_cast<float4 *>(exp_avg), reinterpret_cast<float4 *>(exp_avg_sq), last_step, tiles_y, tiles_x,
+                       reinterpret_cast<const float2 *>(hist), upto, min_depth, beta1, beta2, eps, Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW});
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
 
 extern "C" int vl3d_adam_window_catchup_boxes(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
                                               float *param, float *exp_avg, float *exp_avg_sq, int32_t *last_step, const float *hist,

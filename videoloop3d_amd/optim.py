@@ -34,7 +34,7 @@ def align_window(y0, y1, x0, x1, Hs, Ws):
 
 
 class WindowAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, quad_keep=None, quad_dyn=None, culled_alpha=-1e4):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, quad_keep=None, quad_dyn=None, culled_alpha=-1e4, max_defer=32):
         """quad_keep / quad_dyn [D,QH,QW] (a tile-culled model, videoloop3d_amd/tiles.py): culled texels are no parameters, a texel only
         static quads can read is ONE parameter stored in frame 0 of the stack (the reference's static atlas, MPV.py:235-288) -- the
         window copy shows it in every frame, the step sums its gradient over the frames and writes that one copy; flush() refreshes
@@ -49,6 +49,10 @@ class WindowAdam(torch.optim.Optimizer):
         self.p = ps[0]
         self.pending = None          # (window, compact leaf) of the forward since the last step
         self.t = 0
+        # bound on the deferral: after every step, tiles that have missed max_defer steps are brought up to date (exactly: the same
+        # replay), so a crop window that comes back after a whole epoch of other crops replays at most max_defer steps per texel
+        # instead of the epoch's length, twice.  0 = unbounded.
+        self.max_defer = int(max_defer)
 
     # ---- state ----------------------------------------------------------------------------------------------------------
     def _st(self):
@@ -191,4 +195,9 @@ class WindowAdam(torch.optim.Optimizer):
                                                         None if boxes is None else boxes.ctypes.data, L.stream_ptr(p.device)),
                     "vl3d_adam_window_step")
         self.t = t
+        if self.max_defer > 0 and t >= self.max_defer:
+            with torch.cuda.device(p.device):
+                L.check(L.lib().vl3d_adam_flush_older(D, T, Hs, Ws, L.ptr(p), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), L.ptr(st["last_step"]),
+                                                      L.ptr(st["hist"]), t, self.max_defer, float(b1), float(b2), eps, qk, qd, QH, QW,
+                                                      L.stream_ptr(p.device)), "vl3d_adam_flush_older")
         return loss
