@@ -511,6 +511,14 @@ def main():
                 res["stage2_step"]["reference_estimate"] = "0.4-0.9 it/s on the authors' GPU (BASELINE.md, derived from README wall times)"
             except Exception as e:
                 res["stage2_step"] = {"error": repr(e)}
+            try:    # BASELINE.json configs[1]: a stage-1 iteration (train_3d.py:189-250: MPMesh.forward + MSE + loop-mask entropy + the four
+                    # regularisers of configs/mpi_base.txt:37-40 + Adam), reference-native crop and the full 720p frame
+                torch.cuda.empty_cache()
+                import stage1_step
+                res["stage1_step"] = {"native_crop": stage1_step.run(dev=str(dev)),
+                                      "cfg2_720p_frame": stage1_step.run(frame=(720, 1280), crop=(720, 1280), scale=1.1, dev=str(dev))}
+            except Exception as e:
+                res["stage1_step"] = {"error": repr(e)}
             try:    # the same iteration on the REFERENCE'S SCHEDULE (train_3dvid.py:22-66, 263-290): 8 views with their own poses, the
                     # {4, 4, 9} crops per view of the last three pyramid levels, shuffled -- a crop's texel window comes back after 32-72
                     # other crops, which is what the crop-aware optimiser's deferral has to live with (examples/stage2_schedule.py)

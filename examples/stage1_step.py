@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""End-to-end STAGE-1 training iterations on the drop-in module (BASELINE.json configs[1]; reference loop train_3d.py:189-250 run_iter):
+MPMesh.forward (one view, B = 1 as the reference's DataLoader(dataset, 1): MPI.py:596-652 -> render + learned loop mask + the four
+regularisers) -> MSE on the scale-invariant image (train_3d.py:213-220) + entropy loss on the loop mask (:200-209) + sparsity 0.004 /
+rgb_smooth 0.2 / a_smooth 0.5 / density 0.02 (configs/mpi_base.txt:37-40) -> backward -> Adam.
+
+Two shapes: the reference-native one (360 x 640 frames = 720p data at factor 2, 180 x 320 crops, planes at 1.6x: 576 x 1024, D = 32;
+configs/mpi_base.txt:5,12-16,27-30) and the full 720p frame BASELINE.json names (cfg2: 720 x 1280, D = 32, planes at 1.1x).  Synthetic data."""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+
+def run(iters=20, planes=32, frame=(360, 640), crop=(180, 320), scale=1.6, loop_mask=True, dev="cuda:0"):
+    from videoloop3d_amd import synth
+    from videoloop3d_amd.MPI import MPMesh
+    dev = torch.device(dev)
+    H, W = frame
+    h, w = crop
+    args = types.SimpleNamespace(
+        mpi_h_scale=scale, mpi_w_scale=scale, mpi_d=planes, mpi_h_verts=36, mpi_w_verts=64, atlas_grid_h=4, rgb_mlp_type="direct",
+        rgb_activate="sigmoid", alpha_activate="sigmoid", bg_color="", learn_loop_mask=loop_mask, scale_invariant=True,
+        sparsity_loss_weight=0.004, rgb_smooth_loss_weight=0.2, a_smooth_loss_weight=0.5, density_loss_weight=0.02, d_smooth_loss_weight=0.0,
+        l_smooth_loss_weight=0.0)
+    K = np.array([[0.9 * W, 0, W / 2], [0, 0.9 * W, H / 2], [0, 0, 1]], np.float64)
+    model = MPMesh(args, H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=0.05, betas=(0.9, 0.999))                  # MPI.py:122-141, configs/mpi_base.txt:31
+    a = np.radians(0.5)
+    tar = np.eye(4)
+    tar[:3, :3] = [[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]
+    tar[:3, 3] = [0.03, 0.01, 0.0]
+    tar_e = torch.tensor(tar, device=dev)[None]
+    target = synth.hash_uniform((1, 3, h, w), seed=8, device=dev)
+    target_mask = (synth.hash_uniform((1, h, w), seed=9, device=dev) > 0.5).float()
+    wts = vars(args)
+    for it in range(iters + 3):
+        if it == 3:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        Kc = K.copy()
+        if (h, w) != (H, W):
+            Kc[0, 2] -= 90 + (it % 3) * 40                                   # crop offset (utils.py:196-200)
+            Kc[1, 2] -= 45 + (it % 2) * 60
+        rgbl, extra = model(h, w, tar_e, torch.tensor(Kc, device=dev)[None])
+        loop_loss = 0
+        rgb = rgbl
+        if loop_mask:                                                        # train_3d.py:200-211
+            lm = torch.clamp(rgbl[:, -1], 0.001, 1 - 0.001)
+            loop_loss = -(target_mask * torch.log(lm) + (1 - target_mask) * torch.log(1 - lm)).mean()
+            rgb = rgbl[:, :3]
+        sc = torch.exp(torch.log((target + 0.01) / (rgb.detach() + 0.01)).mean())     # train_3d.py:213-217
+        rgb = rgb * ((sc + 3) / 4)
+        loss = ((rgb - target) ** 2).mean() + loop_loss
+        for k, v in extra.items():
+            if wts[f"{k}_loss_weight"] > 0:
+                loss = loss + v.mean() * wts[f"{k}_loss_weight"]
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    return {"iters_per_s": iters / (time.perf_counter() - t0), "loss": float(loss.detach()),
+            "shape": f"D={planes}, frame {H}x{W}, view {h}x{w}, planes {tuple(model.stack.shape[2:4])}, loop mask {loop_mask}, "
+                     f"sparsity 0.004 / rgb_smooth 0.2 / a_smooth 0.5 / density 0.02, torch.optim.Adam over the dense stack"}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    import __graft_entry__ as g
+    g.build()
+    print(json.dumps({"native_crop": run(a.iters), "cfg2_720p_frame": run(a.iters, frame=(720, 1280), crop=(720, 1280), scale=1.1),
+                      "cfg2_720p_frame_no_loop_mask": run(a.iters, frame=(720, 1280), crop=(720, 1280), scale=1.1, loop_mask=False)}))
