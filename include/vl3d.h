@@ -164,7 +164,15 @@ int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t 
                           const uint8_t *quad_dyn,
                           int32_t QH, int32_t QW, int32_t static_tied, vl3d_stream_t stream);
 
-/* The same two with per-plane boxes: plane_boxes [D][4] = (y0, y1, x0, x1) in plane texels, tile aligned, inside the window, in HOST
+/* PACKED storage of a tile-culled model (`blocks` != NULL on the three entry points below; quad maps required): the reference keeps a
+ * static atlas (one frame), a dynamic atlas (T frames) and no storage for culled quads (MPI.py:364-436, MPV.py:235-288).  Here
+ * param / exp_avg / exp_avg_sq are pools of 8 x 8-texel blocks (vl3d_adam_window_tile()): blocks [D][ceil(Hs/8)][ceil(Ws/8)] int32 = -1 for
+ * a block no kept quad can read (not stored), else slot << 1 | dynamic, a slot being 64 texels (1 KiB); a static block owns one slot, a
+ * dynamic block T consecutive ones (frame-major).  The compact window copy / gradient the render kernels work on stay dense, so the
+ * kernels of the hot path are unchanged and the parameters after every step have the bits of the dense (D,T,Hs,Ws,4) model; the pool of
+ * a model with 16 % of its quads kept is about a seventh of the dense stack (videoloop3d_amd/packed.py).
+ *
+ * The same two with per-plane boxes: plane_boxes [D][4] = (y0, y1, x0, x1) in plane texels, tile aligned, inside the window, in HOST
  * memory -- 16 bytes per plane that travel in the kernel arguments, no copy, no synchronisation (NULL, or more than 128 planes: the whole
  * window for every plane).  The window of a crop is the union of the planes' footprints; texels of the window outside
  * their own plane's box cannot be sampled in this iteration, their gradient is exactly zero and their update stays deferred like that of
@@ -173,18 +181,18 @@ int vl3d_adam_window_catchup_boxes(int32_t D, int32_t T, int32_t Hs, int32_t Ws,
                                    float *param, float *exp_avg, float *exp_avg_sq, int32_t *last_step, const float *hist, int32_t upto,
                                    float beta1, float beta2, float eps, float *compact, const uint8_t *quad_keep, const uint8_t *quad_dyn,
                                    int32_t QH, int32_t QW, float culled_alpha, int32_t mirror_static, const int32_t *plane_boxes,
-                                   vl3d_stream_t stream);
+                                   const int32_t *blocks, vl3d_stream_t stream);
 int vl3d_adam_window_step_boxes(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
                                 float *param, const float *grad_compact, float *exp_avg, float *exp_avg_sq, int32_t *last_step,
                                 const float *hist, float lr, float beta1, float beta2, float eps, int64_t step, const uint8_t *quad_keep,
                                 const uint8_t *quad_dyn, int32_t QH, int32_t QW, int32_t static_tied, const int32_t *plane_boxes,
-                                vl3d_stream_t stream);
+                                const int32_t *blocks, vl3d_stream_t stream);
 /* Bound on the deferral: every bookkeeping tile that has missed at least min_depth steps is replayed up to `upto`, written back and marked
  * (the others are left alone).  Run after each step it keeps what a returning crop window has to replay below min_depth steps per texel
  * -- the reference shuffles 32-72 crops x views per epoch (train_3dvid.py:263-290), so a window comes back after that many steps. */
 int vl3d_adam_flush_older(int32_t D, int32_t T, int32_t Hs, int32_t Ws, float *param, float *exp_avg, float *exp_avg_sq, int32_t *last_step,
                           const float *hist, int32_t upto, int32_t min_depth, float beta1, float beta2, float eps, const uint8_t *quad_keep,
-                          const uint8_t *quad_dyn, int32_t QH, int32_t QW, vl3d_stream_t stream);
+                          const uint8_t *quad_dyn, int32_t QH, int32_t QW, const int32_t *blocks, vl3d_stream_t stream);
 void vl3d_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, float *lr_bc1, float *bc2s);
 
 /* Layer-space smoothness regularisers (MPV.py:517-531 rgb_smooth / a_smooth; MPI.py:608-622) WITHOUT the materialised [T,h,w,K,4]

@@ -400,3 +400,101 @@ def test_tile_adam_static_texels_are_one_parameter(dev):
         assert float((pa - pb).abs().max()) <= 2e-6
     static_t = (tiles.quad_to_texel_mask(keep, Hs, Ws) & ~tiles.quad_to_texel_mask(dyn, Hs, Ws))[:, None, :, :, None].expand_as(p0)
     assert torch.equal(pb.detach()[:, :1].expand_as(p0)[static_t], pb.detach()[static_t])    # the copies stayed identical
+
+
+def _sparsified_pair(dev, frames=5):
+    """a sparsified stage-1 MPI handed to two stage-2 models: the dense one and one to be packed"""
+    from videoloop3d_amd.MPI import MPMesh
+    from videoloop3d_amd.MPV import MPMeshVid
+    H, W = 44, 60
+    K, ref_extrin, tar = scene(H, W)
+    a1 = make_args_mpi(learn_loop_mask=True, mpi_h_verts=5, mpi_w_verts=7, sparsify_rmfirstlayer=0)
+    mpi = MPMesh(a1, H, W, ref_extrin, K, 1.0, 100.0).to(dev)
+    with torch.no_grad():
+        mpi.stack.copy_(synth.make_plane_stack(*mpi.stack.shape[:4], seed=7) * 0.5)
+        mpi.stack[..., 3] = -6.0
+        mpi.stack[2, 0, 6:30, 8:50, 3] = 2.0
+        mpi.stack[4, 0, 10:40, 20:60, 3] = 1.0
+        mpi.stack[1, 0, 30:46, 4:30, 3] = 0.5
+        mpi.stack_mask[4, 0, 15:30, 28:50] = 4.0
+    mpi.sparsify_faces(erode_num=1)
+    a2 = make_args(mpv_frm_num=frames, mpi_d=a1.mpi_d, mpi_h_scale=a1.mpi_h_scale, mpi_w_scale=a1.mpi_w_scale, lrate=0.05, lrate_decay=30,
+                   optimizer="adam", optimize_verts_gain=1, mpi_h_verts=5, mpi_w_verts=7)
+    sd = mpi.state_dict()
+    dense = MPMeshVid(a2, H, W, ref_extrin, K, 1.0, 100.0).to(dev)
+    dense.init_from_mpi(sd)
+    packed = MPMeshVid(a2, H, W, ref_extrin, K, 1.0, 100.0).to(dev)
+    packed.init_from_mpi({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in sd.items()}, packed=True)      # the checkpoint stays on the host
+    return dense, packed, (H, W, K, tar)
+
+
+def test_packed_model_trains_and_renders_like_the_dense_one(dev):
+    """§8f-2: static blocks stored once, dynamic blocks per frame, culled blocks not at all (MPI.py:364-436, MPV.py:235-288).  A packed
+    model has the dense + quad-map model's BITS: evaluation images (whole clip, frame subsets), losses of training iterations over
+    shifting crops and poses, and the parameters afterwards -- while its texture memory is a fraction of the dense stack's."""
+    from videoloop3d_amd import tiles
+    dense, packed, (H, W, K, tar) = _sparsified_pair(dev)
+    assert packed.packed is not None and "stack" not in dict(packed.named_parameters())
+    assert packed.packed.pool_bytes < 0.6 * packed.packed.dense_bytes
+    D, T, Hs, Ws = dense.stack.shape[:4]
+    tar_e, tar_k = torch.tensor(tar)[None].to(dev), torch.tensor(K)[None].to(dev)
+    for m in (dense, packed):
+        m.eval()
+    with torch.no_grad():
+        for ts in (None, torch.tensor([3]), torch.tensor([4, 0, 2])):
+            ra, _ = dense(H, W, tar_e, tar_k, ts=ts)
+            rb, _ = packed(H, W, tar_e, tar_k, ts=ts)
+            assert torch.equal(ra, rb)
+    res = synth.make_video(9, 24, 32, seed=31, device=dev)[0].permute(1, 0, 2, 3)[None].contiguous()      # [1,F,3,h,w]
+    cfg = collate({"loss_name": "gpnn_lm", "patch_size": 3, "patcht_size": 3, "stride": 2, "stridet": 1, "alpha": 10000.0,
+                   "rou": "-2", "scaling": 0.1, "macro_block": 65})
+    opts = []
+    for m in (dense, packed):
+        m.train()
+        opts.append(m.get_optimizer(0))
+    for it in range(7):
+        Kc = K.copy()
+        Kc[0, 2] -= 4 + (it % 3) * 9
+        Kc[1, 2] -= 3 + (it % 2) * 11
+        te = tar.copy()
+        te[:3, 3] += [0.01 * (it % 4), -0.005 * (it % 3), 0.0]
+        losses = []
+        for m, opt in zip((dense, packed), opts):
+            _, extra = m(24, 32, torch.tensor(te)[None], torch.tensor(Kc)[None], res=res, losscfg=dict(cfg))
+            loss = extra["swd"].mean() + 0.2 * extra["rgb_smooth"].mean() + 0.2 * extra["a_smooth"].mean()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        assert losses[0] == losses[1]
+    now = dense.state_dict()["stack"]
+    sd_p = packed.state_dict()
+    assert "stack" not in sd_p and "stack_pool" in sd_p
+    keep_t = tiles.quad_to_texel_mask(dense.quad_keep, Hs, Ws)
+    for d in range(D):
+        pl = packed.stack_plane(d)
+        m = keep_t[d][None, :, :, None].expand_as(pl)
+        assert torch.equal(pl[m], now[d][m])
+    # checkpoint round trip of the packed model, and lod() of both
+    from videoloop3d_amd.MPV import MPMeshVid
+    again = MPMeshVid(packed.args, H, W, packed.ref_extrin.cpu().numpy(), K, 1.0, 100.0).to(dev)
+    again.init_from_mpi(sd_p)
+    assert torch.equal(again.stack_pool.detach(), packed.stack_pool.detach()) and torch.equal(again.packed.blocks, packed.packed.blocks)
+    for m in (dense, packed):
+        m.lod(0.75)
+        m.eval()
+    with torch.no_grad():
+        ra, _ = dense(H, W, tar_e, tar_k, ts=torch.tensor([1, 3]))
+        rb, _ = packed(H, W, tar_e, tar_k, ts=torch.tensor([1, 3]))
+    assert torch.equal(ra, rb)
+
+
+def test_packed_model_exports_the_reference_layout_like_the_dense_one(dev):
+    dense, packed, _ = _sparsified_pair(dev, frames=3)
+    a, b = dense.reference_state_dict(), packed.reference_state_dict()
+    assert set(a) == set(b)
+    for k in a:
+        if torch.is_tensor(a[k]):
+            assert torch.equal(a[k].cpu(), b[k].cpu()), k
+        else:
+            assert a[k] == b[k], k

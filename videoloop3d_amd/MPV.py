@@ -111,6 +111,7 @@ class MPMeshVid(nn.Module):
         self._tie_hook = None
         self._static_compact = False
         self._window_opt = None          # the crop-aware Adam handed out by get_optimizer (dense CUDA models)
+        self.packed = None               # packed.PackedLayout once pack_() has replaced the dense stack by the pool `stack_pool`
 
         self.swd_patch_size, self.swd_patcht_size = args.swd_patch_size, args.swd_patcht_size
         self.swd_stride, self.swd_stridet = args.swd_stride, args.swd_stridet
@@ -122,9 +123,61 @@ class MPMeshVid(nn.Module):
             'avg': Patch3DAvg,
         }
 
+    # ---- packed storage of a tile-culled model (videoloop3d_amd/packed.py) -------------------------------------------------
+    def _param(self):
+        """the texture parameter: the dense stack, or the pool of a packed model."""
+        return self.stack_pool if self.packed is not None else self.stack
+
+    def stack_dims(self):
+        """(D, T, Hs, Ws) of the plane stack, whichever way it is stored."""
+        if self.packed is not None:
+            return self.packed.D, self.packed.T, self.packed.Hs, self.packed.Ws
+        return tuple(self.stack.shape[:4])
+
+    def stack_plane(self, d, frames=None):
+        """(T' ,Hs,Ws,4): plane d of the dense stack (all frames or `frames`), current (deferred updates flushed by the caller)."""
+        if self.packed is not None:
+            return self.packed.unpack_plane(self.stack_pool.data, d, frames)
+        return self.stack.data[d] if frames is None else self.stack.data[d, torch.as_tensor(frames, device=self.stack.device).long()]
+
+    @torch.no_grad()
+    def pack_(self, stack=None):
+        """Replace the dense stack of a SPARSIFIED model by the packed pool: static blocks stored once, dynamic blocks per frame, culled
+        blocks not at all (the reference's static / dynamic atlases, MPI.py:364-436, MPV.py:235-288) -- about a seventh of the dense
+        bytes at 16 % kept quads.  Training (window path of the crop-aware Adam), evaluation renders of chosen frames, lod(), state_dict()
+        and the export to the reference's layout work on the pool; results have the dense model's bits.
+        stack (optional): a dense (D,T,Hs,Ws,4) tensor on ANY device (e.g. a reference checkpoint resampled on the host) to pack instead
+        of self.stack -- it never has to exist on the GPU."""
+        from .packed import PackedLayout
+        if not (self.is_sparse and self.quad_keep is not None):
+            raise RuntimeError("pack_() needs the quad maps of a sparsified model (init_from_mpi of a sparsified MPI)")
+        if self.atlas_exact:
+            raise RuntimeError("atlas_exact renders the dense stack")
+        self._flush_deferred_updates()
+        self._window_opt = None
+        dev = self._param().device
+        src = self.stack.data if stack is None else stack
+        lay = PackedLayout(self.quad_keep.to(dev), self.quad_dyn.to(dev), src.shape[1], src.shape[2], src.shape[3])
+        pool = lay.new_pool(dev)
+        for d in range(lay.D):
+            lay.pack_plane_(pool, d, src[d])
+        if self._tie_hook is not None:
+            self._tie_hook.remove()
+            self._tie_hook = None
+        if "stack" in self._parameters:
+            del self._parameters["stack"]
+        if "stack_pool" in self._parameters:
+            del self._parameters["stack_pool"]
+        self.register_parameter("stack_pool", nn.Parameter(pool, requires_grad=True))
+        self.packed = lay
+        self.frm_num = lay.T
+        return self
+
     # ---- stage-1 -> stage-2 hand-over (MPV.py:235-304) ------------------------------------------------------------------
-    def init_from_mpi(self, state_dict):
-        """MPV.py:235-288 for the dense representation: take the stage-1 MPI (`MPMesh.state_dict()`) as the initial value of
+    def init_from_mpi(self, state_dict, packed=False):
+        """packed=True (sparsified checkpoints): go straight to the packed pool (pack_()); the checkpoint's dense form stays where the
+        caller put it (the host) and never exists on the GPU.  Checkpoints of a packed model ('stack_pool') are loaded as such.
+        MPV.py:235-288 for the dense representation: take the stage-1 MPI (`MPMesh.state_dict()`) as the initial value of
         every frame.  With a sparsified MPI the quad maps come along: culled quads stay invisible, static quads stay ONE
         texture shared by all frames (their gradient is summed over the frames, as the reference's static atlas sees it),
         dynamic quads are free per frame; without them everything is dynamic ("load static as dynamic", MPV.py:266-288)."""
@@ -142,14 +195,46 @@ class MPMeshVid(nn.Module):
         self.ref_intrin.data = state_dict['ref_intrin'].type_as(self.ref_intrin)
         self.planedepth.data = state_dict['planedepth'].type_as(self.planedepth)
         self.ref_intrin_mpi.data = get_new_intrin(self.ref_intrin, -self.H_start, -self.W_start)
+        dev = self._param().device
+        if "stack_pool" in state_dict:       # a checkpoint of a packed model of this package: quad maps + dims rebuild the block table
+            from .packed import PackedLayout
+            D, T, hs, ws = (int(v) for v in state_dict["self.packed_dims"])
+            self.register_buffer("quad_keep", state_dict["quad_keep"].to(dev).bool())
+            self.register_buffer("quad_dyn", state_dict["quad_dyn"].to(dev).bool())
+            lay = PackedLayout(self.quad_keep, self.quad_dyn, T, hs, ws)
+            pool = state_dict["stack_pool"].to(dev, torch.float32).reshape(-1, 4).contiguous()
+            if pool.shape[0] != lay.n_slots * 64:
+                raise RuntimeError("packed checkpoint: the pool does not match the block table of its quad maps")
+            for name in ("stack", "stack_pool"):
+                self._parameters.pop(name, None)
+            self.register_parameter("stack_pool", nn.Parameter(pool, requires_grad=True))
+            self.packed, self.frm_num, self.is_sparse, self.has_dyn = lay, T, True, True
+            self._window_opt = None
+            self.spec = dataclasses.replace(self.spec, scale=(self.texel_scale[0] * (ws - 1) / max(self.mpi_w - 1, 1),
+                                                              self.texel_scale[1] * (hs - 1) / max(self.mpi_h - 1, 1)))
+            return
         mpi = state_dict['stack']
         if mpi.dim() != 5 or mpi.shape[0] != self.mpi_d or mpi.shape[-1] != 4:
             raise RuntimeError(f"checkpoint stack {tuple(mpi.shape)} does not match mpi_d={self.mpi_d}")
         if mpi.shape[1] not in (1, self.frm_num):        # a stage-2 checkpoint with another frame count (MPV.py:262-265)
             print(f"Warnining, inconsistent frame number detected, change from {self.frm_num} to {mpi.shape[1]}")
             self.frm_num = int(mpi.shape[1])
+        if packed:
+            if not bool(state_dict.get("self.is_sparse", False)):
+                raise RuntimeError("init_from_mpi(packed=True) needs a sparsified checkpoint (quad maps)")
+            self.is_sparse, self.has_dyn = True, bool(state_dict.get("self.has_dyn", False))
+            self.register_buffer("quad_keep", state_dict["quad_keep"].to(dev).bool())
+            self.register_buffer("quad_dyn", state_dict["quad_dyn"].to(dev).bool())
+            hs, ws = mpi.shape[2:4]
+            self.spec = dataclasses.replace(self.spec, scale=(self.texel_scale[0] * (ws - 1) / max(self.mpi_w - 1, 1),
+                                                              self.texel_scale[1] * (hs - 1) / max(self.mpi_h - 1, 1)))
+            self.pack_(stack=mpi.float().expand(-1, self.frm_num, -1, -1, -1))      # (a view: a static MPI is not copied T times)
+            return
+        if self.packed is not None:
+            self._parameters.pop("stack_pool", None)
+            self.packed = None
         with torch.no_grad():
-            new = mpi.type_as(self.stack).expand(-1, self.frm_num, -1, -1, -1).contiguous()
+            new = mpi.to(dev, torch.float32).expand(-1, self.frm_num, -1, -1, -1).contiguous()
         self.register_parameter("stack", nn.Parameter(new, requires_grad=True))
         # planes saved at a pyramid level (lod) keep their extent: the plane-pixel -> texel scale follows the texture size
         hs, ws = new.shape[2:4]
@@ -170,6 +255,8 @@ class MPMeshVid(nn.Module):
         if self._tie_hook is not None:
             self._tie_hook.remove()
             self._tie_hook = None
+        if self.packed is not None:      # a packed model trains through the window leaf: static gradients are summed inside the step
+            return
         if self.is_sparse and self.quad_keep is not None:
             from . import tiles
             if self.stack.is_cuda:    # the gradient comes from the culled render: culled texels already hold exact zeros
@@ -186,6 +273,8 @@ class MPMeshVid(nn.Module):
         sd = super().state_dict(*args, **kwargs)
         sd["self.is_sparse"] = self.is_sparse
         sd["self.has_dyn"] = self.has_dyn
+        if self.packed is not None:
+            sd["self.packed_dims"] = self.stack_dims()      # with quad_keep / quad_dyn this rebuilds the block table (init_from_mpi)
         return sd
 
     # ---- driver hooks (train_3dvid.py:264-281) ------------------------------------------------------------------------
@@ -198,9 +287,28 @@ class MPMeshVid(nn.Module):
         self._flush_deferred_updates()
         self._window_opt = None          # the parameter object changes: the driver asks for a new optimiser (train_3dvid.py:264-265)
         h, w = max(int(self.mpi_h * factor), 2), max(int(self.mpi_w * factor), 2)
-        D, T, hs, ws, _ = self.stack.shape
+        D, T, hs, ws = self.stack_dims()
         print(f"MPV.lod:: Resizing the planes from {(hs, ws)} to {(h, w)}")
-        if (hs, ws) != (h, w):
+        if (hs, ws) != (h, w) and self.packed is not None:
+            # packed model: plane by plane through the dense form of ONE plane (1/D of the dense stack), the same mask-weighted filter
+            from . import tiles
+            from .packed import PackedLayout
+            with torch.no_grad():
+                dev = self.stack_pool.device
+                lay = PackedLayout(self.quad_keep.to(dev), self.quad_dyn.to(dev), T, h, w)
+                pool = lay.new_pool(dev)
+                for d in range(D):
+                    planes = self.packed.unpack_plane(self.stack_pool.data, d).permute(0, 3, 1, 2)               # T,4,hs,ws
+                    m = tiles.quad_to_texel_mask(self.quad_keep[d:d + 1], hs, ws).to(planes.dtype)[None]         # 1,1,hs,ws
+                    num = torch.nn.functional.interpolate(planes * m, size=(h, w), mode="bilinear", align_corners=False, antialias=True)
+                    den = torch.nn.functional.interpolate(m, size=(h, w), mode="bilinear", align_corners=False, antialias=True)
+                    new = (num / den.clamp_min(1e-6)).permute(0, 2, 3, 1).contiguous()
+                    tiles.cull_stack_(new[None], self.quad_keep[d:d + 1])
+                    lay.pack_plane_(pool, d, new)
+            del self._parameters["stack_pool"]
+            self.register_parameter("stack_pool", nn.Parameter(pool, requires_grad=True))
+            self.packed = lay
+        elif (hs, ws) != (h, w):
             sparse = self.is_sparse and self.quad_keep is not None
             with torch.no_grad():
                 new = torch.empty((D, T, h, w, 4), dtype=self.stack.dtype, device=self.stack.device)
@@ -247,7 +355,7 @@ class MPMeshVid(nn.Module):
         c = float(self.spec.pixel_center)
         pts = torch.tensor([[c, W - 1 + c, c, W - 1 + c], [c, c, H - 1 + c, H - 1 + c], [1.0, 1.0, 1.0, 1.0]], dtype=torch.float64)
         q = homos.double() @ pts                                                                  # D,3,4
-        Hs, Ws = self.stack.shape[2:4]
+        Hs, Ws = self.stack_dims()[2:4]
         if bool((q[:, 2] <= 1e-9).any()):
             return ((0, 0, Hs, Ws), None) if per_plane else (0, 0, Hs, Ws)
         tx = q[:, 0] / q[:, 2] * self.spec.scale[0] + self.spec.offset[0]
@@ -301,6 +409,12 @@ class MPMeshVid(nn.Module):
         self._static_compact = False
         self._window_opt = None
         if self.args.optimizer == 'adam':
+            if self.packed is not None:
+                from .optim import WindowAdam
+                from .tiles import CULLED_ALPHA
+                self._window_opt = WindowAdam([{'params': [self.stack_pool]}], lr=base_lr, betas=(0.9, 0.999), eps=6e-8, quad_keep=self.quad_keep,
+                                              quad_dyn=self.quad_dyn, culled_alpha=CULLED_ALPHA, layout=self.packed)
+                return self._window_opt
             if self.stack.is_cuda and self.is_sparse and getattr(self.args, "tile_adam", False):
                 # (the round-1 optimiser of sparsified models, kept selectable: one pass over the kept texels of the WHOLE stack, static
                 # gradients summed into frame 0 by the tie hook while it is the optimiser handed out last)
@@ -356,36 +470,50 @@ class MPMeshVid(nn.Module):
         return cache[name][1]
 
     # ---- render ------------------------------------------------------------------------------------------------------
+    def _all_frames(self, ts):
+        return len(ts) == self.frm_num and bool((torch.as_tensor(ts).cpu() == torch.arange(self.frm_num)).all())
+
     def _frames(self, ts):
-        if len(ts) == self.frm_num and bool((torch.as_tensor(ts).cpu() == torch.arange(self.frm_num)).all()):
+        if self.packed is not None:
+            return None if self._all_frames(ts) else self.packed.unpack_frames(self.stack_pool.data, torch.as_tensor(ts).tolist())
+        if self._all_frames(ts):
             return self.stack
         return self.stack[:, torch.as_tensor(ts, device=self.stack.device).long()]
 
     def render(self, H, W, extrin, intrin, ts, need_layers=False, need_smooth=False):
         """MPV.py:351-475 -> (rgb [T',H,W,3], variables).  `variables['mpi']`/`['blend_weight']` (the warped per-layer
         rgba, only consumed by the smoothness/sparsity regularisers) are materialised on demand with the unfused operators."""
-        stack = self._frames(ts)
+        if self.packed is not None and not self._all_frames(ts):
+            self._flush_deferred_updates()
+        stack = self._frames(ts)          # (a packed model: None for the full clip -- the window path below, or unpacked on demand)
+        all_frames = stack is None or stack is getattr(self, "stack", None)
         homos = self.plane_homographies(extrin, intrin)
         smooth_sums = alpha_sums = None
         spec = self.spec
         cull_window = None
         if self._window_opt is not None:
-            if self.training and torch.is_grad_enabled() and stack is self.stack:
+            if self.training and torch.is_grad_enabled() and all_frames:
                 # crop-aware training step: render from a compact, up-to-date copy of the texel window this view can reach
                 # (homographies on the host: a few hundred bytes; CPU inputs cost nothing, device inputs one small sync)
                 (y0, x0, wh, ww), boxes = self.crop_window(homos.detach().cpu(), H, W, per_plane=True)
                 if wh > 0 and ww > 0:
-                    cull_window = (y0, x0) + tuple(self.stack.shape[2:4])
+                    cull_window = (y0, x0) + tuple(self.stack_dims()[2:4])
                     stack = self._window_opt.window_leaf((y0, x0, wh, ww), boxes if self.per_plane_boxes else None)
                     spec = dataclasses.replace(spec, offset=(spec.offset[0] - x0, spec.offset[1] - y0))
             else:
                 self._flush_deferred_updates()
-        if homos.device.type == "cpu" and self.stack.is_cuda:
+        if stack is None:
+            if self.training and torch.is_grad_enabled():
+                raise RuntimeError("a packed model trains through the crop-aware optimiser: call get_optimizer() first (train_3dvid.py:264-265)")
+            # an evaluation render of the whole clip from the pool: the frames are unpacked (the dense stack exists for this call only)
+            self._flush_deferred_updates()
+            stack = self.packed.unpack_frames(self.stack_pool.data, range(self.frm_num))
+        if homos.device.type == "cpu" and self._param().is_cuda:
             # host homographies (a few hundred bytes): through a pinned staging buffer and an asynchronous copy -- a pageable upload is a
             # full host-device synchronisation in the middle of the forward, after which the GPU idles while the launches catch up
-            homos = homos.pin_memory().to(self.stack.device, non_blocking=True)
+            homos = homos.pin_memory().to(self._param().device, non_blocking=True)
         else:
-            homos = homos.to(self.stack.device)
+            homos = homos.to(self._param().device)
         if self.atlas_exact:
             if need_smooth or self.is_sparse or tuple(stack.shape[2:4]) != (self.mpi_h, self.mpi_w):
                 raise RuntimeError("atlas_exact renders the dense full-resolution stack without the fused regularisers / tile culling / lod")

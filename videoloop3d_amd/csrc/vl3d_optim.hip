@@ -81,13 +81,32 @@ __device__ __forceinline__ int texel_class(const Quads &q, int d, int x, int y, 
     return (m[ylo * q.QW + xlo] | m[ylo * q.QW + xhi] | m[yhi * q.QW + xlo] | m[yhi * q.QW + xhi]) ? 1 : 2;
 }
 
+// PACKED storage of a tile-culled model (the reference stores static quads once, dynamic quads per frame and culled quads not at all:
+// MPI.py:364-436, MPV.py:235-288).  Parameters and moments live in a pool of 8 x 8-texel blocks (the bookkeeping tiles): blocks [D][tiles_y][tiles_x]
+// int32 = -1 for a block no kept quad can read (no storage), else slot << 1 | dynamic -- a static block (only static quads can read it) is ONE
+// slot of 64 texels, a dynamic block T consecutive slots (frame-major).  A texel's class (texel_class) and everything computed from it
+// are those of the dense layout: only the address changes, so training from the pool gives the dense model's bits.  blocks == NULL: the
+// dense (D,T,Hs,Ws,4) stack.
+struct Layout { const int *blocks; };
+// index (in texels) of frame 0 of texel (d, y, x) and the stride between its frames (0: one shared copy)
+__device__ __forceinline__ void texel_slot(const Layout &L, int d, int y, int x, int T, int Hs, int Ws, int tiles_y, int tiles_x, size_t &o, size_t &fs) {
+    if (!L.blocks) {
+        fs = (size_t)Hs * Ws;
+        o = (size_t)d * T * fs + (size_t)y * Ws + x;
+        return;
+    }
+    const int e = L.blocks[((size_t)d * tiles_y + y / TS) * tiles_x + x / TS];      // (>= 0 for every texel that is a parameter)
+    o = (size_t)(e >> 1) * (TS * TS) + (size_t)((y % TS) * TS + (x % TS));
+    fs = (e & 1) ? (size_t)(TS * TS) : 0;
+}
+
 // one thread per window texel and plane, looping over the frames.  `upto`: the step the window must be current for (the
 // step about to be taken minus one).  compact (optional): (D,T,wh,ww,4) copy of the window's parameters after the catch-up.
 __global__ __launch_bounds__(256) void adam_window_catchup_k(int T, int Hs, int Ws, Win w, float4 *__restrict__ p, float4 *__restrict__ m,
                                                              float4 *__restrict__ v, const int *__restrict__ last_step, int tiles_y, int tiles_x,
                                                              const float2 *__restrict__ hist, int upto, float beta1, float beta2, float eps,
                                                              float4 *__restrict__ compact, Quads q, float culled_alpha, int mirror,
-                                                             int writeback, const BoxTable boxes) {
+                                                             int writeback, const BoxTable boxes, Layout lay) {
     const int lx = blockIdx.x * 64 + (threadIdx.x & 63), ly = blockIdx.y * 4 + (threadIdx.x >> 6), d = blockIdx.z;
     if (lx >= w.ww || ly >= w.wh) return;
     const int x = w.x0 + lx, y = w.y0 + ly;
@@ -99,14 +118,16 @@ __global__ __launch_bounds__(256) void adam_window_catchup_k(int T, int Hs, int 
         return;
     }
     const int from = last_step[((size_t)d * tiles_y + y / TS) * tiles_x + x / TS];
-    const size_t frame = (size_t)Hs * Ws, cframe = (size_t)w.wh * w.ww;
-    size_t o = (size_t)d * T * frame + (size_t)y * Ws + x, oc = (size_t)d * T * cframe + (size_t)ly * w.ww + lx;
+    const size_t cframe = (size_t)w.wh * w.ww;
+    size_t oc = (size_t)d * T * cframe + (size_t)ly * w.ww + lx;
     const int cls = texel_class(q, d, x, y, Hs, Ws);
     if (cls == 0) {           // culled: not a parameter; the render must see it transparent (and finite)
         if (compact)
             for (int t = 0; t < T; ++t, oc += cframe) compact[oc] = make_float4(0.f, 0.f, 0.f, culled_alpha);
         return;
     }
+    size_t o, frame;
+    texel_slot(lay, d, y, x, T, Hs, Ws, tiles_y, tiles_x, o, frame);
     if (cls == 2) {           // static: the one parameter lives in frame 0; every frame of the compact copy shows it
         float4 pp = p[o];
         if (from < upto) {
@@ -116,7 +137,7 @@ __global__ __launch_bounds__(256) void adam_window_catchup_k(int T, int Hs, int 
         }
         if (compact)
             for (int t = 0; t < T; ++t, oc += cframe) compact[oc] = pp;
-        if (mirror)           // flush: refresh the other frames' slots so that the dense stack reads consistently everywhere
+        if (mirror && frame)  // flush: refresh the other frames' slots so that the stack reads consistently everywhere (a static block has one copy)
             for (int t = 1; t < T; ++t) p[o + (size_t)t * frame] = pp;
         return;
     }
@@ -137,17 +158,19 @@ __global__ __launch_bounds__(256) void adam_window_step_k(int T, int Hs, int Ws,
                                                           float4 *__restrict__ m, float4 *__restrict__ v, float lr_bc1, float beta1, float beta2,
                                                           float eps, float bc2s, Quads q, int static_tied, const int *__restrict__ last_step,
                                                           int tiles_y, int tiles_x, const float2 *__restrict__ hist, int step,
-                                                          const BoxTable boxes) {
+                                                          const BoxTable boxes, Layout lay) {
     const int lx = blockIdx.x * 64 + (threadIdx.x & 63), ly = blockIdx.y * 4 + (threadIdx.x >> 6), d = blockIdx.z;
     if (lx >= w.ww || ly >= w.wh) return;
     if (outside_box(boxes, d, w.x0 + lx, w.y0 + ly)) return;     // zero gradient by construction: the update stays deferred
     // the zero-gradient steps this texel's tile has not seen yet are replayed HERE, in front of the real step: the catch-up before
     // the render only computed the current parameters for the compact copy and wrote nothing back (3 write streams fewer)
     const int from = last_step[((size_t)d * tiles_y + (w.y0 + ly) / TS) * tiles_x + (w.x0 + lx) / TS];
-    const size_t frame = (size_t)Hs * Ws, cframe = (size_t)w.wh * w.ww;
-    size_t o = (size_t)d * T * frame + (size_t)(w.y0 + ly) * Ws + (w.x0 + lx), oc = (size_t)d * T * cframe + (size_t)ly * w.ww + lx;
+    const size_t cframe = (size_t)w.wh * w.ww;
+    size_t oc = (size_t)d * T * cframe + (size_t)ly * w.ww + lx;
     const int cls = texel_class(q, d, w.x0 + lx, w.y0 + ly, Hs, Ws);
     if (cls == 0) return;
+    size_t o, frame;
+    texel_slot(lay, d, w.y0 + ly, w.x0 + lx, T, Hs, Ws, tiles_y, tiles_x, o, frame);
     if (cls == 2) {           // static: gradient = the sum over the frames (frame order: deterministic), one update, one write
         float4 gg = g[oc];
         for (int t = 1; t < T && !static_tied; ++t) {        // static_tied: frame 0 already holds the frame sum (tie_static_grad)
@@ -203,17 +226,17 @@ int check_window(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32
 __global__ __launch_bounds__(64) void adam_flush_older_k(int T, int Hs, int Ws, float4 *__restrict__ p, float4 *__restrict__ m,
                                                          float4 *__restrict__ v, int *__restrict__ last_step, int tiles_y, int tiles_x,
                                                          const float2 *__restrict__ hist, int upto, int min_depth, float beta1, float beta2,
-                                                         float eps, Quads q) {
+                                                         float eps, Quads q, Layout lay) {
     const int tile = blockIdx.x, d = blockIdx.y, ty = tile / tiles_x, tx = tile - ty * tiles_x;
     int *ls = last_step + ((size_t)d * tiles_y + ty) * tiles_x + tx;
     const int from = *ls;
     if (upto - from < min_depth) return;                     // uniform
     const int x = tx * TS + (threadIdx.x % TS), y = ty * TS + (threadIdx.x / TS);
     if (x < Ws && y < Hs) {
-        const size_t frame = (size_t)Hs * Ws;
-        size_t o = (size_t)d * T * frame + (size_t)y * Ws + x;
         const int cls = texel_class(q, d, x, y, Hs, Ws);
         const int nt = cls == 0 ? 0 : (cls == 2 ? 1 : T);    // culled: no parameter; static: the one copy in frame 0
+        size_t o = 0, frame = 0;
+        if (nt) texel_slot(lay, d, y, x, T, Hs, Ws, tiles_y, tiles_x, o, frame);
         for (int t = 0; t < nt; ++t, o += frame) {
             float4 pp = p[o], mm = m[o], vv = v[o];
             replay(pp, mm, vv, hist, from, upto, beta1, beta2, eps);
@@ -227,15 +250,17 @@ extern "C" int32_t vl3d_adam_window_tile(void) { return TS; }
 
 extern "C" int vl3d_adam_flush_older(int32_t D, int32_t T, int32_t Hs, int32_t Ws, float *param, float *exp_avg, float *exp_avg_sq,
                                      int32_t *last_step, const float *hist, int32_t upto, int32_t min_depth, float beta1, float beta2, float eps,
-                                     const uint8_t *quad_keep, const uint8_t *quad_dyn, int32_t QH, int32_t QW, vl3d_stream_t stream) {
+                                     const uint8_t *quad_keep, const uint8_t *quad_dyn, int32_t QH, int32_t QW, const int32_t *blocks,
+                                     vl3d_stream_t stream) {
     VL3D_REQUIRE(D > 0 && D <= 65535 && T > 0 && Hs > 0 && Ws > 0, "vl3d_adam_flush_older: bad dims");
+    VL3D_REQUIRE(!blocks || quad_keep, "vl3d_adam_flush_older: the packed layout belongs to a tile-culled model (quad maps)");
     VL3D_REQUIRE(param && exp_avg && exp_avg_sq && last_step && hist && upto >= 0 && min_depth >= 1, "vl3d_adam_flush_older: null pointer / bad step");
     VL3D_REQUIRE(!quad_keep || (QH > 0 && QW > 0), "vl3d_adam_flush_older: bad quad grid");
     static_assert(TS * TS == 64, "one wave per bookkeeping tile");
     const int tiles_y = (Hs + TS - 1) / TS, tiles_x = (Ws + TS - 1) / TS;
     hipLaunchKernelGGL(adam_flush_older_k, dim3(tiles_y * tiles_x, D), dim3(64), 0, (hipStream_t)stream, T, Hs, Ws, reinterpret_cast<float4 *>(param),
                        reinterpret_cast<float4 *>(exp_avg), reinterpret_cast<float4 *>(exp_avg_sq), last_step, tiles_y, tiles_x,
-                       reinterpret_cast<const float2 *>(hist), upto, min_depth, beta1, beta2, eps, Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW});
+                       reinterpret_cast<const float2 *>(hist), upto, min_depth, beta1, beta2, eps, Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW}, Layout{blocks});
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
 }
@@ -244,8 +269,9 @@ extern "C" int vl3d_adam_window_catchup_boxes(int32_t D, int32_t T, int32_t Hs, 
                                               float *param, float *exp_avg, float *exp_avg_sq, int32_t *last_step, const float *hist,
                                               int32_t upto, float beta1, float beta2, float eps, float *compact, const uint8_t *quad_keep,
                                               const uint8_t *quad_dyn, int32_t QH, int32_t QW, float culled_alpha, int32_t mirror_static,
-                                              const int32_t *plane_boxes, vl3d_stream_t stream) {
+                                              const int32_t *plane_boxes, const int32_t *blocks, vl3d_stream_t stream) {
     int rc = check_window(D, T, Hs, Ws, y0, x0, wh, ww);
+    VL3D_REQUIRE(!blocks || quad_keep, "vl3d_adam_window_catchup: the packed layout belongs to a tile-culled model (quad maps)");
     if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE(param && exp_avg && exp_avg_sq && last_step && hist && upto >= 0, "vl3d_adam_window_catchup: null pointer / negative step");
     VL3D_REQUIRE(!quad_keep || (QH > 0 && QW > 0), "vl3d_adam_window_catchup: bad quad grid");
@@ -256,7 +282,7 @@ extern "C" int vl3d_adam_window_catchup_boxes(int32_t D, int32_t T, int32_t Hs, 
                        reinterpret_cast<float4 *>(param), reinterpret_cast<float4 *>(exp_avg), reinterpret_cast<float4 *>(exp_avg_sq), last_step,
                        tiles_y, tiles_x, reinterpret_cast<const float2 *>(hist), upto, beta1, beta2, eps, reinterpret_cast<float4 *>(compact),
                        Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW}, culled_alpha, mirror_static, compact ? 0 : 1,
-                       boxes);
+                       boxes, Layout{blocks});
     if (!compact) {      // a flush writes the replayed state back and marks the tiles; a catch-up for a render only fills the compact copy
         const int nty = (y0 + wh + TS - 1) / TS - y0 / TS, ntx = (x0 + ww + TS - 1) / TS - x0 / TS;
         hipLaunchKernelGGL(mark_tiles_k, dim3((D * nty * ntx + 255) / 256), dim3(256), 0, s, last_step, tiles_y, tiles_x, y0 / TS, x0 / TS, nty, ntx, D, upto, boxes);
@@ -271,15 +297,16 @@ extern "C" int vl3d_adam_window_catchup(int32_t D, int32_t T, int32_t Hs, int32_
                                         const uint8_t *quad_dyn, int32_t QH, int32_t QW, float culled_alpha, int32_t mirror_static,
                                         vl3d_stream_t stream) {
     return vl3d_adam_window_catchup_boxes(D, T, Hs, Ws, y0, x0, wh, ww, param, exp_avg, exp_avg_sq, last_step, hist, upto, beta1, beta2, eps,
-                                          compact, quad_keep, quad_dyn, QH, QW, culled_alpha, mirror_static, nullptr, stream);
+                                          compact, quad_keep, quad_dyn, QH, QW, culled_alpha, mirror_static, nullptr, nullptr, stream);
 }
 
 extern "C" int vl3d_adam_window_step_boxes(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
                                            float *param, const float *grad_compact, float *exp_avg, float *exp_avg_sq, int32_t *last_step,
                                            const float *hist, float lr, float beta1, float beta2, float eps, int64_t step,
                                            const uint8_t *quad_keep, const uint8_t *quad_dyn, int32_t QH, int32_t QW, int32_t static_tied,
-                                           const int32_t *plane_boxes, vl3d_stream_t stream) {
+                                           const int32_t *plane_boxes, const int32_t *blocks, vl3d_stream_t stream) {
     int rc = check_window(D, T, Hs, Ws, y0, x0, wh, ww);
+    VL3D_REQUIRE(!blocks || quad_keep, "vl3d_adam_window_step: the packed layout belongs to a tile-culled model (quad maps)");
     if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE(param && grad_compact && exp_avg && exp_avg_sq && last_step && hist && step >= 1, "vl3d_adam_window_step: null pointer / bad step");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -290,7 +317,7 @@ extern "C" int vl3d_adam_window_step_boxes(int32_t D, int32_t T, int32_t Hs, int
                        reinterpret_cast<float4 *>(param), reinterpret_cast<const float4 *>(grad_compact), reinterpret_cast<float4 *>(exp_avg),
                        reinterpret_cast<float4 *>(exp_avg_sq), (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2),
                        Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW}, static_tied, last_step, tiles_y, tiles_x,
-                       reinterpret_cast<const float2 *>(hist), (int)step, boxes);
+                       reinterpret_cast<const float2 *>(hist), (int)step, boxes, Layout{blocks});
     const int nty = (y0 + wh + TS - 1) / TS - y0 / TS, ntx = (x0 + ww + TS - 1) / TS - x0 / TS;
     hipLaunchKernelGGL(mark_tiles_k, dim3((D * nty * ntx + 255) / 256), dim3(256), 0, s, last_step, tiles_y, tiles_x, y0 / TS, x0 / TS, nty, ntx, D, (int)step, boxes);
     VL3D_CHECK_LAUNCH();
@@ -303,7 +330,7 @@ extern "C" int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t W
                                      const uint8_t *quad_keep, const uint8_t *quad_dyn, int32_t QH, int32_t QW, int32_t static_tied,
                                      vl3d_stream_t stream) {
     return vl3d_adam_window_step_boxes(D, T, Hs, Ws, y0, x0, wh, ww, param, grad_compact, exp_avg, exp_avg_sq, last_step, hist, lr, beta1, beta2,
-                                       eps, step, quad_keep, quad_dyn, QH, QW, static_tied, nullptr, stream);
+                                       eps, step, quad_keep, quad_dyn, QH, QW, static_tied, nullptr, nullptr, stream);
 }
 
 // the per-step scalars of the table, computed exactly like vl3d_adam_window_step / vl3d_adam_step_tiles compute theirs

@@ -57,7 +57,7 @@ def _pack_tiles(stack, mask, frames, tile_hw):
     idx = mask.reshape(-1).nonzero()[:, 0]
     n = len(idx)
     if n == 0:
-        return idx, stack.new_zeros((frames, 4, 1, 1)), stack.new_zeros((0, 2)), torch.zeros((0, 3), dtype=torch.long), (0, 0)
+        return idx, torch.zeros((frames, 4, 1, 1), device=stack.device), torch.zeros((0, 2), device=stack.device), torch.zeros((0, 3), dtype=torch.long), (0, 0)
     d, rem = idx // (QH * QW), idx % (QH * QW)
     vy, vx = rem // QW, rem % QW
     ys = vy[:, None].double() * ch + torch.linspace(0, ch, ih, dtype=torch.float64)[None]
@@ -66,12 +66,12 @@ def _pack_tiles(stack, mask, frames, tile_hw):
     grid = torch.stack([gx[:, None, :].expand(n, ih, iw), gy[:, :, None].expand(n, ih, iw)], -1).to(stack.device)
     # plane by plane, all frames and all of the plane's tiles in one call (the tiles' grids stacked along the rows): indexing
     # stack[d, t] with one plane index per TILE materialised a whole (H,W,4) plane per tile -- 174 GB at the shipped size
-    tiles = stack.new_empty((frames, n, 4, ih, iw), dtype=torch.float32)
+    tiles = torch.empty((frames, n, 4, ih, iw), dtype=torch.float32, device=stack.device)
     dd = d.to(stack.device)
     for plane in torch.unique(d).tolist():
         sel = (dd == plane).nonzero()[:, 0]
         g = grid[sel].reshape(1, len(sel) * ih, iw, 2).expand(frames, -1, -1, -1)
-        img = stack[plane, :frames].permute(0, 3, 1, 2).float()                                 # frames,4,H,W
+        img = stack.plane(plane, frames).permute(0, 3, 1, 2).float()                            # frames,4,H,W
         out = F.grid_sample(img, g, mode="bilinear", align_corners=True)                        # frames,4,len(sel)*ih,iw
         tiles[:, sel] = out.reshape(frames, 4, len(sel), ih, iw).permute(0, 2, 1, 3, 4)
     gh, gw, pad = atlas_grid(n)
@@ -91,12 +91,23 @@ def _pack_tiles(stack, mask, frames, tile_hw):
 def reference_state_dict(model, tile_texels=None):
     """model: videoloop3d_amd MPMeshVid / MPMesh (dense or sparsified).  tile_texels=(ih, iw) overrides the tile size (default:
     one sample per texel of the quad, round(quad extent) + 1, the choice oracle/ckpt_oracle.py pins the reader with)."""
-    stack = model.stack.detach()
-    if bool(getattr(model, "is_sparse", False)):
-        # texels no kept quad can read hold the alpha logit CULLED_ALPHA (-1e4, tiles.py); a tile's border samples sit exactly on
-        # texel centres, but their fp32 coordinates carry ~1e-6 texels of rounding, which would pull 1e-6 * (-1e4) of a culled
-        # neighbour into an exported kept texel.  -30 is as transparent (sigmoid = 1e-13) and bleeds nothing.
-        stack = torch.cat([stack[..., :3], stack[..., 3:].clamp_min(-30.0)], dim=-1)
+    class _Planes:
+        """plane accessor: stack[d, :frames] of the dense model without ever holding more than one plane of a packed one."""
+        def __init__(self, m):
+            self.m = m
+            self.shape = tuple(m.stack_dims()) + (4,) if hasattr(m, "stack_dims") else tuple(m.stack.shape)
+            self.device = (m._param() if hasattr(m, "_param") else m.stack).device
+
+        def plane(self, d, frames):
+            pl = self.m.stack_plane(d, range(frames)) if hasattr(self.m, "stack_plane") else self.m.stack.detach()[d, :frames]
+            pl = pl.detach()
+            if bool(getattr(self.m, "is_sparse", False)):
+                # texels no kept quad can read hold the alpha logit CULLED_ALPHA (-1e4, tiles.py); a tile's border samples sit exactly on
+                # texel centres, but their fp32 coordinates carry ~1e-6 texels of rounding, which would pull 1e-6 * (-1e4) of a culled
+                # neighbour into an exported kept texel.  -30 is as transparent (sigmoid = 1e-13) and bleeds nothing.
+                pl = torch.cat([pl[..., :3], pl[..., 3:].clamp_min(-30.0)], dim=-1)
+            return pl
+    stack = _Planes(model)
     D, T, H, W, _ = stack.shape
     hv, wv = int(model.args.mpi_h_verts), int(model.args.mpi_w_verts)
     QH, QW = hv - 1, wv - 1

@@ -34,7 +34,7 @@ def align_window(y0, y1, x0, x1, Hs, Ws):
 
 
 class WindowAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, quad_keep=None, quad_dyn=None, culled_alpha=-1e4, max_defer=32):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, quad_keep=None, quad_dyn=None, culled_alpha=-1e4, max_defer=32, layout=None):
         """quad_keep / quad_dyn [D,QH,QW] (a tile-culled model, videoloop3d_amd/tiles.py): culled texels are no parameters, a texel only
         static quads can read is ONE parameter stored in frame 0 of the stack (the reference's static atlas, MPV.py:235-288) -- the
         window copy shows it in every frame, the step sums its gradient over the frames and writes that one copy; flush() refreshes
@@ -49,20 +49,36 @@ class WindowAdam(torch.optim.Optimizer):
         self.p = ps[0]
         self.pending = None          # (window, compact leaf) of the forward since the last step
         self.t = 0
+        # packed.PackedLayout: the parameter is the pool of 8 x 8-texel blocks of a tile-culled model (static blocks once, dynamic blocks
+        # per frame, culled blocks not at all) instead of the dense (D,T,Hs,Ws,4) stack; moments live in pools of the same shape
+        self.layout = layout
+        if layout is not None and self.quad_keep is None:
+            raise RuntimeError("WindowAdam: a packed layout belongs to a tile-culled model (quad_keep / quad_dyn)")
         # bound on the deferral: after every step, tiles that have missed max_defer steps are brought up to date (exactly: the same
         # replay), so a crop window that comes back after a whole epoch of other crops replays at most max_defer steps per texel
         # instead of the epoch's length, twice.  0 = unbounded.
         self.max_defer = int(max_defer)
 
     # ---- state ----------------------------------------------------------------------------------------------------------
+    def dims(self):
+        if self.layout is not None:
+            return self.layout.D, self.layout.T, self.layout.Hs, self.layout.Ws
+        return tuple(self.p.shape[:4])
+
+    def _blocks(self):
+        return None if self.layout is None else L.ptr(self.layout.blocks)
+
     def _st(self):
         p = self.p
         L.check_cuda(p)
-        if p.dim() != 5 or p.shape[-1] != 4 or p.dtype != torch.float32 or not p.is_contiguous():
+        if self.layout is not None:
+            if p.dtype != torch.float32 or not p.is_contiguous() or p.numel() != self.layout.n_slots * 256 or self.layout.blocks.device != p.device:
+                raise RuntimeError("WindowAdam: the parameter must be the contiguous float32 pool of its packed layout, on the layout's device")
+        elif p.dim() != 5 or p.shape[-1] != 4 or p.dtype != torch.float32 or not p.is_contiguous():
             raise RuntimeError("WindowAdam: the parameter must be a contiguous float32 plane stack (D,T,Hs,Ws,4)")
         st = self.state[p]
         if not st:
-            D, T, Hs, Ws, _ = p.shape
+            D, T, Hs, Ws = self.dims()
             st["exp_avg"] = torch.zeros_like(p)
             st["exp_avg_sq"] = torch.zeros_like(p)
             ts = tile_side()
@@ -76,7 +92,7 @@ class WindowAdam(torch.optim.Optimizer):
 
     def _catchup(self, window, upto, compact, mirror=False, boxes=None):
         st, p = self._st(), self.p
-        D, T, Hs, Ws, _ = p.shape
+        D, T, Hs, Ws = self.dims()
         y0, x0, wh, ww = window
         b1, b2 = self.param_groups[0]["betas"]
         qk, qd, QH, QW = self._quads()
@@ -85,7 +101,7 @@ class WindowAdam(torch.optim.Optimizer):
                                                            L.ptr(st["exp_avg_sq"]), L.ptr(st["last_step"]), L.ptr(st["hist"]), int(upto),
                                                            float(b1), float(b2), float(self.param_groups[0]["eps"]), L.ptr(compact), qk, qd,
                                                            QH, QW, self.culled_alpha, 1 if mirror else 0, None if boxes is None else boxes.ctypes.data,
-                                                           L.stream_ptr(p.device)),
+                                                           self._blocks(), L.stream_ptr(p.device)),
                     "vl3d_adam_window_catchup")
 
     # ---- forward side ---------------------------------------------------------------------------------------------------
@@ -97,7 +113,7 @@ class WindowAdam(torch.optim.Optimizer):
         window this plane's taps can reach.  Outside its box a plane's texels get no gradient in this iteration by construction: their
         slots of the leaf are zeros, their update stays deferred."""
         p = self.p
-        D, T, Hs, Ws, _ = p.shape
+        D, T, Hs, Ws = self.dims()
         y0, x0, wh, ww = window
         if plane_boxes is not None:                       # stays on the HOST (numpy int32 [D,4]): the table travels in the kernel arguments
             import numpy as np
@@ -116,7 +132,7 @@ class WindowAdam(torch.optim.Optimizer):
         """make the whole stack current for the steps taken so far (exact replay of the deferred zero-gradient updates)."""
         if self.t == 0 or not self.state.get(self.p):
             return
-        D, T, Hs, Ws, _ = self.p.shape
+        D, T, Hs, Ws = self.dims()
         self._catchup((0, 0, Hs, Ws), self.t, None, mirror=self.quad_keep is not None)
 
     # ---- checkpointing -------------------------------------------------------------------------------------------------
@@ -136,7 +152,7 @@ class WindowAdam(torch.optim.Optimizer):
         st = self.state.get(self.p)
         if st:
             self.t = int(st.pop("step", torch.tensor(0.0)).item())
-            D, T, Hs, Ws, _ = self.p.shape
+            D, T, Hs, Ws = self.dims()
             ts = tile_side()
             # every tile is current for step t (the saved moments came out of a flush); the scalars of steps <= t are never replayed again
             st["last_step"] = torch.full((D, (Hs + ts - 1) // ts, (Ws + ts - 1) // ts), self.t, dtype=torch.int32, device=self.p.device)
@@ -175,7 +191,9 @@ class WindowAdam(torch.optim.Optimizer):
         L.lib().vl3d_adam_step_scalars(lr, float(b1), float(b2), t, C.byref(a), C.byref(b))
         st["hist"][t, 0].fill_(a.value)                   # scalars travel as kernel arguments: no host-to-device copy, no sync
         st["hist"][t, 1].fill_(b.value)
-        D, T, Hs, Ws, _ = p.shape
+        D, T, Hs, Ws = self.dims()
+        if dense and self.layout is not None:
+            raise RuntimeError("WindowAdam: a packed model trains through its window leaf only (no dense gradient of the pool exists)")
         if dense:        # (the step kernel replays what is outstanding itself: no flush needed first)
             window, g, boxes = (0, 0, Hs, Ws), (p.grad if p.grad.is_contiguous() else p.grad.contiguous()), None
         else:
@@ -192,12 +210,12 @@ class WindowAdam(torch.optim.Optimizer):
                                                         L.ptr(st["exp_avg_sq"]), L.ptr(st["last_step"]), L.ptr(st["hist"]), lr, float(b1),
                                                         float(b2), eps, t, qk, qd, QH, QW,
                                                         1 if (dense and qk is not None) else 0,  # a dense p.grad of a sparsified model went through the tie hook
-                                                        None if boxes is None else boxes.ctypes.data, L.stream_ptr(p.device)),
+                                                        None if boxes is None else boxes.ctypes.data, self._blocks(), L.stream_ptr(p.device)),
                     "vl3d_adam_window_step")
         self.t = t
         if self.max_defer > 0 and t >= self.max_defer:
             with torch.cuda.device(p.device):
                 L.check(L.lib().vl3d_adam_flush_older(D, T, Hs, Ws, L.ptr(p), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), L.ptr(st["last_step"]),
                                                       L.ptr(st["hist"]), t, self.max_defer, float(b1), float(b2), eps, qk, qd, QH, QW,
-                                                      L.stream_ptr(p.device)), "vl3d_adam_flush_older")
+                                                      self._blocks(), L.stream_ptr(p.device)), "vl3d_adam_flush_older")
         return loss
