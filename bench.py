@@ -511,6 +511,26 @@ def main():
                 res["stage2_step"]["reference_estimate"] = "0.4-0.9 it/s on the authors' GPU (BASELINE.md, derived from README wall times)"
             except Exception as e:
                 res["stage2_step"] = {"error": repr(e)}
+            try:    # texture memory of tile-culled models in the packed form (videoloop3d_amd/packed.py), from the block tables alone
+                from videoloop3d_amd.packed import PackedLayout
+                fp = {}
+                for name, (D_, T_, Hs_, Ws_) in {"cfg3_720p": (32, 50, 720, 1280), "cfg3_training_stack_396x704": (32, 50, 396, 704),
+                                                 "cfg5_band_of_8_fp32": (96, 120, 311, 3840)}.items():
+                    QH, QW = 35, 63
+                    qy, qx = torch.meshgrid(torch.arange(QH, device=dev), torch.arange(QW, device=dev), indexing="ij")
+                    keep = torch.zeros((D_, QH, QW), dtype=torch.bool, device=dev)
+                    for d in range(D_):
+                        cy, cx = (7 * d + 3) % QH, (11 * d + 5) % QW
+                        keep[d] = ((qy - cy).abs() <= QH // 5) & ((qx - cx).abs() <= QW // 4)
+                    blob = ((qy - QH // 2).abs() <= QH // 4) & ((qx - QW // 2).abs() <= QW // 4)      # the moving part of the scene: one region
+                    lay = PackedLayout(keep, keep & blob[None], T_, Hs_, Ws_)
+                    fp[name] = {"kept_quads": float(keep.float().mean()), "dynamic_of_kept": float((keep & blob[None]).float().sum() / keep.float().sum()),
+                                "dense_bytes": lay.dense_bytes, "packed_bytes": lay.pool_bytes, "fraction": lay.pool_bytes / lay.dense_bytes,
+                                "blocks_static": lay.n_static, "blocks_dynamic": lay.n_dynamic}
+                    del lay, keep
+                res["packed_footprint"] = fp
+            except Exception as e:
+                res["packed_footprint"] = {"error": repr(e)}
             try:    # BASELINE.json configs[1]: a stage-1 iteration (train_3d.py:189-250: MPMesh.forward + MSE + loop-mask entropy + the four
                     # regularisers of configs/mpi_base.txt:37-40 + Adam), reference-native crop and the full 720p frame
                 torch.cuda.empty_cache()

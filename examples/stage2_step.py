@@ -105,8 +105,35 @@ def run(iters=10, frames=50, planes=32, smooth=0.2, dev="cuda:0", crop=(180, 320
             opt.step()
         torch.cuda.synchronize()
         out["other_tile_culled"] = {"iters_per_s": iters / (time.perf_counter() - t0), "loss": float(loss.detach()),
-                                    "kept_quads": float(keep.float().mean())}
-    out["shape"] = (f"D={planes} T={frames} stack {tuple(model.stack.shape)} crop {h}x{w} of {H}x{W}, Ty=75, "
+                                    "kept_quads": float(keep.float().mean()),
+                                    "texture_bytes": int(model.stack.numel() * 4), "texture_and_adam_state_bytes": int(model.stack.numel() * 12)}
+        # ... and on the PACKED model (videoloop3d_amd/packed.py: static blocks once, dynamic blocks per frame, culled blocks not stored --
+        # the reference's static / dynamic atlases, MPI.py:364-436): same kernels on the hot path, same bits, a fraction of the memory
+        model.pack_()
+        torch.cuda.empty_cache()
+        opt = model.get_optimizer(0)
+        for it in range(iters + 2):
+            if it == 2:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            Kc = K.copy()
+            Kc[0, 2] -= 90 + (it % 3) * 40
+            Kc[1, 2] -= 45 + (it % 2) * 60
+            opt.zero_grad(set_to_none=True)
+            _, extra = model(h, w, tar_e, torch.tensor(Kc)[None], res=res, losscfg=cfg)
+            loss = extra["swd"].sum()
+            for k in ("rgb_smooth", "a_smooth"):
+                if k in extra:
+                    loss = loss + smooth * extra[k].sum()
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        lay = model.packed
+        out["other_tile_culled_packed"] = {"iters_per_s": iters / (time.perf_counter() - t0), "loss": float(loss.detach()),
+                                           "texture_bytes": int(lay.pool_bytes), "texture_and_adam_state_bytes": int(3 * lay.pool_bytes),
+                                           "fraction_of_dense": lay.pool_bytes / lay.dense_bytes,
+                                           "blocks": {"static": lay.n_static, "dynamic": lay.n_dynamic, "of": int(lay.blocks.numel())}}
+    out["shape"] = (f"D={planes} T={frames} stack {tuple(model.stack_dims()) + (4,)} crop {h}x{w} of {H}x{W}, Ty=75, "
                     f"smooth weights {smooth}, Adam")
     return out
 
