@@ -58,7 +58,7 @@ torch.cuda.empty_cache()
 # (3)
 x = torch.empty((1, 3, T + 2, H, W), dtype=torch.float32, device=dev).uniform_(0.0, 1.0).requires_grad_(True)
 y = torch.empty((1, 3, 75, H, W), dtype=torch.float32, device=dev).uniform_(0.0, 1.0)
-cfgs = [dict(macro_block=65, patch_size=11, stride=4, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=0.5),
+cfgs = [dict(macro_block=65, patch_size=11, stride=4, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=0),
         dict(macro_block=65, patch_size=3, stride=2, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=10000)]
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
