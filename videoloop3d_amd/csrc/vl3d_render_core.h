@@ -398,6 +398,25 @@ __device__ __forceinline__ f4 reg_grad(unsigned w_own, unsigned w_left, unsigned
     return r;
 }
 
+// The same for the hot backward kernels: the words are the 32-bit halves of a group (two planes each) and `bo` (uniform: 0 or 16) the bit
+// offset of this plane's fields, so a field is ONE v_bfe_u32 with a scalar offset -- no 64-bit shifts, no masks.  Regular pairs (all of a
+// dense frame but plane edges) take the 10-instruction-per-channel path; a pixel with an irregular left / upper pair branches (rare, divergent).
+// w_left / w_up must hold REG_ZERO's pattern (0x55555555) where that neighbour does not exist.
+__device__ __forceinline__ f4 reg_grad32(unsigned w_own, unsigned w_left, unsigned w_up, unsigned w_patch, unsigned bo, unsigned fl, f4 gx, f4 gy) {
+    f4 r;
+    if (__builtin_expect((fl & 12u) == 0u, 1)) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ix = (int)__builtin_amdgcn_ubfe(w_own, bo + 2 * c, 2) - (int)__builtin_amdgcn_ubfe(w_left, bo + 2 * c, 2);
+            const int iy = (int)__builtin_amdgcn_ubfe(w_own, bo + 8 + 2 * c, 2) - (int)__builtin_amdgcn_ubfe(w_up, bo + 8 + 2 * c, 2);
+            r[c] = fmaf(gy[c], (float)iy, gx[c] * (float)ix);
+        }
+    } else {
+        r = reg_grad((w_own >> bo) & 0xffffu, (w_left >> bo) & 0xffffu, (w_up >> bo) & 0xffffu, (w_patch >> bo) & 0xffffu, fl, gx, gy);
+    }
+    return r;
+}
+
 template <int COORD, int BORDER>
 __global__ __launch_bounds__(256) void reg_masks_k(RenderArgs a) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -1116,15 +1135,15 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTI
     float Tr = 1.0f, P = 0.0f;
     float gsx_c = 0.f, gsy_c = 0.f, gsx_a = 0.f, gsy_a = 0.f;
     unsigned fl = 0u;
-    const unsigned long long *sgp = nullptr;      // this pixel's sign words of planes 0-3 (clamped into the frame: the loads are unconditional)
-    unsigned long long wg_own = 0ull, wg_l = 0ull, wg_u = 0ull, wg_p = 0ull;      // sign words of the current group of four planes
+    const uint2 *sgp = nullptr;      // this pixel's sign words of planes 0-3 (clamped into the frame: the loads are unconditional)
+    uint2 wg_own = make_uint2(0u, 0u), wg_l = wg_own, wg_u = wg_own, wg_p = wg_own;      // sign words of the current group of four planes (planes 0, 1 | 2, 3)
     int wg_idx = -1;
     const bool has_l = inimg && x >= 1, has_u = inimg && y >= 1;
     const bool reg_on = REG && a.g_reg != nullptr;
     if constexpr (REG) if (reg_on) {
         gsx_c = a.g_reg[0]; gsy_c = a.g_reg[1]; gsx_a = a.g_reg[2]; gsy_a = a.g_reg[3];
         const int xc = min(max(x, 0), a.W - 1), yc = min(max(y, 0), a.H - 1);
-        sgp = reinterpret_cast<const unsigned long long *>(a.reg_signs) + ((size_t)t * a.H + yc) * a.W + xc;
+        sgp = reinterpret_cast<const uint2 *>(a.reg_signs) + ((size_t)t * a.H + yc) * a.W + xc;
         if (inimg) fl = a.reg_flags[(size_t)y * a.W + x];
     }
     const size_t sg_plane = (size_t)a.T * a.H * a.W;
@@ -1188,14 +1207,16 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTI
         if constexpr (REG) if (reg_on) {      // uniform
             if ((d >> 2) != wg_idx) {      // (not "d & 3 == 0": a culled plane skips this block)
                 wg_idx = d >> 2;
-                const unsigned long long *w = sgp + (size_t)(d >> 2) * sg_plane;
+                const uint2 *w = sgp + (size_t)(d >> 2) * sg_plane;
+                const uint2 zz = make_uint2(0x55555555u, 0x55555555u);      // a neighbour that does not exist: sign 0 everywhere
                 wg_own = w[0]; wg_l = w[has_l ? -1 : 0]; wg_u = w[has_u ? -(ptrdiff_t)a.W : 0];
-                if (fl & 12u) wg_p = reinterpret_cast<const unsigned long long *>(a.reg_patch)[w - reinterpret_cast<const unsigned long long *>(a.reg_signs)];
+                if (!has_l) wg_l = zz;
+                if (!has_u) wg_u = zz;
+                if (fl & 12u) wg_p = reinterpret_cast<const uint2 *>(a.reg_patch)[w - reinterpret_cast<const uint2 *>(a.reg_signs)];
             }
-            const int sh = 16 * (d & 3);
-            sg = reg_grad((unsigned)(wg_own >> sh) & 0xffffu, has_l ? (unsigned)(wg_l >> sh) & 0xffffu : REG_ZERO,
-                          has_u ? (unsigned)(wg_u >> sh) & 0xffffu : REG_ZERO, (unsigned)(wg_p >> sh) & 0xffffu, fl,
-                          f4{gsx_c, gsx_c, gsx_c, gsx_a}, f4{gsy_c, gsy_c, gsy_c, gsy_a});
+            const bool hi = (d & 2) != 0;       // uniform
+            sg = reg_grad32(hi ? wg_own.y : wg_own.x, hi ? wg_l.y : wg_l.x, hi ? wg_u.y : wg_u.x, hi ? wg_p.y : wg_p.x, 16u * (d & 1), fl,
+                            f4{gsx_c, gsx_c, gsx_c, gsx_a}, f4{gsy_c, gsy_c, gsy_c, gsy_a});
         }
         if (inimg) {
             const float q = dot3p(Gr, o.x, Gg, o.y, Gb, o.z, gA);
@@ -1427,8 +1448,8 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
     float gN10 = 0.f, gN20 = 0.f, gN11 = 0.f, gN21 = 0.f;
     f4 gx = f4{0.f, 0.f, 0.f, 0.f}, gy = gx;
     unsigned fl = 0u;
-    const unsigned long long *sgp = nullptr;
-    unsigned long long go0 = 0ull, gl0 = 0ull, gu0 = 0ull, gp0 = 0ull, go1 = 0ull, gl1 = 0ull, gu1 = 0ull, gp1 = 0ull;   // the group's sign words
+    const uint2 *sgp = nullptr;
+    uint2 go0 = make_uint2(0u, 0u), gl0 = go0, gu0 = go0, gp0 = go0, go1 = go0, gl1 = go0, gu1 = go0, gp1 = go0;   // the group's sign words (planes 0, 1 | 2, 3)
     const bool has_l = inimg && x >= 1, has_u = inimg && y >= 1;
     const bool reg_on = REG && a.g_reg != nullptr;
     const size_t sg_plane = (size_t)a.T * a.H * a.W, sg_f1 = has1 ? (size_t)a.H * a.W : 0;
@@ -1442,7 +1463,7 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
         if (reg_on) {
             gx = f4{a.g_reg[0], a.g_reg[0], a.g_reg[0], a.g_reg[2]}; gy = f4{a.g_reg[1], a.g_reg[1], a.g_reg[1], a.g_reg[3]};
             const int xc = min(max(x, 0), a.W - 1), yc = min(max(y, 0), a.H - 1);
-            sgp = reinterpret_cast<const unsigned long long *>(a.reg_signs) + ((size_t)t0 * a.H + yc) * a.W + xc;      // clamped into the frame: the loads below are unconditional
+            sgp = reinterpret_cast<const uint2 *>(a.reg_signs) + ((size_t)t0 * a.H + yc) * a.W + xc;      // clamped into the frame: the loads below are unconditional
             if (inimg) fl = a.reg_flags[(size_t)y * a.W + x];
         }
     }
@@ -1464,12 +1485,16 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
         const unsigned e0 = oplane[(unsigned)(Y0 * a.Ws + X0) + toff_thread];     // unconditional (padded table), arrives in the shadow of the sweep
         // sign words of this group of four planes (own, left, upper; two frames): requested with the taps of its first plane
         if constexpr (REG) if (reg_on && (d & 3) == 0) {      // uniform
-            const unsigned long long *w = sgp + (size_t)(d >> 2) * sg_plane;
+            const uint2 *w = sgp;      // (advanced by one group of planes below: no 64-bit multiply per group)
+            sgp += sg_plane;
             const ptrdiff_t ol = has_l ? -1 : 0, ou = has_u ? -(ptrdiff_t)a.W : 0;
+            const uint2 zz = make_uint2(0x55555555u, 0x55555555u);      // a neighbour that does not exist: sign 0 everywhere
             go0 = w[0]; gl0 = w[ol]; gu0 = w[ou];
             go1 = w[sg_f1]; gl1 = w[sg_f1 + ol]; gu1 = w[sg_f1 + ou];
+            if (!has_l) { gl0 = zz; gl1 = zz; }
+            if (!has_u) { gu0 = zz; gu1 = zz; }
             if (fl & 12u) {
-                const unsigned long long *pw = reinterpret_cast<const unsigned long long *>(a.reg_patch) + (w - reinterpret_cast<const unsigned long long *>(a.reg_signs));
+                const uint2 *pw = reinterpret_cast<const uint2 *>(a.reg_patch) + (w - reinterpret_cast<const uint2 *>(a.reg_signs));
                 gp0 = pw[0]; gp1 = pw[sg_f1];
             }
         }
@@ -1487,10 +1512,10 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
             f4 ex0 = f4{0.f, 0.f, 0.f, 0.f}, ex1 = ex0;
             if constexpr (REG) {
                 if (reg_on) {
-                    const int sh = 16 * (d & 3);
-                    auto fld = [sh](unsigned long long g) { return (unsigned)(g >> sh) & 0xffffu; };
-                    ex0 = reg_grad(fld(go0), has_l ? fld(gl0) : REG_ZERO, has_u ? fld(gu0) : REG_ZERO, fld(gp0), fl, gx, gy);
-                    ex1 = reg_grad(fld(go1), has_l ? fld(gl1) : REG_ZERO, has_u ? fld(gu1) : REG_ZERO, fld(gp1), fl, gx, gy);
+                    const bool hi = (d & 2) != 0;       // uniform
+                    const unsigned bo = 16u * (d & 1);
+                    ex0 = reg_grad32(hi ? go0.y : go0.x, hi ? gl0.y : gl0.x, hi ? gu0.y : gu0.x, hi ? gp0.y : gp0.x, bo, fl, gx, gy);
+                    ex1 = reg_grad32(hi ? go1.y : go1.x, hi ? gl1.y : gl1.x, hi ? gu1.y : gu1.x, hi ? gp1.y : gp1.x, bo, fl, gx, gy);
                 }
                 ex0.w += fmaf(gN20, o0.w, gN10);
                 ex1.w += fmaf(gN21, o1.w, gN11);
