@@ -328,6 +328,10 @@ int vl3d_vote_fold_robust_strided(const vl3d_loss_desc *desc, const float *y, co
                                   float rou, float scale, float *y2x, float *weight, float *grad_x, int64_t gx_sc, int64_t gx_st,
                                   int64_t gx_sr, double *loss_sum, vl3d_stream_t stream);
 
+/* x[0..n) *= *scale with `scale` a DEVICE scalar (no host sync); no memory traffic at all when it is exactly 1 -- the backward of the fused
+ * looping loss: its gradient buffer exists since the forward and the upstream gradient of a loss differentiated directly is 1.  n % 4 == 0. */
+int vl3d_scale_inplace(int64_t n, float *x, const float *scale, vl3d_stream_t stream);
+
 /* robust_lossfun (utils_vid.py:10-26) fused with the mean (utils_vid.py:348).
  * kind: 0 'mse', 1 'abs', 2 general Barron with float rou (rou==0 and rou==2 special-cased as the reference).
  * loss_sum: device double, overwritten with sum over n elements of rho(x - y2x). */

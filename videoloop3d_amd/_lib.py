@@ -82,6 +82,7 @@ SIGNATURES = {
     "vl3d_vote_fold_robust": ([C.POINTER(LossDesc), _P, _P, _P, _I32, C.c_float, C.c_float, _P, _P, _P, _P, _P], C.c_int),
     "vl3d_vote_fold_robust_strided": ([C.POINTER(LossDesc), _P, _P, _P, _I32, C.c_float, C.c_float, _P, _P, _P, C.c_int64, C.c_int64,
                                        C.c_int64, _P, _P], C.c_int),
+    "vl3d_scale_inplace": ([_I64, _P, _P, _P], C.c_int),
     "vl3d_robust_fwd": ([_I64, _P, _P, _I32, _F, _F, _P, _P], C.c_int),
     "vl3d_robust_bwd": ([_I64, _P, _P, _I32, _F, _F, _P, _F, _P, _P], C.c_int),
 }

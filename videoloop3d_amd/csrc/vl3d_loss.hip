@@ -1466,6 +1466,27 @@ extern "C" int vl3d_robust_bwd(int64_t n, const float *x, const float *y2x, int3
     return VL3D_OK;
 }
 
+// x *= *scale, skipped entirely (one scalar load per wave, no traffic) when the scale is exactly 1: the upstream gradient of a loss that is
+// differentiated directly is 1, and the fused looping loss has its gradient buffer ready since the forward
+__global__ __launch_bounds__(256) void scale_inplace_k(int64_t n4, float4 *__restrict__ x, const float *__restrict__ scale) {
+    const float s = *scale;
+    if (s == 1.0f) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 v = x[i];
+        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+        x[i] = v;
+    }
+}
+
+extern "C" int vl3d_scale_inplace(int64_t n, float *x, const float *scale, vl3d_stream_t stream) {
+    VL3D_REQUIRE(n > 0 && (n & 3) == 0 && x && scale, "vl3d_scale_inplace: n must be a positive multiple of 4 (16-byte aligned buffer)");
+    const int64_t n4 = n / 4;
+    const unsigned blocks = (unsigned)(ceil_div64(n4, 256) < 8192 ? ceil_div64(n4, 256) : 8192);
+    hipLaunchKernelGGL(scale_inplace_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n4, reinterpret_cast<float4 *>(x), scale);
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
 extern "C" int vl3d_nn_vectors(int64_t B, int32_t n1, int32_t n2, int32_t d, const float *X, const float *Y, int32_t use_alpha,
                                float alpha, int64_t *nn, vl3d_stream_t stream) {
     VL3D_REQUIRE(B > 0 && B < (1ll << 31) && n1 > 0 && n2 > 0 && d > 0 && X && Y && nn, "vl3d_nn_vectors: bad arguments");

@@ -312,7 +312,13 @@ class _FoldRobustMean(torch.autograd.Function):
         if getattr(ctx, "consumed", False):
             raise RuntimeError("the fused looping loss keeps its gradient buffer in place: backward through it a second time needs a new forward")
         ctx.consumed = True
-        return gx.mul_(g.to(torch.float32)).to(ctx.x_dtype), None, None, None, None, None, None, None, None, None, None, None, None
+        gs = g.to(torch.float32).contiguous()
+        if gx.numel() % 4 == 0 and gx.is_contiguous():
+            with torch.cuda.device(gx.device):      # (a no-op on the device when the upstream gradient is exactly 1)
+                L.check(L.lib().vl3d_scale_inplace(gx.numel(), L.ptr(gx), L.ptr(gs), L.stream_ptr(gx.device)), "vl3d_scale_inplace")
+        else:
+            gx.mul_(gs)
+        return gx.to(ctx.x_dtype), None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def fit_patch(size, name, patch, step):
