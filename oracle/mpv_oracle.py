@@ -84,6 +84,16 @@ def mpv_forward(stack, args, H, W, ref_extrin, ref_intrin, near, far, h, w, tar_
         extra["a_smooth"] = ((sx + sy) * (loss_gain * denorm)).reshape(1, -1)
     if args.density_loss_weight > 0:
         extra["density"] = (alpha - 1).abs().mean().reshape(1, -1)
+    if getattr(args, "d_smooth_loss_weight", 0) > 0:                                    # MPV.py:385, 463-466, 539-551
+        # disp = sum_k blend_weight_k / zbuf_k; zbuf of a planar mesh = view-space depth of the plane point under the pixel
+        xs, ys = MO._homography_source_coords(h, w, homos.double(), pixel_center)          # plane pixels [D,h,w]
+        ray = torch.inverse(ref_intrin_mpi.double()) @ torch.stack([xs, ys, torch.ones_like(xs)], -1)[..., None]
+        P = ray[..., 0] * planedepth.double()[:, None, None, None]
+        E = extrins[0].double()
+        z = (P * E[2, :3]).sum(-1) + E[2, 3]
+        disp = (bw * (1.0 / z).float().permute(1, 2, 0)[None]).sum(-1)
+        dg = (disp[:, 1:, :-1] - disp[:, 1:, 1:]).abs() + (disp[:, :-1, 1:] - disp[:, 1:, 1:]).abs()
+        extra["d_smooth"] = dg.mean().reshape(1, -1)
     return None, extra
 
 

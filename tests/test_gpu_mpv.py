@@ -107,6 +107,38 @@ def test_forward_eval_and_frame_subset(dev):
             assert float((rgb.cpu() - rgb_o).abs().max()) <= 1e-4
 
 
+def test_d_smooth_regulariser_slow_path(dev):
+    """d_smooth (MPV.py:463-466, 539-551; off in every shipped configuration): finite differences of the blend-weighted inverse view depth.
+    The only term that reads materialised layers: value and stack gradient against the oracle, with the crop-aware optimiser's window path
+    active (the layers are then sampled from the compact window copy)."""
+    from videoloop3d_amd.MPV import MPMeshVid
+    H, W = 44, 60
+    K, ref_extrin, tar = scene(H, W)
+    args = make_args(d_smooth_loss_weight=0.5, rgb_smooth_loss_weight=0.0, a_smooth_loss_weight=0.0, lrate=0.05, lrate_decay=30, optimizer="adam")
+    model = MPMeshVid(args, H, W, ref_extrin, K, 1.0, 100.0).to(dev).train()
+    with torch.no_grad():
+        model.stack.copy_(synth.make_plane_stack(*model.stack.shape[:4], seed=5) * 0.7)
+    res = synth.make_video(9, 24, 32, seed=31)[0].permute(1, 0, 2, 3)[None].contiguous()
+    cfg = {"loss_name": "gpnn_lm", "patch_size": 3, "patcht_size": 3, "stride": 2, "stridet": 1, "alpha": 10000.0, "rou": "-2", "scaling": 0.1,
+           "macro_block": 65}
+    Kc = K.copy(); Kc[0, 2] -= 11; Kc[1, 2] -= 7
+    tar_e, tar_k = torch.tensor(tar)[None], torch.tensor(Kc)[None]
+    s_cpu = model.stack.detach().cpu().clone().requires_grad_(True)
+    _, ex_o = mpv_oracle.mpv_forward(s_cpu, args, H, W, ref_extrin, K, 1.0, 100.0, 24, 32, tar_e, tar_k, res=res, losscfg=collate(cfg))
+    (g_o,) = torch.autograd.grad(ex_o["swd"].sum() + 3.0 * ex_o["d_smooth"].sum(), s_cpu)
+    opt = model.get_optimizer(0)                                  # window path: the render reads the compact copy of the crop's window
+    _, ex = model(24, 32, tar_e, tar_k, res=res.to(dev), losscfg=collate(cfg))
+    assert abs(ex["d_smooth"].item() - ex_o["d_smooth"].item()) <= 1e-5 * max(1.0, abs(ex_o["d_smooth"].item()))
+    (ex["swd"].sum() + 3.0 * ex["d_smooth"].sum()).backward()
+    win, leaf = opt.pending[0], opt.pending[1]
+    y0, x0, wh, ww = win
+    g = torch.zeros_like(model.stack)
+    g[:, :, y0:y0 + wh, x0:x0 + ww] = leaf.grad
+    d = (g.cpu() - g_o).abs()
+    scale = max(1e-6, float(g_o.abs().max()))
+    assert float(d.max()) <= 5e-3 * scale and float((d > 1e-4 * scale).float().mean()) <= 1e-3
+
+
 def test_render_variables_on_request(dev):
     """render(..., need_layers=True): `mpi` in the reference's hit-slot order (MPV.py:441-449) and `blend_weight` (MPV.py:451-453), whose
     composite is the fused kernel's image and whose sum is `alpha` (MPV.py:454); off-centre camera so plane edges cross the view."""

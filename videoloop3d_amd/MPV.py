@@ -532,11 +532,12 @@ class MPMeshVid(nn.Module):
         if need_layers:
             # the reference's `mpi` [T',H,W,K,4] (hit-slot order, MPV.py:441-449) and `blend_weight` [T',H,W,K] (MPV.py:451-453), on request
             # only: materialised with the unfused operators (no shipped configuration reads them; the fused kernels never build them)
-            if cull_window is not None:
-                raise RuntimeError("need_layers renders from the full stack: call render() under torch.no_grad() or in eval mode")
-            mpi = self._layers(stack, homos, H, W)
+            # `disp_norm` = sum_k blend_weight_k / z_k with z the view-space depth of the hit (MPV.py:385, 463-466: 1 / zbuf): for planar
+            # geometry the hit point is the plane point under the pixel, moved into the target camera.  `pix_to_face` has no planar analogue.
+            mpi, planes, inv_z = self._layers(stack, homos, H, W, spec, cull_window, extrin)
             variables["mpi"] = mpi
             variables["blend_weight"] = overcompose(mpi[..., -1], mpi[..., :-1])[1]
+            variables["disp_norm"] = (overcompose(planes[..., -1], planes[..., :-1])[1] * inv_z[None]).sum(-1)
         if len(self.args.bg_color) > 0:                                                     # MPV.py:455-461 (as written)
             if self.args.bg_color == "random":
                 bg_color = torch.rand(3).type_as(rgb)
@@ -546,14 +547,17 @@ class MPMeshVid(nn.Module):
             rgb = rgb * alpha[..., None] + bg_color[None, None, None] * (- alpha[..., None] + 1)
         return rgb[..., :3], variables
 
-    def _layers(self, stack, homos, H, W):
-        """warped + activated per-layer rgba [T',H,W,D,4] (MPV.py:441-449) via the unfused warp kernel.
+    def _layers(self, stack, homos, H, W, spec=None, cull_window=None, extrin=None):
+        """warped + activated per-layer rgba via the unfused warp kernel (differentiable): (slot-ordered [T',H,W,K,4] = the reference's
+        `mpi`, MPV.py:441-449; plane-indexed [T',H,W,D,4]; 1 / view-space depth of every plane under every pixel [H,W,D]).
         warp_homography samples at texel = p*(S-1)/S from integer pixels, so the MPV convention (pixel centre c,
-        texel = p*s + o) is folded into the homography:  H' = diag(Ws/(Ws-1), Hs/(Hs-1), 1) * A * H * shift(c)."""
+        texel = p*s + o) is folded into the homography:  H' = diag(Ws/(Ws-1), Hs/(Hs-1), 1) * A * H * shift(c).
+        spec / cull_window: the render spec and (y0, x0, Hs_plane, Ws_plane) when `stack` is the compact window copy of a training step."""
         D, T, Hs, Ws, _ = stack.shape
-        c = self.spec.pixel_center
-        sx, sy = self.spec.scale
-        ox, oy = self.spec.offset
+        spec = self.spec if spec is None else spec
+        c = spec.pixel_center
+        sx, sy = spec.scale
+        ox, oy = spec.offset
         dev = stack.device
         A = torch.tensor([[sx * Ws / (Ws - 1), 0, ox * Ws / (Ws - 1)], [0, sy * Hs / (Hs - 1), oy * Hs / (Hs - 1)], [0, 0, 1.]], device=dev)
         C = torch.tensor([[1., 0, c], [0, 1., c], [0, 0, 1.]], device=dev)
@@ -569,8 +573,9 @@ class MPMeshVid(nn.Module):
         cov = ((tx >= 0) & (tx <= Ws - 1) & (ty >= 0) & (ty <= Hs - 1)).to(samp.dtype)      # D,H,W
         if self.is_sparse:      # a sample inside a culled quad is not covered (no face there, MPV.py:389-392)
             QH, QW = self.quad_keep.shape[1:]
-            qx = torch.floor(tx * (QW / max(Ws - 1, 1))).clamp(0, QW - 1).long()
-            qy = torch.floor(ty * (QH / max(Hs - 1, 1))).clamp(0, QH - 1).long()
+            y0, x0, Hp, Wp = (0, 0, Hs, Ws) if cull_window is None else cull_window
+            qx = torch.floor((tx + x0) * (QW / max(Wp - 1, 1))).clamp(0, QW - 1).long()
+            qy = torch.floor((ty + y0) * (QH / max(Hp - 1, 1))).clamp(0, QH - 1).long()
             cov = cov * self.quad_keep.to(dev)[torch.arange(D, device=dev)[:, None, None], qy, qx].to(cov.dtype)
         rgba = torch.cat([self.rgb_activate(samp[:, :, :3]), self.alpha_activate(samp[:, :, 3:])], dim=2)
         rgba = (rgba * cov[None, :, None]).permute(0, 3, 4, 1, 2)                            # T,H,W,D,4, plane-indexed
@@ -580,7 +585,16 @@ class MPMeshVid(nn.Module):
         K = max(int(covp.sum(-1).max()), 1)
         slot = (torch.cumsum(covp.long(), -1) - 1).clamp(min=0)[None, ..., None].expand(T, H, W, D, 4)
         out = torch.zeros((T, H, W, max(K, D), 4), dtype=rgba.dtype, device=dev).scatter_add(3, slot, rgba)
-        return out[:, :, :, :K]
+        inv_z = None
+        if extrin is not None:
+            # the plane point under the pixel, P_ref = depth * K_mpi^-1 (xm, ym, 1), in the target camera: z = R[2] . P_ref + t[2]
+            Ki = torch.inverse(self._on(dev, "ref_intrin_mpi").double())
+            E = extrin[0].to(dev).double()
+            ray = Ki @ torch.stack([p[..., 0, 0] / p[..., 2, 0], p[..., 1, 0] / p[..., 2, 0], torch.ones_like(p[..., 2, 0])], -1)[..., None].double()
+            P = ray[..., 0] * self._on(dev, "planedepth").double()[:, None, None, None]                         # D,H,W,3
+            z = (P * E[2, :3]).sum(-1) + E[2, 3]
+            inv_z = (1.0 / z).float().permute(1, 2, 0)                                                           # H,W,D
+        return out[:, :, :, :K], rgba, inv_z
 
     # ---- forward -----------------------------------------------------------------------------------------------------
     def forward(self, h, w, tar_extrins, tar_intrins, ts=None, res=None, losscfg=None):
@@ -590,7 +604,7 @@ class MPMeshVid(nn.Module):
             ts = torch.arange(self.frm_num).long()
         a = self.args
         # rgb_smooth / a_smooth / sparsity are fused into the render kernels: the [T,h,w,K,4] layer tensor is never built
-        need_layers = False
+        need_layers = self.training and getattr(a, "d_smooth_loss_weight", 0) > 0      # the one term that reads materialised layers (slow path)
         need_smooth = self.training and (a.rgb_smooth_loss_weight > 0 or a.a_smooth_loss_weight > 0 or a.sparsity_loss_weight > 0)
         rgb, variables = self.render(h, w, extrins, tar_intrins, ts, need_layers=need_layers, need_smooth=need_smooth)
         rgb = rgb.permute(0, 3, 1, 2)
@@ -630,6 +644,8 @@ class MPMeshVid(nn.Module):
                 extra["a_smooth"] = ((sums[2] / nx + sums[3] / ny) * (loss_gain * denorm)).reshape(1, -1)
         if a.density_loss_weight > 0:
             extra["density"] = (variables["alpha"] - 1).abs().mean().reshape(1, -1)
-        if getattr(a, "d_smooth_loss_weight", 0) > 0:
-            raise RuntimeError("d_smooth_loss_weight > 0 needs the rasteriser depth buffer (MPV.py:463-466); not on the planar path")
+        if getattr(a, "d_smooth_loss_weight", 0) > 0:                                             # MPV.py:539-551 (off in every shipped configuration)
+            disp = variables["disp_norm"]
+            depth_grad = (disp[:, 1:, :-1] - disp[:, 1:, 1:]).abs() + (disp[:, :-1, 1:] - disp[:, 1:, 1:]).abs()
+            extra["d_smooth"] = depth_grad.mean().reshape(1, -1)
         return None, extra
