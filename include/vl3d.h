@@ -66,10 +66,11 @@ typedef struct vl3d_render_desc {
     int32_t stack_dtype;   /* VL3D_F32 | VL3D_F16 (grad_stack has the same dtype) */
     float pixel_center;    /* 0 (utils_mpi) or 0.5 (pytorch3d pixel centres) */
     float sx, sy, ox, oy;  /* VL3D_COORD_AFFINE only */
-    int32_t variant;       /* kernel variant selector for A/B measurements and bitwise cross-checks; 0 = default.  Bits 0-3: backward
-                            * (see vl3d_render_bwd); bits 4-7: timing-only ablations (wrong results); bits 8-11: forward -- 6 = one frame
-                            * per thread (default for the shipped activations and T >= 2: two frames per thread, same bits), 2/4/5 =
-                            * workgroup shapes 64x4 / 64x16 / no XCD remap */
+    int32_t variant;       /* kernel selector for bitwise cross-checks between EXACT kernels; 0 = default.  Bits 0-3: backward (see
+                            * vl3d_render_bwd); bits 8-11: forward -- 6 = one frame per thread (default for the shipped activations and
+                            * T >= 2: two frames per thread, same bits); bits 12-15: 1 = the two-pass forward with regularisers.  Bits 4-7
+                            * (timing-only ablations, wrong results) exist only in a -DVL3D_VARIANTS measurement build: the product
+                            * library returns VL3D_EINVAL for them. */
     /* tile culling on a WINDOW of the stack (vl3d_render_*_culled only; all 0 = the stack is the whole plane): the stack passed in is
      * the texel window [cull_row0, cull_row0+Hs) x [cull_col0, cull_col0+Ws) of a cull_Hs x cull_Ws plane, and the quad grid of
      * quad_keep lies over that whole plane. */
@@ -263,7 +264,7 @@ typedef struct vl3d_loss_desc {
     int32_t variant;       /* kernel variant selector for A/B measurements and cross-checks; 0 = default.  Bits 0-3, vl3d_patchnn: 1 strided
                             * staging (no scratch), 2 one location per workgroup, 3 the fp32 matrix-core kernel, 4 the vector-ALU kernel
                             * (0 picks 3 wherever the clip lengths allow it -- x <= 128, y <= 192 frames -- and 4 otherwise); vl3d_vote_fold: 1 = the
-                            * unstaged kernel.  Bits 4-7: ablation switches (timing only, results invalid).  Bit 8: see vl3d_patchnn.
+                            * unstaged kernel.  Bits 4-7: refused (ablation switches of a -DVL3D_VARIANTS measurement build).  Bit 8: see vl3d_patchnn.
                             * Bits 12-15, vl3d_vote_fold*: tile shape index + 1. */
 } vl3d_loss_desc;
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-process A/B of render kernel variants on ONE resident cfg3 stack (same buffers, same clocks, interleaved rounds): separate
 processes differ by up to 10 % on the same box (allocation, clock state), which is more than most variants are worth.
-  python profiles/ab_inproc.py --variants 0,5,3 [--rounds 6] [--reps 4] [--stack-scale 1.0] [--reg] [--dtype f32|f16] [--T 50]
+  python profiles/ab_inproc.py --variants 0,3 [--rounds 6] [--reps 4] [--stack-scale 1.0] [--reg] [--dtype f32|f16] [--T 50]
 Prints per variant the median / min of the forward and backward times (HIP events on the launch stream)."""
 import argparse
 import os
@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--variants", default="0,5,3")
+ap.add_argument("--variants", default="0,3")
 ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--reps", type=int, default=4)
 ap.add_argument("--stack-scale", type=float, default=1.0)

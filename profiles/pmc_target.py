@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Profile target for the rocprofv3 passes of profiles/run_profiles_r02.sh: one iteration each of
+"""Profile target for the rocprofv3 passes of profiles/run_profiles_r0N.sh: one iteration each of
   (1) cfg3 render fwd+bwd at 1.0x (render_fwd2x_k, render_bwd_pair_k),
-  (2) the reference geometry: 1.1x stack + smoothness regularisers (render_reg_fwd_k, render_bwd_pair_reg_k),
+  (2) the reference geometry: 1.1x stack + smoothness regularisers (render_fwd_reg_k, reg_slot_fwd_k, render_bwd_pair_k<REG>),
   (3) the looping loss at 720p, both shipped configurations (patchnn4_k, vote_fold_lds_k, video_to_pixel_major_k).
 Usage: python profiles/pmc_target.py [T=50]"""
 import os

@@ -771,8 +771,8 @@ def test_abi_is_reentrant_across_host_threads_and_streams(dev):
 @pytest.mark.parametrize("stack_scale", [1.0, 1.1])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_bwd_pair_reg_kernel_vs_oracle_and_tile_kernel(dev, T, stack_scale, dtype):
-    """render_bwd_pair_reg_k (frame pairs WITH the layer regularisers: sampling software-pipelined one plane ahead, one barrier per
-    plane) -- what a shipped stage-2 iteration runs (rgb_smooth / a_smooth 0.2 on a 1.1x stack, configs/mpv_base.txt:10-11,33-34):
+    """render_bwd_pair_k<REG> (frame pairs WITH the layer regularisers, decoded from the forward's sign words) -- what a shipped stage-2
+    iteration runs (rgb_smooth / a_smooth 0.2 on a 1.1x stack, configs/mpv_base.txt:10-11,33-34):
     gradient vs the oracle's materialised layers (smoothness sums + sparsity sums + composite), and per frame the same bits as the
     one-frame REG tile kernel (variant 3), even and odd T, multi-tile frames with ragged borders."""
     from videoloop3d_amd.render import RenderSpec, render_planes_with_regularisers

@@ -265,8 +265,7 @@ static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, cons
         a.plan = (const float *)scratch;
         a.owner = reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(scratch) + owner_table_off(desc));
         const int bv = desc->variant & 0xf;
-        a.tile_rows = (bv == 0 || bv == 5) ? 17 : 16;     // 17: 16 rows, frame-pair kernels allowed
-        a.pair_pipe = bv == 5;
+        a.tile_rows = bv == 0 ? 17 : 16;     // 17: 16 rows, frame-pair kernels allowed
     } else {
         a.plan = nullptr;
         a.tile_rows = 0;

@@ -67,7 +67,6 @@ struct RenderArgs {
     int tile_rows;           // backward: 0 = no owner-computes path for this call (atomics kernel only); 16 = tile kernel; 17 = 16 rows,
                              // frame-pair kernels allowed
     int reg_fwd;             // forward dispatch: 1 = the regulariser-sums kernel instead of the render, 2 = render AND sums in one pass
-    int pair_pipe;           // backward variant 5: the pipelined frame-pair kernel (A/B)
     // hit-slot layer order of the smoothness regularisers (see "Layer regularisers in hit-slot order" below): the caller's reg_state
     // buffer, written by the forward with regularisers and read by the backward
     unsigned char *reg_flags;          // [H][W]      bit 0/1/2/3: the pair with the right / lower / left / upper neighbour is IRREGULAR
@@ -1535,108 +1534,9 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
     }
 }
 
-// Frame pairs, sampling pipelined one plane ahead (measurement variant 5 of the backward): iteration d issues the tap loads of plane
-// d+1 first, forms the gradients of plane d (from the sample shaded by iteration d-1) while they are in flight, shades plane d+1 and
-// only then meets the barrier -- the structure of render_bwd_pair_reg_k below without the layer-value exchange.
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
-__global__ __launch_bounds__(PNT, 4) void render_bwd_pair_pipe_k(RenderArgs a) {
-    if (!reinterpret_cast<const int *>(a.plan)[0]) return;
-    constexpr bool NEED_PRE = RACT == VL3D_ACT_ABS || AACT == VL3D_ACT_ABS;
-    __shared__ float4 s_g[2][2][PNT];
-    __shared__ float2 s_t[2][PNT];
-    const int tid = threadIdx.x, col = tid & (PW - 1), row = tid >> 5;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_x = bid % a.tiles_x, rest = bid / a.tiles_x;
-    const int tile_y = rest % a.tiles_y, t0 = (rest / a.tiles_y) * 2;
-    const bool has1 = t0 + 1 < a.T;
-    const int rx0 = tile_x * (PW - 2) - 1, ry0 = tile_y * (PROWS - 2) - 1;
-    const int x = rx0 + col, y = ry0 + row;
-    const bool inimg = (x >= 0) && (x < a.W) && (y >= 0) && (y < a.H);
-    const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
-    constexpr size_t TEXB = F16 ? 8 : 16;
-    const size_t frame_b = (size_t)a.Hs * a.Ws * TEXB;
-    const size_t plane_stride_b = (size_t)a.T * frame_b;
-    const char *plane0 = reinterpret_cast<const char *>(a.stack) + (size_t)t0 * frame_b;
-    char *gplane0 = reinterpret_cast<char *>(a.g_stack) + (size_t)t0 * frame_b;
-    const size_t f1 = has1 ? frame_b : 0;
-    float Gr0 = 0.f, Gg0 = 0.f, Gb0 = 0.f, gA0 = 0.f, S0 = 0.f, Gr1 = 0.f, Gg1 = 0.f, Gb1 = 0.f, gA1 = 0.f, S1 = 0.f;
-    if (inimg) {
-        size_t pix = ((size_t)t0 * a.H + y) * a.W + x;
-        Gr0 = a.g_rgb[pix * 3 + 0]; Gg0 = a.g_rgb[pix * 3 + 1]; Gb0 = a.g_rgb[pix * 3 + 2];
-        gA0 = a.g_alpha ? a.g_alpha[pix] : 0.0f;
-        S0 = dot3p(Gr0, a.rgb[pix * 3 + 0], Gg0, a.rgb[pix * 3 + 1], Gb0, a.rgb[pix * 3 + 2], gA0 * a.alpha[pix]);
-        if (has1) pix += (size_t)a.H * a.W;
-        Gr1 = a.g_rgb[pix * 3 + 0]; Gg1 = a.g_rgb[pix * 3 + 1]; Gb1 = a.g_rgb[pix * 3 + 2];
-        gA1 = a.g_alpha ? a.g_alpha[pix] : 0.0f;
-        S1 = dot3p(Gr1, a.rgb[pix * 3 + 0], Gg1, a.rgb[pix * 3 + 1], Gb1, a.rgb[pix * 3 + 2], gA1 * a.alpha[pix]);
-    }
-    float Tr0 = 1.0f, P0 = 0.0f, Tr1 = 1.0f, P1 = 0.0f;
-    const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
-    const unsigned my_tile_id = (unsigned)(tile_y * a.tiles_x + tile_x);
-    const unsigned my_tile = (unsigned)((tile_y & 15) << 3 | (tile_x & 7));
-    const unsigned toff_thread = (unsigned)(row * a.Ws + col);
-    const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)my_tile_id * a.D * 4;
-    typedef typename TapVal<F16, ORDER>::type tapv_t;
-    const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
-    f4 o0 = zero4, o1 = zero4, pre0 = zero4, pre1 = zero4;
-    float ctx = 0.f, cty = 0.f, ccov = 0.f;
-    if (inimg) {
-        float h[VL3D_HN];
-        load_uniform(a.homos, h);
-        const Taps2 tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-        tapv_t tv0[4], tv1[4];
-        load_taps2<F16>(plane0, tp, st, tv0);
-        load_taps2<F16>(plane0 + f1, tp, st, tv1);
-        o0 = shade2<ORDER, RACT, AACT>(tp, tv0, &pre0);
-        o1 = shade2<ORDER, RACT, AACT>(tp, tv1, &pre1);
-        if constexpr (!NEED_PRE) { pre0 = o0; pre1 = o1; }
-        ctx = tp.tx; cty = tp.ty; ccov = tp.cov;
-    }
-    for (int d = 0; d < a.D; ++d, plane0 += plane_stride_b, gplane0 += plane_stride_b) {
-        const int X0 = wrec[4 * d], Y0 = wrec[4 * d + 1], wwh = wrec[4 * d + 2];
-        const int ww = wwh & 0xffff, wh = (wwh >> 16) & 0x3fff;
-        const bool apart = (wwh & 0x40000000) != 0;
-        const int buf = d & 1;
-        const unsigned short *oplane = a.owner + (size_t)d * a.Hs * a.Ws;
-        const unsigned e0 = oplane[(unsigned)(Y0 * a.Ws + X0) + toff_thread];
-        const int dn = min(d + 1, a.D - 1);
-        Taps2 tpn{};
-        tapv_t tn0[4], tn1[4];
-        if (inimg) {
-            float h[VL3D_HN];
-            load_uniform(a.homos + VL3D_HS * dn, h);
-            tpn = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
-            const char *pn = plane0 + (size_t)(dn - d) * plane_stride_b;
-            load_taps2<F16>(pn, tpn, st, tn0);
-            load_taps2<F16>(pn + f1, tpn, st, tn1);
-            asm volatile("" ::: "memory");
-        }
-        float2 tc = make_float2(0.f, 0.f);
-        float4 gv0 = make_float4(0.f, 0.f, 0.f, 0.f), gv1 = gv0;
-        if (inimg) {
-            VL3D_PAIR_GRAD(o0, pre0, Gr0, Gg0, Gb0, gA0, S0, P0, Tr0, gv0, zero4)
-            VL3D_PAIR_GRAD(o1, pre1, Gr1, Gg1, Gb1, gA1, S1, P1, Tr1, gv1, zero4)
-            tc = make_float2(ctx, cty);
-            if (!(ccov > 0.0f)) { gv0 = make_float4(0.f, 0.f, 0.f, 0.f); gv1 = gv0; }
-        }
-        s_t[buf][tid] = tc;
-        s_g[buf][0][tid] = gv0;
-        s_g[buf][1][tid] = gv1;
-        if (inimg) {
-            o0 = shade2<ORDER, RACT, AACT>(tpn, tn0, &pre0);
-            o1 = shade2<ORDER, RACT, AACT>(tpn, tn1, &pre1);
-            if constexpr (!NEED_PRE) { pre0 = o0; pre1 = o1; }
-            ctx = tpn.tx; cty = tpn.ty; ccov = tpn.cov;
-        }
-        __syncthreads();
-        pair_gather_plane<ORDER, RACT, AACT, F16>(a, s_g[buf][0], s_g[buf][1], s_t[buf], X0, Y0, ww, wh, apart, my_tile, e0, oplane, plane0, gplane0,
-                                                  f1, frame_b, has1, col, row);
-    }
-}
-
 #undef VL3D_PAIR_GRAD
 
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool REG = false, bool PIPE = false>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool REG = false>
 void launch_pair(const RenderArgs &a, hipStream_t s) {
     constexpr int RH = 1, IW = PW - 2 * RH, IH = PROWS - 2 * RH;
     RenderArgs b = a;
@@ -1648,9 +1548,6 @@ void launch_pair(const RenderArgs &a, hipStream_t s) {
                        const_cast<unsigned short *>(a.owner), PW, 9);
     if constexpr (REG)
         hipLaunchKernelGGL((render_bwd_pair_k<COORD, BORDER, ORDER, RACT, AACT, F16, true>),
-                           dim3((unsigned)(b.tiles_x * b.tiles_y * ((a.T + 1) / 2))), dim3(PNT), 0, s, b);
-    else if constexpr (PIPE)
-        hipLaunchKernelGGL((render_bwd_pair_pipe_k<COORD, BORDER, ORDER, RACT, AACT, F16>),
                            dim3((unsigned)(b.tiles_x * b.tiles_y * ((a.T + 1) / 2))), dim3(PNT), 0, s, b);
     else
         hipLaunchKernelGGL((render_bwd_pair_k<COORD, BORDER, ORDER, RACT, AACT, F16>),
@@ -1813,10 +1710,7 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
                 // pairs): crops of a larger stack and the reference's 1.1x stacks keep the 64 x 16 tile kernel.
                 const bool fits = (int64_t)a.Hs * 100 <= (int64_t)a.H * 107 || (int64_t)a.Ws * 100 <= (int64_t)a.W * 107;
                 if (a.tile_rows == 17 && a.T >= 2 && !a.g_reg && !a.g_asum && !a.quad_keep && fits) {
-                    if (a.pair_pipe) {
-                        if constexpr (VL3D_HN == 9 && COORD == VL3D_COORD_AFFINE && !F16) launch_pair<COORD, BORDER, ORDER, RACT, AACT, F16, false, true>(a, s);
-                        else launch_pair<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
-                    } else launch_pair<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
+                    launch_pair<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
                     done = true;
                 }
                 // with the layer regularisers the pipelined pair kernel wins at every stack size (one barrier per plane and two
