@@ -152,3 +152,44 @@ def test_save_mesh_and_texture(tmp_path):
     t1 = sd["atlas_dyn"][1].permute(1, 2, 0)
     want1 = (torch.sigmoid(t1[..., :3]) * torch.sigmoid(t1[..., 3:]) * 255).type(torch.uint8).numpy()
     assert fr.shape == want1.shape and (fr == want1).all()
+
+
+def test_mpmesh_driver_hooks_and_checkpoint_round_trip():
+    """MPMesh carries the hooks train_3d.py calls (get_optimizer :159, get_lrate :301, update_step :298, init_from_mpi :185, save_* :324-328)
+    and round-trips through the reference's checkpoint layout, dense (one static atlas) and sparsified."""
+    from videoloop3d_amd.MPI import MPMesh
+    K = np.array([[50., 0, 30], [0, 50., 20], [0, 0, 1]])
+    a = _args(optimizer="adam", lrate=0.05, lrate_decay=100)
+    m = MPMesh(a, 41, 61, np.eye(4), K, 1.0, 100.0)
+    torch.manual_seed(4)
+    with torch.no_grad():
+        m.stack.uniform_(-2.0, 2.0)
+    opt = m.get_optimizer()
+    assert isinstance(opt, torch.optim.Adam) and opt.param_groups[0]["lr"] == 0.05
+    assert abs(m.get_lrate(50000)[0][1] - 0.05 * 0.1 ** 0.5) < 1e-12
+    m.update_step(3)
+    sd = m.reference_state_dict()
+    assert "faces_dyn" not in sd and sd["atlas"].shape[0] == 1 and not sd["self.is_sparse"]
+    m2 = MPMesh(_args(optimizer="adam", lrate=0.05, lrate_decay=100), 41, 61, np.eye(4), K, 1.0, 100.0)
+    m2.init_from_mpi(sd)
+    # the atlas is resampled at texel centres with fp32 coordinates: |coordinate error| ~1e-5 texel x a neighbour difference of up to 4
+    assert float((m2.stack - m.stack).detach().abs().max()) <= 2e-4
+    m2.init_from_mpi(m.state_dict())                       # ... and through this package's own state_dict
+    assert torch.equal(m2.stack, m.stack) and torch.equal(m2.stack_mask, m.stack_mask)
+    # sparsified
+    with torch.no_grad():
+        m.stack[..., 3] = -8.0
+        m.stack[0, 0, 5:30, 8:40, 3] = 2.0
+        m.stack[2, 0, 10:35, 20:55, 3] = 1.5
+    m.sparsify_faces(erode_num=1)
+    sd = m.reference_state_dict()
+    m3 = MPMesh(_args(optimizer="adam", lrate=0.05, lrate_decay=100), 41, 61, np.eye(4), K, 1.0, 100.0)
+    m3.init_from_mpi(sd)
+    assert m3.is_sparse and torch.equal(m3.quad_keep, m.quad_keep) and not hasattr(m3, "stack_mask")
+    kt = tiles.quad_to_texel_mask(m.quad_keep, 41, 61)[:, None, :, :, None].expand_as(m.stack)
+    # texels inside kept quads come back (the export keeps the quad rectangles; one-texel aprons outside them are resampled from borders)
+    from videoloop3d_amd.tiles import CULLED_ALPHA
+    inner = torch.zeros_like(kt)
+    for d, qy, qx in m.quad_keep.nonzero().tolist():
+        inner[d, :, qy * 10:qy * 10 + 11, qx * 10:qx * 10 + 11] = True
+    assert float((m3.stack - m.stack).detach()[inner].abs().max()) <= 2e-4

@@ -120,6 +120,74 @@ class MPMesh(nn.Module):
             sd["self.has_dyn"] = self.has_dyn
         return sd
 
+    # ---- driver hooks of train_3d.py (:159, 185, 284-301, 316-332) ------------------------------------------------------------
+    def get_optimizer(self):
+        """MPI.py:122-141 (the planar path has no vertex parameters: one parameter group)."""
+        a = self.args
+        params = [{'params': [p for _, p in self.named_parameters()]}]
+        if a.optimizer == 'adam':
+            return torch.optim.Adam(params=params, lr=a.lrate, betas=(0.9, 0.999))
+        if a.optimizer == 'sgd':
+            return torch.optim.SGD(params=params, lr=a.lrate, momentum=0.9)
+        raise RuntimeError(f"Unrecongnized optimizer type {a.optimizer}")
+
+    def get_lrate(self, step):
+        """MPI.py:143-152."""
+        a = self.args
+        scaling = 0.1 ** (step / (a.lrate_decay * 1000))
+        return [("lr", a.lrate * scaling), ("vertlr", a.lrate * getattr(a, "optimize_verts_gain", 1) * scaling)]
+
+    def update_step(self, step):
+        """MPI.py:154-156; geometry optimisation itself is not on the planar path."""
+        if step >= getattr(self.args, "optimize_geo_start", 10000000):
+            self.optimize_geometry = True
+
+    def init_from_mpi(self, state_dict):
+        """MPI.py:174-205 (resume / warm start, train_3d.py:176-186): a state_dict of this class, or of the REFERENCE's MPMesh (plane
+        meshes + packed atlas: resampled onto the dense stack, quad maps recovered from its face lists; the loop-mask texture of a
+        reference checkpoint is not carried -- the reference drops it at sparsify time, MPI.py:440-441)."""
+        if "stack" not in state_dict and "atlas" in state_dict:
+            hv, wv = int(self.args.mpi_h_verts), int(self.args.mpi_w_verts)
+            st, keep, dyn = tiles.stack_from_reference_state(state_dict, self.mpi_h, self.mpi_w, hv, wv, 1)
+            sparse = bool(state_dict.get("self.is_sparse", False))
+            state_dict = {"ref_extrin": state_dict["ref_extrin"], "ref_intrin": state_dict["ref_intrin"], "planedepth": state_dict["planedepth"],
+                          "stack": st[:, :1], "quad_keep": keep, "quad_dyn": dyn, "self.is_sparse": sparse, "self.has_dyn": sparse}
+        dev = self.stack.device
+        self.ref_extrin.data = state_dict['ref_extrin'].type_as(self.ref_extrin)
+        self.ref_intrin.data = state_dict['ref_intrin'].type_as(self.ref_intrin)
+        self.planedepth.data = state_dict['planedepth'].type_as(self.planedepth)
+        self.ref_intrin_mpi.data = get_new_intrin(self.ref_intrin, -self.H_start, -self.W_start)
+        st = state_dict["stack"]
+        if tuple(st.shape) != tuple(self.stack.shape):
+            raise RuntimeError(f"checkpoint stack {tuple(st.shape)} does not match this model's {tuple(self.stack.shape)}")
+        with torch.no_grad():
+            self.stack.copy_(st.to(dev))
+            if "stack_mask" in state_dict and hasattr(self, "stack_mask"):
+                self.stack_mask.copy_(state_dict["stack_mask"].to(dev))
+        self.is_sparse = bool(state_dict.get("self.is_sparse", False))
+        self.has_dyn = bool(state_dict.get("self.has_dyn", False))
+        if self.is_sparse:
+            self.register_buffer("quad_keep", state_dict["quad_keep"].to(dev).bool())
+            self.register_buffer("quad_dyn", state_dict["quad_dyn"].to(dev).bool())
+            self.args.learn_loop_mask = self.learn_loop_mask = False
+            if hasattr(self, "stack_mask"):
+                del self.stack_mask
+
+    def reference_state_dict(self):
+        """the state_dict of the REFERENCE's MPMesh for these weights (MPI.py:207-221): plane mesh + packed atlas tiles."""
+        from .export import reference_state_dict
+        return reference_state_dict(self)
+
+    def save_mesh(self, prefix):
+        """MPI.py:223-240."""
+        from .export import save_mesh
+        return save_mesh(self, prefix, self.reference_state_dict())
+
+    def save_texture(self, prefix):
+        """MPI.py:242-261."""
+        from .export import save_texture
+        return save_texture(self, prefix, self.reference_state_dict())
+
     def plane_homographies(self, extrin, intrin):
         dev = extrin.device
         eye = torch.eye(4, dtype=extrin.dtype, device=dev)[None]

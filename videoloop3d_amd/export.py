@@ -119,6 +119,8 @@ def reference_state_dict(model, tile_texels=None):
     else:                                           # a dense model: every quad exists and is dynamic ("load static as dynamic", MPV.py:266)
         keep = torch.ones((D, QH, QW), dtype=torch.bool)
         dyn = keep.clone()
+        if not hasattr(model, "frm_num"):           # ... a dense stage-1 MPI is one static atlas (MPI.py:95-117)
+            dyn = torch.zeros_like(keep)
     faces = quad_faces(D, hv, wv)
     idx_s, atlas_s, uvs_s, uvf_s, (gh_s, gw_s) = _pack_tiles(stack, keep & ~dyn, 1, tile_texels)
     idx_d, atlas_d, uvs_d, uvf_d, (gh_d, gw_d) = _pack_tiles(stack, dyn, T, tile_texels)
@@ -128,6 +130,12 @@ def reference_state_dict(model, tile_texels=None):
     if bool(getattr(model.args, "normalize_verts", False)):
         # the reference stores `_verts` divided by the plane depth under this flag and multiplies it back in its `verts` property (MPV.py:62-64)
         verts = (verts.reshape(D, -1, 3) / model.planedepth.detach().cpu().float().reshape(D, 1, 1)).reshape(verts.shape)
+    if not hasattr(model, "frm_num") and not sparse:
+        # a dense stage-1 MPI: the reference's MPMesh.state_dict() before sparsify_faces has no dynamic lists (MPI.py:207-221)
+        return {"_verts": verts, "planedepth": model.planedepth.detach().cpu().clone(), "ref_extrin": model.ref_extrin.detach().cpu().clone(),
+                "ref_intrin": model.ref_intrin.detach().cpu().clone(), "faces": faces[idx_s].reshape(-1, 3), "uvfaces": uvf_s, "uvs": uvs_s.cpu(),
+                "atlas": atlas_s.cpu(), "self.is_sparse": False, "self.atlas_grid_h": gh_s, "self.atlas_grid_w": gw_s,
+                "self.atlas_full_h": int(atlas_s.shape[-2]), "self.atlas_full_w": int(atlas_s.shape[-1])}
     return {
         "_verts": verts, "planedepth": model.planedepth.detach().cpu().clone(), "ref_extrin": model.ref_extrin.detach().cpu().clone(),
         "ref_intrin": model.ref_intrin.detach().cpu().clone(),
