@@ -61,7 +61,9 @@ __global__ __launch_bounds__(512) void render_like_k(const f4 *__restrict__ src,
 // STORE: 0 non-temporal stores of the interior (ragged row segments, as the owner-computes backward writes them), 1 the same with
 // plain write-back stores (the L2 may merge the partial lines of horizontally adjacent tiles), 2 non-temporal stores of row segments
 // ALIGNED to SNAP texels (ownership snapped to SNAP-texel columns: what aligned ownership would give), 3 = 2 with plain stores
-template <int RX, int RY, int FR, int TAPS, bool OWNER, int STORE = 0, int SNAP = 8>
+// HX: halo columns on either side (1 = the shipped kernels).  Ownership snapped to SNAP-texel columns moves a segment's ends by up to
+// SNAP / 2 texels, so a REAL aligned-ownership kernel has to stage 1 + SNAP / 2 halo columns: HX = 3 for SNAP = 4 (26 of 32 columns owned).
+template <int RX, int RY, int FR, int TAPS, bool OWNER, int STORE = 0, int SNAP = 8, int HX = 1>
 __global__ __launch_bounds__(RX *RY) void bwd_like_k(const f4 *__restrict__ src, f4 *__restrict__ dst, const unsigned short *__restrict__ owner, int D,
                                                      int T, int Hs, int Ws, int tiles_x, int tiles_y) {
     const int b = blockIdx.x;
@@ -69,11 +71,12 @@ __global__ __launch_bounds__(RX *RY) void bwd_like_k(const f4 *__restrict__ src,
     const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     const int tile_x = bid % tiles_x, rest = bid / tiles_x, tile_y = rest % tiles_y, t0 = (rest / tiles_y) * FR;
     const int lx = threadIdx.x % RX, ly = threadIdx.x / RX;
-    const int x = min(max(tile_x * (RX - 2) - 1 + lx, 0), Ws - 2), y = min(max(tile_y * (RY - 2) - 1 + ly, 0), Hs - 2);
-    bool interior = lx >= 1 && lx < RX - 1 && ly >= 1 && ly < RY - 1 && tile_x * (RX - 2) - 1 + lx < Ws && tile_y * (RY - 2) - 1 + ly < Hs;
+    constexpr int IWX = RX - 2 * HX;
+    const int gx = tile_x * IWX - HX + lx;
+    const int x = min(max(gx, 0), Ws - 2), y = min(max(tile_y * (RY - 2) - 1 + ly, 0), Hs - 2);
+    bool interior = lx >= HX && lx < RX - HX && ly >= 1 && ly < RY - 1 && gx < Ws && tile_y * (RY - 2) - 1 + ly < Hs;
     if constexpr (STORE >= 2) {      // owned columns [snap(tile_x * IW), snap((tile_x + 1) * IW)): every column owned exactly once, SNAP-aligned ends
-        const int gx = tile_x * (RX - 2) - 1 + lx;
-        const int l = (tile_x * (RX - 2) + SNAP / 2) / SNAP * SNAP, rr = ((tile_x + 1) * (RX - 2) + SNAP / 2) / SNAP * SNAP;
+        const int l = (tile_x * IWX + SNAP / 2) / SNAP * SNAP, rr = ((tile_x + 1) * IWX + SNAP / 2) / SNAP * SNAP;
         interior = gx >= l && gx < rr && gx < Ws && ly >= 1 && ly < RY - 1 && tile_y * (RY - 2) - 1 + ly < Hs && gx >= 0;
     }
     const size_t frame = (size_t)Hs * Ws, plane = (size_t)T * frame;
@@ -192,12 +195,14 @@ static void run(const char *name, F launch, double bytes) {
     fflush(stdout);
 }
 
-int main() {
+int main(int argc, char **argv) {
+    const bool aligned_only = argc > 1 && argv[1][0] == 'a';      // ./rw_bw aligned: only the aligned-ownership comparison at the end
     const size_t unit = 8ull << 30, n = unit / 16;     // 8 GiB per stream
     f4 *src, *dst;
     if (hipMalloc(&src, 3 * unit) != hipSuccess || hipMalloc(&dst, 3 * unit) != hipSuccess) { printf("alloc failed\n"); return 1; }
     hipMemset(src, 0, 3 * unit); hipMemset(dst, 0, 3 * unit);
     char name[160];
+    if (!aligned_only) {
 #define RUN(R, W, NT, U)                                                                                                   \
     for (int bs : {256, 512, 1024})                                                                                         \
         for (int per_cu : {4, 16, 0}) {                                                                                     \
@@ -264,6 +269,33 @@ int main() {
         BLS(64, 8, 2, 0, 8) BLS(64, 8, 2, 1, 8) BLS(64, 8, 2, 2, 4) BLS(64, 8, 2, 2, 8) BLS(64, 8, 2, 3, 8) BLS(64, 8, 2, 2, 16)
         BLS(64, 16, 1, 0, 8) BLS(64, 16, 1, 1, 8) BLS(64, 16, 1, 2, 8) BLS(64, 16, 1, 3, 8)
         BLS(64, 8, 1, 0, 8) BLS(64, 8, 1, 1, 8) BLS(64, 8, 1, 2, 8) BLS(128, 8, 1, 0, 8) BLS(128, 8, 1, 2, 8) BLS(128, 4, 1, 0, 8) BLS(128, 4, 1, 2, 8)
+    }
+    }
+    // Aligned ownership priced WITH the halo it needs (round 3): segments snapped to SNAP-texel columns move by up to SNAP / 2, so the
+    // region stages 1 + SNAP / 2 halo columns per side and owns RX - 2 - SNAP columns: more regions, more tap re-reads.
+    {
+        const int D = 32, T = 12, Hs = 720, Ws = 1280;
+        const double bytes = 2.0 * D * T * Hs * Ws * 16;
+        unsigned short *owner;
+        hipMalloc(&owner, (size_t)D * Hs * Ws * 2 + 4096);
+        hipMemset(owner, 0, (size_t)D * Hs * Ws * 2 + 4096);
+#define BLA(RX, RY, FR, ST, SNAP, HX)                                                                                          \
+        {                                                                                                                      \
+            const int tx = (Ws + RX - 2 * HX - 1) / (RX - 2 * HX), ty = (Hs + RY - 3) / (RY - 2);                              \
+            snprintf(name, sizeof name, "bwd_like  region %3d x %2d  frames %d  store mode %d  snap %2d  x-halo %d (x%.2f pixels swept per pixel owned)", \
+                     RX, RY, FR, ST, SNAP, HX, (double)RX * RY / ((RX - 2 * HX) * (RY - 2)));                                  \
+            run(name, [&] { hipLaunchKernelGGL((bwd_like_k<RX, RY, FR, 4, true, ST, SNAP, HX>), dim3((unsigned)(tx * ty * (T / FR))), dim3(RX * RY), 0, 0, \
+                                               src, dst, owner, D, T, Hs, Ws, tx, ty); }, bytes);                              \
+        }
+        for (int rep = 0; rep < 2; ++rep) {
+            BLA(32, 16, 2, 0, 8, 1)      // shipped pattern: ragged 30-texel segments
+            BLA(32, 16, 2, 2, 4, 1)      // round 2's row: snapped stores WITHOUT the halo they need (not buildable)
+            BLA(32, 16, 2, 0, 4, 3)      // the wider halo alone (ragged 26-texel segments)
+            BLA(32, 16, 2, 2, 4, 3)      // aligned ownership as a kernel could build it: 26 of 32 columns owned, 64-byte aligned ends
+            BLA(32, 16, 2, 2, 8, 5)      // 128-byte aligned ends: 22 of 32
+            BLA(64, 8, 2, 0, 8, 1) BLA(64, 8, 2, 2, 4, 3) BLA(64, 8, 2, 2, 8, 5)
+            BLA(64, 16, 1, 0, 8, 1) BLA(64, 16, 1, 2, 4, 3) BLA(64, 16, 1, 2, 8, 5)
+        }
     }
     return 0;
 }

@@ -448,10 +448,17 @@ __global__ __launch_bounds__(256) void reg_flags_k(RenderArgs a) {
 }
 
 // lowest set bit of a 128-bit mask, removed from it; -1 when empty
+// (selects, not branches: with `if (m0) {...} else if (m1) {...}` hipcc turned the two words into a dynamically indexed private array --
+// 24 bytes of scratch and a scratch store per slot)
 __device__ __forceinline__ int reg_pop_plane(unsigned long long &m0, unsigned long long &m1) {
-    if (m0) { const int d = __builtin_ctzll(m0); m0 &= m0 - 1; return d; }
-    if (m1) { const int d = __builtin_ctzll(m1); m1 &= m1 - 1; return 64 + d; }
-    return -1;
+    const bool lo = m0 != 0ull;
+    const unsigned long long m = lo ? m0 : m1;
+    if (!m) return -1;
+    const int d = __builtin_ctzll(m) + (lo ? 0 : 64);
+    const unsigned long long c = m & (m - 1);
+    m0 = lo ? c : m0;
+    m1 = lo ? m1 : c;
+    return d;
 }
 
 // activated layer value of pixel (px, py) on plane d in frame t, sampled in place (plane and pixel vary per lane)
@@ -1713,13 +1720,15 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
                     launch_pair<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
                     done = true;
                 }
-                // with the layer regularisers the pipelined pair kernel wins at every stack size (one barrier per plane and two
-                // resident workgroups against two barriers on one); sample-then-activate conventions only (activate-then-sample keeps
-                // 8 activated taps per frame live and would spill at the 128-VGPR budget, as do the 13-float plane records of the per-plane
-                // convention: the tile kernel stays in charge there)
-                if (!done && a.tile_rows == 17 && a.T >= 2 && (a.g_reg || a.g_asum) && !a.quad_keep) {
-                    launch_pair<COORD, BORDER, ORDER, RACT, AACT, F16, true>(a, s);
-                    done = true;
+                // with the layer regularisers the pair kernel wins at every stack size (round 3, in process: 15.7 ms against 20.0 ms for
+                // the one-frame tile kernel on a 1.1x stack, 15.4 against 19.6 ms at the frame's resolution: decoding the forward's sign
+                // words is frame-pair work the tile kernel does once per frame).  The utils_mpi cross-check convention keeps the tile
+                // kernel: its texel coordinates cost a reciprocal more and the pair instantiation spilled 8-28 bytes at 128 VGPRs.
+                if constexpr (COORD != VL3D_COORD_UTILS_MPI) {
+                    if (!done && a.tile_rows == 17 && a.T >= 2 && (a.g_reg || a.g_asum) && !a.quad_keep) {
+                        launch_pair<COORD, BORDER, ORDER, RACT, AACT, F16, true>(a, s);
+                        done = true;
+                    }
                 }
             }
             if (!done) {
