@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 
-def run(iters=20, planes=32, frame=(360, 640), crop=(180, 320), scale=1.6, loop_mask=True, dev="cuda:0"):
+def run(iters=20, planes=32, frame=(360, 640), crop=(180, 320), scale=1.6, loop_mask=True, dev="cuda:0", torch_adam=False):
     from videoloop3d_amd import synth
     from videoloop3d_amd.MPI import MPMesh
     dev = torch.device(dev)
@@ -31,12 +31,13 @@ def run(iters=20, planes=32, frame=(360, 640), crop=(180, 320), scale=1.6, loop_
         l_smooth_loss_weight=0.0)
     K = np.array([[0.9 * W, 0, W / 2], [0, 0.9 * W, H / 2], [0, 0, 1]], np.float64)
     model = MPMesh(args, H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
-    opt = torch.optim.Adam(model.parameters(), lr=0.05, betas=(0.9, 0.999))                  # MPI.py:122-141, configs/mpi_base.txt:31
+    args.optimizer, args.lrate, args.lrate_decay, args.torch_adam = "adam", 0.05, 100, torch_adam
+    opt = model.get_optimizer()                                                              # MPI.py:122-141, configs/mpi_base.txt:31
     a = np.radians(0.5)
     tar = np.eye(4)
     tar[:3, :3] = [[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]
     tar[:3, 3] = [0.03, 0.01, 0.0]
-    tar_e = torch.tensor(tar, device=dev)[None]
+    tar_e = torch.tensor(tar)[None]          # poses and intrinsics stay on the host, as the DataLoader yields them (train_3d.py:190-191)
     target = synth.hash_uniform((1, 3, h, w), seed=8, device=dev)
     target_mask = (synth.hash_uniform((1, h, w), seed=9, device=dev) > 0.5).float()
     wts = vars(args)
@@ -48,7 +49,7 @@ def run(iters=20, planes=32, frame=(360, 640), crop=(180, 320), scale=1.6, loop_
         if (h, w) != (H, W):
             Kc[0, 2] -= 90 + (it % 3) * 40                                   # crop offset (utils.py:196-200)
             Kc[1, 2] -= 45 + (it % 2) * 60
-        rgbl, extra = model(h, w, tar_e, torch.tensor(Kc, device=dev)[None])
+        rgbl, extra = model(h, w, tar_e, torch.tensor(Kc)[None])
         loop_loss = 0
         rgb = rgbl
         if loop_mask:                                                        # train_3d.py:200-211
@@ -67,7 +68,7 @@ def run(iters=20, planes=32, frame=(360, 640), crop=(180, 320), scale=1.6, loop_
     torch.cuda.synchronize()
     return {"iters_per_s": iters / (time.perf_counter() - t0), "loss": float(loss.detach()),
             "shape": f"D={planes}, frame {H}x{W}, view {h}x{w}, planes {tuple(model.stack.shape[2:4])}, loop mask {loop_mask}, "
-                     f"sparsity 0.004 / rgb_smooth 0.2 / a_smooth 0.5 / density 0.02, torch.optim.Adam over the dense stack"}
+                     f"sparsity 0.004 / rgb_smooth 0.2 / a_smooth 0.5 / density 0.02, {type(opt).__module__}.{type(opt).__name__}"}
 
 
 if __name__ == "__main__":

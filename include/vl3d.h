@@ -215,6 +215,24 @@ int vl3d_render_fwd_reg(const vl3d_render_desc *desc, const void *stack, const f
 int vl3d_render_reg_fwd_culled(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep,
                                int32_t QH, int32_t QW, double *sums, void *reg_state, vl3d_stream_t stream);
 
+/* Stage 1's learned loop mask (MPI.py:115-117 `atlas_mask`, 568-583) as a FIFTH composited channel of the same pass:
+ *     label(pixel) = sum_k w_k sigmoid(sample(mask_k)),   w_k = a_k T_k  the colour composite's blend weights,
+ * sampled with the colour taps' positions and weights (grid_sample over the same uvs, MPI.py:569-572), and the weights DETACHED
+ * (MPI.py:577-579 "detach mpi so that geometry is not related to mpi"): grad_label reaches the mask texture only.
+ *   mask (D,T,Hs,Ws) logits, one float per texel of the stack;  label (T,H,W);  grad_mask (D,T,Hs,Ws) overwritten.
+ * vl3d_render_fwd_mask: sums / reg_state both NULL = vl3d_render_fwd plus the label, both given = vl3d_render_fwd_reg plus the label
+ * (rgb, alpha, alpha_sums, sums, reg_state exactly as those write them).  vl3d_render_bwd_mask = vl3d_render_bwd plus grad_label ->
+ * grad_mask in the same sweep and gather (one frame per thread; grad_stack as vl3d_render_bwd computes it).  Built for the planar
+ * convention stage 1 ships -- (VL3D_COORD_AFFINE, VL3D_BORDER_HARDCUT, VL3D_ACT_POST), sigmoid / sigmoid, fp32 stack, no quad map
+ * (the reference drops the mask when it sparsifies, MPI.py:440-441); any other descriptor returns VL3D_EUNSUPPORTED and the caller
+ * renders the label in a pass of its own (a stack whose channel 0 is the mask logit and channel 3 the alpha logit). */
+int vl3d_render_fwd_mask(const vl3d_render_desc *desc, const void *stack, const float *mask, const float *homos, float *rgb,
+                         float *alpha, float *label, float *alpha_sums, double *sums, void *reg_state, vl3d_stream_t stream);
+int vl3d_render_bwd_mask(const vl3d_render_desc *desc, const void *stack, const float *mask, const float *homos, const float *rgb,
+                         const float *alpha, const float *grad_rgb, const float *grad_alpha, const float *grad_label,
+                         const float *grad_reg, const void *reg_state, const float *grad_alpha_sums, float *grad_stack,
+                         float *grad_mask, void *scratch, int64_t scratch_bytes, vl3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Unfused operators (drop-ins for the reference's L3 functions).
  *

@@ -126,6 +126,9 @@ class MPMesh(nn.Module):
         a = self.args
         params = [{'params': [p for _, p in self.named_parameters()]}]
         if a.optimizer == 'adam':
+            # torch.optim.Adam's update in one pass per parameter (tiles.TileAdam without a quad map; getattr(args, 'torch_adam') keeps torch's)
+            if self.stack.is_cuda and not getattr(a, "torch_adam", False):
+                return tiles.TileAdam(params, lr=a.lrate, betas=(0.9, 0.999), eps=1e-8)
             return torch.optim.Adam(params=params, lr=a.lrate, betas=(0.9, 0.999))
         if a.optimizer == 'sgd':
             return torch.optim.SGD(params=params, lr=a.lrate, momentum=0.9)
@@ -188,12 +191,25 @@ class MPMesh(nn.Module):
         from .export import save_texture
         return save_texture(self, prefix, self.reference_state_dict())
 
+    def _on(self, dev, name):
+        """the (small, constant) camera buffers on the device of the pose tensors: poses that arrive on the HOST (as the DataLoader
+        produces them, train_3d.py:190-191) are turned into homographies there -- the 4 x 4 inverse and the chain of small matrix
+        products were ~40 kernel launches per view on the device."""
+        buf = getattr(self, name)
+        if buf.device == dev:
+            return buf
+        cache = self.__dict__.setdefault("_host_mirrors", {})
+        key = (str(dev), buf.data_ptr(), buf._version)
+        if cache.get(name, (None,))[0] != key:
+            cache[name] = (key, buf.detach().to(dev))
+        return cache[name][1]
+
     def plane_homographies(self, extrin, intrin):
         dev = extrin.device
         eye = torch.eye(4, dtype=extrin.dtype, device=dev)[None]
         normal = torch.tensor([0., 0., 1.], dtype=extrin.dtype, device=dev).expand(1, self.mpi_d, 3)
-        return compute_homography(eye, self.ref_intrin_mpi[None].to(extrin.dtype), extrin, intrin, normal,
-                                  self.planedepth[None].to(extrin.dtype))[0].float()
+        return compute_homography(eye, self._on(dev, "ref_intrin_mpi")[None].to(extrin.dtype), extrin, intrin.to(dev), normal,
+                                  self._on(dev, "planedepth")[None].to(extrin.dtype))[0].float()
 
     def render(self, H, W, extrin, intrin, need_reg=False):
         """MPI.py:452-594 -> (rgbl [B,H,W,3|4], variables).  One fused render per view (the kernels share one camera per call)."""
@@ -206,7 +222,7 @@ class MPMesh(nn.Module):
                 self._mask_buf[..., 0].copy_(self.stack_mask)
                 self._mask_buf[..., 3].copy_(self.stack[..., 3])
         for b in range(B):
-            homos = self.plane_homographies(extrin[b:b + 1], intrin[b:b + 1])
+            homos = self.plane_homographies(extrin[b:b + 1], intrin[b:b + 1]).to(self.stack.device)
             if need_reg:
                 rgb, alpha, ss, asum = render_planes_with_regularisers(self.stack, homos, H, W, self.spec)
                 ssums.append(ss)
@@ -235,7 +251,7 @@ class MPMesh(nn.Module):
     def forward(self, h, w, tar_extrins, tar_intrins):
         """MPI.py:596-652 -> (rgbl [B,3|4,h,w], extra)."""
         a = self.args
-        extrins = tar_extrins @ self.ref_extrin[None, ...].inverse().to(tar_extrins.dtype)
+        extrins = tar_extrins @ self._on(tar_extrins.device, "ref_extrin")[None, ...].inverse().to(tar_extrins.dtype)
         need_reg = self.training and (a.sparsity_loss_weight > 0 or a.rgb_smooth_loss_weight > 0 or a.a_smooth_loss_weight > 0)
         rgbl, variables = self.render(h, w, extrins, tar_intrins, need_reg=need_reg)
         B = rgbl.shape[0]

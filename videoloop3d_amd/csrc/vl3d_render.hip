@@ -3,6 +3,7 @@
 //
 // Replaces (reference, /root/reference): MPV.py:351-454 (planar geometry) ==
 // utils_mpi.py:159-176 (warp_homography) + utils_mpi.py:92-107 (overcompose), and their autograd.
+#include <string>
 #include "vl3d_render_core.h"
 
 using vl3d_render_detail::RenderArgs;
@@ -178,6 +179,76 @@ extern "C" int vl3d_render_fwd_reg(const vl3d_render_desc *desc, const void *sta
     a.reg_fwd = 2;
     VL3D_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(double), (hipStream_t)stream));
     rc = dispatch(false, desc, a, (hipStream_t)stream);
+    if (rc != VL3D_OK) return rc;
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
+// ---- stage 1's loop mask as a fifth composited channel (MPI.py:115-117, 568-583) ---------------------------------------------------
+static int check_mask_desc(const vl3d_render_desc *d, const char *who) {
+    if (d->coord_mode == VL3D_COORD_AFFINE && d->border_mode == VL3D_BORDER_HARDCUT && d->act_order == VL3D_ACT_POST &&
+        d->rgb_act == VL3D_ACT_SIGMOID && d->alpha_act == VL3D_ACT_SIGMOID && d->stack_dtype == VL3D_F32)
+        return VL3D_OK;
+    vl3d_set_error((std::string(who) + ": the loop-mask channel is built for the planar convention stage 1 ships -- (affine, hardcut, post), "
+                   "sigmoid / sigmoid, fp32 stack (MPI.py:452-594); render the label in a pass of its own otherwise").c_str());
+    return VL3D_EUNSUPPORTED;
+}
+
+extern "C" int vl3d_render_fwd_mask(const vl3d_render_desc *desc, const void *stack, const float *mask, const float *homos, float *rgb,
+                                    float *alpha, float *label, float *alpha_sums, double *sums, void *reg_state, vl3d_stream_t stream) {
+    int rc = check_desc(desc);
+    if (rc != VL3D_OK) return rc;
+    rc = check_mask_desc(desc, "vl3d_render_fwd_mask");
+    if (rc != VL3D_OK) return rc;
+    VL3D_REQUIRE(stack && mask && homos && rgb && alpha && label, "null pointer passed to vl3d_render_fwd_mask");
+    VL3D_REQUIRE((sums == nullptr) == (reg_state == nullptr), "vl3d_render_fwd_mask: sums and reg_state come together (both NULL: no layer regularisers)");
+    VL3D_REQUIRE(!sums || desc->D <= 128, "the layer regularisers support at most 128 planes (coverage masks)");
+    VL3D_REQUIRE((int64_t)desc->Hs * desc->Ws * 16 < (1ll << 32), "frame too large for 32-bit byte offsets");
+    RenderArgs a = make_args(desc);
+    a.stack = (const float *)stack; a.homos = homos; a.rgb = rgb; a.alpha = alpha; a.asum = alpha_sums;
+    a.mask = mask; a.label = label;
+    a.fwd_variant = (desc->variant >> 8) & 0xf;
+    if (sums) {
+        a.reg_sums = sums;
+        set_reg_state(a, desc, reg_state);
+        a.reg_fwd = 2;
+        VL3D_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(double), (hipStream_t)stream));
+    }
+    rc = dispatch(false, desc, a, (hipStream_t)stream);
+    if (rc != VL3D_OK) return rc;
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
+extern "C" int vl3d_render_bwd_mask(const vl3d_render_desc *desc, const void *stack, const float *mask, const float *homos, const float *rgb,
+                                    const float *alpha, const float *grad_rgb, const float *grad_alpha, const float *grad_label,
+                                    const float *grad_reg, const void *reg_state, const float *grad_alpha_sums, float *grad_stack,
+                                    float *grad_mask, void *scratch, int64_t scratch_bytes, vl3d_stream_t stream) {
+    int rc = check_desc(desc);
+    if (rc != VL3D_OK) return rc;
+    rc = check_mask_desc(desc, "vl3d_render_bwd_mask");
+    if (rc != VL3D_OK) return rc;
+    VL3D_REQUIRE(stack && mask && homos && rgb && alpha && grad_rgb && grad_label && grad_stack && grad_mask, "null pointer passed to vl3d_render_bwd_mask");
+    VL3D_REQUIRE(!grad_reg || reg_state, "vl3d_render_bwd_mask: grad_reg needs the reg_state the forward with regularisers filled");
+    VL3D_REQUIRE((int64_t)desc->Hs * desc->Ws * 16 < (1ll << 32), "frame too large for 32-bit byte offsets");
+    RenderArgs a = make_args(desc);
+    if (grad_reg) set_reg_state(a, desc, reg_state);
+    a.stack = (const float *)stack; a.homos = homos;
+    a.rgb = const_cast<float *>(rgb); a.alpha = const_cast<float *>(alpha);
+    a.g_rgb = grad_rgb; a.g_alpha = grad_alpha; a.g_reg = grad_reg; a.g_asum = grad_alpha_sums; a.g_stack = grad_stack;
+    a.mask = mask; a.g_label = grad_label; a.g_mask = grad_mask;
+    const bool want_tile = (desc->variant & 0xf) != 1 && scratch != nullptr && scratch_bytes >= vl3d_render_bwd_scratch_bytes(desc);
+    a.gather9 = (desc->variant & 0xf) == 4;
+    if (want_tile) {
+        a.plan = (const float *)scratch;
+        a.owner = reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(scratch) + owner_table_off(desc));
+        a.tile_rows = 16;
+    } else {
+        const size_t texels = (size_t)desc->D * desc->T * desc->Hs * desc->Ws;
+        VL3D_HIP(hipMemsetAsync(grad_stack, 0, texels * 16, (hipStream_t)stream));
+        VL3D_HIP(hipMemsetAsync(grad_mask, 0, texels * 4, (hipStream_t)stream));
+    }
+    rc = dispatch(true, desc, a, (hipStream_t)stream);
     if (rc != VL3D_OK) return rc;
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;

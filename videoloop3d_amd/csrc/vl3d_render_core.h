@@ -76,6 +76,12 @@ struct RenderArgs {
     // row segments measured +1.6 ms on the 7.4 ms forward at cfg3: every cache line was written in parts)
     unsigned short *reg_signs;         // signs of (this pixel's layer value - right neighbour's) | (... - lower neighbour's) << 8
     unsigned short *reg_patch;         // the same towards the left | upper neighbour, irregular pairs only
+    // stage 1's learned loop mask as a fifth composited channel (MPI.py:115-117, 568-583; vl3d_render_fwd_mask / _bwd_mask):
+    // label = sum_k w_k sigmoid(sample(mask_k)) with the colour composite's weights w_k = a_k T_k, which get no gradient from it
+    const float *mask;       // (D,T,Hs,Ws) logits, one float per texel of the stack
+    float *label;            // (T,H,W)
+    const float *g_label;    // (T,H,W)
+    float *g_mask;           // (D,T,Hs,Ws), overwritten
 };
 
 // one entry point per compiled convention (coord_mode, border_mode, act_order): vl3d_render_c*.hip
@@ -343,6 +349,15 @@ __device__ __forceinline__ f4 shade2(const Taps2 &t, const u2 v[4], f4 *pre_out 
     return s;
 }
 
+// the loop-mask texture's four taps (4-byte texels at the stack's tap positions) and their blend, associated like shade2's
+__device__ __forceinline__ void load_mask_taps(const float *__restrict__ mplane, unsigned off16, TapStep st, float m[4]) {
+    const char *b = reinterpret_cast<const char *>(mplane) + (size_t)(off16 >> 2);
+    m[0] = *reinterpret_cast<const float *>(b);
+    m[1] = *reinterpret_cast<const float *>(b + (st.dx >> 2));
+    m[2] = *reinterpret_cast<const float *>(b + (st.dy >> 2));
+    m[3] = *reinterpret_cast<const float *>(b + (st.dy >> 2) + (st.dx >> 2));
+}
+__device__ __forceinline__ float mask_blend(const float m[4], f4 w) { return m[0] * w[0] + (m[1] * w[1] + (m[2] * w[2] + m[3] * w[3])); }
 
 // =====================================================================================================
 // Layer regularisers in hit-slot order (MPV.py:386-392, 441-449, 517-531; MPI.py:553-566, 608-622; utils.py:51-69).
@@ -599,7 +614,7 @@ void launch_reg_slots(const RenderArgs &a, hipStream_t s) {
 
 constexpr int TILE_X = 64, TILE_Y = 4;
 
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool MASK = false>
 __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
     if (a.plan && reinterpret_cast<const int *>(a.plan)[0]) return;   // the tile path owns this call
     const int x = blockIdx.x * TILE_X + (threadIdx.x & (TILE_X - 1));
@@ -621,6 +636,8 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
     const unsigned fl = a.g_reg ? a.reg_flags[(size_t)y * a.W + x] : 0u;
     float Tr = 1.0f, P = 0.0f;
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws), gst = make_tap_step<false>(a.Hs, a.Ws);
+    const float gL = MASK ? a.g_label[pix] : 0.0f;
+    const size_t mframe = (size_t)a.Hs * a.Ws;
     for (int d = 0; d < a.D; ++d, plane += (size_t)a.T * a.Hs * a.Ws * TEXB, gplane += (size_t)a.T * a.Hs * a.Ws * TEXB) {
         const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + VL3D_HS * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
         if (tp.cov == 0.0f) continue;
@@ -630,6 +647,16 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
         const f4 o = shade2<ORDER, RACT, AACT>(tp, tv, &pre);
         const float q = dot3p(Gr, o.x, Gg, o.y, Gb, o.z, gA);
         const float w = o.w * Tr;
+        if constexpr (MASK) {      // d label / d mask texel = g_label w_k sigmoid'(m_k) x tap weight (the weights w_k are detached, MPI.py:577-579)
+            float mt[4];
+            load_mask_taps(a.mask + ((size_t)d * a.T + t) * mframe, tp.off, gst, mt);
+            const float sm = act_fwd<VL3D_ACT_SIGMOID>(mask_blend(mt, tp.w));
+            const float gm = gL * w * (sm * (1.0f - sm));
+            float *gmp = a.g_mask + ((size_t)d * a.T + t) * mframe + (tp.off >> 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (tp.w[i] != 0.0f) atomicAdd(gmp + ((i & 1) ? (gst.dx >> 4) : 0u) + ((i & 2) ? (gst.dy >> 4) : 0u), gm * tp.w[i]);
+        }
         P = fmaf(w, q, P);
         const float om = 1.0f - o.w;
         // dL/da_k = T_k q_k - (sum_{j>k} w_j q_j)/(1-a_k); everything behind a fully opaque plane has zero weight
@@ -694,8 +721,9 @@ __global__ __launch_bounds__(256) void cull_fwd_plan_k(RenderArgs a, int TY, int
     if (box_touches_kept_quad(a, d, tnx, txx, tny, txy)) atomicOr(masks + (size_t)tile * 2 + (d >> 6), 1ull << (d & 63));
 }
 
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool SWZ, bool F16, bool CULL = false>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool SWZ, bool F16, bool CULL = false, bool MASK = false>
 __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles_x, int tiles_y) {
+    static_assert(!(MASK && (CULL || F16)), "the loop-mask channel: dense fp32 stage-1 stacks");
     int b = blockIdx.x;
     if constexpr (SWZ) b = xcd_remap(b, gridDim.x);
     const int tile_x = b % tiles_x, rest = b / tiles_x;
@@ -711,13 +739,17 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
     typedef typename TapVal<F16, ORDER>::type tapv_t;
     tapv_t vA[4], vB[4];
-#define VL3D_COMPOSITE(T_, V_)                                        \
+    float mA[4] = {0.f, 0.f, 0.f, 0.f}, mB[4] = {0.f, 0.f, 0.f, 0.f}, lab = 0.f;      // MASK: the loop-mask texture's taps, the composited label
+    const float *mplane = MASK ? a.mask + (size_t)t * a.Hs * a.Ws : nullptr;
+    const size_t mplane_stride = (size_t)a.T * a.Hs * a.Ws;
+#define VL3D_COMPOSITE(T_, V_, M_)                                    \
     {                                                                 \
         const f4 o = shade2<ORDER, RACT, AACT>(T_, V_);               \
         const float w = o.w * Tr;                                     \
         cr += w * o.x; cg += w * o.y; cb += w * o.z; A += w;          \
         n1 += o.w; n2 = fmaf(o.w, o.w, n2);                           \
         Tr *= (1.0f - o.w);                                           \
+        if constexpr (MASK) lab = fmaf(w, act_fwd<VL3D_ACT_SIGMOID>(mask_blend(M_, T_.w)), lab);      \
     }
     if constexpr (CULL) {
         // tile culling: walk only the planes whose bit is set for this workgroup (two 64-bit words in SGPRs, scalar bit scans);
@@ -745,11 +777,11 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
             for (;;) {
                 const int dB = next();
                 fetch(dB < 0 ? dA : dB, tB, vB);      // unconditional prefetch (re-reads the current plane past the end)
-                VL3D_COMPOSITE(tA, vA)
+                VL3D_COMPOSITE(tA, vA, mA)
                 if (dB < 0) break;
                 const int dC = next();
                 fetch(dC < 0 ? dB : dC, tA, vA);
-                VL3D_COMPOSITE(tB, vB)
+                VL3D_COMPOSITE(tB, vB, mB)
                 if (dC < 0) break;
                 dA = dC;
             }
@@ -758,6 +790,7 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
     // two register sets (A/B) so the taps of plane d+1 are in flight while plane d is shaded, without register copies
     Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy), tB = tA;
     load_taps2<F16>(plane, tA, st, vA);
+    if constexpr (MASK) load_mask_taps(mplane, tA.off, st, mA);
     // The prefetch of the next plane is unconditional (past the end it re-reads the last plane): with a branch around the
     // loads hipcc merges the two paths' counters and waits with vmcnt(0), i.e. for the taps it has just issued as well.
     for (int d = 0;; d += 2) {
@@ -767,9 +800,10 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
             load_uniform(a.homos + VL3D_HS * dn, h);
             tB = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
             load_taps2<F16>(plane + (size_t)dn * plane_stride_b, tB, st, vB);
+            if constexpr (MASK) load_mask_taps(mplane + (size_t)dn * mplane_stride, tB.off, st, mB);
             asm volatile("" ::: "memory");   // keep the loads here: hipcc otherwise sinks them below the composite
         }
-        VL3D_COMPOSITE(tA, vA)
+        VL3D_COMPOSITE(tA, vA, mA)
         if (d + 1 >= a.D) break;
         {
             const int dn = min(d + 2, a.D - 1);
@@ -777,9 +811,10 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
             load_uniform(a.homos + VL3D_HS * dn, h);
             tA = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
             load_taps2<F16>(plane + (size_t)dn * plane_stride_b, tA, st, vA);
+            if constexpr (MASK) load_mask_taps(mplane + (size_t)dn * mplane_stride, tA.off, st, mA);
             asm volatile("" ::: "memory");
         }
-        VL3D_COMPOSITE(tB, vB)
+        VL3D_COMPOSITE(tB, vB, mB)
         if (d + 2 >= a.D) break;
     }
     }
@@ -788,6 +823,7 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
     a.rgb[pix * 3 + 0] = cr; a.rgb[pix * 3 + 1] = cg; a.rgb[pix * 3 + 2] = cb;
     a.alpha[pix] = A;
     if (a.asum) { a.asum[pix * 2 + 0] = n1; a.asum[pix * 2 + 1] = n2; }
+    if constexpr (MASK) a.label[pix] = lab;
 }
 
 // Forward, two frames per thread.  Both render kernels are VALU-issue bound, and half of the forward's instruction
@@ -1090,19 +1126,31 @@ __global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, i
         float4 *g = reinterpret_cast<float4 *>(a.g_stack) + (size_t)d * a.T * frame + (size_t)y * a.Ws + x;
         for (int t = 0; t < a.T; ++t, g += frame) *g = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (a.g_mask) {      // the loop-mask gradient follows the stack gradient's ownership
+        float *g = a.g_mask + (size_t)d * a.T * frame + (size_t)y * a.Ws + x;
+        for (int t = 0; t < a.T; ++t, g += frame) *g = 0.f;
+    }
 }
 
 __global__ __launch_bounds__(256) void bwd_fill_zero_if_infeasible_k(float2 *g, size_t n8, const float *plan) {      // n8: 8-byte units
     if (reinterpret_cast<const int *>(plan)[0]) return;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) g[i] = make_float2(0.f, 0.f);
 }
+__global__ __launch_bounds__(256) void bwd_fill_zero_f32_if_infeasible_k(float *g, size_t n, const float *plan) {
+    if (reinterpret_cast<const int *>(plan)[0]) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) g[i] = 0.f;
+}
 
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16, bool CULL = false>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16, bool CULL = false, bool MASK = false>
 // (the culled instantiation of the utils_mpi coordinate convention -- a cross-check convention, its texel coordinates cost a
 // reciprocal more -- does not fit 64 VGPRs: it takes the 128-register budget (one workgroup per CU) rather than spill)
-__global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTILS_MPI)) ? 4 : 8)) void render_bwd_tile_k(RenderArgs a) {
+// MASK: stage 1's loop-mask texture as a fifth channel of the same sweep and gather (a fifth staged value, a fifth accumulator, one
+// 4-byte store per owned texel); T = 1 there, so the instantiation simply takes the 128-register budget.
+__global__ __launch_bounds__(RW *ROWS, ((REG || MASK || (CULL && COORD == VL3D_COORD_UTILS_MPI)) ? 4 : 8)) void render_bwd_tile_k(RenderArgs a) {
+    static_assert(!(MASK && (CULL || F16 || ORDER != VL3D_ACT_POST)), "the loop-mask channel: dense fp32 stage-1 stacks, sample-then-activate");
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
     constexpr int NT = RW * ROWS;
+    __shared__ float s_gm[MASK ? 2 : 1][MASK ? NT : 1];     // MASK: gradient w.r.t. the sampled mask logit of this pixel on this plane
     // REG: the layer-space smoothness regularisers (MPV.py:517-531) are differentiated here as well: their gradient at a pixel is
     // decoded from the sign words the forward stored (reg_grad) -- no neighbours' layer values, no extra halo.  The sparsity-sum
     // gradients ride in this instantiation too (g_reg == NULL: sparsity only).
@@ -1138,6 +1186,11 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTI
         // the sparsity-sum gradients ride in the REG instantiation only (launch_t): the plain one is at its 64-VGPR budget
         if constexpr (REG) if (a.g_asum) { gN1 = a.g_asum[pix * 2 + 0]; gN2 = 2.0f * a.g_asum[pix * 2 + 1]; }
     }
+    float gL = 0.f;
+    if constexpr (MASK) if (inimg) gL = a.g_label[((size_t)t * a.H + y) * a.W + x];
+    const float *mplane = MASK ? a.mask + (size_t)t * a.Hs * a.Ws : nullptr;
+    float *gmplane = MASK ? a.g_mask + (size_t)t * a.Hs * a.Ws : nullptr;
+    const size_t mplane_stride = (size_t)a.T * a.Hs * a.Ws;
     float Tr = 1.0f, P = 0.0f;
     float gsx_c = 0.f, gsy_c = 0.f, gsx_a = 0.f, gsy_a = 0.f;
     unsigned fl = 0u;
@@ -1161,7 +1214,7 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTI
     const unsigned toff_thread = (unsigned)(row * a.Ws + lane);   // texel (lane, row) of a window, relative to its corner
     const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)my_tile_id * a.D * 4;
     int nswept = 0;
-    for (int d = 0; d < a.D; ++d, plane += plane_stride_b, gplane += plane_stride_b) {
+    for (int d = 0; d < a.D; ++d, plane += plane_stride_b, gplane += plane_stride_b, mplane += mplane_stride, gmplane += mplane_stride) {
         float h[VL3D_HN];
         load_uniform(a.homos + VL3D_HS * d, h);
         // texel window of this tile on plane d (wave = window row, lane = window column); bit 31: culled for this tile
@@ -1197,6 +1250,7 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTI
         float4 gval = make_float4(0.f, 0.f, 0.f, 0.f);
         f4 o = f4{0.f, 0.f, 0.f, 0.f}, pre = o;
         Taps2 tp{};
+        float gm = 0.f, msig = 0.f;
         if (inimg) {
             if constexpr (CULL) tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
             else tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
@@ -1207,7 +1261,10 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTI
             }
             typename TapVal<F16, ORDER>::type tv[4];
             load_taps2<F16>(src, tp, st, tv);
+            float mt[4];
+            if constexpr (MASK) load_mask_taps(mplane, tp.off, st, mt);
             o = shade2<ORDER, RACT, AACT>(tp, tv, &pre);                 // o.w already 0 when the plane does not cover the pixel
+            if constexpr (MASK) msig = act_fwd<VL3D_ACT_SIGMOID>(mask_blend(mt, tp.w));
         }
         f4 sg = f4{0.f, 0.f, 0.f, 0.f};
         if constexpr (REG) if (reg_on) {      // uniform
@@ -1227,6 +1284,9 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTI
         if (inimg) {
             const float q = dot3p(Gr, o.x, Gg, o.y, Gb, o.z, gA);
             const float w = o.w * Tr;
+            // loop mask: d label / d (sampled logit) = g_label w_k sigmoid'; w_k is 0 where the plane does not cover the pixel, and the
+            // colour composite's weights get nothing back from the label (detached, MPI.py:577-579)
+            if constexpr (MASK) gm = gL * w * (msig * (1.0f - msig));
             P = fmaf(w, q, P);
             const float om = 1.0f - o.w;
             const float behind = (om > 1e-12f) ? (S - P) * fast_rcp(om) : 0.0f;
@@ -1244,6 +1304,7 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTI
         }
         s_t[buf][tid] = tc;
         s_g[buf][tid] = gval;
+        if constexpr (MASK) s_gm[buf][tid] = gm;
         __syncthreads();   // staging of plane d visible (the other buffer may still be read by slower waves: not touched here)
         // (3) every texel of this tile's window that the owner table assigns to this tile gathers its taps from the 3x3
         //     pixels around its owner pixel.  Wave = window row, lane = window column: uniform row bases, no index arithmetic.
@@ -1254,6 +1315,7 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTI
             const int lc = (int)(e & 1023u);
             const f2 tau = f2{(float)(X0 + wx), (float)(Y0 + wy)};
             f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+            float accm = 0.f;
             if VL3D_ABLATE(a.ablate, 8) {
             } else if (apart) {
                 // 2x2 block of the owner pixel towards tau, summed in the 3x3 loop's order: the five pixels left out have weight
@@ -1264,7 +1326,9 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTI
                 for (int k = 0; k < 4; ++k) {
                     const int li = li0 + (k >> 1) * RW + (k & 1);
                     const f2 dc = *reinterpret_cast<const f2 *>(&s_t[buf][li]) - tau;
-                    acc += *reinterpret_cast<const f4 *>(&s_g[buf][li]) * (tent_weight(dc.x) * tent_weight(dc.y));
+                    const float wgt = tent_weight(dc.x) * tent_weight(dc.y);
+                    acc += *reinterpret_cast<const f4 *>(&s_g[buf][li]) * wgt;
+                    if constexpr (MASK) accm = fmaf(s_gm[buf][li], wgt, accm);
                 }
             } else {
 #pragma unroll
@@ -1273,7 +1337,9 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTI
                 for (int dx = -1; dx <= 1; ++dx) {
                     const int li = lc + dy * RW + dx;
                     const f2 dc = *reinterpret_cast<const f2 *>(&s_t[buf][li]) - tau;
-                    acc += *reinterpret_cast<const f4 *>(&s_g[buf][li]) * (tent_weight(dc.x) * tent_weight(dc.y));
+                    const float wgt = tent_weight(dc.x) * tent_weight(dc.y);
+                    acc += *reinterpret_cast<const f4 *>(&s_g[buf][li]) * wgt;
+                    if constexpr (MASK) accm = fmaf(s_gm[buf][li], wgt, accm);
                 }
             }
             if constexpr (ORDER == VL3D_ACT_PRE) {   // d act(s_tau)/d s_tau factors out of the tap sum
@@ -1282,6 +1348,7 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || (CULL && COORD == VL3D_COORD_UTI
                          acc.z * act_bwd<RACT>(sv.z, act_fwd<RACT>(sv.z)), acc.w * act_bwd<AACT>(sv.w, act_fwd<AACT>(sv.w))};
             }
             if (!VL3D_ABLATE(a.ablate, 2)) store_grad_texel<F16>(gplane, tix << 4, acc);
+            if constexpr (MASK) __builtin_nontemporal_store(accm, gmplane + tix);
         };
         if (row < wh && lane < ww) gather(e0, lane, row, win0 + toff_thread);
         // rest of a window larger than 64 x ROWS (stacks stored above the frame's resolution, frame-border tiles, rotations)
@@ -1568,7 +1635,7 @@ void launch_pair(const RenderArgs &a, hipStream_t s) {
 // row are halo (63 x 7 pixels owned: their outputs and the |o - o_right|, |o - o_down| pairs), each plane's activated layer values
 // go through a double-buffered LDS tile (one barrier per plane), and the taps of plane d+1 are in flight across that barrier (two
 // register sets, as in render_fwd2_k).  Per pixel the composite is render_fwd2_k's, instruction for instruction (same bits).
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool MASK = false>
 __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_x, int tiles_y) {
     constexpr int FW = 64, FH = 8, NT = FW * FH;
     __shared__ float4 s_o[2][NT];
@@ -1595,7 +1662,11 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
     typedef typename TapVal<F16, ORDER>::type tapv_t;
     tapv_t vA[4], vB[4];
-#define VL3D_PLANE(T_, V_, BUF_, S_)                                                                      \
+    static_assert(!(MASK && F16), "the loop-mask channel: fp32 stage-1 stacks");
+    float mA[4] = {0.f, 0.f, 0.f, 0.f}, mB[4] = {0.f, 0.f, 0.f, 0.f}, lab = 0.f;      // MASK: the loop-mask texture's taps, the composited label
+    const float *mplane = MASK ? a.mask + (size_t)t * a.Hs * a.Ws : nullptr;
+    const size_t mplane_stride = (size_t)a.T * a.Hs * a.Ws;
+#define VL3D_PLANE(T_, V_, BUF_, S_, M_)                                                                  \
     {                                                                                                     \
         const f4 o = shade2<ORDER, RACT, AACT>(T_, V_);                                                   \
         const f4 ol = inimg ? o * T_.cov : f4{0.f, 0.f, 0.f, 0.f};                                        \
@@ -1604,6 +1675,7 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
         cr += w * o.x; cg += w * o.y; cb += w * o.z; A += w;                                              \
         n1 += o.w; n2 = fmaf(o.w, o.w, n2);                                                               \
         Tr *= (1.0f - o.w);                                                                               \
+        if constexpr (MASK) lab = fmaf(w, act_fwd<VL3D_ACT_SIGMOID>(mask_blend(M_, T_.w)), lab);          \
         __syncthreads();                                                                                  \
         int code = (int)REG_ZERO;                                                                         \
         if (own_r) {                                                                                      \
@@ -1631,29 +1703,31 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
     }
     Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy), tB = tA;
     load_taps2<F16>(plane, tA, st, vA);
-#define VL3D_FETCH(T_, V_, DN_)                                                                           \
+    if constexpr (MASK) load_mask_taps(mplane, tA.off, st, mA);
+#define VL3D_FETCH(T_, V_, DN_, M_)                                                                       \
     {                                                                                                     \
         const int dn = min(DN_, a.D - 1);                                                                 \
         float h[VL3D_HN];                                                                                 \
         load_uniform(a.homos + VL3D_HS * dn, h);                                                          \
         T_ = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);                    \
         load_taps2<F16>(plane + (size_t)dn * plane_stride_b, T_, st, V_);                                 \
+        if constexpr (MASK) load_mask_taps(mplane + (size_t)dn * mplane_stride, T_.off, st, M_);          \
         asm volatile("" ::: "memory");                                                                    \
     }
     // four planes per trip: the slot of a plane inside its group of sign words is a compile-time constant
     int d = 0;
     for (;; d += 4) {
-        VL3D_FETCH(tB, vB, d + 1)
-        VL3D_PLANE(tA, vA, 0, 0)
+        VL3D_FETCH(tB, vB, d + 1, mB)
+        VL3D_PLANE(tA, vA, 0, 0, mA)
         if (d + 1 >= a.D) break;
-        VL3D_FETCH(tA, vA, d + 2)
-        VL3D_PLANE(tB, vB, 1, 1)
+        VL3D_FETCH(tA, vA, d + 2, mA)
+        VL3D_PLANE(tB, vB, 1, 1, mB)
         if (d + 2 >= a.D) break;
-        VL3D_FETCH(tB, vB, d + 3)
-        VL3D_PLANE(tA, vA, 0, 2)
+        VL3D_FETCH(tB, vB, d + 3, mB)
+        VL3D_PLANE(tA, vA, 0, 2, mA)
         if (d + 3 >= a.D) break;
-        VL3D_FETCH(tA, vA, d + 4)
-        VL3D_PLANE(tB, vB, 1, 3)
+        VL3D_FETCH(tA, vA, d + 4, mA)
+        VL3D_PLANE(tB, vB, 1, 3, mB)
         if (d + 4 >= a.D) break;
     }
     if ((a.D & 3) && owner) *sgq = make_uint2(sg_lo, (a.D & 3) == 3 ? sg_hi : 0u);      // the last, partial group
@@ -1664,6 +1738,7 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
         a.rgb[pix * 3 + 0] = cr; a.rgb[pix * 3 + 1] = cg; a.rgb[pix * 3 + 2] = cb;
         a.alpha[pix] = A;
         if (a.asum) { a.asum[pix * 2 + 0] = n1; a.asum[pix * 2 + 1] = n2; }
+        if constexpr (MASK) a.label[pix] = lab;
     }
     float v[4] = {sxc, syc, sxa, sya};
 #pragma unroll
@@ -1681,7 +1756,7 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
 }
 
 // ---- launch templates ---------------------------------------------------------------------------------------------
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16 = false>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16 = false, bool MASK = false>
 void launch_tile(const RenderArgs &a, hipStream_t s) {
     constexpr int RH = 1, IW = RW - 2 * RH, IH = ROWS - 2 * RH;
     RenderArgs b = a;
@@ -1691,7 +1766,10 @@ void launch_tile(const RenderArgs &a, hipStream_t s) {
                        reinterpret_cast<int *>(const_cast<float *>(a.plan)) + plan_win_off(a.D));
     hipLaunchKernelGGL(bwd_owner_table_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x,
                        const_cast<unsigned short *>(a.owner));
-    if (a.quad_keep)
+    if constexpr (MASK) {       // (dense models only: the entry point refuses a quad map)
+        hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16, false, true>),
+                           dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
+    } else if (a.quad_keep)
         hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16, true>),
                            dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
     else
@@ -1702,12 +1780,25 @@ void launch_tile(const RenderArgs &a, hipStream_t s) {
 template <bool BWD, int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
 void launch_t(const RenderArgs &a, hipStream_t s) {
     dim3 grid((a.W + TILE_X - 1) / TILE_X, (a.H + TILE_Y - 1) / TILE_Y, a.T), block(TILE_X * TILE_Y);
+    // the loop-mask channel (a.mask != NULL) is built for the convention stage 1 ships (MPI.py planar path, sigmoid / sigmoid, fp32); the
+    // entry points refuse every other descriptor
+    constexpr bool MASKABLE = COORD == VL3D_COORD_AFFINE && BORDER == VL3D_BORDER_HARDCUT && ORDER == VL3D_ACT_POST &&
+                              RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID && !F16;
     if constexpr (BWD) {
         if (a.tile_rows) {
             hipLaunchKernelGGL((bwd_plan_k<COORD>), dim3(1), dim3(64), 0, s, a, 16, const_cast<float *>(a.plan));
             const size_t n8 = (size_t)a.D * a.T * a.Hs * a.Ws * (a.g_f16 ? 1 : 2);          // fp16 texels are 8 bytes, fp32 ones 16
             hipLaunchKernelGGL(bwd_fill_zero_if_infeasible_k, dim3(4096), dim3(256), 0, s, reinterpret_cast<float2 *>(a.g_stack), n8, a.plan);
             bool done = false;
+            if constexpr (MASKABLE) {
+                if (a.mask) {      // one frame per thread, fifth channel in the sweep and the gather
+                    hipLaunchKernelGGL(bwd_fill_zero_f32_if_infeasible_k, dim3(1024), dim3(256), 0, s, a.g_mask, (size_t)a.D * a.T * a.Hs * a.Ws, a.plan);
+                    if (a.g_reg || a.g_asum) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, false, true>(a, s);
+                    else launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, false, false, true>(a, s);
+                    hipLaunchKernelGGL((render_bwd_k<COORD, BORDER, ORDER, RACT, AACT, false, true>), grid, block, 0, s, a);
+                    return;
+                }
+            }
             if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID) {
                 // two frames per thread: dense stacks without layer regularisers (tile_rows 17 = "16 rows, pairs allowed"), when a
                 // 30 x 14-pixel tile's texel window fits the 32 x 16 threads of its workgroup -- judged by the sizes alone (the
@@ -1739,6 +1830,12 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
                 }
             }
         }
+        if constexpr (MASKABLE) {
+            if (a.mask) {
+                hipLaunchKernelGGL((render_bwd_k<COORD, BORDER, ORDER, RACT, AACT, false, true>), grid, block, 0, s, a);
+                return;
+            }
+        }
         hipLaunchKernelGGL((render_bwd_k<COORD, BORDER, ORDER, RACT, AACT, F16>), grid, block, 0, s, a);
     } else {
         // with the regularisers: coverage masks + pair flags (frame independent), the plane-by-plane kernel over the regular pairs,
@@ -1746,7 +1843,15 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
         if (a.reg_fwd == 2) {       // render + regulariser sums in one pass (dense stacks)
             launch_reg_prepass<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
             const int tx = (a.W + 62) / 63, ty = (a.H + 6) / 7;
-            hipLaunchKernelGGL((render_fwd_reg_k<COORD, BORDER, ORDER, RACT, AACT, F16>), dim3((unsigned)(tx * ty * a.T)), dim3(512), 0, s, a, tx, ty);
+            bool with_mask = false;
+            if constexpr (MASKABLE) {
+                if (a.mask) {
+                    hipLaunchKernelGGL((render_fwd_reg_k<COORD, BORDER, ORDER, RACT, AACT, false, true>), dim3((unsigned)(tx * ty * a.T)), dim3(512), 0, s, a, tx, ty);
+                    with_mask = true;
+                }
+            }
+            if (!with_mask)
+                hipLaunchKernelGGL((render_fwd_reg_k<COORD, BORDER, ORDER, RACT, AACT, F16>), dim3((unsigned)(tx * ty * a.T)), dim3(512), 0, s, a, tx, ty);
             launch_reg_slots<COORD, BORDER, ORDER, RACT, AACT, F16, true>(a, s);
             return;
         }
@@ -1758,6 +1863,14 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
         // frame pairs (shipped activations, dense stacks, T >= 2); forward variant 6 (desc->variant bits 8..11) keeps the one-frame
         // kernel (A/B, bitwise tests).  The workgroup-shape variants of round 1 (64x4, 64x16, no XCD remap) measured within the
         // noise of the default and are no longer built.
+        if constexpr (MASKABLE) {
+            if (a.mask) {       // one frame per thread with the fifth channel
+                const int tiles_x = (a.W + 63) / 64, tiles_y = (a.H + 7) / 8;
+                hipLaunchKernelGGL((render_fwd2_k<COORD, BORDER, ORDER, RACT, AACT, 8, true, false, false, true>), dim3((unsigned)(tiles_x * tiles_y * a.T)),
+                                   dim3(64 * 8), 0, s, a, tiles_x, tiles_y);
+                return;
+            }
+        }
         if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID) {
             if (a.T >= 2 && a.fwd_variant != 6 && !(a.quad_keep && a.cull_masks)) return launch_fwd2x<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
         }

@@ -130,7 +130,9 @@ class TileAdam(torch.optim.Optimizer):
     tile-culled model: one HIP kernel per step that walks only the texels a kept quad can read (vl3d_adam_step_tiles).  Culled
     texels never get a gradient, their moments stay zero and Adam would not move them, so the parameters after every step are
     the ones torch.optim.Adam produces (to fp32 rounding of the fused update) while the 7 streams over the culled 80-95 % of the
-    stack disappear.  `quad_keep` may be replaced at any time through `.quad_keep` (None = dense)."""
+    stack disappear.  `quad_keep` may be replaced at any time through `.quad_keep` (None = dense: ONE pass over (p, g, m, v) for any
+    contiguous float32 parameter, against the 7 chunked multi-tensor passes of torch.optim.Adam's default path -- 49 launches and 2.3 of the
+    4.3 ms of GPU time of a 720p stage-1 iteration, profiles/r03_kernel_stats_s1.csv)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, quad_keep=None, quad_dyn=None):
         """quad_dyn (with quad_keep): static texels are treated as ONE parameter with T copies -- their gradient is read from
@@ -155,8 +157,17 @@ class TileAdam(torch.optim.Optimizer):
                 if p.grad is None:
                     continue
                 L.check_cuda(p, p.grad)
-                if p.dim() != 5 or p.shape[-1] != 4 or p.dtype != torch.float32 or not p.is_contiguous():
-                    raise RuntimeError("TileAdam: parameters must be contiguous float32 plane stacks (D,T,Hs,Ws,4)")
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("TileAdam: parameters must be contiguous float32 tensors")
+                if p.dim() != 5 or p.shape[-1] != 4:
+                    # any other parameter of a DENSE model (stage 1's loop-mask texture [D,1,Hs,Ws], MPI.py:115-117): Adam is elementwise,
+                    # so the tensor is walked as rows of 16-byte groups
+                    if qk is not None or p.numel() % 4 != 0:
+                        raise RuntimeError("TileAdam: with a quad map the parameters must be plane stacks (D,T,Hs,Ws,4); dense ones need numel % 4 == 0")
+                    rows = p.numel() // p.shape[-1]
+                    dims = (1, 1, rows, p.shape[-1] // 4) if p.shape[-1] % 4 == 0 and rows <= 4 * 65535 else (1, 1, 1, p.numel() // 4)
+                else:
+                    dims = tuple(p.shape[:4])
                 st = self.state[p]
                 if not st:
                     st["step"] = 0
@@ -164,7 +175,7 @@ class TileAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p)
                 st["step"] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                D, T, Hs, Ws, _ = p.shape
+                D, T, Hs, Ws = dims
                 with torch.cuda.device(p.device):
                     L.check(L.lib().vl3d_adam_step_tiles(D, T, Hs, Ws, L.ptr(qk), L.ptr(qd), 0 if qk is None else qk.shape[1],
                                                          0 if qk is None else qk.shape[2], L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]),
