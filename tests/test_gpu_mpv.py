@@ -237,6 +237,85 @@ def test_mpmesh_forward_train_matches_oracle(dev, loop_mask):
         assert float(go.abs().max()) > 0
 
 
+def test_loop_mask_fifth_channel_equals_the_label_pass(dev):
+    """The loop mask composited as a fifth channel of the colour pass (vl3d_render_fwd_mask / _bwd_mask) against the separate label pass
+    (a second render of a (mask logit, -, -, alpha logit) stack): label, gradient to the mask texture, and colours / regulariser terms /
+    stack gradient untouched by the extra channel.  Owner-computes tile path, the atomics fallback (variant 1), with and without the
+    layer regularisers, poses on the host and on the device."""
+    import dataclasses
+    from videoloop3d_amd.MPI import MPMesh
+    H, W = 44, 60
+    K, ref_extrin, tar = scene(H, W)
+    h, w = 33, 47
+    Kc = K.copy(); Kc[0, 2] -= 6; Kc[1, 2] -= 5
+    tar_e, tar_k = torch.tensor(tar)[None], torch.tensor(Kc)[None]
+
+    def run(two_pass, reg, variant=0, host_pose=False):
+        kw = {} if reg else dict(sparsity_loss_weight=0.0, rgb_smooth_loss_weight=0.0, a_smooth_loss_weight=0.0)
+        args = make_args_mpi(loop_mask_two_pass=two_pass, **kw)
+        m = MPMesh(args, H, W, ref_extrin, K, 1.0, 100.0).to(dev).train()
+        m.spec = dataclasses.replace(m.spec, variant=variant)
+        with torch.no_grad():
+            m.stack.copy_(synth.make_plane_stack(*m.stack.shape[:4], seed=5) * 0.7)
+            m.stack_mask.copy_(synth.hash_uniform(tuple(m.stack_mask.shape), seed=6) * 3 - 2)
+        rgbl, extra = m(h, w, tar_e if host_pose else tar_e.to(dev), tar_k if host_pose else tar_k.to(dev))
+        g = (synth.hash_uniform(tuple(rgbl.shape), seed=9) - 0.5).to(dev)
+        tot = (rgbl * g).sum() + sum(v.sum() for v in extra.values()) * 10
+        gs, gm = torch.autograd.grad(tot, [m.stack, m.stack_mask])
+        return rgbl.detach(), {k: float(v) for k, v in extra.items()}, gs, gm
+
+    for reg in (True, False):
+        ref = run(True, reg)
+        for variant, host_pose in ((0, False), (1, False), (0, True)):
+            got = run(False, reg, variant, host_pose)
+            assert float((got[0] - ref[0]).abs().max()) <= 2e-6, (reg, variant)
+            assert got[1].keys() == ref[1].keys() and all(abs(got[1][k] - ref[1][k]) <= 1e-6 * max(1.0, abs(ref[1][k])) for k in ref[1])
+            tol = 2e-5 if variant == 1 else 2e-6             # (the atomics fallback sums in a different order)
+            assert float((got[2] - ref[2]).abs().max()) <= tol * max(1.0, float(ref[2].abs().max())), (reg, variant)
+            assert float((got[3] - ref[3]).abs().max()) <= tol * max(1.0, float(ref[3].abs().max())), (reg, variant)
+            assert float(ref[3].abs().max()) > 0
+
+
+def test_loop_mask_channel_is_refused_for_other_conventions(dev):
+    from videoloop3d_amd import _lib as L
+    from videoloop3d_amd.render import RenderSpec, _desc
+    stack = torch.zeros((2, 1, 8, 8, 4), device=dev)
+    mask = torch.zeros((2, 1, 8, 8), device=dev)
+    out = torch.zeros((1, 4, 4, 3), device=dev)
+    a = torch.zeros((1, 4, 4), device=dev)
+    homos = torch.eye(3, device=dev).repeat(2, 1, 1)
+    desc = _desc(stack, 4, 4, RenderSpec(), 0, 0)            # the utils_mpi convention
+    with torch.cuda.device(dev):
+        rc = L.lib().vl3d_render_fwd_mask(desc, L.ptr(stack), L.ptr(mask), L.ptr(homos), L.ptr(out), L.ptr(a), L.ptr(a.clone()), None, None, None,
+                                          L.stream_ptr(dev))
+    assert rc == 3 and b"loop-mask" in L.lib().vl3d_last_error()
+
+
+def test_one_pass_adam_on_stage1_parameters_matches_torch_adam(dev):
+    """MPMesh.get_optimizer: tiles.TileAdam without a quad map walks ANY contiguous float32 parameter (the plane stack and the
+    [D,1,Hs,Ws] loop-mask texture) in one pass; same parameters as torch.optim.Adam after several steps with a changing lr."""
+    from videoloop3d_amd.MPI import MPMesh
+    H, W = 44, 60
+    K, ref_extrin, _ = scene(H, W)
+    args = make_args_mpi(optimizer="adam", lrate=0.05, lrate_decay=100)
+    m = MPMesh(args, H, W, ref_extrin, K, 1.0, 100.0).to(dev)
+    opt = m.get_optimizer()
+    assert type(opt).__name__ == "TileAdam"
+    ref = [p.detach().clone().requires_grad_(True) for p in m.parameters()]
+    opt_t = torch.optim.Adam(ref, lr=0.05, betas=(0.9, 0.999))
+    for it in range(6):
+        for g_, o_ in ((opt.param_groups, opt), (opt_t.param_groups, opt_t)):
+            for grp in g_:
+                grp["lr"] = 0.05 * 0.9 ** it
+        for i, (p, q) in enumerate(zip(m.parameters(), ref)):
+            g = synth.hash_uniform(tuple(p.shape), seed=30 + 7 * it + i).to(dev) - 0.5
+            p.grad, q.grad = g.clone(), g.clone()
+        opt.step()
+        opt_t.step()
+    for p, q in zip(m.parameters(), ref):
+        assert float((p - q).abs().max()) <= 2e-6
+
+
 def test_mpmesh_eval(dev):
     from videoloop3d_amd.MPI import MPMesh
     H, W = 44, 60

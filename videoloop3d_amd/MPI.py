@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from . import tiles
 from .MPV import ACTIVATES, get_new_intrin, sparsity_ratio
-from .render import RenderSpec, render_planes, render_planes_with_regularisers
+from .render import RenderSpec, mask_channel_supported, render_planes, render_planes_with_mask, render_planes_with_regularisers
 from .utils_mpi import compute_homography, make_depths
 
 ALPHA_INIT_VAL = -3.     # MPI.py:33
@@ -215,7 +215,11 @@ class MPMesh(nn.Module):
         """MPI.py:452-594 -> (rgbl [B,H,W,3|4], variables).  One fused render per view (the kernels share one camera per call)."""
         B = len(extrin)
         rgbs, alphas, labels, ssums, asums = [], [], [], [], []
-        if self.learn_loop_mask:
+        # the loop mask rides the colour pass as a fifth channel where the kernels are built for it (the shipped planar convention, a CUDA
+        # stack); args.loop_mask_two_pass keeps the separate label pass (A/B, cross-checks)
+        fused_mask = (self.learn_loop_mask and self.stack.is_cuda and mask_channel_supported(self.stack, self.spec)
+                      and not self.is_sparse and not getattr(self.args, "loop_mask_two_pass", False))
+        if self.learn_loop_mask and not fused_mask:
             if getattr(self, "_mask_buf", None) is None or self._mask_buf.shape != self.stack.shape or self._mask_buf.device != self.stack.device:
                 self._mask_buf = torch.zeros_like(self.stack)
             with torch.no_grad():          # channel 0: mask logit, channel 3: the layer alpha logit (detached, MPI.py:572)
@@ -223,7 +227,13 @@ class MPMesh(nn.Module):
                 self._mask_buf[..., 3].copy_(self.stack[..., 3])
         for b in range(B):
             homos = self.plane_homographies(extrin[b:b + 1], intrin[b:b + 1]).to(self.stack.device)
-            if need_reg:
+            if fused_mask:
+                rgb, alpha, label, ss, asum = render_planes_with_mask(self.stack, self.stack_mask, homos, H, W, self.spec, with_regularisers=need_reg)
+                labels.append(label[..., None])
+                if need_reg:
+                    ssums.append(ss)
+                    asums.append(asum)
+            elif need_reg:
                 rgb, alpha, ss, asum = render_planes_with_regularisers(self.stack, homos, H, W, self.spec)
                 ssums.append(ss)
                 asums.append(asum)
@@ -238,7 +248,7 @@ class MPMesh(nn.Module):
                 rgb = rgb * alpha[..., None] + bg[None, None, None] * (- alpha[..., None] + 1)
             rgbs.append(rgb)
             alphas.append(alpha)
-            if self.learn_loop_mask:                                                              # MPI.py:568-583
+            if self.learn_loop_mask and not fused_mask:                                           # MPI.py:568-583
                 labels.append(_LoopMaskLabel.apply(self.stack_mask, self.stack, self._mask_buf, homos, H, W, self.spec_mask))
         rgb = torch.cat(rgbs, 0)
         rgbl = torch.cat([rgb, torch.cat(labels, 0)], dim=-1) if self.learn_loop_mask else rgb

@@ -160,6 +160,74 @@ class _RenderPlanes(torch.autograd.Function):
         return g_stack, None, None, None, None, None, None, None, None, None
 
 
+def mask_channel_supported(stack, spec):
+    """the descriptors vl3d_render_fwd_mask / _bwd_mask are built for (include/vl3d.h): the planar convention stage 1 ships."""
+    return (spec.coord_mode == "affine" and spec.border == "hardcut" and spec.act_order == "post" and spec.rgb_act == "sigmoid"
+            and spec.alpha_act == "sigmoid" and stack.dtype == torch.float32)
+
+
+class _RenderPlanesMask(torch.autograd.Function):
+    """render (+ layer regularisers) with stage 1's loop mask as a fifth composited channel (MPI.py:568-583): one forward and one backward
+    sweep over the stack for colours, regularisers and label; the label's gradient reaches the mask texture only (detached weights)."""
+
+    @staticmethod
+    def forward(ctx, stack, mask, homos, H, W, spec, with_reg):
+        L.check_cuda(stack, mask, homos)
+        D, T, Hs, Ws, _ = stack.shape
+        if tuple(mask.shape) not in ((D, T, Hs, Ws), (D, T, Hs, Ws, 1)) or mask.dtype != torch.float32:
+            raise RuntimeError(f"the loop-mask texture must be float32 [D,T,Hs,Ws] = {(D, T, Hs, Ws)}, got {tuple(mask.shape)} {mask.dtype}")
+        if homos.shape != (D, 3, 3):
+            raise RuntimeError(f"homos must be [D,3,3] = [{D},3,3], got {tuple(homos.shape)}")
+        stack, mask = stack.contiguous(), mask.contiguous()
+        homos = homos.detach().to(torch.float32).contiguous()
+        dev = stack.device
+        rgb = torch.empty((T, H, W, 3), dtype=torch.float32, device=dev)
+        alpha = torch.empty((T, H, W), dtype=torch.float32, device=dev)
+        label = torch.empty((T, H, W), dtype=torch.float32, device=dev)
+        desc = _desc(stack, H, W, spec, 0, 0)
+        asum = torch.empty((T, H, W, 2), dtype=torch.float32, device=dev) if with_reg else None
+        sums = torch.zeros(4, dtype=torch.float64, device=dev) if with_reg else None
+        reg_state = None
+        with torch.cuda.device(dev):
+            if with_reg:
+                reg_state = torch.empty(int(L.lib().vl3d_render_reg_state_bytes(desc)), dtype=torch.uint8, device=dev)
+            L.check(L.lib().vl3d_render_fwd_mask(desc, L.ptr(stack), L.ptr(mask), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.ptr(label), L.ptr(asum),
+                                                 L.ptr(sums), L.ptr(reg_state), L.stream_ptr(dev)), "vl3d_render_fwd_mask")
+        ctx.save_for_backward(stack, mask, homos, rgb, alpha)
+        ctx.desc, ctx.reg_state, ctx.with_reg = desc, reg_state, with_reg
+        z = torch.zeros((0,), dtype=torch.float32, device=dev)
+        return rgb, alpha, label, (sums.to(torch.float32) if with_reg else z), (asum if with_reg else z)
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_alpha, g_label, g_sums, g_asum):
+        stack, mask, homos, rgb, alpha = ctx.saved_tensors
+        dev = stack.device
+        g_reg = g_sums.to(torch.float32).contiguous() if (ctx.with_reg and g_sums is not None) else None
+        g_asum = g_asum.to(torch.float32).contiguous() if (ctx.with_reg and g_asum is not None) else None
+        g_rgb = g_rgb.contiguous() if g_rgb is not None else torch.zeros_like(rgb)
+        g_alpha = g_alpha.contiguous() if g_alpha is not None else None
+        g_label = g_label.contiguous() if g_label is not None else torch.zeros_like(alpha)
+        g_stack = torch.empty_like(stack)
+        g_mask = torch.empty_like(mask)
+        with torch.cuda.device(dev):
+            nscratch = int(L.lib().vl3d_render_bwd_scratch_bytes(ctx.desc))
+            scratch = torch.empty((nscratch + 3) // 4, dtype=torch.float32, device=dev)
+            scratch[:16].zero_()
+            L.check(L.lib().vl3d_render_bwd_mask(ctx.desc, L.ptr(stack), L.ptr(mask), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.ptr(g_rgb), L.ptr(g_alpha),
+                                                 L.ptr(g_label), L.ptr(g_reg), L.ptr(ctx.reg_state), L.ptr(g_asum), L.ptr(g_stack), L.ptr(g_mask),
+                                                 L.ptr(scratch), nscratch, L.stream_ptr(dev)), "vl3d_render_bwd_mask")
+        global LAST_BWD_SCRATCH
+        LAST_BWD_SCRATCH = scratch
+        return g_stack, g_mask, None, None, None, None, None
+
+
+def render_planes_with_mask(stack, mask, homos, H, W, spec: RenderSpec = RenderSpec(), with_regularisers=False):
+    """-> (rgb [T,H,W,3], alpha [T,H,W], label [T,H,W], smooth_sums[4], alpha_sums [T,H,W,2]) -- render_planes (with_regularisers: plus
+    render_planes_with_regularisers' sums) and the composited loop-mask label `sum_k w_k sigmoid(sample(mask_k))` of MPI.py:568-583 from the
+    same pass; `mask` [D,T,Hs,Ws] logits.  Needs mask_channel_supported(stack, spec)."""
+    return _RenderPlanesMask.apply(stack, mask, homos, int(H), int(W), spec, bool(with_regularisers))
+
+
 def render_planes(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0), quad_keep=None, cull_window=None):
     """stack (D,T,Hs,Ws,4) pre-activation fp32 (plane 0 = nearest), homos [D,3,3] (target pixel -> plane pixel).
 
