@@ -151,9 +151,12 @@ int vl3d_adam_step_tiles(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uin
  * A catch-up with the full plane as the window makes the whole stack current (checkpoints, lod, evaluation renders).
  * Tile-culled models (quad_keep / quad_dyn != NULL, device byte maps [D][QH][QW]): culled texels are no parameters (the compact copy
  * shows them as (0, 0, 0, culled_alpha)); a texel only static quads can read is ONE parameter stored in frame 0 -- the compact copy
- * shows it in every frame, the step sums its compact gradient over the frames and writes frame 0 only; mirror_static != 0 makes a
+ * shows it in every frame, the step sums its compact gradient over the frames and writes frame 0 only; mirror_static bit 0 makes a
  * catch-up refresh the other frames' slots of static texels (so that the dense stack reads consistently: flush); static_tied != 0
- * tells the step that frame 0 of the gradient already holds a static texel's frame sum (vl3d_tie_static_grad ran on it). */
+ * tells the step that frame 0 of the gradient already holds a static texel's frame sum (vl3d_tie_static_grad ran on it).
+ * mirror_static bit 1 ("lean" compact copy): the caller guarantees that `compact` holds FINITE values everywhere already (a persistent
+ * buffer that was zero-filled once and has only ever been written by this call), so the slots the render cannot read with a non-zero
+ * weight -- culled texels, texels outside their plane's box -- are not written: for a tile-culled model they were most of the copy. */
 int32_t vl3d_adam_window_tile(void);
 int vl3d_adam_window_catchup(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
                              float *param, float *exp_avg, float *exp_avg_sq, int32_t *last_step, const float *hist, int32_t upto,

@@ -19,13 +19,14 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("with_boxes", [False, True])
-def test_window_adam_equals_torch_adam_over_a_shuffled_window_schedule(dev, with_boxes):
+@pytest.mark.parametrize("with_boxes,lean", [(False, False), (True, False), (True, True), (False, True)])
+def test_window_adam_equals_torch_adam_over_a_shuffled_window_schedule(dev, with_boxes, lean):
     """the optimiser alone, on identical gradients: torch.optim.Adam sees the dense gradient (zero outside the step's window),
     WindowAdam the compact one; windows jump around, overlap, leave tiles untouched for many steps, the learning rate changes
     every step (train_3dvid.py:263-277), and one step has no window at all (dense fallback).  After flush(): equal to 2e-6.
     with_boxes: every plane has its own box inside the window (what a crop's parallax leaves of the union window for one plane): the
-    gradient is zero outside it, the leaf shows zeros there, and those texels' updates stay deferred like the rest of the plane."""
+    gradient is zero outside it, the leaf shows zeros there, and those texels' updates stay deferred like the rest of the plane.
+    lean: the window copy is a view of a persistent buffer and slots outside the boxes are not written (the default)."""
     from videoloop3d_amd.optim import WindowAdam, align_window, tile_side
     D, T, Hs, Ws = 3, 2, 75, 101
     g = torch.Generator().manual_seed(11)
@@ -33,7 +34,7 @@ def test_window_adam_equals_torch_adam_over_a_shuffled_window_schedule(dev, with
     pa = torch.nn.Parameter(p0.clone())
     pb = torch.nn.Parameter(p0.clone())
     oa = torch.optim.Adam([pa], lr=5e-3, betas=(0.9, 0.999), eps=6e-8)
-    ob = WindowAdam([pb], lr=5e-3, betas=(0.9, 0.999), eps=6e-8)
+    ob = WindowAdam([pb], lr=5e-3, betas=(0.9, 0.999), eps=6e-8, lean_window=lean)
     r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
     for step in range(40):
         lr = 5e-3 * 0.97 ** step
@@ -67,7 +68,10 @@ def test_window_adam_equals_torch_adam_over_a_shuffled_window_schedule(dev, with
         # the leaf holds the CURRENT parameters (what torch's Adam has there now), the stack itself is not written before the step
         cur = pa.detach()[:, :, wy:wy + wh, wx:wx + ww]
         assert float(((leaf.detach() - cur) * inside).abs().max()) <= 2e-6
-        assert float((leaf.detach() * ~inside).abs().max()) == 0
+        if ob.lean_window:      # slots outside a plane's box are left alone (finite leftovers of earlier windows in the persistent buffer)
+            assert bool(torch.isfinite(leaf.detach()).all())
+        else:
+            assert float((leaf.detach() * ~inside).abs().max()) == 0
         gc = (torch.rand((D, T, wh, ww, 4), generator=g) - 0.5).to(dev) * inside
         gc[:, :, :3] = 0                     # texels with a zero gradient inside the window as well
         leaf.grad = gc
@@ -170,7 +174,12 @@ def test_window_adam_with_quad_maps_stores_static_texels_once(dev):
     pa = torch.nn.Parameter(p0.clone().to(dev))
     pb = torch.nn.Parameter(p0.clone().to(dev))
     oa = torch.optim.Adam([pa], lr=5e-3, betas=(0.9, 0.999), eps=6e-8)
-    ob = WindowAdam([pb], lr=5e-3, betas=(0.9, 0.999), eps=6e-8, quad_keep=keep.to(dev), quad_dyn=dyn.to(dev), culled_alpha=tiles.CULLED_ALPHA)
+    ob = WindowAdam([pb], lr=5e-3, betas=(0.9, 0.999), eps=6e-8, quad_keep=keep.to(dev), quad_dyn=dyn.to(dev), culled_alpha=tiles.CULLED_ALPHA,
+                    lean_window=False)
+    # the default, lean window copy (a persistent buffer; culled texels are left alone) of a second optimiser over the same parameters:
+    # what the render can read must be identical, what it cannot must be finite
+    ol = WindowAdam([torch.nn.Parameter(p0.clone().to(dev))], lr=5e-3, betas=(0.9, 0.999), eps=6e-8, quad_keep=keep.to(dev), quad_dyn=dyn.to(dev),
+                    culled_alpha=tiles.CULLED_ALPHA)
     r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
     for step in range(25):
         for o in (oa, ob):
@@ -184,6 +193,12 @@ def test_window_adam_with_quad_maps_stores_static_texels_once(dev):
         assert torch.equal(leaf.detach()[:, 1][stt], leaf.detach()[:, 0][stt])                                      # static: one texture
         gc = (torch.rand((D, T, wh, ww, 4), generator=g) - 0.5).to(dev) * kt[:, None, :, :, None]                  # the culled render leaves 0 there
         leaf.grad = gc
+        ol.param_groups[0]["lr"] = 5e-3 * 0.97 ** step
+        lean = ol.window_leaf((wy, wx, wh, ww))
+        ktx = kt[:, None, :, :, None].expand(D, T, wh, ww, 4)
+        assert torch.equal(lean.detach()[ktx], leaf.detach()[ktx]) and bool(torch.isfinite(lean.detach()).all())
+        lean.grad = gc.clone()
+        ol.step()
         G = torch.zeros_like(pa)
         G[:, :, wy:wy + wh, wx:wx + ww] = gc
         pa.grad = tiles.tie_static_grad(G, keep.to(dev), dyn.to(dev))
@@ -193,6 +208,8 @@ def test_window_adam_with_quad_maps_stores_static_texels_once(dev):
     kept = keep_t[:, None, :, :, None].expand_as(pa).to(dev)
     assert float((pa.detach() - pb.detach())[kept].abs().max()) <= 2e-6
     assert torch.equal(pb.detach()[~kept], p0.to(dev)[~kept])                    # culled texels were never written
+    ol.flush()
+    assert torch.equal(ol.p.detach(), pb.detach())                                # lean and full window copies: the same training
 
 
 def test_culled_render_from_a_window_of_the_stack(dev):

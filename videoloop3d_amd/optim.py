@@ -34,7 +34,8 @@ def align_window(y0, y1, x0, x1, Hs, Ws):
 
 
 class WindowAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, quad_keep=None, quad_dyn=None, culled_alpha=-1e4, max_defer=32, layout=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, quad_keep=None, quad_dyn=None, culled_alpha=-1e4, max_defer=32, layout=None,
+                 lean_window=True):
         """quad_keep / quad_dyn [D,QH,QW] (a tile-culled model, videoloop3d_amd/tiles.py): culled texels are no parameters, a texel only
         static quads can read is ONE parameter stored in frame 0 of the stack (the reference's static atlas, MPV.py:235-288) -- the
         window copy shows it in every frame, the step sums its gradient over the frames and writes that one copy; flush() refreshes
@@ -58,6 +59,13 @@ class WindowAdam(torch.optim.Optimizer):
         # replay), so a crop window that comes back after a whole epoch of other crops replays at most max_defer steps per texel
         # instead of the epoch's length, twice.  0 = unbounded.
         self.max_defer = int(max_defer)
+        # lean window copies: the compact leaf is a view of ONE persistent buffer (zero-filled when it is allocated or grown, only ever
+        # written by the catch-up: finite everywhere), and the catch-up leaves alone what the render cannot read with a non-zero weight --
+        # culled texels (shown as (0, 0, 0, culled_alpha) otherwise) and texels outside their plane's box.  For a tile-culled model those
+        # are most of the window: 2.3 GB of stores per iteration at the reference's crop for the 16 % that are parameters.  The leaf of
+        # one forward is overwritten by the next window_leaf() call (one windowed forward per step is the contract anyway).
+        self.lean_window = bool(lean_window)
+        self._compact_buf = None
 
     # ---- state ----------------------------------------------------------------------------------------------------------
     def dims(self):
@@ -90,7 +98,7 @@ class WindowAdam(torch.optim.Optimizer):
         qk, qd = self.quad_keep, self.quad_dyn
         return L.ptr(qk), L.ptr(qd), (0 if qk is None else qk.shape[1]), (0 if qk is None else qk.shape[2])
 
-    def _catchup(self, window, upto, compact, mirror=False, boxes=None):
+    def _catchup(self, window, upto, compact, mirror=False, boxes=None, lean=False):
         st, p = self._st(), self.p
         D, T, Hs, Ws = self.dims()
         y0, x0, wh, ww = window
@@ -100,7 +108,8 @@ class WindowAdam(torch.optim.Optimizer):
             L.check(L.lib().vl3d_adam_window_catchup_boxes(D, T, Hs, Ws, y0, x0, wh, ww, L.ptr(p), L.ptr(st["exp_avg"]),
                                                            L.ptr(st["exp_avg_sq"]), L.ptr(st["last_step"]), L.ptr(st["hist"]), int(upto),
                                                            float(b1), float(b2), float(self.param_groups[0]["eps"]), L.ptr(compact), qk, qd,
-                                                           QH, QW, self.culled_alpha, 1 if mirror else 0, None if boxes is None else boxes.ctypes.data,
+                                                           QH, QW, self.culled_alpha, (1 if mirror else 0) | (2 if lean else 0),
+                                                           None if boxes is None else boxes.ctypes.data,
                                                            self._blocks(), L.stream_ptr(p.device)),
                     "vl3d_adam_window_catchup")
 
@@ -118,8 +127,15 @@ class WindowAdam(torch.optim.Optimizer):
         if plane_boxes is not None:                       # stays on the HOST (numpy int32 [D,4]): the table travels in the kernel arguments
             import numpy as np
             plane_boxes = np.ascontiguousarray(np.asarray(plane_boxes, dtype=np.int32).reshape(D, 4))
-        compact = torch.empty((D, T, wh, ww, 4), dtype=p.dtype, device=p.device)
-        self._catchup(window, self.t, compact, boxes=plane_boxes)
+        if self.lean_window:
+            n = D * T * wh * ww * 4
+            if self._compact_buf is None or self._compact_buf.numel() < n or self._compact_buf.device != p.device:
+                self._compact_buf = None                                       # (release before growing)
+                self._compact_buf = torch.zeros(n, dtype=p.dtype, device=p.device)
+            compact = self._compact_buf[:n].view(D, T, wh, ww, 4)
+        else:
+            compact = torch.empty((D, T, wh, ww, 4), dtype=p.dtype, device=p.device)
+        self._catchup(window, self.t, compact, boxes=plane_boxes, lean=self.lean_window)
         compact.requires_grad_(True)
         if self.pending is not None:
             self.pending = "multiple"
