@@ -239,6 +239,15 @@ def test_culled_render_from_a_window_of_the_stack(dev):
     assert float(((out_w[2] - out_f[2]).abs() / out_f[2].abs().clamp_min(1.0)).max()) <= 1e-5
     assert float((g_w - g_f[:, :, y0:y0 + wh, x0:x0 + ww]).abs().max()) <= 1e-5 * max(1.0, float(g_f.abs().max()))
     assert float(out_f[0].abs().max()) > 0.01
+    # VL3D_GRAD_CULLED_UNWRITTEN (what the window path of a sparsified model asks for): texels no kept quad can read are left undefined,
+    # every texel that is a parameter gets the same gradient bit for bit
+    from videoloop3d_amd import tiles
+    win2 = win.detach().clone().requires_grad_(True)
+    out_u = render_planes_with_regularisers(win2, homos, H, W, dataclasses.replace(spec, offset=(-float(x0), -float(y0))), quad_keep=keep,
+                                            cull_window=(y0, x0, Hs, Ws), grad_culled_unwritten=True)
+    (g_u,) = torch.autograd.grad(obj(out_u), win2)
+    kt = tiles.quad_to_texel_mask(keep.cpu(), Hs, Ws)[:, y0:y0 + wh, x0:x0 + ww].to(dev)[:, None, :, :, None].expand_as(g_w)
+    assert torch.equal(g_u[kt], g_w[kt]) and float(g_w[~kt].abs().max()) == 0.0
 
 
 def test_sparsified_model_trains_through_the_window_path(dev):

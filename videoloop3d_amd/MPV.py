@@ -521,12 +521,15 @@ class MPMeshVid(nn.Module):
             rgb, alpha = render_atlas_exact(stack, homos, H, W, self.atlas_grid_h, pixel_center=self.spec.pixel_center,
                                             rgb_act=self.spec.rgb_act, alpha_act=self.spec.alpha_act)
         elif need_smooth:
+            # (the window leaf's gradient goes to WindowAdam, which never reads culled texels: the backward need not zero-fill them)
             rgb, alpha, smooth_sums, alpha_sums = render_planes_with_regularisers(stack, homos, H, W, spec,
                                                                                   quad_keep=self.quad_keep if self.is_sparse else None,
-                                                                                  cull_window=cull_window)
+                                                                                  cull_window=cull_window,
+                                                                                  grad_culled_unwritten=cull_window is not None)
         else:
             # a sparsified model renders with tile culling: samples in culled quads are uncovered, workgroups skip planes without kept quads
-            rgb, alpha = render_planes(stack, homos, H, W, spec, quad_keep=self.quad_keep if self.is_sparse else None, cull_window=cull_window)
+            rgb, alpha = render_planes(stack, homos, H, W, spec, quad_keep=self.quad_keep if self.is_sparse else None, cull_window=cull_window,
+                                       grad_culled_unwritten=cull_window is not None)
         variables = {"pix_to_face": None, "blend_weight": None, "mpi": None, "disp_norm": None, "alpha": alpha,
                      "smooth_sums": smooth_sums, "alpha_sums": alpha_sums}
         if need_layers:

@@ -326,6 +326,7 @@ static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, cons
     a.quad_keep = quad_keep; a.QH = QH; a.QW = QW;
     set_cull_geometry(a, desc, QH, QW);
     a.g_f16 = desc->stack_dtype == VL3D_F16;
+    a.grad_culled_unwritten = (quad_keep && (desc->grad_flags & VL3D_GRAD_CULLED_UNWRITTEN)) ? 1 : 0;
     // variant: 0 auto (tile kernel when its on-device plan says feasible, else atomics), 1 force atomics,
     //          3 tile kernel (16-row regions, one frame per thread), 4 = 3 without the 2x2 gather   (2, the 8-row regions of round 1,
     //          measured 18.9 vs 16.8 ms and is no longer built: it selects 3)

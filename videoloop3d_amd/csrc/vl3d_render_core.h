@@ -82,6 +82,7 @@ struct RenderArgs {
     float *label;            // (T,H,W)
     const float *g_label;    // (T,H,W)
     float *g_mask;           // (D,T,Hs,Ws), overwritten
+    int grad_culled_unwritten;   // desc->grad_flags bit 0: texels owned on a plane the workgroup skips (all of them culled) are not zero-filled
 };
 
 // one entry point per compiled convention (coord_mode, border_mode, act_order): vl3d_render_c*.hip
@@ -1234,6 +1235,9 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || MASK || (CULL && COORD == VL3D_C
         if (CULL && culled) {
             // tile culling: no pixel of the region sees a kept quad of this plane -- its alpha is exactly 0 for all of them, the
             // composite state does not move, and the texels this tile owns get a zero gradient (written: nothing memsets it)
+            // (... unless the caller never reads the gradient of culled texels -- every texel this tile owns on this plane is one: the box
+            // test of bwd_windows_k is two texels wider than the region's footprint, a texel's class looks one texel around it)
+            if (a.grad_culled_unwritten) continue;
             const f4 z = f4{0.f, 0.f, 0.f, 0.f};
             if (row < wh && lane < ww && (e0 >> 10) == my_tile)
                 store_grad_texel<F16>(gplane, (win0 + toff_thread) << 4, z);

@@ -33,7 +33,7 @@ class RenderSpec:
                           act_order="post", rgb_act=rgb_act, alpha_act=alpha_act, variant=variant)
 
 
-def _desc(stack, H, W, spec, row0, col0, cull_window=None):
+def _desc(stack, H, W, spec, row0, col0, cull_window=None, grad_flags=0):
     D, T, Hs, Ws, C4 = stack.shape
     assert C4 == 4, "plane stack must be (D,T,Hs,Ws,4)"
     d = L.RenderDesc()
@@ -50,6 +50,7 @@ def _desc(stack, H, W, spec, row0, col0, cull_window=None):
     d.variant = int(spec.variant)
     if cull_window is not None:        # the stack is the texel window (y0, x0) of a (Hs_plane, Ws_plane) plane the quad grid lies over
         d.cull_row0, d.cull_col0, d.cull_Hs, d.cull_Ws = (int(v) for v in cull_window)
+    d.grad_flags = int(grad_flags)
     return d
 
 
@@ -60,7 +61,7 @@ LAST_BWD_SCRATCH = None
 
 class _RenderPlanes(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, stack, homos, H, W, spec, row0, col0, with_reg, quad_keep=None, cull_window=None):
+    def forward(ctx, stack, homos, H, W, spec, row0, col0, with_reg, quad_keep=None, cull_window=None, grad_culled_unwritten=False):
         L.check_cuda(stack, homos)
         if quad_keep is not None:
             L.check_cuda(quad_keep)
@@ -89,7 +90,8 @@ class _RenderPlanes(torch.autograd.Function):
             z = torch.zeros
             return (rgb, alpha, z(4, dtype=torch.float32, device=stack.device),
                     z((T, H, W, 2) if with_reg else (0,), dtype=torch.float32, device=stack.device))
-        desc = _desc(stack, H, W, spec, row0, col0, cull_window if quad_keep is not None else None)
+        desc = _desc(stack, H, W, spec, row0, col0, cull_window if quad_keep is not None else None,
+                     grad_flags=1 if (grad_culled_unwritten and quad_keep is not None) else 0)
         asum = torch.empty((T, H, W, 2), dtype=torch.float32, device=stack.device) if with_reg else None
         sums = torch.zeros(4, dtype=torch.float64, device=stack.device)
         reg_state = None
@@ -133,7 +135,7 @@ class _RenderPlanes(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_alpha, g_sums, g_asum):
         if ctx.nothing_to_render:
-            return (torch.zeros_like(ctx.saved_tensors[0]),) + (None,) * 9
+            return (torch.zeros_like(ctx.saved_tensors[0]),) + (None,) * 10
         stack, homos, rgb, alpha = ctx.saved_tensors
         g_reg = g_sums.to(torch.float32).contiguous() if (ctx.with_reg and g_sums is not None) else None
         g_asum = g_asum.to(torch.float32).contiguous() if (ctx.with_reg and g_asum is not None) else None
@@ -157,7 +159,7 @@ class _RenderPlanes(torch.autograd.Function):
                         "vl3d_render_bwd_culled")
         global LAST_BWD_SCRATCH
         LAST_BWD_SCRATCH = scratch
-        return g_stack, None, None, None, None, None, None, None, None, None
+        return g_stack, None, None, None, None, None, None, None, None, None, None
 
 
 def mask_channel_supported(stack, spec):
@@ -228,7 +230,7 @@ def render_planes_with_mask(stack, mask, homos, H, W, spec: RenderSpec = RenderS
     return _RenderPlanesMask.apply(stack, mask, homos, int(H), int(W), spec, bool(with_regularisers))
 
 
-def render_planes(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0), quad_keep=None, cull_window=None):
+def render_planes(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0), quad_keep=None, cull_window=None, grad_culled_unwritten=False):
     """stack (D,T,Hs,Ws,4) pre-activation fp32 (plane 0 = nearest), homos [D,3,3] (target pixel -> plane pixel).
 
     Returns rgb [T,H,W,3], alpha [T,H,W].  `window=(row0,col0)` renders the H x W sub-window whose top-left
@@ -237,8 +239,11 @@ def render_planes(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0
     `quad_keep` [D,QH,QW] (bool/uint8, optional): tile culling map (videoloop3d_amd.tiles): a sample that falls into a culled quad
     of a plane is not covered by it, and workgroups skip the planes of which they see no kept quad (include/vl3d.h).
     `cull_window` (y0, x0, Hs_plane, Ws_plane), with quad_keep: `stack` is the texel window at (y0, x0) of a plane of that size and the
-    quad grid lies over the whole plane (crop-aware training renders from a compact copy of the window, optim.WindowAdam)."""
-    rgb, alpha, _, _ = _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), False, quad_keep, cull_window)
+    quad grid lies over the whole plane (crop-aware training renders from a compact copy of the window, optim.WindowAdam).
+    `grad_culled_unwritten` (with quad_keep): the consumer of the stack gradient never reads texels no kept quad can read (WindowAdam / TileAdam
+    skip them), so the backward leaves those slots UNDEFINED instead of zero-filling them (VL3D_GRAD_CULLED_UNWRITTEN, include/vl3d.h)."""
+    rgb, alpha, _, _ = _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), False, quad_keep, cull_window,
+                                           bool(grad_culled_unwritten))
     return rgb, alpha
 
 
@@ -250,7 +255,9 @@ def render_planes_with_smoothness(stack, homos, H, W, spec: RenderSpec = RenderS
     return rgb, alpha, sums
 
 
-def render_planes_with_regularisers(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0), quad_keep=None, cull_window=None):
+def render_planes_with_regularisers(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0), quad_keep=None, cull_window=None,
+                                    grad_culled_unwritten=False):
     """(rgb, alpha, smooth_sums[4], alpha_sums[T,H,W,2]): render_planes_with_smoothness plus the per-pixel (sum_k a_k,
     sum_k a_k^2) the sparsity regulariser |a|_1/|a|_2 (MPV.py:511-515, MPI.py:599-603) is built from; all differentiable."""
-    return _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), True, quad_keep, cull_window)
+    return _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), True, quad_keep, cull_window,
+                               bool(grad_culled_unwritten))
