@@ -222,6 +222,57 @@ def test_render_feature_fuzz(dev, seed):
 
 
 @pytest.mark.parametrize("seed", list(range(12 + _EXTRA)))
+def test_loop_mask_channel_fuzz(dev, seed):
+    """stage 1's loop mask as a fifth channel (vl3d_render_fwd_mask / _bwd_mask) on random multi-tile shapes, plane counts, magnifications and
+    rotations (large ones leave the owner-computes kernel's preconditions: atomics fallback), with and without the layer regularisers,
+    both backward kernels -- against the oracle: the label is the red channel of a render of the stack (mask logit, 0, 0, alpha logit
+    DETACHED) (MPI.py:568-583), colours / sums / stack gradient are those of the render without the mask."""
+    from videoloop3d_amd.render import RenderSpec, render_planes_with_mask
+    g = torch.Generator().manual_seed(9100 + seed)
+    r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    u = lambda lo, hi: float(torch.rand(1, generator=g)) * (hi - lo) + lo
+    D, T = r(1, 9), r(1, 2)
+    H, W = r(1, 140), r(1, 230)
+    mag = u(1.0, 1.3)
+    Hs, Ws = max(2, int(H * mag) + r(0, 6)), max(2, int(W * mag) + r(0, 6))
+    th = math.radians(u(-3, 3) if seed % 4 else u(20, 40))
+    base = torch.tensor([[math.cos(th) * mag, -math.sin(th) * mag, u(-2, 2)], [math.sin(th) * mag, math.cos(th) * mag, u(-2, 2)],
+                         [u(-5e-5, 5e-5), u(-5e-5, 5e-5), 1.0]])
+    homos = torch.stack([base + torch.tensor([[0, 0, 1.3 * d], [0, 0, -0.6 * d], [0, 0, 0.0]]) for d in range(D)])
+    kw = dict(pixel_center=0.5, coord_mode="affine", border="hardcut", act_order="post")
+    with_reg = seed % 2 == 1
+    variant = 1 if seed % 5 == 4 else 0
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=500 + seed)
+    mask = synth.hash_uniform((D, T, Hs, Ws), seed=600 + seed) * 4 - 2
+    g_rgb = synth.hash_uniform((T, H, W, 3), seed=5) - 0.5
+    g_lab = synth.hash_uniform((T, H, W), seed=7) - 0.5
+    wts = torch.tensor([1e-3, 2e-3, 3e-3, 4e-3]) * (1.0 if with_reg else 0.0)
+    s_cpu, m_cpu = stack.clone().requires_grad_(True), mask.clone().requires_grad_(True)
+    rgb_o, alpha_o, _, layers = MO.render_planes(s_cpu, homos, H, W, MO.RenderSpec(**kw), return_layers=True)
+    lab_stack = torch.stack([m_cpu, torch.zeros_like(m_cpu), torch.zeros_like(m_cpu), s_cpu.detach()[..., 3]], -1)
+    lab_o = MO.render_planes(lab_stack, homos, H, W, MO.RenderSpec(**kw))[0][..., 0]
+    dx = lambda c: (layers[:, :, 1:, :, c] - layers[:, :, :-1, :, c]).abs().sum()
+    dy = lambda c: (layers[:, 1:, :, :, c] - layers[:, :-1, :, :, c]).abs().sum()
+    sums_o = torch.stack([dx(slice(0, 3)), dy(slice(0, 3)), dx(3), dy(3)])
+    gs_o, gm_o = torch.autograd.grad((rgb_o * g_rgb).sum() + (lab_o * g_lab).sum() + (sums_o * wts).sum(), [s_cpu, m_cpu])
+    s_gpu, m_gpu = stack.to(dev).requires_grad_(True), mask.to(dev).requires_grad_(True)
+    rgb, alpha, lab, sums, asum = render_planes_with_mask(s_gpu, m_gpu, homos.to(dev), H, W, RenderSpec(variant=variant, **kw), with_regularisers=with_reg)
+    obj = (rgb * g_rgb.to(dev)).sum() + (lab * g_lab.to(dev)).sum() + ((sums * wts.to(dev)).sum() if with_reg else 0.0)
+    gs, gm = torch.autograd.grad(obj, [s_gpu, m_gpu])
+    assert float((rgb.detach().cpu() - rgb_o.detach()).abs().max()) <= TOL and float((alpha.detach().cpu() - alpha_o.detach()).abs().max()) <= TOL
+    assert float((lab.detach().cpu() - lab_o.detach()).abs().max()) <= TOL
+    if with_reg:
+        assert float(((sums.detach().cpu() - sums_o).abs() / sums_o.abs().clamp_min(1.0)).max()) <= 1e-4
+    assert float((gm.cpu() - gm_o).abs().max()) <= TOL * max(1.0, float(gm_o.abs().max()))
+    d = (gs.cpu() - gs_o).abs()
+    tol = TOL * max(1.0, float(gs_o.abs().max()))
+    if with_reg:
+        assert float(d.max()) <= 2.0 * float(wts.max()) + tol and int((d > tol).sum()) <= 64      # (sign kinks: see test_render_feature_fuzz)
+    else:
+        assert float(d.max()) <= tol
+
+
+@pytest.mark.parametrize("seed", list(range(12 + _EXTRA)))
 def test_fp16_stack_fuzz_equals_fp32_kernels_on_rounded_values(dev, seed):
     """fp16 plane stacks (cfg5's storage format: packed taps, one 16-byte load per tap row, v_fma_mix blend, fp16 gradient
     stores) against the fp32 kernels on the same values rounded to fp16: fp32 arithmetic either way -> identical images and a
