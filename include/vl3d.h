@@ -78,7 +78,8 @@ typedef struct vl3d_render_desc {
     /* vl3d_render_bwd_culled only.  Bit 0 (VL3D_GRAD_CULLED_UNWRITTEN): the caller never reads the gradient of texels no kept quad can
      * read (vl3d_adam_window_step / vl3d_adam_step_tiles skip them: they are no parameters), so the texels a workgroup owns on a plane it
      * skips are not written at all instead of being zero-filled -- on a 16 %-kept model that fill was a quarter of the backward's time.
-     * Those slots of grad_stack are then UNDEFINED.  0 = every texel of grad_stack is written (a gradient any consumer may read). */
+     * Those slots of grad_stack are then UNDEFINED.  0 = every texel of grad_stack is written (a gradient any consumer may read).
+     * A permission, not a promise: instantiations without the layer regularisers still write the zeros. */
     int32_t grad_flags;
 } vl3d_render_desc;
 enum { VL3D_GRAD_CULLED_UNWRITTEN = 1 };
@@ -359,6 +360,19 @@ int vl3d_vote_fold_robust_strided(const vl3d_loss_desc *desc, const float *y, co
 /* x[0..n) *= *scale with `scale` a DEVICE scalar (no host sync); no memory traffic at all when it is exactly 1 -- the backward of the fused
  * looping loss: its gradient buffer exists since the forward and the upstream gradient of a loss differentiated directly is 1.  n % 4 == 0. */
 int vl3d_scale_inplace(int64_t n, float *x, const float *scale, vl3d_stream_t stream);
+
+/* The loss prologue of MPMeshVid.forward (MPV.py:484-507), from the render's NHWC output to the loss's video in three launches:
+ *   rgb_pad = cat(rgb, rgb[:pad])                                       loop padding (MPV.py:490-492)
+ *   scale   = (exp(mean(log((mean_f res + 0.01) / (mean_t rgb + 0.01)))) + 3) / 4     scale-invariant gain (MPV.py:499-504; rgb detached)
+ *   x       = rgb_pad * scale,  handed to the loss as [1,3,T+pad,h,w]
+ * vl3d_loop_gain: rgb (T,h,w,3), res (F,3,h,w) -> *log_sum (device double, zeroed by the call) = the sum of the 3 h w log ratios.
+ * vl3d_loop_pad_fwd: x (3,T+pad,h,w) = gain * rgb with the first `pad` frames repeated at the end; log_sum == NULL: gain 1.
+ * vl3d_loop_pad_bwd: grad_rgb (T,h,w,3) = gain * (grad_x[:, t] + grad_x[:, T + t] for t < pad); grad_x (3,T+pad,h,w) with channel /
+ * frame strides gx_sc / gx_st in floats (unit column stride, rows contiguous). */
+int vl3d_loop_gain(int32_t T, int32_t F, int32_t h, int32_t w, const float *rgb, const float *res, double *log_sum, vl3d_stream_t stream);
+int vl3d_loop_pad_fwd(int32_t T, int32_t pad, int32_t h, int32_t w, const float *rgb, const double *log_sum, float *x, vl3d_stream_t stream);
+int vl3d_loop_pad_bwd(int32_t T, int32_t pad, int32_t h, int32_t w, const float *grad_x, int64_t gx_sc, int64_t gx_st, const double *log_sum,
+                      float *grad_rgb, vl3d_stream_t stream);
 
 /* robust_lossfun (utils_vid.py:10-26) fused with the mean (utils_vid.py:348).
  * kind: 0 'mse', 1 'abs', 2 general Barron with float rou (rou==0 and rou==2 special-cased as the reference).

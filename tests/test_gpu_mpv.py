@@ -237,6 +237,34 @@ def test_mpmesh_forward_train_matches_oracle(dev, loop_mask):
         assert float(go.abs().max()) > 0
 
 
+@pytest.mark.parametrize("gain", [True, False])
+def test_loss_prologue_equals_the_torch_chain(dev, gain):
+    """MPV.py:484-507 (loop padding, scale-invariant gain, layout) as three kernels against the same lines in torch, value and gradient."""
+    from videoloop3d_amd.MPV import _LoopPrologue
+    T, F, h, w, pad = 7, 9, 37, 53, 2
+    rgb = synth.hash_uniform((T, h, w, 3), seed=3).to(dev).requires_grad_(True)
+    res = synth.hash_uniform((F, 3, h, w), seed=4).to(dev)
+    x = _LoopPrologue.apply(rgb, res if gain else None, pad)
+    r = rgb.detach().clone().requires_grad_(True)
+    rp = r.permute(0, 3, 1, 2)
+    rp_pad = torch.cat([rp, rp[:pad]], 0)
+    if gain:
+        scale = torch.exp(torch.log((res.mean(dim=0) + 0.01) / (rp.detach().mean(dim=0) + 0.01)).mean())
+        rp_pad = rp_pad * ((scale + 3) / 4)
+    x_t = rp_pad.permute(1, 0, 2, 3)[None]
+    assert x.shape == x_t.shape and float((x - x_t).abs().max()) <= 2e-6
+    g = synth.hash_uniform(tuple(x.shape), seed=5).to(dev) - 0.5
+    (ga,) = torch.autograd.grad((x * g).sum(), rgb, retain_graph=True)
+    (gb,) = torch.autograd.grad((x_t * g).sum(), r)
+    assert ga.is_contiguous() and float((ga - gb).abs().max()) <= 2e-6
+    # a strided upstream gradient (the loss trims to the patch grid and writes through strides)
+    big = torch.zeros((1, 3, T + pad + 1, h, w + 3), device=dev)
+    gv = big[:, :, :T + pad, :, :w]
+    gv.copy_(g)
+    (gc,) = torch.autograd.grad(x, rgb, gv)
+    assert torch.equal(gc, ga)
+
+
 def test_loop_mask_fifth_channel_equals_the_label_pass(dev):
     """The loop mask composited as a fifth channel of the colour pass (vl3d_render_fwd_mask / _bwd_mask) against the separate label pass
     (a second render of a (mask logit, -, -, alpha logit) stack): label, gradient to the mask texture, and colours / regulariser terms /

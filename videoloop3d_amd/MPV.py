@@ -46,6 +46,63 @@ def sparsity_ratio(alpha_sums, eps):
     return n1 / n2.clamp_min(eps)
 
 
+class _LoopPrologue(torch.autograd.Function):
+    """MPV.py:484-507 between the render and the loss in three launches (csrc/vl3d_loss.hip `loop_*_k`): loop padding
+    `cat(rgb, rgb[:pad])`, the scale-invariant gain `(exp(mean(log((mean_f res + .01) / (mean_t rgb.detach() + .01)))) + 3) / 4` and the
+    layout the loss takes, [1,3,T+pad,h,w]; the backward folds the pad frames' gradient back and writes the NHWC gradient the render's
+    backward reads.  rgb [T,h,w,3] contiguous float32 CUDA; res [F,3,h,w] or None (no gain)."""
+
+    @staticmethod
+    def forward(ctx, rgb, res, pad):
+        from . import _lib as L
+        L.check_cuda(rgb)
+        T, h, w, _ = rgb.shape
+        rgb = rgb.contiguous()
+        dev = rgb.device
+        log_sum = None
+        with torch.cuda.device(dev):
+            if res is not None:
+                L.check_cuda(res)
+                if res.dim() != 4 or res.shape[1:] != (3, h, w):
+                    raise RuntimeError(f"scale-invariant gain: res must be [F,3,{h},{w}], got {tuple(res.shape)}")
+                res = res.detach().to(torch.float32).contiguous()
+                log_sum = torch.empty(1, dtype=torch.float64, device=dev)
+                L.check(L.lib().vl3d_loop_gain(T, res.shape[0], h, w, L.ptr(rgb), L.ptr(res), L.ptr(log_sum), L.stream_ptr(dev)), "vl3d_loop_gain")
+            x = torch.empty((1, 3, T + pad, h, w), dtype=torch.float32, device=dev)
+            L.check(L.lib().vl3d_loop_pad_fwd(T, pad, h, w, L.ptr(rgb), L.ptr(log_sum), L.ptr(x), L.stream_ptr(dev)), "vl3d_loop_pad_fwd")
+        ctx.log_sum, ctx.dims = log_sum, (T, pad, h, w)
+        return x
+
+    @staticmethod
+    def backward(ctx, gx):
+        from . import _lib as L
+        T, pad, h, w = ctx.dims
+        gx = gx[0]
+        if gx.stride(3) != 1 or gx.stride(2) != w:
+            gx = gx.contiguous()
+        dev = gx.device
+        g_rgb = torch.empty((T, h, w, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.check(L.lib().vl3d_loop_pad_bwd(T, pad, h, w, L.ptr(gx), gx.stride(0), gx.stride(1), L.ptr(ctx.log_sum), L.ptr(g_rgb),
+                                              L.stream_ptr(dev)), "vl3d_loop_pad_bwd")
+        return g_rgb, None, None
+
+
+class _SmoothTerms(torch.autograd.Function):
+    """rgb_smooth / a_smooth from the four fused sums (MPV.py:517-531): (c0 s0 + c1 s1, c2 s2 + c3 s3) in two launches each way instead of
+    ~16 scalar kernels.  coef: device float32 [4]."""
+
+    @staticmethod
+    def forward(ctx, sums, coef):
+        ctx.save_for_backward(coef)
+        return (sums * coef).view(2, 2).sum(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (coef,) = ctx.saved_tensors
+        return g.repeat_interleave(2) * coef, None
+
+
 def atlas_to_stack(atlas_dyn, mpi_d, grid_h):
     """(T,4,Ah,Aw) atlas of grid_h x grid_w plane cells (MPV.py:37-44,75-81: plane p <-> cell (p // grid_w, p % grid_w))
     -> (D,T,mpi_h,mpi_w,4) stack."""
@@ -610,26 +667,32 @@ class MPMeshVid(nn.Module):
         need_layers = self.training and getattr(a, "d_smooth_loss_weight", 0) > 0      # the one term that reads materialised layers (slow path)
         need_smooth = self.training and (a.rgb_smooth_loss_weight > 0 or a.a_smooth_loss_weight > 0 or a.sparsity_loss_weight > 0)
         rgb, variables = self.render(h, w, extrins, tar_intrins, ts, need_layers=need_layers, need_smooth=need_smooth)
+        rgb_nhwc = rgb
         rgb = rgb.permute(0, 3, 1, 2)
         extra = {}
         if not self.training:
             return rgb, {}
         assert res is not None
-        rgb_pad = rgb
-        if self.isloop:
-            pad_frame = self.swd_patcht_size - 1
-            rgb_pad = torch.cat([rgb, rgb[:pad_frame]], 0)
         losscfg = {k: v[0].item() if torch.is_tensor(v) else v[0] for k, v in losscfg.items()}   # un-collate (MPV.py:494)
         loss_name = losscfg.pop('loss_name')
         loss_gain = losscfg.pop('loss_gain', 1.)
         loss = self.losses[loss_name]
-        if a.scale_invariant and self.training:
-            res_avg = res[0].mean(dim=0)
-            rgb_avg = rgb.detach().mean(dim=0)
-            scale = torch.exp(torch.log((res_avg + 0.01) / (rgb_avg + 0.01)).mean())
-            scale = (scale + 3) / 4
-            rgb_pad = rgb_pad * scale
-        main_loss = loss(rgb_pad.permute(1, 0, 2, 3)[None], res.permute(0, 2, 1, 3, 4), **losscfg)
+        pad_frame = self.swd_patcht_size - 1 if self.isloop else 0
+        if rgb_nhwc.is_cuda and rgb_nhwc.dtype == torch.float32 and pad_frame <= rgb_nhwc.shape[0] and not getattr(a, "unfused_prologue", False):
+            # loop padding + scale-invariant gain + the loss's layout (and their backward) in three launches
+            x = _LoopPrologue.apply(rgb_nhwc, res[0] if a.scale_invariant else None, pad_frame)
+        else:
+            rgb_pad = rgb
+            if self.isloop:
+                rgb_pad = torch.cat([rgb, rgb[:pad_frame]], 0)
+            if a.scale_invariant and self.training:
+                res_avg = res[0].mean(dim=0)
+                rgb_avg = rgb.detach().mean(dim=0)
+                scale = torch.exp(torch.log((res_avg + 0.01) / (rgb_avg + 0.01)).mean())
+                scale = (scale + 3) / 4
+                rgb_pad = rgb_pad * scale
+            x = rgb_pad.permute(1, 0, 2, 3)[None]
+        main_loss = loss(x, res.permute(0, 2, 1, 3, 4), **losscfg)
         extra['swd'] = main_loss.reshape(1, -1) * loss_gain
 
         if a.sparsity_loss_weight > 0:
@@ -641,10 +704,22 @@ class MPMeshVid(nn.Module):
             nx, ny = T_ * h * (w - 1) * K_, T_ * (h - 1) * w * K_
             sums = variables["smooth_sums"]
             denorm = K_ / self.mpi_d
-            if a.rgb_smooth_loss_weight > 0:
-                extra["rgb_smooth"] = ((sums[0] / (3 * nx) + sums[1] / (3 * ny)) * (loss_gain * denorm)).reshape(1, -1)
-            if a.a_smooth_loss_weight > 0:
-                extra["a_smooth"] = ((sums[2] / nx + sums[3] / ny) * (loss_gain * denorm)).reshape(1, -1)
+            if sums.is_cuda and min(nx, ny) > 0:
+                gd = float(loss_gain) * denorm
+                key = (nx, ny, gd, str(sums.device))
+                if getattr(self, "_smooth_coef_key", None) != key:
+                    self._smooth_coef_key = key
+                    self._smooth_coef = torch.tensor([gd / (3 * nx), gd / (3 * ny), gd / nx, gd / ny], dtype=torch.float32, device=sums.device)
+                terms = _SmoothTerms.apply(sums, self._smooth_coef)
+                if a.rgb_smooth_loss_weight > 0:
+                    extra["rgb_smooth"] = terms[0:1].view(1, 1)
+                if a.a_smooth_loss_weight > 0:
+                    extra["a_smooth"] = terms[1:2].view(1, 1)
+            else:
+                if a.rgb_smooth_loss_weight > 0:
+                    extra["rgb_smooth"] = ((sums[0] / (3 * nx) + sums[1] / (3 * ny)) * (loss_gain * denorm)).reshape(1, -1)
+                if a.a_smooth_loss_weight > 0:
+                    extra["a_smooth"] = ((sums[2] / nx + sums[3] / ny) * (loss_gain * denorm)).reshape(1, -1)
         if a.density_loss_weight > 0:
             extra["density"] = (variables["alpha"] - 1).abs().mean().reshape(1, -1)
         if getattr(a, "d_smooth_loss_weight", 0) > 0:                                             # MPV.py:539-551 (off in every shipped configuration)

@@ -86,6 +86,9 @@ SIGNATURES = {
     "vl3d_vote_fold_robust_strided": ([C.POINTER(LossDesc), _P, _P, _P, _I32, C.c_float, C.c_float, _P, _P, _P, C.c_int64, C.c_int64,
                                        C.c_int64, _P, _P], C.c_int),
     "vl3d_scale_inplace": ([_I64, _P, _P, _P], C.c_int),
+    "vl3d_loop_gain": ([_I32] * 4 + [_P, _P, _P, _P], C.c_int),
+    "vl3d_loop_pad_fwd": ([_I32] * 4 + [_P, _P, _P, _P], C.c_int),
+    "vl3d_loop_pad_bwd": ([_I32] * 4 + [_P, _I64, _I64, _P, _P, _P], C.c_int),
     "vl3d_robust_fwd": ([_I64, _P, _P, _I32, _F, _F, _P, _P], C.c_int),
     "vl3d_robust_bwd": ([_I64, _P, _P, _I32, _F, _F, _P, _F, _P, _P], C.c_int),
 }

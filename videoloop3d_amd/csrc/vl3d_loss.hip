@@ -1487,6 +1487,100 @@ extern "C" int vl3d_scale_inplace(int64_t n, float *x, const float *scale, vl3d_
     return VL3D_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The loss prologue of MPMeshVid.forward (MPV.py:484-507): NHWC render -> loop-padded, scale-invariant-gained video for the loss.
+//   rgb_pad = cat(rgb, rgb[:pad]);  scale = (exp(mean(log((mean_f res + .01) / (mean_t rgb.detach() + .01)))) + 3) / 4;  x = rgb_pad * scale
+// was cat + mul (two copies of the padded clip), two frame means, five scalar kernels, and in the backward mul, two slices, an add and the
+// NCHW -> NHWC copy the render backward needs -- ~20 launches around kernels that take 0.1-0.2 ms at the training crop.  Here: one kernel
+// for the log-ratio sum, one that writes x [3,T+pad,h,w] from rgb [T,h,w,3], one that folds the pad frames' gradient back into
+// g_rgb [T,h,w,3] (the gain has no gradient: the reference detaches rgb in it).
+__global__ __launch_bounds__(256) void loop_gain_k(int T, int F, int64_t hw, const float *__restrict__ rgb, const float *__restrict__ res,
+                                                   double *__restrict__ log_sum) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float v = 0.f;
+    if (p < hw) {
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f, y0 = 0.f, y1 = 0.f, y2 = 0.f;
+        const float *rp = rgb + p * 3;
+#pragma unroll 4
+        for (int t = 0; t < T; ++t, rp += hw * 3) { r0 += rp[0]; r1 += rp[1]; r2 += rp[2]; }
+        const float *yp = res + p;
+#pragma unroll 4
+        for (int f = 0; f < F; ++f, yp += hw * 3) { y0 += yp[0]; y1 += yp[hw]; y2 += yp[2 * hw]; }
+        const float it = 1.0f / (float)T, jf = 1.0f / (float)F;
+        v = __logf((y0 * jf + 0.01f) / (r0 * it + 0.01f)) + __logf((y1 * jf + 0.01f) / (r1 * it + 0.01f)) + __logf((y2 * jf + 0.01f) / (r2 * it + 0.01f));
+    }
+    __shared__ float red[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(log_sum, (double)((red[0] + red[1]) + (red[2] + red[3])));
+}
+
+__device__ __forceinline__ float loop_gain(const double *log_sum, int64_t hw) {
+    if (!log_sum) return 1.0f;
+    return (__expf((float)(*log_sum / (double)(3 * hw))) + 3.0f) * 0.25f;
+}
+
+__global__ __launch_bounds__(256) void loop_pad_fwd_k(int T, int pad, int64_t hw, const float *__restrict__ rgb, const double *__restrict__ log_sum,
+                                                      float *__restrict__ x) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.y, ts = t < T ? t : t - T;
+    if (p >= hw) return;
+    const float g = loop_gain(log_sum, hw);
+    const float *rp = rgb + ((int64_t)ts * hw + p) * 3;
+    const int64_t frames = T + pad;
+    x[((int64_t)0 * frames + t) * hw + p] = rp[0] * g;
+    x[((int64_t)1 * frames + t) * hw + p] = rp[1] * g;
+    x[((int64_t)2 * frames + t) * hw + p] = rp[2] * g;
+}
+
+__global__ __launch_bounds__(256) void loop_pad_bwd_k(int T, int pad, int64_t hw, const float *__restrict__ gx, int64_t gx_sc, int64_t gx_st,
+                                                      const double *__restrict__ log_sum, float *__restrict__ g_rgb) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.y;
+    if (p >= hw) return;
+    const float g = loop_gain(log_sum, hw);
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        v[c] = gx[c * gx_sc + t * gx_st + p];
+        if (t < pad) v[c] += gx[c * gx_sc + (T + t) * gx_st + p];
+    }
+    float *o = g_rgb + ((int64_t)t * hw + p) * 3;
+    o[0] = v[0] * g; o[1] = v[1] * g; o[2] = v[2] * g;
+}
+
+extern "C" int vl3d_loop_gain(int32_t T, int32_t F, int32_t h, int32_t w, const float *rgb, const float *res, double *log_sum,
+                              vl3d_stream_t stream) {
+    VL3D_REQUIRE(T > 0 && F > 0 && h > 0 && w > 0 && rgb && res && log_sum, "vl3d_loop_gain: bad arguments");
+    const int64_t hw = (int64_t)h * w;
+    VL3D_HIP(hipMemsetAsync(log_sum, 0, sizeof(double), (hipStream_t)stream));
+    hipLaunchKernelGGL(loop_gain_k, dim3((unsigned)ceil_div64(hw, 256)), dim3(256), 0, (hipStream_t)stream, T, F, hw, rgb, res, log_sum);
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
+extern "C" int vl3d_loop_pad_fwd(int32_t T, int32_t pad, int32_t h, int32_t w, const float *rgb, const double *log_sum, float *x,
+                                 vl3d_stream_t stream) {
+    VL3D_REQUIRE(T > 0 && pad >= 0 && pad <= T && T + pad <= 65535 && h > 0 && w > 0 && rgb && x, "vl3d_loop_pad_fwd: bad arguments");
+    const int64_t hw = (int64_t)h * w;
+    hipLaunchKernelGGL(loop_pad_fwd_k, dim3((unsigned)ceil_div64(hw, 256), (unsigned)(T + pad)), dim3(256), 0, (hipStream_t)stream, T, pad, hw, rgb,
+                       log_sum, x);
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
+extern "C" int vl3d_loop_pad_bwd(int32_t T, int32_t pad, int32_t h, int32_t w, const float *grad_x, int64_t gx_sc, int64_t gx_st,
+                                 const double *log_sum, float *grad_rgb, vl3d_stream_t stream) {
+    VL3D_REQUIRE(T > 0 && pad >= 0 && pad <= T && T <= 65535 && h > 0 && w > 0 && grad_x && grad_rgb, "vl3d_loop_pad_bwd: bad arguments");
+    const int64_t hw = (int64_t)h * w;
+    hipLaunchKernelGGL(loop_pad_bwd_k, dim3((unsigned)ceil_div64(hw, 256), (unsigned)T), dim3(256), 0, (hipStream_t)stream, T, pad, hw, grad_x, gx_sc,
+                       gx_st, log_sum, grad_rgb);
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
 extern "C" int vl3d_nn_vectors(int64_t B, int32_t n1, int32_t n2, int32_t d, const float *X, const float *Y, int32_t use_alpha,
                                float alpha, int64_t *nn, vl3d_stream_t stream) {
     VL3D_REQUIRE(B > 0 && B < (1ll << 31) && n1 > 0 && n2 > 0 && d > 0 && X && Y && nn, "vl3d_nn_vectors: bad arguments");

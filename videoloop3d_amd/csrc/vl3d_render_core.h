@@ -1226,6 +1226,10 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || MASK || (CULL && COORD == VL3D_C
         // staging buffer of this plane: alternates over the planes that are actually swept (a culled plane has no barrier)
         const int buf = CULL ? (nswept & 1) : (d & 1);
         if constexpr (CULL) nswept += culled ? 0 : 1;
+        // (a skipped plane whose owned texels need no zero fill -- grad_culled_unwritten -- costs one scalar record, not a table load per
+        // thread.  In the instantiation with regularisers only, the one a shipped stage-2 iteration runs: the plain culled kernel sits
+        // exactly at its 64-register budget and the extra branch spilled 12 bytes; it keeps filling zeros, which is always correct.)
+        if constexpr (REG) { if (CULL && culled && a.grad_culled_unwritten) continue; }
         const unsigned win0 = (unsigned)(Y0 * a.Ws + X0);          // frame texel index of the window's corner (uniform)
         const unsigned short *oplane = a.owner + (size_t)d * a.Hs * a.Ws;
         // this thread's first owner-table entry, requested now so that it arrives in the shadow of the sweep.  Unconditional
@@ -1237,7 +1241,6 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || MASK || (CULL && COORD == VL3D_C
             // composite state does not move, and the texels this tile owns get a zero gradient (written: nothing memsets it)
             // (... unless the caller never reads the gradient of culled texels -- every texel this tile owns on this plane is one: the box
             // test of bwd_windows_k is two texels wider than the region's footprint, a texel's class looks one texel around it)
-            if (a.grad_culled_unwritten) continue;
             const f4 z = f4{0.f, 0.f, 0.f, 0.f};
             if (row < wh && lane < ww && (e0 >> 10) == my_tile)
                 store_grad_texel<F16>(gplane, (win0 + toff_thread) << 4, z);
