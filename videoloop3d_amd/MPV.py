@@ -706,11 +706,14 @@ class MPMeshVid(nn.Module):
             denorm = K_ / self.mpi_d
             if sums.is_cuda and min(nx, ny) > 0:
                 gd = float(loss_gain) * denorm
+                # (one small upload per distinct (crop size, view gain): the ref view and the other views alternate within an epoch)
+                cache = self.__dict__.setdefault("_smooth_coef", {})
                 key = (nx, ny, gd, str(sums.device))
-                if getattr(self, "_smooth_coef_key", None) != key:
-                    self._smooth_coef_key = key
-                    self._smooth_coef = torch.tensor([gd / (3 * nx), gd / (3 * ny), gd / nx, gd / ny], dtype=torch.float32, device=sums.device)
-                terms = _SmoothTerms.apply(sums, self._smooth_coef)
+                if key not in cache:
+                    if len(cache) > 64:
+                        cache.clear()
+                    cache[key] = torch.tensor([gd / (3 * nx), gd / (3 * ny), gd / nx, gd / ny], dtype=torch.float32, device=sums.device)
+                terms = _SmoothTerms.apply(sums, cache[key])
                 if a.rgb_smooth_loss_weight > 0:
                     extra["rgb_smooth"] = terms[0:1].view(1, 1)
                 if a.a_smooth_loss_weight > 0:
