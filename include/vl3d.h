@@ -201,6 +201,10 @@ int vl3d_adam_window_step_boxes(int32_t D, int32_t T, int32_t Hs, int32_t Ws, in
 /* Bound on the deferral: every bookkeeping tile that has missed at least min_depth steps is replayed up to `upto`, written back and marked
  * (the others are left alone).  Run after each step it keeps what a returning crop window has to replay below min_depth steps per texel
  * -- the reference shuffles 32-72 crops x views per epoch (train_3dvid.py:263-290), so a window comes back after that many steps. */
+/* Chosen frames of a PACKED model as a dense stack for an evaluation render (MPV.py:439 `atlas_dyn[ts]`): out (D,n,Hs,Ws,4); frames =
+ * device int32 [n], each in [0,T); blocks without storage read (0, 0, 0, culled_alpha), static blocks their one copy in every frame. */
+int vl3d_packed_unpack_frames(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const int32_t *blocks, const float *pool, int32_t n,
+                              const int32_t *frames, float culled_alpha, float *out, vl3d_stream_t stream);
 int vl3d_adam_flush_older(int32_t D, int32_t T, int32_t Hs, int32_t Ws, float *param, float *exp_avg, float *exp_avg_sq, int32_t *last_step,
                           const float *hist, int32_t upto, int32_t min_depth, float beta1, float beta2, float eps, const uint8_t *quad_keep,
                           const uint8_t *quad_dyn, int32_t QH, int32_t QW, const int32_t *blocks, vl3d_stream_t stream);

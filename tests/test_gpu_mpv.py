@@ -584,6 +584,9 @@ def test_packed_model_trains_and_renders_like_the_dense_one(dev):
             ra, _ = dense(H, W, tar_e, tar_k, ts=ts)
             rb, _ = packed(H, W, tar_e, tar_k, ts=ts)
             assert torch.equal(ra, rb)
+        # the one-launch unpack of chosen frames (vl3d_packed_unpack_frames) == the plane-by-plane torch path
+        lay, pool = packed.packed, packed.stack_pool.data
+        assert torch.equal(lay.unpack_frames(pool, [4, 0, 2]), torch.stack([lay.unpack_plane(pool, d, [4, 0, 2]) for d in range(D)], 0))
     res = synth.make_video(9, 24, 32, seed=31, device=dev)[0].permute(1, 0, 2, 3)[None].contiguous()      # [1,F,3,h,w]
     cfg = collate({"loss_name": "gpnn_lm", "patch_size": 3, "patcht_size": 3, "stride": 2, "stridet": 1, "alpha": 10000.0,
                    "rou": "-2", "scaling": 0.1, "macro_block": 65})

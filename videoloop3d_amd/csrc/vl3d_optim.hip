@@ -251,6 +251,33 @@ __global__ __launch_bounds__(64) void adam_flush_older_k(int T, int Hs, int Ws, 
     if (threadIdx.x == 0) *ls = upto;                         // this wave is the tile's only reader and writer in this launch
 }
 
+// chosen frames of a packed model as a dense (D,n,Hs,Ws,4) stack (evaluation renders, MPV.py:439 `atlas_dyn[ts]`): one thread per texel
+// and plane; blocks without storage read (0, 0, 0, culled_alpha), static blocks their one copy in every frame
+__global__ __launch_bounds__(256) void packed_unpack_k(int T, int Hs, int Ws, int tiles_y, int tiles_x, Layout lay, const float4 *__restrict__ pool,
+                                                       int n, const int *__restrict__ frames, float culled_alpha, float4 *__restrict__ out) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), d = blockIdx.z;
+    if (x >= Ws || y >= Hs) return;
+    const int e = lay.blocks[((size_t)d * tiles_y + y / TS) * tiles_x + x / TS];
+    const size_t frame = (size_t)Hs * Ws;
+    float4 *o = out + (size_t)d * n * frame + (size_t)y * Ws + x;
+    if (e < 0) {
+        for (int i = 0; i < n; ++i, o += frame) *o = make_float4(0.f, 0.f, 0.f, culled_alpha);
+        return;
+    }
+    const size_t base = (size_t)(e >> 1) * (TS * TS) + (size_t)((y % TS) * TS + (x % TS)), fs = (e & 1) ? (size_t)(TS * TS) : 0;
+    for (int i = 0; i < n; ++i, o += frame) *o = pool[base + (size_t)frames[i] * fs];
+}
+
+extern "C" int vl3d_packed_unpack_frames(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const int32_t *blocks, const float *pool, int32_t n,
+                                         const int32_t *frames, float culled_alpha, float *out, vl3d_stream_t stream) {
+    VL3D_REQUIRE(D > 0 && D <= 65535 && T > 0 && Hs > 0 && Ws > 0 && n > 0 && blocks && pool && frames && out, "vl3d_packed_unpack_frames: bad arguments");
+    const int tiles_y = (Hs + TS - 1) / TS, tiles_x = (Ws + TS - 1) / TS;
+    hipLaunchKernelGGL(packed_unpack_k, dim3((Ws + 63) / 64, (Hs + 3) / 4, D), dim3(256), 0, (hipStream_t)stream, T, Hs, Ws, tiles_y, tiles_x,
+                       Layout{blocks}, reinterpret_cast<const float4 *>(pool), n, frames, culled_alpha, reinterpret_cast<float4 *>(out));
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
 extern "C" int32_t vl3d_adam_window_tile(void) { return TS; }
 
 extern "C" int vl3d_adam_flush_older(int32_t D, int32_t T, int32_t Hs, int32_t Ws, float *param, float *exp_avg, float *exp_avg_sq,

@@ -104,6 +104,18 @@ class PackedLayout:
     @torch.no_grad()
     def unpack_frames(self, pool, frames):
         """-> (D,len(frames),Hs,Ws,4): the frames an evaluation render asks for (MPV.py:439 `atlas_dyn[ts]`)."""
+        frames = [int(t) for t in frames]
+        if pool.is_cuda and self.blocks.device == pool.device and len(frames) > 0:
+            from . import _lib as L
+            if min(frames) < 0 or max(frames) >= self.T:
+                raise IndexError(f"frame index out of range [0, {self.T})")
+            out = torch.empty((self.D, len(frames), self.Hs, self.Ws, 4), dtype=torch.float32, device=pool.device)
+            ft = torch.tensor(frames, dtype=torch.int32).to(pool.device, non_blocking=True)
+            with torch.cuda.device(pool.device):
+                L.check(L.lib().vl3d_packed_unpack_frames(self.D, self.T, self.Hs, self.Ws, L.ptr(self.blocks), L.ptr(pool), len(frames), L.ptr(ft),
+                                                          float(tiles.CULLED_ALPHA), L.ptr(out), L.stream_ptr(pool.device)),
+                        "vl3d_packed_unpack_frames")
+            return out
         return torch.stack([self.unpack_plane(pool, d, frames) for d in range(self.D)], 0)
 
     @staticmethod
