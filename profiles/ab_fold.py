@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-process A/B of the LDS-staged vote-fold tile shapes (variant bits 12-15 = shape index + 1; 0 = the library's choice) on
 resident 720p clips, both loss configurations: kernel time per shape, outputs compared with shape 1's bit for bit.
-  python profiles/ab_fold.py 0,1,2,3,4,5,6 [rounds]"""
+  python profiles/ab_fold.py 0,1,2,3,4,5,6 [rounds]        (shape + 100: the same with the dynamic covering loops, variant bit 9)"""
 import os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,7 +23,7 @@ for name, (ps, s, al) in {"ref": (11, 4, 0.5), "other": (3, 2, None)}.items():
     res, ref = {v: [] for v in shapes}, None
     for r in range(rounds + 1):
         for v in shapes:
-            desc.variant = base | (int(v) << 12) | (int(round(v * 10)) % 10 << 16)
+            desc.variant = (base & ~0x200) | (int(v) % 100 << 12) | (0x200 if v >= 100 else 0)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             L.check(L.lib().vl3d_vote_fold_robust(desc, L.ptr(yv), L.ptr(nn), L.ptr(xv), L.RHO["barron"], -2.0, 0.1, L.ptr(outs[0]), L.ptr(w),

@@ -279,6 +279,30 @@ def test_lowmem_loss_trims_inside_the_fused_op(dev):
     assert float(ga.abs().max()) > 0
 
 
+@pytest.mark.parametrize("ps,s", [(11, 4), (3, 2), (7, 3), (5, 1)])
+def test_fold_fixed_trip_covering_loops_equal_the_dynamic_ones(dev, ps, s, monkeypatch):
+    """vote_fold_lds_k with NB x NB fixed-trip covering loops (at most 3 x 3 / 2 x 2 locations cover a pixel: the shipped configurations;
+    locations that do not exist vote with weight 0) against the dynamic loops (variant bit 9; (5, 1) covers 5 x 5 and takes them anyway):
+    loss, gradient, y2x and weight bit for bit, on frames with ragged borders."""
+    from videoloop3d_amd.utils_vid import Patch3DGPNNLowMemLoss
+    cfg = dict(macro_block=65, patch_size=ps, stride=s, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=0.5)
+    x0 = synth.make_video(9, 61, 83, seed=21).to(dev)
+    y = synth.make_video(12, 61, 83, seed=22).to(dev)
+    out = []
+    for variant in ("0", "0x200"):
+        monkeypatch.setenv("VL3D_LOSS_VARIANT", variant)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            xa = x0.clone().requires_grad_(True)
+            L = Patch3DGPNNLowMemLoss()
+            la = L(xa, y, **cfg)
+            (ga,) = torch.autograd.grad(la, xa)
+        out.append((float(la), ga, L.last_y2x.clone(), L.last_weight.clone()))
+    assert out[0][0] == out[1][0]
+    assert all(torch.equal(a, b) for a, b in zip(out[0][1:], out[1][1:]))
+    assert float(out[0][1].abs().max()) > 0
+
+
 def test_g10_compute_nnerr(dev, golden):
     """evaluations/NNMSE.compute_nnerr on the HIP patch-NN path vs the reference golden G10."""
     import warnings as _w

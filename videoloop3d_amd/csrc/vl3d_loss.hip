@@ -957,7 +957,12 @@ __global__ __launch_bounds__(256) void vote_fold_k(FoldArgs a) {
 // any scattered global access.  (v1 -- one thread per voxel reading y and nn through L2 -- measured 12.3 ms at 720p.)
 // Tile shapes (FT_W x FT_H pixels, FT_NT threads = pixels x FT_G temporal groups): see fold_shapes[] below.
 
-template <int FT_W, int FT_H, int FT_NT>
+// NB > 0 (patch-major form only): a pixel is covered by at most NB x NB patch locations (NB = ceil(ps / stride): 3 for the shipped ref view,
+// 2 for the other views).  The covering loops then have a FIXED trip count -- locations that do not exist vote with weight 0 from a
+// valid address -- so the NB x NB index reads of a patch are issued together and the 3 NB^2 vote reads behind them together: two LDS
+// round trips per patch instead of two per LOCATION (the dependent index -> vote chain with its dynamic loop bounds left the LDS idle:
+// 66 % of the wave-cycles waiting, profiles/r03_pmc_summary.txt).  fma(y, 1, w) == y + w and fma(y, 0, w) == w: same sums, same order.
+template <int FT_W, int FT_H, int FT_NT, int NB = 0>
 __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NP = FT_W * FT_H, FT_G = FT_NT / NP, NT = FT_NT;
@@ -1006,12 +1011,34 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
     // three frame sums slide through registers (w0 = frame i, complete after patch i) -- a third of the index reads and of the
     // address arithmetic of the frame-major form below, and the same summation order per frame (kt = 2, 1, 0 -> patches i-2, i-1, i).
     float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+    constexpr int NBB = NB > 0 ? NB * NB : 1;
+    int loc_off[NBB];            // NB > 0: index rows of the covering locations relative to nn0 (row 0 for one that does not exist) ...
+    float loc_w[NBB];            // ... and their vote weight, 1 or 0
+    if constexpr (NB > 0) {
+#pragma unroll
+        for (int k = 0; k < NBB; ++k) {
+            const int by = k / NB, bx = k % NB;
+            const bool ok = by <= by_hi - by_lo && bx <= bx_hi - bx_lo;
+            loc_off[k] = ok ? (by * nbx + bx) * a.n1 : 0;
+            loc_w[k] = ok ? 1.0f : 0.0f;
+        }
+    }
     for (int tau = slide ? t0 - 2 : t0; tau < t1; tau += tstep) {
         float s = 0.f;
         int cnt = 0;
         if (slide) {
             const int i = tau;                                     // patch index == first frame it votes for
             if (i >= 0 && i < a.n1) {
+                if constexpr (NB > 0) {
+                    int idx[NBB];
+#pragma unroll
+                    for (int k = 0; k < NBB; ++k) idx[k] = nn0[loc_off[k] + i];
+#pragma unroll
+                    for (int k = 0; k < NBB; ++k) {
+                        const float *yp = ysp + idx[k];
+                        w0 = fmaf(yp[0], loc_w[k], w0); w1 = fmaf(yp[NP], loc_w[k], w1); w2 = fmaf(yp[2 * NP], loc_w[k], w2);
+                    }
+                } else {
                 const int *nrow = nn0 + i;
                 for (int by = by_lo; by <= by_hi; ++by, nrow += nbx * a.n1) {
                     const int *np = nrow;
@@ -1019,6 +1046,7 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
                         const float *yp = ysp + *np;                    // staged as index * NP
                         w0 += yp[0]; w1 += yp[NP]; w2 += yp[2 * NP];
                     }
+                }
                 }
             }
             s = w0; w0 = w1; w1 = w2; w2 = 0.f;
@@ -1350,16 +1378,26 @@ static int fold_shape(const vl3d_loss_desc *desc, int n1) {
             if (fold_lds_bytes(desc, n1, fold_shapes[i]) <= budget) return i;
     return -1;
 }
-template <int FW, int FH, int NT>
-static int launch_fold_lds(const vl3d_loss_desc *desc, const FoldArgs &a, size_t lds, hipStream_t s) {
+template <int FW, int FH, int NT, int NB>
+static int launch_fold_lds_nb(const vl3d_loss_desc *desc, const FoldArgs &a, size_t lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        VL3D_HIP(hipFuncSetAttribute((const void *)vote_fold_lds_k<FW, FH, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        VL3D_HIP(hipFuncSetAttribute((const void *)vote_fold_lds_k<FW, FH, NT, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
         attr_set = true;
     }
     dim3 grid((desc->W + FW - 1) / FW, (desc->H + FH - 1) / FH, 3);
-    hipLaunchKernelGGL((vote_fold_lds_k<FW, FH, NT>), grid, dim3(NT), lds, s, a, desc->Ty);
+    hipLaunchKernelGGL((vote_fold_lds_k<FW, FH, NT, NB>), grid, dim3(NT), lds, s, a, desc->Ty);
     return VL3D_OK;
+}
+template <int FW, int FH, int NT>
+static int launch_fold_lds(const vl3d_loss_desc *desc, const FoldArgs &a, size_t lds, hipStream_t s) {
+    // fixed-trip covering loops for the patch-major form when a pixel has at most 2 x 2 / 3 x 3 covering locations (the shipped
+    // configurations); variant bit 9 keeps the dynamic loops (A/B, cross-checks: same bits)
+    const int cover = (desc->ps + desc->stride - 1) / desc->stride;
+    const bool slide = desc->pt == 3 && desc->stridet == 1 && !(desc->variant & 0x200);
+    if (slide && cover == 3) return launch_fold_lds_nb<FW, FH, NT, 3>(desc, a, lds, s);
+    if (slide && cover <= 2) return launch_fold_lds_nb<FW, FH, NT, 2>(desc, a, lds, s);
+    return launch_fold_lds_nb<FW, FH, NT, 0>(desc, a, lds, s);
 }
 static int launch_fold_lds_w(int shape, const vl3d_loss_desc *desc, const FoldArgs &a, hipStream_t s) {
     const size_t lds = fold_lds_bytes(desc, a.n1, fold_shapes[shape]);
