@@ -856,6 +856,7 @@ __global__ __launch_bounds__(256) void nn_vectors_k(const float *__restrict__ X,
 struct Rho {
     int kind;      // 0 mse, 1 abs, 2 log1p (rou==0), 3 quadratic (rou==2), 4 general
     float scale, b, d, coef;
+    float inv_scale, inv_b;      // host reciprocals for the fused kernel (the two IEEE quotients by constants were ~20 instructions per voxel)
 };
 
 __device__ __forceinline__ float rho_f(const Rho &r, float e) {
@@ -885,8 +886,8 @@ __device__ __forceinline__ float rho_g(const Rho &r, float e) {
 // (s^2/b+1)^(d/2) = exp2(d/2 * log2(u)) and the derivative's power is that over u -- instead of two powf calls
 __device__ __forceinline__ void rho_fg(const Rho &r, float e, float &f, float &g) {
     if (r.kind == 4) {
-        const float s = e / r.scale;
-        const float u = s * s / r.b + 1.0f;
+        const float s = e * r.inv_scale;
+        const float u = fmaf(s * s, r.inv_b, 1.0f);
         const float p = __builtin_amdgcn_exp2f(0.5f * r.d * __builtin_amdgcn_logf(u));
         f = r.coef * (p - 1.0f) * (r.scale * 10.0f);
         g = 10.0f * s * p * __builtin_amdgcn_rcpf(u);
@@ -986,8 +987,16 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
     const int chunk = (a.Tx + FT_G - 1) / FT_G, t0 = slide ? grp * chunk : grp, t1 = slide ? min(a.Tx, t0 + chunk) : a.Tx;
     const int tstep = slide ? 1 : FT_G;
     const float *xsrc = a.x ? a.x + (int64_t)c * a.x_sc + (int64_t)min(eta, a.H - 1) * a.x_sr + min(xi, a.W - 1) : nullptr;
-    auto xload = [&](int t) -> float { return (xsrc && t < t1) ? xsrc[(int64_t)t * a.x_st] : 0.f; };
-    float xq0 = xload(t0), xq1 = xload(t0 + tstep), xq2 = xload(t0 + 2 * tstep), xq3 = xload(t0 + 3 * tstep);
+    // (the prefetch pointer walks by a frame step: no 64-bit multiply per load)
+    const int64_t xstep = (int64_t)tstep * a.x_st;
+    const float *xnext = xsrc ? xsrc + (int64_t)t0 * a.x_st : nullptr;
+    int tnext = t0;
+    auto xload = [&]() -> float {
+        const float v = (xnext && tnext < t1) ? *xnext : 0.f;
+        xnext += xstep; tnext += tstep;
+        return v;
+    };
+    float xq0 = xload(), xq1 = xload(), xq2 = xload(), xq3 = xload();
 #pragma unroll 8
     for (int f = grp; f < Ty; f += FT_G) ys[f * NP + pix] = ysrc[(int64_t)f * a.y_st];
     for (int i = tid; i < nby * nbx * a.n1; i += NT) {
@@ -1006,6 +1015,8 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
     float *wout = a.weight + (size_t)eta * a.W + xi;
     const int *nn0 = nns + ((by_lo - tby0) * nbx + (bx_lo - tbx0)) * a.n1;
     const float *ysp = ys + pix;
+    float *gxp = a.x ? a.gx + (int64_t)c * a.gx_sc + (int64_t)t0 * a.gx_st + (int64_t)eta * a.gx_sr + xi : nullptr;      // walks by a frame step
+    const int64_t gxstep = (int64_t)tstep * a.gx_st;
     // Each temporal group owns a contiguous run of frames.  With pt == 3 and stridet == 1 (every shipped configuration) the
     // votes are accumulated patch-major: patch i votes for frames i, i+1, i+2, so its NN index is read from LDS ONCE and the
     // three frame sums slide through registers (w0 = frame i, complete after patch i) -- a third of the index reads and of the
@@ -1067,18 +1078,20 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
         }
         }
         const float wgt = fmaxf((float)cnt, 1e-10f);                  // utils_vid.py:228
-        const float v = a.normalize ? s / wgt : s;
+        // (the vote count is a small integer: s * rcp(count) is within an ulp of the reference's quotient, a fifth of its instructions)
+        const float v = a.normalize ? s * __builtin_amdgcn_rcpf(wgt) : s;
         if (a.sum) {      // uniform
             out[(size_t)tau * fs] = v;
             if (c == 0) wout[(size_t)tau * fs] = wgt;
         }
         if (a.x) {      // robust_lossfun(x - y2x) and its derivative while y2x is in a register (utils_vid.py:348)
             const float e = xq0 - v;
-            xq0 = xq1; xq1 = xq2; xq2 = xq3; xq3 = xload(tau + 4 * tstep);
+            xq0 = xq1; xq1 = xq2; xq2 = xq3; xq3 = xload();
             float f, g;
             rho_fg(a.rho, e, f, g);
             lacc += f;
-            a.gx[(int64_t)c * a.gx_sc + (int64_t)tau * a.gx_st + (int64_t)eta * a.gx_sr + xi] = g * a.gscale;
+            *gxp = g * a.gscale;
+            gxp += gxstep;
         }
     }
     }
@@ -1130,7 +1143,9 @@ Rho make_rho(int kind, float rou, float scale) {
         r.b = fabsf(rou - 2.0f) + eps;
         r.d = rou >= 0.f ? rou + eps : rou - eps;
         r.coef = r.b / r.d;
+        r.inv_b = 1.0f / r.b;
     }
+    r.inv_scale = 1.0f / scale;
     return r;
 }
 
