@@ -959,16 +959,17 @@ __global__ __launch_bounds__(256) void vote_fold_k(FoldArgs a) {
 // Tile shapes (FT_W x FT_H pixels, FT_NT threads = pixels x FT_G temporal groups): see fold_shapes[] below.
 
 // NB > 0 (patch-major form only): a pixel is covered by at most NB x NB patch locations (NB = ceil(ps / stride): 3 for the shipped ref view,
-// 2 for the other views).  The covering loops then have a FIXED trip count -- locations that do not exist vote with weight 0 from a
-// valid address -- so the NB x NB index reads of a patch are issued together and the 3 NB^2 vote reads behind them together: two LDS
-// round trips per patch instead of two per LOCATION (the dependent index -> vote chain with its dynamic loop bounds left the LDS idle:
-// 66 % of the wave-cycles waiting, profiles/r03_pmc_summary.txt).  fma(y, 1, w) == y + w and fma(y, 0, w) == w: same sums, same order.
+// 2 for the other views).  The covering loops then have a FIXED trip count -- a location that does not exist reads its index from a
+// row of the table that points at three all-zero frames behind the staged column, i.e. votes 0 -- so a row of NB index reads is issued
+// together and its 3 NB vote reads behind them together, instead of one dependent index -> vote chain per location under dynamic
+// loop bounds (the PMC pass had the kernel waiting in 66 % of its wave-cycles and VALU bound on the address arithmetic,
+// profiles/r03_pmc_summary.txt).  y + 0 == y: same sums, same order.
 template <int FT_W, int FT_H, int FT_NT, int NB = 0>
 __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NP = FT_W * FT_H, FT_G = FT_NT / NP, NT = FT_NT;
-    float *ys = smem;                                            // [Ty][NP]
-    int *nns = reinterpret_cast<int *>(smem + (size_t)Ty * NP);   // [nby][nbx][n1]
+    float *ys = smem;                                            // [Ty + 3][NP]: the tile's y columns, then three zero frames
+    int *nns = reinterpret_cast<int *>(smem + (size_t)(Ty + 3) * NP);   // [nby][nbx][n1], then n1 indices of the zero frames
     const int tid = threadIdx.x, pix = tid % NP, grp = tid / NP, lx = pix % FT_W, ly = pix / FT_W;
     const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H, c = blockIdx.z;
     const int xi = x0 + lx, eta = y0 + ly;
@@ -997,12 +998,24 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
         return v;
     };
     float xq0 = xload(), xq1 = xload(), xq2 = xload(), xq3 = xload();
+    {   // (source pointer and LDS slot walk by a group step: no 64-bit multiply per frame)
+        const float *yf = ysrc + (int64_t)grp * a.y_st;
+        const int64_t ystep = (int64_t)FT_G * a.y_st;
+        float *yd = ys + grp * NP + pix;
 #pragma unroll 8
-    for (int f = grp; f < Ty; f += FT_G) ys[f * NP + pix] = ysrc[(int64_t)f * a.y_st];
-    for (int i = tid; i < nby * nbx * a.n1; i += NT) {
-        const int ii = i % a.n1, b = i / a.n1;
-        const int bx = b % nbx, by = b / nbx;
-        nns[i] = a.nn[((size_t)(tby0 + by) * a.w_o + (tbx0 + bx)) * a.n1 + ii] * (slide ? NP : 1);
+        for (int f = grp; f < Ty; f += FT_G, yf += ystep, yd += FT_G * NP) *yd = *yf;
+    }
+    // the covering locations' index rows: a run of n1 consecutive ints per location -- rows of the tile's locations are contiguous in nn
+    // along bx, so a (by) row of the table is ONE contiguous run of nbx * n1 ints: no division per element
+    {
+        const int run = nbx * a.n1, mul = slide ? NP : 1;
+        for (int by = 0; by < nby; ++by) {
+            const int32_t *src = a.nn + ((size_t)(tby0 + by) * a.w_o + tbx0) * a.n1;
+            int *dst = nns + by * run;
+            for (int i = tid; i < run; i += NT) dst[i] = src[i] * mul;
+        }
+        for (int i = tid; i < 3 * NP; i += NT) ys[Ty * NP + i] = 0.f;
+        for (int i = tid; i < a.n1; i += NT) nns[nby * run + i] = Ty * mul;
     }
     __syncthreads();
     float lacc = 0.f;
@@ -1023,15 +1036,14 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
     // address arithmetic of the frame-major form below, and the same summation order per frame (kt = 2, 1, 0 -> patches i-2, i-1, i).
     float w0 = 0.f, w1 = 0.f, w2 = 0.f;
     constexpr int NBB = NB > 0 ? NB * NB : 1;
-    int loc_off[NBB];            // NB > 0: index rows of the covering locations relative to nn0 (row 0 for one that does not exist) ...
-    float loc_w[NBB];            // ... and their vote weight, 1 or 0
+    int loc_off[NBB];            // NB > 0: index rows of the covering locations relative to nn0 (the zero-frame row for one that does not exist)
     if constexpr (NB > 0) {
+        const int zero_row = (int)(nns + nby * nbx * a.n1 - nn0);
 #pragma unroll
         for (int k = 0; k < NBB; ++k) {
             const int by = k / NB, bx = k % NB;
             const bool ok = by <= by_hi - by_lo && bx <= bx_hi - bx_lo;
-            loc_off[k] = ok ? (by * nbx + bx) * a.n1 : 0;
-            loc_w[k] = ok ? 1.0f : 0.0f;
+            loc_off[k] = ok ? (by * nbx + bx) * a.n1 : zero_row;
         }
     }
     for (int tau = slide ? t0 - 2 : t0; tau < t1; tau += tstep) {
@@ -1041,13 +1053,19 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
             const int i = tau;                                     // patch index == first frame it votes for
             if (i >= 0 && i < a.n1) {
                 if constexpr (NB > 0) {
-                    int idx[NBB];
+                    // one row of locations at a time: NB index reads together, then their 3 NB vote reads together (all NB x NB at once
+                    // needed 102 registers for NB = 3 -- two workgroups per CU instead of three)
 #pragma unroll
-                    for (int k = 0; k < NBB; ++k) idx[k] = nn0[loc_off[k] + i];
+                    for (int r = 0; r < NB; ++r) {
+                        int idx[NB];
 #pragma unroll
-                    for (int k = 0; k < NBB; ++k) {
-                        const float *yp = ysp + idx[k];
-                        w0 = fmaf(yp[0], loc_w[k], w0); w1 = fmaf(yp[NP], loc_w[k], w1); w2 = fmaf(yp[2 * NP], loc_w[k], w2);
+                        for (int q = 0; q < NB; ++q) idx[q] = nn0[loc_off[r * NB + q] + i];
+#pragma unroll
+                        for (int q = 0; q < NB; ++q) {
+                            const float *yp = ysp + idx[q];
+                            w0 += yp[0]; w1 += yp[NP]; w2 += yp[2 * NP];
+                        }
+                        if (NB > 2 && r + 1 < NB) __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {
                 const int *nrow = nn0 + i;
@@ -1381,7 +1399,8 @@ static int fold_cover(int f, int ps, int stride) {
 }
 static size_t fold_lds_bytes(const vl3d_loss_desc *desc, int n1, const FoldShape &sh) {
     const int nby_max = fold_cover(sh.fh, desc->ps, desc->stride), nbx_max = fold_cover(sh.fw, desc->ps, desc->stride);
-    return ((size_t)desc->Ty * sh.fw * sh.fh + (size_t)nby_max * nbx_max * n1) * sizeof(float);
+    // y columns + three zero frames | index rows of the covering locations + one row pointing at the zero frames
+    return ((size_t)(desc->Ty + 3) * sh.fw * sh.fh + ((size_t)nby_max * nbx_max + 1) * n1) * sizeof(float);
 }
 // -1 = no shape fits.  First choice: the first shape that leaves room for three workgroups per CU, then two, then one.
 // variant bits 12-15 (measurement hook): shape index + 1
