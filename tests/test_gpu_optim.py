@@ -81,6 +81,18 @@ def test_window_adam_equals_torch_adam_over_a_shuffled_window_schedule(dev, with
         oa.step(); ob.step()
         pa.grad = None
     assert float((pa.detach() - pb.detach()).abs().max()) > 1e-3          # deferred updates are really outstanding ...
+    # ... but bounded: the sweep that runs one step in eight leaves no tile more than max_defer steps behind (a dense step at 17 made
+    # everything current; 22 more steps followed, so without the bound tiles would sit at step 18)
+    ob8 = WindowAdam([torch.nn.Parameter(p0.clone())], lr=5e-3, betas=(0.9, 0.999), eps=6e-8, max_defer=8, lean_window=lean)
+    deepest = 0
+    for step in range(30):
+        leaf = ob8.window_leaf(align_window(0, 16, 0, 16, Hs, Ws))
+        leaf.grad = torch.ones_like(leaf)
+        ob8.step()
+        depth = int((ob8.t - ob8.state[ob8.p]["last_step"]).max())
+        assert depth <= 8
+        deepest = max(deepest, depth)
+    assert deepest >= 4                                                        # (and really deferred in between)
     ob.flush()
     assert float((pa.detach() - pb.detach()).abs().max()) <= 2e-6         # ... and replayed exactly
     sa, sb = oa.state[pa], ob.state[pb]

@@ -229,9 +229,12 @@ class WindowAdam(torch.optim.Optimizer):
                                                         None if boxes is None else boxes.ctypes.data, self._blocks(), L.stream_ptr(p.device)),
                     "vl3d_adam_window_step")
         self.t = t
-        if self.max_defer > 0 and t >= self.max_defer:
+        # every `every` steps, tiles that have missed max_defer - every steps or more are brought up to date: nothing is ever older than
+        # max_defer when its window comes back, and the sweep over the step table (a wave per tile) is paid on one step in `every`
+        every = max(1, min(8, self.max_defer // 4))
+        if self.max_defer > 0 and t >= self.max_defer - every and t % every == 0:
             with torch.cuda.device(p.device):
                 L.check(L.lib().vl3d_adam_flush_older(D, T, Hs, Ws, L.ptr(p), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), L.ptr(st["last_step"]),
-                                                      L.ptr(st["hist"]), t, self.max_defer, float(b1), float(b2), eps, qk, qd, QH, QW,
+                                                      L.ptr(st["hist"]), t, max(1, self.max_defer - every), float(b1), float(b2), eps, qk, qd, QH, QW,
                                                       self._blocks(), L.stream_ptr(p.device)), "vl3d_adam_flush_older")
         return loss
