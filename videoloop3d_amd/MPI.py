@@ -226,7 +226,13 @@ class MPMesh(nn.Module):
                 self._mask_buf[..., 0].copy_(self.stack_mask)
                 self._mask_buf[..., 3].copy_(self.stack[..., 3])
         for b in range(B):
-            homos = self.plane_homographies(extrin[b:b + 1], intrin[b:b + 1]).to(self.stack.device)
+            homos = self.plane_homographies(extrin[b:b + 1], intrin[b:b + 1])
+            if homos.device.type == "cpu" and self.stack.is_cuda:
+                # host homographies (a few hundred bytes): through a pinned staging buffer and an asynchronous copy -- a pageable upload blocks
+                # the host until everything queued before it has run (1.7 of the 2.9 ms of a 720p stage-1 iteration, profiles/host_profile_stage1.py)
+                homos = homos.pin_memory().to(self.stack.device, non_blocking=True)
+            else:
+                homos = homos.to(self.stack.device)
             if fused_mask:
                 rgb, alpha, label, ss, asum = render_planes_with_mask(self.stack, self.stack_mask, homos, H, W, self.spec, with_regularisers=need_reg)
                 labels.append(label[..., None])
