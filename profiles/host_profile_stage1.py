@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Host-side cost of a 720p stage-1 iteration: cProfile over examples/stage1_step.py (sorted by own time)."""
 import cProfile, pstats, sys, os, io
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "examples"))
 import __graft_entry__ as g; g.build()
