@@ -286,7 +286,10 @@ def test_loop_mask_fifth_channel_equals_the_label_pass(dev):
         with torch.no_grad():
             m.stack.copy_(synth.make_plane_stack(*m.stack.shape[:4], seed=5) * 0.7)
             m.stack_mask.copy_(synth.hash_uniform(tuple(m.stack_mask.shape), seed=6) * 3 - 2)
-        rgbl, extra = m(h, w, tar_e if host_pose else tar_e.to(dev), tar_k if host_pose else tar_k.to(dev))
+        if host_pose == "numpy":      # (what nn.DataParallel's scatter leaves on the host)
+            rgbl, extra = m(h, w, tar_e.numpy(), tar_k.numpy())
+        else:
+            rgbl, extra = m(h, w, tar_e if host_pose else tar_e.to(dev), tar_k if host_pose else tar_k.to(dev))
         g = (synth.hash_uniform(tuple(rgbl.shape), seed=9) - 0.5).to(dev)
         tot = (rgbl * g).sum() + sum(v.sum() for v in extra.values()) * 10
         gs, gm = torch.autograd.grad(tot, [m.stack, m.stack_mask])
@@ -294,7 +297,7 @@ def test_loop_mask_fifth_channel_equals_the_label_pass(dev):
 
     for reg in (True, False):
         ref = run(True, reg)
-        for variant, host_pose in ((0, False), (1, False), (0, True)):
+        for variant, host_pose in ((0, False), (1, False), (0, True), (0, "numpy")):
             got = run(False, reg, variant, host_pose)
             assert float((got[0] - ref[0]).abs().max()) <= 2e-6, (reg, variant)
             assert got[1].keys() == ref[1].keys() and all(abs(got[1][k] - ref[1][k]) <= 1e-6 * max(1.0, abs(ref[1][k])) for k in ref[1])

@@ -267,6 +267,7 @@ class MPMesh(nn.Module):
     def forward(self, h, w, tar_extrins, tar_intrins):
         """MPI.py:596-652 -> (rgbl [B,3|4,h,w], extra)."""
         a = self.args
+        tar_extrins, tar_intrins = torch.as_tensor(tar_extrins), torch.as_tensor(tar_intrins)      # (numpy arrays pass nn.DataParallel's scatter untouched: host poses)
         extrins = tar_extrins @ self._on(tar_extrins.device, "ref_extrin")[None, ...].inverse().to(tar_extrins.dtype)
         need_reg = self.training and (a.sparsity_loss_weight > 0 or a.rgb_smooth_loss_weight > 0 or a.a_smooth_loss_weight > 0)
         rgbl, variables = self.render(h, w, extrins, tar_intrins, need_reg=need_reg)

@@ -659,6 +659,11 @@ class MPMeshVid(nn.Module):
     # ---- forward -----------------------------------------------------------------------------------------------------
     def forward(self, h, w, tar_extrins, tar_intrins, ts=None, res=None, losscfg=None):
         """MPV.py:477-556.  train -> (None, {'swd': [1,1], ...}); eval -> (rgb [T',3,h,w], {})."""
+        tar_extrins, tar_intrins = torch.as_tensor(tar_extrins), torch.as_tensor(tar_intrins)      # (numpy arrays pass nn.DataParallel's scatter untouched: host poses)
+        if tar_extrins.is_cuda and self.training and self._window_opt is not None:
+            # the crop-aware step sizes its texel window on the host: device poses (nn.DataParallel's scatter) come back once, here, instead
+            # of as homographies after ~40 small device kernels
+            tar_extrins, tar_intrins = tar_extrins.cpu(), tar_intrins.cpu()
         extrins = tar_extrins @ self._on(tar_extrins.device, "ref_extrin")[None, ...].inverse().to(tar_extrins.dtype)
         if ts is None:
             ts = torch.arange(self.frm_num).long()
