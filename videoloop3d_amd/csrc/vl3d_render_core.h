@@ -1113,7 +1113,16 @@ __global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, i
     // 64 x 8 ones along y), which the low bits of each tile coordinate tell apart: 16 bits per texel = slot_bits for the slot
     // (10 for the 1024-thread tile kernel, 9 for the 512-thread pair kernels), the rest for (tile_y & 7 | 15, tile_x & 7)
     const unsigned ymask = slot_bits == 9 ? 15u : 7u;
-    owner[((size_t)d * a.Hs + y) * a.Ws + x] = (unsigned short)(((((unsigned)ty & ymask) << 3 | (unsigned)(tx & 7)) << slot_bits) | lc);
+    const unsigned ent = ((((unsigned)ty & ymask) << 3 | (unsigned)(tx & 7)) << slot_bits) | lc;
+    // four lanes' entries leave as ONE 8-byte store from the first of them where the row is 8-byte aligned (the 2-byte stores were a third of
+    // this pre-pass for a single frame); the lane -> texel mapping stays one to one: the zero fill below needs contiguous lanes
+    const unsigned e1 = __shfl_down(ent, 1, 64), e2 = __shfl_down(ent, 2, 64), e3 = __shfl_down(ent, 3, 64);
+    unsigned short *dst = owner + ((size_t)d * a.Hs + y) * a.Ws + x;
+    if ((a.Ws & 3) == 0 && x + 3 < a.Ws) {      // (uniform per row of the block but for its last lanes; x is a multiple of 4 where lane & 3 == 0)
+        if ((threadIdx.x & 3) == 0) *reinterpret_cast<uint2 *>(dst) = make_uint2(ent | e1 << 16, e2 | e3 << 16);
+    } else {
+        *dst = (unsigned short)ent;
+    }
     // same pass (it already has the texel's owner pixel): texels no tile is certain to own -- owner pixel on or outside the frame's
     // border ring -- are zero-filled for all T frames here, so nothing memsets the gradient; the tile kernel runs after this
     // kernel and overwrites the border ring's texels it does own
