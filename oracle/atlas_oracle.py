@@ -11,10 +11,10 @@ Restates, in plain PyTorch on the (T,4,Ah,Aw) ATLAS itself, what MPV.py does wit
 The plane coordinates (xm, ym) of a target pixel come from the same homography the other oracles use (ray through the pixel centre
 x + 0.5, ref_intrin_mpi), coverage is the quad extent 0 <= xm <= mpi_w-1, 0 <= ym <= mpi_h-1.
 
-Pinning: MPV.py cannot be imported here (pytorch3d, cv2, imageio, torchvision are absent) and no reference test holds vectors for
-this path: "parity unpinned" at the pytorch3d boundary, like oracle/mpv_oracle.py.  What IS pinned: grid_sample is PyTorch's own
-(the very function the reference calls), the UV layout is the closed form of MPV.py:75-81 (checked in tests against a literal
-re-execution of those lines), compositing is oracle/mpi_oracle.overcompose (golden G3).
+Pinning (round 4): goldens G14 / G17 (tests/golden/make_golden_r04.py) hold what the reference's OWN MPI.py / MPV.py produce -- the
+constructor's `uvs` tensors (G14 == reference_vertex_uvs) and full renders / forwards of dense models through a harness-side analytic
+rasteriser (G17 == render_atlas to 1e-6, tests/test_reference_modules_cpu.py).  Still unpinned, by necessity: the un-vendored
+rasteriser's pixel-centre (+0.5) and edge rule, which the harness takes from this file's reading of pytorch3d.
 Only tests/ import this module.
 """
 import torch
@@ -41,21 +41,28 @@ def plane_uv(xm, ym, p, grid_h, grid_w, mpi_h, mpi_w):
     return u, v
 
 
-def render_atlas(atlas, homos, H, W, grid_h, mpi_h, mpi_w, pixel_center=0.5):
-    """atlas (T,4,Ah,Aw) pre-activation, homos [D,3,3] target pixel -> plane pixel -> rgb [T,H,W,3], alpha [T,H,W], layers."""
-    T = atlas.shape[0]
+def sample_atlas_layers(atlas, homos, H, W, grid_h, mpi_h, mpi_w, pixel_center=0.5, acts=(torch.sigmoid, torch.sigmoid)):
+    """atlas (T,C,Ah,Aw) pre-activation (C = 4: rgba; C = 1: the loop-mask texture, MPI.py:568-571), homos [D,3,3] target pixel -> plane
+    pixel -> (plane-indexed activated layers [T,H,W,D,C], zero where uncovered; covered [H,W,D] bool)."""
+    T, C = atlas.shape[:2]
     D = homos.shape[0]
     grid_w = D // grid_h
     xs, ys = MO._homography_source_coords(H, W, homos, pixel_center)          # [D,H,W] plane pixels
-    layers = []
+    layers, covs = [], []
     for p in range(D):
         xm, ym = xs[p], ys[p]
         u, v = plane_uv(xm, ym, p, grid_h, grid_w, mpi_h, mpi_w)
         grid = torch.stack([u, v], dim=-1)[None].expand(T, -1, -1, -1).to(atlas.dtype)
-        samp = F.grid_sample(atlas, grid, mode="bilinear", padding_mode="zeros", align_corners=True)      # T,4,H,W
-        rgba = torch.sigmoid(samp)
-        cov = ((xm >= 0) & (xm <= mpi_w - 1) & (ym >= 0) & (ym <= mpi_h - 1)).to(atlas.dtype)
-        layers.append(rgba * cov[None, None])
-    layers = torch.stack(layers, dim=-1).permute(0, 2, 3, 4, 1)                   # T,H,W,D,4
+        samp = F.grid_sample(atlas, grid, mode="bilinear", padding_mode="zeros", align_corners=True)      # T,C,H,W
+        act = torch.cat([acts[0](samp[:, :-1]), acts[1](samp[:, -1:])], 1) if C > 1 else acts[0](samp)
+        cov = (xm >= 0) & (xm <= mpi_w - 1) & (ym >= 0) & (ym <= mpi_h - 1)
+        layers.append(act * cov[None, None].to(atlas.dtype))
+        covs.append(cov)
+    return torch.stack(layers, dim=-1).permute(0, 2, 3, 4, 1), torch.stack(covs, dim=-1)
+
+
+def render_atlas(atlas, homos, H, W, grid_h, mpi_h, mpi_w, pixel_center=0.5):
+    """atlas (T,4,Ah,Aw) pre-activation, homos [D,3,3] target pixel -> plane pixel -> rgb [T,H,W,3], alpha [T,H,W], layers."""
+    layers, _ = sample_atlas_layers(atlas, homos, H, W, grid_h, mpi_h, mpi_w, pixel_center)       # T,H,W,D,4
     rgb, bw = MO.overcompose(layers[..., 3], layers[..., :3])
     return rgb, bw.sum(-1), layers

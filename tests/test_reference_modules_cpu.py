@@ -1,0 +1,349 @@
+"""Module-level parity against what the reference's OWN MPI.py / MPV.py produce (goldens G14-G17, tests/golden/make_golden_r04.py):
+constructors, sparsify_faces + state_dict, init_from_mpi, and render / forward downstream of a harness rasteriser.  CPU only: the
+host-side product code (classifier, checkpoint reader, exporter, geometry) and the oracles (atlas_oracle, ckpt_oracle, mpv_oracle) are
+checked here; tests/test_gpu_reference_modules.py runs the HIP modules against the same goldens."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import refmod as RM
+from oracle import atlas_oracle as AO, ckpt_oracle as CO, mpv_oracle
+from videoloop3d_amd import export, tiles
+from videoloop3d_amd.MPV import atlas_to_stack, stack_to_atlas
+from videoloop3d_amd.utils_mpi import gen_mpi_vertices
+
+R4 = RM.R4
+
+
+# ---- G14: constructors ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["A", "B"])
+def test_g14_constructor_geometry(name):
+    from videoloop3d_amd.MPI import MPMesh
+    from videoloop3d_amd.MPV import MPMeshVid
+    g = RM.load("g14_constructors")
+    H, W, over = R4.SHAPES[name]
+    K, ref_extrin, _ = R4.scene(H, W)
+    args = R4.make_args(learn_loop_mask=True, mpv_frm_num=3, init_std=0.3, **over)
+    gh, D, hv, wv = args.atlas_grid_h, args.mpi_d, args.mpi_h_verts, args.mpi_w_verts
+    gw = D // gh
+    mpi = MPMesh(args, H, W, ref_extrin, K, 1.0, 100.0)
+    mpv = MPMeshVid(copy.copy(args), H, W, ref_extrin, K, 1.0, 100.0)
+    for tag, m in (("mpi", mpi), ("mpv", mpv)):
+        p = f"{name}_{tag}_"
+        Hs, Ws, ggh, ggw, Ah, Aw = (int(v) for v in g[p + "scalars"])
+        assert (m.H_start, m.W_start) == (Hs, Ws) and (ggh, ggw) == (gh, gw)
+        assert (Ah, Aw) == (gh * m.mpi_h, gw * m.mpi_w)                       # the atlas is the grid of the stack's planes
+        assert np.array_equal(m.planedepth.numpy(), g[p + "planedepth"])
+        assert np.array_equal(m.ref_intrin.numpy(), g[p + "ref_intrin"]) and np.array_equal(m.ref_extrin.numpy(), g[p + "ref_extrin"])
+        # vertices: the product's gen_mpi_vertices on the product's shifted intrinsics == the `verts` property; `_verts` under normalize_verts
+        verts = gen_mpi_vertices(m.mpi_h, m.mpi_w, m.ref_intrin_mpi, hv, wv, m.planedepth)
+        assert np.allclose(verts.numpy(), g[p + "verts_property"], rtol=1e-6, atol=1e-6)
+        sd = m.reference_state_dict()
+        assert np.allclose(sd["_verts"].numpy(), g[p + "_verts"], rtol=1e-6, atol=1e-6)
+    faces = export.quad_faces(D, hv, wv).reshape(-1, 3).numpy()
+    assert np.array_equal(faces, g[f"{name}_mpi_faces"]) and np.array_equal(faces, g[f"{name}_mpi_uvfaces"])
+    assert np.array_equal(faces, g[f"{name}_mpv_faces_dyn"]) and np.array_equal(faces, g[f"{name}_mpv_uvfaces_dyn"])
+    assert g[f"{name}_mpv_faces"].shape == (0, 3) and g[f"{name}_mpv_uvs"].shape == (0, 2)       # MPV.py:95-100: the static lists start empty
+    # UV layout: the oracle's restatement, and the product's per-axis closed form (tiles.cell_vertex_uvs), == the reference's tensors
+    uvs_o = AO.reference_vertex_uvs(gh, gw, hv, wv).reshape(-1, 2).numpy()
+    assert np.array_equal(uvs_o, g[f"{name}_mpi_uvs"]) and np.array_equal(uvs_o, g[f"{name}_mpv_uvs_dyn"])
+    u, v = tiles.cell_vertex_uvs(gw, wv), tiles.cell_vertex_uvs(gh, hv)
+    uv_p = torch.stack([u[None, :, None, :].expand(gh, gw, hv, wv), v[:, None, :, None].expand(gh, gw, hv, wv)], -1).reshape(-1, 2)
+    assert np.allclose(uv_p.numpy(), g[f"{name}_mpi_uvs"], atol=2e-7)
+    assert tuple(g[f"{name}_mpv_atlas_dyn_shape"]) == (3, 4, gh * mpv.mpi_h, gw * mpv.mpi_w)
+    assert tuple(g[f"{name}_mpi_atlas_mask_shape"]) == (1, 1, gh * mpi.mpi_h, gw * mpi.mpi_w)
+    assert float(g[f"{name}_mpv_dyn_alpha_init"].max()) == -2.0 == float(mpv.stack.detach()[..., 3].max())       # MPV.py:109-110
+    assert float(mpi.stack.detach()[..., 3].max()) == -3.0                                                          # MPI.py:33, 103
+
+
+# ---- G15: sparsify_faces --------------------------------------------------------------------------------------------------------
+def _quad_map(q, D, QH, QW):
+    m = torch.zeros((D, QH, QW), dtype=torch.bool)
+    q = torch.from_numpy(q).long()
+    m[q[:, 0], q[:, 1], q[:, 2]] = True
+    return m
+
+
+def _dense_product_mpi(g15, **kw):
+    from videoloop3d_amd.MPI import MPMesh
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    args = R4.make_args(learn_loop_mask=True, **over, **kw)
+    m = MPMesh(args, H, W, ref_extrin, K, 1.0, 100.0)
+    with torch.no_grad():      # identical weights: the reference's atlas of plane cells IS the product's stack, cell by cell
+        m.stack.copy_(atlas_to_stack(torch.from_numpy(g15["in_atlas"]), args.mpi_d, args.atlas_grid_h))
+        m.stack_mask.copy_(atlas_to_stack(torch.from_numpy(g15["in_atlas_mask"]), args.mpi_d, args.atlas_grid_h)[..., 0])
+    return m, args
+
+
+@pytest.mark.parametrize("rm", [0, 1])
+def test_g15_sparsify_classifies_like_the_reference(rm):
+    g = RM.load("g15_sparsify")
+    m, args = _dense_product_mpi(g, sparsify_rmfirstlayer=rm)
+    e, at, lt = g["thresh"]
+    m.sparsify_faces(erode_num=int(e), alpha_thresh=float(at), loop_thresh=float(lt))
+    D, QH, QW = args.mpi_d, args.mpi_h_verts - 1, args.mpi_w_verts - 1
+    pre = "rm1_" if rm else ""
+    ks, kd = _quad_map(g[pre + "quads_static"], D, QH, QW), _quad_map(g[pre + "quads_dyn"], D, QH, QW)
+    assert int(kd.sum()) >= 9 and int(ks.sum()) >= 9 and int((~(ks | kd)).sum()) >= 9          # all three classes are populated
+    assert torch.equal(m.quad_keep, ks | kd) and torch.equal(m.quad_dyn, kd)
+    assert m.is_sparse and m.has_dyn and not m.learn_loop_mask and not hasattr(m, "stack_mask")      # MPI.py:423-441
+    # the plane-by-plane variant (textures without an atlas layout) is a different rule: it must NOT be what sparsify_faces ran
+    a = m.alpha_activate(torch.where(torch.from_numpy(g["in_atlas"])[0, 3] == -3.0, torch.tensor(-10.0), torch.from_numpy(g["in_atlas"])[0, 3]))
+    cells = atlas_to_stack(a[None, None], D, args.atlas_grid_h)[:, 0, :, :, 0]
+    k2, _ = tiles.classify_quads(cells, None, QH, QW, int(e), float(at), float(lt), rm)
+    assert not torch.equal(k2, ks | kd)
+
+
+def test_g15_ckpt_oracle_packs_like_the_reference():
+    """oracle/ckpt_oracle.sparsify_atlas (the test-side restatement of MPI.py:288-442) == the reference's state_dict."""
+    g = RM.load("g15_sparsify")
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    e, at, lt = g["thresh"]
+    sd_o = CO.sparsify_atlas(torch.from_numpy(g["in_atlas"]), torch.from_numpy(g["in_atlas_mask"]), over["atlas_grid_h"], over["mpi_d"],
+                             over["mpi_h_verts"], over["mpi_w_verts"], int(e), float(at), float(lt))
+    sd = RM.state_dict_of(g, "sd_")
+    for k in ("faces", "uvfaces", "faces_dyn", "uvfaces_dyn"):
+        assert torch.equal(sd_o[k], sd[k]), k
+    for k in ("uvs", "uvs_dyn", "atlas", "atlas_dyn"):
+        assert sd_o[k].shape == sd[k].shape and float((sd_o[k] - sd[k]).abs().max()) <= 1e-6, k
+    for k in sd:
+        if k.startswith("self."):
+            assert sd_o[k] == sd[k], k
+
+
+def _check_state(out, sd, atol=1e-4):
+    for k, v in sd.items():
+        if torch.is_tensor(v):
+            o = out[k]
+            assert tuple(o.shape) == tuple(v.shape), (k, o.shape, v.shape)
+            if v.dtype in (torch.int64, torch.int32):
+                assert torch.equal(o.long(), v.long()), k
+            elif v.numel():
+                assert float((o.double() - v.double()).abs().max()) <= (atol if k.startswith("atlas") else 1e-6), k
+        else:
+            assert out[k] == v, (k, out[k], v)
+
+
+def test_g15_reader_and_exporter_round_trip_the_reference_checkpoint():
+    """tiles.stack_from_reference_state reads the reference's sparsified checkpoint texel for texel (tile lattice, quad maps) and
+    export.reference_state_dict writes the reference's layout back: every tensor and every "self.*" scalar of the REAL state_dict."""
+    from videoloop3d_amd.MPI import MPMesh
+    g = RM.load("g15_sparsify")
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    sd = RM.state_dict_of(g, "sd_")
+    hv, wv, D = over["mpi_h_verts"], over["mpi_w_verts"], over["mpi_d"]
+    st, keep, dyn = tiles.stack_from_reference_state(sd, 40, 60, hv, wv, 1)
+    th = sd["atlas"].shape[2] // sd["self.atlas_grid_h"]
+    assert st.shape == (D, 1, (hv - 1) * (th - 1) + 1, (wv - 1) * (th - 1) + 1, 4)
+    ks, kd = _quad_map(g["quads_static"], D, hv - 1, wv - 1), _quad_map(g["quads_dyn"], D, hv - 1, wv - 1)
+    assert torch.equal(keep, ks | kd) and torch.equal(dyn, kd)
+    # every tile texel of the checkpoint sits on its lattice texel (interiors exactly, duplicated borders to the fp32 jitter of the two copies)
+    (t_h, t_w), lists = tiles._aligned_tiles([("static", sd["faces"], sd["uvfaces"], sd["uvs"], sd["atlas"]),
+                                              ("dyn", sd["faces_dyn"], sd["uvfaces_dyn"], sd["uvs_dyn"], sd["atlas_dyn"])], hv, wv)
+    assert (t_h, t_w) == (th, th)
+    for kind, d, vy, vx, y0, x0, atlas in lists:
+        for i in range(0, len(d), 7):
+            tile = atlas[0, :, int(y0[i]):int(y0[i]) + th, int(x0[i]):int(x0[i]) + th].permute(1, 2, 0)
+            lat = st[int(d[i]), 0, int(vy[i]) * (th - 1):int(vy[i]) * (th - 1) + th, int(vx[i]) * (th - 1):int(vx[i]) * (th - 1) + th]
+            assert torch.equal(lat[1:-1, 1:-1], tile[1:-1, 1:-1]) and float((lat - tile).abs().max()) <= 1e-4
+    closed = torch.zeros(st.shape[0], *st.shape[2:4], dtype=torch.bool)           # closed texel rectangles of the kept quads
+    for d_, qy, qx in keep.nonzero().tolist():
+        closed[d_, qy * (th - 1):qy * (th - 1) + th, qx * (th - 1):qx * (th - 1) + th] = True
+    assert bool((st[:, 0, :, :, 3][~closed] == tiles.CULLED_ALPHA).all()) and bool((st[:, 0, :, :, 3][closed] > -50).all())
+    # through the module, and back out in the reference's layout
+    m = MPMesh(R4.make_args(learn_loop_mask=True, **over), H, W, ref_extrin, K, 1.0, 100.0)
+    m.init_from_mpi(sd)
+    assert m.is_sparse and not m.learn_loop_mask and torch.equal(m.quad_keep, keep)
+    assert m.spec.scale == ((st.shape[3] - 1) / 59, (st.shape[2] - 1) / 39)
+    _check_state(m.reference_state_dict(), sd)
+
+
+# ---- G16: MPMeshVid.init_from_mpi -----------------------------------------------------------------------------------------------
+def test_g16_init_from_mpi_of_the_sparsified_checkpoint():
+    from videoloop3d_amd.MPV import MPMeshVid
+    g15, g16 = RM.load("g15_sparsify"), RM.load("g16_init_from_mpi")
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    args = R4.make_args(mpv_frm_num=4, mpv_isloop=True, init_std=0.2, **over)
+    v = MPMeshVid(args, H, W, ref_extrin, K, 1.0, 100.0)
+    v.init_from_mpi(RM.state_dict_of(g15, "sd_"))                 # the stage-1 checkpoint (one frame) -> T frames (MPV.py:254-260)
+    ref = RM.state_dict_of(g16, "sparse_")
+    assert v.frm_num == 4 == ref["atlas_dyn"].shape[0] and v.stack.shape[1] == 4 and v.tile_full == (10, 10) and v.is_sparse and v.has_dyn
+    assert bool((v.stack.detach()[:, :1] == v.stack.detach()).all())          # every frame starts as the stage-1 texture
+    _check_state(v.reference_state_dict(), ref)
+    # ... and the stage-2 checkpoint itself (a T-frame dynamic atlas) reads back to the same model
+    v2 = MPMeshVid(R4.make_args(mpv_frm_num=2, mpv_isloop=True, init_std=0.2, **over), H, W, ref_extrin, K, 1.0, 100.0)
+    v2.init_from_mpi(ref)
+    assert v2.frm_num == 4 and float((v2.stack.detach() - v.stack.detach()).abs().max()) <= 1e-6 and torch.equal(v2.quad_dyn, v.quad_dyn)
+    # the product's own checkpoint of that model keeps the lattice (tile size) for lod()
+    v3 = MPMeshVid(copy.copy(args), H, W, ref_extrin, K, 1.0, 100.0)
+    v3.init_from_mpi(v.state_dict())
+    assert v3.tile_full == (10, 10) and torch.equal(v3.stack.detach(), v.stack.detach())
+    v3.lod(0.5)                                                    # tiles of max(int(10 * 0.5), 2) = 5 texels (MPV.py:146-151)
+    assert v3.stack.shape[2:4] == (4 * 4 + 1, 6 * 4 + 1)
+
+
+def test_g16_dense_checkpoint_loads_static_as_dynamic():
+    """MPV.py:266-288: a dense stage-1 checkpoint becomes the dynamic atlas of every frame.  The product resamples the cell atlas
+    (pitch (Aw-1)/(gw*(mpi_w-1))) onto its pitch-1 stack: == grid_sample of the atlas at the reference's UV of every plane pixel."""
+    from videoloop3d_amd.MPV import MPMeshVid
+    g15, g16 = RM.load("g15_sparsify"), RM.load("g16_init_from_mpi")
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    ref = RM.state_dict_of(g16, "dense_")
+    assert bool(g16["dense_atlas_dyn_equals_g15_atlas"]) and tuple(g16["dense_atlas_dyn_shape"]) == (4, 4, 80, 240)
+    assert ref["faces"].shape == (0, 3) and ref["atlas"].shape == (1, 4, 1, 1) and not ref["self.is_sparse"]       # dummy static lists
+    sd = dict(ref, atlas_dyn=torch.from_numpy(g15["in_atlas"]).expand(4, -1, -1, -1))
+    v = MPMeshVid(R4.make_args(mpv_frm_num=4, mpv_isloop=True, **over), H, W, ref_extrin, K, 1.0, 100.0)
+    v.init_from_mpi(sd)
+    assert not v.is_sparse and v.stack.shape == (8, 4, 40, 60, 4)
+    atlas = torch.from_numpy(g15["in_atlas"])
+    ym, xm = torch.meshgrid(torch.arange(40.), torch.arange(60.), indexing="ij")
+    for p in (0, 3, 7):
+        u, vv = AO.plane_uv(xm, ym, p, 2, 4, 40, 60)
+        want = torch.nn.functional.grid_sample(atlas, torch.stack([u, vv], -1)[None], mode="bilinear", align_corners=True)[0].permute(1, 2, 0)
+        assert float((v.stack.detach()[p, 2] - want).abs().max()) <= 1e-4        # fp32 UV arithmetic against an atlas of 240 texels
+
+
+# ---- G17: render / forward ------------------------------------------------------------------------------------------------------
+def _close(a, b, tol, what):
+    a, b = torch.as_tensor(a).detach().double(), torch.as_tensor(b).detach().double()
+    err = float((a - b).abs().max())
+    assert err <= tol, (what, err)
+
+
+def _close_grad(a, b, what, rel=3e-5):
+    """gradients: fp32 sums over thousands of pixels in another order -> relative to the largest entry."""
+    _close(a, b, rel * max(1.0, float(torch.as_tensor(b).abs().max())), what)
+
+
+@pytest.mark.parametrize("tag", ["a", "a2", "a3"])
+def test_g17_mpmesh_dense_forward_oracle(tag):
+    """mpv_oracle.mpi_forward on the reference's atlas == the reference's MPMesh.forward: rgb + loop-mask label, every regulariser
+    (a2 / a3: l_smooth, edge-weighted d_smooth, bg colour, normalised blend weights), gradients to both textures."""
+    g15, g = RM.load("g15_sparsify"), RM.load("g17_forward")
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    extra_kw = {"a": {}, "a2": dict(l_smooth_loss_weight=0.3, d_smooth_loss_weight=0.1, bg_color="0.2#0.4#0.6"),
+                "a3": dict(l_smooth_loss_weight=0.3, d_smooth_loss_weight=0.1, normalize_blendweight_fordepth=True)}[tag]
+    args = R4.make_args(learn_loop_mask=True, **over, **RM.REG, **extra_kw)
+    h, w, tar_e, K_crop, _ = RM.crop_view(g)
+    atlas = torch.from_numpy(g15["in_atlas"]).clone().requires_grad_(True)
+    mask = torch.from_numpy(g15["in_atlas_mask"]).clone().requires_grad_(True)
+    rgbl, extra = mpv_oracle.mpi_forward(atlas, mask, args, H, W, ref_extrin, K, 1.0, 100.0, h, w, tar_e, K_crop, atlas_grid_h=over["atlas_grid_h"])
+    _close(rgbl, g[f"{tag}_rgbl"], 2e-6, "rgbl")
+    keys = sorted(k[len(tag) + 7:] for k in g.files if k.startswith(f"{tag}_extra_"))
+    assert sorted(extra) == keys and ("l_smooth" in keys) == (tag != "a")
+    for k in keys:
+        _close(extra[k], g[f"{tag}_extra_{k}"], 2e-6 * max(1.0, float(abs(g[f"{tag}_extra_{k}"]).max())), k)
+    total = (rgbl * torch.from_numpy(g[f"{tag}_G"])).sum() + sum(getattr(args, k + "_loss_weight") * v.sum() for k, v in extra.items())
+    ga, gm = torch.autograd.grad(total, [atlas, mask])
+    _close_grad(ga, g[f"{tag}_grad_atlas"], "grad atlas")
+    _close_grad(gm, g[f"{tag}_grad_atlas_mask"], "grad mask")
+    assert float(abs(g[f"{tag}_grad_atlas_mask"]).max()) > 1e-3
+
+
+def test_g17_mpmesh_dense_variables_and_eval():
+    g15, g = RM.load("g15_sparsify"), RM.load("g17_forward")
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    args = R4.make_args(learn_loop_mask=True, d_smooth_loss_weight=0.1, **over, **RM.REG)
+    h, w, tar_e, K_crop, K_full = RM.crop_view(g)
+    atlas, mask = torch.from_numpy(g15["in_atlas"]), torch.from_numpy(g15["in_atlas_mask"])
+    rgbl, _ = mpv_oracle.mpi_forward(atlas, mask, args, H, W, ref_extrin, K, 1.0, 100.0, H, W, tar_e, K_full, training=False,
+                                     atlas_grid_h=over["atlas_grid_h"])
+    _close(rgbl, g["a_eval_rgbl_full"], 2e-6, "eval")
+    # the rasteriser's hit count per pixel == the number of planes the analytic coverage test finds, K = its maximum
+    p2f = torch.from_numpy(g["a_pix_to_face"])
+    assert int(g["a_num_layers"]) == int((p2f >= 0).sum(-1).max()) == p2f.shape[-1]
+
+
+def _lattice_case(g15, g, which):
+    """the sparsified reference checkpoint of case (b) / (d) on the tile lattice + what the reference's atlas gradients mean there."""
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    hv, wv, D = over["mpi_h_verts"], over["mpi_w_verts"], over["mpi_d"]
+    if which == "b":
+        sd, T = RM.state_dict_of(g15, "sd_"), 1
+    else:
+        sd = RM.state_dict_of(g15, "sd_", atlas_dyn=torch.from_numpy(g["d_atlas_dyn"]))
+        T = sd["atlas_dyn"].shape[0]
+    st, keep, dyn = tiles.stack_from_reference_state(sd, 40, 60, hv, wv, T)
+    g_dyn, g_static = RM.lattice_grad_from_reference(sd, hv, wv, D, T, torch.from_numpy(g[f"{which}_grad_atlas"]),
+                                                     torch.from_numpy(g[f"{which}_grad_atlas_dyn"]))
+    return st, keep, dyn, g_dyn, g_static
+
+
+def test_g17_mpmesh_sparsified_forward_oracle():
+    """MPI.py:544-548 (static + dynamic face lists) == the oracle on the tile lattice with the quad map: a sample in a culled quad is
+    not covered, the smoothness terms run over hit slots."""
+    g15, g = RM.load("g15_sparsify"), RM.load("g17_forward")
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    args = R4.make_args(**over, **RM.REG)
+    h, w, tar_e, K_crop, K_full = RM.crop_view(g)
+    st, keep, dyn, g_dyn, g_static = _lattice_case(g15, g, "b")
+    st = st.requires_grad_(True)
+    rgb, extra = mpv_oracle.mpi_forward(st, None, args, H, W, ref_extrin, K, 1.0, 100.0, h, w, tar_e, K_crop, quad_keep=keep)
+    _close(rgb, g["b_rgb"], 3e-6, "rgb")
+    for k in ("sparsity", "rgb_smooth", "a_smooth", "density"):
+        _close(extra[k], g[f"b_extra_{k}"], 3e-6, k)
+    assert int(g["b_num_layers"]) < over["mpi_d"]                  # culling made some slot unused everywhere: K < mpi_d enters the means
+    total = (rgb * torch.from_numpy(g["b_G"])).sum() + sum(getattr(args, k + "_loss_weight") * v.sum() for k, v in extra.items())
+    (gs,) = torch.autograd.grad(total, st)
+    _close_grad(gs[:, 0], g_dyn[:, 0] + g_static, "lattice gradient")
+    rgb_e, _ = mpv_oracle.mpi_forward(st.detach(), None, args, H, W, ref_extrin, K, 1.0, 100.0, H, W, tar_e, K_full, training=False, quad_keep=keep)
+    _close(rgb_e, g["b_eval_rgb_full"], 3e-6, "eval")
+    # without the quad map the same stack renders the same IMAGE (culled texels are transparent) but not the same regularisers
+    _, extra_nq = mpv_oracle.mpi_forward(st.detach(), None, args, H, W, ref_extrin, K, 1.0, 100.0, h, w, tar_e, K_crop)
+    assert abs(float(extra_nq["rgb_smooth"]) - float(g["b_extra_rgb_smooth"].item())) > 1e-3
+
+
+@pytest.mark.parametrize("which", ["other", "ref", "plain"])
+def test_g17_mpmeshvid_dense_forward_oracle(which):
+    g = RM.load("g17_forward")
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    bg = "0.2#0.4#0.6" if which == "ref" else ""
+    args = RM.mpv_args(5, bg=bg, regs={} if which == "plain" else RM.REG)
+    h, w, tar_e, K_crop, K_full = RM.crop_view(g)
+    res = torch.from_numpy(g["res"])
+    atlas = torch.from_numpy(g["c_atlas_dyn"]).clone().requires_grad_(True)
+    cfg = RM.LOSS_CFGS["other" if which == "plain" else which]
+    _, extra = mpv_oracle.mpv_forward(atlas, args, H, W, ref_extrin, K, 1.0, 100.0, h, w, tar_e, K_crop, res=res, losscfg=R4.collate(cfg),
+                                      atlas_grid_h=over["atlas_grid_h"])
+    keys = sorted(k[len(which) + 9:] for k in g.files if k.startswith(f"c_{which}_extra_"))
+    assert sorted(extra) == keys
+    for k in keys:
+        _close(extra[k], g[f"c_{which}_extra_{k}"], 3e-6 * max(1.0, float(abs(g[f"c_{which}_extra_{k}"]).max())), k)
+    total = sum(RM.MPV_WEIGHTS[k] * v.sum() for k, v in extra.items())
+    (ga,) = torch.autograd.grad(total, atlas)
+    _close_grad(ga, g[f"c_{which}_grad_atlas_dyn"], "grad atlas_dyn")
+    rgb, _ = mpv_oracle.mpv_forward(atlas.detach(), args, H, W, ref_extrin, K, 1.0, 100.0, H, W, tar_e, K_full, training=False,
+                                    atlas_grid_h=over["atlas_grid_h"])
+    _close(rgb, g[f"c_{which}_eval_rgb_full"], 3e-6, "eval")
+    rgb_ts, _ = mpv_oracle.mpv_forward(atlas.detach(), args, H, W, ref_extrin, K, 1.0, 100.0, h, w, tar_e, K_crop, ts=torch.tensor([3, 1]),
+                                       training=False, atlas_grid_h=over["atlas_grid_h"])
+    _close(rgb_ts, g[f"c_{which}_eval_rgb_crop_ts"], 3e-6, "eval ts")
+
+
+def test_g17_mpmeshvid_sparsified_forward_oracle():
+    g15, g = RM.load("g15_sparsify"), RM.load("g17_forward")
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    args = RM.mpv_args(5)
+    h, w, tar_e, K_crop, K_full = RM.crop_view(g)
+    res = torch.from_numpy(g["res"])
+    st, keep, dyn, g_dyn, g_static = _lattice_case(g15, g, "d")
+    assert st.shape[1] == 5 and float((st[:, 0] - st[:, 1]).abs().max()) > 0.1          # per-frame dynamic content
+    st = st.requires_grad_(True)
+    _, extra = mpv_oracle.mpv_forward(st, args, H, W, ref_extrin, K, 1.0, 100.0, h, w, tar_e, K_crop, res=res,
+                                      losscfg=R4.collate(RM.LOSS_CFGS["other"]), quad_keep=keep)
+    for k in ("swd", "sparsity", "rgb_smooth", "a_smooth", "density"):
+        _close(extra[k], g[f"d_extra_{k}"], 3e-6 * max(1.0, float(abs(g[f"d_extra_{k}"]).max())), k)
+    total = sum(RM.MPV_WEIGHTS[k] * v.sum() for k, v in extra.items())
+    (gs,) = torch.autograd.grad(total, st)
+    # the static atlas is ONE texture: its gradient is the lattice gradient summed over the frames (static texels), the dynamic atlas' is per frame
+    dyn_t = tiles.quad_to_texel_mask(dyn, *st.shape[2:4])
+    keep_t = tiles.quad_to_texel_mask(keep, *st.shape[2:4])
+    only_dyn = dyn_t & ~tiles.quad_to_texel_mask(keep & ~dyn, *st.shape[2:4])
+    scale = max(1.0, float(g_dyn.abs().max()))
+    _close(gs.sum(1), g_dyn.sum(1) + g_static, 3e-5 * scale, "frame-summed lattice gradient")
+    _close(gs[only_dyn[:, None].expand(-1, 5, -1, -1)], g_dyn[only_dyn[:, None].expand(-1, 5, -1, -1)], 3e-5 * scale, "dynamic texels per frame")
+    assert float(gs[~keep_t[:, None].expand(-1, 5, -1, -1)].abs().max()) == 0.0
+    rgb, _ = mpv_oracle.mpv_forward(st.detach(), args, H, W, ref_extrin, K, 1.0, 100.0, H, W, tar_e, K_full, training=False, quad_keep=keep)
+    _close(rgb, g["d_eval_rgb_full"], 3e-6, "eval")

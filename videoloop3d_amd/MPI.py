@@ -72,8 +72,9 @@ class MPMesh(nn.Module):
             self.stack_mask = nn.Parameter(torch.ones((self.mpi_d, 1, mpi_h, mpi_w)) * ALPHA_INIT_VAL, requires_grad=True)
         if args.rgb_activate not in ACTIVATES or args.alpha_activate not in ACTIVATES:
             raise RuntimeError(f"activation ({args.rgb_activate}, {args.alpha_activate}) not implemented by the HIP kernels")
+        self.texel_scale = tuple(float(v) for v in texel_scale)
         self.spec = dataclasses.replace(RenderSpec.mpv(rgb_act=args.rgb_activate, alpha_act=args.alpha_activate,
-                                                       scale=tuple(texel_scale)), pixel_center=float(pixel_center))
+                                                       scale=self.texel_scale), pixel_center=float(pixel_center))
         # the loop-mask pass: label = sigmoid(mask), alpha = the (detached) layer alpha with the model's activation
         self.spec_mask = dataclasses.replace(self.spec, rgb_act="sigmoid")
         self.alpha_activate = ACTIVATES[args.alpha_activate]
@@ -96,8 +97,16 @@ class MPMesh(nn.Module):
             m = self.stack_mask[:, 0].detach().clone()
             m[m == ALPHA_INIT_VAL] = -10                                                          # MPI.py:321
             loop = torch.sigmoid(m)
-        keep, dyn = tiles.classify_quads(alpha, loop, self.quad_h, self.quad_w, erode_num, alpha_thresh, loop_thresh,
-                                         int(getattr(self.args, "sparsify_rmfirstlayer", 0)))
+        grid_h = int(getattr(self.args, "atlas_grid_h", 0))
+        rm = int(getattr(self.args, "sparsify_rmfirstlayer", 0))
+        if grid_h > 0 and self.mpi_d % grid_h == 0 and tuple(self.stack.shape[2:4]) == (self.mpi_h, self.mpi_w):
+            # the reference's classification as it runs it: morphology on the ATLAS of plane cells, quads judged by their tile samples
+            # (same kept / dynamic quads as MPI.py:288-356 on identical weights: golden G15)
+            keep, dyn = tiles.classify_quads_atlas(alpha.cpu(), None if loop is None else loop.cpu(), grid_h, self.quad_h + 1, self.quad_w + 1,
+                                                   erode_num, alpha_thresh, loop_thresh, rm)
+            keep, dyn = keep.to(alpha.device), dyn.to(alpha.device)
+        else:
+            keep, dyn = tiles.classify_quads(alpha, loop, self.quad_h, self.quad_w, erode_num, alpha_thresh, loop_thresh, rm)
         n_quad, n_mask, n_dyn = keep.numel(), int(keep.sum()), int(dyn.sum())
         print(f"mask {n_mask} / {n_quad} ({100 * n_mask / n_quad:.2f}%) quads")
         print(f"   of {n_mask}, {n_dyn} ({100 * n_dyn / max(n_mask, 1):.2f}%) is dynamic quads")
@@ -161,12 +170,23 @@ class MPMesh(nn.Module):
         self.planedepth.data = state_dict['planedepth'].type_as(self.planedepth)
         self.ref_intrin_mpi.data = get_new_intrin(self.ref_intrin, -self.H_start, -self.W_start)
         st = state_dict["stack"]
-        if tuple(st.shape) != tuple(self.stack.shape):
+        if st.dim() != 5 or st.shape[0] != self.mpi_d or st.shape[1] != 1 or st.shape[-1] != 4:
             raise RuntimeError(f"checkpoint stack {tuple(st.shape)} does not match this model's {tuple(self.stack.shape)}")
         with torch.no_grad():
-            self.stack.copy_(st.to(dev))
+            if tuple(st.shape) != tuple(self.stack.shape):
+                # another texture resolution over the same plane extent (a sparsified reference checkpoint on its tile lattice): the
+                # plane-pixel -> texel scale follows the texture size, as in MPMeshVid.init_from_mpi / lod
+                if "stack_mask" in state_dict and hasattr(self, "stack_mask"):
+                    raise RuntimeError("a loop-mask texture needs the stack's resolution")
+                self.stack = nn.Parameter(st.to(dev, torch.float32).contiguous(), requires_grad=True)
+            else:
+                self.stack.copy_(st.to(dev))
             if "stack_mask" in state_dict and hasattr(self, "stack_mask"):
                 self.stack_mask.copy_(state_dict["stack_mask"].to(dev))
+        hs, ws = self.stack.shape[2:4]
+        self.spec = dataclasses.replace(self.spec, scale=(self.texel_scale[0] * (ws - 1) / max(self.mpi_w - 1, 1),
+                                                          self.texel_scale[1] * (hs - 1) / max(self.mpi_h - 1, 1)))
+        self.spec_mask = dataclasses.replace(self.spec, rgb_act="sigmoid")
         self.is_sparse = bool(state_dict.get("self.is_sparse", False))
         self.has_dyn = bool(state_dict.get("self.has_dyn", False))
         if self.is_sparse:
@@ -215,6 +235,10 @@ class MPMesh(nn.Module):
         """MPI.py:452-594 -> (rgbl [B,H,W,3|4], variables).  One fused render per view (the kernels share one camera per call)."""
         B = len(extrin)
         rgbs, alphas, labels, ssums, asums = [], [], [], [], []
+        # a sparsified model (train_3d.py:282-285: the last epochs of stage 1 train it) renders with its quad map: a sample inside a culled
+        # quad is NOT covered by that plane -- no face there in the reference (MPI.py:483-487, 544-548) -- so the slot-ordered smoothness
+        # terms skip it and workgroups skip the planes of which they see no kept quad
+        qk = self.quad_keep if (self.is_sparse and getattr(self, "quad_keep", None) is not None) else None
         # the loop mask rides the colour pass as a fifth channel where the kernels are built for it (the shipped planar convention, a CUDA
         # stack); args.loop_mask_two_pass keeps the separate label pass (A/B, cross-checks)
         fused_mask = (self.learn_loop_mask and self.stack.is_cuda and mask_channel_supported(self.stack, self.spec)
@@ -240,11 +264,11 @@ class MPMesh(nn.Module):
                     ssums.append(ss)
                     asums.append(asum)
             elif need_reg:
-                rgb, alpha, ss, asum = render_planes_with_regularisers(self.stack, homos, H, W, self.spec)
+                rgb, alpha, ss, asum = render_planes_with_regularisers(self.stack, homos, H, W, self.spec, quad_keep=qk)
                 ssums.append(ss)
                 asums.append(asum)
             else:
-                rgb, alpha = render_planes(self.stack, homos, H, W, self.spec)
+                rgb, alpha = render_planes(self.stack, homos, H, W, self.spec, quad_keep=qk)
             if len(self.args.bg_color) > 0:                                                       # MPI.py:550-556
                 if self.args.bg_color == "random":
                     bg = torch.rand(3).type_as(rgb)

@@ -169,6 +169,7 @@ class MPMeshVid(nn.Module):
         self._static_compact = False
         self._window_opt = None          # the crop-aware Adam handed out by get_optimizer (dense CUDA models)
         self.packed = None               # packed.PackedLayout once pack_() has replaced the dense stack by the pool `stack_pool`
+        self.tile_full = None            # (th, tw): texels per quad of a model loaded from a sparsified REFERENCE checkpoint (tile lattice)
 
         self.swd_patch_size, self.swd_patcht_size = args.swd_patch_size, args.swd_patcht_size
         self.swd_stride, self.swd_stridet = args.swd_stride, args.swd_stridet
@@ -245,14 +246,18 @@ class MPMeshVid(nn.Module):
             hv, wv = int(self.args.mpi_h_verts), int(self.args.mpi_w_verts)
             st, keep, dyn = tiles.stack_from_reference_state(state_dict, self.mpi_h, self.mpi_w, hv, wv, self.frm_num)
             sparse = bool(state_dict.get("self.is_sparse", False))
+            # a sparsified checkpoint arrives on its tile lattice (identical weights); the tile size drives lod() like the reference's (MPV.py:146-151)
+            tile = ((st.shape[2] - 1) // (hv - 1) + 1, (st.shape[3] - 1) // (wv - 1) + 1) if tuple(st.shape[2:4]) != (self.mpi_h, self.mpi_w) else None
             state_dict = {"ref_extrin": state_dict["ref_extrin"], "ref_intrin": state_dict["ref_intrin"],
                           "planedepth": state_dict["planedepth"], "stack": st, "quad_keep": keep, "quad_dyn": dyn,
-                          "self.is_sparse": sparse, "self.has_dyn": sparse}
+                          "self.is_sparse": sparse, "self.has_dyn": sparse, "self.tile_full": tile}
         self.ref_extrin.data = state_dict['ref_extrin'].type_as(self.ref_extrin)
         self.ref_intrin.data = state_dict['ref_intrin'].type_as(self.ref_intrin)
         self.planedepth.data = state_dict['planedepth'].type_as(self.planedepth)
         self.ref_intrin_mpi.data = get_new_intrin(self.ref_intrin, -self.H_start, -self.W_start)
         dev = self._param().device
+        tf = state_dict.get("self.tile_full", None)
+        self.tile_full = None if tf is None else (int(tf[0]), int(tf[1]))
         if "stack_pool" in state_dict:       # a checkpoint of a packed model of this package: quad maps + dims rebuild the block table
             from .packed import PackedLayout
             D, T, hs, ws = (int(v) for v in state_dict["self.packed_dims"])
@@ -330,6 +335,8 @@ class MPMeshVid(nn.Module):
         sd = super().state_dict(*args, **kwargs)
         sd["self.is_sparse"] = self.is_sparse
         sd["self.has_dyn"] = self.has_dyn
+        if self.tile_full is not None:
+            sd["self.tile_full"] = self.tile_full
         if self.packed is not None:
             sd["self.packed_dims"] = self.stack_dims()      # with quad_keep / quad_dyn this rebuilds the block table (init_from_mpi)
         return sd
@@ -344,6 +351,12 @@ class MPMeshVid(nn.Module):
         self._flush_deferred_updates()
         self._window_opt = None          # the parameter object changes: the driver asks for a new optimiser (train_3dvid.py:264-265)
         h, w = max(int(self.mpi_h * factor), 2), max(int(self.mpi_w * factor), 2)
+        if self.tile_full is not None:
+            # a model on the reference's tile lattice: every quad holds max(int(tile * factor), 2) texels per axis at this level, as the
+            # reference resizes its tiles (MPV.py:146-151); neighbouring quads share their border texels
+            qh, qw = int(self.args.mpi_h_verts) - 1, int(self.args.mpi_w_verts) - 1
+            h = qh * (max(int(self.tile_full[0] * factor), 2) - 1) + 1
+            w = qw * (max(int(self.tile_full[1] * factor), 2) - 1) + 1
         D, T, hs, ws = self.stack_dims()
         print(f"MPV.lod:: Resizing the planes from {(hs, ws)} to {(h, w)}")
         if (hs, ws) != (h, w) and self.packed is not None:

@@ -48,9 +48,72 @@ def quad_max(img, QH, QW):
     return out
 
 
+def cell_vertex_uvs(grid, verts):
+    """one axis of the reference's vertex UVs (MPI.py:75-81): cell origins k/grid*2-1, vertices at linspace(0,1,verts) of the cell extent
+    (1 - the last origin), in float32 like the reference -> [grid, verts]."""
+    origin = torch.arange(grid, dtype=torch.float32) / grid * 2 - 1
+    return origin[:, None] + torch.linspace(0, 1, verts)[None] * (1 - origin[-1])
+
+
+def tile_lattice(grid, verts, atlas_size):
+    """the per-quad sample lattice `sparsify_faces` cuts out of the atlas along one axis (MPI.py:296-313): n = round(quad UV extent / 2 *
+    (atlas_size - 1)) samples from the quad's first vertex over its UV extent -> (n, atlas texel coordinates [grid, verts-1, n] float32)."""
+    uv = cell_vertex_uvs(grid, verts)
+    ext = float(uv[0, 1] - uv[0, 0])
+    n = int(round(ext / 2 * (atlas_size - 1)))
+    pos = uv[:, :-1, None] + torch.linspace(0, ext, n)[None, None]
+    return n, pos
+
+
+def classify_quads_atlas(alpha, loopmask, grid_h, hv, wv, erode_num=2, alpha_thresh=0.03, loop_thresh=0.5, rmfirstlayer=0):
+    """The reference's tile classification, as it runs it (MPI.py:288-356, pinned by golden G15): the D planes are laid out as the
+    grid_h x (D / grid_h) cells of ONE atlas, the erosions / dilations run on that atlas (so neighbouring cells -- other planes -- bleed
+    into each other at cell borders and only the atlas border erodes), every quad is then cut out as a tile of bilinear samples
+    (`tile_lattice`, grid_sample, align_corners=True) and classified by its largest sample.  `sparsify_rmfirstlayer` zeroes the first
+    mpi_h_verts * mpi_w_verts * rm TILES (MPI.py:343-346 as written: vertices per plane, not quads per plane).
+    alpha, loopmask: activated [D,H,W] maps (loopmask None: everything kept is dynamic) -> (keep, dyn) bool [D,hv-1,wv-1]."""
+    D, H, W = alpha.shape
+    if D % grid_h != 0:
+        raise RuntimeError("mpi_d and atlas_grid_h should match")                       # MPI.py:46
+    gw = D // grid_h
+    QH, QW = hv - 1, wv - 1
+
+    def to_atlas(m):
+        return m.reshape(grid_h, gw, H, W).permute(0, 2, 1, 3).reshape(1, 1, grid_h * H, gw * W).float()
+
+    nh, ty = tile_lattice(grid_h, hv, grid_h * H)                                      # [gh,QH,nh] normalised v
+    nw, tx = tile_lattice(gw, wv, gw * W)                                              # [gw,QW,nw] normalised u
+    # one grid_sample over all tiles: rows = (cell row, quad row, sample), columns = (cell column, quad column, sample)
+    grid = torch.stack([tx.reshape(1, -1).expand(grid_h * QH * nh, -1), ty.reshape(-1, 1).expand(-1, gw * QW * nw)], -1)[None]
+
+    def tile_max(atlas):
+        samp = F.grid_sample(atlas, grid.to(atlas.dtype), mode="bilinear", padding_mode="zeros", align_corners=True)[0, 0]
+        samp = samp.reshape(grid_h, QH, nh, gw, QW, nw).amax((2, 5))                    # gh,QH,gw,QW
+        return samp.permute(0, 2, 1, 3).reshape(D, QH, QW)
+
+    a = to_atlas(alpha)
+    for _ in range(erode_num):
+        a = erode(a)
+    for _ in range(erode_num + 2):
+        a = dilate(a)
+    qa = tile_max(a)
+    if rmfirstlayer > 0:
+        qa.reshape(-1)[:hv * wv * rmfirstlayer] = 0
+    keep = qa > alpha_thresh
+    if loopmask is None:
+        return keep, keep.clone()
+    m = to_atlas(loopmask)
+    for _ in range(erode_num):
+        m = erode(m)
+    for _ in range(erode_num):
+        m = dilate(m)
+    return keep, keep & (tile_max(m) > loop_thresh)
+
+
 def classify_quads(alpha, loopmask, QH, QW, erode_num=2, alpha_thresh=0.03, loop_thresh=0.5, rmfirstlayer=0):
-    """MPI.py:319-356.  alpha, loopmask: activated [D,H,W] maps in [0,1] (loopmask may be None: everything kept is dynamic).
-    -> (keep, dyn) bool [D,QH,QW]."""
+    """Plane-by-plane variant of `classify_quads_atlas` for textures that have no atlas layout (no bleeding between planes; a quad is
+    judged by the texels of its closed rectangle).  alpha, loopmask: activated [D,H,W] maps in [0,1] (loopmask may be None: everything
+    kept is dynamic).  -> (keep, dyn) bool [D,QH,QW].  MPMesh.sparsify_faces uses the atlas variant whenever args.atlas_grid_h divides mpi_d."""
     a = alpha[None]
     for _ in range(erode_num):
         a = erode(a)
@@ -208,11 +271,83 @@ def _decode_quads(faces, uvfaces, uvs, hv, wv):
     return d, rem // wv, rem % wv, uvs[uq[:, 0, 0]], uvs[uq[:, 0, 2]]
 
 
-def stack_from_reference_state(sd, mpi_h, mpi_w, hv, wv, frm_num):
-    """Reference state_dict (stage-1 MPMesh or stage-2 MPMeshVid, sparsified or not) -> (stack (D,T,mpi_h,mpi_w,4) float32 on CPU,
-    quad_keep, quad_dyn [D,hv-1,wv-1] bool).  Static quads are written into every frame, culled texels get CULLED_ALPHA."""
+def _aligned_tiles(parts, hv, wv):
+    """If every quad of the checkpoint is a texel-aligned tile of ONE common size -- what `sparsify_faces` writes (MPI.py:403-418:
+    tile k of an atlas at texels [ky*th, ky*th + th - 1] x [kx*tw, kx*tw + tw - 1], corner UVs on texel centres) -- return
+    ((th, tw), [(kind, d, vy, vx, y0, x0, atlas)]) with integer tile origins; else None."""
+    size, out = None, []
+    for kind, faces, uvfaces, uvs, atlas in parts:
+        if faces is None or faces.numel() == 0:
+            continue
+        d, vy, vx, uv0, uv3 = _decode_quads(faces, uvfaces, uvs, hv, wv)
+        Ah, Aw = atlas.shape[-2:]
+        x0, x1 = (uv0[:, 0].double() + 1) / 2 * (Aw - 1), (uv3[:, 0].double() + 1) / 2 * (Aw - 1)
+        y0, y1 = (uv0[:, 1].double() + 1) / 2 * (Ah - 1), (uv3[:, 1].double() + 1) / 2 * (Ah - 1)
+        c = torch.stack([x0, x1, y0, y1])
+        if float((c - c.round()).abs().max()) > 1e-3:
+            return None
+        tw, th = (c[1] - c[0]).round().long() + 1, (c[3] - c[2]).round().long() + 1
+        if size is None:
+            size = (int(th[0]), int(tw[0]))
+        if bool((th != size[0]).any()) or bool((tw != size[1]).any()) or min(size) < 2:
+            return None
+        out.append((kind, d, vy, vx, c[2].round().long(), c[0].round().long(), atlas.detach().float().cpu()))
+    return None if size is None else (size, out)
+
+
+def _stack_on_tile_lattice(aligned, D, T, QH, QW):
+    """tiles of th x tw texels -> the plane lattice of QH*(th-1)+1 x QW*(tw-1)+1 texels on which neighbouring quads share their border
+    row / column (the same samples: `sparsify_faces` cuts neighbouring tiles from the same atlas positions).  Where tiles overlap the
+    dynamic tile's texels win over a static tile's, equals are averaged (identical in a fresh checkpoint; a trained stage-2 checkpoint's
+    duplicated border texels have drifted apart by what the optimiser made of their separate gradients)."""
+    (th, tw), lists = aligned
+    Hl, Wl = QH * (th - 1) + 1, QW * (tw - 1) + 1
+    acc = {k: [torch.zeros((D, Hl, Wl, T, 4)), torch.zeros((D, Hl, Wl, 1, 1))] for k in ("static", "dyn")}
+    iy, ix = torch.arange(th), torch.arange(tw)
+    for kind, d, vy, vx, y0, x0, atlas in lists:
+        A = atlas.shape[0]
+        ay = (y0[:, None] + iy[None])[:, :, None].expand(-1, th, tw)                                # n,th,tw atlas rows
+        ax = (x0[:, None] + ix[None])[:, None, :].expand(-1, th, tw)
+        tl = atlas[:, :, ay, ax].permute(2, 0, 3, 4, 1)                                              # n,A,th,tw,4
+        if A == 1:
+            tl = tl.expand(-1, T, -1, -1, -1)
+        elif A != T:
+            raise RuntimeError(f"checkpoint atlas holds {A} frames, expected 1 or {T}")
+        ly = (vy[:, None] * (th - 1) + iy[None])[:, :, None].expand(-1, th, tw)
+        lx = (vx[:, None] * (tw - 1) + ix[None])[:, None, :].expand(-1, th, tw)
+        dd = d[:, None, None].expand(-1, th, tw)
+        acc[kind][0].index_put_((dd, ly, lx), tl.permute(0, 2, 3, 1, 4), accumulate=True)
+        acc[kind][1].index_put_((dd, ly, lx), torch.ones((len(d), th, tw, 1, 1)), accumulate=True)
+    stack = torch.zeros((D, Hl, Wl, T, 4))
+    stack[..., 3] = CULLED_ALPHA
+    for kind in ("static", "dyn"):
+        val, cnt = acc[kind]
+        stack = torch.where(cnt > 0, val / cnt.clamp_min(1), stack)
+    return stack.permute(0, 3, 1, 2, 4).contiguous()
+
+
+def stack_from_reference_state(sd, mpi_h, mpi_w, hv, wv, frm_num, lattice=True):
+    """Reference state_dict (stage-1 MPMesh or stage-2 MPMeshVid, sparsified or not) -> (stack (D,T,Hs,Ws,4) float32 on CPU, quad_keep,
+    quad_dyn [D,hv-1,wv-1] bool).  Static quads are written into every frame, culled texels get CULLED_ALPHA.
+    lattice (default): a SPARSIFIED checkpoint (texel-aligned tiles of one size, MPI.py:364-436) is copied texel for texel onto the tile
+    lattice, Hs x Ws = (hv-1)*(th-1)+1 x (wv-1)*(tw-1)+1 -- the reference's own stage-2 resolution (its `lod` resizes tiles, MPV.py:146-163);
+    the planes keep their extent, so the caller renders with texel scale (Ws-1)/(mpi_w-1).  Identical weights, identical image
+    (golden G17).  Otherwise (dense cell atlases, lattice=False): bilinear resampling onto the (mpi_h, mpi_w) grid of pitch 1."""
     D = int(sd["planedepth"].numel())
     QH, QW = hv - 1, wv - 1
+    if lattice and "faces_dyn" in sd and bool(sd.get("self.is_sparse", False)):
+        parts_ = [("static", sd.get("faces"), sd.get("uvfaces"), sd.get("uvs"), sd.get("atlas")),
+                  ("dyn", sd["faces_dyn"], sd["uvfaces_dyn"], sd["uvs_dyn"], sd["atlas_dyn"])]
+        aligned = _aligned_tiles(parts_, hv, wv)
+        if aligned is not None:
+            T_ = int(sd["atlas_dyn"].shape[0]) if sd["atlas_dyn"].shape[0] > 1 else frm_num
+            keep = torch.zeros((D, QH, QW), dtype=torch.bool)
+            dyn = torch.zeros((D, QH, QW), dtype=torch.bool)
+            for kind, d, vy, vx, *_ in aligned[1]:
+                keep[d, vy, vx] = True
+                if kind == "dyn":
+                    dyn[d, vy, vx] = True
+            return _stack_on_tile_lattice(aligned, D, T_, QH, QW), keep, dyn
     ch, cw = (mpi_h - 1) / QH, (mpi_w - 1) / QW
     has_dyn_lists = "faces_dyn" in sd
     parts = [("static", sd.get("faces"), sd.get("uvfaces"), sd.get("uvs"), sd.get("atlas"))]
