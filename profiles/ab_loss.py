@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""In-process A/B of the patch-NN kernel variants (VL3D_LOSS_VARIANT bits) on resident 720p clips: NN search time per variant.
+"""In-process A/B of the patch-NN kernel variants (utils_vid.KERNEL_VARIANT bits) on resident 720p clips: NN search time per variant.
   python profiles/ab_loss.py 0,0x80 [rounds]"""
 import os, statistics, sys, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,6 +7,7 @@ import torch
 import __graft_entry__ as ge
 ge.build()
 from videoloop3d_amd import synth
+from videoloop3d_amd import utils_vid as UV
 from videoloop3d_amd.utils_vid import find_nn_indices
 variants = [int(v, 0) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,0x80").split(",")]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
@@ -17,7 +18,7 @@ for name, (ps, s, al) in {"ref": (11, 4, 0.0), "other": (3, 2, None)}.items():
     res = {v: [] for v in variants}
     for r in range(rounds + 1):
         for v in variants:
-            os.environ["VL3D_LOSS_VARIANT"] = str(v)
+            UV.KERNEL_VARIANT = v
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             nn = find_nn_indices(x, y, ps, 3, s, 1, al)[0]

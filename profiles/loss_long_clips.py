@@ -1,6 +1,7 @@
 import sys, os, time, torch
 sys.path.insert(0, ".")
 from videoloop3d_amd import synth
+from videoloop3d_amd import utils_vid as UV
 from videoloop3d_amd.utils_vid import Patch3DGPNNLowMemLoss
 dev = torch.device("cuda:0")
 H, W = 719, 1279
@@ -10,7 +11,7 @@ for Tx, Ty in clips:
     x = synth.make_video(Tx, H, W, seed=3, device=dev).requires_grad_(True)
     y = synth.make_video(Ty, H, W, seed=4, device=dev)
     for variant in variants:
-        os.environ["VL3D_LOSS_VARIANT"] = variant
+        UV.KERNEL_VARIANT = int(variant, 0)
         L = Patch3DGPNNLowMemLoss()
         def step():
             loss = L(x, y, macro_block=65, patch_size=11, stride=4, patcht_size=3, stridet=1, rou="-2", scaling=0.1, alpha=0.5)

@@ -103,6 +103,67 @@ __global__ __launch_bounds__(RX *RY) void bwd_like_k(const f4 *__restrict__ src,
     }
 }
 
+// HALO-ATOMICS backward (SURVEY §7's design, priced in round 4): NO halo -- a workgroup sweeps exactly the RX x RY pixels it owns (x1.00
+// instead of x1.22 pixels swept per pixel owned) -- so a texel whose 3 x 3 gathering pixels straddle a tile border gets a PARTIAL sum from
+// each side: the tile's perimeter threads add theirs with float atomics (4 x global_atomic_add_f32 per 16-byte texel) to their own
+// texel AND to the texel across the border (owned by the neighbour, who needs this tile's share), interior threads keep the plain
+// non-temporal store.  The ring's texels must start from zero: ZERO = 1 charges that fill to the kernel's own time (a pre-pass writes
+// the perimeter texels of every tile, as the owner-table pre-pass would).  Sums arrive in any order: not bitwise reproducible.
+template <int RX, int RY, int FR, int TAPS>
+__global__ __launch_bounds__(RX *RY) void bwd_like_ha_k(const f4 *__restrict__ src, f4 *__restrict__ dst, const unsigned short *__restrict__ owner, int D,
+                                                        int T, int Hs, int Ws, int tiles_x, int tiles_y) {
+    const int b = blockIdx.x;
+    const int q = gridDim.x >> 3, r = gridDim.x & 7, xcd = b & 7, k = b >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    const int tile_x = bid % tiles_x, rest = bid / tiles_x, tile_y = rest % tiles_y, t0 = (rest / tiles_y) * FR;
+    const int lx = threadIdx.x % RX, ly = threadIdx.x / RX;
+    const int gx = tile_x * RX + lx, gy = tile_y * RY + ly;
+    const int x = min(max(gx, 1), Ws - 3), y = min(max(gy, 1), Hs - 3);
+    const bool live = gx < Ws && gy < Hs;
+    const bool ring = lx == 0 || lx == RX - 1 || ly == 0 || ly == RY - 1;
+    // the texel across the border this perimeter thread also contributes to (corners: the row neighbour; the diagonal's share is 1/16 of the
+    // ring and would only add atomics)
+    const int nb = ly == 0 ? -Ws : (ly == RY - 1 ? Ws : (lx == 0 ? -1 : 1));
+    const size_t frame = (size_t)Hs * Ws, plane = (size_t)T * frame;
+    size_t o = (size_t)t0 * frame + (size_t)y * Ws + x;
+    size_t oo = (size_t)y * Ws + x;
+    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < D; ++d, o += plane, oo += frame) {
+        f4 v[FR];
+        const unsigned e = owner[oo];
+#pragma unroll
+        for (int f = 0; f < FR; ++f) {
+            v[f] = src[o + f * frame];
+            if constexpr (TAPS == 4) v[f] += src[o + f * frame + 1] + src[o + f * frame + Ws] + src[o + f * frame + Ws + 1];
+        }
+        if (live) {
+#pragma unroll
+            for (int f = 0; f < FR; ++f) {
+                const f4 g = v[f] + acc;
+                if (!ring) {
+                    __builtin_nontemporal_store(g, &dst[o + f * frame]);
+                } else {
+                    float *p0 = reinterpret_cast<float *>(&dst[o + f * frame]), *p1 = reinterpret_cast<float *>(&dst[o + f * frame + nb]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { unsafeAtomicAdd(p0 + c, g[c]); unsafeAtomicAdd(p1 + c, g[c] * 0.5f); }
+                }
+            }
+        }
+        acc.x += (float)e;
+    }
+}
+// the zero fill the ring needs before the atomics: the perimeter texels (and the row / column across the border) of every tile, all planes and frames
+template <int RX, int RY>
+__global__ __launch_bounds__(256) void ha_zero_ring_k(f4 *__restrict__ dst, int D, int T, int Hs, int Ws) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= Ws || y >= Hs) return;
+    const int mx = x % RX, my = y % RY;
+    if (!(mx == 0 || mx == RX - 1 || my == 0 || my == RY - 1)) return;
+    const size_t frame = (size_t)Hs * Ws;
+    f4 *g = dst + (size_t)blockIdx.z * T * frame + (size_t)y * Ws + x;
+    for (int t = 0; t < T; ++t, g += frame) __builtin_nontemporal_store(f4{0.f, 0.f, 0.f, 0.f}, g);
+}
+
 // the same pattern on a FRAME-PAIR INTERLEAVED layout (D, T/2, Hs, Ws, 2 frames, 4): a thread's two frames are 32 contiguous bytes,
 // a wave's row segment is 2 KiB (region 64 wide) or 1 KiB (32 wide) -- what a pair kernel would stream if the stack were stored so.
 template <int RX, int RY, bool OWNER, int STORE, int SNAP>
@@ -196,7 +257,8 @@ static void run(const char *name, F launch, double bytes) {
 }
 
 int main(int argc, char **argv) {
-    const bool aligned_only = argc > 1 && argv[1][0] == 'a';      // ./rw_bw aligned: only the aligned-ownership comparison at the end
+    const bool aligned_only = argc > 1 && (argv[1][0] == 'a' || argv[1][0] == 'h');      // ./rw_bw aligned | halo: only that comparison at the end
+    const bool halo_only = argc > 1 && argv[1][0] == 'h';
     const size_t unit = 8ull << 30, n = unit / 16;     // 8 GiB per stream
     f4 *src, *dst;
     if (hipMalloc(&src, 3 * unit) != hipSuccess || hipMalloc(&dst, 3 * unit) != hipSuccess) { printf("alloc failed\n"); return 1; }
@@ -270,6 +332,38 @@ int main(int argc, char **argv) {
         BLS(64, 16, 1, 0, 8) BLS(64, 16, 1, 1, 8) BLS(64, 16, 1, 2, 8) BLS(64, 16, 1, 3, 8)
         BLS(64, 8, 1, 0, 8) BLS(64, 8, 1, 1, 8) BLS(64, 8, 1, 2, 8) BLS(128, 8, 1, 0, 8) BLS(128, 8, 1, 2, 8) BLS(128, 4, 1, 0, 8) BLS(128, 4, 1, 2, 8)
     }
+    }
+    // Halo-atomics backward against the shipped halo pattern (round 4), same geometry, algorithmic bytes as the unit.
+    if (halo_only) {
+        const int D = 32, T = 12, Hs = 720, Ws = 1280;
+        const double bytes = 2.0 * D * T * Hs * Ws * 16;
+        unsigned short *owner;
+        hipMalloc(&owner, (size_t)D * Hs * Ws * 2 + 4096);
+        hipMemset(owner, 0, (size_t)D * Hs * Ws * 2 + 4096);
+#define BLH(RX, RY, FR, ZERO)                                                                                                  \
+        {                                                                                                                      \
+            const int tx = (Ws + RX - 1) / RX, ty = (Hs + RY - 1) / RY;                                                        \
+            snprintf(name, sizeof name, "bwd_like HALO-ATOMICS  region %3d x %2d  frames %d  ring = %4.1f %% of the texels  zero fill %s", RX, RY, FR, \
+                     100.0 * (2.0 * RX + 2.0 * RY - 4) / (RX * RY), ZERO ? "timed" : "free ");                                  \
+            run(name, [&] { if (ZERO) hipLaunchKernelGGL((ha_zero_ring_k<RX, RY>), dim3((Ws + 63) / 64, (Hs + 3) / 4, D), dim3(256), 0, 0, dst, D, T, Hs, Ws); \
+                            hipLaunchKernelGGL((bwd_like_ha_k<RX, RY, FR, 4>), dim3((unsigned)(tx * ty * (T / FR))), dim3(RX * RY), 0, 0, src, dst, \
+                                               owner, D, T, Hs, Ws, tx, ty); }, bytes);                                        \
+        }
+#define BLREF(RX, RY, FR)                                                                                                      \
+        {                                                                                                                      \
+            const int tx = (Ws + RX - 3) / (RX - 2), ty = (Hs + RY - 3) / (RY - 2);                                            \
+            snprintf(name, sizeof name, "bwd_like  shipped halo pattern  region %3d x %2d  frames %d  (x%.2f pixels swept per pixel owned)", RX, RY, FR, \
+                     (double)RX * RY / ((RX - 2) * (RY - 2)));                                                                 \
+            run(name, [&] { hipLaunchKernelGGL((bwd_like_k<RX, RY, FR, 4, true, 0, 8, 1>), dim3((unsigned)(tx * ty * (T / FR))), dim3(RX * RY), 0, 0, \
+                                               src, dst, owner, D, T, Hs, Ws, tx, ty); }, bytes);                              \
+        }
+        for (int rep = 0; rep < 2; ++rep) {
+            BLREF(32, 16, 2) BLH(32, 16, 2, false) BLH(32, 16, 2, true)
+            BLREF(64, 16, 1) BLH(64, 16, 1, false) BLH(64, 16, 1, true)
+            BLREF(64, 8, 2) BLH(64, 8, 2, false) BLH(64, 8, 2, true)
+            BLH(32, 32, 1, false) BLH(32, 32, 1, true)
+        }
+        return 0;
     }
     // Aligned ownership priced WITH the halo it needs (round 3): segments snapped to SNAP-texel columns move by up to SNAP / 2, so the
     // region stages 1 + SNAP / 2 halo columns per side and owns RX - 2 - SNAP columns: more regions, more tap re-reads.

@@ -9,6 +9,7 @@ import torch
 import __graft_entry__ as ge
 ge.build()
 from videoloop3d_amd import synth
+from videoloop3d_amd import utils_vid as UV
 from videoloop3d_amd.utils_vid import _nn_and_fold
 from test_gpu_loss import nn_mismatch_is_near_tie
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -30,7 +31,7 @@ for seed in range(first, first + n):
         y[:, :, : min(tx, ty)] = x[:, :, : min(tx, ty)] + 1e-4 * torch.randn_like(x[:, :, : min(tx, ty)])
     res = []
     for variant in ("3", "4"):
-        os.environ["VL3D_LOSS_VARIANT"] = variant
+        UV.KERNEL_VARIANT = int(variant, 0)
         _, _, nng = _nn_and_fold(x.to(dev), y.to(dev), ps, 3, s, 1, alpha, normalize=False)
         nbad, unexplained = nn_mismatch_is_near_tie(x, y, ps, 3, s, 1, alpha, nng)
         res.append((nbad, unexplained))

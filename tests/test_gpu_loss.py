@@ -7,6 +7,7 @@ import torch
 
 from oracle import vid_oracle as VO
 from videoloop3d_amd import synth
+from videoloop3d_amd import utils_vid as UV_MOD
 
 pytestmark = pytest.mark.gpu
 T_ = lambda a: torch.from_numpy(np.asarray(a))
@@ -229,7 +230,7 @@ def test_patchnn_kernel_variants_agree(dev, variant, monkeypatch):
     and v5 = variant 3 (the same workgroup on the matrix cores, |x|^2+|y|^2-2x.y like the reference; the default where it applies)
     pick the same neighbours up to exact-distance near-ties."""
     from videoloop3d_amd.utils_vid import _nn_and_fold
-    monkeypatch.setenv("VL3D_LOSS_VARIANT", variant)
+    monkeypatch.setattr(UV_MOD, "KERNEL_VARIANT", int(variant, 0))
     x = synth.make_video(12, 43, 51, seed=3)
     y = synth.make_video(20, 43, 51, seed=4)
     for ps, pt, s, st, alpha in ((11, 3, 4, 1, 0.5), (7, 3, 4, 1, None), (3, 3, 2, 1, None)):
@@ -248,7 +249,7 @@ def test_patchnn_matrix_core_tile_counts(dev, tx, ty, ps, s, alpha, monkeypatch)
     reads; <= 128: two locations; <= 192: one; x clips of <= 64 frames on four waves, <= 128 on eight -- cfg4's 80 / 120 and cfg5's
     120 / 180 frames), at the largest clips it takes, with a narrow last group and with alpha."""
     from videoloop3d_amd.utils_vid import _nn_and_fold
-    monkeypatch.setenv("VL3D_LOSS_VARIANT", "3")
+    monkeypatch.setattr(UV_MOD, "KERNEL_VARIANT", 3)
     H, W = ps + 5 * s, ps + 9 * s                        # 6 x 10 patch locations: the last group of a row is two locations wide
     x = synth.make_video(tx, H, W, seed=5)
     y = synth.make_video(ty, H, W, seed=6)
@@ -290,7 +291,7 @@ def test_fold_fixed_trip_covering_loops_equal_the_dynamic_ones(dev, ps, s, monke
     y = synth.make_video(12, 61, 83, seed=22).to(dev)
     out = []
     for variant in ("0", "0x200"):
-        monkeypatch.setenv("VL3D_LOSS_VARIANT", variant)
+        monkeypatch.setattr(UV_MOD, "KERNEL_VARIANT", int(variant, 0))
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             xa = x0.clone().requires_grad_(True)
@@ -397,7 +398,7 @@ def test_g13_alpha0_get_nn_indices_low_memory(dev, golden):
 @pytest.mark.parametrize("ps,pt,s,st", [(5, 3, 2, 1), (3, 3, 2, 1), (3, 2, 1, 2)])
 def test_g13_alpha0_find_nn_and_merge(dev, golden, ps, pt, s, st, variant, monkeypatch):
     from videoloop3d_amd.utils_vid import FindNNpatchAndMerge
-    monkeypatch.setenv("VL3D_LOSS_VARIANT", variant)
+    monkeypatch.setattr(UV_MOD, "KERNEL_VARIANT", int(variant, 0))
     g7, g = golden("g7_merge.npz"), golden("g13_alpha0.npz")
     sm, w = FindNNpatchAndMerge(T_(g7["x"]).to(dev), T_(g7["y"]).to(dev), patch_size=ps, patcht_size=pt, stride=s, stridet=st, alpha=0)
     assert maxabs(w, g[f"b_ps{ps}_pt{pt}_s{s}_st{st}_weight"]) == 0
@@ -408,7 +409,7 @@ def test_g13_alpha0_find_nn_and_merge(dev, golden, ps, pt, s, st, variant, monke
 def test_g13_alpha0_shipped_ref_view_loss_value_and_grad(dev, golden, variant, monkeypatch):
     """Patch3DGPNNLowMemLoss with the SHIPPED ref-view kwargs (ps 11, stride 4, pt 3, alpha = 0, rou '-2', scaling 0.1) against the reference."""
     from videoloop3d_amd.utils_vid import Patch3DGPNNDirectLoss, Patch3DGPNNLowMemLoss, find_nn_indices
-    monkeypatch.setenv("VL3D_LOSS_VARIANT", variant)
+    monkeypatch.setattr(UV_MOD, "KERNEL_VARIANT", int(variant, 0))
     g8, g = golden("g8_loss.npz"), golden("g13_alpha0.npz")
     x, y = T_(g8["x"]).to(dev).requires_grad_(True), T_(g8["y"]).to(dev)
     cfg = dict(macro_block=19, patch_size=11, stride=4, patcht_size=3, stridet=1, rou='-2', scaling=0.1, alpha=0, dist_fn='mse')
@@ -431,7 +432,7 @@ def test_g13_alpha0_exact_ties_take_the_first_minimum(dev, golden, ps, s, varian
     """n2 > n1 at alpha = 0: most rows are decided by an EXACT tie at score 1.0 (the row is the minimum of several columns) and the
     reference keeps the first such column.  The kernels' per-column weight form scores a column minimum through its tie value."""
     from videoloop3d_amd.utils_vid import Patch3DGPNNLowMemLoss, find_nn_indices
-    monkeypatch.setenv("VL3D_LOSS_VARIANT", variant)
+    monkeypatch.setattr(UV_MOD, "KERNEL_VARIANT", int(variant, 0))
     g = golden("g13_alpha0.npz")
     x, y = T_(g["d_x"]).to(dev), T_(g["d_y"]).to(dev)
     nn, *_ = find_nn_indices(x, y, ps, 3, s, 1, 0)
@@ -468,7 +469,7 @@ def test_g13_alpha0_degenerate_input_documented_behaviour(dev, golden, variant, 
     other row; nothing is negative, the indices are valid and the loss is finite.  With the exact-SSD kernel (variant 4) every x patch
     that has an exact copy in y therefore picks its first copy."""
     from videoloop3d_amd.utils_vid import Patch3DGPNNLowMemLoss, find_nn_indices
-    monkeypatch.setenv("VL3D_LOSS_VARIANT", variant)
+    monkeypatch.setattr(UV_MOD, "KERNEL_VARIANT", int(variant, 0))
     g = golden("g13_alpha0.npz")
     x, y = T_(g["e_x"]).to(dev), T_(g["e_y"]).to(dev)
     nn, *_ = find_nn_indices(x, y, 5, 3, 2, 1, 0)

@@ -262,6 +262,39 @@ def test_culled_render_from_a_window_of_the_stack(dev):
     assert torch.equal(g_u[kt], g_w[kt]) and float(g_w[~kt].abs().max()) == 0.0
 
 
+def test_unwritten_culled_gradient_on_a_texel_aligned_view(dev):
+    """VL3D_GRAD_CULLED_UNWRITTEN rests on the kernels' float box test (a tile / plane pair is skipped when its texel box touches no kept
+    quad) agreeing with the integer texel classification the optimiser uses (tiles.quad_to_texel_mask == vl3d texel_class) -- hardest where
+    samples sit exactly ON texel centres and quad borders: a view that is an integer texel shift of every plane, quad borders on integer
+    texels.  Every texel a kept quad can read must be written, with the zero-filling kernel's bits."""
+    import dataclasses
+    from videoloop3d_amd import tiles
+    from videoloop3d_amd.render import RenderSpec, render_planes_with_regularisers
+    D, T, QH, QW, H, W = 6, 2, 7, 9, 64, 96
+    Hs, Ws = 20 * QH + 1, 22 * QW + 1                       # quad borders on texels 0, 20, 40, ... / 0, 22, 44, ...
+    y0, x0, wh, ww = 32, 40, 96, 136
+    g = synth.hash_uniform((T, H, W, 3), seed=5, device=dev) - 0.5
+    for seed in range(4):
+        torch.manual_seed(seed)
+        keep = (torch.rand(D, QH, QW) < (0.15 if seed == 3 else 0.5)).to(dev)
+        win = synth.make_plane_stack(D, T, wh, ww, seed=13 + seed, device=dev)
+        # plane d: texel = pixel + (41 + 3d, 33 + 2d) exactly (pixel centre 0.5 folded into the offset), inside the window
+        homos = torch.eye(3)[None].repeat(D, 1, 1)
+        homos[:, 0, 2] = 41.0 + 3 * torch.arange(D)
+        homos[:, 1, 2] = 33.0 + 2 * torch.arange(D)
+        spec = dataclasses.replace(RenderSpec.mpv(), offset=(-0.5 - x0, -0.5 - y0))
+        obj = lambda o: (o[0] * g).sum() + 1e-4 * o[2].sum() + 1e-3 * o[3].sum()      # noqa: E731
+        grads = []
+        for lean in (False, True):
+            leaf = win.clone().requires_grad_(True)
+            out = render_planes_with_regularisers(leaf, homos.to(dev), H, W, spec, quad_keep=keep, cull_window=(y0, x0, Hs, Ws),
+                                                  grad_culled_unwritten=lean)
+            grads.append(torch.autograd.grad(obj(out), leaf)[0])
+        kt = tiles.quad_to_texel_mask(keep.cpu(), Hs, Ws)[:, y0:y0 + wh, x0:x0 + ww].to(dev)[:, None, :, :, None].expand_as(grads[0])
+        assert float(grads[0][kt].abs().max()) > 0 and float(grads[0][~kt].abs().max()) == 0.0
+        assert torch.equal(grads[1][kt], grads[0][kt]), seed
+
+
 def test_sparsified_model_trains_through_the_window_path(dev):
     """MPMeshVid of a sparsified MPI: the crop-aware path (WindowAdam with the quad maps, static texels stored once) against the
     round-1 path (TileAdam over the whole stack + tie hook, args.tile_adam): same losses, same kept texels after the flush."""

@@ -1,0 +1,134 @@
+"""The HIP modules against what the reference's OWN MPI.py / MPV.py computed (golden G17, tests/golden/make_golden_r04.py: the reference's
+render / forward arithmetic downstream of a harness rasteriser) on IDENTICAL weights:
+  * sparsified checkpoints (G15 / G16) are read onto the tile lattice texel for texel (tiles.stack_from_reference_state) and rendered with
+    their quad maps: MPMesh.forward (MPI.py:544-548, 596-652) and MPMeshVid.forward (MPV.py:389-556), values and gradients;
+  * dense MPMeshVid weights go through atlas_to_stack + atlas_exact (the reference's cell pitch and neighbour-cell bleed).
+Tolerance 1e-4 max-abs (BASELINE.json north_star) on images, relative on sums / gradients."""
+import numpy as np
+import pytest
+import torch
+
+import refmod as RM
+from videoloop3d_amd import tiles
+
+pytestmark = pytest.mark.gpu
+R4 = RM.R4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    import __graft_entry__ as g
+    g.build()
+    return torch.device("cuda:0")
+
+
+def _close(a, b, tol, what):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    err = float((a - b).abs().max())
+    assert err <= tol, (what, err)
+
+
+def _rel(a, b, what, rel=1e-4):
+    _close(a, b, rel * max(1.0, float(torch.as_tensor(b).abs().max())), what)
+
+
+def test_sparsified_mpmesh_forward_matches_the_reference(dev):
+    from videoloop3d_amd.MPI import MPMesh
+    g15, g = RM.load("g15_sparsify"), RM.load("g17_forward")
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    args = R4.make_args(learn_loop_mask=True, **over, **RM.REG)
+    h, w, tar_e, K_crop, K_full = RM.crop_view(g)
+    sd = RM.state_dict_of(g15, "sd_")
+    m = MPMesh(args, H, W, ref_extrin, K, 1.0, 100.0)
+    m.init_from_mpi(sd)
+    m = m.to(dev)
+    assert m.is_sparse and m.stack.shape[2:4] == (37, 55) and not m.learn_loop_mask
+    m.train()
+    rgbl, extra = m(h, w, tar_e, K_crop)
+    assert rgbl.shape == (1, 3, h, w)
+    _close(rgbl, g["b_rgb"], 1e-4, "rgb")
+    for k in ("sparsity", "rgb_smooth", "a_smooth", "density"):
+        _rel(extra[k], g[f"b_extra_{k}"], k)
+    total = (rgbl * torch.from_numpy(g["b_G"]).to(dev)).sum() + sum(getattr(args, k + "_loss_weight") * v.sum() for k, v in extra.items())
+    (gs,) = torch.autograd.grad(total, m.stack)
+    g_dyn, g_static = RM.lattice_grad_from_reference(sd, over["mpi_h_verts"], over["mpi_w_verts"], over["mpi_d"], 1,
+                                                     torch.from_numpy(g["b_grad_atlas"]), torch.from_numpy(g["b_grad_atlas_dyn"]))
+    _rel(gs[:, 0], g_dyn[:, 0] + g_static, "stack gradient")
+    m.eval()
+    with torch.no_grad():
+        _close(m(H, W, tar_e, K_full)[0], g["b_eval_rgb_full"], 1e-4, "eval")
+    # the quad map is what makes the regularisers the reference's: the same stack rendered as a dense one composites the same image
+    # (culled texels are transparent) but differences run over planes, not hit slots
+    m.train()
+    m.is_sparse = False
+    _, extra_nq = m(h, w, tar_e, K_crop)
+    assert abs(float(extra_nq["rgb_smooth"]) - float(g["b_extra_rgb_smooth"].item())) > 1e-3
+
+
+def test_sparsified_mpmeshvid_forward_matches_the_reference(dev):
+    from videoloop3d_amd.MPV import MPMeshVid
+    g15, g = RM.load("g15_sparsify"), RM.load("g17_forward")
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    args = RM.mpv_args(5)
+    h, w, tar_e, K_crop, K_full = RM.crop_view(g)
+    res = torch.from_numpy(g["res"]).to(dev)
+    sd = RM.state_dict_of(g15, "sd_", atlas_dyn=torch.from_numpy(g["d_atlas_dyn"]))          # the stage-2 model of G17 (d): 5 dynamic frames
+    v = MPMeshVid(args, H, W, ref_extrin, K, 1.0, 100.0)
+    v.init_from_mpi(sd)
+    v = v.to(dev)
+    v._install_tie_hook()
+    assert v.frm_num == 5 and v.is_sparse and v.tile_full == (10, 10)
+    v.train()
+    _, extra = v(h, w, tar_e, K_crop, res=res, losscfg=R4.collate(RM.LOSS_CFGS["other"]))
+    for k in ("swd", "sparsity", "rgb_smooth", "a_smooth", "density"):
+        _rel(extra[k], g[f"d_extra_{k}"], k)
+    total = sum(RM.MPV_WEIGHTS[k] * x.sum() for k, x in extra.items())
+    total.backward()
+    gs = v.stack.grad.cpu()
+    g_dyn, g_static = RM.lattice_grad_from_reference(sd, over["mpi_h_verts"], over["mpi_w_verts"], over["mpi_d"], 5,
+                                                     torch.from_numpy(g["d_grad_atlas"]), torch.from_numpy(g["d_grad_atlas_dyn"]))
+    want_sum = g_dyn.sum(1) + g_static
+    Hs, Ws = gs.shape[2:4]
+    dyn_t = tiles.quad_to_texel_mask(v.quad_dyn.cpu(), Hs, Ws)
+    keep_t = tiles.quad_to_texel_mask(v.quad_keep.cpu(), Hs, Ws)
+    static_t = keep_t & ~dyn_t
+    scale = max(1.0, float(want_sum.abs().max()))
+    # static texels are ONE texture (MPV.py:389-392: the static atlas has one frame): every frame's copy carries the frame sum
+    for t in (0, 3):
+        _close(gs[:, t][static_t], want_sum[static_t], 1e-4 * scale, f"static texels, frame {t}")
+    _close(gs.sum(1)[dyn_t], want_sum[dyn_t], 1e-4 * scale, "dynamic texels, frame sum")
+    pure = dyn_t & (g_static.abs().sum(-1) == 0)
+    assert int(pure.sum()) > 1000
+    _close(gs[pure[:, None].expand(-1, 5, -1, -1)], g_dyn[pure[:, None].expand(-1, 5, -1, -1)], 1e-4 * scale, "dynamic texels per frame")
+    assert float(gs[~keep_t[:, None].expand(-1, 5, -1, -1)].abs().max()) == 0.0
+    v.eval()
+    with torch.no_grad():
+        _close(v(H, W, tar_e, K_full)[0], g["d_eval_rgb_full"], 1e-4, "eval")
+
+
+@pytest.mark.parametrize("which", ["other", "ref", "plain"])
+def test_dense_mpmeshvid_atlas_exact_matches_the_reference(dev, which):
+    from videoloop3d_amd.MPV import MPMeshVid, atlas_to_stack, stack_to_atlas
+    g = RM.load("g17_forward")
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    bg = "0.2#0.4#0.6" if which == "ref" else ""
+    args = RM.mpv_args(5, bg=bg, regs={})
+    h, w, tar_e, K_crop, K_full = RM.crop_view(g)
+    v = MPMeshVid(args, H, W, ref_extrin, K, 1.0, 100.0, atlas_exact=True)
+    with torch.no_grad():
+        v.stack.copy_(atlas_to_stack(torch.from_numpy(g["c_atlas_dyn"]), over["mpi_d"], over["atlas_grid_h"]))
+    v = v.to(dev)
+    v.eval()
+    with torch.no_grad():
+        _close(v(H, W, tar_e, K_full)[0], g[f"c_{which}_eval_rgb_full"], 1e-4, "eval")
+        _close(v(h, w, tar_e, K_crop, ts=torch.tensor([3, 1]))[0], g[f"c_{which}_eval_rgb_crop_ts"], 1e-4, "eval ts")
+    if which != "plain":
+        return
+    v.train()
+    res = torch.from_numpy(g["res"]).to(dev)
+    _, extra = v(h, w, tar_e, K_crop, res=res, losscfg=R4.collate(RM.LOSS_CFGS["other"]))
+    assert sorted(extra) == ["swd"]
+    _rel(extra["swd"], g["c_plain_extra_swd"], "swd")
+    (gs,) = torch.autograd.grad(extra["swd"].sum(), v.stack)
+    _rel(stack_to_atlas(gs, over["atlas_grid_h"]), g["c_plain_grad_atlas_dyn"], "grad atlas_dyn")

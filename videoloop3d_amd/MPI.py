@@ -231,10 +231,35 @@ class MPMesh(nn.Module):
         return compute_homography(eye, self._on(dev, "ref_intrin_mpi")[None].to(extrin.dtype), extrin, intrin.to(dev), normal,
                                   self._on(dev, "planedepth")[None].to(extrin.dtype))[0].float()
 
-    def render(self, H, W, extrin, intrin, need_reg=False):
-        """MPI.py:452-594 -> (rgbl [B,H,W,3|4], variables).  One fused render per view (the kernels share one camera per call)."""
+    def _layer_variables(self, homos, H, W, extrin, qk):
+        """the materialised tensors of one view (slow path, videoloop3d_amd/layers.py): `mpi` [1,H,W,K,4] and `loopmask3d` [1,H,W,K,1] in hit-slot
+        order (MPI.py:538-548, 575-577), `blend_weight` [1,H,W,K], `disp_norm` [1,H,W] (MPI.py:483-485, 558-561: the disparity of every
+        hit normalised between far and near, blended; args.normalize_blendweight_fordepth divides the weights by alpha first)."""
+        from . import layers as LY
+        from .MPV import ACTIVATES
+        from .utils_mpi import overcompose
+        a = self.args
+        mpi, planes, cov, (_, _, xm, ym) = LY.materialise(self.stack, homos, H, W, self.spec, ACTIVATES[a.rgb_activate], ACTIVATES[a.alpha_activate], qk)
+        bw = overcompose(mpi[..., -1], mpi[..., :-1])[1]                                            # slot order, like the reference's
+        bw_planes = overcompose(planes[..., -1], planes[..., :-1])[1]
+        if getattr(a, "normalize_blendweight_fordepth", False):
+            alpha = bw.sum(-1)
+            bw = bw / alpha.clamp_min(1e-10)[..., None]
+            bw_planes = bw_planes / alpha.clamp_min(1e-10)[..., None]
+        inv_z = LY.inverse_depth(xm, ym, self._on(self.stack.device, "ref_intrin_mpi"), self._on(self.stack.device, "planedepth"), extrin)
+        disp = (bw_planes * ((inv_z - 1 / self.far) / (1 / self.near - 1 / self.far))[None]).sum(-1)
+        mask3d = None
+        if self.learn_loop_mask:
+            lab = torch.sigmoid(LY.sample_planes(self.stack_mask[..., None], homos, H, W, self.spec))   # 1,D,1,H,W
+            mask3d = LY.to_slots((lab * cov[None, :, None]).permute(0, 3, 4, 1, 2), cov)
+        return mpi, bw, disp, mask3d
+
+    def render(self, H, W, extrin, intrin, need_reg=False, need_layers=False):
+        """MPI.py:452-594 -> (rgbl [B,H,W,3|4], variables).  One fused render per view (the kernels share one camera per call).
+        need_layers: also materialise `mpi` / `blend_weight` / `disp_norm` / `loopmask3d` (slow path; no shipped configuration reads them)."""
         B = len(extrin)
         rgbs, alphas, labels, ssums, asums = [], [], [], [], []
+        lay = []
         # a sparsified model (train_3d.py:282-285: the last epochs of stage 1 train it) renders with its quad map: a sample inside a culled
         # quad is NOT covered by that plane -- no face there in the reference (MPI.py:483-487, 544-548) -- so the slot-ordered smoothness
         # terms skip it and workgroups skip the planes of which they see no kept quad
@@ -278,6 +303,8 @@ class MPMesh(nn.Module):
                 rgb = rgb * alpha[..., None] + bg[None, None, None] * (- alpha[..., None] + 1)
             rgbs.append(rgb)
             alphas.append(alpha)
+            if need_layers:
+                lay.append(self._layer_variables(homos, H, W, extrin[b], qk))
             if self.learn_loop_mask and not fused_mask:                                           # MPI.py:568-583
                 labels.append(_LoopMaskLabel.apply(self.stack_mask, self.stack, self._mask_buf, homos, H, W, self.spec_mask))
         rgb = torch.cat(rgbs, 0)
@@ -286,6 +313,15 @@ class MPMesh(nn.Module):
                      "alpha": torch.cat(alphas, 0),
                      "smooth_sums": torch.stack(ssums).sum(0) if ssums else None,
                      "alpha_sums": torch.cat(asums, 0) if asums else None}
+        if lay:
+            # the B views are rasterised in one call by the reference: K = the deepest pixel of the batch
+            kmax = max(m[0].shape[3] for m in lay)
+            padk = lambda t, ax: torch.nn.functional.pad(t, (0, 0) * (t.dim() - 1 - ax) + (0, kmax - t.shape[ax]))   # noqa: E731
+            variables["mpi"] = torch.cat([padk(m[0], 3) for m in lay], 0)
+            variables["blend_weight"] = torch.cat([padk(m[1], 3) for m in lay], 0)
+            variables["disp_norm"] = torch.cat([m[2] for m in lay], 0)
+            if self.learn_loop_mask:
+                variables["loopmask3d"] = torch.cat([padk(m[3], 3) for m in lay], 0)
         return rgbl, variables
 
     def forward(self, h, w, tar_extrins, tar_intrins):
@@ -294,7 +330,9 @@ class MPMesh(nn.Module):
         tar_extrins, tar_intrins = torch.as_tensor(tar_extrins), torch.as_tensor(tar_intrins)      # (numpy arrays pass nn.DataParallel's scatter untouched: host poses)
         extrins = tar_extrins @ self._on(tar_extrins.device, "ref_extrin")[None, ...].inverse().to(tar_extrins.dtype)
         need_reg = self.training and (a.sparsity_loss_weight > 0 or a.rgb_smooth_loss_weight > 0 or a.a_smooth_loss_weight > 0)
-        rgbl, variables = self.render(h, w, extrins, tar_intrins, need_reg=need_reg)
+        # d_smooth / l_smooth read materialised layers (off in every shipped configuration: slow path)
+        need_layers = self.training and (getattr(a, "d_smooth_loss_weight", 0) > 0 or (getattr(a, "l_smooth_loss_weight", 0) > 0 and self.learn_loop_mask))
+        rgbl, variables = self.render(h, w, extrins, tar_intrins, need_reg=need_reg, need_layers=need_layers)
         B = rgbl.shape[0]
         rgbl = rgbl.permute(0, 3, 1, 2)
         extra = {}
@@ -313,10 +351,16 @@ class MPMesh(nn.Module):
                     extra["rgb_smooth"] = ((sums[0] / (3 * nx) + sums[1] / (3 * ny)) * denorm).reshape(1, -1)
                 if a.a_smooth_loss_weight > 0:                                                   # MPI.py:613-619
                     extra["a_smooth"] = ((sums[2] / nx + sums[3] / ny) * denorm).reshape(1, -1)
-            if getattr(a, "d_smooth_loss_weight", 0) > 0:
-                raise RuntimeError("d_smooth_loss_weight > 0 needs the rasteriser depth buffer (MPI.py:563-566); not on the planar path")
-            if getattr(a, "l_smooth_loss_weight", 0) > 0:
-                raise RuntimeError("l_smooth_loss_weight > 0 (default 0, config_parser.py:169) is not fused yet")
+            if getattr(a, "d_smooth_loss_weight", 0) > 0:                                        # MPI.py:622-637
+                disp = variables["disp_norm"]
+                depth_grad = (disp[:, 1:, :-1] - disp[:, 1:, 1:]).abs() + (disp[:, :-1, 1:] - disp[:, 1:, 1:]).abs()
+                c = rgbl[:, :3]
+                edge = (c[..., 1:, :-1] - c[..., 1:, 1:]).abs().sum(dim=1) + (c[..., :-1, 1:] - c[..., 1:, 1:]).abs().sum(dim=1)
+                extra["d_smooth"] = (depth_grad * (- edge * a.edge_scale + 1).clamp_min(0)).mean().reshape(1, -1)
+            if getattr(a, "l_smooth_loss_weight", 0) > 0 and variables["loopmask3d"] is not None:   # MPI.py:639-645
+                lm = variables["loopmask3d"][..., 0]
+                sm = (lm[:, :, :-1] - lm[:, :, 1:]).abs().mean() + (lm[:, :-1] - lm[:, 1:]).abs().mean()
+                extra["l_smooth"] = (sm * (lm.shape[-1] / self.mpi_d)).reshape(1, -1)
             if a.density_loss_weight > 0:                                                        # MPI.py:647-650
                 extra["density"] = (variables["alpha"] - 1).abs().mean().reshape(1, -1)
         return rgbl, extra

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from .render import RenderSpec, render_planes, render_planes_with_regularisers
-from .utils_mpi import compute_homography, make_depths, overcompose, warp_homography
+from .utils_mpi import compute_homography, make_depths, overcompose
 from .utils_vid import Patch3DAvg, Patch3DGPNNDirectLoss, Patch3DGPNNLowMemLoss, Patch3DMSE
 
 # activations the HIP kernels implement (subset of MPI.py:21-31; shipped configs use sigmoid/sigmoid)
@@ -182,6 +182,15 @@ class MPMeshVid(nn.Module):
         }
 
     # ---- packed storage of a tile-culled model (videoloop3d_amd/packed.py) -------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        """module.to() / .cuda() / .cpu(): the block table of a packed model is plain state (not a buffer: its entries are addresses into
+        the pool, meaningless to load_state_dict) and moves with the pool."""
+        out = super()._apply(fn, *a, **k)
+        if self.packed is not None and self.packed.blocks.device != self.stack_pool.device:
+            self.packed.to(self.stack_pool.device)
+            self._window_opt = None          # optimiser state lives on the old device: the driver asks for a new one
+        return out
+
     def _param(self):
         """the texture parameter: the dense stack, or the pool of a packed model."""
         return self.stack_pool if self.packed is not None else self.stack
@@ -478,6 +487,8 @@ class MPMeshVid(nn.Module):
         self._flush_deferred_updates()      # the optimiser handed out before may still hold deferred zero-gradient updates: they belong to the stack
         self._static_compact = False
         self._window_opt = None
+        if self.packed is not None and self.args.optimizer != 'adam':
+            raise RuntimeError(f"a packed model trains through the crop-aware Adam only (optimizer = {self.args.optimizer})")
         if self.args.optimizer == 'adam':
             if self.packed is not None:
                 from .optim import WindowAdam
@@ -566,6 +577,12 @@ class MPMeshVid(nn.Module):
                 # crop-aware training step: render from a compact, up-to-date copy of the texel window this view can reach
                 # (homographies on the host: a few hundred bytes; CPU inputs cost nothing, device inputs one small sync)
                 (y0, x0, wh, ww), boxes = self.crop_window(homos.detach().cpu(), H, W, per_plane=True)
+                if (wh <= 0 or ww <= 0) and self.packed is not None:
+                    # the view sees no texel of any plane (a pose far off the planes): a packed model has no dense stack to fall back to, so
+                    # the step runs over one bookkeeping tile the view cannot reach -- zero gradient, Adam's zero-gradient update, as dense
+                    from .optim import tile_side
+                    Hs_, Ws_ = self.stack_dims()[2:4]
+                    y0, x0, wh, ww, boxes = 0, 0, min(tile_side(), Hs_), min(tile_side(), Ws_), None
                 if wh > 0 and ww > 0:
                     cull_window = (y0, x0) + tuple(self.stack_dims()[2:4])
                     stack = self._window_opt.window_leaf((y0, x0, wh, ww), boxes if self.per_plane_boxes else None)
@@ -584,6 +601,11 @@ class MPMeshVid(nn.Module):
             homos = homos.pin_memory().to(self._param().device, non_blocking=True)
         else:
             homos = homos.to(self._param().device)
+        # The window leaf's gradient goes to WindowAdam, which never reads culled texels: the backward leaves those slots UNWRITTEN
+        # (uninitialised memory) instead of zero-filling them.  Off whenever something else adds to the same leaf (the materialised-layer
+        # path: garbage + 0 is garbage) or the caller asked for a finite gradient everywhere (args.finite_window_grad: gradient clipping,
+        # norm logging, isfinite checks on leaf.grad).
+        lean_grad = cull_window is not None and not need_layers and not getattr(self.args, "finite_window_grad", False)
         if self.atlas_exact:
             if need_smooth or self.is_sparse or tuple(stack.shape[2:4]) != (self.mpi_h, self.mpi_w):
                 raise RuntimeError("atlas_exact renders the dense full-resolution stack without the fused regularisers / tile culling / lod")
@@ -595,11 +617,11 @@ class MPMeshVid(nn.Module):
             rgb, alpha, smooth_sums, alpha_sums = render_planes_with_regularisers(stack, homos, H, W, spec,
                                                                                   quad_keep=self.quad_keep if self.is_sparse else None,
                                                                                   cull_window=cull_window,
-                                                                                  grad_culled_unwritten=cull_window is not None)
+                                                                                  grad_culled_unwritten=lean_grad)
         else:
             # a sparsified model renders with tile culling: samples in culled quads are uncovered, workgroups skip planes without kept quads
             rgb, alpha = render_planes(stack, homos, H, W, spec, quad_keep=self.quad_keep if self.is_sparse else None, cull_window=cull_window,
-                                       grad_culled_unwritten=cull_window is not None)
+                                       grad_culled_unwritten=lean_grad)
         variables = {"pix_to_face": None, "blend_weight": None, "mpi": None, "disp_norm": None, "alpha": alpha,
                      "smooth_sums": smooth_sums, "alpha_sums": alpha_sums}
         if need_layers:
@@ -621,53 +643,18 @@ class MPMeshVid(nn.Module):
         return rgb[..., :3], variables
 
     def _layers(self, stack, homos, H, W, spec=None, cull_window=None, extrin=None):
-        """warped + activated per-layer rgba via the unfused warp kernel (differentiable): (slot-ordered [T',H,W,K,4] = the reference's
-        `mpi`, MPV.py:441-449; plane-indexed [T',H,W,D,4]; 1 / view-space depth of every plane under every pixel [H,W,D]).
-        warp_homography samples at texel = p*(S-1)/S from integer pixels, so the MPV convention (pixel centre c,
-        texel = p*s + o) is folded into the homography:  H' = diag(Ws/(Ws-1), Hs/(Hs-1), 1) * A * H * shift(c).
-        spec / cull_window: the render spec and (y0, x0, Hs_plane, Ws_plane) when `stack` is the compact window copy of a training step."""
-        D, T, Hs, Ws, _ = stack.shape
+        """warped + activated per-layer rgba via the unfused warp kernel (differentiable, videoloop3d_amd/layers.py): (slot-ordered
+        [T',H,W,K,4] = the reference's `mpi`, MPV.py:441-449; plane-indexed [T',H,W,D,4]; 1 / view-space depth of every plane under every
+        pixel [H,W,D]).  spec / cull_window: the render spec and (y0, x0, Hs_plane, Ws_plane) when `stack` is the compact window copy of a
+        training step."""
+        from . import layers as LY
         spec = self.spec if spec is None else spec
-        c = spec.pixel_center
-        sx, sy = spec.scale
-        ox, oy = spec.offset
-        dev = stack.device
-        A = torch.tensor([[sx * Ws / (Ws - 1), 0, ox * Ws / (Ws - 1)], [0, sy * Hs / (Hs - 1), oy * Hs / (Hs - 1)], [0, 0, 1.]], device=dev)
-        C = torch.tensor([[1., 0, c], [0, 1., c], [0, 0, 1.]], device=dev)
-        hm = (A @ homos.to(dev) @ C)
-        imgs = stack.permute(1, 0, 4, 2, 3)                                                  # T,D,4,Hs,Ws
-        samp = warp_homography(H, W, hm[None].expand(T, D, 3, 3), imgs)                      # T,D,4,H,W
-        # hard-cut coverage of the quad (MPV.py:389): texel coords inside [0,S-1]
-        y, x = torch.meshgrid(torch.arange(H, device=dev, dtype=torch.float32) + c,
-                              torch.arange(W, device=dev, dtype=torch.float32) + c, indexing="ij")
-        p = homos.to(dev)[:, None, None] @ torch.stack([x, y, torch.ones_like(x)], -1)[None, ..., None]   # D,H,W,3,1
-        tx = p[..., 0, 0] / p[..., 2, 0] * sx + ox
-        ty = p[..., 1, 0] / p[..., 2, 0] * sy + oy
-        cov = ((tx >= 0) & (tx <= Ws - 1) & (ty >= 0) & (ty <= Hs - 1)).to(samp.dtype)      # D,H,W
-        if self.is_sparse:      # a sample inside a culled quad is not covered (no face there, MPV.py:389-392)
-            QH, QW = self.quad_keep.shape[1:]
-            y0, x0, Hp, Wp = (0, 0, Hs, Ws) if cull_window is None else cull_window
-            qx = torch.floor((tx + x0) * (QW / max(Wp - 1, 1))).clamp(0, QW - 1).long()
-            qy = torch.floor((ty + y0) * (QH / max(Hp - 1, 1))).clamp(0, QH - 1).long()
-            cov = cov * self.quad_keep.to(dev)[torch.arange(D, device=dev)[:, None, None], qy, qx].to(cov.dtype)
-        rgba = torch.cat([self.rgb_activate(samp[:, :, :3]), self.alpha_activate(samp[:, :, 3:])], dim=2)
-        rgba = (rgba * cov[None, :, None]).permute(0, 3, 4, 1, 2)                            # T,H,W,D,4, plane-indexed
-        # hit-slot order: slot k of a pixel = its k-th nearest covered plane (masked_scatter over the z-sorted pix_to_face, MPV.py:441-449),
-        # K = the deepest pixel (utils.py:64-69)
-        covp = cov.permute(1, 2, 0) > 0                                                      # H,W,D
-        K = max(int(covp.sum(-1).max()), 1)
-        slot = (torch.cumsum(covp.long(), -1) - 1).clamp(min=0)[None, ..., None].expand(T, H, W, D, 4)
-        out = torch.zeros((T, H, W, max(K, D), 4), dtype=rgba.dtype, device=dev).scatter_add(3, slot, rgba)
+        slots, planes, _, (_, _, xm, ym) = LY.materialise(stack, homos, H, W, spec, self.rgb_activate, self.alpha_activate,
+                                                          self.quad_keep if self.is_sparse else None, cull_window)
         inv_z = None
         if extrin is not None:
-            # the plane point under the pixel, P_ref = depth * K_mpi^-1 (xm, ym, 1), in the target camera: z = R[2] . P_ref + t[2]
-            Ki = torch.inverse(self._on(dev, "ref_intrin_mpi").double())
-            E = extrin[0].to(dev).double()
-            ray = Ki @ torch.stack([p[..., 0, 0] / p[..., 2, 0], p[..., 1, 0] / p[..., 2, 0], torch.ones_like(p[..., 2, 0])], -1)[..., None].double()
-            P = ray[..., 0] * self._on(dev, "planedepth").double()[:, None, None, None]                         # D,H,W,3
-            z = (P * E[2, :3]).sum(-1) + E[2, 3]
-            inv_z = (1.0 / z).float().permute(1, 2, 0)                                                           # H,W,D
-        return out[:, :, :, :K], rgba, inv_z
+            inv_z = LY.inverse_depth(xm, ym, self._on(stack.device, "ref_intrin_mpi"), self._on(stack.device, "planedepth"), extrin[0])
+        return slots, planes, inv_z
 
     # ---- forward -----------------------------------------------------------------------------------------------------
     def forward(self, h, w, tar_extrins, tar_intrins, ts=None, res=None, losscfg=None):

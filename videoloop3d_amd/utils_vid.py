@@ -5,6 +5,7 @@ robust loss run in the HIP library (csrc/vl3d_loss.hip); patches are never mater
 the macro-block loop of the reference (a pure memory cap that does not change the result, utils_vid.py:323-342)
 is not needed.
 """
+import contextlib
 import os
 import warnings
 
@@ -79,8 +80,24 @@ def _loss_desc(x, y, patch_size, patcht_size, stride, stridet, alpha):
     d.y_sc, d.y_st, d.y_sr = y.stride(0), y.stride(1), y.stride(2)
     # kernel-variant selector for cross-checks (bits 0-3 pick one of the four patch-NN kernels, every one of them exact; bits 12-15 a
     # fold tile shape): the timing-only bits 4-7 never leave this module (the product library refuses them anyway)
-    d.variant = int(os.environ.get("VL3D_LOSS_VARIANT", "0"), 0) & ~0xf0
+    d.variant = int(KERNEL_VARIANT) & ~0xf0
     return d
+
+
+# Kernel-variant selector of the loss kernels (cross-checks and A/B runs; 0 = the dispatch's own choice).  A module attribute set through
+# `kernel_variant(v)`, not an environment variable: nothing outside the caller's own code changes what the product library runs.
+KERNEL_VARIANT = 0
+
+
+@contextlib.contextmanager
+def kernel_variant(v):
+    """with kernel_variant(3): ... -- run the enclosed loss calls on one specific (exact) patch-NN kernel / fold tile shape."""
+    global KERNEL_VARIANT
+    old, KERNEL_VARIANT = KERNEL_VARIANT, int(v)
+    try:
+        yield
+    finally:
+        KERNEL_VARIANT = old
 
 
 def _as_video(v, name):
