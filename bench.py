@@ -536,7 +536,9 @@ def main():
                 torch.cuda.empty_cache()
                 import stage1_step
                 res["stage1_step"] = {"native_crop": stage1_step.run(dev=str(dev)),
-                                      "cfg2_720p_frame": stage1_step.run(frame=(720, 1280), crop=(720, 1280), scale=1.1, dev=str(dev))}
+                                      "cfg2_720p_frame": stage1_step.run(frame=(720, 1280), crop=(720, 1280), scale=1.1, dev=str(dev)),
+                                      # ... and at the SHIPPED plane size (configs/mpi_base.txt:11-12: mpi_h/w_scale = 1.6)
+                                      "cfg2_720p_frame_scale1p6": stage1_step.run(frame=(720, 1280), crop=(720, 1280), scale=1.6, dev=str(dev))}
             except Exception as e:
                 res["stage1_step"] = {"error": repr(e)}
             try:    # the same iteration on the REFERENCE'S SCHEDULE (train_3dvid.py:22-66, 263-290): 8 views with their own poses, the
@@ -553,6 +555,32 @@ def main():
             res["cpu_baseline"] = cpu_baseline(D, H, W, a.cpu_frames, a.spec)
         else:
             res["cpu_baseline"] = None
+        res["build"] = dict(ge.BUILD_INFO)
+
+        def pick(d, *path):
+            for k in path:
+                if not isinstance(d, dict) or k not in d:
+                    return None
+                d = d[k]
+            return d
+        # the numbers a reader looks for first, EARLY in the line (the detailed legs follow; a consumer that cuts the tail keeps these)
+        res["summary"] = {
+            "loss_720p_iters_per_s": {"ref": pick(res, "loss", "ref", "iters_per_s"), "other": pick(res, "loss", "other", "iters_per_s")},
+            "loss_720p_nn_ms": {"ref": pick(res, "loss", "ref", "roofline_nn", "avg_ms"), "other": pick(res, "loss", "other", "roofline_nn", "avg_ms")},
+            "loss_720p_roofline_loss_frac": {"ref": pick(res, "loss", "ref", "roofline_loss", "frac"), "other": pick(res, "loss", "other", "roofline_loss", "frac")},
+            "loss_720p_roofline_nn_frac": {"ref": pick(res, "loss", "ref", "roofline_nn", "frac"), "other": pick(res, "loss", "other", "roofline_nn", "frac")},
+            "loss_native_crop_iters_per_s": {"ref": pick(res, "loss_native_crop", "ref", "iters_per_s"), "other": pick(res, "loss_native_crop", "other", "iters_per_s")},
+            "cfg2_single_frame_mpix_s": pick(res, "cfg2_single_frame", "value"), "fp16_stack_mpix_s": pick(res, "fp16_stack_storage", "value"),
+            "reference_geometry": {"mpix_s": pick(res, "reference_geometry", "value"), "fwd_ms": pick(res, "reference_geometry", "fwd_ms"),
+                                   "bwd_ms": pick(res, "reference_geometry", "bwd_ms"), "fwd_frac": pick(res, "reference_geometry", "roofline_fwd", "frac"),
+                                   "bwd_frac": pick(res, "reference_geometry", "roofline_bwd", "frac")},
+            "stage1_iters_per_s": {k: pick(res, "stage1_step", k, "iters_per_s") for k in ("native_crop", "cfg2_720p_frame", "cfg2_720p_frame_scale1p6")},
+            "stage2_step_iters_per_s": {k: pick(res, "stage2_step", k, "iters_per_s") for k in ("ref", "other", "other_tile_culled", "other_tile_culled_packed")},
+            "stage2_schedule_iters_per_s": {k: pick(res, "stage2_schedule", k, "iters_per_s") for k in ("dense", "tile_culled")},
+        }
+        head = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "stack_storage", "config", "roofline", "cpu_baseline", "build", "summary", "roofline_fwd", "roofline_bwd", "fwd_bwd_algorithmic_frac"]
+        res = {**{k: res[k] for k in head if k in res}, **{k: v for k, v in res.items() if k not in head}}
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

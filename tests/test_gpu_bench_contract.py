@@ -26,5 +26,10 @@ def test_bench_json_contract():
     assert d["value"] > 0 and abs(d["value"] - 2 * 96 * 128 / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # the numbers a reader needs first come first in the line (a consumer that cuts the tail keeps them), and the build is stated
+    keys = list(d)
+    assert keys.index("cpu_baseline") < keys.index("summary") < keys.index("loss") and keys.index("roofline") < keys.index("cpu_baseline")
+    assert d["build"]["translation_units"] >= 10 and "hipcc" in d["build"]["mode"]
+    assert d["summary"]["loss_720p_iters_per_s"]["ref"] == d["loss"]["ref"]["iters_per_s"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mpix/s" and "sample" in c

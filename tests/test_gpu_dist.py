@@ -1,6 +1,9 @@
 """The N-GPU path on the one GPU a test box has: RCCL (backend 'nccl') process group of world size 1, one rank's row band rendered
 from its band-local stack rows, the composited band all-gathered on a side stream.  (World sizes 2 and 3 of the same code run on
-CPU/gloo in test_dist_cpu.py; the 8-GPU run is the driver's.)"""
+CPU/gloo in test_dist_cpu.py; the 8-GPU run is the driver's.)
+`test_two_ranks_on_one_gpu_over_rccl` tries the DEVICE-tensor collectives (`all_gather_frame("direct")`, `exchange_halo_grads`) with two
+ranks sharing the one MI355X: RCCL, like NCCL, refuses two ranks of one communicator on the same device ("Duplicate GPU detected"), in
+which case the test records that as its skip reason -- the device paths then stay covered by world size 1 here and by gloo elsewhere."""
 import os
 import socket
 
@@ -77,3 +80,77 @@ def test_looping_loss_on_row_bands_equals_the_full_loss(cfg, world):
             total, count = total + float(s), count + n
     assert abs(total / count - float(full)) <= 1e-6 * max(1.0, abs(float(full)))
     assert float((g_sum / count - g_full).abs().max()) <= 1e-7 + 1e-5 * float(g_full.abs().max())
+
+
+def _two_rank_worker(rank, port, q):
+    import torch.distributed as dist
+    from videoloop3d_amd.dist import all_gather_frame, exchange_halo_grads, plan_bands
+    from videoloop3d_amd.render import RenderSpec
+    from videoloop3d_amd.utils_mpi import compute_homography, make_depths
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    try:
+        dist.init_process_group("nccl", rank=rank, world_size=2, device_id=dev)
+    except Exception as e:      # noqa: BLE001
+        q.put((rank, "refused", repr(e)[:300]))
+        return
+    try:
+        D, T, H, W = 3, 4, 48, 64
+        spec = RenderSpec.mpv()
+        ref_e, Kr, tar_e, Kt = synth.make_cameras(H, W)
+        homos = compute_homography(ref_e[None], Kr[None], tar_e[None], Kt[None], torch.tensor([0., 0., 1.]).expand(1, D, 3),
+                                   make_depths(D, 1.0, 100.0).flip(0)[None])[0]
+        bands = plan_bands(homos, H, W, H, 2, spec)
+        full = synth.hash_uniform((T, H, W, 3), seed=7, device=dev)
+        b = bands[rank]
+        frame = all_gather_frame(full[:, b.row0:b.row0 + b.rows].contiguous(), bands, algo="direct")
+        ok = torch.equal(frame, full)
+        g_full = synth.hash_uniform((D, T, H, W, 4), seed=8, device=dev)
+        part = g_full[:, :, b.src0:b.src1] * (0.25 + 0.5 * rank)            # the two ranks' partial gradients of the shared rows sum to 1.0 x
+        lo, hi = max(bands[0].src0, bands[1].src0), min(bands[0].src1, bands[1].src1)
+        mine = part.clone()
+        # rows only this rank holds carry the complete gradient already
+        own = torch.ones(b.src1 - b.src0, dtype=torch.bool, device=dev)
+        own[lo - b.src0:hi - b.src0] = False
+        mine[:, :, own] = g_full[:, :, b.src0:b.src1][:, :, own]
+        done = exchange_halo_grads(mine, bands, rank)
+        ok = ok and float((done - g_full[:, :, b.src0:b.src1]).abs().max()) <= 1e-6 and hi > lo
+        torch.cuda.synchronize()
+        q.put((rank, "ok" if ok else "mismatch", ""))
+    except Exception as e:      # noqa: BLE001
+        q.put((rank, "refused", repr(e)[:300]))
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:      # noqa: BLE001
+            pass
+
+
+def test_two_ranks_on_one_gpu_over_rccl():
+    import torch.multiprocessing as mp
+    import __graft_entry__ as g
+    g.build()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(2):
+            res.append(q.get(timeout=150))
+    except Exception:      # noqa: BLE001  (a rank hung in a collective the other one was refused)
+        pass
+    for p in procs:
+        p.join(timeout=20)
+        if p.is_alive():
+            p.kill()
+    states = {r[1] for r in res}
+    if states == {"ok"} and len(res) == 2:
+        return
+    assert "mismatch" not in states, res
+    pytest.skip(f"RCCL does not run two ranks of one communicator on one device here: {res[:1]}")

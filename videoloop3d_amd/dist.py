@@ -86,6 +86,9 @@ def render_band(local_stack, homos, band: Band, W: int, Hs: int, spec: RenderSpe
     return render_planes(local_stack, homos, band.rows, W, band_spec(spec, band, Hs), window=(band.row0, 0))
 
 
+_P2P_OPS_PER_GROUP = 1024      # point-to-point operations per grouped launch (RCCL queues a bounded number per group)
+
+
 def all_gather_frame(band_rgb: torch.Tensor, bands: List[Band], group=None, algo: str = "auto") -> torch.Tensor:
     """The one collective of the render path: composited bands [T,rows_r,W,C] -> full frame [T,H,W,C] on every rank.
     Uses torch.distributed (backend 'nccl' == RCCL over xGMI on ROCm; 'gloo' in the CPU tests).
@@ -96,7 +99,7 @@ def all_gather_frame(band_rgb: torch.Tensor, bands: List[Band], group=None, algo
                 frame over ONE link per GPU: cfg3 at N = 8, 553 MB frame -> 484 MB per rank at ~153 GB/s = ~3.2 ms.
       "direct"  all-peers: every rank sends its band straight to each of the N-1 peers and receives theirs, all transfers in ONE
                 grouped launch (batch_isend_irecv -> ncclGroupStart/End): each of the 7 links carries one 69 MB band per
-                direction concurrently -> ~0.45 ms.  Received bands land in place in the frame buffer (no concat).
+                direction concurrently -> ~0.45 ms.  Received bands land in place in the [T,H,W,C] frame (per-frame receives).
       "auto"    "direct" for world > 2 on device tensors, else "ring".
     Every rank gets bit-identical frames from either algorithm (pure data movement)."""
     import torch.distributed as dist
@@ -110,25 +113,33 @@ def all_gather_frame(band_rgb: torch.Tensor, bands: List[Band], group=None, algo
     band_rgb = band_rgb.contiguous()
     if algo == "direct":
         rank = dist.get_rank(group)
-        # band-major frame buffer: band r is one contiguous block, so a receive writes its final location directly
-        buf = torch.empty((T * sum(rows) * W * C,), dtype=band_rgb.dtype, device=band_rgb.device)
-        offs, o = [], 0
-        for r in rows:
-            offs.append(o)
-            o += T * r * W * C
-        parts = [buf[offs[k]:offs[k] + T * rows[k] * W * C].view(T, rows[k], W, C) for k in range(world)]
-        parts[rank].copy_(band_rgb)
-        ops = []
-        for k in range(world):
-            if k == rank:
-                continue
-            peer = k if group is None else dist.get_global_rank(group, k)
-            ops.append(dist.P2POp(dist.isend, band_rgb, peer, group))
-            ops.append(dist.P2POp(dist.irecv, parts[k], peer, group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        return torch.cat(parts, dim=1) if len(set(rows)) != 1 else torch.stack(parts, 1).reshape(T, sum(rows), W, C)
+        # the frame itself is the receive buffer: band k of frame t is the contiguous block frame[t, row0_k : row0_k + rows_k], so every
+        # peer's band arrives as T per-frame receives straight into place (no band-major staging buffer, no 553 MB repack at cfg3 after
+        # a collective budgeted at 0.45 ms); all transfers of a chunk go out in ONE grouped launch (batch_isend_irecv -> ncclGroupStart/End)
+        H = sum(rows)
+        row0 = [0]
+        for r in rows[:-1]:
+            row0.append(row0[-1] + r)
+        frame = torch.empty((T, H, W, C), dtype=band_rgb.dtype, device=band_rgb.device)
+        frame[:, row0[rank]:row0[rank] + rows[rank]].copy_(band_rgb)
+        # chunks are FRAME ranges over all peers: every rank posts the same (pair, frame) transfers in the same grouped launch, so sends and
+        # receives match chunk by chunk whatever the band sizes (one chunk up to T = 73 at N = 8)
+        tpc = max(1, _P2P_OPS_PER_GROUP // max(2 * (world - 1), 1))
+        for t0 in range(0, T, tpc):
+            ops = []
+            for k in range(world):
+                if k == rank:
+                    continue
+                peer = k if group is None else dist.get_global_rank(group, k)
+                for t in range(t0, min(T, t0 + tpc)):
+                    if rows[rank]:
+                        ops.append(dist.P2POp(dist.isend, band_rgb[t], peer, group))
+                    if rows[k]:
+                        ops.append(dist.P2POp(dist.irecv, frame[t, row0[k]:row0[k] + rows[k]], peer, group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+        return frame
     if len(set(rows)) == 1 and band_rgb.is_cuda:
         out = torch.empty((world, T, rows[0], W, C), dtype=band_rgb.dtype, device=band_rgb.device)
         dist.all_gather_into_tensor(out, band_rgb, group=group)
