@@ -205,6 +205,15 @@ int vl3d_adam_window_step_boxes(int32_t D, int32_t T, int32_t Hs, int32_t Ws, in
  * device int32 [n], each in [0,T); blocks without storage read (0, 0, 0, culled_alpha), static blocks their one copy in every frame. */
 int vl3d_packed_unpack_frames(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const int32_t *blocks, const float *pool, int32_t n,
                               const int32_t *frames, float culled_alpha, float *out, vl3d_stream_t stream);
+/* The forward of MPV.py:351-454 reading the PACKED texture directly -- the reference renders a sparsified model from its static / dynamic
+ * tile lists (MPV.py:389-449), never from a dense texture.  desc: D, T (frames of the model), Hs x Ws (texels of a plane), the H x W view,
+ * pixel_center / sx / sy / ox / oy, activations; convention (VL3D_COORD_AFFINE, VL3D_BORDER_HARDCUT, VL3D_ACT_POST), fp32.  blocks / pool:
+ * as above; frames = device int32 [n]; quad_keep [D][QH][QW] = the map the block table was built from (a sample in a culled quad is not
+ * covered).  rgb (n,H,W,3), alpha (n,H,W): the bits of vl3d_render_fwd_culled on the unpacked frames.  Forward only (evaluation renders):
+ * training renders from the compact window copy of the crop-aware optimiser (vl3d_adam_window_catchup). */
+int vl3d_render_fwd_packed(const vl3d_render_desc *desc, const int32_t *blocks, const float *pool, const int32_t *frames, int32_t n,
+                           const float *homos, const uint8_t *quad_keep, int32_t QH, int32_t QW, float culled_alpha, float *rgb,
+                           float *alpha, vl3d_stream_t stream);
 int vl3d_adam_flush_older(int32_t D, int32_t T, int32_t Hs, int32_t Ws, float *param, float *exp_avg, float *exp_avg_sq, int32_t *last_step,
                           const float *hist, int32_t upto, int32_t min_depth, float beta1, float beta2, float eps, const uint8_t *quad_keep,
                           const uint8_t *quad_dyn, int32_t QH, int32_t QW, const int32_t *blocks, vl3d_stream_t stream);

@@ -142,7 +142,7 @@ def test_two_ranks_on_one_gpu_over_rccl():
     res = []
     try:
         for _ in range(2):
-            res.append(q.get(timeout=150))
+            res.append(q.get(timeout=75))
     except Exception:      # noqa: BLE001  (a rank hung in a collective the other one was refused)
         pass
     for p in procs:

@@ -671,10 +671,19 @@ def test_packed_model_trains_and_renders_like_the_dense_one(dev):
     for m in (dense, packed):
         m.eval()
     with torch.no_grad():
+        # evaluation renders of the packed model read the POOL (vl3d_render_fwd_packed: block table -> 16-byte texel per tap), never an
+        # unpacked stack -- and have the dense culled render's bits
+        unpack = packed.packed.unpack_frames
+        packed.packed.unpack_frames = lambda *a, **k: (_ for _ in ()).throw(AssertionError("an evaluation render unpacked the pool"))
         for ts in (None, torch.tensor([3]), torch.tensor([4, 0, 2])):
             ra, _ = dense(H, W, tar_e, tar_k, ts=ts)
             rb, _ = packed(H, W, tar_e, tar_k, ts=ts)
             assert torch.equal(ra, rb)
+        h_, w_ = 24, 32                                         # a crop view (shifted principal point)
+        Kc = K.copy(); Kc[0, 2] -= 13; Kc[1, 2] -= 7
+        assert torch.equal(dense(h_, w_, tar_e, torch.tensor(Kc)[None].to(dev), ts=torch.tensor([1, 1, 4]))[0],
+                           packed(h_, w_, tar_e, torch.tensor(Kc)[None].to(dev), ts=torch.tensor([1, 1, 4]))[0])
+        packed.packed.unpack_frames = unpack
         # the one-launch unpack of chosen frames (vl3d_packed_unpack_frames) == the plane-by-plane torch path
         lay, pool = packed.packed, packed.stack_pool.data
         assert torch.equal(lay.unpack_frames(pool, [4, 0, 2]), torch.stack([lay.unpack_plane(pool, d, [4, 0, 2]) for d in range(D)], 0))

@@ -564,6 +564,26 @@ class MPMeshVid(nn.Module):
     def render(self, H, W, extrin, intrin, ts, need_layers=False, need_smooth=False):
         """MPV.py:351-475 -> (rgb [T',H,W,3], variables).  `variables['mpi']`/`['blend_weight']` (the warped per-layer
         rgba, only consumed by the smoothness/sparsity regularisers) are materialised on demand with the unfused operators."""
+        if self.packed is not None and not (self.training and torch.is_grad_enabled()) and not need_layers and not need_smooth:
+            # an evaluation render of a packed model reads the pool itself (vl3d_render_fwd_packed): static blocks once, dynamic blocks
+            # per frame, culled blocks nowhere -- like the reference's render from its tile lists (MPV.py:389-449); no dense frames are built
+            from .render import render_planes_packed
+            from .tiles import CULLED_ALPHA
+            self._flush_deferred_updates()
+            dev = self.stack_pool.device
+            homos = self.plane_homographies(extrin, intrin).to(dev)
+            rgb, alpha = render_planes_packed(self.packed, self.stack_pool.data, torch.as_tensor(ts).tolist(), homos, H, W, self.spec,
+                                              self.quad_keep, CULLED_ALPHA)
+            variables = {"pix_to_face": None, "blend_weight": None, "mpi": None, "disp_norm": None, "alpha": alpha, "smooth_sums": None,
+                         "alpha_sums": None}
+            if len(self.args.bg_color) > 0:                                                     # MPV.py:455-461 (as written)
+                if self.args.bg_color == "random":
+                    bg_color = torch.rand(3).type_as(rgb)
+                else:
+                    r, g, b = map(float, self.args.bg_color.split('#'))
+                    bg_color = torch.tensor([r, g, b]).type_as(rgb)
+                rgb = rgb * alpha[..., None] + bg_color[None, None, None] * (- alpha[..., None] + 1)
+            return rgb[..., :3], variables
         if self.packed is not None and not self._all_frames(ts):
             self._flush_deferred_updates()
         stack = self._frames(ts)          # (a packed model: None for the full clip -- the window path below, or unpacked on demand)

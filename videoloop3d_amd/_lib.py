@@ -60,6 +60,7 @@ SIGNATURES = {
     "vl3d_adam_window_step": ([_I32] * 8 + [_P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I64, _P, _P, _I32, _I32, _I32, _P], C.c_int),
     "vl3d_adam_window_step_boxes": ([_I32] * 8 + [_P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I64, _P, _P, _I32, _I32, _I32, _P, _P, _P], C.c_int),
     "vl3d_packed_unpack_frames": ([_I32] * 4 + [_P, _P, _I32, _P, _F, _P, _P], C.c_int),
+    "vl3d_render_fwd_packed": ([C.POINTER(RenderDesc), _P, _P, _P, _I32, _P, _P, _I32, _I32, _F, _P, _P, _P], C.c_int),
     "vl3d_adam_flush_older": ([_I32] * 4 + [_P, _P, _P, _P, _P, _I32, _I32, _F, _F, _F, _P, _P, _I32, _I32, _P, _P], C.c_int),
     "vl3d_adam_step_scalars": ([_F, _F, _F, _I64, C.POINTER(C.c_float), C.POINTER(C.c_float)], None),
     "vl3d_render_cull_scratch_bytes": ([C.POINTER(RenderDesc)], C.c_int64),

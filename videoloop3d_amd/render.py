@@ -261,3 +261,36 @@ def render_planes_with_regularisers(stack, homos, H, W, spec: RenderSpec = Rende
     sum_k a_k^2) the sparsity regulariser |a|_1/|a|_2 (MPV.py:511-515, MPI.py:599-603) is built from; all differentiable."""
     return _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), True, quad_keep, cull_window,
                                bool(grad_culled_unwritten))
+
+
+@torch.no_grad()
+def render_planes_packed(layout, pool, frames, homos, H, W, spec: RenderSpec, quad_keep, culled_alpha):
+    """The forward of a PACKED tile-culled model straight from its pool (videoloop3d_amd/packed.py; the reference renders a sparsified model
+    from its tile lists, MPV.py:389-449): rgb [n,H,W,3], alpha [n,H,W] for the chosen `frames` -- the bits of the culled render of the
+    unpacked frames, without ever building them.  No gradient (evaluation renders; training goes through the optimiser's window copy)."""
+    L.check_cuda(pool, homos, quad_keep, layout.blocks)
+    if spec.coord_mode != "affine" or spec.border != "hardcut" or spec.act_order != "post":
+        raise RuntimeError("a packed model renders in the planar MPV convention (RenderSpec.mpv())")
+    frames = [int(t) for t in frames]
+    if not frames:
+        return (torch.empty((0, H, W, 3), dtype=torch.float32, device=pool.device), torch.empty((0, H, W), dtype=torch.float32, device=pool.device))
+    if min(frames) < 0 or max(frames) >= layout.T:
+        raise IndexError(f"frame index out of range [0, {layout.T})")
+    homos = homos.detach().to(torch.float32).contiguous()
+    if homos.shape != (layout.D, 3, 3):
+        raise RuntimeError(f"homos must be [D,3,3] = [{layout.D},3,3], got {tuple(homos.shape)}")
+    d = L.RenderDesc()
+    d.D, d.T, d.Hs, d.Ws, d.H, d.W = layout.D, layout.T, layout.Hs, layout.Ws, int(H), int(W)
+    d.coord_mode, d.border_mode, d.act_order = L.COORD["affine"], L.BORDER["hardcut"], L.ACT_ORDER["post"]
+    d.rgb_act, d.alpha_act = L.ACT[spec.rgb_act], L.ACT[spec.alpha_act]
+    d.pixel_center = float(spec.pixel_center)
+    d.sx, d.sy, d.ox, d.oy = float(spec.scale[0]), float(spec.scale[1]), float(spec.offset[0]), float(spec.offset[1])
+    dev = pool.device
+    qk = quad_keep.to(torch.uint8).contiguous()
+    ft = torch.tensor(frames, dtype=torch.int32).to(dev, non_blocking=True)
+    rgb = torch.empty((len(frames), H, W, 3), dtype=torch.float32, device=dev)
+    alpha = torch.empty((len(frames), H, W), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        L.check(L.lib().vl3d_render_fwd_packed(d, L.ptr(layout.blocks), L.ptr(pool), L.ptr(ft), len(frames), L.ptr(homos), L.ptr(qk), qk.shape[1],
+                                               qk.shape[2], float(culled_alpha), L.ptr(rgb), L.ptr(alpha), L.stream_ptr(dev)), "vl3d_render_fwd_packed")
+    return rgb, alpha
