@@ -3,7 +3,8 @@
   (1) cfg3 render fwd+bwd at 1.0x (render_fwd2x_k, render_bwd_pair_k),
   (2) the reference geometry: 1.1x stack + smoothness regularisers (render_fwd_reg_k, reg_slot_fwd_k, render_bwd_pair_k<REG>),
   (3) the looping loss at 720p, both shipped configurations (patchnn4_k, vote_fold_lds_k, video_to_pixel_major_k).
-Usage: python profiles/pmc_target.py [T=50]"""
+  (4) with a second argument "fp16": the cfg3 render from an fp16 stack (cfg5 of BASELINE.json).
+Usage: python profiles/pmc_target.py [T=50] [fp16]"""
 import os
 import sys
 import warnings
@@ -67,4 +68,13 @@ with warnings.catch_warnings():
             loss = Patch3DGPNNLowMemLoss()(x, y, **cfg)
             (gx,) = torch.autograd.grad(loss, x)
 torch.cuda.synchronize()
+del x, y
+torch.cuda.empty_cache()
+# (4) cfg5's storage format on the cfg3 geometry: fp16 stack and fp16 gradient (8-byte texels), fp32 arithmetic  [argv[2] == "fp16"]
+if len(sys.argv) > 2 and sys.argv[2] == "fp16":
+    stack = rand_stack(D, T, H, W).detach().half().requires_grad_(True)
+    rgb, _ = render_planes(stack, homos.to(dev), H, W, spec)
+    (gs,) = torch.autograd.grad(rgb, stack, g)
+    del gs, rgb, stack
+    torch.cuda.synchronize()
 print("pmc target done")

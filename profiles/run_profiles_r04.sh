@@ -1,0 +1,31 @@
+#!/bin/bash
+# Round-4 profile recipe -- ONE run (on the GPU box through gpurun) regenerates every tracked summary from the same tree:
+#   bench line (bench.json) + rocprofv3 kernel stats of the SAME command          -> r04_bench.json, r04_kernel_stats.csv
+#   pmc_target.py (cfg3 render, reference geometry, looping loss; + fp16 stack)   -> r04_kernel_stats_target.csv, r04_pmc_summary.txt
+#   the stage-2 schedule, the loss iteration, the stage-1 iteration               -> r04_kernel_stats_{sched,loss,s1}.csv
+# PMC passes are separate runs per counter group with --kernel-trace only (gpurun refuses --pmc with the sys / hip / hsa trace domains).
+# Outputs land in gpurun_out/$R (scratch); profiles/collect_r04.sh copies the summaries into profiles/.
+set -x
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+R=${1:-r04}
+O=gpurun_out/$R
+mkdir -p $O
+python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/trace.log 2>&1
+B="python profiles/pmc_target.py 50 fp16"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ttrace -o t -- $B > $O/ttrace.log 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o p -- $B > $O/fetch.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o p -- $B > $O/write.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/sq -o p -- $B > $O/sq.log 2>&1
+timeout 400 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/sq2 -o p -- $B > $O/sq2.log 2>&1
+for f in $O/*/p_counter_collection.csv; do head -1 $f > $f.tmp; grep -E "render_|bwd_|reg_|patchnn|vote_fold|robust_|video_to|adam_|loop_" $f >> $f.tmp; mv $f.tmp $f; done
+python profiles/summarize_pmc.py $O "" > $O/pmc_summary.txt
+for leg in "sched examples/stage2_schedule.py" "loss profiles/loss_iter_prof.py" "s1 examples/stage1_step.py"; do
+  set -- $leg
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$1 -o t -- python $2 > $O/$1.log 2>&1
+  cp $O/$1/t_kernel_stats.csv $O/kernel_stats_$1.csv
+done
+rm -f $O/*/p_kernel_trace.csv $O/*/t_kernel_trace.csv $O/*/p_agent_info.csv $O/*/t_agent_info.csv
+[ -f $O/trace/t_kernel_stats.csv ] && cp $O/trace/t_kernel_stats.csv $O/kernel_stats_bench.csv
+cp $O/ttrace/t_kernel_stats.csv $O/kernel_stats_target.csv
+ls $O; tail -5 $O/pmc_summary.txt; head -c 1500 $O/bench.json
