@@ -1,13 +1,19 @@
 """MPMesh (stage 1, static MPI) on the MI355X-native render kernels: drop-in for the hot path of the reference's MPI.py.
 
-Mirrors /root/reference/MPI.py:36-131 (constructor), :452-594 (render) and :596-652 (forward) for PLANAR, un-sparsified
-geometry with rgb_mlp_type = 'direct' (configs/mpi_base.txt).  As in videoloop3d_amd/MPV.py the texture is the dense plane
-stack `stack` (D,1,mpi_h,mpi_w,4) (+ `stack_mask` (D,1,mpi_h,mpi_w) for the learned loop mask, MPI.py:115-117) instead of the
-atlas grid, and coverage/UVs are the analytic per-plane homography instead of pytorch3d's rasteriser.
-The loop-mask channel (MPI.py:568-583: sigmoid(mask texture) composited with the DETACHED layer alphas) is a second pass of
-the fused renderer on (mask, mask, mask, alpha.detach()).  sparsify_faces (MPI.py:288-442, the paper's tile culling) classifies the
-quads of the dense stack into culled / static / dynamic (videoloop3d_amd/tiles.py) instead of re-packing atlases; direct2sh /
-save_* are out of scope; d_smooth needs the rasteriser's depth buffer (default weight 0).
+Mirrors /root/reference/MPI.py:36-131 (constructor), :452-594 (render) and :596-652 (forward) for PLANAR geometry with
+rgb_mlp_type = 'direct' (configs/mpi_base.txt), dense and after sparsify_faces.  As in videoloop3d_amd/MPV.py the texture is the dense plane
+stack `stack` (D,1,Hs,Ws,4) (+ `stack_mask` (D,1,Hs,Ws) for the learned loop mask, MPI.py:115-117) instead of the atlas grid, and coverage / UVs
+are the analytic per-plane homography instead of pytorch3d's rasteriser.
+  * The loop-mask channel (MPI.py:568-583: sigmoid(mask texture) composited with the DETACHED layer alphas) rides the colour pass as a fifth
+    channel (vl3d_render_fwd_mask / _bwd_mask), or is a second pass of the fused renderer on (mask, -, -, alpha.detach()).
+  * sparsify_faces (MPI.py:288-442, the paper's tile culling) classifies the quads exactly like the reference on identical weights
+    (tiles.classify_quads_atlas, golden G15) into culled / static / dynamic maps instead of re-packing atlases; afterwards render() passes the
+    quad map to the culled kernels (a sample in a culled quad is not covered: MPI.py:483-487, 544-548; train_3d.py:282-285 keeps training it).
+  * init_from_mpi reads this package's checkpoints and the reference's (a sparsified one texel for texel onto its tile lattice);
+    reference_state_dict / save_* write the reference's layout (videoloop3d_amd/export.py).
+  * l_smooth / d_smooth / normalize_blendweight_fordepth / variables['mpi' | 'blend_weight' | 'disp_norm' | 'loopmask3d'] (off in every shipped
+    configuration) come from the materialised-layer slow path (videoloop3d_amd/layers.py); direct2sh is out of scope.
+Module-level parity: tests/test_gpu_reference_modules.py (the reference's own forward, golden G17), tests/test_gpu_mpv.py (oracle).
 """
 import dataclasses
 
@@ -57,6 +63,10 @@ class MPMesh(nn.Module):
         self.H, self.W = H, W
         if getattr(args, "rgb_mlp_type", "direct") != "direct":
             raise RuntimeError(f"rgbmlp_type = {args.rgb_mlp_type} not supported (shipped configs use 'direct', mpi_base.txt:28)")
+        if getattr(args, "add_uv_noise", False):
+            # (MPV.py:412-415 / MPI.py:508-512: a random sub-texel jitter of every sample's UV while training; off in every shipped
+            # configuration.  Not silently ignored: the fused kernels sample at the analytic position.)
+            raise RuntimeError("add_uv_noise is not implemented by the fused render (no shipped configuration sets it)")
         ref_extrin, ref_intrin = np.asarray(ref_extrin), np.asarray(ref_intrin)
         assert ref_extrin.shape == (4, 4) and ref_intrin.shape == (3, 3)
         self.register_buffer("ref_extrin", torch.tensor(ref_extrin))

@@ -142,6 +142,10 @@ class MPMeshVid(nn.Module):
             raise RuntimeError("fp16 is marked 'do NOT use' in the reference (config_parser.py:32-33); fp32 only")
         if getattr(args, "rgb_mlp_type", "direct") != "direct":
             raise RuntimeError(f"rgbmlp_type = {args.rgb_mlp_type} not supported (shipped configs use 'direct', mpv_base.txt:28)")
+        if getattr(args, "add_uv_noise", False):
+            # (MPV.py:412-415 / MPI.py:508-512: a random sub-texel jitter of every sample's UV while training; off in every shipped
+            # configuration.  Not silently ignored: the fused kernels sample at the analytic position.)
+            raise RuntimeError("add_uv_noise is not implemented by the fused render (no shipped configuration sets it)")
         ref_extrin, ref_intrin = np.asarray(ref_extrin), np.asarray(ref_intrin)
         assert ref_extrin.shape == (4, 4) and ref_intrin.shape == (3, 3)
         self.register_buffer("ref_extrin", torch.tensor(ref_extrin))
