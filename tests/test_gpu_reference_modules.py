@@ -104,7 +104,41 @@ def test_sparsified_mpmeshvid_forward_matches_the_reference(dev):
     assert float(gs[~keep_t[:, None].expand(-1, 5, -1, -1)].abs().max()) == 0.0
     v.eval()
     with torch.no_grad():
-        _close(v(H, W, tar_e, K_full)[0], g["d_eval_rgb_full"], 1e-4, "eval")
+        ev = v(H, W, tar_e, K_full)[0]
+        _close(ev, g["d_eval_rgb_full"], 1e-4, "eval")
+    # the path a training run takes -- the crop-aware optimiser's window copy, culled kernels on the window -- computes the reference's terms too
+    v.zero_grad(set_to_none=True)
+    v.train()
+    opt = v.get_optimizer(0)
+    _, extra_w = v(h, w, tar_e, K_crop, res=res, losscfg=R4.collate(RM.LOSS_CFGS["other"]))
+    for k in ("swd", "sparsity", "rgb_smooth", "a_smooth", "density"):
+        _rel(extra_w[k], g[f"d_extra_{k}"], k + " (window path)")
+    sum(RM.MPV_WEIGHTS[k] * x.sum() for k, x in extra_w.items()).backward()
+    opt.step()
+    # ... and the PACKED form of the same checkpoint (static blocks once, dynamic blocks per frame, culled blocks nowhere) renders the reference's
+    # image straight from its pool (vl3d_render_fwd_packed)
+    v2 = MPMeshVid(RM.mpv_args(5), H, W, ref_extrin, K, 1.0, 100.0)
+    v2.init_from_mpi(sd)
+    v2 = v2.to(dev)
+    v2.pack_()
+    v2.eval()
+    assert v2.packed is not None and v2.packed.pool_bytes < 0.8 * v2.packed.dense_bytes
+    with torch.no_grad():
+        ev2 = v2(H, W, tar_e, K_full)[0]
+    assert torch.equal(ev2, ev)
+    with torch.no_grad():
+        sub = v2(h, w, tar_e, K_crop, ts=torch.tensor([4, 2]))[0]
+    assert torch.equal(sub, _eval_frames(sd, dev, H, W, ref_extrin, K, h, w, tar_e, K_crop))
+
+
+def _eval_frames(sd, dev, H, W, ref_extrin, K, h, w, tar_e, K_crop):
+    """the dense model of the same checkpoint rendering frames [4, 2] of the crop view (what the packed model must reproduce bit for bit)."""
+    from videoloop3d_amd.MPV import MPMeshVid
+    d = MPMeshVid(RM.mpv_args(5), H, W, ref_extrin, K, 1.0, 100.0)
+    d.init_from_mpi(sd)
+    d = d.to(dev).eval()
+    with torch.no_grad():
+        return d(h, w, tar_e, K_crop, ts=torch.tensor([4, 2]))[0]
 
 
 @pytest.mark.parametrize("which", ["other", "ref", "plain"])
@@ -132,3 +166,28 @@ def test_dense_mpmeshvid_atlas_exact_matches_the_reference(dev, which):
     _rel(extra["swd"], g["c_plain_extra_swd"], "swd")
     (gs,) = torch.autograd.grad(extra["swd"].sum(), v.stack)
     _rel(stack_to_atlas(gs, over["atlas_grid_h"]), g["c_plain_grad_atlas_dyn"], "grad atlas_dyn")
+
+
+def test_dense_mpmeshvid_second_layout_matches_the_reference(dev):
+    """golden (e): 3 x 2 cells, non-square plane scales, normalize_verts, another view -- atlas_exact on the HIP kernels."""
+    from videoloop3d_amd.MPV import MPMeshVid, atlas_to_stack, stack_to_atlas
+    g = RM.load("g17_forward")
+    H, W, over = R4.SHAPES["B"]
+    K, ref_extrin, _ = R4.scene(H, W, angle_deg=-1.7, trans=(-0.031, 0.022, -0.004))
+    args = R4.make_args(mpv_frm_num=4, mpv_isloop=True, init_std=0.5, scale_invariant=True, swd_patch_size=3, swd_patcht_size=3,
+                        swd_stride=2, swd_stridet=1, **over)
+    h, w = (int(v) for v in g["e_hw_crop"])
+    tar_e, K_crop, K_full = (torch.from_numpy(g[k]) for k in ("e_tar_extrin", "e_tar_intrin_crop", "e_tar_intrin_full"))
+    v = MPMeshVid(args, H, W, ref_extrin, K, 1.0, 100.0, atlas_exact=True)
+    with torch.no_grad():
+        v.stack.copy_(atlas_to_stack(torch.from_numpy(g["e_atlas_dyn"]), over["mpi_d"], over["atlas_grid_h"]))
+    v = v.to(dev)
+    v.eval()
+    with torch.no_grad():
+        _close(v(H, W, tar_e, K_full)[0], g["e_eval_rgb_full"], 1e-4, "eval")
+        _close(v(h, w, tar_e, K_crop, ts=torch.tensor([2, 0]))[0], g["e_eval_rgb_crop_ts"], 1e-4, "eval ts")
+    v.train()
+    _, extra = v(h, w, tar_e, K_crop, res=torch.from_numpy(g["e_res"]).to(dev), losscfg=R4.collate(RM.LOSS_CFGS["other"]))
+    _rel(extra["swd"], g["e_extra_swd"], "swd")
+    (gs,) = torch.autograd.grad(extra["swd"].sum(), v.stack)
+    _rel(stack_to_atlas(gs, over["atlas_grid_h"]), g["e_grad_atlas_dyn"], "grad atlas_dyn")

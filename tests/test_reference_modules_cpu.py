@@ -347,3 +347,28 @@ def test_g17_mpmeshvid_sparsified_forward_oracle():
     assert float(gs[~keep_t[:, None].expand(-1, 5, -1, -1)].abs().max()) == 0.0
     rgb, _ = mpv_oracle.mpv_forward(st.detach(), args, H, W, ref_extrin, K, 1.0, 100.0, H, W, tar_e, K_full, training=False, quad_keep=keep)
     _close(rgb, g["d_eval_rgb_full"], 3e-6, "eval")
+
+
+def test_g17_second_layout_dense_mpmeshvid_oracle():
+    """golden (e): a 3 x 2 atlas of cells, non-square plane scales, normalize_verts, another view -- the cell pitch / bleed of the atlas
+    sampling and the geometry do not depend on the one layout the other cases use."""
+    g = RM.load("g17_forward")
+    H, W, over = R4.SHAPES["B"]
+    K, ref_extrin, _ = R4.scene(H, W, angle_deg=-1.7, trans=(-0.031, 0.022, -0.004))
+    args = R4.make_args(mpv_frm_num=4, mpv_isloop=True, init_std=0.5, scale_invariant=True, swd_patch_size=3, swd_patcht_size=3,
+                        swd_stride=2, swd_stridet=1, **over)
+    h, w = (int(v) for v in g["e_hw_crop"])
+    tar_e, K_crop, K_full = (torch.from_numpy(g[k]) for k in ("e_tar_extrin", "e_tar_intrin_crop", "e_tar_intrin_full"))
+    atlas = torch.from_numpy(g["e_atlas_dyn"]).clone().requires_grad_(True)
+    _, extra = mpv_oracle.mpv_forward(atlas, args, H, W, ref_extrin, K, 1.0, 100.0, h, w, tar_e, K_crop, res=torch.from_numpy(g["e_res"]),
+                                      losscfg=R4.collate(RM.LOSS_CFGS["other"]), atlas_grid_h=over["atlas_grid_h"])
+    assert sorted(extra) == ["swd"]
+    _close(extra["swd"], g["e_extra_swd"], 3e-6, "swd")
+    (ga,) = torch.autograd.grad(extra["swd"].sum(), atlas)
+    _close_grad(ga, g["e_grad_atlas_dyn"], "grad atlas_dyn")
+    rgb, _ = mpv_oracle.mpv_forward(atlas.detach(), args, H, W, ref_extrin, K, 1.0, 100.0, H, W, tar_e, K_full, training=False,
+                                    atlas_grid_h=over["atlas_grid_h"])
+    _close(rgb, g["e_eval_rgb_full"], 3e-6, "eval")
+    rgb_ts, _ = mpv_oracle.mpv_forward(atlas.detach(), args, H, W, ref_extrin, K, 1.0, 100.0, h, w, tar_e, K_crop, ts=torch.tensor([2, 0]),
+                                       training=False, atlas_grid_h=over["atlas_grid_h"])
+    _close(rgb_ts, g["e_eval_rgb_crop_ts"], 3e-6, "eval ts")
