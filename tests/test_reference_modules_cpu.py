@@ -372,3 +372,43 @@ def test_g17_second_layout_dense_mpmeshvid_oracle():
     rgb_ts, _ = mpv_oracle.mpv_forward(atlas.detach(), args, H, W, ref_extrin, K, 1.0, 100.0, h, w, tar_e, K_crop, ts=torch.tensor([2, 0]),
                                        training=False, atlas_grid_h=over["atlas_grid_h"])
     _close(rgb_ts, g["e_eval_rgb_crop_ts"], 3e-6, "eval ts")
+
+
+@pytest.mark.parametrize("H,W,scale,hv,wv,D,gh,seed", [(36, 54, 1.0, 4, 6, 6, 2, 1),        # 12 x 10.8-pixel quads -> 12 x 11 tiles? (skipped unless square)
+                                                       (40, 40, 1.2, 5, 5, 4, 2, 2),        # square planes, 2 x 2 cells
+                                                       (33, 65, 1.0, 3, 5, 6, 3, 3),        # odd sizes
+                                                       (48, 64, 1.5, 7, 9, 8, 4, 4)])       # the shipped 1.5-1.6x plane scale, more quads
+def test_reader_and_exporter_round_trip_oracle_checkpoints(H, W, scale, hv, wv, D, gh, seed):
+    """The G15 round trip on other shapes: oracle/ckpt_oracle.sparsify_atlas (pinned to the reference by G15) sparsifies a random smooth atlas,
+    the product reads the checkpoint onto its tile lattice and writes it back -- same quads, same atlases, same scalars."""
+    from videoloop3d_amd.MPI import MPMesh
+    args = R4.make_args(learn_loop_mask=True, mpi_h_scale=scale, mpi_w_scale=scale, mpi_h_verts=hv, mpi_w_verts=wv, mpi_d=D, atlas_grid_h=gh)
+    K, ref_extrin, _ = R4.scene(H, W)
+    m = MPMesh(args, H, W, ref_extrin, K, 1.0, 100.0)
+    mh, mw, gw = m.mpi_h, m.mpi_w, D // gh
+    th, _ = tiles.tile_lattice(gh, hv, gh * mh)
+    tw, _ = tiles.tile_lattice(gw, wv, gw * mw)
+    if th != tw:
+        pytest.skip(f"tiles of {th} x {tw} texels: the reference's gen_quad_uvs steps both axes by the tile HEIGHT (MPI.py:409-410), square tiles only")
+    atlas = torch.cat([R4.smooth_field((3, gh * mh, gw * mw), seed=100 + seed, scale=5.0) * 2.0,
+                       R4.smooth_field((1, gh * mh, gw * mw), seed=200 + seed, scale=8.0) * 6.0 - 4.0], 0)[None].contiguous()
+    mask = (R4.smooth_field((1, gh * mh, gw * mw), seed=300 + seed, scale=12.0) * 5.0 - 0.5)[None].contiguous()
+    sd = CO.sparsify_atlas(atlas, mask, gh, D, hv, wv, 2, 0.05, 0.5)
+    n_s, n_d = sd["faces"].shape[0] // 2, sd["faces_dyn"].shape[0] // 2
+    if min(n_s, n_d) < 4:
+        pytest.skip("too few static / dynamic quads for the reference's atlas grid rule")
+    sd.update({"planedepth": m.planedepth.clone(), "ref_extrin": m.ref_extrin.clone(), "ref_intrin": m.ref_intrin.clone(),
+               "_verts": gen_mpi_vertices(mh, mw, m.ref_intrin_mpi, hv, wv, m.planedepth)})
+    # the product's own sparsify on the same weights keeps the same quads
+    with torch.no_grad():
+        m.stack.copy_(atlas_to_stack(atlas, D, gh))
+        m.stack_mask.copy_(atlas_to_stack(mask, D, gh)[..., 0])
+    m2 = MPMesh(copy.copy(args), H, W, ref_extrin, K, 1.0, 100.0)
+    m2.init_from_mpi(sd)
+    assert m2.stack.shape[2:4] == ((hv - 1) * (th - 1) + 1, (wv - 1) * (tw - 1) + 1)
+    m.sparsify_faces(erode_num=2, alpha_thresh=0.05, loop_thresh=0.5)
+    assert torch.equal(m.quad_keep, m2.quad_keep) and torch.equal(m.quad_dyn, m2.quad_dyn)
+    assert int(m2.quad_keep.sum()) == n_s + n_d and int(m2.quad_dyn.sum()) == n_d
+    # (duplicated border samples of neighbouring tiles differ by the fp32 jitter of their UVs times the atlas' slope -- logits of +-8 over
+    #  a few texels here -- and the lattice holds their mean)
+    _check_state(m2.reference_state_dict(), sd, atol=5e-4)
