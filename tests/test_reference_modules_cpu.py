@@ -374,7 +374,7 @@ def test_g17_second_layout_dense_mpmeshvid_oracle():
     _close(rgb_ts, g["e_eval_rgb_crop_ts"], 3e-6, "eval ts")
 
 
-@pytest.mark.parametrize("H,W,scale,hv,wv,D,gh,seed", [(36, 54, 1.0, 4, 6, 6, 2, 1),        # 12 x 10.8-pixel quads -> 12 x 11 tiles? (skipped unless square)
+@pytest.mark.parametrize("H,W,scale,hv,wv,D,gh,seed", [(36, 60, 1.0, 4, 6, 6, 2, 1),        # 12 x 12-texel tiles, 2 x 3 cells
                                                        (40, 40, 1.2, 5, 5, 4, 2, 2),        # square planes, 2 x 2 cells
                                                        (33, 65, 1.0, 3, 5, 6, 3, 3),        # odd sizes
                                                        (48, 64, 1.5, 7, 9, 8, 4, 4)])       # the shipped 1.5-1.6x plane scale, more quads
