@@ -191,3 +191,47 @@ def test_dense_mpmeshvid_second_layout_matches_the_reference(dev):
     _rel(extra["swd"], g["e_extra_swd"], "swd")
     (gs,) = torch.autograd.grad(extra["swd"].sum(), v.stack)
     _rel(stack_to_atlas(gs, over["atlas_grid_h"]), g["e_grad_atlas_dyn"], "grad atlas_dyn")
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_stage2_training_from_the_reference_checkpoint(dev, packed):
+    """The hand-over the reference's pipeline makes (train_3d.py sparsifies and saves; train_3dvid.py:205-211 loads it with init_from_mpi and trains
+    the pyramid): the REFERENCE's stage-1 checkpoint (G15) into this package's stage-2 driver, dense and packed -- two pyramid levels on the tile
+    lattice (lod follows the reference's tile sizes), the loss goes down, and the trained model exports a checkpoint with the reference's keys,
+    face lists and tile geometry."""
+    from videoloop3d_amd import synth, train_3dvid as drv
+    from videoloop3d_amd.MPV import MPMeshVid
+    g15 = RM.load("g15_sparsify")
+    H, W, over, K, ref_extrin, tar = RM.case_A()
+    sd = RM.state_dict_of(g15, "sd_")
+    args = R4.make_args(mpv_frm_num=5, mpv_isloop=True, init_std=0.1, scale_invariant=True, swd_patch_size=3, swd_patcht_size=3, swd_stride=2,
+                        swd_stridet=1, rgb_smooth_loss_weight=0.05, a_smooth_loss_weight=0.05, pyr_minimal_dim=-1, pyr_stage="2", N_iters=5,
+                        pyr_factor=0.5, pyr_num_epoch=0, patch_h_size=20, patch_w_size=28, patch_h_stride=12, patch_w_stride=20, lrate=0.5,
+                        lrate_adaptive=True, add_intrin_noise=True, swd_loss_weight=1.0, **over)
+    model = MPMeshVid(args, H, W, ref_extrin, K, 1.0, 100.0).to(dev)
+    model.init_from_mpi(sd, packed=packed)
+    assert (model.packed is not None) == packed and model.tile_full == (10, 10) and model.is_sparse
+    vids = [synth.make_video(8, H, W, seed=21 + v, device=dev)[0].permute(1, 0, 2, 3).contiguous() for v in range(2)]
+    poses = torch.stack([torch.tensor(np.linalg.inv(ref_extrin))[:3], torch.tensor(np.linalg.inv(tar))[:3]]).float()
+    intr = torch.tensor(K).float()[None].repeat(2, 1, 1)
+    cfg = {"loss_name": "gpnn_lm", "patch_size": 3, "patcht_size": 3, "stride": 2, "stridet": 1, "alpha": 10000, "rou": "-2", "scaling": 0.1,
+           "dist_fn": "mse", "macro_block": 65, "factor": 1}
+    log = []
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        n = drv.train(model, args, vids, poses, intr, [cfg, dict(cfg, loss_gain=2.0)], H, W, device=dev,
+                      on_step=lambda lvl, ep, it, loss, swd, extra: log.append((lvl, float(loss))), generator=torch.Generator().manual_seed(1))
+    assert n == len(log) and all(np.isfinite(l) for _, l in log)
+    # level 0: tiles of max(int(10 * 0.5), 2) = 5 texels, level 1: the checkpoint's own 10 (MPV.py:146-151)
+    assert model.stack_dims()[2:4] == (4 * 9 + 1, 6 * 9 + 1)
+    fine = [l for lvl, l in log if lvl == 1]
+    assert np.mean(fine[-6:]) < np.mean(fine[:6])
+    out = model.reference_state_dict()
+    for k in ("faces", "uvfaces", "faces_dyn", "uvfaces_dyn", "uvs", "uvs_dyn"):
+        assert torch.equal(out[k].cpu(), sd[k]) if out[k].dtype == torch.int64 else float((out[k].cpu() - sd[k]).abs().max()) <= 1e-6, k
+    assert out["atlas"].shape == sd["atlas"].shape and out["atlas_dyn"].shape == (5,) + tuple(sd["atlas_dyn"].shape[1:])
+    assert float((out["atlas_dyn"][0] - out["atlas_dyn"][3]).abs().max()) > 1e-3            # the dynamic tiles have become per-frame textures
+    for k in sd:
+        if k.startswith("self."):
+            assert out[k] == sd[k], k
