@@ -86,7 +86,7 @@ def render_band(local_stack, homos, band: Band, W: int, Hs: int, spec: RenderSpe
     return render_planes(local_stack, homos, band.rows, W, band_spec(spec, band, Hs), window=(band.row0, 0))
 
 
-_P2P_OPS_PER_GROUP = 1024      # point-to-point operations per grouped launch (RCCL queues a bounded number per group)
+_P2P_OPS_PER_GROUP = 256       # point-to-point operations per grouped launch: 18 frames x 7 peers x (send + receive) at N = 8
 
 
 def all_gather_frame(band_rgb: torch.Tensor, bands: List[Band], group=None, algo: str = "auto") -> torch.Tensor:
@@ -123,7 +123,7 @@ def all_gather_frame(band_rgb: torch.Tensor, bands: List[Band], group=None, algo
         frame = torch.empty((T, H, W, C), dtype=band_rgb.dtype, device=band_rgb.device)
         frame[:, row0[rank]:row0[rank] + rows[rank]].copy_(band_rgb)
         # chunks are FRAME ranges over all peers: every rank posts the same (pair, frame) transfers in the same grouped launch, so sends and
-        # receives match chunk by chunk whatever the band sizes (one chunk up to T = 73 at N = 8)
+        # receives match chunk by chunk whatever the band sizes (three chunks for cfg3 at N = 8)
         tpc = max(1, _P2P_OPS_PER_GROUP // max(2 * (world - 1), 1))
         for t0 in range(0, T, tpc):
             ops = []
