@@ -18,9 +18,9 @@ import numpy as np
 import torch
 
 
-def run(iters=20, planes=32, frame=(360, 640), crop=(180, 320), scale=1.6, loop_mask=True, dev="cuda:0", torch_adam=False):
+def run(iters=20, planes=32, frame=(360, 640), crop=(180, 320), scale=1.6, loop_mask=True, dev="cuda:0", torch_adam=False, fused_loss=True):
     from videoloop3d_amd import synth
-    from videoloop3d_amd.MPI import MPMesh
+    from videoloop3d_amd.MPI import MPMesh, image_and_loop_loss
     dev = torch.device(dev)
     H, W = frame
     h, w = crop
@@ -28,7 +28,7 @@ def run(iters=20, planes=32, frame=(360, 640), crop=(180, 320), scale=1.6, loop_
         mpi_h_scale=scale, mpi_w_scale=scale, mpi_d=planes, mpi_h_verts=36, mpi_w_verts=64, atlas_grid_h=4, rgb_mlp_type="direct",
         rgb_activate="sigmoid", alpha_activate="sigmoid", bg_color="", learn_loop_mask=loop_mask, scale_invariant=True,
         sparsity_loss_weight=0.004, rgb_smooth_loss_weight=0.2, a_smooth_loss_weight=0.5, density_loss_weight=0.02, d_smooth_loss_weight=0.0,
-        l_smooth_loss_weight=0.0)
+        l_smooth_loss_weight=0.0, unfused_terms=not fused_loss)
     K = np.array([[0.9 * W, 0, W / 2], [0, 0.9 * W, H / 2], [0, 0, 1]], np.float64)
     model = MPMesh(args, H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
     args.optimizer, args.lrate, args.lrate_decay, args.torch_adam = "adam", 0.05, 100, torch_adam
@@ -50,15 +50,19 @@ def run(iters=20, planes=32, frame=(360, 640), crop=(180, 320), scale=1.6, loop_
             Kc[0, 2] -= 90 + (it % 3) * 40                                   # crop offset (utils.py:196-200)
             Kc[1, 2] -= 45 + (it % 2) * 60
         rgbl, extra = model(h, w, tar_e, torch.tensor(Kc)[None])
-        loop_loss = 0
-        rgb = rgbl
-        if loop_mask:                                                        # train_3d.py:200-211
-            lm = torch.clamp(rgbl[:, -1], 0.001, 1 - 0.001)
-            loop_loss = -(target_mask * torch.log(lm) + (1 - target_mask) * torch.log(1 - lm)).mean()
-            rgb = rgbl[:, :3]
-        sc = torch.exp(torch.log((target + 0.01) / (rgb.detach() + 0.01)).mean())     # train_3d.py:213-217
-        rgb = rgb * ((sc + 3) / 4)
-        loss = ((rgb - target) ** 2).mean() + loop_loss
+        if fused_loss:                                                       # train_3d.py:200-220 in three launches each way
+            img_loss, loop_loss = image_and_loop_loss(rgbl, target, target_mask if loop_mask else None, scale_invariant=True)
+            loss = img_loss + loop_loss
+        else:
+            loop_loss = 0
+            rgb = rgbl
+            if loop_mask:                                                    # train_3d.py:200-211
+                lm = torch.clamp(rgbl[:, -1], 0.001, 1 - 0.001)
+                loop_loss = -(target_mask * torch.log(lm) + (1 - target_mask) * torch.log(1 - lm)).mean()
+                rgb = rgbl[:, :3]
+            sc = torch.exp(torch.log((target + 0.01) / (rgb.detach() + 0.01)).mean())     # train_3d.py:213-217
+            rgb = rgb * ((sc + 3) / 4)
+            loss = ((rgb - target) ** 2).mean() + loop_loss
         for k, v in extra.items():
             if wts[f"{k}_loss_weight"] > 0:
                 loss = loss + v.mean() * wts[f"{k}_loss_weight"]

@@ -387,6 +387,24 @@ int vl3d_loop_pad_fwd(int32_t T, int32_t pad, int32_t h, int32_t w, const float 
 int vl3d_loop_pad_bwd(int32_t T, int32_t pad, int32_t h, int32_t w, const float *grad_x, int64_t gx_sc, int64_t gx_st, const double *log_sum,
                       float *grad_rgb, vl3d_stream_t stream);
 
+/* Per-pixel terms of MPMesh.forward / MPMeshVid.forward after the fused render, one pass each way instead of ~30 scalar launches:
+ *   sums[0] = sum_p  n1_p / max(sqrt(max(n2_p, 1e-30)), eps)      sparsity (MPI.py:599-603, MPV.py:511-515), (n1, n2) = alpha_sums (n,2) = (sum_k a_k, sum_k a_k^2)
+ *   sums[1] = sum_p | alpha_p - 1 |                               density  (MPI.py:647-650, MPV.py:533-536)
+ * either input may be NULL (its sum stays 0).  grad_alpha_sums (n,2) / grad_alpha (n), optional: d sums[0] / d alpha_sums, d sums[1] / d alpha
+ * (unit upstream gradient, not divided by n: the caller scales).  sums: device double[2], overwritten. */
+int vl3d_pixel_terms(int64_t n, const float *alpha, const float *alpha_sums, float eps, double *sums, float *grad_alpha_sums, float *grad_alpha,
+                     vl3d_stream_t stream);
+
+/* Stage 1's image + loop-mask loss (train_3d.py:200-220) on the module's output rgbl (B,C,h,w), C = 3 | 4, read through strides in floats
+ * (sb batch, sc channel, sp pixel: the NHWC render output viewed as NCHW); target (B,3,h,w), target_mask (B,h,w) contiguous:
+ *   s       = scale_invariant ? (exp(mean log((target + .01) / (rgb + .01))) + 3) / 4 : 1          (rgb detached in it, as in the reference)
+ *   sums[0] = sum (rgb s - target)^2                                     -> img_loss  = sums[0] / (3 B h w)
+ *   sums[1] = - sum (m log l + (1 - m) log(1 - l)), l = clamp(label, .001, .999)     -> loop_loss = sums[1] / (B h w)      (C == 4)
+ * grad (B,h,w,C) contiguous: d sums[0] / d rgb in channels 0-2, d sums[1] / d label in channel 3 (the caller divides by the counts and
+ * multiplies by the upstream gradients).  log_sum: device double scratch; sums: device double[2]; both overwritten. */
+int vl3d_stage1_loss(int32_t B, int32_t C, int32_t h, int32_t w, const float *rgbl, int64_t sb, int64_t sc, int64_t sp, const float *target,
+                     const float *target_mask, int32_t scale_invariant, double *log_sum, double *sums, float *grad, vl3d_stream_t stream);
+
 /* robust_lossfun (utils_vid.py:10-26) fused with the mean (utils_vid.py:348).
  * kind: 0 'mse', 1 'abs', 2 general Barron with float rou (rou==0 and rou==2 special-cased as the reference).
  * loss_sum: device double, overwritten with sum over n elements of rho(x - y2x). */

@@ -325,6 +325,63 @@ def test_sparsified_mpmesh_trains_with_its_quad_map(dev):
     assert float((model.stack.detach() - before).abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize("C,si,layout", [(4, True, "nhwc"), (3, True, "nchw"), (4, False, "nhwc"), (3, False, "nhwc")])
+def test_stage1_loss_equals_the_torch_chain(dev, C, si, layout):
+    """train_3d.py:200-220 (loop-mask entropy on the clamped label, scale-invariant MSE) as vl3d_stage1_loss against the same lines in torch:
+    both losses and the gradient w.r.t. the module's output, for the NHWC-backed view MPMesh.forward returns and a plain NCHW tensor."""
+    from videoloop3d_amd.MPI import image_and_loop_loss
+    B, h, w = 2, 37, 53
+    base = synth.hash_uniform((B, h, w, C), seed=3).to(dev)
+    if C == 4:
+        base[..., 3] = base[..., 3] * 1.1 - 0.05                                     # a few labels outside the clamp
+    rgbl = (base.permute(0, 3, 1, 2) if layout == "nhwc" else base.permute(0, 3, 1, 2).contiguous()).requires_grad_(True)
+    target = synth.hash_uniform((B, 3, h, w), seed=4).to(dev)
+    tm = (synth.hash_uniform((B, h, w), seed=5).to(dev) > 0.5).float()
+    img, loop = image_and_loop_loss(rgbl, target, tm if C == 4 else None, scale_invariant=si)
+    r = rgbl.detach().clone().requires_grad_(True)
+    rgb = r[:, :3]
+    loop_t = torch.zeros((), device=dev)
+    if C == 4:
+        lm = torch.clamp(r[:, -1], 0.001, 1 - 0.001)
+        loop_t = -(tm * torch.log(lm) + (1 - tm) * torch.log(1 - lm)).mean()
+    if si:
+        sc = torch.exp(torch.log((target + 0.01) / (rgb.detach() + 0.01)).mean())
+        rgb = rgb * ((sc + 3) / 4)
+    img_t = ((rgb - target) ** 2).mean()
+    assert abs(float(img) - float(img_t)) <= 2e-6 * max(1.0, float(img_t)) and abs(float(loop) - float(loop_t)) <= 2e-6 * max(1.0, float(loop_t))
+    (ga,) = torch.autograd.grad(0.7 * img + 1.3 * loop, rgbl)
+    (gb,) = torch.autograd.grad(0.7 * img_t + 1.3 * loop_t, r)
+    assert float((ga - gb).abs().max()) <= 1e-6 * max(1.0, float(gb.abs().max())) + 1e-9
+    if C == 4:
+        assert float(gb[:, 3].abs().max()) > 0 and float((gb[:, 3] == 0).float().mean()) > 0.01       # clamped labels carry no gradient
+
+
+@pytest.mark.parametrize("which", ["both", "sparsity", "density"])
+def test_pixel_terms_equal_the_torch_chain(dev, which):
+    """MPI.py:599-603, 647-650 / MPV.py:511-515, 533-536 as vl3d_pixel_terms: mean |a|_1 / max(|a|_2, eps) and mean |alpha - 1|, values and
+    gradients, including pixels no plane covers (sum a^2 = 0: the ratio's denominator sits on its floor, zero gradient to it)."""
+    from videoloop3d_amd.MPV import _PixelTerms, sparsity_ratio
+    T, h, w = 3, 29, 41
+    a = synth.hash_uniform((T, h, w, 8), seed=7).to(dev)
+    a[:, :5, :7] = 0                                                             # uncovered pixels
+    asum = torch.stack([a.sum(-1), (a * a).sum(-1)], -1).requires_grad_(True)
+    alpha = (synth.hash_uniform((T, h, w), seed=8).to(dev) * 1.2).requires_grad_(True)
+    alpha.data[0, 0, :4] = 1.0                                                   # |alpha - 1| at its kink
+    out = _PixelTerms.apply(alpha if which != "sparsity" else None, asum if which != "density" else None, 1e-4)
+    as2, al2 = asum.detach().clone().requires_grad_(True), alpha.detach().clone().requires_grad_(True)
+    sp_t, dn_t = sparsity_ratio(as2, 1e-4).mean(), (al2 - 1).abs().mean()
+    if which != "density":
+        assert abs(float(out[0]) - float(sp_t)) <= 2e-6 * float(sp_t)
+        (g1,) = torch.autograd.grad(out[0] * 1.7, asum)
+        (g2,) = torch.autograd.grad(sp_t * 1.7, as2)
+        assert float((g1 - g2).abs().max()) <= 1e-6 * float(g2.abs().max())
+    if which != "sparsity":
+        assert abs(float(out[1]) - float(dn_t)) <= 2e-6 * float(dn_t)
+        (g1,) = torch.autograd.grad(out[1] * 0.3, alpha)
+        (g2,) = torch.autograd.grad(dn_t * 0.3, al2)
+        assert torch.equal(g1, g2) or float((g1 - g2).abs().max()) <= 1e-9
+
+
 @pytest.mark.parametrize("gain", [True, False])
 def test_loss_prologue_equals_the_torch_chain(dev, gain):
     """MPV.py:484-507 (loop padding, scale-invariant gain, layout) as three kernels against the same lines in torch, value and gradient."""

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import tiles
-from .MPV import ACTIVATES, get_new_intrin, sparsity_ratio
+from .MPV import ACTIVATES, _PixelTerms, get_new_intrin, sparsity_ratio
 from .render import RenderSpec, mask_channel_supported, render_planes, render_planes_with_mask, render_planes_with_regularisers
 from .utils_mpi import compute_homography, make_depths
 
@@ -349,11 +349,18 @@ class MPMesh(nn.Module):
         if self.training:
             K_ = self.mpi_d
             denorm = K_ / self.mpi_d
+            fused_terms = None
+            if variables["alpha"].is_cuda and (a.sparsity_loss_weight > 0 or a.density_loss_weight > 0) and not getattr(a, "unfused_terms", False):
+                fused_terms = _PixelTerms.apply(variables["alpha"] if a.density_loss_weight > 0 else None,
+                                                variables["alpha_sums"] if a.sparsity_loss_weight > 0 else None, 1e-6)
             if a.sparsity_loss_weight > 0:
                 if a.alpha_activate == "none":
                     raise RuntimeError("the fused sparsity term needs a non-negative alpha activation")
-                sp = sparsity_ratio(variables["alpha_sums"], 1e-6)                                # MPI.py:599-603
-                extra["sparsity"] = (sp.mean() / np.sqrt(self.mpi_d)).reshape(1, -1)
+                if fused_terms is not None:
+                    extra["sparsity"] = (fused_terms[0] * (1.0 / np.sqrt(self.mpi_d))).reshape(1, -1)
+                else:
+                    sp = sparsity_ratio(variables["alpha_sums"], 1e-6)                            # MPI.py:599-603
+                    extra["sparsity"] = (sp.mean() / np.sqrt(self.mpi_d)).reshape(1, -1)
             if a.rgb_smooth_loss_weight > 0 or a.a_smooth_loss_weight > 0:
                 nx, ny = B * h * (w - 1) * K_, B * (h - 1) * w * K_
                 sums = variables["smooth_sums"]
@@ -372,5 +379,47 @@ class MPMesh(nn.Module):
                 sm = (lm[:, :, :-1] - lm[:, :, 1:]).abs().mean() + (lm[:, :-1] - lm[:, 1:]).abs().mean()
                 extra["l_smooth"] = (sm * (lm.shape[-1] / self.mpi_d)).reshape(1, -1)
             if a.density_loss_weight > 0:                                                        # MPI.py:647-650
-                extra["density"] = (variables["alpha"] - 1).abs().mean().reshape(1, -1)
+                extra["density"] = (fused_terms[1] if fused_terms is not None else (variables["alpha"] - 1).abs().mean()).reshape(1, -1)
         return rgbl, extra
+
+
+class _Stage1Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgbl, target, target_mask, scale_invariant):
+        from . import _lib as L
+        L.check_cuda(rgbl, target)
+        B, C, h, w = rgbl.shape
+        if C not in (3, 4) or tuple(target.shape) != (B, 3, h, w) or (C == 4 and (target_mask is None or tuple(target_mask.shape) != (B, h, w))):
+            raise RuntimeError(f"stage-1 loss: rgbl {tuple(rgbl.shape)} needs target [B,3,h,w] (and target_mask [B,h,w] for the loop-mask channel)")
+        r = rgbl.detach()
+        if r.dtype != torch.float32 or r.stride(3) * w != r.stride(2):            # pixels of an image must be one strided run (NCHW or NHWC views are)
+            r = r.to(torch.float32).contiguous()
+        t = target.detach().to(torch.float32).contiguous()
+        m = None if C == 3 else target_mask.detach().to(torch.float32).contiguous()
+        dev = r.device
+        scratch = torch.empty(3, dtype=torch.float64, device=dev)
+        grad = torch.empty((B, h, w, C), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.check(L.lib().vl3d_stage1_loss(B, C, h, w, L.ptr(r), r.stride(0), r.stride(1), r.stride(3), L.ptr(t), L.ptr(m), 1 if scale_invariant else 0,
+                                             L.ptr(scratch[2:]), L.ptr(scratch), L.ptr(grad), L.stream_ptr(dev)), "vl3d_stage1_loss")
+        ctx.grad, ctx.counts = grad, (3 * B * h * w, B * h * w)
+        out = scratch[:2].to(torch.float32)
+        return out[0] / ctx.counts[0], out[1] / ctx.counts[1]
+
+    @staticmethod
+    def backward(ctx, g_img, g_loop):
+        g = ctx.grad
+        C = g.shape[-1]
+        k = torch.stack([g_img / ctx.counts[0]] * 3 + ([g_loop / ctx.counts[1]] if C == 4 else [])).to(g.dtype)
+        return (g * k).permute(0, 3, 1, 2), None, None, None
+
+
+def image_and_loop_loss(rgbl, target, target_mask=None, scale_invariant=True):
+    """The image + loop-mask part of a stage-1 iteration's loss (train_3d.py:200-220) on MPMesh.forward's output rgbl [B,3|4,h,w]:
+        loop_loss = -mean(m log l + (1 - m) log(1 - l)),  l = clamp(rgbl[:, -1], .001, .999)            (learn_loop_mask)
+        img_loss  = mean((rgb * s - target)^2),  s = (exp(mean log((target + .01) / (rgb.detach() + .01))) + 3) / 4      (scale_invariant)
+    -> (img_loss, loop_loss) 0-d tensors (loop_loss = 0 without the mask channel), differentiable w.r.t. rgbl, in three launches each way
+    (vl3d_stage1_loss) instead of the ~60 of the torch chain."""
+    if not rgbl.is_cuda:
+        raise RuntimeError("videoloop3d_amd operators run on the MI355X only; there is no CPU fallback")
+    return _Stage1Loss.apply(rgbl, target, target_mask, bool(scale_invariant))

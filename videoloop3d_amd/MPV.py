@@ -88,6 +88,39 @@ class _LoopPrologue(torch.autograd.Function):
         return g_rgb, None, None
 
 
+class _PixelTerms(torch.autograd.Function):
+    """(mean_p |a|_1 / max(|a|_2, eps), mean_p |alpha - 1|) from the render's per-pixel outputs in one launch each way (vl3d_pixel_terms):
+    the sparsity and density regularisers of MPI.py:599-603, 647-650 / MPV.py:511-515, 533-536 were ~30 scalar torch launches per
+    iteration around a 0.2 ms render.  alpha [..] or None, alpha_sums [..,2] or None -> float32 [2] (0 for an absent input)."""
+
+    @staticmethod
+    def forward(ctx, alpha, alpha_sums, eps):
+        from . import _lib as L
+        ref = alpha if alpha is not None else alpha_sums
+        L.check_cuda(ref)
+        dev = ref.device
+        a = None if alpha is None else alpha.detach().to(torch.float32).contiguous()
+        s = None if alpha_sums is None else alpha_sums.detach().to(torch.float32).contiguous()
+        n = a.numel() if a is not None else s.numel() // 2
+        if a is not None and s is not None and s.numel() != 2 * n:
+            raise RuntimeError(f"alpha {tuple(alpha.shape)} and alpha_sums {tuple(alpha_sums.shape)} do not describe the same pixels")
+        sums = torch.empty(2, dtype=torch.float64, device=dev)
+        need_a = a is not None and alpha.requires_grad
+        need_s = s is not None and alpha_sums.requires_grad
+        ga = torch.empty_like(a) if need_a else None
+        gs = torch.empty_like(s) if need_s else None
+        with torch.cuda.device(dev):
+            L.check(L.lib().vl3d_pixel_terms(n, L.ptr(a), L.ptr(s), float(eps), L.ptr(sums), L.ptr(gs), L.ptr(ga), L.stream_ptr(dev)), "vl3d_pixel_terms")
+        ctx.ga, ctx.gs, ctx.n = ga, gs, n
+        return (sums / n).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        ga = None if ctx.ga is None else ctx.ga * (g[1] / ctx.n)
+        gs = None if ctx.gs is None else ctx.gs * (g[0] / ctx.n)
+        return ga, gs, None
+
+
 class _SmoothTerms(torch.autograd.Function):
     """rgb_smooth / a_smooth from the four fused sums (MPV.py:517-531): (c0 s0 + c1 s1, c2 s2 + c3 s3) in two launches each way instead of
     ~16 scalar kernels.  coef: device float32 [4]."""
@@ -724,7 +757,13 @@ class MPMeshVid(nn.Module):
         main_loss = loss(x, res.permute(0, 2, 1, 3, 4), **losscfg)
         extra['swd'] = main_loss.reshape(1, -1) * loss_gain
 
-        if a.sparsity_loss_weight > 0:
+        fused_terms = None
+        if variables["alpha"].is_cuda and (a.sparsity_loss_weight > 0 or a.density_loss_weight > 0) and not getattr(a, "unfused_terms", False):
+            fused_terms = _PixelTerms.apply(variables["alpha"] if a.density_loss_weight > 0 else None,
+                                            variables["alpha_sums"] if a.sparsity_loss_weight > 0 else None, 1e-4)
+        if a.sparsity_loss_weight > 0 and fused_terms is not None:
+            extra["sparsity"] = (fused_terms[0] * (float(loss_gain) / np.sqrt(self.mpi_d))).reshape(1, -1)
+        elif a.sparsity_loss_weight > 0:
             sparsity = sparsity_ratio(variables["alpha_sums"], 1e-4)                       # MPV.py:511-515
             extra["sparsity"] = (sparsity.mean() / np.sqrt(self.mpi_d) * loss_gain).reshape(1, -1)
         if need_smooth:
@@ -752,7 +791,9 @@ class MPMeshVid(nn.Module):
                     extra["rgb_smooth"] = ((sums[0] / (3 * nx) + sums[1] / (3 * ny)) * (loss_gain * denorm)).reshape(1, -1)
                 if a.a_smooth_loss_weight > 0:
                     extra["a_smooth"] = ((sums[2] / nx + sums[3] / ny) * (loss_gain * denorm)).reshape(1, -1)
-        if a.density_loss_weight > 0:
+        if a.density_loss_weight > 0 and fused_terms is not None:
+            extra["density"] = fused_terms[1].reshape(1, -1)
+        elif a.density_loss_weight > 0:
             extra["density"] = (variables["alpha"] - 1).abs().mean().reshape(1, -1)
         if getattr(a, "d_smooth_loss_weight", 0) > 0:                                             # MPV.py:539-551 (off in every shipped configuration)
             disp = variables["disp_norm"]

@@ -91,6 +91,8 @@ SIGNATURES = {
     "vl3d_loop_gain": ([_I32] * 4 + [_P, _P, _P, _P], C.c_int),
     "vl3d_loop_pad_fwd": ([_I32] * 4 + [_P, _P, _P, _P], C.c_int),
     "vl3d_loop_pad_bwd": ([_I32] * 4 + [_P, _I64, _I64, _P, _P, _P], C.c_int),
+    "vl3d_pixel_terms": ([_I64, _P, _P, _F, _P, _P, _P, _P], C.c_int),
+    "vl3d_stage1_loss": ([_I32] * 4 + [_P, _I64, _I64, _I64, _P, _P, _I32, _P, _P, _P, _P], C.c_int),
     "vl3d_robust_fwd": ([_I64, _P, _P, _I32, _F, _F, _P, _P], C.c_int),
     "vl3d_robust_bwd": ([_I64, _P, _P, _I32, _F, _F, _P, _F, _P, _P], C.c_int),
 }
