@@ -113,10 +113,11 @@ def mpv_forward(stack, args, H, W, ref_extrin, ref_intrin, near, far, h, w, tar_
         rgb_pad = rgb_pad * ((scale + 3) / 4)
     x = rgb_pad.permute(1, 0, 2, 3)[None]
     y = res.permute(0, 2, 1, 3, 4)
-    if loss_name in ("gpnn", "gpnn_lm"):
+    if loss_name == "gpnn":                                                             # Patch3DGPNNDirectLoss: no trimming (utils_vid.py:265-286)
         cfg.pop("dist_fn", None)
-        if loss_name == "gpnn":
-            cfg = {"patch_size": 7, "patcht_size": 7, "stride": 1, "stridet": 1, "rou": 0, "scaling": 0.2, **cfg}
+        main, _, _ = VO.gpnn_direct_loss(x, y, **cfg)
+    elif loss_name == "gpnn_lm":
+        cfg.pop("dist_fn", None)
         main, _, _ = VO.gpnn_loss(x, y, **cfg)
     elif loss_name == "mse":
         frm = min(x.shape[2], y.shape[2])

@@ -125,6 +125,15 @@ def gpnn_loss(x, y, macro_block=64, patch_size=7, stride=2, patcht_size=7, strid
     return robust_lossfun(x - y2x, rou, scaling).mean(), y2x, wgt
 
 
+def gpnn_direct_loss(x, y, rou=0, scaling=0.2, patch_size=7, patcht_size=7, stride=1, stridet=1, alpha=1e10, **_):
+    """utils_vid.py:265-286 Patch3DGPNNDirectLoss: NO trimming -- FindNNpatchAndMerge on x as it is (UnfoldNd floors the patch grid, FoldNd fills the
+    whole x.shape: voxels no patch covers get sum 0 / weight 1e-10), the loss mean runs over all of x.  Defaults = FindNNpatchAndMerge's (utils_vid.py:206)."""
+    with torch.no_grad():
+        s, wgt = find_nn_and_merge(x, y, patch_size, patcht_size, stride, stridet, alpha)
+        y2x = s / wgt
+    return robust_lossfun(x - y2x, rou, scaling).mean(), y2x, wgt
+
+
 def compute_nnerr(src, tar, patch_size=7, stride=2, patcht_size=7, stridet=2, macro_block=65):
     """evaluations/NNMSE.py:7-58: mean over macro blocks of mean |NN patch of tar - patch of src| (plain NN, alpha None)."""
     import numpy as np

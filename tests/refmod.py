@@ -85,3 +85,7 @@ def lattice_grad_from_reference(sd, hv, wv, D, T, grad_atlas, grad_atlas_dyn):
         lx = (vx[:, None] * (tw - 1) + ix[None])[:, None, :].expand(-1, th, tw)
         out[kind].index_put_((d[:, None, None].expand(-1, th, tw), ly, lx), tl, accumulate=True)
     return out["dyn"].permute(0, 3, 1, 2, 4).contiguous(), out["static"][:, :, :, 0].contiguous()
+
+
+OTHER_LOSSES = {"gpnn": dict(loss_name="gpnn", loss_gain=1.5, patch_size=5, patcht_size=3, stride=2, stridet=2, rou="0", scaling=0.2, alpha=0.5),
+                "mse": dict(loss_name="mse"), "avg": dict(loss_name="avg", loss_gain=2.0)}

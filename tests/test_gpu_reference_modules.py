@@ -235,3 +235,24 @@ def test_stage2_training_from_the_reference_checkpoint(dev, packed):
     for k in sd:
         if k.startswith("self."):
             assert out[k] == sd[k], k
+
+
+@pytest.mark.parametrize("name", ["gpnn", "mse", "avg"])
+def test_other_loss_entries_match_the_reference(dev, name):
+    """golden (f): MPMeshVid.forward with loss_name 'gpnn' (config_parser.py:56 default: Patch3DGPNNDirectLoss), 'mse', 'avg' on the HIP path."""
+    from videoloop3d_amd.MPV import MPMeshVid, atlas_to_stack, stack_to_atlas
+    g = RM.load("g17_forward")
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    args = RM.mpv_args(5, regs={})
+    h, w, tar_e, K_crop, _ = RM.crop_view(g)
+    v = MPMeshVid(args, H, W, ref_extrin, K, 1.0, 100.0, atlas_exact=True)
+    with torch.no_grad():
+        v.stack.copy_(atlas_to_stack(torch.from_numpy(g["c_atlas_dyn"]), over["mpi_d"], over["atlas_grid_h"]))
+    v = v.to(dev).train()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, extra = v(h, w, tar_e, K_crop, res=torch.from_numpy(g["res"]).to(dev), losscfg=R4.collate(RM.OTHER_LOSSES[name]))
+    _rel(extra["swd"], g[f"f_{name}_extra_swd"], "swd")
+    (gs,) = torch.autograd.grad(extra["swd"].sum(), v.stack)
+    _rel(stack_to_atlas(gs, over["atlas_grid_h"]), g[f"f_{name}_grad_atlas_dyn"], "grad atlas_dyn")

@@ -412,3 +412,18 @@ def test_reader_and_exporter_round_trip_oracle_checkpoints(H, W, scale, hv, wv, 
     # (duplicated border samples of neighbouring tiles differ by the fp32 jitter of their UVs times the atlas' slope -- logits of +-8 over
     #  a few texels here -- and the lattice holds their mean)
     _check_state(m2.reference_state_dict(), sd, atol=5e-4)
+
+
+@pytest.mark.parametrize("name", ["gpnn", "mse", "avg"])
+def test_g17_other_loss_entries_oracle(name):
+    """golden (f): the other entries of MPMeshVid.losses through forward -- 'gpnn' (the parser's default: the direct loss), 'mse', 'avg'."""
+    g = RM.load("g17_forward")
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    args = RM.mpv_args(5, regs={})
+    h, w, tar_e, K_crop, _ = RM.crop_view(g)
+    atlas = torch.from_numpy(g["c_atlas_dyn"]).clone().requires_grad_(True)
+    _, extra = mpv_oracle.mpv_forward(atlas, args, H, W, ref_extrin, K, 1.0, 100.0, h, w, tar_e, K_crop, res=torch.from_numpy(g["res"]),
+                                      losscfg=R4.collate(RM.OTHER_LOSSES[name]), atlas_grid_h=over["atlas_grid_h"])
+    _close(extra["swd"], g[f"f_{name}_extra_swd"], 3e-6, "swd")
+    (ga,) = torch.autograd.grad(extra["swd"].sum(), atlas)
+    _close_grad(ga, g[f"f_{name}_grad_atlas_dyn"], "grad atlas_dyn")
