@@ -256,3 +256,21 @@ def test_other_loss_entries_match_the_reference(dev, name):
     _rel(extra["swd"], g[f"f_{name}_extra_swd"], "swd")
     (gs,) = torch.autograd.grad(extra["swd"].sum(), v.stack)
     _rel(stack_to_atlas(gs, over["atlas_grid_h"]), g[f"f_{name}_grad_atlas_dyn"], "grad atlas_dyn")
+
+
+def test_no_loop_padding_no_gain_matches_the_reference(dev):
+    """golden (g): mpv_isloop off, scale_invariant off (the parser's defaults; the shipped config sets both)."""
+    from videoloop3d_amd.MPV import MPMeshVid, atlas_to_stack, stack_to_atlas
+    g = RM.load("g17_forward")
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    args = RM.mpv_args(5, regs={})
+    args.mpv_isloop, args.scale_invariant = False, False
+    h, w, tar_e, K_crop, _ = RM.crop_view(g)
+    v = MPMeshVid(args, H, W, ref_extrin, K, 1.0, 100.0, atlas_exact=True)
+    with torch.no_grad():
+        v.stack.copy_(atlas_to_stack(torch.from_numpy(g["c_atlas_dyn"]), over["mpi_d"], over["atlas_grid_h"]))
+    v = v.to(dev).train()
+    _, extra = v(h, w, tar_e, K_crop, res=torch.from_numpy(g["res"]).to(dev), losscfg=R4.collate(RM.LOSS_CFGS["other"]))
+    _rel(extra["swd"], g["g_extra_swd"], "swd")
+    (gs,) = torch.autograd.grad(extra["swd"].sum(), v.stack)
+    _rel(stack_to_atlas(gs, over["atlas_grid_h"]), g["g_grad_atlas_dyn"], "grad atlas_dyn")

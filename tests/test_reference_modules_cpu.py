@@ -427,3 +427,19 @@ def test_g17_other_loss_entries_oracle(name):
     _close(extra["swd"], g[f"f_{name}_extra_swd"], 3e-6, "swd")
     (ga,) = torch.autograd.grad(extra["swd"].sum(), atlas)
     _close_grad(ga, g[f"f_{name}_grad_atlas_dyn"], "grad atlas_dyn")
+
+
+def test_g17_no_loop_padding_no_gain_oracle():
+    """golden (g): mpv_isloop off (no frames appended, MPV.py:488-492) and scale_invariant off (MPV.py:499-504)."""
+    g = RM.load("g17_forward")
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    args = RM.mpv_args(5, regs={})
+    args.mpv_isloop, args.scale_invariant = False, False
+    h, w, tar_e, K_crop, _ = RM.crop_view(g)
+    atlas = torch.from_numpy(g["c_atlas_dyn"]).clone().requires_grad_(True)
+    _, extra = mpv_oracle.mpv_forward(atlas, args, H, W, ref_extrin, K, 1.0, 100.0, h, w, tar_e, K_crop, res=torch.from_numpy(g["res"]),
+                                      losscfg=R4.collate(RM.LOSS_CFGS["other"]), atlas_grid_h=over["atlas_grid_h"])
+    _close(extra["swd"], g["g_extra_swd"], 3e-6, "swd")
+    (ga,) = torch.autograd.grad(extra["swd"].sum(), atlas)
+    _close_grad(ga, g["g_grad_atlas_dyn"], "grad atlas_dyn")
+    assert abs(float(g["g_extra_swd"].item()) - float(g["c_plain_extra_swd"].item())) > 1e-4
