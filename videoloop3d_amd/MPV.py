@@ -376,7 +376,9 @@ class MPMeshVid(nn.Module):
                 self._tie_hook = self.stack.register_hook(lambda g: tiles.tie_static_grad(g, self.quad_keep, self.quad_dyn))
 
     def state_dict(self, *args, **kwargs):
-        """MPV.py:290-304: tensors + python scalars under "self.*" keys."""
+        """MPV.py:290-304: tensors + python scalars under "self.*" keys.  Loaded back with init_from_mpi(), like every driver of the reference
+        does (train_3dvid.py:210, scripts/script_render_video.py:119): nn.Module.load_state_dict knows nothing of the "self.*" scalars, of a
+        texture whose resolution changed in lod(), or of a packed model's block table."""
         self._flush_deferred_updates()
         sd = super().state_dict(*args, **kwargs)
         sd["self.is_sparse"] = self.is_sparse

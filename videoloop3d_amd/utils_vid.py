@@ -432,7 +432,9 @@ class Patch3DGPNNDirectLoss(_LazyVotes):
 
 class Patch3DGPNNLowMemLoss(_LazyVotes):
     """utils_vid.py:289-349.  `macro_block` is accepted and fitted (with the reference's warning) but no
-    macro-block loop is needed: the HIP path has no unfold memory to cap and the result is identical."""
+    macro-block loop is needed: the HIP path has no unfold memory to cap and the result is identical.
+    One backward per forward: the fused loss keeps its gradient buffer in place (scaled by the upstream gradient when the backward runs), so
+    differentiating the same loss tensor a second time (retain_graph, gradient penalties) raises -- call the loss again instead."""
 
     def __init__(self):
         self._lazy = self._y2x = self._weight = None
