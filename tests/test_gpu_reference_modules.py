@@ -274,3 +274,29 @@ def test_no_loop_padding_no_gain_matches_the_reference(dev):
     _rel(extra["swd"], g["g_extra_swd"], "swd")
     (gs,) = torch.autograd.grad(extra["swd"].sum(), v.stack)
     _rel(stack_to_atlas(gs, over["atlas_grid_h"]), g["g_grad_atlas_dyn"], "grad atlas_dyn")
+
+
+def test_dense_mpmesh_atlas_exact_matches_the_reference(dev):
+    """golden (a0) / (a): the reference's stage-1 MPMesh.forward on its dense atlas + loop-mask texture -- rgb AND the composited label
+    (MPI.py:568-583), the gradient w.r.t. both textures, the evaluation render -- against MPMesh(atlas_exact=True) on the HIP kernels."""
+    from videoloop3d_amd.MPI import MPMesh
+    from videoloop3d_amd.MPV import atlas_to_stack, stack_to_atlas
+    g15, g = RM.load("g15_sparsify"), RM.load("g17_forward")
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    args = R4.make_args(learn_loop_mask=True, **over)
+    h, w, tar_e, K_crop, K_full = RM.crop_view(g)
+    m = MPMesh(args, H, W, ref_extrin, K, 1.0, 100.0, atlas_exact=True)
+    with torch.no_grad():
+        m.stack.copy_(atlas_to_stack(torch.from_numpy(g15["in_atlas"]), over["mpi_d"], over["atlas_grid_h"]))
+        m.stack_mask.copy_(atlas_to_stack(torch.from_numpy(g15["in_atlas_mask"]), over["mpi_d"], over["atlas_grid_h"])[..., 0])
+    m = m.to(dev).train()
+    rgbl, extra = m(h, w, tar_e, K_crop)
+    assert extra == {} and rgbl.shape == (1, 4, h, w)
+    _close(rgbl, g["a0_rgbl"], 1e-4, "rgbl")
+    gs, gm = torch.autograd.grad((rgbl * torch.from_numpy(g["a0_G"]).to(dev)).sum(), [m.stack, m.stack_mask])
+    _rel(stack_to_atlas(gs, over["atlas_grid_h"]), g["a0_grad_atlas"], "grad atlas")
+    _rel(stack_to_atlas(gm[..., None], over["atlas_grid_h"]), g["a0_grad_atlas_mask"], "grad atlas_mask")
+    assert float(abs(g["a0_grad_atlas_mask"]).max()) > 1e-3
+    m.eval()
+    with torch.no_grad():
+        _close(m(H, W, tar_e, K_full)[0], g["a_eval_rgbl_full"], 1e-4, "eval")

@@ -217,22 +217,23 @@ def _close_grad(a, b, what, rel=3e-5):
     _close(a, b, rel * max(1.0, float(torch.as_tensor(b).abs().max())), what)
 
 
-@pytest.mark.parametrize("tag", ["a", "a2", "a3"])
+@pytest.mark.parametrize("tag", ["a", "a2", "a3", "a0"])
 def test_g17_mpmesh_dense_forward_oracle(tag):
     """mpv_oracle.mpi_forward on the reference's atlas == the reference's MPMesh.forward: rgb + loop-mask label, every regulariser
     (a2 / a3: l_smooth, edge-weighted d_smooth, bg colour, normalised blend weights), gradients to both textures."""
     g15, g = RM.load("g15_sparsify"), RM.load("g17_forward")
     H, W, over, K, ref_extrin, _ = RM.case_A()
     extra_kw = {"a": {}, "a2": dict(l_smooth_loss_weight=0.3, d_smooth_loss_weight=0.1, bg_color="0.2#0.4#0.6"),
-                "a3": dict(l_smooth_loss_weight=0.3, d_smooth_loss_weight=0.1, normalize_blendweight_fordepth=True)}[tag]
-    args = R4.make_args(learn_loop_mask=True, **over, **RM.REG, **extra_kw)
+                "a3": dict(l_smooth_loss_weight=0.3, d_smooth_loss_weight=0.1, normalize_blendweight_fordepth=True),
+                "a0": dict(sparsity_loss_weight=0.0, rgb_smooth_loss_weight=0.0, a_smooth_loss_weight=0.0, density_loss_weight=0.0)}[tag]
+    args = R4.make_args(learn_loop_mask=True, **{**over, **RM.REG, **extra_kw})
     h, w, tar_e, K_crop, _ = RM.crop_view(g)
     atlas = torch.from_numpy(g15["in_atlas"]).clone().requires_grad_(True)
     mask = torch.from_numpy(g15["in_atlas_mask"]).clone().requires_grad_(True)
     rgbl, extra = mpv_oracle.mpi_forward(atlas, mask, args, H, W, ref_extrin, K, 1.0, 100.0, h, w, tar_e, K_crop, atlas_grid_h=over["atlas_grid_h"])
     _close(rgbl, g[f"{tag}_rgbl"], 2e-6, "rgbl")
     keys = sorted(k[len(tag) + 7:] for k in g.files if k.startswith(f"{tag}_extra_"))
-    assert sorted(extra) == keys and ("l_smooth" in keys) == (tag != "a")
+    assert sorted(extra) == keys and ("l_smooth" in keys) == (tag in ("a2", "a3")) and (keys == []) == (tag == "a0")
     for k in keys:
         _close(extra[k], g[f"{tag}_extra_{k}"], 2e-6 * max(1.0, float(abs(g[f"{tag}_extra_{k}"]).max())), k)
     total = (rgbl * torch.from_numpy(g[f"{tag}_G"])).sum() + sum(getattr(args, k + "_loss_weight") * v.sum() for k, v in extra.items())

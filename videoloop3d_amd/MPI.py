@@ -54,8 +54,13 @@ class _LoopMaskLabel(torch.autograd.Function):
 
 
 class MPMesh(nn.Module):
-    def __init__(self, args, H, W, ref_extrin, ref_intrin, near, far, pixel_center=0.5, texel_scale=(1.0, 1.0)):
+    def __init__(self, args, H, W, ref_extrin, ref_intrin, near, far, pixel_center=0.5, texel_scale=(1.0, 1.0), atlas_exact=False):
+        """atlas_exact=True: sample the stack exactly like the reference samples its atlas of plane cells (MPI.py:75-81, 490-520: cell pitch
+        (Aw-1)/(gw*(mpi_w-1)), per-cell sub-texel origin, neighbour-cell bleed) -- videoloop3d_amd/atlas.py, as MPMeshVid(atlas_exact=True).  A
+        parity mode for dense weights that come from / go to the reference (MPV.atlas_to_stack / stack_to_atlas): the image and the loop-mask label
+        (a second pass), no fused regularisers, no tile culling; needs args.atlas_grid_h."""
         super().__init__()
+        self.atlas_exact = bool(atlas_exact)
         self.args = args
         mpi_h, mpi_w = int(args.mpi_h_scale * H), int(args.mpi_w_scale * W)
         self.mpi_h, self.mpi_w = mpi_h, mpi_w
@@ -276,9 +281,11 @@ class MPMesh(nn.Module):
         qk = self.quad_keep if (self.is_sparse and getattr(self, "quad_keep", None) is not None) else None
         # the loop mask rides the colour pass as a fifth channel where the kernels are built for it (the shipped planar convention, a CUDA
         # stack); args.loop_mask_two_pass keeps the separate label pass (A/B, cross-checks)
+        if self.atlas_exact and (need_reg or need_layers or self.is_sparse or tuple(self.stack.shape[2:4]) != (self.mpi_h, self.mpi_w)):
+            raise RuntimeError("atlas_exact renders the dense full-resolution stack without regularisers / materialised layers / tile culling")
         fused_mask = (self.learn_loop_mask and self.stack.is_cuda and mask_channel_supported(self.stack, self.spec)
-                      and not self.is_sparse and not getattr(self.args, "loop_mask_two_pass", False))
-        if self.learn_loop_mask and not fused_mask:
+                      and not self.is_sparse and not self.atlas_exact and not getattr(self.args, "loop_mask_two_pass", False))
+        if self.learn_loop_mask and not fused_mask and not self.atlas_exact:
             if getattr(self, "_mask_buf", None) is None or self._mask_buf.shape != self.stack.shape or self._mask_buf.device != self.stack.device:
                 self._mask_buf = torch.zeros_like(self.stack)
             with torch.no_grad():          # channel 0: mask logit, channel 3: the layer alpha logit (detached, MPI.py:572)
@@ -292,7 +299,16 @@ class MPMesh(nn.Module):
                 homos = homos.pin_memory().to(self.stack.device, non_blocking=True)
             else:
                 homos = homos.to(self.stack.device)
-            if fused_mask:
+            if self.atlas_exact:
+                from .atlas import render_atlas_exact
+                gh = int(self.args.atlas_grid_h)
+                rgb, alpha = render_atlas_exact(self.stack, homos, H, W, gh, pixel_center=self.spec.pixel_center, rgb_act=self.spec.rgb_act,
+                                                alpha_act=self.spec.alpha_act)
+                if self.learn_loop_mask:      # MPI.py:568-583: sigmoid(sample(mask texture)) composited with the DETACHED layer alphas
+                    z = torch.zeros_like(self.stack_mask)
+                    lab_stack = torch.stack([self.stack_mask, z, z, self.stack[..., 3].detach()], -1)
+                    labels.append(render_atlas_exact(lab_stack, homos, H, W, gh, pixel_center=self.spec.pixel_center)[0][..., :1])
+            elif fused_mask:
                 rgb, alpha, label, ss, asum = render_planes_with_mask(self.stack, self.stack_mask, homos, H, W, self.spec, with_regularisers=need_reg)
                 labels.append(label[..., None])
                 if need_reg:
@@ -315,7 +331,7 @@ class MPMesh(nn.Module):
             alphas.append(alpha)
             if need_layers:
                 lay.append(self._layer_variables(homos, H, W, extrin[b], qk))
-            if self.learn_loop_mask and not fused_mask:                                           # MPI.py:568-583
+            if self.learn_loop_mask and not fused_mask and not self.atlas_exact:                  # MPI.py:568-583
                 labels.append(_LoopMaskLabel.apply(self.stack_mask, self.stack, self._mask_buf, homos, H, W, self.spec_mask))
         rgb = torch.cat(rgbs, 0)
         rgbl = torch.cat([rgb, torch.cat(labels, 0)], dim=-1) if self.learn_loop_mask else rgb
