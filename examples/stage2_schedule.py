@@ -40,7 +40,7 @@ def make_views(V, H, W, frames, dev):
     return torch.tensor(np.stack(poses), dtype=torch.float32), torch.tensor(K, dtype=torch.float32)[None].repeat(V, 1, 1), vids
 
 
-def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, dev="cuda:0", sparsify=False):
+def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, dev="cuda:0", sparsify=False, fused=True):
     from videoloop3d_amd.MPV import MPMeshVid
     from videoloop3d_amd.train_3dvid import MVVidPatchDataset, run_iter
     dev = torch.device(dev)
@@ -51,7 +51,8 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
         add_uv_noise=False, fp16=False, swd_patch_size=3, swd_patcht_size=3, swd_stride=2, swd_stridet=1,
         sparsity_loss_weight=0.0, rgb_smooth_loss_weight=smooth, a_smooth_loss_weight=smooth, density_loss_weight=0.0,
         d_smooth_loss_weight=0.0, swd_loss_weight=1.0, optimizer="adam", lrate=0.5, lrate_decay=100, lrate_adaptive=True,
-        add_intrin_noise=True, mpi_h_verts=36, mpi_w_verts=64)
+        add_intrin_noise=True, mpi_h_verts=36, mpi_w_verts=64,
+        fused_adam_backward=bool(fused))      # dense models: the optimiser step inside the render backward (vl3d_render_bwd_adam)
     poses, intrins, vids = make_views(views, H, W, clip, dev)
     K = intrins[0].numpy()
     model = MPMeshVid(args, H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
@@ -134,7 +135,7 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
                                 "p50": int(np.searchsorted(c, 0.5)), "p90": int(np.searchsorted(c, 0.9)), "max": int(len(depth_hist) - 1),
                                 "histogram_by_8": [int(depth_hist[i:i + 8].sum()) for i in range(0, len(depth_hist), 8)]}
     out["shape"] = (f"V={views} views, D={planes}, T={frames}, clips of {clip} frames, 360x640 frames, crops 180x320 stride 90x160 at the last "
-                    f"{levels} pyramid levels, {epochs} epochs per level, smooth {smooth}, {'tile-culled' if sparsify else 'dense'} model")
+                    f"{levels} pyramid levels, {epochs} epochs per level, smooth {smooth}, {'tile-culled' if sparsify else 'dense'} model{'' if sparsify else (', step inside the backward' if fused else ', backward + step kernel')}")
     return out
 
 
@@ -143,7 +144,8 @@ if __name__ == "__main__":
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--epochs", type=int, default=2)
     ap.add_argument("--sparsify", action="store_true")
+    ap.add_argument("--two-kernels", action="store_true", help="dense model: vl3d_render_bwd + the step kernel instead of the step inside the backward")
     a = ap.parse_args()
     import __graft_entry__ as g
     g.build()
-    print(json.dumps(run(a.views, a.epochs, sparsify=a.sparsify)))
+    print(json.dumps(run(a.views, a.epochs, sparsify=a.sparsify, fused=not a.two_kernels)))

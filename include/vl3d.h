@@ -175,6 +175,36 @@ int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t 
                           const uint8_t *quad_dyn,
                           int32_t QH, int32_t QW, int32_t static_tied, vl3d_stream_t stream);
 
+/* The optimiser step INSIDE the render backward (train_3dvid.py:242-244: loss.backward(); optimizer.step() -- for the dense stage-2 model
+ * they are one pass over the window's texels).  vl3d_render_bwd of the crop-aware iteration writes the window's compact gradient
+ * (one stream) only for vl3d_adam_window_step to read it back beside (p, m, v) and write (p, m, v): 2 + 7 streams of the window.  Here the
+ * owner-computes backward applies the step of `adam->step` where it would have stored a texel's complete gradient sum: 1 (taps) + 2 (m, v)
+ * + 3 (p, m, v) streams, no gradient round trip.  `stack` is the compact copy of the texel window at (adam->y0, adam->x0) of the
+ * (D,T,adam->Hs,adam->Ws,4) parameter -- desc->Hs x desc->Ws texels, written by vl3d_adam_window_catchup(_boxes) with upto = step - 1, so it
+ * holds the parameters current for step - 1 and only the two moments are replayed (multiplications).  Window / plane_boxes / last_step /
+ * hist: as vl3d_adam_window_step_boxes (hist[step] written by the caller); on return the window's tiles are marked `step` and (p, m, v) are
+ * bit for bit what vl3d_render_bwd followed by vl3d_adam_window_step_boxes would have left (tests/test_gpu_optim.py).  Every texel of
+ * window and box is stepped exactly once: by the tile that owns it, or -- texels no tile's gather reaches: zero gradient -- by the
+ * backward's pre-pass.  grad_stack (the compact gradient, desc's dims) is still required: when the device-side plan finds the view
+ * infeasible for the owner-computes kernels the atomics kernel fills it and the step kernel runs behind it, decided on the device (no
+ * host synchronisation either way); it is left unwritten otherwise.  Dense fp32 stacks, T >= 2, the planar convention with the shipped
+ * activations ((affine, hardcut, post), sigmoid / sigmoid), desc->variant 0; anything else: VL3D_EUNSUPPORTED, nothing launched. */
+typedef struct vl3d_adam_window {
+    int32_t Hs, Ws;              /* the full planes: param / exp_avg / exp_avg_sq are (D,T,Hs,Ws,4) */
+    int32_t y0, x0;              /* the window [y0, y0 + desc->Hs) x [x0, x0 + desc->Ws), aligned to vl3d_adam_window_tile() */
+    float *param, *exp_avg, *exp_avg_sq;
+    int32_t *last_step;
+    const float *hist;
+    float lr, beta1, beta2, eps;
+    int64_t step;
+    const int32_t *plane_boxes;  /* HOST [D][4] or NULL */
+    void *boxes_scratch;         /* device, 16 * D bytes; required with plane_boxes */
+} vl3d_adam_window;
+int vl3d_render_bwd_adam(const vl3d_render_desc *desc, const void *stack, const float *homos, const float *rgb, const float *alpha,
+                         const float *grad_rgb, const float *grad_alpha, const float *grad_reg, const void *reg_state,
+                         const float *grad_alpha_sums, float *grad_stack, void *scratch, int64_t scratch_bytes,
+                         const vl3d_adam_window *adam, vl3d_stream_t stream);
+
 /* PACKED storage of a tile-culled model (`blocks` != NULL on the three entry points below; quad maps required): the reference keeps a
  * static atlas (one frame), a dynamic atlas (T frames) and no storage for culled quads (MPI.py:364-436, MPV.py:235-288).  Here
  * param / exp_avg / exp_avg_sq are pools of 8 x 8-texel blocks (vl3d_adam_window_tile()): blocks [D][ceil(Hs/8)][ceil(Ws/8)] int32 = -1 for

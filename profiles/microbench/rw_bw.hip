@@ -103,6 +103,44 @@ __global__ __launch_bounds__(RX *RY) void bwd_like_k(const f4 *__restrict__ src,
     }
 }
 
+// The optimiser fused into the owner store (verdict round 3, next #3), as a memory pattern: the shipped halo pattern, but an interior thread
+// does not store its gradient texel -- it READS the two moments of its texel (m, v: two more streams at the tile's ragged segments; p comes
+// with the taps) and WRITES p, m, v (three streams instead of one).  Compared below with what it replaces: the shipped pattern's one
+// gradient store plus a separate streaming step kernel over whole rows (4 reads p, g, m, v; 3 writes p, m, v).
+template <int RX, int RY, int FR>
+__global__ __launch_bounds__(RX *RY) void bwd_like_adam_k(const f4 *__restrict__ src, f4 *__restrict__ dst, const unsigned short *__restrict__ owner, int D,
+                                                          int T, int Hs, int Ws, int tiles_x, int tiles_y, size_t unit) {
+    const int b = blockIdx.x;
+    const int q = gridDim.x >> 3, r = gridDim.x & 7, xcd = b & 7, k = b >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    const int tile_x = bid % tiles_x, rest = bid / tiles_x, tile_y = rest % tiles_y, t0 = (rest / tiles_y) * FR;
+    const int lx = threadIdx.x % RX, ly = threadIdx.x / RX;
+    const int gx = tile_x * (RX - 2) - 1 + lx;
+    const int x = min(max(gx, 0), Ws - 2), y = min(max(tile_y * (RY - 2) - 1 + ly, 0), Hs - 2);
+    const bool interior = lx >= 1 && lx < RX - 1 && ly >= 1 && ly < RY - 1 && gx < Ws && tile_y * (RY - 2) - 1 + ly < Hs;
+    const size_t frame = (size_t)Hs * Ws, plane = (size_t)T * frame;
+    size_t o = (size_t)t0 * frame + (size_t)y * Ws + x;
+    size_t oo = (size_t)y * Ws + x;
+    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < D; ++d, o += plane, oo += frame) {
+        f4 v[FR];
+        const unsigned e = owner[oo];
+#pragma unroll
+        for (int f = 0; f < FR; ++f) v[f] = src[o + f * frame] + src[o + f * frame + 1] + src[o + f * frame + Ws] + src[o + f * frame + Ws + 1];
+        if (interior) {
+#pragma unroll
+            for (int f = 0; f < FR; ++f) {
+                const size_t i = o + f * frame;
+                const f4 g = v[f] + acc, m = src[unit + i] * 0.9f + g * 0.1f, vv = src[2 * unit + i] * 0.999f + g * g * 0.001f;
+                __builtin_nontemporal_store(v[f] - m * 0.01f, &dst[i]);
+                __builtin_nontemporal_store(m, &dst[unit + i]);
+                __builtin_nontemporal_store(vv, &dst[2 * unit + i]);
+            }
+        }
+        acc.x += (float)e;
+    }
+}
+
 // HALO-ATOMICS backward (SURVEY §7's design, priced in round 4): NO halo -- a workgroup sweeps exactly the RX x RY pixels it owns (x1.00
 // instead of x1.22 pixels swept per pixel owned) -- so a texel whose 3 x 3 gathering pixels straddle a tile border gets a PARTIAL sum from
 // each side: the tile's perimeter threads add theirs with float atomics (4 x global_atomic_add_f32 per 16-byte texel) to their own
@@ -257,7 +295,7 @@ static void run(const char *name, F launch, double bytes) {
 }
 
 int main(int argc, char **argv) {
-    const bool aligned_only = argc > 1 && (argv[1][0] == 'a' || argv[1][0] == 'h');      // ./rw_bw aligned | halo: only that comparison at the end
+    const bool aligned_only = argc > 1 && (argv[1][0] == 'a' || argv[1][0] == 'h' || argv[1][0] == 'f');      // ./rw_bw aligned | halo: only that comparison at the end
     const bool halo_only = argc > 1 && argv[1][0] == 'h';
     const size_t unit = 8ull << 30, n = unit / 16;     // 8 GiB per stream
     f4 *src, *dst;
@@ -332,6 +370,40 @@ int main(int argc, char **argv) {
         BLS(64, 16, 1, 0, 8) BLS(64, 16, 1, 1, 8) BLS(64, 16, 1, 2, 8) BLS(64, 16, 1, 3, 8)
         BLS(64, 8, 1, 0, 8) BLS(64, 8, 1, 1, 8) BLS(64, 8, 1, 2, 8) BLS(128, 8, 1, 0, 8) BLS(128, 8, 1, 2, 8) BLS(128, 4, 1, 0, 8) BLS(128, 4, 1, 2, 8)
     }
+    }
+    // The fused optimiser epilogue against what it replaces (round 4): ./rw_bw fused
+    if (argc > 1 && argv[1][0] == 'f') {
+        const int D = 32, T = 12, Hs = 720, Ws = 1280;
+        const size_t texels = (size_t)D * T * Hs * Ws;
+        unsigned short *owner;
+        hipMalloc(&owner, (size_t)D * Hs * Ws * 2 + 4096);
+        hipMemset(owner, 0, (size_t)D * Hs * Ws * 2 + 4096);
+        for (int rep = 0; rep < 2; ++rep) {
+            {
+                const int tx = (Ws + 29) / 30, ty = (Hs + 13) / 14;
+                run("backward pattern 32x16x2, gradient STORED (1 read + 1 write stream)            [bytes: 2 streams]",
+                    [&] { hipLaunchKernelGGL((bwd_like_k<32, 16, 2, 4, true, 0, 8, 1>), dim3((unsigned)(tx * ty * (T / 2))), dim3(512), 0, 0, src, dst, owner, D, T, Hs, Ws, tx, ty); },
+                    2.0 * texels * 16);
+                run("backward pattern 32x16x2, Adam IN the owner store (3 read + 3 write streams)    [bytes: 6 streams]",
+                    [&] { hipLaunchKernelGGL((bwd_like_adam_k<32, 16, 2>), dim3((unsigned)(tx * ty * (T / 2))), dim3(512), 0, 0, src, dst, owner, D, T, Hs, Ws, tx, ty, n); },
+                    6.0 * texels * 16);
+                const int tx1 = (Ws + 61) / 62;
+                run("backward pattern 64x16x1, Adam IN the owner store (3 read + 3 write streams)    [bytes: 6 streams]",
+                    [&] { hipLaunchKernelGGL((bwd_like_adam_k<64, 16, 1>), dim3((unsigned)(tx1 * ty * T)), dim3(1024), 0, 0, src, dst, owner, D, T, Hs, Ws, tx1, ty, n); },
+                    6.0 * texels * 16);
+                const int ty8 = (Hs + 5) / 6;
+                run("backward pattern 64x8x2, Adam IN the owner store (3 read + 3 write streams)     [bytes: 6 streams]",
+                    [&] { hipLaunchKernelGGL((bwd_like_adam_k<64, 8, 2>), dim3((unsigned)(tx1 * ty8 * (T / 2))), dim3(512), 0, 0, src, dst, owner, D, T, Hs, Ws, tx1, ty8, n); },
+                    6.0 * texels * 16);
+            }
+            {
+                const size_t grid = texels / (256 * 4);
+                run("separate step kernel over the same texels (4 read + 3 write streams, whole rows) [bytes: 7 streams]",
+                    [&] { hipLaunchKernelGGL((rw_k<4, 3, true, 4>), dim3((unsigned)grid), dim3(256), 0, 0, src, dst, texels); }, 7.0 * texels * 16);
+            }
+        }
+        printf("fused = row 2;  unfused = row 1 + row 3\n");
+        return 0;
     }
     // Halo-atomics backward against the shipped halo pattern (round 4), same geometry, algorithmic bytes as the unit.
     if (halo_only) {

@@ -382,3 +382,71 @@ def test_window_adam_state_dict_round_trip(dev):
     oa.flush(); ob.flush()
     assert torch.equal(pa.detach(), pb.detach())
     assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"])
+
+
+@pytest.mark.parametrize("smooth,T,scale,rot", [(0.2, 4, 1.1, 0.0), (0.0, 5, 1.6, 0.0), (0.2, 5, 1.25, 0.0), (0.2, 4, 1.1, 40.0)])
+def test_step_fused_into_the_backward_equals_backward_then_step(dev, smooth, T, scale, rot):
+    """WindowAdam(fused_backward=True) -- vl3d_render_bwd_adam: the owner-computes backward applies the optimiser's step where it would have
+    stored a texel's gradient -- against the two-kernel path (vl3d_render_bwd, then vl3d_adam_window_step_boxes) on two copies of one
+    model over the same shuffled crops: the SAME BITS in the parameters, both moments and the step table after every iteration (texels
+    owned by a tile, texels only the pre-pass reaches, texels outside their plane's box, deferred tiles coming back), with and without the
+    layer regularisers, even and odd frame counts, stacks above the frame's resolution (windows larger than a workgroup), and a view the
+    device-side plan refuses (rot 40 degrees about the optical axis: the atomics kernel + the step kernel run instead, decided on the
+    device) -- there the gradient comes from atomics, so only the loss is compared exactly and the parameters to the atomics' noise."""
+    import warnings
+    import videoloop3d_amd.render as R
+    from videoloop3d_amd.MPV import MPMeshVid
+    H, W, h, w = 96, 128, 48, 64
+    K = np.array([[0.9 * W, 0, W / 2], [0, 0.9 * W, H / 2], [0, 0, 1]], np.float64)
+    kw = dict(mpv_frm_num=T, mpi_h_scale=scale, mpi_w_scale=scale, rgb_smooth_loss_weight=smooth, a_smooth_loss_weight=smooth,
+              sparsity_loss_weight=0.01 if smooth else 0.0)
+    torch.manual_seed(5)
+    A = MPMeshVid(_args(fused_adam_backward=False, **kw), H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
+    B = MPMeshVid(_args(**kw), H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()      # (the default for dense models)
+    B.load_state_dict({k: v for k, v in A.state_dict().items() if not k.startswith("self.")})
+    oa, ob = A.get_optimizer(0), B.get_optimizer(0)
+    assert ob.fused_backward and not oa.fused_backward
+    tar = np.eye(4)
+    c, s_ = np.cos(np.radians(rot)), np.sin(np.radians(rot))
+    tar[:3, :3] = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]])
+    tar[:3, 3] = [0.03, 0.01, 0.0]
+    res = synth.hash_uniform((1, 2 * T + 1, 3, h, w), seed=8, device=dev)
+    cfg = dict(loss_name=["gpnn_lm"], loss_gain=torch.tensor([1.0]), macro_block=torch.tensor([65]), patch_size=torch.tensor([3]),
+               stride=torch.tensor([2]), patcht_size=torch.tensor([3]), stridet=torch.tensor([1]), alpha=torch.tensor([10000.0]),
+               dist_fn=["mse"], rou=["-2"], scaling=torch.tensor([0.1]))
+    offs = [(0, 0), (40, 60), (10, 30), (48, 64), (0, 64), (40, 0), (20, 20), (0, 0), (48, 64), (10, 30)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for it, (oy, ox) in enumerate(offs):
+            Kc = K.copy()
+            Kc[0, 2] -= ox
+            Kc[1, 2] -= oy
+            losses, feasible = [], []
+            for model, opt in ((A, oa), (B, ob)):
+                for grp in opt.param_groups:
+                    grp["lr"] = 5e-3 * 0.9 ** it
+                opt.zero_grad(set_to_none=True)
+                _, extra = model(h, w, torch.tensor(tar)[None], torch.tensor(Kc)[None], res=res, losscfg=dict(cfg))
+                loss = extra["swd"].sum()
+                if smooth:
+                    loss = loss + 0.2 * extra["rgb_smooth"].sum() + 0.2 * extra["a_smooth"].sum() + 0.01 * extra["sparsity"].sum()
+                loss.backward()
+                feasible.append(int(R.LAST_BWD_SCRATCH[:1].view(torch.int32)))
+                opt.step()
+                losses.append(float(loss.detach()))
+            assert feasible[0] == feasible[1] == (0 if rot else 1)
+            sa, sb = oa.state[oa.p], ob.state[ob.p]
+            assert torch.equal(sa["last_step"], sb["last_step"]) and oa.t == ob.t == it + 1
+            if rot:
+                assert abs(losses[0] - losses[1]) <= 1e-5 * max(1.0, abs(losses[0]))
+                continue
+            assert losses[0] == losses[1], (it, losses)
+            for name, x, y in (("p", A.stack.data, B.stack.data), ("m", sa["exp_avg"], sb["exp_avg"]), ("v", sa["exp_avg_sq"], sb["exp_avg_sq"])):
+                assert torch.equal(x, y), (it, name, float((x - y).abs().max()), int((x != y).sum()))
+    assert ob.fused_steps == len(offs) and oa.fused_steps == 0
+    assert B.stack.grad is None
+    sda, sdb = A.state_dict(), B.state_dict()           # flushes the deferred updates
+    if rot:
+        assert float((sda["stack"] - sdb["stack"]).abs().mean()) <= 1e-6
+    else:
+        assert torch.equal(sda["stack"], sdb["stack"])

@@ -555,7 +555,12 @@ class MPMeshVid(nn.Module):
                 # compact gradient, the step touches the window only; the zero-gradient updates of everything else are deferred and
                 # replayed exactly (videoloop3d_amd/optim.py).  While it is attached, training renders go through its window.
                 from .optim import WindowAdam
-                self._window_opt = WindowAdam(params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8)
+                # The step is taken INSIDE the render's backward (vl3d_render_bwd_adam: the owner's store applies it; same bits as the two
+                # kernels, 6 instead of 9 streams of the window) -- `loss.backward(); optimizer.step()` of train_3dvid.py:242-244 then update
+                # the parameters at the backward.  args.fused_adam_backward = False or args.finite_window_grad (someone reads the window
+                # leaf's gradient: clipping, norm logging) keep the gradient tensor and the separate step kernel.
+                fused = bool(getattr(self.args, "fused_adam_backward", True)) and not getattr(self.args, "finite_window_grad", False)
+                self._window_opt = WindowAdam(params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8, fused_backward=fused)
                 return self._window_opt
             return torch.optim.Adam(params=params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8)
         if self.args.optimizer == 'sgd':
@@ -665,6 +670,8 @@ class MPMeshVid(nn.Module):
         # path: garbage + 0 is garbage) or the caller asked for a finite gradient everywhere (args.finite_window_grad: gradient clipping,
         # norm logging, isfinite checks on leaf.grad).
         lean_grad = cull_window is not None and not need_layers and not getattr(self.args, "finite_window_grad", False)
+        # WindowAdam(fused_backward=True): the render's backward takes the optimiser's step for the window leaf (nothing else may add to it)
+        fused_adam = self._window_opt if (cull_window is not None and not need_layers and getattr(self._window_opt, "fused_backward", False)) else None
         if self.atlas_exact:
             if need_smooth or self.is_sparse or tuple(stack.shape[2:4]) != (self.mpi_h, self.mpi_w):
                 raise RuntimeError("atlas_exact renders the dense full-resolution stack without the fused regularisers / tile culling / lod")
@@ -676,11 +683,11 @@ class MPMeshVid(nn.Module):
             rgb, alpha, smooth_sums, alpha_sums = render_planes_with_regularisers(stack, homos, H, W, spec,
                                                                                   quad_keep=self.quad_keep if self.is_sparse else None,
                                                                                   cull_window=cull_window,
-                                                                                  grad_culled_unwritten=lean_grad)
+                                                                                  grad_culled_unwritten=lean_grad, fused_adam=fused_adam)
         else:
             # a sparsified model renders with tile culling: samples in culled quads are uncovered, workgroups skip planes without kept quads
             rgb, alpha = render_planes(stack, homos, H, W, spec, quad_keep=self.quad_keep if self.is_sparse else None, cull_window=cull_window,
-                                       grad_culled_unwritten=lean_grad)
+                                       grad_culled_unwritten=lean_grad, fused_adam=fused_adam)
         variables = {"pix_to_face": None, "blend_weight": None, "mpi": None, "disp_norm": None, "alpha": alpha,
                      "smooth_sums": smooth_sums, "alpha_sums": alpha_sums}
         if need_layers:

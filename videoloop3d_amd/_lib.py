@@ -42,6 +42,14 @@ class LossDesc(C.Structure):
 _P = C.c_void_p
 _I32, _I64, _F = C.c_int32, C.c_int64, C.c_float
 
+
+class AdamWindow(C.Structure):
+    _fields_ = [("Hs", C.c_int32), ("Ws", C.c_int32), ("y0", C.c_int32), ("x0", C.c_int32),
+                ("param", _P), ("exp_avg", _P), ("exp_avg_sq", _P), ("last_step", _P), ("hist", _P),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("step", C.c_int64), ("plane_boxes", _P), ("boxes_scratch", _P)]
+
+
 # symbol -> argtypes; every symbol include/vl3d.h declares must be listed here (tests/test_abi.py checks).
 SIGNATURES = {
     "vl3d_last_error": ([], C.c_char_p),
@@ -49,6 +57,7 @@ SIGNATURES = {
     "vl3d_render_fwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P, _P], C.c_int),
     "vl3d_render_bwd_scratch_bytes": ([C.POINTER(RenderDesc)], C.c_int64),
     "vl3d_render_bwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
+    "vl3d_render_bwd_adam": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, C.POINTER(AdamWindow), _P], C.c_int),
     "vl3d_render_reg_state_bytes": ([C.POINTER(RenderDesc)], C.c_int64),
     "vl3d_render_reg_fwd_culled": ([C.POINTER(RenderDesc), _P, _P, _P, _I32, _I32, _P, _P, _P], C.c_int),
     "vl3d_tie_static_grad": ([_I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _I32, _P], C.c_int),

@@ -1,0 +1,79 @@
+// The Adam arithmetic of the plane stack's optimiser (torch.optim.Adam without amsgrad / weight decay; train_3dvid.py:263-290, MPV.py:199-214),
+// shared by the optimiser kernels (vl3d_optim.hip) and the render backward's fused owner store (vl3d_render_core.h, render_bwd_pair_k<ADAM>):
+// ONE spelling, every product and sum an explicit fma / mul, so that a step taken inside the backward, a step taken by the step kernel and
+// a deferred step replayed later give the same bits whatever code surrounds them (no contraction is left to the compiler's choice).
+#pragma once
+#include "vl3d_common.h"
+
+namespace vl3d_adam {
+
+constexpr int TS = 8;       // side of the optimiser's bookkeeping tiles in texels (vl3d_adam_window_tile)
+
+// exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+__device__ __forceinline__ void adam_moments(float &mm, float &vv, float gg, float beta1, float beta2) {
+    mm = __builtin_fmaf(beta1, mm, (1.0f - beta1) * gg);
+    vv = __builtin_fmaf(beta2, vv, ((1.0f - beta2) * gg) * gg);
+}
+
+// One Adam step of one value.  The square root and the two quotients are the hardware's v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the
+// correctly rounded expansions (~40 instructions per value and step): the deferred zero-gradient steps are REPLAYED through this very
+// function -- on the reference's schedule a returning window replays 2-4 steps per texel, twice per iteration, and with the IEEE forms
+// that arithmetic, not the 7 memory streams, set the time of the catch-up and step kernels (2.5 + 3.5 ms against 1.0 + 2.0 at depth ~1).
+// Every path (dense step, window step, catch-up, flush, the render backward's fused store) goes through it, so deferring stays bit-identical
+// to not deferring; against torch.optim.Adam the update term differs by <= 3 ulp per step (tests/test_gpu_optim.py: <= 2e-6 on the
+// parameters after 40 steps).
+__device__ __forceinline__ void adam_upd(float &pp, float gg, float &mm, float &vv, float lr_bc1, float beta1, float beta2, float eps, float bc2s) {
+    adam_moments(mm, vv, gg, beta1, beta2);
+    const float den = __builtin_fmaf(__builtin_amdgcn_sqrtf(vv), __builtin_amdgcn_rcpf(bc2s), eps);      // sqrt(exp_avg_sq)/sqrt(bc2) + eps
+    pp = __builtin_fmaf(-lr_bc1, mm * __builtin_amdgcn_rcpf(den), pp);                                    // param.addcdiv_(exp_avg, den, value=-lr/bc1)
+}
+
+__device__ __forceinline__ void adam_upd4(float4 &pp, const float4 gg, float4 &mm, float4 &vv, float lr_bc1, float beta1, float beta2, float eps,
+                                          float bc2s) {
+    adam_upd(pp.x, gg.x, mm.x, vv.x, lr_bc1, beta1, beta2, eps, bc2s);
+    adam_upd(pp.y, gg.y, mm.y, vv.y, lr_bc1, beta1, beta2, eps, bc2s);
+    adam_upd(pp.z, gg.z, mm.z, vv.z, lr_bc1, beta1, beta2, eps, bc2s);
+    adam_upd(pp.w, gg.w, mm.w, vv.w, lr_bc1, beta1, beta2, eps, bc2s);
+}
+
+// the zero-gradient steps from+1 .. upto of one texel, in registers (the dense update's operations with g = 0, in its order)
+__device__ __forceinline__ void replay(float4 &pp, float4 &mm, float4 &vv, const float2 *__restrict__ hist, int from, int upto, float beta1,
+                                       float beta2, float eps) {
+    for (int s = from + 1; s <= upto; ++s) {
+        const float2 h = hist[s];         // uniform: (lr / bc1, sqrt(bc2)) of step s
+        adam_upd4(pp, make_float4(0.f, 0.f, 0.f, 0.f), mm, vv, h.x, beta1, beta2, eps, h.y);
+    }
+}
+
+// ... of the two moments alone (the same operations replay() applies to them): for a caller that already holds the replayed PARAMETER --
+// the compact window copy the catch-up wrote for the render is exactly that -- and needs no square root, no reciprocal and no step table
+__device__ __forceinline__ void replay_moments(float4 &mm, float4 &vv, int from, int upto, float beta1, float beta2) {
+    for (int s = from + 1; s <= upto; ++s) {
+        adam_moments(mm.x, vv.x, 0.0f, beta1, beta2);
+        adam_moments(mm.y, vv.y, 0.0f, beta1, beta2);
+        adam_moments(mm.z, vv.z, 0.0f, beta1, beta2);
+        adam_moments(mm.w, vv.w, 0.0f, beta1, beta2);
+    }
+}
+
+}  // namespace vl3d_adam
+
+// ---- the render backward's fused owner store (vl3d_render_bwd_adam) ----------------------------------------------------------------
+// What the owner-computes backward needs to apply the step where it would have stored the gradient: the (D,T,Hs,Ws,4) parameter / moment
+// tensors of the full plane stack, the bookkeeping of the crop-aware optimiser (per-tile step table) and the scalars of THIS step.  The
+// stack the backward renders from is the compact copy of the texel window at (y0, x0), holding the parameters current for step - 1.
+struct vl3d_adam_epilogue {
+    float4 *p, *m, *v;             // NULL p: no fused step (the backward stores the gradient)
+    const int *last_step;          // [D][tiles_y][tiles_x]
+    const int4 *boxes;             // device [D] x (y0, y1, x0, x1) in plane texels (a plane's texels outside its box stay deferred) or NULL
+    int y0, x0, Hs, Ws, tiles_y, tiles_x, step;
+    float lr_bc1, beta1, beta2, eps, bc2s;
+};
+
+// (internal, vl3d_optim.hip) the window step from a compact gradient that runs only where the device-side plan of the backward said
+// "infeasible" (plan[0] == 0: the atomics kernel produced the gradient), then the tile marks -- the tail of vl3d_render_bwd_adam
+__attribute__((visibility("hidden"))) int vl3d_adam_window_step_tail(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh,
+                                                                     int32_t ww, float *param, const float *grad_compact, float *exp_avg,
+                                                                     float *exp_avg_sq, int32_t *last_step, const float *hist, float lr, float beta1,
+                                                                     float beta2, float eps, int64_t step, const int32_t *plane_boxes,
+                                                                     const int *only_if_zero, void *boxes_dev, hipStream_t stream);

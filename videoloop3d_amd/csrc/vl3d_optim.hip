@@ -14,25 +14,11 @@
 //   * a catch-up over the full stack brings everything current (checkpoints, lod(), evaluation renders).
 // Per-step scalars (lr / (1 - b1^t), sqrt(1 - b2^t)) come from a device table written by the host when the step is taken, so a
 // changing learning rate (train_3dvid.py:263-277) is replayed as it was.
-#include "vl3d_common.h"
+#include "vl3d_adam.h"
 
 namespace {
 
-constexpr int TS = 8;       // tile side in texels (the bookkeeping granularity: a crop's window is grown to whole tiles, 8 instead of 16
-                            // texels cut ~7 % off the window of a 180 x 320 crop; the step table is 4 bytes per tile)
-
-// One Adam step of one value.  The square root and the two quotients are the hardware's v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the
-// correctly rounded expansions (~40 instructions per value and step): the deferred zero-gradient steps are REPLAYED through this very
-// function -- on the reference's schedule a returning window replays 2-4 steps per texel, twice per iteration, and with the IEEE forms
-// that arithmetic, not the 7 memory streams, set the time of the catch-up and step kernels (2.5 + 3.5 ms against 1.0 + 2.0 at depth ~1).
-// Every path (dense step, window step, catch-up, flush) goes through it, so deferring stays bit-identical to not deferring; against
-// torch.optim.Adam the update term differs by <= 3 ulp per step (tests/test_gpu_optim.py: <= 2e-6 on the parameters after 40 steps).
-__device__ __forceinline__ void adam_upd(float &pp, float gg, float &mm, float &vv, float lr_bc1, float beta1, float beta2, float eps, float bc2s) {
-    mm = beta1 * mm + (1.0f - beta1) * gg;           // exp_avg.lerp_(grad, 1 - beta1)
-    vv = beta2 * vv + (1.0f - beta2) * gg * gg;      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-    const float den = __builtin_amdgcn_sqrtf(vv) * __builtin_amdgcn_rcpf(bc2s) + eps;      // sqrt(exp_avg_sq)/sqrt(bc2) + eps
-    pp -= lr_bc1 * (mm * __builtin_amdgcn_rcpf(den));                                      // param.addcdiv_(exp_avg, den, value=-lr/bc1)
-}
+using namespace vl3d_adam;      // TS (the bookkeeping tile side), adam_upd, replay: vl3d_adam.h -- shared with the render backward's fused store
 
 struct Win { int y0, x0, wh, ww; };
 
@@ -53,18 +39,6 @@ static BoxTable make_boxes(const int32_t *host_boxes, int D) {
     t.n = (host_boxes && D <= MAX_BOX_PLANES) ? D : 0;       // more planes than the table holds: the whole window for every plane
     for (int d = 0; d < t.n; ++d) t.b[d] = make_int4(host_boxes[4 * d], host_boxes[4 * d + 1], host_boxes[4 * d + 2], host_boxes[4 * d + 3]);
     return t;
-}
-
-// the zero-gradient steps from+1 .. upto of one texel, in registers (the dense update's operations with g = 0, in its order)
-__device__ __forceinline__ void replay(float4 &pp, float4 &mm, float4 &vv, const float2 *__restrict__ hist, int from, int upto, float beta1,
-                                       float beta2, float eps) {
-    for (int s = from + 1; s <= upto; ++s) {
-        const float2 h = hist[s];         // uniform: (lr / bc1, sqrt(bc2)) of step s
-        adam_upd(pp.x, 0.0f, mm.x, vv.x, h.x, beta1, beta2, eps, h.y);
-        adam_upd(pp.y, 0.0f, mm.y, vv.y, h.x, beta1, beta2, eps, h.y);
-        adam_upd(pp.z, 0.0f, mm.z, vv.z, h.x, beta1, beta2, eps, h.y);
-        adam_upd(pp.w, 0.0f, mm.w, vv.w, h.x, beta1, beta2, eps, h.y);
-    }
 }
 
 // tile-culled models (quad maps keep / dyn [D][QH][QW], MPI.py:288-442): 0 = culled texel (no kept quad can read it: no parameter),
@@ -163,7 +137,9 @@ __global__ __launch_bounds__(256) void adam_window_step_k(int T, int Hs, int Ws,
                                                           float4 *__restrict__ m, float4 *__restrict__ v, float lr_bc1, float beta1, float beta2,
                                                           float eps, float bc2s, Quads q, int static_tied, const int *__restrict__ last_step,
                                                           int tiles_y, int tiles_x, const float2 *__restrict__ hist, int step,
-                                                          const BoxTable boxes, Layout lay) {
+                                                          const BoxTable boxes, Layout lay, const int *__restrict__ only_if_zero) {
+    // (the tail of vl3d_render_bwd_adam: the owner-computes backward applied the step itself unless its device-side plan said infeasible)
+    if (only_if_zero && *only_if_zero) return;
     const int lx = blockIdx.x * 64 + (threadIdx.x & 63), ly = blockIdx.y * 4 + (threadIdx.x >> 6), d = blockIdx.z;
     if (lx >= w.ww || ly >= w.wh) return;
     if (outside_box(boxes, d, w.x0 + lx, w.y0 + ly)) return;     // zero gradient by construction: the update stays deferred
@@ -201,6 +177,11 @@ __global__ __launch_bounds__(256) void adam_window_step_k(int T, int Hs, int Ws,
         adam_upd(pp.w, gg.w, mm.w, vv.w, lr_bc1, beta1, beta2, eps, bc2s);
         p[o] = pp; m[o] = mm; v[o] = vv;
     }
+}
+
+// the host's box table as a device array (the render backward's fused store reads it per texel: kernel arguments of ITS launch are taken)
+__global__ __launch_bounds__(MAX_BOX_PLANES) void write_boxes_k(const BoxTable boxes, int4 *out) {
+    if ((int)threadIdx.x < boxes.n) out[threadIdx.x] = boxes.b[threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void mark_tiles_k(int *last_step, int tiles_y, int tiles_x, int ty0, int tx0, int nty, int ntx, int D, int step,
@@ -332,11 +313,11 @@ extern "C" int vl3d_adam_window_catchup(int32_t D, int32_t T, int32_t Hs, int32_
                                           compact, quad_keep, quad_dyn, QH, QW, culled_alpha, mirror_static, nullptr, nullptr, stream);
 }
 
-extern "C" int vl3d_adam_window_step_boxes(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
-                                           float *param, const float *grad_compact, float *exp_avg, float *exp_avg_sq, int32_t *last_step,
-                                           const float *hist, float lr, float beta1, float beta2, float eps, int64_t step,
-                                           const uint8_t *quad_keep, const uint8_t *quad_dyn, int32_t QH, int32_t QW, int32_t static_tied,
-                                           const int32_t *plane_boxes, const int32_t *blocks, vl3d_stream_t stream) {
+static int window_step_impl(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
+                            float *param, const float *grad_compact, float *exp_avg, float *exp_avg_sq, int32_t *last_step,
+                            const float *hist, float lr, float beta1, float beta2, float eps, int64_t step,
+                            const uint8_t *quad_keep, const uint8_t *quad_dyn, int32_t QH, int32_t QW, int32_t static_tied,
+                            const int32_t *plane_boxes, const int32_t *blocks, const int *only_if_zero, void *boxes_dev, hipStream_t s) {
     int rc = check_window(D, T, Hs, Ws, y0, x0, wh, ww);
     VL3D_REQUIRE(!blocks || quad_keep, "vl3d_adam_window_step: the packed layout belongs to a tile-culled model (quad maps)");
     if (rc != VL3D_OK) return rc;
@@ -344,16 +325,52 @@ extern "C" int vl3d_adam_window_step_boxes(int32_t D, int32_t T, int32_t Hs, int
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     const int tiles_y = (Hs + TS - 1) / TS, tiles_x = (Ws + TS - 1) / TS;
     const BoxTable boxes = make_boxes(plane_boxes, D);
-    hipStream_t s = (hipStream_t)stream;
+    if (boxes_dev && boxes.n) hipLaunchKernelGGL(write_boxes_k, dim3(1), dim3(MAX_BOX_PLANES), 0, s, boxes, reinterpret_cast<int4 *>(boxes_dev));
     hipLaunchKernelGGL(adam_window_step_k, dim3((ww + 63) / 64, (wh + 3) / 4, D), dim3(256), 0, s, T, Hs, Ws, Win{y0, x0, wh, ww},
                        reinterpret_cast<float4 *>(param), reinterpret_cast<const float4 *>(grad_compact), reinterpret_cast<float4 *>(exp_avg),
                        reinterpret_cast<float4 *>(exp_avg_sq), (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2),
                        Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW}, static_tied, last_step, tiles_y, tiles_x,
-                       reinterpret_cast<const float2 *>(hist), (int)step, boxes, Layout{blocks});
+                       reinterpret_cast<const float2 *>(hist), (int)step, boxes, Layout{blocks}, only_if_zero);
     const int nty = (y0 + wh + TS - 1) / TS - y0 / TS, ntx = (x0 + ww + TS - 1) / TS - x0 / TS;
     hipLaunchKernelGGL(mark_tiles_k, dim3((D * nty * ntx + 255) / 256), dim3(256), 0, s, last_step, tiles_y, tiles_x, y0 / TS, x0 / TS, nty, ntx, D, (int)step, boxes);
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
+}
+
+extern "C" int vl3d_adam_window_step_boxes(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
+                                           float *param, const float *grad_compact, float *exp_avg, float *exp_avg_sq, int32_t *last_step,
+                                           const float *hist, float lr, float beta1, float beta2, float eps, int64_t step,
+                                           const uint8_t *quad_keep, const uint8_t *quad_dyn, int32_t QH, int32_t QW, int32_t static_tied,
+                                           const int32_t *plane_boxes, const int32_t *blocks, vl3d_stream_t stream) {
+    return window_step_impl(D, T, Hs, Ws, y0, x0, wh, ww, param, grad_compact, exp_avg, exp_avg_sq, last_step, hist, lr, beta1, beta2, eps, step,
+                            quad_keep, quad_dyn, QH, QW, static_tied, plane_boxes, blocks, nullptr, nullptr, (hipStream_t)stream);
+}
+
+// (vl3d_adam.h) the tail of vl3d_render_bwd_adam.  Called BEFORE the render kernels with grad_compact == NULL: only the box table is put on
+// the device (boxes_dev); called after them: the conditional step + the tile marks.
+int vl3d_adam_window_step_tail(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww, float *param,
+                               const float *grad_compact, float *exp_avg, float *exp_avg_sq, int32_t *last_step, const float *hist, float lr,
+                               float beta1, float beta2, float eps, int64_t step, const int32_t *plane_boxes, const int *only_if_zero,
+                               void *boxes_dev, hipStream_t stream) {
+    if (!grad_compact) {
+        int rc = check_window(D, T, Hs, Ws, y0, x0, wh, ww);
+        if (rc != VL3D_OK) return rc;
+        VL3D_REQUIRE(!plane_boxes || (boxes_dev && D <= MAX_BOX_PLANES), "vl3d_render_bwd_adam: per-plane boxes need boxes_scratch and at most 128 planes");
+        if (plane_boxes) {
+            const BoxTable boxes = make_boxes(plane_boxes, D);
+            for (int d = 0; d < D; ++d) {
+                const int4 b = boxes.b[d];
+                VL3D_REQUIRE(b.x % TS == 0 && b.z % TS == 0 && b.x >= y0 && b.z >= x0 && b.y <= y0 + wh && b.w <= x0 + ww &&
+                                 (b.y % TS == 0 || b.y == Hs) && (b.w % TS == 0 || b.w == Ws),
+                             "vl3d_render_bwd_adam: plane boxes must be aligned to the bookkeeping tiles and lie inside the window");
+            }
+            hipLaunchKernelGGL(write_boxes_k, dim3(1), dim3(MAX_BOX_PLANES), 0, stream, boxes, reinterpret_cast<int4 *>(boxes_dev));
+            VL3D_CHECK_LAUNCH();
+        }
+        return VL3D_OK;
+    }
+    return window_step_impl(D, T, Hs, Ws, y0, x0, wh, ww, param, grad_compact, exp_avg, exp_avg_sq, last_step, hist, lr, beta1, beta2, eps, step,
+                            nullptr, nullptr, 0, 0, 0, plane_boxes, nullptr, only_if_zero, nullptr, stream);
 }
 
 extern "C" int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,

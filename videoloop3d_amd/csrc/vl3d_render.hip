@@ -349,3 +349,59 @@ static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, cons
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
 }
+
+// ---- the optimiser step inside the backward (include/vl3d.h) ---------------------------------------------------------------------------
+extern "C" int vl3d_render_bwd_adam(const vl3d_render_desc *desc, const void *stack, const float *homos, const float *rgb, const float *alpha,
+                                    const float *grad_rgb, const float *grad_alpha, const float *grad_reg, const void *reg_state,
+                                    const float *grad_alpha_sums, float *grad_stack, void *scratch, int64_t scratch_bytes,
+                                    const vl3d_adam_window *adam, vl3d_stream_t stream) {
+    int rc = check_desc(desc);
+    if (rc != VL3D_OK) return rc;
+    VL3D_REQUIRE(adam != nullptr, "vl3d_render_bwd_adam: null adam window");
+    VL3D_REQUIRE(stack && homos && rgb && alpha && grad_rgb && grad_stack && scratch, "null pointer passed to vl3d_render_bwd_adam");
+    VL3D_REQUIRE(!grad_reg || reg_state, "vl3d_render_bwd_adam: grad_reg needs the reg_state the forward with regularisers filled");
+    if (!(desc->coord_mode == VL3D_COORD_AFFINE && desc->border_mode == VL3D_BORDER_HARDCUT && desc->act_order == VL3D_ACT_POST &&
+          desc->rgb_act == VL3D_ACT_SIGMOID && desc->alpha_act == VL3D_ACT_SIGMOID && desc->stack_dtype == VL3D_F32 && desc->T >= 2 &&
+          (desc->variant & 0xf) == 0)) {
+        vl3d_set_error("vl3d_render_bwd_adam: built for the dense stage-2 iteration -- (affine, hardcut, post), sigmoid / sigmoid, fp32 stack, "
+                       "T >= 2, variant 0; use vl3d_render_bwd + vl3d_adam_window_step otherwise");
+        return VL3D_EUNSUPPORTED;
+    }
+    VL3D_REQUIRE(scratch_bytes >= vl3d_render_bwd_scratch_bytes(desc), "vl3d_render_bwd_adam: scratch smaller than vl3d_render_bwd_scratch_bytes()");
+    VL3D_REQUIRE(adam->param && adam->exp_avg && adam->exp_avg_sq && adam->last_step && adam->hist && adam->step >= 1 &&
+                     adam->step < (1ll << 31), "vl3d_render_bwd_adam: null pointer / bad step in the adam window");
+    VL3D_REQUIRE((int64_t)desc->Hs * desc->Ws * 16 < (1ll << 32) && (int64_t)adam->Hs * adam->Ws * 16 < (1ll << 32),
+                 "frame too large for 32-bit byte offsets");
+    hipStream_t s = (hipStream_t)stream;
+    // window / box checks and the box table on the device (the tail with a NULL gradient does exactly that)
+    rc = vl3d_adam_window_step_tail(desc->D, desc->T, adam->Hs, adam->Ws, adam->y0, adam->x0, desc->Hs, desc->Ws, adam->param, nullptr,
+                                    adam->exp_avg, adam->exp_avg_sq, adam->last_step, adam->hist, adam->lr, adam->beta1, adam->beta2, adam->eps,
+                                    adam->step, adam->plane_boxes, nullptr, adam->boxes_scratch, s);
+    if (rc != VL3D_OK) return rc;
+    RenderArgs a = make_args(desc);
+    if (grad_reg) set_reg_state(a, desc, reg_state);
+    a.stack = (const float *)stack; a.homos = homos;
+    a.rgb = const_cast<float *>(rgb); a.alpha = const_cast<float *>(alpha);
+    a.g_rgb = grad_rgb; a.g_alpha = grad_alpha; a.g_reg = grad_reg; a.g_asum = grad_alpha_sums; a.g_stack = grad_stack;
+    a.plan = (const float *)scratch;
+    a.owner = reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(scratch) + owner_table_off(desc));
+    a.tile_rows = 17;
+    const double bc1 = 1.0 - pow((double)adam->beta1, (double)adam->step), bc2 = 1.0 - pow((double)adam->beta2, (double)adam->step);
+    const int ts = vl3d_adam::TS;
+    a.ad.p = reinterpret_cast<float4 *>(adam->param); a.ad.m = reinterpret_cast<float4 *>(adam->exp_avg);
+    a.ad.v = reinterpret_cast<float4 *>(adam->exp_avg_sq);
+    a.ad.last_step = adam->last_step;
+    a.ad.boxes = (adam->plane_boxes && desc->D <= 128) ? reinterpret_cast<const int4 *>(adam->boxes_scratch) : nullptr;
+    a.ad.y0 = adam->y0; a.ad.x0 = adam->x0; a.ad.Hs = adam->Hs; a.ad.Ws = adam->Ws;
+    a.ad.tiles_y = (adam->Hs + ts - 1) / ts; a.ad.tiles_x = (adam->Ws + ts - 1) / ts;
+    a.ad.step = (int)adam->step;
+    a.ad.lr_bc1 = (float)((double)adam->lr / bc1); a.ad.beta1 = adam->beta1; a.ad.beta2 = adam->beta2; a.ad.eps = adam->eps;
+    a.ad.bc2s = (float)sqrt(bc2);
+    rc = dispatch(true, desc, a, s);
+    if (rc != VL3D_OK) return rc;
+    // infeasible view (decided on the device): the atomics kernel filled grad_stack and the step kernel takes it from there; the tiles are
+    // marked either way
+    return vl3d_adam_window_step_tail(desc->D, desc->T, adam->Hs, adam->Ws, adam->y0, adam->x0, desc->Hs, desc->Ws, adam->param, grad_stack,
+                                      adam->exp_avg, adam->exp_avg_sq, adam->last_step, adam->hist, adam->lr, adam->beta1, adam->beta2, adam->eps,
+                                      adam->step, adam->plane_boxes, reinterpret_cast<const int *>(scratch), nullptr, s);
+}

@@ -25,6 +25,8 @@
 // (vl3d_render_c5_mpv_planes.hip) carries 16 per plane -- matrix, then the hard-cut coverage box (x0, x1, y0, y1) in texel
 // coordinates, 3 pad -- so that every plane can have its own affine texel transform (folded into its matrix by the host) and its own
 // quad extent: the reference's atlas-cell layout (MPV.py:75-81: plane p samples at xm*pitch - (p % grid_w)/grid_w, include/vl3d.h).
+#include "vl3d_adam.h"
+
 #ifndef VL3D_HS
 #define VL3D_HS 9
 #define VL3D_HN 9
@@ -83,6 +85,8 @@ struct RenderArgs {
     const float *g_label;    // (T,H,W)
     float *g_mask;           // (D,T,Hs,Ws), overwritten
     int grad_culled_unwritten;   // desc->grad_flags bit 0: texels owned on a plane the workgroup skips (all of them culled) are not zero-filled
+    // the optimiser step fused into the owner store (vl3d_render_bwd_adam; ad.p == NULL otherwise): `stack` is the optimiser's compact window copy
+    vl3d_adam_epilogue ad;
 };
 
 // one entry point per compiled convention (coord_mode, border_mode, act_order): vl3d_render_c*.hip
@@ -1089,6 +1093,37 @@ __device__ __forceinline__ void owner_pixel(const float *__restrict__ hi, float 
     py = Y * rz - pc - (float)row0;
 }
 
+// ---- the optimiser step in the owner's store (vl3d_render_bwd_adam) ---------------------------------------------------------------------
+// Texel (cx, cy) of the compact window on plane d: false when it lies outside its plane's box (no tap of this iteration can reach it: its
+// update stays deferred like that of every texel outside the window); else the step its bookkeeping tile is current for and the texel's
+// BYTE offset inside a frame of the full (D,T,Hs,Ws,4) parameter / moment tensors (32 bits: one lane offset for p, m and v of every frame,
+// the frame's base is uniform -- global_load / global_store v_off, s[base:base+1]).
+__device__ __forceinline__ bool adam_texel(const RenderArgs &a, int d, int cx, int cy, int &from, unsigned &off) {
+    const int X = a.ad.x0 + cx, Y = a.ad.y0 + cy;
+    if (a.ad.boxes) {      // (d is uniform: four scalar loads)
+        const cint_p b = (cint_p)a.ad.boxes + 4 * d;
+        if (Y < b[0] || Y >= b[1] || X < b[2] || X >= b[3]) return false;
+    }
+    static_assert(vl3d_adam::TS == 8, "bookkeeping tiles of 8 x 8 texels");
+    from = a.ad.last_step[((size_t)d * a.ad.tiles_y + (Y >> 3)) * a.ad.tiles_x + (X >> 3)];
+    off = (unsigned)(Y * a.ad.Ws + X) << 4;
+    return true;
+}
+// One Adam step of one texel and frame with gradient g: `pcur` is the parameter current for step - 1 (the compact copy holds it: the
+// catch-up replayed the deferred steps into it, so only the two moments are replayed here -- multiplications), (p, m, v) are written.
+// fb: byte offset of the frame (uniform).
+__device__ __forceinline__ void adam_texel_step(const RenderArgs &a, size_t fb, unsigned off, int from, f4 pcur, f4 g) {
+    char *pb = reinterpret_cast<char *>(a.ad.p) + fb, *mb = reinterpret_cast<char *>(a.ad.m) + fb, *vb = reinterpret_cast<char *>(a.ad.v) + fb;
+    const f4 m0 = *reinterpret_cast<const f4 *>(mb + (size_t)off), v0 = *reinterpret_cast<const f4 *>(vb + (size_t)off);
+    float4 mm = make_float4(m0.x, m0.y, m0.z, m0.w), vv = make_float4(v0.x, v0.y, v0.z, v0.w);
+    vl3d_adam::replay_moments(mm, vv, from, a.ad.step - 1, a.ad.beta1, a.ad.beta2);
+    float4 pp = make_float4(pcur.x, pcur.y, pcur.z, pcur.w);
+    vl3d_adam::adam_upd4(pp, make_float4(g.x, g.y, g.z, g.w), mm, vv, a.ad.lr_bc1, a.ad.beta1, a.ad.beta2, a.ad.eps, a.ad.bc2s);
+    __builtin_nontemporal_store(f4{pp.x, pp.y, pp.z, pp.w}, reinterpret_cast<f4 *>(pb + (size_t)off));
+    __builtin_nontemporal_store(f4{mm.x, mm.y, mm.z, mm.w}, reinterpret_cast<f4 *>(mb + (size_t)off));
+    __builtin_nontemporal_store(f4{vv.x, vv.y, vv.z, vv.w}, reinterpret_cast<f4 *>(vb + (size_t)off));
+}
+
 // Owner table: for every texel of every plane, the tile that owns it (the tile of its owner pixel p0 = clamp_to_frame(
 // round(H_d^-1 tau))) and p0's index in that tile's pixel region, packed as tile << 10 | index.  Frame independent, so it
 // is built once per call (D*Hs*Ws entries) and read once per frame by the gather, which then needs no inverse homography,
@@ -1129,6 +1164,23 @@ __global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, i
     const bool safe = (qx > 0.5f) && (qx < (float)a.W - 1.5f) && (qy > 0.5f) && (qy < (float)a.H - 1.5f);
     if (safe) return;
     const size_t frame = (size_t)a.Hs * a.Ws;
+    if (a.ad.p) {
+        // fused optimiser step: there is no gradient to zero-fill -- the texels the tile kernel will NOT reach take their zero-gradient step
+        // here, exactly once: the tile kernel's gather visits the texels of its window (bwd_windows_k, run before this kernel) the table
+        // assigns to it, so a texel outside its owner tile's window is visited by nobody (tiles far enough apart to share a code have
+        // disjoint windows: the table's premise)
+        const int4 rec = reinterpret_cast<const int4 *>(reinterpret_cast<const int *>(a.plan) + plan_win_off(a.D))[(size_t)(ty * tiles_x + tx) * a.D + d];
+        const int ww = rec.z & 0xffff, wh = (rec.z >> 16) & 0x3fff;
+        if (x >= rec.x && x < rec.x + ww && y >= rec.y && y < rec.y + wh) return;
+        int from;
+        unsigned off;
+        if (!adam_texel(a, d, x, y, from, off)) return;
+        const f4 *pc = reinterpret_cast<const f4 *>(a.stack) + (size_t)d * a.T * frame + (size_t)y * a.Ws + x;
+        const size_t fbytes = (size_t)a.ad.Hs * a.ad.Ws * 16;
+        size_t fb = (size_t)d * a.T * fbytes;
+        for (int t = 0; t < a.T; ++t, pc += frame, fb += fbytes) adam_texel_step(a, fb, off, from, *pc, f4{0.f, 0.f, 0.f, 0.f});
+        return;
+    }
     if (a.g_f16) {
         float2 *g = reinterpret_cast<float2 *>(a.g_stack) + (size_t)d * a.T * frame + (size_t)y * a.Ws + x;
         for (int t = 0; t < a.T; ++t, g += frame) *g = make_float2(0.f, 0.f);
@@ -1415,10 +1467,13 @@ constexpr int PNT = 512, PW = 32, PROWS = 16;
 // gather of one plane for a frame pair: every texel of the tile's window that the owner table assigns to this tile sums its taps
 // from the 3 x 3 (or, where pixels are >= 1 texel apart, 2 x 2) staged pixels around its owner pixel -- one set of weights, two
 // accumulators, two stores.  sg0 / sg1: staged gradients of frames t and t+1, st: staged texel coordinates (this plane's buffers).
-template <int ORDER, int RACT, int AACT, bool F16>
+// ADAM: the owner applies the optimiser's step where it would have stored the gradient (vl3d_render_bwd_adam): (d, t0) = the plane and the
+// pair's first frame.
+template <int ORDER, int RACT, int AACT, bool F16, bool ADAM = false>
 __device__ __forceinline__ void pair_gather_plane(const RenderArgs &a, const float4 *sg0, const float4 *sg1, const float2 *st, int X0, int Y0,
                                                   int ww, int wh, bool apart, unsigned my_tile, unsigned e0, const unsigned short *oplane,
-                                                  const char *plane0, char *gplane0, size_t f1, size_t frame_b, bool has1, int col, int row) {
+                                                  const char *plane0, char *gplane0, size_t f1, size_t frame_b, bool has1, int col, int row,
+                                                  int d = 0, int t0 = 0) {
     const unsigned win0 = (unsigned)(Y0 * a.Ws + X0);
     auto gather = [&](unsigned e, int wx, int wy, unsigned tix) {
         if ((e >> 9) != my_tile) return;
@@ -1455,8 +1510,18 @@ __device__ __forceinline__ void pair_gather_plane(const RenderArgs &a, const flo
             acc1 = f4{acc1.x * act_bwd<RACT>(sv1.x, act_fwd<RACT>(sv1.x)), acc1.y * act_bwd<RACT>(sv1.y, act_fwd<RACT>(sv1.y)),
                       acc1.z * act_bwd<RACT>(sv1.z, act_fwd<RACT>(sv1.z)), acc1.w * act_bwd<AACT>(sv1.w, act_fwd<AACT>(sv1.w))};
         }
-        store_grad_texel<F16>(gplane0, tix << 4, acc0);
-        if (has1) store_grad_texel<F16>(gplane0 + frame_b, tix << 4, acc1);
+        if constexpr (ADAM) {
+            static_assert(!F16, "the fused optimiser step: fp32 stacks");
+            int from;
+            unsigned off;
+            if (!adam_texel(a, d, X0 + wx, Y0 + wy, from, off)) return;      // outside its plane's box: deferred (its gradient is exactly 0)
+            const size_t fbytes = (size_t)a.ad.Hs * a.ad.Ws * 16, fb = ((size_t)d * a.T + t0) * fbytes;      // uniform
+            adam_texel_step(a, fb, off, from, load_texel<false>(plane0, tix << 4), acc0);
+            if (has1) adam_texel_step(a, fb + fbytes, off, from, load_texel<false>(plane0 + f1, tix << 4), acc1);
+        } else {
+            store_grad_texel<F16>(gplane0, tix << 4, acc0);
+            if (has1) store_grad_texel<F16>(gplane0 + frame_b, tix << 4, acc1);
+        }
     };
     if (row < wh && col < ww) gather(e0, col, row, win0 + (unsigned)(row * a.Ws + col));
     // rest of a window larger than 32 x 16: columns beyond 32 as a packed strip, rows beyond 16 one half-wave per row
@@ -1502,7 +1567,7 @@ __device__ __forceinline__ void pair_gather_plane(const RenderArgs &a, const flo
 // sparsity-sum gradient is gN1 + gN2 a_k.  Until round 3 this was a kernel of its own (render_bwd_pair_reg_k: 2-pixel halo, the
 // neighbours' layer values through a second LDS stage, sampling pipelined one plane ahead, 128 VGPRs, 18.2 ms at cfg3 against 12.0
 // without the regularisers -- VALU bound on re-deriving signs the forward had already formed).
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool REG = false>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool REG = false, bool ADAM = false>
 __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {      // >= 4 waves per SIMD (2 workgroups per CU): <= 128 VGPRs
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
     __shared__ float4 s_g[2][2][PNT];   // [buffer][frame][pixel]
@@ -1619,14 +1684,14 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
         s_g[buf][1][tid] = gv1;
         __syncthreads();
         // (3) gather: one set of weights, two accumulators
-        pair_gather_plane<ORDER, RACT, AACT, F16>(a, s_g[buf][0], s_g[buf][1], s_t[buf], X0, Y0, ww, wh, apart, my_tile, e0, oplane, plane0, gplane0,
-                                                  f1, frame_b, has1, col, row);
+        pair_gather_plane<ORDER, RACT, AACT, F16, ADAM>(a, s_g[buf][0], s_g[buf][1], s_t[buf], X0, Y0, ww, wh, apart, my_tile, e0, oplane, plane0,
+                                                        gplane0, f1, frame_b, has1, col, row, d, t0);
     }
 }
 
 #undef VL3D_PAIR_GRAD
 
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool REG = false>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool REG = false, bool ADAM = false>
 void launch_pair(const RenderArgs &a, hipStream_t s) {
     constexpr int RH = 1, IW = PW - 2 * RH, IH = PROWS - 2 * RH;
     RenderArgs b = a;
@@ -1636,12 +1701,8 @@ void launch_pair(const RenderArgs &a, hipStream_t s) {
                        reinterpret_cast<int *>(const_cast<float *>(a.plan)) + plan_win_off(a.D));
     hipLaunchKernelGGL(bwd_owner_table_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x,
                        const_cast<unsigned short *>(a.owner), PW, 9);
-    if constexpr (REG)
-        hipLaunchKernelGGL((render_bwd_pair_k<COORD, BORDER, ORDER, RACT, AACT, F16, true>),
-                           dim3((unsigned)(b.tiles_x * b.tiles_y * ((a.T + 1) / 2))), dim3(PNT), 0, s, b);
-    else
-        hipLaunchKernelGGL((render_bwd_pair_k<COORD, BORDER, ORDER, RACT, AACT, F16>),
-                           dim3((unsigned)(b.tiles_x * b.tiles_y * ((a.T + 1) / 2))), dim3(PNT), 0, s, b);
+    hipLaunchKernelGGL((render_bwd_pair_k<COORD, BORDER, ORDER, RACT, AACT, F16, REG, ADAM>),
+                       dim3((unsigned)(b.tiles_x * b.tiles_y * ((a.T + 1) / 2))), dim3(PNT), 0, s, b);
 }
 
 // =====================================================================================================
@@ -1812,6 +1873,16 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
                     if (a.g_reg || a.g_asum) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, false, true>(a, s);
                     else launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, false, false, true>(a, s);
                     hipLaunchKernelGGL((render_bwd_k<COORD, BORDER, ORDER, RACT, AACT, false, true>), grid, block, 0, s, a);
+                    return;
+                }
+            }
+            // the optimiser step in the owner store (vl3d_render_bwd_adam; the entry point admits this convention only): always the frame pairs
+            if constexpr (COORD == VL3D_COORD_AFFINE && BORDER == VL3D_BORDER_HARDCUT && ORDER == VL3D_ACT_POST && RACT == VL3D_ACT_SIGMOID &&
+                          AACT == VL3D_ACT_SIGMOID && !F16 && VL3D_HS == 9) {
+                if (a.ad.p) {
+                    if (a.g_reg || a.g_asum) launch_pair<COORD, BORDER, ORDER, RACT, AACT, false, true, true>(a, s);
+                    else launch_pair<COORD, BORDER, ORDER, RACT, AACT, false, false, true>(a, s);
+                    hipLaunchKernelGGL((render_bwd_k<COORD, BORDER, ORDER, RACT, AACT, F16>), grid, block, 0, s, a);
                     return;
                 }
             }

@@ -12,6 +12,12 @@ the one-pass update -- while touching only the texels the current training crop 
   flush()   replays everything outstanding (before checkpoints, lod(), evaluation renders; MPMeshVid calls it).
 
 Without a pending window (someone filled `p.grad` densely) step() falls back to the dense update: flush + full-window step.
+
+`fused_backward=True` (dense models): the step is taken INSIDE the render's backward (vl3d_render_bwd_adam) -- the owner-computes kernel
+applies the update where it would have stored a texel's gradient, so the window's gradient is never written or read back (6 streams of
+the window instead of 2 + 7).  `loss.backward()` then leaves the parameters updated and `step()` only does its periodic housekeeping; the
+learning rate is the group's at the time of the backward (train_3dvid.py:263-277 sets it before the iteration).  The parameters are bit
+for bit those of the two-kernel path.  Contract: one backward per window_leaf(), nothing else reads the leaf's gradient (it stays None).
 """
 import ctypes as C
 
@@ -35,7 +41,7 @@ def align_window(y0, y1, x0, x1, Hs, Ws):
 
 class WindowAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, quad_keep=None, quad_dyn=None, culled_alpha=-1e4, max_defer=32, layout=None,
-                 lean_window=True):
+                 lean_window=True, fused_backward=False):
         """quad_keep / quad_dyn [D,QH,QW] (a tile-culled model, videoloop3d_amd/tiles.py): culled texels are no parameters, a texel only
         static quads can read is ONE parameter stored in frame 0 of the stack (the reference's static atlas, MPV.py:235-288) -- the
         window copy shows it in every frame, the step sums its gradient over the frames and writes that one copy; flush() refreshes
@@ -66,6 +72,11 @@ class WindowAdam(torch.optim.Optimizer):
         # one forward is overwritten by the next window_leaf() call (one windowed forward per step is the contract anyway).
         self.lean_window = bool(lean_window)
         self._compact_buf = None
+        self.fused_backward = bool(fused_backward)
+        if self.fused_backward and (self.quad_keep is not None or layout is not None):
+            raise RuntimeError("WindowAdam(fused_backward=True) is built for dense models (no quad maps / packed layout)")
+        self._boxes_dev = None
+        self.fused_steps = 0             # steps taken inside a backward (diagnostics / tests)
 
     # ---- state ----------------------------------------------------------------------------------------------------------
     def dims(self):
@@ -137,9 +148,9 @@ class WindowAdam(torch.optim.Optimizer):
             compact = torch.empty((D, T, wh, ww, 4), dtype=p.dtype, device=p.device)
         self._catchup(window, self.t, compact, boxes=plane_boxes, lean=self.lean_window)
         compact.requires_grad_(True)
-        if self.pending is not None:
+        if self.pending is not None and self.pending != "stepped":
             self.pending = "multiple"
-        else:
+        else:                                             # ("stepped": the previous backward took its step; step() was not called for the housekeeping)
             self.pending = (window, compact, plane_boxes)
         return compact
 
@@ -176,8 +187,82 @@ class WindowAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=True):
         super().zero_grad(set_to_none)
-        if self.pending is not None and self.pending != "multiple" and self.pending[1].grad is not None:
+        if isinstance(self.pending, tuple) and self.pending[1].grad is not None:
             self.pending[1].grad = None
+
+    # ---- the step inside the render's backward -------------------------------------------------------------------------
+    def fuses(self, stack, spec):
+        """does the backward of a render of `stack` (the pending window leaf?) under `spec` take this optimiser's step itself?"""
+        pend = self.pending
+        return (self.fused_backward and isinstance(pend, tuple) and len(pend) == 3 and self._is_leaf(pend, stack) and stack.dtype == torch.float32
+                and stack.shape[1] >= 2 and spec.coord_mode == "affine" and spec.border == "hardcut" and spec.act_order == "post"
+                and spec.rgb_act == "sigmoid" and spec.alpha_act == "sigmoid" and (int(spec.variant) & 0xf) == 0)
+
+    @staticmethod
+    def _is_leaf(pend, stack):
+        return pend[1].data_ptr() == stack.data_ptr() and pend[1].shape == stack.shape
+
+    @torch.no_grad()
+    def backward_step(self, desc, stack, homos, rgb, alpha, g_rgb, g_alpha, g_reg, reg_state, g_asum):
+        """called by the render's autograd backward (render._RenderPlanes) instead of vl3d_render_bwd: backward + step of the pending window in
+        one pass (vl3d_render_bwd_adam).  -> the scratch buffer of the call (its first word: 1 = the owner-computes kernels ran)."""
+        pend = self.pending
+        if not (isinstance(pend, tuple) and len(pend) == 3 and self._is_leaf(pend, stack)):
+            raise RuntimeError("WindowAdam: the fused backward belongs to the pending window leaf (one backward per window_leaf())")
+        st, p = self._st(), self.p
+        grp = self.param_groups[0]
+        b1, b2 = grp["betas"]
+        t = self._register_step(st, float(grp["lr"]), b1, b2)
+        window, _, boxes = pend
+        D, T, Hs, Ws = self.dims()
+        dev = p.device
+        aw = L.AdamWindow()
+        aw.Hs, aw.Ws, aw.y0, aw.x0 = Hs, Ws, window[0], window[1]
+        aw.param, aw.exp_avg, aw.exp_avg_sq = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+        aw.last_step, aw.hist = st["last_step"].data_ptr(), st["hist"].data_ptr()
+        aw.lr, aw.beta1, aw.beta2, aw.eps, aw.step = float(grp["lr"]), float(b1), float(b2), float(grp["eps"]), t
+        if boxes is not None and D <= 128:
+            if self._boxes_dev is None or self._boxes_dev.device != dev:
+                self._boxes_dev = torch.empty(128 * 4, dtype=torch.int32, device=dev)
+            aw.plane_boxes, aw.boxes_scratch = boxes.ctypes.data, self._boxes_dev.data_ptr()
+        g_fallback = torch.empty_like(stack)       # written (and consumed) on the device only when the plan finds the view infeasible
+        with torch.cuda.device(dev):
+            nscratch = int(L.lib().vl3d_render_bwd_scratch_bytes(desc))
+            scratch = torch.empty((nscratch + 3) // 4, dtype=torch.float32, device=dev)
+            scratch[:16].zero_()
+            L.check(L.lib().vl3d_render_bwd_adam(desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.ptr(g_rgb), L.ptr(g_alpha),
+                                                 L.ptr(g_reg), L.ptr(reg_state), L.ptr(g_asum), L.ptr(g_fallback), L.ptr(scratch), nscratch,
+                                                 C.byref(aw), L.stream_ptr(dev)), "vl3d_render_bwd_adam")
+        self.t = t
+        self.fused_steps += 1
+        self.pending = "stepped"
+        return scratch
+
+    def _register_step(self, st, lr, b1, b2):
+        """the scalars of the step about to be taken into the history table -> its number."""
+        t = self.t + 1
+        if t >= st["hist"].shape[0]:
+            st["hist"] = torch.cat([st["hist"], torch.zeros_like(st["hist"])])
+        a, b = C.c_float(), C.c_float()
+        L.lib().vl3d_adam_step_scalars(lr, float(b1), float(b2), t, C.byref(a), C.byref(b))
+        st["hist"][t, 0].fill_(a.value)                   # scalars travel as kernel arguments: no host-to-device copy, no sync
+        st["hist"][t, 1].fill_(b.value)
+        return t
+
+    def _bound_deferral(self, st, t):
+        # every `every` steps, tiles that have missed max_defer - every steps or more are brought up to date: nothing is ever older than
+        # max_defer when its window comes back, and the sweep over the step table (a wave per tile) is paid on one step in `every`
+        p = self.p
+        D, T, Hs, Ws = self.dims()
+        grp = self.param_groups[0]
+        b1, b2 = grp["betas"]
+        qk, qd, QH, QW = self._quads()
+        every = max(1, min(8, self.max_defer // 4))
+        if self.max_defer > 0 and t >= self.max_defer - every and t % every == 0:
+            with torch.cuda.device(p.device):
+                L.check(L.lib().vl3d_adam_flush_older(D, T, Hs, Ws, L.ptr(p), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), L.ptr(st["last_step"]),
+                                                      L.ptr(st["hist"]), t, max(1, self.max_defer - every), float(b1), float(b2), float(grp["eps"]),
+                                                      qk, qd, QH, QW, self._blocks(), L.stream_ptr(p.device)), "vl3d_adam_flush_older")
 
     # ---- the step -------------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -191,6 +276,9 @@ class WindowAdam(torch.optim.Optimizer):
         b1, b2 = grp["betas"]
         lr, eps = float(grp["lr"]), float(grp["eps"])
         pending, self.pending = self.pending, None
+        if pending == "stepped":                          # the backward took the step (fused_backward): housekeeping only
+            self._bound_deferral(st, self.t)
+            return loss
         if pending == "multiple":
             raise RuntimeError("WindowAdam: two windowed forwards before one step(); accumulate through the dense path (model.stack.grad) instead")
         dense = pending is None
@@ -200,13 +288,7 @@ class WindowAdam(torch.optim.Optimizer):
             if p.grad is None:
                 return loss
             dense = True                                   # the graph went around the window leaf
-        t = self.t + 1
-        if t >= st["hist"].shape[0]:
-            st["hist"] = torch.cat([st["hist"], torch.zeros_like(st["hist"])])
-        a, b = C.c_float(), C.c_float()
-        L.lib().vl3d_adam_step_scalars(lr, float(b1), float(b2), t, C.byref(a), C.byref(b))
-        st["hist"][t, 0].fill_(a.value)                   # scalars travel as kernel arguments: no host-to-device copy, no sync
-        st["hist"][t, 1].fill_(b.value)
+        t = self._register_step(st, lr, b1, b2)
         D, T, Hs, Ws = self.dims()
         if dense and self.layout is not None:
             raise RuntimeError("WindowAdam: a packed model trains through its window leaf only (no dense gradient of the pool exists)")
@@ -229,12 +311,5 @@ class WindowAdam(torch.optim.Optimizer):
                                                         None if boxes is None else boxes.ctypes.data, self._blocks(), L.stream_ptr(p.device)),
                     "vl3d_adam_window_step")
         self.t = t
-        # every `every` steps, tiles that have missed max_defer - every steps or more are brought up to date: nothing is ever older than
-        # max_defer when its window comes back, and the sweep over the step table (a wave per tile) is paid on one step in `every`
-        every = max(1, min(8, self.max_defer // 4))
-        if self.max_defer > 0 and t >= self.max_defer - every and t % every == 0:
-            with torch.cuda.device(p.device):
-                L.check(L.lib().vl3d_adam_flush_older(D, T, Hs, Ws, L.ptr(p), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), L.ptr(st["last_step"]),
-                                                      L.ptr(st["hist"]), t, max(1, self.max_defer - every), float(b1), float(b2), eps, qk, qd, QH, QW,
-                                                      self._blocks(), L.stream_ptr(p.device)), "vl3d_adam_flush_older")
+        self._bound_deferral(st, t)
         return loss

@@ -61,8 +61,12 @@ LAST_BWD_SCRATCH = None
 
 class _RenderPlanes(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, stack, homos, H, W, spec, row0, col0, with_reg, quad_keep=None, cull_window=None, grad_culled_unwritten=False):
+    def forward(ctx, stack, homos, H, W, spec, row0, col0, with_reg, quad_keep=None, cull_window=None, grad_culled_unwritten=False, fused_adam=None):
         L.check_cuda(stack, homos)
+        # fused_adam (optim.WindowAdam with fused_backward): `stack` is its pending window leaf and the backward takes the step itself
+        ctx.fused_adam = fused_adam if (fused_adam is not None and quad_keep is None and (row0, col0) == (0, 0) and stack.is_contiguous()
+                                        and fused_adam.fuses(stack, spec)) else None
+        ctx.leaf = stack if ctx.fused_adam is not None else None
         if quad_keep is not None:
             L.check_cuda(quad_keep)
             if quad_keep.dim() != 3 or quad_keep.shape[0] != stack.shape[0]:
@@ -135,12 +139,17 @@ class _RenderPlanes(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_alpha, g_sums, g_asum):
         if ctx.nothing_to_render:
-            return (torch.zeros_like(ctx.saved_tensors[0]),) + (None,) * 10
+            return (torch.zeros_like(ctx.saved_tensors[0]),) + (None,) * 11
         stack, homos, rgb, alpha = ctx.saved_tensors
         g_reg = g_sums.to(torch.float32).contiguous() if (ctx.with_reg and g_sums is not None) else None
         g_asum = g_asum.to(torch.float32).contiguous() if (ctx.with_reg and g_asum is not None) else None
         g_rgb = g_rgb.contiguous() if g_rgb is not None else torch.zeros_like(rgb)
         g_alpha = g_alpha.contiguous() if g_alpha is not None else None
+        global LAST_BWD_SCRATCH
+        if ctx.fused_adam is not None:
+            # backward + optimiser step in one pass over the window (vl3d_render_bwd_adam): no gradient tensor exists afterwards
+            LAST_BWD_SCRATCH = ctx.fused_adam.backward_step(ctx.desc, ctx.leaf, homos, rgb, alpha, g_rgb, g_alpha, g_reg, ctx.reg_state, g_asum)
+            return (None,) * 12
         g_stack = torch.empty(stack.shape, dtype=stack.dtype, device=stack.device)     # the gradient has the stack's dtype in the ABI
         with torch.cuda.device(stack.device):
             nscratch = int(L.lib().vl3d_render_bwd_scratch_bytes(ctx.desc))
@@ -157,9 +166,8 @@ class _RenderPlanes(torch.autograd.Function):
                                                        L.ptr(rgb), L.ptr(alpha), L.ptr(g_rgb), L.ptr(g_alpha), L.ptr(g_reg), L.ptr(ctx.reg_state), L.ptr(g_asum),
                                                        L.ptr(g_stack), L.ptr(scratch), nscratch, L.stream_ptr(stack.device)),
                         "vl3d_render_bwd_culled")
-        global LAST_BWD_SCRATCH
         LAST_BWD_SCRATCH = scratch
-        return g_stack, None, None, None, None, None, None, None, None, None, None
+        return (g_stack,) + (None,) * 11
 
 
 def mask_channel_supported(stack, spec):
@@ -230,7 +238,8 @@ def render_planes_with_mask(stack, mask, homos, H, W, spec: RenderSpec = RenderS
     return _RenderPlanesMask.apply(stack, mask, homos, int(H), int(W), spec, bool(with_regularisers))
 
 
-def render_planes(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0), quad_keep=None, cull_window=None, grad_culled_unwritten=False):
+def render_planes(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0), quad_keep=None, cull_window=None, grad_culled_unwritten=False,
+                  fused_adam=None):
     """stack (D,T,Hs,Ws,4) pre-activation fp32 (plane 0 = nearest), homos [D,3,3] (target pixel -> plane pixel).
 
     Returns rgb [T,H,W,3], alpha [T,H,W].  `window=(row0,col0)` renders the H x W sub-window whose top-left
@@ -241,9 +250,11 @@ def render_planes(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0
     `cull_window` (y0, x0, Hs_plane, Ws_plane), with quad_keep: `stack` is the texel window at (y0, x0) of a plane of that size and the
     quad grid lies over the whole plane (crop-aware training renders from a compact copy of the window, optim.WindowAdam).
     `grad_culled_unwritten` (with quad_keep): the consumer of the stack gradient never reads texels no kept quad can read (WindowAdam / TileAdam
-    skip them), so the backward leaves those slots UNDEFINED instead of zero-filling them (VL3D_GRAD_CULLED_UNWRITTEN, include/vl3d.h)."""
+    skip them), so the backward leaves those slots UNDEFINED instead of zero-filling them (VL3D_GRAD_CULLED_UNWRITTEN, include/vl3d.h).
+    `fused_adam`: an optim.WindowAdam(fused_backward=True) whose pending window leaf `stack` is -- the backward then takes its step
+    (vl3d_render_bwd_adam) and the leaf receives no gradient."""
     rgb, alpha, _, _ = _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), False, quad_keep, cull_window,
-                                           bool(grad_culled_unwritten))
+                                           bool(grad_culled_unwritten), fused_adam)
     return rgb, alpha
 
 
@@ -256,11 +267,11 @@ def render_planes_with_smoothness(stack, homos, H, W, spec: RenderSpec = RenderS
 
 
 def render_planes_with_regularisers(stack, homos, H, W, spec: RenderSpec = RenderSpec(), window=(0, 0), quad_keep=None, cull_window=None,
-                                    grad_culled_unwritten=False):
+                                    grad_culled_unwritten=False, fused_adam=None):
     """(rgb, alpha, smooth_sums[4], alpha_sums[T,H,W,2]): render_planes_with_smoothness plus the per-pixel (sum_k a_k,
     sum_k a_k^2) the sparsity regulariser |a|_1/|a|_2 (MPV.py:511-515, MPI.py:599-603) is built from; all differentiable."""
     return _RenderPlanes.apply(stack, homos, int(H), int(W), spec, int(window[0]), int(window[1]), True, quad_keep, cull_window,
-                               bool(grad_culled_unwritten))
+                               bool(grad_culled_unwritten), fused_adam)
 
 
 @torch.no_grad()
