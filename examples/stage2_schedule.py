@@ -40,7 +40,7 @@ def make_views(V, H, W, frames, dev):
     return torch.tensor(np.stack(poses), dtype=torch.float32), torch.tensor(K, dtype=torch.float32)[None].repeat(V, 1, 1), vids
 
 
-def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, dev="cuda:0", sparsify=False, fused=True):
+def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, dev="cuda:0", sparsify=False, fused=True, bwd_variant=0):
     from videoloop3d_amd.MPV import MPMeshVid
     from videoloop3d_amd.train_3dvid import MVVidPatchDataset, run_iter
     dev = torch.device(dev)
@@ -56,6 +56,9 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
     poses, intrins, vids = make_views(views, H, W, clip, dev)
     K = intrins[0].numpy()
     model = MPMeshVid(args, H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
+    if bwd_variant:      # A/B of the backward kernels (include/vl3d.h: desc->variant bits 0-3)
+        import dataclasses
+        model.spec = dataclasses.replace(model.spec, variant=int(bwd_variant))
     other = dict(loss_name="gpnn_lm", patch_size=3, patcht_size=3, stride=2, stridet=1, alpha=10000.0, rou="-2", scaling=0.1, dist_fn="mse",
                  macro_block=65)
     ref = dict(loss_name="gpnn_lm", loss_gain=3.5, patch_size=11, patcht_size=3, stride=4, stridet=1, alpha=0.0, rou="-2", scaling=0.1,
@@ -145,7 +148,8 @@ if __name__ == "__main__":
     ap.add_argument("--epochs", type=int, default=2)
     ap.add_argument("--sparsify", action="store_true")
     ap.add_argument("--two-kernels", action="store_true", help="dense model: vl3d_render_bwd + the step kernel instead of the step inside the backward")
+    ap.add_argument("--bwd-variant", type=int, default=0)
     a = ap.parse_args()
     import __graft_entry__ as g
     g.build()
-    print(json.dumps(run(a.views, a.epochs, sparsify=a.sparsify, fused=not a.two_kernels)))
+    print(json.dumps(run(a.views, a.epochs, sparsify=a.sparsify, fused=not a.two_kernels, bwd_variant=a.bwd_variant)))

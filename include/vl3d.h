@@ -187,8 +187,14 @@ int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t 
  * window and box is stepped exactly once: by the tile that owns it, or -- texels no tile's gather reaches: zero gradient -- by the
  * backward's pre-pass.  grad_stack (the compact gradient, desc's dims) is still required: when the device-side plan finds the view
  * infeasible for the owner-computes kernels the atomics kernel fills it and the step kernel runs behind it, decided on the device (no
- * host synchronisation either way); it is left unwritten otherwise.  Dense fp32 stacks, T >= 2, the planar convention with the shipped
- * activations ((affine, hardcut, post), sigmoid / sigmoid), desc->variant 0; anything else: VL3D_EUNSUPPORTED, nothing launched. */
+ * host synchronisation either way); it is left unwritten otherwise.
+ * Tile-culled models (adam->quad_keep != NULL; the render culls with the same map, desc->cull_* = the window (y0, x0) of the (Hs, Ws) plane):
+ * a DYNAMIC texel is stepped in the owner's store, a STATIC texel (one parameter for all frames) has its gradient stored to grad_stack as
+ * vl3d_render_bwd_culled does and the step kernel behind the backward sums it over the frames -- static texels only, unless the plan was
+ * infeasible --, culled texels are nobody's (grad_stack holds defined values in static texels only).  Dense (unpacked) storage.
+ * fp32 stacks, the planar convention with the shipped activations ((affine, hardcut, post), sigmoid / sigmoid); dense models: T >= 2,
+ * desc->variant 0 (frame pairs) or 3 (the one-frame tile kernel, which tile-culled models always take); anything else: VL3D_EUNSUPPORTED,
+ * nothing launched. */
 typedef struct vl3d_adam_window {
     int32_t Hs, Ws;              /* the full planes: param / exp_avg / exp_avg_sq are (D,T,Hs,Ws,4) */
     int32_t y0, x0;              /* the window [y0, y0 + desc->Hs) x [x0, x0 + desc->Ws), aligned to vl3d_adam_window_tile() */
@@ -199,6 +205,11 @@ typedef struct vl3d_adam_window {
     int64_t step;
     const int32_t *plane_boxes;  /* HOST [D][4] or NULL */
     void *boxes_scratch;         /* device, 16 * D bytes; required with plane_boxes */
+    /* tile-culled model (NULL quad_keep: dense): the quad maps of vl3d_adam_window_step (device byte maps [D][QH][QW]) and a device scratch
+     * of D * desc->Hs * desc->Ws bytes for the texel classes of the window */
+    const uint8_t *quad_keep, *quad_dyn;
+    int32_t QH, QW;
+    void *class_scratch;
 } vl3d_adam_window;
 int vl3d_render_bwd_adam(const vl3d_render_desc *desc, const void *stack, const float *homos, const float *rgb, const float *alpha,
                          const float *grad_rgb, const float *grad_alpha, const float *grad_reg, const void *reg_state,

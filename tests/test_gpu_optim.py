@@ -384,8 +384,9 @@ def test_window_adam_state_dict_round_trip(dev):
     assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"])
 
 
-@pytest.mark.parametrize("smooth,T,scale,rot", [(0.2, 4, 1.1, 0.0), (0.0, 5, 1.6, 0.0), (0.2, 5, 1.25, 0.0), (0.2, 4, 1.1, 40.0)])
-def test_step_fused_into_the_backward_equals_backward_then_step(dev, smooth, T, scale, rot):
+@pytest.mark.parametrize("smooth,T,scale,rot,variant", [(0.2, 4, 1.1, 0.0, 0), (0.0, 5, 1.6, 0.0, 0), (0.2, 5, 1.25, 0.0, 0), (0.2, 4, 1.1, 40.0, 0),
+                                                        (0.2, 5, 1.25, 0.0, 3), (0.0, 4, 1.6, 0.0, 3)])
+def test_step_fused_into_the_backward_equals_backward_then_step(dev, smooth, T, scale, rot, variant):
     """WindowAdam(fused_backward=True) -- vl3d_render_bwd_adam: the owner-computes backward applies the optimiser's step where it would have
     stored a texel's gradient -- against the two-kernel path (vl3d_render_bwd, then vl3d_adam_window_step_boxes) on two copies of one
     model over the same shuffled crops: the SAME BITS in the parameters, both moments and the step table after every iteration (texels
@@ -404,6 +405,9 @@ def test_step_fused_into_the_backward_equals_backward_then_step(dev, smooth, T, 
     A = MPMeshVid(_args(fused_adam_backward=False, **kw), H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
     B = MPMeshVid(_args(**kw), H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()      # (the default for dense models)
     B.load_state_dict({k: v for k, v in A.state_dict().items() if not k.startswith("self.")})
+    if variant:      # variant 3: the one-frame tile kernel (64-wide regions) carries the step instead of the frame pairs
+        import dataclasses
+        B.spec = dataclasses.replace(B.spec, variant=variant)
     oa, ob = A.get_optimizer(0), B.get_optimizer(0)
     assert ob.fused_backward and not oa.fused_backward
     tar = np.eye(4)
@@ -450,3 +454,87 @@ def test_step_fused_into_the_backward_equals_backward_then_step(dev, smooth, T, 
         assert float((sda["stack"] - sdb["stack"]).abs().mean()) <= 1e-6
     else:
         assert torch.equal(sda["stack"], sdb["stack"])
+
+
+@pytest.mark.parametrize("smooth,T,scale,rot", [(0.2, 4, 1.1, 0.0), (0.0, 5, 1.6, 0.0), (0.2, 3, 1.25, 40.0)])
+def test_tile_culled_step_fused_into_the_backward(dev, smooth, T, scale, rot):
+    """the same for a TILE-CULLED model (vl3d_render_bwd_adam with quad maps): dynamic texels are stepped in the owner's store, a static
+    texel's gradient is stored and summed over the frames by the step kernel behind the backward (static texels only), culled texels are
+    no parameters -- against vl3d_render_bwd_culled + vl3d_adam_window_step_boxes over all classes: the same bits in p, m, v and the step
+    table after every iteration (kept texels; culled slots hold whatever they held).  rot: the infeasible view (atomics + full step kernel)."""
+    import warnings
+    import videoloop3d_amd.render as R
+    from videoloop3d_amd import tiles
+    from videoloop3d_amd.MPV import MPMeshVid
+    H, W, h, w = 96, 128, 48, 64
+    K = np.array([[0.9 * W, 0, W / 2], [0, 0.9 * W, H / 2], [0, 0, 1]], np.float64)
+    torch.manual_seed(6)
+    keep = torch.rand(5, 8, 11) < 0.6
+    keep[3] = False                                # a plane without a single kept quad
+    dyn = keep & (torch.rand(5, 8, 11) < 0.5)
+    kw = dict(mpv_frm_num=T, mpi_h_scale=scale, mpi_w_scale=scale, rgb_smooth_loss_weight=smooth, a_smooth_loss_weight=smooth,
+              sparsity_loss_weight=0.01 if smooth else 0.0, mpi_h_verts=9, mpi_w_verts=12)
+    models = []
+    for fused in (False, True):
+        torch.manual_seed(7)
+        m = MPMeshVid(_args(fused_adam_backward=fused, **kw), H, W, np.eye(4), K, 1.0, 100.0)
+        with torch.no_grad():
+            st = tiles.quad_to_texel_mask(keep, m.mpi_h, m.mpi_w) & ~tiles.quad_to_texel_mask(dyn, m.mpi_h, m.mpi_w)
+            m.stack.data = torch.where(st[:, None, :, :, None], m.stack.data[:, :1], m.stack.data)
+            tiles.cull_stack_(m.stack.data, keep)
+        m.register_buffer("quad_keep", keep.clone())
+        m.register_buffer("quad_dyn", dyn.clone())
+        m.is_sparse = m.has_dyn = True
+        m = m.to(dev).train()
+        m._install_tie_hook()
+        models.append((m, m.get_optimizer(0)))
+    (A, oa), (B, ob) = models
+    assert ob.fused_backward and not oa.fused_backward and ob.quad_keep is not None
+    tar = np.eye(4)
+    c, s_ = np.cos(np.radians(rot)), np.sin(np.radians(rot))
+    tar[:3, :3] = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]])
+    tar[:3, 3] = [0.03, 0.01, 0.0]
+    res = synth.hash_uniform((1, 2 * T + 1, 3, h, w), seed=8, device=dev)
+    cfg = dict(loss_name=["gpnn_lm"], loss_gain=torch.tensor([1.0]), macro_block=torch.tensor([65]), patch_size=torch.tensor([3]),
+               stride=torch.tensor([2]), patcht_size=torch.tensor([3]), stridet=torch.tensor([1]), alpha=torch.tensor([10000.0]),
+               dist_fn=["mse"], rou=["-2"], scaling=torch.tensor([0.1]))
+    kept = tiles.quad_to_texel_mask(keep, *A.stack.shape[2:4]).to(dev)[:, None, :, :, None].expand_as(A.stack)
+    static = (tiles.quad_to_texel_mask(keep, *A.stack.shape[2:4]) & ~tiles.quad_to_texel_mask(dyn, *A.stack.shape[2:4])).to(dev)
+    offs = [(0, 0), (40, 60), (10, 30), (48, 64), (0, 64), (40, 0), (20, 20), (0, 0), (48, 64), (10, 30)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for it, (oy, ox) in enumerate(offs):
+            Kc = K.copy()
+            Kc[0, 2] -= ox
+            Kc[1, 2] -= oy
+            losses, feasible = [], []
+            for model, opt in models:
+                for grp in opt.param_groups:
+                    grp["lr"] = 5e-3 * 0.9 ** it
+                opt.zero_grad(set_to_none=True)
+                _, extra = model(h, w, torch.tensor(tar)[None], torch.tensor(Kc)[None], res=res, losscfg=dict(cfg))
+                loss = extra["swd"].sum()
+                if smooth:
+                    loss = loss + 0.2 * extra["rgb_smooth"].sum() + 0.2 * extra["a_smooth"].sum() + 0.01 * extra["sparsity"].sum()
+                loss.backward()
+                feasible.append(int(R.LAST_BWD_SCRATCH[:1].view(torch.int32)))
+                opt.step()
+                losses.append(float(loss.detach()))
+            assert feasible[0] == feasible[1] == (0 if rot else 1)
+            sa, sb = oa.state[oa.p], ob.state[ob.p]
+            assert torch.equal(sa["last_step"], sb["last_step"]) and oa.t == ob.t == it + 1
+            if rot:
+                assert abs(losses[0] - losses[1]) <= 1e-5 * max(1.0, abs(losses[0]))
+                continue
+            assert losses[0] == losses[1], (it, losses)
+            for name, x, y in (("p", A.stack.data, B.stack.data), ("m", sa["exp_avg"], sb["exp_avg"]), ("v", sa["exp_avg_sq"], sb["exp_avg_sq"])):
+                # a static texel is ONE parameter living in frame 0 (the other frames' slots are refreshed by flush())
+                x = torch.where(static[:, None, :, :, None], x[:, :1].expand_as(x), x)[kept]
+                y = torch.where(static[:, None, :, :, None], y[:, :1].expand_as(y), y)[kept]
+                assert torch.equal(x, y), (it, name, float((x - y).abs().max()), int((x != y).sum()))
+    assert ob.fused_steps == len(offs) and oa.fused_steps == 0
+    sda, sdb = A.state_dict()["stack"], B.state_dict()["stack"]           # flushes the deferred updates
+    if rot:
+        assert float((sda - sdb)[kept].abs().mean()) <= 1e-6
+    else:
+        assert torch.equal(sda[kept], sdb[kept])

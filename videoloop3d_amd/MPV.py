@@ -547,8 +547,10 @@ class MPMeshVid(nn.Module):
                 # the step), dynamic texels one per frame; only the crop's window is touched per step
                 from .optim import WindowAdam
                 from .tiles import CULLED_ALPHA
+                # (fused: dynamic texels are stepped inside the render's backward, static ones by the step kernel behind it -- see the dense branch)
+                fused = bool(getattr(self.args, "fused_adam_backward", True)) and not getattr(self.args, "finite_window_grad", False)
                 self._window_opt = WindowAdam(params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8, quad_keep=self.quad_keep,
-                                              quad_dyn=self.quad_dyn, culled_alpha=CULLED_ALPHA)
+                                              quad_dyn=self.quad_dyn, culled_alpha=CULLED_ALPHA, fused_backward=fused)
                 return self._window_opt
             if self.stack.is_cuda and not self.atlas_exact:
                 # dense model: crop-aware Adam -- the render reads a compact copy of the crop's texel window, the backward writes a

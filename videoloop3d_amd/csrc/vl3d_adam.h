@@ -56,6 +56,20 @@ __device__ __forceinline__ void replay_moments(float4 &mm, float4 &vv, int from,
     }
 }
 
+// tile-culled models (quad maps keep / dyn [D][QH][QW], MPI.py:288-442): 0 = culled texel (no kept quad can read it: no parameter),
+// 1 = dynamic (a parameter per frame), 2 = static (only static quads can read it: ONE parameter, living in frame 0 -- the reference's
+// static atlas, MPV.py:235-288).  Same classification as tiles.quad_to_texel_mask / adam_tiles_k.  keep == NULL: everything dynamic.
+struct Quads { const unsigned char *keep, *dyn; int QH, QW; };
+__device__ __forceinline__ int texel_class(const Quads &q, int d, int x, int y, int Hs, int Ws) {
+    if (!q.keep) return 1;
+    const int ylo = quad_index(y - 1, Hs, q.QH), yhi = quad_index(y + 1, Hs, q.QH), xlo = quad_index(x - 1, Ws, q.QW), xhi = quad_index(x + 1, Ws, q.QW);
+    const unsigned char *k = q.keep + (size_t)d * q.QH * q.QW;
+    if (!(k[ylo * q.QW + xlo] | k[ylo * q.QW + xhi] | k[yhi * q.QW + xlo] | k[yhi * q.QW + xhi])) return 0;
+    if (!q.dyn) return 1;
+    const unsigned char *m = q.dyn + (size_t)d * q.QH * q.QW;
+    return (m[ylo * q.QW + xlo] | m[ylo * q.QW + xhi] | m[yhi * q.QW + xlo] | m[yhi * q.QW + xhi]) ? 1 : 2;
+}
+
 }  // namespace vl3d_adam
 
 // ---- the render backward's fused owner store (vl3d_render_bwd_adam) ----------------------------------------------------------------
@@ -68,12 +82,20 @@ struct vl3d_adam_epilogue {
     const int4 *boxes;             // device [D] x (y0, y1, x0, x1) in plane texels (a plane's texels outside its box stay deferred) or NULL
     int y0, x0, Hs, Ws, tiles_y, tiles_x, step;
     float lr_bc1, beta1, beta2, eps, bc2s;
+    // tile-culled models: the quad maps (classification of a texel: vl3d_adam::texel_class) and a byte per texel of the compact window
+    // [D][desc->Hs][desc->Ws], written by the backward's pre-pass (frame independent) and read by the gather: 0 culled / 1 dynamic (stepped in
+    // the owner's store) / 2 static (its gradient is stored: the step kernel sums it over the frames) / 3 outside its plane's box
+    const unsigned char *quad_dyn;
+    unsigned char *cls;            // NULL: dense model (every texel dynamic)
 };
 
-// (internal, vl3d_optim.hip) the window step from a compact gradient that runs only where the device-side plan of the backward said
-// "infeasible" (plan[0] == 0: the atomics kernel produced the gradient), then the tile marks -- the tail of vl3d_render_bwd_adam
+// (internal, vl3d_optim.hip) the tail of vl3d_render_bwd_adam: the window step from the compact gradient for what the backward did not step
+// itself -- static texels of a tile-culled model always; everything when the device-side plan of the backward said "infeasible"
+// (*plan_ok == 0: the atomics kernel produced the gradient) -- then the tile marks.  Called BEFORE the render kernels with
+// grad_compact == NULL: window / box checks and the box table onto the device (boxes_dev).
 __attribute__((visibility("hidden"))) int vl3d_adam_window_step_tail(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh,
                                                                      int32_t ww, float *param, const float *grad_compact, float *exp_avg,
                                                                      float *exp_avg_sq, int32_t *last_step, const float *hist, float lr, float beta1,
-                                                                     float beta2, float eps, int64_t step, const int32_t *plane_boxes,
-                                                                     const int *only_if_zero, void *boxes_dev, hipStream_t stream);
+                                                                     float beta2, float eps, int64_t step, const uint8_t *quad_keep,
+                                                                     const uint8_t *quad_dyn, int32_t QH, int32_t QW, const int32_t *plane_boxes,
+                                                                     const int *plan_ok, void *boxes_dev, hipStream_t stream);

@@ -41,20 +41,6 @@ static BoxTable make_boxes(const int32_t *host_boxes, int D) {
     return t;
 }
 
-// tile-culled models (quad maps keep / dyn [D][QH][QW], MPI.py:288-442): 0 = culled texel (no kept quad can read it: no parameter),
-// 1 = dynamic (a parameter per frame), 2 = static (only static quads can read it: ONE parameter, living in frame 0 -- the reference's
-// static atlas, MPV.py:235-288).  Same classification as tiles.quad_to_texel_mask / adam_tiles_k.  keep == NULL: everything dynamic.
-struct Quads { const unsigned char *keep, *dyn; int QH, QW; };
-__device__ __forceinline__ int texel_class(const Quads &q, int d, int x, int y, int Hs, int Ws) {
-    if (!q.keep) return 1;
-    const int ylo = quad_index(y - 1, Hs, q.QH), yhi = quad_index(y + 1, Hs, q.QH), xlo = quad_index(x - 1, Ws, q.QW), xhi = quad_index(x + 1, Ws, q.QW);
-    const unsigned char *k = q.keep + (size_t)d * q.QH * q.QW;
-    if (!(k[ylo * q.QW + xlo] | k[ylo * q.QW + xhi] | k[yhi * q.QW + xlo] | k[yhi * q.QW + xhi])) return 0;
-    if (!q.dyn) return 1;
-    const unsigned char *m = q.dyn + (size_t)d * q.QH * q.QW;
-    return (m[ylo * q.QW + xlo] | m[ylo * q.QW + xhi] | m[yhi * q.QW + xlo] | m[yhi * q.QW + xhi]) ? 1 : 2;
-}
-
 // PACKED storage of a tile-culled model (the reference stores static quads once, dynamic quads per frame and culled quads not at all:
 // MPI.py:364-436, MPV.py:235-288).  Parameters and moments live in a pool of 8 x 8-texel blocks (the bookkeeping tiles): blocks [D][tiles_y][tiles_x]
 // int32 = -1 for a block no kept quad can read (no storage), else slot << 1 | dynamic -- a static block (only static quads can read it) is ONE
@@ -137,9 +123,10 @@ __global__ __launch_bounds__(256) void adam_window_step_k(int T, int Hs, int Ws,
                                                           float4 *__restrict__ m, float4 *__restrict__ v, float lr_bc1, float beta1, float beta2,
                                                           float eps, float bc2s, Quads q, int static_tied, const int *__restrict__ last_step,
                                                           int tiles_y, int tiles_x, const float2 *__restrict__ hist, int step,
-                                                          const BoxTable boxes, Layout lay, const int *__restrict__ only_if_zero) {
-    // (the tail of vl3d_render_bwd_adam: the owner-computes backward applied the step itself unless its device-side plan said infeasible)
-    if (only_if_zero && *only_if_zero) return;
+                                                          const BoxTable boxes, Layout lay, const int *__restrict__ dyn_stepped) {
+    // (the tail of vl3d_render_bwd_adam: the owner-computes backward stepped the DYNAMIC texels itself unless its device-side plan said infeasible)
+    const bool skip_dyn = dyn_stepped && *dyn_stepped;
+    if (skip_dyn && !q.keep) return;
     const int lx = blockIdx.x * 64 + (threadIdx.x & 63), ly = blockIdx.y * 4 + (threadIdx.x >> 6), d = blockIdx.z;
     if (lx >= w.ww || ly >= w.wh) return;
     if (outside_box(boxes, d, w.x0 + lx, w.y0 + ly)) return;     // zero gradient by construction: the update stays deferred
@@ -149,7 +136,7 @@ __global__ __launch_bounds__(256) void adam_window_step_k(int T, int Hs, int Ws,
     const size_t cframe = (size_t)w.wh * w.ww;
     size_t oc = (size_t)d * T * cframe + (size_t)ly * w.ww + lx;
     const int cls = texel_class(q, d, w.x0 + lx, w.y0 + ly, Hs, Ws);
-    if (cls == 0) return;
+    if (cls == 0 || (cls == 1 && skip_dyn)) return;
     size_t o, frame;
     texel_slot(lay, d, w.y0 + ly, w.x0 + lx, T, Hs, Ws, tiles_y, tiles_x, o, frame);
     if (cls == 2) {           // static: gradient = the sum over the frames (frame order: deterministic), one update, one write
@@ -317,7 +304,7 @@ static int window_step_impl(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_
                             float *param, const float *grad_compact, float *exp_avg, float *exp_avg_sq, int32_t *last_step,
                             const float *hist, float lr, float beta1, float beta2, float eps, int64_t step,
                             const uint8_t *quad_keep, const uint8_t *quad_dyn, int32_t QH, int32_t QW, int32_t static_tied,
-                            const int32_t *plane_boxes, const int32_t *blocks, const int *only_if_zero, void *boxes_dev, hipStream_t s) {
+                            const int32_t *plane_boxes, const int32_t *blocks, const int *dyn_stepped, void *boxes_dev, hipStream_t s) {
     int rc = check_window(D, T, Hs, Ws, y0, x0, wh, ww);
     VL3D_REQUIRE(!blocks || quad_keep, "vl3d_adam_window_step: the packed layout belongs to a tile-culled model (quad maps)");
     if (rc != VL3D_OK) return rc;
@@ -330,7 +317,7 @@ static int window_step_impl(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_
                        reinterpret_cast<float4 *>(param), reinterpret_cast<const float4 *>(grad_compact), reinterpret_cast<float4 *>(exp_avg),
                        reinterpret_cast<float4 *>(exp_avg_sq), (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2),
                        Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW}, static_tied, last_step, tiles_y, tiles_x,
-                       reinterpret_cast<const float2 *>(hist), (int)step, boxes, Layout{blocks}, only_if_zero);
+                       reinterpret_cast<const float2 *>(hist), (int)step, boxes, Layout{blocks}, dyn_stepped);
     const int nty = (y0 + wh + TS - 1) / TS - y0 / TS, ntx = (x0 + ww + TS - 1) / TS - x0 / TS;
     hipLaunchKernelGGL(mark_tiles_k, dim3((D * nty * ntx + 255) / 256), dim3(256), 0, s, last_step, tiles_y, tiles_x, y0 / TS, x0 / TS, nty, ntx, D, (int)step, boxes);
     VL3D_CHECK_LAUNCH();
@@ -346,20 +333,22 @@ extern "C" int vl3d_adam_window_step_boxes(int32_t D, int32_t T, int32_t Hs, int
                             quad_keep, quad_dyn, QH, QW, static_tied, plane_boxes, blocks, nullptr, nullptr, (hipStream_t)stream);
 }
 
-// (vl3d_adam.h) the tail of vl3d_render_bwd_adam.  Called BEFORE the render kernels with grad_compact == NULL: only the box table is put on
-// the device (boxes_dev); called after them: the conditional step + the tile marks.
+// (vl3d_adam.h) the tail of vl3d_render_bwd_adam.  Called BEFORE the render kernels with grad_compact == NULL: only the checks and the box
+// table onto the device (boxes_dev); called after them: the step of what the backward left + the tile marks.
 int vl3d_adam_window_step_tail(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww, float *param,
                                const float *grad_compact, float *exp_avg, float *exp_avg_sq, int32_t *last_step, const float *hist, float lr,
-                               float beta1, float beta2, float eps, int64_t step, const int32_t *plane_boxes, const int *only_if_zero,
-                               void *boxes_dev, hipStream_t stream) {
+                               float beta1, float beta2, float eps, int64_t step, const uint8_t *quad_keep, const uint8_t *quad_dyn, int32_t QH,
+                               int32_t QW, const int32_t *plane_boxes, const int *plan_ok, void *boxes_dev, hipStream_t stream) {
     if (!grad_compact) {
         int rc = check_window(D, T, Hs, Ws, y0, x0, wh, ww);
         if (rc != VL3D_OK) return rc;
         VL3D_REQUIRE(!plane_boxes || (boxes_dev && D <= MAX_BOX_PLANES), "vl3d_render_bwd_adam: per-plane boxes need boxes_scratch and at most 128 planes");
+        VL3D_REQUIRE(!quad_keep || (QH > 0 && QW > 0), "vl3d_render_bwd_adam: bad quad grid");
         if (plane_boxes) {
             const BoxTable boxes = make_boxes(plane_boxes, D);
             for (int d = 0; d < D; ++d) {
                 const int4 b = boxes.b[d];
+                if (b.y <= b.x || b.w <= b.z) continue;      // an empty box: nothing of this plane is stepped
                 VL3D_REQUIRE(b.x % TS == 0 && b.z % TS == 0 && b.x >= y0 && b.z >= x0 && b.y <= y0 + wh && b.w <= x0 + ww &&
                                  (b.y % TS == 0 || b.y == Hs) && (b.w % TS == 0 || b.w == Ws),
                              "vl3d_render_bwd_adam: plane boxes must be aligned to the bookkeeping tiles and lie inside the window");
@@ -370,7 +359,7 @@ int vl3d_adam_window_step_tail(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int
         return VL3D_OK;
     }
     return window_step_impl(D, T, Hs, Ws, y0, x0, wh, ww, param, grad_compact, exp_avg, exp_avg_sq, last_step, hist, lr, beta1, beta2, eps, step,
-                            nullptr, nullptr, 0, 0, 0, plane_boxes, nullptr, only_if_zero, nullptr, stream);
+                            quad_keep, quad_dyn, QH, QW, 0, plane_boxes, nullptr, plan_ok, nullptr, stream);
 }
 
 extern "C" int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,

@@ -360,11 +360,13 @@ extern "C" int vl3d_render_bwd_adam(const vl3d_render_desc *desc, const void *st
     VL3D_REQUIRE(adam != nullptr, "vl3d_render_bwd_adam: null adam window");
     VL3D_REQUIRE(stack && homos && rgb && alpha && grad_rgb && grad_stack && scratch, "null pointer passed to vl3d_render_bwd_adam");
     VL3D_REQUIRE(!grad_reg || reg_state, "vl3d_render_bwd_adam: grad_reg needs the reg_state the forward with regularisers filled");
+    const uint8_t *qk = adam->quad_keep;
+    const int bv = desc->variant & 0xf;
     if (!(desc->coord_mode == VL3D_COORD_AFFINE && desc->border_mode == VL3D_BORDER_HARDCUT && desc->act_order == VL3D_ACT_POST &&
-          desc->rgb_act == VL3D_ACT_SIGMOID && desc->alpha_act == VL3D_ACT_SIGMOID && desc->stack_dtype == VL3D_F32 && desc->T >= 2 &&
-          (desc->variant & 0xf) == 0)) {
-        vl3d_set_error("vl3d_render_bwd_adam: built for the dense stage-2 iteration -- (affine, hardcut, post), sigmoid / sigmoid, fp32 stack, "
-                       "T >= 2, variant 0; use vl3d_render_bwd + vl3d_adam_window_step otherwise");
+          desc->rgb_act == VL3D_ACT_SIGMOID && desc->alpha_act == VL3D_ACT_SIGMOID && desc->stack_dtype == VL3D_F32 &&
+          (qk ? (bv == 0 || bv == 3) : (desc->T >= 2 && (bv == 0 || bv == 3))))) {
+        vl3d_set_error("vl3d_render_bwd_adam: built for the stage-2 iteration -- (affine, hardcut, post), sigmoid / sigmoid, fp32 stack, "
+                       "T >= 2 for a dense model, variant 0 / 3; use vl3d_render_bwd(_culled) + vl3d_adam_window_step otherwise");
         return VL3D_EUNSUPPORTED;
     }
     VL3D_REQUIRE(scratch_bytes >= vl3d_render_bwd_scratch_bytes(desc), "vl3d_render_bwd_adam: scratch smaller than vl3d_render_bwd_scratch_bytes()");
@@ -372,20 +374,30 @@ extern "C" int vl3d_render_bwd_adam(const vl3d_render_desc *desc, const void *st
                      adam->step < (1ll << 31), "vl3d_render_bwd_adam: null pointer / bad step in the adam window");
     VL3D_REQUIRE((int64_t)desc->Hs * desc->Ws * 16 < (1ll << 32) && (int64_t)adam->Hs * adam->Ws * 16 < (1ll << 32),
                  "frame too large for 32-bit byte offsets");
+    if (qk) {
+        rc = check_cull(desc, qk, adam->QH, adam->QW);
+        if (rc != VL3D_OK) return rc;
+        VL3D_REQUIRE(adam->class_scratch, "vl3d_render_bwd_adam: a tile-culled model needs class_scratch (D * Hs * Ws bytes)");
+        VL3D_REQUIRE(desc->cull_Hs == adam->Hs && desc->cull_Ws == adam->Ws && desc->cull_row0 == adam->y0 && desc->cull_col0 == adam->x0,
+                     "vl3d_render_bwd_adam: desc->cull_* must name the optimiser's window (y0, x0) of its (Hs, Ws) planes");
+    }
     hipStream_t s = (hipStream_t)stream;
     // window / box checks and the box table on the device (the tail with a NULL gradient does exactly that)
     rc = vl3d_adam_window_step_tail(desc->D, desc->T, adam->Hs, adam->Ws, adam->y0, adam->x0, desc->Hs, desc->Ws, adam->param, nullptr,
                                     adam->exp_avg, adam->exp_avg_sq, adam->last_step, adam->hist, adam->lr, adam->beta1, adam->beta2, adam->eps,
-                                    adam->step, adam->plane_boxes, nullptr, adam->boxes_scratch, s);
+                                    adam->step, qk, adam->quad_dyn, adam->QH, adam->QW, adam->plane_boxes, nullptr, adam->boxes_scratch, s);
     if (rc != VL3D_OK) return rc;
     RenderArgs a = make_args(desc);
     if (grad_reg) set_reg_state(a, desc, reg_state);
     a.stack = (const float *)stack; a.homos = homos;
     a.rgb = const_cast<float *>(rgb); a.alpha = const_cast<float *>(alpha);
     a.g_rgb = grad_rgb; a.g_alpha = grad_alpha; a.g_reg = grad_reg; a.g_asum = grad_alpha_sums; a.g_stack = grad_stack;
+    a.quad_keep = qk; a.QH = adam->QH; a.QW = adam->QW;
+    set_cull_geometry(a, desc, adam->QH, adam->QW);
+    a.grad_culled_unwritten = qk ? 1 : 0;
     a.plan = (const float *)scratch;
     a.owner = reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(scratch) + owner_table_off(desc));
-    a.tile_rows = 17;
+    a.tile_rows = (bv == 3 || qk) ? 16 : 17;      // 16: the one-frame tile kernel (64-wide regions) instead of the frame pairs
     const double bc1 = 1.0 - pow((double)adam->beta1, (double)adam->step), bc2 = 1.0 - pow((double)adam->beta2, (double)adam->step);
     const int ts = vl3d_adam::TS;
     a.ad.p = reinterpret_cast<float4 *>(adam->param); a.ad.m = reinterpret_cast<float4 *>(adam->exp_avg);
@@ -397,11 +409,14 @@ extern "C" int vl3d_render_bwd_adam(const vl3d_render_desc *desc, const void *st
     a.ad.step = (int)adam->step;
     a.ad.lr_bc1 = (float)((double)adam->lr / bc1); a.ad.beta1 = adam->beta1; a.ad.beta2 = adam->beta2; a.ad.eps = adam->eps;
     a.ad.bc2s = (float)sqrt(bc2);
+    a.ad.quad_dyn = qk ? adam->quad_dyn : nullptr;
+    a.ad.cls = qk ? reinterpret_cast<unsigned char *>(adam->class_scratch) : nullptr;
     rc = dispatch(true, desc, a, s);
     if (rc != VL3D_OK) return rc;
-    // infeasible view (decided on the device): the atomics kernel filled grad_stack and the step kernel takes it from there; the tiles are
-    // marked either way
+    // behind the backward, under the plan's device-side flag: nothing more (dense, feasible) / the static texels (tile-culled, feasible) / the
+    // whole window from the atomics kernel's gradient (infeasible view); the tiles are marked either way
     return vl3d_adam_window_step_tail(desc->D, desc->T, adam->Hs, adam->Ws, adam->y0, adam->x0, desc->Hs, desc->Ws, adam->param, grad_stack,
                                       adam->exp_avg, adam->exp_avg_sq, adam->last_step, adam->hist, adam->lr, adam->beta1, adam->beta2, adam->eps,
-                                      adam->step, adam->plane_boxes, reinterpret_cast<const int *>(scratch), nullptr, s);
+                                      adam->step, qk, adam->quad_dyn, adam->QH, adam->QW, adam->plane_boxes,
+                                      reinterpret_cast<const int *>(scratch), nullptr, s);
 }

@@ -1109,6 +1109,12 @@ __device__ __forceinline__ bool adam_texel(const RenderArgs &a, int d, int cx, i
     off = (unsigned)(Y * a.ad.Ws + X) << 4;
     return true;
 }
+// ... for a caller that already knows the texel is one the optimiser steps now (the class table of a tile-culled model holds the box test)
+__device__ __forceinline__ void adam_texel_inbox(const RenderArgs &a, int d, int cx, int cy, int &from, unsigned &off) {
+    const int X = a.ad.x0 + cx, Y = a.ad.y0 + cy;
+    from = a.ad.last_step[((size_t)d * a.ad.tiles_y + (Y >> 3)) * a.ad.tiles_x + (X >> 3)];
+    off = (unsigned)(Y * a.ad.Ws + X) << 4;
+}
 // One Adam step of one texel and frame with gradient g: `pcur` is the parameter current for step - 1 (the compact copy holds it: the
 // catch-up replayed the deferred steps into it, so only the two moments are replayed here -- multiplications), (p, m, v) are written.
 // fb: byte offset of the frame (uniform).
@@ -1161,20 +1167,38 @@ __global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, i
     // same pass (it already has the texel's owner pixel): texels no tile is certain to own -- owner pixel on or outside the frame's
     // border ring -- are zero-filled for all T frames here, so nothing memsets the gradient; the tile kernel runs after this
     // kernel and overwrites the border ring's texels it does own
+    int cls = 1;
+    if (a.ad.p && a.ad.cls) {      // tile-culled model under the fused step: classify the texel once (frame independent), the gather reads a byte
+        const int X = a.ad.x0 + x, Y = a.ad.y0 + y;
+        bool inbox = true;
+        if (a.ad.boxes) {
+            const cint_p b = (cint_p)a.ad.boxes + 4 * d;
+            inbox = !(Y < b[0] || Y >= b[1] || X < b[2] || X >= b[3]);
+        }
+        cls = inbox ? vl3d_adam::texel_class(vl3d_adam::Quads{a.quad_keep, a.ad.quad_dyn, a.QH, a.QW}, d, X, Y, a.ad.Hs, a.ad.Ws) : 3;
+        a.ad.cls[((size_t)d * a.Hs + y) * a.Ws + x] = (unsigned char)cls;
+    }
     const bool safe = (qx > 0.5f) && (qx < (float)a.W - 1.5f) && (qy > 0.5f) && (qy < (float)a.H - 1.5f);
     if (safe) return;
     const size_t frame = (size_t)a.Hs * a.Ws;
     if (a.ad.p) {
-        // fused optimiser step: there is no gradient to zero-fill -- the texels the tile kernel will NOT reach take their zero-gradient step
-        // here, exactly once: the tile kernel's gather visits the texels of its window (bwd_windows_k, run before this kernel) the table
-        // assigns to it, so a texel outside its owner tile's window is visited by nobody (tiles far enough apart to share a code have
-        // disjoint windows: the table's premise)
+        // fused optimiser step: the texels the tile kernel will NOT reach take their zero-gradient step here, exactly once: the tile kernel's
+        // gather visits the texels of its window (bwd_windows_k, run before this kernel) the table assigns to it, so a texel outside its owner
+        // tile's window is visited by nobody (tiles far enough apart to share a code have disjoint windows: the table's premise)
         const int4 rec = reinterpret_cast<const int4 *>(reinterpret_cast<const int *>(a.plan) + plan_win_off(a.D))[(size_t)(ty * tiles_x + tx) * a.D + d];
         const int ww = rec.z & 0xffff, wh = (rec.z >> 16) & 0x3fff;
-        if (x >= rec.x && x < rec.x + ww && y >= rec.y && y < rec.y + wh) return;
+        // (bit 31: a tile-culled model's tile that skips this plane altogether -- none of its pixels sees a kept quad -- visits nothing)
+        if (rec.z >= 0 && x >= rec.x && x < rec.x + ww && y >= rec.y && y < rec.y + wh) return;
         int from;
         unsigned off;
-        if (!adam_texel(a, d, x, y, from, off)) return;
+        if (cls == 2) {      // a static texel's gradient is summed over the frames by the step kernel: zeros, as without the fused step
+            float4 *g = reinterpret_cast<float4 *>(a.g_stack) + (size_t)d * a.T * frame + (size_t)y * a.Ws + x;
+            for (int t = 0; t < a.T; ++t, g += frame) *g = make_float4(0.f, 0.f, 0.f, 0.f);
+            return;
+        }
+        if (cls != 1) return;
+        if (a.ad.cls) adam_texel_inbox(a, d, x, y, from, off);
+        else if (!adam_texel(a, d, x, y, from, off)) return;
         const f4 *pc = reinterpret_cast<const f4 *>(a.stack) + (size_t)d * a.T * frame + (size_t)y * a.Ws + x;
         const size_t fbytes = (size_t)a.ad.Hs * a.ad.Ws * 16;
         size_t fb = (size_t)d * a.T * fbytes;
@@ -1203,13 +1227,14 @@ __global__ __launch_bounds__(256) void bwd_fill_zero_f32_if_infeasible_k(float *
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) g[i] = 0.f;
 }
 
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16, bool CULL = false, bool MASK = false>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16, bool CULL = false, bool MASK = false, bool ADAM = false>
 // (the culled instantiation of the utils_mpi coordinate convention -- a cross-check convention, its texel coordinates cost a
 // reciprocal more -- does not fit 64 VGPRs: it takes the 128-register budget (one workgroup per CU) rather than spill)
 // MASK: stage 1's loop-mask texture as a fifth channel of the same sweep and gather (a fifth staged value, a fifth accumulator, one
 // 4-byte store per owned texel); T = 1 there, so the instantiation simply takes the 128-register budget.
 __global__ __launch_bounds__(RW *ROWS, ((REG || MASK || (CULL && COORD == VL3D_COORD_UTILS_MPI)) ? 4 : 8)) void render_bwd_tile_k(RenderArgs a) {
     static_assert(!(MASK && (CULL || F16 || ORDER != VL3D_ACT_POST)), "the loop-mask channel: dense fp32 stage-1 stacks, sample-then-activate");
+    static_assert(!(ADAM && (F16 || MASK || !REG)), "the fused optimiser step: fp32 stacks, the instantiation with the 128-register budget");
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
     constexpr int NT = RW * ROWS;
     __shared__ float s_gm[MASK ? 2 : 1][MASK ? NT : 1];     // MASK: gradient w.r.t. the sampled mask logit of this pixel on this plane
@@ -1290,7 +1315,7 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || MASK || (CULL && COORD == VL3D_C
         // (a skipped plane whose owned texels need no zero fill -- grad_culled_unwritten -- costs one scalar record, not a table load per
         // thread.  In the instantiation with regularisers only, the one a shipped stage-2 iteration runs: the plain culled kernel sits
         // exactly at its 64-register budget and the extra branch spilled 12 bytes; it keeps filling zeros, which is always correct.)
-        if constexpr (REG) { if (CULL && culled && a.grad_culled_unwritten) continue; }
+        if constexpr (REG) { if (CULL && culled && (ADAM || a.grad_culled_unwritten)) continue; }
         const unsigned win0 = (unsigned)(Y0 * a.Ws + X0);          // frame texel index of the window's corner (uniform)
         const unsigned short *oplane = a.owner + (size_t)d * a.Hs * a.Ws;
         // this thread's first owner-table entry, requested now so that it arrives in the shadow of the sweep.  Unconditional
@@ -1415,7 +1440,19 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || MASK || (CULL && COORD == VL3D_C
                 acc = f4{acc.x * act_bwd<RACT>(sv.x, act_fwd<RACT>(sv.x)), acc.y * act_bwd<RACT>(sv.y, act_fwd<RACT>(sv.y)),
                          acc.z * act_bwd<RACT>(sv.z, act_fwd<RACT>(sv.z)), acc.w * act_bwd<AACT>(sv.w, act_fwd<AACT>(sv.w))};
             }
-            if (!VL3D_ABLATE(a.ablate, 2)) store_grad_texel<F16>(gplane, tix << 4, acc);
+            if constexpr (ADAM) {      // the optimiser's step instead of the gradient store (vl3d_render_bwd_adam; t = this workgroup's frame)
+                int from;
+                unsigned off;
+                if constexpr (CULL) {
+                    // tile-culled model: the pre-pass's class byte -- a dynamic texel is stepped here, a static texel's gradient is stored (the step
+                    // kernel sums it over the frames), culled texels and texels outside their plane's box are nobody's business
+                    const unsigned c = a.ad.cls[(size_t)d * a.Hs * a.Ws + tix];
+                    if (c == 2) store_grad_texel<false>(gplane, tix << 4, acc);
+                    if (c != 1) return;
+                    adam_texel_inbox(a, d, X0 + wx, Y0 + wy, from, off);
+                } else if (!adam_texel(a, d, X0 + wx, Y0 + wy, from, off)) return;
+                adam_texel_step(a, ((size_t)d * a.T + t) * ((size_t)a.ad.Hs * a.ad.Ws * 16), off, from, load_texel<false>(plane, tix << 4), acc);
+            } else if (!VL3D_ABLATE(a.ablate, 2)) store_grad_texel<F16>(gplane, tix << 4, acc);
             if constexpr (MASK) __builtin_nontemporal_store(accm, gmplane + tix);
         };
         if (row < wh && lane < ww) gather(e0, lane, row, win0 + toff_thread);
@@ -1833,7 +1870,7 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
 }
 
 // ---- launch templates ---------------------------------------------------------------------------------------------
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16 = false, bool MASK = false>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16 = false, bool MASK = false, bool ADAM = false>
 void launch_tile(const RenderArgs &a, hipStream_t s) {
     constexpr int RH = 1, IW = RW - 2 * RH, IH = ROWS - 2 * RH;
     RenderArgs b = a;
@@ -1843,7 +1880,14 @@ void launch_tile(const RenderArgs &a, hipStream_t s) {
                        reinterpret_cast<int *>(const_cast<float *>(a.plan)) + plan_win_off(a.D));
     hipLaunchKernelGGL(bwd_owner_table_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x,
                        const_cast<unsigned short *>(a.owner));
-    if constexpr (MASK) {       // (dense models only: the entry point refuses a quad map)
+    if constexpr (ADAM) {
+        if (a.quad_keep)
+            hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, true, false, true, false, true>),
+                               dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
+        else
+            hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, true, false, false, false, true>),
+                               dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
+    } else if constexpr (MASK) {       // (dense models only: the entry point refuses a quad map)
         hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16, false, true>),
                            dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
     } else if (a.quad_keep)
@@ -1880,7 +1924,9 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
             if constexpr (COORD == VL3D_COORD_AFFINE && BORDER == VL3D_BORDER_HARDCUT && ORDER == VL3D_ACT_POST && RACT == VL3D_ACT_SIGMOID &&
                           AACT == VL3D_ACT_SIGMOID && !F16 && VL3D_HS == 9) {
                 if (a.ad.p) {
-                    if (a.g_reg || a.g_asum) launch_pair<COORD, BORDER, ORDER, RACT, AACT, false, true, true>(a, s);
+                    // tile-culled models and variant 3: one frame per thread, 64-wide regions (the frame pairs are built for dense stacks)
+                    if (a.tile_rows == 16 || a.quad_keep) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, false, false, true>(a, s);
+                    else if (a.g_reg || a.g_asum) launch_pair<COORD, BORDER, ORDER, RACT, AACT, false, true, true>(a, s);
                     else launch_pair<COORD, BORDER, ORDER, RACT, AACT, false, false, true>(a, s);
                     hipLaunchKernelGGL((render_bwd_k<COORD, BORDER, ORDER, RACT, AACT, F16>), grid, block, 0, s, a);
                     return;

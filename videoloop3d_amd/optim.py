@@ -13,9 +13,10 @@ the one-pass update -- while touching only the texels the current training crop 
 
 Without a pending window (someone filled `p.grad` densely) step() falls back to the dense update: flush + full-window step.
 
-`fused_backward=True` (dense models): the step is taken INSIDE the render's backward (vl3d_render_bwd_adam) -- the owner-computes kernel
+`fused_backward=True` (unpacked storage): the step is taken INSIDE the render's backward (vl3d_render_bwd_adam) -- the owner-computes kernel
 applies the update where it would have stored a texel's gradient, so the window's gradient is never written or read back (6 streams of
-the window instead of 2 + 7).  `loss.backward()` then leaves the parameters updated and `step()` only does its periodic housekeeping; the
+the window instead of 2 + 7).  With quad maps that holds for the DYNAMIC texels; a static texel's gradient is still stored and the step
+kernel behind the backward sums it over the frames (static texels only).  `loss.backward()` then leaves the parameters updated and `step()` only does its periodic housekeeping; the
 learning rate is the group's at the time of the backward (train_3dvid.py:263-277 sets it before the iteration).  The parameters are bit
 for bit those of the two-kernel path.  Contract: one backward per window_leaf(), nothing else reads the leaf's gradient (it stays None).
 """
@@ -73,9 +74,9 @@ class WindowAdam(torch.optim.Optimizer):
         self.lean_window = bool(lean_window)
         self._compact_buf = None
         self.fused_backward = bool(fused_backward)
-        if self.fused_backward and (self.quad_keep is not None or layout is not None):
-            raise RuntimeError("WindowAdam(fused_backward=True) is built for dense models (no quad maps / packed layout)")
-        self._boxes_dev = None
+        if self.fused_backward and layout is not None:
+            raise RuntimeError("WindowAdam(fused_backward=True) is built for unpacked storage (the dense stack, with or without quad maps)")
+        self._boxes_dev = self._class_dev = None
         self.fused_steps = 0             # steps taken inside a backward (diagnostics / tests)
 
     # ---- state ----------------------------------------------------------------------------------------------------------
@@ -195,8 +196,8 @@ class WindowAdam(torch.optim.Optimizer):
         """does the backward of a render of `stack` (the pending window leaf?) under `spec` take this optimiser's step itself?"""
         pend = self.pending
         return (self.fused_backward and isinstance(pend, tuple) and len(pend) == 3 and self._is_leaf(pend, stack) and stack.dtype == torch.float32
-                and stack.shape[1] >= 2 and spec.coord_mode == "affine" and spec.border == "hardcut" and spec.act_order == "post"
-                and spec.rgb_act == "sigmoid" and spec.alpha_act == "sigmoid" and (int(spec.variant) & 0xf) == 0)
+                and (stack.shape[1] >= 2 or self.quad_keep is not None) and spec.coord_mode == "affine" and spec.border == "hardcut" and spec.act_order == "post"
+                and spec.rgb_act == "sigmoid" and spec.alpha_act == "sigmoid" and (int(spec.variant) & 0xf) in (0, 3))
 
     @staticmethod
     def _is_leaf(pend, stack):
@@ -225,6 +226,14 @@ class WindowAdam(torch.optim.Optimizer):
             if self._boxes_dev is None or self._boxes_dev.device != dev:
                 self._boxes_dev = torch.empty(128 * 4, dtype=torch.int32, device=dev)
             aw.plane_boxes, aw.boxes_scratch = boxes.ctypes.data, self._boxes_dev.data_ptr()
+        if self.quad_keep is not None:
+            n = D * stack.shape[2] * stack.shape[3]
+            if self._class_dev is None or self._class_dev.numel() < n or self._class_dev.device != dev:
+                self._class_dev = None
+                self._class_dev = torch.empty(n, dtype=torch.uint8, device=dev)
+            aw.quad_keep, aw.QH, aw.QW = self.quad_keep.data_ptr(), self.quad_keep.shape[1], self.quad_keep.shape[2]
+            aw.quad_dyn = None if self.quad_dyn is None else self.quad_dyn.data_ptr()
+            aw.class_scratch = self._class_dev.data_ptr()
         g_fallback = torch.empty_like(stack)       # written (and consumed) on the device only when the plan finds the view infeasible
         with torch.cuda.device(dev):
             nscratch = int(L.lib().vl3d_render_bwd_scratch_bytes(desc))

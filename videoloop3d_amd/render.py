@@ -64,7 +64,10 @@ class _RenderPlanes(torch.autograd.Function):
     def forward(ctx, stack, homos, H, W, spec, row0, col0, with_reg, quad_keep=None, cull_window=None, grad_culled_unwritten=False, fused_adam=None):
         L.check_cuda(stack, homos)
         # fused_adam (optim.WindowAdam with fused_backward): `stack` is its pending window leaf and the backward takes the step itself
-        ctx.fused_adam = fused_adam if (fused_adam is not None and quad_keep is None and (row0, col0) == (0, 0) and stack.is_contiguous()
+        # (a tile-culled model: the optimiser classifies texels with ITS quad maps, the render culls with `quad_keep`: the same map, same device)
+        ctx.fused_adam = fused_adam if (fused_adam is not None and (row0, col0) == (0, 0) and stack.is_contiguous()
+                                        and (quad_keep is None) == (fused_adam.quad_keep is None)
+                                        and (quad_keep is None or (cull_window is not None and tuple(quad_keep.shape) == tuple(fused_adam.quad_keep.shape)))
                                         and fused_adam.fuses(stack, spec)) else None
         ctx.leaf = stack if ctx.fused_adam is not None else None
         if quad_keep is not None:
