@@ -548,7 +548,8 @@ def main():
                 import stage2_schedule
                 # dense: the optimiser step inside the render backward (vl3d_render_bwd_adam, the default); dense_two_kernels: vl3d_render_bwd + step kernel
                 res["stage2_schedule"] = {"dense": stage2_schedule.run(dev=str(dev)), "dense_two_kernels": stage2_schedule.run(dev=str(dev), fused=False),
-                                          "tile_culled": stage2_schedule.run(dev=str(dev), sparsify=True)}
+                                          "tile_culled": stage2_schedule.run(dev=str(dev), sparsify=True),
+                                          "tile_culled_two_kernels": stage2_schedule.run(dev=str(dev), sparsify=True, fused=False)}
             except Exception as e:
                 res["stage2_schedule"] = {"error": repr(e)}
         if not a.no_cpu_baseline:
@@ -578,7 +579,7 @@ def main():
                                    "bwd_frac": pick(res, "reference_geometry", "roofline_bwd", "frac")},
             "stage1_iters_per_s": {k: pick(res, "stage1_step", k, "iters_per_s") for k in ("native_crop", "cfg2_720p_frame", "cfg2_720p_frame_scale1p6")},
             "stage2_step_iters_per_s": {k: pick(res, "stage2_step", k, "iters_per_s") for k in ("ref", "other", "other_tile_culled", "other_tile_culled_packed")},
-            "stage2_schedule_iters_per_s": {k: pick(res, "stage2_schedule", k, "iters_per_s") for k in ("dense", "dense_two_kernels", "tile_culled")},
+            "stage2_schedule_iters_per_s": {k: pick(res, "stage2_schedule", k, "iters_per_s") for k in ("dense", "dense_two_kernels", "tile_culled", "tile_culled_two_kernels")},
         }
         head = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                 "stack_storage", "config", "roofline", "cpu_baseline", "build", "summary", "roofline_fwd", "roofline_bwd", "fwd_bwd_algorithmic_frac"]

@@ -191,7 +191,7 @@ int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t 
  * Tile-culled models (adam->quad_keep != NULL; the render culls with the same map, desc->cull_* = the window (y0, x0) of the (Hs, Ws) plane):
  * a DYNAMIC texel is stepped in the owner's store, a STATIC texel (one parameter for all frames) has its gradient stored to grad_stack as
  * vl3d_render_bwd_culled does and the step kernel behind the backward sums it over the frames -- static texels only, unless the plan was
- * infeasible --, culled texels are nobody's (grad_stack holds defined values in static texels only).  Dense (unpacked) storage.
+ * infeasible --, culled texels are nobody's (grad_stack holds defined values in static texels only).  adam->blocks: packed storage.
  * fp32 stacks, the planar convention with the shipped activations ((affine, hardcut, post), sigmoid / sigmoid); dense models: T >= 2,
  * desc->variant 0 (frame pairs) or 3 (the one-frame tile kernel, which tile-culled models always take); anything else: VL3D_EUNSUPPORTED,
  * nothing launched. */
@@ -210,6 +210,7 @@ typedef struct vl3d_adam_window {
     const uint8_t *quad_keep, *quad_dyn;
     int32_t QH, QW;
     void *class_scratch;
+    const int32_t *blocks;       /* PACKED storage (as vl3d_adam_window_step_boxes; needs the quad maps): param / exp_avg / exp_avg_sq are the pools */
 } vl3d_adam_window;
 int vl3d_render_bwd_adam(const vl3d_render_desc *desc, const void *stack, const float *homos, const float *rgb, const float *alpha,
                          const float *grad_rgb, const float *grad_alpha, const float *grad_reg, const void *reg_state,

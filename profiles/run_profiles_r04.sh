@@ -2,7 +2,7 @@
 # Round-4 profile recipe -- ONE run (on the GPU box through gpurun) regenerates every tracked summary from the same tree:
 #   bench line (bench.json) + rocprofv3 kernel stats of the SAME command          -> r04_bench.json, r04_kernel_stats.csv
 #   pmc_target.py (cfg3 render, reference geometry, looping loss; + fp16 stack)   -> r04_kernel_stats_target.csv, r04_pmc_summary.txt
-#   the stage-2 schedule, the loss iteration, the stage-1 iteration               -> r04_kernel_stats_{sched,loss,s1}.csv
+#   the stage-2 schedule (dense / tile-culled, fused step / two kernels), the loss iteration, the stage-1 iteration -> r04_kernel_stats_{sched,sched2k,schedc,schedc2k,loss,s1}.csv
 # PMC passes are separate runs per counter group with --kernel-trace only (gpurun refuses --pmc with the sys / hip / hsa trace domains).
 # Outputs land in gpurun_out/$R (scratch); profiles/collect_r04.sh copies the summaries into profiles/.
 set -x
@@ -20,10 +20,14 @@ timeout 400 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY S
 timeout 400 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/sq2 -o p -- $B > $O/sq2.log 2>&1
 for f in $O/*/p_counter_collection.csv; do head -1 $f > $f.tmp; grep -E "render_|bwd_|reg_|patchnn|vote_fold|robust_|video_to|adam_|loop_" $f >> $f.tmp; mv $f.tmp $f; done
 python profiles/summarize_pmc.py $O "" > $O/pmc_summary.txt
-for leg in "sched examples/stage2_schedule.py" "loss profiles/loss_iter_prof.py" "s1 examples/stage1_step.py"; do
+# sched: the dense schedule with the optimiser step inside the backward (the default); sched2k: vl3d_render_bwd + the step kernel;
+# schedc / schedc2k: the same pair for the tile-culled model
+for leg in "sched examples/stage2_schedule.py" "sched2k examples/stage2_schedule.py --two-kernels" "schedc examples/stage2_schedule.py --sparsify" \
+           "schedc2k examples/stage2_schedule.py --sparsify --two-kernels" "loss profiles/loss_iter_prof.py" "s1 examples/stage1_step.py"; do
   set -- $leg
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$1 -o t -- python $2 > $O/$1.log 2>&1
-  cp $O/$1/t_kernel_stats.csv $O/kernel_stats_$1.csv
+  L=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$L -o t -- python "$@" > $O/$L.log 2>&1
+  cp $O/$L/t_kernel_stats.csv $O/kernel_stats_$L.csv
 done
 rm -f $O/*/p_kernel_trace.csv $O/*/t_kernel_trace.csv $O/*/p_agent_info.csv $O/*/t_agent_info.csv
 [ -f $O/trace/t_kernel_stats.csv ] && cp $O/trace/t_kernel_stats.csv $O/kernel_stats_bench.csv

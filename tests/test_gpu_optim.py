@@ -456,12 +456,14 @@ def test_step_fused_into_the_backward_equals_backward_then_step(dev, smooth, T, 
         assert torch.equal(sda["stack"], sdb["stack"])
 
 
-@pytest.mark.parametrize("smooth,T,scale,rot", [(0.2, 4, 1.1, 0.0), (0.0, 5, 1.6, 0.0), (0.2, 3, 1.25, 40.0)])
-def test_tile_culled_step_fused_into_the_backward(dev, smooth, T, scale, rot):
+@pytest.mark.parametrize("smooth,T,scale,rot,packed", [(0.2, 4, 1.1, 0.0, False), (0.0, 5, 1.6, 0.0, False), (0.2, 3, 1.25, 40.0, False),
+                                                       (0.2, 4, 1.1, 0.0, True), (0.0, 5, 1.25, 0.0, True), (0.2, 3, 1.1, 40.0, True)])
+def test_tile_culled_step_fused_into_the_backward(dev, smooth, T, scale, rot, packed):
     """the same for a TILE-CULLED model (vl3d_render_bwd_adam with quad maps): dynamic texels are stepped in the owner's store, a static
     texel's gradient is stored and summed over the frames by the step kernel behind the backward (static texels only), culled texels are
     no parameters -- against vl3d_render_bwd_culled + vl3d_adam_window_step_boxes over all classes: the same bits in p, m, v and the step
-    table after every iteration (kept texels; culled slots hold whatever they held).  rot: the infeasible view (atomics + full step kernel)."""
+    table after every iteration (kept texels; culled slots hold whatever they held).  rot: the infeasible view (atomics + full step kernel).
+    packed: parameters and moments in the pools of 8 x 8-texel blocks (block table addressing in the owner's store)."""
     import warnings
     import videoloop3d_amd.render as R
     from videoloop3d_amd import tiles
@@ -487,9 +489,11 @@ def test_tile_culled_step_fused_into_the_backward(dev, smooth, T, scale, rot):
         m.is_sparse = m.has_dyn = True
         m = m.to(dev).train()
         m._install_tie_hook()
+        if packed:
+            m.pack_()
         models.append((m, m.get_optimizer(0)))
     (A, oa), (B, ob) = models
-    assert ob.fused_backward and not oa.fused_backward and ob.quad_keep is not None
+    assert ob.fused_backward and not oa.fused_backward and ob.quad_keep is not None and (ob.layout is not None) == packed
     tar = np.eye(4)
     c, s_ = np.cos(np.radians(rot)), np.sin(np.radians(rot))
     tar[:3, :3] = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]])
@@ -498,8 +502,9 @@ def test_tile_culled_step_fused_into_the_backward(dev, smooth, T, scale, rot):
     cfg = dict(loss_name=["gpnn_lm"], loss_gain=torch.tensor([1.0]), macro_block=torch.tensor([65]), patch_size=torch.tensor([3]),
                stride=torch.tensor([2]), patcht_size=torch.tensor([3]), stridet=torch.tensor([1]), alpha=torch.tensor([10000.0]),
                dist_fn=["mse"], rou=["-2"], scaling=torch.tensor([0.1]))
-    kept = tiles.quad_to_texel_mask(keep, *A.stack.shape[2:4]).to(dev)[:, None, :, :, None].expand_as(A.stack)
-    static = (tiles.quad_to_texel_mask(keep, *A.stack.shape[2:4]) & ~tiles.quad_to_texel_mask(dyn, *A.stack.shape[2:4])).to(dev)
+    Dd, Td, Hs_, Ws_ = A.stack_dims()
+    kept = tiles.quad_to_texel_mask(keep, Hs_, Ws_).to(dev)[:, None, :, :, None].expand(Dd, Td, Hs_, Ws_, 4)
+    static = (tiles.quad_to_texel_mask(keep, Hs_, Ws_) & ~tiles.quad_to_texel_mask(dyn, Hs_, Ws_)).to(dev)
     offs = [(0, 0), (40, 60), (10, 30), (48, 64), (0, 64), (40, 0), (20, 20), (0, 0), (48, 64), (10, 30)]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -527,13 +532,20 @@ def test_tile_culled_step_fused_into_the_backward(dev, smooth, T, scale, rot):
                 assert abs(losses[0] - losses[1]) <= 1e-5 * max(1.0, abs(losses[0]))
                 continue
             assert losses[0] == losses[1], (it, losses)
-            for name, x, y in (("p", A.stack.data, B.stack.data), ("m", sa["exp_avg"], sb["exp_avg"]), ("v", sa["exp_avg_sq"], sb["exp_avg_sq"])):
+            for name, x, y in (("p", oa.p.data, ob.p.data), ("m", sa["exp_avg"], sb["exp_avg"]), ("v", sa["exp_avg_sq"], sb["exp_avg_sq"])):
+                if packed:       # the pools: every slot belongs to a kept block
+                    assert torch.equal(x, y), (it, name, float((x - y).abs().max()), int((x != y).sum()))
+                    continue
                 # a static texel is ONE parameter living in frame 0 (the other frames' slots are refreshed by flush())
                 x = torch.where(static[:, None, :, :, None], x[:, :1].expand_as(x), x)[kept]
                 y = torch.where(static[:, None, :, :, None], y[:, :1].expand_as(y), y)[kept]
                 assert torch.equal(x, y), (it, name, float((x - y).abs().max()), int((x != y).sum()))
     assert ob.fused_steps == len(offs) and oa.fused_steps == 0
-    sda, sdb = A.state_dict()["stack"], B.state_dict()["stack"]           # flushes the deferred updates
+    if packed:
+        oa.flush(); ob.flush()
+        sda, sdb, kept = oa.p.data, ob.p.data, slice(None)
+    else:
+        sda, sdb = A.state_dict()["stack"], B.state_dict()["stack"]           # flushes the deferred updates
     if rot:
         assert float((sda - sdb)[kept].abs().mean()) <= 1e-6
     else:

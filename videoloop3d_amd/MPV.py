@@ -533,7 +533,9 @@ class MPMeshVid(nn.Module):
                 from .optim import WindowAdam
                 from .tiles import CULLED_ALPHA
                 self._window_opt = WindowAdam([{'params': [self.stack_pool]}], lr=base_lr, betas=(0.9, 0.999), eps=6e-8, quad_keep=self.quad_keep,
-                                              quad_dyn=self.quad_dyn, culled_alpha=CULLED_ALPHA, layout=self.packed)
+                                              quad_dyn=self.quad_dyn, culled_alpha=CULLED_ALPHA, layout=self.packed,
+                                              fused_backward=bool(getattr(self.args, "fused_adam_backward", True))
+                                              and not getattr(self.args, "finite_window_grad", False))
                 return self._window_opt
             if self.stack.is_cuda and self.is_sparse and getattr(self.args, "tile_adam", False):
                 # (the round-1 optimiser of sparsified models, kept selectable: one pass over the kept texels of the WHOLE stack, static

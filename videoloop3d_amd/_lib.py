@@ -48,7 +48,8 @@ class AdamWindow(C.Structure):
                 ("param", _P), ("exp_avg", _P), ("exp_avg_sq", _P), ("last_step", _P), ("hist", _P),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("step", C.c_int64), ("plane_boxes", _P), ("boxes_scratch", _P),
-                ("quad_keep", _P), ("quad_dyn", _P), ("QH", C.c_int32), ("QW", C.c_int32), ("class_scratch", _P)]
+                ("quad_keep", _P), ("quad_dyn", _P), ("QH", C.c_int32), ("QW", C.c_int32), ("class_scratch", _P),
+                ("blocks", _P)]
 
 
 # symbol -> argtypes; every symbol include/vl3d.h declares must be listed here (tests/test_abi.py checks).

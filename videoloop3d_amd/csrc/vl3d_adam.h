@@ -87,6 +87,9 @@ struct vl3d_adam_epilogue {
     // the owner's store) / 2 static (its gradient is stored: the step kernel sums it over the frames) / 3 outside its plane's box
     const unsigned char *quad_dyn;
     unsigned char *cls;            // NULL: dense model (every texel dynamic)
+    // PACKED storage (vl3d_adam_window_step_boxes' `blocks`): p / m / v are pools of 8 x 8-texel blocks, blocks [D][tiles_y][tiles_x] = -1 or
+    // slot << 1 | dynamic; a dynamic block owns T consecutive slots (frame-major).  NULL: the dense (D,T,Hs,Ws,4) tensors.
+    const int *blocks;
 };
 
 // (internal, vl3d_optim.hip) the tail of vl3d_render_bwd_adam: the window step from the compact gradient for what the backward did not step
@@ -98,4 +101,4 @@ __attribute__((visibility("hidden"))) int vl3d_adam_window_step_tail(int32_t D, 
                                                                      float *exp_avg_sq, int32_t *last_step, const float *hist, float lr, float beta1,
                                                                      float beta2, float eps, int64_t step, const uint8_t *quad_keep,
                                                                      const uint8_t *quad_dyn, int32_t QH, int32_t QW, const int32_t *plane_boxes,
-                                                                     const int *plan_ok, void *boxes_dev, hipStream_t stream);
+                                                                     const int32_t *blocks, const int *plan_ok, void *boxes_dev, hipStream_t stream);

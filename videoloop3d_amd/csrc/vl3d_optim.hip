@@ -338,7 +338,8 @@ extern "C" int vl3d_adam_window_step_boxes(int32_t D, int32_t T, int32_t Hs, int
 int vl3d_adam_window_step_tail(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww, float *param,
                                const float *grad_compact, float *exp_avg, float *exp_avg_sq, int32_t *last_step, const float *hist, float lr,
                                float beta1, float beta2, float eps, int64_t step, const uint8_t *quad_keep, const uint8_t *quad_dyn, int32_t QH,
-                               int32_t QW, const int32_t *plane_boxes, const int *plan_ok, void *boxes_dev, hipStream_t stream) {
+                               int32_t QW, const int32_t *plane_boxes, const int32_t *blocks, const int *plan_ok, void *boxes_dev,
+                               hipStream_t stream) {
     if (!grad_compact) {
         int rc = check_window(D, T, Hs, Ws, y0, x0, wh, ww);
         if (rc != VL3D_OK) return rc;
@@ -359,7 +360,7 @@ int vl3d_adam_window_step_tail(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int
         return VL3D_OK;
     }
     return window_step_impl(D, T, Hs, Ws, y0, x0, wh, ww, param, grad_compact, exp_avg, exp_avg_sq, last_step, hist, lr, beta1, beta2, eps, step,
-                            quad_keep, quad_dyn, QH, QW, 0, plane_boxes, nullptr, plan_ok, nullptr, stream);
+                            quad_keep, quad_dyn, QH, QW, 0, plane_boxes, blocks, plan_ok, nullptr, stream);
 }
 
 extern "C" int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t y0, int32_t x0, int32_t wh, int32_t ww,

@@ -378,6 +378,10 @@ extern "C" int vl3d_render_bwd_adam(const vl3d_render_desc *desc, const void *st
         rc = check_cull(desc, qk, adam->QH, adam->QW);
         if (rc != VL3D_OK) return rc;
         VL3D_REQUIRE(adam->class_scratch, "vl3d_render_bwd_adam: a tile-culled model needs class_scratch (D * Hs * Ws bytes)");
+    } else {
+        VL3D_REQUIRE(!adam->blocks, "vl3d_render_bwd_adam: the packed layout belongs to a tile-culled model (quad maps)");
+    }
+    if (qk) {
         VL3D_REQUIRE(desc->cull_Hs == adam->Hs && desc->cull_Ws == adam->Ws && desc->cull_row0 == adam->y0 && desc->cull_col0 == adam->x0,
                      "vl3d_render_bwd_adam: desc->cull_* must name the optimiser's window (y0, x0) of its (Hs, Ws) planes");
     }
@@ -385,7 +389,7 @@ extern "C" int vl3d_render_bwd_adam(const vl3d_render_desc *desc, const void *st
     // window / box checks and the box table on the device (the tail with a NULL gradient does exactly that)
     rc = vl3d_adam_window_step_tail(desc->D, desc->T, adam->Hs, adam->Ws, adam->y0, adam->x0, desc->Hs, desc->Ws, adam->param, nullptr,
                                     adam->exp_avg, adam->exp_avg_sq, adam->last_step, adam->hist, adam->lr, adam->beta1, adam->beta2, adam->eps,
-                                    adam->step, qk, adam->quad_dyn, adam->QH, adam->QW, adam->plane_boxes, nullptr, adam->boxes_scratch, s);
+                                    adam->step, qk, adam->quad_dyn, adam->QH, adam->QW, adam->plane_boxes, adam->blocks, nullptr, adam->boxes_scratch, s);
     if (rc != VL3D_OK) return rc;
     RenderArgs a = make_args(desc);
     if (grad_reg) set_reg_state(a, desc, reg_state);
@@ -411,12 +415,13 @@ extern "C" int vl3d_render_bwd_adam(const vl3d_render_desc *desc, const void *st
     a.ad.bc2s = (float)sqrt(bc2);
     a.ad.quad_dyn = qk ? adam->quad_dyn : nullptr;
     a.ad.cls = qk ? reinterpret_cast<unsigned char *>(adam->class_scratch) : nullptr;
+    a.ad.blocks = adam->blocks;
     rc = dispatch(true, desc, a, s);
     if (rc != VL3D_OK) return rc;
     // behind the backward, under the plan's device-side flag: nothing more (dense, feasible) / the static texels (tile-culled, feasible) / the
     // whole window from the atomics kernel's gradient (infeasible view); the tiles are marked either way
     return vl3d_adam_window_step_tail(desc->D, desc->T, adam->Hs, adam->Ws, adam->y0, adam->x0, desc->Hs, desc->Ws, adam->param, grad_stack,
                                       adam->exp_avg, adam->exp_avg_sq, adam->last_step, adam->hist, adam->lr, adam->beta1, adam->beta2, adam->eps,
-                                      adam->step, qk, adam->quad_dyn, adam->QH, adam->QW, adam->plane_boxes,
+                                      adam->step, qk, adam->quad_dyn, adam->QH, adam->QW, adam->plane_boxes, adam->blocks,
                                       reinterpret_cast<const int *>(scratch), nullptr, s);
 }

@@ -1109,16 +1109,24 @@ __device__ __forceinline__ bool adam_texel(const RenderArgs &a, int d, int cx, i
     off = (unsigned)(Y * a.ad.Ws + X) << 4;
     return true;
 }
-// ... for a caller that already knows the texel is one the optimiser steps now (the class table of a tile-culled model holds the box test)
-__device__ __forceinline__ void adam_texel_inbox(const RenderArgs &a, int d, int cx, int cy, int &from, unsigned &off) {
+// ... for a caller that already knows the texel is one the optimiser steps now (the class table of a tile-culled model holds the box test).
+// PACKED storage: the texel's byte offset inside frame 0 of its block's slots in the pool (the frames of a dynamic block are 1 KiB apart).
+__device__ __forceinline__ void adam_texel_inbox(const RenderArgs &a, int d, int cx, int cy, int &from, size_t &off) {
     const int X = a.ad.x0 + cx, Y = a.ad.y0 + cy;
-    from = a.ad.last_step[((size_t)d * a.ad.tiles_y + (Y >> 3)) * a.ad.tiles_x + (X >> 3)];
-    off = (unsigned)(Y * a.ad.Ws + X) << 4;
+    const size_t tile = ((size_t)d * a.ad.tiles_y + (Y >> 3)) * a.ad.tiles_x + (X >> 3);
+    from = a.ad.last_step[tile];
+    if (a.ad.blocks) off = ((size_t)(a.ad.blocks[tile] >> 1) * 64 + (size_t)((Y & 7) * 8 + (X & 7))) << 4;      // (a dynamic texel's block: >= 0, dynamic)
+    else off = (size_t)((unsigned)(Y * a.ad.Ws + X) << 4);
+}
+// byte offset of frame t of plane d (uniform): dense tensors / packed pools
+__device__ __forceinline__ size_t adam_frame_base(const RenderArgs &a, int d, int t) {
+    return a.ad.blocks ? (size_t)t * 1024 : ((size_t)d * a.T + t) * ((size_t)a.ad.Hs * a.ad.Ws * 16);
 }
 // One Adam step of one texel and frame with gradient g: `pcur` is the parameter current for step - 1 (the compact copy holds it: the
 // catch-up replayed the deferred steps into it, so only the two moments are replayed here -- multiplications), (p, m, v) are written.
-// fb: byte offset of the frame (uniform).
-__device__ __forceinline__ void adam_texel_step(const RenderArgs &a, size_t fb, unsigned off, int from, f4 pcur, f4 g) {
+// fb: byte offset of the frame (uniform), off: of the texel inside it.
+template <typename OFF>
+__device__ __forceinline__ void adam_texel_step(const RenderArgs &a, size_t fb, OFF off, int from, f4 pcur, f4 g) {
     char *pb = reinterpret_cast<char *>(a.ad.p) + fb, *mb = reinterpret_cast<char *>(a.ad.m) + fb, *vb = reinterpret_cast<char *>(a.ad.v) + fb;
     const f4 m0 = *reinterpret_cast<const f4 *>(mb + (size_t)off), v0 = *reinterpret_cast<const f4 *>(vb + (size_t)off);
     float4 mm = make_float4(m0.x, m0.y, m0.z, m0.w), vv = make_float4(v0.x, v0.y, v0.z, v0.w);
@@ -1197,12 +1205,15 @@ __global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, i
             return;
         }
         if (cls != 1) return;
-        if (a.ad.cls) adam_texel_inbox(a, d, x, y, from, off);
-        else if (!adam_texel(a, d, x, y, from, off)) return;
         const f4 *pc = reinterpret_cast<const f4 *>(a.stack) + (size_t)d * a.T * frame + (size_t)y * a.Ws + x;
-        const size_t fbytes = (size_t)a.ad.Hs * a.ad.Ws * 16;
-        size_t fb = (size_t)d * a.T * fbytes;
-        for (int t = 0; t < a.T; ++t, pc += frame, fb += fbytes) adam_texel_step(a, fb, off, from, *pc, f4{0.f, 0.f, 0.f, 0.f});
+        if (a.ad.cls) {
+            size_t offp;
+            adam_texel_inbox(a, d, x, y, from, offp);
+            for (int t = 0; t < a.T; ++t, pc += frame) adam_texel_step(a, adam_frame_base(a, d, t), offp, from, *pc, f4{0.f, 0.f, 0.f, 0.f});
+            return;
+        }
+        if (!adam_texel(a, d, x, y, from, off)) return;
+        for (int t = 0; t < a.T; ++t, pc += frame) adam_texel_step(a, adam_frame_base(a, d, t), off, from, *pc, f4{0.f, 0.f, 0.f, 0.f});
         return;
     }
     if (a.g_f16) {
@@ -1442,16 +1453,20 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || MASK || (CULL && COORD == VL3D_C
             }
             if constexpr (ADAM) {      // the optimiser's step instead of the gradient store (vl3d_render_bwd_adam; t = this workgroup's frame)
                 int from;
-                unsigned off;
                 if constexpr (CULL) {
                     // tile-culled model: the pre-pass's class byte -- a dynamic texel is stepped here, a static texel's gradient is stored (the step
                     // kernel sums it over the frames), culled texels and texels outside their plane's box are nobody's business
                     const unsigned c = a.ad.cls[(size_t)d * a.Hs * a.Ws + tix];
                     if (c == 2) store_grad_texel<false>(gplane, tix << 4, acc);
                     if (c != 1) return;
-                    adam_texel_inbox(a, d, X0 + wx, Y0 + wy, from, off);
-                } else if (!adam_texel(a, d, X0 + wx, Y0 + wy, from, off)) return;
-                adam_texel_step(a, ((size_t)d * a.T + t) * ((size_t)a.ad.Hs * a.ad.Ws * 16), off, from, load_texel<false>(plane, tix << 4), acc);
+                    size_t offp;
+                    adam_texel_inbox(a, d, X0 + wx, Y0 + wy, from, offp);
+                    adam_texel_step(a, adam_frame_base(a, d, t), offp, from, load_texel<false>(plane, tix << 4), acc);
+                } else {
+                    unsigned off;
+                    if (!adam_texel(a, d, X0 + wx, Y0 + wy, from, off)) return;
+                    adam_texel_step(a, adam_frame_base(a, d, t), off, from, load_texel<false>(plane, tix << 4), acc);
+                }
             } else if (!VL3D_ABLATE(a.ablate, 2)) store_grad_texel<F16>(gplane, tix << 4, acc);
             if constexpr (MASK) __builtin_nontemporal_store(accm, gmplane + tix);
         };

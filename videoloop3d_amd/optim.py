@@ -13,7 +13,7 @@ the one-pass update -- while touching only the texels the current training crop 
 
 Without a pending window (someone filled `p.grad` densely) step() falls back to the dense update: flush + full-window step.
 
-`fused_backward=True` (unpacked storage): the step is taken INSIDE the render's backward (vl3d_render_bwd_adam) -- the owner-computes kernel
+`fused_backward=True`: the step is taken INSIDE the render's backward (vl3d_render_bwd_adam) -- the owner-computes kernel
 applies the update where it would have stored a texel's gradient, so the window's gradient is never written or read back (6 streams of
 the window instead of 2 + 7).  With quad maps that holds for the DYNAMIC texels; a static texel's gradient is still stored and the step
 kernel behind the backward sums it over the frames (static texels only).  `loss.backward()` then leaves the parameters updated and `step()` only does its periodic housekeeping; the
@@ -74,8 +74,6 @@ class WindowAdam(torch.optim.Optimizer):
         self.lean_window = bool(lean_window)
         self._compact_buf = None
         self.fused_backward = bool(fused_backward)
-        if self.fused_backward and layout is not None:
-            raise RuntimeError("WindowAdam(fused_backward=True) is built for unpacked storage (the dense stack, with or without quad maps)")
         self._boxes_dev = self._class_dev = None
         self.fused_steps = 0             # steps taken inside a backward (diagnostics / tests)
 
@@ -234,6 +232,8 @@ class WindowAdam(torch.optim.Optimizer):
             aw.quad_keep, aw.QH, aw.QW = self.quad_keep.data_ptr(), self.quad_keep.shape[1], self.quad_keep.shape[2]
             aw.quad_dyn = None if self.quad_dyn is None else self.quad_dyn.data_ptr()
             aw.class_scratch = self._class_dev.data_ptr()
+            if self.layout is not None:
+                aw.blocks = self.layout.blocks.data_ptr()
         g_fallback = torch.empty_like(stack)       # written (and consumed) on the device only when the plan finds the view infeasible
         with torch.cuda.device(dev):
             nscratch = int(L.lib().vl3d_render_bwd_scratch_bytes(desc))
