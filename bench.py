@@ -177,6 +177,8 @@ def loss_bench(dev, H, W, T, Ty, steps):
 
 def main():
     a = parse()
+    # ONE JSON line on stdout: whatever the legs' own code prints (pyramid / dataset messages of the drivers) goes to stderr
+    out, sys.stdout = sys.stdout, sys.stderr
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -584,7 +586,7 @@ def main():
         head = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                 "stack_storage", "config", "roofline", "cpu_baseline", "build", "summary", "roofline_fwd", "roofline_bwd", "fwd_bwd_algorithmic_frac"]
         res = {**{k: res[k] for k in head if k in res}, **{k: v for k, v in res.items() if k not in head}}
-        print(json.dumps(res))
+        print(json.dumps(res), file=out, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -33,3 +33,14 @@ rm -f $O/*/p_kernel_trace.csv $O/*/t_kernel_trace.csv $O/*/p_agent_info.csv $O/*
 [ -f $O/trace/t_kernel_stats.csv ] && cp $O/trace/t_kernel_stats.csv $O/kernel_stats_bench.csv
 cp $O/ttrace/t_kernel_stats.csv $O/kernel_stats_target.csv
 ls $O; tail -5 $O/pmc_summary.txt; head -c 1500 $O/bench.json
+# HBM traffic of the fused backward + step on the schedule (means over the schedule's mix of levels and crops, like the kernel stats' averages)
+for leg in "sched " "schedc --sparsify"; do
+  set -- $leg
+  L=$1; shift
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$L/$c -o p -- python examples/stage2_schedule.py --epochs 1 "$@" > $O/pmc_$L.$c.log 2>&1
+    f=$O/pmc_$L/$c/p_counter_collection.csv; head -1 $f > $f.tmp; grep -E "render_|bwd_|adam_" $f >> $f.tmp; mv $f.tmp $f
+    rm -f $O/pmc_$L/$c/p_kernel_trace.csv $O/pmc_$L/$c/p_agent_info.csv
+  done
+  python profiles/summarize_pmc.py $O/pmc_$L "" > $O/pmc_summary_$L.txt
+done
