@@ -550,3 +550,45 @@ def test_tile_culled_step_fused_into_the_backward(dev, smooth, T, scale, rot, pa
         assert float((sda - sdb)[kept].abs().mean()) <= 1e-6
     else:
         assert torch.equal(sda[kept], sdb[kept])
+
+
+def test_render_bwd_adam_refuses_what_it_is_not_built_for(dev):
+    """vl3d_render_bwd_adam launches nothing for descriptors outside its scope (include/vl3d.h): other conventions / activations / fp16 stacks,
+    a dense model with one frame, a window that is not aligned to the bookkeeping tiles, quad maps without the class scratch, a packed
+    layout without quad maps -- VL3D_EUNSUPPORTED / VL3D_EINVAL with a message, parameters untouched."""
+    import ctypes as C
+    from videoloop3d_amd import _lib as L
+    from videoloop3d_amd.render import RenderSpec, _desc
+    D, T, Hs, Ws, wh, ww, H, W = 2, 2, 32, 40, 16, 24, 8, 12
+    z = lambda *sh, dt=torch.float32: torch.zeros(sh, dtype=dt, device=dev)      # noqa: E731
+    stack, homos = z(D, T, wh, ww, 4), torch.eye(3, device=dev).repeat(D, 1, 1).contiguous()
+    p, m, v = torch.ones((D, T, Hs, Ws, 4), device=dev), z(D, T, Hs, Ws, 4), z(D, T, Hs, Ws, 4)
+    last, hist = z(D, 4, 5, dt=torch.int32), z(16, 2)
+    rgb, alpha, g_rgb, g = z(T, H, W, 3), z(T, H, W), z(T, H, W, 3), z(D, T, wh, ww, 4)
+
+    def call(spec=RenderSpec.mpv(), stack=stack, y0=8, **over):
+        desc = _desc(stack, H, W, spec, 0, 0)
+        aw = L.AdamWindow()
+        aw.Hs, aw.Ws, aw.y0, aw.x0 = Hs, Ws, y0, 8
+        aw.param, aw.exp_avg, aw.exp_avg_sq, aw.last_step, aw.hist = (t.data_ptr() for t in (p, m, v, last, hist))
+        aw.lr, aw.beta1, aw.beta2, aw.eps, aw.step = 1e-3, 0.9, 0.999, 1e-8, 1
+        for k, val in over.items():
+            setattr(aw, k, val)
+        n = int(L.lib().vl3d_render_bwd_scratch_bytes(desc))
+        scratch = z((n + 3) // 4)
+        rc = L.lib().vl3d_render_bwd_adam(desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.ptr(g_rgb), None, None, None, None, L.ptr(g),
+                                          L.ptr(scratch), n, C.byref(aw), L.stream_ptr(dev))
+        return rc, (L.lib().vl3d_last_error() or b"").decode()
+    qk = torch.ones((D, 3, 4), dtype=torch.uint8, device=dev)
+    blocks = z(D, 4, 5, dt=torch.int32)
+    cases = [dict(spec=RenderSpec()), dict(spec=RenderSpec.mpv(rgb_act="none")), dict(stack=stack.half()), dict(stack=stack[:, :1].contiguous()),
+             dict(spec=RenderSpec.mpv(variant=1)), dict(y0=4), dict(quad_keep=qk.data_ptr(), QH=3, QW=4), dict(blocks=blocks.data_ptr())]
+    for kw in cases:
+        rc, msg = call(**kw)
+        assert rc != 0 and msg, (kw, rc, msg)
+    torch.cuda.synchronize()
+    assert bool((p == 1).all()) and bool((m == 0).all()) and int(last.abs().max()) == 0
+    rc, msg = call()                                  # ... and the plain call goes through (zero upstream gradient: a zero-gradient step of the window)
+    assert rc == 0, msg
+    torch.cuda.synchronize()
+    assert int(last[:, 1:3, 1:4].min()) == 1 and int(last.sum()) == D * 2 * 3
