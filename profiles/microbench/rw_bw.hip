@@ -391,6 +391,12 @@ int main(int argc, char **argv) {
                 run("backward pattern 64x16x1, Adam IN the owner store (3 read + 3 write streams)    [bytes: 6 streams]",
                     [&] { hipLaunchKernelGGL((bwd_like_adam_k<64, 16, 1>), dim3((unsigned)(tx1 * ty * T)), dim3(1024), 0, 0, src, dst, owner, D, T, Hs, Ws, tx1, ty, n); },
                     6.0 * texels * 16);
+                run("backward pattern 64x16x2, gradient STORED (1 read + 1 write stream)            [bytes: 2 streams]",
+                    [&] { hipLaunchKernelGGL((bwd_like_k<64, 16, 2, 4, true, 0, 8, 1>), dim3((unsigned)(tx1 * ty * (T / 2))), dim3(1024), 0, 0, src, dst, owner, D, T, Hs, Ws, tx1, ty); },
+                    2.0 * texels * 16);
+                run("backward pattern 64x16x2, Adam IN the owner store (3 read + 3 write streams)    [bytes: 6 streams]",
+                    [&] { hipLaunchKernelGGL((bwd_like_adam_k<64, 16, 2>), dim3((unsigned)(tx1 * ty * (T / 2))), dim3(1024), 0, 0, src, dst, owner, D, T, Hs, Ws, tx1, ty, n); },
+                    6.0 * texels * 16);
                 const int ty8 = (Hs + 5) / 6;
                 run("backward pattern 64x8x2, Adam IN the owner store (3 read + 3 write streams)     [bytes: 6 streams]",
                     [&] { hipLaunchKernelGGL((bwd_like_adam_k<64, 8, 2>), dim3((unsigned)(tx1 * ty8 * (T / 2))), dim3(512), 0, 0, src, dst, owner, D, T, Hs, Ws, tx1, ty8, n); },

@@ -797,3 +797,83 @@ def test_packed_model_exports_the_reference_layout_like_the_dense_one(dev):
             assert torch.equal(a[k].cpu(), b[k].cpu()), k
         else:
             assert a[k] == b[k], k
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_stage1_crop_aware_optimiser_equals_the_whole_stack_adam(dev, sparse):
+    """MPMesh.get_optimizer() with args.crop_aware_adam -> optim.Stage1Adam: the crop-aware engine for the plane stack (compact window leaf,
+    deferred zero-gradient updates replayed exactly) + the one-pass Adam for the loop-mask texture, against the default one pass over the
+    whole stack (tiles.TileAdam) on copies of one model over shuffled crops of shifting views: the same losses along the way, the same
+    parameters after the flush state_dict() does.  sparse: the model after sparsify_faces (train_3d.py:282-286; quad map, no loop mask) --
+    its step is taken inside the render's backward (vl3d_render_bwd_adam, T = 1), bit-identical to the window path's two kernels."""
+    from videoloop3d_amd.MPI import MPMesh
+    from videoloop3d_amd.optim import Stage1Adam
+    H, W, h, w = 66, 80, 30, 40            # (planes 85 x 104: TileAdam walks the loop-mask texture in 16-byte groups)
+    K, ref_extrin, tar = scene(H, W)
+    variants = [dict(), dict(crop_aware_adam=True), dict(crop_aware_adam=True, fused_adam_backward=False)]
+    torch.manual_seed(3)
+    proto = MPMesh(make_args_mpi(mpi_h_verts=7, mpi_w_verts=9, optimizer="adam", lrate=0.02, lrate_decay=100), H, W, ref_extrin, K, 1.0, 100.0).to(dev)
+    with torch.no_grad():
+        D_, _, Hs_, Ws_, _ = proto.stack.shape
+        st = synth.make_plane_stack(D_, 1, Hs_, Ws_, seed=5) * 0.7
+        yy, xx = torch.meshgrid(torch.arange(Hs_).float(), torch.arange(Ws_).float(), indexing="ij")
+        for d in range(D_):          # an alpha blob per plane: part of every plane is culled by sparsify_faces, plane 5 entirely
+            blob = 6.0 * torch.exp(-(((yy - Hs_ * (0.3 + 0.1 * d)) / 16) ** 2 + ((xx - Ws_ * (0.2 + 0.12 * d)) / 22) ** 2)) - 4.5
+            st[d, 0, :, :, 3] = blob if d < 5 else -8.0
+        proto.stack.copy_(st.to(dev))
+        proto.stack_mask.copy_((synth.hash_uniform(tuple(proto.stack_mask.shape), seed=6) * 3 - 2).to(dev))
+    if sparse:
+        proto.sparsify_faces(erode_num=1, alpha_thresh=0.05)
+        assert 0.1 < float(proto.quad_keep.float().mean()) < 0.9 and not bool(proto.quad_keep[5].any())
+    sd = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in proto.state_dict().items()}
+    models = []
+    for kw in variants:
+        m = MPMesh(make_args_mpi(mpi_h_verts=7, mpi_w_verts=9, optimizer="adam", lrate=0.02, lrate_decay=100, **kw), H, W, ref_extrin, K, 1.0, 100.0).to(dev)
+        m.init_from_mpi(sd)
+        m.train()
+        models.append((m, m.get_optimizer()))
+    assert type(models[0][1]).__name__ == "TileAdam" and isinstance(models[1][1], Stage1Adam) and isinstance(models[2][1], Stage1Adam)
+    assert models[1][1].window.fused_backward and not models[2][1].window.fused_backward
+    wts = {"sparsity": 0.004, "rgb_smooth": 0.2, "a_smooth": 0.5, "density": 0.02}
+    offs = [(0, 0), (30, 35), (10, 20), (36, 40), (0, 40), (36, 0), (18, 25), (0, 0), (36, 40)]
+    for it, (oy, ox) in enumerate(offs):
+        Kc = K.copy()
+        Kc[0, 2] -= ox
+        Kc[1, 2] -= oy
+        te = tar.copy()
+        te[:3, 3] += [0.01 * (it % 3), -0.005 * (it % 2), 0.0]
+        g = (synth.hash_uniform((1, 3 if sparse else 4, h, w), seed=40 + it) - 0.5).to(dev)
+        losses = []
+        for m, opt in models:
+            for grp in opt.param_groups:
+                grp["lr"] = 0.02 * 0.9 ** it
+            opt.zero_grad()
+            rgbl, extra = m(h, w, torch.tensor(te)[None], torch.tensor(Kc)[None])       # poses on the host, as the DataLoader yields them
+            loss = (rgbl * g).sum() + sum(extra[k].sum() * wts[k] for k in wts) * 20
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        for l in losses[1:]:
+            assert abs(l - losses[0]) <= 2e-5 * max(1.0, abs(losses[0])), (it, losses)
+        if sparse:       # fused and two-kernel window paths: the same bits, every iteration
+            assert losses[1] == losses[2]
+            assert torch.equal(models[1][0].stack.data, models[2][0].stack.data), it
+    if sparse:
+        assert models[1][1].window.fused_steps == len(offs) and models[2][1].window.fused_steps == 0
+    assert float((models[1][0].stack.detach() - models[0][0].stack.detach()).abs().max()) > 1e-4          # updates really are deferred ...
+    sds = [m.state_dict() for m, _ in models]                                                              # ... until the flush
+    keep = slice(None)
+    if sparse:
+        from videoloop3d_amd import tiles
+        keep = tiles.quad_to_texel_mask(proto.quad_keep.cpu(), *proto.stack.shape[2:4]).to(dev)[:, None, :, :, None].expand_as(proto.stack)
+    for sd_b in sds[1:]:
+        diff = (sds[0]["stack"] - sd_b["stack"])[keep].abs()
+        assert float((diff > 2e-5).float().mean()) <= 1e-3 and float(diff.max()) <= 2e-3 and float(diff.mean()) <= 1e-6
+        if not sparse:
+            assert float((sds[0]["stack_mask"] - sd_b["stack_mask"]).abs().max()) <= 2e-5
+    # evaluation renders read the whole (current) stack
+    for m, _ in models:
+        m.eval()
+    with torch.no_grad():
+        imgs = [m(H, W, torch.tensor(tar)[None].to(dev), torch.tensor(K)[None].to(dev))[0] for m, _ in models]
+    assert float((imgs[0] - imgs[1]).abs().max()) <= 2e-4

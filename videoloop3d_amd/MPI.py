@@ -97,6 +97,21 @@ class MPMesh(nn.Module):
         self.quad_h, self.quad_w = max(int(getattr(args, "mpi_h_verts", 12)) - 1, 1), max(int(getattr(args, "mpi_w_verts", 15)) - 1, 1)
         self.is_sparse = False
         self.has_dyn = False
+        self._window_opt = None          # the crop-aware optimiser handed out by get_optimizer (optim.Stage1Adam): training renders go through its window
+
+    def _flush_deferred_updates(self):
+        """bring the whole stack up to date with the optimiser handed out last (optim.WindowAdam defers the zero-gradient updates of texels
+        outside the training crops' windows): before anything reads the stack as a whole."""
+        if self._window_opt is not None:
+            self._window_opt.flush()
+
+    def _apply(self, fn, *a, **k):
+        self._flush_deferred_updates()
+        dev = self.stack.device
+        out = super()._apply(fn, *a, **k)
+        if self.stack.device != dev:
+            self._window_opt = None      # optimiser state lives on the old device: the driver asks for a new one
+        return out
 
     @torch.no_grad()
     def sparsify_faces(self, erode_num=2, alpha_thresh=0.03, loop_thresh=0.5):
@@ -104,6 +119,8 @@ class MPMesh(nn.Module):
         exceeds `alpha_thresh` are culled, kept quads whose (eroded, dilated) loop mask exceeds `loop_thresh` are dynamic, the
         rest static.  Registers `quad_keep`, `quad_dyn` [D,QH,QW] and writes the culling into the alpha logits."""
         print("Sparsifying the faces")
+        self._flush_deferred_updates()
+        self._window_opt = None          # (train_3d.py:284-286 asks for a new optimiser after this call)
         a_logit = self.stack[:, 0, :, :, 3].detach().clone()
         a_logit[a_logit == ALPHA_INIT_VAL] = -10                                                  # MPI.py:318
         alpha = self.alpha_activate(a_logit)
@@ -137,6 +154,7 @@ class MPMesh(nn.Module):
 
     def state_dict(self, *args, **kwargs):
         """MPI.py-style: the tensors plus python scalars under "self.*" keys (consumed by MPMeshVid.init_from_mpi)."""
+        self._flush_deferred_updates()
         sd = super().state_dict(*args, **kwargs)
         sd["self.is_sparse"] = self.is_sparse
         sd["self.quad_h"], sd["self.quad_w"] = self.quad_h, self.quad_w
@@ -149,7 +167,25 @@ class MPMesh(nn.Module):
         """MPI.py:122-141 (the planar path has no vertex parameters: one parameter group)."""
         a = self.args
         params = [{'params': [p for _, p in self.named_parameters()]}]
+        self._flush_deferred_updates()      # the optimiser handed out before may still hold deferred updates: they belong to the stack
+        self._window_opt = None
         if a.optimizer == 'adam':
+            if self.stack.is_cuda and not getattr(a, "torch_adam", False) and not self.atlas_exact and getattr(a, "crop_aware_adam", False):
+                # OPT-IN (args.crop_aware_adam): torch.optim.Adam's parameters through the crop-aware engine for the plane stack (a stage-1
+                # iteration renders ONE crop of one view, train_3d.py:20-95: the render reads a compact copy of the crop's texel window, the step
+                # touches the window only, the zero-gradient updates of the rest are deferred and replayed exactly -- optim.WindowAdam, as in
+                # stage 2; a sparsified model, train_3d.py:282-286, takes its step inside the render's backward) and the one-pass Adam for the
+                # loop-mask texture.  Measured in round 4 (examples/stage1_step.py, D = 32, 576 x 1024 planes, 180 x 320 crops): 635 it/s against
+                # 766 with the one pass over the whole stack below -- the optimiser's GPU time halves (0.38 -> 0.2 ms) but a stage-1 iteration is
+                # bound by its ~70 launches and the host work of the window (1.3 ms), which this path lengthens.  Hence not the default.
+                from .optim import Stage1Adam
+                from .tiles import CULLED_ALPHA
+                others = [p for _, p in self.named_parameters() if p is not self.stack]
+                qk = self.quad_keep if (self.is_sparse and getattr(self, "quad_keep", None) is not None) else None
+                fused = bool(getattr(a, "fused_adam_backward", True)) and not getattr(a, "finite_window_grad", False)
+                self._window_opt = Stage1Adam(self.stack, others, lr=a.lrate, betas=(0.9, 0.999), eps=1e-8, quad_keep=qk,
+                                              culled_alpha=CULLED_ALPHA, fused_backward=fused)
+                return self._window_opt
             # torch.optim.Adam's update in one pass per parameter (tiles.TileAdam without a quad map; getattr(args, 'torch_adam') keeps torch's)
             if self.stack.is_cuda and not getattr(a, "torch_adam", False):
                 return tiles.TileAdam(params, lr=a.lrate, betas=(0.9, 0.999), eps=1e-8)
@@ -173,6 +209,7 @@ class MPMesh(nn.Module):
         """MPI.py:174-205 (resume / warm start, train_3d.py:176-186): a state_dict of this class, or of the REFERENCE's MPMesh (plane
         meshes + packed atlas: resampled onto the dense stack, quad maps recovered from its face lists; the loop-mask texture of a
         reference checkpoint is not carried -- the reference drops it at sparsify time, MPI.py:440-441)."""
+        self._window_opt = None          # (the parameters are replaced: the driver asks for a new optimiser)
         if "stack" not in state_dict and "atlas" in state_dict:
             hv, wv = int(self.args.mpi_h_verts), int(self.args.mpi_w_verts)
             st, keep, dyn = tiles.stack_from_reference_state(state_dict, self.mpi_h, self.mpi_w, hv, wv, 1)
@@ -214,6 +251,7 @@ class MPMesh(nn.Module):
     def reference_state_dict(self):
         """the state_dict of the REFERENCE's MPMesh for these weights (MPI.py:207-221): plane mesh + packed atlas tiles."""
         from .export import reference_state_dict
+        self._flush_deferred_updates()
         return reference_state_dict(self)
 
     def save_mesh(self, prefix):
@@ -291,8 +329,29 @@ class MPMesh(nn.Module):
             with torch.no_grad():          # channel 0: mask logit, channel 3: the layer alpha logit (detached, MPI.py:572)
                 self._mask_buf[..., 0].copy_(self.stack_mask)
                 self._mask_buf[..., 3].copy_(self.stack[..., 3])
+        # crop-aware training (optim.Stage1Adam handed out by get_optimizer): ONE view per iteration (the reference's DataLoader(dataset, 1)),
+        # rendered from a compact, up-to-date copy of the texel window the crop can reach; every other case reads the whole (flushed) stack
+        windowed = (self._window_opt is not None and self.training and torch.is_grad_enabled() and B == 1 and not need_layers and not self.atlas_exact
+                    and (fused_mask or not self.learn_loop_mask))
+        if self._window_opt is not None and not windowed:
+            self._flush_deferred_updates()
         for b in range(B):
             homos = self.plane_homographies(extrin[b:b + 1], intrin[b:b + 1])
+            stack, mask, spec, cull_window, fused_adam, lean = self.stack, (self.stack_mask if self.learn_loop_mask else None), self.spec, None, None, False
+            if windowed:
+                from .optim import crop_window
+                Hs_, Ws_ = self.stack.shape[2:4]
+                (y0, x0, wh, ww), boxes = crop_window(self.spec, Hs_, Ws_, homos.detach().cpu(), H, W, per_plane=True)
+                if wh > 0 and ww > 0:
+                    stack = self._window_opt.window_leaf((y0, x0, wh, ww), boxes)
+                    spec = dataclasses.replace(spec, offset=(spec.offset[0] - x0, spec.offset[1] - y0))
+                    cull_window = (y0, x0, Hs_, Ws_)
+                    if mask is not None:
+                        mask = mask[:, :, y0:y0 + wh, x0:x0 + ww].contiguous()
+                    fused_adam = self._window_opt.window if self._window_opt.window.fused_backward else None
+                    lean = not getattr(self.args, "finite_window_grad", False)
+                else:
+                    self._flush_deferred_updates()
             if homos.device.type == "cpu" and self.stack.is_cuda:
                 # host homographies (a few hundred bytes): through a pinned staging buffer and an asynchronous copy -- a pageable upload blocks
                 # the host until everything queued before it has run (1.7 of the 2.9 ms of a 720p stage-1 iteration, profiles/host_profile_stage1.py)
@@ -309,17 +368,19 @@ class MPMesh(nn.Module):
                     lab_stack = torch.stack([self.stack_mask, z, z, self.stack[..., 3].detach()], -1)
                     labels.append(render_atlas_exact(lab_stack, homos, H, W, gh, pixel_center=self.spec.pixel_center)[0][..., :1])
             elif fused_mask:
-                rgb, alpha, label, ss, asum = render_planes_with_mask(self.stack, self.stack_mask, homos, H, W, self.spec, with_regularisers=need_reg)
+                rgb, alpha, label, ss, asum = render_planes_with_mask(stack, mask, homos, H, W, spec, with_regularisers=need_reg)
                 labels.append(label[..., None])
                 if need_reg:
                     ssums.append(ss)
                     asums.append(asum)
             elif need_reg:
-                rgb, alpha, ss, asum = render_planes_with_regularisers(self.stack, homos, H, W, self.spec, quad_keep=qk)
+                rgb, alpha, ss, asum = render_planes_with_regularisers(stack, homos, H, W, spec, quad_keep=qk, cull_window=cull_window if qk is not None else None,
+                                                                       grad_culled_unwritten=lean and qk is not None, fused_adam=fused_adam)
                 ssums.append(ss)
                 asums.append(asum)
             else:
-                rgb, alpha = render_planes(self.stack, homos, H, W, self.spec, quad_keep=qk)
+                rgb, alpha = render_planes(stack, homos, H, W, spec, quad_keep=qk, cull_window=cull_window if qk is not None else None,
+                                           grad_culled_unwritten=lean and qk is not None, fused_adam=fused_adam)
             if len(self.args.bg_color) > 0:                                                       # MPI.py:550-556
                 if self.args.bg_color == "random":
                     bg = torch.rand(3).type_as(rgb)

@@ -469,31 +469,9 @@ class MPMeshVid(nn.Module):
         plus the +1 bilinear tap and a margin.  homos [D,3,3] on the HOST (float64).
         per_plane: also return the planes' own boxes [D,4] = (y0, y1, x0, x1) (same rule per plane; the window is their union), or None
         when a plane has the view behind it."""
-        from .optim import align_window, tile_side
-        c = float(self.spec.pixel_center)
-        pts = torch.tensor([[c, W - 1 + c, c, W - 1 + c], [c, c, H - 1 + c, H - 1 + c], [1.0, 1.0, 1.0, 1.0]], dtype=torch.float64)
-        q = homos.double() @ pts                                                                  # D,3,4
+        from .optim import crop_window
         Hs, Ws = self.stack_dims()[2:4]
-        if bool((q[:, 2] <= 1e-9).any()):
-            return ((0, 0, Hs, Ws), None) if per_plane else (0, 0, Hs, Ws)
-        tx = q[:, 0] / q[:, 2] * self.spec.scale[0] + self.spec.offset[0]
-        ty = q[:, 1] / q[:, 2] * self.spec.scale[1] + self.spec.offset[1]
-        win = align_window(int(torch.floor(ty.min())) - margin, int(torch.ceil(ty.max())) + 2 + margin,
-                           int(torch.floor(tx.min())) - margin, int(torch.ceil(tx.max())) + 2 + margin, Hs, Ws)
-        if not per_plane:
-            return win
-        # the planes' boxes by the same rule, vectorised (align_window per plane).  numpy, not torch: a dozen tiny torch CPU ops cost 2 ms
-        # per call on a 256-core host (thread-pool wake-ups) and starve the launch thread -- the iteration fell from 168 to 30 it/s
-        ts = tile_side()
-        tyn, txn = ty.numpy(), tx.numpy()
-        ylo = np.maximum(np.floor(tyn.min(1)).astype(np.int64) - margin, 0) // ts * ts
-        xlo = np.maximum(np.floor(txn.min(1)).astype(np.int64) - margin, 0) // ts * ts
-        yhi = np.minimum(np.ceil(tyn.max(1)).astype(np.int64) + 2 + margin, Hs)
-        xhi = np.minimum(np.ceil(txn.max(1)).astype(np.int64) + 2 + margin, Ws)
-        yhi = np.minimum(-(-yhi // ts) * ts, Hs)
-        xhi = np.minimum(-(-xhi // ts) * ts, Ws)
-        boxes = np.stack([ylo, np.maximum(yhi, ylo), xlo, np.maximum(xhi, xlo)], axis=1).astype(np.int32)
-        return win, boxes
+        return crop_window(self.spec, Hs, Ws, homos, H, W, margin=margin, per_plane=per_plane)
 
     # ---- export to the reference's layout (MPV.py:290-341) ------------------------------------------------------------------
     def reference_state_dict(self):

@@ -40,6 +40,38 @@ def align_window(y0, y1, x0, x1, Hs, Ws):
     return y0, x0, max(y1 - y0, 0), max(x1 - x0, 0)
 
 
+def crop_window(spec, Hs, Ws, homos, H, W, margin=3, per_plane=False):
+    """texel window (y0, x0, wh, ww), aligned to the optimiser's bookkeeping tiles, that contains every tap of every pixel of the
+    H x W view on every plane of an Hs x Ws stack rendered under `spec`: the image of the view's corners under the plane homographies
+    (convex: extremes at the corners), plus the +1 bilinear tap and a margin.  homos [D,3,3] on the HOST (float64).
+    per_plane: also return the planes' own boxes [D,4] = (y0, y1, x0, x1) (same rule per plane; the window is their union), or None
+    when a plane has the view behind it."""
+    import numpy as np
+    c = float(spec.pixel_center)
+    pts = torch.tensor([[c, W - 1 + c, c, W - 1 + c], [c, c, H - 1 + c, H - 1 + c], [1.0, 1.0, 1.0, 1.0]], dtype=torch.float64)
+    q = homos.double() @ pts                                                                  # D,3,4
+    if bool((q[:, 2] <= 1e-9).any()):
+        return ((0, 0, Hs, Ws), None) if per_plane else (0, 0, Hs, Ws)
+    tx = q[:, 0] / q[:, 2] * spec.scale[0] + spec.offset[0]
+    ty = q[:, 1] / q[:, 2] * spec.scale[1] + spec.offset[1]
+    win = align_window(int(torch.floor(ty.min())) - margin, int(torch.ceil(ty.max())) + 2 + margin,
+                       int(torch.floor(tx.min())) - margin, int(torch.ceil(tx.max())) + 2 + margin, Hs, Ws)
+    if not per_plane:
+        return win
+    # the planes' boxes by the same rule, vectorised (align_window per plane).  numpy, not torch: a dozen tiny torch CPU ops cost 2 ms
+    # per call on a 256-core host (thread-pool wake-ups) and starve the launch thread -- the iteration fell from 168 to 30 it/s
+    ts = tile_side()
+    tyn, txn = ty.numpy(), tx.numpy()
+    ylo = np.maximum(np.floor(tyn.min(1)).astype(np.int64) - margin, 0) // ts * ts
+    xlo = np.maximum(np.floor(txn.min(1)).astype(np.int64) - margin, 0) // ts * ts
+    yhi = np.minimum(np.ceil(tyn.max(1)).astype(np.int64) + 2 + margin, Hs)
+    xhi = np.minimum(np.ceil(txn.max(1)).astype(np.int64) + 2 + margin, Ws)
+    yhi = np.minimum(-(-yhi // ts) * ts, Hs)
+    xhi = np.minimum(-(-xhi // ts) * ts, Ws)
+    boxes = np.stack([ylo, np.maximum(yhi, ylo), xlo, np.maximum(xhi, xlo)], axis=1).astype(np.int32)
+    return win, boxes
+
+
 class WindowAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, quad_keep=None, quad_dyn=None, culled_alpha=-1e4, max_defer=32, layout=None,
                  lean_window=True, fused_backward=False):
@@ -322,3 +354,56 @@ class WindowAdam(torch.optim.Optimizer):
         self.t = t
         self._bound_deferral(st, t)
         return loss
+
+
+class Stage1Adam:
+    """The optimiser `MPMesh.get_optimizer()` hands to train_3d.py (:159, 284-301): torch.optim.Adam over all parameters in ONE group
+    (MPI.py:122-141: the planar path has no vertex group), as two engines -- the crop-aware `WindowAdam` for the plane stack (a stage-1
+    iteration renders one 180 x 320 crop of one view, train_3d.py:20-95: about a third of every plane), `tiles.TileAdam` (one pass per
+    parameter) for whatever else the model trains (the loop-mask texture).  The driver sees `param_groups[0]` (learning rate set per
+    iteration, train_3d.py:303-310), zero_grad(), step(), state_dict()."""
+
+    def __init__(self, stack_param, other_params, lr, betas=(0.9, 0.999), eps=1e-8, quad_keep=None, culled_alpha=-1e4, fused_backward=True):
+        from .tiles import TileAdam
+        self.window = WindowAdam([stack_param], lr=lr, betas=betas, eps=eps, quad_keep=quad_keep, culled_alpha=culled_alpha,
+                                 fused_backward=fused_backward)
+        other_params = list(other_params)
+        self.other = TileAdam([{'params': other_params}], lr=lr, betas=betas, eps=eps) if other_params else None
+        self.param_groups = [dict(params=[stack_param] + other_params, lr=lr, betas=betas, eps=eps)]
+
+    def _engines(self):
+        return [self.window] + ([self.other] if self.other is not None else [])
+
+    def sync(self):
+        """the driver's learning rate into both engines (called before the forward: a fused backward reads it there)."""
+        for o in self._engines():
+            for g in o.param_groups:
+                g["lr"] = self.param_groups[0]["lr"]
+
+    def window_leaf(self, window, plane_boxes=None):
+        self.sync()
+        return self.window.window_leaf(window, plane_boxes)
+
+    def flush(self):
+        self.window.flush()
+
+    def zero_grad(self, set_to_none=True):
+        for o in self._engines():
+            o.zero_grad(set_to_none)
+
+    def step(self, closure=None):
+        self.sync()
+        loss = self.window.step(closure)
+        if self.other is not None:
+            self.other.step()
+        return loss
+
+    def state_dict(self):
+        return {"window": self.window.state_dict(), "other": None if self.other is None else self.other.state_dict(),
+                "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+
+    def load_state_dict(self, sd):
+        self.window.load_state_dict(sd["window"])
+        if self.other is not None and sd.get("other") is not None:
+            self.other.load_state_dict(sd["other"])
+        self.param_groups[0].update(sd["param_groups"][0])
