@@ -107,7 +107,7 @@ __global__ __launch_bounds__(RX *RY) void bwd_like_k(const f4 *__restrict__ src,
 // does not store its gradient texel -- it READS the two moments of its texel (m, v: two more streams at the tile's ragged segments; p comes
 // with the taps) and WRITES p, m, v (three streams instead of one).  Compared below with what it replaces: the shipped pattern's one
 // gradient store plus a separate streaming step kernel over whole rows (4 reads p, g, m, v; 3 writes p, m, v).
-template <int RX, int RY, int FR>
+template <int RX, int RY, int FR, bool NT = true>
 __global__ __launch_bounds__(RX *RY) void bwd_like_adam_k(const f4 *__restrict__ src, f4 *__restrict__ dst, const unsigned short *__restrict__ owner, int D,
                                                           int T, int Hs, int Ws, int tiles_x, int tiles_y, size_t unit) {
     const int b = blockIdx.x;
@@ -132,9 +132,15 @@ __global__ __launch_bounds__(RX *RY) void bwd_like_adam_k(const f4 *__restrict__
             for (int f = 0; f < FR; ++f) {
                 const size_t i = o + f * frame;
                 const f4 g = v[f] + acc, m = src[unit + i] * 0.9f + g * 0.1f, vv = src[2 * unit + i] * 0.999f + g * g * 0.001f;
-                __builtin_nontemporal_store(v[f] - m * 0.01f, &dst[i]);
-                __builtin_nontemporal_store(m, &dst[unit + i]);
-                __builtin_nontemporal_store(vv, &dst[2 * unit + i]);
+                if constexpr (NT) {
+                    __builtin_nontemporal_store(v[f] - m * 0.01f, &dst[i]);
+                    __builtin_nontemporal_store(m, &dst[unit + i]);
+                    __builtin_nontemporal_store(vv, &dst[2 * unit + i]);
+                } else {      // plain write-back stores: the L2 may merge the partial lines of horizontally adjacent tiles
+                    dst[i] = v[f] - m * 0.01f;
+                    dst[unit + i] = m;
+                    dst[2 * unit + i] = vv;
+                }
             }
         }
         acc.x += (float)e;
@@ -386,6 +392,9 @@ int main(int argc, char **argv) {
                     2.0 * texels * 16);
                 run("backward pattern 32x16x2, Adam IN the owner store (3 read + 3 write streams)    [bytes: 6 streams]",
                     [&] { hipLaunchKernelGGL((bwd_like_adam_k<32, 16, 2>), dim3((unsigned)(tx * ty * (T / 2))), dim3(512), 0, 0, src, dst, owner, D, T, Hs, Ws, tx, ty, n); },
+                    6.0 * texels * 16);
+                run("backward pattern 32x16x2, Adam IN the owner store, PLAIN (write-back) stores       [bytes: 6 streams]",
+                    [&] { hipLaunchKernelGGL((bwd_like_adam_k<32, 16, 2, false>), dim3((unsigned)(tx * ty * (T / 2))), dim3(512), 0, 0, src, dst, owner, D, T, Hs, Ws, tx, ty, n); },
                     6.0 * texels * 16);
                 const int tx1 = (Ws + 61) / 62;
                 run("backward pattern 64x16x1, Adam IN the owner store (3 read + 3 write streams)    [bytes: 6 streams]",

@@ -1514,22 +1514,26 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || MASK || (CULL && COORD == VL3D_C
 // (profiles/ab_inproc.py): the memory pattern alone prefers 1-KiB row segments (profiles/microbench/rw_bw.hip `bwd_like`: 4.51 vs
 // 4.18 TB/s of algorithmic bytes), but its halo (x1.38 instead of x1.22 pixels swept per pixel owned) costs more than that:
 // 12.58 vs 11.96 ms.  An L2 prefetch of the next plane's tap rows in front of the barrier (4-byte LDS-DMA loads): +0.5 ms.
-constexpr int PNT = 512, PW = 32, PROWS = 16;
+constexpr int PROWS = 16;      // region rows.  The region width PW is a template parameter (PW * 16 threads): 32 is shipped; 64 -- 992-byte owner
+// segments, x1.18 instead of x1.22 pixels swept per pixel owned, but ONE 1024-thread workgroup per CU (80 KB LDS, <= 128 VGPRs) -- was built and
+// measured in round 4 (same bits): cfg3 13.3 against 12.6-12.9 ms, reference geometry 16.3 against 15.9, fused schedule 201 against 214 it/s:
+// with a single workgroup per CU nothing runs while its 16 waves meet at the per-plane barrier.  Not instantiated.
 
 // gather of one plane for a frame pair: every texel of the tile's window that the owner table assigns to this tile sums its taps
 // from the 3 x 3 (or, where pixels are >= 1 texel apart, 2 x 2) staged pixels around its owner pixel -- one set of weights, two
 // accumulators, two stores.  sg0 / sg1: staged gradients of frames t and t+1, st: staged texel coordinates (this plane's buffers).
 // ADAM: the owner applies the optimiser's step where it would have stored the gradient (vl3d_render_bwd_adam): (d, t0) = the plane and the
 // pair's first frame.
-template <int ORDER, int RACT, int AACT, bool F16, bool ADAM = false>
+template <int ORDER, int RACT, int AACT, bool F16, bool ADAM = false, int PW = 32>
 __device__ __forceinline__ void pair_gather_plane(const RenderArgs &a, const float4 *sg0, const float4 *sg1, const float2 *st, int X0, int Y0,
                                                   int ww, int wh, bool apart, unsigned my_tile, unsigned e0, const unsigned short *oplane,
                                                   const char *plane0, char *gplane0, size_t f1, size_t frame_b, bool has1, int col, int row,
                                                   int d = 0, int t0 = 0) {
     const unsigned win0 = (unsigned)(Y0 * a.Ws + X0);
     auto gather = [&](unsigned e, int wx, int wy, unsigned tix) {
-        if ((e >> 9) != my_tile) return;
-        const int lc = (int)(e & 511u);
+        constexpr int SLOT_BITS = PW == 64 ? 10 : 9;      // PW * 16 slots of the region (bwd_owner_table_k)
+        if ((e >> SLOT_BITS) != my_tile) return;
+        const int lc = (int)(e & ((1u << SLOT_BITS) - 1u));
         const f2 tau = f2{(float)(X0 + wx), (float)(Y0 + wy)};
         f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
         if (apart) {
@@ -1619,12 +1623,14 @@ __device__ __forceinline__ void pair_gather_plane(const RenderArgs &a, const flo
 // sparsity-sum gradient is gN1 + gN2 a_k.  Until round 3 this was a kernel of its own (render_bwd_pair_reg_k: 2-pixel halo, the
 // neighbours' layer values through a second LDS stage, sampling pipelined one plane ahead, 128 VGPRs, 18.2 ms at cfg3 against 12.0
 // without the regularisers -- VALU bound on re-deriving signs the forward had already formed).
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool REG = false, bool ADAM = false>
-__global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {      // >= 4 waves per SIMD (2 workgroups per CU): <= 128 VGPRs
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool REG = false, bool ADAM = false, int PW = 32>
+__global__ __launch_bounds__(PW * PROWS, 4) void render_bwd_pair_k(RenderArgs a) {      // >= 4 waves per SIMD (2 workgroups per CU at PW = 32): <= 128 VGPRs
+    static_assert(PW == 32 || PW == 64, "region width");
+    constexpr int PNT = PW * PROWS;
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
     __shared__ float4 s_g[2][2][PNT];   // [buffer][frame][pixel]
     __shared__ float2 s_t[2][PNT];
-    const int tid = threadIdx.x, col = tid & (PW - 1), row = tid >> 5;
+    const int tid = threadIdx.x, col = tid & (PW - 1), row = tid / PW;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_x = bid % a.tiles_x, rest = bid / a.tiles_x;
     const int tile_y = rest % a.tiles_y, t0 = (rest / a.tiles_y) * 2;
@@ -1676,7 +1682,8 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
     float Tr0 = 1.0f, P0 = 0.0f, Tr1 = 1.0f, P1 = 0.0f;
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
     const unsigned my_tile_id = (unsigned)(tile_y * a.tiles_x + tile_x);
-    const unsigned my_tile = (unsigned)((tile_y & 15) << 3 | (tile_x & 7));     // 9-bit slots: 4 + 3 bits of tile code (bwd_owner_table_k)
+    // 9-bit slots (PW = 32): 4 + 3 bits of tile code; 10-bit slots (PW = 64): 3 + 3 (bwd_owner_table_k)
+    const unsigned my_tile = (unsigned)((tile_y & (PW == 64 ? 7 : 15)) << 3 | (tile_x & 7));
     const unsigned toff_thread = (unsigned)(row * a.Ws + col);
     const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)my_tile_id * a.D * 4;
     typedef typename TapVal<F16, ORDER>::type tapv_t;
@@ -1736,14 +1743,14 @@ __global__ __launch_bounds__(PNT, 4) void render_bwd_pair_k(RenderArgs a) {     
         s_g[buf][1][tid] = gv1;
         __syncthreads();
         // (3) gather: one set of weights, two accumulators
-        pair_gather_plane<ORDER, RACT, AACT, F16, ADAM>(a, s_g[buf][0], s_g[buf][1], s_t[buf], X0, Y0, ww, wh, apart, my_tile, e0, oplane, plane0,
+        pair_gather_plane<ORDER, RACT, AACT, F16, ADAM, PW>(a, s_g[buf][0], s_g[buf][1], s_t[buf], X0, Y0, ww, wh, apart, my_tile, e0, oplane, plane0,
                                                         gplane0, f1, frame_b, has1, col, row, d, t0);
     }
 }
 
 #undef VL3D_PAIR_GRAD
 
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool REG = false, bool ADAM = false>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool REG = false, bool ADAM = false, int PW = 32>
 void launch_pair(const RenderArgs &a, hipStream_t s) {
     constexpr int RH = 1, IW = PW - 2 * RH, IH = PROWS - 2 * RH;
     RenderArgs b = a;
@@ -1752,9 +1759,9 @@ void launch_pair(const RenderArgs &a, hipStream_t s) {
     hipLaunchKernelGGL((bwd_windows_k<COORD>), dim3((nwin + 255) / 256), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x, b.tiles_y,
                        reinterpret_cast<int *>(const_cast<float *>(a.plan)) + plan_win_off(a.D));
     hipLaunchKernelGGL(bwd_owner_table_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x,
-                       const_cast<unsigned short *>(a.owner), PW, 9);
-    hipLaunchKernelGGL((render_bwd_pair_k<COORD, BORDER, ORDER, RACT, AACT, F16, REG, ADAM>),
-                       dim3((unsigned)(b.tiles_x * b.tiles_y * ((a.T + 1) / 2))), dim3(PNT), 0, s, b);
+                       const_cast<unsigned short *>(a.owner), PW, PW == 64 ? 10 : 9);
+    hipLaunchKernelGGL((render_bwd_pair_k<COORD, BORDER, ORDER, RACT, AACT, F16, REG, ADAM, PW>),
+                       dim3((unsigned)(b.tiles_x * b.tiles_y * ((a.T + 1) / 2))), dim3(PW * PROWS), 0, s, b);
 }
 
 // =====================================================================================================
