@@ -394,12 +394,13 @@ class MPMesh(nn.Module):
                 lay.append(self._layer_variables(homos, H, W, extrin[b], qk))
             if self.learn_loop_mask and not fused_mask and not self.atlas_exact:                  # MPI.py:568-583
                 labels.append(_LoopMaskLabel.apply(self.stack_mask, self.stack, self._mask_buf, homos, H, W, self.spec_mask))
-        rgb = torch.cat(rgbs, 0)
-        rgbl = torch.cat([rgb, torch.cat(labels, 0)], dim=-1) if self.learn_loop_mask else rgb
+        cat0 = lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts, 0)      # noqa: E731  (B = 1, the reference's DataLoader(dataset, 1): no copy, no launch)
+        rgb = cat0(rgbs)
+        rgbl = torch.cat([rgb, cat0(labels)], dim=-1) if self.learn_loop_mask else rgb
         variables = {"pix_to_face": None, "blend_weight": None, "mpi": None, "loopmask3d": None, "disp_norm": None,
-                     "alpha": torch.cat(alphas, 0),
-                     "smooth_sums": torch.stack(ssums).sum(0) if ssums else None,
-                     "alpha_sums": torch.cat(asums, 0) if asums else None}
+                     "alpha": cat0(alphas),
+                     "smooth_sums": (ssums[0] if len(ssums) == 1 else torch.stack(ssums).sum(0)) if ssums else None,
+                     "alpha_sums": cat0(asums) if asums else None}
         if lay:
             # the B views are rasterised in one call by the reference: K = the deepest pixel of the batch
             kmax = max(m[0].shape[3] for m in lay)
@@ -441,10 +442,26 @@ class MPMesh(nn.Module):
             if a.rgb_smooth_loss_weight > 0 or a.a_smooth_loss_weight > 0:
                 nx, ny = B * h * (w - 1) * K_, B * (h - 1) * w * K_
                 sums = variables["smooth_sums"]
-                if a.rgb_smooth_loss_weight > 0:                                                 # MPI.py:605-611
-                    extra["rgb_smooth"] = ((sums[0] / (3 * nx) + sums[1] / (3 * ny)) * denorm).reshape(1, -1)
-                if a.a_smooth_loss_weight > 0:                                                   # MPI.py:613-619
-                    extra["a_smooth"] = ((sums[2] / nx + sums[3] / ny) * denorm).reshape(1, -1)
+                if sums.is_cuda and min(nx, ny) > 0 and not getattr(a, "unfused_terms", False):
+                    # both means from the four fused sums in two launches each way (MPV._SmoothTerms) instead of ~14 scalar kernels each way:
+                    # a stage-1 iteration is bound by its launches (one small upload per distinct crop size)
+                    from .MPV import _SmoothTerms
+                    cache = self.__dict__.setdefault("_smooth_coef", {})
+                    key = (nx, ny, denorm, str(sums.device))
+                    if key not in cache:
+                        if len(cache) > 64:
+                            cache.clear()
+                        cache[key] = torch.tensor([denorm / (3 * nx), denorm / (3 * ny), denorm / nx, denorm / ny], dtype=torch.float32, device=sums.device)
+                    terms = _SmoothTerms.apply(sums, cache[key])
+                    if a.rgb_smooth_loss_weight > 0:                                             # MPI.py:605-611
+                        extra["rgb_smooth"] = terms[0:1].view(1, 1)
+                    if a.a_smooth_loss_weight > 0:                                               # MPI.py:613-619
+                        extra["a_smooth"] = terms[1:2].view(1, 1)
+                else:
+                    if a.rgb_smooth_loss_weight > 0:                                             # MPI.py:605-611
+                        extra["rgb_smooth"] = ((sums[0] / (3 * nx) + sums[1] / (3 * ny)) * denorm).reshape(1, -1)
+                    if a.a_smooth_loss_weight > 0:                                               # MPI.py:613-619
+                        extra["a_smooth"] = ((sums[2] / nx + sums[3] / ny) * denorm).reshape(1, -1)
             if getattr(a, "d_smooth_loss_weight", 0) > 0:                                        # MPI.py:622-637
                 disp = variables["disp_norm"]
                 depth_grad = (disp[:, 1:, :-1] - disp[:, 1:, 1:]).abs() + (disp[:, :-1, 1:] - disp[:, 1:, 1:]).abs()
