@@ -279,6 +279,11 @@ int vl3d_render_fwd_reg(const vl3d_render_desc *desc, const void *stack, const f
                         float *alpha_sums, double *sums, void *reg_state, vl3d_stream_t stream);
 int vl3d_render_reg_fwd_culled(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep,
                                int32_t QH, int32_t QW, double *sums, void *reg_state, vl3d_stream_t stream);
+/* ... and the whole forward of a tile-culled model WITH the regularisers in one pass: rgb / alpha / alpha_sums as vl3d_render_fwd_culled
+ * writes them (the same bits) and sums / reg_state as vl3d_render_reg_fwd_culled -- the slot kernel visits every covered plane of every
+ * pixel nearest first, which is the order of the over-composite, so the render falls out of the samples it takes anyway. */
+int vl3d_render_fwd_reg_culled(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep, int32_t QH,
+                               int32_t QW, float *rgb, float *alpha, float *alpha_sums, double *sums, void *reg_state, vl3d_stream_t stream);
 
 /* Stage 1's learned loop mask (MPI.py:115-117 `atlas_mask`, 568-583) as a FIFTH composited channel of the same pass:
  *     label(pixel) = sum_k w_k sigmoid(sample(mask_k)),   w_k = a_k T_k  the colour composite's blend weights,

@@ -827,6 +827,38 @@ def test_fused_forward_with_regularisers_equals_the_two_pass_forward(dev, spec_n
     assert float(out[0][2].abs().min()) > 0
 
 
+@pytest.mark.parametrize("T,window", [(1, False), (3, False), (4, True)])
+def test_one_pass_culled_forward_with_regularisers_equals_the_two_passes(dev, T, window):
+    """vl3d_render_fwd_reg_culled (a tile-culled model's render AND its regulariser sums from one walk over every pixel's covered planes:
+    the slot kernel composites as it goes) against vl3d_render_fwd_culled followed by vl3d_render_reg_fwd_culled (variant 0x1000): image,
+    alpha and alpha sums bit for bit, the four sums and -- through the sign words both forwards leave for the backward -- the stack
+    gradient too.  window: the stack is a texel window of a larger plane the quad grid lies over (crop-aware training)."""
+    from videoloop3d_amd.render import RenderSpec, render_planes_with_regularisers
+    D, Hs, Ws, H, W = 7, 66, 88, 60, 80
+    kw_p, _ = SPECS["mpv"]
+    torch.manual_seed(11)
+    keep = (torch.rand(D, 6, 8) < 0.45).to(dev)
+    keep[2] = False
+    shift = torch.tensor([[1.0, 0, -8.0], [0, 1.0, -6.0], [0, 0, 1.0]])
+    homos = (bench_homos(D, H, W, scale=2.5) @ shift).to(dev)
+    cull_window = (8, 16, Hs + 24, Ws + 40) if window else None
+    g_rgb = (synth.hash_uniform((T, H, W, 3), seed=5) - 0.5).to(dev)
+    wts = torch.tensor([1.1e-3, 0.7e-3, 1.6e-3, 0.9e-3], device=dev)
+    out, grads = {}, {}
+    for variant in (0, 0x1000):
+        stack = synth.make_plane_stack(D, T, Hs, Ws, seed=29, device=dev).requires_grad_(True)
+        rgb, alpha, sums, asum = render_planes_with_regularisers(stack, homos, H, W, RenderSpec(variant=variant, **kw_p), quad_keep=keep,
+                                                                 cull_window=cull_window)
+        out[variant] = (rgb.detach(), alpha.detach(), sums.detach(), asum.detach())
+        ((rgb * g_rgb).sum() + (sums * wts).sum() + 1e-3 * asum.sum()).backward()
+        grads[variant] = stack.grad
+    for k in (0, 1, 3):
+        assert torch.equal(out[0][k], out[0x1000][k]), k
+    assert float(((out[0][2] - out[0x1000][2]).abs() / out[0x1000][2].abs().clamp_min(1.0)).max()) <= 1e-6
+    assert float(out[0][2].abs().min()) > 0 and float(out[0][1].max()) > 0.1
+    assert torch.equal(grads[0], grads[0x1000])
+
+
 @pytest.mark.parametrize("T", [1, 2, 3])
 @pytest.mark.parametrize("mode", ["dense_plane_edges", "sparsified", "sparsified_atomics", "sparsified_f16"])
 def test_smoothness_regularisers_are_hit_slot_indexed(dev, mode, T):

@@ -61,6 +61,7 @@ SIGNATURES = {
     "vl3d_render_bwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),
     "vl3d_render_bwd_adam": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, C.POINTER(AdamWindow), _P], C.c_int),
     "vl3d_render_reg_state_bytes": ([C.POINTER(RenderDesc)], C.c_int64),
+    "vl3d_render_fwd_reg_culled": ([C.POINTER(RenderDesc), _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _P], C.c_int),
     "vl3d_render_reg_fwd_culled": ([C.POINTER(RenderDesc), _P, _P, _P, _I32, _I32, _P, _P, _P], C.c_int),
     "vl3d_tie_static_grad": ([_I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _I32, _P], C.c_int),
     "vl3d_adam_step_tiles": ([_I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _I64, _P],

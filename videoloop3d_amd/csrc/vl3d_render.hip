@@ -264,6 +264,30 @@ extern "C" int vl3d_render_reg_fwd_culled(const vl3d_render_desc *desc, const vo
     return render_reg_fwd_impl(desc, stack, homos, quad_keep, QH, QW, sums, reg_state, stream);
 }
 
+extern "C" int vl3d_render_fwd_reg_culled(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep, int32_t QH,
+                                          int32_t QW, float *rgb, float *alpha, float *alpha_sums, double *sums, void *reg_state,
+                                          vl3d_stream_t stream) {
+    int rc = check_desc(desc);
+    if (rc != VL3D_OK) return rc;
+    VL3D_REQUIRE(stack && homos && quad_keep && rgb && alpha && sums && reg_state, "null pointer passed to vl3d_render_fwd_reg_culled");
+    VL3D_REQUIRE(desc->D <= 128, "the layer regularisers support at most 128 planes (coverage masks)");
+    rc = check_cull(desc, quad_keep, QH, QW);
+    if (rc != VL3D_OK) return rc;
+    VL3D_REQUIRE((int64_t)desc->Hs * desc->Ws * 16 < (1ll << 32), "frame too large for 32-bit byte offsets");
+    RenderArgs a = make_args(desc);
+    a.stack = (const float *)stack; a.homos = homos; a.rgb = rgb; a.alpha = alpha; a.asum = alpha_sums; a.reg_sums = sums;
+    a.quad_keep = quad_keep; a.QH = QH; a.QW = QW;
+    set_cull_geometry(a, desc, QH, QW);
+    set_reg_state(a, desc, reg_state);
+    VL3D_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(double), (hipStream_t)stream));
+    a.reg_fwd = 3;
+    a.g_f16 = desc->stack_dtype == VL3D_F16;
+    rc = dispatch(false, desc, a, (hipStream_t)stream);
+    if (rc != VL3D_OK) return rc;
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
 static int render_reg_fwd_impl(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep, int32_t QH,
                                int32_t QW, double *sums, void *reg_state, vl3d_stream_t stream) {
     int rc = check_desc(desc);

@@ -506,8 +506,13 @@ __device__ __forceinline__ f4 reg_sample(const RenderArgs &a, float px, float py
 //   two-pass forward of dense ones); sign words are written whole, four planes per 8-byte store.
 // PATCH = true: only the irregular pairs, after render_fwd_reg_k took the regular ones plane by plane: regions without an irregular
 //   pair return at once; the signs are ADDED to the words that kernel wrote (it left sign 0 in those fields).
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool PATCH>
+// RENDER (with PATCH = false): the composite as well -- a thread visits its covered planes nearest first, which is the order of the
+//   over-composite, so rgb / alpha / the alpha sums of its pixel fall out of the same samples (the planes it skips have alpha exactly 0
+//   for it: the bits of render_fwd2_k's culled composite).  The whole forward of a tile-culled model with regularisers in one pass
+//   (vl3d_render_fwd_reg_culled) instead of the culled render + this kernel over the same taps.
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool PATCH, bool RENDER = false>
 __global__ __launch_bounds__(512) void reg_slot_fwd_k(RenderArgs a, int tiles_x, int tiles_y) {
+    static_assert(!(PATCH && RENDER), "the composite rides the kernel that visits every covered plane of every pixel");
     constexpr int FW = 64, FH = 8, NT = FW * FH;
     __shared__ float4 s_v[2][NT];
     __shared__ int s_d[2][NT];
@@ -537,6 +542,7 @@ __global__ __launch_bounds__(512) void reg_slot_fwd_k(RenderArgs a, int tiles_x,
     unsigned long long *const sg64 = reinterpret_cast<unsigned long long *>(a.reg_signs);
     unsigned char *const patch8 = reinterpret_cast<unsigned char *>(a.reg_patch);
     float sxc = 0.f, syc = 0.f, sxa = 0.f, sya = 0.f;
+    float Tr = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, A = 0.f, n1 = 0.f, n2 = 0.f;      // RENDER: the composite state of this pixel
     unsigned long long sgw = 0ull;      // (full mode) sign words of the group of four planes being filled
     int sgg = -1;                       // ... and its index
     for (int k = 0; k < kmax; ++k) {
@@ -544,6 +550,12 @@ __global__ __launch_bounds__(512) void reg_slot_fwd_k(RenderArgs a, int tiles_x,
         const int d = reg_pop_plane(m0, m1);      // my plane in slot k (-1: I have no slot k)
         f4 v = f4{0.f, 0.f, 0.f, 0.f};
         if (d >= 0) v = reg_sample<COORD, BORDER, ORDER, RACT, AACT, F16>(a, px, py, d, t);
+        if constexpr (RENDER) {      // (spelt like VL3D_COMPOSITE of render_fwd2_k; an absent slot adds exact zeros)
+            const float w = v.w * Tr;
+            cr += w * v.x; cg += w * v.y; cb += w * v.z; A += w;
+            n1 += v.w; n2 = fmaf(v.w, v.w, n2);
+            Tr *= (1.0f - v.w);
+        }
         s_v[buf][tid] = make_float4(v.x, v.y, v.z, v.w);
         s_d[buf][tid] = d;
         __syncthreads();
@@ -590,6 +602,11 @@ __global__ __launch_bounds__(512) void reg_slot_fwd_k(RenderArgs a, int tiles_x,
         }
     }
     if (!PATCH && owner && sgg >= 0) sg64[(size_t)sgg * plane_px + fpix] = sgw;
+    if constexpr (RENDER) if (owner) {
+        a.rgb[fpix * 3 + 0] = cr; a.rgb[fpix * 3 + 1] = cg; a.rgb[fpix * 3 + 2] = cb;
+        a.alpha[fpix] = A;
+        if (a.asum) { a.asum[fpix * 2 + 0] = n1; a.asum[fpix * 2 + 1] = n2; }
+    }
     float v4[4] = {sxc, syc, sxa, sya};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -611,10 +628,10 @@ void launch_reg_prepass(const RenderArgs &a, hipStream_t s) {
     hipLaunchKernelGGL((reg_masks_k<COORD, BORDER>), g, dim3(256), 0, s, a);
     hipLaunchKernelGGL(reg_flags_k, g, dim3(256), 0, s, a);
 }
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool PATCH>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool PATCH, bool RENDER = false>
 void launch_reg_slots(const RenderArgs &a, hipStream_t s) {
     const int tx = (a.W + 62) / 63, ty = (a.H + 6) / 7;
-    hipLaunchKernelGGL((reg_slot_fwd_k<COORD, BORDER, ORDER, RACT, AACT, F16, PATCH>), dim3((unsigned)(tx * ty * a.T)), dim3(512), 0, s, a, tx, ty);
+    hipLaunchKernelGGL((reg_slot_fwd_k<COORD, BORDER, ORDER, RACT, AACT, F16, PATCH, RENDER>), dim3((unsigned)(tx * ty * a.T)), dim3(512), 0, s, a, tx, ty);
 }
 
 constexpr int TILE_X = 64, TILE_Y = 4;
@@ -2008,6 +2025,11 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
             if (!with_mask)
                 hipLaunchKernelGGL((render_fwd_reg_k<COORD, BORDER, ORDER, RACT, AACT, F16>), dim3((unsigned)(tx * ty * a.T)), dim3(512), 0, s, a, tx, ty);
             launch_reg_slots<COORD, BORDER, ORDER, RACT, AACT, F16, true>(a, s);
+            return;
+        }
+        if (a.reg_fwd == 3) {       // render + regulariser sums of a tile-culled model in one pass: the slot kernel composites as it goes
+            launch_reg_prepass<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
+            launch_reg_slots<COORD, BORDER, ORDER, RACT, AACT, F16, false, true>(a, s);
             return;
         }
         if (a.reg_fwd) {        // the sums alone (tile-culled models; the two-pass forward of dense ones): every pair slot by slot

@@ -107,11 +107,15 @@ class _RenderPlanes(torch.autograd.Function):
             with torch.cuda.device(stack.device):
                 reg_state = torch.empty(int(L.lib().vl3d_render_reg_state_bytes(desc)), dtype=torch.uint8, device=stack.device)
         # variant bits 12-15: 1 = keep the two-pass forward with regularisers (render, then the sums kernel) for A/B and cross-checks
-        fused_reg = with_reg and quad_keep is None and ((int(spec.variant) >> 12) & 0xf) != 1
+        fused_reg = with_reg and ((int(spec.variant) >> 12) & 0xf) != 1
         with torch.cuda.device(stack.device):
-            if fused_reg:         # render + smoothness sums in ONE sweep over the stack
+            if fused_reg and quad_keep is None:         # render + smoothness sums in ONE sweep over the stack
                 L.check(L.lib().vl3d_render_fwd_reg(desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.ptr(asum), L.ptr(sums),
                                                     L.ptr(reg_state), L.stream_ptr(stack.device)), "vl3d_render_fwd_reg")
+            elif fused_reg:       # tile-culled model: the slot-by-slot regulariser kernel composites the render from the samples it takes
+                L.check(L.lib().vl3d_render_fwd_reg_culled(desc, L.ptr(stack), L.ptr(homos), L.ptr(quad_keep), quad_keep.shape[1], quad_keep.shape[2],
+                                                           L.ptr(rgb), L.ptr(alpha), L.ptr(asum), L.ptr(sums), L.ptr(reg_state),
+                                                           L.stream_ptr(stack.device)), "vl3d_render_fwd_reg_culled")
             elif quad_keep is None:
                 L.check(L.lib().vl3d_render_fwd(desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.ptr(asum),
                                                 L.stream_ptr(stack.device)), "vl3d_render_fwd")
