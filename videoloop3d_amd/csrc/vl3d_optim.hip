@@ -111,7 +111,27 @@ __global__ __launch_bounds__(256) void adam_window_catchup_k(int T, int Hs, int 
             for (int t = 0; t < T; ++t, o += frame, oc += cframe) compact[oc] = p[o];
         return;
     }
-    for (int t = 0; t < T; ++t, o += frame, oc += cframe) {
+    // four frames of the texel per trip: twelve independent 16-byte loads in flight and four independent replay chains per thread (the
+    // same operations per value: the same bits) -- one frame per trip left a kept texel's thread with three loads in flight and one
+    // dependent chain of sqrt / rcp per step, and the catch-up of a tile-culled window at 64 % of the rate its bytes allow
+    int t = 0;
+    constexpr int NF = 4;
+    for (; t + NF <= T; t += NF, o += NF * frame, oc += NF * cframe) {
+        float4 pp[NF], mm[NF], vv[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) { pp[f] = p[o + f * frame]; mm[f] = m[o + f * frame]; vv[f] = v[o + f * frame]; }
+        for (int s = from + 1; s <= upto; ++s) {
+            const float2 h = hist[s];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) adam_upd4(pp[f], make_float4(0.f, 0.f, 0.f, 0.f), mm[f], vv[f], h.x, beta1, beta2, eps, h.y);
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            if (writeback) { p[o + f * frame] = pp[f]; m[o + f * frame] = mm[f]; v[o + f * frame] = vv[f]; }
+            if (compact) compact[oc + f * cframe] = pp[f];
+        }
+    }
+    for (; t < T; ++t, o += frame, oc += cframe) {
         float4 pp = p[o], mm = m[o], vv = v[o];
         replay(pp, mm, vv, hist, from, upto, beta1, beta2, eps);
         if (writeback) { p[o] = pp; m[o] = mm; v[o] = vv; }
