@@ -559,10 +559,26 @@ class MPMeshVid(nn.Module):
         """[D,3,3] target pixel -> plane pixel for the view `extrin` (ref -> target, [1,4,4]) / `intrin` [1,3,3]
         (utils_mpi.py:240-273 with src = the reference camera, plane normal (0,0,1), distance = planedepth)."""
         dev = extrin.device
+        if dev.type == "cpu" and extrin.dtype == torch.float64 and not extrin.requires_grad and not getattr(self.args, "torch_homographies", False):
+            # float64 host poses: the closed form in numpy (utils_mpi.plane_homographies_host) -- the same bits as the torch spelling below at a
+            # third of the host time.  (float32 poses, as the reference's drivers hold them, keep the torch operators: their rounding is the
+            # reference's own, which the goldens pin.)
+            from .utils_mpi import plane_homographies_host
+            return plane_homographies_host(self._host_np("ref_intrin_mpi"), self._host_np("planedepth"), extrin[0].numpy(),
+                                           torch.as_tensor(intrin)[0].detach().cpu().numpy())
         eye = torch.eye(4, dtype=extrin.dtype, device=dev)[None]
         normal = torch.tensor([0., 0., 1.], dtype=extrin.dtype, device=dev).expand(1, self.mpi_d, 3)
         return compute_homography(eye, self._on(dev, "ref_intrin_mpi")[None].to(extrin.dtype), extrin, intrin.to(dev), normal,
                                   self._on(dev, "planedepth")[None].to(extrin.dtype))[0].float()
+
+    def _host_np(self, name):
+        """numpy mirror of a (small, constant) camera buffer, refreshed when the buffer changes."""
+        buf = getattr(self, name)
+        cache = self.__dict__.setdefault("_host_np_mirrors", {})
+        key = (buf.data_ptr(), buf._version, str(buf.device))
+        if cache.get(name, (None,))[0] != key:
+            cache[name] = (key, buf.detach().cpu().numpy().copy())
+        return cache[name][1]
 
     def _on(self, dev, name):
         """the (small, constant) camera buffers on the device of the pose tensors: poses that arrive on the HOST (as the DataLoader

@@ -44,6 +44,22 @@ def compute_homography(src_extrin_4x4, src_intrin, tar_extrin_4x4, tar_intrin, n
     return src_intrin.unsqueeze(-3) @ homo @ torch.inverse(tar_intrin.unsqueeze(-3))
 
 
+def plane_homographies_host(src_intrin, planedepth, tar_extrin, tar_intrin):
+    """compute_homography for the case the modules need every iteration -- source camera at the identity, plane normal (0, 0, 1), poses on
+    the HOST -- in numpy: H_d = K_src (R + t R[2] / (d - t_z)) K_tar^-1 with [R|t] = E_tar^-1 (the same operations in the same order, in the
+    poses' dtype; (t n^T) R = t R[2] exactly).  The torch spelling is ~30 CPU operators of a few microseconds each, in iterations that are
+    bound by the host (stage 1: 0.9 ms of GPU time in 1.24 ms).  numpy arrays: src_intrin [3,3], planedepth [D], tar_extrin [4,4],
+    tar_intrin [3,3] -> float32 tensor [D,3,3]."""
+    import numpy as np
+    dt = tar_extrin.dtype
+    pose = np.linalg.inv(tar_extrin)
+    R, t = pose[:3, :3], pose[:3, 3]
+    dist = planedepth.astype(dt) - t[2]
+    homo = R[None] + (t[:, None] * R[2][None, :])[None] / dist[:, None, None]
+    H = src_intrin.astype(dt)[None] @ homo @ np.linalg.inv(tar_intrin.astype(dt))[None]
+    return torch.from_numpy(np.ascontiguousarray(H, dtype=np.float32))
+
+
 # ---- warp_homography ------------------------------------------------------------------------------
 class _Warp(torch.autograd.Function):
     @staticmethod
