@@ -8,4 +8,4 @@ stage1_step.run(5) if len(sys.argv) > 1 else stage1_step.run(5, frame=(720, 1280
 pr = cProfile.Profile(); pr.enable()
 stage1_step.run(200) if len(sys.argv) > 1 else stage1_step.run(60, frame=(720, 1280), crop=(720, 1280), scale=1.1)
 pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats(sys.argv[2] if len(sys.argv) > 2 else "tottime").print_stats(45); print(s.getvalue()[:6000])
