@@ -594,3 +594,90 @@ def test_render_bwd_adam_refuses_what_it_is_not_built_for(dev):
     assert rc == 0, msg
     torch.cuda.synchronize()
     assert int(last[:, 1:3, 1:4].min()) == 1 and int(last.sum()) == D * 2 * 3
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_fused_step_at_the_schedule_s_shapes(dev, sparse):
+    """the same bit-for-bit property at the shapes examples/stage2_schedule.py trains (configs/mpv_base.txt: 360 x 640 frames, 180 x 320 crops,
+    D = 32 planes at 1.1x, 36 x 64 vertices; 6 frames here to bound the memory), two pyramid levels (lod 0.75, then 1.0: new optimisers), three
+    poses, per-plane boxes, regularisers on: fused step == backward + step kernel in p, m, v and the step table after every iteration."""
+    import warnings
+    from videoloop3d_amd import tiles
+    from videoloop3d_amd.MPV import MPMeshVid
+    H, W, h, w, T, D = 360, 640, 180, 320, 6, 32
+    K = np.array([[0.9 * W, 0, W / 2], [0, 0.9 * W, H / 2], [0, 0, 1]], np.float64)
+    kw = dict(mpv_frm_num=T, mpi_d=D, atlas_grid_h=4, init_std=0.02, mpi_h_verts=36, mpi_w_verts=64)
+    models = []
+    for fused in (False, True):
+        torch.manual_seed(7)
+        m = MPMeshVid(_args(fused_adam_backward=fused, **kw), H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
+        if sparse:      # the quad maps of examples/stage2_schedule.py: a blob per plane, every other kept quad dynamic
+            QH, QW = 35, 63
+            qy, qx = torch.meshgrid(torch.arange(QH, device=dev), torch.arange(QW, device=dev), indexing="ij")
+            keep = torch.zeros((D, QH, QW), dtype=torch.bool, device=dev)
+            for d in range(D):
+                cy, cx = (7 * d + 3) % QH, (11 * d + 5) % QW
+                keep[d] = ((qy - cy).abs() <= QH // 5) & ((qx - cx).abs() <= QW // 4)
+            m.register_buffer("quad_keep", keep)
+            m.register_buffer("quad_dyn", keep & ((qy + qx) % 2 == 0)[None])
+            m.is_sparse = m.has_dyn = True
+            with torch.no_grad():
+                tiles.cull_stack_(m.stack.data, keep)
+            m._install_tie_hook()
+        models.append(m)
+    A, B = models
+    res = synth.hash_uniform((1, 2 * T + 1, 3, h, w), seed=8, device=dev)
+    cfg = dict(loss_name=["gpnn_lm"], loss_gain=torch.tensor([1.0]), macro_block=torch.tensor([65]), patch_size=torch.tensor([3]),
+               stride=torch.tensor([2]), patcht_size=torch.tensor([3]), stridet=torch.tensor([1]), alpha=torch.tensor([10000.0]),
+               dist_fn=["mse"], rou=["-2"], scaling=torch.tensor([0.1]))
+    poses = []
+    for v in range(3):
+        a_, b_ = np.radians(1.2 * np.cos(2 * np.pi * v / 3)), np.radians(0.8 * np.sin(2 * np.pi * v / 3))
+        Ry = np.array([[np.cos(a_), 0, np.sin(a_)], [0, 1, 0], [-np.sin(a_), 0, np.cos(a_)]])
+        Rx = np.array([[1, 0, 0], [0, np.cos(b_), -np.sin(b_)], [0, np.sin(b_), np.cos(b_)]])
+        E = np.eye(4)
+        E[:3, :3], E[:3, 3] = Ry @ Rx, [0.06 * np.cos(2 * np.pi * v / 3), 0.04 * np.sin(2 * np.pi * v / 3), 0.01 * (v - 1)]
+        poses.append(E)
+    it = 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for factor in (0.75, 1.0):
+            for m in models:
+                m.lod(factor)
+            opts = [m.get_optimizer(0) for m in models]
+            assert opts[1].fused_backward and not opts[0].fused_backward
+            fh, fw = int(H * factor), int(W * factor)
+            Kl = K.copy()
+            Kl[:2] *= factor
+            for (oy, ox) in [(0, 0), (fh - h, fw - w), (45, 80), (0, fw - w), (fh - h, 0), (30, 100)]:
+                Kc = Kl.copy()
+                Kc[0, 2] -= ox
+                Kc[1, 2] -= oy
+                E = poses[it % 3]
+                losses = []
+                for m, opt in zip(models, opts):
+                    for grp in opt.param_groups:
+                        grp["lr"] = 5e-3 * 0.95 ** it
+                    opt.zero_grad(set_to_none=True)
+                    _, extra = m(h, w, torch.tensor(E)[None], torch.tensor(Kc)[None], res=res, losscfg=dict(cfg))
+                    loss = extra["swd"].sum() + 0.2 * extra["rgb_smooth"].sum() + 0.2 * extra["a_smooth"].sum()
+                    loss.backward()
+                    opt.step()
+                    losses.append(float(loss.detach()))
+                assert losses[0] == losses[1], (it, losses)
+                sa, sb = opts[0].state[opts[0].p], opts[1].state[opts[1].p]
+                assert torch.equal(sa["last_step"], sb["last_step"])
+                for name, x, y in (("p", A.stack.data, B.stack.data), ("m", sa["exp_avg"], sb["exp_avg"]), ("v", sa["exp_avg_sq"], sb["exp_avg_sq"])):
+                    if sparse:      # frames 1.. of a static texel are scratch until the flush; culled slots are nobody's
+                        x, y = x[:, :1], y[:, :1]
+                        kept = tiles.quad_to_texel_mask(A.quad_keep.cpu(), *A.stack.shape[2:4]).to(dev)[:, None, :, :, None].expand_as(x)
+                        x, y = x[kept], y[kept]
+                    assert torch.equal(x, y), (it, name, int((x != y).sum()))
+                it += 1
+            assert opts[1].fused_steps == 6
+    sda, sdb = A.state_dict()["stack"], B.state_dict()["stack"]
+    if sparse:
+        kept = tiles.quad_to_texel_mask(A.quad_keep.cpu(), *A.stack.shape[2:4]).to(dev)[:, None, :, :, None].expand_as(sda)
+        assert torch.equal(sda[kept], sdb[kept])
+    else:
+        assert torch.equal(sda, sdb)
