@@ -266,7 +266,9 @@ class WindowAdam(torch.optim.Optimizer):
             aw.class_scratch = self._class_dev.data_ptr()
             if self.layout is not None:
                 aw.blocks = self.layout.blocks.data_ptr()
-        g_fallback = torch.empty_like(stack)       # written (and consumed) on the device only when the plan finds the view infeasible
+        # the compact gradient buffer: static texels of a tile-culled model (summed over the frames by the step kernel behind the backward) and
+        # everything when the device-side plan finds the view infeasible; untouched otherwise (an allocation, no traffic)
+        g_fallback = torch.empty_like(stack)
         with torch.cuda.device(dev):
             nscratch = int(L.lib().vl3d_render_bwd_scratch_bytes(desc))
             scratch = torch.empty((nscratch + 3) // 4, dtype=torch.float32, device=dev)
