@@ -142,6 +142,13 @@ int vl3d_tie_static_grad(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uin
 int vl3d_adam_step_tiles(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uint8_t *quad_keep, const uint8_t *quad_dyn, int32_t QH, int32_t QW,
                          float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float lr, float beta1, float beta2,
                          float eps, int64_t step, vl3d_stream_t stream);
+/* ... with the step's scalars in DEVICE memory: step_scalars = float[2] (lr / (1 - beta1^step), sqrt(1 - beta2^step)), as
+ * vl3d_adam_step_scalars computes them.  The launch carries nothing that changes from step to step, so an iteration recorded in a hipGraph
+ * (a stage-1 iteration is bound by its ~80 launches: videoloop3d_amd/graphs.py) replays with a new learning rate and step count after one
+ * 8-byte copy. */
+int vl3d_adam_step_tiles_dev(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uint8_t *quad_keep, const uint8_t *quad_dyn, int32_t QH,
+                             int32_t QW, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *step_scalars,
+                             float beta1, float beta2, float eps, vl3d_stream_t stream);
 
 /* Crop-aware Adam for the DENSE stack (csrc/vl3d_optim.hip; the optimiser of train_3dvid.py:263-290 / MPV.py:199-214).  A training
  * iteration renders one crop, so only the texels of the crop's parallax window (y0, x0, wh, ww; aligned to
