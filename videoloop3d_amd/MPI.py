@@ -176,8 +176,9 @@ class MPMesh(nn.Module):
                 # touches the window only, the zero-gradient updates of the rest are deferred and replayed exactly -- optim.WindowAdam, as in
                 # stage 2; a sparsified model, train_3d.py:282-286, takes its step inside the render's backward) and the one-pass Adam for the
                 # loop-mask texture.  Measured in round 4 (examples/stage1_step.py, D = 32, 576 x 1024 planes, 180 x 320 crops): 635 it/s against
-                # 766 with the one pass over the whole stack below -- the optimiser's GPU time halves (0.38 -> 0.2 ms) but a stage-1 iteration is
-                # bound by its ~70 launches and the host work of the window (1.3 ms), which this path lengthens.  Hence not the default.
+                # 766 with the one pass over the whole stack below, 710-860 against 1015-1100 after the module's host path was trimmed -- the
+                # optimiser's GPU time halves (0.38 -> 0.2 ms) but the window adds ~15 launches and host work to an iteration of ~1 ms.  Hence
+                # not the default.
                 from .optim import Stage1Adam
                 from .tiles import CULLED_ALPHA
                 others = [p for _, p in self.named_parameters() if p is not self.stack]
