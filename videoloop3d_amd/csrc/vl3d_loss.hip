@@ -800,6 +800,368 @@ __global__ __launch_bounds__(64 * NW, 2) void patchnn5_k(NN2Args a, int groups_x
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K3 v6: the v5 workgroup with the frame-pair energies on the HALF-PRECISION matrix cores at fp32-class accuracy.
+// v_mfma_f32_16x16x4_f32 runs at the vector rate (32 cycles per 16x16x4 issue); v_mfma_f32_16x16x32_f16 contracts 32 k in 16-17 cycles
+// (16x the rate, MI355X_MICROARCH.md).  The cross term of  e(ti, tj) = |u(ti)|^2 + |v(tj)|^2 - 2 u(ti).v(tj)  is formed from a two-term
+// split of every value, u = hi + lo with hi = f16(u), lo = f16(u - hi) (11 + 11 mantissa bits; f16 subnormals are kept by the conversion
+// and by the matrix cores, measured in profiles/microbench/dma_f16.hip), as  hi.hi' + hi.lo' + lo.hi'  accumulated in fp32 (the dropped
+// lo.lo' is < 2^-24 of the product: an fp32 rounding).  The two norms are fp32 sums on the side.
+// gram16 form (video_to_gram16_k): per pixel and frame ONE 16-byte piece  [h0 h1 | l0 l1 | h2 l2 | nh nl]  -- the split of the three
+// channels (x: u = x - 1/2; y: -2 v, v = y - 1/2) and of the norm n = sum_c u_c^2 (y: sum_c v_c^2; 22 bits, below the rounding of the fp32 window
+// sum it enters) -- pixel-major [H][W][T] like v5's form, so a region row is one contiguous run for the LDS-DMA (strided lanes cost 5x:
+// dma_f16.hip) and any crop origin of a prepared clip is valid.
+// One MFMA covers TWO cells (pixels) of a region column for a 16 x 16 frame-pair tile: its four 8-element k blocks (lane >> 4) are
+//   kb 0: cell a, A = [h0 h1 h0 h1 h2 h2 0 0]   kb 1: cell a, A = [l0 l1 0 0 l2 0 0 0]   kb 2 / 3: the same for cell b
+// against B = the RAW y piece [h0' h1' l0' l1' h2' l2' nh' nl'] in all four: kb 0 gives h.h' + h.l', kb 1 gives l.h', and the norm
+// halves meet zeros.  The A blocks come out of the raw x piece in three instructions (a select, a mask, a byte permute with a per-lane
+// selector): 9 of 16 k slots carry products, 5.5 issues of 17 cycles per 11-pixel column and tile instead of 11 of 32.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint4 gram16_piece(float a0, float a1, float a2, float s) {
+    const float n = fmaf(a2, a2, fmaf(a1, a1, a0 * a0));
+    const float u0 = a0 * s, u1 = a1 * s, u2 = a2 * s;
+    const _Float16 h0 = (_Float16)u0, h1 = (_Float16)u1, h2 = (_Float16)u2, nh = (_Float16)n;
+    const _Float16 l0 = (_Float16)(u0 - (float)h0), l1 = (_Float16)(u1 - (float)h1), l2 = (_Float16)(u2 - (float)h2), nl = (_Float16)(n - (float)nh);
+    auto bits = [](_Float16 h) -> unsigned { return (unsigned)__builtin_bit_cast(unsigned short, h); };
+    uint4 o;
+    o.x = bits(h0) | (bits(h1) << 16);
+    o.y = bits(l0) | (bits(l1) << 16);
+    o.z = bits(h2) | (bits(l2) << 16);
+    o.w = bits(nh) | (bits(nl) << 16);
+    return o;
+}
+
+template <bool IS_Y>
+__global__ __launch_bounds__(256) void video_to_gram16_k(const float *__restrict__ v, int64_t sc, int64_t st, int64_t sr,
+                                                         int T, int H, int W, uint4 *__restrict__ out) {
+    __shared__ float tile[3][16][65];      // [channel][frame of the group][pixel] (+1 pad: conflict-free transposed reads)
+    const int row = blockIdx.y, x0 = blockIdx.x * 64, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = (T + 15) >> 4;
+    float pre[12];
+    const float *src = v + (int64_t)row * sr + min(x0 + lane, W - 1);
+    auto load = [&](int f0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int j = wave + 4 * k, c = j >> 4, f = f0 + (j & 15);
+            pre[k] = f < T ? src[c * sc + f * st] : 0.5f;
+        }
+    };
+    load(0);
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int j = wave + 4 * k;
+            tile[j >> 4][j & 15][lane] = pre[k] - 0.5f;
+        }
+        __syncthreads();
+        if (g + 1 < G) load((g + 1) * 16);
+        // write: 16 lanes = the 16 frames of one pixel = 256 contiguous bytes; 4 pixels per wave and pass
+        const int m = lane & 15, f = g * 16 + m;
+        for (int p = wave * 4 + (lane >> 4); p < 64; p += 16)
+            if (x0 + p < W && f < T)
+                out[((size_t)row * W + x0 + p) * T + f] = gram16_piece(tile[0][m][p], tile[1][m][p], tile[2][m][p], IS_Y ? -2.0f : 1.0f);
+        __syncthreads();
+    }
+}
+
+template <int J>
+__device__ __forceinline__ void nn6_issue_tile(u32x4_t &dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(J * 256) : "memory");
+}
+template <int N, int... Js>
+__device__ __forceinline__ void nn6_issue_tiles(u32x4_t (&b)[N], unsigned addr, std::integer_sequence<int, Js...>) {
+    (nn6_issue_tile<Js>(b[Js], addr), ...);
+}
+
+// One wave's rows of a location, no alpha, pt = 3, stridet = 1: s(i, j) = E(i, j) + E(i + 1, j + 1) + E(i + 2, j + 2) over the wave's slab
+// E [16][EP]; first minimum over j, NaN minimal (torch.argmin); 4 lanes per row, each a quarter of whole column groups.  Returns the index
+// (valid in the lanes with sub == 0).
+__device__ __forceinline__ int nn_argmin_rows3(const float *E, int EP, int n2, int i, bool active, int sub) {
+    const float4 *E4 = reinterpret_cast<const float4 *>(E);
+    const int q4 = ((n2 + 3) / 4 + 3) & ~3, j0 = sub * q4, j1 = min(n2, j0 + q4);
+    float best = INFINITY;
+    int bj = j0;
+    bool best_nan = false;
+    if (active && j0 < j1) {
+        const float4 *p = E4 + (i * EP + j0) / 4;
+        float4 l1 = p[EP / 4], l2 = p[EP / 2];
+        for (int jb = j0; jb < j1; jb += 4, ++p) {
+            const float4 c0 = p[0], h1 = p[EP / 4 + 1], h2 = p[EP / 2 + 1];
+            const float sa[4] = {(c0.x + l1.y) + l2.z, (c0.y + l1.z) + l2.w, (c0.z + l1.w) + h2.x, (c0.w + h1.x) + h2.y};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float v = sa[u];
+                const bool vn = (v != v);
+                if (jb + u < j1 && !best_nan && (vn || v < best)) { best = v; bj = jb + u; best_nan = vn; }
+            }
+            l1 = h1; l2 = h2;
+        }
+    }
+#pragma unroll
+    for (int step = 1; step <= 2; step <<= 1) {      // combine the 4 quarters in ascending-j order so that ties keep the lowest index
+        const float ob = __shfl_xor(best, step, 64);
+        const int oj = __shfl_xor(bj, step, 64);
+        const int on = __shfl_xor((int)best_nan, step, 64);
+        const bool other_lower = (sub & step) != 0;
+        bool take;
+        if (best_nan || on) take = on && (!best_nan || other_lower);
+        else take = (ob < best) || (ob == best && other_lower);
+        if (take) { best = ob; bj = oj; best_nan = on != 0; }
+    }
+    return bj;
+}
+
+// NN2Args: PX / PY = frames per pixel of the gram16 x / y (exact, no padding); xt / yt = the gram16 buffers (16-byte pieces).
+// DB: operands of chunk c + 1 in flight during the MFMAs of chunk c (two register sets) or one set (fewer registers: three waves per SIMD).
+// XS: first x frame of wave w is XS * w.  16: the waves' tiles abut, the epilogue runs workgroup-wide through the shared E (v5's).  14: the
+// tiles overlap by pt - 1 = 2 frames, so wave w holds every frame pair of its 14 patches: each wave finishes its own rows through a
+// private 16-row slab, no workgroup barrier between the locations (no alpha, pt = 3, stridet = 1 only: the column minima of the alpha
+// path need all rows).
+template <int TYT, int NL, int NW, bool DB, int XS>
+__global__ __launch_bounds__(64 * NW, (DB || NW > 4) ? 2 : 3) void patchnn6_k(NN2Args a, int groups_x, int CHC) {
+    constexpr int NTHR = 64 * NW, NXT = 16 * NW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KX = 4, KY = 2 * TYT > 7 ? 7 : 2 * TYT;       // DMA pieces per wave and stage at most
+    const int RWc = a.ps + (NL - 1) * a.stride;                 // region width in pixels
+    const int FX = a.PX, FY = a.PY;
+    const int xs4 = CHC * a.ps * FX, ys4 = CHC * a.ps * FY;       // 16-byte pieces per stage and part
+    const int ybase = xs4 * 4, bufF = (xs4 + ys4) * 4;            // (floats)
+    const int n2p = (a.n2 + 3) & ~3;
+    const int EP = XS == 16 ? a.TyP : (((a.TyP + 3) & ~7) + 4);  // slab row pitch: 4 EP = 16 mod 32 banks (the two lane groups of a store never meet)
+    float *E = smem;                                            // XS 16: [TxP][TyP], one location at a time; XS 14: NW slabs [17][EP]: aliases the staging
+    float *colw = E + (XS == 16 ? (size_t)a.TxP * a.TyP : (size_t)NW * 17 * EP);
+    float *sy = colw + NL * 3 * n2p;                            // [NL][TyP] y norms of the locations   (colw: [NL][3][n2p])
+    float *sx = sy + NL * a.TyP;                                // [NL][NXT] x norms
+    const int g = blockIdx.x, by = g / groups_x, bx0 = (g % groups_x) * NL;
+    const int r0 = by * a.stride, c0 = bx0 * a.stride, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cols = min(RWc, a.W - c0);
+    const int nloc = min(NL, a.w_o - bx0);
+    f32x4_t acc[NL][TYT], R[TYT];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int j = 0; j < TYT; ++j) acc[l][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < TYT; ++j) R[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // norms on the side: thread tid < FX sums frame tid of x, thread NXT + f frame f of y (one LDS word + one dot2 per cell, in the MFMAs' shadow)
+    const bool xside = tid < FX, yside = tid >= NXT && tid - NXT < FY;
+    float an[NL], Rn = 0.f;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) an[l] = 0.f;
+    int offx[KX], offy[KY];
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        const int idx = (wave + NW * k) * 64 + lane, cc = fdiv_small(idx, a.ps * FX), rem = idx - cc * a.ps * FX, r = fdiv_small(rem, FX);
+        offx[k] = idx < xs4 ? ((r * a.W + cc) * FX + (rem - r * FX)) | (cc << 24) : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < KY; ++k) {
+        const int idx = (wave + NW * k) * 64 + lane, cc = fdiv_small(idx, a.ps * FY), rem = idx - cc * a.ps * FY, r = fdiv_small(rem, FY);
+        offy[k] = idx < ys4 ? ((r * a.Wy + cc) * FY + (rem - r * FY)) | (cc << 24) : -1;
+    }
+    const int S = (cols + CHC - 1) / CHC;                       // stages
+    auto issue = [&](int st) {
+        const int q0 = st * CHC, nc = min(CHC, cols - q0);
+        float *dst = smem + (st & 1) * bufF;
+        const float4 *xsrc = reinterpret_cast<const float4 *>(a.xt) + ((size_t)r0 * a.W + c0 + q0) * FX;
+        const float4 *ysrc = reinterpret_cast<const float4 *>(a.yt) + ((size_t)r0 * a.Wy + c0 + q0) * FY;
+#pragma unroll
+        for (int k = 0; k < KX; ++k)
+            if (offx[k] >= 0 && (offx[k] >> 24) < nc) lds_dma16(xsrc + (offx[k] & 0xffffff), dst + (wave + NW * k) * 256);
+#pragma unroll
+        for (int k = 0; k < KY; ++k)
+            if (offy[k] >= 0 && (offy[k] >> 24) < nc) lds_dma16(ysrc + (offy[k] & 0xffffff), dst + ybase + (wave + NW * k) * 256);
+    };
+    // operand fragments: lane = frame (lane & 15) + 16 * k block; k blocks 0 / 1 read cell a of the chunk, 2 / 3 cell b -- 16 lanes x 16 bytes
+    // of one pixel's frames are 256 contiguous bytes: conflict-free ds_read_b128
+    const int kb = lane >> 4;
+    const bool lo_blk = (kb & 1) != 0;
+    const unsigned ymask = lo_blk ? 0u : 0xffffffffu;           // A.y = (h0 h1) in the h block, 0 in the l block
+    const unsigned zsel = lo_blk ? 0x0c0c0302u : 0x01000100u;   // A.z = (h2 h2) / (l2 0) out of the piece's (h2 l2)
+    const unsigned cellx = (unsigned)FX * 16u, celly = (unsigned)FY * 16u;
+    const int nch = (a.ps + 1) >> 1;
+    const bool odd = (a.ps & 1) != 0;
+    // per-lane byte steps from chunk to chunk; into the LAST chunk of an odd column the lanes of cell b step one cell only (they re-read the
+    // column's last cell, their A block is zeroed)
+    const unsigned xstep2 = 2u * cellx, ystep2 = 2u * celly;
+    const unsigned xstepL = (odd && kb >= 2) ? cellx : xstep2, ystepL = (odd && kb >= 2) ? celly : ystep2;
+    const unsigned nstep2 = xside ? xstep2 : (yside ? ystep2 : 0u);
+    const f16x2_t ones = {(_Float16)1.0f, (_Float16)1.0f};
+    if (!VL3D_ABLATE(a.ablate, 4)) issue(0);
+    for (int st = 0; st < S; ++st) {
+        __syncthreads();                                         // stage st has landed; everyone is done with the other buffer
+        if (st + 1 < S && !VL3D_ABLATE(a.ablate, 4)) issue(st + 1);
+        if VL3D_ABLATE(a.ablate, 2) continue;
+        const int q0 = st * CHC, nc = min(CHC, cols - q0);
+        const float *buf = smem + (st & 1) * bufF;
+        for (int cc = 0; cc < nc; ++cc) {
+            const int q = q0 + cc;
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+                if (q == l * a.stride) {      // window of location l starts at this column (uniform): acc = R(end) - R(before start)
+#pragma unroll
+                    for (int j = 0; j < TYT; ++j) acc[l][j] -= R[j];
+                    an[l] -= Rn;
+                }
+            const bool one_cell = a.ps == 1;
+            unsigned xad = (unsigned)reinterpret_cast<uintptr_t>(buf) + (unsigned)(cc * a.ps * FX + XS * wave + (lane & 15)) * 16u + ((kb >= 2 && !one_cell) ? cellx : 0u);
+            unsigned yad = (unsigned)reinterpret_cast<uintptr_t>(buf + ybase) + (unsigned)(cc * a.ps * FY + (lane & 15)) * 16u + ((kb >= 2 && !one_cell) ? celly : 0u);
+            unsigned nad0 = xside ? (unsigned)reinterpret_cast<uintptr_t>(buf) + (unsigned)(cc * a.ps * FX + tid) * 16u + 12u
+                                  : (yside ? (unsigned)reinterpret_cast<uintptr_t>(buf + ybase) + (unsigned)(cc * a.ps * FY + tid - NXT) * 16u + 12u
+                                           : (unsigned)reinterpret_cast<uintptr_t>(buf));
+            unsigned nad1 = nad0 + (nstep2 >> 1);
+            // The reads and their wait are asm statements fenced by scheduling barriers (as in v5), or hipcc folds them back next to their use.
+            {
+                u32x4_t a0, b0[TYT];
+                unsigned n00, n01;
+                constexpr auto tiles = std::make_integer_sequence<int, TYT>{};
+#define VL3D_NN6_ISSUE(A, N0, N1, B)                                                                      \
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %5"                        \
+                 : "=&v"(A), "=&v"(N0), "=&v"(N1) : "v"(xad), "v"(nad0), "v"(nad1) : "memory");           \
+    nn6_issue_tiles(B, yad, tiles);                                                                       \
+    __builtin_amdgcn_sched_barrier(0)
+#define VL3D_NN6_WAIT(A, N0, N1, B)                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A), "+v"(N0), "+v"(N1)::"memory");                         \
+    _Pragma("unroll") for (int j = 0; j < TYT; ++j) asm volatile("" : "+v"(B[j])::"memory")
+#define VL3D_NN6_NEXT(C)      /* addresses of chunk C + 1 */                                             \
+    {                                                                                                     \
+        const bool last_ = (C) + 2 >= nch;                                                                \
+        xad += last_ ? xstepL : xstep2; yad += last_ ? ystepL : ystep2;                                   \
+        nad0 += nstep2; nad1 += nstep2;                                                                   \
+    }
+#define VL3D_NN6_MMA(C, A, N0, N1, B)                                                                     \
+    {                                                                                                     \
+        u32x4_t s_;                                                                                       \
+        s_.x = lo_blk ? A.y : A.x;                                                                        \
+        s_.y = A.x & ymask;                                                                               \
+        s_.z = __builtin_amdgcn_perm(A.z, A.z, zsel);                                                     \
+        s_.w = 0u;                                                                                        \
+        const bool odd_ = 2 * (C) + 1 >= a.ps;            /* (uniform) the chunk's second cell does not exist */ \
+        if (odd_ && kb >= 2) { s_.x = 0u; s_.y = 0u; s_.z = 0u; }                                         \
+        const f16x8_t af_ = __builtin_bit_cast(f16x8_t, s_);                                              \
+        _Pragma("unroll") for (int j = 0; j < TYT; ++j)                                                   \
+            R[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af_, __builtin_bit_cast(f16x8_t, B[j]), R[j], 0, 0, 0); \
+        Rn = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, N0), ones, Rn, false);                    \
+        if (!odd_) Rn = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, N1), ones, Rn, false);         \
+    }
+                if constexpr (DB) {
+                    u32x4_t a1, b1[TYT];
+                    unsigned n10, n11;
+                    VL3D_NN6_ISSUE(a0, n00, n01, b0);
+                    VL3D_NN6_WAIT(a0, n00, n01, b0);
+                    int c = 0;
+                    for (; c + 1 < nch; c += 2) {
+                        VL3D_NN6_NEXT(c);
+                        VL3D_NN6_ISSUE(a1, n10, n11, b1);
+                        VL3D_NN6_MMA(c, a0, n00, n01, b0);
+                        VL3D_NN6_WAIT(a1, n10, n11, b1);
+                        if (c + 2 < nch) {
+                            VL3D_NN6_NEXT(c + 1);
+                            VL3D_NN6_ISSUE(a0, n00, n01, b0);
+                        }
+                        VL3D_NN6_MMA(c + 1, a1, n10, n11, b1);
+                        if (c + 2 < nch) {
+                            VL3D_NN6_WAIT(a0, n00, n01, b0);
+                        }
+                    }
+                    if (c < nch) { VL3D_NN6_MMA(c, a0, n00, n01, b0); }
+                } else {
+                    for (int c = 0; c < nch; ++c) {
+                        VL3D_NN6_ISSUE(a0, n00, n01, b0);
+                        VL3D_NN6_WAIT(a0, n00, n01, b0);
+                        VL3D_NN6_MMA(c, a0, n00, n01, b0);
+                        VL3D_NN6_NEXT(c);
+                    }
+                }
+#undef VL3D_NN6_ISSUE
+#undef VL3D_NN6_WAIT
+#undef VL3D_NN6_NEXT
+#undef VL3D_NN6_MMA
+            }
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+                if (q == l * a.stride + a.ps - 1) {   // ... and ends at this one
+#pragma unroll
+                    for (int j = 0; j < TYT; ++j) acc[l][j] += R[j];
+                    an[l] += Rn;
+                }
+        }
+    }
+    // epilogue.  C/D layout of a 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg
+    const int sub = tid & 3;
+    __syncthreads();                                             // the staging buffers are dead from here on
+    if (xside) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) sx[l * NXT + tid] = an[l];
+    } else if (tid < NXT) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) sx[l * NXT + tid] = 0.f;
+    }
+    if (tid >= NXT && tid - NXT < a.TyP) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) sy[l * a.TyP + tid - NXT] = yside ? an[l] : 0.f;
+    }
+    if constexpr (XS == 16) {
+        // one location at a time through the shared E buffer, the whole workgroup on it (v5's epilogue)
+        for (int j = tid; j < NL * n2p; j += NTHR) reinterpret_cast<int *>(colw)[(j / n2p) * 3 * n2p + j % n2p] = 0x7f800000;     // column minima start at +inf
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            if (l >= nloc) break;                                    // uniform
+            __syncthreads();                                         // sx / sy written / the previous location's E read
+            float syv[TYT];
+#pragma unroll
+            for (int j = 0; j < TYT; ++j) syv[j] = sy[l * a.TyP + min(j * 16 + (lane & 15), a.TyP - 1)];
+            const float4 sxv = *reinterpret_cast<const float4 *>(sx + l * NXT + wave * 16 + (lane >> 4) * 4);
+            const float sxa[4] = {sxv.x, sxv.y, sxv.z, sxv.w};
+#pragma unroll
+            for (int j = 0; j < TYT; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int row = wave * 16 + (lane >> 4) * 4 + rr, col = j * 16 + (lane & 15);
+                    if (row < a.TxP && col < a.TyP) E[row * a.TyP + col] = fmaxf(acc[l][j][rr] + (sxa[rr] + syv[j]), 0.0f);
+                }
+            __syncthreads();
+            const size_t b = (size_t)by * a.w_o + bx0 + l;
+            if VL3D_ABLATE(a.ablate, 1) { if (tid < a.n1) a.nn[b * a.n1 + tid] = 0; continue; }
+            nn_epilogue<NTHR, true>(a, E, colw + l * 3 * n2p, n2p, b, tid, sub);
+        }
+    } else {
+        // every wave finishes the 14 patches whose frames it holds, through its own slab: no workgroup barrier between the locations
+        __syncthreads();                                         // sx / sy written
+        float *Ew = E + wave * 17 * EP;
+        const int i0 = XS * wave, nrow = min(XS, a.n1 - i0);      // (may be <= 0: a wave past the last patch)
+        const int irow = lane >> 2;
+        float sxa[NL][4];
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) sxa[l][rr] = sx[l * NXT + min(i0 + (lane >> 4) * 4 + rr, NXT - 1)];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            if (l >= nloc) break;                                    // uniform
+            float syv[TYT];
+#pragma unroll
+            for (int j = 0; j < TYT; ++j) syv[j] = sy[l * a.TyP + min(j * 16 + (lane & 15), a.TyP - 1)];
+#pragma unroll
+            for (int j = 0; j < TYT; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int col = j * 16 + (lane & 15);
+                    if (col < a.TyP) Ew[((lane >> 4) * 4 + rr) * EP + col] = fmaxf(acc[l][j][rr] + (sxa[l][rr] + syv[j]), 0.0f);
+                }
+            const size_t b = (size_t)by * a.w_o + bx0 + l;
+            if VL3D_ABLATE(a.ablate, 1) { if (lane < nrow) a.nn[b * a.n1 + i0 + lane] = 0; continue; }
+            const int bj = nn_argmin_rows3(Ew, EP, a.n2, irow, irow < nrow, sub);
+            if (irow < nrow && sub == 0) a.nn[b * a.n1 + i0 + irow] = bj;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // get_NN_indices_low_memory on MATERIALISED patches (utils_vid.py:122-142; used by evaluations/NNMSE.py:45-56):
 // X [B,n1,d], Y [B,n2,d] dense.  One workgroup per batch entry b; dist[i][j] = sum_k (X[b,i,k]-Y[b,j,k])^2 / d kept in LDS.
 // API-parity kernel (the training loss never materialises patches); plain VALU, K staged in chunks.
@@ -1214,31 +1576,123 @@ static inline int pad16(int t) { return (t + 15) / 16 * 16; }
 extern "C" int64_t vl3d_patchnn_scratch_bytes(const vl3d_loss_desc *d) {
     if (!d || d->H <= 0 || d->W <= 0) return 0;
     const int TxU = ((d->Tx - d->pt) / d->stridet) * d->stridet + d->pt;
-    return (int64_t)d->H * d->W * 4 * (pad16(TxU) + pad16(d->Ty)) * (int64_t)sizeof(float);   // the gram-major form (v5): 4 floats per pixel and frame, whole 16-frame groups
+    // the larger of the two matrix-core forms: v5 gram-major (4 floats per pixel and frame, whole 16-frame groups) and v6 gram16 (16 bytes
+    // per pixel and frame, exact frame counts)
+    return (int64_t)d->H * d->W * 4 * (pad16(TxU) + pad16(d->Ty)) * (int64_t)sizeof(float);
 }
 
-// y_gram != nullptr: y arrives in the NN kernel's own gram-major form (vl3d_video_to_gram_major), as the crop at (y_row0, y_col0) of a
-// clip whose rows are y_pitch pixels long -- the captured video is constant training data, so it is rewritten once per pyramid level and
-// not once per iteration
-static int patchnn_impl(const vl3d_loss_desc *desc, const float *x, const float *y, const float *y_gram, int32_t y_pitch, int32_t y_row0,
-                        int32_t y_col0, int32_t *nn, void *scratch, vl3d_stream_t stream) {
+// The split-f16 matrix-core kernel (v6) and its plan: instantiation, stage size, LDS bytes.  x in at most 16 NW frames (NW = 4 / 8 waves),
+// y in at most 16 TYT (5 tiles x 4 locations, 8 x 2, 12 x 1 per wave).
+struct NN6Plan { int nw, tyt, nl, ch, xs; size_t lds; bool ok; };
+static NN6Plan plan_nn6(const NNArgs &a, int W, int Wy, int Ty, bool wave_epilogue) {
+    NN6Plan p{};
+    const int FX = a.TxU, FY = Ty, TyT = (FY + 15) / 16;
+    p.nw = FX <= 64 ? 4 : 8;
+    // every wave finishes its own 14 patches (no alpha, three-frame patches at temporal stride 1, and the clip fits the overlapping tiles)
+    p.xs = (wave_epilogue && !a.use_alpha && a.pt == 3 && a.stridet == 1 && a.n1 <= 14 * (FX <= 58 ? 4 : 8) && FX <= 14 * (FX <= 58 ? 4 : 8) + 2) ? 14 : 16;
+    if (p.xs == 14) p.nw = FX <= 58 ? 4 : 8;
+    p.tyt = TyT <= 5 ? 5 : (TyT <= 8 ? 8 : 12);
+    p.nl = p.tyt == 5 ? 4 : (p.tyt == 8 ? 2 : 1);
+    const int RWc = a.ps + (p.nl - 1) * a.stride;
+    const size_t cell = (size_t)16 * (FX + FY), over = (size_t)(16 * p.tyt - FY + 16 * p.nw) * 16;      // (the tiles' over-read past the last cell)
+    int ch = (int)((53 * 1024 / 2) / (cell * a.ps));
+    p.ch = ch < 1 ? 1 : (ch > RWc ? RWc : ch);
+    const size_t stage = 2 * (size_t)p.ch * a.ps * cell + over;
+    const int EP = ((a.TyP + 3) & ~7) + 4;
+    const size_t ebuf = p.xs == 16 ? (size_t)a.TxP * a.TyP : (size_t)p.nw * 17 * EP;
+    const size_t epi = (ebuf + (size_t)p.nl * (3 * ((a.n2 + 3) & ~3) + a.TyP + 16 * p.nw)) * sizeof(float);
+    p.lds = stage > epi ? stage : epi;
+    p.ok = FX <= 16 * p.nw && TyT <= 12 && p.lds <= 150 * 1024 &&
+           (size_t)p.ch * a.ps * FX <= (size_t)4 * p.nw * 64 && (size_t)p.ch * a.ps * FY <= (size_t)(2 * p.tyt > 7 ? 7 : 2 * p.tyt) * p.nw * 64 &&   // KX / KY pieces per wave
+           ((size_t)a.ps * W + p.ch) * (size_t)(FX > FY ? FX : FY) < (1u << 24) && ((size_t)a.ps * Wy + p.ch) * (size_t)FY < (1u << 24) &&   // 24-bit DMA offsets
+           16 * p.nw + a.TyP <= 64 * p.nw;                                                                             // side threads
+    return p;
+}
+
+// variant bit 10 (0x400): one operand register set (three waves per SIMD) instead of two; bit 11 (0x800): workgroup-wide epilogue also without alpha
+static int launch_nn6(const NN6Plan &p, const NN2Args &b, int w_o, int h_o, bool db, hipStream_t s) {
+    const int groups_x = (w_o + p.nl - 1) / p.nl;
+    const dim3 grid6((unsigned)(groups_x * h_o));
+#define VL3D_LAUNCH6(TYT_, NL_, NW_, DB_, XS_)                                                                                     \
+    {                                                                                                                              \
+        static bool attr = false;                                                                                                  \
+        if (!attr) {                                                                                                               \
+            VL3D_HIP(hipFuncSetAttribute((const void *)patchnn6_k<TYT_, NL_, NW_, DB_, XS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr = true;                                                                                                           \
+        }                                                                                                                          \
+        hipLaunchKernelGGL((patchnn6_k<TYT_, NL_, NW_, DB_, XS_>), grid6, dim3(64 * NW_), p.lds, s, b, groups_x, p.ch);             \
+    }
+#define VL3D_LAUNCH6_T(NW_, DB_, XS_)                                                                                              \
+    if (p.tyt == 5) VL3D_LAUNCH6(5, 4, NW_, DB_, XS_) else if (p.tyt == 8) VL3D_LAUNCH6(8, 2, NW_, DB_, XS_) else VL3D_LAUNCH6(12, 1, NW_, DB_, XS_)
+#define VL3D_LAUNCH6_X(NW_, DB_)                                                                                                   \
+    if (p.xs == 14) { VL3D_LAUNCH6_T(NW_, DB_, 14) } else { VL3D_LAUNCH6_T(NW_, DB_, 16) }
+    if (p.nw == 4) {
+        if (db) { VL3D_LAUNCH6_X(4, true) } else { VL3D_LAUNCH6_X(4, false) }
+    } else {
+        if (db) { VL3D_LAUNCH6_X(8, true) } else { VL3D_LAUNCH6_X(8, false) }
+    }
+#undef VL3D_LAUNCH6_X
+#undef VL3D_LAUNCH6_T
+#undef VL3D_LAUNCH6
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
+// x_gram / y_gram != nullptr: that video arrives in the NN kernel's own gram16 form (vl3d_video_to_gram_major / vl3d_loop_pad_fwd), y as the
+// crop at (y_row0, y_col0) of a clip whose rows are y_pitch pixels long -- the captured video is constant training data, so it is
+// rewritten once per pyramid level and not once per iteration; the render's x is written in that form by the loss prologue
+static int patchnn_impl(const vl3d_loss_desc *desc, const float *x, const float *x_gram, const float *y, const float *y_gram, int32_t y_pitch,
+                        int32_t y_row0, int32_t y_col0, int32_t *nn, void *scratch, vl3d_stream_t stream) {
     int rc = check_loss(desc);
     if (rc != VL3D_OK) return rc;
-    VL3D_REQUIRE(x && (y || y_gram) && nn, "vl3d_patchnn: null pointer");
+    VL3D_REQUIRE((x || x_gram) && (y || y_gram) && nn, "vl3d_patchnn: null pointer");
     NNArgs a{};
     size_t lds = 0;
     rc = plan_nn(desc, a, lds);
     if (rc != VL3D_OK) return rc;
-    VL3D_REQUIRE(!y_gram || scratch, "vl3d_patchnn_prepared: needs the scratch buffer (x's gram-major copy)");
-    if (scratch != nullptr && ((desc->variant & 0xf) != 1 || y_gram)) {
-        // pixel-major (v2 / v4) or gram-major (v5) copies in the caller's scratch, then the coalesced-staging kernel
+    VL3D_REQUIRE(!(y_gram && !x_gram) || scratch, "vl3d_patchnn_prepared: needs the scratch buffer (x's gram16 copy)");
+    if (scratch != nullptr || (x_gram && y_gram)) {
         hipStream_t s = (hipStream_t)stream;
         const int pv = desc->variant & 0xf;
-        // v5 (matrix cores) whenever x's frames fit the waves' 16-frame groups (4 waves: <= 64 frames, 8 waves: <= 128) and y's its column
-        // tiles (5 tiles x 4 locations, 8 x 2, 12 x 1 per wave)
+        VL3D_REQUIRE(!(x_gram || y_gram) || pv == 0 || pv == 6, "vl3d_patchnn: prepared (gram16) inputs run on the default kernel only");
+        const int Wy = y_gram ? y_pitch : desc->W;
+        NN2Args b{};
+        b.nn = nn; b.W = desc->W; b.ps = a.ps; b.pt = a.pt; b.stride = a.stride; b.stridet = a.stridet;
+        b.h_o = a.h_o; b.w_o = a.w_o; b.n1 = a.n1; b.n2 = a.n2; b.TxP = a.TxP; b.TyP = a.TyP; b.K = a.K; b.KC = a.KC;
+        b.use_alpha = a.use_alpha; b.alpha = a.alpha; b.dnorm = a.inv_d;
+        b.Wy = Wy;
+        b.ablate = (desc->variant >> 4) & 15;
+        dim3 tg((desc->W + 63) / 64, desc->H);
+        // v6 (split-f16 matrix cores): the default wherever the clip lengths fit its instantiations
+        const NN6Plan p6 = plan_nn6(a, desc->W, Wy, desc->Ty, !(desc->variant & 0x800));
+        const bool v4_has_tiles = (size_t)(a.TxP / TI) * (a.TyP / TJ) <= 1024;
+        const bool use_v6 = p6.ok && (x_gram || y_gram || pv == 6 || (pv == 0 && !(p6.nl == 1 && v4_has_tiles)));
+        if ((x_gram || y_gram) && !use_v6) {
+            vl3d_set_error("vl3d_patchnn_prepared: these clip lengths / this frame width are outside the matrix-core kernel's range; use vl3d_patchnn");
+            return VL3D_EUNSUPPORTED;
+        }
+        if (use_v6) {
+            uint4 *xs = (uint4 *)scratch;
+            if (!x_gram)
+                hipLaunchKernelGGL(video_to_gram16_k<false>, tg, dim3(256), 0, s, x, desc->x_sc, desc->x_st, desc->x_sr, a.TxU, desc->H, desc->W, xs);
+            const uint4 *ys = nullptr;
+            if (y_gram) ys = reinterpret_cast<const uint4 *>(y_gram) + ((size_t)y_row0 * Wy + y_col0) * desc->Ty;
+            else {
+                // (the y copy sits behind the x copy of the largest x this scratch can hold: its place does not depend on x_gram)
+                uint4 *yd = xs + (size_t)desc->H * desc->W * a.TxU;
+                // variant bit 8: the y half of the scratch still holds this y from the previous call
+                if (!(desc->variant & 0x100))
+                    hipLaunchKernelGGL(video_to_gram16_k<true>, tg, dim3(256), 0, s, y, desc->y_sc, desc->y_st, desc->y_sr, desc->Ty, desc->H, desc->W, yd);
+                ys = yd;
+            }
+            b.xt = x_gram ? x_gram : reinterpret_cast<const float *>(xs);
+            b.yt = reinterpret_cast<const float *>(ys);
+            b.PX = a.TxU; b.PY = desc->Ty;
+            return launch_nn6(p6, b, a.w_o, a.h_o, !(desc->variant & 0x400), s);
+        }
+        // v5 (fp32 matrix cores; explicit variant 3 only, kept for A/B) whenever x's frames fit the waves' 16-frame groups (4 waves: <= 64 frames,
+        // 8 waves: <= 128 frames) and y's its column tiles (5 tiles x 4 locations, 8 x 2, 12 x 1 per wave)
         const int PX = pad16(a.TxU), PY = pad16(desc->Ty), TyT = PY / 16;
-        // (8 / 6 locations per workgroup -- 4.9 / 5.2 instead of 5.75 region columns per location -- need 237 / 195 registers = two workgroups
-        // per CU: 2.81 / 2.87 ms against 2.68 in one process)
         const int nw5 = PX <= 64 ? 4 : 8;
         const int tyt5 = TyT <= 5 ? 5 : (TyT <= 8 ? 8 : 12), nl5 = tyt5 == 5 ? 4 : (tyt5 == 8 ? 2 : 1);
         const int RWc5 = a.ps + (nl5 - 1) * a.stride;
@@ -1250,29 +1704,13 @@ static int patchnn_impl(const vl3d_loss_desc *desc, const float *x, const float 
         const size_t lds5 = stage5 > epi5 ? stage5 : epi5;
         const bool fits5 = (size_t)ch5 * a.ps * PX <= (size_t)4 * nw5 * 64 && (size_t)ch5 * a.ps * PY <= (size_t)7 * nw5 * 64 &&  // KX / KY pieces per wave
                            ((size_t)a.ps * desc->W + ch5) * (PX > PY ? PX : PY) < (1u << 24);                  // 24-bit DMA source offsets
-        // (the default wherever it applies: 2.52 vs 3.55 ms for v4 at 720p with 11-pixel patches at stride 4, 2.45 vs 2.54 ms with 3-pixel
-        // patches at stride 2, profiles/ab_loss.py)
-        // (... and for the long clips of cfg4 / cfg5, 720p, it/s of a loss iteration v5 | v4: 82 x 75 frames 118 | 92, 82 x 120: 72 | 68,
-        // 122 x 180: 38 | 14, 52 x 120: 124 | 93; the one-location instantiation loses to v4's running sums where v4 still has a tile per
-        // thread: 82 x 150: 41 | 56 -- v4 there)
-        const bool v4_has_tiles = (size_t)(a.TxP / TI) * (a.TyP / TJ) <= 1024;
-        const int Wy = y_gram ? y_pitch : desc->W;
-        const bool fits5y = ((size_t)a.ps * Wy + ch5) * (size_t)PY < (1u << 24);
-        const bool use_v5 = (y_gram || pv == 3 || (pv == 0 && !(nl5 == 1 && v4_has_tiles))) && PX <= 128 && TyT <= 12 && lds5 <= 150 * 1024 && fits5 && fits5y;
-        if (y_gram && !use_v5) {
-            vl3d_set_error("vl3d_patchnn_prepared: these clip lengths / this frame width are outside the matrix-core kernel's range; use vl3d_patchnn");
-            return VL3D_EUNSUPPORTED;
-        }
+        const bool use_v5 = pv == 3 && PX <= 128 && TyT <= 12 && lds5 <= 150 * 1024 && fits5;
         float *xt = (float *)scratch;
-        float *yt = y_gram ? const_cast<float *>(y_gram) + ((size_t)y_row0 * Wy + y_col0) * 4 * PY
-                           : xt + (size_t)desc->H * desc->W * (use_v5 ? 4 * PX : 3 * a.TxP);
-        dim3 tg((desc->W + 63) / 64, desc->H);
-        // variant bit 8: the y half of the scratch still holds this y from the previous call (the captured video is constant
-        // over the iterations of the training loop; the caller keeps the scratch alive and vouches for it)
+        float *yt = xt + (size_t)desc->H * desc->W * (use_v5 ? 4 * PX : 3 * a.TxP);
         if (use_v5) {
             hipLaunchKernelGGL(video_to_gram_major_k<false>, tg, dim3(256), 0, s, x, desc->x_sc, desc->x_st, desc->x_sr, a.TxU, PX / 16,
                                desc->H, desc->W, xt);
-            if (!y_gram && !(desc->variant & 0x100))
+            if (!(desc->variant & 0x100))
                 hipLaunchKernelGGL(video_to_gram_major_k<true>, tg, dim3(256), 0, s, y, desc->y_sc, desc->y_st, desc->y_sr, desc->Ty, PY / 16,
                                    desc->H, desc->W, yt);
         } else {
@@ -1282,12 +1720,8 @@ static int patchnn_impl(const vl3d_loss_desc *desc, const float *x, const float 
                 hipLaunchKernelGGL(video_to_pixel_major_k, tg, dim3(256), 0, s, y, desc->y_sc, desc->y_st, desc->y_sr, desc->Ty, a.TyP,
                                    desc->H, desc->W, yt);
         }
-        NN2Args b{};
-        b.xt = xt; b.yt = yt; b.nn = nn; b.W = desc->W; b.ps = a.ps; b.pt = a.pt; b.stride = a.stride; b.stridet = a.stridet;
-        b.h_o = a.h_o; b.w_o = a.w_o; b.n1 = a.n1; b.n2 = a.n2; b.TxP = a.TxP; b.TyP = a.TyP; b.K = a.K; b.KC = a.KC;
-        b.use_alpha = a.use_alpha; b.alpha = a.alpha; b.dnorm = a.inv_d;
-        b.PX = PX; b.PY = PY; b.Wy = Wy;
-        b.ablate = (desc->variant >> 4) & 15;
+        b.xt = xt; b.yt = yt;
+        b.PX = PX; b.PY = PY;
         static bool attr2 = false;
         if (!attr2) {
             VL3D_HIP(hipFuncSetAttribute((const void *)patchnn2_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1356,18 +1790,18 @@ static int patchnn_impl(const vl3d_loss_desc *desc, const float *x, const float 
 
 extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const float *y, int32_t *nn, void *scratch,
                             vl3d_stream_t stream) {
-    return patchnn_impl(desc, x, y, nullptr, 0, 0, 0, nn, scratch, stream);
+    return patchnn_impl(desc, x, nullptr, y, nullptr, 0, 0, 0, nn, scratch, stream);
 }
 
 extern "C" int64_t vl3d_gram_major_bytes(int32_t T, int32_t H, int32_t W) {
     if (T <= 0 || H <= 0 || W <= 0) return 0;
-    return (int64_t)H * W * 4 * pad16(T) * (int64_t)sizeof(float);
+    return (int64_t)H * W * T * 16;
 }
 
 extern "C" int vl3d_video_to_gram_major(const float *y, int64_t sc, int64_t st, int64_t sr, int32_t T, int32_t H, int32_t W, float *out,
                                         vl3d_stream_t stream) {
     VL3D_REQUIRE(y && out && T > 0 && H > 0 && W > 0, "vl3d_video_to_gram_major: null pointer / non-positive dims");
-    hipLaunchKernelGGL(video_to_gram_major_k<true>, dim3((W + 63) / 64, H), dim3(256), 0, (hipStream_t)stream, y, sc, st, sr, T, pad16(T) / 16, H, W, out);
+    hipLaunchKernelGGL(video_to_gram16_k<true>, dim3((W + 63) / 64, H), dim3(256), 0, (hipStream_t)stream, y, sc, st, sr, T, H, W, (uint4 *)out);
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
 }
@@ -1377,7 +1811,7 @@ extern "C" int vl3d_patchnn_prepared(const vl3d_loss_desc *desc, const float *x,
     VL3D_REQUIRE(desc && y_gram, "vl3d_patchnn_prepared: null pointer");
     VL3D_REQUIRE(y_row0 >= 0 && y_col0 >= 0 && y_row0 + desc->H <= y_rows && y_col0 + desc->W <= y_pitch,
                  "vl3d_patchnn_prepared: the crop (y_row0, y_col0) + (H, W) leaves the prepared clip (y_rows, y_pitch)");
-    return patchnn_impl(desc, x, nullptr, y_gram, y_pitch, y_row0, y_col0, nn, scratch, stream);
+    return patchnn_impl(desc, x, nullptr, nullptr, y_gram, y_pitch, y_row0, y_col0, nn, scratch, stream);
 }
 
 // LDS-staged fold: tile shapes {FT_W, FT_H, threads}.  The whole Ty column of a tile has to sit in LDS (an NN index may point at
