@@ -876,54 +876,65 @@ __device__ __forceinline__ void nn6_issue_tiles(u32x4_t (&b)[N], unsigned addr, 
 }
 
 // One wave's rows of a location, no alpha, pt = 3, stridet = 1: s(i, j) = E(i, j) + E(i + 1, j + 1) + E(i + 2, j + 2) over the wave's slab
-// E [16][EP]; first minimum over j, NaN minimal (torch.argmin); 4 lanes per row, each a quarter of whole column groups.  Returns the index
-// (valid in the lanes with sub == 0).
+// E [16][EP]; first minimum over j; 4 lanes per row, each a quarter of whole column groups.  The slab holds fmaxf(., 0) of finite sums:
+// no NaN can reach the comparison (a NaN accumulator is stored as 0), so it is a plain `<` -- a compare, an index select and a min per
+// column instead of the NaN-aware form's seven instructions.  Returns the index (valid in the lanes with sub == 0).
 __device__ __forceinline__ int nn_argmin_rows3(const float *E, int EP, int n2, int i, bool active, int sub) {
     const float4 *E4 = reinterpret_cast<const float4 *>(E);
     const int q4 = ((n2 + 3) / 4 + 3) & ~3, j0 = sub * q4, j1 = min(n2, j0 + q4);
     float best = INFINITY;
     int bj = j0;
-    bool best_nan = false;
     if (active && j0 < j1) {
         const float4 *p = E4 + (i * EP + j0) / 4;
         float4 l1 = p[EP / 4], l2 = p[EP / 2];
-        for (int jb = j0; jb < j1; jb += 4, ++p) {
+        int jb = j0;
+        for (; jb + 3 < j1; jb += 4, ++p) {
             const float4 c0 = p[0], h1 = p[EP / 4 + 1], h2 = p[EP / 2 + 1];
             const float sa[4] = {(c0.x + l1.y) + l2.z, (c0.y + l1.z) + l2.w, (c0.z + l1.w) + h2.x, (c0.w + h1.x) + h2.y};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float v = sa[u];
-                const bool vn = (v != v);
-                if (jb + u < j1 && !best_nan && (vn || v < best)) { best = v; bj = jb + u; best_nan = vn; }
+                bj = sa[u] < best ? jb + u : bj;
+                best = fminf(best, sa[u]);
             }
             l1 = h1; l2 = h2;
+        }
+        if (jb < j1) {                                            // the quarter's last, partial group
+            const float4 c0 = p[0], h1 = p[EP / 4 + 1], h2 = p[EP / 2 + 1];
+            const float sa[4] = {(c0.x + l1.y) + l2.z, (c0.y + l1.z) + l2.w, (c0.z + l1.w) + h2.x, (c0.w + h1.x) + h2.y};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (jb + u < j1) {
+                    bj = sa[u] < best ? jb + u : bj;
+                    best = fminf(best, sa[u]);
+                }
         }
     }
 #pragma unroll
     for (int step = 1; step <= 2; step <<= 1) {      // combine the 4 quarters in ascending-j order so that ties keep the lowest index
         const float ob = __shfl_xor(best, step, 64);
         const int oj = __shfl_xor(bj, step, 64);
-        const int on = __shfl_xor((int)best_nan, step, 64);
         const bool other_lower = (sub & step) != 0;
-        bool take;
-        if (best_nan || on) take = on && (!best_nan || other_lower);
-        else take = (ob < best) || (ob == best && other_lower);
-        if (take) { best = ob; bj = oj; best_nan = on != 0; }
+        const bool take = (ob < best) || (ob == best && other_lower);
+        if (take) { best = ob; bj = oj; }
     }
     return bj;
 }
 
+constexpr int NN6_KX = 3;
+constexpr int nn6_ky(int tyt) { return tyt == 5 ? 4 : (tyt == 8 ? 6 : 7); }
+
 // NN2Args: PX / PY = frames per pixel of the gram16 x / y (exact, no padding); xt / yt = the gram16 buffers (16-byte pieces).
-// DB: operands of chunk c + 1 in flight during the MFMAs of chunk c (two register sets) or one set (fewer registers: three waves per SIMD).
+// One operand register set: a second one (the reads of chunk c + 1 in flight during the MFMAs of chunk c) takes 202 registers = two waves
+// per SIMD and measured 1.76 / 1.93 ms against 1.54 / 1.47 ms with three (720p, ref / other cfg): the other waves hide the reads better.
 // XS: first x frame of wave w is XS * w.  16: the waves' tiles abut, the epilogue runs workgroup-wide through the shared E (v5's).  14: the
 // tiles overlap by pt - 1 = 2 frames, so wave w holds every frame pair of its 14 patches: each wave finishes its own rows through a
 // private 16-row slab, no workgroup barrier between the locations (no alpha, pt = 3, stridet = 1 only: the column minima of the alpha
 // path need all rows).
-template <int TYT, int NL, int NW, bool DB, int XS>
-__global__ __launch_bounds__(64 * NW, (DB || NW > 4) ? 2 : 3) void patchnn6_k(NN2Args a, int groups_x, int CHC) {
+template <int TYT, int NL, int NW, int XS>
+__global__ __launch_bounds__(64 * NW, TYT == 5 ? 3 : 2) void patchnn6_k(NN2Args a, int groups_x, int CHC) {
     constexpr int NTHR = 64 * NW, NXT = 16 * NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int KX = 4, KY = 2 * TYT > 7 ? 7 : 2 * TYT;       // DMA pieces per wave and stage at most
+    constexpr int KX = NN6_KX, KY = nn6_ky(TYT);                // DMA pieces per wave and stage at most (their source offsets live in registers)
     const int RWc = a.ps + (NL - 1) * a.stride;                 // region width in pixels
     const int FX = a.PX, FY = a.PY;
     const int xs4 = CHC * a.ps * FX, ys4 = CHC * a.ps * FY;       // 16-byte pieces per stage and part
@@ -1048,34 +1059,11 @@ __global__ __launch_bounds__(64 * NW, (DB || NW > 4) ? 2 : 3) void patchnn6_k(NN
         Rn = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, N0), ones, Rn, false);                    \
         if (!odd_) Rn = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, N1), ones, Rn, false);         \
     }
-                if constexpr (DB) {
-                    u32x4_t a1, b1[TYT];
-                    unsigned n10, n11;
+                for (int c = 0; c < nch; ++c) {
                     VL3D_NN6_ISSUE(a0, n00, n01, b0);
                     VL3D_NN6_WAIT(a0, n00, n01, b0);
-                    int c = 0;
-                    for (; c + 1 < nch; c += 2) {
-                        VL3D_NN6_NEXT(c);
-                        VL3D_NN6_ISSUE(a1, n10, n11, b1);
-                        VL3D_NN6_MMA(c, a0, n00, n01, b0);
-                        VL3D_NN6_WAIT(a1, n10, n11, b1);
-                        if (c + 2 < nch) {
-                            VL3D_NN6_NEXT(c + 1);
-                            VL3D_NN6_ISSUE(a0, n00, n01, b0);
-                        }
-                        VL3D_NN6_MMA(c + 1, a1, n10, n11, b1);
-                        if (c + 2 < nch) {
-                            VL3D_NN6_WAIT(a0, n00, n01, b0);
-                        }
-                    }
-                    if (c < nch) { VL3D_NN6_MMA(c, a0, n00, n01, b0); }
-                } else {
-                    for (int c = 0; c < nch; ++c) {
-                        VL3D_NN6_ISSUE(a0, n00, n01, b0);
-                        VL3D_NN6_WAIT(a0, n00, n01, b0);
-                        VL3D_NN6_MMA(c, a0, n00, n01, b0);
-                        VL3D_NN6_NEXT(c);
-                    }
+                    VL3D_NN6_MMA(c, a0, n00, n01, b0);
+                    VL3D_NN6_NEXT(c);
                 }
 #undef VL3D_NN6_ISSUE
 #undef VL3D_NN6_WAIT
@@ -1596,42 +1584,41 @@ static NN6Plan plan_nn6(const NNArgs &a, int W, int Wy, int Ty, bool wave_epilog
     const int RWc = a.ps + (p.nl - 1) * a.stride;
     const size_t cell = (size_t)16 * (FX + FY), over = (size_t)(16 * p.tyt - FY + 16 * p.nw) * 16;      // (the tiles' over-read past the last cell)
     int ch = (int)((53 * 1024 / 2) / (cell * a.ps));
-    p.ch = ch < 1 ? 1 : (ch > RWc ? RWc : ch);
+    ch = ch < 1 ? 1 : (ch > RWc ? RWc : ch);
+    while (ch > 1 && ((size_t)ch * a.ps * FX > (size_t)NN6_KX * p.nw * 64 || (size_t)ch * a.ps * FY > (size_t)nn6_ky(p.tyt) * p.nw * 64)) --ch;
+    p.ch = ch;
     const size_t stage = 2 * (size_t)p.ch * a.ps * cell + over;
     const int EP = ((a.TyP + 3) & ~7) + 4;
     const size_t ebuf = p.xs == 16 ? (size_t)a.TxP * a.TyP : (size_t)p.nw * 17 * EP;
     const size_t epi = (ebuf + (size_t)p.nl * (3 * ((a.n2 + 3) & ~3) + a.TyP + 16 * p.nw)) * sizeof(float);
     p.lds = stage > epi ? stage : epi;
     p.ok = FX <= 16 * p.nw && TyT <= 12 && p.lds <= 150 * 1024 &&
-           (size_t)p.ch * a.ps * FX <= (size_t)4 * p.nw * 64 && (size_t)p.ch * a.ps * FY <= (size_t)(2 * p.tyt > 7 ? 7 : 2 * p.tyt) * p.nw * 64 &&   // KX / KY pieces per wave
+           (size_t)p.ch * a.ps * FX <= (size_t)NN6_KX * p.nw * 64 && (size_t)p.ch * a.ps * FY <= (size_t)nn6_ky(p.tyt) * p.nw * 64 &&   // KX / KY pieces per wave
            ((size_t)a.ps * W + p.ch) * (size_t)(FX > FY ? FX : FY) < (1u << 24) && ((size_t)a.ps * Wy + p.ch) * (size_t)FY < (1u << 24) &&   // 24-bit DMA offsets
            16 * p.nw + a.TyP <= 64 * p.nw;                                                                             // side threads
     return p;
 }
 
-// variant bit 10 (0x400): one operand register set (three waves per SIMD) instead of two; bit 11 (0x800): workgroup-wide epilogue also without alpha
-static int launch_nn6(const NN6Plan &p, const NN2Args &b, int w_o, int h_o, bool db, hipStream_t s) {
+// variant bit 11 (0x800): workgroup-wide epilogue also without alpha (cross-checks)
+static int launch_nn6(const NN6Plan &p, const NN2Args &b, int w_o, int h_o, hipStream_t s) {
     const int groups_x = (w_o + p.nl - 1) / p.nl;
     const dim3 grid6((unsigned)(groups_x * h_o));
-#define VL3D_LAUNCH6(TYT_, NL_, NW_, DB_, XS_)                                                                                     \
+#define VL3D_LAUNCH6(TYT_, NL_, NW_, XS_)                                                                                          \
     {                                                                                                                              \
         static bool attr = false;                                                                                                  \
         if (!attr) {                                                                                                               \
-            VL3D_HIP(hipFuncSetAttribute((const void *)patchnn6_k<TYT_, NL_, NW_, DB_, XS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            VL3D_HIP(hipFuncSetAttribute((const void *)patchnn6_k<TYT_, NL_, NW_, XS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr = true;                                                                                                           \
         }                                                                                                                          \
-        hipLaunchKernelGGL((patchnn6_k<TYT_, NL_, NW_, DB_, XS_>), grid6, dim3(64 * NW_), p.lds, s, b, groups_x, p.ch);             \
+        hipLaunchKernelGGL((patchnn6_k<TYT_, NL_, NW_, XS_>), grid6, dim3(64 * NW_), p.lds, s, b, groups_x, p.ch);                  \
     }
-#define VL3D_LAUNCH6_T(NW_, DB_, XS_)                                                                                              \
-    if (p.tyt == 5) VL3D_LAUNCH6(5, 4, NW_, DB_, XS_) else if (p.tyt == 8) VL3D_LAUNCH6(8, 2, NW_, DB_, XS_) else VL3D_LAUNCH6(12, 1, NW_, DB_, XS_)
-#define VL3D_LAUNCH6_X(NW_, DB_)                                                                                                   \
-    if (p.xs == 14) { VL3D_LAUNCH6_T(NW_, DB_, 14) } else { VL3D_LAUNCH6_T(NW_, DB_, 16) }
+#define VL3D_LAUNCH6_T(NW_, XS_)                                                                                                   \
+    if (p.tyt == 5) VL3D_LAUNCH6(5, 4, NW_, XS_) else if (p.tyt == 8) VL3D_LAUNCH6(8, 2, NW_, XS_) else VL3D_LAUNCH6(12, 1, NW_, XS_)
     if (p.nw == 4) {
-        if (db) { VL3D_LAUNCH6_X(4, true) } else { VL3D_LAUNCH6_X(4, false) }
+        if (p.xs == 14) { VL3D_LAUNCH6_T(4, 14) } else { VL3D_LAUNCH6_T(4, 16) }
     } else {
-        if (db) { VL3D_LAUNCH6_X(8, true) } else { VL3D_LAUNCH6_X(8, false) }
+        if (p.xs == 14) { VL3D_LAUNCH6_T(8, 14) } else { VL3D_LAUNCH6_T(8, 16) }
     }
-#undef VL3D_LAUNCH6_X
 #undef VL3D_LAUNCH6_T
 #undef VL3D_LAUNCH6
     VL3D_CHECK_LAUNCH();
@@ -1688,7 +1675,7 @@ static int patchnn_impl(const vl3d_loss_desc *desc, const float *x, const float 
             b.xt = x_gram ? x_gram : reinterpret_cast<const float *>(xs);
             b.yt = reinterpret_cast<const float *>(ys);
             b.PX = a.TxU; b.PY = desc->Ty;
-            return launch_nn6(p6, b, a.w_o, a.h_o, !(desc->variant & 0x400), s);
+            return launch_nn6(p6, b, a.w_o, a.h_o, s);
         }
         // v5 (fp32 matrix cores; explicit variant 3 only, kept for A/B) whenever x's frames fit the waves' 16-frame groups (4 waves: <= 64 frames,
         // 8 waves: <= 128 frames) and y's its column tiles (5 tiles x 4 locations, 8 x 2, 12 x 1 per wave)
