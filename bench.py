@@ -148,12 +148,13 @@ def loss_bench(dev, H, W, T, Ty, steps):
         TxP, TyP = -(-(T + 2) // 4) * 4, -(-Ty // 4) * 4
         cells = (B / 4) * ps * (ps + 3 * st_)                                  # (row, column) cells of the regions
         if TxP <= 64 and TyP <= 80:
-            # v5, matrix cores: one v_mfma_f32_16x16x4_f32 per cell and 16x16 frame-pair tile, 4 x 5 tiles, k = 3 channels + the |x|^2 slot.
-            # `achieved` counts the useful multiply-adds only (3 channels x the real TxP x TyP frame pairs), `issued` what the tiles cost.
+            # v6, half-precision matrix cores at fp32-class accuracy (csrc/vl3d_loss.hip patchnn6_k): one v_mfma_f32_16x16x32_f16 per TWO cells
+            # and 16x16 frame-pair tile, 4 x 5 tiles; 9 of its 16 k slots per cell carry the three split products of the three channels.
+            # `achieved` counts the useful multiply-adds (3 channels x the real frame pairs, as one fp32 product each), `issued` what the tiles cost.
             own_flops = 2.0 * cells * 3 * TxP * TyP
-            issued = 2.0 * cells * 4 * 64 * 80
-            PEAK = 256 * 4 * 64 * 2.4e9 / 1e12                                 # fp32 MFMA: 64 flop per clock and SIMD = 157.3 TFLOP/s
-            kern, bound = "patchnn5_k (+ video_to_gram_major_k of x; y prepared once per clip)", "mfma-fp32"
+            issued = 2.0 * (cells / 2) * 32 * 64 * 80
+            PEAK = 256 * 4 * 1024 * 2.4e9 / 1e12                               # f16 MFMA: 1024 flop per clock and SIMD = 2516 TFLOP/s dense
+            kern, bound = "patchnn6_k (+ video_to_gram16_k of x; y prepared once per clip)", "mfma-f16 (split hi/lo, three products)"
         else:
             # v4, vector ALUs: (sub, fma) = 3 flop per (cell, channel, frame pair)
             own_flops = issued = 3.0 * cells * 3 * TxP * TyP
@@ -418,6 +419,7 @@ def main():
                 torch.cuda.synchronize()
                 dt1 = (time.perf_counter() - t1) / 20
                 res["cfg2_single_frame"] = {"value": H * W / dt1 / 1e6, "unit": "Mpix/s", "ms_per_step": dt1 * 1e3,
+                                            "frac": H * W * (48 * D + 24) / dt1 / 1e9 / HBM_PEAK_GBS,      # fwd+bwd algorithmic bytes / wall time / HBM peak
                                             "workload": f"D={D}, T=1, {H}x{W} render fwd+bwd (stage-1 shape)"}
                 del st1, gs1
             except Exception as e:
@@ -433,6 +435,7 @@ def main():
                 torch.cuda.synchronize()
                 dt16 = (time.perf_counter() - t1) / 4
                 res["fp16_stack_storage"] = {"value": T * H * W / dt16 / 1e6, "unit": "Mpix/s", "ms_per_step": dt16 * 1e3,
+                                             "frac": T * H * W * (24 * D + 24) / dt16 / 1e9 / HBM_PEAK_GBS,      # 8-byte texels: fwd 8 D + 12, bwd 12 + 16 D
                                              "workload": "cfg3 geometry with the plane stack and its gradient stored as fp16 (cfg5's format); fp32 arithmetic"}
                 del st16, r1, gs1
             except Exception as e:
@@ -568,25 +571,59 @@ def main():
                     return None
                 d = d[k]
             return d
-        # the numbers a reader looks for first, EARLY in the line (the detailed legs follow; a consumer that cuts the tail keeps these)
-        res["summary"] = {
-            "loss_720p_iters_per_s": {"ref": pick(res, "loss", "ref", "iters_per_s"), "other": pick(res, "loss", "other", "iters_per_s")},
-            "loss_720p_nn_ms": {"ref": pick(res, "loss", "ref", "roofline_nn", "avg_ms"), "other": pick(res, "loss", "other", "roofline_nn", "avg_ms")},
-            "loss_720p_roofline_loss_frac": {"ref": pick(res, "loss", "ref", "roofline_loss", "frac"), "other": pick(res, "loss", "other", "roofline_loss", "frac")},
-            "loss_720p_roofline_nn_frac": {"ref": pick(res, "loss", "ref", "roofline_nn", "frac"), "other": pick(res, "loss", "other", "roofline_nn", "frac")},
-            "loss_native_crop_iters_per_s": {"ref": pick(res, "loss_native_crop", "ref", "iters_per_s"), "other": pick(res, "loss_native_crop", "other", "iters_per_s")},
-            "cfg2_single_frame_mpix_s": pick(res, "cfg2_single_frame", "value"), "fp16_stack_mpix_s": pick(res, "fp16_stack_storage", "value"),
-            "reference_geometry": {"mpix_s": pick(res, "reference_geometry", "value"), "fwd_ms": pick(res, "reference_geometry", "fwd_ms"),
-                                   "bwd_ms": pick(res, "reference_geometry", "bwd_ms"), "fwd_frac": pick(res, "reference_geometry", "roofline_fwd", "frac"),
-                                   "bwd_frac": pick(res, "reference_geometry", "roofline_bwd", "frac")},
-            "stage1_iters_per_s": {k: pick(res, "stage1_step", k, "iters_per_s") for k in ("native_crop", "cfg2_720p_frame", "cfg2_720p_frame_scale1p6")},
-            "stage2_step_iters_per_s": {k: pick(res, "stage2_step", k, "iters_per_s") for k in ("ref", "other", "other_tile_culled", "other_tile_culled_packed")},
-            "stage2_schedule_iters_per_s": {k: pick(res, "stage2_schedule", k, "iters_per_s") for k in ("dense", "dense_two_kernels", "tile_culled", "tile_culled_two_kernels")},
-        }
+
+        def r4(v):
+            return float(f"{v:.4g}") if isinstance(v, (int, float)) and not isinstance(v, bool) else v
+        # Every leg in full goes to a side file (per-level arrays, histograms, footprints, workloads); the stdout line carries the headline,
+        # `roofline`, `cpu_baseline`, `build` and -- LAST, where a consumer that keeps only the tail of the line still finds it -- a flat
+        # `summary` of every leg.  The line stays under 6 KB.
+        detail_path = os.environ.get("VL3D_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+        try:
+            os.makedirs(os.path.dirname(detail_path), exist_ok=True)
+            with open(detail_path, "w") as fh:
+                json.dump(res, fh)
+        except OSError as e:
+            detail_path = f"(not written: {e})"
+        summ = {}
+        for cfg_ in ("ref", "other"):
+            summ[f"loss720_{cfg_}_it_s"] = pick(res, "loss", cfg_, "iters_per_s")
+            summ[f"loss720_{cfg_}_nn_ms"] = pick(res, "loss", cfg_, "roofline_nn", "avg_ms")
+            summ[f"loss720_{cfg_}_hbm_frac"] = pick(res, "loss", cfg_, "roofline_loss", "frac")
+            summ[f"loss720_{cfg_}_nn_mfma_frac_issued"] = pick(res, "loss", cfg_, "roofline_nn", "frac_issued")
+            summ[f"loss_crop_{cfg_}_it_s"] = pick(res, "loss_native_crop", cfg_, "iters_per_s")
+        summ["fwd_ms"], summ["fwd_frac"], summ["fwd_traffic_GB"] = r_f["avg_ms"], r_f["frac"], (r_f["traffic"] or 0) / 1e9 or None
+        summ["bwd_ms"], summ["bwd_frac"], summ["bwd_traffic_GB"] = r_b["avg_ms"], r_b["frac"], (r_b["traffic"] or 0) / 1e9 or None
+        summ["cfg2_ms"], summ["cfg2_mpix_s"] = pick(res, "cfg2_single_frame", "ms_per_step"), pick(res, "cfg2_single_frame", "value")
+        summ["cfg2_frac"] = pick(res, "cfg2_single_frame", "frac")
+        summ["fp16_ms"], summ["fp16_mpix_s"], summ["fp16_frac"] = pick(res, "fp16_stack_storage", "ms_per_step"), pick(res, "fp16_stack_storage", "value"), pick(res, "fp16_stack_storage", "frac")
+        summ["cull_ms_plain"], summ["cull_ms_culled"], summ["cull_kept"] = pick(res, "tile_culling", "ms_plain"), pick(res, "tile_culling", "ms_culled"), pick(res, "tile_culling", "kept_quads")
+        summ["refgeo_mpix_s"], summ["refgeo_fwd_ms"], summ["refgeo_bwd_ms"] = pick(res, "reference_geometry", "value"), pick(res, "reference_geometry", "fwd_ms"), pick(res, "reference_geometry", "bwd_ms")
+        summ["refgeo_fwd_frac"], summ["refgeo_bwd_frac"] = pick(res, "reference_geometry", "roofline_fwd", "frac"), pick(res, "reference_geometry", "roofline_bwd", "frac")
+        for k_, n_ in (("native_crop", "s1_crop"), ("cfg2_720p_frame", "s1_720p_1p1"), ("cfg2_720p_frame_scale1p6", "s1_720p_1p6")):
+            summ[f"{n_}_it_s"] = pick(res, "stage1_step", k_, "iters_per_s")
+        summ["s1_train_epochs_per_min"] = pick(res, "stage1_train", "epochs_per_min")
+        for k_ in ("ref", "other", "other_tile_culled", "other_tile_culled_packed"):
+            summ[f"s2step_{k_}_it_s"] = pick(res, "stage2_step", k_, "iters_per_s")
+        for k_ in ("dense", "dense_two_kernels", "tile_culled", "tile_culled_two_kernels"):
+            summ[f"s2sched_{k_}_it_s"] = pick(res, "stage2_schedule", k_, "iters_per_s")
+            summ[f"s2sched_{k_}_iter_frac"] = pick(res, "stage2_schedule", k_, "roofline_iter", "frac")
+        for k_ in list(summ):
+            if summ[k_] is None:
+                del summ[k_]
+        errors = {k: v["error"][:120] for k, v in res.items() if isinstance(v, dict) and "error" in v}
+        if errors:
+            summ["errors"] = errors
         head = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-                "stack_storage", "config", "roofline", "cpu_baseline", "build", "summary", "roofline_fwd", "roofline_bwd", "fwd_bwd_algorithmic_frac"]
-        res = {**{k: res[k] for k in head if k in res}, **{k: v for k, v in res.items() if k not in head}}
-        print(json.dumps(res), file=out, flush=True)
+                "stack_storage", "config", "frame_checksum", "collective", "loss_band", "roofline", "cpu_baseline", "build"]
+        line = {k: res[k] for k in head if k in res}
+        line["detail_file"] = os.path.relpath(detail_path, ROOT) if os.path.isabs(detail_path) else detail_path
+        line["summary"] = {k: r4(v) for k, v in summ.items()}
+        text = json.dumps(line)
+        for k_ in ("build", "collective"):      # never silently exceed what the record keeps: the longest free-text fields go first
+            if len(text) > 6000 and k_ in line:
+                line[k_] = {"see": "detail_file"}
+                text = json.dumps(line)
+        print(text, file=out, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

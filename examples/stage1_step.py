@@ -35,6 +35,8 @@ def run(iters=20, planes=32, frame=(360, 640), crop=(180, 320), scale=1.6, loop_
     model = MPMesh(args, H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
     args.optimizer, args.lrate, args.lrate_decay, args.torch_adam = "adam", 0.05, 100, torch_adam
     opt = model.get_optimizer()                                                              # MPI.py:122-141, configs/mpi_base.txt:31
+    if hasattr(opt, "acknowledge_fused_backward"):
+        opt.acknowledge_fused_backward()      # this loop steps once per backward
     a = np.radians(0.5)
     tar = np.eye(4)
     tar[:3, :3] = [[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]

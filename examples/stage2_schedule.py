@@ -82,6 +82,7 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
     gen = torch.Generator().manual_seed(2)
     out = {"levels": []}
     total_it, total_s = 0, 0.0
+    total_win = [0, 0]
     depth_hist = np.zeros(0, np.int64)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -92,6 +93,8 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
             ds = MVVidPatchDataset(hw, vids, (180, 320), (90, 160), poses, intrins, loss_configs=cfgs)
             order = [i for _ in range(epochs + 1) for i in torch.randperm(len(ds), generator=gen).tolist()]
 
+            win_texels = [0, 0]      # sum over the timed iterations of the crop window's texels per plane and frame | iterations counted
+
             def one(i, epoch):
                 for (_, lr), g in zip(model.get_lrate(epoch), opt.param_groups):
                     g["lr"] = lr / len(ds)                                     # lrate_adaptive (train_3dvid.py:281-287)
@@ -99,14 +102,26 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
             for k in range(8):                                                 # warm-up (allocator, first-call set-up)
                 one(order[k], 0)
             torch.cuda.synchronize()
+            # the crop's texel window of every timed iteration (host integers: no synchronisation), for `roofline_iter`
+            count_leaf = getattr(opt, "window_leaf", None) if getattr(model, "_window_opt", None) is opt else None
+            if count_leaf is not None:
+                def counting(window, plane_boxes=None, _orig=count_leaf):
+                    win_texels[0] += int(window[2]) * int(window[3])
+                    win_texels[1] += 1
+                    return _orig(window, plane_boxes)
+                opt.window_leaf = counting
             t0 = time.perf_counter()
             timed = order[8:8 + epochs * len(ds)]
             for k, i in enumerate(timed):
                 one(i, k // len(ds))
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            if count_leaf is not None:
+                opt.window_leaf = count_leaf
             total_it += len(timed)
             total_s += dt
+            total_win[0] += win_texels[0]
+            total_win[1] += win_texels[1]
             out["levels"].append({"frame": hw, "crops_per_view": len(ds) // views, "crops": len(ds), "iters": len(timed),
                                   "iters_per_s": len(timed) / dt, "stack": tuple(model.stack.shape[2:4])})
             # instrumented pass (synchronising; not timed): how many steps had each tile of the crop's window missed?
@@ -132,6 +147,16 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
                 opt.window_leaf = orig
     out["iters_per_s"] = total_it / total_s
     out["iters"] = total_it
+    if total_win[1]:
+        # the bytes a crop iteration MUST move: the window of the parameters read by the forward (1 stream), then read and written once
+        # each with both Adam moments by the step (6 streams) -- 7 streams x D x T x 16 bytes per window texel (tile-culled: of the kept
+        # texels) -- over the whole iteration's wall time (render, loss, regularisers, optimiser, host) against the 8 TB/s HBM peak
+        kept = float(model.quad_keep.float().mean()) if sparsify else 1.0
+        win = total_win[0] / total_win[1]
+        nbytes = 7.0 * planes * frames * 16.0 * win * kept
+        out["roofline_iter"] = {"bound": "hbm", "streams": 7, "mean_window_texels": win, "kept_fraction": kept, "compulsory_bytes": nbytes,
+                                "ms_per_iter": total_s / total_it * 1e3, "achieved": nbytes / (total_s / total_it) / 1e9, "peak": 8000.0,
+                                "unit": "GB/s", "frac": nbytes / (total_s / total_it) / 1e9 / 8000.0}
     if depth_hist.sum() > 0:
         c = np.cumsum(depth_hist) / depth_hist.sum()
         out["catchup_depth"] = {"mean": float((np.arange(len(depth_hist)) * depth_hist).sum() / depth_hist.sum()),

@@ -34,6 +34,8 @@ def run(iters=10, frames=50, planes=32, smooth=0.2, dev="cuda:0", crop=(180, 320
     model = MPMeshVid(args, H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
     args.optimizer, args.lrate, args.lrate_decay = "adam", 0.5 * 0.01, 30
     opt = model.get_optimizer(0)        # MPV.py:199-214 (Adam, betas (0.9, 0.999), eps 6e-8): the crop-aware WindowAdam on a dense model
+    if hasattr(opt, "acknowledge_fused_backward"):
+        opt.acknowledge_fused_backward()      # this loop steps once per backward
     a = np.radians(0.5)
     tar = np.eye(4)
     tar[:3, :3] = [[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]
@@ -87,6 +89,8 @@ def run(iters=10, frames=50, planes=32, smooth=0.2, dev="cuda:0", crop=(180, 320
             tiles.cull_stack_(model.stack.data, keep)
         model._install_tie_hook()
         opt = model.get_optimizer(0)                       # the same Adam update on the kept texels only
+        if hasattr(opt, "acknowledge_fused_backward"):
+            opt.acknowledge_fused_backward()      # this loop steps once per backward
         cfg = cfgs["other"]
         for it in range(iters + 2):
             if it == 2:
@@ -112,6 +116,8 @@ def run(iters=10, frames=50, planes=32, smooth=0.2, dev="cuda:0", crop=(180, 320
         model.pack_()
         torch.cuda.empty_cache()
         opt = model.get_optimizer(0)
+        if hasattr(opt, "acknowledge_fused_backward"):
+            opt.acknowledge_fused_backward()      # this loop steps once per backward
         for it in range(iters + 2):
             if it == 2:
                 torch.cuda.synchronize()

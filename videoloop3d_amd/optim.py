@@ -22,6 +22,8 @@ for bit those of the two-kernel path.  Contract: one backward per window_leaf(),
 """
 import ctypes as C
 
+import warnings
+
 import torch
 
 from . import _lib as L
@@ -106,6 +108,8 @@ class WindowAdam(torch.optim.Optimizer):
         self.lean_window = bool(lean_window)
         self._compact_buf = None
         self.fused_backward = bool(fused_backward)
+        self._fused_ack = self._warned_no_step = False
+        self._gfb = self._bwd_scratch = None
         self._boxes_dev = self._class_dev = None
         self.fused_steps = 0             # steps taken inside a backward (diagnostics / tests)
 
@@ -179,11 +183,35 @@ class WindowAdam(torch.optim.Optimizer):
             compact = torch.empty((D, T, wh, ww, 4), dtype=p.dtype, device=p.device)
         self._catchup(window, self.t, compact, boxes=plane_boxes, lean=self.lean_window)
         compact.requires_grad_(True)
-        if self.pending is not None and self.pending != "stepped":
+        if self._stepped(self.pending):
+            # the previous backward took its step and step() was not called since: legal (step() is housekeeping only then), but the caller
+            # should know that nothing accumulates -- every backward of a fused window is one Adam step
+            self._check_stepped_leaf(self.pending)
+            if not self._warned_no_step:
+                self._warned_no_step = True
+                warnings.warn("WindowAdam(fused_backward=True): a second windowed forward before optimizer.step() -- each loss.backward() has "
+                              "already applied its own Adam step (no gradient accumulation on this path)", RuntimeWarning, stacklevel=3)
+            self.pending = None
+        if self.pending is not None:
             self.pending = "multiple"
-        else:                                             # ("stepped": the previous backward took its step; step() was not called for the housekeeping)
+        else:
             self.pending = (window, compact, plane_boxes)
         return compact
+
+    @staticmethod
+    def _stepped(pend):
+        return isinstance(pend, tuple) and len(pend) == 2 and pend[0] == "stepped"
+
+    @staticmethod
+    def _check_stepped_leaf(pend):
+        """after a fused backward the window leaf must not hold a gradient: one that arrived through another autograd path would be dropped"""
+        if pend[1].grad is not None:
+            raise RuntimeError("WindowAdam: the window leaf received a gradient outside the render's fused backward (another autograd path into "
+                               "the leaf); that gradient is not part of the step the backward took -- use fused_backward=False for such graphs")
+
+    def acknowledge_fused_backward(self):
+        """the training loop knows that loss.backward() applies the update (train_3dvid.run_iter, train_3d.run_iter call this): no warning"""
+        self._fused_ack = True
 
     @torch.no_grad()
     def flush(self):
@@ -268,17 +296,30 @@ class WindowAdam(torch.optim.Optimizer):
                 aw.blocks = self.layout.blocks.data_ptr()
         # the compact gradient buffer: static texels of a tile-culled model (summed over the frames by the step kernel behind the backward) and
         # everything when the device-side plan finds the view infeasible; untouched otherwise (an allocation, no traffic)
-        g_fallback = torch.empty_like(stack)
+        if not self._fused_ack:
+            self._fused_ack = True
+            warnings.warn("WindowAdam(fused_backward=True): loss.backward() APPLIES the Adam update of the rendered window (the optimiser step "
+                          "runs inside the render backward, vl3d_render_bwd_adam); optimizer.step() afterwards is housekeeping only, and skipping "
+                          "it (NaN guards, GradScaler) does NOT skip the update.  Pass fused_adam_backward=False to get_optimizer's args for the "
+                          "two-kernel path, or call optimizer.acknowledge_fused_backward() to silence this.", RuntimeWarning, stacklevel=2)
+        # (buffers of the call kept on the optimiser, grown on demand like the compact window: no allocator traffic inside autograd)
+        if self._gfb is None or self._gfb.numel() < stack.numel() or self._gfb.device != dev:
+            self._gfb = None
+            self._gfb = torch.empty(stack.numel(), dtype=torch.float32, device=dev)
+        g_fallback = self._gfb[:stack.numel()].view(stack.shape)
         with torch.cuda.device(dev):
-            nscratch = int(L.lib().vl3d_render_bwd_scratch_bytes(desc))
-            scratch = torch.empty((nscratch + 3) // 4, dtype=torch.float32, device=dev)
+            nscratch = max(int(L.lib().vl3d_render_bwd_scratch_bytes(desc)), 64)
+            if self._bwd_scratch is None or self._bwd_scratch.numel() * 4 < nscratch or self._bwd_scratch.device != dev:
+                self._bwd_scratch = None
+                self._bwd_scratch = torch.empty((nscratch + 3) // 4, dtype=torch.float32, device=dev)
+            scratch = self._bwd_scratch
             scratch[:16].zero_()
             L.check(L.lib().vl3d_render_bwd_adam(desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.ptr(g_rgb), L.ptr(g_alpha),
                                                  L.ptr(g_reg), L.ptr(reg_state), L.ptr(g_asum), L.ptr(g_fallback), L.ptr(scratch), nscratch,
                                                  C.byref(aw), L.stream_ptr(dev)), "vl3d_render_bwd_adam")
         self.t = t
         self.fused_steps += 1
-        self.pending = "stepped"
+        self.pending = ("stepped", pend[1])              # the leaf stays referenced: step() / the next window_leaf() check that nothing else reached it
         return scratch
 
     def _register_step(self, st, lr, b1, b2):
@@ -319,7 +360,8 @@ class WindowAdam(torch.optim.Optimizer):
         b1, b2 = grp["betas"]
         lr, eps = float(grp["lr"]), float(grp["eps"])
         pending, self.pending = self.pending, None
-        if pending == "stepped":                          # the backward took the step (fused_backward): housekeeping only
+        if self._stepped(pending):                        # the backward took the step (fused_backward): housekeeping only
+            self._check_stepped_leaf(pending)
             self._bound_deferral(st, self.t)
             return loss
         if pending == "multiple":
@@ -388,6 +430,9 @@ class Stage1Adam:
 
     def flush(self):
         self.window.flush()
+
+    def acknowledge_fused_backward(self):
+        self.window.acknowledge_fused_backward()
 
     def zero_grad(self, set_to_none=True):
         for o in self._engines():

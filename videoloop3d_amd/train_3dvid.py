@@ -73,7 +73,7 @@ class MVVidPatchDataset:
 
     def __init__(self, resize_hw, videos, patch_size, patch_stride, poses, intrins, loss_configs=None, prepare="auto", prepare_budget=0.25):
         """prepare: True / False / "auto" -- build the NN search's gram-major copy of every GPU-resident clip (utils_vid.PreparedClip:
-        16*H*W*pad16(F) bytes per view, about 1.4x the clip, ON TOP of the clip).  "auto" does it only while the copies of all views stay
+        16*H*W*F bytes per view, about 1.33x the clip, ON TOP of the clip).  "auto" does it only while the copies of all views stay
         below `prepare_budget` of the device memory that is free right now; otherwise the loss transposes the crop it is handed, per
         iteration, as before (same results, ~0.4 ms more per iteration at 720p)."""
         h_raw, w_raw = videos[0].shape[-2:]
@@ -102,7 +102,7 @@ class MVVidPatchDataset:
         self.prepared = None
         if prepare and all(v.is_cuda for v in self.videos):
             if prepare == "auto":
-                need = sum(16 * v.shape[-2] * v.shape[-1] * (-(-v.shape[0] // 16) * 16) for v in self.videos)
+                need = sum(16 * v.shape[-2] * v.shape[-1] * v.shape[0] for v in self.videos)
                 free, _ = torch.cuda.mem_get_info(self.videos[0].device)
                 prepare = need <= prepare_budget * free
                 if not prepare:
@@ -144,6 +144,8 @@ def run_iter(nerf, optimizer, item, args, device):
         b_intrin = b_intrin.clone()
         b_intrin[:, :2, 2] += torch.rand(2).type_as(b_intrin) - 0.5     # half pixel
     nerf.train()
+    if hasattr(optimizer, "acknowledge_fused_backward"):
+        optimizer.acknowledge_fused_backward()      # this loop steps once per backward: the update inside the render backward is what it wants
     _, extra = nerf(patch_h, patch_w, b_extrin, b_intrin, res=b_rgbs, losscfg=_collate1(cfg))
     swd_loss = extra.pop("swd").mean()
     args_var = vars(args)
