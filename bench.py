@@ -277,7 +277,7 @@ def main():
         if timed:
             fwd_ms.append((e0, e1))
             bwd_ms.append((e1, e2))
-        last["rgb"], last["frame"] = rgb.detach(), frame
+        last["rgb"], last["frame"], last["gs"] = rgb.detach(), frame, gs
         return gs
 
     def fence():
@@ -285,6 +285,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:
+        # every rank is really there before anything is timed: a collective over the backend that will carry the step's traffic
+        ones = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        assert dist.get_world_size() == world and int(ones.item()) == world, f"backend {backend} reports {dist.get_world_size()} ranks / sum {ones.item()}, expected {world}"
     for _ in range(a.warmup):
         step(False)
     fence()
@@ -301,7 +306,11 @@ def main():
     # ---- what was gathered is what was rendered: per-band checksums travel beside the frame, and the frame's own checksum is the
     #      same number at every N (band renders are bit-identical to the full render: tests/test_gpu_render.py row-band tests)
     def bits_sum(t):
-        return int(t.contiguous().view(torch.int32).to(torch.int64).sum().item())
+        # (slice by slice along the first axis: the int64 copy of a 24 GB gradient would not be a small temporary)
+        tot = 0
+        for part in (t if t.dim() > 1 and t.numel() > (1 << 28) else [t]):
+            tot += int(part.contiguous().view(torch.int32).to(torch.int64).sum().item())
+        return tot
     frame = last["frame"]
     frame_checksum = bits_sum(frame)
     gather_check = None
@@ -315,6 +324,28 @@ def main():
         gather_check = bool(int(okt.item()))
         assert gather_check, "the gathered frame differs from the rendered bands"
 
+    # the stack gradient over a PARTITION of the stack rows -- rank r's rows from its first row up to the next rank's first row: with the
+    # halo exchange every replica of a row holds the sum of all bands' contributions, so the sums over ranks are the N = 1 numbers up to
+    # the rounding of that sum's order (a halo texel adds two per-band partial sums where one GPU adds pixel by pixel: a few ulps on
+    # those texels -- the fp64 sum and absolute sum agree to ~1e-7 relative; rows no band touches have gradient 0 at N = 1)
+    def f64_sums(t):
+        tot, tota = 0.0, 0.0
+        for part in (t if t.dim() > 1 and t.numel() > (1 << 28) else [t]):
+            pd = part.double()
+            tot += float(pd.sum().item())
+            tota += float(pd.abs().sum().item())
+        return tot, tota
+    gs_last = last.pop("gs")
+    if world == 1:
+        grad_sums = f64_sums(gs_last)
+    elif a.exchange_halo_grads:
+        hi = bands[rank + 1].src0 if rank + 1 < world else band.src1
+        tg = torch.tensor(f64_sums(gs_last[:, :, :max(0, hi - band.src0)]), dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tg)
+        grad_sums = (float(tg[0].item()), float(tg[1].item()))
+    else:
+        grad_sums = None
+    del gs_last
     ms_per_step = dt / a.steps * 1e3
     pix_per_step = T * H * W
     value = pix_per_step / (dt / a.steps) / 1e6
@@ -358,6 +389,7 @@ def main():
         "roofline": dominant, "roofline_fwd": r_f, "roofline_bwd": r_b,
         "fwd_bwd_algorithmic_frac": (fwd_bytes + bwd_bytes) / ((f_ms + b_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "frame_checksum": frame_checksum,       # sum of the frame's bit patterns: identical at N = 1, 2, 4, 8
+        "grad_sums": grad_sums,                 # (sum, sum of absolute values) of the stack gradient in fp64, after the halo exchange: the N = 1 numbers to ~1e-7
         # what this rank keeps in HBM for the step: its rows of the stack, the gradient of the same size and type, frame-sized buffers
         "resident_bytes_per_rank": {"stack": stack.numel() * stack.element_size(), "grad_stack": stack.numel() * stack.element_size(),
                                     "frames": int(last["frame"].numel() * 4 + g_rgb.numel() * 4 + last["rgb"].numel() * 4),
@@ -614,7 +646,7 @@ def main():
         if errors:
             summ["errors"] = errors
         head = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-                "stack_storage", "config", "frame_checksum", "collective", "loss_band", "roofline", "cpu_baseline", "build"]
+                "stack_storage", "config", "frame_checksum", "grad_sums", "collective", "loss_band", "roofline", "cpu_baseline", "build"]
         line = {k: res[k] for k in head if k in res}
         line["detail_file"] = os.path.relpath(detail_path, ROOT) if os.path.isabs(detail_path) else detail_path
         line["summary"] = {k: r4(v) for k, v in summ.items()}
