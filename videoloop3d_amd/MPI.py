@@ -134,9 +134,9 @@ class MPMesh(nn.Module):
         if grid_h > 0 and self.mpi_d % grid_h == 0 and tuple(self.stack.shape[2:4]) == (self.mpi_h, self.mpi_w):
             # the reference's classification as it runs it: morphology on the ATLAS of plane cells, quads judged by their tile samples
             # (same kept / dynamic quads as MPI.py:288-356 on identical weights: golden G15)
-            keep, dyn = tiles.classify_quads_atlas(alpha.cpu(), None if loop is None else loop.cpu(), grid_h, self.quad_h + 1, self.quad_w + 1,
-                                                   erode_num, alpha_thresh, loop_thresh, rm)
-            keep, dyn = keep.to(alpha.device), dyn.to(alpha.device)
+            # (on the model's device: a one-shot of max-pool / grid_sample passes over the 19-Mpixel atlas of the shipped size -- 3.8 s on the
+            # host, which was a fifth of an end-to-end stage-1 run here, examples/stage1_train.py)
+            keep, dyn = tiles.classify_quads_atlas(alpha, loop, grid_h, self.quad_h + 1, self.quad_w + 1, erode_num, alpha_thresh, loop_thresh, rm)
         else:
             keep, dyn = tiles.classify_quads(alpha, loop, self.quad_h, self.quad_w, erode_num, alpha_thresh, loop_thresh, rm)
         n_quad, n_mask, n_dyn = keep.numel(), int(keep.sum()), int(dyn.sum())

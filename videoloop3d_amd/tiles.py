@@ -87,7 +87,7 @@ def classify_quads_atlas(alpha, loopmask, grid_h, hv, wv, erode_num=2, alpha_thr
     grid = torch.stack([tx.reshape(1, -1).expand(grid_h * QH * nh, -1), ty.reshape(-1, 1).expand(-1, gw * QW * nw)], -1)[None]
 
     def tile_max(atlas):
-        samp = F.grid_sample(atlas, grid.to(atlas.dtype), mode="bilinear", padding_mode="zeros", align_corners=True)[0, 0]
+        samp = F.grid_sample(atlas, grid.to(device=atlas.device, dtype=atlas.dtype), mode="bilinear", padding_mode="zeros", align_corners=True)[0, 0]
         samp = samp.reshape(grid_h, QH, nh, gw, QW, nw).amax((2, 5))                    # gh,QH,gw,QW
         return samp.permute(0, 2, 1, 3).reshape(D, QH, QW)
 
