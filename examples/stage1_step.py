@@ -19,7 +19,7 @@ import torch
 
 
 def run(iters=20, planes=32, frame=(360, 640), crop=(180, 320), scale=1.6, loop_mask=True, dev="cuda:0", torch_adam=False, fused_loss=True,
-        crop_aware_adam=False, graph=False):
+        crop_aware_adam=False):
     from videoloop3d_amd import synth
     from videoloop3d_amd.MPI import MPMesh, image_and_loop_loss
     dev = torch.device(dev)
@@ -45,29 +45,14 @@ def run(iters=20, planes=32, frame=(360, 640), crop=(180, 320), scale=1.6, loop_
     target = synth.hash_uniform((1, 3, h, w), seed=8, device=dev)
     target_mask = (synth.hash_uniform((1, h, w), seed=9, device=dev) > 0.5).float()
     wts = vars(args)
-    graphed = None
-    if graph:      # the whole iteration as ONE hipGraph launch (videoloop3d_amd/graphs.py): view, crop and step scalars through device memory
-        from videoloop3d_amd.graphs import GraphedStage1Iteration
-
-        def loss_fn(rgbl, extra, tgt, tmask):
-            img_loss, loop_loss = image_and_loop_loss(rgbl, tgt, tmask if loop_mask else None, scale_invariant=True)
-            l_ = img_loss + loop_loss
-            for k, v in extra.items():
-                if wts[f"{k}_loss_weight"] > 0:
-                    l_ = l_ + v.mean() * wts[f"{k}_loss_weight"]
-            return l_
-        graphed = GraphedStage1Iteration(model, opt, h, w, loss_fn, loop_mask=loop_mask, warmup=3)
-    for it in range(iters + (5 if graph else 3)):
-        if it == (5 if graph else 3):
+    for it in range(iters + 3):
+        if it == 3:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         Kc = K.copy()
         if (h, w) != (H, W):
             Kc[0, 2] -= 90 + (it % 3) * 40                                   # crop offset (utils.py:196-200)
             Kc[1, 2] -= 45 + (it % 2) * 60
-        if graphed is not None:
-            loss = graphed(tar_e, torch.tensor(Kc)[None], target, target_mask if loop_mask else None)
-            continue
         rgbl, extra = model(h, w, tar_e, torch.tensor(Kc)[None])
         if fused_loss:                                                       # train_3d.py:200-220 in three launches each way
             img_loss, loop_loss = image_and_loop_loss(rgbl, target, target_mask if loop_mask else None, scale_invariant=True)
@@ -91,16 +76,14 @@ def run(iters=20, planes=32, frame=(360, 640), crop=(180, 320), scale=1.6, loop_
     torch.cuda.synchronize()
     return {"iters_per_s": iters / (time.perf_counter() - t0), "loss": float(loss.detach()),
             "shape": f"D={planes}, frame {H}x{W}, view {h}x{w}, planes {tuple(model.stack.shape[2:4])}, loop mask {loop_mask}, "
-                     f"sparsity 0.004 / rgb_smooth 0.2 / a_smooth 0.5 / density 0.02, {type(opt).__module__}.{type(opt).__name__}"
-                     + (", one hipGraph launch per iteration" if graph else "")}
+                     f"sparsity 0.004 / rgb_smooth 0.2 / a_smooth 0.5 / density 0.02, {type(opt).__module__}.{type(opt).__name__}"}
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--graph", action="store_true", help="the native-shape iteration as one hipGraph launch (videoloop3d_amd/graphs.py; measured: no gain)")
     a = ap.parse_args()
     import __graft_entry__ as g
     g.build()
-    print(json.dumps({"native_crop": run(a.iters, graph=a.graph), "cfg2_720p_frame": run(a.iters, frame=(720, 1280), crop=(720, 1280), scale=1.1),
+    print(json.dumps({"native_crop": run(a.iters), "cfg2_720p_frame": run(a.iters, frame=(720, 1280), crop=(720, 1280), scale=1.1),
                       "cfg2_720p_frame_no_loop_mask": run(a.iters, frame=(720, 1280), crop=(720, 1280), scale=1.1, loop_mask=False)}))

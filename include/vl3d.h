@@ -142,13 +142,6 @@ int vl3d_tie_static_grad(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uin
 int vl3d_adam_step_tiles(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uint8_t *quad_keep, const uint8_t *quad_dyn, int32_t QH, int32_t QW,
                          float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float lr, float beta1, float beta2,
                          float eps, int64_t step, vl3d_stream_t stream);
-/* ... with the step's scalars in DEVICE memory: step_scalars = float[2] (lr / (1 - beta1^step), sqrt(1 - beta2^step)), as
- * vl3d_adam_step_scalars computes them.  The launch carries nothing that changes from step to step, so an iteration recorded in a hipGraph
- * (a stage-1 iteration is bound by its ~80 launches: videoloop3d_amd/graphs.py) replays with a new learning rate and step count after one
- * 8-byte copy. */
-int vl3d_adam_step_tiles_dev(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uint8_t *quad_keep, const uint8_t *quad_dyn, int32_t QH,
-                             int32_t QW, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *step_scalars,
-                             float beta1, float beta2, float eps, vl3d_stream_t stream);
 
 /* Crop-aware Adam for the DENSE stack (csrc/vl3d_optim.hip; the optimiser of train_3dvid.py:263-290 / MPV.py:199-214).  A training
  * iteration renders one crop, so only the texels of the crop's parallax window (y0, x0, wh, ww; aligned to
@@ -200,7 +193,7 @@ int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t 
  * vl3d_render_bwd_culled does and the step kernel behind the backward sums it over the frames -- static texels only, unless the plan was
  * infeasible --, culled texels are nobody's (grad_stack holds defined values in static texels only).  adam->blocks: packed storage.
  * fp32 stacks, the planar convention with the shipped activations ((affine, hardcut, post), sigmoid / sigmoid); dense models: T >= 2,
- * desc->variant 0 (frame pairs) or 3 (the one-frame tile kernel, which tile-culled models always take); anything else: VL3D_EUNSUPPORTED,
+ * desc->variant 0 (the frame pairs; tile-culled models always take the one-frame tile kernel); anything else: VL3D_EUNSUPPORTED,
  * nothing launched. */
 typedef struct vl3d_adam_window {
     int32_t Hs, Ws;              /* the full planes: param / exp_avg / exp_avg_sq are (D,T,Hs,Ws,4) */
@@ -357,10 +350,10 @@ typedef struct vl3d_loss_desc {
     int64_t x_sc, x_st, x_sr;
     int64_t y_sc, y_st, y_sr;
     int32_t variant;       /* kernel variant selector for A/B measurements and cross-checks; 0 = default.  Bits 0-3, vl3d_patchnn: 1 strided
-                            * staging (no scratch), 2 one location per workgroup, 3 the fp32 matrix-core kernel, 4 the vector-ALU kernel
-                            * (0 picks 3 wherever the clip lengths allow it -- x <= 128, y <= 192 frames -- and 4 otherwise); vl3d_vote_fold: 1 = the
+                            * staging (no scratch), 2 one location per workgroup, 4 the vector-ALU kernel, 6 the split-f16 matrix-core kernel
+                            * (0 picks 6 wherever the clip lengths allow it -- x <= 128, y <= 192 frames -- and 4 otherwise); vl3d_vote_fold: 1 = the
                             * unstaged kernel.  Bits 4-7: refused (ablation switches of a -DVL3D_VARIANTS measurement build).  Bit 8: see vl3d_patchnn.
-                            * Bits 12-15, vl3d_vote_fold*: tile shape index + 1. */
+                            * Bit 11 (0x800), kernel 6: the workgroup-wide epilogue also without alpha.  Bits 12-15, vl3d_vote_fold*: tile shape index + 1. */
 } vl3d_loss_desc;
 
 /* bytes of device scratch vl3d_patchnn needs for this problem (0 if none). */

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-process A/B of the patch-NN kernel variants (utils_vid.KERNEL_VARIANT bits) on resident 720p clips: NN search time per variant.
-  python profiles/ab_loss.py 0,0x80 [rounds]"""
+  python profiles/ab_loss.py 0,4 [rounds]"""
 import os, statistics, sys, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,7 +9,7 @@ ge.build()
 from videoloop3d_amd import synth
 from videoloop3d_amd import utils_vid as UV
 from videoloop3d_amd.utils_vid import find_nn_indices
-variants = [int(v, 0) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,0x80").split(",")]
+variants = [int(v, 0) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,4").split(",")]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = torch.device("cuda:0")
 x = synth.make_video(52, 719, 1279, seed=3, device=dev)

@@ -26,10 +26,16 @@ def test_bench_json_contract():
     assert d["value"] > 0 and abs(d["value"] - 2 * 96 * 128 / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    # the numbers a reader needs first come first in the line (a consumer that cuts the tail keeps them), and the build is stated
+    # the line stays under 6 KB, its LAST key is the flat summary (what survives in a record that keeps the tail), the legs in full are in
+    # the side file the line names, and the build is stated
+    assert len(lines[0]) < 6000
     keys = list(d)
-    assert keys.index("cpu_baseline") < keys.index("summary") < keys.index("loss") and keys.index("roofline") < keys.index("cpu_baseline")
+    assert keys[-1] == "summary" and keys.index("roofline") < keys.index("cpu_baseline") < keys.index("summary")
     assert d["build"]["translation_units"] >= 10 and "hipcc" in d["build"]["mode"]
-    assert d["summary"]["loss_720p_iters_per_s"]["ref"] == d["loss"]["ref"]["iters_per_s"] > 0
+    detail = json.load(open(os.path.join(ROOT, d["detail_file"])))
+    assert abs(d["summary"]["loss720_ref_it_s"] - detail["loss"]["ref"]["iters_per_s"]) <= 1e-3 * detail["loss"]["ref"]["iters_per_s"]
+    assert all(not isinstance(v, (dict, list)) for k, v in d["summary"].items() if k != "errors")
+    assert "errors" not in d["summary"], d["summary"].get("errors")
+    assert d["grad_sums"][1] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mpix/s" and "sample" in c

@@ -224,11 +224,12 @@ def test_g6_get_nn_indices_low_memory(dev, golden):
     assert maxabs(extract_3Dpatches(ramp, 5, 2, 4, 2), g5["p_5_2_4_2"]) == 0
 
 
-@pytest.mark.parametrize("variant", ["1", "2", "3", "4"])
+@pytest.mark.parametrize("variant", ["1", "2", "6", "0x806", "4"])
 def test_patchnn_kernel_variants_agree(dev, variant, monkeypatch):
     """v1 (strided staging), v2 (pixel-major staging, one location per workgroup), v4 (four locations per workgroup, VALU direct SSD)
-    and v5 = variant 3 (the same workgroup on the matrix cores, |x|^2+|y|^2-2x.y like the reference; the default where it applies)
-    pick the same neighbours up to exact-distance near-ties."""
+    and v6 = variant 6 (the same workgroup on the half-precision matrix cores with split operands, |x|^2+|y|^2-2x.y like the reference; the
+    default where it applies; 0x806: its workgroup-wide epilogue also without alpha instead of the per-wave one) pick the same neighbours up
+    to exact-distance near-ties."""
     from videoloop3d_amd.utils_vid import _nn_and_fold
     monkeypatch.setattr(UV_MOD, "KERNEL_VARIANT", int(variant, 0))
     x = synth.make_video(12, 43, 51, seed=3)
@@ -249,7 +250,7 @@ def test_patchnn_matrix_core_tile_counts(dev, tx, ty, ps, s, alpha, monkeypatch)
     reads; <= 128: two locations; <= 192: one; x clips of <= 64 frames on four waves, <= 128 on eight -- cfg4's 80 / 120 and cfg5's
     120 / 180 frames), at the largest clips it takes, with a narrow last group and with alpha."""
     from videoloop3d_amd.utils_vid import _nn_and_fold
-    monkeypatch.setattr(UV_MOD, "KERNEL_VARIANT", 3)
+    monkeypatch.setattr(UV_MOD, "KERNEL_VARIANT", 6)
     H, W = ps + 5 * s, ps + 9 * s                        # 6 x 10 patch locations: the last group of a row is two locations wide
     x = synth.make_video(tx, H, W, seed=5)
     y = synth.make_video(ty, H, W, seed=6)
@@ -394,7 +395,7 @@ def test_g13_alpha0_get_nn_indices_low_memory(dev, golden):
     assert (nn.cpu().numpy() == g["a_nn_alpha0"]).all()
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "6", "4"])
 @pytest.mark.parametrize("ps,pt,s,st", [(5, 3, 2, 1), (3, 3, 2, 1), (3, 2, 1, 2)])
 def test_g13_alpha0_find_nn_and_merge(dev, golden, ps, pt, s, st, variant, monkeypatch):
     from videoloop3d_amd.utils_vid import FindNNpatchAndMerge
@@ -405,7 +406,7 @@ def test_g13_alpha0_find_nn_and_merge(dev, golden, ps, pt, s, st, variant, monke
     assert maxabs(sm, g[f"b_ps{ps}_pt{pt}_s{s}_st{st}_sum"]) <= 1e-5
 
 
-@pytest.mark.parametrize("variant", ["0", "3", "4"])
+@pytest.mark.parametrize("variant", ["0", "6", "4"])
 def test_g13_alpha0_shipped_ref_view_loss_value_and_grad(dev, golden, variant, monkeypatch):
     """Patch3DGPNNLowMemLoss with the SHIPPED ref-view kwargs (ps 11, stride 4, pt 3, alpha = 0, rou '-2', scaling 0.1) against the reference."""
     from videoloop3d_amd.utils_vid import Patch3DGPNNDirectLoss, Patch3DGPNNLowMemLoss, find_nn_indices
@@ -426,7 +427,7 @@ def test_g13_alpha0_shipped_ref_view_loss_value_and_grad(dev, golden, variant, m
     assert (nn.cpu().numpy() == g["c_nn"]).all()
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "6", "4"])
 @pytest.mark.parametrize("ps,s", [(11, 4), (3, 2)])
 def test_g13_alpha0_exact_ties_take_the_first_minimum(dev, golden, ps, s, variant, monkeypatch):
     """n2 > n1 at alpha = 0: most rows are decided by an EXACT tie at score 1.0 (the row is the minimum of several columns) and the

@@ -877,52 +877,3 @@ def test_stage1_crop_aware_optimiser_equals_the_whole_stack_adam(dev, sparse):
     with torch.no_grad():
         imgs = [m(H, W, torch.tensor(tar)[None].to(dev), torch.tensor(K)[None].to(dev))[0] for m, _ in models]
     assert float((imgs[0] - imgs[1]).abs().max()) <= 2e-4
-
-
-def test_graphed_stage1_iteration_equals_the_eager_loop(dev):
-    """videoloop3d_amd/graphs.py: a stage-1 iteration (MPMesh.forward, image + loop-mask loss, regularisers, backward, Adam) recorded
-    once as a hipGraph and replayed -- view, crop and the optimiser's scalars reach the recorded kernels through device memory -- against
-    the eager loop on a copy of the model: the same losses and parameters over shifting crops, poses and a decaying learning rate."""
-    from videoloop3d_amd.MPI import MPMesh, image_and_loop_loss
-    from videoloop3d_amd.graphs import GraphedStage1Iteration
-    H, W, h, w = 66, 80, 30, 40
-    K, ref_extrin, tar = scene(H, W)
-    args = lambda: make_args_mpi(mpi_h_verts=7, mpi_w_verts=9, optimizer="adam", lrate=0.02, lrate_decay=100)      # noqa: E731
-    torch.manual_seed(3)
-    A = MPMesh(args(), H, W, ref_extrin, K, 1.0, 100.0).to(dev).train()
-    B = MPMesh(args(), H, W, ref_extrin, K, 1.0, 100.0).to(dev).train()
-    B.load_state_dict({k: v for k, v in A.state_dict().items() if not k.startswith("self.")})
-    oa, ob = A.get_optimizer(), B.get_optimizer()
-    wts = {"sparsity": 0.004, "rgb_smooth": 0.2, "a_smooth": 0.5, "density": 0.02}
-
-    def loss_fn(rgbl, extra, target, target_mask):
-        img, loop = image_and_loop_loss(rgbl, target, target_mask, scale_invariant=True)
-        loss = img + loop
-        for k, v in extra.items():
-            loss = loss + v.mean() * wts[k]
-        return loss
-    graphed = GraphedStage1Iteration(B, ob, h, w, loss_fn, loop_mask=True, warmup=3)
-    offs = [(0, 0), (30, 35), (10, 20), (36, 40), (0, 40), (36, 0), (18, 25), (0, 0), (36, 40), (5, 5), (20, 30), (30, 10)]
-    for it, (oy, ox) in enumerate(offs):
-        Kc = K.copy()
-        Kc[0, 2] -= ox
-        Kc[1, 2] -= oy
-        te = tar.copy()
-        te[:3, 3] += [0.01 * (it % 3), -0.005 * (it % 2), 0.0]
-        target = synth.hash_uniform((1, 3, h, w), seed=60 + it, device=dev)
-        tmask = (synth.hash_uniform((1, h, w), seed=90 + it, device=dev) > 0.5).float()
-        lr = 0.02 * 0.93 ** it
-        for o in (oa, ob):
-            for grp in o.param_groups:
-                grp["lr"] = lr
-        oa.zero_grad(set_to_none=True)
-        rgbl, extra = A(h, w, torch.tensor(te)[None], torch.tensor(Kc)[None])
-        la = loss_fn(rgbl, extra, target, tmask)
-        la.backward()
-        oa.step()
-        lb = graphed(torch.tensor(te)[None], torch.tensor(Kc)[None], target, tmask)
-        assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(la))), (it, float(la), float(lb))
-    assert graphed.graph is not None and graphed.calls == len(offs)
-    for (na, pa), (nb, pb) in zip(A.named_parameters(), B.named_parameters()):
-        assert float((pa - pb).abs().max()) <= 1e-6, na
-    assert int(oa.state[A.stack]["step"]) == int(ob.state[B.stack]["step"]) == len(offs)

@@ -348,14 +348,12 @@ class MPMesh(nn.Module):
                 self._mask_buf[..., 3].copy_(self.stack[..., 3])
         # crop-aware training (optim.Stage1Adam handed out by get_optimizer): ONE view per iteration (the reference's DataLoader(dataset, 1)),
         # rendered from a compact, up-to-date copy of the texel window the crop can reach; every other case reads the whole (flushed) stack
-        windowed = (self._window_opt is not None and getattr(self, "_static_homos", None) is None and self.training and torch.is_grad_enabled() and B == 1 and not need_layers and not self.atlas_exact
+        windowed = (self._window_opt is not None and self.training and torch.is_grad_enabled() and B == 1 and not need_layers and not self.atlas_exact
                     and (fused_mask or not self.learn_loop_mask))
         if self._window_opt is not None and not windowed:
             self._flush_deferred_updates()
         for b in range(B):
-            # (a recorded iteration -- videoloop3d_amd/graphs.py -- reads the view from a device tensor it refreshes before every replay)
-            static_homos = getattr(self, "_static_homos", None) if B == 1 else None
-            homos = static_homos if static_homos is not None else self.plane_homographies(extrin[b:b + 1], intrin[b:b + 1])
+            homos = self.plane_homographies(extrin[b:b + 1], intrin[b:b + 1])
             stack, mask, spec, cull_window, fused_adam, lean = self.stack, (self.stack_mask if self.learn_loop_mask else None), self.spec, None, None, False
             if windowed:
                 from .optim import crop_window

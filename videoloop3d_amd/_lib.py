@@ -66,7 +66,6 @@ SIGNATURES = {
     "vl3d_tie_static_grad": ([_I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _I32, _P], C.c_int),
     "vl3d_adam_step_tiles": ([_I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _I64, _P],
                              C.c_int),
-    "vl3d_adam_step_tiles_dev": ([_I32, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P], C.c_int),
     "vl3d_adam_window_tile": ([], C.c_int32),
     "vl3d_adam_window_catchup": ([_I32] * 8 + [_P, _P, _P, _P, _P, _I32, _F, _F, _F, _P, _P, _P, _I32, _I32, _F, _I32, _P], C.c_int),
     "vl3d_adam_window_catchup_boxes": ([_I32] * 8 + [_P, _P, _P, _P, _P, _I32, _F, _F, _F, _P, _P, _P, _I32, _I32, _F, _I32, _P, _P, _P], C.c_int),

@@ -157,8 +157,8 @@ struct NN2Args {
     int32_t *nn;
     int W, ps, pt, stride, stridet, h_o, w_o, n1, n2;
     int TxP, TyP, K, KC;
-    int PX, PY;             // v5: frames per pixel of the gram-major copies (padded to whole 16-frame groups)
-    int Wy;                 // v5: pixels per row of the gram-major y (== W, or the full frame's width when y is a crop of a prepared clip)
+    int PX, PY;             // v6: frames per pixel of the gram16 copies of x / y (exact)
+    int Wy;                 // v6: pixels per row of the gram16 y (== W, or the full frame's width when y is a crop of a prepared clip)
     int use_alpha;
     float alpha, dnorm;
     int ablate;   // measurement only: 1 skip epilogue, 2 skip compute, 4 skip staging loads
@@ -560,255 +560,29 @@ __global__ __launch_bounds__(NTHR) void patchnn4_k(NN2Args a, int H_unused, int 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// K3 v5: the v4 workgroup (NL neighbouring locations, one staged region row at a time, running sums along the row, E through the
-// shared epilogue) with the frame-pair energies on the matrix cores.  The reference forms its distances as |x|^2 + |y|^2 - 2 x.y in
-// fp32 (utils_vid.py:82); per frame pair and region column q that is, over the channels c,
-//     e_q(ti, tj) = sum_c u_c(ti)^2  +  sum_c v_c(tj)^2  -  2 sum_c u_c(ti) v_c(tj),      u = x - 1/2, v = y - 1/2
-// (the shift cancels in x - y and keeps the three terms four times smaller for data in [0, 1]).  v_mfma_f32_16x16x4_f32 contracts
-// FOUR k per issue and a pixel has three channels: the fourth slot carries A = sum_c u_c^2, B = 1, so that ONE issue per column and
-// 16x16 frame-pair tile accumulates  s_x - 2 u.v  exactly as an fp32 FMA chain -- 64 frame pairs x 3 channels per lane-cycle slot
-// that the VALU form spends on one subtract + one FMA per pair and channel.  The y term depends on tj only: TyP threads keep its
-// window sums on the side (one LDS read + add per column) and it is added when E is written out.
-// gram-major scratch: per pixel the frames in groups of 16, [group][slot][frame], slots x = (u0, u1, u2, u.u), y = (-2 v0, -2 v1, -2 v2, v.v):
-// the operand fragment of a 16-frame tile (lane = frame + 16 * slot) is the group's 64 consecutive floats.  Wave w owns group w of x and
-// all TYT groups of y.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-template <bool IS_Y>
-__global__ __launch_bounds__(256) void video_to_gram_major_k(const float *__restrict__ v, int64_t sc, int64_t st, int64_t sr,
-                                                             int T, int G, int H, int W, float *__restrict__ out) {
-    __shared__ float tile[3][16][65];      // [channel][frame of the group][pixel] (+1 pad: conflict-free transposed reads)
-    const int row = blockIdx.y, x0 = blockIdx.x * 64, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // read: lanes over pixels (coalesced along the row), 12 (channel, frame) pairs per thread and 16-frame group; the NEXT group's reads
-    // are issued before this group is written out, so that they are in flight across the write phase and its barriers
-    float pre[12];
-    const float *src = v + (int64_t)row * sr + min(x0 + lane, W - 1);
-    auto load = [&](int f0) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            const int j = wave + 4 * k, c = j >> 4, f = f0 + (j & 15);
-            pre[k] = f < T ? src[c * sc + f * st] : 0.5f;                       // padding frames: u = v = 0
-        }
-    };
-    load(0);
-    for (int g = 0; g < G; ++g) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            const int j = wave + 4 * k;
-            tile[j >> 4][j & 15][lane] = pre[k] - 0.5f;
-        }
-        __syncthreads();
-        if (g + 1 < G) load((g + 1) * 16);
-        // write: a wave = one pixel's group, 64 contiguous floats = [slot][frame]; 16 pixels per wave
-        const int k = lane >> 4, m = lane & 15;
-        for (int p = wave; p < 64 && x0 + p < W; p += 4) {
-            const float a0 = tile[0][m][p], a1 = tile[1][m][p], a2 = tile[2][m][p];
-            float val = k == 0 ? a0 : (k == 1 ? a1 : (k == 2 ? a2 : fmaf(a2, a2, fmaf(a1, a1, a0 * a0))));
-            if (IS_Y && k < 3) val *= -2.f;
-            out[(((size_t)row * W + x0 + p) * G + g) * 64 + lane] = val;
-        }
-        __syncthreads();
-    }
-}
-
-// Staging and order of the contraction: a STAGE is CHC region columns x all ps rows (x [CHC][ps][TxP][4] | y [CHC][ps][TyP][4]), moved by
-// LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction straight into LDS, each lane from its own row -- no staging registers,
-// no ds_write pass) into one of TWO buffers: the stage after the one being contracted is in flight during the MFMA loop, one barrier
-// per stage.  Within a stage a column's ps rows are contracted back to back, so the running sum R (a prefix over COLUMNS, each with all
-// its rows) meets a window boundary once per boundary column of the whole region -- 2 NL times per workgroup -- instead of once per
-// row: the accumulator traffic R -> acc[l] and the operand pipeline's warm-up are paid per column, not per row segment.
 // floor(n / d) for 0 <= n < 2^16, 0 < d < 2^12 through the hardware reciprocal: (n + 1/2) / d is at least 1 / (2 d) away from any
 // integer, far more than the reciprocal's relative error times the quotient
 __device__ __forceinline__ int fdiv_small(int n, int d) { return (int)(((float)n + 0.5f) * __builtin_amdgcn_rcpf((float)d)); }
-
-// one ds_read_b32 per 16-frame tile of y, tile J at byte offset J * 256 of the cell (the offset is an instruction immediate)
-template <int J>
-__device__ __forceinline__ void nn5_issue_tile(float &dst, unsigned addr) {
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(J * 256) : "memory");
-}
-template <int N, int... Js>
-__device__ __forceinline__ void nn5_issue_tiles(float (&b)[N], unsigned addr, std::integer_sequence<int, Js...>) {
-    (nn5_issue_tile<Js>(b[Js], addr), ...);
-}
 
 __device__ __forceinline__ void lds_dma16(const float4 *g, float *lds_wave_uniform) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)lds_wave_uniform, 16, 0, 0);
 }
 
-// (two waves per SIMD at least: with at most 256 registers a wave the compiler keeps the MFMA accumulators in VGPRs; allowed the
-// full 512 it put R in AGPRs and copied it to VGPRs and back around every MFMA -- 41 % matrix-core utilisation)
-// NW waves = x's 16-frame groups: 4 (<= 64 frames, the shipped clips) or 8 (<= 128 frames: cfg4 / cfg5 clip lengths)
-template <int TYT, int NL, int NW = 4>
-__global__ __launch_bounds__(64 * NW, 2) void patchnn5_k(NN2Args a, int groups_x, int CHC) {
-    constexpr int NTHR = 64 * NW;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int KX = 4, KY = 2 * TYT > 7 ? 7 : 2 * TYT;       // DMA pieces per wave and stage at most (x: 13 * 64 / 64 / 4, y: 13 * 128 / 64 / 4)
-    const int RWc = a.ps + (NL - 1) * a.stride;                 // region width in pixels
-    const int PX = a.PX, PY = a.PY, GX = PX >> 4, GY = PY >> 4;   // frames per pixel (whole 16-frame groups) of x / y
-    const int xs4 = CHC * a.ps * PX, ys4 = CHC * a.ps * PY;       // float4 per stage and part
-    const int ybase = xs4 * 4, bufF = (xs4 + ys4) * 4 + (TYT - GY) * 64;   // (+ the over-read of tiles past y's last group)
-    float *E = smem;                                            // [TxP][TyP], one location at a time in the epilogue: aliases the staging
-    float *colw = E + (size_t)a.TxP * a.TyP;
-    const int n2p = (a.n2 + 3) & ~3;                            // (16-byte aligned weight rows: the epilogue reads them four at a time)
-    float *sy = colw + NL * 3 * n2p;                            // [NL][TyP] y terms of the locations   (colw: [NL][3][n2p])
-    const int g = blockIdx.x, by = g / groups_x, bx0 = (g % groups_x) * NL;
-    const int r0 = by * a.stride, c0 = bx0 * a.stride, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cols = min(RWc, a.W - c0);                        // the last group of a row may be narrower
-    const int nloc = min(NL, a.w_o - bx0);
-    f32x4_t acc[NL][TYT], R[TYT];
-#pragma unroll
-    for (int l = 0; l < NL; ++l)
-#pragma unroll
-        for (int j = 0; j < TYT; ++j) acc[l][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < TYT; ++j) R[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float an[NL], Rn = 0.f;                                     // tid < TyP: window sums of v.v for frame tid
-#pragma unroll
-    for (int l = 0; l < NL; ++l) an[l] = 0.f;
-    // per-lane DMA sources: float4 slot idx = piece * 64 + lane of a stage part is (column cc, row r, frame f); its source, relative to
-    // the stage's first column in row r0, is (r * W + cc) * TP + f.  The same for every stage: kept in registers (cc in the top byte).
-    int offx[KX], offy[KY];
-#pragma unroll
-    for (int k = 0; k < KX; ++k) {
-        const int idx = (wave + NW * k) * 64 + lane, cc = fdiv_small(idx, a.ps * PX), rem = idx - cc * a.ps * PX, r = fdiv_small(rem, PX);
-        offx[k] = idx < xs4 ? ((r * a.W + cc) * PX + (rem - r * PX)) | (cc << 24) : -1;
-    }
-#pragma unroll
-    for (int k = 0; k < KY; ++k) {
-        const int idx = (wave + NW * k) * 64 + lane, cc = fdiv_small(idx, a.ps * PY), rem = idx - cc * a.ps * PY, r = fdiv_small(rem, PY);
-        offy[k] = idx < ys4 ? ((r * a.Wy + cc) * PY + (rem - r * PY)) | (cc << 24) : -1;
-    }
-    const int S = (cols + CHC - 1) / CHC;                       // stages
-    auto issue = [&](int st) {
-        const int q0 = st * CHC, nc = min(CHC, cols - q0);
-        float *dst = smem + (st & 1) * bufF;
-        const float4 *xsrc = reinterpret_cast<const float4 *>(a.xt) + ((size_t)r0 * a.W + c0 + q0) * PX;
-        const float4 *ysrc = reinterpret_cast<const float4 *>(a.yt) + ((size_t)r0 * a.Wy + c0 + q0) * PY;
-#pragma unroll
-        for (int k = 0; k < KX; ++k)
-            if (offx[k] >= 0 && (offx[k] >> 24) < nc) lds_dma16(xsrc + (offx[k] & 0xffffff), dst + (wave + NW * k) * 256);
-#pragma unroll
-        for (int k = 0; k < KY; ++k)
-            if (offy[k] >= 0 && (offy[k] >> 24) < nc) lds_dma16(ysrc + (offy[k] & 0xffffff), dst + ybase + (wave + NW * k) * 256);
-    };
-    // operand fragments: a pixel's frames are stored in groups of 16, [group][slot][frame]: the fragment of a 16-frame tile (lane = frame
-    // + 16 * slot) is the group's 64 consecutive floats -- one conflict-free ds_read_b32 per tile.  (With [frame][slot] the two half-waves
-    // of a read met on the same banks: SQ_LDS_BANK_CONFLICT was twice the LDS-active cycles and the matrix cores 51 % busy.)
-    const int xoff = min(wave, GX - 1) * 64 + lane, yoff = ybase + lane;
-    const bool one = lane >= 48;                                 // B slot 3 = 1
-    const bool side = tid < a.TyP;
-    if (!VL3D_ABLATE(a.ablate, 4)) issue(0);
-    for (int st = 0; st < S; ++st) {
-        __syncthreads();                                         // stage st has landed; everyone is done with the other buffer
-        if (st + 1 < S && !VL3D_ABLATE(a.ablate, 4)) issue(st + 1);
-        if VL3D_ABLATE(a.ablate, 2) continue;
-        const int q0 = st * CHC, nc = min(CHC, cols - q0);
-        const float *buf = smem + (st & 1) * bufF;
-        for (int cc = 0; cc < nc; ++cc) {
-            const int q = q0 + cc;
-#pragma unroll
-            for (int l = 0; l < NL; ++l)
-                if (q == l * a.stride) {      // window of location l starts at this column (uniform): acc = R(end) - R(before start)
-#pragma unroll
-                    for (int j = 0; j < TYT; ++j) acc[l][j] -= R[j];
-                    an[l] -= Rn;
-                }
-            const float *xq = buf + xoff + cc * a.ps * PX * 4, *yq = buf + yoff + cc * a.ps * PY * 4;
-            const float *nq = buf + ybase + cc * a.ps * PY * 4 + (side ? (tid >> 4) * 64 + 48 + (tid & 15) : 48);
-            // Operands one row ahead of the MFMAs that use them, in two register sets used alternately: the reads of row r + 1 are issued,
-            // row r is contracted, THEN the reads are waited for.  (The read past the column's last row stays put and is dropped.)  hipcc
-            // folds such reads back to the top of the iteration that uses them, or waits for them with lgkmcnt(0) right after issuing
-            // them, so the reads and their wait are asm statements (the wait hands the registers on, so nothing that uses them can
-            // move above it) fenced by scheduling barriers.
-            {
-                unsigned xad = (unsigned)reinterpret_cast<uintptr_t>(xq), yad = (unsigned)reinterpret_cast<uintptr_t>(yq);
-                unsigned nad = (unsigned)reinterpret_cast<uintptr_t>(nq);
-                const unsigned xstep = PX * 16, ystep = PY * 16;
-                float a0, n0, b0[TYT], a1, n1, b1[TYT];
-                constexpr auto tiles = std::make_integer_sequence<int, TYT>{};
-#define VL3D_NN5_ISSUE(A, N, B)                                                                           \
-    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=&v"(A), "=&v"(N) : "v"(xad), "v"(nad) : "memory"); \
-    nn5_issue_tiles(B, yad, tiles);                                                                       \
-    __builtin_amdgcn_sched_barrier(0)
-#define VL3D_NN5_WAIT(A, N, B)                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                    \
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A), "+v"(N)::"memory");                                    \
-    _Pragma("unroll") for (int j = 0; j < TYT; ++j) asm volatile("" : "+v"(B[j])::"memory")
-#define VL3D_NN5_MMA(A, N, B)                                                                             \
-    _Pragma("unroll") for (int j = 0; j < TYT; ++j) R[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, one ? 1.0f : B[j], R[j], 0, 0, 0); \
-    Rn += N
-#define VL3D_NN5_NEXT(RR)                                                                                 \
-    if ((RR) + 1 < a.ps) { xad += xstep; yad += ystep; nad += ystep; }
-                VL3D_NN5_ISSUE(a0, n0, b0);
-                VL3D_NN5_WAIT(a0, n0, b0);
-                int r = 0;
-                for (; r + 1 < a.ps; r += 2) {
-                    VL3D_NN5_NEXT(r);
-                    VL3D_NN5_ISSUE(a1, n1, b1);
-                    VL3D_NN5_MMA(a0, n0, b0);
-                    VL3D_NN5_WAIT(a1, n1, b1);
-                    VL3D_NN5_NEXT(r + 1);
-                    VL3D_NN5_ISSUE(a0, n0, b0);
-                    VL3D_NN5_MMA(a1, n1, b1);
-                    VL3D_NN5_WAIT(a0, n0, b0);
-                }
-                if (r < a.ps) { VL3D_NN5_MMA(a0, n0, b0); }
-#undef VL3D_NN5_ISSUE
-#undef VL3D_NN5_WAIT
-#undef VL3D_NN5_MMA
-#undef VL3D_NN5_NEXT
-            }
-#pragma unroll
-            for (int l = 0; l < NL; ++l)
-                if (q == l * a.stride + a.ps - 1) {   // ... and ends at this one
-#pragma unroll
-                    for (int j = 0; j < TYT; ++j) acc[l][j] += R[j];
-                    an[l] += Rn;
-                }
-        }
-    }
-    // epilogue, one location at a time through the shared E buffer.  C/D layout of a 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg
-    const int sub = tid & 3;
-    __syncthreads();                                             // the staging buffers are dead from here on
-    if (tid < a.TyP) {
-#pragma unroll
-        for (int l = 0; l < NL; ++l) sy[l * a.TyP + tid] = an[l];
-    }
-    for (int j = tid; j < NL * n2p; j += NTHR) reinterpret_cast<int *>(colw)[(j / n2p) * 3 * n2p + j % n2p] = 0x7f800000;     // column minima start at +inf
-#pragma unroll
-    for (int l = 0; l < NL; ++l) {
-        if (l >= nloc) break;                                    // uniform
-        __syncthreads();                                         // sy written / the previous location's E read
-        float syv[TYT];                                          // the y terms of this lane's columns: read together, ahead of the stores
-#pragma unroll
-        for (int j = 0; j < TYT; ++j) syv[j] = sy[l * a.TyP + min(j * 16 + (lane & 15), a.TyP - 1)];
-#pragma unroll
-        for (int j = 0; j < TYT; ++j)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int row = wave * 16 + (lane >> 4) * 4 + rr, col = j * 16 + (lane & 15);
-                if (row < a.TxP && col < a.TyP) E[row * a.TyP + col] = fmaxf(acc[l][j][rr] + syv[j], 0.0f);
-            }
-        __syncthreads();
-        const size_t b = (size_t)by * a.w_o + bx0 + l;
-        if VL3D_ABLATE(a.ablate, 1) { if (tid < a.n1) a.nn[b * a.n1 + tid] = 0; continue; }
-        nn_epilogue<NTHR, true>(a, E, colw + l * 3 * n2p, n2p, b, tid, sub);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
-// K3 v6: the v5 workgroup with the frame-pair energies on the HALF-PRECISION matrix cores at fp32-class accuracy.
-// v_mfma_f32_16x16x4_f32 runs at the vector rate (32 cycles per 16x16x4 issue); v_mfma_f32_16x16x32_f16 contracts 32 k in 16-17 cycles
-// (16x the rate, MI355X_MICROARCH.md).  The cross term of  e(ti, tj) = |u(ti)|^2 + |v(tj)|^2 - 2 u(ti).v(tj)  is formed from a two-term
+// K3 v6: the v4 workgroup (NL neighbouring locations, a shared ps x (ps + (NL - 1) stride) region, running sums along the region's columns,
+// E through the shared epilogue) with the frame-pair energies on the HALF-PRECISION matrix cores at fp32-class accuracy and the region staged
+// by LDS-DMA, one stage of CHC columns x all ps rows in flight behind the one being contracted.  (Rounds 2-4 ran this workgroup on
+// v_mfma_f32_16x16x4_f32 -- `patchnn5_k`, the vector rate: 32 cycles per 16x16x4 issue, 2.0-2.1 ms at 720p; removed in round 5, its numbers are
+// in DESIGN.)  v_mfma_f32_16x16x32_f16 contracts 32 k in 16-17 cycles (16x the rate, MI355X_MICROARCH.md).  The cross term of  e(ti, tj) = |u(ti)|^2 + |v(tj)|^2 - 2 u(ti).v(tj)  is formed from a two-term
 // split of every value, u = hi + lo with hi = f16(u), lo = f16(u - hi) (11 + 11 mantissa bits; f16 subnormals are kept by the conversion
 // and by the matrix cores, measured in profiles/microbench/dma_f16.hip), as  hi.hi' + hi.lo' + lo.hi'  accumulated in fp32 (the dropped
 // lo.lo' is < 2^-24 of the product: an fp32 rounding).  The two norms are fp32 sums on the side.
 // gram16 form (video_to_gram16_k): per pixel and frame ONE 16-byte piece  [h0 h1 | l0 l1 | h2 l2 | nh nl]  -- the split of the three
 // channels (x: u = x - 1/2; y: -2 v, v = y - 1/2) and of the norm n = sum_c u_c^2 (y: sum_c v_c^2; 22 bits, below the rounding of the fp32 window
-// sum it enters) -- pixel-major [H][W][T] like v5's form, so a region row is one contiguous run for the LDS-DMA (strided lanes cost 5x:
+// sum it enters) -- pixel-major [H][W][T], so a region row is one contiguous run for the LDS-DMA (strided lanes cost 5x:
 // dma_f16.hip) and any crop origin of a prepared clip is valid.
 // One MFMA covers TWO cells (pixels) of a region column for a 16 x 16 frame-pair tile: its four 8-element k blocks (lane >> 4) are
 //   kb 0: cell a, A = [h0 h1 h0 h1 h2 h2 0 0]   kb 1: cell a, A = [l0 l1 0 0 l2 0 0 0]   kb 2 / 3: the same for cell b
@@ -926,7 +700,7 @@ constexpr int nn6_ky(int tyt) { return tyt == 5 ? 4 : (tyt == 8 ? 6 : 7); }
 // NN2Args: PX / PY = frames per pixel of the gram16 x / y (exact, no padding); xt / yt = the gram16 buffers (16-byte pieces).
 // One operand register set: a second one (the reads of chunk c + 1 in flight during the MFMAs of chunk c) takes 202 registers = two waves
 // per SIMD and measured 1.76 / 1.93 ms against 1.54 / 1.47 ms with three (720p, ref / other cfg): the other waves hide the reads better.
-// XS: first x frame of wave w is XS * w.  16: the waves' tiles abut, the epilogue runs workgroup-wide through the shared E (v5's).  14: the
+// XS: first x frame of wave w is XS * w.  16: the waves' tiles abut, the epilogue runs workgroup-wide through the shared E.  14: the
 // tiles overlap by pt - 1 = 2 frames, so wave w holds every frame pair of its 14 patches: each wave finishes its own rows through a
 // private 16-row slab, no workgroup barrier between the locations (no alpha, pt = 3, stridet = 1 only: the column minima of the alpha
 // path need all rows).
@@ -1024,7 +798,7 @@ __global__ __launch_bounds__(64 * NW, TYT == 5 ? 3 : 2) void patchnn6_k(NN2Args 
                                   : (yside ? (unsigned)reinterpret_cast<uintptr_t>(buf + ybase) + (unsigned)(cc * a.ps * FY + tid - NXT) * 16u + 12u
                                            : (unsigned)reinterpret_cast<uintptr_t>(buf));
             unsigned nad1 = nad0 + (nstep2 >> 1);
-            // The reads and their wait are asm statements fenced by scheduling barriers (as in v5), or hipcc folds them back next to their use.
+            // The reads and their wait are asm statements fenced by scheduling barriers, or hipcc folds them back next to their use.
             {
                 u32x4_t a0, b0[TYT];
                 unsigned n00, n01;
@@ -1094,7 +868,7 @@ __global__ __launch_bounds__(64 * NW, TYT == 5 ? 3 : 2) void patchnn6_k(NN2Args 
         for (int l = 0; l < NL; ++l) sy[l * a.TyP + tid - NXT] = yside ? an[l] : 0.f;
     }
     if constexpr (XS == 16) {
-        // one location at a time through the shared E buffer, the whole workgroup on it (v5's epilogue)
+        // one location at a time through the shared E buffer, the whole workgroup on it
         for (int j = tid; j < NL * n2p; j += NTHR) reinterpret_cast<int *>(colw)[(j / n2p) * 3 * n2p + j % n2p] = 0x7f800000;     // column minima start at +inf
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
@@ -1564,9 +1338,9 @@ static inline int pad16(int t) { return (t + 15) / 16 * 16; }
 extern "C" int64_t vl3d_patchnn_scratch_bytes(const vl3d_loss_desc *d) {
     if (!d || d->H <= 0 || d->W <= 0) return 0;
     const int TxU = ((d->Tx - d->pt) / d->stridet) * d->stridet + d->pt;
-    // the larger of the two matrix-core forms: v5 gram-major (4 floats per pixel and frame, whole 16-frame groups) and v6 gram16 (16 bytes
-    // per pixel and frame, exact frame counts)
-    return (int64_t)d->H * d->W * 4 * (pad16(TxU) + pad16(d->Ty)) * (int64_t)sizeof(float);
+    // the larger of the two layouts: v6 gram16 (16 bytes per pixel and frame) and v4's pixel-major copies (3 floats, frames padded to 4)
+    const int64_t v6 = 16 * ((int64_t)TxU + d->Ty), v4 = 12 * ((int64_t)pad4(TxU) + pad4(d->Ty));
+    return (int64_t)d->H * d->W * (v6 > v4 ? v6 : v4);
 }
 
 // The split-f16 matrix-core kernel (v6) and its plan: instantiation, stage size, LDS bytes.  x in at most 16 NW frames (NW = 4 / 8 waves),
@@ -1677,38 +1451,15 @@ static int patchnn_impl(const vl3d_loss_desc *desc, const float *x, const float 
             b.PX = a.TxU; b.PY = desc->Ty;
             return launch_nn6(p6, b, a.w_o, a.h_o, s);
         }
-        // v5 (fp32 matrix cores; explicit variant 3 only, kept for A/B) whenever x's frames fit the waves' 16-frame groups (4 waves: <= 64 frames,
-        // 8 waves: <= 128 frames) and y's its column tiles (5 tiles x 4 locations, 8 x 2, 12 x 1 per wave)
-        const int PX = pad16(a.TxU), PY = pad16(desc->Ty), TyT = PY / 16;
-        const int nw5 = PX <= 64 ? 4 : 8;
-        const int tyt5 = TyT <= 5 ? 5 : (TyT <= 8 ? 8 : 12), nl5 = tyt5 == 5 ? 4 : (tyt5 == 8 ? 2 : 1);
-        const int RWc5 = a.ps + (nl5 - 1) * a.stride;
-        const size_t pad5 = (size_t)(tyt5 - TyT) * 64 * sizeof(float);
-        // stage = the most columns (all ps rows each) whose two buffers leave room for three workgroups per CU (or fit at all)
-        int ch5 = (int)((53 * 1024 / 2 - pad5) / ((size_t)4 * (PX + PY) * sizeof(float))) / a.ps;
-        ch5 = ch5 < 1 ? 1 : (ch5 > RWc5 ? RWc5 : ch5);
-        const size_t stage5 = 2 * ((size_t)ch5 * a.ps * 4 * (PX + PY) * sizeof(float) + pad5), epi5 = ((size_t)a.TxP * a.TyP + 4 * (3 * (a.n2 + 3) + a.TyP)) * sizeof(float);
-        const size_t lds5 = stage5 > epi5 ? stage5 : epi5;
-        const bool fits5 = (size_t)ch5 * a.ps * PX <= (size_t)4 * nw5 * 64 && (size_t)ch5 * a.ps * PY <= (size_t)7 * nw5 * 64 &&  // KX / KY pieces per wave
-                           ((size_t)a.ps * desc->W + ch5) * (PX > PY ? PX : PY) < (1u << 24);                  // 24-bit DMA source offsets
-        const bool use_v5 = pv == 3 && PX <= 128 && TyT <= 12 && lds5 <= 150 * 1024 && fits5;
+        VL3D_REQUIRE(pv != 3 && pv != 6, "vl3d_patchnn: variant 3 (the fp32 matrix-core kernel) was removed in round 5; variant 6 needs clip lengths within the matrix-core kernel's range");
         float *xt = (float *)scratch;
-        float *yt = xt + (size_t)desc->H * desc->W * (use_v5 ? 4 * PX : 3 * a.TxP);
-        if (use_v5) {
-            hipLaunchKernelGGL(video_to_gram_major_k<false>, tg, dim3(256), 0, s, x, desc->x_sc, desc->x_st, desc->x_sr, a.TxU, PX / 16,
-                               desc->H, desc->W, xt);
-            if (!(desc->variant & 0x100))
-                hipLaunchKernelGGL(video_to_gram_major_k<true>, tg, dim3(256), 0, s, y, desc->y_sc, desc->y_st, desc->y_sr, desc->Ty, PY / 16,
-                                   desc->H, desc->W, yt);
-        } else {
-            hipLaunchKernelGGL(video_to_pixel_major_k, tg, dim3(256), 0, s, x, desc->x_sc, desc->x_st, desc->x_sr, a.TxU, a.TxP,
-                               desc->H, desc->W, xt);
-            if (!(desc->variant & 0x100))
-                hipLaunchKernelGGL(video_to_pixel_major_k, tg, dim3(256), 0, s, y, desc->y_sc, desc->y_st, desc->y_sr, desc->Ty, a.TyP,
-                                   desc->H, desc->W, yt);
-        }
+        float *yt = xt + (size_t)desc->H * desc->W * 3 * a.TxP;
+        hipLaunchKernelGGL(video_to_pixel_major_k, tg, dim3(256), 0, s, x, desc->x_sc, desc->x_st, desc->x_sr, a.TxU, a.TxP,
+                           desc->H, desc->W, xt);
+        if (!(desc->variant & 0x100))
+            hipLaunchKernelGGL(video_to_pixel_major_k, tg, dim3(256), 0, s, y, desc->y_sc, desc->y_st, desc->y_sr, desc->Ty, a.TyP,
+                               desc->H, desc->W, yt);
         b.xt = xt; b.yt = yt;
-        b.PX = PX; b.PY = PY;
         static bool attr2 = false;
         if (!attr2) {
             VL3D_HIP(hipFuncSetAttribute((const void *)patchnn2_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1720,25 +1471,7 @@ static int patchnn_impl(const vl3d_loss_desc *desc, const float *x, const float 
         const size_t stage4 = (size_t)RWc4 * 3 * (a.TxP + a.TyP), epi4 = (size_t)a.TxP * a.TyP + 3 * (a.n2 + 3);   // the epilogue aliases the staging
         const size_t lds4 = (stage4 > epi4 ? stage4 : epi4) * sizeof(float);
         const bool use_v4 = (pv == 0 || pv == 4) && ntiles4 <= 1024 && lds4 <= 150 * 1024;
-        if (use_v5) {
-            const int groups_x = (a.w_o + nl5 - 1) / nl5;
-            const dim3 grid5((unsigned)(groups_x * a.h_o));
-#define VL3D_LAUNCH5(TYT_, NL_, NW_)                                                                                               \
-    {                                                                                                                              \
-        static bool attr = false;                                                                                                  \
-        if (!attr) {                                                                                                               \
-            VL3D_HIP(hipFuncSetAttribute((const void *)patchnn5_k<TYT_, NL_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr = true;                                                                                                           \
-        }                                                                                                                          \
-        hipLaunchKernelGGL((patchnn5_k<TYT_, NL_, NW_>), grid5, dim3(64 * NW_), lds5, s, b, groups_x, ch5);                          \
-    }
-            if (nw5 == 4) {
-                if (tyt5 == 5) VL3D_LAUNCH5(5, 4, 4) else if (tyt5 == 8) VL3D_LAUNCH5(8, 2, 4) else VL3D_LAUNCH5(12, 1, 4)
-            } else {
-                if (tyt5 == 5) VL3D_LAUNCH5(5, 4, 8) else if (tyt5 == 8) VL3D_LAUNCH5(8, 2, 8) else VL3D_LAUNCH5(12, 1, 8)
-            }
-#undef VL3D_LAUNCH5
-        } else if (use_v4) {
+        if (use_v4) {
             static bool attr4 = false;
             if (!attr4) {
 #define VL3D_ATTR4(R, N) VL3D_HIP(hipFuncSetAttribute((const void *)patchnn4_k<R, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))

@@ -342,14 +342,9 @@ extern "C" int vl3d_tie_static_grad(int32_t D, int32_t T, int32_t Hs, int32_t Ws
 __global__ __launch_bounds__(256) void adam_tiles_k(int T, int Hs, int Ws, const unsigned char *__restrict__ keep,
                                                     const unsigned char *__restrict__ dyn, int QH, int QW,
                                                     float4 *__restrict__ p, const float4 *__restrict__ g, float4 *__restrict__ m,
-                                                    float4 *__restrict__ v, float lr_bc1, float beta1, float beta2, float eps, float bc2s,
-                                                    const float2 *__restrict__ step_scalars) {
+                                                    float4 *__restrict__ v, float lr_bc1, float beta1, float beta2, float eps, float bc2s) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), d = blockIdx.z;
     if (x >= Ws || y >= Hs) return;
-    if (step_scalars) {      // (lr / bc1, sqrt(bc2)) of this step from DEVICE memory: a launch recorded in a hipGraph serves every step
-        const float2 sc = *step_scalars;
-        lr_bc1 = sc.x; bc2s = sc.y;
-    }
     bool is_static = false;
     if (keep) {
         const int ylo = quad_index(y - 1, Hs, QH), yhi = quad_index(y + 1, Hs, QH), xlo = quad_index(x - 1, Ws, QW), xhi = quad_index(x + 1, Ws, QW);
@@ -387,14 +382,14 @@ __global__ __launch_bounds__(256) void adam_tiles_k(int T, int Hs, int Ws, const
 
 static int adam_step_tiles_impl(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uint8_t *quad_keep, const uint8_t *quad_dyn,
                                 int32_t QH, int32_t QW, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float lr_bc1,
-                                float beta1, float beta2, float eps, float bc2s, const float *step_scalars, vl3d_stream_t stream) {
+                                float beta1, float beta2, float eps, float bc2s, vl3d_stream_t stream) {
     VL3D_REQUIRE(D > 0 && D <= 65535 && T > 0 && Hs > 0 && Ws > 0, "vl3d_adam_step_tiles: bad dims");
     VL3D_REQUIRE(param && grad && exp_avg && exp_avg_sq, "vl3d_adam_step_tiles: null pointer");
     VL3D_REQUIRE(!quad_keep || (QH > 0 && QW > 0), "vl3d_adam_step_tiles: bad quad grid");
     hipLaunchKernelGGL(adam_tiles_k, dim3((Ws + 63) / 64, (Hs + 3) / 4, D), dim3(256), 0, (hipStream_t)stream, T, Hs, Ws, quad_keep,
                        quad_keep ? quad_dyn : nullptr, QH, QW,
                        reinterpret_cast<float4 *>(param), reinterpret_cast<const float4 *>(grad), reinterpret_cast<float4 *>(exp_avg),
-                       reinterpret_cast<float4 *>(exp_avg_sq), lr_bc1, beta1, beta2, eps, bc2s, reinterpret_cast<const float2 *>(step_scalars));
+                       reinterpret_cast<float4 *>(exp_avg_sq), lr_bc1, beta1, beta2, eps, bc2s);
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
 }
@@ -406,13 +401,5 @@ extern "C" int vl3d_adam_step_tiles(int32_t D, int32_t T, int32_t Hs, int32_t Ws
     VL3D_REQUIRE(step >= 1, "vl3d_adam_step_tiles: bad step");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     return adam_step_tiles_impl(D, T, Hs, Ws, quad_keep, quad_dyn, QH, QW, param, grad, exp_avg, exp_avg_sq, (float)((double)lr / bc1), beta1, beta2,
-                                eps, (float)sqrt(bc2), nullptr, stream);
-}
-
-extern "C" int vl3d_adam_step_tiles_dev(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uint8_t *quad_keep, const uint8_t *quad_dyn,
-                                        int32_t QH, int32_t QW, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
-                                        const float *step_scalars, float beta1, float beta2, float eps, vl3d_stream_t stream) {
-    VL3D_REQUIRE(step_scalars != nullptr, "vl3d_adam_step_tiles_dev: null step scalars");
-    return adam_step_tiles_impl(D, T, Hs, Ws, quad_keep, quad_dyn, QH, QW, param, grad, exp_avg, exp_avg_sq, 0.0f, beta1, beta2, eps, 1.0f,
-                                step_scalars, stream);
+                                eps, (float)sqrt(bc2), stream);
 }

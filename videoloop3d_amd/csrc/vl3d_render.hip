@@ -388,9 +388,9 @@ extern "C" int vl3d_render_bwd_adam(const vl3d_render_desc *desc, const void *st
     const int bv = desc->variant & 0xf;
     if (!(desc->coord_mode == VL3D_COORD_AFFINE && desc->border_mode == VL3D_BORDER_HARDCUT && desc->act_order == VL3D_ACT_POST &&
           desc->rgb_act == VL3D_ACT_SIGMOID && desc->alpha_act == VL3D_ACT_SIGMOID && desc->stack_dtype == VL3D_F32 &&
-          (qk ? (bv == 0 || bv == 3) : (desc->T >= 2 && (bv == 0 || bv == 3))))) {
+          (qk ? (bv == 0 || bv == 3) : (desc->T >= 2 && bv == 0)))) {
         vl3d_set_error("vl3d_render_bwd_adam: built for the stage-2 iteration -- (affine, hardcut, post), sigmoid / sigmoid, fp32 stack, "
-                       "T >= 2 for a dense model, variant 0 / 3; use vl3d_render_bwd(_culled) + vl3d_adam_window_step otherwise");
+                       "T >= 2 and variant 0 for a dense model; use vl3d_render_bwd(_culled) + vl3d_adam_window_step otherwise");
         return VL3D_EUNSUPPORTED;
     }
     VL3D_REQUIRE(scratch_bytes >= vl3d_render_bwd_scratch_bytes(desc), "vl3d_render_bwd_adam: scratch smaller than vl3d_render_bwd_scratch_bytes()");
@@ -425,7 +425,7 @@ extern "C" int vl3d_render_bwd_adam(const vl3d_render_desc *desc, const void *st
     a.grad_culled_unwritten = qk ? 1 : 0;
     a.plan = (const float *)scratch;
     a.owner = reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(scratch) + owner_table_off(desc));
-    a.tile_rows = (bv == 3 || qk) ? 16 : 17;      // 16: the one-frame tile kernel (64-wide regions) instead of the frame pairs
+    a.tile_rows = qk ? 16 : 17;      // 16: the one-frame tile kernel (64-wide regions, tile-culled models), 17: the frame pairs
     const double bc1 = 1.0 - pow((double)adam->beta1, (double)adam->step), bc2 = 1.0 - pow((double)adam->beta2, (double)adam->step);
     const int ts = vl3d_adam::TS;
     a.ad.p = reinterpret_cast<float4 *>(adam->param); a.ad.m = reinterpret_cast<float4 *>(adam->exp_avg);

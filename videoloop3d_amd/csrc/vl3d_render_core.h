@@ -1919,13 +1919,9 @@ void launch_tile(const RenderArgs &a, hipStream_t s) {
                        reinterpret_cast<int *>(const_cast<float *>(a.plan)) + plan_win_off(a.D));
     hipLaunchKernelGGL(bwd_owner_table_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x,
                        const_cast<unsigned short *>(a.owner));
-    if constexpr (ADAM) {
-        if (a.quad_keep)
-            hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, true, false, true, false, true>),
-                               dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
-        else
-            hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, true, false, false, false, true>),
-                               dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
+    if constexpr (ADAM) {      // (tile-culled models only: the dense fused step rides the frame pairs -- the one-frame form measured 202 against 213-218 it/s)
+        hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, true, false, true, false, true>),
+                           dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
     } else if constexpr (MASK) {       // (dense models only: the entry point refuses a quad map)
         hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16, false, true>),
                            dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
@@ -1963,8 +1959,8 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
             if constexpr (COORD == VL3D_COORD_AFFINE && BORDER == VL3D_BORDER_HARDCUT && ORDER == VL3D_ACT_POST && RACT == VL3D_ACT_SIGMOID &&
                           AACT == VL3D_ACT_SIGMOID && !F16 && VL3D_HS == 9) {
                 if (a.ad.p) {
-                    // tile-culled models and variant 3: one frame per thread, 64-wide regions (the frame pairs are built for dense stacks)
-                    if (a.tile_rows == 16 || a.quad_keep) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, false, false, true>(a, s);
+                    // tile-culled models: one frame per thread, 64-wide regions (the frame pairs are built for dense stacks)
+                    if (a.quad_keep) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, false, false, true>(a, s);
                     else if (a.g_reg || a.g_asum) launch_pair<COORD, BORDER, ORDER, RACT, AACT, false, true, true>(a, s);
                     else launch_pair<COORD, BORDER, ORDER, RACT, AACT, false, false, true>(a, s);
                     hipLaunchKernelGGL((render_bwd_k<COORD, BORDER, ORDER, RACT, AACT, F16>), grid, block, 0, s, a);

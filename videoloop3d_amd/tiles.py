@@ -204,29 +204,6 @@ class TileAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.quad_keep = quad_keep
         self.quad_dyn = quad_dyn
-        # graph mode (videoloop3d_amd/graphs.py): the step's scalars live in a device tensor per parameter group, filled by prepare_step()
-        # on the host BEFORE the recorded iteration is replayed; step() then launches vl3d_adam_step_tiles_dev and counts nothing itself
-        self.device_scalars = None
-
-    def use_device_scalars(self, device):
-        """switch to graph mode: (lr / bc1, sqrt(bc2)) of every step come from device memory (one device pair per group)."""
-        self.device_scalars = [(torch.zeros(2, dtype=torch.float32, device=device), None) for _ in self.param_groups]
-        self._graph_step = max([int(st.get("step", 0)) for st in self.state.values()] + [0])
-
-    def prepare_step(self):
-        """graph mode, on the host before a replay: the next step's scalars (from each group's CURRENT lr) into the device tensors."""
-        import ctypes as C
-        from . import _lib as L
-        self._graph_step += 1
-        for group, (dev_t, pin_t) in zip(self.param_groups, self.device_scalars):
-            a, b = C.c_float(), C.c_float()
-            b1, b2 = group["betas"]
-            L.lib().vl3d_adam_step_scalars(float(group["lr"]), float(b1), float(b2), self._graph_step, C.byref(a), C.byref(b))
-            dev_t[0].fill_(a.value)          # (the values travel as kernel arguments: no staging buffer the host could overwrite too early)
-            dev_t[1].fill_(b.value)
-        for st in self.state.values():
-            if "step" in st:
-                st["step"] = self._graph_step
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -261,14 +238,6 @@ class TileAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p)
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 D, T, Hs, Ws = dims
-                if self.device_scalars is not None:
-                    sc = self.device_scalars[self.param_groups.index(group)][0]
-                    with torch.cuda.device(p.device):
-                        L.check(L.lib().vl3d_adam_step_tiles_dev(D, T, Hs, Ws, L.ptr(qk), L.ptr(qd), 0 if qk is None else qk.shape[1],
-                                                                 0 if qk is None else qk.shape[2], L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]),
-                                                                 L.ptr(st["exp_avg_sq"]), L.ptr(sc), float(b1), float(b2), float(group["eps"]),
-                                                                 L.stream_ptr(p.device)), "vl3d_adam_step_tiles_dev")
-                    continue
                 st["step"] += 1
                 with torch.cuda.device(p.device):
                     L.check(L.lib().vl3d_adam_step_tiles(D, T, Hs, Ws, L.ptr(qk), L.ptr(qd), 0 if qk is None else qk.shape[1],
