@@ -63,7 +63,10 @@ __global__ __launch_bounds__(512) void render_like_k(const f4 *__restrict__ src,
 // ALIGNED to SNAP texels (ownership snapped to SNAP-texel columns: what aligned ownership would give), 3 = 2 with plain stores
 // HX: halo columns on either side (1 = the shipped kernels).  Ownership snapped to SNAP-texel columns moves a segment's ends by up to
 // SNAP / 2 texels, so a REAL aligned-ownership kernel has to stage 1 + SNAP / 2 halo columns: HX = 3 for SNAP = 4 (26 of 32 columns owned).
-template <int RX, int RY, int FR, int TAPS, bool OWNER, int STORE = 0, int SNAP = 8, int HX = 1>
+// HY: halo rows above and below (1 = the shipped kernels; 0 = the memory pattern of a backward WITHOUT the vertical halo -- a persistent
+// workgroup walking a column strip top to bottom that carries the boundary rows' staged values from block to block: its upper bound, the
+// carry itself costs nothing here).
+template <int RX, int RY, int FR, int TAPS, bool OWNER, int STORE = 0, int SNAP = 8, int HX = 1, int HY = 1>
 __global__ __launch_bounds__(RX *RY) void bwd_like_k(const f4 *__restrict__ src, f4 *__restrict__ dst, const unsigned short *__restrict__ owner, int D,
                                                      int T, int Hs, int Ws, int tiles_x, int tiles_y) {
     const int b = blockIdx.x;
@@ -73,11 +76,12 @@ __global__ __launch_bounds__(RX *RY) void bwd_like_k(const f4 *__restrict__ src,
     const int lx = threadIdx.x % RX, ly = threadIdx.x / RX;
     constexpr int IWX = RX - 2 * HX;
     const int gx = tile_x * IWX - HX + lx;
-    const int x = min(max(gx, 0), Ws - 2), y = min(max(tile_y * (RY - 2) - 1 + ly, 0), Hs - 2);
-    bool interior = lx >= HX && lx < RX - HX && ly >= 1 && ly < RY - 1 && gx < Ws && tile_y * (RY - 2) - 1 + ly < Hs;
+    const int gy = tile_y * (RY - 2 * HY) - HY + ly;
+    const int x = min(max(gx, 0), Ws - 2), y = min(max(gy, 0), Hs - 2);
+    bool interior = lx >= HX && lx < RX - HX && ly >= HY && ly < RY - HY && gx < Ws && gy < Hs;
     if constexpr (STORE >= 2) {      // owned columns [snap(tile_x * IW), snap((tile_x + 1) * IW)): every column owned exactly once, SNAP-aligned ends
         const int l = (tile_x * IWX + SNAP / 2) / SNAP * SNAP, rr = ((tile_x + 1) * IWX + SNAP / 2) / SNAP * SNAP;
-        interior = gx >= l && gx < rr && gx < Ws && ly >= 1 && ly < RY - 1 && tile_y * (RY - 2) - 1 + ly < Hs && gx >= 0;
+        interior = gx >= l && gx < rr && gx < Ws && ly >= HY && ly < RY - HY && gy < Hs && gx >= 0;
     }
     const size_t frame = (size_t)Hs * Ws, plane = (size_t)T * frame;
     size_t o = (size_t)t0 * frame + (size_t)y * Ws + x;
@@ -301,7 +305,7 @@ static void run(const char *name, F launch, double bytes) {
 }
 
 int main(int argc, char **argv) {
-    const bool aligned_only = argc > 1 && (argv[1][0] == 'a' || argv[1][0] == 'h' || argv[1][0] == 'f');      // ./rw_bw aligned | halo: only that comparison at the end
+    const bool aligned_only = argc > 1 && (argv[1][0] == 'a' || argv[1][0] == 'h' || argv[1][0] == 'f' || argv[1][0] == 'v');      // ./rw_bw aligned | halo: only that comparison at the end
     const bool halo_only = argc > 1 && argv[1][0] == 'h';
     const size_t unit = 8ull << 30, n = unit / 16;     // 8 GiB per stream
     f4 *src, *dst;
@@ -418,6 +422,26 @@ int main(int argc, char **argv) {
             }
         }
         printf("fused = row 2;  unfused = row 1 + row 3\n");
+        return 0;
+    }
+    // A backward WITHOUT the vertical halo (round 5): the shipped pattern against its no-vertical-halo upper bound, same geometry.
+    if (argc > 1 && argv[1][0] == 'v') {
+        const int D = 32, T = 12, Hs = 720, Ws = 1280;
+        const double bytes = 2.0 * D * T * Hs * Ws * 16;
+        unsigned short *owner;
+        hipMalloc(&owner, (size_t)D * Hs * Ws * 2 + 4096);
+        hipMemset(owner, 0, (size_t)D * Hs * Ws * 2 + 4096);
+#define BLV(RX, RY, FR, HY)                                                                                                    \
+        {                                                                                                                      \
+            const int tx = (Ws + RX - 3) / (RX - 2), ty = (Hs + RY - 2 * HY - 1) / (RY - 2 * HY);                              \
+            snprintf(name, sizeof name, "bwd_like  region %3d x %2d  frames %d  vertical halo %d  (x%.2f pixels swept per pixel owned)", RX, RY, FR, HY, \
+                     (double)RX * RY / ((RX - 2) * (RY - 2 * HY)));                                                            \
+            run(name, [&] { hipLaunchKernelGGL((bwd_like_k<RX, RY, FR, 4, true, 0, 8, 1, HY>), dim3((unsigned)(tx * ty * (T / FR))), dim3(RX * RY), 0, 0, \
+                                               src, dst, owner, D, T, Hs, Ws, tx, ty); }, bytes);                              \
+        }
+        for (int rep = 0; rep < 3; ++rep) {
+            BLV(32, 16, 2, 1) BLV(32, 16, 2, 0) BLV(64, 16, 1, 1) BLV(64, 16, 1, 0) BLV(64, 8, 2, 1) BLV(64, 8, 2, 0)
+        }
         return 0;
     }
     // Halo-atomics backward against the shipped halo pattern (round 4), same geometry, algorithmic bytes as the unit.

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak of the matrix-core patch-NN kernel (variant 6; 0x806 = its workgroup-wide epilogue everywhere) over random clip lengths, patch sizes, strides, alphas and frame sizes: the
+"""Soak of the matrix-core patch-NN kernel (the default, variant 0, wherever the clip lengths fit it; 0x800 = its workgroup-wide epilogue everywhere) over random clip lengths, patch sizes, strides, alphas and frame sizes: the
 indices must equal the fp64-exact objective's wherever its top-2 gap exceeds 1e-5 of the row's range (the criterion of
 tests/test_gpu_loss.py), and v4 (variant 4) must pass the same check.   python profiles/soak_nn.py [seeds] [first]"""
 import os, sys, random
@@ -30,7 +30,7 @@ for seed in range(first, first + n):
     if seed % 5 == 0:                                   # near-duplicate frames: many near-ties and Gram cancellation
         y[:, :, : min(tx, ty)] = x[:, :, : min(tx, ty)] + 1e-4 * torch.randn_like(x[:, :, : min(tx, ty)])
     res = []
-    for variant in ("6", "0x806", "4"):
+    for variant in ("0", "0x800", "4"):
         UV.KERNEL_VARIANT = int(variant, 0)
         _, _, nng = _nn_and_fold(x.to(dev), y.to(dev), ps, 3, s, 1, alpha, normalize=False)
         nbad, unexplained = nn_mismatch_is_near_tie(x, y, ps, 3, s, 1, alpha, nng)
