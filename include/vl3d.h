@@ -381,6 +381,11 @@ int vl3d_video_to_gram_major(const float *y, int64_t sc, int64_t st, int64_t sr,
                              vl3d_stream_t stream);
 int vl3d_patchnn_prepared(const vl3d_loss_desc *desc, const float *x, const float *y_gram, int32_t y_pitch, int32_t y_rows,
                           int32_t y_row0, int32_t y_col0, int32_t *nn, void *scratch, vl3d_stream_t stream);
+/* ... with x in that form too (vl3d_loop_pad_fwd_gram writes it beside the video: the render's output is read once for both layouts of the
+ * loss, MPV.py:484-507 -> utils_vid.py:209-216): x_gram holds an x_rows x x_pitch clip of x_frames frames, desc (Tx, H, W) names its
+ * leading frames / rows / columns (the loss's trim to the patch grid, utils_vid.py:307-320).  No scratch. */
+int vl3d_patchnn_grams(const vl3d_loss_desc *desc, const float *x_gram, int32_t x_pitch, int32_t x_rows, int32_t x_frames, const float *y_gram,
+                       int32_t y_pitch, int32_t y_rows, int32_t y_row0, int32_t y_col0, int32_t *nn, vl3d_stream_t stream);
 
 /* get_NN_indices_low_memory(X[B,n1,...], Y[B,n2,...], alpha, chunksz, 'mse') on MATERIALISED patches
  * (utils_vid.py:122-142; the caller evaluations/NNMSE.py:45-56 builds them with extract_3Dpatches).
@@ -431,6 +436,9 @@ int vl3d_scale_inplace(int64_t n, float *x, const float *scale, vl3d_stream_t st
  * frame strides gx_sc / gx_st in floats (unit column stride, rows contiguous). */
 int vl3d_loop_gain(int32_t T, int32_t F, int32_t h, int32_t w, const float *rgb, const float *res, double *log_sum, vl3d_stream_t stream);
 int vl3d_loop_pad_fwd(int32_t T, int32_t pad, int32_t h, int32_t w, const float *rgb, const double *log_sum, float *x, vl3d_stream_t stream);
+/* ... writing, beside x, its form for the NN search: x_gram = vl3d_gram_major_bytes(T + pad, h, w) bytes (for vl3d_patchnn_grams). */
+int vl3d_loop_pad_fwd_gram(int32_t T, int32_t pad, int32_t h, int32_t w, const float *rgb, const double *log_sum, float *x, float *x_gram,
+                           vl3d_stream_t stream);
 int vl3d_loop_pad_bwd(int32_t T, int32_t pad, int32_t h, int32_t w, const float *grad_x, int64_t gx_sc, int64_t gx_st, const double *log_sum,
                       float *grad_rgb, vl3d_stream_t stream);
 

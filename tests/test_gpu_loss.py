@@ -525,3 +525,31 @@ def test_prepared_clip_crops_give_the_same_indices_and_loss(dev):
             assert torch.equal(la.last_y2x, lb.last_y2x) and torch.equal(la.last_weight, lb.last_weight)
     with pytest.raises(RuntimeError, match="leaves the prepared clip"):
         find_nn_indices(x.detach()[..., :35, :47], clip[..., :35, :47], 3, 3, 2, 1, None, y_prepared=pc.crop(Hf - 10, 0))
+
+
+@pytest.mark.parametrize("T,pad,h,w,ps,s,alpha", [(10, 2, 37, 53, 11, 4, 0.0), (9, 2, 30, 70, 3, 2, None), (50, 2, 45, 67, 5, 2, 0.5)])
+def test_loss_prologue_writes_the_search_form_of_x(dev, T, pad, h, w, ps, s, alpha):
+    """vl3d_loop_pad_fwd_gram: the loop-padded, gained video AND its gram16 form from one pass over the render's NHWC output -- the video
+    equals vl3d_loop_pad_fwd's bit for bit, and the search on (x form, prepared clip) through vl3d_patchnn_grams returns the indices of the
+    search that rewrites x itself, also when the loss trims x to the patch grid (the form keeps the untrimmed pitch and frame count)."""
+    from videoloop3d_amd import _lib as L
+    from videoloop3d_amd.MPV import _LoopPrologue
+    from videoloop3d_amd.utils_vid import PreparedClip, PreparedX, find_nn_indices, fit_patch
+    import warnings
+    rgb = synth.hash_uniform((T, h, w, 3), seed=11, device=dev)
+    res = synth.hash_uniform((14, 3, h, w), seed=12, device=dev)
+    x0, g0 = _LoopPrologue.apply(rgb, res, pad, False)
+    x1, g1 = _LoopPrologue.apply(rgb, res, pad, True)
+    assert g0.numel() == 0 and g1.numel() * 4 == 16 * h * w * (T + pad) and torch.equal(x0, x1)
+    y = res.permute(1, 0, 2, 3)[None].contiguous()
+    yp = PreparedClip(y).crop(0, 0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hh, ww, tt = fit_patch(h, "h", ps, s), fit_patch(w, "w", ps, s), fit_patch(T + pad, "t", 3, 1)
+    xs, ys = x1[..., :tt, :hh, :ww], y[..., :hh, :ww]
+    nn_a = find_nn_indices(xs, ys, ps, 3, s, 1, alpha, y_prepared=yp)[0]
+    nn_b = find_nn_indices(xs, ys, ps, 3, s, 1, alpha, y_prepared=yp, x_prepared=PreparedX(g1, T + pad, h, w))[0]
+    assert torch.equal(nn_a, nn_b)
+    # ... and a form that does not belong to this x is refused by its dimensions, falling back to the rewrite
+    nn_c = find_nn_indices(xs, ys, ps, 3, s, 1, alpha, y_prepared=yp, x_prepared=PreparedX(g1, tt - 1, h, w))[0]
+    assert torch.equal(nn_a, nn_c)

@@ -389,7 +389,7 @@ def test_loss_prologue_equals_the_torch_chain(dev, gain):
     T, F, h, w, pad = 7, 9, 37, 53, 2
     rgb = synth.hash_uniform((T, h, w, 3), seed=3).to(dev).requires_grad_(True)
     res = synth.hash_uniform((F, 3, h, w), seed=4).to(dev)
-    x = _LoopPrologue.apply(rgb, res if gain else None, pad)
+    x, _ = _LoopPrologue.apply(rgb, res if gain else None, pad)
     r = rgb.detach().clone().requires_grad_(True)
     rp = r.permute(0, 3, 1, 2)
     rp_pad = torch.cat([rp, rp[:pad]], 0)

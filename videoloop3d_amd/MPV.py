@@ -53,7 +53,7 @@ class _LoopPrologue(torch.autograd.Function):
     backward reads.  rgb [T,h,w,3] contiguous float32 CUDA; res [F,3,h,w] or None (no gain)."""
 
     @staticmethod
-    def forward(ctx, rgb, res, pad):
+    def forward(ctx, rgb, res, pad, want_gram=False):
         from . import _lib as L
         L.check_cuda(rgb)
         T, h, w, _ = rgb.shape
@@ -69,12 +69,18 @@ class _LoopPrologue(torch.autograd.Function):
                 log_sum = torch.empty(1, dtype=torch.float64, device=dev)
                 L.check(L.lib().vl3d_loop_gain(T, res.shape[0], h, w, L.ptr(rgb), L.ptr(res), L.ptr(log_sum), L.stream_ptr(dev)), "vl3d_loop_gain")
             x = torch.empty((1, 3, T + pad, h, w), dtype=torch.float32, device=dev)
-            L.check(L.lib().vl3d_loop_pad_fwd(T, pad, h, w, L.ptr(rgb), L.ptr(log_sum), L.ptr(x), L.stream_ptr(dev)), "vl3d_loop_pad_fwd")
+            if want_gram:      # x's form for the NN search in the same pass over the render's output (utils_vid.PreparedX)
+                xg = torch.empty(int(L.lib().vl3d_gram_major_bytes(T + pad, h, w)) // 4, dtype=torch.float32, device=dev)
+                L.check(L.lib().vl3d_loop_pad_fwd_gram(T, pad, h, w, L.ptr(rgb), L.ptr(log_sum), L.ptr(x), L.ptr(xg), L.stream_ptr(dev)), "vl3d_loop_pad_fwd_gram")
+            else:
+                xg = torch.empty(0, dtype=torch.float32, device=dev)
+                L.check(L.lib().vl3d_loop_pad_fwd(T, pad, h, w, L.ptr(rgb), L.ptr(log_sum), L.ptr(x), L.stream_ptr(dev)), "vl3d_loop_pad_fwd")
         ctx.log_sum, ctx.dims = log_sum, (T, pad, h, w)
-        return x
+        ctx.mark_non_differentiable(xg)
+        return x, xg
 
     @staticmethod
-    def backward(ctx, gx):
+    def backward(ctx, gx, _gxg=None):
         from . import _lib as L
         T, pad, h, w = ctx.dims
         gx = gx[0]
@@ -85,7 +91,7 @@ class _LoopPrologue(torch.autograd.Function):
         with torch.cuda.device(dev):
             L.check(L.lib().vl3d_loop_pad_bwd(T, pad, h, w, L.ptr(gx), gx.stride(0), gx.stride(1), L.ptr(ctx.log_sum), L.ptr(g_rgb),
                                               L.stream_ptr(dev)), "vl3d_loop_pad_bwd")
-        return g_rgb, None, None
+        return g_rgb, None, None, None
 
 
 class _PixelTerms(torch.autograd.Function):
@@ -749,7 +755,12 @@ class MPMeshVid(nn.Module):
         pad_frame = self.swd_patcht_size - 1 if self.isloop else 0
         if rgb_nhwc.is_cuda and rgb_nhwc.dtype == torch.float32 and pad_frame <= rgb_nhwc.shape[0] and not getattr(a, "unfused_prologue", False):
             # loop padding + scale-invariant gain + the loss's layout (and their backward) in three launches
-            x = _LoopPrologue.apply(rgb_nhwc, res[0] if a.scale_invariant else None, pad_frame)
+            # (a patch-NN loss with a prepared captured clip takes x in the search's own form too, written in the same pass)
+            want_gram = losscfg.get("y_prepared") is not None and str(loss_name).startswith("gpnn")
+            x, xg = _LoopPrologue.apply(rgb_nhwc, res[0] if a.scale_invariant else None, pad_frame, want_gram)
+            if want_gram:
+                from .utils_vid import PreparedX
+                losscfg = dict(losscfg, x_prepared=PreparedX(xg, rgb_nhwc.shape[0] + pad_frame, rgb_nhwc.shape[1], rgb_nhwc.shape[2]))
         else:
             rgb_pad = rgb
             if self.isloop:

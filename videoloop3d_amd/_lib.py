@@ -93,6 +93,7 @@ SIGNATURES = {
     "vl3d_gram_major_bytes": ([_I32, _I32, _I32], C.c_int64),
     "vl3d_video_to_gram_major": ([_P, _I64, _I64, _I64, _I32, _I32, _I32, _P, _P], C.c_int),
     "vl3d_patchnn_prepared": ([C.POINTER(LossDesc), _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P], C.c_int),
+    "vl3d_patchnn_grams": ([C.POINTER(LossDesc), _P, _I32, _I32, _I32, _P, _I32, _I32, _I32, _I32, _P, _P], C.c_int),
     "vl3d_nn_vectors": ([_I64, _I32, _I32, _I32, _P, _P, _I32, _F, _P, _P], C.c_int),
     "vl3d_patch_l1": ([C.POINTER(LossDesc), _P, _P, _P, _P, _P], C.c_int),
     "vl3d_vote_fold": ([C.POINTER(LossDesc), _P, _P, _P, _P, _I32, _P], C.c_int),
@@ -102,6 +103,7 @@ SIGNATURES = {
     "vl3d_scale_inplace": ([_I64, _P, _P, _P], C.c_int),
     "vl3d_loop_gain": ([_I32] * 4 + [_P, _P, _P, _P], C.c_int),
     "vl3d_loop_pad_fwd": ([_I32] * 4 + [_P, _P, _P, _P], C.c_int),
+    "vl3d_loop_pad_fwd_gram": ([_I32] * 4 + [_P, _P, _P, _P, _P], C.c_int),
     "vl3d_loop_pad_bwd": ([_I32] * 4 + [_P, _I64, _I64, _P, _P, _P], C.c_int),
     "vl3d_pixel_terms": ([_I64, _P, _P, _F, _P, _P, _P, _P], C.c_int),
     "vl3d_stage1_loss": ([_I32] * 4 + [_P, _I64, _I64, _I64, _P, _P, _I32, _P, _P, _P, _P], C.c_int),

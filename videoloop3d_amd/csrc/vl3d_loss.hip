@@ -159,6 +159,7 @@ struct NN2Args {
     int TxP, TyP, K, KC;
     int PX, PY;             // v6: frames per pixel of the gram16 copies of x / y (exact)
     int Wy;                 // v6: pixels per row of the gram16 y (== W, or the full frame's width when y is a crop of a prepared clip)
+    int Wx, FXm;            // v6: pixels per row / frames per pixel of the gram16 x IN MEMORY (== W / PX, or the untrimmed clip's when the loss prologue wrote it)
     int use_alpha;
     float alpha, dnorm;
     int ablate;   // measurement only: 1 skip epilogue, 2 skip compute, 4 skip staging loads
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(64 * NW, TYT == 5 ? 3 : 2) void patchnn6_k(NN2Args 
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
         const int idx = (wave + NW * k) * 64 + lane, cc = fdiv_small(idx, a.ps * FX), rem = idx - cc * a.ps * FX, r = fdiv_small(rem, FX);
-        offx[k] = idx < xs4 ? ((r * a.W + cc) * FX + (rem - r * FX)) | (cc << 24) : -1;
+        offx[k] = idx < xs4 ? ((r * a.Wx + cc) * a.FXm + (rem - r * FX)) | (cc << 24) : -1;
     }
 #pragma unroll
     for (int k = 0; k < KY; ++k) {
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(64 * NW, TYT == 5 ? 3 : 2) void patchnn6_k(NN2Args 
     auto issue = [&](int st) {
         const int q0 = st * CHC, nc = min(CHC, cols - q0);
         float *dst = smem + (st & 1) * bufF;
-        const float4 *xsrc = reinterpret_cast<const float4 *>(a.xt) + ((size_t)r0 * a.W + c0 + q0) * FX;
+        const float4 *xsrc = reinterpret_cast<const float4 *>(a.xt) + ((size_t)r0 * a.Wx + c0 + q0) * a.FXm;
         const float4 *ysrc = reinterpret_cast<const float4 *>(a.yt) + ((size_t)r0 * a.Wy + c0 + q0) * FY;
 #pragma unroll
         for (int k = 0; k < KX; ++k)
@@ -1347,7 +1348,7 @@ extern "C" int64_t vl3d_patchnn_scratch_bytes(const vl3d_loss_desc *d) {
 // The split-f16 matrix-core kernel (v6) and its plan: instantiation, stage size, LDS bytes.  x in at most 16 NW frames (NW = 4 / 8 waves),
 // y in at most 16 TYT (5 tiles x 4 locations, 8 x 2, 12 x 1 per wave).
 struct NN6Plan { int nw, tyt, nl, ch, xs; size_t lds; bool ok; };
-static NN6Plan plan_nn6(const NNArgs &a, int W, int Wy, int Ty, bool wave_epilogue) {
+static NN6Plan plan_nn6(const NNArgs &a, int W, int Wy, int Ty, bool wave_epilogue, int FXm) {
     NN6Plan p{};
     const int FX = a.TxU, FY = Ty, TyT = (FY + 15) / 16;
     p.nw = FX <= 64 ? 4 : 8;
@@ -1369,7 +1370,7 @@ static NN6Plan plan_nn6(const NNArgs &a, int W, int Wy, int Ty, bool wave_epilog
     p.lds = stage > epi ? stage : epi;
     p.ok = FX <= 16 * p.nw && TyT <= 12 && p.lds <= 150 * 1024 &&
            (size_t)p.ch * a.ps * FX <= (size_t)NN6_KX * p.nw * 64 && (size_t)p.ch * a.ps * FY <= (size_t)nn6_ky(p.tyt) * p.nw * 64 &&   // KX / KY pieces per wave
-           ((size_t)a.ps * W + p.ch) * (size_t)(FX > FY ? FX : FY) < (1u << 24) && ((size_t)a.ps * Wy + p.ch) * (size_t)FY < (1u << 24) &&   // 24-bit DMA offsets
+           ((size_t)a.ps * W + p.ch) * (size_t)FXm < (1u << 24) && ((size_t)a.ps * Wy + p.ch) * (size_t)FY < (1u << 24) &&   // 24-bit DMA offsets
            16 * p.nw + a.TyP <= 64 * p.nw;                                                                             // side threads
     return p;
 }
@@ -1403,8 +1404,8 @@ static int launch_nn6(const NN6Plan &p, const NN2Args &b, int w_o, int h_o, hipS
 // x_gram / y_gram != nullptr: that video arrives in the NN kernel's own gram16 form (vl3d_video_to_gram_major / vl3d_loop_pad_fwd), y as the
 // crop at (y_row0, y_col0) of a clip whose rows are y_pitch pixels long -- the captured video is constant training data, so it is
 // rewritten once per pyramid level and not once per iteration; the render's x is written in that form by the loss prologue
-static int patchnn_impl(const vl3d_loss_desc *desc, const float *x, const float *x_gram, const float *y, const float *y_gram, int32_t y_pitch,
-                        int32_t y_row0, int32_t y_col0, int32_t *nn, void *scratch, vl3d_stream_t stream) {
+static int patchnn_impl(const vl3d_loss_desc *desc, const float *x, const float *x_gram, int32_t x_pitch, int32_t x_frames, const float *y,
+                        const float *y_gram, int32_t y_pitch, int32_t y_row0, int32_t y_col0, int32_t *nn, void *scratch, vl3d_stream_t stream) {
     int rc = check_loss(desc);
     if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE((x || x_gram) && (y || y_gram) && nn, "vl3d_patchnn: null pointer");
@@ -1426,7 +1427,8 @@ static int patchnn_impl(const vl3d_loss_desc *desc, const float *x, const float 
         b.ablate = (desc->variant >> 4) & 15;
         dim3 tg((desc->W + 63) / 64, desc->H);
         // v6 (split-f16 matrix cores): the default wherever the clip lengths fit its instantiations
-        const NN6Plan p6 = plan_nn6(a, desc->W, Wy, desc->Ty, !(desc->variant & 0x800));
+        const int Wx = x_gram ? x_pitch : desc->W, FXm = x_gram ? x_frames : a.TxU;
+        const NN6Plan p6 = plan_nn6(a, Wx, Wy, desc->Ty, !(desc->variant & 0x800), FXm);
         const bool v4_has_tiles = (size_t)(a.TxP / TI) * (a.TyP / TJ) <= 1024;
         const bool use_v6 = p6.ok && (x_gram || y_gram || pv == 6 || (pv == 0 && !(p6.nl == 1 && v4_has_tiles)));
         if ((x_gram || y_gram) && !use_v6) {
@@ -1450,6 +1452,7 @@ static int patchnn_impl(const vl3d_loss_desc *desc, const float *x, const float 
             b.xt = x_gram ? x_gram : reinterpret_cast<const float *>(xs);
             b.yt = reinterpret_cast<const float *>(ys);
             b.PX = a.TxU; b.PY = desc->Ty;
+            b.Wx = Wx; b.FXm = FXm;
             return launch_nn6(p6, b, a.w_o, a.h_o, s);
         }
         VL3D_REQUIRE(pv != 3 && pv != 6, "vl3d_patchnn: variant 3 (the fp32 matrix-core kernel) was removed in round 5; variant 6 needs clip lengths within the matrix-core kernel's range");
@@ -1511,7 +1514,7 @@ static int patchnn_impl(const vl3d_loss_desc *desc, const float *x, const float 
 
 extern "C" int vl3d_patchnn(const vl3d_loss_desc *desc, const float *x, const float *y, int32_t *nn, void *scratch,
                             vl3d_stream_t stream) {
-    return patchnn_impl(desc, x, nullptr, y, nullptr, 0, 0, 0, nn, scratch, stream);
+    return patchnn_impl(desc, x, nullptr, 0, 0, y, nullptr, 0, 0, 0, nn, scratch, stream);
 }
 
 extern "C" int64_t vl3d_gram_major_bytes(int32_t T, int32_t H, int32_t W) {
@@ -1532,7 +1535,16 @@ extern "C" int vl3d_patchnn_prepared(const vl3d_loss_desc *desc, const float *x,
     VL3D_REQUIRE(desc && y_gram, "vl3d_patchnn_prepared: null pointer");
     VL3D_REQUIRE(y_row0 >= 0 && y_col0 >= 0 && y_row0 + desc->H <= y_rows && y_col0 + desc->W <= y_pitch,
                  "vl3d_patchnn_prepared: the crop (y_row0, y_col0) + (H, W) leaves the prepared clip (y_rows, y_pitch)");
-    return patchnn_impl(desc, x, nullptr, nullptr, y_gram, y_pitch, y_row0, y_col0, nn, scratch, stream);
+    return patchnn_impl(desc, x, nullptr, 0, 0, nullptr, y_gram, y_pitch, y_row0, y_col0, nn, scratch, stream);
+}
+
+extern "C" int vl3d_patchnn_grams(const vl3d_loss_desc *desc, const float *x_gram, int32_t x_pitch, int32_t x_rows, int32_t x_frames, const float *y_gram,
+                                  int32_t y_pitch, int32_t y_rows, int32_t y_row0, int32_t y_col0, int32_t *nn, vl3d_stream_t stream) {
+    VL3D_REQUIRE(desc && x_gram && y_gram, "vl3d_patchnn_grams: null pointer");
+    VL3D_REQUIRE(desc->H <= x_rows && desc->W <= x_pitch && desc->Tx <= x_frames, "vl3d_patchnn_grams: desc (Tx, H, W) leaves the x clip (x_frames, x_rows, x_pitch)");
+    VL3D_REQUIRE(y_row0 >= 0 && y_col0 >= 0 && y_row0 + desc->H <= y_rows && y_col0 + desc->W <= y_pitch,
+                 "vl3d_patchnn_grams: the crop (y_row0, y_col0) + (H, W) leaves the prepared clip (y_rows, y_pitch)");
+    return patchnn_impl(desc, nullptr, x_gram, x_pitch, x_frames, nullptr, y_gram, y_pitch, y_row0, y_col0, nn, nullptr, stream);
 }
 
 // LDS-staged fold: tile shapes {FT_W, FT_H, threads}.  The whole Ty column of a tile has to sit in LDS (an NN index may point at
@@ -1762,6 +1774,45 @@ __global__ __launch_bounds__(256) void loop_pad_fwd_k(int T, int pad, int64_t hw
     x[((int64_t)2 * frames + t) * hw + p] = rp[2] * g;
 }
 
+// ... and the same with the NN kernel's gram16 form of x written beside the video: the render's NHWC output is read ONCE for the loss's
+// two layouts (the separate video -> gram16 pass re-read x: 0.30 of the 1.66 ms of a 720p search).  A workgroup takes 64 pixels of a row
+// through all T + pad frames in groups of 16: lanes over pixels read 768 contiguous bytes per frame, write x coalesced per channel, the
+// tile goes through LDS, 16 lanes = the 16 frames of a pixel write 256 contiguous bytes of pieces.
+__global__ __launch_bounds__(256) void loop_pad_fwd_gram_k(int T, int pad, int H, int W, const float *__restrict__ rgb, const double *__restrict__ log_sum,
+                                                           float *__restrict__ x, uint4 *__restrict__ xg) {
+    __shared__ float tile[3][16][65];
+    const int row = blockIdx.y, x0 = blockIdx.x * 64, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int F = T + pad, G = (F + 15) >> 4;
+    const int64_t hw = (int64_t)H * W;
+    const float gain = loop_gain(log_sum, hw);
+    const int px = min(x0 + lane, W - 1);
+    const bool inx = x0 + lane < W;
+    float pre[12];
+    auto load = [&](int f0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int j = wave + 4 * k, c = j >> 4, f = f0 + (j & 15), ts = f < T ? f : f - T;
+            pre[k] = f < F ? rgb[(((int64_t)ts * H + row) * W + px) * 3 + c] * gain : 0.5f;
+        }
+    };
+    load(0);
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int j = wave + 4 * k, c = j >> 4, f = g * 16 + (j & 15);
+            if (f < F && inx) x[((int64_t)c * F + f) * hw + (int64_t)row * W + px] = pre[k];
+            tile[c][j & 15][lane] = pre[k] - 0.5f;
+        }
+        __syncthreads();
+        if (g + 1 < G) load((g + 1) * 16);
+        const int m = lane & 15, f = g * 16 + m;
+        for (int p = wave * 4 + (lane >> 4); p < 64; p += 16)
+            if (x0 + p < W && f < F)
+                xg[((size_t)row * W + x0 + p) * F + f] = gram16_piece(tile[0][m][p], tile[1][m][p], tile[2][m][p], 1.0f);
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void loop_pad_bwd_k(int T, int pad, int64_t hw, const float *__restrict__ gx, int64_t gx_sc, int64_t gx_st,
                                                       const double *__restrict__ log_sum, float *__restrict__ g_rgb) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1794,6 +1845,15 @@ extern "C" int vl3d_loop_pad_fwd(int32_t T, int32_t pad, int32_t h, int32_t w, c
     const int64_t hw = (int64_t)h * w;
     hipLaunchKernelGGL(loop_pad_fwd_k, dim3((unsigned)ceil_div64(hw, 256), (unsigned)(T + pad)), dim3(256), 0, (hipStream_t)stream, T, pad, hw, rgb,
                        log_sum, x);
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
+extern "C" int vl3d_loop_pad_fwd_gram(int32_t T, int32_t pad, int32_t h, int32_t w, const float *rgb, const double *log_sum, float *x, float *x_gram,
+                                      vl3d_stream_t stream) {
+    VL3D_REQUIRE(T > 0 && pad >= 0 && pad <= T && T + pad <= 65535 && h > 0 && w > 0 && rgb && x && x_gram, "vl3d_loop_pad_fwd_gram: bad arguments");
+    hipLaunchKernelGGL(loop_pad_fwd_gram_k, dim3((unsigned)((w + 63) / 64), (unsigned)h), dim3(256), 0, (hipStream_t)stream, T, pad, h, w, rgb, log_sum, x,
+                       reinterpret_cast<uint4 *>(x_gram));
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
 }

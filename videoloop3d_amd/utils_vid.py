@@ -142,11 +142,21 @@ class ClipCrop:
         self.clip, self.h0, self.w0 = clip, h0, w0
 
 
-def find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha, y_is_constant=False, y_prepared=None):
+class PreparedX:
+    """The generated clip x in the NN kernel's form, written by the loss prologue beside the video (MPV._LoopPrologue: the render's output is
+    read once for both).  `gram`: the buffer; (frames, rows, pitch): the clip it holds -- the loss may trim x to the patch grid, the form
+    keeps the untrimmed pitch.  Passed to the loss classes as keyword `x_prepared` next to x itself."""
+
+    def __init__(self, gram, frames, rows, pitch):
+        self.gram, self.frames, self.rows, self.pitch = gram, int(frames), int(rows), int(pitch)
+
+
+def find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha, y_is_constant=False, y_prepared=None, x_prepared=None):
     """Per-location temporal NN search on videos x,y [1,3,T,h,w] (already trimmed).  Returns int32 [h_o,w_o,n1].
     y_is_constant: the caller vouches that y's bytes have not changed since the previous call with the same y tensor, so its
     pixel-major copy inside the scratch may be reused (see _patchnn_scratch).
-    y_prepared: a ClipCrop -- y is the crop at that origin of a PreparedClip, whose gram-major form is read in place."""
+    y_prepared: a ClipCrop -- y is the crop at that origin of a PreparedClip, whose gram-major form is read in place.
+    x_prepared: a PreparedX (with y_prepared) -- x's form exists already: nothing is rewritten."""
     L.check_cuda(x, y)
     xv, yv = _as_video(x.detach(), "x"), _as_video(y.detach(), "y")
     if xv.shape[2:] != yv.shape[2:]:
@@ -160,6 +170,15 @@ def find_nn_indices(x, y, patch_size, patcht_size, stride, stridet, alpha, y_is_
         c = y_prepared.clip
         if c.T != desc.Ty or c.gram.device != xv.device:
             raise RuntimeError("y_prepared does not belong to this y (frames / device)")
+        rc = 3
+        if x_prepared is not None and x_prepared.gram.device == xv.device and x_prepared.frames >= desc.Tx and x_prepared.rows >= desc.H and x_prepared.pitch >= desc.W:
+            with torch.cuda.device(xv.device):
+                rc = L.lib().vl3d_patchnn_grams(desc, L.ptr(x_prepared.gram), x_prepared.pitch, x_prepared.rows, x_prepared.frames, L.ptr(c.gram), c.W, c.H,
+                                                y_prepared.h0, y_prepared.w0, L.ptr(nn), L.stream_ptr(xv.device))
+            if rc == 0:
+                return nn, desc, xv, yv
+            if rc != 3:
+                L.check(rc, "vl3d_patchnn_grams")
         with torch.cuda.device(xv.device):
             nscratch = int(L.lib().vl3d_patchnn_scratch_bytes(desc))
             scratch, _ = _patchnn_scratch(nscratch, yv, desc, xv.device, False)
@@ -296,9 +315,9 @@ class _FoldRobustMean(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant=False, trim=None, holder=None,
-                y_prepared=None):
+                y_prepared=None, x_prepared=None):
         xs = x if trim is None else x[..., :trim[0], :trim[1], :trim[2]]
-        nn, desc, xv, yv = find_nn_indices(xs, y, patch_size, patcht_size, stride, stridet, alpha, y_is_constant, y_prepared)
+        nn, desc, xv, yv = find_nn_indices(xs, y, patch_size, patcht_size, stride, stridet, alpha, y_is_constant, y_prepared, x_prepared)
         dev = xv.device
         gx = torch.empty(x.shape, dtype=torch.float32, device=dev)
         if tuple(xs.shape) != tuple(x.shape):
@@ -335,7 +354,7 @@ class _FoldRobustMean(torch.autograd.Function):
                 L.check(L.lib().vl3d_scale_inplace(gx.numel(), L.ptr(gx), L.ptr(gs), L.stream_ptr(gx.device)), "vl3d_scale_inplace")
         else:
             gx.mul_(gs)
-        return gx.to(ctx.x_dtype), None, None, None, None, None, None, None, None, None, None, None, None
+        return gx.to(ctx.x_dtype), None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def fit_patch(size, name, patch, step):
@@ -347,7 +366,8 @@ def fit_patch(size, name, patch, step):
     return trimmed
 
 
-def _gpnn_loss(holder, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant=False, trim=None, y_prepared=None):
+def _gpnn_loss(holder, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant=False, trim=None, y_prepared=None,
+               x_prepared=None):
     """NN search + vote-fold + robust mean, fused (one pass over the video for fold, loss and gradient); falls back to the
     separate kernels when a fold tile does not fit LDS, or when x does not fit the patch grid (direct path only: the LowMem class
     trims first).  Caches y2x / weight on `holder` like the reference (utils_vid.py:345-346)."""
@@ -356,7 +376,8 @@ def _gpnn_loss(holder, x, y, patch_size, patcht_size, stride, stridet, alpha, ro
     try:
         if not fits_grid:
             raise RuntimeError("x does not fit the patch grid: unfused path")
-        loss = _FoldRobustMean.apply(x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant, trim, holder, y_prepared)
+        loss = _FoldRobustMean.apply(x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant, trim, holder, y_prepared,
+                                     x_prepared)
         holder._y2x = holder._weight = None
         return loss
     except RuntimeError as e:
@@ -427,7 +448,7 @@ class Patch3DGPNNDirectLoss(_LazyVotes):
         if kwargs.get("dist_fn", "mse") != "mse":
             raise RuntimeError("dist_fn other than 'mse' is not settable in the reference")
         return _gpnn_loss(self, x, y, cfg["patch_size"], cfg["patcht_size"], cfg["stride"], cfg["stridet"], alpha, rou, scaling,
-                          bool(kwargs.get("y_is_constant", False)), None, kwargs.get("y_prepared"))
+                          bool(kwargs.get("y_is_constant", False)), None, kwargs.get("y_prepared"), kwargs.get("x_prepared"))
 
 
 class Patch3DGPNNLowMemLoss(_LazyVotes):
@@ -458,7 +479,7 @@ class Patch3DGPNNLowMemLoss(_LazyVotes):
             # x is trimmed INSIDE the fused op (same values as slicing here, utils_vid.py:318): its gradient comes back in x's full shape
             trim = None if (t, h, w) == tuple(x.shape[-3:]) else (t, h, w)
             return _gpnn_loss(self, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling,
-                              bool(kwargs.get("y_is_constant", False)), trim, kwargs.get("y_prepared"))
+                              bool(kwargs.get("y_is_constant", False)), trim, kwargs.get("y_prepared"), kwargs.get("x_prepared"))
         return _RobustMean.apply(x, y2x, rou, scaling)
 
 
