@@ -45,10 +45,10 @@ if f16f and f16b:
                                            "source": "render_fwd2x_k<F16> and render_bwd_pair_k<F16>: cfg5's storage format on the cfg3 geometry"}
 loss = {}
 for k in blocks:
-    if any(k.startswith(p) for p in ("patchnn5_k", "vote_fold_lds_k", "video_to_gram_major_k")) and "FETCH_SIZE" in blocks[k]:
+    if any(k.startswith(p) for p in ("patchnn6_k", "vote_fold_lds_k", "video_to_gram16_k")) and "FETCH_SIZE" in blocks[k]:
         loss[k] = traffic(k)["bytes"]
 out["loss_720p_kernels"] = {"bytes_per_launch": loss, "compulsory_bytes_per_iteration": 4.0 * 720 * 1280 * (3 * 52 * 3 + 3 * 75 * 2),
-                            "note": "one looping-loss iteration = video_to_gram_major_k<false> (x) + patchnn5_k + vote_fold_lds_k (y prepared once per clip); "
-                                    "patchnn5_k / vote_fold entries are means over the two shipped configurations where both ran"}
+                            "note": "one looping-loss iteration = video_to_gram16_k<false> (x) + patchnn6_k + vote_fold_lds_k (y prepared once per clip: "
+                                    "video_to_gram16_k<true> is not part of an iteration); patchnn6_k<..., 16> is the ref-view configuration, <..., 14> the other views'"}
 json.dump(out, open(os.path.join(os.path.dirname(src), "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}, indent=1)[:1800])
