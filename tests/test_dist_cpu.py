@@ -59,15 +59,14 @@ def _worker(rank, world, port, out):
         mine = _render_band_oracle(stack, homos, bands[rank], W, Hs, spec)
         frame = all_gather_frame(mine, bands)
         direct = all_gather_frame(mine, bands, algo="direct")          # all-peers send/recv: the same bytes as the ring
-        import videoloop3d_amd.dist as DM
-        DM._P2P_OPS_PER_GROUP = 4                                       # several grouped launches (frame ranges): same frame
-        direct = direct if torch.equal(all_gather_frame(mine, bands, algo="direct"), direct) else direct + 1
+        chunked = all_gather_frame(mine, bands, algo="direct", ops_per_group=4)      # several grouped launches (frame ranges): same frame
         full, _, _ = MO.render_planes(stack, homos, H, W, _oracle_spec(spec))
         err = float((frame - full).abs().max())
-        ok = torch.tensor([1.0 if (frame.shape == full.shape and err <= 2e-5 and torch.equal(direct, frame)) else 0.0])
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        # (each comparison on its own: a failure says WHICH one)
+        flags = torch.tensor([float(frame.shape == full.shape and err <= 2e-5), float(torch.equal(direct, frame)), float(torch.equal(chunked, frame))])
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
         if rank == 0:
-            out.put((float(ok.item()), err, [b.__dict__ for b in bands]))
+            out.put((flags.tolist(), err, [b.__dict__ for b in bands]))
     finally:
         dist.destroy_process_group()
 
@@ -84,7 +83,9 @@ def test_row_bands_allgather_gloo(world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert ok == 1.0, (err, bands)
+    assert ok[0] == 1.0, ("gathered frame differs from the single-rank render", err, bands)
+    assert ok[1] == 1.0, "the all-peers gather differs from the ring"
+    assert ok[2] == 1.0, "the all-peers gather in several grouped launches differs from the ring"
     assert sum(b["rows"] for b in bands) == 60 and bands[0]["row0"] == 0
 
 

@@ -678,3 +678,58 @@ def test_fused_step_at_the_schedule_s_shapes(dev, sparse):
         assert torch.equal(sda[kept], sdb[kept])
     else:
         assert torch.equal(sda, sdb)
+
+
+def test_fused_backward_announces_itself_and_refuses_stray_gradients(dev):
+    """The fused step changes what `loss.backward()` means (the update happens there; `step()` is housekeeping): the optimiser says so ONCE
+    unless the training loop has acknowledged it, says so once more when a second windowed forward arrives before `step()` (every backward
+    is its own Adam step: nothing accumulates), and RAISES when a gradient reached the window leaf through another autograd path -- it would
+    have been dropped silently."""
+    import warnings
+    from videoloop3d_amd.MPV import MPMeshVid
+    H, W, h, w, T = 96, 128, 48, 64, 4
+    K = np.array([[0.9 * W, 0, W / 2], [0, 0.9 * W, H / 2], [0, 0, 1]], np.float64)
+    tar = np.eye(4)
+    tar[:3, 3] = [0.03, 0.01, 0.0]
+    res = synth.hash_uniform((1, 2 * T + 1, 3, h, w), seed=8, device=dev)
+    cfg = dict(loss_name=["gpnn_lm"], loss_gain=torch.tensor([1.0]), macro_block=torch.tensor([65]), patch_size=torch.tensor([3]),
+               stride=torch.tensor([2]), patcht_size=torch.tensor([3]), stridet=torch.tensor([1]), alpha=torch.tensor([10000.0]),
+               dist_fn=["mse"], rou=["-2"], scaling=torch.tensor([0.1]))
+    model = MPMeshVid(_args(mpv_frm_num=T), H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
+    opt = model.get_optimizer(0)
+    assert opt.fused_backward
+
+    def fwd():
+        _, extra = model(h, w, torch.tensor(tar)[None], torch.tensor(K)[None], res=res, losscfg=dict(cfg))
+        return extra["swd"].sum()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        before = model.stack.detach().clone()
+        fwd().backward()
+        assert not torch.equal(model.stack.detach(), before)                 # the backward moved the parameters ...
+        assert sum("APPLIES the Adam update" in str(w_.message) for w_ in rec) == 1      # ... and said so
+        opt.step()
+        fwd().backward()
+        opt.step()
+        assert sum("APPLIES the Adam update" in str(w_.message) for w_ in rec) == 1      # once
+        # two forward / backward pairs without step(): legal, announced once
+        fwd().backward()
+        fwd().backward()
+        opt.step()
+        assert sum("second windowed forward" in str(w_.message) for w_ in rec) == 1 and opt.t == 4
+    # a loop that knows (train_3dvid.run_iter / train_3d.run_iter call this) hears nothing
+    m2 = MPMeshVid(_args(mpv_frm_num=T), H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
+    o2 = m2.get_optimizer(0)
+    o2.acknowledge_fused_backward()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        _, extra = m2(h, w, torch.tensor(tar)[None], torch.tensor(K)[None], res=res, losscfg=dict(cfg))
+        extra["swd"].sum().backward()
+        o2.step()
+        assert not any("APPLIES" in str(w_.message) for w_ in rec)
+    # a gradient that reaches the window leaf around the render: step() refuses instead of dropping it
+    _, extra = m2(h, w, torch.tensor(tar)[None], torch.tensor(K)[None], res=res, losscfg=dict(cfg))
+    leaf = o2.pending[1]
+    (extra["swd"].sum() + 1e-3 * (leaf ** 2).sum()).backward()
+    with pytest.raises(RuntimeError, match="outside the render's fused backward"):
+        o2.step()

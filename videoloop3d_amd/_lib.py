@@ -123,9 +123,20 @@ def lib():
                 f"HIP library {LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
                 "videoloop3d_amd has no CPU fallback.")
         l = C.CDLL(LIB_PATH)
+        # Every symbol of include/vl3d.h must resolve (tests/test_abi.py relies on it).  The one exception is explicit: an A/B run against an
+        # OLDER build (VL3D_LIB_PATH + VL3D_ALLOW_MISSING_SYMBOLS=1) may lack entry points added since; they are listed on stderr once and
+        # calling one fails with AttributeError.
+        tolerate = bool(os.environ.get("VL3D_LIB_PATH")) and os.environ.get("VL3D_ALLOW_MISSING_SYMBOLS") == "1"
+        missing = [name for name in SIGNATURES if not hasattr(l, name)]
+        if missing and not tolerate:
+            raise RuntimeError(f"HIP library {LIB_PATH} lacks {len(missing)} entry point(s) of include/vl3d.h ({', '.join(missing[:6])}...): it is stale or "
+                               "belongs to another revision -- rebuild it (or, for an A/B against an older build, set VL3D_ALLOW_MISSING_SYMBOLS=1)")
+        if missing:
+            import sys
+            print(f"[videoloop3d_amd] {LIB_PATH}: missing entry points tolerated (VL3D_ALLOW_MISSING_SYMBOLS=1): {', '.join(missing)}", file=sys.stderr)
         for name, (argtypes, restype) in SIGNATURES.items():
-            if not hasattr(l, name) and os.environ.get("VL3D_LIB_PATH"):
-                continue          # (A/B of an OLDER build through the measurement hook: entry points added since are simply absent)
+            if name in missing:
+                continue
             fn = getattr(l, name)
             fn.argtypes = argtypes
             fn.restype = restype

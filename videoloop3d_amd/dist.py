@@ -86,10 +86,10 @@ def render_band(local_stack, homos, band: Band, W: int, Hs: int, spec: RenderSpe
     return render_planes(local_stack, homos, band.rows, W, band_spec(spec, band, Hs), window=(band.row0, 0))
 
 
-_P2P_OPS_PER_GROUP = 256       # point-to-point operations per grouped launch: 18 frames x 7 peers x (send + receive) at N = 8
+P2P_OPS_PER_GROUP = 256        # point-to-point operations per grouped launch: 18 frames x 7 peers x (send + receive) at N = 8
 
 
-def all_gather_frame(band_rgb: torch.Tensor, bands: List[Band], group=None, algo: str = "auto") -> torch.Tensor:
+def all_gather_frame(band_rgb: torch.Tensor, bands: List[Band], group=None, algo: str = "auto", ops_per_group: int = P2P_OPS_PER_GROUP) -> torch.Tensor:
     """The one collective of the render path: composited bands [T,rows_r,W,C] -> full frame [T,H,W,C] on every rank.
     Uses torch.distributed (backend 'nccl' == RCCL over xGMI on ROCm; 'gloo' in the CPU tests).
 
@@ -101,6 +101,7 @@ def all_gather_frame(band_rgb: torch.Tensor, bands: List[Band], group=None, algo
                 grouped launch (batch_isend_irecv -> ncclGroupStart/End): each of the 7 links carries one 69 MB band per
                 direction concurrently -> ~0.45 ms.  Received bands land in place in the [T,H,W,C] frame (per-frame receives).
       "auto"    "direct" for world > 2 on device tensors, else "ring".
+    ops_per_group ("direct"): point-to-point operations per grouped launch; the transfers are cut by frame ranges over all peers.
     Every rank gets bit-identical frames from either algorithm (pure data movement)."""
     import torch.distributed as dist
     T, _, W, C = band_rgb.shape
@@ -124,7 +125,7 @@ def all_gather_frame(band_rgb: torch.Tensor, bands: List[Band], group=None, algo
         frame[:, row0[rank]:row0[rank] + rows[rank]].copy_(band_rgb)
         # chunks are FRAME ranges over all peers: every rank posts the same (pair, frame) transfers in the same grouped launch, so sends and
         # receives match chunk by chunk whatever the band sizes (three chunks for cfg3 at N = 8)
-        tpc = max(1, _P2P_OPS_PER_GROUP // max(2 * (world - 1), 1))
+        tpc = max(1, int(ops_per_group) // max(2 * (world - 1), 1))
         for t0 in range(0, T, tpc):
             ops = []
             for k in range(world):
