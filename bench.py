@@ -578,6 +578,12 @@ def main():
                                       "cfg2_720p_frame_scale1p6": stage1_step.run(frame=(720, 1280), crop=(720, 1280), scale=1.6, dev=str(dev))}
             except Exception as e:
                 res["stage1_step"] = {"error": repr(e)}
+            try:    # the offline renderer (scripts/script_render_video.py as videoloop3d_amd/render_video.py): eval frames per second at 720p
+                torch.cuda.empty_cache()
+                import render_video as render_video_example
+                res["offline_render"] = render_video_example.run(dev=str(dev))
+            except Exception as e:
+                res["offline_render"] = {"error": repr(e)}
             try:    # stage 1 END TO END (videoloop3d_amd/train_3d.py on the reference's schedule: 8 views x 9 crops per epoch, sparsify switch-over)
                 torch.cuda.empty_cache()
                 import stage1_train
@@ -639,6 +645,7 @@ def main():
         summ["refgeo_fwd_frac"], summ["refgeo_bwd_frac"] = pick(res, "reference_geometry", "roofline_fwd", "frac"), pick(res, "reference_geometry", "roofline_bwd", "frac")
         for k_, n_ in (("native_crop", "s1_crop"), ("cfg2_720p_frame", "s1_720p_1p1"), ("cfg2_720p_frame_scale1p6", "s1_720p_1p6")):
             summ[f"{n_}_it_s"] = pick(res, "stage1_step", k_, "iters_per_s")
+        summ["render_spiral_fps"], summ["render_fixed_view_fps"] = pick(res, "offline_render", "spiral", "frames_per_s"), pick(res, "offline_render", "fixed_view", "frames_per_s")
         summ["s1_train_epochs_per_min"], summ["s1_train_it_s"] = pick(res, "stage1_train", "epochs_per_min"), pick(res, "stage1_train", "iters_per_s")
         summ["s1_train_140_epochs_s"] = pick(res, "stage1_train", "projected_140_epochs_s")
         for k_ in ("ref", "other", "other_tile_culled", "other_tile_culled_packed"):

@@ -1,0 +1,199 @@
+"""Offline renderer on the device: the caller of the hot path in eval mode (scripts/script_render_video.py).
+
+Mirrors /root/reference/scripts/script_render_video.py: the camera side of `dataloader.load_llff_data` it renders from -- LLFF
+`poses_bounds.npy` -> axis flip, bound rescale, `recenter_poses`, the spiral of `render_path_spiral`, the intrinsics
+(`dataloader.py:60-134, 205-260`) --, the view / time selection of its `--v` / `--t` switches (`:47-85`), the reference camera of the
+model (`:84-87`), and the frame loop `nerf(H, W, pose, intrin, t)` in eval mode (`:129-139`).  Differences: no disk I/O besides the pose
+file (frames are returned as a uint8 device tensor; writing PNG / MP4 is the caller's), and consecutive frames that share ONE camera -- the
+`--v` modes render mpv_frm_num times of a fixed view -- go through the renderer as ONE call with `ts` a vector instead of one launch per
+frame (the fused kernel takes T' frames of a view at once; same pixels).
+
+The pose arithmetic is numpy like the reference's and pinned to it by golden G18 (`tests/golden/make_golden_r05.py` imports the reference's
+dataloader.py with name-only stand-ins for cv2 / imageio).
+"""
+import os
+
+import numpy as np
+import torch
+
+
+def _unit(v):
+    return v / np.linalg.norm(v)
+
+
+def viewmatrix(z, up, pos):
+    """dataloader.py:209-215: camera-to-world 3 x 4 looking along z: columns (right, true up, forward, position)."""
+    fwd = _unit(z)
+    right = _unit(np.cross(up, fwd))
+    return np.stack([right, _unit(np.cross(fwd, right)), fwd, pos], axis=1)
+
+
+def poses_avg(poses):
+    """dataloader.py:218-226: the views' average camera (mean position, summed forward / up axes); its last column is pose 0's last column
+    (the (H, W, f) column of 3 x 5 poses)."""
+    pos = poses[:, :3, 3].mean(axis=0)
+    fwd, up = poses[:, :3, 2].sum(axis=0), poses[:, :3, 1].sum(axis=0)
+    return np.concatenate([viewmatrix(fwd, up, pos), poses[0, :3, -1:]], axis=1)
+
+
+def _homog(m34):
+    return np.concatenate([m34, np.broadcast_to(np.array([0, 0, 0, 1.0], m34.dtype), m34.shape[:-2] + (1, 4))], axis=-2)
+
+
+def recenter_poses(poses):
+    """dataloader.py:235-246: every pose expressed in the average camera's frame (the (H, W, f) column untouched)."""
+    out = poses + 0
+    world_to_avg = np.linalg.inv(_homog(poses_avg(poses)[:3, :4]))
+    out[:, :3, :4] = (world_to_avg @ _homog(poses[:, :3, :4]))[:, :3, :4]
+    return out
+
+
+def render_path_spiral(c2w, up, rads, focal, zrate, zdelta, rots, N):
+    """dataloader.py:249-260: N cameras on a spiral around c2w, all looking at the point `focal` in front of it."""
+    scale = np.append(np.asarray(rads, dtype=np.float64), 1.0)
+    thetas = np.linspace(0.0, 2.0 * np.pi * rots, N + 1)[:-1]
+    local = np.stack([np.cos(thetas), -np.sin(thetas), (np.cos(thetas * zrate) * zdelta) ** 2, np.ones_like(thetas)], axis=1) * scale
+    centres = local @ c2w[:3, :4].T
+    return np.stack([viewmatrix(np.array([0, 0, focal]) - c, up, c) for c in centres])
+
+
+def load_llff_poses(poses_bounds, factor=8, recenter=True, bd_factor=(1, 1), render_frm=120, render_scaling=1.):
+    """dataloader.py:9-29, 60-134 without the images: `poses_bounds` = the array of poses_bounds.npy (or its path) ->
+    (poses [V,3,4], intrins [V,3,3], bds [2], render_poses [N,3,4], render_intrins [N,3,3]), float32 like the reference."""
+    if isinstance(poses_bounds, (str, os.PathLike)):
+        poses_bounds = np.load(poses_bounds)
+    poses_arr = np.asarray(poses_bounds)
+    poses = poses_arr[:, :-2].reshape([-1, 3, 5]).transpose([1, 2, 0])
+    bds = poses_arr[:, -2:].transpose([1, 0])
+    factor = 1 if factor is None else factor
+    poses = poses + 0
+    poses[:2, 4, :] = poses[:2, 4, :] / factor          # hw
+    poses[2, 4, :] = poses[2, 4, :] / factor            # focal
+    # rotation matrix ordering, variable dim to axis 0
+    poses = np.concatenate([poses[:, 1:2, :], poses[:, 0:1, :], -poses[:, 2:3, :], poses[:, 3:, :]], 1)
+    poses = np.moveaxis(poses, -1, 0).astype(np.float32)
+    bds = np.moveaxis(bds, -1, 0).astype(np.float32)
+    bds = np.array([bds.min(), bds.max()]).astype(poses.dtype)
+    sc = 1. / bds[0]
+    poses[:, :3, 3] *= sc
+    bds *= sc
+    if bd_factor is not None:
+        bds *= bd_factor
+    if recenter:
+        poses = recenter_poses(poses)
+    c2w = poses_avg(poses)
+    up = _unit(poses[:, :3, 1].sum(0))
+    close_depth, inf_depth = bds.min() * .9, bds.max() * 5.
+    dt = .75
+    focal = 1. / (((1. - dt) / close_depth + dt / inf_depth))
+    zdelta = close_depth * .2
+    rads = np.abs(poses[:, :3, 3]).max(0) * 0.8 * render_scaling
+    render_poses = np.array(render_path_spiral(c2w, up, rads, focal, zrate=.5, zdelta=zdelta, rots=2, N=render_frm)).astype(np.float32)
+    poses = poses.astype(np.float32)
+    H, W, f = poses[:, :3, -1].T
+    poses = poses[:, :3, :4]
+    intrins = np.zeros_like(poses[:, :3, :3])
+    intrins[:, -1, -1] = 1
+    intrins[:, 0, 0] = f
+    intrins[:, 1, 1] = f
+    intrins[:, 0, 2] = 0.5 * W
+    intrins[:, 1, 2] = 0.5 * H
+    render_intrins = np.repeat(intrins[:1, ...], len(render_poses), 0)
+    return poses, intrins, bds, render_poses, render_intrins
+
+
+def pose2extrin_np(pose):
+    """utils.py:203-209: camera-to-world [...,3|4,4] -> world-to-camera [...,4,4]."""
+    if pose.shape[-2] == 3:
+        bottom = np.zeros_like(pose[..., :1, :])
+        bottom[..., 3] = 1
+        pose = np.concatenate([pose, bottom], axis=-2)
+    return np.linalg.inv(pose)
+
+
+def default_render_frames(mpv_frm_num, f=-1):
+    """script_render_video.py:33: the number of spiral poses, a whole number of loops."""
+    return f if f > 0 else (120 // mpv_frm_num + 1) * mpv_frm_num
+
+
+def select_views_times(render_poses, render_intrins, poses, intrins, mpv_frm_num, v="", t="", test_view_idx=""):
+    """script_render_video.py:47-85: which camera and which frame index every output frame takes.
+    v: '' the spiral, 'r#' the #-th spiral pose held fixed, '#' the #-th training view held fixed, 'test' the first test view;
+    t: '' frame i of the loop for output i, '#,#,#' those entries, '#:#[,#:#]' ranges (end excluded, descending allowed), '#' one entry.
+    -> (view_poses [N,3,4], view_intrins [N,3,3], render_t int array [N])."""
+    view_poses, view_intrins = render_poses.copy(), render_intrins.copy()
+    render_t = np.arange(len(render_poses)) % mpv_frm_num
+    if v == 'test':
+        v = test_view_idx.split(',')[0]
+    if len(v) > 0:
+        render_t = render_t[:mpv_frm_num]
+        if v[0] == 'r':
+            i = int(v[1:])
+            view_poses[:] = view_poses[i:i + 1]
+            view_intrins[:] = render_intrins[i:i + 1]
+        else:
+            i = int(v)
+            view_poses[:] = poses[i:i + 1]
+            view_intrins[:] = intrins[i:i + 1]
+    if len(t) > 0:
+        if ',' in t and ':' not in t:
+            render_t = render_t[list(map(int, t.split(',')))]
+        elif ':' in t:
+            parts = []
+            for slic in t.split(','):
+                start, end = list(map(int, slic.split(':')))
+                parts.append(np.arange(start, end, 1 if start <= end else -1))
+            render_t = np.concatenate(parts)
+        else:
+            render_t = render_t[[int(t)]]
+    return view_poses[:len(render_t)], view_intrins[:len(render_t)], render_t
+
+
+def reference_camera(poses, intrins, bds):
+    """script_render_view.py:84-87 -> (ref_extrin [4,4], ref_intrin [3,3], near, far) the model is built with."""
+    ref_pose = poses_avg(poses)[:, :4]
+    return pose2extrin_np(ref_pose), intrins[0], float(bds.min()), float(bds.max())
+
+
+def to8b(x):
+    """utils.py: (255 * clip(x, 0, 1)).astype(uint8), on the device."""
+    return (255 * x.clamp(0, 1)).to(torch.uint8)
+
+
+@torch.no_grad()
+def render_frames(nerf, H, W, view_extrins, view_intrins, render_t, max_batch=64):
+    """script_render_video.py:129-139: `nerf(H, W, extrin, intrin, t)` in eval mode for every output frame -> uint8 [N,H,W,3] on the
+    model's device.  Runs of consecutive frames with one camera are rendered by ONE call with `ts` a vector (at most `max_batch` frames:
+    the frames of a call are resident together)."""
+    module = getattr(nerf, "module", nerf)
+    was_training = module.training
+    nerf.eval()
+    view_extrins = torch.as_tensor(np.asarray(view_extrins), dtype=torch.float32)
+    view_intrins = torch.as_tensor(np.asarray(view_intrins), dtype=torch.float32)
+    render_t = np.asarray(render_t).astype(np.int64)
+    out, i, n = [], 0, len(render_t)
+    while i < n:
+        j = i + 1
+        while j < n and j - i < max_batch and torch.equal(view_extrins[j], view_extrins[i]) and torch.equal(view_intrins[j], view_intrins[i]):
+            j += 1
+        rgb, _ = nerf(H, W, view_extrins[i:i + 1], view_intrins[i:i + 1], torch.as_tensor(render_t[i:j]))
+        out.append(to8b(rgb.permute(0, 2, 3, 1)))
+        i = j
+    if was_training:
+        nerf.train()
+    return torch.cat(out, 0)
+
+
+def render_video(nerf, args, poses_bounds, ckpt=None, v="", t="", f=-1, render_scaling=1., factor=None):
+    """The whole of script_render_video.evaluate() but the files: poses -> selection -> (optional) checkpoint -> frames.
+    `nerf`: an MPMeshVid built with `reference_camera(...)` of the same poses; `ckpt`: a path or a loaded dict with 'network_state_dict'."""
+    frm = default_render_frames(args.mpv_frm_num, f)
+    poses, intrins, bds, rposes, rintr = load_llff_poses(poses_bounds, factor=factor if factor is not None else getattr(args, "factor", 1),
+                                                         recenter=True, bd_factor=(getattr(args, "near_factor", 1), getattr(args, "far_factor", 1)),
+                                                         render_frm=frm, render_scaling=render_scaling)
+    vp, vi, rt = select_views_times(rposes, rintr, poses, intrins, args.mpv_frm_num, v, t, getattr(args, "test_view_idx", ""))
+    if ckpt is not None:
+        sd = torch.load(ckpt, weights_only=False) if isinstance(ckpt, (str, os.PathLike)) else ckpt
+        getattr(nerf, "module", nerf).init_from_mpi(sd['network_state_dict'])
+    H, W = int(round(2 * intrins[0, 1, 2])), int(round(2 * intrins[0, 0, 2]))
+    return render_frames(nerf, H, W, pose2extrin_np(vp), vi, rt)
