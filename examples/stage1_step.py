@@ -19,7 +19,7 @@ import torch
 
 
 def run(iters=20, planes=32, frame=(360, 640), crop=(180, 320), scale=1.6, loop_mask=True, dev="cuda:0", torch_adam=False, fused_loss=True,
-        crop_aware_adam=False):
+        crop_aware_adam="auto"):
     from videoloop3d_amd import synth
     from videoloop3d_amd.MPI import MPMesh, image_and_loop_loss
     dev = torch.device(dev)
@@ -30,7 +30,8 @@ def run(iters=20, planes=32, frame=(360, 640), crop=(180, 320), scale=1.6, loop_
         rgb_activate="sigmoid", alpha_activate="sigmoid", bg_color="", learn_loop_mask=loop_mask, scale_invariant=True,
         sparsity_loss_weight=0.004, rgb_smooth_loss_weight=0.2, a_smooth_loss_weight=0.5, density_loss_weight=0.02, d_smooth_loss_weight=0.0,
         l_smooth_loss_weight=0.0, unfused_terms=not fused_loss,
-        crop_aware_adam=crop_aware_adam)      # True: optim.Stage1Adam (window of the crop) instead of the one pass over the whole stack; measured slower (MPI.get_optimizer)
+        patch_h_size=h, patch_w_size=w,       # configs/mpi_base.txt: the training crop
+        crop_aware_adam=crop_aware_adam)      # True: optim.Stage1Adam (window of the crop); False: one pass over the whole stack; "auto": by stack size (MPI.get_optimizer)
     K = np.array([[0.9 * W, 0, W / 2], [0, 0.9 * W, H / 2], [0, 0, 1]], np.float64)
     model = MPMesh(args, H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
     args.optimizer, args.lrate, args.lrate_decay, args.torch_adam = "adam", 0.05, 100, torch_adam

@@ -119,3 +119,12 @@ def test_epoch_loop_schedule(monkeypatch, tmp_path):
     rec.clear()
     out = drv.train(_FakeMesh(a), a, vids, poses, K, 20, 32, device="cpu", start_epoch=4)
     assert out["iters"] == n and len(rec) == n
+
+
+def test_crop_aware_optimiser_rule():
+    """args.crop_aware_adam = "auto": the four measured shapes of profiles/s1_crop_aware.py fall on the faster side."""
+    from videoloop3d_amd.MPI import crop_aware_pays
+    assert not crop_aware_pays((32, 1, 576, 1024, 4), 180, 320)        # the reference's native shape: 302 MB, host-bound
+    assert not crop_aware_pays((32, 1, 792, 1408, 4), 720, 1280)       # 720p on 1.1x planes: the view is most of a plane
+    assert crop_aware_pays((32, 1, 1152, 2048, 4), 720, 1280)          # 720p on 1.6x planes: 1.2 GB, the view 39 % of a plane
+    assert crop_aware_pays((32, 1, 1152, 2048, 4), 360, 640)

@@ -53,6 +53,13 @@ class _LoopMaskLabel(torch.autograd.Function):
         return gb[..., 0].contiguous(), None, None, None, None, None, None
 
 
+def crop_aware_pays(stack_shape, view_h, view_w):
+    """The rule behind args.crop_aware_adam = "auto" (MPMesh.get_optimizer): a stack [D,1,Hs,Ws,4] fp32 of >= 768 MB of which a view_h x
+    view_w view reaches at most half a plane."""
+    D_, _, Hs_, Ws_, _ = stack_shape
+    return D_ * Hs_ * Ws_ * 16 >= 768 * 2 ** 20 and view_h * view_w * 2 <= Hs_ * Ws_
+
+
 class MPMesh(nn.Module):
     def __init__(self, args, H, W, ref_extrin, ref_intrin, near, far, pixel_center=0.5, texel_scale=(1.0, 1.0), atlas_exact=False):
         """atlas_exact=True: sample the stack exactly like the reference samples its atlas of plane cells (MPI.py:75-81, 490-520: cell pitch
@@ -170,8 +177,17 @@ class MPMesh(nn.Module):
         self._flush_deferred_updates()      # the optimiser handed out before may still hold deferred updates: they belong to the stack
         self._window_opt = None
         if a.optimizer == 'adam':
-            if self.stack.is_cuda and not getattr(a, "torch_adam", False) and not self.atlas_exact and getattr(a, "crop_aware_adam", False):
-                # OPT-IN (args.crop_aware_adam): torch.optim.Adam's parameters through the crop-aware engine for the plane stack (a stage-1
+            crop_aware = getattr(a, "crop_aware_adam", "auto")
+            if crop_aware == "auto":
+                # the crop-aware engine pays where the optimiser's streams over the WHOLE stack dominate the iteration and a view reaches a minor
+                # part of it: a large stack (>= 768 MB: seven streams of it are >= 1 ms) of which a view's footprint -- the training crop, or the
+                # frame, on planes mpi_h_scale x mpi_w_scale larger -- is at most half.  Measured (profiles/s1_crop_aware.py, D = 32, it/s whole
+                # stack | crop-aware): 720p frame on 1.6x planes (1.2 GB) 314 | 361, a 360 x 640 crop of them 392 | 638; but the reference's native
+                # shape (302 MB) 852 | 690 and a 720p frame on 1.1x planes (571 MB) 470 | 397: there the extra launches cost more than the streams.
+                ph, pw = min(int(getattr(a, "patch_h_size", self.H)), self.H), min(int(getattr(a, "patch_w_size", self.W)), self.W)
+                crop_aware = crop_aware_pays(tuple(self.stack.shape), ph, pw)
+            if self.stack.is_cuda and not getattr(a, "torch_adam", False) and not self.atlas_exact and crop_aware:
+                # (args.crop_aware_adam = True / False / "auto"): torch.optim.Adam's parameters through the crop-aware engine for the plane stack (a stage-1
                 # iteration renders ONE crop of one view, train_3d.py:20-95: the render reads a compact copy of the crop's texel window, the step
                 # touches the window only, the zero-gradient updates of the rest are deferred and replayed exactly -- optim.WindowAdam, as in
                 # stage 2; a sparsified model, train_3d.py:282-286, takes its step inside the render's backward) and the one-pass Adam for the
