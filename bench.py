@@ -484,19 +484,28 @@ def main():
                 with torch.no_grad():
                     tiles.cull_stack_(stack, keep)
                 times = {}
-                for name, qk in (("plain", None), ("culled", keep)):
+                # culled: the autograd contract (a dense gradient: the texels no kept quad can read are written as zeros -- 23.6 GB of stores whatever
+                # is kept); lean: VL3D_GRAD_CULLED_UNWRITTEN, the contract of the training path (WindowAdam / TileAdam never read those texels)
+                for name, qk, lean in (("plain", None, False), ("culled", keep, False), ("lean", keep, True)):
                     for it in range(6):
                         if it == 2:
                             torch.cuda.synchronize()
                             t1 = time.perf_counter()
-                        r1, _ = render_planes(stack, homos_d, H, W, spec, quad_keep=qk)
+                        r1, _ = render_planes(stack, homos_d, H, W, spec, quad_keep=qk, grad_culled_unwritten=lean)
                         (gs1,) = torch.autograd.grad(r1, stack, g_rgb)
                     torch.cuda.synchronize()
                     times[name] = (time.perf_counter() - t1) / 4
                     del r1, gs1
-                res["tile_culling"] = {"kept_quads": float(keep.float().mean()), "ms_plain": times["plain"] * 1e3,
-                                       "ms_culled": times["culled"] * 1e3, "value": T * H * W / times["culled"] / 1e6, "unit": "Mpix/s",
-                                       "workload": "cfg3 render fwd+bwd on a tile-culled stack (one blob of kept quads per plane): plain = without the quad map, culled = with it"}
+                kept = float(keep.float().mean())
+                res["tile_culling"] = {"kept_quads": kept, "ms_plain": times["plain"] * 1e3,
+                                       "ms_culled": times["culled"] * 1e3, "ms_culled_lean": times["lean"] * 1e3,
+                                       "value": T * H * W / times["lean"] / 1e6, "unit": "Mpix/s",
+                                       # the kept quads' share of the plain step's algorithmic bytes / time / peak
+                                       "frac_kept_bytes": kept * T * H * W * (48 * D + 24) / times["lean"] / 1e9 / HBM_PEAK_GBS,
+                                       "frac_kept_bytes_dense_grad": kept * T * H * W * (48 * D + 24) / times["culled"] / 1e9 / HBM_PEAK_GBS,
+                                       "workload": "cfg3 render fwd+bwd on a tile-culled stack (one blob of kept quads per plane): plain = without the quad "
+                                                   "map, culled = with it and a dense gradient (zeros written for culled texels: the autograd contract), "
+                                                   "lean = with it and VL3D_GRAD_CULLED_UNWRITTEN (the training path's contract); value = lean"}
             except Exception as e:
                 res["tile_culling"] = {"error": repr(e)}
             try:    # the geometry a shipped stage-2 iteration renders (configs/mpv_base.txt:10-11,33-34): stack stored at 1.1x the frame,
@@ -641,6 +650,7 @@ def main():
         summ["cfg2_frac"] = pick(res, "cfg2_single_frame", "frac")
         summ["fp16_ms"], summ["fp16_mpix_s"], summ["fp16_frac"] = pick(res, "fp16_stack_storage", "ms_per_step"), pick(res, "fp16_stack_storage", "value"), pick(res, "fp16_stack_storage", "frac")
         summ["cull_ms_plain"], summ["cull_ms_culled"], summ["cull_kept"] = pick(res, "tile_culling", "ms_plain"), pick(res, "tile_culling", "ms_culled"), pick(res, "tile_culling", "kept_quads")
+        summ["cull_ms_lean"], summ["cull_frac_kept"] = pick(res, "tile_culling", "ms_culled_lean"), pick(res, "tile_culling", "frac_kept_bytes")
         summ["refgeo_mpix_s"], summ["refgeo_fwd_ms"], summ["refgeo_bwd_ms"] = pick(res, "reference_geometry", "value"), pick(res, "reference_geometry", "fwd_ms"), pick(res, "reference_geometry", "bwd_ms")
         summ["refgeo_fwd_frac"], summ["refgeo_bwd_frac"] = pick(res, "reference_geometry", "roofline_fwd", "frac"), pick(res, "reference_geometry", "roofline_bwd", "frac")
         for k_, n_ in (("native_crop", "s1_crop"), ("cfg2_720p_frame", "s1_720p_1p1"), ("cfg2_720p_frame_scale1p6", "s1_720p_1p6")):

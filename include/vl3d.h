@@ -97,8 +97,10 @@ int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, const float
  * scratch: caller-owned device buffer of vl3d_render_bwd_scratch_bytes(desc) bytes (plan written and read on
  * `stream`, no host sync); with scratch == NULL the universal global-atomics kernel is used.
  * desc->variant: 0 auto (LDS-staged owner-computes kernel when its on-device feasibility plan allows, atomics
- * kernel otherwise), 1 force atomics, 2/3 owner-computes kernel with 8-/16-row regions, 4 = 3 with the 3x3 gather everywhere
- * (reference for the 2x2 gather of no-minification tiles, which must equal it bit for bit). */
+ * kernel otherwise), 1 force atomics, 3 owner-computes kernel, one frame per thread in 64 x 16-pixel regions (2: the 8-row regions of
+ * round 1, no longer built, selects 3), 4 = 3 with the 3x3 gather everywhere (reference for the 2x2 gather of no-minification tiles, which
+ * must equal it bit for bit), 5 = one frame per thread in 32 x 16-pixel regions (the shipped planar convention with fp32 stacks; = 3
+ * elsewhere).  All of them produce the same gradient bits. */
 int64_t vl3d_render_bwd_scratch_bytes(const vl3d_render_desc *desc);
 int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, const float *homos,
                     const float *rgb, const float *alpha, const float *grad_rgb, const float *grad_alpha,
@@ -193,7 +195,7 @@ int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t 
  * vl3d_render_bwd_culled does and the step kernel behind the backward sums it over the frames -- static texels only, unless the plan was
  * infeasible --, culled texels are nobody's (grad_stack holds defined values in static texels only).  adam->blocks: packed storage.
  * fp32 stacks, the planar convention with the shipped activations ((affine, hardcut, post), sigmoid / sigmoid); dense models: T >= 2,
- * desc->variant 0 (the frame pairs; tile-culled models always take the one-frame tile kernel); anything else: VL3D_EUNSUPPORTED,
+ * desc->variant 0 (the frame pairs; tile-culled models always take the one-frame tile kernel: 32-wide regions, variant 3 = 64-wide); anything else: VL3D_EUNSUPPORTED,
  * nothing launched. */
 typedef struct vl3d_adam_window {
     int32_t Hs, Ws;              /* the full planes: param / exp_avg / exp_avg_sq are (D,T,Hs,Ws,4) */
@@ -206,12 +208,14 @@ typedef struct vl3d_adam_window {
     const int32_t *plane_boxes;  /* HOST [D][4] or NULL */
     void *boxes_scratch;         /* device, 16 * D bytes; required with plane_boxes */
     /* tile-culled model (NULL quad_keep: dense): the quad maps of vl3d_adam_window_step (device byte maps [D][QH][QW]) and a device scratch
-     * of D * desc->Hs * desc->Ws bytes for the texel classes of the window */
+     * of vl3d_render_bwd_adam_class_bytes(desc) bytes for the texel records of the window (8 bytes per plane texel: class, the step its
+     * bookkeeping tile is current for, its slot in the parameter tensors / pools -- written by the pre-pass, read by the owner's store) */
     const uint8_t *quad_keep, *quad_dyn;
     int32_t QH, QW;
     void *class_scratch;
     const int32_t *blocks;       /* PACKED storage (as vl3d_adam_window_step_boxes; needs the quad maps): param / exp_avg / exp_avg_sq are the pools */
 } vl3d_adam_window;
+int64_t vl3d_render_bwd_adam_class_bytes(const vl3d_render_desc *desc);
 int vl3d_render_bwd_adam(const vl3d_render_desc *desc, const void *stack, const float *homos, const float *rgb, const float *alpha,
                          const float *grad_rgb, const float *grad_alpha, const float *grad_reg, const void *reg_state,
                          const float *grad_alpha_sums, float *grad_stack, void *scratch, int64_t scratch_bytes,

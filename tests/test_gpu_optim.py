@@ -295,6 +295,32 @@ def test_unwritten_culled_gradient_on_a_texel_aligned_view(dev):
         assert torch.equal(grads[1][kt], grads[0][kt]), seed
 
 
+@pytest.mark.parametrize("variant", [0, 3, 5])
+def test_unwritten_culled_gradient_without_regularisers(dev, variant):
+    """VL3D_GRAD_CULLED_UNWRITTEN on the plain culled backward (no layer regularisers): the call takes the instantiation that SKIPS the planes a
+    tile cannot see (64-wide regions; desc->variant 5: 32-wide) -- every texel a kept quad can read has the zero-filling kernel's bits."""
+    from videoloop3d_amd import tiles
+    from videoloop3d_amd.render import RenderSpec, render_planes
+    from test_gpu_render import bench_homos
+    D, T, Hs, Ws, H, W, QH, QW = 7, 3, 170, 230, 150, 200, 9, 12
+    torch.manual_seed(11)
+    keep = (torch.rand(D, QH, QW) < 0.3).to(dev)
+    keep[2] = False
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=17, device=dev)
+    with torch.no_grad():
+        tiles.cull_stack_(stack, keep)
+    homos = (torch.tensor([[1.0, 0, 14.0], [0, 1.0, 9.0], [0, 0, 1.0]]) @ bench_homos(D, H, W)).to(dev)
+    g = synth.hash_uniform((T, H, W, 3), seed=5, device=dev) - 0.5
+    grads = []
+    for lean, v in ((False, 0), (True, variant)):
+        leaf = stack.clone().requires_grad_(True)
+        rgb, _ = render_planes(leaf, homos, H, W, RenderSpec.mpv(variant=v), quad_keep=keep, grad_culled_unwritten=lean)
+        grads.append(torch.autograd.grad(rgb, leaf, g)[0])
+    kt = tiles.quad_to_texel_mask(keep.cpu(), Hs, Ws).to(dev)[:, None, :, :, None].expand_as(grads[0])
+    assert float(grads[0][kt].abs().max()) > 1e-4 and float(grads[0][~kt].abs().max()) == 0.0
+    assert torch.equal(grads[1][kt], grads[0][kt])
+
+
 def test_sparsified_model_trains_through_the_window_path(dev):
     """MPMeshVid of a sparsified MPI: the crop-aware path (WindowAdam with the quad maps, static texels stored once) against the
     round-1 path (TileAdam over the whole stack + tie hook, args.tile_adam): same losses, same kept texels after the flush."""
@@ -455,9 +481,10 @@ def test_step_fused_into_the_backward_equals_backward_then_step(dev, smooth, T, 
         assert torch.equal(sda["stack"], sdb["stack"])
 
 
+@pytest.mark.parametrize("variant", [0, 3, 5])      # 0: the default region shape, 3: 64-wide regions, 5: 32-wide regions (two workgroups per CU)
 @pytest.mark.parametrize("smooth,T,scale,rot,packed", [(0.2, 4, 1.1, 0.0, False), (0.0, 5, 1.6, 0.0, False), (0.2, 3, 1.25, 40.0, False),
                                                        (0.2, 4, 1.1, 0.0, True), (0.0, 5, 1.25, 0.0, True), (0.2, 3, 1.1, 40.0, True)])
-def test_tile_culled_step_fused_into_the_backward(dev, smooth, T, scale, rot, packed):
+def test_tile_culled_step_fused_into_the_backward(dev, smooth, T, scale, rot, packed, variant):
     """the same for a TILE-CULLED model (vl3d_render_bwd_adam with quad maps): dynamic texels are stepped in the owner's store, a static
     texel's gradient is stored and summed over the frames by the step kernel behind the backward (static texels only), culled texels are
     no parameters -- against vl3d_render_bwd_culled + vl3d_adam_window_step_boxes over all classes: the same bits in p, m, v and the step
@@ -490,6 +517,9 @@ def test_tile_culled_step_fused_into_the_backward(dev, smooth, T, scale, rot, pa
         m._install_tie_hook()
         if packed:
             m.pack_()
+        if fused and variant:
+            import dataclasses
+            m.spec = dataclasses.replace(m.spec, variant=variant)
         models.append((m, m.get_optimizer(0)))
     (A, oa), (B, ob) = models
     assert ob.fused_backward and not oa.fused_backward and ob.quad_keep is not None and (ob.layout is not None) == packed

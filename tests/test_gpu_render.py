@@ -700,7 +700,7 @@ def test_bwd_frame_pair_kernel_equals_tile_kernel_bitwise(dev, spec_name, stack_
     g_rgb = synth.hash_uniform((T, H, W, 3), seed=5, device=dev) - 0.5
     g_a = synth.hash_uniform((T, H, W), seed=6, device=dev) - 0.5
     out = {}
-    for variant in (0, 3, 5):          # 0: frame pairs, 5: frame pairs with the sampling pipelined one plane ahead, 3: one frame per thread
+    for variant in (0, 3, 5):          # 0: frame pairs, 3: one frame per thread in 64-wide regions, 5: in 32-wide regions (fp32 planar convention; else = 3)
         rgb, alpha = render_planes(stack, homos, H, W, RenderSpec(variant=variant, **kw_p))
         (gs,) = torch.autograd.grad([rgb, alpha], stack, [g_rgb, g_a])
         assert _tile_ran() == 1

@@ -82,11 +82,13 @@ struct vl3d_adam_epilogue {
     const int4 *boxes;             // device [D] x (y0, y1, x0, x1) in plane texels (a plane's texels outside its box stay deferred) or NULL
     int y0, x0, Hs, Ws, tiles_y, tiles_x, step;
     float lr_bc1, beta1, beta2, eps, bc2s;
-    // tile-culled models: the quad maps (classification of a texel: vl3d_adam::texel_class) and a byte per texel of the compact window
-    // [D][desc->Hs][desc->Ws], written by the backward's pre-pass (frame independent) and read by the gather: 0 culled / 1 dynamic (stepped in
-    // the owner's store) / 2 static (its gradient is stored: the step kernel sums it over the frames) / 3 outside its plane's box
+    // tile-culled models: the quad maps (classification of a texel: vl3d_adam::texel_class) and an 8-byte record per texel of the compact window
+    // [D][desc->Hs][desc->Ws] (+ the owner table's padding), written by the backward's pre-pass (frame independent) and read by the gather next
+    // to its owner entry: .x = class | step << 2 -- class 0 culled / 1 dynamic (stepped in the owner's store) / 2 static (its gradient is
+    // stored: the step kernel sums it over the frames) / 3 outside its plane's box; step = what the texel's bookkeeping tile is current for --,
+    // .y = the texel's 16-byte slot inside a frame of p / m / v (dense tensors or packed pools; dynamic texels only)
     const unsigned char *quad_dyn;
-    unsigned char *cls;            // NULL: dense model (every texel dynamic)
+    uint2 *cls;                    // NULL: dense model (every texel dynamic)
     // PACKED storage (vl3d_adam_window_step_boxes' `blocks`): p / m / v are pools of 8 x 8-texel blocks, blocks [D][tiles_y][tiles_x] = -1 or
     // slot << 1 | dynamic; a dynamic block owns T consecutive slots (frame-major).  NULL: the dense (D,T,Hs,Ws,4) tensors.
     const int *blocks;

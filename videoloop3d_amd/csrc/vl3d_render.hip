@@ -361,7 +361,7 @@ static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, cons
         a.plan = (const float *)scratch;
         a.owner = reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(scratch) + owner_table_off(desc));
         const int bv = desc->variant & 0xf;
-        a.tile_rows = bv == 0 ? 17 : 16;     // 17: 16 rows, frame-pair kernels allowed
+        a.tile_rows = bv == 0 ? 17 : (bv == 5 ? 18 : 16);     // 17: 16 rows, frame-pair kernels allowed; 18: 32-wide one-frame regions
     } else {
         a.plan = nullptr;
         a.tile_rows = 0;
@@ -375,6 +375,12 @@ static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, cons
 }
 
 // ---- the optimiser step inside the backward (include/vl3d.h) ---------------------------------------------------------------------------
+extern "C" int64_t vl3d_render_bwd_adam_class_bytes(const vl3d_render_desc *desc) {
+    if (!desc || desc->D <= 0 || desc->Hs <= 0 || desc->Ws <= 0) return 0;
+    // one 8-byte record per (plane, texel) of the compact window, padded like the owner table (the gather's unconditional prefetch)
+    return ((int64_t)desc->D * desc->Hs * desc->Ws + 16 * (int64_t)desc->Ws + 64) * 8;
+}
+
 extern "C" int vl3d_render_bwd_adam(const vl3d_render_desc *desc, const void *stack, const float *homos, const float *rgb, const float *alpha,
                                     const float *grad_rgb, const float *grad_alpha, const float *grad_reg, const void *reg_state,
                                     const float *grad_alpha_sums, float *grad_stack, void *scratch, int64_t scratch_bytes,
@@ -388,7 +394,7 @@ extern "C" int vl3d_render_bwd_adam(const vl3d_render_desc *desc, const void *st
     const int bv = desc->variant & 0xf;
     if (!(desc->coord_mode == VL3D_COORD_AFFINE && desc->border_mode == VL3D_BORDER_HARDCUT && desc->act_order == VL3D_ACT_POST &&
           desc->rgb_act == VL3D_ACT_SIGMOID && desc->alpha_act == VL3D_ACT_SIGMOID && desc->stack_dtype == VL3D_F32 &&
-          (qk ? (bv == 0 || bv == 3) : (desc->T >= 2 && bv == 0)))) {
+          (qk ? (bv == 0 || bv == 3 || bv == 5) : (desc->T >= 2 && bv == 0)))) {
         vl3d_set_error("vl3d_render_bwd_adam: built for the stage-2 iteration -- (affine, hardcut, post), sigmoid / sigmoid, fp32 stack, "
                        "T >= 2 and variant 0 for a dense model; use vl3d_render_bwd(_culled) + vl3d_adam_window_step otherwise");
         return VL3D_EUNSUPPORTED;
@@ -401,7 +407,8 @@ extern "C" int vl3d_render_bwd_adam(const vl3d_render_desc *desc, const void *st
     if (qk) {
         rc = check_cull(desc, qk, adam->QH, adam->QW);
         if (rc != VL3D_OK) return rc;
-        VL3D_REQUIRE(adam->class_scratch, "vl3d_render_bwd_adam: a tile-culled model needs class_scratch (D * Hs * Ws bytes)");
+        VL3D_REQUIRE(adam->class_scratch, "vl3d_render_bwd_adam: a tile-culled model needs class_scratch (vl3d_render_bwd_adam_class_bytes())");
+        VL3D_REQUIRE(adam->step < (1ll << 29), "vl3d_render_bwd_adam: tile-culled models keep the step in 29 bits of the texel records");
     } else {
         VL3D_REQUIRE(!adam->blocks, "vl3d_render_bwd_adam: the packed layout belongs to a tile-culled model (quad maps)");
     }
@@ -425,7 +432,7 @@ extern "C" int vl3d_render_bwd_adam(const vl3d_render_desc *desc, const void *st
     a.grad_culled_unwritten = qk ? 1 : 0;
     a.plan = (const float *)scratch;
     a.owner = reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(scratch) + owner_table_off(desc));
-    a.tile_rows = qk ? 16 : 17;      // 16: the one-frame tile kernel (64-wide regions, tile-culled models), 17: the frame pairs
+    a.tile_rows = qk ? (bv == 3 ? 16 : 18) : 17;      // 16 / 18: the one-frame tile kernel (64- / 32-wide regions, tile-culled models), 17: the frame pairs
     const double bc1 = 1.0 - pow((double)adam->beta1, (double)adam->step), bc2 = 1.0 - pow((double)adam->beta2, (double)adam->step);
     const int ts = vl3d_adam::TS;
     a.ad.p = reinterpret_cast<float4 *>(adam->param); a.ad.m = reinterpret_cast<float4 *>(adam->exp_avg);
@@ -438,7 +445,7 @@ extern "C" int vl3d_render_bwd_adam(const vl3d_render_desc *desc, const void *st
     a.ad.lr_bc1 = (float)((double)adam->lr / bc1); a.ad.beta1 = adam->beta1; a.ad.beta2 = adam->beta2; a.ad.eps = adam->eps;
     a.ad.bc2s = (float)sqrt(bc2);
     a.ad.quad_dyn = qk ? adam->quad_dyn : nullptr;
-    a.ad.cls = qk ? reinterpret_cast<unsigned char *>(adam->class_scratch) : nullptr;
+    a.ad.cls = qk ? reinterpret_cast<uint2 *>(adam->class_scratch) : nullptr;
     a.ad.blocks = adam->blocks;
     rc = dispatch(true, desc, a, s);
     if (rc != VL3D_OK) return rc;

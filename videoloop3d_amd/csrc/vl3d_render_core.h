@@ -1142,10 +1142,10 @@ __device__ __forceinline__ size_t adam_frame_base(const RenderArgs &a, int d, in
 // One Adam step of one texel and frame with gradient g: `pcur` is the parameter current for step - 1 (the compact copy holds it: the
 // catch-up replayed the deferred steps into it, so only the two moments are replayed here -- multiplications), (p, m, v) are written.
 // fb: byte offset of the frame (uniform), off: of the texel inside it.
+// (m0, v0: the two moments as stored -- the caller may have requested them long before the gradient was complete)
 template <typename OFF>
-__device__ __forceinline__ void adam_texel_step(const RenderArgs &a, size_t fb, OFF off, int from, f4 pcur, f4 g) {
+__device__ __forceinline__ void adam_texel_step_mv(const RenderArgs &a, size_t fb, OFF off, int from, f4 pcur, f4 g, f4 m0, f4 v0) {
     char *pb = reinterpret_cast<char *>(a.ad.p) + fb, *mb = reinterpret_cast<char *>(a.ad.m) + fb, *vb = reinterpret_cast<char *>(a.ad.v) + fb;
-    const f4 m0 = *reinterpret_cast<const f4 *>(mb + (size_t)off), v0 = *reinterpret_cast<const f4 *>(vb + (size_t)off);
     float4 mm = make_float4(m0.x, m0.y, m0.z, m0.w), vv = make_float4(v0.x, v0.y, v0.z, v0.w);
     vl3d_adam::replay_moments(mm, vv, from, a.ad.step - 1, a.ad.beta1, a.ad.beta2);
     float4 pp = make_float4(pcur.x, pcur.y, pcur.z, pcur.w);
@@ -1153,6 +1153,11 @@ __device__ __forceinline__ void adam_texel_step(const RenderArgs &a, size_t fb, 
     __builtin_nontemporal_store(f4{pp.x, pp.y, pp.z, pp.w}, reinterpret_cast<f4 *>(pb + (size_t)off));
     __builtin_nontemporal_store(f4{mm.x, mm.y, mm.z, mm.w}, reinterpret_cast<f4 *>(mb + (size_t)off));
     __builtin_nontemporal_store(f4{vv.x, vv.y, vv.z, vv.w}, reinterpret_cast<f4 *>(vb + (size_t)off));
+}
+template <typename OFF>
+__device__ __forceinline__ void adam_texel_step(const RenderArgs &a, size_t fb, OFF off, int from, f4 pcur, f4 g) {
+    const char *mb = reinterpret_cast<const char *>(a.ad.m) + fb, *vb = reinterpret_cast<const char *>(a.ad.v) + fb;
+    adam_texel_step_mv(a, fb, off, from, pcur, g, *reinterpret_cast<const f4 *>(mb + (size_t)off), *reinterpret_cast<const f4 *>(vb + (size_t)off));
 }
 
 // Owner table: for every texel of every plane, the tile that owns it (the tile of its owner pixel p0 = clamp_to_frame(
@@ -1201,7 +1206,13 @@ __global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, i
             inbox = !(Y < b[0] || Y >= b[1] || X < b[2] || X >= b[3]);
         }
         cls = inbox ? vl3d_adam::texel_class(vl3d_adam::Quads{a.quad_keep, a.ad.quad_dyn, a.QH, a.QW}, d, X, Y, a.ad.Hs, a.ad.Ws) : 3;
-        a.ad.cls[((size_t)d * a.Hs + y) * a.Ws + x] = (unsigned char)cls;
+        // the record the gather reads with its owner entry, long before it needs it: class | (step the texel's bookkeeping tile is current
+        // for) << 2, and the texel's 16-byte slot inside a frame of the parameter / moment tensors (dense) or pools (packed) -- so that the
+        // owner's store asks for nothing but the two moments (no class byte -> step table / block table -> moments chain of dependent loads)
+        int rfrom = 0;
+        size_t roff = 0;
+        if (cls == 1) adam_texel_inbox(a, d, x, y, rfrom, roff);
+        a.ad.cls[((size_t)d * a.Hs + y) * a.Ws + x] = make_uint2((unsigned)cls | ((unsigned)rfrom << 2), (unsigned)(roff >> 4));
     }
     const bool safe = (qx > 0.5f) && (qx < (float)a.W - 1.5f) && (qy > 0.5f) && (qy < (float)a.H - 1.5f);
     if (safe) return;
@@ -1255,15 +1266,22 @@ __global__ __launch_bounds__(256) void bwd_fill_zero_f32_if_infeasible_k(float *
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) g[i] = 0.f;
 }
 
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16, bool CULL = false, bool MASK = false, bool ADAM = false>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16, bool CULL = false, bool MASK = false, bool ADAM = false, int RWT = 64>
 // (the culled instantiation of the utils_mpi coordinate convention -- a cross-check convention, its texel coordinates cost a
 // reciprocal more -- does not fit 64 VGPRs: it takes the 128-register budget (one workgroup per CU) rather than spill)
 // MASK: stage 1's loop-mask texture as a fifth channel of the same sweep and gather (a fifth staged value, a fifth accumulator, one
 // 4-byte store per owned texel); T = 1 there, so the instantiation simply takes the 128-register budget.
-__global__ __launch_bounds__(RW *ROWS, ((REG || MASK || (CULL && COORD == VL3D_COORD_UTILS_MPI)) ? 4 : 8)) void render_bwd_tile_k(RenderArgs a) {
+// RWT: region width in pixels.  64 = one wave per region row (1024 threads at 16 rows); 32 = the frame pairs' region shape for ONE frame
+// (512 threads: two workgroups per CU at the 128-register budget, so that one workgroup's tap / moment latencies run under the other's
+// arithmetic -- the shape of the tile-culled fused step, where a workgroup sweeps a handful of planes with nothing else resident).
+__global__ __launch_bounds__(RWT *ROWS, ((REG || MASK || (CULL && COORD == VL3D_COORD_UTILS_MPI)) ? 4 : 8)) void render_bwd_tile_k(RenderArgs a) {
     static_assert(!(MASK && (CULL || F16 || ORDER != VL3D_ACT_POST)), "the loop-mask channel: dense fp32 stage-1 stacks, sample-then-activate");
     static_assert(!(ADAM && (F16 || MASK || !REG)), "the fused optimiser step: fp32 stacks, the instantiation with the 128-register budget");
+    static_assert(RWT == 64 || RWT == 32, "region width");
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
+    constexpr int RW = RWT;                                  // (shadows the 64-wide default of the namespace)
+    constexpr int SLOT_BITS = RW * ROWS > 512 ? 10 : 9;      // the owner table's slot field (bwd_owner_table_k)
+    constexpr unsigned SLOT_MASK = (1u << SLOT_BITS) - 1u;
     constexpr int NT = RW * ROWS;
     __shared__ float s_gm[MASK ? 2 : 1][MASK ? NT : 1];     // MASK: gradient w.r.t. the sampled mask logit of this pixel on this plane
     // REG: the layer-space smoothness regularisers (MPV.py:517-531) are differentiated here as well: their gradient at a pixel is
@@ -1273,7 +1291,7 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || MASK || (CULL && COORD == VL3D_C
     // per-plane staging of the region's pixels, double buffered so one barrier per plane suffices
     __shared__ float4 s_g[2][NT];     // gradient w.r.t. the sampled (POST) / activated (PRE) value of this pixel on this plane
     __shared__ float2 s_t[2][NT];     // its texel coordinates (tx,ty) (true ones also where the plane does not cover it: then g = 0)
-    const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & (RW - 1), row = tid / RW;
     // 1-D grid, XCD-aware order: every XCD walks a contiguous run of tiles (row-major within a frame), so a tile's halo
     // rows and its neighbours' taps hit the same L2
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -1325,7 +1343,7 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || MASK || (CULL && COORD == VL3D_C
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
     // this tile's texel windows, one int4 per plane (bwd_windows_k)
     const unsigned my_tile_id = (unsigned)(tile_y * a.tiles_x + tile_x);
-    const unsigned my_tile = (unsigned)((tile_y & 7) << 3 | (tile_x & 7));      // the owner table's code of this tile
+    const unsigned my_tile = (unsigned)((tile_y & (SLOT_BITS == 9 ? 15 : 7)) << 3 | (tile_x & 7));      // the owner table's code of this tile
     const unsigned toff_thread = (unsigned)(row * a.Ws + lane);   // texel (lane, row) of a window, relative to its corner
     const cint_p wrec = (cint_p)a.plan + plan_win_off(a.D) + (size_t)my_tile_id * a.D * 4;
     int nswept = 0;
@@ -1350,18 +1368,25 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || MASK || (CULL && COORD == VL3D_C
         // (threads outside the window read a neighbouring entry -- the table is padded by ROWS rows -- and ignore it): no
         // branch around the load, so no merged wait counters.
         const unsigned e0 = oplane[win0 + toff_thread];
+        // (fused step of a tile-culled model) this thread's record of the same texel: class, step, slot (bwd_owner_table_k)
+        const uint2 *rplane = nullptr;
+        uint2 rec0 = make_uint2(0u, 0u);
+        if constexpr (ADAM && CULL) {
+            rplane = a.ad.cls + (size_t)d * a.Hs * a.Ws;
+            rec0 = rplane[win0 + toff_thread];
+        }
         if (CULL && culled) {
             // tile culling: no pixel of the region sees a kept quad of this plane -- its alpha is exactly 0 for all of them, the
             // composite state does not move, and the texels this tile owns get a zero gradient (written: nothing memsets it)
             // (... unless the caller never reads the gradient of culled texels -- every texel this tile owns on this plane is one: the box
             // test of bwd_windows_k is two texels wider than the region's footprint, a texel's class looks one texel around it)
             const f4 z = f4{0.f, 0.f, 0.f, 0.f};
-            if (row < wh && lane < ww && (e0 >> 10) == my_tile)
+            if (row < wh && lane < ww && (e0 >> SLOT_BITS) == my_tile)
                 store_grad_texel<F16>(gplane, (win0 + toff_thread) << 4, z);
             for (int wy = row; wy < wh; wy += ROWS)
                 for (int wx = lane + (wy == row ? RW : 0); wx < ww; wx += RW) {
                     const unsigned tix = win0 + (unsigned)(wy * a.Ws + wx);
-                    if ((oplane[tix] >> 10) == my_tile)
+                    if ((oplane[tix] >> SLOT_BITS) == my_tile)
                         store_grad_texel<F16>(gplane, tix << 4, z);
                 }
             continue;
@@ -1426,14 +1451,26 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || MASK || (CULL && COORD == VL3D_C
         s_t[buf][tid] = tc;
         s_g[buf][tid] = gval;
         if constexpr (MASK) s_gm[buf][tid] = gm;
+        // (fused step of a tile-culled model) the moments and the current parameter of this thread's first texel are requested HERE, in front
+        // of the barrier: they arrive while the workgroup meets and the gather reads LDS.  Unconditional (a thread without a dynamic texel of
+        // its own reads slot 0 and drops it): no branch around the loads, no merged wait counters.
+        f4 pre_m = f4{0.f, 0.f, 0.f, 0.f}, pre_v = pre_m, pre_p = pre_m;
+        if constexpr (ADAM && CULL) {
+            const bool mine0 = row < wh && lane < ww && (e0 >> SLOT_BITS) == my_tile && (rec0.x & 3u) == 1u;
+            const size_t fb = adam_frame_base(a, d, t), o = mine0 ? (size_t)rec0.y << 4 : 0;
+            pre_m = *reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(a.ad.m) + fb + o);
+            pre_v = *reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(a.ad.v) + fb + o);
+            pre_p = load_texel<false>(plane, mine0 ? (win0 + toff_thread) << 4 : 0u);
+            asm volatile("" ::: "memory");      // keep the requests in front of the barrier
+        }
         __syncthreads();   // staging of plane d visible (the other buffer may still be read by slower waves: not touched here)
         // (3) every texel of this tile's window that the owner table assigns to this tile gathers its taps from the 3x3
         //     pixels around its owner pixel.  Wave = window row, lane = window column: uniform row bases, no index arithmetic.
         if VL3D_ABLATE(a.ablate, 1) continue;
-        auto gather = [&](unsigned e, int wx, int wy, unsigned tix) {   // tix = frame texel index of window texel (wx, wy)
-            if ((e >> 10) != my_tile) return;
+        auto gather = [&](unsigned e, int wx, int wy, unsigned tix, uint2 rec = make_uint2(0u, 0u), bool pre = false) {   // tix = frame texel index of window texel (wx, wy)
+            if ((e >> SLOT_BITS) != my_tile) return;
             // fixed trip count, constant LDS offsets; weights clamp to 0 for non-contributing pixels (|J^-1|_inf < 1.4)
-            const int lc = (int)(e & 1023u);
+            const int lc = (int)(e & SLOT_MASK);
             const f2 tau = f2{(float)(X0 + wx), (float)(Y0 + wy)};
             f4 acc = f4{0.f, 0.f, 0.f, 0.f};
             float accm = 0.f;
@@ -1473,12 +1510,13 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || MASK || (CULL && COORD == VL3D_C
                 if constexpr (CULL) {
                     // tile-culled model: the pre-pass's class byte -- a dynamic texel is stepped here, a static texel's gradient is stored (the step
                     // kernel sums it over the frames), culled texels and texels outside their plane's box are nobody's business
-                    const unsigned c = a.ad.cls[(size_t)d * a.Hs * a.Ws + tix];
+                    const unsigned c = rec.x & 3u;
                     if (c == 2) store_grad_texel<false>(gplane, tix << 4, acc);
                     if (c != 1) return;
-                    size_t offp;
-                    adam_texel_inbox(a, d, X0 + wx, Y0 + wy, from, offp);
-                    adam_texel_step(a, adam_frame_base(a, d, t), offp, from, load_texel<false>(plane, tix << 4), acc);
+                    from = (int)(rec.x >> 2);
+                    const size_t offp = (size_t)rec.y << 4;
+                    if (pre) adam_texel_step_mv(a, adam_frame_base(a, d, t), offp, from, pre_p, acc, pre_m, pre_v);
+                    else adam_texel_step(a, adam_frame_base(a, d, t), offp, from, load_texel<false>(plane, tix << 4), acc);
                 } else {
                     unsigned off;
                     if (!adam_texel(a, d, X0 + wx, Y0 + wy, from, off)) return;
@@ -1487,7 +1525,8 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || MASK || (CULL && COORD == VL3D_C
             } else if (!VL3D_ABLATE(a.ablate, 2)) store_grad_texel<F16>(gplane, tix << 4, acc);
             if constexpr (MASK) __builtin_nontemporal_store(accm, gmplane + tix);
         };
-        if (row < wh && lane < ww) gather(e0, lane, row, win0 + toff_thread);
+        auto rec_at = [&](unsigned tix) { if constexpr (ADAM && CULL) return rplane[tix]; else return make_uint2(0u, 0u); };
+        if (row < wh && lane < ww) gather(e0, lane, row, win0 + toff_thread, rec0, true);
         // rest of a window larger than 64 x ROWS (stacks stored above the frame's resolution, frame-border tiles, rotations)
         const int nec = ww - RW;                     // columns right of the first 64 (uniform)
         if (nec > 0 && nec <= RW) {
@@ -1499,19 +1538,19 @@ __global__ __launch_bounds__(RW *ROWS, ((REG || MASK || (CULL && COORD == VL3D_C
                 const int wy = wy0 + r, wx = RW + c;
                 if (c < nec && wy < rmain) {
                     const unsigned tix = win0 + (unsigned)(wy * a.Ws + wx);
-                    gather(oplane[tix], wx, wy, tix);
+                    gather(oplane[tix], wx, wy, tix, rec_at(tix));
                 }
             }
         } else if (nec > RW) {
             for (int wx = lane + RW; wx < ww && row < wh; wx += RW) {
                 const unsigned tix = win0 + (unsigned)(row * a.Ws + wx);
-                gather(oplane[tix], wx, row, tix);
+                gather(oplane[tix], wx, row, tix, rec_at(tix));
             }
         }
         for (int wy = row + ROWS; wy < wh; wy += ROWS)      // rows below the first ROWS: one wave per row
             for (int wx = lane; wx < ww; wx += RW) {
                 const unsigned tix = win0 + (unsigned)(wy * a.Ws + wx);
-                gather(oplane[tix], wx, wy, tix);
+                gather(oplane[tix], wx, wy, tix, rec_at(tix));
             }
     }
 }
@@ -1909,28 +1948,26 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
 }
 
 // ---- launch templates ---------------------------------------------------------------------------------------------
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16 = false, bool MASK = false, bool ADAM = false>
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool REG, bool F16 = false, bool MASK = false, bool ADAM = false, int RWT = 64>
 void launch_tile(const RenderArgs &a, hipStream_t s) {
-    constexpr int RH = 1, IW = RW - 2 * RH, IH = ROWS - 2 * RH;
+    constexpr int RH = 1, IW = RWT - 2 * RH, IH = ROWS - 2 * RH;
+    constexpr int SLOT_BITS = RWT * ROWS > 512 ? 10 : 9;
     RenderArgs b = a;
     b.tiles_x = (a.W + IW - 1) / IW; b.tiles_y = (a.H + IH - 1) / IH;
     const int nwin = b.tiles_x * b.tiles_y * a.D;
     hipLaunchKernelGGL((bwd_windows_k<COORD>), dim3((nwin + 255) / 256), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x, b.tiles_y,
                        reinterpret_cast<int *>(const_cast<float *>(a.plan)) + plan_win_off(a.D));
     hipLaunchKernelGGL(bwd_owner_table_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x,
-                       const_cast<unsigned short *>(a.owner));
+                       const_cast<unsigned short *>(a.owner), RWT, SLOT_BITS);
+    const dim3 grid((unsigned)(b.tiles_x * b.tiles_y * a.T)), block(RWT * ROWS);
     if constexpr (ADAM) {      // (tile-culled models only: the dense fused step rides the frame pairs -- the one-frame form measured 202 against 213-218 it/s)
-        hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, true, false, true, false, true>),
-                           dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
+        hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, true, false, true, false, true, RWT>), grid, block, 0, s, b);
     } else if constexpr (MASK) {       // (dense models only: the entry point refuses a quad map)
-        hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16, false, true>),
-                           dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
+        hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16, false, true, false, RWT>), grid, block, 0, s, b);
     } else if (a.quad_keep)
-        hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16, true>),
-                           dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
+        hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16, true, false, false, RWT>), grid, block, 0, s, b);
     else
-        hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16>),
-                           dim3((unsigned)(b.tiles_x * b.tiles_y * a.T)), dim3(RW * ROWS), 0, s, b);
+        hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, REG, F16, false, false, false, RWT>), grid, block, 0, s, b);
 }
 
 template <bool BWD, int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
@@ -1960,7 +1997,12 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
                           AACT == VL3D_ACT_SIGMOID && !F16 && VL3D_HS == 9) {
                 if (a.ad.p) {
                     // tile-culled models: one frame per thread, 64-wide regions (the frame pairs are built for dense stacks)
-                    if (a.quad_keep) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, false, false, true>(a, s);
+                    // (32-wide regions unless variant 3 asks for the 64-wide ones: two workgroups per CU, 0.60 against 0.71 ms per iteration of the
+                    // tile-culled schedule, docs/kernels/K2_render_backward.md round 5)
+                    if (a.quad_keep) {
+                        if (a.tile_rows != 16) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, false, false, true, 32>(a, s);
+                        else launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, false, false, true>(a, s);
+                    }
                     else if (a.g_reg || a.g_asum) launch_pair<COORD, BORDER, ORDER, RACT, AACT, false, true, true>(a, s);
                     else launch_pair<COORD, BORDER, ORDER, RACT, AACT, false, false, true>(a, s);
                     hipLaunchKernelGGL((render_bwd_k<COORD, BORDER, ORDER, RACT, AACT, F16>), grid, block, 0, s, a);
@@ -1990,8 +2032,18 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
                     }
                 }
             }
+            // 32-wide one-frame regions (variant 5; the shipped planar convention only): half the workgroup, twice as many of them
+            if constexpr (MASKABLE && VL3D_HS == 9) {
+                if (!done && a.tile_rows == 18) {
+                    if (a.g_reg || a.g_asum || (a.quad_keep && a.grad_culled_unwritten)) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, false, false, false, 32>(a, s);
+                    else launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, false, false, false, false, 32>(a, s);
+                    done = true;
+                }
+            }
             if (!done) {
-                if (a.g_reg || a.g_asum) {     // layer regularisers and / or sparsity sums: the REG instantiation (128-VGPR budget)
+                // layer regularisers and / or sparsity sums: the REG instantiation (128-VGPR budget); a tile-culled call whose consumer never
+                // reads culled texels takes it too -- it is the one that SKIPS the planes a tile cannot see instead of zero-filling them
+                if (a.g_reg || a.g_asum || (a.quad_keep && a.grad_culled_unwritten)) {
                     launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, F16>(a, s);
                 } else {
                     launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, false, F16>(a, s);

@@ -255,7 +255,7 @@ class WindowAdam(torch.optim.Optimizer):
         pend = self.pending
         return (self.fused_backward and isinstance(pend, tuple) and len(pend) == 3 and self._is_leaf(pend, stack) and stack.dtype == torch.float32
                 and (stack.shape[1] >= 2 or self.quad_keep is not None) and spec.coord_mode == "affine" and spec.border == "hardcut" and spec.act_order == "post"
-                and spec.rgb_act == "sigmoid" and spec.alpha_act == "sigmoid" and (int(spec.variant) & 0xf) in ((0, 3) if self.quad_keep is not None else (0,)))
+                and spec.rgb_act == "sigmoid" and spec.alpha_act == "sigmoid" and (int(spec.variant) & 0xf) in ((0, 3, 5) if self.quad_keep is not None else (0,)))
 
     @staticmethod
     def _is_leaf(pend, stack):
@@ -285,7 +285,7 @@ class WindowAdam(torch.optim.Optimizer):
                 self._boxes_dev = torch.empty(128 * 4, dtype=torch.int32, device=dev)
             aw.plane_boxes, aw.boxes_scratch = boxes.ctypes.data, self._boxes_dev.data_ptr()
         if self.quad_keep is not None:
-            n = D * stack.shape[2] * stack.shape[3]
+            n = int(L.lib().vl3d_render_bwd_adam_class_bytes(desc))
             if self._class_dev is None or self._class_dev.numel() < n or self._class_dev.device != dev:
                 self._class_dev = None
                 self._class_dev = torch.empty(n, dtype=torch.uint8, device=dev)
