@@ -2034,7 +2034,11 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
             }
             // 32-wide one-frame regions (variant 5; the shipped planar convention only): half the workgroup, twice as many of them
             if constexpr (MASKABLE && VL3D_HS == 9) {
-                if (!done && a.tile_rows == 18) {
+                // (... and the default of a tile-culled call under VL3D_GRAD_CULLED_UNWRITTEN: two workgroups per CU -- cfg3 at 16.5 % kept quads
+                // 4.5 against 5.1 ms, profiles/r05b_cull_lean.txt.  A per-tile work list of the swept planes -- bit masks written by
+                // bwd_windows_k, scalar bit scans instead of one record load per skipped plane -- measured the same 4.49 ms / 0.60 ms per
+                // schedule iteration: the skipped planes' scalar loads are hidden, not built)
+                if (!done && (a.tile_rows == 18 || (a.tile_rows == 17 && a.quad_keep && a.grad_culled_unwritten))) {
                     if (a.g_reg || a.g_asum || (a.quad_keep && a.grad_culled_unwritten)) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, false, false, false, 32>(a, s);
                     else launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, false, false, false, false, 32>(a, s);
                     done = true;
