@@ -482,11 +482,13 @@ __device__ __forceinline__ int reg_pop_plane(unsigned long long &m0, unsigned lo
 }
 
 // activated layer value of pixel (px, py) on plane d in frame t, sampled in place (plane and pixel vary per lane)
+// (hs: the homography table -- the slot kernel stages it in LDS: the plane varies per lane, and a global load per slot in front of the taps
+// was a full memory latency on the slot loop's critical path)
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
-__device__ __forceinline__ f4 reg_sample(const RenderArgs &a, float px, float py, int d, int t) {
+__device__ __forceinline__ f4 reg_sample(const RenderArgs &a, const float *hs, float px, float py, int d, int t) {
     float h[VL3D_HN];
 #pragma unroll
-    for (int i = 0; i < VL3D_HN; ++i) h[i] = a.homos[VL3D_HS * d + i];
+    for (int i = 0; i < VL3D_HN; ++i) h[i] = hs[VL3D_HS * d + i];
     const Taps2 tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
     const char *plane = reinterpret_cast<const char *>(a.stack) + ((size_t)d * a.T + t) * ((size_t)a.Hs * a.Ws * (F16 ? 8 : 16));
     typename TapVal<F16, ORDER>::type tv[4];
@@ -518,6 +520,8 @@ __global__ __launch_bounds__(512) void reg_slot_fwd_k(RenderArgs a, int tiles_x,
     __shared__ int s_d[2][NT];
     __shared__ float red[4][FH];
     __shared__ int s_kmax;
+    __shared__ float s_h[128 * VL3D_HS];      // the planes' homography records (D <= 128: the coverage masks' limit)
+    for (int i = threadIdx.x; i < a.D * VL3D_HS; i += NT) s_h[i] = a.homos[i];      // (visible behind the barriers below)
     const int b = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_x = b % tiles_x, rest = b / tiles_x;
     const int tile_y = rest % tiles_y, t = rest / tiles_y;
@@ -549,7 +553,7 @@ __global__ __launch_bounds__(512) void reg_slot_fwd_k(RenderArgs a, int tiles_x,
         const int buf = k & 1;
         const int d = reg_pop_plane(m0, m1);      // my plane in slot k (-1: I have no slot k)
         f4 v = f4{0.f, 0.f, 0.f, 0.f};
-        if (d >= 0) v = reg_sample<COORD, BORDER, ORDER, RACT, AACT, F16>(a, px, py, d, t);
+        if (d >= 0) v = reg_sample<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s_h, px, py, d, t);
         if constexpr (RENDER) {      // (spelt like VL3D_COMPOSITE of render_fwd2_k; an absent slot adds exact zeros)
             const float w = v.w * Tr;
             cr += w * v.x; cg += w * v.y; cb += w * v.z; A += w;
