@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """bench.py's `tile_culling` leg in process, interleaved rounds: cfg3 render fwd + bwd on the blob model (16.5 % of the quads kept) --
-plain (no quad map) / culled (dense gradient: zeros written for culled texels) / lean (VL3D_GRAD_CULLED_UNWRITTEN) in 64- and 32-wide regions.
+plain (no quad map) / culled (dense gradient: zeros written for culled texels) / lean (VL3D_GRAD_CULLED_UNWRITTEN: the default, 32-wide regions
+at the plain kernel's register budget) / lean_reg32 (desc->variant 5: the instantiation with the regularisers' 128-register budget).
   python profiles/cull_lean.py [--T 50] [--rounds 5]"""
 import argparse
 import os
@@ -35,7 +36,7 @@ for d in range(D):
     keep[d] = ((qy - cy).abs() <= QH // 5) & ((qx - cx).abs() <= QW // 4)
 with torch.no_grad():
     tiles.cull_stack_(stack, keep)
-legs = {"plain": (None, False, 0), "culled": (keep, False, 0), "lean64": (keep, True, 0), "lean32": (keep, True, 5)}
+legs = {"plain": (None, False, 0), "culled": (keep, False, 0), "lean": (keep, True, 0), "lean_reg32": (keep, True, 5)}
 ev = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
 res = {k: ([], []) for k in legs}
 for r in range(a.rounds + 1):
@@ -52,4 +53,4 @@ for r in range(a.rounds + 1):
         del rgb, gs
 print(f"kept quads {float(keep.float().mean()):.3f}, T = {T}")
 for name, (f, b) in res.items():
-    print(f"{name:8s} fwd median {statistics.median(f):7.3f}  bwd median {statistics.median(b):7.3f} min {min(b):7.3f}  step {statistics.median(f) + statistics.median(b):7.3f} ms")
+    print(f"{name:10s} fwd median {statistics.median(f):7.3f}  bwd median {statistics.median(b):7.3f} min {min(b):7.3f}  step {statistics.median(f) + statistics.median(b):7.3f} ms")

@@ -1278,7 +1278,7 @@ template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int ROWS, bool R
 // RWT: region width in pixels.  64 = one wave per region row (1024 threads at 16 rows); 32 = the frame pairs' region shape for ONE frame
 // (512 threads: two workgroups per CU at the 128-register budget, so that one workgroup's tap / moment latencies run under the other's
 // arithmetic -- the shape of the tile-culled fused step, where a workgroup sweeps a handful of planes with nothing else resident).
-__global__ __launch_bounds__(RWT *ROWS, ((REG || MASK || (CULL && COORD == VL3D_COORD_UTILS_MPI)) ? 4 : 8)) void render_bwd_tile_k(RenderArgs a) {
+__global__ __launch_bounds__(RWT *ROWS, ((REG || MASK || (CULL && COORD == VL3D_COORD_UTILS_MPI)) ? 4 : ((CULL && RWT == 32) ? 6 : 8))) void render_bwd_tile_k(RenderArgs a) {
     static_assert(!(MASK && (CULL || F16 || ORDER != VL3D_ACT_POST)), "the loop-mask channel: dense fp32 stage-1 stacks, sample-then-activate");
     static_assert(!(ADAM && (F16 || MASK || !REG)), "the fused optimiser step: fp32 stacks, the instantiation with the 128-register budget");
     static_assert(RWT == 64 || RWT == 32, "region width");
@@ -1365,7 +1365,7 @@ __global__ __launch_bounds__(RWT *ROWS, ((REG || MASK || (CULL && COORD == VL3D_
         // (a skipped plane whose owned texels need no zero fill -- grad_culled_unwritten -- costs one scalar record, not a table load per
         // thread.  In the instantiation with regularisers only, the one a shipped stage-2 iteration runs: the plain culled kernel sits
         // exactly at its 64-register budget and the extra branch spilled 12 bytes; it keeps filling zeros, which is always correct.)
-        if constexpr (REG) { if (CULL && culled && (ADAM || a.grad_culled_unwritten)) continue; }
+        if constexpr (REG || RWT == 32) { if (CULL && culled && (ADAM || a.grad_culled_unwritten)) continue; }
         const unsigned win0 = (unsigned)(Y0 * a.Ws + X0);          // frame texel index of the window's corner (uniform)
         const unsigned short *oplane = a.owner + (size_t)d * a.Hs * a.Ws;
         // this thread's first owner-table entry, requested now so that it arrives in the shadow of the sweep.  Unconditional
@@ -2038,12 +2038,13 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
             }
             // 32-wide one-frame regions (variant 5; the shipped planar convention only): half the workgroup, twice as many of them
             if constexpr (MASKABLE && VL3D_HS == 9) {
-                // (... and the default of a tile-culled call under VL3D_GRAD_CULLED_UNWRITTEN: two workgroups per CU -- cfg3 at 16.5 % kept quads
-                // 4.5 against 5.1 ms, profiles/r05b_cull_lean.txt.  A per-tile work list of the swept planes -- bit masks written by
+                // (... and the default of a tile-culled call under VL3D_GRAD_CULLED_UNWRITTEN, which SKIPS the planes a tile cannot see: cfg3 at
+                // 16.5 % kept quads 3.7 ms at the plain kernel's register budget (70 VGPRs, three workgroups per CU), 4.5-4.8 ms in the
+                // instantiation with the regularisers' 128 (variant 5), 5.1 ms in its 64-wide form, profiles/r05b_cull_lean.txt.  A per-tile work list of the swept planes -- bit masks written by
                 // bwd_windows_k, scalar bit scans instead of one record load per skipped plane -- measured the same 4.49 ms / 0.60 ms per
                 // schedule iteration: the skipped planes' scalar loads are hidden, not built)
                 if (!done && (a.tile_rows == 18 || (a.tile_rows == 17 && a.quad_keep && a.grad_culled_unwritten))) {
-                    if (a.g_reg || a.g_asum || (a.quad_keep && a.grad_culled_unwritten)) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, false, false, false, 32>(a, s);
+                    if (a.g_reg || a.g_asum || (a.tile_rows == 18 && a.quad_keep && a.grad_culled_unwritten)) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, false, false, false, 32>(a, s);
                     else launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, false, false, false, false, 32>(a, s);
                     done = true;
                 }
