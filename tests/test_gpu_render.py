@@ -525,6 +525,9 @@ def test_tile_culling_matches_oracle(dev, spec_name, keep_frac):
     assert _tile_ran() == 1
     assert maxabs(rgb, rgb_o) <= TOL and maxabs(alpha, alpha_o) <= TOL
     assert maxabs(gs, gs_o) <= TOL * max(1.0, float(gs_o.abs().max()))
+    # the culled forward composites two frames per thread (render_fwd2x_k<CULL>); forward variant 6 = one frame per thread: the same bits
+    rgb1, alpha1 = render_planes(s_gpu, homos.to(dev), H, W, RenderSpec(variant=0x600, **kw_p), quad_keep=keep.to(dev))
+    assert torch.equal(rgb, rgb1) and torch.equal(alpha, alpha1)
     dead = ~tiles.quad_to_texel_mask(keep.to(dev), Hs, Ws)
     assert float(gs[dead[:, None].expand(D, T, Hs, Ws)].abs().max() if dead.any() else 0.0) == 0.0
     if keep_frac == 1.0:

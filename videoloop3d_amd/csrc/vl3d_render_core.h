@@ -857,7 +857,8 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
 // not on the frame: a thread that composites frames t and t+1 of its pixel side by side pays for it once.  The per-frame
 // arithmetic is that of render_fwd2_k instruction for instruction (same results bit for bit); the 8 tap loads per plane and
 // thread also replace occupancy as the source of memory parallelism (<= 128 VGPRs, 4 waves per SIMD).
-template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool F16>
+// CULL: tile culling (render_fwd2_k's plan and plane walk): only the planes whose bit is set for this workgroup, two frames each.
+template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool F16, bool CULL = false>
 __global__ __launch_bounds__(64 * TY, 4) void render_fwd2x_k(RenderArgs a, int tiles_x, int tiles_y) {      // >= 4 waves per SIMD: <= 128 VGPRs
     const int b = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_x = b % tiles_x, rest = b / tiles_x;
@@ -887,6 +888,43 @@ __global__ __launch_bounds__(64 * TY, 4) void render_fwd2x_k(RenderArgs a, int t
         n11 += o1.w; n21 = fmaf(o1.w, o1.w, n21);                            \
         Tr0 *= (1.0f - o0.w); Tr1 *= (1.0f - o1.w);                          \
     }
+    if constexpr (CULL) {
+        // the workgroup's plane list (cull_fwd_plan_k): two 64-bit words in SGPRs, scalar bit scans; a skipped plane's taps are all culled
+        // texels (alpha exactly 0), so the result is bit-identical to walking it
+        const unsigned long long *mk = a.cull_masks + (size_t)(tile_y * tiles_x + tile_x) * 2;
+        unsigned long long m0 = ((const __attribute__((address_space(4))) unsigned long long *)mk)[0];
+        unsigned long long m1 = ((const __attribute__((address_space(4))) unsigned long long *)mk)[1];
+        auto next = [&]() {
+            int d = -1;
+            if (m0) { d = __builtin_ctzll(m0); m0 &= m0 - 1; }
+            else if (m1) { d = 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
+            return d;
+        };
+        auto fetch = [&](int d, Taps2 &t, tapv_t *v0, tapv_t *v1) {
+            float h[VL3D_HN];
+            load_uniform(a.homos + VL3D_HS * d, h);
+            t = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
+            load_taps2<F16>(plane0 + (size_t)d * plane_stride_b, t, st, v0);
+            load_taps2<F16>(plane1 + (size_t)d * plane_stride_b, t, st, v1);
+            asm volatile("" ::: "memory");
+        };
+        int dA = next();
+        if (dA >= 0) {
+            Taps2 tA, tB;
+            fetch(dA, tA, vA0, vA1);
+            for (;;) {
+                const int dB = next();
+                fetch(dB < 0 ? dA : dB, tB, vB0, vB1);      // unconditional prefetch (re-reads the current plane past the end)
+                VL3D_COMPOSITE2(tA, vA0, vA1)
+                if (dB < 0) break;
+                const int dC = next();
+                fetch(dC < 0 ? dB : dC, tA, vA0, vA1);
+                VL3D_COMPOSITE2(tB, vB0, vB1)
+                if (dC < 0) break;
+                dA = dC;
+            }
+        }
+    } else {
     Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy), tB = tA;
     load_taps2<F16>(plane0, tA, st, vA0);
     load_taps2<F16>(plane1, tA, st, vA1);
@@ -914,6 +952,7 @@ __global__ __launch_bounds__(64 * TY, 4) void render_fwd2x_k(RenderArgs a, int t
         VL3D_COMPOSITE2(tB, vB0, vB1)
         if (d + 2 >= a.D) break;
     }
+    }
 #undef VL3D_COMPOSITE2
     size_t pix = ((size_t)t0 * a.H + y) * a.W + x;
     a.rgb[pix * 3 + 0] = cr0; a.rgb[pix * 3 + 1] = cg0; a.rgb[pix * 3 + 2] = cb0;
@@ -931,8 +970,16 @@ template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16>
 void launch_fwd2x(const RenderArgs &a, hipStream_t s) {
     constexpr int TY = 8;
     const int tiles_x = (a.W + 63) / 64, tiles_y = (a.H + TY - 1) / TY;
-    hipLaunchKernelGGL((render_fwd2x_k<COORD, BORDER, ORDER, RACT, AACT, TY, F16>), dim3((unsigned)(tiles_x * tiles_y * ((a.T + 1) / 2))),
-                       dim3(64 * TY), 0, s, a, tiles_x, tiles_y);
+    const dim3 grid((unsigned)(tiles_x * tiles_y * ((a.T + 1) / 2))), block(64 * TY);
+    if (a.quad_keep && a.cull_masks) {       // tile culling: plan (frame independent; the workgroups are render_fwd2_k's 64 x 8 tiles), then the plane-list kernel
+        auto *masks = const_cast<unsigned long long *>(a.cull_masks);
+        (void)hipMemsetAsync(masks, 0, (size_t)tiles_x * tiles_y * 16, s);
+        const int n = tiles_x * tiles_y * a.D;
+        hipLaunchKernelGGL((cull_fwd_plan_k<COORD>), dim3((n + 255) / 256), dim3(256), 0, s, a, TY, tiles_x, tiles_y, masks);
+        hipLaunchKernelGGL((render_fwd2x_k<COORD, BORDER, ORDER, RACT, AACT, TY, F16, true>), grid, block, 0, s, a, tiles_x, tiles_y);
+        return;
+    }
+    hipLaunchKernelGGL((render_fwd2x_k<COORD, BORDER, ORDER, RACT, AACT, TY, F16>), grid, block, 0, s, a, tiles_x, tiles_y);
 }
 
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool SWZ, bool F16 = false>
@@ -2106,7 +2153,7 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
             }
         }
         if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID) {
-            if (a.T >= 2 && a.fwd_variant != 6 && !(a.quad_keep && a.cull_masks)) return launch_fwd2x<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
+            if (a.T >= 2 && a.fwd_variant != 6) return launch_fwd2x<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);      // (tile-culled models too)
         }
         launch_fwd2<COORD, BORDER, ORDER, RACT, AACT, 8, true, F16>(a, s);
     }
