@@ -1547,6 +1547,7 @@ __global__ __launch_bounds__(RWT *ROWS, ((REG || MASK || (CULL && COORD == VL3D_
                     const int li = lc + dy * RW + dx;
                     const f2 dc = *reinterpret_cast<const f2 *>(&s_t[buf][li]) - tau;
                     const float wgt = tent_weight(dc.x) * tent_weight(dc.y);
+                    if (!a.gather9 && __builtin_amdgcn_ballot_w64(wgt != 0.0f) == 0ull) continue;      // (exact zeros for the whole wave: pair_gather_plane)
                     acc += *reinterpret_cast<const f4 *>(&s_g[buf][li]) * wgt;
                     if constexpr (MASK) accm = fmaf(s_gm[buf][li], wgt, accm);
                 }
@@ -1662,6 +1663,11 @@ __device__ __forceinline__ void pair_gather_plane(const RenderArgs &a, const flo
                     const int li = lc + dy * PW + dx;
                     const f2 dc = *reinterpret_cast<const f2 *>(&st[li]) - tau;
                     const float wgt = tent_weight(dc.x) * tent_weight(dc.y);
+                    // a staged pixel whose weight is 0 for EVERY texel of the wave adds exact zeros: its 16-byte LDS reads and multiply-adds are
+                    // skipped (uniform branch).  Near unit magnification -- stacks at the frame's resolution, J within a fraction of a percent
+                    // of 1 -- the 2x2 test of bwd_windows_k stays undecided, yet five of the nine pixels almost never reach a texel: cfg3
+                    // backward -2 % (fp32) / -4 % (fp16 stacks), same bits.  (variant 4 -- the plain 3x3 definition -- does not skip.)
+                    if (!a.gather9 && __builtin_amdgcn_ballot_w64(wgt != 0.0f) == 0ull) continue;
                     acc0 += *reinterpret_cast<const f4 *>(&sg0[li]) * wgt;
                     acc1 += *reinterpret_cast<const f4 *>(&sg1[li]) * wgt;
                 }
