@@ -27,7 +27,7 @@ def find(prefix):
     return [k for k in blocks if k.startswith(prefix)]
 
 
-fwd, bwd = traffic("render_fwd2x_k<1, 1, 1, 1, 1, 8, false>"), traffic("render_bwd_pair_k<1, 1, 1, 1, 1, false, false, false, 32>")
+fwd, bwd = traffic("render_fwd2x_k<1, 1, 1, 1, 1, 8, false, false>"), traffic("render_bwd_pair_k<1, 1, 1, 1, 1, false, false, false, 32>")
 fr, br = traffic("render_fwd_reg_k<1, 1, 1, 1, 1, false, false>"), traffic("render_bwd_pair_k<1, 1, 1, 1, 1, false, true, false, 32>")
 out = {
     "_note": "HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate passes, --kernel-trace only). FETCH_SIZE (KB) is doubled per "
@@ -38,7 +38,7 @@ out = {
     "D32_T50_720x1280_stack792x1408_reg": {"fwd": fr["bytes"], "bwd": br["bytes"],
                                             "source": "render_fwd_reg_k and render_bwd_pair_k<..., true> on the 1.1x stack with the smoothness regularisers"},
 }
-f16f, f16b = find("render_fwd2x_k<1, 1, 1, 1, 1, 8, true>"), find("render_bwd_pair_k<1, 1, 1, 1, 1, true, false, false, 32>")
+f16f, f16b = find("render_fwd2x_k<1, 1, 1, 1, 1, 8, true, false>"), find("render_bwd_pair_k<1, 1, 1, 1, 1, true, false, false, 32>")
 if f16f and f16b:
     a, b = traffic(f16f[0]), traffic(f16b[0])
     out["D32_T50_720x1280_fp16_stack"] = {"fwd": a["bytes"], "bwd": b["bytes"], "algorithmic": {"fwd": 50 * 720 * 1280 * (8 * 32 + 12), "bwd": 50 * 720 * 1280 * (16 * 32 + 12)},
