@@ -143,10 +143,9 @@ def run_iter(nerf, optimizer, item, args, device):
     img_loss, loop_loss = image_and_loop_loss(rgbl, b_rgbs, b_loopmask if learn_mask else None,
                                               scale_invariant=bool(getattr(args, "scale_invariant", False)))
     args_var = vars(args)
-    extra_losses = {k: v.mean() * args_var[f"{k}_loss_weight"] for k, v in extra.items() if args_var.get(f"{k}_loss_weight", 0) > 0}
-    loss = img_loss + loop_loss
-    for v in extra_losses.values():
-        loss = loss + v
+    from .train_3dvid import weighted_total
+    mains = [img_loss] + ([loop_loss] if torch.is_tensor(loop_loss) else [])
+    loss, _, extra_losses = weighted_total(mains, extra, lambda k: args_var.get(f"{k}_loss_weight", 0))
     optimizer.zero_grad()
     loss.backward()
     if hasattr(getattr(nerf, "module", nerf), "post_backward"):
