@@ -81,6 +81,14 @@ typedef struct vl3d_render_desc {
      * Those slots of grad_stack are then UNDEFINED.  0 = every texel of grad_stack is written (a gradient any consumer may read).
      * A permission, not a promise: instantiations without the layer regularisers still write the zeros. */
     int32_t grad_flags;
+    /* add_uv_noise of the reference (MPV.py:420-423, MPI.py:519-522; config_parser.py:48; off in every shipped configuration): while training,
+     * every sample's UV is jittered by hpix * (2 rand - 1), hpix = 1 / (atlas size - 1) in normalised coordinates = HALF A TEXEL, one draw
+     * per (pixel, layer), shared by all frames.  0 = off.  Non-zero: the seed of this call's jitter field -- (jx, jy) uniform in
+     * [-0.5, 0.5) texels from a counter hash of (seed, plane, frame pixel): a pure function, so forward, backward and any tiling see the
+     * same field (the oracle restates it: oracle/mpi_oracle.uv_jitter_field).  Coverage (hard cut, quad culling) is decided at the UNJITTERED
+     * position, as the rasteriser decides it in the reference; the taps move.  VL3D_COORD_AFFINE(_PLANES) with VL3D_BORDER_HARDCUT only; the backward takes the atomics
+     * kernel (a jittered tap can leave the owner-computes kernels' 1-pixel halo); vl3d_render_bwd_adam / _fwd_packed refuse it. */
+    uint32_t uv_noise_seed;
 } vl3d_render_desc;
 enum { VL3D_GRAD_CULLED_UNWRITTEN = 1 };
 

@@ -40,7 +40,7 @@ def test_no_gpu_calls_needed_for_metadata(built):
 
 def test_struct_layout_matches_header(built):
     # 25 x 4-byte fields / (10 x 4 + pad + 6 x 8 + 4 + pad): catches accidental drift between vl3d.h and ctypes
-    assert ctypes.sizeof(built.RenderDesc) == 100
+    assert ctypes.sizeof(built.RenderDesc) == 104
     assert ctypes.sizeof(built.LossDesc) == 96
 
 

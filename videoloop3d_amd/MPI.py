@@ -75,10 +75,11 @@ class MPMesh(nn.Module):
         self.H, self.W = H, W
         if getattr(args, "rgb_mlp_type", "direct") != "direct":
             raise RuntimeError(f"rgbmlp_type = {args.rgb_mlp_type} not supported (shipped configs use 'direct', mpi_base.txt:28)")
-        if getattr(args, "add_uv_noise", False):
-            # (MPV.py:412-415 / MPI.py:508-512: a random sub-texel jitter of every sample's UV while training; off in every shipped
-            # configuration.  Not silently ignored: the fused kernels sample at the analytic position.)
-            raise RuntimeError("add_uv_noise is not implemented by the fused render (no shipped configuration sets it)")
+        if getattr(args, "add_uv_noise", False) and getattr(args, "learn_loop_mask", False):
+            # (MPI.py:519-522 jitters the colour samples, :568-572 samples the loop mask at the UNJITTERED position and composites it with the
+            # jittered samples' alphas: two sampling positions per layer, which the fused label channel / label pass do not have.  Off in every
+            # shipped configuration; not silently approximated.)
+            raise RuntimeError("add_uv_noise together with learn_loop_mask is not implemented by the fused render (no shipped configuration sets add_uv_noise)")
         ref_extrin, ref_intrin = np.asarray(ref_extrin), np.asarray(ref_intrin)
         assert ref_extrin.shape == (4, 4) and ref_intrin.shape == (3, 3)
         self.register_buffer("ref_extrin", torch.tensor(ref_extrin))
@@ -371,6 +372,10 @@ class MPMesh(nn.Module):
         for b in range(B):
             homos = self.plane_homographies(extrin[b:b + 1], intrin[b:b + 1])
             stack, mask, spec, cull_window, fused_adam, lean = self.stack, (self.stack_mask if self.learn_loop_mask else None), self.spec, None, None, False
+            if self.training and getattr(self.args, "add_uv_noise", False):      # MPI.py:519-522 (see MPMeshVid.render); one field per view
+                if need_layers or self.atlas_exact:
+                    raise RuntimeError("add_uv_noise: not available with the materialised-layer path / atlas_exact")
+                spec = dataclasses.replace(spec, uv_noise_seed=int(torch.randint(1, 2 ** 31 - 1, (1,))))
             if windowed:
                 from .optim import crop_window
                 Hs_, Ws_ = self.stack.shape[2:4]

@@ -181,10 +181,6 @@ class MPMeshVid(nn.Module):
             raise RuntimeError("fp16 is marked 'do NOT use' in the reference (config_parser.py:32-33); fp32 only")
         if getattr(args, "rgb_mlp_type", "direct") != "direct":
             raise RuntimeError(f"rgbmlp_type = {args.rgb_mlp_type} not supported (shipped configs use 'direct', mpv_base.txt:28)")
-        if getattr(args, "add_uv_noise", False):
-            # (MPV.py:412-415 / MPI.py:508-512: a random sub-texel jitter of every sample's UV while training; off in every shipped
-            # configuration.  Not silently ignored: the fused kernels sample at the analytic position.)
-            raise RuntimeError("add_uv_noise is not implemented by the fused render (no shipped configuration sets it)")
         ref_extrin, ref_intrin = np.asarray(ref_extrin), np.asarray(ref_intrin)
         assert ref_extrin.shape == (4, 4) and ref_intrin.shape == (3, 3)
         self.register_buffer("ref_extrin", torch.tensor(ref_extrin))
@@ -639,6 +635,13 @@ class MPMeshVid(nn.Module):
         homos = self.plane_homographies(extrin, intrin)
         smooth_sums = alpha_sums = None
         spec = self.spec
+        if self.training and getattr(self.args, "add_uv_noise", False):
+            # MPV.py:420-423: every sample's UV jittered by half a texel while training, one draw per (pixel, layer), shared by the frames.  The
+            # kernels draw the field from a counter hash of (seed, plane, frame pixel); the seed comes from torch's host generator (no device
+            # round trip; reproducible under torch.manual_seed).  Forward: the one-frame kernels; backward: the atomics kernel.
+            if need_layers or self.atlas_exact:
+                raise RuntimeError("add_uv_noise: not available with the materialised-layer path / atlas_exact")
+            spec = dataclasses.replace(spec, uv_noise_seed=int(torch.randint(1, 2 ** 31 - 1, (1,))))
         cull_window = None
         if self._window_opt is not None:
             if self.training and torch.is_grad_enabled() and all_frames:

@@ -27,7 +27,7 @@ class RenderDesc(C.Structure):
                 ("pixel_center", C.c_float), ("sx", C.c_float), ("sy", C.c_float), ("ox", C.c_float),
                 ("oy", C.c_float), ("variant", C.c_int32),
                 ("cull_row0", C.c_int32), ("cull_col0", C.c_int32), ("cull_Hs", C.c_int32), ("cull_Ws", C.c_int32),
-                ("grad_flags", C.c_int32)]
+                ("grad_flags", C.c_int32), ("uv_noise_seed", C.c_uint32)]
 
 
 class LossDesc(C.Structure):

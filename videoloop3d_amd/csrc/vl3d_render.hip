@@ -44,6 +44,8 @@ int check_desc(const vl3d_render_desc *d) {
                  "fp16 plane stacks are implemented for the shipped (sigmoid, sigmoid) activations only");
     // the packed fp16 tap load fetches texels x0 and x0+1 of a row with one 16-byte read (load_taps2): a row needs two texels
     VL3D_REQUIRE(d->stack_dtype == VL3D_F32 || d->Ws >= 2, "fp16 plane stacks need Ws >= 2");
+    VL3D_REQUIRE(d->uv_noise_seed == 0 || (d->border_mode == VL3D_BORDER_HARDCUT && d->coord_mode != VL3D_COORD_UTILS_MPI),
+                 "uv_noise_seed (add_uv_noise, MPV.py:420-423) belongs to the planar MPV / MPI convention: affine coordinates, VL3D_BORDER_HARDCUT");
     return VL3D_OK;
 }
 
@@ -52,6 +54,7 @@ RenderArgs make_args(const vl3d_render_desc *d) {
     a.D = d->D; a.T = d->T; a.Hs = d->Hs; a.Ws = d->Ws; a.H = d->H; a.W = d->W;
     a.row0 = d->row0; a.col0 = d->col0;
     a.pc = d->pixel_center; a.sx = d->sx; a.sy = d->sy; a.ox = d->ox; a.oy = d->oy;
+    a.uv_seed = d->uv_noise_seed;
     return a;
 }
 
@@ -201,6 +204,7 @@ extern "C" int vl3d_render_fwd_mask(const vl3d_render_desc *desc, const void *st
     rc = check_mask_desc(desc, "vl3d_render_fwd_mask");
     if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE(stack && mask && homos && rgb && alpha && label, "null pointer passed to vl3d_render_fwd_mask");
+    VL3D_REQUIRE(desc->uv_noise_seed == 0, "vl3d_render_fwd_mask: add_uv_noise jitters the colour samples only (MPI.py:519-522, 568-572): render the label in a pass of its own");
     VL3D_REQUIRE((sums == nullptr) == (reg_state == nullptr), "vl3d_render_fwd_mask: sums and reg_state come together (both NULL: no layer regularisers)");
     VL3D_REQUIRE(!sums || desc->D <= 128, "the layer regularisers support at most 128 planes (coverage masks)");
     VL3D_REQUIRE((int64_t)desc->Hs * desc->Ws * 16 < (1ll << 32), "frame too large for 32-bit byte offsets");
@@ -237,6 +241,7 @@ extern "C" int vl3d_render_bwd_mask(const vl3d_render_desc *desc, const void *st
     a.rgb = const_cast<float *>(rgb); a.alpha = const_cast<float *>(alpha);
     a.g_rgb = grad_rgb; a.g_alpha = grad_alpha; a.g_reg = grad_reg; a.g_asum = grad_alpha_sums; a.g_stack = grad_stack;
     a.mask = mask; a.g_label = grad_label; a.g_mask = grad_mask;
+    VL3D_REQUIRE(desc->uv_noise_seed == 0, "vl3d_render_bwd_mask: add_uv_noise jitters the colour samples only (MPI.py:519-522, 568-572): render the label in a pass of its own");
     const bool want_tile = (desc->variant & 0xf) != 1 && scratch != nullptr && scratch_bytes >= vl3d_render_bwd_scratch_bytes(desc);
     a.gather9 = (desc->variant & 0xf) == 4;
     if (want_tile) {
@@ -354,7 +359,9 @@ static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, cons
     // variant: 0 auto (tile kernel when its on-device plan says feasible, else atomics), 1 force atomics,
     //          3 tile kernel (16-row regions, one frame per thread), 4 = 3 without the 2x2 gather   (2, the 8-row regions of round 1,
     //          measured 18.9 vs 16.8 ms and is no longer built: it selects 3)
-    const bool want_tile = (desc->variant & 0xf) != 1 && scratch != nullptr && scratch_bytes >= vl3d_render_bwd_scratch_bytes(desc);
+    // (add_uv_noise: a jittered tap can leave the 1-pixel halo the owner-computes kernels stage -- the atomics kernel takes the call)
+    const bool want_tile = (desc->variant & 0xf) != 1 && scratch != nullptr && scratch_bytes >= vl3d_render_bwd_scratch_bytes(desc) &&
+                           desc->uv_noise_seed == 0;
     a.ablate = (desc->variant >> 4) & 0xf;
     a.gather9 = (desc->variant & 0xf) == 4;
     if (want_tile) {
@@ -388,6 +395,10 @@ extern "C" int vl3d_render_bwd_adam(const vl3d_render_desc *desc, const void *st
     int rc = check_desc(desc);
     if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE(adam != nullptr, "vl3d_render_bwd_adam: null adam window");
+    if (desc->uv_noise_seed) {
+        vl3d_set_error("vl3d_render_bwd_adam: add_uv_noise takes the atomics backward (vl3d_render_bwd(_culled) + vl3d_adam_window_step)");
+        return VL3D_EUNSUPPORTED;
+    }
     VL3D_REQUIRE(stack && homos && rgb && alpha && grad_rgb && grad_stack && scratch, "null pointer passed to vl3d_render_bwd_adam");
     VL3D_REQUIRE(!grad_reg || reg_state, "vl3d_render_bwd_adam: grad_reg needs the reg_state the forward with regularisers filled");
     const uint8_t *qk = adam->quad_keep;

@@ -84,6 +84,7 @@ struct RenderArgs {
     float *label;            // (T,H,W)
     const float *g_label;    // (T,H,W)
     float *g_mask;           // (D,T,Hs,Ws), overwritten
+    unsigned uv_seed;            // desc->uv_noise_seed: the jitter field of add_uv_noise (0: off); forward kernels and the atomics backward
     int grad_culled_unwritten;   // desc->grad_flags bit 0: texels owned on a plane the workgroup skips (all of them culled) are not zero-filled
     // the optimiser step fused into the owner store (vl3d_render_bwd_adam; ad.p == NULL otherwise): `stack` is the optimiser's compact window copy
     vl3d_adam_epilogue ad;
@@ -198,16 +199,37 @@ struct TapsI {
 // at constant steps from ONE offset, and each weight is the tent max(0, 1-|t - tap|): for the sample's two neighbours that is
 // (1-f, f); for a tap that is not a neighbour (sample within one texel outside the plane, or t == S-1) it is 0, which is
 // exactly grid_sample's zeros padding (utils_mpi.py:159-176) -- no per-tap validity selects, no per-tap address clamps.
+// add_uv_noise (MPV.py:420-423, MPI.py:519-522): the jitter of one sample, uniform in [-0.5, 0.5) texels per axis, a counter hash of
+// (seed, plane, frame pixel) -- restated by oracle/mpi_oracle.uv_jitter_field.  `d` < 0 or seed == 0: no jitter.
+struct UvNoise { unsigned seed; int d; };
+__device__ __forceinline__ f2 uv_jitter(UvNoise nz, float px, float py) {
+    const unsigned ix = (unsigned)(int)floorf(px), iy = (unsigned)(int)floorf(py);      // the frame pixel (pixel centres are 0 or 0.5)
+    unsigned hh = nz.seed ^ (ix * 0x9E3779B1u) ^ (iy * 0x85EBCA77u) ^ ((unsigned)nz.d * 0xC2B2AE3Du);
+    hh ^= hh >> 15; hh *= 0x2C1B3C6Du; hh ^= hh >> 12; hh *= 0x297A2D39u; hh ^= hh >> 15;
+    return f2{((float)(hh & 0xffffu) + 0.5f) * (1.0f / 65536.0f) - 0.5f, ((float)(hh >> 16) + 0.5f) * (1.0f / 65536.0f) - 0.5f};
+}
+
 template <int COORD, int BORDER>
 __device__ __forceinline__ TapsI make_taps_i(const float *__restrict__ h, float px, float py, int Hs, int Ws,
-                                             float sx, float sy, float ox, float oy, QuadCull qc = QuadCull{nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f}) {
+                                             float sx, float sy, float ox, float oy, QuadCull qc = QuadCull{nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f},
+                                             UvNoise nz = UvNoise{0u, 0}) {
     TapsI t;
     const f2 px2 = f2{px, px}, py2 = f2{py, py};
     const f2 XY = __builtin_elementwise_fma(f2{h[0], h[3]}, px2, __builtin_elementwise_fma(f2{h[1], h[4]}, py2, f2{h[2], h[5]}));
     const float Z = fmaf(h[6], px, fmaf(h[7], py, h[8]));
     const f2 pxy = fast_div2(XY, Z);
-    const float tx = texel_coord<COORD>(pxy.x, (float)Ws / 2.0f, (float)(Ws - 1), sx, ox);
-    const float ty = texel_coord<COORD>(pxy.y, (float)Hs / 2.0f, (float)(Hs - 1), sy, oy);
+    const float tx0 = texel_coord<COORD>(pxy.x, (float)Ws / 2.0f, (float)(Ws - 1), sx, ox);
+    const float ty0 = texel_coord<COORD>(pxy.y, (float)Hs / 2.0f, (float)(Hs - 1), sy, oy);
+    float tx = tx0, ty = ty0;
+    // (the affine conventions only -- MPV.py / MPI.py's planar path is where the reference has the flag, and the entry points refuse it
+    // elsewhere: in the utils_mpi instantiations a possibly-jittered tx would also stop hipcc from contracting the last multiply of the
+    // coordinate into `tx - x0`, one ulp away from the kernels that do not carry the branch)
+    if constexpr (COORD != VL3D_COORD_UTILS_MPI) {
+        if (nz.seed) {      // uniform branch: the taps move, the coverage tests below keep the unjittered position (the rasteriser's, in the reference)
+            const f2 j = uv_jitter(nz, px, py);
+            tx += j.x; ty += j.y;
+        }
+    }
     t.tx = tx; t.ty = ty;
     const float x0f = __builtin_amdgcn_fmed3f(floorf(tx), 0.0f, (float)max(Ws - 2, 0));
     const float y0f = __builtin_amdgcn_fmed3f(floorf(ty), 0.0f, (float)max(Hs - 2, 0));
@@ -218,16 +240,16 @@ __device__ __forceinline__ TapsI make_taps_i(const float *__restrict__ h, float 
     const float wy0 = tent_weight(dy), wy1 = tent_weight(dy - (Hs > 1 ? 1.0f : 3e38f));
     t.w = f4{wx0, wx1, wx0, wx1} * f4{wy0, wy0, wy1, wy1};
     if constexpr (BORDER == VL3D_BORDER_HARDCUT && VL3D_HN == 13) {   // per-plane quad extent (atlas cells: the box is not the texel range)
-        const bool cov = (tx >= h[9]) && (tx <= h[10]) && (ty >= h[11]) && (ty <= h[12]);
+        const bool cov = (tx0 >= h[9]) && (tx0 <= h[10]) && (ty0 >= h[11]) && (ty0 <= h[12]);
         t.cov = cov ? 1.0f : 0.0f;
     } else if constexpr (BORDER == VL3D_BORDER_HARDCUT) {   // MPV.py:374-453: the plane quad ends at the outermost texel centres
-        const bool cov = (tx >= 0.0f) && (tx <= (float)(Ws - 1)) && (ty >= 0.0f) && (ty <= (float)(Hs - 1));
+        const bool cov = (tx0 >= 0.0f) && (tx0 <= (float)(Ws - 1)) && (ty0 >= 0.0f) && (ty0 <= (float)(Hs - 1));
         t.cov = cov ? 1.0f : 0.0f;
     } else {                                         // zeros padding: covered while any tap is inside, i.e. any weight > 0
         t.cov = ((t.w[0] + t.w[1]) + (t.w[2] + t.w[3]) > 0.0f) ? 1.0f : 0.0f;
     }
     if (qc.keep) {      // uniform branch
-        const int qx = min(max((int)floorf((tx + qc.x0) * qc.inv_cw), 0), qc.QW - 1), qy = min(max((int)floorf((ty + qc.y0) * qc.inv_ch), 0), qc.QH - 1);
+        const int qx = min(max((int)floorf((tx0 + qc.x0) * qc.inv_cw), 0), qc.QW - 1), qy = min(max((int)floorf((ty0 + qc.y0) * qc.inv_ch), 0), qc.QH - 1);
         if (!qc.keep[qy * qc.QW + qx]) t.cov = 0.0f;
     }
     return t;
@@ -235,8 +257,9 @@ __device__ __forceinline__ TapsI make_taps_i(const float *__restrict__ h, float 
 
 template <int COORD, int BORDER>
 __device__ __forceinline__ Taps2 make_taps2(const float *__restrict__ h, float px, float py, int Hs, int Ws,
-                                            float sx, float sy, float ox, float oy, QuadCull qc = QuadCull{nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f}) {
-    const TapsI ti = make_taps_i<COORD, BORDER>(h, px, py, Hs, Ws, sx, sy, ox, oy, qc);
+                                            float sx, float sy, float ox, float oy, QuadCull qc = QuadCull{nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f},
+                                            UvNoise nz = UvNoise{0u, 0}) {
+    const TapsI ti = make_taps_i<COORD, BORDER>(h, px, py, Hs, Ws, sx, sy, ox, oy, qc, nz);
     Taps2 t;
     t.w = ti.w;
     t.cov = ti.cov; t.tx = ti.tx; t.ty = ti.ty;
@@ -489,7 +512,7 @@ __device__ __forceinline__ f4 reg_sample(const RenderArgs &a, const float *hs, f
     float h[VL3D_HN];
 #pragma unroll
     for (int i = 0; i < VL3D_HN; ++i) h[i] = hs[VL3D_HS * d + i];
-    const Taps2 tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
+    const Taps2 tp = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d), UvNoise{a.uv_seed, d});
     const char *plane = reinterpret_cast<const char *>(a.stack) + ((size_t)d * a.T + t) * ((size_t)a.Hs * a.Ws * (F16 ? 8 : 16));
     typename TapVal<F16, ORDER>::type tv[4];
     load_taps2<F16>(plane, tp, make_tap_step<F16>(a.Hs, a.Ws), tv);
@@ -665,7 +688,7 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void render_bwd_k(RenderArgs a) {
     const float gL = MASK ? a.g_label[pix] : 0.0f;
     const size_t mframe = (size_t)a.Hs * a.Ws;
     for (int d = 0; d < a.D; ++d, plane += (size_t)a.T * a.Hs * a.Ws * TEXB, gplane += (size_t)a.T * a.Hs * a.Ws * TEXB) {
-        const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + VL3D_HS * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
+        const Taps2 tp = make_taps2<COORD, BORDER>(a.homos + VL3D_HS * d, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d), UvNoise{a.uv_seed, d});
         if (tp.cov == 0.0f) continue;
         typename TapVal<F16, ORDER>::type tv[4];
         f4 pre;
@@ -792,7 +815,7 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
         auto fetch = [&](int d, Taps2 &t, tapv_t *v) {
             float h[VL3D_HN];
             load_uniform(a.homos + VL3D_HS * d, h);
-            t = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d));
+            t = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, plane_cull(a, d), UvNoise{a.uv_seed, d});
             load_taps2<F16>(plane + (size_t)d * plane_stride_b, t, st, v);
             asm volatile("" ::: "memory");
         };
@@ -814,7 +837,8 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
         }
     } else {
     // two register sets (A/B) so the taps of plane d+1 are in flight while plane d is shaded, without register copies
-    Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy), tB = tA;
+    const QuadCull noq = QuadCull{nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f};
+    Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, noq, UvNoise{a.uv_seed, 0}), tB = tA;
     load_taps2<F16>(plane, tA, st, vA);
     if constexpr (MASK) load_mask_taps(mplane, tA.off, st, mA);
     // The prefetch of the next plane is unconditional (past the end it re-reads the last plane): with a branch around the
@@ -824,7 +848,7 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
             const int dn = min(d + 1, a.D - 1);
             float h[VL3D_HN];
             load_uniform(a.homos + VL3D_HS * dn, h);
-            tB = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            tB = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, noq, UvNoise{a.uv_seed, dn});
             load_taps2<F16>(plane + (size_t)dn * plane_stride_b, tB, st, vB);
             if constexpr (MASK) load_mask_taps(mplane + (size_t)dn * mplane_stride, tB.off, st, mB);
             asm volatile("" ::: "memory");   // keep the loads here: hipcc otherwise sinks them below the composite
@@ -835,7 +859,7 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
             const int dn = min(d + 2, a.D - 1);
             float h[VL3D_HN];
             load_uniform(a.homos + VL3D_HS * dn, h);
-            tA = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);
+            tA = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, noq, UvNoise{a.uv_seed, dn});
             load_taps2<F16>(plane + (size_t)dn * plane_stride_b, tA, st, vA);
             if constexpr (MASK) load_mask_taps(mplane + (size_t)dn * mplane_stride, tA.off, st, mA);
             asm volatile("" ::: "memory");
@@ -1950,7 +1974,8 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
             sgq += sg_plane;                                                                              \
         }                                                                                                 \
     }
-    Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy), tB = tA;
+    const QuadCull noq = QuadCull{nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f};
+    Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, noq, UvNoise{a.uv_seed, 0}), tB = tA;
     load_taps2<F16>(plane, tA, st, vA);
     if constexpr (MASK) load_mask_taps(mplane, tA.off, st, mA);
 #define VL3D_FETCH(T_, V_, DN_, M_)                                                                       \
@@ -1958,7 +1983,7 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
         const int dn = min(DN_, a.D - 1);                                                                 \
         float h[VL3D_HN];                                                                                 \
         load_uniform(a.homos + VL3D_HS * dn, h);                                                          \
-        T_ = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy);                    \
+        T_ = make_taps2<COORD, BORDER>(h, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, noq, UvNoise{a.uv_seed, dn});  \
         load_taps2<F16>(plane + (size_t)dn * plane_stride_b, T_, st, V_);                                 \
         if constexpr (MASK) load_mask_taps(mplane + (size_t)dn * mplane_stride, T_.off, st, M_);          \
         asm volatile("" ::: "memory");                                                                    \
@@ -2159,7 +2184,8 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
             }
         }
         if constexpr (RACT == VL3D_ACT_SIGMOID && AACT == VL3D_ACT_SIGMOID) {
-            if (a.T >= 2 && a.fwd_variant != 6) return launch_fwd2x<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);      // (tile-culled models too)
+            // (tile-culled models too; add_uv_noise: the jitter lives in the one-frame kernel)
+            if (a.T >= 2 && a.fwd_variant != 6 && !a.uv_seed) return launch_fwd2x<COORD, BORDER, ORDER, RACT, AACT, F16>(a, s);
         }
         launch_fwd2<COORD, BORDER, ORDER, RACT, AACT, 8, true, F16>(a, s);
     }

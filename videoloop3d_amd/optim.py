@@ -255,7 +255,8 @@ class WindowAdam(torch.optim.Optimizer):
         pend = self.pending
         return (self.fused_backward and isinstance(pend, tuple) and len(pend) == 3 and self._is_leaf(pend, stack) and stack.dtype == torch.float32
                 and (stack.shape[1] >= 2 or self.quad_keep is not None) and spec.coord_mode == "affine" and spec.border == "hardcut" and spec.act_order == "post"
-                and spec.rgb_act == "sigmoid" and spec.alpha_act == "sigmoid" and (int(spec.variant) & 0xf) in ((0, 3, 5) if self.quad_keep is not None else (0,)))
+                and spec.rgb_act == "sigmoid" and spec.alpha_act == "sigmoid" and (int(spec.variant) & 0xf) in ((0, 3, 5) if self.quad_keep is not None else (0,))
+                and not getattr(spec, "uv_noise_seed", 0))      # (add_uv_noise: the atomics backward + the step kernel)
 
     @staticmethod
     def _is_leaf(pend, stack):

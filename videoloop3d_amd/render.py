@@ -26,6 +26,7 @@ class RenderSpec:
     rgb_act: str = "sigmoid"
     alpha_act: str = "sigmoid"
     variant: int = 0
+    uv_noise_seed: int = 0      # add_uv_noise (MPV.py:420-423, MPI.py:519-522; include/vl3d.h): 0 = off, else the seed of this call's half-texel jitter field
 
     @staticmethod
     def mpv(rgb_act="sigmoid", alpha_act="sigmoid", scale=(1.0, 1.0), offset=(0.0, 0.0), variant=0):
@@ -48,6 +49,7 @@ def _desc(stack, H, W, spec, row0, col0, cull_window=None, grad_flags=0):
     d.sx, d.sy = float(spec.scale[0]), float(spec.scale[1])
     d.ox, d.oy = float(spec.offset[0]), float(spec.offset[1])
     d.variant = int(spec.variant)
+    d.uv_noise_seed = int(getattr(spec, "uv_noise_seed", 0)) & 0xFFFFFFFF
     if cull_window is not None:        # the stack is the texel window (y0, x0) of a (Hs_plane, Ws_plane) plane the quad grid lies over
         d.cull_row0, d.cull_col0, d.cull_Hs, d.cull_Ws = (int(v) for v in cull_window)
     d.grad_flags = int(grad_flags)
