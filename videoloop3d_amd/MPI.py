@@ -492,9 +492,9 @@ class MPMesh(nn.Module):
                         cache[key] = torch.tensor([denorm / (3 * nx), denorm / (3 * ny), denorm / nx, denorm / ny], dtype=torch.float32, device=sums.device)
                     terms = _SmoothTerms.apply(sums, cache[key])
                     if a.rgb_smooth_loss_weight > 0:                                             # MPI.py:605-611
-                        extra["rgb_smooth"] = terms[0:1].view(1, 1)
+                        extra["rgb_smooth"] = terms[0].view(1, 1)
                     if a.a_smooth_loss_weight > 0:                                               # MPI.py:613-619
-                        extra["a_smooth"] = terms[1:2].view(1, 1)
+                        extra["a_smooth"] = terms[1].view(1, 1)
                 else:
                     if a.rgb_smooth_loss_weight > 0:                                             # MPI.py:605-611
                         extra["rgb_smooth"] = ((sums[0] / (3 * nx) + sums[1] / (3 * ny)) * denorm).reshape(1, -1)

@@ -118,12 +118,13 @@ class _PixelTerms(torch.autograd.Function):
         with torch.cuda.device(dev):
             L.check(L.lib().vl3d_pixel_terms(n, L.ptr(a), L.ptr(s), float(eps), L.ptr(sums), L.ptr(gs), L.ptr(ga), L.stream_ptr(dev)), "vl3d_pixel_terms")
         ctx.ga, ctx.gs, ctx.n = ga, gs, n
-        return (sums / n).to(torch.float32)
+        # TWO outputs (0-d views of one tensor), not one tensor the caller slices: a slice's backward is a zero fill, a copy and an add per term
+        return tuple((sums / n).to(torch.float32).unbind(0))
 
     @staticmethod
-    def backward(ctx, g):
-        ga = None if ctx.ga is None else ctx.ga * (g[1] / ctx.n)
-        gs = None if ctx.gs is None else ctx.gs * (g[0] / ctx.n)
+    def backward(ctx, g_sparsity, g_density):
+        ga = None if (ctx.ga is None or g_density is None) else ctx.ga * (g_density / ctx.n)
+        gs = None if (ctx.gs is None or g_sparsity is None) else ctx.gs * (g_sparsity / ctx.n)
         return ga, gs, None
 
 
@@ -134,12 +135,14 @@ class _SmoothTerms(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sums, coef):
         ctx.save_for_backward(coef)
-        return (sums * coef).view(2, 2).sum(1)
+        return tuple((sums * coef).view(2, 2).sum(1).unbind(0))      # (rgb_smooth, a_smooth): two outputs, see _PixelTerms
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g_rgb, g_a):
         (coef,) = ctx.saved_tensors
-        return g.repeat_interleave(2) * coef, None
+        z = coef.new_zeros(())
+        g = torch.stack([z if g_rgb is None else g_rgb.reshape(()), z if g_a is None else g_a.reshape(())])
+        return (coef.view(2, 2) * g[:, None]).reshape(4), None
 
 
 def atlas_to_stack(atlas_dyn, mpi_d, grid_h):
@@ -804,9 +807,9 @@ class MPMeshVid(nn.Module):
                     cache[key] = torch.tensor([gd / (3 * nx), gd / (3 * ny), gd / nx, gd / ny], dtype=torch.float32, device=sums.device)
                 terms = _SmoothTerms.apply(sums, cache[key])
                 if a.rgb_smooth_loss_weight > 0:
-                    extra["rgb_smooth"] = terms[0:1].view(1, 1)
+                    extra["rgb_smooth"] = terms[0].view(1, 1)
                 if a.a_smooth_loss_weight > 0:
-                    extra["a_smooth"] = terms[1:2].view(1, 1)
+                    extra["a_smooth"] = terms[1].view(1, 1)
             else:
                 if a.rgb_smooth_loss_weight > 0:
                     extra["rgb_smooth"] = ((sums[0] / (3 * nx) + sums[1] / (3 * ny)) * (loss_gain * denorm)).reshape(1, -1)
