@@ -60,11 +60,17 @@ def once(v):
         (gs,) = torch.autograd.grad(rgb, stack, g)
     e2.record()
     torch.cuda.synchronize()
+    once.last = gs
     return e0.elapsed_time(e1), e1.elapsed_time(e2)
 
 
+g_first = None
 for v in variants:
     once(v)
+    if g_first is None:
+        g_first = once.last.clone() if T <= 4 else None       # (bit comparison of the gradients: small shapes only -- a second 23.6 GB buffer otherwise)
+    elif T <= 4:
+        print(f"variant {v:#x}: gradient bits equal to variant {variants[0]:#x}: {torch.equal(g_first, once.last)}")
 for r in range(a.rounds):
     for v in variants:
         for _ in range(a.reps):

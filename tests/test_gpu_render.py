@@ -256,13 +256,14 @@ def _tile_ran():
     return int(render.LAST_BWD_SCRATCH.view(torch.int32)[0].item())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("spec_name", ["mpv", "utils_mpi", "hardcut_pre"])
 @pytest.mark.parametrize("shape", [(6, 2, 150, 200, 139, 187), (4, 1, 70, 300, 64, 280), (3, 1, 40, 40, 37, 35), (5, 3, 96, 130, 96, 130)])
 def test_bwd_variants_agree_with_oracle(dev, variant, spec_name, shape):
     """variant 0 = default dispatch (frame-pair kernels where they apply: the last shape is a 1.0x stack with T = 3, i.e. the
-    pair kernel DIRECTLY against the oracle, incl. the odd tail frame), 1 = global atomics, 3 = LDS-staged owner-computes tile
-    kernel; near-unit-scale geometry with rotation + perspective so the owner-computes plan is feasible, odd sizes so tiles
+    pair kernel DIRECTLY against the oracle, incl. the odd tail frame; the T = 1 shapes take the flat 64 x 8 regions under "mpv"),
+    1 = global atomics, 2 = the tile kernel in flat 64 x 8 regions at any T, 3 = LDS-staged owner-computes tile
+    kernel in 64 x 16 regions; near-unit-scale geometry with rotation + perspective so the owner-computes plan is feasible, odd sizes so tiles
     are ragged."""
     from videoloop3d_amd.render import RenderSpec, render_planes
     D, T, Hs, Ws, H, W = shape
@@ -314,7 +315,7 @@ def test_bwd_tile_720p_matches_atomics(dev):
     from videoloop3d_amd import _lib as L
     from videoloop3d_amd.render import _desc
     rgb, alpha = render_planes(stack.detach(), homos, H, W, RenderSpec.mpv())
-    for variant in (1, 0, 3):
+    for variant in (1, 0, 3, 2):
         # raw ABI with the gradient buffer pre-filled with NaN: a texel no kernel writes stays NaN (deterministic, unlike hoping
         # that the caching allocator hands out a poisoned block)
         d = _desc(stack, H, W, RenderSpec.mpv(variant=variant), 0, 0)
@@ -329,6 +330,8 @@ def test_bwd_tile_720p_matches_atomics(dev):
     scale = float(out[1].abs().max())
     # frame pairs (default dispatch) and the one-frame tile kernel: the same bits
     assert torch.equal(out[0], out[3])
+    # ... and the flat 64 x 8 regions (the default of a single frame)
+    assert torch.equal(out[2], out[3])
     # vs the atomics kernel: same coordinates bit for bit (explicit FMAs in make_taps2), so only the summation order differs
     assert maxabs(out[3], out[1]) <= 2e-6 * max(1.0, scale)
 

@@ -357,8 +357,9 @@ static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, cons
     a.g_f16 = desc->stack_dtype == VL3D_F16;
     a.grad_culled_unwritten = (quad_keep && (desc->grad_flags & VL3D_GRAD_CULLED_UNWRITTEN)) ? 1 : 0;
     // variant: 0 auto (tile kernel when its on-device plan says feasible, else atomics), 1 force atomics,
-    //          3 tile kernel (16-row regions, one frame per thread), 4 = 3 without the 2x2 gather   (2, the 8-row regions of round 1,
-    //          measured 18.9 vs 16.8 ms and is no longer built: it selects 3)
+    //          3 tile kernel (16-row regions, one frame per thread), 4 = 3 without the 2x2 gather, 2 = the tile kernel in flat 64 x 8
+    //          regions (round 1 measured them 18.9 vs 16.8 ms at cfg3 and dropped them; round 5 brought them back for ONE frame, T = 1,
+    //          where 2520 half-size workgroups on 1024 slots beat 1092 on 512: 0.380 vs 0.394 ms, same bits -- the default there)
     // (add_uv_noise: a jittered tap can leave the 1-pixel halo the owner-computes kernels stage -- the atomics kernel takes the call)
     const bool want_tile = (desc->variant & 0xf) != 1 && scratch != nullptr && scratch_bytes >= vl3d_render_bwd_scratch_bytes(desc) &&
                            desc->uv_noise_seed == 0;
@@ -368,7 +369,7 @@ static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, cons
         a.plan = (const float *)scratch;
         a.owner = reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(scratch) + owner_table_off(desc));
         const int bv = desc->variant & 0xf;
-        a.tile_rows = bv == 0 ? 17 : (bv == 5 ? 18 : 16);     // 17: 16 rows, frame-pair kernels allowed; 18: 32-wide one-frame regions
+        a.tile_rows = bv == 0 ? 17 : (bv == 5 ? 18 : (bv == 2 ? 8 : 16));     // 17: 16 rows, frame-pair kernels / flat one-frame regions allowed; 18: 32-wide one-frame regions; 8: flat 64 x 8 one-frame regions
     } else {
         a.plan = nullptr;
         a.tile_rows = 0;

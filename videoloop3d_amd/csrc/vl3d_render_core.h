@@ -2127,6 +2127,16 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
                     done = true;
                 }
             }
+            // flat 64 x 8 one-frame regions (512 threads, four workgroups per CU at the plain kernel's 64 registers) for a SINGLE frame (cfg2, the
+            // stage-1 shape): 2520 workgroups on 1024 slots instead of 1092 on 512 -- the x1.33 halo costs less than the 2.13-round tail of the
+            // 16-row regions: backward 0.380 against 0.394 ms at 720p, D = 32, same bits (profiles/r05d_cfg2_rows.txt; 10 rows 0.442, 12 rows
+            // 0.393: measured, not instantiated).  Variant 2 forces them at any T, variant 3 keeps the 16 rows.
+            if constexpr (MASKABLE && VL3D_HS == 9) {
+                if (!done && !a.g_reg && !a.g_asum && !a.quad_keep && (a.tile_rows == 8 || (a.tile_rows == 17 && a.T == 1))) {
+                    launch_tile<COORD, BORDER, ORDER, RACT, AACT, 8, false, false>(a, s);
+                    done = true;
+                }
+            }
             if (!done) {
                 // layer regularisers and / or sparsity sums: the REG instantiation (128-VGPR budget); a tile-culled call whose consumer never
                 // reads culled texels takes it too -- it is the one that SKIPS the planes a tile cannot see instead of zero-filling them
