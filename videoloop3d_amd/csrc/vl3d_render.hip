@@ -126,10 +126,10 @@ extern "C" int vl3d_render_fwd_culled(const vl3d_render_desc *desc, const void *
 // uses (60 x 6) | (256-byte aligned) owner table, one uint16 per (plane, texel)
 static int64_t owner_table_off(const vl3d_render_desc *desc) {
     // window records: the largest tile count of any backward kernel (owned pixels per tile: 62 x 14 / 60 x 12 for the one-frame tile
-    // kernel without / with regularisers, 30 x 14 / 28 x 12 for the frame pairs)
+    // kernel without / with regularisers, 30 x 14 / 28 x 12 for the frame pairs, 62 x 6 for the flat one-frame regions of a single frame)
     auto ntiles = [&](int iw, int ih) { return (int64_t)((desc->W + iw - 1) / iw) * ((desc->H + ih - 1) / ih); };
     int64_t tiles = ntiles(62, 14);
-    for (const auto &t : {ntiles(60, 12), ntiles(30, 14), ntiles(28, 12)}) tiles = t > tiles ? t : tiles;
+    for (const auto &t : {ntiles(60, 12), ntiles(30, 14), ntiles(28, 12), ntiles(62, 6)}) tiles = t > tiles ? t : tiles;
     const int64_t b = (int64_t)plan_win_off(desc->D) * sizeof(float) + tiles * desc->D * 16;
     return (b + 255) & ~(int64_t)255;
 }
