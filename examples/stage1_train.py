@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 
-def run(views=8, epochs=14, planes=32, dev="cuda:0"):
+def run(views=8, epochs=14, planes=32, dev="cuda:0", generic_objective=False, crop_aware_adam="auto"):
     from videoloop3d_amd.MPI import MPMesh
     from videoloop3d_amd import train_3d as drv
     from stage2_schedule import make_views
@@ -31,7 +31,8 @@ def run(views=8, epochs=14, planes=32, dev="cuda:0"):
         sparsity_loss_weight=0.004, rgb_smooth_loss_weight=0.2, a_smooth_loss_weight=0.5, density_loss_weight=0.02, d_smooth_loss_weight=0.0,
         l_smooth_loss_weight=0.0, optimizer="adam", lrate=0.05, lrate_decay=100, add_intrin_noise=True,
         N_iters=epochs, sparsify_epoch=sparsify_epoch, sparsify_erode=2, sparsify_alpha_thresh=0.05, density_loss_epoch=max(1, epochs * 60 // 140),
-        patch_h_size=180, patch_w_size=320, patch_h_stride=90, patch_w_stride=160, vid2img_mode="dynamic", i_weights=10 ** 9)
+        patch_h_size=180, patch_w_size=320, patch_h_stride=90, patch_w_stride=160, vid2img_mode="dynamic", i_weights=10 ** 9,
+        crop_aware_adam=crop_aware_adam, generic_objective=bool(generic_objective))      # True: the reference's spelling of the loss head (A/B against MPMesh.objective)
     poses, intrins, vids = make_views(views, H, W, 16, dev)
     K = intrins[0].numpy().astype(np.float64)
     with warnings.catch_warnings():      # untimed warm-up on a throw-away model: code objects, allocator, first-call set-up of every kernel
@@ -79,7 +80,9 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--epochs", type=int, default=14)
     ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--crop-aware-adam", default="auto", choices=["auto", "on", "off"], help="optim.Stage1Adam (the crop's texel window) / one pass over the whole stack / by size")
+    ap.add_argument("--generic-objective", action="store_true", help="forward + image_and_loop_loss + weighted_total instead of MPMesh.objective")
     a = ap.parse_args()
     import __graft_entry__ as g
     g.build()
-    print(json.dumps(run(a.views, a.epochs)))
+    print(json.dumps(run(a.views, a.epochs, generic_objective=a.generic_objective, crop_aware_adam={'auto': 'auto', 'on': True, 'off': False}[a.crop_aware_adam])))

@@ -472,6 +472,27 @@ int vl3d_pixel_terms(int64_t n, const float *alpha, const float *alpha_sums, flo
 int vl3d_stage1_loss(int32_t B, int32_t C, int32_t h, int32_t w, const float *rgbl, int64_t sb, int64_t sc, int64_t sp, const float *target,
                      const float *target_mask, int32_t scale_invariant, double *log_sum, double *sums, float *grad, vl3d_stream_t stream);
 
+/* The whole scalar head of a stage-1 iteration (train_3d.py:200-232 on MPI.py:596-652's outputs) in one sweep over the crop's pixels:
+ *   img_loss, loop_loss as vl3d_stage1_loss; sparsity, density as vl3d_pixel_terms (sparsity times `sparsity_scale` = 1 / sqrt(mpi_d));
+ *   rgb_smooth = coef0 s0 + coef1 s1, a_smooth = coef2 s2 + coef3 s3 from the render's four smoothness sums (MPI.py:605-619);
+ *   total = w_img img + w_loop loop + w_sparsity sparsity + w_density density + w_rgb_smooth rgb_smooth + w_a_smooth a_smooth.
+ * Inputs are the render's own outputs: rgb (B,h,w,3), label (B,h,w) | NULL, alpha (B,h,w) | NULL, alpha_sums (B,h,w,2) | NULL,
+ * smooth_sums float[4] | NULL; target (B,3,h,w) and target_mask (B,h,w) | NULL (with label) through strides in floats (t_sb batch, t_sc channel,
+ * t_sr row; m_sb, m_sr; unit column stride: a crop of a larger image needs no copy).  Outputs: out float[8] = (total, img, loop,
+ * w sparsity, w density, w rgb_smooth, w a_smooth, gain) and the gradients of `total` w.r.t. every given input, FINAL for a unit upstream
+ * gradient (the caller scales them by the actual one: vl3d_scale_inplace skips the pass when it is 1).  scratch: 6 device doubles. */
+typedef struct vl3d_stage1_objective_desc {
+    int32_t B, h, w;
+    int32_t scale_invariant;
+    float w_img, w_loop, w_sparsity, w_density, w_rgb_smooth, w_a_smooth;
+    float sparsity_scale, eps;
+    float smooth_coef[4];
+} vl3d_stage1_objective_desc;
+int vl3d_stage1_objective(const vl3d_stage1_objective_desc *desc, const float *rgb, const float *label, const float *alpha, const float *alpha_sums,
+                          const float *smooth_sums, const float *target, int64_t t_sb, int64_t t_sc, int64_t t_sr, const float *target_mask,
+                          int64_t m_sb, int64_t m_sr, double *scratch, float *out, float *grad_rgb,
+                          float *grad_label, float *grad_alpha, float *grad_alpha_sums, float *grad_smooth, vl3d_stream_t stream);
+
 /* robust_lossfun (utils_vid.py:10-26) fused with the mean (utils_vid.py:348).
  * kind: 0 'mse', 1 'abs', 2 general Barron with float rou (rou==0 and rou==2 special-cased as the reference).
  * loss_sum: device double, overwritten with sum over n elements of rho(x - y2x). */

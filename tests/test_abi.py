@@ -42,6 +42,7 @@ def test_struct_layout_matches_header(built):
     # 25 x 4-byte fields / (10 x 4 + pad + 6 x 8 + 4 + pad): catches accidental drift between vl3d.h and ctypes
     assert ctypes.sizeof(built.RenderDesc) == 104
     assert ctypes.sizeof(built.LossDesc) == 96
+    assert ctypes.sizeof(built.Stage1ObjectiveDesc) == 64      # 4 x int32 + 12 x float
 
 
 def test_cpu_tensor_is_rejected_loudly(built):

@@ -341,7 +341,7 @@ class MPMesh(nn.Module):
             mask3d = LY.to_slots((lab * cov[None, :, None]).permute(0, 3, 4, 1, 2), cov)
         return mpi, bw, disp, mask3d
 
-    def render(self, H, W, extrin, intrin, need_reg=False, need_layers=False):
+    def render(self, H, W, extrin, intrin, need_reg=False, need_layers=False, cat_label=True):
         """MPI.py:452-594 -> (rgbl [B,H,W,3|4], variables).  One fused render per view (the kernels share one camera per call).
         need_layers: also materialise `mpi` / `blend_weight` / `disp_norm` / `loopmask3d` (slow path; no shipped configuration reads them)."""
         B = len(extrin)
@@ -434,8 +434,11 @@ class MPMesh(nn.Module):
                 labels.append(_LoopMaskLabel.apply(self.stack_mask, self.stack, self._mask_buf, homos, H, W, self.spec_mask))
         cat0 = lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts, 0)      # noqa: E731  (B = 1, the reference's DataLoader(dataset, 1): no copy, no launch)
         rgb = cat0(rgbs)
-        rgbl = torch.cat([rgb, cat0(labels)], dim=-1) if self.learn_loop_mask else rgb
+        # (cat_label = False, MPMesh.objective: the fused head reads colour and label where the render wrote them -- no concatenation, no split
+        # of its gradient on the way back)
+        rgbl = (torch.cat([rgb, cat0(labels)], dim=-1) if self.learn_loop_mask else rgb) if cat_label else None
         variables = {"pix_to_face": None, "blend_weight": None, "mpi": None, "loopmask3d": None, "disp_norm": None,
+                     "rgb": rgb, "label": cat0(labels) if self.learn_loop_mask else None,
                      "alpha": cat0(alphas),
                      "smooth_sums": (ssums[0] if len(ssums) == 1 else torch.stack(ssums).sum(0)) if ssums else None,
                      "alpha_sums": cat0(asums) if asums else None}
@@ -513,6 +516,113 @@ class MPMesh(nn.Module):
             if a.density_loss_weight > 0:                                                        # MPI.py:647-650
                 extra["density"] = (fused_terms[1] if fused_terms is not None else (variables["alpha"] - 1).abs().mean()).reshape(1, -1)
         return rgbl, extra
+
+
+    def objective(self, h, w, tar_extrins, tar_intrins, target, target_mask=None, scale_invariant=True):
+        """One stage-1 training objective, train_3d.py:196-232 on MPI.py:596-652: render the view, form img_loss (+ loop_loss) against `target`
+        [B,3,h,w] (`target_mask` [B,h,w]), the regularisers with a positive `args.<name>_loss_weight`, and their weighted total
+            -> (loss, img_loss, loop_loss, {name: weighted term})        loss differentiable, the parts detached
+        -- what `forward` + `image_and_loop_loss` + `train_3dvid.weighted_total` give (tests/test_gpu_stage1_driver.py compares the two),
+        but with the whole scalar head in three launches and one on the way back (vl3d_stage1_objective): a stage-1 iteration at the
+        reference's crop is ~0.45 ms of GPU work that the ~45 one-element torch launches of the generic spelling kept host bound at 0.74 ms.
+        Falls back to the generic spelling where the head is not built for the call (CPU, several views, materialised-layer terms)."""
+        a = self.args
+        wts = {k: float(getattr(a, f"{k}_loss_weight", 0) or 0) for k in ("sparsity", "rgb_smooth", "a_smooth", "density", "d_smooth", "l_smooth")}
+        slow = (not self.training or not self.stack.is_cuda or len(tar_extrins) != 1 or getattr(a, "unfused_terms", False)
+                or wts["d_smooth"] > 0 or (wts["l_smooth"] > 0 and self.learn_loop_mask) or self.atlas_exact
+                or (self.learn_loop_mask and target_mask is None))
+        if slow:
+            from .train_3dvid import weighted_total
+            rgbl, extra = self(h, w, tar_extrins, tar_intrins)
+            img_loss, loop_loss = image_and_loop_loss(rgbl, target, target_mask if self.learn_loop_mask else None, scale_invariant=scale_invariant)
+            mains = [img_loss] + ([loop_loss] if torch.is_tensor(loop_loss) else [])
+            loss, _, extra_losses = weighted_total(mains, extra, lambda k: wts.get(k, 0))
+            return loss, img_loss.detach(), (loop_loss.detach() if torch.is_tensor(loop_loss) else loop_loss), {k: v.detach() for k, v in extra_losses.items()}
+        tar_extrins, tar_intrins = torch.as_tensor(tar_extrins), torch.as_tensor(tar_intrins)
+        extrins = tar_extrins @ self._on(tar_extrins.device, "ref_extrin")[None, ...].inverse().to(tar_extrins.dtype)
+        if wts["sparsity"] > 0 and a.alpha_activate == "none":
+            raise RuntimeError("the fused sparsity term needs a non-negative alpha activation")
+        need_reg = wts["sparsity"] > 0 or wts["rgb_smooth"] > 0 or wts["a_smooth"] > 0
+        _, var = self.render(h, w, extrins, tar_intrins, need_reg=need_reg, cat_label=False)
+        B, K_ = 1, self.mpi_d
+        nx, ny = B * h * (w - 1) * K_, B * (h - 1) * w * K_
+        smooth_on = (wts["rgb_smooth"] > 0 or wts["a_smooth"] > 0) and min(nx, ny) > 0
+        coef = (1.0 / (3 * nx), 1.0 / (3 * ny), 1.0 / nx, 1.0 / ny) if smooth_on else (0.0,) * 4      # (denorm = K / mpi_d = 1, MPI.py:605-619)
+        cfg = (int(B), int(h), int(w), bool(scale_invariant), 1.0, 1.0, wts["sparsity"], wts["density"],
+               wts["rgb_smooth"] if smooth_on else 0.0, wts["a_smooth"] if smooth_on else 0.0, 1.0 / float(np.sqrt(self.mpi_d)), 1e-6) + coef
+        total, parts = _Stage1Objective.apply(var["rgb"], var["label"], var["alpha"] if wts["density"] > 0 else None,
+                                              var["alpha_sums"] if wts["sparsity"] > 0 else None, var["smooth_sums"] if smooth_on else None,
+                                              target, target_mask if self.learn_loop_mask else None, cfg)
+        extra = {}
+        if wts["sparsity"] > 0:
+            extra["sparsity"] = parts[3]
+        if wts["rgb_smooth"] > 0 and smooth_on:
+            extra["rgb_smooth"] = parts[5]
+        if wts["a_smooth"] > 0 and smooth_on:
+            extra["a_smooth"] = parts[6]
+        if wts["density"] > 0:
+            extra["density"] = parts[4]
+        return total, parts[1], (parts[2] if self.learn_loop_mask else 0), extra
+
+
+class _Stage1Objective(torch.autograd.Function):
+    """(rgb [B,h,w,3], label [B,h,w] | None, alpha [B,h,w] | None, alpha_sums [B,h,w,2] | None, smooth_sums [4] | None) -- the render's outputs
+    as it wrote them -- and the targets -> (total, parts [8]) through vl3d_stage1_objective; the gradients of the total w.r.t. every input
+    exist after the forward, the backward scales them by the upstream gradient in one launch (none when it is 1)."""
+
+    @staticmethod
+    def forward(ctx, rgb, label, alpha, asum, ssums, target, tmask, cfg):
+        from . import _lib as L
+        L.check_cuda(rgb, target)
+        B, h, w = cfg[0], cfg[1], cfg[2]
+        n = B * h * w
+        f32c = lambda t: None if t is None else (t.detach() if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().to(torch.float32).contiguous())  # noqa: E731
+        rgb_, label_, alpha_, asum_, ss_ = (f32c(t) for t in (rgb, label, alpha, asum, ssums))
+        # the targets go in through their strides (a crop of the view's image: no copy) as long as their columns are contiguous
+        strided = lambda t: None if t is None else (t.detach() if (t.dtype == torch.float32 and t.stride(-1) == 1) else t.detach().to(torch.float32).contiguous())  # noqa: E731
+        tgt_, tm_ = strided(target), strided(tmask)
+        if tuple(rgb_.shape) != (B, h, w, 3) or tuple(tgt_.shape) != (B, 3, h, w):
+            raise RuntimeError(f"stage-1 objective: rgb {tuple(rgb_.shape)} / target {tuple(tgt_.shape)} do not describe {B} view(s) of {h} x {w}")
+        if label_ is not None and tuple(label_.shape) == (B, h, w, 1):      # (MPMesh.render hands the label out with its channel axis)
+            label_ = label_.view(B, h, w)
+        for t_, shp in ((label_, (B, h, w)), (tm_, (B, h, w)), (alpha_, (B, h, w)), (asum_, (B, h, w, 2)), (ss_, (4,))):
+            if t_ is not None and tuple(t_.shape) != shp:
+                raise RuntimeError(f"stage-1 objective: an input of shape {tuple(t_.shape)} where {shp} is expected")
+        r4 = lambda v: (v + 3) & ~3  # noqa: E731
+        # one buffer: [6 doubles scratch | out 8] [g_rgb | g_label | g_alpha | g_asum | g_smooth], every part 16-byte aligned
+        o_out, o_rgb = 12, 20
+        o_label = o_rgb + r4(3 * n)
+        o_alpha = o_label + (r4(n) if label_ is not None else 0)
+        o_asum = o_alpha + (r4(n) if alpha_ is not None else 0)
+        o_ss = o_asum + (r4(2 * n) if asum_ is not None else 0)
+        end = o_ss + (4 if ss_ is not None else 0)
+        dev = rgb_.device
+        buf = torch.empty(end, dtype=torch.float32, device=dev)
+        base = buf.data_ptr()
+        at = lambda off, on=True: L.C.c_void_p(base + 4 * off) if on else None  # noqa: E731
+        d = L.Stage1ObjectiveDesc(B, h, w, 1 if cfg[3] else 0, *[float(v) for v in cfg[4:12]], (L.C.c_float * 4)(*[float(v) for v in cfg[12:16]]))
+        with torch.cuda.device(dev):
+            L.check(L.lib().vl3d_stage1_objective(L.C.byref(d), L.ptr(rgb_), L.ptr(label_), L.ptr(alpha_), L.ptr(asum_), L.ptr(ss_), L.ptr(tgt_), tgt_.stride(0), tgt_.stride(1), tgt_.stride(2),
+                                                  L.ptr(tm_), 0 if tm_ is None else tm_.stride(0), 0 if tm_ is None else tm_.stride(1), at(0), at(o_out), at(o_rgb), at(o_label, label_ is not None), at(o_alpha, alpha_ is not None),
+                                                  at(o_asum, asum_ is not None), at(o_ss, ss_ is not None), L.stream_ptr(dev)), "vl3d_stage1_objective")
+        ctx.label_shape = None if label is None else tuple(label.shape)
+        ctx.buf, ctx.layout = buf, (n, B, h, w, o_rgb, o_label if label_ is not None else -1, o_alpha if alpha_ is not None else -1,
+                                    o_asum if asum_ is not None else -1, o_ss if ss_ is not None else -1, end)
+        parts = buf[o_out:o_out + 8]
+        ctx.mark_non_differentiable(parts)
+        return buf[o_out], parts
+
+    @staticmethod
+    def backward(ctx, g_total, _g_parts):
+        from . import _lib as L
+        buf = ctx.buf
+        n, B, h, w, o_rgb, o_label, o_alpha, o_asum, o_ss, end = ctx.layout
+        g = g_total if (g_total.dtype == torch.float32 and g_total.is_contiguous()) else g_total.to(torch.float32).contiguous()
+        with torch.cuda.device(buf.device):
+            L.check(L.lib().vl3d_scale_inplace(end - o_rgb, L.C.c_void_p(buf.data_ptr() + 4 * o_rgb), L.ptr(g), L.stream_ptr(buf.device)), "vl3d_scale_inplace")
+        cut = lambda off, m, shape: None if off < 0 else buf[off:off + m].view(shape)  # noqa: E731
+        return (cut(o_rgb, 3 * n, (B, h, w, 3)), cut(o_label, n, ctx.label_shape), cut(o_alpha, n, (B, h, w)), cut(o_asum, 2 * n, (B, h, w, 2)),
+                cut(o_ss, 4, (4,)), None, None, None)
 
 
 class _Stage1Loss(torch.autograd.Function):

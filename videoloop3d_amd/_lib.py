@@ -52,6 +52,13 @@ class AdamWindow(C.Structure):
                 ("blocks", _P)]
 
 
+class Stage1ObjectiveDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("scale_invariant", C.c_int32),
+                ("w_img", C.c_float), ("w_loop", C.c_float), ("w_sparsity", C.c_float), ("w_density", C.c_float),
+                ("w_rgb_smooth", C.c_float), ("w_a_smooth", C.c_float), ("sparsity_scale", C.c_float), ("eps", C.c_float),
+                ("smooth_coef", C.c_float * 4)]
+
+
 # symbol -> argtypes; every symbol include/vl3d.h declares must be listed here (tests/test_abi.py checks).
 SIGNATURES = {
     "vl3d_last_error": ([], C.c_char_p),
@@ -108,6 +115,7 @@ SIGNATURES = {
     "vl3d_loop_pad_bwd": ([_I32] * 4 + [_P, _I64, _I64, _P, _P, _P], C.c_int),
     "vl3d_pixel_terms": ([_I64, _P, _P, _F, _P, _P, _P, _P], C.c_int),
     "vl3d_stage1_loss": ([_I32] * 4 + [_P, _I64, _I64, _I64, _P, _P, _I32, _P, _P, _P, _P], C.c_int),
+    "vl3d_stage1_objective": ([C.POINTER(Stage1ObjectiveDesc)] + [_P] * 6 + [_I64] * 3 + [_P, _I64, _I64] + [_P] * 8, C.c_int),
     "vl3d_robust_fwd": ([_I64, _P, _P, _I32, _F, _F, _P, _P], C.c_int),
     "vl3d_robust_bwd": ([_I64, _P, _P, _I32, _F, _F, _P, _F, _P, _P], C.c_int),
 }

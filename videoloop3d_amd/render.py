@@ -102,7 +102,8 @@ class _RenderPlanes(torch.autograd.Function):
         desc = _desc(stack, H, W, spec, row0, col0, cull_window if quad_keep is not None else None,
                      grad_flags=1 if (grad_culled_unwritten and quad_keep is not None) else 0)
         asum = torch.empty((T, H, W, 2), dtype=torch.float32, device=stack.device) if with_reg else None
-        sums = torch.zeros(4, dtype=torch.float64, device=stack.device)
+        # (with_reg: every entry point that forms the sums clears them itself -- no second fill)
+        sums = (torch.empty if with_reg else torch.zeros)(4, dtype=torch.float64, device=stack.device)
         reg_state = None
         if with_reg:
             # coverage masks / pair flags / sign words of the layer differences: written by the forward, read by the backward (include/vl3d.h)
@@ -205,7 +206,7 @@ class _RenderPlanesMask(torch.autograd.Function):
         label = torch.empty((T, H, W), dtype=torch.float32, device=dev)
         desc = _desc(stack, H, W, spec, 0, 0)
         asum = torch.empty((T, H, W, 2), dtype=torch.float32, device=dev) if with_reg else None
-        sums = torch.zeros(4, dtype=torch.float64, device=dev) if with_reg else None
+        sums = torch.empty(4, dtype=torch.float64, device=dev) if with_reg else None      # (cleared by vl3d_render_fwd_mask)
         reg_state = None
         with torch.cuda.device(dev):
             if with_reg:

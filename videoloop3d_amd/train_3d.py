@@ -138,20 +138,29 @@ def run_iter(nerf, optimizer, item, args, device):
     nerf.train()
     if hasattr(optimizer, "acknowledge_fused_backward"):
         optimizer.acknowledge_fused_backward()
-    rgbl, extra = nerf(patch_h, patch_w, b_extrin, b_intrin)
     learn_mask = bool(getattr(args, "learn_loop_mask", False))
-    img_loss, loop_loss = image_and_loop_loss(rgbl, b_rgbs, b_loopmask if learn_mask else None,
-                                              scale_invariant=bool(getattr(args, "scale_invariant", False)))
-    args_var = vars(args)
-    from .train_3dvid import weighted_total
-    mains = [img_loss] + ([loop_loss] if torch.is_tensor(loop_loss) else [])
-    loss, _, extra_losses = weighted_total(mains, extra, lambda k: args_var.get(f"{k}_loss_weight", 0))
+    module = getattr(nerf, "module", nerf)
+    if hasattr(module, "objective") and not getattr(args, "generic_objective", False):
+        # render + every loss term + their weighted total with the scalar head fused (MPMesh.objective: same values and gradients as the
+        # spelling below, tests/test_gpu_stage1_driver.py); args.generic_objective keeps the reference's spelling for A/B
+        loss, img_loss, loop_loss, extra_losses = module.objective(patch_h, patch_w, b_extrin, b_intrin, b_rgbs, b_loopmask if learn_mask else None,
+                                                                   scale_invariant=bool(getattr(args, "scale_invariant", False)))
+    else:
+        rgbl, extra = nerf(patch_h, patch_w, b_extrin, b_intrin)
+        img_loss, loop_loss = image_and_loop_loss(rgbl, b_rgbs, b_loopmask if learn_mask else None,
+                                                  scale_invariant=bool(getattr(args, "scale_invariant", False)))
+        args_var = vars(args)
+        from .train_3dvid import weighted_total
+        mains = [img_loss] + ([loop_loss] if torch.is_tensor(loop_loss) else [])
+        loss, _, extra_losses = weighted_total(mains, extra, lambda k: args_var.get(f"{k}_loss_weight", 0))
+        img_loss, loop_loss = img_loss.detach(), (loop_loss.detach() if torch.is_tensor(loop_loss) else loop_loss)
+        extra_losses = {k: v.detach() for k, v in extra_losses.items()}
     optimizer.zero_grad()
     loss.backward()
-    if hasattr(getattr(nerf, "module", nerf), "post_backward"):
-        getattr(nerf, "module", nerf).post_backward()
+    if hasattr(module, "post_backward"):
+        module.post_backward()
     optimizer.step()
-    return loss.detach(), img_loss.detach(), (loop_loss.detach() if torch.is_tensor(loop_loss) else loop_loss), {k: v.detach() for k, v in extra_losses.items()}
+    return loss.detach(), img_loss, loop_loss, extra_losses
 
 
 def train(nerf, args, videos, poses, intrins, H, W, device="cuda:0", on_step=None, generator=None, save_dir=None, start_epoch=0,
