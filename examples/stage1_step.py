@@ -19,7 +19,9 @@ import torch
 
 
 def run(iters=20, planes=32, frame=(360, 640), crop=(180, 320), scale=1.6, loop_mask=True, dev="cuda:0", torch_adam=False, fused_loss=True,
-        crop_aware_adam="auto"):
+        crop_aware_adam="auto", objective=True):
+    """objective: the driver's spelling (videoloop3d_amd/train_3d.py run_iter -> MPMesh.objective: render + every loss term + the weighted total with
+    the scalar head in one sweep); False: forward + image_and_loop_loss + a python sum (fused_loss) or the reference's torch chain (not fused_loss)."""
     from videoloop3d_amd import synth
     from videoloop3d_amd.MPI import MPMesh, image_and_loop_loss
     dev = torch.device(dev)
@@ -54,6 +56,12 @@ def run(iters=20, planes=32, frame=(360, 640), crop=(180, 320), scale=1.6, loop_
         if (h, w) != (H, W):
             Kc[0, 2] -= 90 + (it % 3) * 40                                   # crop offset (utils.py:196-200)
             Kc[1, 2] -= 45 + (it % 2) * 60
+        if objective and fused_loss:
+            loss, _, _, _ = model.objective(h, w, tar_e, torch.tensor(Kc)[None], target, target_mask if loop_mask else None, scale_invariant=True)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            continue
         rgbl, extra = model(h, w, tar_e, torch.tensor(Kc)[None])
         if fused_loss:                                                       # train_3d.py:200-220 in three launches each way
             img_loss, loop_loss = image_and_loop_loss(rgbl, target, target_mask if loop_mask else None, scale_invariant=True)

@@ -665,6 +665,37 @@ def test_tile_adam_matches_torch_adam(dev):
     assert float((dense.param_groups[0]["params"][0] - (p0 - 0.01)).abs().max()) <= 1e-6
 
 
+def test_one_pass_adam_skips_untouched_texels_exactly(dev):
+    """adam_tiles_k neither reads the parameter nor writes anything where g = m = v = 0 (texels no view has reached: the margins of planes
+    stored larger than the frame): the same bits as torch.optim.Adam there (whose update of such a texel is p - 0) and the usual 2e-6 everywhere else, step after step -- a texel that receives its
+    first gradient later joins in, one whose gradient returns to 0 keeps decaying its moments."""
+    from videoloop3d_amd import tiles
+    torch.manual_seed(5)
+    D, T, Hs, Ws = 3, 1, 37, 53
+    p0 = torch.randn(D, T, Hs, Ws, 4, device=dev)
+    pa, pb = p0.clone().requires_grad_(True), p0.clone().requires_grad_(True)
+    oa = torch.optim.Adam([pa], lr=0.05, betas=(0.9, 0.999), eps=1e-8)
+    ob = tiles.TileAdam([pb], lr=0.05, betas=(0.9, 0.999), eps=1e-8)
+    yy, xx = torch.meshgrid(torch.arange(Hs, device=dev), torch.arange(Ws, device=dev), indexing="ij")
+    never = ((yy < 6) | (xx > 44))[None, None, :, :, None]                      # no gradient in any step
+    for it in range(6):
+        seen = ((yy + xx) % 7 < 2 + it)[None, None, :, :, None] & ~never        # grows: first gradients arrive in later steps; some -0.0 too
+        g = torch.randn_like(p0) * seen
+        g = torch.where((g == 0) & (torch.rand_like(g) < 0.3), -torch.zeros_like(g), g)
+        if it == 4:
+            g = g * 0                                                           # a step without any gradient: moments decay, parameters still move
+        for o, p in ((oa, pa), (ob, pb)):
+            p.grad = g.clone()
+            o.step()
+        assert float((pa - pb).abs().max()) <= 2e-6, it
+        untouched = (ob.state[pb]["exp_avg"] == 0) & (ob.state[pb]["exp_avg_sq"] == 0)
+        assert torch.equal(pa.detach()[untouched], pb.detach()[untouched])      # (torch's own update of a texel with g = m = v = 0 is p - 0)
+    assert torch.equal((pb.detach() * never), (p0 * never)) and torch.equal((pa.detach() * never), (p0 * never))
+    sa, sb = oa.state[pa], ob.state[pb]
+    assert float((sa["exp_avg"] - sb["exp_avg"]).abs().max()) <= 1e-6 and float((sa["exp_avg_sq"] - sb["exp_avg_sq"]).abs().max()) <= 1e-6
+    assert float(sb["exp_avg"].abs().max()) > 0 and not bool((sb["exp_avg"] * never).any()) and not bool((sb["exp_avg_sq"] * never).any())
+
+
 def test_tile_adam_static_texels_are_one_parameter(dev):
     """TileAdam with quad_dyn: a static texel is updated once from frame 0 (frame-summed gradient left there by
     tie_static_grad_hip(frame0_only=True)) and the value is written to all T copies == torch.optim.Adam on the fully tied gradient."""

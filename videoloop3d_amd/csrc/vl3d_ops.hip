@@ -373,8 +373,16 @@ __global__ __launch_bounds__(256) void adam_tiles_k(int T, int Hs, int Ws, const
         return;
     }
     for (int t = 0; t < T; ++t, o += frame) {
-        float4 pp = p[o], mm = m[o], vv = v[o];
+        float4 mm = m[o], vv = v[o];
         const float4 gg = g[o];
+        // A texel no view has reached yet (g = m = v = 0: the margins of planes stored larger than the frame, half of a stage-1 stack at the
+        // shipped 1.6x) keeps m = v = 0 and takes a step of exactly 0: its parameter is neither read nor written, its moments not written --
+        // three streams instead of seven over that part of the stack, the same bits as the full update (-0 counts as 0).
+        const unsigned any = (__float_as_uint(gg.x) | __float_as_uint(gg.y) | __float_as_uint(gg.z) | __float_as_uint(gg.w) |
+                              __float_as_uint(mm.x) | __float_as_uint(mm.y) | __float_as_uint(mm.z) | __float_as_uint(mm.w) |
+                              __float_as_uint(vv.x) | __float_as_uint(vv.y) | __float_as_uint(vv.z) | __float_as_uint(vv.w)) & 0x7fffffffu;
+        if (any == 0u) continue;
+        float4 pp = p[o];
         upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
         p[o] = pp; m[o] = mm; v[o] = vv;
     }
