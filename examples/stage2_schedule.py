@@ -40,7 +40,7 @@ def make_views(V, H, W, frames, dev):
     return torch.tensor(np.stack(poses), dtype=torch.float32), torch.tensor(K, dtype=torch.float32)[None].repeat(V, 1, 1), vids
 
 
-def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, dev="cuda:0", sparsify=False, fused=True, bwd_variant=0):
+def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, dev="cuda:0", sparsify=False, fused=True, bwd_variant=0, generic_objective=False):
     from videoloop3d_amd.MPV import MPMeshVid
     from videoloop3d_amd.train_3dvid import MVVidPatchDataset, run_iter
     dev = torch.device(dev)
@@ -52,6 +52,7 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
         sparsity_loss_weight=0.0, rgb_smooth_loss_weight=smooth, a_smooth_loss_weight=smooth, density_loss_weight=0.0,
         d_smooth_loss_weight=0.0, swd_loss_weight=1.0, optimizer="adam", lrate=0.5, lrate_decay=100, lrate_adaptive=True,
         add_intrin_noise=True, mpi_h_verts=36, mpi_w_verts=64,
+        generic_objective=bool(generic_objective),      # True: forward + weighted_total instead of MPMeshVid.objective (A/B)
         fused_adam_backward=bool(fused))      # dense models: the optimiser step inside the render backward (vl3d_render_bwd_adam)
     poses, intrins, vids = make_views(views, H, W, clip, dev)
     K = intrins[0].numpy()
@@ -174,7 +175,8 @@ if __name__ == "__main__":
     ap.add_argument("--sparsify", action="store_true")
     ap.add_argument("--two-kernels", action="store_true", help="dense model: vl3d_render_bwd + the step kernel instead of the step inside the backward")
     ap.add_argument("--bwd-variant", type=int, default=0)
+    ap.add_argument("--generic-objective", action="store_true", help="forward + weighted_total instead of MPMeshVid.objective")
     a = ap.parse_args()
     import __graft_entry__ as g
     g.build()
-    print(json.dumps(run(a.views, a.epochs, sparsify=a.sparsify, fused=not a.two_kernels, bwd_variant=a.bwd_variant)))
+    print(json.dumps(run(a.views, a.epochs, sparsify=a.sparsify, fused=not a.two_kernels, bwd_variant=a.bwd_variant, generic_objective=a.generic_objective)))

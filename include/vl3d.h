@@ -493,6 +493,14 @@ int vl3d_stage1_objective(const vl3d_stage1_objective_desc *desc, const float *r
                           int64_t m_sb, int64_t m_sr, double *scratch, float *out, float *grad_rgb,
                           float *grad_label, float *grad_alpha, float *grad_alpha_sums, float *grad_smooth, vl3d_stream_t stream);
 
+/* The weighted total of a stage-2 iteration (train_3dvid.py:230-240: loss = swd + sum_k weight_k term_k) over n <= 16 device scalars
+ * v = (*main_term, rest[0..n-2]) with device coefficients coef[n]; term i belongs to group (groups >> 4 i) & 15 of `ngroups` <= 16 (a smoothness
+ * mean is two of the render's four sums): out[0] = sum_i coef_i v_i, out[1 + g] = the sum of group g's terms (one launch instead of a stack, a
+ * multiply and a sum on one-element tensors and their autograd mirrors).  Backward: grad_terms[i] = coef_i * *grad_total. */
+int vl3d_linear_head_fwd(int32_t n, uint64_t groups, int32_t ngroups, const float *main_term, const float *rest, const float *coef, float *out,
+                         vl3d_stream_t stream);
+int vl3d_linear_head_bwd(int32_t n, const float *coef, const float *grad_total, float *grad_terms, vl3d_stream_t stream);
+
 /* robust_lossfun (utils_vid.py:10-26) fused with the mean (utils_vid.py:348).
  * kind: 0 'mse', 1 'abs', 2 general Barron with float rou (rou==0 and rou==2 special-cased as the reference).
  * loss_sum: device double, overwritten with sum over n elements of rho(x - y2x). */

@@ -90,6 +90,56 @@ def test_forward_train_matches_oracle(dev, which, bg):
     assert float(g_o.abs().max()) > 0
 
 
+@pytest.mark.parametrize("which", ["other", "ref", "one_term", "no_terms", "generic_fallback"])
+def test_stage2_objective_equals_forward_plus_weighted_total(dev, which):
+    """MPMeshVid.objective (the weighted total in one launch each way, vl3d_linear_head_*) against forward + train_3dvid.weighted_total: the
+    total, the swd term, every weighted regulariser and the gradient w.r.t. the stack -- also under an upstream gradient that is not 1, and
+    through the generic spelling it falls back to when a per-pixel term is on."""
+    from videoloop3d_amd.MPV import MPMeshVid
+    from videoloop3d_amd.train_3dvid import weighted_total
+    H, W = 44, 60
+    K, ref_extrin, tar = scene(H, W)
+    kw = {}
+    if which == "one_term":
+        kw["a_smooth_loss_weight"] = 0.0
+    if which == "no_terms":
+        kw.update(a_smooth_loss_weight=0.0, rgb_smooth_loss_weight=0.0)
+    if which == "generic_fallback":
+        kw.update(sparsity_loss_weight=0.1, density_loss_weight=0.05)
+    args = make_args(**kw)
+    model = MPMeshVid(args, H, W, ref_extrin, K, 1.0, 100.0).to(dev).train()
+    with torch.no_grad():
+        model.stack.copy_(synth.make_plane_stack(*model.stack.shape[:4], seed=5) * 0.7)
+    h, w = 33, 47
+    Kc = K.copy(); Kc[0, 2] -= 6; Kc[1, 2] -= 5
+    tar_e, tar_k = torch.tensor(tar)[None], torch.tensor(Kc)[None]
+    res = synth.hash_uniform((1, 9, 3, h, w), seed=8).to(dev)
+    if which == "ref":
+        cfg = dict(loss_name="gpnn_lm", loss_gain=3.5, macro_block=21, patch_size=11, stride=4, patcht_size=3, stridet=1,
+                   alpha=0.5, dist_fn="mse", rou="-2", scaling=0.1)
+    else:
+        cfg = dict(loss_name="gpnn_lm", loss_gain=1.0, macro_block=21, patch_size=3, stride=2, patcht_size=3, stridet=1,
+                   alpha=10000, dist_fn="mse", rou="-2", scaling=0.1)
+    wt = lambda k: getattr(args, f"{k}_loss_weight", 0)  # noqa: E731
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for up in (1.0, 0.4):
+            la, sa, ea = model.objective(h, w, tar_e, tar_k, res, collate(cfg))
+            (ga,) = torch.autograd.grad(la * up, model.stack)
+            _, extra = model(h, w, tar_e, tar_k, res=res, losscfg=collate(cfg))
+            swd = extra.pop("swd")
+            lb, (sb,), eb = weighted_total([swd], extra, wt)
+            (gb,) = torch.autograd.grad(lb * up, model.stack)
+            assert abs(float(la) - float(lb)) <= 2e-6 * max(1.0, abs(float(lb)))
+            assert abs(float(sa) - float(sb)) <= 2e-6 * max(1.0, abs(float(sb)))
+            assert sorted(ea) == sorted(eb)
+            for k in ea:
+                assert abs(float(ea[k]) - float(eb[k])) <= 2e-6 * max(1e-3, abs(float(eb[k]))), k
+            assert float((ga - gb).abs().max()) <= 2e-6 * max(1e-6, float(gb.abs().max()))
+            assert float(gb.abs().max()) > 0
+
+
 def test_forward_eval_and_frame_subset(dev):
     from videoloop3d_amd.MPV import MPMeshVid
     H, W = 44, 60

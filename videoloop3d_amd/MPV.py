@@ -145,6 +145,38 @@ class _SmoothTerms(torch.autograd.Function):
         return (coef.view(2, 2) * g[:, None]).reshape(4), None
 
 
+class _LinearHead(torch.autograd.Function):
+    """total = sum_i coef_i v_i over the device scalars v = (main, rest[0..n-2]) -> (total, groups [ngroups]) in one launch (vl3d_linear_head_fwd),
+    coef * g in one more on the way back: the weighted total of train_3dvid.py:230-240 without a stack, a multiply and a sum on one-element
+    tensors and their autograd mirrors (~14 launches of a stage-2 iteration that is bound by the GPU's timeline)."""
+
+    @staticmethod
+    def forward(ctx, main, rest, coef, groups, ngroups):
+        from . import _lib as L
+        L.check_cuda(main, coef)
+        n = 1 + (0 if rest is None else rest.numel())
+        m = main.detach().reshape(1)
+        m = m if m.dtype == torch.float32 else m.to(torch.float32)
+        r = None if rest is None else rest.detach().to(torch.float32).contiguous()
+        out = torch.empty(1 + ngroups, dtype=torch.float32, device=main.device)
+        with torch.cuda.device(main.device):
+            L.check(L.lib().vl3d_linear_head_fwd(n, int(groups), int(ngroups), L.ptr(m), L.ptr(r), L.ptr(coef), L.ptr(out), L.stream_ptr(main.device)),
+                    "vl3d_linear_head_fwd")
+        ctx.coef, ctx.n, ctx.main_shape = coef, n, tuple(main.shape)
+        parts = out[1:]
+        ctx.mark_non_differentiable(parts)
+        return out[0], parts
+
+    @staticmethod
+    def backward(ctx, g, _gp):
+        from . import _lib as L
+        gs = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.to(torch.float32).contiguous()
+        gt = torch.empty(ctx.n, dtype=torch.float32, device=gs.device)
+        with torch.cuda.device(gs.device):
+            L.check(L.lib().vl3d_linear_head_bwd(ctx.n, L.ptr(ctx.coef), L.ptr(gs), L.ptr(gt), L.stream_ptr(gs.device)), "vl3d_linear_head_bwd")
+        return gt[0].view(ctx.main_shape), (gt[1:] if ctx.n > 1 else None), None, None, None
+
+
 def atlas_to_stack(atlas_dyn, mpi_d, grid_h):
     """(T,4,Ah,Aw) atlas of grid_h x grid_w plane cells (MPV.py:37-44,75-81: plane p <-> cell (p // grid_w, p % grid_w))
     -> (D,T,mpi_h,mpi_w,4) stack."""
@@ -733,7 +765,49 @@ class MPMeshVid(nn.Module):
         return slots, planes, inv_z
 
     # ---- forward -----------------------------------------------------------------------------------------------------
-    def forward(self, h, w, tar_extrins, tar_intrins, ts=None, res=None, losscfg=None):
+    def objective(self, h, w, tar_extrins, tar_intrins, res, losscfg):
+        """One stage-2 training objective, train_3dvid.py:228-240 on MPV.py:477-556: render the crop, the looping loss against `res`, the
+        regularisers with a positive `args.<name>_loss_weight` and their weighted total
+            -> (loss, swd_loss, {name: weighted term})        loss differentiable, the parts detached
+        -- what `forward` + `train_3dvid.weighted_total` give, with the total formed in one launch each way (vl3d_linear_head_*).  Falls back to
+        that spelling where a per-pixel term (sparsity, density, d_smooth: off in configs/mpv_base.txt) is on."""
+        a = self.args
+        wts = {k: float(getattr(a, f"{k}_loss_weight", 0) or 0) for k in ("sparsity", "rgb_smooth", "a_smooth", "density", "d_smooth")}
+        if (not self.training or not self.stack_device_is_cuda() or wts["sparsity"] > 0 or wts["density"] > 0 or wts["d_smooth"] > 0
+                or getattr(a, "unfused_terms", False)):
+            from .train_3dvid import weighted_total
+            _, extra = self(h, w, tar_extrins, tar_intrins, res=res, losscfg=losscfg)
+            swd = extra.pop("swd")
+            loss, (swd_loss,), extra_losses = weighted_total([swd], extra, lambda k: wts.get(k, 0))
+            return loss, swd_loss.detach(), {k: v.detach() for k, v in extra_losses.items()}
+        main_loss, gain, variables, T_ = self(h, w, tar_extrins, tar_intrins, res=res, losscfg=losscfg, _head=True)
+        K_ = self.mpi_d
+        nx, ny = T_ * h * (w - 1) * K_, T_ * (h - 1) * w * K_
+        sums = variables["smooth_sums"] if (wts["rgb_smooth"] > 0 or wts["a_smooth"] > 0) and min(nx, ny) > 0 else None
+        names = [k for k in ("rgb_smooth", "a_smooth") if wts[k] > 0] if sums is not None else []
+        # coefficients: the view's loss gain on every term (MPV.py:507-531), the means' counts and the weights folded in
+        if sums is not None:
+            gi = {k: 1 + i for i, k in enumerate(names)}      # group 0 = swd; a term with weight 0 joins it with coefficient 0
+            coef = (gain, wts["rgb_smooth"] * gain / (3 * nx), wts["rgb_smooth"] * gain / (3 * ny), wts["a_smooth"] * gain / nx, wts["a_smooth"] * gain / ny)
+            grp = (0, gi.get("rgb_smooth", 0), gi.get("rgb_smooth", 0), gi.get("a_smooth", 0), gi.get("a_smooth", 0))
+        else:
+            coef, grp = (gain,), (0,)
+        groups = sum(g << (4 * i) for i, g in enumerate(grp))
+        cache = self.__dict__.setdefault("_head_coef", {})
+        key = (coef, str(main_loss.device))
+        cd = cache.get(key)
+        if cd is None:
+            if len(cache) > 64:
+                cache.clear()
+            cd = cache[key] = torch.tensor(coef, dtype=torch.float32, device=main_loss.device)
+        total, parts = _LinearHead.apply(main_loss, sums, cd, groups, 1 + len(names))
+        return total, parts[0], {k: parts[1 + i] for i, k in enumerate(names)}
+
+    def stack_device_is_cuda(self):
+        p = self.stack_pool if self.packed is not None else self.stack
+        return p.is_cuda
+
+    def forward(self, h, w, tar_extrins, tar_intrins, ts=None, res=None, losscfg=None, _head=False):
         """MPV.py:477-556.  train -> (None, {'swd': [1,1], ...}); eval -> (rgb [T',3,h,w], {})."""
         tar_extrins, tar_intrins = torch.as_tensor(tar_extrins), torch.as_tensor(tar_intrins)      # (numpy arrays pass nn.DataParallel's scatter untouched: host poses)
         if tar_extrins.is_cuda and self.training and self._window_opt is not None:
@@ -779,6 +853,8 @@ class MPMeshVid(nn.Module):
                 rgb_pad = rgb_pad * scale
             x = rgb_pad.permute(1, 0, 2, 3)[None]
         main_loss = loss(x, res.permute(0, 2, 1, 3, 4), **losscfg)
+        if _head:      # (MPMeshVid.objective: the caller forms the weighted total itself, in one launch)
+            return main_loss, float(loss_gain), variables, rgb.shape[0]
         extra['swd'] = main_loss.reshape(1, -1) * loss_gain
 
         fused_terms = None

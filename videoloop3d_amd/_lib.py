@@ -116,6 +116,8 @@ SIGNATURES = {
     "vl3d_pixel_terms": ([_I64, _P, _P, _F, _P, _P, _P, _P], C.c_int),
     "vl3d_stage1_loss": ([_I32] * 4 + [_P, _I64, _I64, _I64, _P, _P, _I32, _P, _P, _P, _P], C.c_int),
     "vl3d_stage1_objective": ([C.POINTER(Stage1ObjectiveDesc)] + [_P] * 6 + [_I64] * 3 + [_P, _I64, _I64] + [_P] * 8, C.c_int),
+    "vl3d_linear_head_fwd": ([_I32, C.c_uint64, _I32, _P, _P, _P, _P, _P], C.c_int),
+    "vl3d_linear_head_bwd": ([_I32, _P, _P, _P, _P], C.c_int),
     "vl3d_robust_fwd": ([_I64, _P, _P, _I32, _F, _F, _P, _P], C.c_int),
     "vl3d_robust_bwd": ([_I64, _P, _P, _I32, _F, _F, _P, _F, _P, _P], C.c_int),
 }

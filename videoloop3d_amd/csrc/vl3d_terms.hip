@@ -190,6 +190,35 @@ __global__ __launch_bounds__(256) void stage1_objective_k(S1Obj a) {
     a.out[1] = img; a.out[2] = loop; a.out[3] = spars; a.out[4] = dens; a.out[5] = rs; a.out[6] = as; a.out[7] = s;
 }
 
+// total = sum_i coef_i v_i over n <= 16 device scalars (v_0 = *main, v_1.. = rest[0..n-2]); term i belongs to group (groups >> 4 i) & 15:
+// out[0] = total, out[1 + g] = the sum of group g's terms -- the weighted total of a stage-2 iteration (train_3dvid.py:230-240: swd +
+// weight_k mean_k, a smoothness mean being two of the render's four sums) in one launch; its backward is coef * g in one more.
+__global__ __launch_bounds__(64) void linear_head_fwd_k(int n, unsigned long long groups, int ngroups, const float *__restrict__ main_,
+                                                        const float *__restrict__ rest, const float *__restrict__ coef, float *__restrict__ out) {
+    if (threadIdx.x != 0) return;
+    float acc[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+    float tot = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float t = coef[i] * (i == 0 ? *main_ : rest[i - 1]);
+        const int g = (int)((groups >> (4 * i)) & 15ull);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] += (k == g) ? t : 0.f;
+        tot += t;
+    }
+    out[0] = tot;
+    for (int g = 0; g < ngroups; ++g) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v = (k == g) ? acc[k] : v;
+        out[1 + g] = v;
+    }
+}
+__global__ __launch_bounds__(64) void linear_head_bwd_k(int n, const float *__restrict__ coef, const float *__restrict__ g, float *__restrict__ out) {
+    if ((int)threadIdx.x < n) out[threadIdx.x] = coef[threadIdx.x] * *g;
+}
+
 unsigned grid_for(int64_t n) {
     const int64_t g = (n + 255) / 256;
     return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -252,6 +281,21 @@ extern "C" int vl3d_stage1_objective(const vl3d_stage1_objective_desc *d, const 
     a.g_rgb = grad_rgb; a.g_label = grad_label; a.g_alpha = grad_alpha; a.g_smooth = grad_smooth;
     a.g_asum = reinterpret_cast<float2 *>(grad_alpha_sums);
     hipLaunchKernelGGL(stage1_objective_k, dim3(grid_for(n)), dim3(256), 0, s, a);
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
+extern "C" int vl3d_linear_head_fwd(int32_t n, uint64_t groups, int32_t ngroups, const float *main_term, const float *rest, const float *coef, float *out,
+                                    vl3d_stream_t stream) {
+    VL3D_REQUIRE(n >= 1 && n <= 16 && ngroups >= 1 && ngroups <= 16 && main_term && coef && out && (n == 1 || rest), "vl3d_linear_head_fwd: bad arguments");
+    hipLaunchKernelGGL(linear_head_fwd_k, dim3(1), dim3(64), 0, (hipStream_t)stream, n, (unsigned long long)groups, ngroups, main_term, rest, coef, out);
+    VL3D_CHECK_LAUNCH();
+    return VL3D_OK;
+}
+
+extern "C" int vl3d_linear_head_bwd(int32_t n, const float *coef, const float *grad_total, float *grad_terms, vl3d_stream_t stream) {
+    VL3D_REQUIRE(n >= 1 && n <= 16 && coef && grad_total && grad_terms, "vl3d_linear_head_bwd: bad arguments");
+    hipLaunchKernelGGL(linear_head_bwd_k, dim3(1), dim3(64), 0, (hipStream_t)stream, n, coef, grad_total, grad_terms);
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
 }

@@ -171,14 +171,21 @@ def run_iter(nerf, optimizer, item, args, device):
     nerf.train()
     if hasattr(optimizer, "acknowledge_fused_backward"):
         optimizer.acknowledge_fused_backward()      # this loop steps once per backward: the update inside the render backward is what it wants
-    _, extra = nerf(patch_h, patch_w, b_extrin, b_intrin, res=b_rgbs, losscfg=_collate1(cfg))
-    swd = extra.pop("swd")
-    args_var = vars(args)
-    loss, (swd_loss,), extra_losses = weighted_total([swd], extra, lambda k: args_var[f"{k}_loss_weight"])
+    module = getattr(nerf, "module", nerf)
+    if hasattr(module, "objective") and not getattr(args, "generic_objective", False):
+        # render + looping loss + regularisers + their weighted total, the total in one launch each way (MPMeshVid.objective: the same values
+        # and gradients as the spelling below); args.generic_objective keeps the reference's spelling for A/B
+        loss, swd_loss, extra_losses = module.objective(patch_h, patch_w, b_extrin, b_intrin, b_rgbs, _collate1(cfg))
+    else:
+        _, extra = nerf(patch_h, patch_w, b_extrin, b_intrin, res=b_rgbs, losscfg=_collate1(cfg))
+        swd = extra.pop("swd")
+        args_var = vars(args)
+        loss, (swd_loss,), extra_losses = weighted_total([swd], extra, lambda k: args_var[f"{k}_loss_weight"])
+        swd_loss, extra_losses = swd_loss.detach(), {k: v.detach() for k, v in extra_losses.items()}
     optimizer.zero_grad()
     loss.backward()
     optimizer.step()
-    return loss.detach(), swd_loss.detach(), {k: v.detach() for k, v in extra_losses.items()}
+    return loss.detach(), swd_loss, extra_losses
 
 
 def train(nerf, args, videos, poses, intrins, loss_cfgs, H, W, device="cuda:0", on_step=None, generator=None, save_dir=None):
