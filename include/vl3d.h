@@ -96,6 +96,11 @@ enum { VL3D_GRAD_CULLED_UNWRITTEN = 1 };
  * sparsity regulariser (MPV.py:511-515 / MPI.py:599-603: |a|_1 / |a|_2 per pixel) is made of. */
 int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos,
                     float *rgb, float *alpha, float *alpha_sums, vl3d_stream_t stream);
+/* ... of frames frame0 .. frame0 + desc->T - 1 of a LONGER clip, read in place: `stack` is the base of a (D, T_alloc, Hs, Ws, 4) allocation,
+ * desc->T the number of consecutive frames to render (an evaluation render of single frames or runs of frames -- scripts/script_render_video.py:
+ * 129-139 renders one frame per camera of its path -- without gathering `stack[:, ts]` first: 571 MB per 720p frame at D = 32 on 1.1x planes). */
+int vl3d_render_fwd_frames(const vl3d_render_desc *desc, const void *stack, int32_t frame0, int32_t T_alloc, const float *homos, float *rgb,
+                           float *alpha, vl3d_stream_t stream);
 
 /* Backward of the above w.r.t. the stack (geometry is not differentiated: MPV.py:354).
  * rgb/alpha are the saved forward outputs; grad_alpha may be NULL (treated as 0).

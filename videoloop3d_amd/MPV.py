@@ -665,7 +665,16 @@ class MPMeshVid(nn.Module):
             return rgb[..., :3], variables
         if self.packed is not None and not self._all_frames(ts):
             self._flush_deferred_updates()
-        stack = self._frames(ts)          # (a packed model: None for the full clip -- the window path below, or unpacked on demand)
+        # an evaluation render of a run of consecutive frames of a dense model reads them where they lie (vl3d_render_fwd_frames): gathering
+        # stack[:, ts] first moved 571 MB per 720p frame, more than the render itself reads (scripts/script_render_video.py renders one frame per
+        # camera of its path)
+        frame_run = None
+        if (self.packed is None and not (self.training and torch.is_grad_enabled()) and not need_layers and not need_smooth and not self.atlas_exact
+                and not self.is_sparse and self.stack.is_cuda and self.stack.is_contiguous() and not self._all_frames(ts)):
+            tl = torch.as_tensor(ts).tolist()
+            if len(tl) >= 1 and tl == list(range(tl[0], tl[0] + len(tl))) and 0 <= tl[0] and tl[-1] < self.stack.shape[1]:
+                frame_run = (tl[0], len(tl))
+        stack = self.stack if frame_run is not None else self._frames(ts)          # (a packed model: None for the full clip -- the window path below, or unpacked on demand)
         all_frames = stack is None or stack is getattr(self, "stack", None)
         homos = self.plane_homographies(extrin, intrin)
         smooth_sums = alpha_sums = None
@@ -728,8 +737,12 @@ class MPMeshVid(nn.Module):
                                                                                   grad_culled_unwritten=lean_grad, fused_adam=fused_adam)
         else:
             # a sparsified model renders with tile culling: samples in culled quads are uncovered, workgroups skip planes without kept quads
-            rgb, alpha = render_planes(stack, homos, H, W, spec, quad_keep=self.quad_keep if self.is_sparse else None, cull_window=cull_window,
-                                       grad_culled_unwritten=lean_grad, fused_adam=fused_adam)
+            if frame_run is not None:
+                from .render import render_frame_run
+                rgb, alpha = render_frame_run(stack.detach(), frame_run[0], frame_run[1], homos, H, W, spec)
+            else:
+                rgb, alpha = render_planes(stack, homos, H, W, spec, quad_keep=self.quad_keep if self.is_sparse else None, cull_window=cull_window,
+                                           grad_culled_unwritten=lean_grad, fused_adam=fused_adam)
         variables = {"pix_to_face": None, "blend_weight": None, "mpi": None, "disp_norm": None, "alpha": alpha,
                      "smooth_sums": smooth_sums, "alpha_sums": alpha_sums}
         if need_layers:

@@ -52,6 +52,7 @@ int check_desc(const vl3d_render_desc *d) {
 RenderArgs make_args(const vl3d_render_desc *d) {
     RenderArgs a{};
     a.D = d->D; a.T = d->T; a.Hs = d->Hs; a.Ws = d->Ws; a.H = d->H; a.W = d->W;
+    a.Tstride = d->T;
     a.row0 = d->row0; a.col0 = d->col0;
     a.pc = d->pixel_center; a.sx = d->sx; a.sy = d->sy; a.ox = d->ox; a.oy = d->oy;
     a.uv_seed = d->uv_noise_seed;
@@ -90,7 +91,8 @@ extern "C" int64_t vl3d_render_cull_scratch_bytes(const vl3d_render_desc *desc) 
 }
 
 static int render_fwd_impl(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep, int32_t QH,
-                           int32_t QW, void *cull_scratch, float *rgb, float *alpha, float *alpha_sums, vl3d_stream_t stream) {
+                           int32_t QW, void *cull_scratch, float *rgb, float *alpha, float *alpha_sums, vl3d_stream_t stream, int32_t frame0 = 0,
+                           int32_t T_alloc = 0) {
     int rc = check_desc(desc);
     if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE(stack && homos && rgb && alpha, "null pointer passed to vl3d_render_fwd");
@@ -105,10 +107,21 @@ static int render_fwd_impl(const vl3d_render_desc *desc, const void *stack, cons
     a.ablate = (desc->variant >> 4) & 0xf;
     VL3D_REQUIRE((int64_t)desc->Hs * desc->Ws * 16 < (1ll << 32), "frame too large for 32-bit byte offsets");
     a.g_f16 = desc->stack_dtype == VL3D_F16;
+    if (T_alloc > 0) {      // vl3d_render_fwd_frames: frames frame0 .. frame0 + T - 1 of a (D, T_alloc, Hs, Ws, 4) allocation, read in place
+        VL3D_REQUIRE(frame0 >= 0 && frame0 + desc->T <= T_alloc, "vl3d_render_fwd_frames: the run of frames leaves the clip");
+        a.stack = reinterpret_cast<const float *>(reinterpret_cast<const char *>(stack) + (size_t)frame0 * desc->Hs * desc->Ws * (a.g_f16 ? 8 : 16));
+        a.Tstride = T_alloc;
+    }
     rc = dispatch(false, desc, a, (hipStream_t)stream);
     if (rc != VL3D_OK) return rc;
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
+}
+
+extern "C" int vl3d_render_fwd_frames(const vl3d_render_desc *desc, const void *stack, int32_t frame0, int32_t T_alloc, const float *homos,
+                                      float *rgb, float *alpha, vl3d_stream_t stream) {
+    VL3D_REQUIRE(T_alloc > 0, "vl3d_render_fwd_frames: T_alloc must be the clip length of the stack allocation");
+    return render_fwd_impl(desc, stack, homos, nullptr, 0, 0, nullptr, rgb, alpha, nullptr, stream, frame0, T_alloc);
 }
 
 extern "C" int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos,

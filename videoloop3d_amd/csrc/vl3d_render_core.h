@@ -43,6 +43,7 @@ struct RenderArgs {
     const float *g_alpha;
     float *g_stack;
     int D, T, Hs, Ws, H, W, row0, col0;
+    int Tstride;          // frames between two planes of the stack allocation (= T but for vl3d_render_fwd_frames: a run of frames of a longer clip); read by the plain forward kernels only
     float pc, sx, sy, ox, oy;
     float *asum;          // forward out (optional): per pixel (sum_k a_k, sum_k a_k^2) for the sparsity regulariser (MPV.py:511-515)
     const float *g_asum;  // backward in (optional): per pixel dL/d(sum a), dL/d(sum a^2)
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
     if (x >= a.W || y >= a.H) return;
     const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
     const size_t frame_b = (size_t)a.Hs * a.Ws * (F16 ? 8 : 16);
-    const size_t plane_stride_b = (size_t)a.T * frame_b;
+    const size_t plane_stride_b = (size_t)a.Tstride * frame_b;
     const char *plane = reinterpret_cast<const char *>(a.stack) + (size_t)t * frame_b;
     float Tr = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, A = 0.f, n1 = 0.f, n2 = 0.f;
     const TapStep st = make_tap_step<F16>(a.Hs, a.Ws);
@@ -893,7 +894,7 @@ __global__ __launch_bounds__(64 * TY, 4) void render_fwd2x_k(RenderArgs a, int t
     if (x >= a.W || y >= a.H) return;
     const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
     const size_t frame_b = (size_t)a.Hs * a.Ws * (F16 ? 8 : 16);
-    const size_t plane_stride_b = (size_t)a.T * frame_b;
+    const size_t plane_stride_b = (size_t)a.Tstride * frame_b;
     const char *plane0 = reinterpret_cast<const char *>(a.stack) + (size_t)t0 * frame_b;
     const char *plane1 = plane0 + (has1 ? frame_b : 0);
     float Tr0 = 1.0f, cr0 = 0.f, cg0 = 0.f, cb0 = 0.f, A0 = 0.f, n10 = 0.f, n20 = 0.f;

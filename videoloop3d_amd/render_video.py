@@ -160,10 +160,63 @@ def to8b(x):
     return (255 * x.clamp(0, 1)).to(torch.uint8)
 
 
+def _render_frames_in_place(module, H, W, view_extrins, view_intrins, render_t, chunk):
+    """render_frames for a dense model on the device: the plane homographies of every DISTINCT camera of the path are formed up front (the
+    module's own `plane_homographies`, the same bits as its forward) and uploaded in ONE copy, every frame -- or run of consecutive frames of
+    one camera -- is rendered where it lies in the clip (render.render_frame_run: no gather of stack[:, ts]), straight into a chunk buffer
+    that is converted to uint8 once.  None when the model is not one this path serves (packed / sparsified / atlas_exact / CPU)."""
+    from .render import render_frame_run
+    stack = getattr(module, "stack", None)
+    if (getattr(module, "packed", None) is not None or stack is None or not stack.is_cuda or not stack.is_contiguous() or module.is_sparse
+            or module.atlas_exact or module.training):
+        return None
+    if getattr(module, "_window_opt", None) is not None:
+        module._flush_deferred_updates()
+    n, T, dev = len(render_t), stack.shape[1], stack.device
+    ref_inv = module._on(view_extrins.device, "ref_extrin")[None, ...].inverse().to(view_extrins.dtype)
+    cams, cam_of = {}, []
+    for i in range(n):
+        key = (view_extrins[i].numpy().tobytes(), view_intrins[i].numpy().tobytes())
+        if key not in cams:
+            cams[key] = (len(cams), module.plane_homographies(view_extrins[i:i + 1] @ ref_inv, view_intrins[i:i + 1]))
+        cam_of.append(cams[key][0])
+    homos = torch.stack([h for _, h in sorted(cams.values(), key=lambda c: c[0])]).pin_memory().to(dev, non_blocking=True)      # [cameras, D, 3, 3]
+    bg = None
+    if len(module.args.bg_color) > 0:                                                        # MPV.py:455-461
+        if module.args.bg_color == "random":
+            return None                                                                      # (a draw per call: the module's own path)
+        bg = torch.tensor([float(v) for v in module.args.bg_color.split('#')], dtype=torch.float32, device=dev)
+    out = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
+    chunk = max(1, min(int(chunk), n))
+    rgb, alpha = torch.empty((chunk, H, W, 3), dtype=torch.float32, device=dev), torch.empty((chunk, H, W), dtype=torch.float32, device=dev)
+    c0 = 0
+    while c0 < n:
+        c1 = min(n, c0 + chunk)
+        i = c0
+        while i < c1:
+            j = i + 1      # a run: one camera, consecutive frames of the clip
+            while j < c1 and cam_of[j] == cam_of[i] and render_t[j] == render_t[j - 1] + 1:
+                j += 1
+            t0 = int(render_t[i])
+            if not (0 <= t0 and t0 + (j - i) <= T):
+                raise IndexError(f"frame index {t0} .. {t0 + j - i - 1} outside the clip of {T} frames")
+            render_frame_run(stack, t0, j - i, homos[cam_of[i]], H, W, module.spec, out=(rgb[i - c0:j - c0], alpha[i - c0:j - c0]))
+            i = j
+        m = c1 - c0
+        x = rgb[:m]
+        if bg is not None:
+            x = x * alpha[:m, ..., None] + bg[None, None, None] * (-alpha[:m, ..., None] + 1)
+        out[c0:c1] = to8b(x)
+        c0 = c1
+    return out
+
+
 @torch.no_grad()
-def render_frames(nerf, H, W, view_extrins, view_intrins, render_t, max_batch=64):
+def render_frames(nerf, H, W, view_extrins, view_intrins, render_t, max_batch=64, in_place=True):
     """script_render_video.py:129-139: `nerf(H, W, extrin, intrin, t)` in eval mode for every output frame -> uint8 [N,H,W,3] on the
-    model's device.  Runs of consecutive frames with one camera are rendered by ONE call with `ts` a vector (at most `max_batch` frames:
+    model's device.  A dense model on the device renders every frame where it lies in the clip, with the path's homographies uploaded once
+    (`_render_frames_in_place`: 720p, D = 32, T = 50 along a spiral 1430 -> several thousand frames / s; `in_place=False` keeps the loop below).
+    Otherwise runs of consecutive frames with one camera are rendered by ONE call of the module with `ts` a vector (at most `max_batch` frames:
     the frames of a call are resident together)."""
     module = getattr(nerf, "module", nerf)
     was_training = module.training
@@ -171,17 +224,22 @@ def render_frames(nerf, H, W, view_extrins, view_intrins, render_t, max_batch=64
     view_extrins = torch.as_tensor(np.asarray(view_extrins), dtype=torch.float32)
     view_intrins = torch.as_tensor(np.asarray(view_intrins), dtype=torch.float32)
     render_t = np.asarray(render_t).astype(np.int64)
-    out, i, n = [], 0, len(render_t)
-    while i < n:
-        j = i + 1
-        while j < n and j - i < max_batch and torch.equal(view_extrins[j], view_extrins[i]) and torch.equal(view_intrins[j], view_intrins[i]):
-            j += 1
-        rgb, _ = nerf(H, W, view_extrins[i:i + 1], view_intrins[i:i + 1], torch.as_tensor(render_t[i:j]))
-        out.append(to8b(rgb.permute(0, 2, 3, 1)))
-        i = j
+    res = None
+    if in_place and hasattr(module, "plane_homographies") and len(render_t) > 0:
+        res = _render_frames_in_place(module, H, W, view_extrins, view_intrins, render_t, max_batch)
+    if res is None:
+        out, i, n = [], 0, len(render_t)
+        while i < n:
+            j = i + 1
+            while j < n and j - i < max_batch and torch.equal(view_extrins[j], view_extrins[i]) and torch.equal(view_intrins[j], view_intrins[i]):
+                j += 1
+            rgb, _ = nerf(H, W, view_extrins[i:i + 1], view_intrins[i:i + 1], torch.as_tensor(render_t[i:j]))
+            out.append(to8b(rgb.permute(0, 2, 3, 1)))
+            i = j
+        res = torch.cat(out, 0)
     if was_training:
         nerf.train()
-    return torch.cat(out, 0)
+    return res
 
 
 def render_video(nerf, args, poses_bounds, ckpt=None, v="", t="", f=-1, render_scaling=1., factor=None):
