@@ -101,6 +101,10 @@ int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, const float
  * 129-139 renders one frame per camera of its path -- without gathering `stack[:, ts]` first: 571 MB per 720p frame at D = 32 on 1.1x planes). */
 int vl3d_render_fwd_frames(const vl3d_render_desc *desc, const void *stack, int32_t frame0, int32_t T_alloc, const float *homos, float *rgb,
                            float *alpha, vl3d_stream_t stream);
+/* ... of a tile-culled (sparsified) dense model: vl3d_render_fwd_culled's quad map and scratch, the same run of frames. */
+int vl3d_render_fwd_frames_culled(const vl3d_render_desc *desc, const void *stack, int32_t frame0, int32_t T_alloc, const float *homos,
+                                  const uint8_t *quad_keep, int32_t QH, int32_t QW, void *cull_scratch, float *rgb, float *alpha,
+                                  vl3d_stream_t stream);
 
 /* Backward of the above w.r.t. the stack (geometry is not differentiated: MPV.py:354).
  * rgb/alpha are the saved forward outputs; grad_alpha may be NULL (treated as 0).

@@ -90,7 +90,7 @@ def test_render_frames_in_place_equals_the_module_loop(dev, golden):
     sc = np.diag([W / (2 * intrins[0, 0, 2]), H / (2 * intrins[0, 1, 2]), 1.0]).astype(np.float32)
     intrins, rintr = sc @ intrins, sc @ rintr
     ext, K, near, far = RV.reference_camera(poses, intrins, bds)
-    for bg in ("", "0.1#0.5#0.9"):
+    for bg, sparse in (("", False), ("0.1#0.5#0.9", False), ("", True)):
         args = types.SimpleNamespace(mpv_frm_num=T, mpv_isloop=True, mpi_h_scale=1.1, mpi_w_scale=1.1, mpi_d=6, atlas_grid_h=2, init_std=0.5,
                                      rgb_mlp_type="direct", rgb_activate="sigmoid", alpha_activate="sigmoid", bg_color=bg, scale_invariant=True,
                                      fp16=False, swd_patch_size=3, swd_patcht_size=3, swd_stride=2, swd_stridet=1, sparsity_loss_weight=0.0,
@@ -99,9 +99,17 @@ def test_render_frames_in_place_equals_the_module_loop(dev, golden):
         model = MPMeshVid(args, H, W, ext, K.astype(np.float64), near, far).to(dev)
         with torch.no_grad():
             model.stack.copy_(synth.make_plane_stack(*model.stack.shape[:4], seed=5, device=dev) * 0.8)
+        if sparse:      # a tile-culled model: samples inside culled quads are not covered (the culled forward, on frame runs too)
+            model.quad_keep = synth.hash_uniform((6, 5, 7), seed=12, device=dev) > 0.45
+            model.quad_dyn = model.quad_keep.clone()
+            model.is_sparse = model.has_dyn = True
         for v, t in (("", ""), ("r3", ""), ("1", "0:6,5:2"), ("", "0,5,11")):
             vp, vi, rt = RV.select_views_times(rposes, rintr, poses, intrins, T, v, t)
             ve = RV.pose2extrin_np(vp)
             loop = RV.render_frames(model, H, W, ve, vi, rt, in_place=False)
+            if sparse:
+                model.is_sparse = False
+                assert not torch.equal(RV.render_frames(model, H, W, ve, vi, rt, in_place=False), loop)      # (the quad map matters)
+                model.is_sparse = True
             for chunk in (64, 4, 1):
-                assert torch.equal(RV.render_frames(model, H, W, ve, vi, rt, max_batch=chunk), loop), (bg, v, t, chunk)
+                assert torch.equal(RV.render_frames(model, H, W, ve, vi, rt, max_batch=chunk), loop), (bg, sparse, v, t, chunk)

@@ -670,7 +670,7 @@ class MPMeshVid(nn.Module):
         # camera of its path)
         frame_run = None
         if (self.packed is None and not (self.training and torch.is_grad_enabled()) and not need_layers and not need_smooth and not self.atlas_exact
-                and not self.is_sparse and self.stack.is_cuda and self.stack.is_contiguous() and not self._all_frames(ts)):
+                and self.stack.is_cuda and self.stack.is_contiguous() and not self._all_frames(ts)):
             tl = torch.as_tensor(ts).tolist()
             if len(tl) >= 1 and tl == list(range(tl[0], tl[0] + len(tl))) and 0 <= tl[0] and tl[-1] < self.stack.shape[1]:
                 frame_run = (tl[0], len(tl))
@@ -739,7 +739,7 @@ class MPMeshVid(nn.Module):
             # a sparsified model renders with tile culling: samples in culled quads are uncovered, workgroups skip planes without kept quads
             if frame_run is not None:
                 from .render import render_frame_run
-                rgb, alpha = render_frame_run(stack.detach(), frame_run[0], frame_run[1], homos, H, W, spec)
+                rgb, alpha = render_frame_run(stack.detach(), frame_run[0], frame_run[1], homos, H, W, spec, quad_keep=self.quad_keep if self.is_sparse else None)
             else:
                 rgb, alpha = render_planes(stack, homos, H, W, spec, quad_keep=self.quad_keep if self.is_sparse else None, cull_window=cull_window,
                                            grad_culled_unwritten=lean_grad, fused_adam=fused_adam)

@@ -65,6 +65,7 @@ SIGNATURES = {
     "vl3d_version": ([], C.c_int),
     "vl3d_render_fwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P, _P], C.c_int),
     "vl3d_render_fwd_frames": ([C.POINTER(RenderDesc), _P, _I32, _I32, _P, _P, _P, _P], C.c_int),
+    "vl3d_render_fwd_frames_culled": ([C.POINTER(RenderDesc), _P, _I32, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P], C.c_int),
     "vl3d_render_bwd_scratch_bytes": ([C.POINTER(RenderDesc)], C.c_int64),
     "vl3d_render_bwd_adam_class_bytes": ([C.POINTER(RenderDesc)], C.c_int64),
     "vl3d_render_bwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P], C.c_int),

@@ -124,6 +124,14 @@ extern "C" int vl3d_render_fwd_frames(const vl3d_render_desc *desc, const void *
     return render_fwd_impl(desc, stack, homos, nullptr, 0, 0, nullptr, rgb, alpha, nullptr, stream, frame0, T_alloc);
 }
 
+extern "C" int vl3d_render_fwd_frames_culled(const vl3d_render_desc *desc, const void *stack, int32_t frame0, int32_t T_alloc, const float *homos,
+                                             const uint8_t *quad_keep, int32_t QH, int32_t QW, void *cull_scratch, float *rgb, float *alpha,
+                                             vl3d_stream_t stream) {
+    VL3D_REQUIRE(T_alloc > 0, "vl3d_render_fwd_frames_culled: T_alloc must be the clip length of the stack allocation");
+    VL3D_REQUIRE(quad_keep != nullptr, "vl3d_render_fwd_frames_culled: null quad map (vl3d_render_fwd_frames renders a dense model)");
+    return render_fwd_impl(desc, stack, homos, quad_keep, QH, QW, cull_scratch, rgb, alpha, nullptr, stream, frame0, T_alloc);
+}
+
 extern "C" int vl3d_render_fwd(const vl3d_render_desc *desc, const void *stack, const float *homos,
                                float *rgb, float *alpha, float *alpha_sums, vl3d_stream_t stream) {
     return render_fwd_impl(desc, stack, homos, nullptr, 0, 0, nullptr, rgb, alpha, alpha_sums, stream);

@@ -248,10 +248,11 @@ def render_planes_with_mask(stack, mask, homos, H, W, spec: RenderSpec = RenderS
     return _RenderPlanesMask.apply(stack, mask, homos, int(H), int(W), spec, bool(with_regularisers))
 
 
-def render_frame_run(stack, frame0, nframes, homos, H, W, spec: RenderSpec = RenderSpec(), out=None):
+def render_frame_run(stack, frame0, nframes, homos, H, W, spec: RenderSpec = RenderSpec(), out=None, quad_keep=None):
     """Evaluation render (no gradient) of frames frame0 .. frame0 + nframes - 1 of the clip `stack` [D,T,Hs,Ws,4], read IN PLACE
     (vl3d_render_fwd_frames) -> (rgb [n,H,W,3], alpha [n,H,W]): `render_planes(stack[:, ts], ...)` gathers the frames first -- 571 MB per
-    720p frame at D = 32 on 1.1x planes, more than the render reads.  `out`: an (rgb, alpha) pair of buffers to write into."""
+    720p frame at D = 32 on 1.1x planes, more than the render reads.  `out`: an (rgb, alpha) pair of buffers to write into; `quad_keep`
+    [D,QH,QW]: a tile-culled model (a sample inside a culled quad is not covered, as in render_planes(quad_keep=...))."""
     L.check_cuda(stack, homos)
     D, T = stack.shape[:2]
     if not stack.is_contiguous() or stack.dtype not in (torch.float32, torch.float16):
@@ -271,8 +272,18 @@ def render_frame_run(stack, frame0, nframes, homos, H, W, spec: RenderSpec = Ren
         if tuple(rgb.shape) != (nframes, H, W, 3) or tuple(alpha.shape) != (nframes, H, W) or not rgb.is_contiguous() or not alpha.is_contiguous():
             raise RuntimeError("render_frame_run: `out` must be contiguous float32 (rgb [n,H,W,3], alpha [n,H,W])")
     with torch.cuda.device(stack.device):
-        L.check(L.lib().vl3d_render_fwd_frames(desc, L.ptr(stack), int(frame0), int(T), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.stream_ptr(stack.device)),
-                "vl3d_render_fwd_frames")
+        if quad_keep is None:
+            L.check(L.lib().vl3d_render_fwd_frames(desc, L.ptr(stack), int(frame0), int(T), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.stream_ptr(stack.device)),
+                    "vl3d_render_fwd_frames")
+        else:
+            L.check_cuda(quad_keep)
+            if quad_keep.dim() != 3 or quad_keep.shape[0] != D:
+                raise RuntimeError(f"quad_keep must be [D,QH,QW] with D = {D}, got {tuple(quad_keep.shape)}")
+            qk = quad_keep if (quad_keep.dtype == torch.uint8 and quad_keep.is_contiguous()) else quad_keep.to(torch.uint8).contiguous()
+            ncull = int(L.lib().vl3d_render_cull_scratch_bytes(desc))
+            cull = torch.empty((ncull + 3) // 4, dtype=torch.float32, device=stack.device)
+            L.check(L.lib().vl3d_render_fwd_frames_culled(desc, L.ptr(stack), int(frame0), int(T), L.ptr(homos), L.ptr(qk), qk.shape[1], qk.shape[2],
+                                                          L.ptr(cull), L.ptr(rgb), L.ptr(alpha), L.stream_ptr(stack.device)), "vl3d_render_fwd_frames_culled")
     return rgb, alpha
 
 

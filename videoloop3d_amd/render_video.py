@@ -164,15 +164,17 @@ def _render_frames_in_place(module, H, W, view_extrins, view_intrins, render_t, 
     """render_frames for a dense model on the device: the plane homographies of every DISTINCT camera of the path are formed up front (the
     module's own `plane_homographies`, the same bits as its forward) and uploaded in ONE copy, every frame -- or run of consecutive frames of
     one camera -- is rendered where it lies in the clip (render.render_frame_run: no gather of stack[:, ts]), straight into a chunk buffer
-    that is converted to uint8 once.  None when the model is not one this path serves (packed / sparsified / atlas_exact / CPU)."""
+    that is converted to uint8 once (a sparsified model with its quad map).  None when the model is not one this path serves (packed /
+    atlas_exact / CPU)."""
     from .render import render_frame_run
     stack = getattr(module, "stack", None)
-    if (getattr(module, "packed", None) is not None or stack is None or not stack.is_cuda or not stack.is_contiguous() or module.is_sparse
+    if (getattr(module, "packed", None) is not None or stack is None or not stack.is_cuda or not stack.is_contiguous()
             or module.atlas_exact or module.training):
         return None
     if getattr(module, "_window_opt", None) is not None:
         module._flush_deferred_updates()
     n, T, dev = len(render_t), stack.shape[1], stack.device
+    qk = module.quad_keep.to(torch.uint8).contiguous() if (module.is_sparse and getattr(module, "quad_keep", None) is not None) else None
     ref_inv = module._on(view_extrins.device, "ref_extrin")[None, ...].inverse().to(view_extrins.dtype)
     cams, cam_of = {}, []
     for i in range(n):
@@ -200,7 +202,7 @@ def _render_frames_in_place(module, H, W, view_extrins, view_intrins, render_t, 
             t0 = int(render_t[i])
             if not (0 <= t0 and t0 + (j - i) <= T):
                 raise IndexError(f"frame index {t0} .. {t0 + j - i - 1} outside the clip of {T} frames")
-            render_frame_run(stack, t0, j - i, homos[cam_of[i]], H, W, module.spec, out=(rgb[i - c0:j - c0], alpha[i - c0:j - c0]))
+            render_frame_run(stack, t0, j - i, homos[cam_of[i]], H, W, module.spec, out=(rgb[i - c0:j - c0], alpha[i - c0:j - c0]), quad_keep=qk)
             i = j
         m = c1 - c0
         x = rgb[:m]
