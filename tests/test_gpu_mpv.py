@@ -869,6 +869,28 @@ def test_packed_model_trains_and_renders_like_the_dense_one(dev):
     assert torch.equal(ra, rb)
 
 
+def test_offline_renderer_reads_sparsified_and_packed_models_in_place(dev):
+    """render_video.render_frames on a sparsified dense model (frames read where they lie, vl3d_render_fwd_frames_culled) and on its packed
+    twin (the pool through the block table, frame indices uploaded once): the frames of the loop over the module's eval forward, and the two
+    models agree -- a camera per frame, a fixed camera's run with a wrap-around, any chunk size."""
+    from videoloop3d_amd import render_video as RV
+    dense, packed, (H, W, K, tar) = _sparsified_pair(dev)
+    n = 7
+    ext = np.stack([tar.copy() for _ in range(n)]).astype(np.float32)
+    for i in range(n):
+        ext[i, 0, 3] += 0.004 * i
+        ext[i, 1, 3] -= 0.003 * i
+    intr = np.stack([K.astype(np.float32)] * n)
+    fixed = np.stack([tar.astype(np.float32)] * n)
+    for extr, ts in ((ext, [0, 1, 2, 3, 4, 0, 1]), (fixed, [3, 4, 0, 1, 2, 3, 4]), (ext, [2, 2, 4, 1, 0, 3, 3])):
+        loop_d = RV.render_frames(dense, H, W, extr, intr, ts, in_place=False)
+        loop_p = RV.render_frames(packed, H, W, extr, intr, ts, in_place=False)
+        assert torch.equal(loop_d, loop_p) and float(loop_d.float().std()) > 1.0
+        for chunk in (64, 3, 1):
+            assert torch.equal(RV.render_frames(dense, H, W, extr, intr, ts, max_batch=chunk), loop_d), (ts, chunk)
+            assert torch.equal(RV.render_frames(packed, H, W, extr, intr, ts, max_batch=chunk), loop_d), (ts, chunk)
+
+
 def test_packed_model_exports_the_reference_layout_like_the_dense_one(dev):
     dense, packed, _ = _sparsified_pair(dev, frames=3)
     a, b = dense.reference_state_dict(), packed.reference_state_dict()

@@ -43,7 +43,6 @@ struct RenderArgs {
     const float *g_alpha;
     float *g_stack;
     int D, T, Hs, Ws, H, W, row0, col0;
-    int Tstride;          // frames between two planes of the stack allocation (= T but for vl3d_render_fwd_frames: a run of frames of a longer clip); read by the plain forward kernels only
     float pc, sx, sy, ox, oy;
     float *asum;          // forward out (optional): per pixel (sum_k a_k, sum_k a_k^2) for the sparsity regulariser (MPV.py:511-515)
     const float *g_asum;  // backward in (optional): per pixel dL/d(sum a), dL/d(sum a^2)
@@ -63,6 +62,9 @@ struct RenderArgs {
     // tile culling (optional): quad_keep [D][QH][QW] bytes, 1 = the quad (cell of the plane's vertex grid) may be visible.
     // cull_masks (forward): per 64x8-pixel workgroup two 64-bit words, bit d = plane d can contribute to the workgroup.
     int g_f16;               // the stack is fp16 (8-byte texels) and so is its gradient
+    int Tstride;             // frames between two planes of the stack allocation (= T but for vl3d_render_fwd_frames: a run of frames of a longer clip);
+                             // read by the plain forward kernels only.  (HERE, in the padding behind g_f16: as a ninth int behind col0 it shifted every
+                             // later kernel argument by 4 bytes and the cfg3 frame-pair backward measured 13.4-14.2 against 12.3-12.5 ms, profiles/r05d_ab_lib.txt)
     const unsigned char *quad_keep;
     int QH, QW;
     const unsigned long long *cull_masks;

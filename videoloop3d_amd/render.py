@@ -324,10 +324,12 @@ def render_planes_with_regularisers(stack, homos, H, W, spec: RenderSpec = Rende
 
 
 @torch.no_grad()
-def render_planes_packed(layout, pool, frames, homos, H, W, spec: RenderSpec, quad_keep, culled_alpha):
+def render_planes_packed(layout, pool, frames, homos, H, W, spec: RenderSpec, quad_keep, culled_alpha, out=None, frames_dev=None):
     """The forward of a PACKED tile-culled model straight from its pool (videoloop3d_amd/packed.py; the reference renders a sparsified model
     from its tile lists, MPV.py:389-449): rgb [n,H,W,3], alpha [n,H,W] for the chosen `frames` -- the bits of the culled render of the
-    unpacked frames, without ever building them.  No gradient (evaluation renders; training goes through the optimiser's window copy)."""
+    unpacked frames, without ever building them.  No gradient (evaluation renders; training goes through the optimiser's window copy).
+    `out`: (rgb, alpha) buffers to write into; `frames_dev`: the same frame indices as an int32 device tensor (a caller rendering a long path
+    uploads them once instead of per call)."""
     L.check_cuda(pool, homos, quad_keep, layout.blocks)
     if spec.coord_mode != "affine" or spec.border != "hardcut" or spec.act_order != "post":
         raise RuntimeError("a packed model renders in the planar MPV convention (RenderSpec.mpv())")
@@ -346,10 +348,20 @@ def render_planes_packed(layout, pool, frames, homos, H, W, spec: RenderSpec, qu
     d.pixel_center = float(spec.pixel_center)
     d.sx, d.sy, d.ox, d.oy = float(spec.scale[0]), float(spec.scale[1]), float(spec.offset[0]), float(spec.offset[1])
     dev = pool.device
-    qk = quad_keep.to(torch.uint8).contiguous()
-    ft = torch.tensor(frames, dtype=torch.int32).to(dev, non_blocking=True)
-    rgb = torch.empty((len(frames), H, W, 3), dtype=torch.float32, device=dev)
-    alpha = torch.empty((len(frames), H, W), dtype=torch.float32, device=dev)
+    qk = quad_keep if (quad_keep.dtype == torch.uint8 and quad_keep.is_contiguous()) else quad_keep.to(torch.uint8).contiguous()
+    if frames_dev is not None:
+        if frames_dev.dtype != torch.int32 or frames_dev.numel() != len(frames) or not frames_dev.is_contiguous() or frames_dev.device != dev:
+            raise RuntimeError("render_planes_packed: frames_dev must be the contiguous int32 device copy of `frames`")
+        ft = frames_dev
+    else:
+        ft = torch.tensor(frames, dtype=torch.int32).to(dev, non_blocking=True)
+    if out is None:
+        rgb = torch.empty((len(frames), H, W, 3), dtype=torch.float32, device=dev)
+        alpha = torch.empty((len(frames), H, W), dtype=torch.float32, device=dev)
+    else:
+        rgb, alpha = out
+        if tuple(rgb.shape) != (len(frames), H, W, 3) or tuple(alpha.shape) != (len(frames), H, W) or not rgb.is_contiguous() or not alpha.is_contiguous():
+            raise RuntimeError("render_planes_packed: `out` must be contiguous float32 (rgb [n,H,W,3], alpha [n,H,W])")
     with torch.cuda.device(dev):
         L.check(L.lib().vl3d_render_fwd_packed(d, L.ptr(layout.blocks), L.ptr(pool), L.ptr(ft), len(frames), L.ptr(homos), L.ptr(qk), qk.shape[1],
                                                qk.shape[2], float(culled_alpha), L.ptr(rgb), L.ptr(alpha), L.stream_ptr(dev)), "vl3d_render_fwd_packed")

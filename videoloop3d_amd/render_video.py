@@ -164,16 +164,19 @@ def _render_frames_in_place(module, H, W, view_extrins, view_intrins, render_t, 
     """render_frames for a dense model on the device: the plane homographies of every DISTINCT camera of the path are formed up front (the
     module's own `plane_homographies`, the same bits as its forward) and uploaded in ONE copy, every frame -- or run of consecutive frames of
     one camera -- is rendered where it lies in the clip (render.render_frame_run: no gather of stack[:, ts]), straight into a chunk buffer
-    that is converted to uint8 once (a sparsified model with its quad map).  None when the model is not one this path serves (packed /
-    atlas_exact / CPU)."""
-    from .render import render_frame_run
-    stack = getattr(module, "stack", None)
-    if (getattr(module, "packed", None) is not None or stack is None or not stack.is_cuda or not stack.is_contiguous()
-            or module.atlas_exact or module.training):
+    that is converted to uint8 once (a sparsified model with its quad map; a packed one through its block table).  None when the model is
+    not one this path serves (atlas_exact / CPU)."""
+    from .render import render_frame_run, render_planes_packed
+    packed = getattr(module, "packed", None)
+    stack = module.stack_pool.data if packed is not None else getattr(module, "stack", None)
+    if stack is None or not stack.is_cuda or not stack.is_contiguous() or module.atlas_exact or module.training:
         return None
     if getattr(module, "_window_opt", None) is not None:
         module._flush_deferred_updates()
-    n, T, dev = len(render_t), stack.shape[1], stack.device
+    n, T, dev = len(render_t), (packed.T if packed is not None else stack.shape[1]), stack.device
+    if packed is not None:      # a packed model reads its pool through the block table (vl3d_render_fwd_packed): the frame indices go up once
+        from .tiles import CULLED_ALPHA
+        t_dev = torch.as_tensor(render_t.astype(np.int32)).pin_memory().to(dev, non_blocking=True)
     qk = module.quad_keep.to(torch.uint8).contiguous() if (module.is_sparse and getattr(module, "quad_keep", None) is not None) else None
     ref_inv = module._on(view_extrins.device, "ref_extrin")[None, ...].inverse().to(view_extrins.dtype)
     cams, cam_of = {}, []
@@ -202,7 +205,11 @@ def _render_frames_in_place(module, H, W, view_extrins, view_intrins, render_t, 
             t0 = int(render_t[i])
             if not (0 <= t0 and t0 + (j - i) <= T):
                 raise IndexError(f"frame index {t0} .. {t0 + j - i - 1} outside the clip of {T} frames")
-            render_frame_run(stack, t0, j - i, homos[cam_of[i]], H, W, module.spec, out=(rgb[i - c0:j - c0], alpha[i - c0:j - c0]), quad_keep=qk)
+            if packed is not None:
+                render_planes_packed(packed, stack, render_t[i:j].tolist(), homos[cam_of[i]], H, W, module.spec, qk, CULLED_ALPHA,
+                                     out=(rgb[i - c0:j - c0], alpha[i - c0:j - c0]), frames_dev=t_dev[i:j])
+            else:
+                render_frame_run(stack, t0, j - i, homos[cam_of[i]], H, W, module.spec, out=(rgb[i - c0:j - c0], alpha[i - c0:j - c0]), quad_keep=qk)
             i = j
         m = c1 - c0
         x = rgb[:m]
