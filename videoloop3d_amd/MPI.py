@@ -55,9 +55,10 @@ class _LoopMaskLabel(torch.autograd.Function):
 
 def crop_aware_pays(stack_shape, view_h, view_w):
     """The rule behind args.crop_aware_adam = "auto" (MPMesh.get_optimizer): a stack [D,1,Hs,Ws,4] fp32 of >= 768 MB of which a view_h x
-    view_w view reaches at most half a plane."""
+    view_w view reaches at most a THIRD of a plane (half, until the one-pass Adam learnt to skip the texels no view has reached: the whole-
+    stack step of a 720p frame on 1.6x planes went from 314 to 376 it/s, past the crop-aware 366)."""
     D_, _, Hs_, Ws_, _ = stack_shape
-    return D_ * Hs_ * Ws_ * 16 >= 768 * 2 ** 20 and view_h * view_w * 2 <= Hs_ * Ws_
+    return D_ * Hs_ * Ws_ * 16 >= 768 * 2 ** 20 and view_h * view_w * 3 <= Hs_ * Ws_
 
 
 class MPMesh(nn.Module):
@@ -182,9 +183,10 @@ class MPMesh(nn.Module):
             if crop_aware == "auto":
                 # the crop-aware engine pays where the optimiser's streams over the WHOLE stack dominate the iteration and a view reaches a minor
                 # part of it: a large stack (>= 768 MB: seven streams of it are >= 1 ms) of which a view's footprint -- the training crop, or the
-                # frame, on planes mpi_h_scale x mpi_w_scale larger -- is at most half.  Measured (profiles/s1_crop_aware.py, D = 32, it/s whole
-                # stack | crop-aware): 720p frame on 1.6x planes (1.2 GB) 314 | 361, a 360 x 640 crop of them 392 | 638; but the reference's native
-                # shape (302 MB) 852 | 690 and a 720p frame on 1.1x planes (571 MB) 470 | 397: there the extra launches cost more than the streams.
+                # frame, on planes mpi_h_scale x mpi_w_scale larger -- is at most a third.  Measured (profiles/s1_crop_aware.py, D = 32, it/s whole
+                # stack | crop-aware; round 5 session 4, with MPMesh.objective and the zero-skip Adam): a 360 x 640 crop of 720p planes at 1.6x
+                # (1.2 GB) 608 | 872; the 720p frame on them 376 | 366; the reference's native shape (302 MB) 1498 | 1049 and a 720p frame on 1.1x
+                # planes (571 MB) 470 | 389: there the window's launches and host work cost more than the streams.
                 ph, pw = min(int(getattr(a, "patch_h_size", self.H)), self.H), min(int(getattr(a, "patch_w_size", self.W)), self.W)
                 crop_aware = crop_aware_pays(tuple(self.stack.shape), ph, pw)
             if self.stack.is_cuda and not getattr(a, "torch_adam", False) and not self.atlas_exact and crop_aware:
