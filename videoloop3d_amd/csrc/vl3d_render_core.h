@@ -34,6 +34,15 @@
 
 namespace vl3d_render_detail {
 
+// occupancy targets of the two frame-pair kernels (waves per SIMD hipcc must leave room for): measurement builds override them
+// (profiles/build_variant.sh NAME -DVL3D_PAIR_MIN_WAVES=...; round 5 session 4 A/B'd 3 / 5 / 6 against 4: profiles/r05d_ab_min_waves.txt)
+#ifndef VL3D_PAIR_MIN_WAVES
+#define VL3D_PAIR_MIN_WAVES 4
+#endif
+#ifndef VL3D_FWD2X_MIN_WAVES
+#define VL3D_FWD2X_MIN_WAVES 4
+#endif
+
 struct RenderArgs {
     const float *stack;
     const float *homos;
@@ -886,7 +895,7 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
 // thread also replace occupancy as the source of memory parallelism (<= 128 VGPRs, 4 waves per SIMD).
 // CULL: tile culling (render_fwd2_k's plan and plane walk): only the planes whose bit is set for this workgroup, two frames each.
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, int TY, bool F16, bool CULL = false>
-__global__ __launch_bounds__(64 * TY, 4) void render_fwd2x_k(RenderArgs a, int tiles_x, int tiles_y) {      // >= 4 waves per SIMD: <= 128 VGPRs
+__global__ __launch_bounds__(64 * TY, VL3D_FWD2X_MIN_WAVES) void render_fwd2x_k(RenderArgs a, int tiles_x, int tiles_y) {      // >= 4 waves per SIMD: <= 128 VGPRs
     const int b = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_x = b % tiles_x, rest = b / tiles_x;
     const int tile_y = rest % tiles_y, t0 = (rest / tiles_y) * 2;
@@ -1764,7 +1773,7 @@ __device__ __forceinline__ void pair_gather_plane(const RenderArgs &a, const flo
 // neighbours' layer values through a second LDS stage, sampling pipelined one plane ahead, 128 VGPRs, 18.2 ms at cfg3 against 12.0
 // without the regularisers -- VALU bound on re-deriving signs the forward had already formed).
 template <int COORD, int BORDER, int ORDER, int RACT, int AACT, bool F16, bool REG = false, bool ADAM = false, int PW = 32>
-__global__ __launch_bounds__(PW * PROWS, 4) void render_bwd_pair_k(RenderArgs a) {      // >= 4 waves per SIMD (2 workgroups per CU at PW = 32): <= 128 VGPRs
+__global__ __launch_bounds__(PW * PROWS, VL3D_PAIR_MIN_WAVES) void render_bwd_pair_k(RenderArgs a) {      // >= 4 waves per SIMD (2 workgroups per CU at PW = 32): <= 128 VGPRs
     static_assert(PW == 32 || PW == 64, "region width");
     constexpr int PNT = PW * PROWS;
     if (!reinterpret_cast<const int *>(a.plan)[0]) return;
