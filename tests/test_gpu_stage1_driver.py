@@ -181,3 +181,8 @@ def test_fused_objective_equals_the_generic_spelling(dev, case):
         for x, y in zip(ga, gb):
             assert float((x - y).abs().max()) <= 2e-6 * max(1e-6, float(y.abs().max()))
         assert not la.requires_grad or la.grad_fn is not None
+    # the node scales its gradient buffer in place: a second backward through the same forward is refused, not silently wrong
+    lc, _, _, _ = model.objective(h, w, ext, K2, target, tmask if model.learn_loop_mask else None, scale_invariant=args.scale_invariant)
+    torch.autograd.grad(lc, params, retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        torch.autograd.grad(lc, params)

@@ -618,6 +618,10 @@ class _Stage1Objective(torch.autograd.Function):
     def backward(ctx, g_total, _g_parts):
         from . import _lib as L
         buf = ctx.buf
+        # the gradients are scaled IN PLACE (they belong to this node): it can be differentiated once, like the fused looping loss
+        if getattr(ctx, "consumed", False):
+            raise RuntimeError("the fused stage-1 objective keeps its gradient buffer in place: backward through it a second time needs a new forward")
+        ctx.consumed = True
         n, B, h, w, o_rgb, o_label, o_alpha, o_asum, o_ss, end = ctx.layout
         g = g_total if (g_total.dtype == torch.float32 and g_total.is_contiguous()) else g_total.to(torch.float32).contiguous()
         with torch.cuda.device(buf.device):
