@@ -265,6 +265,7 @@ extern "C" int vl3d_render_bwd_mask(const vl3d_render_desc *desc, const void *st
     VL3D_REQUIRE(desc->uv_noise_seed == 0, "vl3d_render_bwd_mask: add_uv_noise jitters the colour samples only (MPI.py:519-522, 568-572): render the label in a pass of its own");
     const bool want_tile = (desc->variant & 0xf) != 1 && scratch != nullptr && scratch_bytes >= vl3d_render_bwd_scratch_bytes(desc);
     a.gather9 = (desc->variant & 0xf) == 4;
+    a.owner4 = (desc->variant & 0xf) != 3 && (desc->variant & 0xf) != 4;
     if (want_tile) {
         a.plan = (const float *)scratch;
         a.owner = reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(scratch) + owner_table_off(desc));
@@ -386,6 +387,7 @@ static int render_bwd_impl(const vl3d_render_desc *desc, const void *stack, cons
                            desc->uv_noise_seed == 0;
     a.ablate = (desc->variant >> 4) & 0xf;
     a.gather9 = (desc->variant & 0xf) == 4;
+    a.owner4 = (desc->variant & 0xf) != 3 && (desc->variant & 0xf) != 4;
     if (want_tile) {
         a.plan = (const float *)scratch;
         a.owner = reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(scratch) + owner_table_off(desc));

@@ -64,6 +64,7 @@ struct RenderArgs {
     float q_x0, q_y0;           // ... with the stack being the texel window [q_y0, q_y0+Hs) x [q_x0, q_x0+Ws) of a q_Hs x q_Ws plane the
     int q_Hs, q_Ws;             // quad grid is laid over (desc->cull_*; the whole plane by default)
     int gather9;         // 1: never take the 2x2 gather (variant 4; the 3x3 gather is the definition the 2x2 one must equal bit for bit)
+    int owner4;          // 1: a single frame (T = 1) builds its owner table four texels per thread (bwd_owner_table4_k; variant 3 keeps the one-texel pass).  (In the padding behind gather9.)
     const float *plan;   // device scratch written by bwd_plan_k: [0] feasible flag, [16 + 12*d ..] inverse texel homographies,
                          // then (bwd_windows_k) one int4 texel window per (tile, plane)
     const unsigned short *owner;   // device scratch written by bwd_owner_table_k: per (plane, texel) a 6-bit code of the owner
@@ -1344,6 +1345,52 @@ __global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, i
     }
 }
 
+// ... for a SINGLE frame (T = 1: cfg2, every stage-1 iteration), four consecutive texels of a row per thread: the table is written and read
+// once there, so this pass is a quarter of the backward -- one 8-byte store of four entries without the three shuffles, row / plane
+// arithmetic once per four texels (0.414 -> 0.389 ms for a 720p backward when it was tried in round 3; not usable for T > 1, where the zero
+// fill below walks the frames at a 64-byte lane stride: 15.8 -> 19.4 ms on a 1.1x stack).  Same entries and the same zero fill as
+// bwd_owner_table_k (the owner pixel of every texel is computed by the same function on the same inputs).
+__global__ __launch_bounds__(256) void bwd_owner_table4_k(RenderArgs a, int iw, int ih, int rh, unsigned short *owner, int rw, int slot_bits) {
+    if (!reinterpret_cast<const int *>(a.plan)[0]) return;
+    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int d = blockIdx.z;
+    if (x0 >= a.Ws || y >= a.Hs) return;
+    const float *hi = a.plan + PLAN_HDR + PLAN_REC * d;
+    const unsigned ymask = slot_bits == 9 ? 15u : 7u;
+    const float inv_iw = 1.0f / (float)iw, inv_ih = 1.0f / (float)ih;
+    unsigned ent[4];
+    bool unsafe[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float qx, qy;
+        owner_pixel(hi, (float)(x0 + k), (float)y, a.pc, a.col0, a.row0, qx, qy);
+        const float rxf = fminf(fmaxf(rintf(qx), 0.0f), (float)(a.W - 1)), ryf = fminf(fmaxf(rintf(qy), 0.0f), (float)(a.H - 1));
+        const int rx = (int)rxf, ry = (int)ryf;
+        const int tx = (int)((rxf + 0.5f) * inv_iw), ty = (int)((ryf + 0.5f) * inv_ih);
+        const unsigned lc = (unsigned)((ry - ty * ih + rh) * rw + (rx - tx * iw + rh));
+        ent[k] = ((((unsigned)ty & ymask) << 3 | (unsigned)(tx & 7)) << slot_bits) | lc;
+        unsafe[k] = !((qx > 0.5f) && (qx < (float)a.W - 1.5f) && (qy > 0.5f) && (qy < (float)a.H - 1.5f));
+    }
+    const size_t row = ((size_t)d * a.Hs + y) * a.Ws;
+    unsigned short *dst = owner + row + x0;
+    if ((a.Ws & 3) == 0) {      // (x0 + 3 < Ws then; rows are 8-byte aligned)
+        *reinterpret_cast<uint2 *>(dst) = make_uint2(ent[0] | ent[1] << 16, ent[2] | ent[3] << 16);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (x0 + k < a.Ws) dst[k] = (unsigned short)ent[k];
+    }
+    // texels no tile is certain to own: zero gradient here (T = 1: one frame), the tile kernel overwrites those it does own
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!unsafe[k] || x0 + k >= a.Ws) continue;
+        if (a.g_f16) reinterpret_cast<float2 *>(a.g_stack)[row + x0 + k] = make_float2(0.f, 0.f);
+        else reinterpret_cast<float4 *>(a.g_stack)[row + x0 + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.g_mask) a.g_mask[row + x0 + k] = 0.f;
+    }
+}
+
 __global__ __launch_bounds__(256) void bwd_fill_zero_if_infeasible_k(float2 *g, size_t n8, const float *plan) {      // n8: 8-byte units
     if (reinterpret_cast<const int *>(plan)[0]) return;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) g[i] = make_float2(0.f, 0.f);
@@ -2051,8 +2098,12 @@ void launch_tile(const RenderArgs &a, hipStream_t s) {
     const int nwin = b.tiles_x * b.tiles_y * a.D;
     hipLaunchKernelGGL((bwd_windows_k<COORD>), dim3((nwin + 255) / 256), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x, b.tiles_y,
                        reinterpret_cast<int *>(const_cast<float *>(a.plan)) + plan_win_off(a.D));
-    hipLaunchKernelGGL(bwd_owner_table_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x,
-                       const_cast<unsigned short *>(a.owner), RWT, SLOT_BITS);
+    if (a.T == 1 && !a.ad.p && a.owner4)      // (a single frame: four texels per thread; the fused optimiser step keeps its per-texel records)
+        hipLaunchKernelGGL(bwd_owner_table4_k, dim3(((a.Ws + 3) / 4 + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, b, IW, IH, RH,
+                           const_cast<unsigned short *>(a.owner), RWT, SLOT_BITS);
+    else
+        hipLaunchKernelGGL(bwd_owner_table_k, dim3((a.Ws + 63) / 64, (a.Hs + 3) / 4, a.D), dim3(256), 0, s, b, IW, IH, RH, b.tiles_x,
+                           const_cast<unsigned short *>(a.owner), RWT, SLOT_BITS);
     const dim3 grid((unsigned)(b.tiles_x * b.tiles_y * a.T)), block(RWT * ROWS);
     if constexpr (ADAM) {      // (tile-culled models only: the dense fused step rides the frame pairs -- the one-frame form measured 202 against 213-218 it/s)
         hipLaunchKernelGGL((render_bwd_tile_k<COORD, BORDER, ORDER, RACT, AACT, ROWS, true, false, true, false, true, RWT>), grid, block, 0, s, b);
