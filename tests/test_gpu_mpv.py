@@ -500,6 +500,9 @@ def test_loop_mask_fifth_channel_equals_the_label_pass(dev):
             assert float((got[2] - ref[2]).abs().max()) <= tol * max(1.0, float(ref[2].abs().max())), (reg, variant)
             assert float((got[3] - ref[3]).abs().max()) <= tol * max(1.0, float(ref[3].abs().max())), (reg, variant)
             assert float(ref[3].abs().max()) > 0
+        # the flat 64 x 8 regions of the default and the 64 x 16 ones of variant 3: the same bits in both gradients
+        a0, a3 = run(False, reg, 0), run(False, reg, 3)
+        assert torch.equal(a0[2], a3[2]) and torch.equal(a0[3], a3[3]) and torch.equal(a0[0], a3[0])
 
 
 def test_loop_mask_channel_is_refused_for_other_conventions(dev):

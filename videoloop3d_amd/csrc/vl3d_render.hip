@@ -269,7 +269,9 @@ extern "C" int vl3d_render_bwd_mask(const vl3d_render_desc *desc, const void *st
     if (want_tile) {
         a.plan = (const float *)scratch;
         a.owner = reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(scratch) + owner_table_off(desc));
-        a.tile_rows = 16;
+        // flat 64 x 8 regions (two 512-thread workgroups per CU at this instantiation's 128 registers) unless variant 3 / 4 ask for the 16 rows:
+        // stage-1 iterations +3.3 % at the reference's crop, +2 % for a 720p frame (profiles/r05d_s1_mask_rows.txt), same bits
+        a.tile_rows = ((desc->variant & 0xf) == 3 || (desc->variant & 0xf) == 4) ? 16 : 8;
     } else {
         const size_t texels = (size_t)desc->D * desc->T * desc->Hs * desc->Ws;
         VL3D_HIP(hipMemsetAsync(grad_stack, 0, texels * 16, (hipStream_t)stream));

@@ -2131,7 +2131,12 @@ void launch_t(const RenderArgs &a, hipStream_t s) {
             if constexpr (MASKABLE) {
                 if (a.mask) {      // one frame per thread, fifth channel in the sweep and the gather
                     hipLaunchKernelGGL(bwd_fill_zero_f32_if_infeasible_k, dim3(1024), dim3(256), 0, s, a.g_mask, (size_t)a.D * a.T * a.Hs * a.Ws, a.plan);
-                    if (a.g_reg || a.g_asum) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, false, true>(a, s);
+                    // (flat 64 x 8 regions, tile_rows 8: 512 threads at this instantiation's 128-register budget are TWO workgroups per CU -- the
+                    // 1024-thread regions run alone on theirs; variant 3 keeps the 16 rows)
+                    if (a.tile_rows == 8) {
+                        if (a.g_reg || a.g_asum) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 8, true, false, true>(a, s);
+                        else launch_tile<COORD, BORDER, ORDER, RACT, AACT, 8, false, false, true>(a, s);
+                    } else if (a.g_reg || a.g_asum) launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, true, false, true>(a, s);
                     else launch_tile<COORD, BORDER, ORDER, RACT, AACT, 16, false, false, true>(a, s);
                     hipLaunchKernelGGL((render_bwd_k<COORD, BORDER, ORDER, RACT, AACT, false, true>), grid, block, 0, s, a);
                     return;
