@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""The whole path of the reference on a synthetic capture, end to end on one MI355X, through the drop-in modules and drivers:
+
+    stage 1  train_3d.py        MPMesh, crops of V stills, sparsify_faces at 85 % of the epochs        videoloop3d_amd/train_3d.py
+    hand-over                   MPMesh.state_dict() -> MPMeshVid.init_from_mpi (MPV.py:235-288)
+    stage 2  train_3dvid.py     MPMeshVid, looping loss over the pyramid levels, tile-culled model      videoloop3d_amd/train_3dvid.py
+    render   scripts/script_render_video.py    a spiral around the reference view, uint8 frames         videoloop3d_amd/render_video.py
+    export   MPV.py:290-341     the reference's checkpoint layout                                        videoloop3d_amd/export.py
+
+Synthetic clips (counter-hash noise): the numbers printed are WALL TIMES of each stage, not image quality.   python examples/pipeline.py [--small]"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+import warnings
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
+import torch
+
+
+def run(small=False, dev="cuda:0"):
+    from stage2_schedule import make_views
+    from videoloop3d_amd import render_video as RV
+    from videoloop3d_amd import train_3d, train_3dvid
+    from videoloop3d_amd.MPI import MPMesh
+    from videoloop3d_amd.MPV import MPMeshVid
+    dev = torch.device(dev)
+    H, W, V, D, T, F = (180, 320, 4, 16, 12, 20) if small else (360, 640, 8, 32, 50, 75)
+    crop, stride = ((90, 160), (90, 160)) if small else ((180, 320), (90, 160))
+    e1, e2 = (6, 2) if small else (14, 2)
+    common = dict(mpi_h_scale=1.1, mpi_w_scale=1.1, mpi_d=D, mpi_h_verts=18 if small else 36, mpi_w_verts=32 if small else 64, atlas_grid_h=4, rgb_mlp_type="direct",
+                  rgb_activate="sigmoid", alpha_activate="sigmoid", bg_color="", scale_invariant=True, optimizer="adam", lrate_decay=100,
+                  add_intrin_noise=True, patch_h_size=crop[0], patch_w_size=crop[1], patch_h_stride=stride[0], patch_w_stride=stride[1], d_smooth_loss_weight=0.0)
+    a1 = types.SimpleNamespace(**common, learn_loop_mask=True, sparsity_loss_weight=0.004, rgb_smooth_loss_weight=0.2, a_smooth_loss_weight=0.5,
+                               density_loss_weight=0.02, l_smooth_loss_weight=0.0, lrate=0.05, N_iters=e1, sparsify_epoch=int(round(e1 * 0.85)), sparsify_erode=2,
+                               sparsify_alpha_thresh=0.05, density_loss_epoch=max(1, e1 // 2), vid2img_mode="dynamic", i_weights=10 ** 9)
+    a2 = types.SimpleNamespace(**common, mpv_frm_num=T, mpv_isloop=True, init_std=0.02, add_uv_noise=False, fp16=False, swd_patch_size=3, swd_patcht_size=3,
+                               swd_stride=2, swd_stridet=1, sparsity_loss_weight=0.0, rgb_smooth_loss_weight=0.2, a_smooth_loss_weight=0.2, density_loss_weight=0.0,
+                               swd_loss_weight=1.0, lrate=0.5, lrate_adaptive=True, pyr_minimal_dim=-1, pyr_stage=str(e2), N_iters=2 * e2, pyr_factor=0.5,
+                               pyr_num_epoch=0, optimize_verts_gain=1, i_weights=10 ** 9)
+    poses, intrins, vids = make_views(V, H, W, F, dev)
+    K = intrins[0].numpy().astype(np.float64)
+    other = dict(loss_name="gpnn_lm", patch_size=3, patcht_size=3, stride=2, stridet=1, alpha=10000.0, rou="-2", scaling=0.1, dist_fn="mse", macro_block=65, factor=1)
+    ref = dict(loss_name="gpnn_lm", loss_gain=3.5, patch_size=11, patcht_size=3, stride=4, stridet=1, alpha=0.0, rou="-2", scaling=0.1, dist_fn="mse", macro_block=65, factor=1)
+    out = {}
+    sync = torch.cuda.synchronize
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sync(); t0 = time.perf_counter()
+        mpi = MPMesh(a1, H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
+        r1 = train_3d.train(mpi, a1, vids, poses, intrins, H, W, device=dev, generator=torch.Generator().manual_seed(1))
+        sync(); t1 = time.perf_counter()
+        out["stage1"] = {"seconds": t1 - t0, "iters": r1["iters"], "iters_per_s": r1["iters"] / (t1 - t0), "sparsified_at_epoch": r1["sparsified_at"],
+                         "kept_quads": float(mpi.quad_keep.float().mean()) if mpi.is_sparse else 1.0}
+        mpv = MPMeshVid(a2, H, W, np.eye(4), K, 1.0, 100.0, device=dev).to(dev)      # (device=: the 7 GB stack is created where it lives)
+        mpv.init_from_mpi(mpi.state_dict())                                  # train_3dvid.py:131-141: stage 2 starts from the stage-1 checkpoint
+        del mpi
+        sync(); t2 = time.perf_counter()
+        out["hand_over"] = {"seconds": t2 - t1, "tile_culled": bool(mpv.is_sparse)}
+        n2 = train_3dvid.train(mpv, a2, vids, poses, intrins, [ref] + [other] * (V - 1), H, W, device=dev, generator=torch.Generator().manual_seed(2))
+        sync(); t3 = time.perf_counter()
+        out["stage2"] = {"seconds": t3 - t2, "iters": n2, "iters_per_s": n2 / (t3 - t2), "levels": 2}
+        # a spiral of cameras around the reference view (the renderer's own path generator needs the capture's bounds: here a hand-made one)
+        N = 60 if small else 150
+        ext = np.stack([np.eye(4, dtype=np.float32)] * N)
+        for i in range(N):
+            a = 2 * np.pi * i / N
+            ext[i, :3, 3] = [0.05 * np.cos(a), 0.03 * np.sin(a), 0.01 * np.sin(2 * a)]
+        frames = RV.render_frames(mpv, H, W, ext, np.stack([K.astype(np.float32)] * N), np.arange(N) % T)
+        sync(); t4 = time.perf_counter()
+        out["render"] = {"seconds": t4 - t3, "frames": N, "frames_per_s": N / (t4 - t3), "shape": list(frames.shape), "dtype": str(frames.dtype)}
+        sd = mpv.state_dict()                                                 # the reference's checkpoint keys (MPV.py:290-304)
+        sync(); t5 = time.perf_counter()
+        out["export"] = {"seconds": t5 - t4, "keys": len(sd)}
+    out["total_seconds"] = t5 - t0
+    out["shape"] = f"V={V} views of {H}x{W}, D={D}, T={T}, clips of {F} frames, crops {crop[0]}x{crop[1]}, stage 1 {e1} epochs, stage 2 2 levels x {e2} epochs"
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--small", action="store_true")
+    a = ap.parse_args()
+    import __graft_entry__ as g
+    g.build()
+    run(True)      # untimed warm-up on the small scene: code objects, allocator, first-call set-up of every kernel
+    print(json.dumps(run(a.small)))

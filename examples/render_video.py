@@ -30,7 +30,7 @@ def run(H=720, W=1280, planes=32, frames=50, views=8, dev="cuda:0"):
                                  rgb_mlp_type="direct", rgb_activate="sigmoid", alpha_activate="sigmoid", bg_color="", scale_invariant=True, fp16=False,
                                  swd_patch_size=3, swd_patcht_size=3, swd_stride=2, swd_stridet=1, sparsity_loss_weight=0.0, rgb_smooth_loss_weight=0.0,
                                  a_smooth_loss_weight=0.0, density_loss_weight=0.0, d_smooth_loss_weight=0.0, optimizer="adam", lrate=0.1, lrate_decay=30)
-    model = MPMeshVid(args, H, W, ext, K.astype(np.float64), near, far).to(dev)
+    model = MPMeshVid(args, H, W, ext, K.astype(np.float64), near, far, device=dev).to(dev)
     out = {}
     for name, v in (("spiral", ""), ("fixed_view", "r0")):
         vp, vi, rt = RV.select_views_times(rposes, rintr, poses, intrins, frames, v, "")

@@ -56,7 +56,7 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
         fused_adam_backward=bool(fused))      # dense models: the optimiser step inside the render backward (vl3d_render_bwd_adam)
     poses, intrins, vids = make_views(views, H, W, clip, dev)
     K = intrins[0].numpy()
-    model = MPMeshVid(args, H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
+    model = MPMeshVid(args, H, W, np.eye(4), K, 1.0, 100.0, device=dev).to(dev).train()
     if bwd_variant:      # A/B of the backward kernels (include/vl3d.h: desc->variant bits 0-3)
         import dataclasses
         model.spec = dataclasses.replace(model.spec, variant=int(bwd_variant))

@@ -31,7 +31,7 @@ def run(iters=10, frames=50, planes=32, smooth=0.2, dev="cuda:0", crop=(180, 320
         sparsity_loss_weight=0.0, rgb_smooth_loss_weight=smooth, a_smooth_loss_weight=smooth, density_loss_weight=0.0,
         d_smooth_loss_weight=0.0)
     K = np.array([[0.9 * W, 0, W / 2], [0, 0.9 * W, H / 2], [0, 0, 1]], np.float64)
-    model = MPMeshVid(args, H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
+    model = MPMeshVid(args, H, W, np.eye(4), K, 1.0, 100.0, device=dev).to(dev).train()
     args.optimizer, args.lrate, args.lrate_decay = "adam", 0.5 * 0.01, 30
     opt = model.get_optimizer(0)        # MPV.py:199-214 (Adam, betas (0.9, 0.999), eps 6e-8): the crop-aware WindowAdam on a dense model
     if hasattr(opt, "acknowledge_fused_backward"):

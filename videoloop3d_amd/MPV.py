@@ -195,8 +195,11 @@ def stack_to_atlas(stack, grid_h):
 
 
 class MPMeshVid(nn.Module):
-    def __init__(self, args, H, W, ref_extrin, ref_intrin, near, far, pixel_center=0.5, texel_scale=(1.0, 1.0), atlas_exact=False):
-        """atlas_exact=True: sample the stack exactly like the reference samples its atlas of plane cells (MPV.py:75-81, 394-439:
+    def __init__(self, args, H, W, ref_extrin, ref_intrin, near, far, pixel_center=0.5, texel_scale=(1.0, 1.0), atlas_exact=False, device=None):
+        """device: where the plane stack is CREATED (an addition to the reference's signature: its `torch.randn` on the host followed by `.to(device)`
+        is 7 GB and ~7 s for the shipped stage-2 shape -- D = 32, T = 50, 396 x 704 planes -- before init_from_mpi overwrites it; the small camera
+        buffers still follow `.to()`).
+        atlas_exact=True: sample the stack exactly like the reference samples its atlas of plane cells (MPV.py:75-81, 394-439:
         pitch (Aw-1)/(gw*(mpi_w-1)), per-cell sub-texel origin, neighbour-cell bleed at cell edges) -- videoloop3d_amd/atlas.py.
         A parity mode for weights that come from / go to the reference (atlas_to_stack / stack_to_atlas); needs args.atlas_grid_h."""
         super().__init__()
@@ -225,7 +228,7 @@ class MPMeshVid(nn.Module):
         self.H_start, self.W_start = (mpi_h - H) // 2, (mpi_w - W) // 2
         self.register_buffer("ref_intrin_mpi", get_new_intrin(self.ref_intrin, -self.H_start, -self.W_start))
 
-        stack = torch.randn((self.mpi_d, self.frm_num, mpi_h, mpi_w, 4)) * args.init_std          # MPV.py:84-85
+        stack = torch.randn((self.mpi_d, self.frm_num, mpi_h, mpi_w, 4), device=device) * args.init_std          # MPV.py:84-85
         stack[..., -1] = -2                                                                       # MPV.py:109-110
         self.stack = nn.Parameter(stack, requires_grad=True)
 
