@@ -73,9 +73,21 @@ def run(small=False, dev="cuda:0"):
         frames = RV.render_frames(mpv, H, W, ext, np.stack([K.astype(np.float32)] * N), np.arange(N) % T)
         sync(); t4 = time.perf_counter()
         out["render"] = {"seconds": t4 - t3, "frames": N, "frames_per_s": N / (t4 - t3), "shape": list(frames.shape), "dtype": str(frames.dtype)}
-        sd = mpv.state_dict()                                                 # the reference's checkpoint keys (MPV.py:290-304)
+        sd = mpv.state_dict()                                                 # this package's checkpoint (the dense stack + quad maps)
         sync(); t5 = time.perf_counter()
         out["export"] = {"seconds": t5 - t4, "keys": len(sd)}
+        import tempfile
+        ref_sd = mpv.reference_state_dict()                                   # the REFERENCE's layout: packed tile atlases, meshes, uvs (MPV.py:290-304)
+        sync(); t6 = time.perf_counter()
+        with tempfile.TemporaryDirectory() as tmp:
+            mpv.save_mesh(os.path.join(tmp, "mesh"))                          # MPV.py:306-341: geometry.obj / static + dynamic textures for the viewer
+            mpv.save_texture(os.path.join(tmp, "tex"))
+            files = sorted(os.listdir(tmp))
+        sync(); t7 = time.perf_counter()
+        out["export_reference_layout"] = {"seconds": t6 - t5, "keys": len(ref_sd),
+                                          "atlas_dyn": list(ref_sd["atlas_dyn"].shape) if "atlas_dyn" in ref_sd else None}
+        out["export_assets"] = {"seconds": t7 - t6, "files": len(files)}
+        t5 = t7
     out["total_seconds"] = t5 - t0
     out["shape"] = f"V={V} views of {H}x{W}, D={D}, T={T}, clips of {F} frames, crops {crop[0]}x{crop[1]}, stage 1 {e1} epochs, stage 2 2 levels x {e2} epochs"
     return out

@@ -16,6 +16,7 @@ The reader of this layout is videoloop3d_amd.tiles.stack_from_reference_state (u
 round-trips (tests/test_export_cpu.py).  Unpinned like every statement about the reference's packed format: no checkpoint ships
 with the reference and its MPI.py / MPV.py cannot be imported here (oracle/ckpt_oracle.py restates the packing for the tests).
 """
+import os
 import struct
 import zlib
 
@@ -200,7 +201,7 @@ def write_png(path, img):
     img = np.ascontiguousarray(img, dtype=np.uint8)
     h, w, c = img.shape
     assert c in (3, 4)
-    raw = b"".join(b"\x00" + img[y].tobytes() for y in range(h))
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), img.reshape(h, w * c)], axis=1).tobytes()      # filter type 0 in front of every row
 
     def chunk(tag, data):
         body = tag + data
@@ -224,7 +225,10 @@ def save_texture(model, prefix, state=None):
         t = sd["atlas_dyn"].permute(0, 2, 3, 1)
         rgb = model.rgb_activate(t[..., :-1]) * model.alpha_activate(t[..., -1:])
         frames = (rgb * 255).type(torch.uint8).numpy()
-        for i, fr in enumerate(frames):
-            write_png(f"{prefix}_dyn_{i:04d}.png", fr)
-            out.append(f"{prefix}_dyn_{i:04d}.png")
+        names = [f"{prefix}_dyn_{i:04d}.png" for i in range(len(frames))]
+        # (zlib releases the interpreter lock: the T frames of a 2K x 4K dynamic atlas compress side by side -- 25 s -> a few for T = 50)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1, len(frames)))) as ex:
+            list(ex.map(write_png, names, frames))
+        out.extend(names)
     return out
