@@ -258,12 +258,13 @@ def _tile_ran():
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("spec_name", ["mpv", "utils_mpi", "hardcut_pre"])
-@pytest.mark.parametrize("shape", [(6, 2, 150, 200, 139, 187), (4, 1, 70, 300, 64, 280), (3, 1, 40, 40, 37, 35), (5, 3, 96, 130, 96, 130)])
+@pytest.mark.parametrize("shape", [(6, 2, 150, 200, 139, 187), (4, 1, 70, 300, 64, 280), (3, 1, 40, 40, 37, 35), (5, 3, 96, 130, 96, 130), (3, 1, 45, 53, 41, 50)])
 def test_bwd_variants_agree_with_oracle(dev, variant, spec_name, shape):
     """variant 0 = default dispatch (frame-pair kernels where they apply: the last shape is a 1.0x stack with T = 3, i.e. the
     pair kernel DIRECTLY against the oracle, incl. the odd tail frame; the T = 1 shapes take the flat 64 x 8 regions under "mpv"),
     1 = global atomics, 2 = the tile kernel in flat 64 x 8 regions at any T, 3 = LDS-staged owner-computes tile
-    kernel in 64 x 16 regions; near-unit-scale geometry with rotation + perspective so the owner-computes plan is feasible, odd sizes so tiles
+    kernel in 64 x 16 regions (and the one-texel owner-table pass; the last shape: one frame whose rows are no multiple of four texels -- the
+    four-texel pass's scalar stores); near-unit-scale geometry with rotation + perspective so the owner-computes plan is feasible, odd sizes so tiles
     are ragged."""
     from videoloop3d_amd.render import RenderSpec, render_planes
     D, T, Hs, Ws, H, W = shape
