@@ -456,6 +456,9 @@ int vl3d_scale_inplace(int64_t n, float *x, const float *scale, vl3d_stream_t st
  * vl3d_loop_pad_bwd: grad_rgb (T,h,w,3) = gain * (grad_x[:, t] + grad_x[:, T + t] for t < pad); grad_x (3,T+pad,h,w) with channel /
  * frame strides gx_sc / gx_st in floats (unit column stride, rows contiguous). */
 int vl3d_loop_gain(int32_t T, int32_t F, int32_t h, int32_t w, const float *rgb, const float *res, double *log_sum, vl3d_stream_t stream);
+/* ... with res (F,3,h,w) read through strides in floats (r_sf frame, r_sc channel, r_sr row; unit column stride): a crop of the captured clip as it lies. */
+int vl3d_loop_gain_strided(int32_t T, int32_t F, int32_t h, int32_t w, const float *rgb, const float *res, int64_t r_sf, int64_t r_sc, int64_t r_sr,
+                           double *log_sum, vl3d_stream_t stream);
 int vl3d_loop_pad_fwd(int32_t T, int32_t pad, int32_t h, int32_t w, const float *rgb, const double *log_sum, float *x, vl3d_stream_t stream);
 /* ... writing, beside x, its form for the NN search: x_gram = vl3d_gram_major_bytes(T + pad, h, w) bytes (for vl3d_patchnn_grams). */
 int vl3d_loop_pad_fwd_gram(int32_t T, int32_t pad, int32_t h, int32_t w, const float *rgb, const double *log_sum, float *x, float *x_gram,

@@ -438,8 +438,14 @@ def test_loss_prologue_equals_the_torch_chain(dev, gain):
     from videoloop3d_amd.MPV import _LoopPrologue
     T, F, h, w, pad = 7, 9, 37, 53, 2
     rgb = synth.hash_uniform((T, h, w, 3), seed=3).to(dev).requires_grad_(True)
-    res = synth.hash_uniform((F, 3, h, w), seed=4).to(dev)
+    # the target is a CROP of a larger clip, as the stage-2 dataset hands it out: read through its strides (vl3d_loop_gain_strided), no copy
+    clip = synth.hash_uniform((F, 3, h + 9, w + 14), seed=4).to(dev)
+    res = clip[:, :, 5:5 + h, 6:6 + w]
+    assert not res.is_contiguous()
     x, _ = _LoopPrologue.apply(rgb, res if gain else None, pad)
+    if gain:
+        x_c, _ = _LoopPrologue.apply(rgb, res.contiguous(), pad)
+        assert torch.equal(x, x_c)
     r = rgb.detach().clone().requires_grad_(True)
     rp = r.permute(0, 3, 1, 2)
     rp_pad = torch.cat([rp, rp[:pad]], 0)

@@ -65,9 +65,11 @@ class _LoopPrologue(torch.autograd.Function):
                 L.check_cuda(res)
                 if res.dim() != 4 or res.shape[1:] != (3, h, w):
                     raise RuntimeError(f"scale-invariant gain: res must be [F,3,{h},{w}], got {tuple(res.shape)}")
-                res = res.detach().to(torch.float32).contiguous()
+                # (a crop of the captured clip goes in through its strides: the copy was 23 us of a 1.7 ms tile-culled iteration)
+                res = res.detach() if (res.dtype == torch.float32 and res.stride(3) == 1) else res.detach().to(torch.float32).contiguous()
                 log_sum = torch.empty(1, dtype=torch.float64, device=dev)
-                L.check(L.lib().vl3d_loop_gain(T, res.shape[0], h, w, L.ptr(rgb), L.ptr(res), L.ptr(log_sum), L.stream_ptr(dev)), "vl3d_loop_gain")
+                L.check(L.lib().vl3d_loop_gain_strided(T, res.shape[0], h, w, L.ptr(rgb), L.ptr(res), res.stride(0), res.stride(1), res.stride(2),
+                                                       L.ptr(log_sum), L.stream_ptr(dev)), "vl3d_loop_gain")
             x = torch.empty((1, 3, T + pad, h, w), dtype=torch.float32, device=dev)
             if want_gram:      # x's form for the NN search in the same pass over the render's output (utils_vid.PreparedX)
                 xg = torch.empty(int(L.lib().vl3d_gram_major_bytes(T + pad, h, w)) // 4, dtype=torch.float32, device=dev)

@@ -112,6 +112,7 @@ SIGNATURES = {
                                        C.c_int64, _P, _P], C.c_int),
     "vl3d_scale_inplace": ([_I64, _P, _P, _P], C.c_int),
     "vl3d_loop_gain": ([_I32] * 4 + [_P, _P, _P, _P], C.c_int),
+    "vl3d_loop_gain_strided": ([_I32] * 4 + [_P, _P, _I64, _I64, _I64, _P, _P], C.c_int),
     "vl3d_loop_pad_fwd": ([_I32] * 4 + [_P, _P, _P, _P], C.c_int),
     "vl3d_loop_pad_fwd_gram": ([_I32] * 4 + [_P, _P, _P, _P, _P], C.c_int),
     "vl3d_loop_pad_bwd": ([_I32] * 4 + [_P, _I64, _I64, _P, _P, _P], C.c_int),

@@ -1733,8 +1733,9 @@ extern "C" int vl3d_scale_inplace(int64_t n, float *x, const float *scale, vl3d_
 // NCHW -> NHWC copy the render backward needs -- ~20 launches around kernels that take 0.1-0.2 ms at the training crop.  Here: one kernel
 // for the log-ratio sum, one that writes x [3,T+pad,h,w] from rgb [T,h,w,3], one that folds the pad frames' gradient back into
 // g_rgb [T,h,w,3] (the gain has no gradient: the reference detaches rgb in it).
-__global__ __launch_bounds__(256) void loop_gain_k(int T, int F, int64_t hw, const float *__restrict__ rgb, const float *__restrict__ res,
-                                                   double *__restrict__ log_sum) {
+// res (F,3,h,w) through strides in floats (r_sf frame, r_sc channel, r_sr row; unit column stride): a crop of the captured clip needs no copy
+__global__ __launch_bounds__(256) void loop_gain_k(int T, int F, int64_t hw, int w, const float *__restrict__ rgb, const float *__restrict__ res,
+                                                   int64_t r_sf, int64_t r_sc, int64_t r_sr, double *__restrict__ log_sum) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float v = 0.f;
     if (p < hw) {
@@ -1742,9 +1743,10 @@ __global__ __launch_bounds__(256) void loop_gain_k(int T, int F, int64_t hw, con
         const float *rp = rgb + p * 3;
 #pragma unroll 4
         for (int t = 0; t < T; ++t, rp += hw * 3) { r0 += rp[0]; r1 += rp[1]; r2 += rp[2]; }
-        const float *yp = res + p;
+        const int64_t py = p / w, px = p - py * w;
+        const float *yp = res + py * r_sr + px;
 #pragma unroll 4
-        for (int f = 0; f < F; ++f, yp += hw * 3) { y0 += yp[0]; y1 += yp[hw]; y2 += yp[2 * hw]; }
+        for (int f = 0; f < F; ++f, yp += r_sf) { y0 += yp[0]; y1 += yp[r_sc]; y2 += yp[2 * r_sc]; }
         const float it = 1.0f / (float)T, jf = 1.0f / (float)F;
         v = __logf((y0 * jf + 0.01f) / (r0 * it + 0.01f)) + __logf((y1 * jf + 0.01f) / (r1 * it + 0.01f)) + __logf((y2 * jf + 0.01f) / (r2 * it + 0.01f));
     }
@@ -1829,14 +1831,21 @@ __global__ __launch_bounds__(256) void loop_pad_bwd_k(int T, int pad, int64_t hw
     o[0] = v[0] * g; o[1] = v[1] * g; o[2] = v[2] * g;
 }
 
-extern "C" int vl3d_loop_gain(int32_t T, int32_t F, int32_t h, int32_t w, const float *rgb, const float *res, double *log_sum,
-                              vl3d_stream_t stream) {
+extern "C" int vl3d_loop_gain_strided(int32_t T, int32_t F, int32_t h, int32_t w, const float *rgb, const float *res, int64_t r_sf, int64_t r_sc,
+                                      int64_t r_sr, double *log_sum, vl3d_stream_t stream) {
     VL3D_REQUIRE(T > 0 && F > 0 && h > 0 && w > 0 && rgb && res && log_sum, "vl3d_loop_gain: bad arguments");
     const int64_t hw = (int64_t)h * w;
     VL3D_HIP(hipMemsetAsync(log_sum, 0, sizeof(double), (hipStream_t)stream));
-    hipLaunchKernelGGL(loop_gain_k, dim3((unsigned)ceil_div64(hw, 256)), dim3(256), 0, (hipStream_t)stream, T, F, hw, rgb, res, log_sum);
+    hipLaunchKernelGGL(loop_gain_k, dim3((unsigned)ceil_div64(hw, 256)), dim3(256), 0, (hipStream_t)stream, T, F, hw, w, rgb, res, r_sf, r_sc, r_sr,
+                       log_sum);
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
+}
+
+extern "C" int vl3d_loop_gain(int32_t T, int32_t F, int32_t h, int32_t w, const float *rgb, const float *res, double *log_sum,
+                              vl3d_stream_t stream) {
+    const int64_t hw = (int64_t)(h > 0 ? h : 0) * (w > 0 ? w : 0);
+    return vl3d_loop_gain_strided(T, F, h, w, rgb, res, 3 * hw, hw, w, log_sum, stream);
 }
 
 extern "C" int vl3d_loop_pad_fwd(int32_t T, int32_t pad, int32_t h, int32_t w, const float *rgb, const double *log_sum, float *x,
