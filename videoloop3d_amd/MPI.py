@@ -574,6 +574,7 @@ class _Stage1Objective(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rgb, label, alpha, asum, ssums, target, tmask, cfg):
+        ctx.set_materialize_grads(False)      # outputs the loss does not use come back as None, not as zero-filled tensors (a fill each, and reads in the backward kernels)
         from . import _lib as L
         L.check_cuda(rgb, target)
         B, h, w = cfg[0], cfg[1], cfg[2]
@@ -617,6 +618,8 @@ class _Stage1Objective(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_parts):
         from . import _lib as L
+        if g_total is None:
+            return (None,) * 8
         buf = ctx.buf
         # the gradients are scaled IN PLACE (they belong to this node): it can be differentiated once, like the fused looping loss
         if getattr(ctx, "consumed", False):

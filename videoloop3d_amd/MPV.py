@@ -54,6 +54,7 @@ class _LoopPrologue(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rgb, res, pad, want_gram=False):
+        ctx.set_materialize_grads(False)      # outputs the loss does not use come back as None, not as zero-filled tensors (a fill each, and reads in the backward kernels)
         from . import _lib as L
         L.check_cuda(rgb)
         T, h, w, _ = rgb.shape
@@ -85,6 +86,8 @@ class _LoopPrologue(torch.autograd.Function):
     def backward(ctx, gx, _gxg=None):
         from . import _lib as L
         T, pad, h, w = ctx.dims
+        if gx is None:
+            return None, None, None, None
         gx = gx[0]
         if gx.stride(3) != 1 or gx.stride(2) != w:
             gx = gx.contiguous()
@@ -103,6 +106,7 @@ class _PixelTerms(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, alpha, alpha_sums, eps):
+        ctx.set_materialize_grads(False)      # outputs the loss does not use come back as None, not as zero-filled tensors (a fill each, and reads in the backward kernels)
         from . import _lib as L
         ref = alpha if alpha is not None else alpha_sums
         L.check_cuda(ref)
@@ -136,6 +140,7 @@ class _SmoothTerms(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, sums, coef):
+        ctx.set_materialize_grads(False)      # outputs the loss does not use come back as None, not as zero-filled tensors (a fill each, and reads in the backward kernels)
         ctx.save_for_backward(coef)
         return tuple((sums * coef).view(2, 2).sum(1).unbind(0))      # (rgb_smooth, a_smooth): two outputs, see _PixelTerms
 
@@ -154,6 +159,7 @@ class _LinearHead(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, main, rest, coef, groups, ngroups):
+        ctx.set_materialize_grads(False)      # outputs the loss does not use come back as None, not as zero-filled tensors (a fill each, and reads in the backward kernels)
         from . import _lib as L
         L.check_cuda(main, coef)
         n = 1 + (0 if rest is None else rest.numel())
@@ -172,6 +178,8 @@ class _LinearHead(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gp):
         from . import _lib as L
+        if g is None:
+            return None, None, None, None, None
         gs = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.to(torch.float32).contiguous()
         gt = torch.empty(ctx.n, dtype=torch.float32, device=gs.device)
         with torch.cuda.device(gs.device):

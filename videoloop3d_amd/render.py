@@ -64,6 +64,7 @@ LAST_BWD_SCRATCH = None
 class _RenderPlanes(torch.autograd.Function):
     @staticmethod
     def forward(ctx, stack, homos, H, W, spec, row0, col0, with_reg, quad_keep=None, cull_window=None, grad_culled_unwritten=False, fused_adam=None):
+        ctx.set_materialize_grads(False)      # outputs the loss does not use come back as None, not as zero-filled tensors (a fill each, and reads in the backward kernels)
         L.check_cuda(stack, homos)
         # fused_adam (optim.WindowAdam with fused_backward): `stack` is its pending window leaf and the backward takes the step itself
         # (a tile-culled model: the optimiser classifies texels with ITS quad maps, the render culls with `quad_keep`: the same map, same device)
@@ -192,6 +193,7 @@ class _RenderPlanesMask(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, stack, mask, homos, H, W, spec, with_reg):
+        ctx.set_materialize_grads(False)      # outputs the loss does not use come back as None, not as zero-filled tensors (a fill each, and reads in the backward kernels)
         L.check_cuda(stack, mask, homos)
         D, T, Hs, Ws, _ = stack.shape
         if tuple(mask.shape) not in ((D, T, Hs, Ws), (D, T, Hs, Ws, 1)) or mask.dtype != torch.float32:

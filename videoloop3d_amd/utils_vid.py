@@ -316,6 +316,7 @@ class _FoldRobustMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, patch_size, patcht_size, stride, stridet, alpha, rou, scaling, y_is_constant=False, trim=None, holder=None,
                 y_prepared=None, x_prepared=None):
+        ctx.set_materialize_grads(False)      # outputs the loss does not use come back as None, not as zero-filled tensors (a fill each, and reads in the backward kernels)
         xs = x if trim is None else x[..., :trim[0], :trim[1], :trim[2]]
         nn, desc, xv, yv = find_nn_indices(xs, y, patch_size, patcht_size, stride, stridet, alpha, y_is_constant, y_prepared, x_prepared)
         dev = xv.device
@@ -342,6 +343,8 @@ class _FoldRobustMean(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 14
         (gx,) = ctx.saved_tensors
         # scaled IN PLACE (the buffer belongs to this node; an out-of-place product is one more pass over the video, 0.2 ms at 720p),
         # so the node can be differentiated once
