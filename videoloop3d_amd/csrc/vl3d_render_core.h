@@ -1116,6 +1116,8 @@ __global__ void bwd_plan_k(RenderArgs a, int rows, float *plan) {
     __syncthreads();
     if (threadIdx.x == 0) { reinterpret_cast<int *>(plan)[0] = ok_all; reinterpret_cast<int *>(plan)[1] = 0; }
     if (threadIdx.x < 4) plan[4 + threadIdx.x] = 0.0f;     // four zero floats: stand-in for g_reg when only the sparsity sums have a gradient
+    if (threadIdx.x >= 8 && threadIdx.x < 16) plan[threadIdx.x] = 0.0f;      // (the rest of the header: the caller need not clear the scratch buffer)
+    if (threadIdx.x == 2 || threadIdx.x == 3) plan[threadIdx.x] = 0.0f;
 }
 
 // Texel window of every (tile, plane): the footprint of the tile's owned pixels, from the image of its four corners

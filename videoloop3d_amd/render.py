@@ -164,9 +164,10 @@ class _RenderPlanes(torch.autograd.Function):
         g_stack = torch.empty(stack.shape, dtype=stack.dtype, device=stack.device)     # the gradient has the stack's dtype in the ABI
         with torch.cuda.device(stack.device):
             nscratch = int(L.lib().vl3d_render_bwd_scratch_bytes(ctx.desc))
-            # every word the kernels read is written by the plan kernels of the same call; only the header is cleared (flags)
+            # every word the kernels read is written by the plan kernels of the same call, the header included (bwd_plan_k): nothing to clear
             scratch = torch.empty((nscratch + 3) // 4, dtype=torch.float32, device=stack.device)
-            scratch[:16].zero_()
+            if (ctx.desc.variant & 0xf) == 1 or ctx.desc.uv_noise_seed:      # (no plan kernel will write the header: the diagnostic word reads 0)
+                scratch[:16].zero_()
             qk = ctx.quad_keep
             if qk is None:
                 L.check(L.lib().vl3d_render_bwd(ctx.desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha),
@@ -234,7 +235,8 @@ class _RenderPlanesMask(torch.autograd.Function):
         with torch.cuda.device(dev):
             nscratch = int(L.lib().vl3d_render_bwd_scratch_bytes(ctx.desc))
             scratch = torch.empty((nscratch + 3) // 4, dtype=torch.float32, device=dev)
-            scratch[:16].zero_()
+            if (ctx.desc.variant & 0xf) == 1:
+                scratch[:16].zero_()
             L.check(L.lib().vl3d_render_bwd_mask(ctx.desc, L.ptr(stack), L.ptr(mask), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.ptr(g_rgb), L.ptr(g_alpha),
                                                  L.ptr(g_label), L.ptr(g_reg), L.ptr(ctx.reg_state), L.ptr(g_asum), L.ptr(g_stack), L.ptr(g_mask),
                                                  L.ptr(scratch), nscratch, L.stream_ptr(dev)), "vl3d_render_bwd_mask")
