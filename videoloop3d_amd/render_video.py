@@ -169,7 +169,8 @@ def _render_frames_in_place(module, H, W, view_extrins, view_intrins, render_t, 
     from .render import render_frame_run, render_planes_packed
     packed = getattr(module, "packed", None)
     stack = module.stack_pool.data if packed is not None else getattr(module, "stack", None)
-    if stack is None or not stack.is_cuda or not stack.is_contiguous() or module.atlas_exact or module.training:
+    if (stack is None or not stack.is_cuda or not stack.is_contiguous() or module.atlas_exact or module.training
+            or module.args.bg_color == "random"):      # (a random background is a draw per call: the module's own path)
         return None
     if getattr(module, "_window_opt", None) is not None:
         module._flush_deferred_updates()
@@ -188,8 +189,6 @@ def _render_frames_in_place(module, H, W, view_extrins, view_intrins, render_t, 
     homos = torch.stack([h for _, h in sorted(cams.values(), key=lambda c: c[0])]).pin_memory().to(dev, non_blocking=True)      # [cameras, D, 3, 3]
     bg = None
     if len(module.args.bg_color) > 0:                                                        # MPV.py:455-461
-        if module.args.bg_color == "random":
-            return None                                                                      # (a draw per call: the module's own path)
         bg = torch.tensor([float(v) for v in module.args.bg_color.split('#')], dtype=torch.float32, device=dev)
     out = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
     chunk = max(1, min(int(chunk), n))
