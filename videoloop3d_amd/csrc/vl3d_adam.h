@@ -59,9 +59,28 @@ __device__ __forceinline__ void replay_moments(float4 &mm, float4 &vv, int from,
 // tile-culled models (quad maps keep / dyn [D][QH][QW], MPI.py:288-442): 0 = culled texel (no kept quad can read it: no parameter),
 // 1 = dynamic (a parameter per frame), 2 = static (only static quads can read it: ONE parameter, living in frame 0 -- the reference's
 // static atlas, MPV.py:235-288).  Same classification as tiles.quad_to_texel_mask / adam_tiles_k.  keep == NULL: everything dynamic.
-struct Quads { const unsigned char *keep, *dyn; int QH, QW; };
+// th, tw != 0: the TILE-EXACT layout (include/vl3d.h: a negative quad grid at the ABI) -- the plane is QH x QW tiles of th x tw texels, each quad owning
+// its border row / column (the reference's sparsified atlases, MPI.py:380-418): a texel belongs to exactly one quad and has that quad's class.
+struct Quads { const unsigned char *keep, *dyn; int QH, QW, th, tw; };
+// the ABI's (QH, QW) -> Quads: a negative grid selects the tile-exact layout of a plane of Hs x Ws = |QH| th x |QW| tw texels
+__host__ inline Quads make_quads(const unsigned char *keep, const unsigned char *dyn, int QH, int QW, int Hs, int Ws) {
+    Quads q{keep, keep ? dyn : nullptr, QH < 0 ? -QH : QH, QW < 0 ? -QW : QW, 0, 0};
+    if (keep && QH < 0 && QW < 0) { q.th = Hs / q.QH; q.tw = Ws / q.QW; }
+    return q;
+}
+// (what a caller's quad grid must satisfy: both signs equal; tile-exact planes are whole tiles of at least 2 x 2 texels)
+__host__ inline bool quad_grid_ok(int QH, int QW, int Hs, int Ws) {
+    if (QH > 0 && QW > 0) return true;
+    return QH < 0 && QW < 0 && Hs % (-QH) == 0 && Ws % (-QW) == 0 && Hs / (-QH) >= 2 && Ws / (-QW) >= 2;
+}
 __device__ __forceinline__ int texel_class(const Quads &q, int d, int x, int y, int Hs, int Ws) {
     if (!q.keep) return 1;
+    if (q.th) {      // uniform: tile-exact layout, one quad per texel ((i + 1/2) / t in fp32 is exact to the tile for i < 2^22)
+        const int qy = min((int)(((float)y + 0.5f) * (1.0f / (float)q.th)), q.QH - 1), qx = min((int)(((float)x + 0.5f) * (1.0f / (float)q.tw)), q.QW - 1);
+        const size_t i = ((size_t)d * q.QH + qy) * q.QW + qx;
+        if (!q.keep[i]) return 0;
+        return (!q.dyn || q.dyn[i]) ? 1 : 2;
+    }
     const int ylo = quad_index(y - 1, Hs, q.QH), yhi = quad_index(y + 1, Hs, q.QH), xlo = quad_index(x - 1, Ws, q.QW), xhi = quad_index(x + 1, Ws, q.QW);
     const unsigned char *k = q.keep + (size_t)d * q.QH * q.QW;
     if (!(k[ylo * q.QW + xlo] | k[ylo * q.QW + xhi] | k[yhi * q.QW + xlo] | k[yhi * q.QW + xhi])) return 0;

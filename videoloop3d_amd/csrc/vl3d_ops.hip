@@ -4,7 +4,7 @@
 // training/render hot path uses the fused kernel in vl3d_render.hip.
 #include <string.h>
 
-#include "vl3d_common.h"
+#include "vl3d_adam.h"
 
 static thread_local char g_err[256] = "";
 
@@ -298,16 +298,13 @@ extern "C" int vl3d_overcompose_nto0_bwd(int32_t B, int32_t D, int32_t C, int64_
 // In place on grad (D,T,Hs,Ws,4): texels only static quads can read -> sum over frames in every frame; texels no kept quad
 // can read -> 0; texels a dynamic quad can read -> untouched.  "Can read" = the quad's closed rectangle grown by one texel
 // (the bilinear taps of a sample inside it), as in videoloop3d_amd/tiles.py quad_to_texel_mask.
-__global__ __launch_bounds__(256) void tie_static_grad_k(int D, int T, int Hs, int Ws, const unsigned char *__restrict__ keep,
-                                                         const unsigned char *__restrict__ dyn, int QH, int QW, float4 *__restrict__ g,
+__global__ __launch_bounds__(256) void tie_static_grad_k(int D, int T, int Hs, int Ws, vl3d_adam::Quads q, float4 *__restrict__ g,
                                                          int assume_culled_zero) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), d = blockIdx.z;
     if (x >= Ws || y >= Hs) return;
-    const int ylo = quad_index(y - 1, Hs, QH), yhi = quad_index(y + 1, Hs, QH), xlo = quad_index(x - 1, Ws, QW), xhi = quad_index(x + 1, Ws, QW);
-    const unsigned char *k = keep + (size_t)d * QH * QW, *m = dyn + (size_t)d * QH * QW;
-    const bool kept = k[ylo * QW + xlo] | k[ylo * QW + xhi] | k[yhi * QW + xlo] | k[yhi * QW + xhi];
-    const bool dynamic = m[ylo * QW + xlo] | m[ylo * QW + xhi] | m[yhi * QW + xlo] | m[yhi * QW + xhi];
-    if (dynamic && kept) return;
+    const int cls = vl3d_adam::texel_class(q, d, x, y, Hs, Ws);      // 0 culled, 1 dynamic, 2 static (shared-border or tile-exact layout)
+    const bool kept = cls != 0;
+    if (cls == 1) return;
     const size_t frame = (size_t)Hs * Ws;
     float4 *p = g + (size_t)d * T * frame + (size_t)y * Ws + x;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -326,10 +323,10 @@ __global__ __launch_bounds__(256) void tie_static_grad_k(int D, int T, int Hs, i
 
 extern "C" int vl3d_tie_static_grad(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uint8_t *quad_keep, const uint8_t *quad_dyn,
                                     int32_t QH, int32_t QW, float *grad, int32_t assume_culled_zero, vl3d_stream_t stream) {
-    VL3D_REQUIRE(D > 0 && T > 0 && Hs > 0 && Ws > 0 && QH > 0 && QW > 0 && D <= 65535, "vl3d_tie_static_grad: bad dims");
+    VL3D_REQUIRE(D > 0 && T > 0 && Hs > 0 && Ws > 0 && vl3d_adam::quad_grid_ok(QH, QW, Hs, Ws) && D <= 65535, "vl3d_tie_static_grad: bad dims / quad grid");
     VL3D_REQUIRE(quad_keep && quad_dyn && grad, "vl3d_tie_static_grad: null pointer");
-    hipLaunchKernelGGL(tie_static_grad_k, dim3((Ws + 63) / 64, (Hs + 3) / 4, D), dim3(256), 0, (hipStream_t)stream, D, T, Hs, Ws, quad_keep,
-                       quad_dyn, QH, QW, reinterpret_cast<float4 *>(grad), assume_culled_zero);
+    hipLaunchKernelGGL(tie_static_grad_k, dim3((Ws + 63) / 64, (Hs + 3) / 4, D), dim3(256), 0, (hipStream_t)stream, D, T, Hs, Ws,
+                       vl3d_adam::make_quads(quad_keep, quad_dyn, QH, QW, Hs, Ws), reinterpret_cast<float4 *>(grad), assume_culled_zero);
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
 }
@@ -339,21 +336,16 @@ extern "C" int vl3d_tie_static_grad(int32_t D, int32_t T, int32_t Hs, int32_t Ws
 // the texels a kept quad can read.  Culled texels never receive a gradient, so their moments stay 0 and Adam would leave them
 // unchanged anyway -- skipping them removes 7 streams over the culled part of the stack (the optimiser is 2/3 of a stage-2
 // iteration on the dense stack).  m, v, p are updated in place; bc1 = 1 - beta1^step, bc2s = sqrt(1 - beta2^step).
-__global__ __launch_bounds__(256) void adam_tiles_k(int T, int Hs, int Ws, const unsigned char *__restrict__ keep,
-                                                    const unsigned char *__restrict__ dyn, int QH, int QW,
+__global__ __launch_bounds__(256) void adam_tiles_k(int T, int Hs, int Ws, vl3d_adam::Quads q,
                                                     float4 *__restrict__ p, const float4 *__restrict__ g, float4 *__restrict__ m,
                                                     float4 *__restrict__ v, float lr_bc1, float beta1, float beta2, float eps, float bc2s) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), d = blockIdx.z;
     if (x >= Ws || y >= Hs) return;
     bool is_static = false;
-    if (keep) {
-        const int ylo = quad_index(y - 1, Hs, QH), yhi = quad_index(y + 1, Hs, QH), xlo = quad_index(x - 1, Ws, QW), xhi = quad_index(x + 1, Ws, QW);
-        const unsigned char *k = keep + (size_t)d * QH * QW;
-        if (!(k[ylo * QW + xlo] | k[ylo * QW + xhi] | k[yhi * QW + xlo] | k[yhi * QW + xhi])) return;
-        if (dyn) {
-            const unsigned char *m_ = dyn + (size_t)d * QH * QW;
-            is_static = !(m_[ylo * QW + xlo] | m_[ylo * QW + xhi] | m_[yhi * QW + xlo] | m_[yhi * QW + xhi]);
-        }
+    if (q.keep) {
+        const int cls = vl3d_adam::texel_class(q, d, x, y, Hs, Ws);      // 0 culled, 1 dynamic, 2 static
+        if (cls == 0) return;
+        is_static = cls == 2;
     }
     const size_t frame = (size_t)Hs * Ws;
     size_t o = (size_t)d * T * frame + (size_t)y * Ws + x;
@@ -393,9 +385,9 @@ static int adam_step_tiles_impl(int32_t D, int32_t T, int32_t Hs, int32_t Ws, co
                                 float beta1, float beta2, float eps, float bc2s, vl3d_stream_t stream) {
     VL3D_REQUIRE(D > 0 && D <= 65535 && T > 0 && Hs > 0 && Ws > 0, "vl3d_adam_step_tiles: bad dims");
     VL3D_REQUIRE(param && grad && exp_avg && exp_avg_sq, "vl3d_adam_step_tiles: null pointer");
-    VL3D_REQUIRE(!quad_keep || (QH > 0 && QW > 0), "vl3d_adam_step_tiles: bad quad grid");
-    hipLaunchKernelGGL(adam_tiles_k, dim3((Ws + 63) / 64, (Hs + 3) / 4, D), dim3(256), 0, (hipStream_t)stream, T, Hs, Ws, quad_keep,
-                       quad_keep ? quad_dyn : nullptr, QH, QW,
+    VL3D_REQUIRE(!quad_keep || vl3d_adam::quad_grid_ok(QH, QW, Hs, Ws), "vl3d_adam_step_tiles: bad quad grid");
+    hipLaunchKernelGGL(adam_tiles_k, dim3((Ws + 63) / 64, (Hs + 3) / 4, D), dim3(256), 0, (hipStream_t)stream, T, Hs, Ws,
+                       vl3d_adam::make_quads(quad_keep, quad_dyn, QH, QW, Hs, Ws),
                        reinterpret_cast<float4 *>(param), reinterpret_cast<const float4 *>(grad), reinterpret_cast<float4 *>(exp_avg),
                        reinterpret_cast<float4 *>(exp_avg_sq), lr_bc1, beta1, beta2, eps, bc2s);
     VL3D_CHECK_LAUNCH();

@@ -275,12 +275,12 @@ extern "C" int vl3d_adam_flush_older(int32_t D, int32_t T, int32_t Hs, int32_t W
     VL3D_REQUIRE(D > 0 && D <= 65535 && T > 0 && Hs > 0 && Ws > 0, "vl3d_adam_flush_older: bad dims");
     VL3D_REQUIRE(!blocks || quad_keep, "vl3d_adam_flush_older: the packed layout belongs to a tile-culled model (quad maps)");
     VL3D_REQUIRE(param && exp_avg && exp_avg_sq && last_step && hist && upto >= 0 && min_depth >= 1, "vl3d_adam_flush_older: null pointer / bad step");
-    VL3D_REQUIRE(!quad_keep || (QH > 0 && QW > 0), "vl3d_adam_flush_older: bad quad grid");
+    VL3D_REQUIRE(!quad_keep || quad_grid_ok(QH, QW, Hs, Ws), "vl3d_adam_flush_older: bad quad grid");
     static_assert(TS * TS == 64, "one wave per bookkeeping tile");
     const int tiles_y = (Hs + TS - 1) / TS, tiles_x = (Ws + TS - 1) / TS;
     hipLaunchKernelGGL(adam_flush_older_k, dim3(tiles_y * tiles_x, D), dim3(64), 0, (hipStream_t)stream, T, Hs, Ws, reinterpret_cast<float4 *>(param),
                        reinterpret_cast<float4 *>(exp_avg), reinterpret_cast<float4 *>(exp_avg_sq), last_step, tiles_y, tiles_x,
-                       reinterpret_cast<const float2 *>(hist), upto, min_depth, beta1, beta2, eps, Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW}, Layout{blocks});
+                       reinterpret_cast<const float2 *>(hist), upto, min_depth, beta1, beta2, eps, make_quads(quad_keep, quad_dyn, QH, QW, Hs, Ws), Layout{blocks});
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
 }
@@ -294,14 +294,14 @@ extern "C" int vl3d_adam_window_catchup_boxes(int32_t D, int32_t T, int32_t Hs, 
     VL3D_REQUIRE(!blocks || quad_keep, "vl3d_adam_window_catchup: the packed layout belongs to a tile-culled model (quad maps)");
     if (rc != VL3D_OK) return rc;
     VL3D_REQUIRE(param && exp_avg && exp_avg_sq && last_step && hist && upto >= 0, "vl3d_adam_window_catchup: null pointer / negative step");
-    VL3D_REQUIRE(!quad_keep || (QH > 0 && QW > 0), "vl3d_adam_window_catchup: bad quad grid");
+    VL3D_REQUIRE(!quad_keep || quad_grid_ok(QH, QW, Hs, Ws), "vl3d_adam_window_catchup: bad quad grid");
     const BoxTable boxes = make_boxes(plane_boxes, D);
     const int tiles_y = (Hs + TS - 1) / TS, tiles_x = (Ws + TS - 1) / TS;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_window_catchup_k, dim3((ww + 63) / 64, (wh + 3) / 4, D), dim3(256), 0, s, T, Hs, Ws, Win{y0, x0, wh, ww},
                        reinterpret_cast<float4 *>(param), reinterpret_cast<float4 *>(exp_avg), reinterpret_cast<float4 *>(exp_avg_sq), last_step,
                        tiles_y, tiles_x, reinterpret_cast<const float2 *>(hist), upto, beta1, beta2, eps, reinterpret_cast<float4 *>(compact),
-                       Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW}, culled_alpha, mirror_static, compact ? 0 : 1,
+                       make_quads(quad_keep, quad_dyn, QH, QW, Hs, Ws), culled_alpha, mirror_static, compact ? 0 : 1,
                        boxes, Layout{blocks});
     if (!compact) {      // a flush writes the replayed state back and marks the tiles; a catch-up for a render only fills the compact copy
         const int nty = (y0 + wh + TS - 1) / TS - y0 / TS, ntx = (x0 + ww + TS - 1) / TS - x0 / TS;
@@ -336,7 +336,7 @@ static int window_step_impl(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_
     hipLaunchKernelGGL(adam_window_step_k, dim3((ww + 63) / 64, (wh + 3) / 4, D), dim3(256), 0, s, T, Hs, Ws, Win{y0, x0, wh, ww},
                        reinterpret_cast<float4 *>(param), reinterpret_cast<const float4 *>(grad_compact), reinterpret_cast<float4 *>(exp_avg),
                        reinterpret_cast<float4 *>(exp_avg_sq), (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2),
-                       Quads{quad_keep, quad_keep ? quad_dyn : nullptr, QH, QW}, static_tied, last_step, tiles_y, tiles_x,
+                       make_quads(quad_keep, quad_dyn, QH, QW, Hs, Ws), static_tied, last_step, tiles_y, tiles_x,
                        reinterpret_cast<const float2 *>(hist), (int)step, boxes, Layout{blocks}, dyn_stepped);
     const int nty = (y0 + wh + TS - 1) / TS - y0 / TS, ntx = (x0 + ww + TS - 1) / TS - x0 / TS;
     hipLaunchKernelGGL(mark_tiles_k, dim3((D * nty * ntx + 255) / 256), dim3(256), 0, s, last_step, tiles_y, tiles_x, y0 / TS, x0 / TS, nty, ntx, D, (int)step, boxes);
@@ -364,7 +364,7 @@ int vl3d_adam_window_step_tail(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int
         int rc = check_window(D, T, Hs, Ws, y0, x0, wh, ww);
         if (rc != VL3D_OK) return rc;
         VL3D_REQUIRE(!plane_boxes || (boxes_dev && D <= MAX_BOX_PLANES), "vl3d_render_bwd_adam: per-plane boxes need boxes_scratch and at most 128 planes");
-        VL3D_REQUIRE(!quad_keep || (QH > 0 && QW > 0), "vl3d_render_bwd_adam: bad quad grid");
+        VL3D_REQUIRE(!quad_keep || quad_grid_ok(QH, QW, Hs, Ws), "vl3d_render_bwd_adam: bad quad grid");
         if (plane_boxes) {
             const BoxTable boxes = make_boxes(plane_boxes, D);
             for (int d = 0; d < D; ++d) {

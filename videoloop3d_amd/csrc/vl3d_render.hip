@@ -69,6 +69,17 @@ static void set_cull_geometry(RenderArgs &a, const vl3d_render_desc *desc, int32
     a.q_Ws = win ? desc->cull_Ws : desc->Ws;
     a.q_x0 = win ? (float)desc->cull_col0 : 0.0f;
     a.q_y0 = win ? (float)desc->cull_row0 : 0.0f;
+    a.q_th = a.q_tw = 0;
+    if (QH < 0 && QW < 0) {
+        // TILE-EXACT layout (include/vl3d.h): the plane is |QH| x |QW| tiles of th x tw texels, every quad owning its border row / column; the
+        // homography + (sx, ox) give LATTICE coordinates (a quad spans tw - 1 of them), the kernels add the quad index (make_taps_i)
+        a.QH = -QH; a.QW = -QW;
+        a.q_th = a.q_Hs / a.QH; a.q_tw = a.q_Ws / a.QW;
+        a.q_inv_cw = 1.0f / (float)(a.q_tw > 1 ? a.q_tw - 1 : 1);
+        a.q_inv_ch = 1.0f / (float)(a.q_th > 1 ? a.q_th - 1 : 1);
+        return;
+    }
+    a.QH = QH; a.QW = QW;
     a.q_inv_cw = (float)QW / (float)(a.q_Ws > 1 ? a.q_Ws - 1 : 1);
     a.q_inv_ch = (float)QH / (float)(a.q_Hs > 1 ? a.q_Hs - 1 : 1);
 }
@@ -76,7 +87,14 @@ static void set_cull_geometry(RenderArgs &a, const vl3d_render_desc *desc, int32
 static int check_cull(const vl3d_render_desc *desc, const uint8_t *quad_keep, int32_t QH, int32_t QW) {
     if (!quad_keep) return VL3D_OK;
     VL3D_REQUIRE(desc->coord_mode != VL3D_COORD_AFFINE_PLANES, "tile culling is not available with per-plane texel transforms");
-    VL3D_REQUIRE(QH > 0 && QW > 0, "tile culling: non-positive quad grid");
+    VL3D_REQUIRE((QH > 0 && QW > 0) || (QH < 0 && QW < 0), "tile culling: empty quad grid (both positive, or both negative for the tile-exact layout)");
+    if (QH < 0) {
+        const int pH = desc->cull_Hs > 0 ? desc->cull_Hs : desc->Hs, pW = desc->cull_Ws > 0 ? desc->cull_Ws : desc->Ws;
+        VL3D_REQUIRE(pH % (-QH) == 0 && pW % (-QW) == 0 && pH / (-QH) >= 2 && pW / (-QW) >= 2,
+                     "tile-exact layout: the plane must be |QH| x |QW| whole tiles of at least 2 x 2 texels");
+        VL3D_REQUIRE(desc->coord_mode == VL3D_COORD_AFFINE && desc->border_mode == VL3D_BORDER_HARDCUT,
+                     "tile-exact layout: the planar MPV / MPI convention only (VL3D_COORD_AFFINE, VL3D_BORDER_HARDCUT)");
+    }
     VL3D_REQUIRE((desc->cull_Hs == 0 && desc->cull_Ws == 0) ||
                      (desc->cull_row0 >= 0 && desc->cull_col0 >= 0 && desc->cull_row0 + desc->Hs <= desc->cull_Hs && desc->cull_col0 + desc->Ws <= desc->cull_Ws),
                  "tile culling: the stack window (cull_row0, cull_col0) + (Hs, Ws) leaves the plane (cull_Hs, cull_Ws)");

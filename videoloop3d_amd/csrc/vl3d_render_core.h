@@ -101,6 +101,11 @@ struct RenderArgs {
     int grad_culled_unwritten;   // desc->grad_flags bit 0: texels owned on a plane the workgroup skips (all of them culled) are not zero-filled
     // the optimiser step fused into the owner store (vl3d_render_bwd_adam; ad.p == NULL otherwise): `stack` is the optimiser's compact window copy
     vl3d_adam_epilogue ad;
+    // TILE-EXACT layout of a tile-culled model (include/vl3d.h "Tile-exact layout": a NEGATIVE quad grid at the ABI): every quad owns a tile of
+    // q_th x q_tw texels with its OWN border row / column, as the reference's sparsified atlases store them (MPI.py:380-418); the plane is
+    // QH * q_th x QW * q_tw texels and a sample's texel coordinate is its shared-border (lattice) coordinate plus its quad index.  0: quads share
+    // their border texels.  (At the END of the struct: no earlier kernel argument moves -- see Tstride above.)
+    int q_th, q_tw;
 };
 
 // one entry point per compiled convention (coord_mode, border_mode, act_order): vl3d_render_c*.hip
@@ -122,7 +127,8 @@ using vl3d_render_detail::RenderArgs;
 __device__ __forceinline__ bool box_touches_kept_quad(const RenderArgs &a, int d, float tnx, float txx, float tny, float txy) {
     tnx += a.q_x0; txx += a.q_x0; tny += a.q_y0; txy += a.q_y0;       // window-local -> plane texel coordinates
     if (!(txx >= -2.0f && tnx <= (float)a.q_Ws + 1.0f && txy >= -2.0f && tny <= (float)a.q_Hs + 1.0f)) return !(tnx == tnx && tny == tny);   // outside the plane (NaN: keep)
-    const float cw = (float)max(a.q_Ws - 1, 1) / (float)a.QW, ch = (float)max(a.q_Hs - 1, 1) / (float)a.QH;
+    // (tile-exact layout: the box arrives in LATTICE coordinates -- texel_coord of the corners -- and a quad spans q_tw - 1 of them)
+    const float cw = a.q_tw ? (float)(a.q_tw - 1) : (float)max(a.q_Ws - 1, 1) / (float)a.QW, ch = a.q_th ? (float)(a.q_th - 1) : (float)max(a.q_Hs - 1, 1) / (float)a.QH;
     const int qx0 = max(0, (int)floorf((tnx - 2.0f) / cw)), qx1 = min(a.QW - 1, (int)floorf((txx + 2.0f) / cw));
     const int qy0 = max(0, (int)floorf((tny - 2.0f) / ch)), qy1 = min(a.QH - 1, (int)floorf((txy + 2.0f) / ch));
     const unsigned char *k = a.quad_keep + (size_t)d * a.QH * a.QW;
@@ -194,10 +200,11 @@ struct QuadCull {
     int QH, QW;
     float inv_cw, inv_ch;        // quads per texel along x / y: QW/(Ws-1), QH/(Hs-1)
     float x0, y0;                // texel origin of the stack window inside the plane (0 for a whole plane)
+    int own;                     // tile-exact layout: the texel coordinate is the lattice coordinate + the quad index (RenderArgs::q_th)
 };
 __device__ __forceinline__ QuadCull plane_cull(const RenderArgs &a, int d) {
-    if (!a.quad_keep) return QuadCull{nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f};
-    return QuadCull{a.quad_keep + (size_t)d * a.QH * a.QW, a.QH, a.QW, a.q_inv_cw, a.q_inv_ch, a.q_x0, a.q_y0};     // the two quotients come from the host: uniform, in SGPRs
+    if (!a.quad_keep) return QuadCull{nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f, 0};
+    return QuadCull{a.quad_keep + (size_t)d * a.QH * a.QW, a.QH, a.QW, a.q_inv_cw, a.q_inv_ch, a.q_x0, a.q_y0, a.q_th};     // the two quotients come from the host: uniform, in SGPRs
 }
 
 // integer form of the taps: base tap (x0,y0) with x0 <= Ws-2, y0 <= Hs-2 (so the 2x2 block is inside the plane) + weights
@@ -224,15 +231,30 @@ __device__ __forceinline__ f2 uv_jitter(UvNoise nz, float px, float py) {
 
 template <int COORD, int BORDER>
 __device__ __forceinline__ TapsI make_taps_i(const float *__restrict__ h, float px, float py, int Hs, int Ws,
-                                             float sx, float sy, float ox, float oy, QuadCull qc = QuadCull{nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f},
+                                             float sx, float sy, float ox, float oy, QuadCull qc = QuadCull{nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f, 0},
                                              UvNoise nz = UvNoise{0u, 0}) {
     TapsI t;
     const f2 px2 = f2{px, px}, py2 = f2{py, py};
     const f2 XY = __builtin_elementwise_fma(f2{h[0], h[3]}, px2, __builtin_elementwise_fma(f2{h[1], h[4]}, py2, f2{h[2], h[5]}));
     const float Z = fmaf(h[6], px, fmaf(h[7], py, h[8]));
     const f2 pxy = fast_div2(XY, Z);
-    const float tx0 = texel_coord<COORD>(pxy.x, (float)Ws / 2.0f, (float)(Ws - 1), sx, ox);
-    const float ty0 = texel_coord<COORD>(pxy.y, (float)Hs / 2.0f, (float)(Hs - 1), sy, oy);
+    float tx0 = texel_coord<COORD>(pxy.x, (float)Ws / 2.0f, (float)(Ws - 1), sx, ox);
+    float ty0 = texel_coord<COORD>(pxy.y, (float)Hs / 2.0f, (float)(Hs - 1), sy, oy);
+    // tile culling: the quad the sample falls into (cells of the plane's vertex grid, in plane coordinates: window offset added back)
+    // (the utils_mpi convention -- no tile-exact layout there -- finds its quad at the END of this function, where it always did: computed up
+    // here, hipcc contracts the coordinate's last multiply differently and the culled kernels lose their bit-equality with the plain ones)
+    int qx = 0, qy = 0;
+    if (COORD != VL3D_COORD_UTILS_MPI && qc.keep) {      // uniform branch
+        qx = min(max((int)floorf((tx0 + qc.x0) * qc.inv_cw), 0), qc.QW - 1); qy = min(max((int)floorf((ty0 + qc.y0) * qc.inv_ch), 0), qc.QH - 1);
+        // TILE-EXACT layout (MPI.py:380-418: every kept quad is a tile with its own border samples; MPV.py:394-427: a face's UVs span exactly
+        // its tile): what the homography + (sx, ox) gave is the LATTICE coordinate L (quads sharing their borders, qx = floor(L / (tw - 1)));
+        // the sample's texel coordinate inside the plane of QW x tw texels is L + qx -- local position L - qx (tw - 1) in [0, tw - 1] of tile
+        // qx, whose first texel is qx tw.  A piecewise translation: tap weights, hard cut and window offsets work on it unchanged, and the
+        // second tap of a sample never leaves its tile with a non-zero weight (local position tw - 1 exactly: weight 0).
+        if constexpr (COORD != VL3D_COORD_UTILS_MPI) {      // (the planar conventions only: check_cull refuses it elsewhere)
+            if (qc.own) { tx0 += (float)qx; ty0 += (float)qy; }
+        }
+    }
     float tx = tx0, ty = ty0;
     // (the affine conventions only -- MPV.py / MPI.py's planar path is where the reference has the flag, and the entry points refuse it
     // elsewhere: in the utils_mpi instantiations a possibly-jittered tx would also stop hipcc from contracting the last multiply of the
@@ -262,7 +284,9 @@ __device__ __forceinline__ TapsI make_taps_i(const float *__restrict__ h, float 
         t.cov = ((t.w[0] + t.w[1]) + (t.w[2] + t.w[3]) > 0.0f) ? 1.0f : 0.0f;
     }
     if (qc.keep) {      // uniform branch
-        const int qx = min(max((int)floorf((tx0 + qc.x0) * qc.inv_cw), 0), qc.QW - 1), qy = min(max((int)floorf((ty0 + qc.y0) * qc.inv_ch), 0), qc.QH - 1);
+        if constexpr (COORD == VL3D_COORD_UTILS_MPI) {
+            qx = min(max((int)floorf((tx0 + qc.x0) * qc.inv_cw), 0), qc.QW - 1); qy = min(max((int)floorf((ty0 + qc.y0) * qc.inv_ch), 0), qc.QH - 1);
+        }
         if (!qc.keep[qy * qc.QW + qx]) t.cov = 0.0f;
     }
     return t;
@@ -270,7 +294,7 @@ __device__ __forceinline__ TapsI make_taps_i(const float *__restrict__ h, float 
 
 template <int COORD, int BORDER>
 __device__ __forceinline__ Taps2 make_taps2(const float *__restrict__ h, float px, float py, int Hs, int Ws,
-                                            float sx, float sy, float ox, float oy, QuadCull qc = QuadCull{nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f},
+                                            float sx, float sy, float ox, float oy, QuadCull qc = QuadCull{nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f, 0},
                                             UvNoise nz = UvNoise{0u, 0}) {
     const TapsI ti = make_taps_i<COORD, BORDER>(h, px, py, Hs, Ws, sx, sy, ox, oy, qc, nz);
     Taps2 t;
@@ -850,7 +874,7 @@ __global__ __launch_bounds__(64 * TY) void render_fwd2_k(RenderArgs a, int tiles
         }
     } else {
     // two register sets (A/B) so the taps of plane d+1 are in flight while plane d is shaded, without register copies
-    const QuadCull noq = QuadCull{nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f};
+    const QuadCull noq = QuadCull{nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f, 0};
     Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, noq, UvNoise{a.uv_seed, 0}), tB = tA;
     load_taps2<F16>(plane, tA, st, vA);
     if constexpr (MASK) load_mask_taps(mplane, tA.off, st, mA);
@@ -1143,6 +1167,17 @@ __global__ __launch_bounds__(256) void bwd_windows_k(RenderArgs a, int iw, int i
         const float cty = texel_coord<COORD>(Y / Z, (float)a.Hs / 2.0f, (float)(a.Hs - 1), a.sy, a.oy);
         mnx = fminf(mnx, ctx); mxx = fmaxf(mxx, ctx); mny = fminf(mny, cty); mxy = fmaxf(mxy, cty);
     }
+    if (a.q_th) {
+        // tile-exact layout: the corners' images are LATTICE coordinates (window-local; + q_x0 = in the plane); a texel of quad q sits q
+        // columns to the right of its lattice position, and a lattice column on a quad border is TWO texel columns (the last of one tile,
+        // the first of the next): the lower end of the box takes the quad strictly below its coordinate, the upper end the quad at or
+        // above it (1e-3 quads of slack for the fp32 product: a larger window is only a few more table entries)
+        const float qlo_x = fminf(fmaxf(ceilf((mnx - 0.01f + a.q_x0) * a.q_inv_cw - 1e-3f) - 1.0f, 0.0f), (float)(a.QW - 1));
+        const float qhi_x = fminf(fmaxf(floorf((mxx + 0.01f + a.q_x0) * a.q_inv_cw + 1e-3f), 0.0f), (float)(a.QW - 1));
+        const float qlo_y = fminf(fmaxf(ceilf((mny - 0.01f + a.q_y0) * a.q_inv_ch - 1e-3f) - 1.0f, 0.0f), (float)(a.QH - 1));
+        const float qhi_y = fminf(fmaxf(floorf((mxy + 0.01f + a.q_y0) * a.q_inv_ch + 1e-3f), 0.0f), (float)(a.QH - 1));
+        mnx += qlo_x; mxx += qhi_x; mny += qlo_y; mxy += qhi_y;
+    }
     const int wX0 = max(0, (int)ceilf(fmaxf(mnx - 0.01f, -2.0f))), wY0 = max(0, (int)ceilf(fmaxf(mny - 0.01f, -2.0f)));
     const int wX1 = min(a.Ws - 1, (int)floorf(fminf(mxx + 0.01f, (float)a.Ws)));
     const int wY1 = min(a.Hs - 1, (int)floorf(fminf(mxy + 0.01f, (float)a.Hs)));
@@ -1187,6 +1222,17 @@ __global__ __launch_bounds__(256) void bwd_windows_k(RenderArgs a, int iw, int i
         if (!box_touches_kept_quad(a, d, tnx, txx, tny, txy)) rec.z |= (int)0x80000000;
     }
     reinterpret_cast<int4 *>(win)[i] = rec;     // [tile][plane]: one contiguous run per workgroup
+}
+
+// tile-exact layout: the lattice position of texel (x, y) of the (window of the) plane -- texel coordinate minus the index of the tile
+// that holds it (tiles of q_th x q_tw texels; (x + 1/2) / tw in fp32 is exact to the quad for plane coordinates < 2^22).  The inverse
+// homographies of the plan map LATTICE positions to pixels: both copies of a border sample have the same owner pixel.
+__device__ __forceinline__ void lattice_texel(const RenderArgs &a, int x, int y, float &lx, float &ly) {
+    lx = (float)x; ly = (float)y;
+    if (a.q_th) {      // uniform
+        lx -= fminf(floorf(((float)x + a.q_x0 + 0.5f) * (1.0f / (float)a.q_tw)), (float)(a.QW - 1));
+        ly -= fminf(floorf(((float)y + a.q_y0 + 0.5f) * (1.0f / (float)a.q_th)), (float)(a.QH - 1));
+    }
 }
 
 // owner pixel (float, before rounding) of texel (tx,ty) on plane d, relative to this window's pixel origin
@@ -1261,8 +1307,9 @@ __global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, i
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int d = blockIdx.z;
     if (x >= a.Ws || y >= a.Hs) return;
-    float qx, qy;
-    owner_pixel(a.plan + PLAN_HDR + PLAN_REC * d, (float)x, (float)y, a.pc, a.col0, a.row0, qx, qy);
+    float qx, qy, lx, ly;
+    lattice_texel(a, x, y, lx, ly);
+    owner_pixel(a.plan + PLAN_HDR + PLAN_REC * d, lx, ly, a.pc, a.col0, a.row0, qx, qy);
     // owner = nearest FRAME pixel: texels just outside the frame still collect taps of the border pixels
     const float rxf = fminf(fmaxf(rintf(qx), 0.0f), (float)(a.W - 1)), ryf = fminf(fmaxf(rintf(qy), 0.0f), (float)(a.H - 1));
     const int rx = (int)rxf, ry = (int)ryf;
@@ -1295,7 +1342,7 @@ __global__ __launch_bounds__(256) void bwd_owner_table_k(RenderArgs a, int iw, i
             const cint_p b = (cint_p)a.ad.boxes + 4 * d;
             inbox = !(Y < b[0] || Y >= b[1] || X < b[2] || X >= b[3]);
         }
-        cls = inbox ? vl3d_adam::texel_class(vl3d_adam::Quads{a.quad_keep, a.ad.quad_dyn, a.QH, a.QW}, d, X, Y, a.ad.Hs, a.ad.Ws) : 3;
+        cls = inbox ? vl3d_adam::texel_class(vl3d_adam::Quads{a.quad_keep, a.ad.quad_dyn, a.QH, a.QW, a.q_th, a.q_tw}, d, X, Y, a.ad.Hs, a.ad.Ws) : 3;
         // the record the gather reads with its owner entry, long before it needs it: class | (step the texel's bookkeeping tile is current
         // for) << 2, and the texel's 16-byte slot inside a frame of the parameter / moment tensors (dense) or pools (packed) -- so that the
         // owner's store asks for nothing but the two moments (no class byte -> step table / block table -> moments chain of dependent loads)
@@ -1365,8 +1412,9 @@ __global__ __launch_bounds__(256) void bwd_owner_table4_k(RenderArgs a, int iw, 
     bool unsafe[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float qx, qy;
-        owner_pixel(hi, (float)(x0 + k), (float)y, a.pc, a.col0, a.row0, qx, qy);
+        float qx, qy, lx, ly;
+        lattice_texel(a, x0 + k, y, lx, ly);
+        owner_pixel(hi, lx, ly, a.pc, a.col0, a.row0, qx, qy);
         const float rxf = fminf(fmaxf(rintf(qx), 0.0f), (float)(a.W - 1)), ryf = fminf(fmaxf(rintf(qy), 0.0f), (float)(a.H - 1));
         const int rx = (int)rxf, ry = (int)ryf;
         const int tx = (int)((rxf + 0.5f) * inv_iw), ty = (int)((ryf + 0.5f) * inv_ih);
@@ -2035,7 +2083,7 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
             sgq += sg_plane;                                                                              \
         }                                                                                                 \
     }
-    const QuadCull noq = QuadCull{nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f};
+    const QuadCull noq = QuadCull{nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f, 0};
     Taps2 tA = make_taps2<COORD, BORDER>(a.homos, px, py, a.Hs, a.Ws, a.sx, a.sy, a.ox, a.oy, noq, UvNoise{a.uv_seed, 0}), tB = tA;
     load_taps2<F16>(plane, tA, st, vA);
     if constexpr (MASK) load_mask_taps(mplane, tA.off, st, mA);

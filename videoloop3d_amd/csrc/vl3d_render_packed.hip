@@ -90,7 +90,9 @@ extern "C" int vl3d_render_fwd_packed(const vl3d_render_desc *desc, const int32_
     if (vl3d_check_variant(desc->variant) != VL3D_OK) return VL3D_EINVAL;
     VL3D_REQUIRE(desc->D > 0 && desc->D <= 128 && desc->T > 0 && desc->Hs > 0 && desc->Ws > 0 && desc->H > 0 && desc->W > 0 && n > 0,
                  "vl3d_render_fwd_packed: non-positive dims (or more than 128 planes)");
-    VL3D_REQUIRE(blocks && pool && frames && homos && quad_keep && rgb && alpha && QH > 0 && QW > 0, "vl3d_render_fwd_packed: null pointer / bad quad grid");
+    VL3D_REQUIRE(blocks && pool && frames && homos && quad_keep && rgb && alpha, "vl3d_render_fwd_packed: null pointer");
+    VL3D_REQUIRE((QH > 0 && QW > 0) || (QH < 0 && QW < 0 && desc->Hs % (-QH) == 0 && desc->Ws % (-QW) == 0 && desc->Hs / (-QH) >= 2 && desc->Ws / (-QW) >= 2),
+                 "vl3d_render_fwd_packed: bad quad grid (tile-exact layout: whole tiles of at least 2 x 2 texels)");
     VL3D_REQUIRE(desc->coord_mode == VL3D_COORD_AFFINE && desc->border_mode == VL3D_BORDER_HARDCUT && desc->act_order == VL3D_ACT_POST,
                  "vl3d_render_fwd_packed: the planar MPV convention (affine, hardcut, post) only");
     VL3D_REQUIRE(desc->stack_dtype == VL3D_F32, "vl3d_render_fwd_packed: the pool holds fp32 texels");
@@ -102,8 +104,15 @@ extern "C" int vl3d_render_fwd_packed(const vl3d_render_desc *desc, const int32_
     a.homos = homos; a.rgb = rgb; a.alpha = alpha;
     a.quad_keep = quad_keep; a.QH = QH; a.QW = QW;
     a.q_Hs = desc->Hs; a.q_Ws = desc->Ws; a.q_x0 = 0.0f; a.q_y0 = 0.0f;
-    a.q_inv_cw = (float)QW / (float)(a.q_Ws > 1 ? a.q_Ws - 1 : 1);
-    a.q_inv_ch = (float)QH / (float)(a.q_Hs > 1 ? a.q_Hs - 1 : 1);
+    if (QH < 0) {      // tile-exact layout (include/vl3d.h): |QH| x |QW| tiles, each quad owning its border texels
+        a.QH = -QH; a.QW = -QW;
+        a.q_th = desc->Hs / a.QH; a.q_tw = desc->Ws / a.QW;
+        a.q_inv_cw = 1.0f / (float)(a.q_tw - 1);
+        a.q_inv_ch = 1.0f / (float)(a.q_th - 1);
+    } else {
+        a.q_inv_cw = (float)QW / (float)(a.q_Ws > 1 ? a.q_Ws - 1 : 1);
+        a.q_inv_ch = (float)QH / (float)(a.q_Hs > 1 ? a.q_Hs - 1 : 1);
+    }
     PackedSrc p{blocks, reinterpret_cast<const float4 *>(pool), frames, (desc->Hs + TSB - 1) / TSB, (desc->Ws + TSB - 1) / TSB, culled_alpha};
     hipStream_t s = (hipStream_t)stream;
 #define VL3D_CASE(R, A)                                                   \

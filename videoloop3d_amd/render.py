@@ -27,11 +27,21 @@ class RenderSpec:
     alpha_act: str = "sigmoid"
     variant: int = 0
     uv_noise_seed: int = 0      # add_uv_noise (MPV.py:420-423, MPI.py:519-522; include/vl3d.h): 0 = off, else the seed of this call's half-texel jitter field
+    # TILE-EXACT layout of a tile-culled model (include/vl3d.h "Tile-exact layout"; needs quad_keep): (th, tw) texels per quad, every quad owning
+    # its border row / column as the reference's sparsified atlases store them (MPI.py:380-418).  The planes are QH th x QW tw texels; `scale`
+    # / `offset` then give the LATTICE coordinate (a quad spans tw - 1 of them) and the kernels add the quad index.  (0, 0): shared borders.
+    tile: tuple = (0, 0)
 
     @staticmethod
     def mpv(rgb_act="sigmoid", alpha_act="sigmoid", scale=(1.0, 1.0), offset=(0.0, 0.0), variant=0):
         return RenderSpec(pixel_center=0.5, coord_mode="affine", scale=scale, offset=offset, border="hardcut",
                           act_order="post", rgb_act=rgb_act, alpha_act=alpha_act, variant=variant)
+
+
+def _qgrid(quad_keep, spec):
+    """(QH, QW) of a quad map as the C ABI takes them: negative for the tile-exact layout."""
+    QH, QW = int(quad_keep.shape[1]), int(quad_keep.shape[2])
+    return (-QH, -QW) if getattr(spec, "tile", (0, 0))[0] else (QH, QW)
 
 
 def _desc(stack, H, W, spec, row0, col0, cull_window=None, grad_flags=0):
@@ -80,6 +90,8 @@ class _RenderPlanes(torch.autograd.Function):
             quad_keep = quad_keep.to(torch.uint8).contiguous()
         if stack.dtype not in (torch.float32, torch.float16):
             raise RuntimeError("plane stack must be float32 or float16 (arithmetic is fp32 either way)")
+        if getattr(spec, "tile", (0, 0))[0] and quad_keep is None:
+            raise RuntimeError("RenderSpec.tile (tile-exact layout) belongs to a tile-culled model: pass its quad_keep map")
         stack = stack.contiguous()
         homos = homos.detach().to(torch.float32).contiguous()
         D, T = stack.shape[:2]
@@ -117,7 +129,7 @@ class _RenderPlanes(torch.autograd.Function):
                 L.check(L.lib().vl3d_render_fwd_reg(desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.ptr(asum), L.ptr(sums),
                                                     L.ptr(reg_state), L.stream_ptr(stack.device)), "vl3d_render_fwd_reg")
             elif fused_reg:       # tile-culled model: the slot-by-slot regulariser kernel composites the render from the samples it takes
-                L.check(L.lib().vl3d_render_fwd_reg_culled(desc, L.ptr(stack), L.ptr(homos), L.ptr(quad_keep), quad_keep.shape[1], quad_keep.shape[2],
+                L.check(L.lib().vl3d_render_fwd_reg_culled(desc, L.ptr(stack), L.ptr(homos), L.ptr(quad_keep), *_qgrid(quad_keep, spec),
                                                            L.ptr(rgb), L.ptr(alpha), L.ptr(asum), L.ptr(sums), L.ptr(reg_state),
                                                            L.stream_ptr(stack.device)), "vl3d_render_fwd_reg_culled")
             elif quad_keep is None:
@@ -126,11 +138,11 @@ class _RenderPlanes(torch.autograd.Function):
             else:
                 ncull = int(L.lib().vl3d_render_cull_scratch_bytes(desc))
                 cull = torch.empty((ncull + 3) // 4, dtype=torch.float32, device=stack.device)
-                L.check(L.lib().vl3d_render_fwd_culled(desc, L.ptr(stack), L.ptr(homos), L.ptr(quad_keep), quad_keep.shape[1],
-                                                       quad_keep.shape[2], L.ptr(cull), L.ptr(rgb), L.ptr(alpha), L.ptr(asum),
+                L.check(L.lib().vl3d_render_fwd_culled(desc, L.ptr(stack), L.ptr(homos), L.ptr(quad_keep), *_qgrid(quad_keep, spec), L.ptr(cull), L.ptr(rgb), L.ptr(alpha), L.ptr(asum),
                                                        L.stream_ptr(stack.device)), "vl3d_render_fwd_culled")
         ctx.save_for_backward(stack, homos, rgb, alpha)
         ctx.quad_keep = quad_keep
+        ctx.spec = spec
         ctx.reg_state = reg_state
         ctx.desc = desc
         ctx.with_reg = with_reg
@@ -140,8 +152,8 @@ class _RenderPlanes(torch.autograd.Function):
                     L.check(L.lib().vl3d_render_reg_fwd(desc, L.ptr(stack), L.ptr(homos), L.ptr(sums), L.ptr(reg_state), L.stream_ptr(stack.device)),
                             "vl3d_render_reg_fwd")
                 else:
-                    L.check(L.lib().vl3d_render_reg_fwd_culled(desc, L.ptr(stack), L.ptr(homos), L.ptr(quad_keep), quad_keep.shape[1],
-                                                               quad_keep.shape[2], L.ptr(sums), L.ptr(reg_state), L.stream_ptr(stack.device)),
+                    L.check(L.lib().vl3d_render_reg_fwd_culled(desc, L.ptr(stack), L.ptr(homos), L.ptr(quad_keep), *_qgrid(quad_keep, spec),
+                                                               L.ptr(sums), L.ptr(reg_state), L.stream_ptr(stack.device)),
                             "vl3d_render_reg_fwd_culled")
         if asum is None:
             asum = torch.zeros((0,), dtype=torch.float32, device=stack.device)
@@ -174,7 +186,7 @@ class _RenderPlanes(torch.autograd.Function):
                                                 L.ptr(g_rgb), L.ptr(g_alpha), L.ptr(g_reg), L.ptr(ctx.reg_state), L.ptr(g_asum), L.ptr(g_stack), L.ptr(scratch), nscratch,
                                                 L.stream_ptr(stack.device)), "vl3d_render_bwd")
             else:
-                L.check(L.lib().vl3d_render_bwd_culled(ctx.desc, L.ptr(stack), L.ptr(homos), L.ptr(qk), qk.shape[1], qk.shape[2],
+                L.check(L.lib().vl3d_render_bwd_culled(ctx.desc, L.ptr(stack), L.ptr(homos), L.ptr(qk), *_qgrid(qk, ctx.spec),
                                                        L.ptr(rgb), L.ptr(alpha), L.ptr(g_rgb), L.ptr(g_alpha), L.ptr(g_reg), L.ptr(ctx.reg_state), L.ptr(g_asum),
                                                        L.ptr(g_stack), L.ptr(scratch), nscratch, L.stream_ptr(stack.device)),
                         "vl3d_render_bwd_culled")
@@ -286,7 +298,7 @@ def render_frame_run(stack, frame0, nframes, homos, H, W, spec: RenderSpec = Ren
             qk = quad_keep if (quad_keep.dtype == torch.uint8 and quad_keep.is_contiguous()) else quad_keep.to(torch.uint8).contiguous()
             ncull = int(L.lib().vl3d_render_cull_scratch_bytes(desc))
             cull = torch.empty((ncull + 3) // 4, dtype=torch.float32, device=stack.device)
-            L.check(L.lib().vl3d_render_fwd_frames_culled(desc, L.ptr(stack), int(frame0), int(T), L.ptr(homos), L.ptr(qk), qk.shape[1], qk.shape[2],
+            L.check(L.lib().vl3d_render_fwd_frames_culled(desc, L.ptr(stack), int(frame0), int(T), L.ptr(homos), L.ptr(qk), *_qgrid(qk, spec),
                                                           L.ptr(cull), L.ptr(rgb), L.ptr(alpha), L.stream_ptr(stack.device)), "vl3d_render_fwd_frames_culled")
     return rgb, alpha
 
@@ -367,6 +379,5 @@ def render_planes_packed(layout, pool, frames, homos, H, W, spec: RenderSpec, qu
         if tuple(rgb.shape) != (len(frames), H, W, 3) or tuple(alpha.shape) != (len(frames), H, W) or not rgb.is_contiguous() or not alpha.is_contiguous():
             raise RuntimeError("render_planes_packed: `out` must be contiguous float32 (rgb [n,H,W,3], alpha [n,H,W])")
     with torch.cuda.device(dev):
-        L.check(L.lib().vl3d_render_fwd_packed(d, L.ptr(layout.blocks), L.ptr(pool), L.ptr(ft), len(frames), L.ptr(homos), L.ptr(qk), qk.shape[1],
-                                               qk.shape[2], float(culled_alpha), L.ptr(rgb), L.ptr(alpha), L.stream_ptr(dev)), "vl3d_render_fwd_packed")
+        L.check(L.lib().vl3d_render_fwd_packed(d, L.ptr(layout.blocks), L.ptr(pool), L.ptr(ft), len(frames), L.ptr(homos), L.ptr(qk), *_qgrid(qk, spec), float(culled_alpha), L.ptr(rgb), L.ptr(alpha), L.stream_ptr(dev)), "vl3d_render_fwd_packed")
     return rgb, alpha

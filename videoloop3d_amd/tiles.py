@@ -134,10 +134,17 @@ def classify_quads(alpha, loopmask, QH, QW, erode_num=2, alpha_thresh=0.03, loop
     return keep, dyn
 
 
-def quad_to_texel_mask(qmask, Hs, Ws):
+def quad_to_texel_mask(qmask, Hs, Ws, tile=None):
     """[D,QH,QW] bool -> [D,Hs,Ws] bool: true for every texel a bilinear tap of a sample inside a true quad can read (the
-    quad's closed rectangle grown by one texel)."""
+    quad's closed rectangle grown by one texel).
+    tile = (th, tw): the TILE-EXACT layout (every quad owns a th x tw tile with its own border texels, Hs x Ws = QH th x QW tw): a texel
+    belongs to exactly one quad."""
     D, QH, QW = qmask.shape
+    if tile is not None and tile[0]:
+        th, tw = int(tile[0]), int(tile[1])
+        if (Hs, Ws) != (QH * th, QW * tw):
+            raise RuntimeError(f"tile-exact layout: a plane of {QH} x {QW} tiles of {th} x {tw} texels is {(QH * th, QW * tw)}, got {(Hs, Ws)}")
+        return qmask.repeat_interleave(th, 1).repeat_interleave(tw, 2)
     dev = qmask.device
     y = torch.arange(Hs, device=dev, dtype=torch.int64)
     x = torch.arange(Ws, device=dev, dtype=torch.int64)
@@ -150,15 +157,21 @@ def quad_to_texel_mask(qmask, Hs, Ws):
     return rows_lo[:, :, xlo] | rows_lo[:, :, xhi] | rows_hi[:, :, xlo] | rows_hi[:, :, xhi]
 
 
-def cull_stack_(stack, keep):
+def cull_stack_(stack, keep, tile=None):
     """write CULLED_ALPHA into the alpha logit of every texel no kept quad can read.  stack (D,T,Hs,Ws,4), in place."""
     D, T, Hs, Ws, _ = stack.shape
-    dead = ~quad_to_texel_mask(keep, Hs, Ws)
+    dead = ~quad_to_texel_mask(keep, Hs, Ws, tile)
     stack[..., 3].masked_fill_(dead[:, None], CULLED_ALPHA)
     return stack
 
 
-def tie_static_grad_hip(grad, keep, dyn, assume_culled_zero=False, frame0_only=False):
+def quad_grid_args(keep, tile=None):
+    """(QH, QW) as the C ABI takes them: NEGATIVE for the tile-exact layout (include/vl3d.h "Tile-exact layout")."""
+    QH, QW = int(keep.shape[1]), int(keep.shape[2])
+    return (-QH, -QW) if (tile is not None and tile[0]) else (QH, QW)
+
+
+def tie_static_grad_hip(grad, keep, dyn, assume_culled_zero=False, frame0_only=False, tile=None):
     """`tie_static_grad` as ONE in-place HIP kernel on the (fresh) gradient tensor of the stack -- the hook MPMeshVid installs
     (vl3d_tie_static_grad): static texels read T frames and write T frames, dynamic texels are not touched."""
     from . import _lib as L
@@ -169,19 +182,19 @@ def tie_static_grad_hip(grad, keep, dyn, assume_culled_zero=False, frame0_only=F
     g = grad if grad.is_contiguous() else grad.contiguous()
     k8, d8 = keep.to(torch.uint8).contiguous(), dyn.to(torch.uint8).contiguous()
     with torch.cuda.device(g.device):
-        L.check(L.lib().vl3d_tie_static_grad(D, T, Hs, Ws, L.ptr(k8), L.ptr(d8), keep.shape[1], keep.shape[2], L.ptr(g),
+        L.check(L.lib().vl3d_tie_static_grad(D, T, Hs, Ws, L.ptr(k8), L.ptr(d8), *quad_grid_args(keep, tile), L.ptr(g),
                                              (1 if assume_culled_zero else 0) | (2 if frame0_only else 0), L.stream_ptr(g.device)),
                 "vl3d_tie_static_grad")
     return g
 
 
-def tie_static_grad(grad, keep, dyn):
+def tie_static_grad(grad, keep, dyn, tile=None):
     """DEFINITION (plain torch, any device; used by the tests as the statement of the rule): gradient of the dense stack
     (D,T,Hs,Ws,4) -> the gradient the reference's (static atlas, dynamic atlas) pair would see: texels only static quads
     read get the SUM over frames in every frame's copy; culled texels get 0."""
     D, T, Hs, Ws, _ = grad.shape
-    keep_t = quad_to_texel_mask(keep, Hs, Ws)
-    dyn_t = quad_to_texel_mask(dyn, Hs, Ws)
+    keep_t = quad_to_texel_mask(keep, Hs, Ws, tile)
+    dyn_t = quad_to_texel_mask(dyn, Hs, Ws, tile)
     static_t = (keep_t & ~dyn_t)[:, None, :, :, None]
     tied = grad.sum(dim=1, keepdim=True)
     out = torch.where(static_t, tied.expand_as(grad), grad)
@@ -197,13 +210,14 @@ class TileAdam(torch.optim.Optimizer):
     contiguous float32 parameter, against the 7 chunked multi-tensor passes of torch.optim.Adam's default path -- 49 launches and 2.3 of the
     4.3 ms of GPU time of a 720p stage-1 iteration, profiles/r03_kernel_stats_s1.csv)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, quad_keep=None, quad_dyn=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, quad_keep=None, quad_dyn=None, tile=None):
         """quad_dyn (with quad_keep): static texels are treated as ONE parameter with T copies -- their gradient is read from
         frame 0 (where tie_static_grad_hip(..., frame0_only=True) leaves the frame sum), their moments live in frame 0, and the
-        new value is written to all copies."""
+        new value is written to all copies.  tile = (th, tw): the tile-exact layout (quad_to_texel_mask)."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.quad_keep = quad_keep
         self.quad_dyn = quad_dyn
+        self.tile = tile
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -240,8 +254,8 @@ class TileAdam(torch.optim.Optimizer):
                 D, T, Hs, Ws = dims
                 st["step"] += 1
                 with torch.cuda.device(p.device):
-                    L.check(L.lib().vl3d_adam_step_tiles(D, T, Hs, Ws, L.ptr(qk), L.ptr(qd), 0 if qk is None else qk.shape[1],
-                                                         0 if qk is None else qk.shape[2], L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]),
+                    QH_, QW_ = (0, 0) if qk is None else quad_grid_args(qk, self.tile)
+                    L.check(L.lib().vl3d_adam_step_tiles(D, T, Hs, Ws, L.ptr(qk), L.ptr(qd), QH_, QW_, L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]),
                                                          L.ptr(st["exp_avg_sq"]), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                                          st["step"], L.stream_ptr(p.device)), "vl3d_adam_step_tiles")
         return loss
@@ -326,13 +340,43 @@ def _stack_on_tile_lattice(aligned, D, T, QH, QW):
     return stack.permute(0, 3, 1, 2, 4).contiguous()
 
 
-def stack_from_reference_state(sd, mpi_h, mpi_w, hv, wv, frm_num, lattice=True):
+def _stack_on_own_tiles(aligned, D, T, QH, QW):
+    """tiles of th x tw texels -> the TILE-EXACT plane of QH th x QW tw texels: tile (vy, vx) of plane d occupies rows [vy th, vy th + th),
+    columns [vx tw, vx tw + tw) -- every texel of the checkpoint exactly once, the two copies of a border sample that neighbouring tiles hold
+    (MPI.py:380-400) side by side and INDEPENDENT, as stage 2 trains them (a static tile's copy is one texture, its dynamic neighbour's moves
+    per frame).  The render adds the quad index to a sample's lattice coordinate (csrc/vl3d_render_core.h make_taps_i), so a sample's two
+    taps per axis stay inside its own tile -- grid_sample on the reference's atlas between the tile's corner texel centres (MPV.py:394-427)."""
+    (th, tw), lists = aligned
+    stack = torch.zeros((D, T, QH * th, QW * tw, 4))
+    stack[..., 3] = CULLED_ALPHA
+    iy, ix = torch.arange(th), torch.arange(tw)
+    for kind, d, vy, vx, y0, x0, atlas in lists:
+        A = atlas.shape[0]
+        ay = (y0[:, None] + iy[None])[:, :, None].expand(-1, th, tw)                                # n,th,tw atlas rows
+        ax = (x0[:, None] + ix[None])[:, None, :].expand(-1, th, tw)
+        tl = atlas[:, :, ay, ax].permute(2, 0, 3, 4, 1)                                              # n,A,th,tw,4
+        if A == 1:
+            tl = tl.expand(-1, T, -1, -1, -1)
+        elif A != T:
+            raise RuntimeError(f"checkpoint atlas holds {A} frames, expected 1 or {T}")
+        ly = (vy[:, None] * th + iy[None])[:, None, :, None].expand(-1, T, th, tw)
+        lx = (vx[:, None] * tw + ix[None])[:, None, None, :].expand(-1, T, th, tw)
+        dd = d[:, None, None, None].expand(-1, T, th, tw)
+        tt = torch.arange(T)[None, :, None, None].expand(len(d), T, th, tw)
+        stack[dd, tt, ly, lx] = tl
+    return stack
+
+
+def stack_from_reference_state(sd, mpi_h, mpi_w, hv, wv, frm_num, lattice=True, own_borders=False):
     """Reference state_dict (stage-1 MPMesh or stage-2 MPMeshVid, sparsified or not) -> (stack (D,T,Hs,Ws,4) float32 on CPU, quad_keep,
     quad_dyn [D,hv-1,wv-1] bool).  Static quads are written into every frame, culled texels get CULLED_ALPHA.
     lattice (default): a SPARSIFIED checkpoint (texel-aligned tiles of one size, MPI.py:364-436) is copied texel for texel onto the tile
     lattice, Hs x Ws = (hv-1)*(th-1)+1 x (wv-1)*(tw-1)+1 -- the reference's own stage-2 resolution (its `lod` resizes tiles, MPV.py:146-163);
     the planes keep their extent, so the caller renders with texel scale (Ws-1)/(mpi_w-1).  Identical weights, identical image
-    (golden G17).  Otherwise (dense cell atlases, lattice=False): bilinear resampling onto the (mpi_h, mpi_w) grid of pitch 1."""
+    (golden G17) for a FRESH checkpoint (duplicated border samples equal).
+    own_borders (with lattice): the tile-exact plane of (hv-1)*th x (wv-1)*tw texels instead (`_stack_on_own_tiles`): identical weights for
+    ANY checkpoint, trained ones included (golden G19); the caller renders with the lattice's scale ((wv-1)(tw-1))/(mpi_w-1) and the tile size
+    (RenderSpec.tile).  Otherwise (dense cell atlases, lattice=False): bilinear resampling onto the (mpi_h, mpi_w) grid of pitch 1."""
     D = int(sd["planedepth"].numel())
     QH, QW = hv - 1, wv - 1
     if lattice and "faces_dyn" in sd and bool(sd.get("self.is_sparse", False)):
@@ -347,6 +391,8 @@ def stack_from_reference_state(sd, mpi_h, mpi_w, hv, wv, frm_num, lattice=True):
                 keep[d, vy, vx] = True
                 if kind == "dyn":
                     dyn[d, vy, vx] = True
+            if own_borders:      # every tile with its own border texels: a TRAINED checkpoint's weights, exactly (golden G19)
+                return _stack_on_own_tiles(aligned, D, T_, QH, QW), keep, dyn
             return _stack_on_tile_lattice(aligned, D, T_, QH, QW), keep, dyn
     ch, cw = (mpi_h - 1) / QH, (mpi_w - 1) / QW
     has_dyn_lists = "faces_dyn" in sd
