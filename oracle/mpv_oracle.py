@@ -42,14 +42,20 @@ def _homos(ref_intrin_mpi, extrin, intrin, planedepth):
     return MO.compute_homography(eye, ref_intrin_mpi[None].to(extrin.dtype), extrin, intrin, normal, planedepth[None].to(extrin.dtype))[0].float()
 
 
-def _layers(tex, homos, h, w, args, mpi_h, mpi_w, pixel_center, atlas_grid_h, quad_keep, acts=None):
-    """plane-indexed activated layers [T,h,w,D,C] + coverage [h,w,D] of a stack or (atlas_grid_h) of the reference's atlas."""
+def _layers(tex, homos, h, w, args, mpi_h, mpi_w, pixel_center, atlas_grid_h, quad_keep, acts=None, tile=None):
+    """plane-indexed activated layers [T,h,w,D,C] + coverage [h,w,D] of a stack or (atlas_grid_h) of the reference's atlas.
+    tile = (th, tw): the stack is in the TILE-EXACT layout (every quad of `quad_keep`'s grid owns a th x tw tile, border texels included --
+    the reference's sparsified atlases, MPI.py:380-418; pinned by golden G19)."""
     if atlas_grid_h is not None:
         acts = (MO.ACTS[args.rgb_activate], MO.ACTS[args.alpha_activate]) if acts is None else acts
         return AO.sample_atlas_layers(tex, homos, h, w, atlas_grid_h, mpi_h, mpi_w, pixel_center, acts)
     Hs, Ws = tex.shape[2:4]
-    spec = MO.RenderSpec(pixel_center=pixel_center, coord_mode="affine", border="hardcut", act_order="post",
-                         scale=((Ws - 1) / max(mpi_w - 1, 1), (Hs - 1) / max(mpi_h - 1, 1)),
+    if tile is not None:      # plane pixel -> LATTICE coordinate: a quad spans tile - 1 of them
+        QH, QW = quad_keep.shape[1:]
+        scale, tl = (QW * (tile[1] - 1) / max(mpi_w - 1, 1), QH * (tile[0] - 1) / max(mpi_h - 1, 1)), (int(tile[0]), int(tile[1]))
+    else:
+        scale, tl = ((Ws - 1) / max(mpi_w - 1, 1), (Hs - 1) / max(mpi_h - 1, 1)), (0, 0)
+    spec = MO.RenderSpec(pixel_center=pixel_center, coord_mode="affine", border="hardcut", act_order="post", scale=scale, tile=tl,
                          rgb_act=args.rgb_activate if acts is None else acts[0], alpha_act=args.alpha_activate if acts is None else acts[1])
     return MO.sample_layers(tex, homos, h, w, spec, quad_keep)
 
@@ -78,7 +84,7 @@ def _smooth(t, D):
 
 
 def mpv_forward(stack, args, H, W, ref_extrin, ref_intrin, near, far, h, w, tar_extrins, tar_intrins, ts=None, res=None,
-                losscfg=None, training=True, pixel_center=0.5, atlas_grid_h=None, quad_keep=None):
+                losscfg=None, training=True, pixel_center=0.5, atlas_grid_h=None, quad_keep=None, tile=None):
     """stack (D,T,Hs,Ws,4), or the atlas (T,4,Ah,Aw) with atlas_grid_h.  Returns (rgb [T',3,h,w] or None, extra dict) like MPV.py:553-556."""
     D = args.mpi_d if atlas_grid_h is not None else stack.shape[0]
     T = stack.shape[0] if atlas_grid_h is not None else stack.shape[1]
@@ -88,7 +94,7 @@ def mpv_forward(stack, args, H, W, ref_extrin, ref_intrin, near, far, h, w, tar_
         ts = torch.arange(T)
     homos = _homos(ref_intrin_mpi, extrins, tar_intrins, planedepth)
     tex = stack[ts] if atlas_grid_h is not None else stack[:, ts]
-    layers, cov = _layers(tex, homos, h, w, args, mpi_h, mpi_w, pixel_center, atlas_grid_h, quad_keep)
+    layers, cov = _layers(tex, homos, h, w, args, mpi_h, mpi_w, pixel_center, atlas_grid_h, quad_keep, tile=tile)
     rgb, bw = MO.overcompose(layers[..., 3], layers[..., :3])
     alpha = bw.sum(-1)
     mpi = MO.layers_to_slots(layers, cov)
@@ -144,7 +150,7 @@ def mpv_forward(stack, args, H, W, ref_extrin, ref_intrin, near, far, h, w, tar_
 
 
 def mpi_forward(stack, stack_mask, args, H, W, ref_extrin, ref_intrin, near, far, h, w, tar_extrins, tar_intrins,
-                training=True, pixel_center=0.5, atlas_grid_h=None, quad_keep=None):
+                training=True, pixel_center=0.5, atlas_grid_h=None, quad_keep=None, tile=None):
     """MPMesh.forward (MPI.py:596-652) for planar geometry.  stack (D,1,Hs,Ws,4) + stack_mask (D,1,Hs,Ws) or None; with atlas_grid_h the
     reference's atlas (1,4,Ah,Aw) + atlas_mask (1,1,Ah,Aw).  Returns (rgbl [B,3|4,h,w], extra)."""
     D = args.mpi_d if atlas_grid_h is not None else stack.shape[0]
@@ -153,7 +159,7 @@ def mpi_forward(stack, stack_mask, args, H, W, ref_extrin, ref_intrin, near, far
     outs, mpis, alphas, masks, disps = [], [], [], [], []
     for b in range(len(extrins)):
         homos = _homos(ref_intrin_mpi, extrins[b:b + 1], tar_intrins[b:b + 1], planedepth)
-        layers, cov = _layers(stack, homos, h, w, args, mpi_h, mpi_w, pixel_center, atlas_grid_h, quad_keep)   # 1,h,w,D,4
+        layers, cov = _layers(stack, homos, h, w, args, mpi_h, mpi_w, pixel_center, atlas_grid_h, quad_keep, tile=tile)   # 1,h,w,D,4
         rgb, bw = MO.overcompose(layers[..., 3], layers[..., :3])
         alpha = bw.sum(-1)
         if len(args.bg_color) > 0:                                                                   # MPI.py:550-556
@@ -167,7 +173,7 @@ def mpi_forward(stack, stack_mask, args, H, W, ref_extrin, ref_intrin, near, far
             m = stack_mask if atlas_grid_h is not None else stack_mask[..., None]
             lab_layers, _ = _layers(m if atlas_grid_h is not None else torch.cat([m, m, m, m], -1), homos, h, w, args, mpi_h, mpi_w,
                                     pixel_center, atlas_grid_h, quad_keep,
-                                    acts=(torch.sigmoid, torch.sigmoid) if atlas_grid_h is not None else ("sigmoid", "sigmoid"))
+                                    acts=(torch.sigmoid, torch.sigmoid) if atlas_grid_h is not None else ("sigmoid", "sigmoid"), tile=tile)
             lab_layers = lab_layers[..., :1]
             label, _ = MO.overcompose(layers[..., -1].detach(), lab_layers)
             rgb = torch.cat([rgb, label], dim=-1)

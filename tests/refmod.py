@@ -87,5 +87,24 @@ def lattice_grad_from_reference(sd, hv, wv, D, T, grad_atlas, grad_atlas_dyn):
     return out["dyn"].permute(0, 3, 1, 2, 4).contiguous(), out["static"][:, :, :, 0].contiguous()
 
 
+def own_grad_from_reference(sd, hv, wv, D, T, grad_atlas, grad_atlas_dyn):
+    """the reference's gradients w.r.t. its tile atlases, tile for tile on the TILE-EXACT stack (every tile texel is its own parameter: no sums):
+    -> (per-frame gradient of the dynamic tiles [D,T,H,W,4], gradient of the static tiles -- ONE texture for all frames -- [D,H,W,4])."""
+    from videoloop3d_amd import tiles
+    parts = [("static", sd["faces"], sd["uvfaces"], sd["uvs"], grad_atlas), ("dyn", sd["faces_dyn"], sd["uvfaces_dyn"], sd["uvs_dyn"], grad_atlas_dyn)]
+    (th, tw), lists = tiles._aligned_tiles(parts, hv, wv)
+    QH, QW = hv - 1, wv - 1
+    g_dyn, g_static = torch.zeros((D, T, QH * th, QW * tw, 4)), torch.zeros((D, QH * th, QW * tw, 4))
+    for kind, d, vy, vx, y0, x0, atlas in lists:
+        for i in range(len(d)):
+            tl = atlas[:, :, int(y0[i]):int(y0[i]) + th, int(x0[i]):int(x0[i]) + tw].permute(0, 2, 3, 1)
+            ys, xs = slice(int(vy[i]) * th, (int(vy[i]) + 1) * th), slice(int(vx[i]) * tw, (int(vx[i]) + 1) * tw)
+            if kind == "dyn":
+                g_dyn[int(d[i]), :, ys, xs] = tl
+            else:
+                g_static[int(d[i]), ys, xs] = tl[0]
+    return g_dyn, g_static
+
+
 OTHER_LOSSES = {"gpnn": dict(loss_name="gpnn", loss_gain=1.5, patch_size=5, patcht_size=3, stride=2, stridet=2, rou="0", scaling=0.2, alpha=0.5),
                 "mse": dict(loss_name="mse"), "avg": dict(loss_name="avg", loss_gain=2.0)}

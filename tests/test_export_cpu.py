@@ -66,7 +66,7 @@ def test_export_then_read_roundtrip():
     assert sd["_verts"].shape == (3 * 5 * 7, 3)
     # back through the reader: the same quad maps and, on every texel a kept quad can read, the same values
     b = MPMeshVid(_args(), 41, 61, np.eye(4), np.array([[50., 0, 30], [0, 50., 20], [0, 0, 1]]), 1.0, 100.0)
-    b.init_from_mpi(sd)
+    b.init_from_mpi(sd, tile_layout="lattice")      # (a pitch-1 model's export, read back onto the stack it came from)
     assert b.is_sparse and torch.equal(b.quad_keep, keep) and torch.equal(b.quad_dyn, dyn)
     inside = tiles.quad_to_texel_mask(keep, 41, 61)
     closed = torch.zeros_like(inside)                                                        # closed rectangles of the kept quads

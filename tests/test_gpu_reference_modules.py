@@ -75,10 +75,10 @@ def test_sparsified_mpmeshvid_forward_matches_the_reference(dev):
     res = torch.from_numpy(g["res"]).to(dev)
     sd = RM.state_dict_of(g15, "sd_", atlas_dyn=torch.from_numpy(g["d_atlas_dyn"]))          # the stage-2 model of G17 (d): 5 dynamic frames
     v = MPMeshVid(args, H, W, ref_extrin, K, 1.0, 100.0)
-    v.init_from_mpi(sd)
+    v.init_from_mpi(sd, tile_layout="lattice")      # (the shared-border representation of rounds 4-5: this checkpoint's border copies agree)
     v = v.to(dev)
     v._install_tie_hook()
-    assert v.frm_num == 5 and v.is_sparse and v.tile_full == (10, 10)
+    assert v.frm_num == 5 and v.is_sparse and v.tile_full == (10, 10) and v.tile_own is None
     v.train()
     _, extra = v(h, w, tar_e, K_crop, res=res, losscfg=R4.collate(RM.LOSS_CFGS["other"]))
     for k in ("swd", "sparsity", "rgb_smooth", "a_smooth", "density"):
@@ -118,7 +118,7 @@ def test_sparsified_mpmeshvid_forward_matches_the_reference(dev):
     # ... and the PACKED form of the same checkpoint (static blocks once, dynamic blocks per frame, culled blocks nowhere) renders the reference's
     # image straight from its pool (vl3d_render_fwd_packed)
     v2 = MPMeshVid(RM.mpv_args(5), H, W, ref_extrin, K, 1.0, 100.0)
-    v2.init_from_mpi(sd)
+    v2.init_from_mpi(sd, tile_layout="lattice")
     v2 = v2.to(dev)
     v2.pack_()
     v2.eval()
@@ -135,10 +135,119 @@ def _eval_frames(sd, dev, H, W, ref_extrin, K, h, w, tar_e, K_crop):
     """the dense model of the same checkpoint rendering frames [4, 2] of the crop view (what the packed model must reproduce bit for bit)."""
     from videoloop3d_amd.MPV import MPMeshVid
     d = MPMeshVid(RM.mpv_args(5), H, W, ref_extrin, K, 1.0, 100.0)
-    d.init_from_mpi(sd)
+    d.init_from_mpi(sd, tile_layout="lattice")
     d = d.to(dev).eval()
     with torch.no_grad():
         return d(h, w, tar_e, K_crop, ts=torch.tensor([4, 2]))[0]
+
+
+def test_trained_tile_checkpoint_matches_the_reference(dev):
+    """Golden G19 (tests/golden/make_golden_r06.py): a TRAINED stage-2 checkpoint -- every tile texel perturbed independently, so the two copies
+    of every border sample that neighbouring tiles hold differ (static next to dynamic included).  The tile-exact layout (init_from_mpi's
+    default) holds it exactly and the HIP module reproduces the reference's own forward: every `extra` term, the gradient of EVERY TILE TEXEL of
+    both atlases, evaluation renders -- through the dense stack, the crop-aware optimiser's window path and the packed pool.  The shared-border
+    lattice of rounds 4-5 misses the same checkpoint's image by ~0.27."""
+    from videoloop3d_amd.MPV import MPMeshVid
+    g = RM.load("g19_trained_tiles")
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    hv, wv, D = over["mpi_h_verts"], over["mpi_w_verts"], over["mpi_d"]
+    h, w, tar_e, K_crop, K_full = RM.crop_view(g)
+    res = torch.from_numpy(g["res"]).to(dev)
+    sd = RM.state_dict_of(g, "h_sd_")
+    v = MPMeshVid(RM.mpv_args(5), H, W, ref_extrin, K, 1.0, 100.0)
+    v.init_from_mpi(sd)
+    v = v.to(dev)
+    v._install_tie_hook()
+    assert v.tile_own == (10, 10) and v.stack.shape == (D, 5, 40, 60, 4) and v.spec.tile == (10, 10)
+    v.train()
+    _, extra = v(h, w, tar_e, K_crop, res=res, losscfg=R4.collate(RM.LOSS_CFGS["other"]))
+    for k in ("swd", "sparsity", "rgb_smooth", "a_smooth", "density"):
+        _rel(extra[k], g[f"h_extra_{k}"], k)
+    sum(RM.MPV_WEIGHTS[k] * x.sum() for k, x in extra.items()).backward()
+    gs = v.stack.grad.cpu()
+    g_dyn, g_static = RM.own_grad_from_reference(sd, hv, wv, D, 5, torch.from_numpy(g["h_grad_atlas"]), torch.from_numpy(g["h_grad_atlas_dyn"]))
+    tile = (10, 10)
+    dyn_t = tiles.quad_to_texel_mask(v.quad_dyn.cpu(), 40, 60, tile)
+    static_t = tiles.quad_to_texel_mask((v.quad_keep & ~v.quad_dyn).cpu(), 40, 60, tile)
+    scale = float(g_dyn.abs().max())
+    assert int(dyn_t.sum()) == 80 * 100 and int(static_t.sum()) == 16 * 100 and scale > 1e-5
+    sel = dyn_t[:, None].expand(-1, 5, -1, -1)
+    _close(gs[sel], g_dyn[sel], 1e-4 * scale, "every texel of every dynamic tile, per frame")
+    for t in (0, 2, 4):      # a static tile is ONE texture (MPV.py:389-392): every frame's copy carries the reference's gradient of that one tile
+        _close(gs[:, t][static_t], g_static[static_t], 1e-4 * scale, f"static tiles, frame {t}")
+    assert float(gs[(~(dyn_t | static_t))[:, None].expand(-1, 5, -1, -1)].abs().max()) == 0.0
+    v.eval()
+    with torch.no_grad():
+        ev = v(H, W, tar_e, K_full)[0]
+        _close(ev, g["h_eval_rgb_full"], 1e-4, "eval, full frame")
+        _close(v(h, w, tar_e, K_crop, ts=torch.tensor([3, 1]))[0], g["h_eval_rgb_crop_ts"], 1e-4, "eval, frames [3, 1] of the crop")
+    # the shared-border reader on the same checkpoint (what rounds 4-5 rendered): wrong by the size of the border drift
+    vl = MPMeshVid(RM.mpv_args(5), H, W, ref_extrin, K, 1.0, 100.0)
+    vl.init_from_mpi(sd, tile_layout="lattice")
+    vl = vl.to(dev).eval()
+    with torch.no_grad():
+        err_lattice = float((vl(H, W, tar_e, K_full)[0].cpu() - torch.from_numpy(g["h_eval_rgb_full"])).abs().max())
+    assert err_lattice > 0.05, err_lattice
+    # the path a training run takes: the crop-aware optimiser's compact window copy, culled kernels on a WINDOW of the tile planes.  Two-kernel
+    # step (fused_adam_backward off) so that the window leaf's gradient can be read: the reference's per-tile-texel gradients again
+    v.zero_grad(set_to_none=True)
+    v.train()
+    v.args.fused_adam_backward = False
+    opt = v.get_optimizer(0)
+    _, extra_w = v(h, w, tar_e, K_crop, res=res, losscfg=R4.collate(RM.LOSS_CFGS["other"]))
+    for k in ("swd", "sparsity", "rgb_smooth", "a_smooth", "density"):
+        _rel(extra_w[k], g[f"h_extra_{k}"], k + " (window path)")
+    sum(RM.MPV_WEIGHTS[k] * x.sum() for k, x in extra_w.items()).backward()
+    (y0, x0, wh, ww), leaf, _ = opt.pending
+    gw = leaf.grad.cpu()
+    selw = dyn_t[:, None, y0:y0 + wh, x0:x0 + ww].expand(-1, 5, -1, -1)
+    _close(gw[selw], g_dyn[:, :, y0:y0 + wh, x0:x0 + ww][selw], 1e-4 * scale, "window leaf gradient, dynamic tiles")
+    _close(gw.sum(1)[static_t[:, y0:y0 + wh, x0:x0 + ww]], g_static[:, y0:y0 + wh, x0:x0 + ww][static_t[:, y0:y0 + wh, x0:x0 + ww]], 1e-4 * scale,
+           "window leaf gradient, static tiles (summed over the frames by the step)")
+    outside = torch.ones((40, 60), dtype=torch.bool)
+    outside[y0:y0 + wh, x0:x0 + ww] = False
+    assert float(g_dyn[:, :, outside].abs().max()) == 0.0 and float(g_static[:, outside].abs().max()) == 0.0      # the window holds every texel the crop reaches
+    before = v.stack.detach().clone()
+    opt.step()
+    opt.flush()
+    moved = (v.stack.detach() - before).abs().amax((1, 4)).cpu()
+    assert float(moved[dyn_t | static_t].max()) > 0 and float(moved[~(dyn_t | static_t)].max()) == 0.0
+    d0, y_, x_ = static_t.nonzero()[0].tolist()      # (static tiles stay one texture after the step)
+    assert bool((v.stack.detach()[d0, :, y_, x_] == v.stack.detach()[d0, :1, y_, x_]).all())
+    # the fused step (the default: the backward applies Adam where it would have stored the gradient) leaves the same parameters as the two kernels
+    def one_step(fused, packed):
+        m = MPMeshVid(RM.mpv_args(5), H, W, ref_extrin, K, 1.0, 100.0)
+        m.init_from_mpi(sd, packed=packed) if packed else m.init_from_mpi(sd)
+        m = m.to(dev)
+        m.train()
+        m.args.fused_adam_backward = fused
+        o = m.get_optimizer(0)
+        if fused:
+            o.acknowledge_fused_backward()
+        _, ex = m(h, w, tar_e, K_crop, res=res, losscfg=R4.collate(RM.LOSS_CFGS["other"]))
+        sum(RM.MPV_WEIGHTS[k] * x.sum() for k, x in ex.items()).backward()
+        o.step()
+        o.flush()
+        return m
+    a, b, c = one_step(False, False), one_step(True, False), one_step(True, True)
+    assert b._window_opt.fused_steps == 1 and c.packed is not None
+    assert torch.equal(a.stack.detach(), v.stack.detach()) and torch.equal(a.stack.detach(), b.stack.detach())
+    for d_ in range(D):
+        assert torch.equal(c.stack_plane(d_)[:, (dyn_t | static_t)[d_]], a.stack.detach()[d_][:, (dyn_t | static_t)[d_]]), d_
+    # ... and the PACKED pool of the checkpoint renders the reference's image straight from its blocks (vl3d_render_fwd_packed)
+    v2 = MPMeshVid(RM.mpv_args(5), H, W, ref_extrin, K, 1.0, 100.0)
+    v2.init_from_mpi(sd, packed=True)
+    v2 = v2.to(dev).eval()
+    assert v2.packed is not None and v2.packed.tile == (10, 10)
+    with torch.no_grad():
+        assert torch.equal(v2(H, W, tar_e, K_full)[0], ev)
+    # the trained model goes back out as the reference's checkpoint, bit for bit where a face references it
+    out = v2.reference_state_dict()
+    for key, faces, gw_ in (("atlas", "faces", "self.atlas_grid_w"), ("atlas_dyn", "faces_dyn", "self.atlas_grid_dyn_w")):
+        for k_ in range(sd[faces].shape[0] // 2):
+            ys, xs = slice((k_ // sd[gw_]) * 10, (k_ // sd[gw_]) * 10 + 10), slice((k_ % sd[gw_]) * 10, (k_ % sd[gw_]) * 10 + 10)
+            assert torch.equal(out[key][..., ys, xs].cpu(), sd[key][..., ys, xs]), (key, k_)
+    print(f"G19: shared-border lattice image error {err_lattice:.3f}; tile-exact layout within 1e-4")
 
 
 @pytest.mark.parametrize("which", ["other", "ref", "plain"])
@@ -193,8 +302,9 @@ def test_dense_mpmeshvid_second_layout_matches_the_reference(dev):
     _rel(stack_to_atlas(gs, over["atlas_grid_h"]), g["e_grad_atlas_dyn"], "grad atlas_dyn")
 
 
+@pytest.mark.parametrize("layout", ["exact", "lattice"])
 @pytest.mark.parametrize("packed", [False, True])
-def test_stage2_training_from_the_reference_checkpoint(dev, packed):
+def test_stage2_training_from_the_reference_checkpoint(dev, packed, layout):
     """The hand-over the reference's pipeline makes (train_3d.py sparsifies and saves; train_3dvid.py:205-211 loads it with init_from_mpi and trains
     the pyramid): the REFERENCE's stage-1 checkpoint (G15) into this package's stage-2 driver, dense and packed -- two pyramid levels on the tile
     lattice (lod follows the reference's tile sizes), the loss goes down, and the trained model exports a checkpoint with the reference's keys,
@@ -209,8 +319,9 @@ def test_stage2_training_from_the_reference_checkpoint(dev, packed):
                         pyr_factor=0.5, pyr_num_epoch=0, patch_h_size=20, patch_w_size=28, patch_h_stride=12, patch_w_stride=20, lrate=0.5,
                         lrate_adaptive=True, add_intrin_noise=True, swd_loss_weight=1.0, **over)
     model = MPMeshVid(args, H, W, ref_extrin, K, 1.0, 100.0).to(dev)
-    model.init_from_mpi(sd, packed=packed)
+    model.init_from_mpi(sd, packed=packed, tile_layout=layout)
     assert (model.packed is not None) == packed and model.tile_full == (10, 10) and model.is_sparse
+    assert model.tile_own == ((10, 10) if layout == "exact" else None)
     vids = [synth.make_video(8, H, W, seed=21 + v, device=dev)[0].permute(1, 0, 2, 3).contiguous() for v in range(2)]
     poses = torch.stack([torch.tensor(np.linalg.inv(ref_extrin))[:3], torch.tensor(np.linalg.inv(tar))[:3]]).float()
     intr = torch.tensor(K).float()[None].repeat(2, 1, 1)
@@ -224,7 +335,7 @@ def test_stage2_training_from_the_reference_checkpoint(dev, packed):
                       on_step=lambda lvl, ep, it, loss, swd, extra: log.append((lvl, float(loss))), generator=torch.Generator().manual_seed(1))
     assert n == len(log) and all(np.isfinite(l) for _, l in log)
     # level 0: tiles of max(int(10 * 0.5), 2) = 5 texels, level 1: the checkpoint's own 10 (MPV.py:146-151)
-    assert model.stack_dims()[2:4] == (4 * 9 + 1, 6 * 9 + 1)
+    assert model.stack_dims()[2:4] == ((4 * 10, 6 * 10) if layout == "exact" else (4 * 9 + 1, 6 * 9 + 1))
     fine = [l for lvl, l in log if lvl == 1]
     assert np.mean(fine[-6:]) < np.mean(fine[:6])
     out = model.reference_state_dict()

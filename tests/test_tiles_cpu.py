@@ -204,7 +204,7 @@ def test_reference_checkpoint_is_read_onto_the_dense_stack():
     # through the module: frame count taken from the dynamic atlas, maps registered, static tying installed
     a = _args(mpi_d=D, mpv_frm_num=2, mpi_h_verts=hv, mpi_w_verts=wv)
     vid = MPMeshVid(a, H, W, np.eye(4), np.array([[30., 0, W / 2], [0, 30., H / 2], [0, 0, 1]]), 1.0, 100.0)
-    vid.init_from_mpi(sd)
+    vid.init_from_mpi(sd, tile_layout="lattice")
     assert vid.frm_num == T and vid.stack.shape == (D, T, H, W, 4) and vid.is_sparse and vid._tie_hook is not None
     assert torch.equal(vid.quad_keep, keep) and torch.equal(vid.quad_dyn, dyn)
     assert torch.allclose(vid.planedepth, torch.linspace(1, 2, D))

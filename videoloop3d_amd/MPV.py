@@ -257,6 +257,8 @@ class MPMeshVid(nn.Module):
         self._window_opt = None          # the crop-aware Adam handed out by get_optimizer (dense CUDA models)
         self.packed = None               # packed.PackedLayout once pack_() has replaced the dense stack by the pool `stack_pool`
         self.tile_full = None            # (th, tw): texels per quad of a model loaded from a sparsified REFERENCE checkpoint (tile lattice)
+        self.tile_own = None             # (th, tw) at the current pyramid level when every quad owns its border texels (TILE-EXACT layout, the
+                                         # default for sparsified reference checkpoints: init_from_mpi); None: neighbouring quads share them
 
         self.swd_patch_size, self.swd_patcht_size = args.swd_patch_size, args.swd_patcht_size
         self.swd_stride, self.swd_stridet = args.swd_stride, args.swd_stridet
@@ -294,6 +296,23 @@ class MPMeshVid(nn.Module):
             return self.packed.unpack_plane(self.stack_pool.data, d, frames)
         return self.stack.data[d] if frames is None else self.stack.data[d, torch.as_tensor(frames, device=self.stack.device).long()]
 
+    def _set_texture_geometry(self, hs, ws):
+        """the render spec of a texture of hs x ws texels per plane: the planes keep their extent (MPV.py:75-81: normalised UVs), so the
+        plane-pixel -> texel scale follows the texture size; in the tile-exact layout the scale gives the LATTICE coordinate (a quad spans
+        tile - 1 of them) and the spec carries the tile size (render.RenderSpec.tile)."""
+        if self.tile_own is not None:
+            qh, qw = int(self.args.mpi_h_verts) - 1, int(self.args.mpi_w_verts) - 1
+            th, tw = hs // qh, ws // qw
+            if (qh * th, qw * tw) != (hs, ws) or min(th, tw) < 2:
+                raise RuntimeError(f"tile-exact layout: planes of {(hs, ws)} texels are not {qh} x {qw} whole tiles")
+            self.tile_own = (th, tw)
+            self.spec = dataclasses.replace(self.spec, tile=(th, tw),
+                                            scale=(self.texel_scale[0] * (qw * (tw - 1)) / max(self.mpi_w - 1, 1),
+                                                   self.texel_scale[1] * (qh * (th - 1)) / max(self.mpi_h - 1, 1)))
+            return
+        self.spec = dataclasses.replace(self.spec, tile=(0, 0), scale=(self.texel_scale[0] * (ws - 1) / max(self.mpi_w - 1, 1),
+                                                                       self.texel_scale[1] * (hs - 1) / max(self.mpi_h - 1, 1)))
+
     @torch.no_grad()
     def pack_(self, stack=None):
         """Replace the dense stack of a SPARSIFIED model by the packed pool: static blocks stored once, dynamic blocks per frame, culled
@@ -311,7 +330,7 @@ class MPMeshVid(nn.Module):
         self._window_opt = None
         dev = self._param().device
         src = self.stack.data if stack is None else stack
-        lay = PackedLayout(self.quad_keep.to(dev), self.quad_dyn.to(dev), src.shape[1], src.shape[2], src.shape[3])
+        lay = PackedLayout(self.quad_keep.to(dev), self.quad_dyn.to(dev), src.shape[1], src.shape[2], src.shape[3], self.tile_own)
         pool = lay.new_pool(dev)
         for d in range(lay.D):
             lay.pack_plane_(pool, d, src[d])
@@ -328,8 +347,12 @@ class MPMeshVid(nn.Module):
         return self
 
     # ---- stage-1 -> stage-2 hand-over (MPV.py:235-304) ------------------------------------------------------------------
-    def init_from_mpi(self, state_dict, packed=False):
-        """packed=True (sparsified checkpoints): go straight to the packed pool (pack_()); the checkpoint's dense form stays where the
+    def init_from_mpi(self, state_dict, packed=False, tile_layout=None):
+        """tile_layout (sparsified REFERENCE checkpoints; default args.tile_layout or "exact"): "exact" = every quad keeps its tile with its OWN
+        border row / column, the reference's representation (MPI.py:380-418) -- identical weights for ANY checkpoint, trained ones included
+        (golden G19), and the reference's training trajectory (the two copies of a border sample are separate parameters); "lattice" = the
+        shared-border stack of rounds 4-5 (exact for FRESH checkpoints only; 6-12 % fewer texels).
+        packed=True (sparsified checkpoints): go straight to the packed pool (pack_()); the checkpoint's dense form stays where the
         caller put it (the host) and never exists on the GPU.  Checkpoints of a packed model ('stack_pool') are loaded as such.
         MPV.py:235-288 for the dense representation: take the stage-1 MPI (`MPMesh.state_dict()`) as the initial value of
         every frame.  With a sparsified MPI the quad maps come along: culled quads stay invisible, static quads stay ONE
@@ -340,13 +363,26 @@ class MPMeshVid(nn.Module):
             # tiles onto the dense stack and recover the culled / static / dynamic quad maps from its face lists
             from . import tiles
             hv, wv = int(self.args.mpi_h_verts), int(self.args.mpi_w_verts)
-            st, keep, dyn = tiles.stack_from_reference_state(state_dict, self.mpi_h, self.mpi_w, hv, wv, self.frm_num)
+            layout = tile_layout if tile_layout is not None else getattr(self.args, "tile_layout", "exact")
+            if layout not in ("exact", "lattice"):
+                raise RuntimeError(f"tile_layout must be 'exact' or 'lattice', got {layout!r}")
             sparse = bool(state_dict.get("self.is_sparse", False))
-            # a sparsified checkpoint arrives on its tile lattice (identical weights); the tile size drives lod() like the reference's (MPV.py:146-151)
-            tile = ((st.shape[2] - 1) // (hv - 1) + 1, (st.shape[3] - 1) // (wv - 1) + 1) if tuple(st.shape[2:4]) != (self.mpi_h, self.mpi_w) else None
+            tile_ref = tiles.reference_tile_size(state_dict, hv, wv) if sparse else None      # (th, tw) of a checkpoint `sparsify_faces` wrote
+            own = layout == "exact" and tile_ref is not None and not self.atlas_exact
+            st, keep, dyn = tiles.stack_from_reference_state(state_dict, self.mpi_h, self.mpi_w, hv, wv, self.frm_num, own_borders=own)
+            # a sparsified checkpoint arrives tile for tile (identical weights); the tile size drives lod() like the reference's (MPV.py:146-151)
+            tile_own = tile_ref if own else None
+            if own and "self.atlas_full_h" in state_dict and int(state_dict.get("self.atlas_grid_h", 0)) > 0 and int(state_dict.get("self.atlas_grid_w", 0)) > 0:
+                # (a checkpoint saved at a pyramid level: the FULL tile size is what lod() scales, MPV.py:149-151)
+                tile_ref_full = (int(state_dict["self.atlas_full_h"]) // int(state_dict["self.atlas_grid_h"]),
+                                 int(state_dict["self.atlas_full_w"]) // int(state_dict["self.atlas_grid_w"]))
+            else:
+                tile_ref_full = tile_ref
+            tile = tile_ref_full if own else (((st.shape[2] - 1) // (hv - 1) + 1, (st.shape[3] - 1) // (wv - 1) + 1)
+                                         if tuple(st.shape[2:4]) != (self.mpi_h, self.mpi_w) else None)
             state_dict = {"ref_extrin": state_dict["ref_extrin"], "ref_intrin": state_dict["ref_intrin"],
                           "planedepth": state_dict["planedepth"], "stack": st, "quad_keep": keep, "quad_dyn": dyn,
-                          "self.is_sparse": sparse, "self.has_dyn": sparse, "self.tile_full": tile}
+                          "self.is_sparse": sparse, "self.has_dyn": sparse, "self.tile_full": tile, "self.tile_own": tile_own}
         self.ref_extrin.data = state_dict['ref_extrin'].type_as(self.ref_extrin)
         self.ref_intrin.data = state_dict['ref_intrin'].type_as(self.ref_intrin)
         self.planedepth.data = state_dict['planedepth'].type_as(self.planedepth)
@@ -354,12 +390,14 @@ class MPMeshVid(nn.Module):
         dev = self._param().device
         tf = state_dict.get("self.tile_full", None)
         self.tile_full = None if tf is None else (int(tf[0]), int(tf[1]))
+        to = state_dict.get("self.tile_own", None)
+        self.tile_own = None if to is None else (int(to[0]), int(to[1]))
         if "stack_pool" in state_dict:       # a checkpoint of a packed model of this package: quad maps + dims rebuild the block table
             from .packed import PackedLayout
             D, T, hs, ws = (int(v) for v in state_dict["self.packed_dims"])
             self.register_buffer("quad_keep", state_dict["quad_keep"].to(dev).bool())
             self.register_buffer("quad_dyn", state_dict["quad_dyn"].to(dev).bool())
-            lay = PackedLayout(self.quad_keep, self.quad_dyn, T, hs, ws)
+            lay = PackedLayout(self.quad_keep, self.quad_dyn, T, hs, ws, self.tile_own)
             pool = state_dict["stack_pool"].to(dev, torch.float32).reshape(-1, 4).contiguous()
             if pool.shape[0] != lay.n_slots * 64:
                 raise RuntimeError("packed checkpoint: the pool does not match the block table of its quad maps")
@@ -368,8 +406,7 @@ class MPMeshVid(nn.Module):
             self.register_parameter("stack_pool", nn.Parameter(pool, requires_grad=True))
             self.packed, self.frm_num, self.is_sparse, self.has_dyn = lay, T, True, True
             self._window_opt = None
-            self.spec = dataclasses.replace(self.spec, scale=(self.texel_scale[0] * (ws - 1) / max(self.mpi_w - 1, 1),
-                                                              self.texel_scale[1] * (hs - 1) / max(self.mpi_h - 1, 1)))
+            self._set_texture_geometry(hs, ws)
             return
         mpi = state_dict['stack']
         if mpi.dim() != 5 or mpi.shape[0] != self.mpi_d or mpi.shape[-1] != 4:
@@ -384,8 +421,7 @@ class MPMeshVid(nn.Module):
             self.register_buffer("quad_keep", state_dict["quad_keep"].to(dev).bool())
             self.register_buffer("quad_dyn", state_dict["quad_dyn"].to(dev).bool())
             hs, ws = mpi.shape[2:4]
-            self.spec = dataclasses.replace(self.spec, scale=(self.texel_scale[0] * (ws - 1) / max(self.mpi_w - 1, 1),
-                                                              self.texel_scale[1] * (hs - 1) / max(self.mpi_h - 1, 1)))
+            self._set_texture_geometry(hs, ws)
             self.pack_(stack=mpi.float().expand(-1, self.frm_num, -1, -1, -1))      # (a view: a static MPI is not copied T times)
             return
         if self.packed is not None:
@@ -396,8 +432,7 @@ class MPMeshVid(nn.Module):
         self.register_parameter("stack", nn.Parameter(new, requires_grad=True))
         # planes saved at a pyramid level (lod) keep their extent: the plane-pixel -> texel scale follows the texture size
         hs, ws = new.shape[2:4]
-        self.spec = dataclasses.replace(self.spec, scale=(self.texel_scale[0] * (ws - 1) / max(self.mpi_w - 1, 1),
-                                                          self.texel_scale[1] * (hs - 1) / max(self.mpi_h - 1, 1)))
+        self._set_texture_geometry(hs, ws)
         self.is_sparse = bool(state_dict.get("self.is_sparse", False))
         self.has_dyn = bool(state_dict.get("self.has_dyn", False))
         if self.is_sparse:
@@ -421,9 +456,9 @@ class MPMeshVid(nn.Module):
                 # frame0_only once get_optimizer has handed out the tile-aware Adam, which reads static gradients from frame 0
                 self._tie_hook = self.stack.register_hook(
                     lambda g: tiles.tie_static_grad_hip(g, self.quad_keep, self.quad_dyn, assume_culled_zero=True,
-                                                        frame0_only=self._static_compact))
+                                                        frame0_only=self._static_compact, tile=self.tile_own))
             else:                     # (CPU: host-logic tests only)
-                self._tie_hook = self.stack.register_hook(lambda g: tiles.tie_static_grad(g, self.quad_keep, self.quad_dyn))
+                self._tie_hook = self.stack.register_hook(lambda g: tiles.tie_static_grad(g, self.quad_keep, self.quad_dyn, self.tile_own))
 
     def state_dict(self, *args, **kwargs):
         """MPV.py:290-304: tensors + python scalars under "self.*" keys.  Loaded back with init_from_mpi(), like every driver of the reference
@@ -435,6 +470,8 @@ class MPMeshVid(nn.Module):
         sd["self.has_dyn"] = self.has_dyn
         if self.tile_full is not None:
             sd["self.tile_full"] = self.tile_full
+        if self.tile_own is not None:
+            sd["self.tile_own"] = self.tile_own
         if self.packed is not None:
             sd["self.packed_dims"] = self.stack_dims()      # with quad_keep / quad_dyn this rebuilds the block table (init_from_mpi)
         return sd
@@ -456,6 +493,43 @@ class MPMeshVid(nn.Module):
             h = qh * (max(int(self.tile_full[0] * factor), 2) - 1) + 1
             w = qw * (max(int(self.tile_full[1] * factor), 2) - 1) + 1
         D, T, hs, ws = self.stack_dims()
+        if self.tile_own is not None:
+            # tile-exact layout: the reference's own operation (MPV.py:146-163) -- every tile resized ON ITS OWN to max(int(tile_full * factor), 2)
+            # texels per axis (nothing bleeds between tiles, static and dynamic tiles alike; culled tiles hold nothing that is ever read)
+            qh, qw = int(self.args.mpi_h_verts) - 1, int(self.args.mpi_w_verts) - 1
+            nth, ntw = max(int(self.tile_full[0] * factor), 2), max(int(self.tile_full[1] * factor), 2)
+            h, w = qh * nth, qw * ntw
+            print(f"MPV.lod:: Sparse! Resizing the tiles from {self.tile_own} to {(nth, ntw)}")
+            if (hs, ws) != (h, w):
+                oth, otw = self.tile_own
+
+                def resize_plane(planes):          # (T,hs,ws,4) -> (T,h,w,4), tile by tile
+                    t_ = planes.shape[0]
+                    tl = planes.reshape(t_, qh, oth, qw, otw, 4).permute(0, 1, 3, 5, 2, 4).reshape(t_ * qh * qw, 4, oth, otw)
+                    tl = torch.nn.functional.interpolate(tl, size=(nth, ntw), mode="bilinear", align_corners=False, antialias=True)
+                    return tl.reshape(t_, qh, qw, 4, nth, ntw).permute(0, 1, 4, 2, 5, 3).reshape(t_, h, w, 4)
+                with torch.no_grad():
+                    if self.packed is not None:
+                        from .packed import PackedLayout
+                        dev = self.stack_pool.device
+                        lay = PackedLayout(self.quad_keep.to(dev), self.quad_dyn.to(dev), T, h, w, (nth, ntw))
+                        pool = lay.new_pool(dev)
+                        for d in range(D):
+                            lay.pack_plane_(pool, d, resize_plane(self.packed.unpack_plane(self.stack_pool.data, d)))
+                        del self._parameters["stack_pool"]
+                        self.register_parameter("stack_pool", nn.Parameter(pool, requires_grad=True))
+                        self.packed = lay
+                    else:
+                        from . import tiles
+                        new = torch.empty((D, T, h, w, 4), dtype=self.stack.dtype, device=self.stack.device)
+                        for d in range(D):
+                            new[d] = resize_plane(self.stack.data[d])
+                        tiles.cull_stack_(new, self.quad_keep, (nth, ntw))
+                        self.register_parameter("stack", nn.Parameter(new, requires_grad=True))
+            self._set_texture_geometry(h, w)
+            self._install_tie_hook()
+            print("MPV.los:: Resizing successful !")
+            return
         print(f"MPV.lod:: Resizing the planes from {(hs, ws)} to {(h, w)}")
         if (hs, ws) != (h, w) and self.packed is not None:
             # packed model: plane by plane through the dense form of ONE plane (1/D of the dense stack), the same mask-weighted filter
@@ -561,7 +635,7 @@ class MPMeshVid(nn.Module):
                 from .optim import WindowAdam
                 from .tiles import CULLED_ALPHA
                 self._window_opt = WindowAdam([{'params': [self.stack_pool]}], lr=base_lr, betas=(0.9, 0.999), eps=6e-8, quad_keep=self.quad_keep,
-                                              quad_dyn=self.quad_dyn, culled_alpha=CULLED_ALPHA, layout=self.packed,
+                                              quad_dyn=self.quad_dyn, culled_alpha=CULLED_ALPHA, layout=self.packed, tile=self.tile_own,
                                               fused_backward=bool(getattr(self.args, "fused_adam_backward", True))
                                               and not getattr(self.args, "finite_window_grad", False))
                 return self._window_opt
@@ -570,7 +644,7 @@ class MPMeshVid(nn.Module):
                 # gradients summed into frame 0 by the tie hook while it is the optimiser handed out last)
                 from .tiles import TileAdam
                 self._static_compact = True
-                return TileAdam(params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8, quad_keep=self.quad_keep, quad_dyn=self.quad_dyn)
+                return TileAdam(params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8, quad_keep=self.quad_keep, quad_dyn=self.quad_dyn, tile=self.tile_own)
             if self.stack.is_cuda and self.is_sparse and not self.atlas_exact:
                 # sparsified model: the crop-aware Adam with the quad maps -- culled texels are no parameters, a static texel is ONE
                 # parameter stored once (frame 0; the window copy shows it in every frame, its gradient is summed over the frames inside
@@ -580,7 +654,7 @@ class MPMeshVid(nn.Module):
                 # (fused: dynamic texels are stepped inside the render's backward, static ones by the step kernel behind it -- see the dense branch)
                 fused = bool(getattr(self.args, "fused_adam_backward", True)) and not getattr(self.args, "finite_window_grad", False)
                 self._window_opt = WindowAdam(params, lr=base_lr, betas=(0.9, 0.999), eps=6e-8, quad_keep=self.quad_keep,
-                                              quad_dyn=self.quad_dyn, culled_alpha=CULLED_ALPHA, fused_backward=fused)
+                                              quad_dyn=self.quad_dyn, culled_alpha=CULLED_ALPHA, fused_backward=fused, tile=self.tile_own)
                 return self._window_opt
             if self.stack.is_cuda and not self.atlas_exact:
                 # dense model: crop-aware Adam -- the render reads a compact copy of the crop's texel window, the backward writes a
@@ -758,6 +832,9 @@ class MPMeshVid(nn.Module):
                                            grad_culled_unwritten=lean_grad, fused_adam=fused_adam)
         variables = {"pix_to_face": None, "blend_weight": None, "mpi": None, "disp_norm": None, "alpha": alpha,
                      "smooth_sums": smooth_sums, "alpha_sums": alpha_sums}
+        if need_layers and self.tile_own is not None:
+            raise RuntimeError("the materialised-layer path (d_smooth_loss_weight > 0: off in every shipped configuration) is built for shared-border "
+                               "stacks: load the checkpoint with init_from_mpi(..., tile_layout='lattice')")
         if need_layers:
             # the reference's `mpi` [T',H,W,K,4] (hit-slot order, MPV.py:441-449) and `blend_weight` [T',H,W,K] (MPV.py:451-453), on request
             # only: materialised with the unfused operators (no shipped configuration reads them; the fused kernels never build them)

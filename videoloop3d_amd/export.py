@@ -48,9 +48,11 @@ def quad_faces(D, hv, wv):
     return torch.cat([f013.reshape(-1, 1, 3), f320.reshape(-1, 1, 3)], dim=1)
 
 
-def _pack_tiles(stack, mask, frames, tile_hw):
+def _pack_tiles(stack, mask, frames, tile_hw, own=False):
     """tiles of the quads in `mask` [D,QH,QW], sampled from stack (D,T,H,W,4) like MPI.py:306-340 (grid_sample, align_corners=True,
-    from the quad's first to its last corner), packed row-major into an atlas [frames,4,Ah,Aw] + per-tile corner UVs / uv faces."""
+    from the quad's first to its last corner), packed row-major into an atlas [frames,4,Ah,Aw] + per-tile corner UVs / uv faces.
+    own: the stack is in the TILE-EXACT layout (tile (vy, vx) = rows [vy ih, (vy+1) ih), columns [vx iw, (vx+1) iw)): its tiles are copied
+    texel for texel -- the checkpoint the model was read from comes back bit for bit."""
     D, T, H, W, _ = stack.shape
     QH, QW = mask.shape[1:]
     ch, cw = (H - 1) / QH, (W - 1) / QW
@@ -71,6 +73,11 @@ def _pack_tiles(stack, mask, frames, tile_hw):
     dd = d.to(stack.device)
     for plane in torch.unique(d).tolist():
         sel = (dd == plane).nonzero()[:, 0]
+        if own:
+            img = stack.plane(plane, frames, raw=True).float()                                  # frames,H,W,4 = frames,QH,ih,QW,iw,4
+            tl = img.reshape(frames, QH, ih, QW, iw, 4)[:, vy[sel.cpu()].to(img.device), :, vx[sel.cpu()].to(img.device)]    # n_sel,frames,ih,iw,4
+            tiles[:, sel] = tl.permute(1, 0, 4, 2, 3)
+            continue
         g = grid[sel].reshape(1, len(sel) * ih, iw, 2).expand(frames, -1, -1, -1)
         img = stack.plane(plane, frames).permute(0, 3, 1, 2).float()                            # frames,4,H,W
         out = F.grid_sample(img, g, mode="bilinear", align_corners=True)                        # frames,4,len(sel)*ih,iw
@@ -99,10 +106,10 @@ def reference_state_dict(model, tile_texels=None):
             self.shape = tuple(m.stack_dims()) + (4,) if hasattr(m, "stack_dims") else tuple(m.stack.shape)
             self.device = (m._param() if hasattr(m, "_param") else m.stack).device
 
-        def plane(self, d, frames):
+        def plane(self, d, frames, raw=False):
             pl = self.m.stack_plane(d, range(frames)) if hasattr(self.m, "stack_plane") else self.m.stack.detach()[d, :frames]
             pl = pl.detach()
-            if bool(getattr(self.m, "is_sparse", False)):
+            if bool(getattr(self.m, "is_sparse", False)) and not raw:
                 # texels no kept quad can read hold the alpha logit CULLED_ALPHA (-1e4, tiles.py); a tile's border samples sit exactly on
                 # texel centres, but their fp32 coordinates carry ~1e-6 texels of rounding, which would pull 1e-6 * (-1e4) of a culled
                 # neighbour into an exported kept texel.  -30 is as transparent (sigmoid = 1e-13) and bleeds nothing.
@@ -112,6 +119,11 @@ def reference_state_dict(model, tile_texels=None):
     D, T, H, W, _ = stack.shape
     hv, wv = int(model.args.mpi_h_verts), int(model.args.mpi_w_verts)
     QH, QW = hv - 1, wv - 1
+    own = getattr(model, "tile_own", None) is not None
+    if own:                                         # tile-exact layout: the model's tiles ARE the reference's (texel for texel)
+        if tile_texels is not None and tuple(tile_texels) != tuple(model.tile_own):
+            raise RuntimeError(f"a tile-exact model exports its own tiles of {model.tile_own} texels")
+        tile_texels = tuple(model.tile_own)
     if tile_texels is None:
         tile_texels = (int(round((H - 1) / QH)) + 1, int(round((W - 1) / QW)) + 1)
     sparse = bool(getattr(model, "is_sparse", False)) and getattr(model, "quad_keep", None) is not None
@@ -123,8 +135,11 @@ def reference_state_dict(model, tile_texels=None):
         if not hasattr(model, "frm_num"):           # ... a dense stage-1 MPI is one static atlas (MPI.py:95-117)
             dyn = torch.zeros_like(keep)
     faces = quad_faces(D, hv, wv)
-    idx_s, atlas_s, uvs_s, uvf_s, (gh_s, gw_s) = _pack_tiles(stack, keep & ~dyn, 1, tile_texels)
-    idx_d, atlas_d, uvs_d, uvf_d, (gh_d, gw_d) = _pack_tiles(stack, dyn, T, tile_texels)
+    idx_s, atlas_s, uvs_s, uvf_s, (gh_s, gw_s) = _pack_tiles(stack, keep & ~dyn, 1, tile_texels, own)
+    idx_d, atlas_d, uvs_d, uvf_d, (gh_d, gw_d) = _pack_tiles(stack, dyn, T, tile_texels, own)
+    # atlas_full_*: the atlas size at FULL resolution -- what MPV.lod scales its tiles from (MPV.py:149-151); a model exported at a pyramid
+    # level keeps the full tile size there (tile-exact models know it: tile_full), everything else is exported at the size it has
+    full_hw = tuple(model.tile_full) if (own and getattr(model, "tile_full", None) is not None) else tuple(tile_texels)
     intrin_mpi = model.ref_intrin_mpi.detach().cpu().float()
     mh, mw = model.mpi_h, model.mpi_w
     verts = gen_mpi_vertices(mh, mw, intrin_mpi, hv, wv, model.planedepth.detach().cpu().float())
@@ -143,9 +158,9 @@ def reference_state_dict(model, tile_texels=None):
         "faces": faces[idx_s].reshape(-1, 3), "uvfaces": uvf_s, "uvs": uvs_s.cpu(), "atlas": atlas_s.cpu(),
         "faces_dyn": faces[idx_d].reshape(-1, 3), "uvfaces_dyn": uvf_d, "uvs_dyn": uvs_d.cpu(), "atlas_dyn": atlas_d.cpu(),
         "self.is_sparse": sparse, "self.has_dyn": True,
-        "self.atlas_grid_h": gh_s, "self.atlas_grid_w": gw_s, "self.atlas_full_h": int(atlas_s.shape[-2]), "self.atlas_full_w": int(atlas_s.shape[-1]),
-        "self.atlas_grid_dyn_h": gh_d, "self.atlas_grid_dyn_w": gw_d, "self.atlas_full_dyn_h": int(atlas_d.shape[-2]),
-        "self.atlas_full_dyn_w": int(atlas_d.shape[-1]),
+        "self.atlas_grid_h": gh_s, "self.atlas_grid_w": gw_s, "self.atlas_full_h": gh_s * full_hw[0] if gh_s else int(atlas_s.shape[-2]), "self.atlas_full_w": gw_s * full_hw[1] if gw_s else int(atlas_s.shape[-1]),
+        "self.atlas_grid_dyn_h": gh_d, "self.atlas_grid_dyn_w": gw_d, "self.atlas_full_dyn_h": gh_d * full_hw[0] if gh_d else int(atlas_d.shape[-2]),
+        "self.atlas_full_dyn_w": gw_d * full_hw[1] if gw_d else int(atlas_d.shape[-1]),
     }
 
 

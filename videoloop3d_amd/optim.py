@@ -57,18 +57,30 @@ def crop_window(spec, Hs, Ws, homos, H, W, margin=3, per_plane=False):
         return ((0, 0, Hs, Ws), None) if per_plane else (0, 0, Hs, Ws)
     tx = q[:, 0] / q[:, 2] * spec.scale[0] + spec.offset[0]
     ty = q[:, 1] / q[:, 2] * spec.scale[1] + spec.offset[1]
-    win = align_window(int(torch.floor(ty.min())) - margin, int(torch.ceil(ty.max())) + 2 + margin,
-                       int(torch.floor(tx.min())) - margin, int(torch.ceil(tx.max())) + 2 + margin, Hs, Ws)
+    # per plane the extremes of the footprint (numpy, not torch: a dozen tiny torch CPU ops cost 2 ms per call on a 256-core host --
+    # thread-pool wake-ups -- and starve the launch thread: the iteration fell from 168 to 30 it/s)
+    tyn, txn = ty.numpy(), tx.numpy()
+    ymin, ymax, xmin, xmax = tyn.min(1), tyn.max(1), txn.min(1), txn.max(1)
+    tile = getattr(spec, "tile", (0, 0))
+    if tile[0]:
+        # tile-exact layout: (tx, ty) are LATTICE coordinates; a texel of quad q lies q columns to the right of its lattice position, and a
+        # lattice column on a quad border is two texel columns (the lower end takes the quad strictly below, the upper end the quad at or above)
+        th, tw = int(tile[0]), int(tile[1])
+        QH, QW = Hs // th, Ws // tw
+        ymin = ymin + np.clip(np.ceil(ymin / (th - 1) - 1e-6) - 1, 0, QH - 1)
+        ymax = ymax + np.clip(np.floor(ymax / (th - 1) + 1e-6), 0, QH - 1)
+        xmin = xmin + np.clip(np.ceil(xmin / (tw - 1) - 1e-6) - 1, 0, QW - 1)
+        xmax = xmax + np.clip(np.floor(xmax / (tw - 1) + 1e-6), 0, QW - 1)
+    win = align_window(int(np.floor(ymin.min())) - margin, int(np.ceil(ymax.max())) + 2 + margin,
+                       int(np.floor(xmin.min())) - margin, int(np.ceil(xmax.max())) + 2 + margin, Hs, Ws)
     if not per_plane:
         return win
-    # the planes' boxes by the same rule, vectorised (align_window per plane).  numpy, not torch: a dozen tiny torch CPU ops cost 2 ms
-    # per call on a 256-core host (thread-pool wake-ups) and starve the launch thread -- the iteration fell from 168 to 30 it/s
+    # the planes' boxes by the same rule, vectorised (align_window per plane)
     ts = tile_side()
-    tyn, txn = ty.numpy(), tx.numpy()
-    ylo = np.maximum(np.floor(tyn.min(1)).astype(np.int64) - margin, 0) // ts * ts
-    xlo = np.maximum(np.floor(txn.min(1)).astype(np.int64) - margin, 0) // ts * ts
-    yhi = np.minimum(np.ceil(tyn.max(1)).astype(np.int64) + 2 + margin, Hs)
-    xhi = np.minimum(np.ceil(txn.max(1)).astype(np.int64) + 2 + margin, Ws)
+    ylo = np.maximum(np.floor(ymin).astype(np.int64) - margin, 0) // ts * ts
+    xlo = np.maximum(np.floor(xmin).astype(np.int64) - margin, 0) // ts * ts
+    yhi = np.minimum(np.ceil(ymax).astype(np.int64) + 2 + margin, Hs)
+    xhi = np.minimum(np.ceil(xmax).astype(np.int64) + 2 + margin, Ws)
     yhi = np.minimum(-(-yhi // ts) * ts, Hs)
     xhi = np.minimum(-(-xhi // ts) * ts, Ws)
     boxes = np.stack([ylo, np.maximum(yhi, ylo), xlo, np.maximum(xhi, xlo)], axis=1).astype(np.int32)
@@ -77,7 +89,7 @@ def crop_window(spec, Hs, Ws, homos, H, W, margin=3, per_plane=False):
 
 class WindowAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, quad_keep=None, quad_dyn=None, culled_alpha=-1e4, max_defer=32, layout=None,
-                 lean_window=True, fused_backward=False):
+                 lean_window=True, fused_backward=False, tile=None):
         """quad_keep / quad_dyn [D,QH,QW] (a tile-culled model, videoloop3d_amd/tiles.py): culled texels are no parameters, a texel only
         static quads can read is ONE parameter stored in frame 0 of the stack (the reference's static atlas, MPV.py:235-288) -- the
         window copy shows it in every frame, the step sums its gradient over the frames and writes that one copy; flush() refreshes
@@ -86,6 +98,9 @@ class WindowAdam(torch.optim.Optimizer):
         self.quad_keep = None if quad_keep is None else quad_keep.to(torch.uint8).contiguous()
         self.quad_dyn = None if (quad_keep is None or quad_dyn is None) else quad_dyn.to(torch.uint8).contiguous()
         self.culled_alpha = float(culled_alpha)
+        # tile = (th, tw): the TILE-EXACT layout (every quad owns its border texels; the planes are QH th x QW tw texels): a texel has the
+        # class of the one quad that holds it.  The C ABI takes it as a NEGATIVE quad grid (include/vl3d.h).
+        self.tile = (int(tile[0]), int(tile[1])) if (tile is not None and tile[0] and self.quad_keep is not None) else None
         ps = [p for g in self.param_groups for p in g["params"]]
         if len(ps) != 1:
             raise RuntimeError("WindowAdam drives exactly one parameter: the plane stack (D,T,Hs,Ws,4)")
@@ -143,7 +158,8 @@ class WindowAdam(torch.optim.Optimizer):
 
     def _quads(self):
         qk, qd = self.quad_keep, self.quad_dyn
-        return L.ptr(qk), L.ptr(qd), (0 if qk is None else qk.shape[1]), (0 if qk is None else qk.shape[2])
+        sgn = -1 if self.tile is not None else 1
+        return L.ptr(qk), L.ptr(qd), (0 if qk is None else sgn * qk.shape[1]), (0 if qk is None else sgn * qk.shape[2])
 
     def _catchup(self, window, upto, compact, mirror=False, boxes=None, lean=False):
         st, p = self._st(), self.p
@@ -257,7 +273,8 @@ class WindowAdam(torch.optim.Optimizer):
         return (self.fused_backward and isinstance(pend, tuple) and len(pend) == 3 and self._is_leaf(pend, stack) and stack.dtype == torch.float32
                 and (stack.shape[1] >= 2 or self.quad_keep is not None) and spec.coord_mode == "affine" and spec.border == "hardcut" and spec.act_order == "post"
                 and spec.rgb_act == "sigmoid" and spec.alpha_act == "sigmoid" and (int(spec.variant) & 0xf) in ((0, 3, 5) if self.quad_keep is not None else (0,))
-                and not getattr(spec, "uv_noise_seed", 0))      # (add_uv_noise: the atomics backward + the step kernel)
+                and not getattr(spec, "uv_noise_seed", 0)       # (add_uv_noise: the atomics backward + the step kernel)
+                and (tuple(getattr(spec, "tile", (0, 0))) == (self.tile or (0, 0))))
 
     @staticmethod
     def _is_leaf(pend, stack):
@@ -291,7 +308,8 @@ class WindowAdam(torch.optim.Optimizer):
             if self._class_dev is None or self._class_dev.numel() < n or self._class_dev.device != dev:
                 self._class_dev = None
                 self._class_dev = torch.empty(n, dtype=torch.uint8, device=dev)
-            aw.quad_keep, aw.QH, aw.QW = self.quad_keep.data_ptr(), self.quad_keep.shape[1], self.quad_keep.shape[2]
+            sgn = -1 if self.tile is not None else 1
+            aw.quad_keep, aw.QH, aw.QW = self.quad_keep.data_ptr(), sgn * self.quad_keep.shape[1], sgn * self.quad_keep.shape[2]
             aw.quad_dyn = None if self.quad_dyn is None else self.quad_dyn.data_ptr()
             aw.class_scratch = self._class_dev.data_ptr()
             if self.layout is not None:

@@ -25,12 +25,14 @@ TS = 8      # block side = vl3d_adam_window_tile()
 
 
 class PackedLayout:
-    def __init__(self, quad_keep, quad_dyn, T, Hs, Ws):
-        """quad_keep / quad_dyn [D,QH,QW] bool (any device; the table is built there)."""
+    def __init__(self, quad_keep, quad_dyn, T, Hs, Ws, tile=None):
+        """quad_keep / quad_dyn [D,QH,QW] bool (any device; the table is built there).  tile = (th, tw): the tile-exact layout (every quad owns
+        its border texels, Hs x Ws = QH th x QW tw): a block is stored when a kept tile overlaps it."""
         self.D, self.T, self.Hs, self.Ws = int(quad_keep.shape[0]), int(T), int(Hs), int(Ws)
+        self.tile = (int(tile[0]), int(tile[1])) if (tile is not None and tile[0]) else None
         dev = quad_keep.device
-        keep_t = tiles.quad_to_texel_mask(quad_keep.bool(), Hs, Ws)                       # D,Hs,Ws: texels a kept quad can read
-        dyn_t = tiles.quad_to_texel_mask((quad_keep & quad_dyn).bool(), Hs, Ws)           # ... a dynamic quad can read
+        keep_t = tiles.quad_to_texel_mask(quad_keep.bool(), Hs, Ws, self.tile)                       # D,Hs,Ws: texels a kept quad can read
+        dyn_t = tiles.quad_to_texel_mask((quad_keep & quad_dyn).bool(), Hs, Ws, self.tile)           # ... a dynamic quad can read
         th, tw = -(-Hs // TS), -(-Ws // TS)
         pad = (0, tw * TS - Ws, 0, th * TS - Hs)
 
@@ -120,10 +122,10 @@ class PackedLayout:
 
     @staticmethod
     @torch.no_grad()
-    def from_dense(stack, quad_keep, quad_dyn):
+    def from_dense(stack, quad_keep, quad_dyn, tile=None):
         """dense (D,T,Hs,Ws,4) stack (any device, e.g. a reference checkpoint resampled on the host) -> (layout, pool on stack.device)."""
         D, T, Hs, Ws, _ = stack.shape
-        lay = PackedLayout(quad_keep.to(stack.device), quad_dyn.to(stack.device), T, Hs, Ws)
+        lay = PackedLayout(quad_keep.to(stack.device), quad_dyn.to(stack.device), T, Hs, Ws, tile)
         pool = lay.new_pool(stack.device)
         for d in range(D):
             lay.pack_plane_(pool, d, stack[d])

@@ -340,6 +340,17 @@ def _stack_on_tile_lattice(aligned, D, T, QH, QW):
     return stack.permute(0, 3, 1, 2, 4).contiguous()
 
 
+def reference_tile_size(sd, hv, wv):
+    """(th, tw) when the reference state_dict `sd` holds texel-aligned tiles of one size in its static / dynamic atlases (what `sparsify_faces`
+    and `MPV.lod` write, MPI.py:403-418 / MPV.py:146-197), else None (dense cell atlases, hand-made UVs)."""
+    if "faces_dyn" not in sd:
+        return None
+    parts = [("static", sd.get("faces"), sd.get("uvfaces"), sd.get("uvs"), sd.get("atlas")),
+             ("dyn", sd["faces_dyn"], sd["uvfaces_dyn"], sd["uvs_dyn"], sd["atlas_dyn"])]
+    aligned = _aligned_tiles(parts, hv, wv)
+    return None if aligned is None else aligned[0]
+
+
 def _stack_on_own_tiles(aligned, D, T, QH, QW):
     """tiles of th x tw texels -> the TILE-EXACT plane of QH th x QW tw texels: tile (vy, vx) of plane d occupies rows [vy th, vy th + th),
     columns [vx tw, vx tw + tw) -- every texel of the checkpoint exactly once, the two copies of a border sample that neighbouring tiles hold
