@@ -607,6 +607,7 @@ def main():
                 # dense: the optimiser step inside the render backward (vl3d_render_bwd_adam, the default); dense_two_kernels: vl3d_render_bwd + step kernel
                 res["stage2_schedule"] = {"dense": stage2_schedule.run(dev=str(dev)), "dense_two_kernels": stage2_schedule.run(dev=str(dev), fused=False),
                                           "tile_culled": stage2_schedule.run(dev=str(dev), sparsify=True),
+                                          "tile_exact": stage2_schedule.run(dev=str(dev), sparsify=True, tile_exact=True),
                                           "tile_culled_two_kernels": stage2_schedule.run(dev=str(dev), sparsify=True, fused=False)}
             except Exception as e:
                 res["stage2_schedule"] = {"error": repr(e)}
@@ -660,7 +661,7 @@ def main():
         summ["s1_train_140_epochs_s"] = pick(res, "stage1_train", "projected_140_epochs_s")
         for k_ in ("ref", "other", "other_tile_culled", "other_tile_culled_packed"):
             summ[f"s2step_{k_}_it_s"] = pick(res, "stage2_step", k_, "iters_per_s")
-        for k_ in ("dense", "dense_two_kernels", "tile_culled", "tile_culled_two_kernels"):
+        for k_ in ("dense", "dense_two_kernels", "tile_culled", "tile_exact", "tile_culled_two_kernels"):
             summ[f"s2sched_{k_}_it_s"] = pick(res, "stage2_schedule", k_, "iters_per_s")
             summ[f"s2sched_{k_}_iter_frac"] = pick(res, "stage2_schedule", k_, "roofline_iter", "frac")
         for k_ in list(summ):

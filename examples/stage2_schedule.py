@@ -40,7 +40,10 @@ def make_views(V, H, W, frames, dev):
     return torch.tensor(np.stack(poses), dtype=torch.float32), torch.tensor(K, dtype=torch.float32)[None].repeat(V, 1, 1), vids
 
 
-def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, dev="cuda:0", sparsify=False, fused=True, bwd_variant=0, generic_objective=False):
+def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, dev="cuda:0", sparsify=False, fused=True, bwd_variant=0, generic_objective=False,
+        tile_exact=False):
+    """tile_exact (with sparsify): the model in the TILE-EXACT layout a sparsified reference checkpoint is loaded into (every quad owns its tile,
+    border texels included: 12 x 12 texels per quad of the 396 x 704 planes, MPI.py:296-313) instead of the shared-border pitch-1 stack."""
     from videoloop3d_amd.MPV import MPMeshVid
     from videoloop3d_amd.train_3dvid import MVVidPatchDataset, run_iter
     dev = torch.device(dev)
@@ -76,8 +79,17 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
         model.register_buffer("quad_keep", keep)
         model.register_buffer("quad_dyn", keep & ((qy + qx) % 2 == 0)[None])
         model.is_sparse = model.has_dyn = True
+        if tile_exact:
+            # round(quad extent) + 1 texels per axis, as `sparsify_faces` sizes its tiles (MPI.py:296-313: 703 / 63 = 11.2 -> 12)
+            th, tw = int(round((model.mpi_h - 1) / QH)) + 1, int(round((model.mpi_w - 1) / QW)) + 1
+            model.tile_full = model.tile_own = (th, tw)
+            with torch.no_grad():
+                st = torch.randn((planes, frames, QH * th, QW * tw, 4), device=dev) * args.init_std
+                st[..., -1] = -2
+            model.register_parameter("stack", torch.nn.Parameter(st, requires_grad=True))
+            model._set_texture_geometry(QH * th, QW * tw)
         with torch.no_grad():
-            tiles.cull_stack_(model.stack.data, keep)
+            tiles.cull_stack_(model.stack.data, keep, model.tile_own)
         model._install_tie_hook()
     factors = [0.75 ** i for i in range(levels)][::-1]
     gen = torch.Generator().manual_seed(2)
@@ -164,7 +176,7 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
                                 "p50": int(np.searchsorted(c, 0.5)), "p90": int(np.searchsorted(c, 0.9)), "max": int(len(depth_hist) - 1),
                                 "histogram_by_8": [int(depth_hist[i:i + 8].sum()) for i in range(0, len(depth_hist), 8)]}
     out["shape"] = (f"V={views} views, D={planes}, T={frames}, clips of {clip} frames, 360x640 frames, crops 180x320 stride 90x160 at the last "
-                    f"{levels} pyramid levels, {epochs} epochs per level, smooth {smooth}, {'tile-culled' if sparsify else 'dense'} model{'' if sparsify else (', step inside the backward' if fused else ', backward + step kernel')}")
+                    f"{levels} pyramid levels, {epochs} epochs per level, smooth {smooth}, {('tile-culled, tile-exact layout' if tile_exact else 'tile-culled') if sparsify else 'dense'} model{'' if sparsify else (', step inside the backward' if fused else ', backward + step kernel')}")
     return out
 
 
@@ -173,10 +185,12 @@ if __name__ == "__main__":
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--epochs", type=int, default=2)
     ap.add_argument("--sparsify", action="store_true")
+    ap.add_argument("--tile-exact", action="store_true", help="with --sparsify: every quad owns its tile, border texels included (the layout of a reference checkpoint)")
     ap.add_argument("--two-kernels", action="store_true", help="dense model: vl3d_render_bwd + the step kernel instead of the step inside the backward")
     ap.add_argument("--bwd-variant", type=int, default=0)
     ap.add_argument("--generic-objective", action="store_true", help="forward + weighted_total instead of MPMeshVid.objective")
     a = ap.parse_args()
     import __graft_entry__ as g
     g.build()
-    print(json.dumps(run(a.views, a.epochs, sparsify=a.sparsify, fused=not a.two_kernels, bwd_variant=a.bwd_variant, generic_objective=a.generic_objective)))
+    print(json.dumps(run(a.views, a.epochs, sparsify=a.sparsify, fused=not a.two_kernels, bwd_variant=a.bwd_variant, generic_objective=a.generic_objective,
+                         tile_exact=a.tile_exact)))

@@ -133,6 +133,22 @@ int vl3d_render_bwd(const vl3d_render_desc *desc, const void *stack, const float
  * window record -- no sweep, no barrier, zeros stored to the texels it owns), which changes no result.  D <= 128.
  * cull_scratch: vl3d_render_cull_scratch_bytes(desc) bytes (forward plan, rebuilt every call, no host sync); the backward
  * keeps its plan in its own scratch. */
+/* Tile-exact layout (round 6).  `sparsify_faces` cuts every kept quad out of the atlas as a tile WITH ITS OWN border row / column (MPI.py:380-418:
+ * neighbouring tiles hold two copies of their common border samples), every face's UVs span exactly its tile (gen_quad_uvs, MPI.py:403-418;
+ * sampled by MPV.py:394-427 / MPI.py:497-536), and stage 2 trains the two copies APART -- a static tile's copy is one texture, its dynamic
+ * neighbour's copy moves per frame.  A stack on which neighbouring quads SHARE their border texels (the layout above) cannot hold such a
+ * checkpoint.  Passing a NEGATIVE quad grid (-QH, -QW) to any entry point that takes one selects the tile-exact layout instead:
+ *   - a plane is QH x QW tiles of th x tw texels, th = Hs / QH, tw = Ws / QW (whole tiles of at least 2 x 2 texels; with desc->cull_*: of the
+ *     cull_Hs x cull_Ws plane the stack is a window of -- the window itself need not be tile aligned); texel (y, x) belongs to quad
+ *     (y / th, x / tw) and to no other: its class (culled / static / dynamic) is that quad's;
+ *   - desc->sx, sy, ox, oy map a plane pixel to the LATTICE coordinate L (quads sharing borders: a quad spans tw - 1 of them, quad q =
+ *     floor(L / (tw - 1))); the sample's texel coordinate is L + q -- position L - q (tw - 1) in [0, tw - 1] inside tile q, whose first texel
+ *     is q tw -- so its bilinear taps never leave its own tile with a non-zero weight: grid_sample(align_corners=True) on the reference's
+ *     atlas between the tile's corner texel centres.  With a window, ox / oy are reduced by the window's texel origin as usual.
+ *   - everything else (hard cut at the plane's extent, culled quads uncovered, hit-slot regularisers, owner-computes backward, the fused
+ *     optimiser step, packed pools, add_uv_noise jittering the TILE coordinate) is unchanged: the layout is a piecewise translation of the
+ *     texel coordinate.  VL3D_COORD_AFFINE + VL3D_BORDER_HARDCUT only (the reference has tiles on the planar MPV / MPI path only).
+ * Pinned by golden G19 (tests/golden/make_golden_r06.py: the reference's own forward on a checkpoint whose border copies differ). */
 int64_t vl3d_render_cull_scratch_bytes(const vl3d_render_desc *desc);
 int vl3d_render_fwd_culled(const vl3d_render_desc *desc, const void *stack, const float *homos, const uint8_t *quad_keep,
                            int32_t QH, int32_t QW, void *cull_scratch, float *rgb, float *alpha, float *alpha_sums,
@@ -155,6 +171,7 @@ int vl3d_tie_static_grad(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uin
 /* torch.optim.Adam step (no amsgrad, no weight decay; MPV.py:199-214) on a stack parameter (D,T,Hs,Ws,4), in place on param /
  * exp_avg / exp_avg_sq, restricted to the texels a kept quad can read (quad_keep NULL: all texels).  Culled texels have zero
  * gradient and zero moments for ever, so skipping them is exact; `step` is the 1-based step count of this update.
+ * (QH, QW) negative: the tile-exact layout ("Tile-exact layout" above; also for vl3d_tie_static_grad and the vl3d_adam_window_* family).
  * quad_dyn (optional, with quad_keep): texels only static quads can read are ONE parameter with T identical copies -- the
  * update is computed once from frame 0 (gradient = the frame sum vl3d_tie_static_grad leaves there; moments live in frame 0)
  * and the new value is written to all T copies. */

@@ -184,8 +184,14 @@ def test_mpmesh_driver_hooks_and_checkpoint_round_trip():
     m.sparsify_faces(erode_num=1)
     sd = m.reference_state_dict()
     m3 = MPMesh(_args(optimizer="adam", lrate=0.05, lrate_decay=100), 41, 61, np.eye(4), K, 1.0, 100.0)
-    m3.init_from_mpi(sd)
+    m3.init_from_mpi(sd, tile_layout="lattice")      # (a pitch-1 model's export, read back onto the stack it came from)
     assert m3.is_sparse and torch.equal(m3.quad_keep, m.quad_keep) and not hasattr(m3, "stack_mask")
+    # the default layout keeps every exported tile with its own border texels: the same samples, tile by tile (11 x 11 per quad of 10 plane pixels)
+    m4 = MPMesh(_args(optimizer="adam", lrate=0.05, lrate_decay=100), 41, 61, np.eye(4), K, 1.0, 100.0)
+    m4.init_from_mpi(sd)
+    assert m4.tile_own == (11, 11) and m4.stack.shape[2:4] == (4 * 11, 6 * 11) and torch.equal(m4.quad_keep, m.quad_keep)
+    for d, qy, qx in m.quad_keep.nonzero().tolist()[:5]:
+        assert float((m4.stack.detach()[d, 0, qy * 11:qy * 11 + 11, qx * 11:qx * 11 + 11] - m.stack.detach()[d, 0, qy * 10:qy * 10 + 11, qx * 10:qx * 10 + 11]).abs().max()) <= 2e-4
     kt = tiles.quad_to_texel_mask(m.quad_keep, 41, 61)[:, None, :, :, None].expand_as(m.stack)
     # texels inside kept quads come back (the export keeps the quad rectangles; one-texel aprons outside them are resampled from borders)
     from videoloop3d_amd.tiles import CULLED_ALPHA

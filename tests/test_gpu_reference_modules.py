@@ -41,7 +41,7 @@ def test_sparsified_mpmesh_forward_matches_the_reference(dev):
     h, w, tar_e, K_crop, K_full = RM.crop_view(g)
     sd = RM.state_dict_of(g15, "sd_")
     m = MPMesh(args, H, W, ref_extrin, K, 1.0, 100.0)
-    m.init_from_mpi(sd)
+    m.init_from_mpi(sd, tile_layout="lattice")
     m = m.to(dev)
     assert m.is_sparse and m.stack.shape[2:4] == (37, 55) and not m.learn_loop_mask
     m.train()
@@ -64,6 +64,56 @@ def test_sparsified_mpmesh_forward_matches_the_reference(dev):
     m.is_sparse = False
     _, extra_nq = m(h, w, tar_e, K_crop)
     assert abs(float(extra_nq["rgb_smooth"]) - float(g["b_extra_rgb_smooth"].item())) > 1e-3
+
+
+def test_trained_tile_checkpoint_stage1_matches_the_reference(dev):
+    """golden G19 (j): the stage-1 model AFTER sparsify_faces with both atlases perturbed everywhere (train_3d.py:282-285 trains it for the last
+    epochs: the two copies of a border sample drift apart) -- MPMesh in the tile-exact layout against the reference's own forward: image,
+    regulariser terms, the gradient of every tile texel, evaluation render; one crop-aware training step moves kept tiles only."""
+    from videoloop3d_amd.MPI import MPMesh
+    g = RM.load("g19_trained_tiles")
+    H, W, over, K, ref_extrin, _ = RM.case_A()
+    hv, wv, D = over["mpi_h_verts"], over["mpi_w_verts"], over["mpi_d"]
+    args = R4.make_args(learn_loop_mask=True, **over, **RM.REG)
+    h, w, tar_e, K_crop, K_full = RM.crop_view(g)
+    sd = RM.state_dict_of(g, "j_sd_")
+    m = MPMesh(args, H, W, ref_extrin, K, 1.0, 100.0)
+    m.init_from_mpi(sd)
+    m = m.to(dev)
+    assert m.is_sparse and m.tile_own == (10, 10) and m.stack.shape[2:4] == (40, 60) and m.spec.tile == (10, 10)
+    m.train()
+    rgbl, extra = m(h, w, tar_e, K_crop)
+    _close(rgbl, g["j_rgb"], 1e-4, "rgb")
+    for k in ("sparsity", "rgb_smooth", "a_smooth", "density"):
+        _rel(extra[k], g[f"j_extra_{k}"], k)
+    total = (rgbl * torch.from_numpy(g["j_G"]).to(dev)).sum() + sum(getattr(args, k + "_loss_weight") * v.sum() for k, v in extra.items())
+    (gs,) = torch.autograd.grad(total, m.stack)
+    g_dyn, g_static = RM.own_grad_from_reference(sd, hv, wv, D, 1, torch.from_numpy(g["j_grad_atlas"]), torch.from_numpy(g["j_grad_atlas_dyn"]))
+    _rel(gs[:, 0], g_dyn[:, 0] + g_static, "gradient of every tile texel")
+    m.eval()
+    with torch.no_grad():
+        _close(m(H, W, tar_e, K_full)[0], g["j_eval_rgb_full"], 1e-4, "eval")
+    # the checkpoint goes back out bit for bit (tiles a face references)
+    out = m.reference_state_dict()
+    for key, faces, gw_ in (("atlas", "faces", "self.atlas_grid_w"), ("atlas_dyn", "faces_dyn", "self.atlas_grid_dyn_w")):
+        for k_ in range(sd[faces].shape[0] // 2):
+            ys, xs = slice((k_ // sd[gw_]) * 10, (k_ // sd[gw_]) * 10 + 10), slice((k_ % sd[gw_]) * 10, (k_ % sd[gw_]) * 10 + 10)
+            assert torch.equal(out[key][..., ys, xs].cpu(), sd[key][..., ys, xs]), (key, k_)
+    # a training step through the crop-aware engine (window copy of the tile planes, the step inside the backward)
+    m.train()
+    m.args.crop_aware_adam = True
+    opt = m.get_optimizer()
+    from videoloop3d_amd.optim import Stage1Adam
+    assert isinstance(opt, Stage1Adam) and opt.window.tile == (10, 10)
+    opt.acknowledge_fused_backward()
+    before = m.stack.detach().clone()
+    rgbl, extra = m(h, w, tar_e, K_crop)
+    ((rgbl * torch.from_numpy(g["j_G"]).to(dev)).sum() + sum(getattr(args, k + "_loss_weight") * v.sum() for k, v in extra.items())).backward()
+    opt.step()
+    opt.flush()
+    kept = tiles.quad_to_texel_mask(m.quad_keep, 40, 60, (10, 10))
+    moved = (m.stack.detach() - before).abs().amax((1, 4))
+    assert float(moved[kept].max()) > 0 and float(moved[~kept].max()) == 0.0
 
 
 def test_sparsified_mpmeshvid_forward_matches_the_reference(dev):

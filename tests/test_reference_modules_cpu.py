@@ -515,8 +515,13 @@ def test_reader_and_exporter_round_trip_oracle_checkpoints(H, W, scale, hv, wv, 
         m.stack.copy_(atlas_to_stack(atlas, D, gh))
         m.stack_mask.copy_(atlas_to_stack(mask, D, gh)[..., 0])
     m2 = MPMesh(copy.copy(args), H, W, ref_extrin, K, 1.0, 100.0)
-    m2.init_from_mpi(sd)
+    m2.init_from_mpi(sd, tile_layout="lattice")
     assert m2.stack.shape[2:4] == ((hv - 1) * (th - 1) + 1, (wv - 1) * (tw - 1) + 1)
+    # ... and in the default, tile-exact layout the checkpoint comes back bit for bit
+    m3 = MPMesh(copy.copy(args), H, W, ref_extrin, K, 1.0, 100.0)
+    m3.init_from_mpi(sd)
+    assert m3.tile_own == (th, tw) and m3.stack.shape[2:4] == ((hv - 1) * th, (wv - 1) * tw)
+    _check_state(m3.reference_state_dict(), sd, atol=0.0)
     m.sparsify_faces(erode_num=2, alpha_thresh=0.05, loop_thresh=0.5)
     assert torch.equal(m.quad_keep, m2.quad_keep) and torch.equal(m.quad_dyn, m2.quad_dyn)
     assert int(m2.quad_keep.sum()) == n_s + n_d and int(m2.quad_dyn.sum()) == n_d

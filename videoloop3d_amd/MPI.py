@@ -105,6 +105,7 @@ class MPMesh(nn.Module):
         # quads of the vertex grid (utils_mpi.py:80-89); classified by sparsify_faces
         self.quad_h, self.quad_w = max(int(getattr(args, "mpi_h_verts", 12)) - 1, 1), max(int(getattr(args, "mpi_w_verts", 15)) - 1, 1)
         self.is_sparse = False
+        self.tile_own = None             # (th, tw): tile-exact layout of a sparsified REFERENCE checkpoint (init_from_mpi)
         self.has_dyn = False
         self._window_opt = None          # the crop-aware optimiser handed out by get_optimizer (optim.Stage1Adam): training renders go through its window
 
@@ -167,6 +168,8 @@ class MPMesh(nn.Module):
         sd = super().state_dict(*args, **kwargs)
         sd["self.is_sparse"] = self.is_sparse
         sd["self.quad_h"], sd["self.quad_w"] = self.quad_h, self.quad_w
+        if getattr(self, "tile_own", None) is not None:
+            sd["self.tile_own"] = self.tile_own
         if self.has_dyn:
             sd["self.has_dyn"] = self.has_dyn
         return sd
@@ -204,7 +207,7 @@ class MPMesh(nn.Module):
                 qk = self.quad_keep if (self.is_sparse and getattr(self, "quad_keep", None) is not None) else None
                 fused = bool(getattr(a, "fused_adam_backward", True)) and not getattr(a, "finite_window_grad", False)
                 self._window_opt = Stage1Adam(self.stack, others, lr=a.lrate, betas=(0.9, 0.999), eps=1e-8, quad_keep=qk,
-                                              culled_alpha=CULLED_ALPHA, fused_backward=fused)
+                                              culled_alpha=CULLED_ALPHA, fused_backward=fused, tile=getattr(self, "tile_own", None) if qk is not None else None)
                 return self._window_opt
             # torch.optim.Adam's update in one pass per parameter (tiles.TileAdam without a quad map; getattr(args, 'torch_adam') keeps torch's)
             if self.stack.is_cuda and not getattr(a, "torch_adam", False):
@@ -225,17 +228,28 @@ class MPMesh(nn.Module):
         if step >= getattr(self.args, "optimize_geo_start", 10000000):
             self.optimize_geometry = True
 
-    def init_from_mpi(self, state_dict):
+    def init_from_mpi(self, state_dict, tile_layout=None):
         """MPI.py:174-205 (resume / warm start, train_3d.py:176-186): a state_dict of this class, or of the REFERENCE's MPMesh (plane
         meshes + packed atlas: resampled onto the dense stack, quad maps recovered from its face lists; the loop-mask texture of a
-        reference checkpoint is not carried -- the reference drops it at sparsify time, MPI.py:440-441)."""
+        reference checkpoint is not carried -- the reference drops it at sparsify time, MPI.py:440-441).
+        tile_layout (sparsified reference checkpoints; default args.tile_layout or "exact", as MPMeshVid.init_from_mpi): "exact" = every quad
+        keeps its tile with its own border texels -- the epochs stage 1 trains AFTER the switch-over (train_3d.py:282-285) move the two
+        copies of a border sample apart (golden G19 j); "lattice" = neighbouring quads share them."""
         self._window_opt = None          # (the parameters are replaced: the driver asks for a new optimiser)
         if "stack" not in state_dict and "atlas" in state_dict:
             hv, wv = int(self.args.mpi_h_verts), int(self.args.mpi_w_verts)
-            st, keep, dyn = tiles.stack_from_reference_state(state_dict, self.mpi_h, self.mpi_w, hv, wv, 1)
+            layout = tile_layout if tile_layout is not None else getattr(self.args, "tile_layout", "exact")
+            if layout not in ("exact", "lattice"):
+                raise RuntimeError(f"tile_layout must be 'exact' or 'lattice', got {layout!r}")
             sparse = bool(state_dict.get("self.is_sparse", False))
+            tile_ref = tiles.reference_tile_size(state_dict, hv, wv) if sparse else None
+            own = layout == "exact" and tile_ref is not None and not self.atlas_exact
+            st, keep, dyn = tiles.stack_from_reference_state(state_dict, self.mpi_h, self.mpi_w, hv, wv, 1, own_borders=own)
             state_dict = {"ref_extrin": state_dict["ref_extrin"], "ref_intrin": state_dict["ref_intrin"], "planedepth": state_dict["planedepth"],
-                          "stack": st[:, :1], "quad_keep": keep, "quad_dyn": dyn, "self.is_sparse": sparse, "self.has_dyn": sparse}
+                          "stack": st[:, :1], "quad_keep": keep, "quad_dyn": dyn, "self.is_sparse": sparse, "self.has_dyn": sparse,
+                          "self.tile_own": tile_ref if own else None}
+        to = state_dict.get("self.tile_own", None)
+        self.tile_own = None if to is None else (int(to[0]), int(to[1]))
         dev = self.stack.device
         self.ref_extrin.data = state_dict['ref_extrin'].type_as(self.ref_extrin)
         self.ref_intrin.data = state_dict['ref_intrin'].type_as(self.ref_intrin)
@@ -256,8 +270,15 @@ class MPMesh(nn.Module):
             if "stack_mask" in state_dict and hasattr(self, "stack_mask"):
                 self.stack_mask.copy_(state_dict["stack_mask"].to(dev))
         hs, ws = self.stack.shape[2:4]
-        self.spec = dataclasses.replace(self.spec, scale=(self.texel_scale[0] * (ws - 1) / max(self.mpi_w - 1, 1),
-                                                          self.texel_scale[1] * (hs - 1) / max(self.mpi_h - 1, 1)))
+        if self.tile_own is not None:      # tile-exact layout: the scale gives the LATTICE coordinate, the spec carries the tile (render.RenderSpec.tile)
+            th, tw = self.tile_own
+            if (self.quad_h * th, self.quad_w * tw) != (hs, ws):
+                raise RuntimeError(f"tile-exact checkpoint: planes of {(hs, ws)} texels are not {self.quad_h} x {self.quad_w} tiles of {self.tile_own}")
+            self.spec = dataclasses.replace(self.spec, tile=(th, tw), scale=(self.texel_scale[0] * self.quad_w * (tw - 1) / max(self.mpi_w - 1, 1),
+                                                                             self.texel_scale[1] * self.quad_h * (th - 1) / max(self.mpi_h - 1, 1)))
+        else:
+            self.spec = dataclasses.replace(self.spec, tile=(0, 0), scale=(self.texel_scale[0] * (ws - 1) / max(self.mpi_w - 1, 1),
+                                                                           self.texel_scale[1] * (hs - 1) / max(self.mpi_h - 1, 1)))
         self.spec_mask = dataclasses.replace(self.spec, rgb_act="sigmoid")
         self.is_sparse = bool(state_dict.get("self.is_sparse", False))
         self.has_dyn = bool(state_dict.get("self.has_dyn", False))
@@ -324,6 +345,9 @@ class MPMesh(nn.Module):
         """the materialised tensors of one view (slow path, videoloop3d_amd/layers.py): `mpi` [1,H,W,K,4] and `loopmask3d` [1,H,W,K,1] in hit-slot
         order (MPI.py:538-548, 575-577), `blend_weight` [1,H,W,K], `disp_norm` [1,H,W] (MPI.py:483-485, 558-561: the disparity of every
         hit normalised between far and near, blended; args.normalize_blendweight_fordepth divides the weights by alpha first)."""
+        if getattr(self, "tile_own", None) is not None:
+            raise RuntimeError("the materialised-layer path (d_smooth / l_smooth: off in every shipped configuration) is built for shared-border "
+                               "stacks: load the checkpoint with init_from_mpi(..., tile_layout='lattice')")
         from . import layers as LY
         from .MPV import ACTIVATES
         from .utils_mpi import overcompose

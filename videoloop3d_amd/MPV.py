@@ -756,7 +756,9 @@ class MPMeshVid(nn.Module):
         # stack[:, ts] first moved 571 MB per 720p frame, more than the render itself reads (scripts/script_render_video.py renders one frame per
         # camera of its path)
         frame_run = None
-        if (self.packed is None and not (self.training and torch.is_grad_enabled()) and not need_layers and not need_smooth and not self.atlas_exact
+        # (no autograd on that path: taken only where none is asked for -- an eval-mode render with grad enabled on a trainable stack, e.g. a
+        # gradient check or test-time optimisation, goes through render_planes below and stays differentiable)
+        if (self.packed is None and (not torch.is_grad_enabled() or not self.stack.requires_grad) and not need_layers and not need_smooth and not self.atlas_exact
                 and self.stack.is_cuda and self.stack.is_contiguous() and not self._all_frames(ts)):
             tl = torch.as_tensor(ts).tolist()
             if len(tl) >= 1 and tl == list(range(tl[0], tl[0] + len(tl))) and 0 <= tl[0] and tl[-1] < self.stack.shape[1]:

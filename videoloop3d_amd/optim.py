@@ -426,10 +426,10 @@ class Stage1Adam:
     parameter) for whatever else the model trains (the loop-mask texture).  The driver sees `param_groups[0]` (learning rate set per
     iteration, train_3d.py:303-310), zero_grad(), step(), state_dict()."""
 
-    def __init__(self, stack_param, other_params, lr, betas=(0.9, 0.999), eps=1e-8, quad_keep=None, culled_alpha=-1e4, fused_backward=True):
+    def __init__(self, stack_param, other_params, lr, betas=(0.9, 0.999), eps=1e-8, quad_keep=None, culled_alpha=-1e4, fused_backward=True, tile=None):
         from .tiles import TileAdam
         self.window = WindowAdam([stack_param], lr=lr, betas=betas, eps=eps, quad_keep=quad_keep, culled_alpha=culled_alpha,
-                                 fused_backward=fused_backward)
+                                 fused_backward=fused_backward, tile=tile)
         other_params = list(other_params)
         self.other = TileAdam([{'params': other_params}], lr=lr, betas=betas, eps=eps) if other_params else None
         self.param_groups = [dict(params=[stack_param] + other_params, lr=lr, betas=betas, eps=eps)]

@@ -57,49 +57,50 @@ def render_path_spiral(c2w, up, rads, focal, zrate, zdelta, rots, N):
     return np.stack([viewmatrix(np.array([0, 0, focal]) - c, up, c) for c in centres])
 
 
+def _llff_cameras(table, shrink):
+    """rows of a poses_bounds table [V,17] -> (camera-to-world [V,3,4] with columns (right, up, back, position), (H, W, f) per view [V,3],
+    (near, far) per view [V,2]).  LLFF writes the rotation's columns as (down, right, back) (dataloader.py:79-80 reorders them); `shrink`
+    divides the image size and the focal length (images loaded at 1 / factor of their resolution, dataloader.py:24-28)."""
+    table = np.asarray(table)
+    mats = table[:, :15].reshape(-1, 3, 5)
+    c2w = np.stack([mats[:, :, 1], mats[:, :, 0], -mats[:, :, 2], mats[:, :, 3]], axis=2)
+    return c2w.astype(np.float32), (mats[:, :, 4] / shrink).astype(np.float32), table[:, 15:17].astype(np.float32)
+
+
+def _pinhole(hwf):
+    """(H, W, f) rows [N,3] -> intrinsics [N,3,3] with the principal point at the image centre (dataloader.py:121-131)."""
+    K = np.zeros((len(hwf), 3, 3), dtype=hwf.dtype)
+    K[:, 0, 0] = K[:, 1, 1] = hwf[:, 2]
+    K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = 0.5 * hwf[:, 1], 0.5 * hwf[:, 0], 1
+    return K
+
+
 def load_llff_poses(poses_bounds, factor=8, recenter=True, bd_factor=(1, 1), render_frm=120, render_scaling=1.):
-    """dataloader.py:9-29, 60-134 without the images: `poses_bounds` = the array of poses_bounds.npy (or its path) ->
-    (poses [V,3,4], intrins [V,3,3], bds [2], render_poses [N,3,4], render_intrins [N,3,3]), float32 like the reference."""
+    """The camera side of `dataloader.load_llff_data` (dataloader.py:60-134) without the images: `poses_bounds` = the array of
+    poses_bounds.npy (or its path) -> (poses [V,3,4], intrins [V,3,3], bds [2], render_poses [N,3,4], render_intrins [N,3,3]), float32.
+    Steps: LLFF axes -> (right, up, back); the scene rescaled so that the nearest depth bound is 1; optionally every pose expressed in the
+    average camera's frame; a two-turn spiral of `render_frm` cameras around the average camera, looking at a point between 0.9 x the near
+    and 5 x the far bound (3 : 1 in inverse depth), with radii = 0.8 x the largest camera offsets per axis."""
     if isinstance(poses_bounds, (str, os.PathLike)):
         poses_bounds = np.load(poses_bounds)
-    poses_arr = np.asarray(poses_bounds)
-    poses = poses_arr[:, :-2].reshape([-1, 3, 5]).transpose([1, 2, 0])
-    bds = poses_arr[:, -2:].transpose([1, 0])
-    factor = 1 if factor is None else factor
-    poses = poses + 0
-    poses[:2, 4, :] = poses[:2, 4, :] / factor          # hw
-    poses[2, 4, :] = poses[2, 4, :] / factor            # focal
-    # rotation matrix ordering, variable dim to axis 0
-    poses = np.concatenate([poses[:, 1:2, :], poses[:, 0:1, :], -poses[:, 2:3, :], poses[:, 3:, :]], 1)
-    poses = np.moveaxis(poses, -1, 0).astype(np.float32)
-    bds = np.moveaxis(bds, -1, 0).astype(np.float32)
-    bds = np.array([bds.min(), bds.max()]).astype(poses.dtype)
-    sc = 1. / bds[0]
-    poses[:, :3, 3] *= sc
-    bds *= sc
+    c2w, hwf, depth_bounds = _llff_cameras(poses_bounds, 1 if factor is None else factor)
+    bds = np.array([depth_bounds.min(), depth_bounds.max()], dtype=np.float32)
+    unit = np.float32(1.) / bds[0]                      # the nearest bound becomes 1
+    c2w[:, :, 3] *= unit
+    bds *= unit
     if bd_factor is not None:
         bds *= bd_factor
+    cams = np.concatenate([c2w, hwf[:, :, None]], axis=2)                  # [V,3,5]: the helpers carry the (H, W, f) column along
     if recenter:
-        poses = recenter_poses(poses)
-    c2w = poses_avg(poses)
-    up = _unit(poses[:, :3, 1].sum(0))
-    close_depth, inf_depth = bds.min() * .9, bds.max() * 5.
-    dt = .75
-    focal = 1. / (((1. - dt) / close_depth + dt / inf_depth))
-    zdelta = close_depth * .2
-    rads = np.abs(poses[:, :3, 3]).max(0) * 0.8 * render_scaling
-    render_poses = np.array(render_path_spiral(c2w, up, rads, focal, zrate=.5, zdelta=zdelta, rots=2, N=render_frm)).astype(np.float32)
-    poses = poses.astype(np.float32)
-    H, W, f = poses[:, :3, -1].T
-    poses = poses[:, :3, :4]
-    intrins = np.zeros_like(poses[:, :3, :3])
-    intrins[:, -1, -1] = 1
-    intrins[:, 0, 0] = f
-    intrins[:, 1, 1] = f
-    intrins[:, 0, 2] = 0.5 * W
-    intrins[:, 1, 2] = 0.5 * H
-    render_intrins = np.repeat(intrins[:1, ...], len(render_poses), 0)
-    return poses, intrins, bds, render_poses, render_intrins
+        cams = recenter_poses(cams)
+    centre = poses_avg(cams)
+    look_near, look_far = bds.min() * .9, bds.max() * 5.
+    w_far = .75
+    spiral = render_path_spiral(centre, _unit(cams[:, :3, 1].sum(0)), rads=np.abs(cams[:, :3, 3]).max(0) * 0.8 * render_scaling,
+                                focal=1. / ((1. - w_far) / look_near + w_far / look_far), zrate=.5, zdelta=look_near * .2, rots=2, N=render_frm)
+    cams = cams.astype(np.float32)
+    intrins = _pinhole(cams[:, :, 4])
+    return cams[:, :, :4], intrins, bds, spiral.astype(np.float32), np.repeat(intrins[:1], len(spiral), axis=0)
 
 
 def pose2extrin_np(pose):
@@ -232,6 +233,8 @@ def render_frames(nerf, H, W, view_extrins, view_intrins, render_t, max_batch=64
     view_extrins = torch.as_tensor(np.asarray(view_extrins), dtype=torch.float32)
     view_intrins = torch.as_tensor(np.asarray(view_intrins), dtype=torch.float32)
     render_t = np.asarray(render_t).astype(np.int64)
+    # script_render_video.py:129 loops over the POSES: a `--t` range longer than the camera path renders len(view_poses) frames
+    render_t = render_t[:len(view_extrins)]
     res = None
     if in_place and hasattr(module, "plane_homographies") and len(render_t) > 0:
         res = _render_frames_in_place(module, H, W, view_extrins, view_intrins, render_t, max_batch)

@@ -22,13 +22,23 @@ from .MPV import get_new_intrin
 from .train_3dvid import generate_patchinfo, pose2extrin_torch
 
 
+# OpenCV's fixed kernels for odd k <= 7 when sigma is not given (cv::getGaussianKernel's small_gaussian_tab; from memory of its source -- cv2 is
+# absent from this image, so this is unpinned like everything on the OUT-OF-SCOPE data side)
+_SMALL_GAUSSIAN = {1: [1.0], 3: [0.25, 0.5, 0.25], 5: [0.0625, 0.25, 0.375, 0.25, 0.0625],
+                   7: [0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125]}
+
+
 def _gaussian_blur(x, ksize):
-    """cv2.GaussianBlur(x, (k, k), 0) on [N,C,h,w]: sigma = 0.3 ((k - 1) / 2 - 1) + 0.8, separable, BORDER_REFLECT_101."""
-    sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
+    """cv2.GaussianBlur(x, (k, k), 0) on [N,C,h,w]: separable, BORDER_REFLECT_101; the kernel is OpenCV's fixed table for odd k <= 7, else
+    sigma = 0.3 ((k - 1) / 2 - 1) + 0.8.  (float arithmetic: cv2 filters uint8 images in fixed point, a difference of at most a grey level.)"""
     r = ksize // 2
-    t = torch.arange(-r, r + 1, dtype=x.dtype, device=x.device)
-    k = torch.exp(-(t * t) / (2 * sigma * sigma))
-    k = k / k.sum()
+    if ksize in _SMALL_GAUSSIAN:
+        k = torch.tensor(_SMALL_GAUSSIAN[ksize], dtype=x.dtype, device=x.device)
+    else:
+        sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
+        t = torch.arange(-r, r + 1, dtype=x.dtype, device=x.device)
+        k = torch.exp(-(t * t) / (2 * sigma * sigma))
+        k = k / k.sum()
     c = x.shape[1]
     x = torchf.pad(x, (r, r, r, r), mode="reflect")
     x = torchf.conv2d(x, k.view(1, 1, 1, -1).expand(c, 1, 1, -1), groups=c)
@@ -58,8 +68,8 @@ def compute_loopable_mask(vid, eps=15 / 255, factor=2):
 
 def vid2img(vid, mode="average"):
     """train_3d.py:55-83: the still image a view is trained on, from its clip [F,3,h,w] in [0,1] -> [3,h,w]."""
-    if mode == "median":
-        return vid.median(dim=0).values
+    if mode == "median":      # np.median (train_3d.py:58): the mean of the two middle frames of an even-length clip, not torch's lower median
+        return torch.quantile(vid, 0.5, dim=0)
     if mode == "average":
         return vid.mean(dim=0)
     if mode == "first":
@@ -140,6 +150,11 @@ def run_iter(nerf, optimizer, item, args, device):
         optimizer.acknowledge_fused_backward()
     learn_mask = bool(getattr(args, "learn_loop_mask", False))
     module = getattr(nerf, "module", nerf)
+    if hasattr(module, "objective") and not getattr(args, "generic_objective", False) and getattr(module, "args", args) is not args:
+        # the fused objective reads every *_loss_weight from module.args; this loop (and train()'s density ramp) reads and mutates `args`: a
+        # model built from a COPY of the namespace would silently train with stale weights on one of the two paths
+        raise RuntimeError("run_iter: the model was built with a different args object than the one the driver mutates; pass the same "
+                           "namespace to both (or args.generic_objective = True for the reference's spelling of the objective)")
     if hasattr(module, "objective") and not getattr(args, "generic_objective", False):
         # render + every loss term + their weighted total with the scalar head fused (MPMesh.objective: same values and gradients as the
         # spelling below, tests/test_gpu_stage1_driver.py); args.generic_objective keeps the reference's spelling for A/B

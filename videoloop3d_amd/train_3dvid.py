@@ -172,6 +172,11 @@ def run_iter(nerf, optimizer, item, args, device):
     if hasattr(optimizer, "acknowledge_fused_backward"):
         optimizer.acknowledge_fused_backward()      # this loop steps once per backward: the update inside the render backward is what it wants
     module = getattr(nerf, "module", nerf)
+    if hasattr(module, "objective") and not getattr(args, "generic_objective", False) and getattr(module, "args", args) is not args:
+        # the fused objective reads every *_loss_weight from module.args; this loop (and train()'s density ramp) reads and mutates `args`: a
+        # model built from a COPY of the namespace would silently train with stale weights on one of the two paths
+        raise RuntimeError("run_iter: the model was built with a different args object than the one the driver mutates; pass the same "
+                           "namespace to both (or args.generic_objective = True for the reference's spelling of the objective)")
     if hasattr(module, "objective") and not getattr(args, "generic_objective", False):
         # render + looping loss + regularisers + their weighted total, the total in one launch each way (MPMeshVid.objective: the same values
         # and gradients as the spelling below); args.generic_objective keeps the reference's spelling for A/B
