@@ -124,6 +124,24 @@ def loss_bench(dev, H, W, T, Ty, steps):
             torch.cuda.synchronize()
         it_s = (time.perf_counter() - t0) / steps
         out[name] = {"iters_per_s": 1.0 / it_s, "loss": float(loss.detach())}
+        # ... and as MPMeshVid.forward runs it (MPV.py:484-507 -> videoloop3d_amd/MPV.py _LoopPrologue): the render's NHWC output goes through the
+        # loop padding ONCE, which writes the loss's video and the search's gram16 form of x in the same pass -- no video_to_gram16_k of x.
+        # One iteration = prologue + search + fold / loss + their backward down to the NHWC frames.
+        from videoloop3d_amd.MPV import _LoopPrologue
+        from videoloop3d_amd.utils_vid import PreparedX
+        frames = x.detach()[0, :, :T].permute(1, 2, 3, 0).contiguous().requires_grad_(True)          # [T,H,W,3], what the render returns
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for it in range(steps + 1):
+                if it == 1:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                xx, xg = _LoopPrologue.apply(frames, None, 2, True)
+                loss_p = lm(xx, y, y_prepared=yp, x_prepared=PreparedX(xg, T + 2, H, W), **cfg)
+                (gf,) = torch.autograd.grad(loss_p, frames)
+            torch.cuda.synchronize()
+        out[name]["prepared"] = {"iters_per_s": steps / (time.perf_counter() - t0), "loss": float(loss_p.detach()),
+                                 "what": "loop padding (writes x and its gram16 form) + search + fold / loss + backward to the NHWC frames: the loss side of MPMeshVid.forward"}
         # roofline of the NN search (K3, the dominant kernel of the loss): HIP events around the search alone
         from videoloop3d_amd.utils_vid import find_nn_indices, fit_patch
         ps, st_, pt = cfg["patch_size"], cfg["stride"], cfg["patcht_size"]
@@ -641,6 +659,7 @@ def main():
         summ = {}
         for cfg_ in ("ref", "other"):
             summ[f"loss720_{cfg_}_it_s"] = pick(res, "loss", cfg_, "iters_per_s")
+            summ[f"loss720_{cfg_}_prepared_it_s"] = pick(res, "loss", cfg_, "prepared", "iters_per_s")
             summ[f"loss720_{cfg_}_nn_ms"] = pick(res, "loss", cfg_, "roofline_nn", "avg_ms")
             summ[f"loss720_{cfg_}_hbm_frac"] = pick(res, "loss", cfg_, "roofline_loss", "frac")
             summ[f"loss720_{cfg_}_nn_mfma_frac_issued"] = pick(res, "loss", cfg_, "roofline_nn", "frac_issued")

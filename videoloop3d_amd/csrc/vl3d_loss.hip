@@ -1123,13 +1123,28 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
         xnext += xstep; tnext += tstep;
         return v;
     };
-    float xq0 = xload(), xq1 = xload(), xq2 = xload(), xq3 = xload();
+    // queue depth: measured (profiles/fold_time.py, round 6): with votes and staging ablated the kernel still took 0.77 of its 1.0 ms -- its x / gx /
+    // y2x streams run one 256-byte row segment per wave and request, so the bytes in flight (requests ahead x 24 waves per CU) set the rate
+    // (same box, 720p, ms: other views 0.884 / 0.830 / 0.792 / 0.944 at 4 / 8 / 13 / 16 requests ahead; the ref view's NB = 3 instantiation
+    // sits at its register budget for three workgroups per CU and loses with every deeper queue: 0.898 / 0.913 / 1.038 / 1.056)
+#ifdef VL3D_FOLD_XQ
+    constexpr int XQ = VL3D_FOLD_XQ;
+#else
+    constexpr int XQ = NB >= 3 ? 4 : 12;
+#endif
+    float xq[XQ];
+#pragma unroll
+    for (int k = 0; k < XQ; ++k) xq[k] = xload();
     {   // (source pointer and LDS slot walk by a group step: no 64-bit multiply per frame)
         const float *yf = ysrc + (int64_t)grp * a.y_st;
         const int64_t ystep = (int64_t)FT_G * a.y_st;
         float *yd = ys + grp * NP + pix;
 #pragma unroll 8
+#if defined(VL3D_FOLD_ABLATE) && (VL3D_FOLD_ABLATE & 2)      // measurement build only: no staging loads
+        for (int f = grp; f < Ty; f += FT_G, yd += FT_G * NP) *yd = 0.25f;
+#else
         for (int f = grp; f < Ty; f += FT_G, yf += ystep, yd += FT_G * NP) *yd = *yf;
+#endif
     }
     // the covering locations' index rows: a run of n1 consecutive ints per location -- rows of the tile's locations are contiguous in nn
     // along bx, so a (by) row of the table is ONE contiguous run of nbx * n1 ints: no division per element
@@ -1177,7 +1192,11 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
         int cnt = 0;
         if (slide) {
             const int i = tau;                                     // patch index == first frame it votes for
+#if defined(VL3D_FOLD_ABLATE) && (VL3D_FOLD_ABLATE & 1)      // measurement build only: no votes
+            if (false) {
+#else
             if (i >= 0 && i < a.n1) {
+#endif
                 if constexpr (NB > 0) {
                     // one row of locations at a time: NB index reads together, then their 3 NB vote reads together (all NB x NB at once
                     // needed 102 registers for NB = 3 -- two workgroups per CU instead of three)
@@ -1229,8 +1248,10 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
             if (c == 0) wout[(size_t)tau * fs] = wgt;
         }
         if (a.x) {      // robust_lossfun(x - y2x) and its derivative while y2x is in a register (utils_vid.py:348)
-            const float e = xq0 - v;
-            xq0 = xq1; xq1 = xq2; xq2 = xq3; xq3 = xload();
+            const float e = xq[0] - v;
+#pragma unroll
+            for (int k = 0; k + 1 < XQ; ++k) xq[k] = xq[k + 1];
+            xq[XQ - 1] = xload();
             float f, g;
             rho_fg(a.rho, e, f, g);
             lacc += f;
