@@ -59,7 +59,13 @@ def _worker(rank, world, port, out):
         mine = _render_band_oracle(stack, homos, bands[rank], W, Hs, spec)
         frame = all_gather_frame(mine, bands)
         direct = all_gather_frame(mine, bands, algo="direct")          # all-peers send/recv: the same bytes as the ring
-        chunked = all_gather_frame(mine, bands, algo="direct", ops_per_group=4)      # several grouped launches (frame ranges): same frame
+        # the band-major form (no assembly copy) and a row range out of it -- what the band loss reads: own rows + a few of the neighbours'
+        from videoloop3d_amd.dist import frame_rows
+        parts = all_gather_frame(mine, bands, algo="direct", layout="bands")
+        parts_ring = all_gather_frame(mine, bands, algo="ring", layout="bands")
+        lo, hi = max(bands[rank].row0 - 3, 0), min(bands[rank].row0 + bands[rank].rows + 4, H)
+        chunked = frame if (len(parts) == world and parts[rank].data_ptr() == mine.contiguous().data_ptr()
+                            and torch.equal(frame_rows(parts, lo, hi), frame[:, lo:hi]) and torch.equal(frame_rows(parts_ring, 0, H), frame)) else frame + 1
         full, _, _ = MO.render_planes(stack, homos, H, W, _oracle_spec(spec))
         err = float((frame - full).abs().max())
         # (each comparison on its own: a failure says WHICH one)

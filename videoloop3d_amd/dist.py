@@ -86,22 +86,24 @@ def render_band(local_stack, homos, band: Band, W: int, Hs: int, spec: RenderSpe
     return render_planes(local_stack, homos, band.rows, W, band_spec(spec, band, Hs), window=(band.row0, 0))
 
 
-P2P_OPS_PER_GROUP = 256        # point-to-point operations per grouped launch: 18 frames x 7 peers x (send + receive) at N = 8
-
-
-def all_gather_frame(band_rgb: torch.Tensor, bands: List[Band], group=None, algo: str = "auto", ops_per_group: int = P2P_OPS_PER_GROUP) -> torch.Tensor:
+def all_gather_frame(band_rgb: torch.Tensor, bands: List[Band], group=None, algo: str = "auto", layout: str = "dense"):
     """The one collective of the render path: composited bands [T,rows_r,W,C] -> full frame [T,H,W,C] on every rank.
     Uses torch.distributed (backend 'nccl' == RCCL over xGMI on ROCm; 'gloo' in the CPU tests).
 
     algo:
       "ring"    RCCL's all_gather (all_gather_into_tensor when the bands are equal): ring / tree chosen by RCCL.  On the
                 fully connected xGMI mesh of one node (7 links x ~153 GB/s per GPU, point to point) a ring moves (N-1)/N of the
-                frame over ONE link per GPU: cfg3 at N = 8, 553 MB frame -> 484 MB per rank at ~153 GB/s = ~3.2 ms.
-      "direct"  all-peers: every rank sends its band straight to each of the N-1 peers and receives theirs, all transfers in ONE
-                grouped launch (batch_isend_irecv -> ncclGroupStart/End): each of the 7 links carries one 69 MB band per
-                direction concurrently -> ~0.45 ms.  Received bands land in place in the [T,H,W,C] frame (per-frame receives).
+                frame over ONE link per GPU: cfg3 at N = 8, 553 MB frame -> 484 MB per rank at ~153 GB/s = ~3.2 ms (an estimate).
+      "direct"  all-peers: every rank sends its band straight to each of the N-1 peers and receives theirs -- ONE send and ONE receive
+                per peer (a band [T,rows_k,W,C] is one contiguous message: 14 point-to-point operations at N = 8, where rounds 4-5
+                posted one per frame and peer, 700 at T = 50), all in ONE grouped launch (batch_isend_irecv -> ncclGroupStart/End):
+                each of the 7 links carries one 69 MB band per direction concurrently -> ~0.45 ms (an estimate: no multi-GPU box here).
       "auto"    "direct" for world > 2 on device tensors, else "ring".
-    ops_per_group ("direct"): point-to-point operations per grouped launch; the transfers are cut by frame ranges over all peers.
+    layout:
+      "dense"   the [T,H,W,C] frame (the received bands are copied into place: N - 1 strided copies on the caller's stream, 484 MB at cfg3 /
+                N = 8 -- ~0.2 ms beside a backward of ~1.5 ms, on the side stream the caller gathers on);
+      "bands"   no copy: the list of the N bands [T,rows_k,W,C] as they arrived (this rank's own band is `band_rgb` itself); `frame_rows`
+                assembles a row range from it -- what the band loss needs is its own band and < patch_size rows of its neighbours'.
     Every rank gets bit-identical frames from either algorithm (pure data movement)."""
     import torch.distributed as dist
     T, _, W, C = band_rgb.shape
@@ -111,43 +113,55 @@ def all_gather_frame(band_rgb: torch.Tensor, bands: List[Band], group=None, algo
         algo = "direct" if (world > 2 and band_rgb.is_cuda) else "ring"
     if algo not in ("ring", "direct"):
         raise RuntimeError(f"all_gather_frame: unknown algo {algo!r}")
+    if layout not in ("dense", "bands"):
+        raise RuntimeError(f"all_gather_frame: unknown layout {layout!r}")
     band_rgb = band_rgb.contiguous()
     if algo == "direct":
         rank = dist.get_rank(group)
-        # the frame itself is the receive buffer: band k of frame t is the contiguous block frame[t, row0_k : row0_k + rows_k], so every
-        # peer's band arrives as T per-frame receives straight into place (no band-major staging buffer, no 553 MB repack at cfg3 after
-        # a collective budgeted at 0.45 ms); all transfers of a chunk go out in ONE grouped launch (batch_isend_irecv -> ncclGroupStart/End)
-        H = sum(rows)
-        row0 = [0]
-        for r in rows[:-1]:
-            row0.append(row0[-1] + r)
-        frame = torch.empty((T, H, W, C), dtype=band_rgb.dtype, device=band_rgb.device)
-        frame[:, row0[rank]:row0[rank] + rows[rank]].copy_(band_rgb)
-        # chunks are FRAME ranges over all peers: every rank posts the same (pair, frame) transfers in the same grouped launch, so sends and
-        # receives match chunk by chunk whatever the band sizes (three chunks for cfg3 at N = 8)
-        tpc = max(1, int(ops_per_group) // max(2 * (world - 1), 1))
-        for t0 in range(0, T, tpc):
-            ops = []
-            for k in range(world):
-                if k == rank:
-                    continue
-                peer = k if group is None else dist.get_global_rank(group, k)
-                for t in range(t0, min(T, t0 + tpc)):
-                    if rows[rank]:
-                        ops.append(dist.P2POp(dist.isend, band_rgb[t], peer, group))
-                    if rows[k]:
-                        ops.append(dist.P2POp(dist.irecv, frame[t, row0[k]:row0[k] + rows[k]], peer, group))
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
-        return frame
+        parts = [band_rgb if k == rank else torch.empty((T, rows[k], W, C), dtype=band_rgb.dtype, device=band_rgb.device) for k in range(world)]
+        ops = []
+        for k in range(world):      # every rank lists its peers in rank order: sends and receives of a pair match inside the one group
+            if k == rank:
+                continue
+            peer = k if group is None else dist.get_global_rank(group, k)
+            if rows[rank]:
+                ops.append(dist.P2POp(dist.isend, band_rgb, peer, group))
+            if rows[k]:
+                ops.append(dist.P2POp(dist.irecv, parts[k], peer, group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return parts if layout == "bands" else _dense_frame(parts)
     if len(set(rows)) == 1 and band_rgb.is_cuda:
         out = torch.empty((world, T, rows[0], W, C), dtype=band_rgb.dtype, device=band_rgb.device)
         dist.all_gather_into_tensor(out, band_rgb, group=group)
-        return out.permute(1, 0, 2, 3, 4).reshape(T, sum(rows), W, C)
+        return list(out.unbind(0)) if layout == "bands" else out.permute(1, 0, 2, 3, 4).reshape(T, sum(rows), W, C)
     parts = [torch.empty((T, r, W, C), dtype=band_rgb.dtype, device=band_rgb.device) for r in rows]
     dist.all_gather(parts, band_rgb, group=group)
-    return torch.cat(parts, dim=1)
+    return parts if layout == "bands" else torch.cat(parts, dim=1)
+
+
+def _dense_frame(parts):
+    """bands [T,rows_k,W,C] -> the frame [T,H,W,C] (one strided copy per band)."""
+    T, _, W, C = parts[0].shape
+    frame = torch.empty((T, sum(p.shape[1] for p in parts), W, C), dtype=parts[0].dtype, device=parts[0].device)
+    r = 0
+    for p in parts:
+        frame[:, r:r + p.shape[1]].copy_(p)
+        r += p.shape[1]
+    return frame
+
+
+def frame_rows(parts, lo: int, hi: int) -> torch.Tensor:
+    """rows [lo, hi) of the frame from its bands (all_gather_frame(..., layout="bands")) -> [T,hi-lo,W,C]: a band's own rows plus the few
+    neighbouring rows a consumer needs (loss_band_rows), without assembling the whole frame."""
+    out, r = [], 0
+    for p in parts:
+        a, b = max(lo, r), min(hi, r + p.shape[1])
+        if b > a:
+            out.append(p[:, a - r:b - r])
+        r += p.shape[1]
+    return out[0] if len(out) == 1 else torch.cat(out, dim=1)
 
 
 def halo_overlaps(bands: List[Band], rank: int):
