@@ -706,6 +706,11 @@ constexpr int nn6_ky(int tyt) { return tyt == 5 ? 4 : (tyt == 8 ? 6 : 7); }
 // private 16-row slab, no workgroup barrier between the locations (no alpha, pt = 3, stridet = 1 only: the column minima of the alpha
 // path need all rows -- a two-phase per-wave form of it, minima through an LDS integer min behind one barrier and the slabs written twice,
 // measured 1.46 against 1.41 ms at 720p and was not kept).
+#ifdef VL3D_NN6_FLAT_NORMS
+#define VL3D_NN6_NSTEP 0u
+#else
+#define VL3D_NN6_NSTEP nstep2
+#endif
 template <int TYT, int NL, int NW, int XS>
 __global__ __launch_bounds__(64 * NW, TYT == 5 ? 3 : 2) void patchnn6_k(NN2Args a, int groups_x, int CHC) {
     constexpr int NTHR = 64 * NW, NXT = 16 * NW;
@@ -799,7 +804,10 @@ __global__ __launch_bounds__(64 * NW, TYT == 5 ? 3 : 2) void patchnn6_k(NN2Args 
             unsigned nad0 = xside ? (unsigned)reinterpret_cast<uintptr_t>(buf) + (unsigned)(cc * a.ps * FX + tid) * 16u + 12u
                                   : (yside ? (unsigned)reinterpret_cast<uintptr_t>(buf + ybase) + (unsigned)(cc * a.ps * FY + tid - NXT) * 16u + 12u
                                            : (unsigned)reinterpret_cast<uintptr_t>(buf));
-            unsigned nad1 = nad0 + (nstep2 >> 1);
+#ifdef VL3D_NN6_FLAT_NORMS      // measurement build only (WRONG norms): every lane reads one and the same word -- prices the bank conflicts of the side threads' reads
+            nad0 = (unsigned)reinterpret_cast<uintptr_t>(buf);
+#endif
+            unsigned nad1 = nad0 + (VL3D_NN6_NSTEP >> 1);
             // The reads and their wait are asm statements fenced by scheduling barriers, or hipcc folds them back next to their use.
             {
                 u32x4_t a0, b0[TYT];
@@ -818,7 +826,7 @@ __global__ __launch_bounds__(64 * NW, TYT == 5 ? 3 : 2) void patchnn6_k(NN2Args 
     {                                                                                                     \
         const bool last_ = (C) + 2 >= nch;                                                                \
         xad += last_ ? xstepL : xstep2; yad += last_ ? ystepL : ystep2;                                   \
-        nad0 += nstep2; nad1 += nstep2;                                                                   \
+        nad0 += VL3D_NN6_NSTEP; nad1 += VL3D_NN6_NSTEP;                                                   \
     }
 #define VL3D_NN6_MMA(C, A, N0, N1, B)                                                                     \
     {                                                                                                     \
