@@ -167,3 +167,67 @@ def test_tile_exact_window_of_a_plane(dev, variant):
     (gs,) = torch.autograd.grad(rgb, win, g_rgb.to(dev))
     assert maxabs(rgb, rgb_o) <= TOL and maxabs(alpha, alpha_o) <= TOL
     assert maxabs(gs, gs_o[:, :, y0:y1, x0:x1]) <= TOL * max(1.0, float(gs_o.abs().max()))
+
+
+import os
+_EXTRA = int(os.environ.get("VL3D_FUZZ_EXTRA", "0"))      # soak runs widen the fuzzer (tests/test_gpu_fuzz.py)
+
+
+@pytest.mark.parametrize("seed", list(range(24 + _EXTRA)))
+def test_tile_exact_fuzz(dev, seed):
+    """random tile sizes (2 .. 17 per axis, anisotropic), quad grids, keep maps, rotated / scaled / perspective views (owner-computes path where its
+    plan allows, atomics elsewhere), every second case a texel WINDOW of the planes at an origin off the tile grid, every third with the layer
+    regularisers: image, alpha, sums and the gradient of every tile texel against the oracle."""
+    import dataclasses
+    from videoloop3d_amd.render import RenderSpec, render_planes, render_planes_with_regularisers
+    g = torch.Generator().manual_seed(500 + seed)
+    r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    u = lambda lo, hi: float(torch.rand(1, generator=g)) * (hi - lo) + lo
+    D, T = r(1, 5), r(1, 3)
+    th, tw = r(2, 17), r(2, 17)
+    QH, QW = r(1, max(1, 96 // th)), r(1, max(1, 140 // tw))
+    Hs, Ws = QH * th, QW * tw
+    Ll_h, Ll_w = QH * (th - 1), QW * (tw - 1)                      # lattice extent
+    H, W = max(1, int(Ll_h * u(0.5, 1.3))), max(1, int(Ll_w * u(0.5, 1.3)))
+    zoom = u(0.7, 1.5) if seed % 3 else u(0.97, 1.03)
+    a = math.radians(u(-6, 6))
+    base = torch.tensor([[math.cos(a) * zoom, -math.sin(a) * zoom, u(-4, 4)], [math.sin(a) * zoom, math.cos(a) * zoom, u(-4, 4)], [u(-2e-4, 2e-4), u(-2e-4, 2e-4), 1.0]])
+    homos = torch.stack([base + torch.tensor([[0, 0, 0.9 * d], [0, 0, -0.5 * d], [0, 0, 0.0]]) for d in range(D)])
+    scale = (Ll_w / max(W * zoom, 1.0) * u(0.9, 1.1), Ll_h / max(H * zoom, 1.0) * u(0.9, 1.1))      # frame -> roughly the whole lattice
+    keep = torch.rand(D, QH, QW, generator=g) < [0.3, 0.7, 1.0][seed % 3]
+    stack = synth.make_plane_stack(D, T, Hs, Ws, seed=300 + seed)
+    with_reg = seed % 3 == 0 and D <= 4
+    o_spec = MO.RenderSpec(pixel_center=0.5, coord_mode="affine", border="hardcut", act_order="post", scale=scale, tile=(th, tw))
+    g_rgb = synth.hash_uniform((T, H, W, 3), seed=5) - 0.5
+    g_a = synth.hash_uniform((T, H, W), seed=6) - 0.5
+    wts = torch.tensor([1e-4, 2e-4, 3e-4, 4e-4])
+    s_cpu = stack.clone().requires_grad_(True)
+    rgb_o, alpha_o, _, layers = MO.render_planes(s_cpu, homos, H, W, o_spec, return_layers=True, quad_keep=keep)
+    obj_o = (rgb_o * g_rgb).sum() + (alpha_o * g_a).sum()
+    if with_reg:
+        sums_o = torch.stack([(layers[:, :, 1:, :, :3] - layers[:, :, :-1, :, :3]).abs().sum(), (layers[:, 1:, :, :, :3] - layers[:, :-1, :, :, :3]).abs().sum(),
+                              (layers[:, :, 1:, :, 3] - layers[:, :, :-1, :, 3]).abs().sum(), (layers[:, 1:, :, :, 3] - layers[:, :-1, :, :, 3]).abs().sum()])
+        obj_o = obj_o + (sums_o * wts).sum()
+    (gs_o,) = torch.autograd.grad(obj_o, s_cpu)
+    # every second case renders from a window of the planes (8-aligned like the optimiser's windows, clamped to the plane) that holds every touched texel
+    y0 = x0 = 0
+    y1, x1 = Hs, Ws
+    if seed % 2:
+        nz = gs_o.abs().sum((0, 1, 4)) > 0
+        if bool(nz.any()):
+            ys, xs = nz.any(1).nonzero().flatten(), nz.any(0).nonzero().flatten()
+            y0, y1 = max(int(ys.min()) - 2, 0) // 8 * 8, min(-(-(int(ys.max()) + 3) // 8) * 8, Hs)
+            x0, x1 = max(int(xs.min()) - 2, 0) // 8 * 8, min(-(-(int(xs.max()) + 3) // 8) * 8, Ws)
+    p_spec = dataclasses.replace(RenderSpec.mpv(scale=scale, offset=(-float(x0), -float(y0))), tile=(th, tw))
+    win = stack[:, :, y0:y1, x0:x1].contiguous().to(dev).requires_grad_(True)
+    cw = (y0, x0, Hs, Ws) if seed % 2 else None
+    if with_reg:
+        rgb, alpha, sums, _ = render_planes_with_regularisers(win, homos.to(dev), H, W, p_spec, quad_keep=keep.to(dev), cull_window=cw)
+        obj = (rgb * g_rgb.to(dev)).sum() + (alpha * g_a.to(dev)).sum() + (sums * wts.to(dev)).sum()
+        assert float(((sums.cpu() - sums_o).abs() / sums_o.abs().clamp_min(1.0)).max()) <= 1e-4
+    else:
+        rgb, alpha = render_planes(win, homos.to(dev), H, W, p_spec, quad_keep=keep.to(dev), cull_window=cw)
+        obj = (rgb * g_rgb.to(dev)).sum() + (alpha * g_a.to(dev)).sum()
+    (gs,) = torch.autograd.grad(obj, win)
+    assert maxabs(rgb, rgb_o) <= TOL and maxabs(alpha, alpha_o) <= TOL
+    assert maxabs(gs, gs_o[:, :, y0:y1, x0:x1]) <= TOL * max(1.0, float(gs_o.abs().max()))
