@@ -9,3 +9,4 @@ cp $O/pmc_summary.txt profiles/r06_pmc_summary.txt
 for l in sched schedc; do cp $O/pmc_summary_$l.txt profiles/r06_pmc_summary_$l.txt; done
 python profiles/pmc_to_traffic.py profiles/r06_pmc_summary.txt r06
 cp $O/n4_gloo.json profiles/r06_n4_gloo.json; cp $O/n2_gloo.json profiles/r06_n2_gloo.json
+python profiles/update_design_table.py

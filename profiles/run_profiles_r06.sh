@@ -47,6 +47,6 @@ done
 
 # N = 4 dry run of the multi-GPU path on ONE MI355X (device kernels per rank, host collectives over gloo: a check of the N > 1 code, not a timing):
 # four row bands whose parallax halos span two ranks, direct gather with one message per peer, halo-gradient exchange, band loss
-VL3D_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 4 --steps 3 --warmup 1 > $O/n4_gloo.json 2> $O/n4_gloo.err
+VL3D_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 4 --steps 3 --warmup 1 --gather-algo direct > $O/n4_gloo.json 2> $O/n4_gloo.err
 VL3D_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 2 --steps 3 --warmup 1 > $O/n2_gloo.json 2> $O/n2_gloo.err
 tail -c 600 $O/n4_gloo.json

@@ -50,3 +50,17 @@ def test_cpu_tensor_is_rejected_loudly(built):
     from videoloop3d_amd.render import render_planes
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         render_planes(torch.zeros(2, 1, 8, 8, 4), torch.eye(3).expand(2, 3, 3), 8, 8)
+
+
+def test_a_library_built_from_other_sources_is_refused(tmp_path):
+    """__graft_entry__.build() stamps the library with the sha256 of its sources; _lib refuses a library whose stamp names other sources (a stale
+    prebuilt .so beside edited kernels would otherwise answer with old code behind unchanged symbols) and build() recompiles instead of trusting it."""
+    import pytest
+    import __graft_entry__ as ge
+    from videoloop3d_amd import _lib as L
+    ge.build()
+    assert open(ge.STAMP).read().strip() == ge.source_hash() == L.sources_sha256()
+    L.check_stamp(ge.LIB)                                           # the tree's own library passes
+    (tmp_path / "libvl3d_hip.stamp").write_text("0" * 64 + "\n")
+    with pytest.raises(RuntimeError, match="other sources"):
+        L.check_stamp(str(tmp_path / "libvl3d_hip.so"))

@@ -128,6 +128,27 @@ SIGNATURES = {
 _lib = None
 
 
+def sources_sha256():
+    """sha256 over the files the library is compiled from (the same walk as __graft_entry__.source_hash)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) + glob.glob(os.path.join(_HERE, "csrc", "*.inc"))) \
+            + [os.path.join(os.path.dirname(_HERE), "include", "vl3d.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def check_stamp(lib_path):
+    """The in-tree library carries a stamp of the sources it was linked from (__graft_entry__.build): a library that does not belong to THIS
+    tree -- a stale prebuilt .so beside edited kernels -- fails here, loudly, instead of answering with old code behind unchanged symbols."""
+    stamp = os.path.join(os.path.dirname(lib_path), "libvl3d_hip.stamp")
+    if os.path.exists(stamp) and open(stamp).read().strip() != sources_sha256():
+        raise RuntimeError(f"HIP library {lib_path} was built from other sources than the ones in this tree (stamp mismatch): rebuild it with "
+                           "`python -c 'import __graft_entry__ as g; g.build()'`")
+
+
 def lib():
     """Load videoloop3d_amd/lib/libvl3d_hip.so (built by __graft_entry__.build()); fail loudly if absent."""
     global _lib
@@ -136,6 +157,8 @@ def lib():
             raise RuntimeError(
                 f"HIP library {LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
                 "videoloop3d_amd has no CPU fallback.")
+        if not os.environ.get("VL3D_LIB_PATH"):
+            check_stamp(LIB_PATH)
         l = C.CDLL(LIB_PATH)
         # Every symbol of include/vl3d.h must resolve (tests/test_abi.py relies on it).  The one exception is explicit: an A/B run against an
         # OLDER build (VL3D_LIB_PATH + VL3D_ALLOW_MISSING_SYMBOLS=1) may lack entry points added since; they are listed on stderr once and
