@@ -341,6 +341,16 @@ int vl3d_render_bwd_mask(const vl3d_render_desc *desc, const void *stack, const 
                          const float *grad_reg, const void *reg_state, const float *grad_alpha_sums, float *grad_stack,
                          float *grad_mask, void *scratch, int64_t scratch_bytes, vl3d_stream_t stream);
 
+/* ... and the label alone when add_uv_noise is on (MPI.py:519-522 with :568-583): the reference jitters the COLOUR samples' UVs but samples the loop
+ * mask at the UNJITTERED UVs and composites sigmoid(mask) with the detached alphas of the jittered samples -- two sampling positions per layer,
+ * which the fused label channel above does not have (it refuses desc->uv_noise_seed != 0).  label (T,H,W) = sum_k w_k sigmoid(sample(mask_k, uv)),
+ * w_k = a_k T_k with a_k = alpha_act(sample(alpha_k, uv + jitter_k)) x coverage(uv): the alphas the colour pass of the SAME desc->uv_noise_seed
+ * composites with (same counter-hash field).  Gradient to the mask texture only (grad_mask (D,T,Hs,Ws), overwritten).  Planar convention
+ * (affine, hardcut, post), fp32 stack, any alpha activation.  A completeness path (no shipped configuration sets add_uv_noise): plain kernels. */
+int vl3d_label_noise_fwd(const vl3d_render_desc *desc, const float *stack, const float *mask, const float *homos, float *label, vl3d_stream_t stream);
+int vl3d_label_noise_bwd(const vl3d_render_desc *desc, const float *stack, const float *mask, const float *homos, const float *grad_label,
+                         float *grad_mask, vl3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Unfused operators (drop-ins for the reference's L3 functions).
  *

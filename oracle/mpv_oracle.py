@@ -42,7 +42,7 @@ def _homos(ref_intrin_mpi, extrin, intrin, planedepth):
     return MO.compute_homography(eye, ref_intrin_mpi[None].to(extrin.dtype), extrin, intrin, normal, planedepth[None].to(extrin.dtype))[0].float()
 
 
-def _layers(tex, homos, h, w, args, mpi_h, mpi_w, pixel_center, atlas_grid_h, quad_keep, acts=None, tile=None):
+def _layers(tex, homos, h, w, args, mpi_h, mpi_w, pixel_center, atlas_grid_h, quad_keep, acts=None, tile=None, uv_noise_seed=0):
     """plane-indexed activated layers [T,h,w,D,C] + coverage [h,w,D] of a stack or (atlas_grid_h) of the reference's atlas.
     tile = (th, tw): the stack is in the TILE-EXACT layout (every quad of `quad_keep`'s grid owns a th x tw tile, border texels included --
     the reference's sparsified atlases, MPI.py:380-418; pinned by golden G19)."""
@@ -55,7 +55,7 @@ def _layers(tex, homos, h, w, args, mpi_h, mpi_w, pixel_center, atlas_grid_h, qu
         scale, tl = (QW * (tile[1] - 1) / max(mpi_w - 1, 1), QH * (tile[0] - 1) / max(mpi_h - 1, 1)), (int(tile[0]), int(tile[1]))
     else:
         scale, tl = ((Ws - 1) / max(mpi_w - 1, 1), (Hs - 1) / max(mpi_h - 1, 1)), (0, 0)
-    spec = MO.RenderSpec(pixel_center=pixel_center, coord_mode="affine", border="hardcut", act_order="post", scale=scale, tile=tl,
+    spec = MO.RenderSpec(pixel_center=pixel_center, coord_mode="affine", border="hardcut", act_order="post", scale=scale, tile=tl, uv_noise_seed=int(uv_noise_seed),
                          rgb_act=args.rgb_activate if acts is None else acts[0], alpha_act=args.alpha_activate if acts is None else acts[1])
     return MO.sample_layers(tex, homos, h, w, spec, quad_keep)
 
@@ -150,8 +150,10 @@ def mpv_forward(stack, args, H, W, ref_extrin, ref_intrin, near, far, h, w, tar_
 
 
 def mpi_forward(stack, stack_mask, args, H, W, ref_extrin, ref_intrin, near, far, h, w, tar_extrins, tar_intrins,
-                training=True, pixel_center=0.5, atlas_grid_h=None, quad_keep=None, tile=None):
-    """MPMesh.forward (MPI.py:596-652) for planar geometry.  stack (D,1,Hs,Ws,4) + stack_mask (D,1,Hs,Ws) or None; with atlas_grid_h the
+                training=True, pixel_center=0.5, atlas_grid_h=None, quad_keep=None, tile=None, uv_noise_seeds=None):
+    """uv_noise_seeds (one per view; add_uv_noise while training, MPI.py:519-522): the COLOUR samples are jittered by that seed's field (MO.uv_jitter_field);
+    the loop mask is sampled at the plain positions and composited with the jittered samples' alphas (MPI.py:568-583 reads `uvs`, not the jittered `uvs_`).
+    MPMesh.forward (MPI.py:596-652) for planar geometry.  stack (D,1,Hs,Ws,4) + stack_mask (D,1,Hs,Ws) or None; with atlas_grid_h the
     reference's atlas (1,4,Ah,Aw) + atlas_mask (1,1,Ah,Aw).  Returns (rgbl [B,3|4,h,w], extra)."""
     D = args.mpi_d if atlas_grid_h is not None else stack.shape[0]
     mpi_h, mpi_w, planedepth, ref_intrin_mpi, extrins = _geometry(args, D, H, W, ref_extrin, ref_intrin, near, far, tar_extrins,
@@ -159,7 +161,8 @@ def mpi_forward(stack, stack_mask, args, H, W, ref_extrin, ref_intrin, near, far
     outs, mpis, alphas, masks, disps = [], [], [], [], []
     for b in range(len(extrins)):
         homos = _homos(ref_intrin_mpi, extrins[b:b + 1], tar_intrins[b:b + 1], planedepth)
-        layers, cov = _layers(stack, homos, h, w, args, mpi_h, mpi_w, pixel_center, atlas_grid_h, quad_keep, tile=tile)   # 1,h,w,D,4
+        layers, cov = _layers(stack, homos, h, w, args, mpi_h, mpi_w, pixel_center, atlas_grid_h, quad_keep, tile=tile,
+                              uv_noise_seed=0 if uv_noise_seeds is None else uv_noise_seeds[b])   # 1,h,w,D,4
         rgb, bw = MO.overcompose(layers[..., 3], layers[..., :3])
         alpha = bw.sum(-1)
         if len(args.bg_color) > 0:                                                                   # MPI.py:550-556

@@ -179,9 +179,48 @@ def test_module_trains_with_add_uv_noise(dev):
         assert torch.isfinite(after).all() and float((after - before).abs().max()) > 1e-4
 
 
-def test_stage1_refuses_noise_together_with_the_loop_mask():
+@pytest.mark.gpu
+def test_stage1_loop_mask_with_uv_noise_matches_the_oracle(dev):
+    """MPMesh with add_uv_noise AND learn_loop_mask (MPI.py:519-522 with :568-583; configs/mpi_base.txt ships learn_loop_mask): the colour samples are
+    jittered, the loop mask is sampled at the PLAIN positions and composited with the jittered samples' detached alphas -- two sampling positions
+    per layer (vl3d_label_noise_fwd / _bwd).  Image, label and the gradients w.r.t. both textures against the oracle on the same jitter field."""
+    from oracle import mpv_oracle
     from videoloop3d_amd.MPI import MPMesh
-    args = types.SimpleNamespace(mpi_h_scale=1.0, mpi_w_scale=1.0, mpi_d=4, atlas_grid_h=1, init_std=0.3, rgb_mlp_type="direct", rgb_activate="sigmoid",
-                                 alpha_activate="sigmoid", learn_loop_mask=True, add_uv_noise=True, mpi_h_verts=4, mpi_w_verts=4)
-    with pytest.raises(RuntimeError, match="add_uv_noise together with learn_loop_mask"):
-        MPMesh(args, 32, 48, np.eye(4), np.array([[40.0, 0, 24], [0, 40.0, 16], [0, 0, 1]]), 1.0, 100.0)
+    H, W, h, w = 40, 56, 30, 44
+    K = np.array([[0.9 * W, 0, W / 2], [0, 0.9 * W, H / 2], [0, 0, 1]], np.float64)
+    args = types.SimpleNamespace(mpi_h_scale=1.1, mpi_w_scale=1.1, mpi_d=5, atlas_grid_h=1, init_std=0.3, rgb_mlp_type="direct", rgb_activate="sigmoid",
+                                 alpha_activate="sigmoid", learn_loop_mask=True, add_uv_noise=True, mpi_h_verts=4, mpi_w_verts=4, bg_color="", optimizer="adam",
+                                 lrate=0.01, lrate_decay=100, sparsity_loss_weight=0.0, rgb_smooth_loss_weight=0.0, a_smooth_loss_weight=0.0,
+                                 density_loss_weight=0.0, d_smooth_loss_weight=0.0, l_smooth_loss_weight=0.0, normalize_blendweight_fordepth=False)
+    m = MPMesh(args, H, W, np.eye(4), K, 1.0, 100.0)
+    with torch.no_grad():
+        m.stack.copy_(synth.make_plane_stack(5, 1, m.mpi_h, m.mpi_w, seed=3))
+        m.stack_mask.copy_((synth.hash_uniform((5, 1, m.mpi_h, m.mpi_w), seed=9) - 0.5) * 4)
+    m = m.to(dev).train()
+    tar = np.eye(4)
+    tar[:3, 3] = [0.04, -0.02, 0.0]
+    ext, intr = torch.tensor(tar)[None].float(), torch.tensor(K)[None].float()
+    intr_c = intr.clone()
+    intr_c[:, 0, 2] -= 5
+    intr_c[:, 1, 2] -= 4
+    torch.manual_seed(21)
+    seed = int(torch.randint(1, 2 ** 31 - 1, (1,)))                      # the draw MPMesh.render makes for this view
+    torch.manual_seed(21)
+    rgbl, _ = m(h, w, ext, intr_c)
+    assert rgbl.shape == (1, 4, h, w)
+    G = (synth.hash_uniform(tuple(rgbl.shape), seed=4) - 0.5).to(dev)
+    gs, gm = torch.autograd.grad((rgbl * G).sum(), [m.stack, m.stack_mask])
+    st, mk = m.stack.detach().cpu().requires_grad_(True), m.stack_mask.detach().cpu().requires_grad_(True)
+    rgbl_o, _ = mpv_oracle.mpi_forward(st, mk, args, H, W, np.eye(4), K, 1.0, 100.0, h, w, ext, intr_c, uv_noise_seeds=[seed])
+    gs_o, gm_o = torch.autograd.grad((rgbl_o * G.cpu()).sum(), [st, mk])
+    assert float((rgbl.cpu() - rgbl_o).abs().max()) <= TOL
+    assert float((gs.cpu() - gs_o).abs().max()) <= TOL * max(1.0, float(gs_o.abs().max()))
+    assert float((gm.cpu() - gm_o).abs().max()) <= TOL * max(1.0, float(gm_o.abs().max())) and float(gm_o.abs().max()) > 1e-3
+    # the two positions matter: the label with the mask ALSO sampled at the jittered positions is a different image
+    lab_same, _ = mpv_oracle.mpi_forward(st.detach(), mk.detach(), args, H, W, np.eye(4), K, 1.0, 100.0, h, w, ext, intr_c)      # no noise at all
+    assert float((rgbl_o[:, 3] - lab_same[:, 3]).abs().max()) > 1e-3
+    # eval: no noise (the fused label channel again)
+    m.eval()
+    with torch.no_grad():
+        ev = m(h, w, ext, intr_c)[0]
+    assert float((ev.cpu() - lab_same).abs().max()) <= TOL

@@ -76,11 +76,6 @@ class MPMesh(nn.Module):
         self.H, self.W = H, W
         if getattr(args, "rgb_mlp_type", "direct") != "direct":
             raise RuntimeError(f"rgbmlp_type = {args.rgb_mlp_type} not supported (shipped configs use 'direct', mpi_base.txt:28)")
-        if getattr(args, "add_uv_noise", False) and getattr(args, "learn_loop_mask", False):
-            # (MPI.py:519-522 jitters the colour samples, :568-572 samples the loop mask at the UNJITTERED position and composites it with the
-            # jittered samples' alphas: two sampling positions per layer, which the fused label channel / label pass do not have.  Off in every
-            # shipped configuration; not silently approximated.)
-            raise RuntimeError("add_uv_noise together with learn_loop_mask is not implemented by the fused render (no shipped configuration sets add_uv_noise)")
         ref_extrin, ref_intrin = np.asarray(ref_extrin), np.asarray(ref_intrin)
         assert ref_extrin.shape == (4, 4) and ref_intrin.shape == (3, 3)
         self.register_buffer("ref_extrin", torch.tensor(ref_extrin))
@@ -381,9 +376,12 @@ class MPMesh(nn.Module):
         # stack); args.loop_mask_two_pass keeps the separate label pass (A/B, cross-checks)
         if self.atlas_exact and (need_reg or need_layers or self.is_sparse or tuple(self.stack.shape[2:4]) != (self.mpi_h, self.mpi_w)):
             raise RuntimeError("atlas_exact renders the dense full-resolution stack without regularisers / materialised layers / tile culling")
-        fused_mask = (self.learn_loop_mask and self.stack.is_cuda and mask_channel_supported(self.stack, self.spec)
+        # add_uv_noise with the loop mask (MPI.py:519-522 with :568-572): the colour samples are jittered, the mask is sampled at the PLAIN positions and
+        # composited with the jittered samples' alphas -- two positions per layer: the label comes from its own kernel pair (render.loop_mask_label_with_uv_noise)
+        noisy_label = self.learn_loop_mask and self.training and bool(getattr(self.args, "add_uv_noise", False))
+        fused_mask = (self.learn_loop_mask and self.stack.is_cuda and mask_channel_supported(self.stack, self.spec) and not noisy_label
                       and not self.is_sparse and not self.atlas_exact and not getattr(self.args, "loop_mask_two_pass", False))
-        if self.learn_loop_mask and not fused_mask and not self.atlas_exact:
+        if self.learn_loop_mask and not fused_mask and not self.atlas_exact and not noisy_label:
             if getattr(self, "_mask_buf", None) is None or self._mask_buf.shape != self.stack.shape or self._mask_buf.device != self.stack.device:
                 self._mask_buf = torch.zeros_like(self.stack)
             with torch.no_grad():          # channel 0: mask logit, channel 3: the layer alpha logit (detached, MPI.py:572)
@@ -456,7 +454,10 @@ class MPMesh(nn.Module):
             alphas.append(alpha)
             if need_layers:
                 lay.append(self._layer_variables(homos, H, W, extrin[b], qk))
-            if self.learn_loop_mask and not fused_mask and not self.atlas_exact:                  # MPI.py:568-583
+            if noisy_label and not self.atlas_exact:
+                from .render import loop_mask_label_with_uv_noise
+                labels.append(loop_mask_label_with_uv_noise(self.stack_mask, self.stack, homos, H, W, spec)[..., None])      # (spec: this view's jitter field)
+            elif self.learn_loop_mask and not fused_mask and not self.atlas_exact:                  # MPI.py:568-583
                 labels.append(_LoopMaskLabel.apply(self.stack_mask, self.stack, self._mask_buf, homos, H, W, self.spec_mask))
         cat0 = lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts, 0)      # noqa: E731  (B = 1, the reference's DataLoader(dataset, 1): no copy, no launch)
         rgb = cat0(rgbs)

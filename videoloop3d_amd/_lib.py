@@ -92,6 +92,8 @@ SIGNATURES = {
     "vl3d_render_fwd_reg": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "vl3d_render_fwd_mask": ([C.POINTER(RenderDesc)] + [_P] * 10, C.c_int),
     "vl3d_render_bwd_mask": ([C.POINTER(RenderDesc)] + [_P] * 14 + [_I64, _P], C.c_int),
+    "vl3d_label_noise_fwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P], C.c_int),
+    "vl3d_label_noise_bwd": ([C.POINTER(RenderDesc), _P, _P, _P, _P, _P, _P], C.c_int),
     "vl3d_warp_fwd": ([_I32] * 6 + [_P, _P, _P, _P], C.c_int),
     "vl3d_warp_bwd": ([_I32] * 6 + [_P, _P, _P, _P], C.c_int),
     "vl3d_overcompose_fwd": ([_I64, _I32, _I32, _P, _P, _P, _P, _P], C.c_int),

@@ -264,6 +264,44 @@ def render_planes_with_mask(stack, mask, homos, H, W, spec: RenderSpec = RenderS
     return _RenderPlanesMask.apply(stack, mask, homos, int(H), int(W), spec, bool(with_regularisers))
 
 
+class _LabelNoise(torch.autograd.Function):
+    """MPI.py:568-583 under add_uv_noise (MPI.py:519-522): the loop-mask texture sampled at the UNJITTERED positions, composited with the detached
+    alphas of the JITTERED colour samples (vl3d_label_noise_fwd / _bwd: the jitter field of spec.uv_noise_seed, the colour pass's).  Gradient to the mask only."""
+
+    @staticmethod
+    def forward(ctx, mask, stack, homos, H, W, spec):
+        L.check_cuda(mask, stack, homos)
+        D, T, Hs, Ws, _ = stack.shape
+        if tuple(mask.shape) != (D, T, Hs, Ws) or mask.dtype != torch.float32 or stack.dtype != torch.float32:
+            raise RuntimeError(f"loop-mask label: float32 stack (D,T,Hs,Ws,4) and mask [D,T,Hs,Ws] = {(D, T, Hs, Ws)}, got {tuple(mask.shape)} {mask.dtype}")
+        if homos.shape != (D, 3, 3):
+            raise RuntimeError(f"homos must be [D,3,3] = [{D},3,3], got {tuple(homos.shape)}")
+        stack, mask = stack.detach().contiguous(), mask.detach().contiguous()
+        homos = homos.detach().to(torch.float32).contiguous()
+        desc = _desc(stack, H, W, spec, 0, 0)
+        label = torch.empty((T, H, W), dtype=torch.float32, device=stack.device)
+        with torch.cuda.device(stack.device):
+            L.check(L.lib().vl3d_label_noise_fwd(desc, L.ptr(stack), L.ptr(mask), L.ptr(homos), L.ptr(label), L.stream_ptr(stack.device)), "vl3d_label_noise_fwd")
+        ctx.save_for_backward(stack, mask, homos)
+        ctx.desc = desc
+        return label
+
+    @staticmethod
+    def backward(ctx, g):
+        stack, mask, homos = ctx.saved_tensors
+        g = g.contiguous()
+        gm = torch.empty_like(mask)
+        with torch.cuda.device(stack.device):
+            L.check(L.lib().vl3d_label_noise_bwd(ctx.desc, L.ptr(stack), L.ptr(mask), L.ptr(homos), L.ptr(g), L.ptr(gm), L.stream_ptr(stack.device)), "vl3d_label_noise_bwd")
+        return gm, None, None, None, None, None
+
+
+def loop_mask_label_with_uv_noise(mask, stack, homos, H, W, spec: RenderSpec):
+    """label [T,H,W] = sum_k w_k sigmoid(sample(mask_k)) with the mask sampled at the plain positions and the weights w_k = a_k T_k from the alphas at
+    the positions jittered by spec.uv_noise_seed's field (MPI.py:519-522, 568-583).  mask [D,T,Hs,Ws] logits (receives the gradient), stack detached."""
+    return _LabelNoise.apply(mask, stack, homos, int(H), int(W), spec)
+
+
 def render_frame_run(stack, frame0, nframes, homos, H, W, spec: RenderSpec = RenderSpec(), out=None, quad_keep=None):
     """Evaluation render (no gradient) of frames frame0 .. frame0 + nframes - 1 of the clip `stack` [D,T,Hs,Ws,4], read IN PLACE
     (vl3d_render_fwd_frames) -> (rgb [n,H,W,3], alpha [n,H,W]): `render_planes(stack[:, ts], ...)` gathers the frames first -- 571 MB per
