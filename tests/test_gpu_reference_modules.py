@@ -291,6 +291,19 @@ def test_trained_tile_checkpoint_matches_the_reference(dev):
     assert v2.packed is not None and v2.packed.tile == (10, 10)
     with torch.no_grad():
         assert torch.equal(v2(H, W, tar_e, K_full)[0], ev)
+    # the offline renderer (scripts/script_render_video.py loads the LAST checkpoint -- a trained one -- and renders frame by frame): its in-place
+    # frame path on the tile-exact dense stack and on the packed pool gives the module's own evaluation frames
+    from videoloop3d_amd import render_video as RV
+    ve, vi = tar_e.repeat(4, 1, 1).numpy(), K_full.repeat(4, 1, 1).numpy()
+    rt = np.array([0, 1, 2, 4])
+    want8 = RV.to8b(ev[rt].permute(0, 2, 3, 1))
+    v.eval()
+    vfresh = MPMeshVid(RM.mpv_args(5), H, W, ref_extrin, K, 1.0, 100.0)
+    vfresh.init_from_mpi(sd)
+    vfresh = vfresh.to(dev).eval()
+    for model in (vfresh, v2):
+        got8 = RV.render_frames(model, H, W, ve, vi, rt)
+        assert int((got8.int() - want8.int()).abs().max()) <= 1      # (uint8 of the same floats: the in-place kernels' bits)
     # the trained model goes back out as the reference's checkpoint, bit for bit where a face references it
     out = v2.reference_state_dict()
     for key, faces, gw_ in (("atlas", "faces", "self.atlas_grid_w"), ("atlas_dyn", "faces_dyn", "self.atlas_grid_dyn_w")):
