@@ -43,6 +43,14 @@ namespace vl3d_render_detail {
 #define VL3D_FWD2X_MIN_WAVES 4
 #endif
 
+// measurement builds only (-DVL3D_REG_ABLATE=bits, WRONG results; profiles/r06_reg_isa.sh prices the regulariser terms by instruction count):
+// forward 1 = no sign encoding / sign-word stores, 2 = no neighbour differences (no LDS reads, no sums), 4 = no LDS exchange (store + barrier);
+// backward 8 = no sign decode (reg_grad32), 16 = no sign-word loads
+#ifdef VL3D_REG_ABLATE
+#define VL3D_REGAB(bit) ((VL3D_REG_ABLATE & (bit)) != 0)
+#else
+#define VL3D_REGAB(bit) false
+#endif
 struct RenderArgs {
     const float *stack;
     const float *homos;
@@ -1943,7 +1951,7 @@ __global__ __launch_bounds__(PW * PROWS, VL3D_PAIR_MIN_WAVES) void render_bwd_pa
         const unsigned short *oplane = a.owner + (size_t)d * a.Hs * a.Ws;
         const unsigned e0 = oplane[(unsigned)(Y0 * a.Ws + X0) + toff_thread];     // unconditional (padded table), arrives in the shadow of the sweep
         // sign words of this group of four planes (own, left, upper; two frames): requested with the taps of its first plane
-        if constexpr (REG) if (reg_on && (d & 3) == 0) {      // uniform
+        if constexpr (REG) if (reg_on && (d & 3) == 0 && !VL3D_REGAB(16)) {      // uniform
             const uint2 *w = sgp;      // (advanced by one group of planes below: no 64-bit multiply per group)
             sgp += sg_plane;
             const ptrdiff_t ol = has_l ? -1 : 0, ou = has_u ? -(ptrdiff_t)a.W : 0;
@@ -1970,7 +1978,7 @@ __global__ __launch_bounds__(PW * PROWS, VL3D_PAIR_MIN_WAVES) void render_bwd_pa
             const f4 o1 = shade2<ORDER, RACT, AACT>(tp, tv1, &pre1);
             f4 ex0 = f4{0.f, 0.f, 0.f, 0.f}, ex1 = ex0;
             if constexpr (REG) {
-                if (reg_on) {
+                if (reg_on && !VL3D_REGAB(8)) {
                     const bool hi = (d & 2) != 0;       // uniform
                     const unsigned bo = 16u * (d & 1);
                     ex0 = reg_grad32(hi ? go0.y : go0.x, hi ? gl0.y : gl0.x, hi ? gu0.y : gu0.x, hi ? gp0.y : gp0.x, bo, fl, gx, gy);
@@ -2052,29 +2060,30 @@ __global__ __launch_bounds__(512) void render_fwd_reg_k(RenderArgs a, int tiles_
     {                                                                                                     \
         const f4 o = shade2<ORDER, RACT, AACT>(T_, V_);                                                   \
         const f4 ol = inimg ? o * T_.cov : f4{0.f, 0.f, 0.f, 0.f};                                        \
-        s_o[BUF_][tid] = make_float4(ol.x, ol.y, ol.z, ol.w);                                             \
+        if (!VL3D_REGAB(4)) s_o[BUF_][tid] = make_float4(ol.x, ol.y, ol.z, ol.w);                         \
         const float w = o.w * Tr;                                                                         \
         cr += w * o.x; cg += w * o.y; cb += w * o.z; A += w;                                              \
         n1 += o.w; n2 = fmaf(o.w, o.w, n2);                                                               \
         Tr *= (1.0f - o.w);                                                                               \
         if constexpr (MASK) lab = fmaf(w, act_fwd<VL3D_ACT_SIGMOID>(mask_blend(M_, T_.w)), lab);          \
-        __syncthreads();                                                                                  \
+        if (!VL3D_REGAB(4)) __syncthreads();                                                              \
         int code = (int)REG_ZERO;                                                                         \
-        if (own_r) {                                                                                      \
+        if (own_r && !VL3D_REGAB(2)) {                                                                    \
             const float4 r = s_o[BUF_][tid + 1];                                                          \
             const f4 df = ol - f4{r.x, r.y, r.z, r.w};                                                    \
             sxc += fabsf(df.x) + fabsf(df.y) + fabsf(df.z);                                               \
             sxa += fabsf(df.w);                                                                           \
-            code += reg_signs4(df);                                                                       \
+            if (!VL3D_REGAB(1)) code += reg_signs4(df);                                                   \
         }                                                                                                 \
-        if (own_d) {                                                                                      \
+        if (own_d && !VL3D_REGAB(2)) {                                                                    \
             const float4 r = s_o[BUF_][tid + FW];                                                         \
             const f4 df = ol - f4{r.x, r.y, r.z, r.w};                                                    \
             syc += fabsf(df.x) + fabsf(df.y) + fabsf(df.z);                                               \
             sya += fabsf(df.w);                                                                           \
-            code += reg_signs4(df) << 8;                                                                  \
+            if (!VL3D_REGAB(1)) code += reg_signs4(df) << 8;                                              \
         }                                                                                                 \
-        if (S_ == 0) sg_lo = (unsigned)code;                                                              \
+        if (VL3D_REGAB(1)) { }                                                                            \
+        else if (S_ == 0) sg_lo = (unsigned)code;                                                         \
         else if (S_ == 1) sg_lo |= (unsigned)code << 16;                                                  \
         else if (S_ == 2) sg_hi = (unsigned)code;                                                         \
         else {                                                                                            \
