@@ -47,6 +47,11 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
     from videoloop3d_amd.MPV import MPMeshVid
     from videoloop3d_amd.train_3dvid import MVVidPatchDataset, run_iter
     dev = torch.device(dev)
+    # (a run inside a longer process -- the bench's last leg -- starts from a clean allocator: with segments of earlier legs cached, the 7 GB stack and its
+    # moments occasionally landed so that the full-resolution level ran at 60-70 % of its usual rate: 426 / 337 it/s where every other run reads 570-600)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     H, W = 360, 640
     args = types.SimpleNamespace(
         mpv_frm_num=frames, mpv_isloop=True, mpi_h_scale=1.1, mpi_w_scale=1.1, mpi_d=planes, atlas_grid_h=4, init_std=0.02,
@@ -125,18 +130,40 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
                 opt.window_leaf = counting
             t0 = time.perf_counter()
             timed = order[8:8 + epochs * len(ds)]
+            # a device event after every timed iteration: the per-iteration device time (median reported beside the wall-clock rate, which stays THE rate),
+            # and `stall_ms` = wall time of the loop minus the device time between its first and last event.  Measured (docs/measurement_log.md, round 6): on
+            # some boxes a loop WITHOUT these events lost 0.1 - 2.3 s ONCE somewhere inside a full-resolution level of the tile-culled models, where host and
+            # device run in lockstep (3 of 16 bench runs; every kernel of the 12 iterations profiled right after it at its usual time, no device allocation,
+            # no allocator retry) -- with them, 0 of 24.  Not understood; `stall_ms` is there to make a recurrence visible instead of a silent low rate.
+            marks = []
             for k, i in enumerate(timed):
                 one(i, k // len(ds))
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append(ev)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            gaps = sorted(marks[k - 1].elapsed_time(marks[k]) for k in range(1, len(marks)))
+            dev_ms = {"p50": gaps[len(gaps) // 2], "max": gaps[-1], "stall_ms": dt * 1e3 - marks[0].elapsed_time(marks[-1]) * len(marks) / (len(marks) - 1)}
             if count_leaf is not None:
                 opt.window_leaf = count_leaf
+            if os.environ.get("VL3D_SCHED_DIAG"):      # measurement aid: the allocator's state after the level, the kernels of 12 more iterations
+                from torch.profiler import profile, ProfilerActivity
+                ms = torch.cuda.memory_stats()
+                with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+                    for k in range(12):
+                        one(order[k], 0)
+                    torch.cuda.synchronize()
+                top = [(e.key[:60], e.count, round(e.device_time_total / 12e3, 3), round(e.cpu_time_total / 12e3, 3))
+                       for e in sorted(prof.key_averages(), key=lambda e: -max(e.device_time_total, e.cpu_time_total))[:14]]
+                print("DIAG", hw, round(len(timed) / dt, 1), dev_ms, {k_: ms.get(k_) for k_ in ("num_device_alloc", "num_alloc_retries", "reserved_bytes.all.current",
+                                                                                          "allocated_bytes.all.current")}, top, flush=True)
             total_it += len(timed)
             total_s += dt
             total_win[0] += win_texels[0]
             total_win[1] += win_texels[1]
             out["levels"].append({"frame": hw, "crops_per_view": len(ds) // views, "crops": len(ds), "iters": len(timed),
-                                  "iters_per_s": len(timed) / dt, "stack": tuple(model.stack.shape[2:4])})
+                                  "iters_per_s": len(timed) / dt, "stack": tuple(model.stack.shape[2:4]), "device_ms_per_iter": dev_ms})
             # instrumented pass (synchronising; not timed): how many steps had each tile of the crop's window missed?
             if hasattr(opt, "state") and getattr(model, "_window_opt", None) is opt:
                 import videoloop3d_amd.optim as O
