@@ -62,6 +62,9 @@ __device__ __forceinline__ void texel_slot(const Layout &L, int d, int y, int x,
 
 // one thread per window texel and plane, looping over the frames.  `upto`: the step the window must be current for (the
 // step about to be taken minus one).  compact (optional): (D,T,wh,ww,4) copy of the window's parameters after the catch-up.
+// (115 VGPRs, four waves per SIMD.  Round 6 measured amdgpu_waves_per_eu 5 / 6 / 8 on the tile-culled schedule: 0.243 / 0.244 / 0.278 ms against 0.240 --
+// occupancy is not what bounds a tile-culled window's catch-up; docs/kernels/K6_optimiser.md)
+template <bool FLUSH>
 __global__ __launch_bounds__(256) void adam_window_catchup_k(int T, int Hs, int Ws, Win w, float4 *__restrict__ p, float4 *__restrict__ m,
                                                              float4 *__restrict__ v, const int *__restrict__ last_step, int tiles_y, int tiles_x,
                                                              const float2 *__restrict__ hist, int upto, float beta1, float beta2, float eps,
@@ -93,49 +96,93 @@ __global__ __launch_bounds__(256) void adam_window_catchup_k(int T, int Hs, int 
     }
     size_t o, frame;
     texel_slot(lay, d, y, x, T, Hs, Ws, tiles_y, tiles_x, o, frame);
-    if (cls == 2) {           // static: the one parameter lives in frame 0; every frame of the compact copy shows it
-        float4 pp = p[o];
+    if constexpr (FLUSH) {      // a FLUSH (written back in place, no compact copy): per class, as every round so far
+        if (cls == 2) {           // static: the one parameter lives in frame 0
+            float4 pp = p[o];
+            if (from < upto) {
+                float4 mm = m[o], vv = v[o];
+                replay(pp, mm, vv, hist, from, upto, beta1, beta2, eps);
+                p[o] = pp; m[o] = mm; v[o] = vv;
+            }
+            if (compact)
+                for (int t = 0; t < T; ++t, oc += cframe) compact[oc] = pp;
+            if (mirror && frame)  // refresh the other frames' slots so that the stack reads consistently everywhere (a static block has one copy)
+                for (int t = 1; t < T; ++t) p[o + (size_t)t * frame] = pp;
+            return;
+        }
+        if (from >= upto) {       // current already: copy only
+            if (compact)
+                for (int t = 0; t < T; ++t, o += frame, oc += cframe) compact[oc] = p[o];
+            return;
+        }
+        int t = 0;
+        constexpr int NF = 4;
+        for (; t + NF <= T; t += NF, o += NF * frame, oc += NF * cframe) {
+            float4 pp[NF], mm[NF], vv[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) { pp[f] = p[o + f * frame]; mm[f] = m[o + f * frame]; vv[f] = v[o + f * frame]; }
+            for (int s = from + 1; s <= upto; ++s) {
+                const float2 h = hist[s];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) adam_upd4(pp[f], make_float4(0.f, 0.f, 0.f, 0.f), mm[f], vv[f], h.x, beta1, beta2, eps, h.y);
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                p[o + f * frame] = pp[f]; m[o + f * frame] = mm[f]; v[o + f * frame] = vv[f];
+                if (compact) compact[oc + f * cframe] = pp[f];
+            }
+        }
+        for (; t < T; ++t, o += frame, oc += cframe) {
+            float4 pp = p[o], mm = m[o], vv = v[o];
+            replay(pp, mm, vv, hist, from, upto, beta1, beta2, eps);
+            p[o] = pp; m[o] = mm; v[o] = vv;
+            if (compact) compact[oc] = pp;
+        }
+        return;
+    }
+    // The render's catch-up (compact copy only).  A wave of a tile-culled window mixes the classes -- static next to dynamic quads every 11 texels, tiles
+    // that are current next to tiles that are behind every 8 -- and ran the three per-class loops (static: T stores; current: T copies; behind: T / 4
+    // replay trips) one after the other, each for its lanes only.  ONE loop now, four frames per trip, for every lane: a static lane replays its one
+    // parameter first and then only stores; a current lane skips the moment loads (and the replay loop's zero trips); the operations per value are the
+    // per-class loops' (the same bits).
+    const bool dyn = cls == 1;
+    float4 ps = make_float4(0.f, 0.f, 0.f, 0.f);
+    int from_l = from;
+    if (!dyn) {
+        ps = p[o];
         if (from < upto) {
             float4 mm = m[o], vv = v[o];
-            replay(pp, mm, vv, hist, from, upto, beta1, beta2, eps);
-            if (writeback) { p[o] = pp; m[o] = mm; v[o] = vv; }
+            replay(ps, mm, vv, hist, from, upto, beta1, beta2, eps);
         }
-        if (compact)
-            for (int t = 0; t < T; ++t, oc += cframe) compact[oc] = pp;
-        if (mirror && frame)  // flush: refresh the other frames' slots so that the stack reads consistently everywhere (a static block has one copy)
-            for (int t = 1; t < T; ++t) p[o + (size_t)t * frame] = pp;
-        return;
+        from_l = upto;
     }
-    if (from >= upto) {       // current already: copy only
-        if (compact)
-            for (int t = 0; t < T; ++t, o += frame, oc += cframe) compact[oc] = p[o];
-        return;
-    }
-    // four frames of the texel per trip: twelve independent 16-byte loads in flight and four independent replay chains per thread (the
-    // same operations per value: the same bits) -- one frame per trip left a kept texel's thread with three loads in flight and one
-    // dependent chain of sqrt / rcp per step, and the catch-up of a tile-culled window at 64 % of the rate its bytes allow
+#ifdef VL3D_CATCHUP_ABLATE      // measurement only (profiles/r06_pmc_catchup.sh): 1 = no replay (the loads and stores alone)
+    if (VL3D_CATCHUP_ABLATE & 1) from_l = upto;
+#endif
+    const bool behind = from_l < upto;
     int t = 0;
     constexpr int NF = 4;
     for (; t + NF <= T; t += NF, o += NF * frame, oc += NF * cframe) {
         float4 pp[NF], mm[NF], vv[NF];
 #pragma unroll
-        for (int f = 0; f < NF; ++f) { pp[f] = p[o + f * frame]; mm[f] = m[o + f * frame]; vv[f] = v[o + f * frame]; }
-        for (int s = from + 1; s <= upto; ++s) {
+        for (int f = 0; f < NF; ++f) {
+            pp[f] = dyn ? p[o + f * frame] : ps;
+            if (behind) { mm[f] = m[o + f * frame]; vv[f] = v[o + f * frame]; }
+            else mm[f] = vv[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int s = from_l + 1; s <= upto; ++s) {
             const float2 h = hist[s];
 #pragma unroll
             for (int f = 0; f < NF; ++f) adam_upd4(pp[f], make_float4(0.f, 0.f, 0.f, 0.f), mm[f], vv[f], h.x, beta1, beta2, eps, h.y);
         }
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            if (writeback) { p[o + f * frame] = pp[f]; m[o + f * frame] = mm[f]; v[o + f * frame] = vv[f]; }
-            if (compact) compact[oc + f * cframe] = pp[f];
-        }
+        for (int f = 0; f < NF; ++f) compact[oc + f * cframe] = pp[f];
     }
     for (; t < T; ++t, o += frame, oc += cframe) {
-        float4 pp = p[o], mm = m[o], vv = v[o];
-        replay(pp, mm, vv, hist, from, upto, beta1, beta2, eps);
-        if (writeback) { p[o] = pp; m[o] = mm; v[o] = vv; }
-        if (compact) compact[oc] = pp;
+        float4 pp = dyn ? p[o] : ps, mm = make_float4(0.f, 0.f, 0.f, 0.f), vv = mm;
+        if (behind) { mm = m[o]; vv = v[o]; }
+        replay(pp, mm, vv, hist, from_l, upto, beta1, beta2, eps);
+        compact[oc] = pp;
     }
 }
 
@@ -298,7 +345,7 @@ extern "C" int vl3d_adam_window_catchup_boxes(int32_t D, int32_t T, int32_t Hs, 
     const BoxTable boxes = make_boxes(plane_boxes, D);
     const int tiles_y = (Hs + TS - 1) / TS, tiles_x = (Ws + TS - 1) / TS;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(adam_window_catchup_k, dim3((ww + 63) / 64, (wh + 3) / 4, D), dim3(256), 0, s, T, Hs, Ws, Win{y0, x0, wh, ww},
+    hipLaunchKernelGGL(compact ? adam_window_catchup_k<false> : adam_window_catchup_k<true>, dim3((ww + 63) / 64, (wh + 3) / 4, D), dim3(256), 0, s, T, Hs, Ws, Win{y0, x0, wh, ww},
                        reinterpret_cast<float4 *>(param), reinterpret_cast<float4 *>(exp_avg), reinterpret_cast<float4 *>(exp_avg_sq), last_step,
                        tiles_y, tiles_x, reinterpret_cast<const float2 *>(hist), upto, beta1, beta2, eps, reinterpret_cast<float4 *>(compact),
                        make_quads(quad_keep, quad_dyn, QH, QW, Hs, Ws), culled_alpha, mirror_static, compact ? 0 : 1,
