@@ -107,6 +107,38 @@ __global__ __launch_bounds__(RX *RY) void bwd_like_k(const f4 *__restrict__ src,
     }
 }
 
+// The fp16-STACK backward's pattern (round 6; verdict round 5, item 4: "what do 1.47x read traffic and the mixed stream allow?"): bwd_like_k's halo
+// pattern with 8-BYTE texels (four halves) -- a wave's row segment is 256 B (region 32 wide) or 512 B (64 wide) instead of 512 B / 1 KiB, the
+// gradient store 8 bytes per lane.  E = float2 stands in for the four halves (same bytes, same addresses).  Same geometry and frame pairing
+// as the shipped fp16 instantiation of render_bwd_pair_k (32 x 16 x 2).
+template <typename E, int RX, int RY, int FR>
+__global__ __launch_bounds__(RX *RY) void bwd_like_e_k(const E *__restrict__ src, E *__restrict__ dst, const unsigned short *__restrict__ owner, int D,
+                                                       int T, int Hs, int Ws, int tiles_x, int tiles_y) {
+    const int b = blockIdx.x;
+    const int q = gridDim.x >> 3, r = gridDim.x & 7, xcd = b & 7, k = b >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    const int tile_x = bid % tiles_x, rest = bid / tiles_x, tile_y = rest % tiles_y, t0 = (rest / tiles_y) * FR;
+    const int lx = threadIdx.x % RX, ly = threadIdx.x / RX;
+    const int gx = tile_x * (RX - 2) - 1 + lx, gy = tile_y * (RY - 2) - 1 + ly;
+    const int x = min(max(gx, 0), Ws - 2), y = min(max(gy, 0), Hs - 2);
+    const bool interior = lx >= 1 && lx < RX - 1 && ly >= 1 && ly < RY - 1 && gx < Ws && gy < Hs;
+    const size_t frame = (size_t)Hs * Ws, plane = (size_t)T * frame;
+    size_t o = (size_t)t0 * frame + (size_t)y * Ws + x;
+    size_t oo = (size_t)y * Ws + x;
+    float acc = 0.f;
+    for (int d = 0; d < D; ++d, o += plane, oo += frame) {
+        E v[FR];
+        const unsigned e = owner[oo];
+#pragma unroll
+        for (int f = 0; f < FR; ++f) v[f] = src[o + f * frame] + src[o + f * frame + 1] + src[o + f * frame + Ws] + src[o + f * frame + Ws + 1];
+        if (interior) {
+#pragma unroll
+            for (int f = 0; f < FR; ++f) __builtin_nontemporal_store(v[f] + acc, &dst[o + f * frame]);
+        }
+        acc += (float)e;
+    }
+}
+
 // The optimiser fused into the owner store (verdict round 3, next #3), as a memory pattern: the shipped halo pattern, but an interior thread
 // does not store its gradient texel -- it READS the two moments of its texel (m, v: two more streams at the tile's ragged segments; p comes
 // with the taps) and WRITES p, m, v (three streams instead of one).  Compared below with what it replaces: the shipped pattern's one
@@ -304,8 +336,20 @@ static void run(const char *name, F launch, double bytes) {
     fflush(stdout);
 }
 
+typedef float f2_t __attribute__((ext_vector_type(2)));
+__global__ void rw8_k(const f2_t *__restrict__ src, f2_t *__restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i + 3 * stride < n; i += 4 * stride) {
+        f2_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) __builtin_nontemporal_store(v[u] * 2.f, &dst[i + u * stride]);
+    }
+}
+
 int main(int argc, char **argv) {
-    const bool aligned_only = argc > 1 && (argv[1][0] == 'a' || argv[1][0] == 'h' || argv[1][0] == 'f' || argv[1][0] == 'v');      // ./rw_bw aligned | halo: only that comparison at the end
+    const bool aligned_only = argc > 1 && (argv[1][0] == 'a' || argv[1][0] == 'h' || argv[1][0] == 'f' || argv[1][0] == 'v' || argv[1][0] == 'p');      // ./rw_bw aligned | halo: only that comparison at the end
     const bool halo_only = argc > 1 && argv[1][0] == 'h';
     const size_t unit = 8ull << 30, n = unit / 16;     // 8 GiB per stream
     f4 *src, *dst;
@@ -422,6 +466,30 @@ int main(int argc, char **argv) {
             }
         }
         printf("fused = row 2;  unfused = row 1 + row 3\n");
+        return 0;
+    }
+    // The fp16 stack's backward pattern against the fp32 one, same geometry (round 6): ./rw_bw p
+    if (argc > 1 && argv[1][0] == 'p') {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const int D = 32, T = 12, Hs = 720, Ws = 1280;
+        const size_t texels = (size_t)D * T * Hs * Ws;
+        unsigned short *owner;
+        hipMalloc(&owner, (size_t)D * Hs * Ws * 2 + 4096);
+        hipMemset(owner, 0, (size_t)D * Hs * Ws * 2 + 4096);
+#define BLE(E, EB, RX, RY, FR)                                                                                                 \
+        {                                                                                                                      \
+            const int tx = (Ws + RX - 3) / (RX - 2), ty = (Hs + RY - 3) / (RY - 2);                                            \
+            snprintf(name, sizeof name, "bwd_like  %2d-byte texels  region %3d x %2d  frames %d  (halo x%.2f)", EB, RX, RY, FR,  \
+                     (double)RX * RY / ((RX - 2) * (RY - 2)));                                                                 \
+            run(name, [&] { hipLaunchKernelGGL((bwd_like_e_k<E, RX, RY, FR>), dim3((unsigned)(tx * ty * (T / FR))), dim3(RX * RY), 0, 0, \
+                                               reinterpret_cast<const E *>(src), reinterpret_cast<E *>(dst), owner, D, T, Hs, Ws, tx, ty); }, 2.0 * texels * EB); \
+        }
+        for (int rep = 0; rep < 2; ++rep) {
+            BLE(f4, 16, 32, 16, 2) BLE(f2, 8, 32, 16, 2) BLE(f2, 8, 32, 16, 4) BLE(f2, 8, 64, 8, 2) BLE(f2, 8, 64, 16, 1) BLE(f2, 8, 64, 16, 2) BLE(f2, 8, 64, 8, 4) BLE(f2, 8, 128, 4, 2)
+        }
+        // (streaming reference at 8 bytes per lane: what the HBM gives a read:write = 1:1 kernel whose accesses are 8-byte wide)
+        run("rw 1:1, 8-byte lanes, nt-store (grid-strided)", [&] { hipLaunchKernelGGL((rw8_k), dim3(256 * 16), dim3(512), 0, 0, reinterpret_cast<const f2 *>(src),
+                                                                                    reinterpret_cast<f2 *>(dst), unit / 8); }, 2.0 * unit);
         return 0;
     }
     // A backward WITHOUT the vertical halo (round 5): the shipped pattern against its no-vertical-halo upper bound, same geometry.
