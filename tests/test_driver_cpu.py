@@ -98,11 +98,12 @@ def test_mpmeshvid_driver_hooks():
     assert m.optimize_geometry
     # lod: planes resized, texel scale follows, parameter re-registered (the optimiser is re-created by the driver)
     full = m.stack.detach().clone()
+    aa = bool(getattr(m.args, "lod_antialias", False))      # (torchvision 0.11's Resize of a tensor: no antialiasing -- the release the reference pins)
     m.lod(0.5)
     assert m.stack.shape == (2, 3, 10, 16, 4) and m.stack.requires_grad
     assert m.spec.scale == pytest.approx((15 / 31, 9 / 19))
     ref = torch.nn.functional.interpolate(full.permute(0, 1, 4, 2, 3).reshape(6, 4, 20, 32), size=(10, 16), mode="bilinear",
-                                          align_corners=False, antialias=True).reshape(2, 3, 4, 10, 16).permute(0, 1, 3, 4, 2)
+                                          align_corners=False, antialias=aa).reshape(2, 3, 4, 10, 16).permute(0, 1, 3, 4, 2)
     assert torch.equal(m.stack.detach(), ref)
     m.lod(1.0)
     assert m.stack.shape == (2, 3, 20, 32, 4) and m.spec.scale == pytest.approx((1.0, 1.0))

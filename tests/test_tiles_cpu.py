@@ -146,10 +146,10 @@ def test_lod_of_a_sparsified_model_does_not_bleed_culled_logits():
         assert float(v[kept_t].min()) >= lo - 1e-4 and float(v[kept_t].max()) <= hi + 1e-4, factor     # no -37 / -7509 logits
         assert bool((v[..., 3][~kept_t] == tiles.CULLED_ALPHA).all())                                    # culling re-applied
         assert vid._tie_hook is not None
-    # an un-sparsified model takes the plain antialiased filter (torchvision Resize semantics), untouched by the fix
+    # an un-sparsified model takes the plain filter (torchvision Resize semantics: args.lod_antialias), untouched by the fix
     dense = MPMeshVid(_args(mpv_frm_num=2), H, W, np.eye(4), K, 1.0, 100.0)
     ref = torch.nn.functional.interpolate(dense.stack.detach().permute(0, 1, 4, 2, 3).reshape(6, 4, 80, 120), size=(40, 60),
-                                          mode="bilinear", align_corners=False, antialias=True).reshape(3, 2, 4, 40, 60).permute(0, 1, 3, 4, 2)
+                                          mode="bilinear", align_corners=False, antialias=bool(getattr(dense.args, "lod_antialias", False))).reshape(3, 2, 4, 40, 60).permute(0, 1, 3, 4, 2)
     dense.lod(0.5)
     assert torch.allclose(dense.stack.detach(), ref, atol=1e-6)
 

@@ -479,12 +479,17 @@ class MPMeshVid(nn.Module):
     # ---- driver hooks (train_3dvid.py:264-281) ------------------------------------------------------------------------
     def lod(self, factor):
         """MPV.py:140-197 (dense branch): resample the learnable texture to `factor` of its full resolution for one level of
-        the training pyramid.  Every plane of the stack is resized to (int(mpi_h*factor), int(mpi_w*factor)) with the same
-        antialiased bilinear filter torchvision's Resize applies to the atlas; the plane quads keep their extent, so the
+        the training pyramid.  Every plane of the stack is resized to (int(mpi_h*factor), int(mpi_w*factor)) with the
+        bilinear filter torchvision's Resize applies to the atlas (`args.lod_antialias`, below); the plane quads keep their extent, so the
         plane-pixel -> texel scale of the render spec becomes (w'-1)/(mpi_w-1) (the reference gets this from its
         normalised UVs, MPV.py:75-81)."""
         self._flush_deferred_updates()
         self._window_opt = None          # the parameter object changes: the driver asks for a new optimiser (train_3dvid.py:264-265)
+        # torchvision's Resize on a TENSOR: no antialiasing in the release the reference pins (requirements.txt: torch==1.10 -> torchvision 0.11:
+        # `antialias=None` means False for tensors, transforms/functional_tensor.py), antialiased from torchvision 0.17 on (the default became
+        # True).  Only a DOWN-sampling call differs -- the first lod() of a run, from the full-resolution initialisation to the coarsest level;
+        # the later ones up-sample, where the two filters coincide.  Default: the pinned release's; `args.lod_antialias = True` for the newer one.
+        aa = bool(getattr(self.args, "lod_antialias", False))
         h, w = max(int(self.mpi_h * factor), 2), max(int(self.mpi_w * factor), 2)
         if self.tile_full is not None:
             # a model on the reference's tile lattice: every quad holds max(int(tile * factor), 2) texels per axis at this level, as the
@@ -506,7 +511,7 @@ class MPMeshVid(nn.Module):
                 def resize_plane(planes):          # (T,hs,ws,4) -> (T,h,w,4), tile by tile
                     t_ = planes.shape[0]
                     tl = planes.reshape(t_, qh, oth, qw, otw, 4).permute(0, 1, 3, 5, 2, 4).reshape(t_ * qh * qw, 4, oth, otw)
-                    tl = torch.nn.functional.interpolate(tl, size=(nth, ntw), mode="bilinear", align_corners=False, antialias=True)
+                    tl = torch.nn.functional.interpolate(tl, size=(nth, ntw), mode="bilinear", align_corners=False, antialias=aa)
                     return tl.reshape(t_, qh, qw, 4, nth, ntw).permute(0, 1, 4, 2, 5, 3).reshape(t_, h, w, 4)
                 with torch.no_grad():
                     if self.packed is not None:
@@ -542,8 +547,8 @@ class MPMeshVid(nn.Module):
                 for d in range(D):
                     planes = self.packed.unpack_plane(self.stack_pool.data, d).permute(0, 3, 1, 2)               # T,4,hs,ws
                     m = tiles.quad_to_texel_mask(self.quad_keep[d:d + 1], hs, ws).to(planes.dtype)[None]         # 1,1,hs,ws
-                    num = torch.nn.functional.interpolate(planes * m, size=(h, w), mode="bilinear", align_corners=False, antialias=True)
-                    den = torch.nn.functional.interpolate(m, size=(h, w), mode="bilinear", align_corners=False, antialias=True)
+                    num = torch.nn.functional.interpolate(planes * m, size=(h, w), mode="bilinear", align_corners=False, antialias=aa)
+                    den = torch.nn.functional.interpolate(m, size=(h, w), mode="bilinear", align_corners=False, antialias=aa)
                     new = (num / den.clamp_min(1e-6)).permute(0, 2, 3, 1).contiguous()
                     tiles.cull_stack_(new[None], self.quad_keep[d:d + 1])
                     lay.pack_plane_(pool, d, new)
@@ -566,11 +571,11 @@ class MPMeshVid(nn.Module):
                     planes = self.stack.data[d].permute(0, 3, 1, 2)                                          # T,4,hs,ws
                     if sparse:
                         m = kept[d][None, None]                                                              # 1,1,hs,ws
-                        num = torch.nn.functional.interpolate(planes * m, size=(h, w), mode="bilinear", align_corners=False, antialias=True)
-                        den = torch.nn.functional.interpolate(m, size=(h, w), mode="bilinear", align_corners=False, antialias=True)
+                        num = torch.nn.functional.interpolate(planes * m, size=(h, w), mode="bilinear", align_corners=False, antialias=aa)
+                        den = torch.nn.functional.interpolate(m, size=(h, w), mode="bilinear", align_corners=False, antialias=aa)
                         planes = num / den.clamp_min(1e-6)
                     else:
-                        planes = torch.nn.functional.interpolate(planes, size=(h, w), mode="bilinear", align_corners=False, antialias=True)
+                        planes = torch.nn.functional.interpolate(planes, size=(h, w), mode="bilinear", align_corners=False, antialias=aa)
                     new[d] = planes.permute(0, 2, 3, 1)
                 if sparse:
                     tiles.cull_stack_(new, self.quad_keep)
