@@ -107,6 +107,14 @@ def test_mpmeshvid_driver_hooks():
     assert torch.equal(m.stack.detach(), ref)
     m.lod(1.0)
     assert m.stack.shape == (2, 3, 20, 32, 4) and m.spec.scale == pytest.approx((1.0, 1.0))
+    # args.lod_antialias = True: torchvision >= 0.17's Resize of a tensor (differs from the pinned release's on a down-sampling call only)
+    m2 = MPMeshVid(_mpv_args(lod_antialias=True), 20, 32, np.eye(4), np.array([[30., 0, 16], [0, 30., 10], [0, 0, 1]]), 1.0, 100.0)
+    full2 = m2.stack.detach().clone()
+    m2.lod(0.5)
+    planes = full2.permute(0, 1, 4, 2, 3).reshape(6, 4, 20, 32)
+    want = {aa_: torch.nn.functional.interpolate(planes, size=(10, 16), mode="bilinear", align_corners=False, antialias=aa_)
+            .reshape(2, 3, 4, 10, 16).permute(0, 1, 3, 4, 2) for aa_ in (True, False)}
+    assert torch.equal(m2.stack.detach(), want[True]) and not torch.equal(want[True], want[False])
 
 
 # ---- product helpers against the reference goldens (plain torch: run on the CPU) ------------------------------------------------
