@@ -87,7 +87,8 @@ class _RenderPlanes(torch.autograd.Function):
             L.check_cuda(quad_keep)
             if quad_keep.dim() != 3 or quad_keep.shape[0] != stack.shape[0]:
                 raise RuntimeError(f"quad_keep must be [D,QH,QW] with D = {stack.shape[0]}, got {tuple(quad_keep.shape)}")
-            quad_keep = quad_keep.to(torch.uint8).contiguous()
+            from .tiles import as_u8
+            quad_keep = as_u8(quad_keep)
         if stack.dtype not in (torch.float32, torch.float16):
             raise RuntimeError("plane stack must be float32 or float16 (arithmetic is fp32 either way)")
         if getattr(spec, "tile", (0, 0))[0] and quad_keep is None:
@@ -333,7 +334,8 @@ def render_frame_run(stack, frame0, nframes, homos, H, W, spec: RenderSpec = Ren
             L.check_cuda(quad_keep)
             if quad_keep.dim() != 3 or quad_keep.shape[0] != D:
                 raise RuntimeError(f"quad_keep must be [D,QH,QW] with D = {D}, got {tuple(quad_keep.shape)}")
-            qk = quad_keep if (quad_keep.dtype == torch.uint8 and quad_keep.is_contiguous()) else quad_keep.to(torch.uint8).contiguous()
+            from .tiles import as_u8
+            qk = as_u8(quad_keep)
             ncull = int(L.lib().vl3d_render_cull_scratch_bytes(desc))
             cull = torch.empty((ncull + 3) // 4, dtype=torch.float32, device=stack.device)
             L.check(L.lib().vl3d_render_fwd_frames_culled(desc, L.ptr(stack), int(frame0), int(T), L.ptr(homos), L.ptr(qk), *_qgrid(qk, spec),
@@ -402,7 +404,8 @@ def render_planes_packed(layout, pool, frames, homos, H, W, spec: RenderSpec, qu
     d.pixel_center = float(spec.pixel_center)
     d.sx, d.sy, d.ox, d.oy = float(spec.scale[0]), float(spec.scale[1]), float(spec.offset[0]), float(spec.offset[1])
     dev = pool.device
-    qk = quad_keep if (quad_keep.dtype == torch.uint8 and quad_keep.is_contiguous()) else quad_keep.to(torch.uint8).contiguous()
+    from .tiles import as_u8
+    qk = as_u8(quad_keep)
     if frames_dev is not None:
         if frames_dev.dtype != torch.int32 or frames_dev.numel() != len(frames) or not frames_dev.is_contiguous() or frames_dev.device != dev:
             raise RuntimeError("render_planes_packed: frames_dev must be the contiguous int32 device copy of `frames`")

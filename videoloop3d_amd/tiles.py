@@ -22,6 +22,29 @@ import torch.nn.functional as F
 CULLED_ALPHA = -1e4
 
 
+# The quad maps of a model are constant between two `sparsify_faces` calls, but they live as bool buffers and the C ABI takes bytes: the uint8 form
+# is kept per source tensor (storage address, version counter, view geometry) instead of being converted at every render / step / tie (a launch each:
+# two to three of the ~33 of a tile-culled stage-2 iteration).  The entry holds a reference to its source, so the address cannot be recycled.
+_U8_CACHE = {}
+
+
+def as_u8(t):
+    """bool / uint8 map -> contiguous uint8 tensor on the same device (cached per source tensor and version)."""
+    if t is None:
+        return None
+    if t.dtype == torch.uint8 and t.is_contiguous():
+        return t
+    key = (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype, str(t.device))
+    hit = _U8_CACHE.get(key)
+    if hit is not None:
+        return hit[1]
+    if len(_U8_CACHE) >= 16:
+        _U8_CACHE.clear()
+    u = t.to(torch.uint8).contiguous()
+    _U8_CACHE[key] = (t, u)
+    return u
+
+
 def dilate(alpha, kernelsz=3):
     """utils.py:298-306: max filter, zero padding.  alpha [B,L,H,W]."""
     pad = kernelsz // 2
@@ -180,7 +203,7 @@ def tie_static_grad_hip(grad, keep, dyn, assume_culled_zero=False, frame0_only=F
     if C4 != 4 or grad.dtype != torch.float32:
         raise RuntimeError("tie_static_grad_hip: gradient must be (D,T,Hs,Ws,4) float32")
     g = grad if grad.is_contiguous() else grad.contiguous()
-    k8, d8 = keep.to(torch.uint8).contiguous(), dyn.to(torch.uint8).contiguous()
+    k8, d8 = as_u8(keep), as_u8(dyn)
     with torch.cuda.device(g.device):
         L.check(L.lib().vl3d_tie_static_grad(D, T, Hs, Ws, L.ptr(k8), L.ptr(d8), *quad_grid_args(keep, tile), L.ptr(g),
                                              (1 if assume_culled_zero else 0) | (2 if frame0_only else 0), L.stream_ptr(g.device)),
@@ -226,8 +249,8 @@ class TileAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        qk = None if self.quad_keep is None else self.quad_keep.to(torch.uint8).contiguous()
-        qd = None if (qk is None or self.quad_dyn is None) else self.quad_dyn.to(torch.uint8).contiguous()
+        qk = as_u8(self.quad_keep)
+        qd = None if qk is None else as_u8(self.quad_dyn)
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:

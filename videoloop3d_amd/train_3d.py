@@ -171,7 +171,8 @@ def run_iter(nerf, optimizer, item, args, device):
         img_loss, loop_loss = img_loss.detach(), (loop_loss.detach() if torch.is_tensor(loop_loss) else loop_loss)
         extra_losses = {k: v.detach() for k, v in extra_losses.items()}
     optimizer.zero_grad()
-    loss.backward()
+    from .train_3dvid import unit_grad
+    loss.backward(unit_grad(module, loss))
     if hasattr(module, "post_backward"):
         module.post_backward()
     optimizer.step()

@@ -156,6 +156,18 @@ def weighted_total(mains, extra, weight_of):
     return terms.sum(), [terms[i] for i in range(n)], {k: terms[n + i] for i, k in enumerate(names)}
 
 
+def unit_grad(module, loss):
+    """d loss / d loss = 1 from a tensor cached on the module: `loss.backward()` fills a fresh one on the device at every call -- one launch of a
+    ~30-launch iteration."""
+    cache = getattr(module, "__dict__", None)
+    one = cache.get("_unit_grad") if cache is not None else None
+    if one is None or one.device != loss.device or one.dtype != loss.dtype or one.shape != loss.shape:
+        one = torch.ones_like(loss)
+        if cache is not None:
+            cache["_unit_grad"] = one
+    return one
+
+
 def run_iter(nerf, optimizer, item, args, device):
     """train_3dvid.py:214-255 without the logging."""
     _, _, pose, intrin, crop, cfg = item
@@ -188,7 +200,7 @@ def run_iter(nerf, optimizer, item, args, device):
         loss, (swd_loss,), extra_losses = weighted_total([swd], extra, lambda k: args_var[f"{k}_loss_weight"])
         swd_loss, extra_losses = swd_loss.detach(), {k: v.detach() for k, v in extra_losses.items()}
     optimizer.zero_grad()
-    loss.backward()
+    loss.backward(unit_grad(module, loss))
     optimizer.step()
     return loss.detach(), swd_loss, extra_losses
 

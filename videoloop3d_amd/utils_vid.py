@@ -339,7 +339,8 @@ class _FoldRobustMean(torch.autograd.Function):
             holder._lazy = (desc, yv, nn)
         ctx.save_for_backward(gx)
         ctx.x_dtype = x.dtype
-        return (acc / (3 * desc.Tx * desc.H * desc.W)).to(torch.float32)
+        # (the mean in double, rounded once to fp32 -- one launch: the division writes its fp32 result itself)
+        return torch.div(acc, float(3 * desc.Tx * desc.H * desc.W), out=torch.empty((), dtype=torch.float32, device=dev))
 
     @staticmethod
     def backward(ctx, g):
