@@ -184,8 +184,10 @@ int vl3d_adam_step_tiles(int32_t D, int32_t T, int32_t Hs, int32_t Ws, const uin
  * vl3d_adam_window_tile()-texel tiles, or ending at the plane border) receive a gradient; the zero-gradient Adam steps of all
  * other texels (m <- b1 m, v <- b2 v, p <- p - lr_t m^/(sqrt(v^) + eps)) are deferred and replayed exactly, per tile, when a tile is
  * next needed.  last_step: device int32 [D][ceil(Hs/16)][ceil(Ws/16)], the step each tile is current for (0 initially).
- * hist: device float2 [steps+1], entry t = (lr_t / (1 - beta1^t), sqrt(1 - beta2^t)) as vl3d_adam_step_scalars computes them,
- * written by the caller when step t is taken.
+ * hist: device float2 [steps+1], entry t = (lr_t / (1 - beta1^t), sqrt(1 - beta2^t)) as vl3d_adam_step_scalars computes them.
+ * Round 6: the step functions (vl3d_adam_window_step / _boxes, vl3d_render_bwd_adam) WRITE row `step` themselves from their own lr / betas /
+ * step arguments, behind the update, in the launch that marks the tiles (the table is `const` for every reader; a caller that also fills the row
+ * writes the same two floats).  The caller sizes the table (step < its length) and keeps rows 0 .. step intact.
  *   vl3d_adam_window_catchup: the window's parameters as of step `upto` (steps last_step+1 .. upto replayed with g = 0).  With
  *     compact != NULL they are written to the compact (D,T,wh,ww,4) buffer the render then reads and the stack is left untouched;
  *     with compact == NULL (a flush) they are written back and the tiles marked current.
@@ -218,7 +220,7 @@ int vl3d_adam_window_step(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_t 
  * + 3 (p, m, v) streams, no gradient round trip.  `stack` is the compact copy of the texel window at (adam->y0, adam->x0) of the
  * (D,T,adam->Hs,adam->Ws,4) parameter -- desc->Hs x desc->Ws texels, written by vl3d_adam_window_catchup(_boxes) with upto = step - 1, so it
  * holds the parameters current for step - 1 and only the two moments are replayed (multiplications).  Window / plane_boxes / last_step /
- * hist: as vl3d_adam_window_step_boxes (hist[step] written by the caller); on return the window's tiles are marked `step` and (p, m, v) are
+ * hist: as vl3d_adam_window_step_boxes (hist[step] is written by this call); on return the window's tiles are marked `step` and (p, m, v) are
  * bit for bit what vl3d_render_bwd followed by vl3d_adam_window_step_boxes would have left (tests/test_gpu_optim.py).  Every texel of
  * window and box is stepped exactly once: by the tile that owns it, or -- texels no tile's gather reaches: zero gradient -- by the
  * backward's pre-pass.  grad_stack (the compact gradient, desc's dims) is still required: when the device-side plan finds the view

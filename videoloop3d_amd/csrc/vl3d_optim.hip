@@ -238,9 +238,12 @@ __global__ __launch_bounds__(MAX_BOX_PLANES) void write_boxes_k(const BoxTable b
     if ((int)threadIdx.x < boxes.n) out[threadIdx.x] = boxes.b[threadIdx.x];
 }
 
+// (hist_row: a step's marks also put the step's scalars into its row of the history table -- what the catch-ups of LATER steps replay it with; the
+// host used to upload the row with an 8-byte fill of its own, one launch per iteration)
 __global__ __launch_bounds__(256) void mark_tiles_k(int *last_step, int tiles_y, int tiles_x, int ty0, int tx0, int nty, int ntx, int D, int step,
-                                                    const BoxTable boxes) {
+                                                    const BoxTable boxes, float2 *hist_row = nullptr, float2 hist_val = make_float2(0.f, 0.f)) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && hist_row) *hist_row = hist_val;
     if (i >= D * nty * ntx) return;
     const int tx = i % ntx, ty = (i / ntx) % nty, d = i / (ntx * nty);
     if (outside_box(boxes, d, (tx0 + tx) * TS, (ty0 + ty) * TS)) return;
@@ -386,7 +389,8 @@ static int window_step_impl(int32_t D, int32_t T, int32_t Hs, int32_t Ws, int32_
                        make_quads(quad_keep, quad_dyn, QH, QW, Hs, Ws), static_tied, last_step, tiles_y, tiles_x,
                        reinterpret_cast<const float2 *>(hist), (int)step, boxes, Layout{blocks}, dyn_stepped);
     const int nty = (y0 + wh + TS - 1) / TS - y0 / TS, ntx = (x0 + ww + TS - 1) / TS - x0 / TS;
-    hipLaunchKernelGGL(mark_tiles_k, dim3((D * nty * ntx + 255) / 256), dim3(256), 0, s, last_step, tiles_y, tiles_x, y0 / TS, x0 / TS, nty, ntx, D, (int)step, boxes);
+    hipLaunchKernelGGL(mark_tiles_k, dim3((D * nty * ntx + 255) / 256), dim3(256), 0, s, last_step, tiles_y, tiles_x, y0 / TS, x0 / TS, nty, ntx, D, (int)step, boxes,
+                       reinterpret_cast<float2 *>(const_cast<float *>(hist)) + step, make_float2((float)((double)lr / bc1), (float)sqrt(bc2)));
     VL3D_CHECK_LAUNCH();
     return VL3D_OK;
 }

@@ -346,10 +346,8 @@ class WindowAdam(torch.optim.Optimizer):
         t = self.t + 1
         if t >= st["hist"].shape[0]:
             st["hist"] = torch.cat([st["hist"], torch.zeros_like(st["hist"])])
-        a, b = C.c_float(), C.c_float()
-        L.lib().vl3d_adam_step_scalars(lr, float(b1), float(b2), t, C.byref(a), C.byref(b))
-        # the two scalars travel as ONE kernel argument (an 8-byte fill of the row viewed as int64): no host-to-device copy, no sync, one launch
-        st["hist"].view(torch.int64)[t].fill_(struct.unpack("<q", struct.pack("<ff", a.value, b.value))[0])
+        # (row t itself is written by the step's own launch -- vl3d_adam_window_step* / vl3d_render_bwd_adam put (lr / bc1, sqrt(bc2)) of the step they
+        # take into hist[step], include/vl3d.h: the 8-byte fill the host issued here was one launch per iteration)
         return t
 
     def _bound_deferral(self, st, t):
