@@ -219,7 +219,7 @@ extern "C" int vl3d_render_fwd_reg(const vl3d_render_desc *desc, const void *sta
     set_reg_state(a, desc, reg_state);
     a.g_f16 = desc->stack_dtype == VL3D_F16;
     a.reg_fwd = 2;
-    VL3D_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(double), (hipStream_t)stream));
+    // (the sums are cleared by reg_masks_k, the first kernel of the regulariser forward)
     rc = dispatch(false, desc, a, (hipStream_t)stream);
     if (rc != VL3D_OK) return rc;
     VL3D_CHECK_LAUNCH();
@@ -255,7 +255,7 @@ extern "C" int vl3d_render_fwd_mask(const vl3d_render_desc *desc, const void *st
         a.reg_sums = sums;
         set_reg_state(a, desc, reg_state);
         a.reg_fwd = 2;
-        VL3D_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(double), (hipStream_t)stream));
+        // (the sums are cleared by reg_masks_k, the first kernel of the regulariser forward)
     }
     rc = dispatch(false, desc, a, (hipStream_t)stream);
     if (rc != VL3D_OK) return rc;
@@ -326,7 +326,7 @@ extern "C" int vl3d_render_fwd_reg_culled(const vl3d_render_desc *desc, const vo
     a.quad_keep = quad_keep; a.QH = QH; a.QW = QW;
     set_cull_geometry(a, desc, QH, QW);
     set_reg_state(a, desc, reg_state);
-    VL3D_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(double), (hipStream_t)stream));
+    // (the sums are cleared by reg_masks_k, the first kernel of the regulariser forward)
     a.reg_fwd = 3;
     a.g_f16 = desc->stack_dtype == VL3D_F16;
     rc = dispatch(false, desc, a, (hipStream_t)stream);
@@ -349,7 +349,7 @@ static int render_reg_fwd_impl(const vl3d_render_desc *desc, const void *stack, 
     a.quad_keep = quad_keep; a.QH = QH; a.QW = QW;
     set_cull_geometry(a, desc, QH, QW);
     set_reg_state(a, desc, reg_state);
-    VL3D_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(double), (hipStream_t)stream));
+    // (the sums are cleared by reg_masks_k, the first kernel of the regulariser forward)
     a.reg_fwd = 1;
     a.g_f16 = desc->stack_dtype == VL3D_F16;
     rc = dispatch(false, desc, a, (hipStream_t)stream);

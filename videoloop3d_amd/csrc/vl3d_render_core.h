@@ -506,6 +506,9 @@ __device__ __forceinline__ f4 reg_grad32(unsigned w_own, unsigned w_left, unsign
 
 template <int COORD, int BORDER>
 __global__ __launch_bounds__(256) void reg_masks_k(RenderArgs a) {
+    // (first kernel of every forward that accumulates the four regulariser sums, launch_reg_prepass: it clears them -- the entry points issued a
+    // 32-byte hipMemsetAsync for that, one launch per iteration)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4 && a.reg_sums) a.reg_sums[threadIdx.x] = 0.0;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= a.W || y >= a.H) return;
     const float px = (float)(a.col0 + x) + a.pc, py = (float)(a.row0 + y) + a.pc;
