@@ -135,16 +135,25 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
             # some boxes a loop WITHOUT these events lost 0.1 - 2.3 s ONCE somewhere inside a full-resolution level of the tile-culled models, where host and
             # device run in lockstep (3 of 16 bench runs; every kernel of the 12 iterations profiled right after it at its usual time, no device allocation,
             # no allocator retry) -- with them, 0 of 24.  Not understood; `stall_ms` is there to make a recurrence visible instead of a silent low rate.
-            marks = []
+            marks, host_t = [], []
             for k, i in enumerate(timed):
                 one(i, k // len(ds))
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()
                 marks.append(ev)
+                host_t.append(time.perf_counter())
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            gaps = sorted(marks[k - 1].elapsed_time(marks[k]) for k in range(1, len(marks)))
-            dev_ms = {"p50": gaps[len(gaps) // 2], "max": gaps[-1], "stall_ms": dt * 1e3 - marks[0].elapsed_time(marks[-1]) * len(marks) / (len(marks) - 1)}
+            dgap = [marks[k - 1].elapsed_time(marks[k]) for k in range(1, len(marks))]
+            hgap = [(host_t[k] - host_t[k - 1]) * 1e3 for k in range(1, len(marks))]
+            gaps = sorted(dgap)
+            kd, kh = int(np.argmax(dgap)), int(np.argmax(hgap))
+            # (max / max_at: the longest device interval between two iterations' events and its index; host_max / host_max_at: the same on the host's clock
+            # -- the enqueue side.  A device interval far above p50 WITH the same host interval at the same index is the host being away, not a kernel.)
+            dev_ms = {"p50": gaps[len(gaps) // 2], "max": gaps[-1], "max_at": kd + 1, "host_max": hgap[kh], "host_max_at": kh + 1, "host_at_device_max": hgap[kd],
+                      "stall_ms": dt * 1e3 - marks[0].elapsed_time(marks[-1]) * len(marks) / (len(marks) - 1),
+                      "iters_per_s_without_intervals_over_20x_p50": (len(dgap) - sum(g > 20 * gaps[len(gaps) // 2] for g in dgap))
+                      / max(1e-9, sum(g for g in dgap if g <= 20 * gaps[len(gaps) // 2]) * 1e-3)}
             if count_leaf is not None:
                 opt.window_leaf = count_leaf
             if os.environ.get("VL3D_SCHED_DIAG"):      # measurement aid: the allocator's state after the level, the kernels of 12 more iterations
