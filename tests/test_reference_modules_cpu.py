@@ -193,8 +193,8 @@ def test_g16_init_from_mpi_of_the_sparsified_checkpoint(layout):
         assert v3.tile_own == (5, 5) and v3.spec.tile == (5, 5)
         t_old = v.stack.detach()[2, 1, 10:20, 30:40].permute(2, 0, 1)[None]
         want = torch.nn.functional.interpolate(t_old, size=(5, 5), mode="bilinear", align_corners=False, antialias=bool(getattr(v3.args, "lod_antialias", False)))[0].permute(1, 2, 0)
-        if bool(v.quad_keep[2, 1, 3]):
-            assert torch.equal(v3.stack.detach()[2, 1, 5:10, 15:20], want)
+        if bool(v.quad_keep[2, 1, 3]):      # (the tiles' own resize spells F.interpolate's sum with gathers: equal to a few units in the last place)
+            assert torch.allclose(v3.stack.detach()[2, 1, 5:10, 15:20], want, rtol=0, atol=5e-6)
         # at a pyramid level the export keeps the FULL atlas size under "self.atlas_full_*" (what the reference's lod scales from, MPV.py:149)
         sd5 = v3.reference_state_dict()
         assert sd5["atlas_dyn"].shape[-2] == sd5["self.atlas_grid_dyn_h"] * 5 and sd5["self.atlas_full_dyn_h"] == sd5["self.atlas_grid_dyn_h"] * 10
