@@ -136,6 +136,9 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
             # device run in lockstep (3 of 16 bench runs; every kernel of the 12 iterations profiled right after it at its usual time, no device allocation,
             # no allocator retry) -- with them, 0 of 24.  Not understood; `stall_ms` is there to make a recurrence visible instead of a silent low rate.
             marks, host_t = [], []
+            import gc
+            gc_was = gc.isenabled()
+            gc.disable()      # (no collector pause inside the timed loop: one suspect less for the rare stalled level; re-enabled right after it)
             for k, i in enumerate(timed):
                 one(i, k // len(ds))
                 ev = torch.cuda.Event(enable_timing=True)
@@ -144,6 +147,8 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
                 host_t.append(time.perf_counter())
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            if gc_was:
+                gc.enable()
             dgap = [marks[k - 1].elapsed_time(marks[k]) for k in range(1, len(marks))]
             hgap = [(host_t[k] - host_t[k - 1]) * 1e3 for k in range(1, len(marks))]
             gaps = sorted(dgap)
