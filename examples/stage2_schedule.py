@@ -117,7 +117,13 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
                 for (_, lr), g in zip(model.get_lrate(epoch), opt.param_groups):
                     g["lr"] = lr / len(ds)                                     # lrate_adaptive (train_3dvid.py:281-287)
                 run_iter(model, opt, ds[i], args, dev)
-            for k in range(8):                                                 # warm-up (allocator, first-call set-up)
+            # warm-up: ONE WHOLE EPOCH (every crop of every view once), not eight iterations -- the optimiser's compact window / gradient / scratch
+            # buffers grow to the largest window of the level and the caching allocator has seen every size before the clock starts.  With eight,
+            # the timed loop contained one to three multi-GB hipMallocs per level (`reserved_changes_in_loop` below), normally 2 ms each -- and on some
+            # boxes 1.2 s: the "stalled level" of rounds 5 and 6 (docs/measurement_log.md).  First-epoch allocations are real, once per pyramid
+            # level; a rate over two epochs is not the place to charge them.
+            nwarm = len(ds)
+            for k in range(nwarm):
                 one(order[k], 0)
             torch.cuda.synchronize()
             # the crop's texel window of every timed iteration (host integers: no synchronisation), for `roofline_iter`
@@ -129,13 +135,13 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
                     return _orig(window, plane_boxes)
                 opt.window_leaf = counting
             t0 = time.perf_counter()
-            timed = order[8:8 + epochs * len(ds)]
-            # a device event after every timed iteration: the per-iteration device time (median reported beside the wall-clock rate, which stays THE rate),
-            # and `stall_ms` = wall time of the loop minus the device time between its first and last event.  Measured (docs/measurement_log.md, round 6): on
-            # some boxes a loop WITHOUT these events lost 0.1 - 2.3 s ONCE somewhere inside a full-resolution level of the tile-culled models, where host and
-            # device run in lockstep (3 of 16 bench runs; every kernel of the 12 iterations profiled right after it at its usual time, no device allocation,
-            # no allocator retry) -- with them, 0 of 24.  Not understood; `stall_ms` is there to make a recurrence visible instead of a silent low rate.
-            marks, host_t = [], []
+            timed = order[nwarm:nwarm + epochs * len(ds)]
+            # a device event, the host clock and the allocator's reserved bytes after every timed iteration: the median device time per iteration and the
+            # longest interval (device and host, with their indices) go out beside the wall-clock rate, which stays THE rate.  What they found (round 6):
+            # the rare "stalled level" -- one interval of 0.1 - 1.2 s -- is the HOST inside a multi-GB hipMalloc (a window buffer of the optimiser growing at
+            # that iteration: `reserved_delta_at_host_max`), 2 ms on most boxes and a second on some.  The whole-epoch warm-up above takes the growth out of
+            # the timed loop; the fields stay so that a recurrence reads as what it is.
+            marks, host_t, reserved = [], [], []
             import gc
             gc_was = gc.isenabled()
             gc.disable()      # (no collector pause inside the timed loop: one suspect less for the rare stalled level; re-enabled right after it)
@@ -145,6 +151,7 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
                 ev.record()
                 marks.append(ev)
                 host_t.append(time.perf_counter())
+                reserved.append(torch.cuda.memory_reserved(dev))
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             if gc_was:
@@ -156,6 +163,8 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
             # (max / max_at: the longest device interval between two iterations' events and its index; host_max / host_max_at: the same on the host's clock
             # -- the enqueue side.  A device interval far above p50 WITH the same host interval at the same index is the host being away, not a kernel.)
             dev_ms = {"p50": gaps[len(gaps) // 2], "max": gaps[-1], "max_at": kd + 1, "host_max": hgap[kh], "host_max_at": kh + 1, "host_at_device_max": hgap[kd],
+                      # the caching allocator's reserved bytes moved during the iteration of the longest host interval: a hipMalloc / hipFree inside it
+                      "reserved_delta_at_host_max": int(reserved[kh + 1] - reserved[kh]), "reserved_changes_in_loop": int(sum(reserved[k] != reserved[k - 1] for k in range(1, len(reserved)))),
                       "stall_ms": dt * 1e3 - marks[0].elapsed_time(marks[-1]) * len(marks) / (len(marks) - 1),
                       "iters_per_s_without_intervals_over_20x_p50": (len(dgap) - sum(g > 20 * gaps[len(gaps) // 2] for g in dgap))
                       / max(1e-9, sum(g for g in dgap if g <= 20 * gaps[len(gaps) // 2]) * 1e-3)}

@@ -9,7 +9,7 @@ d = json.load(open("/tmp/detail.json"))["stage2_schedule"]
 for k, v in d.items():
     for l in v["levels"]:
         m = l["device_ms_per_iter"]
-        if m["max"] > 20 * m["p50"] or m["host_max"] > 100:
+        if m["max"] > 20 * m["p50"] or m["host_max"] > 100 or m["reserved_changes_in_loop"]:
             print("run", $i, k, l["frame"], round(l["iters_per_s"], 1), {a: (round(b, 2) if isinstance(b, float) else b) for a, b in m.items()}, flush=True)
 print("run", $i, "done", {k: round(v["iters_per_s"], 1) for k, v in d.items()}, flush=True)
 PY

@@ -194,7 +194,9 @@ class WindowAdam(torch.optim.Optimizer):
             n = D * T * wh * ww * 4
             if self._compact_buf is None or self._compact_buf.numel() < n or self._compact_buf.device != p.device:
                 self._compact_buf = None                                       # (release before growing)
-                self._compact_buf = torch.zeros(n, dtype=p.dtype, device=p.device)
+                # (an eighth of headroom: the windows of a pyramid level's crops differ by a few bookkeeping tiles, and every growth is a multi-GB
+                # hipMalloc in the middle of training -- usually 2 ms, on some boxes 1.2 s: docs/measurement_log.md, round 6)
+                self._compact_buf = torch.zeros(n + n // 8, dtype=p.dtype, device=p.device)
             compact = self._compact_buf[:n].view(D, T, wh, ww, 4)
         else:
             compact = torch.empty((D, T, wh, ww, 4), dtype=p.dtype, device=p.device)
@@ -325,13 +327,13 @@ class WindowAdam(torch.optim.Optimizer):
         # (buffers of the call kept on the optimiser, grown on demand like the compact window: no allocator traffic inside autograd)
         if self._gfb is None or self._gfb.numel() < stack.numel() or self._gfb.device != dev:
             self._gfb = None
-            self._gfb = torch.empty(stack.numel(), dtype=torch.float32, device=dev)
+            self._gfb = torch.empty(stack.numel() + stack.numel() // 8, dtype=torch.float32, device=dev)
         g_fallback = self._gfb[:stack.numel()].view(stack.shape)
         with torch.cuda.device(dev):
             nscratch = max(int(L.lib().vl3d_render_bwd_scratch_bytes(desc)), 64)
             if self._bwd_scratch is None or self._bwd_scratch.numel() * 4 < nscratch or self._bwd_scratch.device != dev:
                 self._bwd_scratch = None
-                self._bwd_scratch = torch.empty((nscratch + 3) // 4, dtype=torch.float32, device=dev)
+                self._bwd_scratch = torch.empty((nscratch + nscratch // 8 + 3) // 4, dtype=torch.float32, device=dev)
             scratch = self._bwd_scratch
             L.check(L.lib().vl3d_render_bwd_adam(desc, L.ptr(stack), L.ptr(homos), L.ptr(rgb), L.ptr(alpha), L.ptr(g_rgb), L.ptr(g_alpha),
                                                  L.ptr(g_reg), L.ptr(reg_state), L.ptr(g_asum), L.ptr(g_fallback), L.ptr(scratch), nscratch,
