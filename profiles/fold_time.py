@@ -25,3 +25,16 @@ for name, (ps, s, al) in {"ref": (11, 4, 0.5), "other": (3, 2, None)}.items():
         if r >= 2:
             ts.append(e0.elapsed_time(e1))
     print(f"{os.path.basename(L.LIB_PATH):24s} {name:6s} fold median {statistics.median(ts):.3f} min {min(ts):.3f} ms")
+    # the TRAINING form: y2x / weight stay in registers (no sum / weight outputs), gradient through strides -- what _FoldRobustMean calls
+    gx = torch.empty((3, desc.Tx, desc.H, desc.W), device=dev)
+    ts = []
+    for r in range(12):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(L.lib().vl3d_vote_fold_robust_strided(desc, L.ptr(yv), L.ptr(nn), L.ptr(xv), L.RHO["barron"], -2.0, 0.1, None, None,
+                                                      L.ptr(gx), gx.stride(0), gx.stride(1), gx.stride(2), L.ptr(acc), L.stream_ptr(dev)), "fold")
+        e1.record()
+        torch.cuda.synchronize()
+        if r >= 2:
+            ts.append(e0.elapsed_time(e1))
+    print(f"{os.path.basename(L.LIB_PATH):24s} {name:6s} fold (training form) median {statistics.median(ts):.3f} min {min(ts):.3f} ms")
