@@ -1127,7 +1127,15 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
     const float *xnext = xsrc ? xsrc + (int64_t)t0 * a.x_st : nullptr;
     int tnext = t0;
     auto xload = [&]() -> float {
+#if defined(VL3D_FOLD_ABLATE) && (VL3D_FOLD_ABLATE & 4)      // measurement build only (WRONG values): every fourth lane moves its four pixels' x as ONE 16-byte load
+        float v = 0.f;
+        if (xnext && tnext < t1 && (tid & 3) == 0 && xi + 3 < a.W) {
+            const float4 q = *reinterpret_cast<const float4 *>(reinterpret_cast<uintptr_t>(xnext) & ~(uintptr_t)15);
+            v = q.x + q.y + q.z + q.w;
+        }
+#else
         const float v = (xnext && tnext < t1) ? *xnext : 0.f;
+#endif
         xnext += xstep; tnext += tstep;
         return v;
     };
@@ -1263,7 +1271,11 @@ __global__ __launch_bounds__(FT_NT) void vote_fold_lds_k(FoldArgs a, int Ty) {
             float f, g;
             rho_fg(a.rho, e, f, g);
             lacc += f;
+#if defined(VL3D_FOLD_ABLATE) && (VL3D_FOLD_ABLATE & 4)      // measurement build only: ... and their gx as ONE 16-byte store
+            if ((tid & 3) == 0 && xi + 3 < a.W) *reinterpret_cast<float4 *>(reinterpret_cast<uintptr_t>(gxp) & ~(uintptr_t)15) = make_float4(g, g, g, g);
+#else
             *gxp = g * a.gscale;
+#endif
             gxp += gxstep;
         }
     }
