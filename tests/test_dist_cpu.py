@@ -77,7 +77,7 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])      # (8: the node size north_star names -- bands of a few rows, halos spanning several ranks)
 def test_row_bands_allgather_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -131,7 +131,7 @@ def _grad_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_halo_gradient_exchange_gives_the_single_rank_gradient(world):
     """stack rows inside a parallax halo are replicated on neighbouring ranks, each with a PARTIAL gradient; after ONE
     neighbour exchange every holder has the single-rank gradient of every row it holds, identical bits on all holders -- the

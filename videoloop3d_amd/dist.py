@@ -132,12 +132,22 @@ def all_gather_frame(band_rgb: torch.Tensor, bands: List[Band], group=None, algo
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         return parts if layout == "bands" else _dense_frame(parts)
-    if len(set(rows)) == 1 and band_rgb.is_cuda:
-        out = torch.empty((world, T, rows[0], W, C), dtype=band_rgb.dtype, device=band_rgb.device)
-        dist.all_gather_into_tensor(out, band_rgb, group=group)
-        return list(out.unbind(0)) if layout == "bands" else out.permute(1, 0, 2, 3, 4).reshape(T, sum(rows), W, C)
-    parts = [torch.empty((T, r, W, C), dtype=band_rgb.dtype, device=band_rgb.device) for r in rows]
-    dist.all_gather(parts, band_rgb, group=group)
+    # An all-gather of EQUAL pieces: ragged bands (H not a multiple of the world size: 60 rows over 8 ranks are 8,8,8,8,7,7,7,7) are padded to the tallest
+    # and trimmed on arrival -- gloo refuses unequal pieces outright, and RCCL's list form falls back to one broadcast per rank.
+    rmax = max(rows)
+    mine = band_rgb
+    if band_rgb.shape[1] != rmax:
+        mine = torch.cat([band_rgb, band_rgb.new_zeros((T, rmax - band_rgb.shape[1], W, C))], dim=1)
+    if band_rgb.is_cuda:
+        out = torch.empty((world, T, rmax, W, C), dtype=band_rgb.dtype, device=band_rgb.device)
+        dist.all_gather_into_tensor(out, mine.contiguous(), group=group)
+        padded = list(out.unbind(0))
+        if rmax == min(rows) and layout == "dense":
+            return out.permute(1, 0, 2, 3, 4).reshape(T, sum(rows), W, C)
+    else:
+        padded = [torch.empty((T, rmax, W, C), dtype=band_rgb.dtype, device=band_rgb.device) for _ in rows]
+        dist.all_gather(padded, mine.contiguous(), group=group)
+    parts = [q if r == rmax else q[:, :r] for q, r in zip(padded, rows)]
     return parts if layout == "bands" else torch.cat(parts, dim=1)
 
 
