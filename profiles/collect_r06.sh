@@ -8,5 +8,5 @@ for l in target sched sched2k schedc schedc2k schedx loss s1 s1train; do cp $O/k
 cp $O/pmc_summary.txt profiles/r06_pmc_summary.txt
 for l in sched schedc; do cp $O/pmc_summary_$l.txt profiles/r06_pmc_summary_$l.txt; done
 python profiles/pmc_to_traffic.py profiles/r06_pmc_summary.txt r06
-cp $O/n4_gloo.json profiles/r06_n4_gloo.json; cp $O/n2_gloo.json profiles/r06_n2_gloo.json
+cp $O/n4_gloo.json profiles/r06_n4_gloo.json; cp $O/n2_gloo.json profiles/r06_n2_gloo.json; [ -f $O/n8_gloo.json ] && cp $O/n8_gloo.json profiles/r06_n8_gloo.json
 python profiles/update_design_table.py

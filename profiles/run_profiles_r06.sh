@@ -49,4 +49,6 @@ done
 # four row bands whose parallax halos span two ranks, direct gather with one message per peer, halo-gradient exchange, band loss
 VL3D_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 4 --steps 3 --warmup 1 --gather-algo direct > $O/n4_gloo.json 2> $O/n4_gloo.err
 VL3D_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 2 --steps 3 --warmup 1 > $O/n2_gloo.json 2> $O/n2_gloo.err
+# ... and at the node size north_star names: eight processes, eight bands of 90 rows
+VL3D_BENCH_BACKEND=gloo timeout 1200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 8 --steps 2 --warmup 1 > $O/n8_gloo.json 2> $O/n8_gloo.err
 tail -c 600 $O/n4_gloo.json
