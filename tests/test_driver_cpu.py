@@ -146,3 +146,21 @@ def test_patch3d_mse_and_avg_match_the_reference_goldens(golden):
     assert abs(float(Patch3DMSE(xa, ya)) - float(g["mse"])) <= 1e-7
     assert abs(float(Patch3DMSE(ya, xa)) - float(g["mse_rev"])) <= 1e-7
     assert abs(float(Patch3DAvg(xa, ya)) - float(g["avg"])) <= 1e-7
+
+
+def test_unit_grad_is_cached_per_module_and_follows_the_loss():
+    """train_3dvid.unit_grad: d loss / d loss = 1 from a tensor cached on the module (no fill launch per iteration); a loss of another dtype / shape gets
+    a new one."""
+    from videoloop3d_amd.train_3dvid import unit_grad
+    mod = types.SimpleNamespace()
+    l32 = torch.tensor(2.0, requires_grad=True) * 3
+    one = unit_grad(mod, l32)
+    assert one.shape == l32.shape and one.dtype == l32.dtype and float(one) == 1.0 and not one.requires_grad
+    assert unit_grad(mod, l32 * 2) is one
+    l64 = torch.tensor(2.0, dtype=torch.float64, requires_grad=True) * 3
+    assert unit_grad(mod, l64).dtype == torch.float64
+    l1 = torch.ones(1, requires_grad=True) * 3
+    assert unit_grad(mod, l1).shape == (1,)
+    w = torch.tensor(2.0, requires_grad=True)
+    (w * 3).backward(unit_grad(mod, w * 3))
+    assert float(w.grad) == 3.0

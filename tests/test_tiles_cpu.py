@@ -1,6 +1,8 @@
 """Tile culling on the dense stack (videoloop3d_amd/tiles.py; MPI.py:288-442, MPV.py:235-288, utils.py:298-317).  CPU only."""
 import types
 
+import pytest
+
 import numpy as np
 import torch
 
@@ -208,3 +210,35 @@ def test_reference_checkpoint_is_read_onto_the_dense_stack():
     assert vid.frm_num == T and vid.stack.shape == (D, T, H, W, 4) and vid.is_sparse and vid._tie_hook is not None
     assert torch.equal(vid.quad_keep, keep) and torch.equal(vid.quad_dyn, dyn)
     assert torch.allclose(vid.planedepth, torch.linspace(1, 2, D))
+
+
+def test_u8_cache_follows_the_source_tensor():
+    """tiles.as_u8: the uint8 form of a (constant) quad map is cached per source tensor and version -- an in-place change of the map or a new map
+    must not be served from the cache."""
+    from videoloop3d_amd import tiles
+    m = torch.zeros((2, 3, 4), dtype=torch.bool)
+    m[0, 1, 2] = True
+    a = tiles.as_u8(m)
+    assert a.dtype == torch.uint8 and a.is_contiguous() and torch.equal(a.bool(), m)
+    assert tiles.as_u8(m) is a                                  # same tensor, same version: the cached conversion
+    m[1, 0, 0] = True                                           # in place: the version counter moves
+    b = tiles.as_u8(m)
+    assert b is not a and torch.equal(b.bool(), m)
+    m2 = m.clone()
+    assert tiles.as_u8(m2) is not b and torch.equal(tiles.as_u8(m2).bool(), m2)
+    u = torch.ones((2, 2), dtype=torch.uint8)
+    assert tiles.as_u8(u) is u and tiles.as_u8(None) is None    # already bytes / absent: passed through
+
+
+@pytest.mark.parametrize("shape", [(12, 12, 9, 9), (9, 9, 12, 12), (7, 7, 9, 9), (10, 10, 5, 5), (12, 11, 6, 7), (2, 2, 5, 3), (5, 5, 2, 2), (6, 6, 6, 6)])
+def test_tile_resize_without_antialiasing_is_interpolates_bilinear(shape):
+    """MPV._resize_tiles(antialias=False) spells F.interpolate(mode='bilinear', align_corners=False) with gathers (the per-tile lod of a tile-exact
+    model, MPV.py:157-162 under torchvision 0.11): same taps and weights, equal to a few units in the last place."""
+    from videoloop3d_amd.MPV import _resize_tiles
+    th, tw, h, w = shape
+    x = torch.randn(37, 4, th, tw, generator=torch.Generator().manual_seed(th * 100 + h))
+    ref = torch.nn.functional.interpolate(x, size=(h, w), mode="bilinear", align_corners=False, antialias=False)
+    out = _resize_tiles(x, h, w, False)
+    assert out.shape == ref.shape and torch.allclose(out, ref, rtol=0, atol=4e-6)
+    aa = torch.nn.functional.interpolate(x, size=(h, w), mode="bilinear", align_corners=False, antialias=True)
+    assert torch.equal(_resize_tiles(x, h, w, True), aa)
