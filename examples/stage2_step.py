@@ -18,6 +18,10 @@ import numpy as np
 import torch
 
 
+# untimed iterations in front of every timed loop: one per distinct crop of the six the loops cycle through (the optimiser's window buffers and the
+# allocator have seen every size before the clock starts: a buffer growing inside the timed loop is a multi-GB hipMalloc, docs/measurement_log.md round 6)
+WARM = 6
+
 def run(iters=10, frames=50, planes=32, smooth=0.2, dev="cuda:0", crop=(180, 320), full=(360, 640), baseline=0.03):
     from videoloop3d_amd import synth
     from videoloop3d_amd.MPV import MPMeshVid
@@ -55,8 +59,8 @@ def run(iters=10, frames=50, planes=32, smooth=0.2, dev="cuda:0", crop=(180, 320
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for name, cfg in cfgs.items():
-            for it in range(iters + 2):
-                if it == 2:
+            for it in range(iters + WARM):
+                if it == WARM:
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                 Kc = K.copy()
@@ -92,8 +96,8 @@ def run(iters=10, frames=50, planes=32, smooth=0.2, dev="cuda:0", crop=(180, 320
         if hasattr(opt, "acknowledge_fused_backward"):
             opt.acknowledge_fused_backward()      # this loop steps once per backward
         cfg = cfgs["other"]
-        for it in range(iters + 2):
-            if it == 2:
+        for it in range(iters + WARM):
+            if it == WARM:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
             Kc = K.copy()
@@ -118,8 +122,8 @@ def run(iters=10, frames=50, planes=32, smooth=0.2, dev="cuda:0", crop=(180, 320
         opt = model.get_optimizer(0)
         if hasattr(opt, "acknowledge_fused_backward"):
             opt.acknowledge_fused_backward()      # this loop steps once per backward
-        for it in range(iters + 2):
-            if it == 2:
+        for it in range(iters + WARM):
+            if it == WARM:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
             Kc = K.copy()
