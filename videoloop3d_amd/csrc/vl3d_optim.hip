@@ -208,9 +208,22 @@ __global__ __launch_bounds__(256) void adam_window_step_k(int T, int Hs, int Ws,
     texel_slot(lay, d, w.y0 + ly, w.x0 + lx, T, Hs, Ws, tiles_y, tiles_x, o, frame);
     if (cls == 2) {           // static: gradient = the sum over the frames (frame order: deterministic), one update, one write
         float4 gg = g[oc];
-        for (int t = 1; t < T && !static_tied; ++t) {        // static_tied: frame 0 already holds the frame sum (tie_static_grad)
-            const float4 gt = g[oc + (size_t)t * cframe];
-            gg.x += gt.x; gg.y += gt.y; gg.z += gt.z; gg.w += gt.w;
+        if (!static_tied) {      // static_tied: frame 0 already holds the frame sum (tie_static_grad)
+            // ten frames' loads in flight, then their ten adds IN FRAME ORDER (the same sum as one load and one add per trip, which walked the T frames
+            // with a full memory round trip each: this loop is the step kernel of a tile-culled model, half of whose kept texels are static)
+            constexpr int NS = 10;
+            int t = 1;
+            for (; t + NS <= T; t += NS) {
+                float4 gt[NS];
+#pragma unroll
+                for (int f = 0; f < NS; ++f) gt[f] = g[oc + (size_t)(t + f) * cframe];
+#pragma unroll
+                for (int f = 0; f < NS; ++f) { gg.x += gt[f].x; gg.y += gt[f].y; gg.z += gt[f].z; gg.w += gt[f].w; }
+            }
+            for (; t < T; ++t) {
+                const float4 gt = g[oc + (size_t)t * cframe];
+                gg.x += gt.x; gg.y += gt.y; gg.z += gt.z; gg.w += gt.w;
+            }
         }
         float4 pp = p[o], mm = m[o], vv = v[o];
         replay(pp, mm, vv, hist, from, step - 1, beta1, beta2, eps);
