@@ -293,7 +293,23 @@ __global__ __launch_bounds__(64) void adam_flush_older_k(int T, int Hs, int Ws, 
         const int nt = cls == 0 ? 0 : (cls == 2 ? 1 : T);    // culled: no parameter; static: the one copy in frame 0
         size_t o = 0, frame = 0;
         if (nt) texel_slot(lay, d, y, x, T, Hs, Ws, tiles_y, tiles_x, o, frame);
-        for (int t = 0; t < nt; ++t, o += frame) {
+        // four frames per trip, like the window catch-up: twelve independent loads in flight and four independent replay chains (the same operations
+        // per value); one frame per trip left every lane of the flush with a memory round trip and one dependent sqrt / rcp chain per frame
+        constexpr int NF = 4;
+        int t = 0;
+        for (; t + NF <= nt; t += NF, o += NF * frame) {
+            float4 pp[NF], mm[NF], vv[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) { pp[f] = p[o + f * frame]; mm[f] = m[o + f * frame]; vv[f] = v[o + f * frame]; }
+            for (int s = from + 1; s <= upto; ++s) {
+                const float2 h = hist[s];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) adam_upd4(pp[f], make_float4(0.f, 0.f, 0.f, 0.f), mm[f], vv[f], h.x, beta1, beta2, eps, h.y);
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) { p[o + f * frame] = pp[f]; m[o + f * frame] = mm[f]; v[o + f * frame] = vv[f]; }
+        }
+        for (; t < nt; ++t, o += frame) {
             float4 pp = p[o], mm = m[o], vv = v[o];
             replay(pp, mm, vv, hist, from, upto, beta1, beta2, eps);
             p[o] = pp; m[o] = mm; v[o] = vv;
