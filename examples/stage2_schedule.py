@@ -110,6 +110,9 @@ def run(views=8, epochs=2, planes=32, frames=50, clip=75, smooth=0.2, levels=3, 
             opt = model.get_optimizer(step=0)
             ds = MVVidPatchDataset(hw, vids, (180, 320), (90, 160), poses, intrins, loss_configs=cfgs)
             order = [i for _ in range(epochs + 1) for i in torch.randperm(len(ds), generator=gen).tolist()]
+            from videoloop3d_amd.train_3dvid import pose2extrin_torch
+            model.reserve_windows((it[4].shape[-2], it[4].shape[-1], pose2extrin_torch(it[2][None].cpu()), it[3][None].cpu())      # as train_3dvid.train() does
+                                  for it in (ds[i] for i in range(len(ds))))
 
             win_texels = [0, 0]      # sum over the timed iterations of the crop window's texels per plane and frame | iterations counted
 

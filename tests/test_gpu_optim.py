@@ -763,3 +763,45 @@ def test_fused_backward_announces_itself_and_refuses_stray_gradients(dev):
     (extra["swd"].sum() + 1e-3 * (leaf ** 2).sum()).backward()
     with pytest.raises(RuntimeError, match="outside the render's fused backward"):
         o2.step()
+
+
+@pytest.mark.gpu
+def test_reserve_windows_takes_the_buffer_growth_out_of_the_epoch(dev):
+    """MPMeshVid.reserve_windows (train_3dvid.train calls it per pyramid level): the crop-aware optimiser's persistent window buffers are sized for the
+    largest crop window of a set of views BEFORE the epoch, so no iteration grows them -- a growth is a multi-GB hipMalloc in the middle of training
+    (docs/measurement_log.md, round 6).  Views in increasing window order, which without the reservation grows the buffers again and again."""
+    import warnings
+    from videoloop3d_amd.MPV import MPMeshVid
+    H, W, T, D = 96, 160, 4, 6
+    K = np.array([[0.9 * W, 0, W / 2], [0, 0.9 * W, H / 2], [0, 0, 1]], np.float64)
+    res_cfg = dict(loss_name=["gpnn_lm"], loss_gain=torch.tensor([1.0]), macro_block=torch.tensor([65]), patch_size=torch.tensor([3]),
+                   stride=torch.tensor([2]), patcht_size=torch.tensor([3]), stridet=torch.tensor([1]), alpha=torch.tensor([10000.0]),
+                   dist_fn=["mse"], rou=["-2"], scaling=torch.tensor([0.1]))
+    views = []
+    for (h, w, ox, oy, tx) in [(32, 48, 10, 8, 0.0), (40, 64, 30, 20, 0.02), (48, 96, 50, 30, -0.03), (64, 128, 16, 16, 0.05)]:
+        Kc = K.copy()
+        Kc[0, 2] -= ox
+        Kc[1, 2] -= oy
+        E = np.eye(4)
+        E[0, 3] = tx
+        views.append((h, w, torch.tensor(E)[None], torch.tensor(Kc)[None]))
+    grown = {}
+    for reserve in (False, True):
+        torch.manual_seed(3)
+        m = MPMeshVid(_args(mpv_frm_num=T, mpi_d=D, atlas_grid_h=2, init_std=0.02), H, W, np.eye(4), K, 1.0, 100.0).to(dev).train()
+        opt = m.get_optimizer(0)
+        if reserve:
+            assert m.reserve_windows(views) > 0
+        ptrs = set()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for (h, w, E, Kc) in views:
+                resv = synth.hash_uniform((1, 2 * T + 1, 3, h, w), seed=8, device=dev)
+                opt.zero_grad(set_to_none=True)
+                _, extra = m(h, w, E, Kc, res=resv, losscfg=dict(res_cfg))
+                extra["swd"].sum().backward()
+                opt.step()
+                ptrs.add((opt._gfb.data_ptr() if opt._gfb is not None else 0, opt._compact_buf.data_ptr() if opt._compact_buf is not None else 0))
+        grown[reserve] = len(ptrs)
+    assert grown[True] == 1, grown      # reserved: the same buffers from the first iteration to the last
+    assert grown[False] > 1, grown      # (and the test's views do grow them otherwise)

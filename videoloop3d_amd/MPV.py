@@ -707,6 +707,28 @@ class MPMeshVid(nn.Module):
             self.optimize_geometry = True
 
     # ---- geometry ----------------------------------------------------------------------------------------------------
+    def reserve_windows(self, views):
+        """Pre-size the crop-aware optimiser's window buffers for a set of training views -- (h, w, tar_extrin [1,4,4], tar_intrin [1,3,3]) on the host,
+        what `forward` will be called with -- so that no iteration of the coming epochs has to grow them (a multi-GB hipMalloc each time: 2 ms on most
+        boxes, a second on some).  One bookkeeping tile of slack per axis covers `add_intrin_noise`.  -> the largest window in texels (0: nothing done)."""
+        opt = self._window_opt
+        opt = getattr(opt, "window", opt)
+        if opt is None or not hasattr(opt, "reserve"):
+            return 0
+        from .optim import tile_side
+        ts, best = tile_side(), 0
+        for h, w, e, k in views:
+            e, k = torch.as_tensor(e).detach().cpu(), torch.as_tensor(k).detach().cpu()
+            extrin = e @ self._on(e.device, "ref_extrin")[None, ...].inverse().to(e.dtype)
+            homos = self.plane_homographies(extrin, k)
+            (_, _, wh, ww), _ = self.crop_window(torch.as_tensor(homos).detach().cpu(), int(h), int(w), per_plane=True)
+            if wh > 0 and ww > 0:
+                Hs, Ws = self.stack_dims()[2:4]
+                best = max(best, min(wh + ts, Hs) * min(ww + ts, Ws))
+        if best:
+            opt.reserve(best)
+        return best
+
     def plane_homographies(self, extrin, intrin):
         """[D,3,3] target pixel -> plane pixel for the view `extrin` (ref -> target, [1,4,4]) / `intrin` [1,3,3]
         (utils_mpi.py:240-273 with src = the reference camera, plane normal (0,0,1), distance = planedepth)."""

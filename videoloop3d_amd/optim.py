@@ -343,6 +343,21 @@ class WindowAdam(torch.optim.Optimizer):
         self.pending = ("stepped", pend[1])              # the leaf stays referenced: step() / the next window_leaf() check that nothing else reached it
         return scratch
 
+    def reserve(self, window_texels):
+        """Size the persistent window buffers (compact copy of a lean model, fallback gradient of the fused backward) for a window of
+        `window_texels` = wh x ww texels per plane and frame, once, before the training loop: every later growth is a multi-GB hipMalloc in the middle
+        of an epoch (docs/measurement_log.md, round 6).  The drivers call it per pyramid level with the largest window of the level's crops."""
+        p = self.p
+        D, T = self.dims()[:2]
+        n = int(D) * int(T) * int(window_texels) * 4
+        n += n // 8
+        if self.lean_window and (self._compact_buf is None or self._compact_buf.numel() < n or self._compact_buf.device != p.device):
+            self._compact_buf = None
+            self._compact_buf = torch.zeros(n, dtype=p.dtype, device=p.device)
+        if self.fused_backward and (self._gfb is None or self._gfb.numel() < n or self._gfb.device != p.device):
+            self._gfb = None
+            self._gfb = torch.empty(n, dtype=torch.float32, device=p.device)
+
     def _register_step(self, st, lr, b1, b2):
         """the scalars of the step about to be taken into the history table -> its number."""
         t = self.t + 1

@@ -221,6 +221,9 @@ def train(nerf, args, videos, poses, intrins, loss_cfgs, H, W, device="cuda:0", 
         dataset = MVVidPatchDataset(hw, videos, (args.patch_h_size, args.patch_w_size),
                                     (args.patch_h_stride, args.patch_w_stride), poses, intrins, loss_configs=loss_cfgs,
                                     prepare=getattr(args, "prepare_clips", "auto"), prepare_budget=float(getattr(args, "prepare_clips_budget", 0.25)))
+        if hasattr(module, "reserve_windows"):      # the optimiser's window buffers at the level's largest crop window, before the first epoch
+            module.reserve_windows((it[4].shape[-2], it[4].shape[-1], pose2extrin_torch(it[2][None].cpu()), it[3][None].cpu())
+                                   for it in (dataset[i] for i in range(len(dataset))))
         for epoch_i in range(num_epoch):
             for item_i in torch.randperm(len(dataset), generator=generator).tolist():       # DataLoader(shuffle=True)
                 if hasattr(module, "update_step"):
